@@ -1,0 +1,162 @@
+/* splashsurf_hip.h -- C ABI of the MI355X-native surface reconstruction (libsplashsurf_hip.so).
+ *
+ * Drop-in boundary for the reference's Rust API (all citations relative to
+ * /root/reference/splashsurf_lib/src/):
+ *
+ *   pub fn reconstruct_surface<I, R>(particle_positions: &[Vector3<R>], parameters: &Parameters<R>)
+ *       -> Result<SurfaceReconstruction<I, R>, ReconstructionError<I, R>>          lib.rs:330-337
+ *   pub fn reconstruct_surface_inplace(.., output_surface: &mut SurfaceReconstruction) lib.rs:340-473
+ *   pub fn grid_for_reconstruction(..) -> Result<UniformGrid<I, R>, ..>             lib.rs:476-516
+ *   pub fn initialize_thread_pool(num_threads)                                     lib.rs:321-326
+ *
+ * for the instantiation <I = i64, R = f32> (splashsurf/src/reconstruct.rs:982-1007,
+ * pysplashsurf/src/utils.rs:9).  A Rust host binds these functions in an `extern "C"` block
+ * (INTEGRATION.md shows the stub); this repository's own hosts are C++ (tests/bench harness) and
+ * Python/ctypes (splashsurf_amd/api.py).
+ *
+ * Conventions: plain pointers and sizes only.  `xyz` is N x 3 contiguous f32 (the memory layout of
+ * `&[Vector3<f32>]`) and may be a HOST or a DEVICE (HBM) pointer -- the library asks the HIP runtime.
+ * Results are owned by the library (`ss_result`), live in HBM and are copied to (pinned) host
+ * memory lazily by the accessors that return host pointers; free with `ss_result_free`.
+ * One context may be used by one thread at a time; several contexts (also on several GPUs) may
+ * coexist.  All functions return an `ss_status`; `ss_last_error` gives the message.
+ */
+#ifndef SPLASHSURF_HIP_H
+#define SPLASHSURF_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SS_ABI_VERSION 1
+
+/* Return codes; 1..4 mirror ReconstructionError (lib.rs:289-314). */
+typedef enum ss_status {
+    SS_OK = 0,
+    SS_ERR_GRID_CONSTRUCTION = 1,    /* GridConstructionError (uniform_grid.rs:147-169) */
+    SS_ERR_DENSITY_MAP = 2,          /* DensityMapGenerationError */
+    SS_ERR_MARCHING_CUBES = 3,       /* MarchingCubesError */
+    SS_ERR_UNKNOWN = 4,              /* anyhow::Error / panics of the reference (e.g. cube_size <= 0, density_map.rs:555-559) */
+    SS_ERR_DEVICE = 5,               /* HIP runtime / RCCL failure (no counterpart in the reference) */
+    SS_ERR_INVALID_ARGUMENT = 6,
+    SS_ERR_UNSUPPORTED = 7           /* feature of the reference not (yet) provided by this build */
+} ss_status;
+
+/* Sub-codes of SS_ERR_GRID_CONSTRUCTION, see ss_last_error_detail (uniform_grid.rs:147-169) */
+enum {
+    SS_GRID_INVALID_CELL_SIZE = 1,
+    SS_GRID_DEGENERATE_AABB = 2,
+    SS_GRID_INCONSISTENT_AABB = 3,
+    SS_GRID_INDEX_TYPE_TOO_SMALL = 4
+};
+
+/* Parameters<f32> (lib.rs:158-189) + SpatialDecomposition/GridDecompositionParameters (lib.rs:121-154) */
+typedef struct ss_params_f32 {
+    float particle_radius;
+    float rest_density;
+    float compact_support_radius; /* absolute distance units */
+    float cube_size;              /* absolute distance units */
+    float iso_surface_threshold;
+    int32_t has_particle_aabb;    /* Option<Aabb3d> */
+    float aabb_min[3];
+    float aabb_max[3];
+    int32_t enable_multi_threading; /* accepted for API parity; the GPU path is always parallel */
+    int32_t enable_simd;            /* accepted for API parity; results follow the reference's scalar path */
+    int32_t decomposition;          /* 0 = SpatialDecomposition::None, 1 = UniformGrid */
+    uint32_t subdomain_num_cubes_per_dim; /* default 64 */
+    int32_t auto_disable;           /* GridDecompositionParameters::auto_disable */
+    int32_t global_neighborhood_list;
+} ss_params_f32;
+
+/* UniformGrid<i64, f32> (uniform_grid.rs:128-142) */
+typedef struct ss_grid_f32 {
+    float aabb_min[3];
+    float aabb_max[3];
+    float cell_size;
+    int64_t n_points[3];
+    int64_t n_cells[3];
+} ss_grid_f32;
+
+/* Stage timings (milliseconds, HIP events on the context's stream) with the reference's profiling
+ * scope names (README.md:198-231; dense_subdomains.rs `profile!` scopes) plus device-specific rows. */
+typedef struct ss_stats {
+    double ms_total;                  /* "surface reconstruction subdomain-grid" */
+    double ms_upload;                 /* H2D of particle positions (0 if xyz was a device pointer) */
+    double ms_aabb_grid;              /* "compute minimum enclosing aabb" + grid set-up */
+    double ms_decomposition;          /* "decomposition": cell binning + stable sort */
+    double ms_density;                /* "compute_global_density_vector" */
+    double ms_levelset;               /* "reconstruction" / density grid loop (level-set splat kernel(s) only) */
+    double ms_levelset_prepare;       /* active-block detection + compaction for the splat */
+    double ms_marching_cubes;         /* "reconstruction" / mc triangulation loop */
+    double ms_stitching;              /* "stitching": global vertex numbering (prefix sums) */
+    uint64_t n_particles;             /* after the AABB filter */
+    uint64_t n_vertices;
+    uint64_t n_triangles;
+    uint64_t n_active_blocks;         /* level-set blocks of 8^3 points evaluated */
+    uint64_t n_block_candidates;      /* sum over blocks of candidate particles (tile sizes) */
+    uint64_t n_density_fixups;        /* particles whose density took the exact-order slow path */
+    uint64_t levelset_kernel_launches;
+    uint64_t bytes_device_peak;       /* HBM held by the context after this call */
+} ss_stats;
+
+typedef struct ss_context ss_context;
+typedef struct ss_result ss_result;
+
+/* -- context: replaces initialize_thread_pool + the reconstruction workspace (lib.rs:321-326, workspace.rs) -- */
+int ss_abi_version(void);
+ss_status ss_context_create(int device_id, ss_context **out);
+void ss_context_destroy(ss_context *ctx);
+const char *ss_last_error(const ss_context *ctx);
+int ss_last_error_detail(const ss_context *ctx);
+/* use an existing HIP stream (hipStream_t passed as void*); NULL = context's own stream */
+ss_status ss_context_set_stream(ss_context *ctx, void *hip_stream);
+
+/* -- the boundary -- */
+ss_status ss_reconstruct_surface_f32(ss_context *ctx, const float *xyz, uint64_t n_particles,
+                                     const ss_params_f32 *params, ss_result **out);
+/* reuses the buffers held by `inout` (obtained from ss_result_create or a previous call) */
+ss_status ss_reconstruct_surface_inplace_f32(ss_context *ctx, const float *xyz, uint64_t n_particles,
+                                             const ss_params_f32 *params, ss_result *inout);
+ss_status ss_grid_for_reconstruction_f32(ss_context *ctx, const float *xyz, uint64_t n_particles,
+                                         const ss_params_f32 *params, ss_grid_f32 *out);
+
+ss_status ss_result_create(ss_context *ctx, ss_result **out);
+void ss_result_free(ss_result *res);
+
+/* -- SurfaceReconstruction accessors (lib.rs:247-262); host pointers stay valid until the result is
+ *    reused or freed -- */
+ss_status ss_result_counts(const ss_result *res, uint64_t *n_vertices, uint64_t *n_triangles);
+ss_status ss_result_vertices(ss_result *res, const float **xyz, uint64_t *n_vertices);          /* mesh.vertices */
+ss_status ss_result_triangles(ss_result *res, const uint64_t **indices, uint64_t *n_triangles); /* mesh.triangles as [usize;3] */
+ss_status ss_result_triangles_u32(ss_result *res, const uint32_t **indices, uint64_t *n_triangles);
+ss_status ss_result_grid(const ss_result *res, ss_grid_f32 *out);
+/* returns SS_OK and *present = 1 if spatial decomposition was used (always, in this build) */
+ss_status ss_result_subdomain_grid(const ss_result *res, ss_grid_f32 *out, int32_t *present);
+ss_status ss_result_particle_densities(ss_result *res, const float **rho, uint64_t *n);
+/* *flags == NULL when no particle AABB was given (Option::None) */
+ss_status ss_result_particle_inside_aabb(ss_result *res, const uint8_t **flags, uint64_t *n);
+ss_status ss_result_stats(const ss_result *res, ss_stats *out);
+
+/* -- device-side views (HBM pointers; no copy) -- */
+ss_status ss_result_device_vertices(const ss_result *res, const float **d_xyz, uint64_t *n_vertices);
+ss_status ss_result_device_triangles_u32(const ss_result *res, const uint32_t **d_indices, uint64_t *n_triangles);
+ss_status ss_result_device_particle_densities(const ss_result *res, const float **d_rho, uint64_t *n);
+
+/* -- extensions used by the parity tests (no counterpart in the reference API) -- */
+/* per-vertex global grid edge key = ((gi*NPy+gj)*NPz+gk)*3 + axis, NP = grid.n_points */
+ss_status ss_result_vertex_keys(ss_result *res, const uint64_t **keys, uint64_t *n_vertices);
+/* Level-set values of the box of grid points [lo, lo+extent) of the global MC grid of the last
+ * reconstruction held by `res` (points outside evaluated blocks read 0); out is host memory,
+ * extent[0]*extent[1]*extent[2] floats, k fastest (dense_subdomains.rs:839 flattening). */
+ss_status ss_result_levelset_box(ss_result *res, const int64_t lo[3], const int64_t extent[3], float *out);
+/* The reference's decomposition statistics for the last reconstruction (number of occupied
+ * subdomains S and sum of per-subdomain particle counts incl. ghosts, dense_subdomains.rs:349-494);
+ * only needed to price the splat kernel in the reference's algorithmic bytes. */
+ss_status ss_result_subdomain_stats(ss_result *res, uint64_t *n_occupied_subdomains, uint64_t *n_subdomain_particles);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SPLASHSURF_HIP_H */

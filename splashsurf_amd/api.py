@@ -1,0 +1,458 @@
+"""Python host of the MI355X surface reconstruction: ctypes over the C ABI (include/splashsurf_hip.h).
+
+Mirrors the reference's Python entry point `pysplashsurf.reconstruct_surface`
+(pysplashsurf/src/reconstruction.rs:135-207): same keyword names, same units (smoothing length and
+cube size RELATIVE to the particle radius, products formed in f64 and cast to f32,
+reconstruction.rs:171-193), same result attributes (`.mesh.vertices`, `.mesh.triangles` as uint64,
+`.grid`, `.particle_densities`, `.particle_inside_aabb`).
+
+There is NO CPU fallback: if libsplashsurf_hip.so is missing or no GPU is visible the call fails loudly.
+"""
+import ctypes as C
+import json
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_NAME = "libsplashsurf_hip.so"
+
+
+class SplashsurfError(RuntimeError):
+    def __init__(self, status, message):
+        super().__init__("splashsurf_hip error %d: %s" % (status, message))
+        self.status = status
+
+
+class GridConstructionError(SplashsurfError):
+    """ReconstructionError::GridConstructionError (lib.rs:291-296)"""
+
+
+class _Params(C.Structure):
+    _fields_ = [
+        ("particle_radius", C.c_float),
+        ("rest_density", C.c_float),
+        ("compact_support_radius", C.c_float),
+        ("cube_size", C.c_float),
+        ("iso_surface_threshold", C.c_float),
+        ("has_particle_aabb", C.c_int32),
+        ("aabb_min", C.c_float * 3),
+        ("aabb_max", C.c_float * 3),
+        ("enable_multi_threading", C.c_int32),
+        ("enable_simd", C.c_int32),
+        ("decomposition", C.c_int32),
+        ("subdomain_num_cubes_per_dim", C.c_uint32),
+        ("auto_disable", C.c_int32),
+        ("global_neighborhood_list", C.c_int32),
+    ]
+
+
+class _Grid(C.Structure):
+    _fields_ = [
+        ("aabb_min", C.c_float * 3),
+        ("aabb_max", C.c_float * 3),
+        ("cell_size", C.c_float),
+        ("n_points", C.c_int64 * 3),
+        ("n_cells", C.c_int64 * 3),
+    ]
+
+
+class _Stats(C.Structure):
+    _fields_ = [
+        ("ms_total", C.c_double),
+        ("ms_upload", C.c_double),
+        ("ms_aabb_grid", C.c_double),
+        ("ms_decomposition", C.c_double),
+        ("ms_density", C.c_double),
+        ("ms_levelset", C.c_double),
+        ("ms_levelset_prepare", C.c_double),
+        ("ms_marching_cubes", C.c_double),
+        ("ms_stitching", C.c_double),
+        ("n_particles", C.c_uint64),
+        ("n_vertices", C.c_uint64),
+        ("n_triangles", C.c_uint64),
+        ("n_active_blocks", C.c_uint64),
+        ("n_block_candidates", C.c_uint64),
+        ("n_density_fixups", C.c_uint64),
+        ("levelset_kernel_launches", C.c_uint64),
+        ("bytes_device_peak", C.c_uint64),
+    ]
+
+
+_lib = None
+
+
+def library_path():
+    return os.path.join(_HERE, _LIB_NAME)
+
+
+def load_library():
+    """Load libsplashsurf_hip.so (built in-tree by __graft_entry__.build()). Fails loudly if absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = library_path()
+    if not os.path.exists(path):
+        raise ImportError(
+            "%s not found: build the HIP extension first (python -c 'import __graft_entry__ as g; g.build()'). "
+            "There is no CPU fallback." % path)
+    L = C.CDLL(path)
+    vp, u64, i32 = C.c_void_p, C.c_uint64, C.c_int32
+    P = C.POINTER
+    L.ss_abi_version.restype = C.c_int
+    L.ss_context_create.argtypes = [C.c_int, P(vp)]
+    L.ss_context_destroy.argtypes = [vp]
+    L.ss_context_destroy.restype = None
+    L.ss_last_error.argtypes = [vp]
+    L.ss_last_error.restype = C.c_char_p
+    L.ss_last_error_detail.argtypes = [vp]
+    L.ss_context_set_stream.argtypes = [vp, vp]
+    L.ss_reconstruct_surface_f32.argtypes = [vp, vp, u64, P(_Params), P(vp)]
+    L.ss_reconstruct_surface_inplace_f32.argtypes = [vp, vp, u64, P(_Params), vp]
+    L.ss_grid_for_reconstruction_f32.argtypes = [vp, vp, u64, P(_Params), P(_Grid)]
+    L.ss_result_create.argtypes = [vp, P(vp)]
+    L.ss_result_free.argtypes = [vp]
+    L.ss_result_free.restype = None
+    L.ss_result_counts.argtypes = [vp, P(u64), P(u64)]
+    L.ss_result_vertices.argtypes = [vp, P(vp), P(u64)]
+    L.ss_result_triangles.argtypes = [vp, P(vp), P(u64)]
+    L.ss_result_triangles_u32.argtypes = [vp, P(vp), P(u64)]
+    L.ss_result_grid.argtypes = [vp, P(_Grid)]
+    L.ss_result_subdomain_grid.argtypes = [vp, P(_Grid), P(i32)]
+    L.ss_result_particle_densities.argtypes = [vp, P(vp), P(u64)]
+    L.ss_result_particle_inside_aabb.argtypes = [vp, P(vp), P(u64)]
+    L.ss_result_stats.argtypes = [vp, P(_Stats)]
+    L.ss_result_device_vertices.argtypes = [vp, P(vp), P(u64)]
+    L.ss_result_device_triangles_u32.argtypes = [vp, P(vp), P(u64)]
+    L.ss_result_device_particle_densities.argtypes = [vp, P(vp), P(u64)]
+    L.ss_result_vertex_keys.argtypes = [vp, P(vp), P(u64)]
+    L.ss_result_levelset_box.argtypes = [vp, P(C.c_int64), P(C.c_int64), vp]
+    L.ss_result_subdomain_stats.argtypes = [vp, P(u64), P(u64)]
+    if L.ss_abi_version() != 1:
+        raise ImportError("libsplashsurf_hip.so ABI version mismatch")
+    _lib = L
+    return L
+
+
+class Parameters:
+    """`splashsurf_lib::Parameters<f32>` (lib.rs:158-210), absolute units."""
+
+    def __init__(self, particle_radius, compact_support_radius, cube_size, rest_density=1000.0,
+                 iso_surface_threshold=0.6, particle_aabb=None, enable_multi_threading=True, enable_simd=True,
+                 subdomain_grid=True, subdomain_num_cubes_per_dim=64, auto_disable=True,
+                 global_neighborhood_list=False):
+        self.particle_radius = np.float32(particle_radius)
+        self.rest_density = np.float32(rest_density)
+        self.compact_support_radius = np.float32(compact_support_radius)
+        self.cube_size = np.float32(cube_size)
+        self.iso_surface_threshold = np.float32(iso_surface_threshold)
+        self.particle_aabb = particle_aabb
+        self.enable_multi_threading = bool(enable_multi_threading)
+        self.enable_simd = bool(enable_simd)
+        self.subdomain_grid = bool(subdomain_grid)
+        self.subdomain_num_cubes_per_dim = int(subdomain_num_cubes_per_dim)
+        self.auto_disable = bool(auto_disable)
+        self.global_neighborhood_list = bool(global_neighborhood_list)
+
+    @classmethod
+    def new_relative(cls, particle_radius, relative_compact_support_radius, relative_cube_size, **kw):
+        """lib.rs:216-226"""
+        r = np.float32(particle_radius)
+        return cls(r, r * np.float32(relative_compact_support_radius), r * np.float32(relative_cube_size), **kw)
+
+    def _c(self):
+        p = _Params()
+        p.particle_radius = self.particle_radius
+        p.rest_density = self.rest_density
+        p.compact_support_radius = self.compact_support_radius
+        p.cube_size = self.cube_size
+        p.iso_surface_threshold = self.iso_surface_threshold
+        if self.particle_aabb is not None:
+            p.has_particle_aabb = 1
+            for d in range(3):
+                p.aabb_min[d] = np.float32(self.particle_aabb[0][d])
+                p.aabb_max[d] = np.float32(self.particle_aabb[1][d])
+        p.enable_multi_threading = int(self.enable_multi_threading)
+        p.enable_simd = int(self.enable_simd)
+        p.decomposition = 1 if self.subdomain_grid else 0
+        p.subdomain_num_cubes_per_dim = self.subdomain_num_cubes_per_dim
+        p.auto_disable = int(self.auto_disable)
+        p.global_neighborhood_list = int(self.global_neighborhood_list)
+        return p
+
+
+class Aabb3d:
+    def __init__(self, mn, mx):
+        self.min = np.array(mn, dtype=np.float32)
+        self.max = np.array(mx, dtype=np.float32)
+
+
+class UniformGrid:
+    """`UniformGrid<i64, f32>` view (pysplashsurf.pyi UniformGrid)."""
+
+    def __init__(self, g):
+        self.aabb = Aabb3d(list(g.aabb_min), list(g.aabb_max))
+        self.cell_size = np.float32(g.cell_size)
+        self.npoints_per_dim = [int(x) for x in g.n_points]
+        self.ncells_per_dim = [int(x) for x in g.n_cells]
+
+
+class TriMesh3d:
+    def __init__(self, owner):
+        self._owner = owner
+
+    @property
+    def vertices(self):
+        return self._owner._vertices()
+
+    @property
+    def triangles(self):
+        return self._owner._triangles()
+
+    @property
+    def triangles_u32(self):
+        return self._owner._triangles_u32()
+
+
+class Context:
+    """Owns the HIP context/stream and reusable device buffers (the reference's thread pool + workspace)."""
+
+    def __init__(self, device_id=0):
+        self._lib = load_library()
+        h = C.c_void_p()
+        st = self._lib.ss_context_create(int(device_id), C.byref(h))
+        if st != 0:
+            raise SplashsurfError(st, "ss_context_create failed (no usable HIP device %d?)" % device_id)
+        self._h = h
+        self.device_id = device_id
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.ss_context_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _raise(self, st):
+        msg = self._lib.ss_last_error(self._h)
+        msg = msg.decode() if msg else ""
+        if st == 1:
+            raise GridConstructionError(st, msg)
+        raise SplashsurfError(st, msg)
+
+    def set_stream(self, hip_stream_ptr):
+        st = self._lib.ss_context_set_stream(self._h, C.c_void_p(hip_stream_ptr))
+        if st != 0:
+            self._raise(st)
+
+    @staticmethod
+    def _as_ptr(particles):
+        """Accept a float32 (N,3) numpy array (host) or anything with `data_ptr()` (torch tensor, host or HBM)."""
+        if hasattr(particles, "data_ptr"):
+            if tuple(particles.shape[1:]) != (3,) or str(particles.dtype) != "torch.float32" or not particles.is_contiguous():
+                raise TypeError("particles tensor must be contiguous float32 of shape (N, 3)")
+            return C.c_void_p(particles.data_ptr()), int(particles.shape[0]), particles
+        a = np.asarray(particles)
+        if a.dtype != np.float32:
+            raise TypeError("unsupported particle dtype %s (only float32 is supported by this build)" % a.dtype)
+        if a.ndim != 2 or a.shape[1] != 3:
+            raise ValueError("particles must have shape (N, 3)")
+        a = np.ascontiguousarray(a)
+        return C.c_void_p(a.ctypes.data), int(a.shape[0]), a
+
+    def reconstruct(self, particles, parameters, out=None):
+        ptr, n, keep = self._as_ptr(particles)
+        p = parameters._c()
+        if out is None:
+            h = C.c_void_p()
+            st = self._lib.ss_reconstruct_surface_f32(self._h, ptr, n, C.byref(p), C.byref(h))
+            if st != 0:
+                self._raise(st)
+            return SurfaceReconstruction(self, h)
+        st = self._lib.ss_reconstruct_surface_inplace_f32(self._h, ptr, n, C.byref(p), out._h)
+        if st != 0:
+            self._raise(st)
+        out._invalidate()
+        return out
+
+    def grid_for_reconstruction(self, particles, parameters):
+        ptr, n, keep = self._as_ptr(particles)
+        p = parameters._c()
+        g = _Grid()
+        st = self._lib.ss_grid_for_reconstruction_f32(self._h, ptr, n, C.byref(p), C.byref(g))
+        if st != 0:
+            self._raise(st)
+        return UniformGrid(g)
+
+
+class SurfaceReconstruction:
+    """`SurfaceReconstruction<i64, f32>` (lib.rs:247-262)."""
+
+    def __init__(self, ctx, handle):
+        self._ctx = ctx
+        self._lib = ctx._lib
+        self._h = handle
+        self._cache = {}
+        self.mesh = TriMesh3d(self)
+
+    def _invalidate(self):
+        self._cache = {}
+
+    def __del__(self):
+        try:
+            if self._h and self._ctx._h:
+                self._lib.ss_result_free(self._h)
+            self._h = None
+        except Exception:
+            pass
+
+    def _check(self, st):
+        if st != 0:
+            self._ctx._raise(st)
+
+    def _host_array(self, fn, ctype, width, dtype):
+        ptr, n = C.c_void_p(), C.c_uint64()
+        self._check(fn(self._h, C.byref(ptr), C.byref(n)))
+        cnt = int(n.value) * width
+        if cnt == 0 or not ptr.value:
+            shape = (0, width) if width > 1 else (0,)
+            return np.zeros(shape, dtype=dtype)
+        arr = np.ctypeslib.as_array(C.cast(ptr, C.POINTER(ctype)), shape=(cnt,)).copy()
+        return arr.reshape(-1, width) if width > 1 else arr
+
+    def counts(self):
+        nv, nt = C.c_uint64(), C.c_uint64()
+        self._check(self._lib.ss_result_counts(self._h, C.byref(nv), C.byref(nt)))
+        return int(nv.value), int(nt.value)
+
+    def _vertices(self):
+        if "v" not in self._cache:
+            self._cache["v"] = self._host_array(self._lib.ss_result_vertices, C.c_float, 3, np.float32)
+        return self._cache["v"]
+
+    def _triangles(self):
+        if "t" not in self._cache:
+            self._cache["t"] = self._host_array(self._lib.ss_result_triangles, C.c_uint64, 3, np.uint64)
+        return self._cache["t"]
+
+    def _triangles_u32(self):
+        if "t32" not in self._cache:
+            self._cache["t32"] = self._host_array(self._lib.ss_result_triangles_u32, C.c_uint32, 3, np.uint32)
+        return self._cache["t32"]
+
+    @property
+    def vertex_keys(self):
+        if "k" not in self._cache:
+            self._cache["k"] = self._host_array(self._lib.ss_result_vertex_keys, C.c_uint64, 1, np.uint64)
+        return self._cache["k"]
+
+    @property
+    def grid(self):
+        g = _Grid()
+        self._check(self._lib.ss_result_grid(self._h, C.byref(g)))
+        return UniformGrid(g)
+
+    @property
+    def subdomain_grid(self):
+        g = _Grid()
+        present = C.c_int32()
+        self._check(self._lib.ss_result_subdomain_grid(self._h, C.byref(g), C.byref(present)))
+        return UniformGrid(g) if present.value else None
+
+    @property
+    def particle_densities(self):
+        if "rho" not in self._cache:
+            self._cache["rho"] = self._host_array(self._lib.ss_result_particle_densities, C.c_float, 1, np.float32)
+        return self._cache["rho"]
+
+    @property
+    def particle_inside_aabb(self):
+        ptr, n = C.c_void_p(), C.c_uint64()
+        self._check(self._lib.ss_result_particle_inside_aabb(self._h, C.byref(ptr), C.byref(n)))
+        if not ptr.value:
+            return None
+        return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_uint8)), shape=(int(n.value),)).copy().astype(bool)
+
+    @property
+    def particle_neighbors(self):
+        return None  # global_neighborhood_list: SURVEY section 8(f) N1, not provided by this build
+
+    @property
+    def stats(self):
+        s = _Stats()
+        self._check(self._lib.ss_result_stats(self._h, C.byref(s)))
+        return {k: getattr(s, k) for k, _ in _Stats._fields_}
+
+    def levelset_box(self, lo, extent):
+        lo_a = (C.c_int64 * 3)(*[int(x) for x in lo])
+        ex_a = (C.c_int64 * 3)(*[int(x) for x in extent])
+        out = np.zeros(tuple(int(x) for x in extent), dtype=np.float32)
+        self._check(self._lib.ss_result_levelset_box(self._h, lo_a, ex_a, out.ctypes.data_as(C.c_void_p)))
+        return out
+
+    def subdomain_stats(self):
+        a, b = C.c_uint64(), C.c_uint64()
+        self._check(self._lib.ss_result_subdomain_stats(self._h, C.byref(a), C.byref(b)))
+        return int(a.value), int(b.value)
+
+    def device_pointers(self):
+        out = {}
+        for name, fn in (("vertices", self._lib.ss_result_device_vertices),
+                         ("triangles_u32", self._lib.ss_result_device_triangles_u32),
+                         ("particle_densities", self._lib.ss_result_device_particle_densities)):
+            ptr, n = C.c_void_p(), C.c_uint64()
+            self._check(fn(self._h, C.byref(ptr), C.byref(n)))
+            out[name] = (ptr.value, int(n.value))
+        return out
+
+
+_default_ctx = {}
+
+
+def default_context(device_id=0):
+    if device_id not in _default_ctx:
+        _default_ctx[device_id] = Context(device_id)
+    return _default_ctx[device_id]
+
+
+def reconstruct_surface_abs(particles, parameters, context=None, out=None):
+    """`splashsurf_lib::reconstruct_surface::<i64, f32>(positions, &parameters)` (lib.rs:330-337)."""
+    ctx = context or default_context()
+    return ctx.reconstruct(particles, parameters, out=out)
+
+
+def reconstruct_surface(particles, *, particle_radius, rest_density=1000.0, smoothing_length, cube_size,
+                        iso_surface_threshold=0.6, aabb_min=None, aabb_max=None, multi_threading=True,
+                        simd=True, global_neighborhood_list=False, subdomain_grid=True,
+                        subdomain_grid_auto_disable=True, subdomain_num_cubes_per_dim=64, context=None):
+    """Signature of `pysplashsurf.reconstruct_surface` (pysplashsurf/src/reconstruction.rs:135-207).
+
+    `smoothing_length` and `cube_size` are relative to `particle_radius`:
+    compact_support_radius = 2 * smoothing_length * particle_radius, cube = cube_size * particle_radius,
+    both formed in f64 and then cast to f32 (reconstruction.rs:171-193).
+    """
+    if global_neighborhood_list:
+        raise NotImplementedError("global_neighborhood_list is not provided by this build (SURVEY.md 8f, N1)")
+    aabb = None
+    if aabb_min is not None and aabb_max is not None:
+        aabb = (np.asarray(aabb_min, dtype=np.float64), np.asarray(aabb_max, dtype=np.float64))
+    r = float(particle_radius)
+    prm = Parameters(
+        particle_radius=r, rest_density=float(rest_density),
+        compact_support_radius=np.float32(2.0 * float(smoothing_length) * r),
+        cube_size=np.float32(float(cube_size) * r),
+        iso_surface_threshold=float(iso_surface_threshold), particle_aabb=aabb,
+        enable_multi_threading=multi_threading, enable_simd=simd, subdomain_grid=subdomain_grid,
+        subdomain_num_cubes_per_dim=subdomain_num_cubes_per_dim, auto_disable=subdomain_grid_auto_disable,
+        global_neighborhood_list=global_neighborhood_list)
+    return reconstruct_surface_abs(particles, prm, context=context)
+
+
+def grid_for_reconstruction(particles, parameters, context=None):
+    """`splashsurf_lib::grid_for_reconstruction` (lib.rs:476-516)."""
+    ctx = context or default_context()
+    return ctx.grid_for_reconstruction(particles, parameters)

@@ -1,0 +1,48 @@
+"""Synthetic particle workloads of BASELINE.json / SURVEY.md section 8(d) (seeded, reproducible).
+
+Shared by bench.py, the parity tests and tools/gen_goldens.py.  Pure numpy; no GPU needed.
+"""
+import numpy as np
+
+
+def uniform_cube_particles(n, seed=12345):
+    """S1M / S10M-cube: `n` uniform-random float32 points in [0,1)^3 (config 2: n=1e6, seed 12345)."""
+    return np.random.default_rng(seed).random((int(n), 3), dtype=np.float32)
+
+
+def _jittered_block(nx, ny, nz, spacing, origin, seed):
+    g = np.stack(np.meshgrid(np.arange(nx), np.arange(ny), np.arange(nz), indexing="ij"), -1).reshape(-1, 3).astype(np.float32)
+    jitter = (np.random.default_rng(seed).random(g.shape, dtype=np.float32) - np.float32(0.5)) * np.float32(0.5)
+    return ((g + np.float32(0.5) + jitter) * np.float32(spacing) + np.asarray(origin, dtype=np.float32)).astype(np.float32)
+
+
+def tank_particles(scale=1.0, particle_radius=0.005):
+    """S10M-tank (config 3) and scaled variants: two jittered-lattice fluid blocks at rest spacing 2r.
+
+    scale=1: blocks of 125x200x200 sites (N = 10 000 000): A = [0,1.25)x[0,2)x[0,2),
+    B = [2.75,4)x[0,2)x[2,4); jitter U(-0.25,0.25)*spacing, seeds 3 (A) and 4 (B).
+    Other scales multiply the site counts and the block-B origin (scale = 4**(1/3) gives S40M-tank).
+    """
+    s = 2.0 * particle_radius
+    nx, ny, nz = max(1, round(125 * scale)), max(1, round(200 * scale)), max(1, round(200 * scale))
+    a = _jittered_block(nx, ny, nz, s, (0.0, 0.0, 0.0), 3)
+    b = _jittered_block(nx, ny, nz, s, (2.75 * scale, 0.0, 2.0 * scale), 4)
+    return np.concatenate([a, b], axis=0)
+
+
+def tank_slab_particles(rank, world, scale=1.0, particle_radius=0.005):
+    """Weak-scaling variant for multi-GPU runs: rank `rank` of `world` gets its own copy of the tank,
+    translated along y by rank * (tank height + 2 * support) so that the union is one big domain."""
+    p = tank_particles(scale, particle_radius)
+    height = 2.0 * scale + 8.0 * particle_radius * 2
+    p[:, 1] += np.float32(rank * height)
+    return p
+
+
+WORKLOADS = {
+    # name: (generator kwargs, particle_radius, smoothing_length, cube_size) -- radius-relative l and c
+    "s1m": dict(gen=lambda: uniform_cube_particles(1_000_000, 12345), particle_radius=0.01, smoothing_length=2.0, cube_size=1.0),
+    "s10m_tank": dict(gen=lambda: tank_particles(1.0), particle_radius=0.005, smoothing_length=2.0, cube_size=0.5),
+    "s10m_cube": dict(gen=lambda: uniform_cube_particles(10_000_000, 12346), particle_radius=0.005, smoothing_length=2.0, cube_size=0.5),
+    "tank_small": dict(gen=lambda: tank_particles(0.08), particle_radius=0.005, smoothing_length=2.0, cube_size=0.5),
+}
