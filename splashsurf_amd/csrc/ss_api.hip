@@ -1,0 +1,860 @@
+// ss_api.hip -- C ABI (include/splashsurf_hip.h) and host orchestration of the gfx950 kernels.
+//
+// Host-side restatement of the reference's grid set-up (lib.rs:476-516, density_map.rs:551-580,
+// uniform_grid.rs:175-232, dense_subdomains.rs:89-244) in IEEE f32 (this file is compiled with
+// -ffp-contract=off like the kernels).  Commodity primitives (radix sort, prefix sums) come from
+// rocPRIM; every domain kernel is hand-written in ss_kernels.hip.
+#include <hip/hip_runtime.h>
+
+#include <string.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include <rocprim/rocprim.hpp>
+
+#include "../../include/splashsurf_hip.h"
+#include "ss_device.h"
+#include "ss_kernels.h"
+
+namespace {
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    hipError_t reserve(size_t bytes) {
+        if (bytes <= cap) return hipSuccess;
+        if (p) {
+            hipError_t e = hipFree(p);
+            p = nullptr;
+            cap = 0;
+            if (e != hipSuccess) return e;
+        }
+        size_t want = bytes + bytes / 8 + 256;
+        hipError_t e = hipMalloc(&p, want);
+        if (e != hipSuccess) {
+            p = nullptr;
+            return e;
+        }
+        cap = want;
+        return hipSuccess;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+    template <class T>
+    T* as() const {
+        return reinterpret_cast<T*>(p);
+    }
+};
+
+struct HostBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    hipError_t reserve(size_t bytes) {
+        if (bytes <= cap) return hipSuccess;
+        if (p) (void)hipHostFree(p);
+        p = nullptr;
+        cap = 0;
+        size_t want = bytes + bytes / 8 + 256;
+        hipError_t e = hipHostMalloc(&p, want, hipHostMallocDefault);
+        if (e != hipSuccess) {
+            p = nullptr;
+            return e;
+        }
+        cap = want;
+        return hipSuccess;
+    }
+    void release() {
+        if (p) (void)hipHostFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+};
+
+}  // namespace
+
+struct ss_context {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipStream_t own_stream = nullptr;
+    std::string err;
+    int err_detail = 0;
+    // scratch (grow-only, reused across calls = the reference's workspace.rs)
+    DevBuf xyz_in, xyz_filt, flags32, offsets, keys_a, keys_b, vals_a, vals_b, cell_count, cell_start, pos_sorted, temp, aabb_partial, aabb_out,
+        block_flag, block_rank, mc_flag, mc_rank, vcount, tcount, counter;
+    HostBuf h_small;
+    hipEvent_t ev[12];
+    bool ev_ok = false;
+};
+
+struct ss_result {
+    ss_context* ctx = nullptr;
+    bool valid = false;
+    SSDev P;
+    ss_grid_f32 grid, subgrid;
+    bool has_inside = false;
+    uint64_t n_input = 0, n_particles = 0, n_vertices = 0, n_triangles = 0;
+    uint32_t n_active = 0, n_mc = 0;
+    ss_stats stats;
+    // device results
+    DevBuf rho, posvol, perm, inside8, G, block_slot, active_list, mc_list, mc_slot, masks, vbase, tbase, vertices, vkeys, tri32, tri64;
+    // host mirrors
+    HostBuf h_vertices, h_tri64, h_tri32, h_rho, h_vkeys, h_inside;
+    bool hv = false, ht64 = false, ht32 = false, hrho = false, hkeys = false, hinside = false;
+};
+
+namespace {
+
+#define SS_HIP(ctx, call)                                                                              \
+    do {                                                                                               \
+        hipError_t _e = (call);                                                                        \
+        if (_e != hipSuccess) {                                                                        \
+            (ctx)->err = std::string("HIP error: ") + hipGetErrorString(_e) + " at " #call;            \
+            (void)hipGetLastError();                                                                   \
+            return SS_ERR_DEVICE;                                                                      \
+        }                                                                                              \
+    } while (0)
+
+ss_status fail(ss_context* ctx, ss_status st, const std::string& msg, int detail = 0) {
+    if (ctx) {
+        ctx->err = msg;
+        ctx->err_detail = detail;
+    }
+    return st;
+}
+
+// ---- uniform grid, host restatement (uniform_grid.rs:175-232, 647-674) ----
+void grid_new(ss_grid_f32* g, const float mn[3], const int64_t nc[3], float cs) {
+    for (int d = 0; d < 3; ++d) {
+        g->aabb_min[d] = mn[d];
+        g->n_cells[d] = nc[d];
+        g->n_points[d] = nc[d] + 1;
+        g->aabb_max[d] = mn[d] + cs * (float)(double)nc[d];
+    }
+    g->cell_size = cs;
+}
+
+int grid_from_aabb(ss_grid_f32* g, const float amin[3], const float amax[3], float cs) {
+    if (!(cs > 0.0f)) return SS_GRID_INVALID_CELL_SIZE;
+    if (amin[0] == amax[0] && amin[1] == amax[1] && amin[2] == amax[2]) return SS_GRID_DEGENERATE_AABB;
+    if (!(amin[0] <= amax[0] && amin[1] <= amax[1] && amin[2] <= amax[2])) return SS_GRID_INCONSISTENT_AABB;
+    float aligned[3];
+    int64_t nc[3];
+    for (int d = 0; d < 3; ++d) {
+        aligned[d] = floorf(amin[d] / cs) * cs;
+        float n_real = (amax[d] - aligned[d]) / cs;
+        double c = (double)ceilf(n_real);
+        if (!(c < 2147483000.0)) return SS_GRID_INDEX_TYPE_TOO_SMALL;  // this build indexes points with i32 per dimension
+        int64_t n = (int64_t)c;
+        nc[d] = n < 1 ? 1 : n;
+    }
+    grid_new(g, aligned, nc, cs);
+    return 0;
+}
+
+// lib.rs:476-516 given the particle AABB (already computed on the device or supplied by the user)
+int grid_for_reconstruction(const ss_params_f32* prm, bool have_particles, const float pmin[3], const float pmax[3], ss_grid_f32* out) {
+    float amin[3], amax[3];
+    if (prm->has_particle_aabb) {
+        for (int d = 0; d < 3; ++d) {
+            amin[d] = prm->aabb_min[d];
+            amax[d] = prm->aabb_max[d];
+        }
+    } else {
+        for (int d = 0; d < 3; ++d) {
+            amin[d] = have_particles ? pmin[d] : 0.0f;  // aabb.rs:28-31: empty -> zeros
+            amax[d] = have_particles ? pmax[d] : 0.0f;
+            amin[d] -= prm->particle_radius;  // lib.rs:496
+            amax[d] += prm->particle_radius;
+        }
+    }
+    const float half_cells = ceilf(prm->compact_support_radius / prm->cube_size);  // density_map.rs:563
+    const float eps_sqrt = sqrtf(1.1920929e-07f);
+    const float kernel_margin = prm->cube_size * half_cells * (1.0f + eps_sqrt);  // density_map.rs:572-573
+    for (int d = 0; d < 3; ++d) {
+        amin[d] -= kernel_margin;  // lib.rs:513
+        amax[d] += kernel_margin;
+    }
+    return grid_from_aabb(out, amin, amax, prm->cube_size);
+}
+
+// dense_subdomains.rs:89-244
+void initialize_subdomain_parameters(const ss_params_f32* prm, const ss_grid_f32* initial, ss_grid_f32* global_grid, ss_grid_f32* sub_grid,
+                                     float* mass, float* margin) {
+    const int64_t n = (int64_t)prm->subdomain_num_cubes_per_dim;
+    const float d = prm->particle_radius + prm->particle_radius;  // kernel.rs:28-30
+    *mass = (d * d * d) * prm->rest_density;
+    *margin = ceilf(prm->compact_support_radius / prm->cube_size) * prm->cube_size * 1.01f;
+    int64_t nsub[3], ncell[3];
+    for (int k = 0; k < 3; ++k) {
+        int64_t c = initial->n_cells[k];
+        int64_t rem = c % n;
+        nsub[k] = c / n + (rem < 1 ? rem : 1);  // int_ceil_div, :2129-2131
+        ncell[k] = nsub[k] * n;
+    }
+    grid_new(global_grid, initial->aabb_min, ncell, prm->cube_size);
+    const float sub_size = prm->cube_size * (float)(double)n;
+    grid_new(sub_grid, global_grid->aabb_min, nsub, sub_size);
+}
+
+bool is_device_pointer(const void* p) {
+    hipPointerAttribute_t attr;
+    hipError_t e = hipPointerGetAttributes(&attr, p);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        return false;
+    }
+    return attr.type == hipMemoryTypeDevice || attr.type == hipMemoryTypeManaged;
+}
+
+template <class T>
+ss_status exclusive_scan_u32(ss_context* ctx, const T* in, T* out, size_t n) {
+    size_t bytes = 0;
+    SS_HIP(ctx, rocprim::exclusive_scan(nullptr, bytes, in, out, (T)0, n, rocprim::plus<T>(), ctx->stream));
+    SS_HIP(ctx, ctx->temp.reserve(bytes));
+    SS_HIP(ctx, rocprim::exclusive_scan(ctx->temp.p, bytes, in, out, (T)0, n, rocprim::plus<T>(), ctx->stream));
+    return SS_OK;
+}
+
+ss_status validate_params(ss_context* ctx, const ss_params_f32* prm, uint64_t n) {
+    if (!prm) return fail(ctx, SS_ERR_INVALID_ARGUMENT, "parameters pointer is null");
+    if (n >= (1ull << 31)) return fail(ctx, SS_ERR_UNSUPPORTED, "more than 2^31-1 particles per call are not supported by this build");
+    // the reference panics for these (density_map.rs:555-559); report instead of aborting the host
+    if (!(prm->cube_size > 0.0f)) return fail(ctx, SS_ERR_UNKNOWN, "cube size must be positive (reference: panic in compute_kernel_evaluation_radius)");
+    if (!(prm->compact_support_radius >= 0.0f)) return fail(ctx, SS_ERR_UNKNOWN, "compact support radius must be non-negative");
+    if (!(prm->compact_support_radius > 0.0f)) return fail(ctx, SS_ERR_UNKNOWN, "search radius for neighborhood search has to be positive");
+    if (prm->subdomain_num_cubes_per_dim < 1 || prm->subdomain_num_cubes_per_dim > (1u << 20))
+        return fail(ctx, SS_ERR_INVALID_ARGUMENT, "subdomain_num_cubes_per_dim out of range");
+    if (prm->decomposition == 0)
+        return fail(ctx, SS_ERR_UNSUPPORTED,
+                    "SpatialDecomposition::None (global strategy, reconstruction.rs:65-112) is not provided by this build; "
+                    "use the uniform-grid decomposition");
+    if (prm->global_neighborhood_list) return fail(ctx, SS_ERR_UNSUPPORTED, "global_neighborhood_list is not provided by this build");
+    return SS_OK;
+}
+
+void reset_host_flags(ss_result* r) { r->hv = r->ht64 = r->ht32 = r->hrho = r->hkeys = r->hinside = false; }
+
+ss_status make_device_params(ss_context* ctx, const ss_params_f32* prm, const ss_grid_f32& g, const ss_grid_f32& sg, float mass, float margin,
+                             uint32_t n, SSDev* out) {
+    SSDev P;
+    memset(&P, 0, sizeof(P));
+    const float h = prm->compact_support_radius;
+    for (int d = 0; d < 3; ++d) {
+        P.gmin[d] = g.aabb_min[d];
+        P.np[d] = (int)g.n_points[d];
+        P.nc[d] = (int)g.n_cells[d];
+        P.ns[d] = (int)sg.n_cells[d];
+        P.nb[d] = (P.np[d] + SS_BLOCK - 1) / SS_BLOCK;
+    }
+    P.cs = g.cell_size;
+    P.n_sub_cubes = (int)prm->subdomain_num_cubes_per_dim;
+    P.sub_size = sg.cell_size;
+    P.h = h;
+    P.h2 = h * h;
+    P.H2 = (h * h) * 1.01f;
+    P.sigma = 8.0f / (h * h * h);
+    P.w0 = ss_kernel_evaluate(0.0f, h, P.sigma);
+    P.mass = mass;
+    P.threshold = prm->iso_surface_threshold;
+    P.margin = margin;
+    P.reach = sqrtf(1.01f) * h * 1.0001f;
+    float amax = 0.0f;
+    for (int d = 0; d < 3; ++d) amax = fmaxf(amax, fmaxf(fabsf(g.aabb_min[d]), fabsf(g.aabb_max[d])));
+    P.coord_slack = 16.0f * 1.1920929e-07f * amax + 1e-30f;
+    double ncells = 1.0, nblocks = 1.0;
+    for (int d = 0; d < 3; ++d) {
+        const double lo = (double)g.aabb_min[d] - 1.5 * (double)margin, hi = (double)g.aabb_max[d] + 1.5 * (double)margin;
+        const double k0 = floor(lo / (double)h) - 2.0, k1 = floor(hi / (double)h) + 2.0;
+        if (!(k0 > -2.0e9 && k1 < 2.0e9)) return fail(ctx, SS_ERR_UNSUPPORTED, "search grid index out of i32 range");
+        P.kmin[d] = (int)k0;
+        P.kdim[d] = (int)(k1 - k0) + 1;
+        ncells *= (double)P.kdim[d];
+        nblocks *= (double)P.nb[d];
+    }
+    if (ncells > 4.0e9 || nblocks > 4.0e9)
+        return fail(ctx, SS_ERR_UNSUPPORTED, "domain too large for the dense cell/block tables of this build (> 4e9 search cells or level-set blocks)");
+    P.n = n;
+    *out = P;
+    return SS_OK;
+}
+
+ss_status ensure_events(ss_context* ctx) {
+    if (ctx->ev_ok) return SS_OK;
+    for (int i = 0; i < 12; ++i) SS_HIP(ctx, hipEventCreate(&ctx->ev[i]));
+    ctx->ev_ok = true;
+    return SS_OK;
+}
+
+float ev_ms(ss_context* ctx, int a, int b) {
+    float ms = 0.0f;
+    if (hipEventElapsedTime(&ms, ctx->ev[a], ctx->ev[b]) != hipSuccess) {
+        (void)hipGetLastError();
+        return 0.0f;
+    }
+    return ms;
+}
+
+// Uploads (if needed) and filters the particles; returns device pointer to the particles used
+ss_status stage_particles(ss_context* ctx, const float* xyz, uint64_t n_in, const ss_params_f32* prm, ss_result* res, const float** d_used,
+                          uint32_t* n_used) {
+    hipStream_t st = ctx->stream;
+    const float* d_xyz = nullptr;
+    if (n_in == 0) {
+        *d_used = nullptr;
+        *n_used = 0;
+        if (res) {
+            res->has_inside = prm->has_particle_aabb != 0;
+        }
+        return SS_OK;
+    }
+    if (!xyz) return fail(ctx, SS_ERR_INVALID_ARGUMENT, "particle pointer is null");
+    if (is_device_pointer(xyz)) {
+        d_xyz = xyz;
+    } else {
+        SS_HIP(ctx, ctx->xyz_in.reserve(n_in * 12));
+        SS_HIP(ctx, hipMemcpyAsync(ctx->xyz_in.p, xyz, n_in * 12, hipMemcpyHostToDevice, st));
+        d_xyz = ctx->xyz_in.as<float>();
+    }
+    if (!prm->has_particle_aabb) {
+        *d_used = d_xyz;
+        *n_used = (uint32_t)n_in;
+        if (res) res->has_inside = false;
+        return SS_OK;
+    }
+    // lib.rs:369-406
+    DevBuf local_inside;
+    DevBuf* inside = res ? &res->inside8 : &local_inside;
+    SS_HIP(ctx, inside->reserve(n_in));
+    SS_HIP(ctx, ctx->flags32.reserve((n_in + 1) * 4));
+    SS_HIP(ctx, ctx->offsets.reserve((n_in + 1) * 4));
+    SS_HIP(ctx, hipMemsetAsync(ctx->flags32.p, 0, (n_in + 1) * 4, st));
+    ss_launch_inside_flags(d_xyz, (uint32_t)n_in, prm->aabb_min, prm->aabb_max, inside->as<uint8_t>(), ctx->flags32.as<uint32_t>(), st);
+    ss_status s = exclusive_scan_u32<uint32_t>(ctx, ctx->flags32.as<uint32_t>(), ctx->offsets.as<uint32_t>(), n_in + 1);
+    if (s != SS_OK) return s;
+    uint32_t cnt = 0;
+    SS_HIP(ctx, hipMemcpyAsync(&cnt, ctx->offsets.as<uint32_t>() + n_in, 4, hipMemcpyDeviceToHost, st));
+    SS_HIP(ctx, hipStreamSynchronize(st));
+    SS_HIP(ctx, ctx->xyz_filt.reserve((size_t)cnt * 12 + 16));
+    ss_launch_compact_xyz(d_xyz, (uint32_t)n_in, ctx->flags32.as<uint32_t>(), ctx->offsets.as<uint32_t>(), ctx->xyz_filt.as<float>(), st);
+    *d_used = ctx->xyz_filt.as<float>();
+    *n_used = cnt;
+    if (res) res->has_inside = true;
+    if (!res) {
+        SS_HIP(ctx, hipStreamSynchronize(st));
+        local_inside.release();
+    }
+    return SS_OK;
+}
+
+ss_status compute_particle_aabb(ss_context* ctx, const float* d_xyz, uint32_t n, float pmin[3], float pmax[3]) {
+    hipStream_t st = ctx->stream;
+    SS_HIP(ctx, ctx->aabb_partial.reserve(1024 * 6 * 4));
+    SS_HIP(ctx, ctx->aabb_out.reserve(6 * 4));
+    ss_launch_aabb(d_xyz, n, ctx->aabb_partial.as<float>(), ctx->aabb_out.as<float>(), st);
+    float h6[6];
+    SS_HIP(ctx, hipMemcpyAsync(h6, ctx->aabb_out.p, 24, hipMemcpyDeviceToHost, st));
+    SS_HIP(ctx, hipStreamSynchronize(st));
+    for (int d = 0; d < 3; ++d) {
+        pmin[d] = h6[d];
+        pmax[d] = h6[3 + d];
+    }
+    return SS_OK;
+}
+
+ss_status reconstruct_impl(ss_context* ctx, const float* xyz, uint64_t n_in, const ss_params_f32* prm, ss_result* res) {
+    ss_status s = validate_params(ctx, prm, n_in);
+    if (s != SS_OK) return s;
+    SS_HIP(ctx, hipSetDevice(ctx->device));
+    s = ensure_events(ctx);
+    if (s != SS_OK) return s;
+    hipStream_t st = ctx->stream;
+    res->valid = false;
+    reset_host_flags(res);
+    memset(&res->stats, 0, sizeof(res->stats));
+    res->n_input = n_in;
+    res->n_vertices = res->n_triangles = 0;
+    res->n_active = res->n_mc = 0;
+
+    const bool host_input = n_in > 0 && xyz && !is_device_pointer(xyz);
+    SS_HIP(ctx, hipEventRecord(ctx->ev[0], st));
+    const float* d_xyz = nullptr;
+    uint32_t n = 0;
+    s = stage_particles(ctx, xyz, n_in, prm, res, &d_xyz, &n);
+    if (s != SS_OK) return s;
+    res->n_particles = n;
+    SS_HIP(ctx, hipEventRecord(ctx->ev[1], st));
+
+    // ---- grid set-up (lib.rs:409-417, reconstruction.rs:24-29) ----
+    float pmin[3] = {0, 0, 0}, pmax[3] = {0, 0, 0};
+    if (!prm->has_particle_aabb && n > 0) {
+        s = compute_particle_aabb(ctx, d_xyz, n, pmin, pmax);
+        if (s != SS_OK) return s;
+    }
+    ss_grid_f32 initial;
+    int gerr = grid_for_reconstruction(prm, n > 0, pmin, pmax, &initial);
+    if (gerr) return fail(ctx, SS_ERR_GRID_CONSTRUCTION, "grid construction failed (uniform_grid.rs:147-169)", gerr);
+    float mass = 0, margin = 0;
+    initialize_subdomain_parameters(prm, &initial, &res->grid, &res->subgrid, &mass, &margin);
+    for (int d = 0; d < 3; ++d)
+        if (res->grid.n_points[d] > 2000000000ll) return fail(ctx, SS_ERR_GRID_CONSTRUCTION, "too many grid points per dimension", SS_GRID_INDEX_TYPE_TOO_SMALL);
+    SSDev P;
+    s = make_device_params(ctx, prm, res->grid, res->subgrid, mass, margin, n, &P);
+    if (s != SS_OK) return s;
+    res->P = P;
+    SS_HIP(ctx, hipEventRecord(ctx->ev[2], st));
+
+    const size_t ncells = (size_t)P.kdim[0] * P.kdim[1] * P.kdim[2];
+    const size_t nblocks = (size_t)P.nb[0] * P.nb[1] * P.nb[2];
+
+    // ---- K1: bin + sort (decomposition) ----
+    SS_HIP(ctx, res->rho.reserve((size_t)n * 4 + 16));
+    SS_HIP(ctx, res->posvol.reserve((size_t)n * 16 + 16));
+    SS_HIP(ctx, res->perm.reserve((size_t)n * 4 + 16));
+    SS_HIP(ctx, ctx->cell_count.reserve((ncells + 1) * 4));
+    SS_HIP(ctx, ctx->cell_start.reserve((ncells + 1) * 4));
+    SS_HIP(ctx, hipMemsetAsync(ctx->cell_count.p, 0, (ncells + 1) * 4, st));
+    if (n > 0) {
+        SS_HIP(ctx, ctx->keys_a.reserve((size_t)n * 4));
+        SS_HIP(ctx, ctx->keys_b.reserve((size_t)n * 4));
+        SS_HIP(ctx, ctx->vals_a.reserve((size_t)n * 4));
+        SS_HIP(ctx, ctx->pos_sorted.reserve((size_t)n * 16));
+        ss_launch_cell_keys(P, d_xyz, ctx->keys_a.as<uint32_t>(), ctx->vals_a.as<uint32_t>(), ctx->cell_count.as<uint32_t>(), st);
+    }
+    s = exclusive_scan_u32<uint32_t>(ctx, ctx->cell_count.as<uint32_t>(), ctx->cell_start.as<uint32_t>(), ncells + 1);
+    if (s != SS_OK) return s;
+    if (n > 0) {
+        unsigned bits = 1;
+        while (bits < 32 && ((size_t)1 << bits) < ncells) ++bits;
+        size_t bytes = 0;
+        SS_HIP(ctx, rocprim::radix_sort_pairs(nullptr, bytes, ctx->keys_a.as<uint32_t>(), ctx->keys_b.as<uint32_t>(), ctx->vals_a.as<uint32_t>(),
+                                              res->perm.as<uint32_t>(), (size_t)n, 0u, bits, st));
+        SS_HIP(ctx, ctx->temp.reserve(bytes));
+        SS_HIP(ctx, rocprim::radix_sort_pairs(ctx->temp.p, bytes, ctx->keys_a.as<uint32_t>(), ctx->keys_b.as<uint32_t>(), ctx->vals_a.as<uint32_t>(),
+                                              res->perm.as<uint32_t>(), (size_t)n, 0u, bits, st));
+        ss_launch_gather_sorted(n, d_xyz, res->perm.as<uint32_t>(), ctx->pos_sorted.as<float4>(), st);
+    }
+    SS_HIP(ctx, hipEventRecord(ctx->ev[3], st));
+
+    // ---- K2: densities ----
+    ss_launch_density(P, ctx->pos_sorted.as<float4>(), res->perm.as<uint32_t>(), ctx->cell_start.as<uint32_t>(), res->rho.as<float>(),
+                      res->posvol.as<float4>(), st);
+    SS_HIP(ctx, hipEventRecord(ctx->ev[4], st));
+
+    // ---- K3 prepare: active level-set blocks and MC blocks ----
+    SS_HIP(ctx, ctx->block_flag.reserve((nblocks + 1) * 4));
+    SS_HIP(ctx, ctx->block_rank.reserve((nblocks + 1) * 4));
+    SS_HIP(ctx, ctx->mc_flag.reserve((nblocks + 1) * 4));
+    SS_HIP(ctx, ctx->mc_rank.reserve((nblocks + 1) * 4));
+    SS_HIP(ctx, res->block_slot.reserve(nblocks * 4));
+    SS_HIP(ctx, res->mc_slot.reserve(nblocks * 4));
+    SS_HIP(ctx, hipMemsetAsync(ctx->block_flag.p, 0, (nblocks + 1) * 4, st));
+    SS_HIP(ctx, hipMemsetAsync(ctx->mc_flag.p, 0, (nblocks + 1) * 4, st));
+    if (n > 0) ss_launch_mark_blocks(P, ctx->cell_start.as<uint32_t>(), (uint32_t)ncells, ctx->block_flag.as<uint32_t>(), st);
+    ss_launch_mark_mc_blocks(P, ctx->block_flag.as<uint32_t>(), (uint32_t)nblocks, ctx->mc_flag.as<uint32_t>(), st);
+    s = exclusive_scan_u32<uint32_t>(ctx, ctx->block_flag.as<uint32_t>(), ctx->block_rank.as<uint32_t>(), nblocks + 1);
+    if (s != SS_OK) return s;
+    s = exclusive_scan_u32<uint32_t>(ctx, ctx->mc_flag.as<uint32_t>(), ctx->mc_rank.as<uint32_t>(), nblocks + 1);
+    if (s != SS_OK) return s;
+    uint32_t counts2[2] = {0, 0};
+    SS_HIP(ctx, hipMemcpyAsync(&counts2[0], ctx->block_rank.as<uint32_t>() + nblocks, 4, hipMemcpyDeviceToHost, st));
+    SS_HIP(ctx, hipMemcpyAsync(&counts2[1], ctx->mc_rank.as<uint32_t>() + nblocks, 4, hipMemcpyDeviceToHost, st));
+    SS_HIP(ctx, hipStreamSynchronize(st));
+    const uint32_t n_active = counts2[0], n_mc = counts2[1];
+    res->n_active = n_active;
+    res->n_mc = n_mc;
+    SS_HIP(ctx, res->active_list.reserve((size_t)n_active * 4 + 16));
+    SS_HIP(ctx, res->mc_list.reserve((size_t)n_mc * 4 + 16));
+    SS_HIP(ctx, res->G.reserve((size_t)n_active * SS_BLOCK_POINTS * 4 + 16));
+    ss_launch_compact_blocks(ctx->block_flag.as<uint32_t>(), ctx->block_rank.as<uint32_t>(), (uint32_t)nblocks, res->active_list.as<uint32_t>(),
+                             res->block_slot.as<uint32_t>(), st);
+    ss_launch_compact_blocks(ctx->mc_flag.as<uint32_t>(), ctx->mc_rank.as<uint32_t>(), (uint32_t)nblocks, res->mc_list.as<uint32_t>(),
+                             res->mc_slot.as<uint32_t>(), st);
+    SS_HIP(ctx, ctx->counter.reserve(64));
+    SS_HIP(ctx, hipMemsetAsync(ctx->counter.p, 0, 64, st));
+    SS_HIP(ctx, hipEventRecord(ctx->ev[5], st));
+
+    // ---- K3: level-set splat ----
+    ss_launch_splat(P, res->posvol.as<float4>(), res->perm.as<uint32_t>(), ctx->cell_start.as<uint32_t>(), res->active_list.as<uint32_t>(), n_active,
+                    res->G.as<float>(), ctx->counter.as<unsigned long long>(), st);
+    SS_HIP(ctx, hipEventRecord(ctx->ev[6], st));
+
+    // ---- K4: MC classification + counts ----
+    SS_HIP(ctx, res->masks.reserve((size_t)n_mc * 24 * 8 + 16));
+    SS_HIP(ctx, ctx->vcount.reserve(((size_t)n_mc + 1) * 4));
+    SS_HIP(ctx, ctx->tcount.reserve(((size_t)n_mc + 1) * 4));
+    SS_HIP(ctx, res->vbase.reserve(((size_t)n_mc + 1) * 4));
+    SS_HIP(ctx, res->tbase.reserve(((size_t)n_mc + 1) * 4));
+    SS_HIP(ctx, hipMemsetAsync(ctx->vcount.p, 0, ((size_t)n_mc + 1) * 4, st));
+    SS_HIP(ctx, hipMemsetAsync(ctx->tcount.p, 0, ((size_t)n_mc + 1) * 4, st));
+    ss_launch_mc_count(P, res->G.as<float>(), res->block_slot.as<uint32_t>(), res->mc_list.as<uint32_t>(), n_mc, res->masks.as<unsigned long long>(),
+                       ctx->vcount.as<uint32_t>(), ctx->tcount.as<uint32_t>(), st);
+    SS_HIP(ctx, hipEventRecord(ctx->ev[7], st));
+    // ---- "stitching": global numbering by prefix sums ----
+    s = exclusive_scan_u32<uint32_t>(ctx, ctx->vcount.as<uint32_t>(), res->vbase.as<uint32_t>(), (size_t)n_mc + 1);
+    if (s != SS_OK) return s;
+    s = exclusive_scan_u32<uint32_t>(ctx, ctx->tcount.as<uint32_t>(), res->tbase.as<uint32_t>(), (size_t)n_mc + 1);
+    if (s != SS_OK) return s;
+    uint32_t totals[2] = {0, 0};
+    unsigned long long cand = 0;
+    SS_HIP(ctx, hipMemcpyAsync(&totals[0], res->vbase.as<uint32_t>() + n_mc, 4, hipMemcpyDeviceToHost, st));
+    SS_HIP(ctx, hipMemcpyAsync(&totals[1], res->tbase.as<uint32_t>() + n_mc, 4, hipMemcpyDeviceToHost, st));
+    SS_HIP(ctx, hipMemcpyAsync(&cand, ctx->counter.p, 8, hipMemcpyDeviceToHost, st));
+    SS_HIP(ctx, hipStreamSynchronize(st));
+    const uint64_t nv = totals[0], nt = totals[1];
+    if (nt * 3 >= (1ull << 32)) return fail(ctx, SS_ERR_UNSUPPORTED, "more than 2^32/3 triangles in one call are not supported by this build");
+    SS_HIP(ctx, res->vertices.reserve(nv * 12 + 16));
+    SS_HIP(ctx, res->vkeys.reserve(nv * 8 + 16));
+    SS_HIP(ctx, res->tri32.reserve(nt * 12 + 16));
+    SS_HIP(ctx, hipEventRecord(ctx->ev[8], st));
+    // ---- K5: emission ----
+    ss_launch_mc_emit(P, res->G.as<float>(), res->block_slot.as<uint32_t>(), res->mc_list.as<uint32_t>(), res->mc_slot.as<uint32_t>(), n_mc,
+                      res->masks.as<unsigned long long>(), res->vbase.as<uint32_t>(), res->tbase.as<uint32_t>(), res->vertices.as<float>(),
+                      res->vkeys.as<unsigned long long>(), res->tri32.as<uint32_t>(), st);
+    SS_HIP(ctx, hipEventRecord(ctx->ev[9], st));
+    SS_HIP(ctx, hipStreamSynchronize(st));
+    {
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return fail(ctx, SS_ERR_DEVICE, std::string("kernel launch failed: ") + hipGetErrorString(e));
+    }
+
+    res->n_vertices = nv;
+    res->n_triangles = nt;
+    ss_stats& S = res->stats;
+    S.ms_total = ev_ms(ctx, 0, 9);
+    S.ms_upload = host_input ? ev_ms(ctx, 0, 1) : 0.0;
+    S.ms_aabb_grid = ev_ms(ctx, 1, 2);
+    S.ms_decomposition = ev_ms(ctx, 2, 3);
+    S.ms_density = ev_ms(ctx, 3, 4);
+    S.ms_levelset_prepare = ev_ms(ctx, 4, 5);
+    S.ms_levelset = ev_ms(ctx, 5, 6);
+    S.ms_marching_cubes = ev_ms(ctx, 6, 7) + ev_ms(ctx, 8, 9);
+    S.ms_stitching = ev_ms(ctx, 7, 8);
+    S.n_particles = n;
+    S.n_vertices = nv;
+    S.n_triangles = nt;
+    S.n_active_blocks = n_active;
+    S.n_block_candidates = cand;
+    S.n_density_fixups = 0;
+    S.levelset_kernel_launches = n_active ? 1 : 0;
+    size_t held = 0;
+    for (const DevBuf* b : {&ctx->xyz_in, &ctx->xyz_filt, &ctx->flags32, &ctx->offsets, &ctx->keys_a, &ctx->keys_b, &ctx->vals_a, &ctx->cell_count,
+                            &ctx->cell_start, &ctx->pos_sorted, &ctx->temp, &ctx->block_flag, &ctx->block_rank, &ctx->mc_flag, &ctx->mc_rank,
+                            &ctx->vcount, &ctx->tcount, &res->rho, &res->posvol, &res->perm, &res->inside8, &res->G, &res->block_slot,
+                            &res->active_list, &res->mc_list, &res->mc_slot, &res->masks, &res->vbase, &res->tbase, &res->vertices, &res->vkeys,
+                            &res->tri32})
+        held += b->cap;
+    S.bytes_device_peak = held;
+    res->valid = true;
+    return SS_OK;
+}
+
+template <class T>
+ss_status download(ss_result* r, const DevBuf& d, HostBuf& h, bool& flag, size_t count, const T** out) {
+    ss_context* ctx = r->ctx;
+    if (!flag) {
+        SS_HIP(ctx, hipSetDevice(ctx->device));
+        SS_HIP(ctx, h.reserve(count * sizeof(T) + 16));
+        if (count) SS_HIP(ctx, hipMemcpyAsync(h.p, d.p, count * sizeof(T), hipMemcpyDeviceToHost, ctx->stream));
+        SS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        flag = true;
+    }
+    *out = reinterpret_cast<const T*>(h.p);
+    return SS_OK;
+}
+
+void result_release(ss_result* r) {
+    for (DevBuf* b : {&r->rho, &r->posvol, &r->perm, &r->inside8, &r->G, &r->block_slot, &r->active_list, &r->mc_list, &r->mc_slot, &r->masks,
+                      &r->vbase, &r->tbase, &r->vertices, &r->vkeys, &r->tri32, &r->tri64})
+        b->release();
+    for (HostBuf* b : {&r->h_vertices, &r->h_tri64, &r->h_tri32, &r->h_rho, &r->h_vkeys, &r->h_inside}) b->release();
+}
+
+}  // namespace
+
+// =====================================================================================================
+// C ABI
+// =====================================================================================================
+extern "C" {
+
+int ss_abi_version(void) { return SS_ABI_VERSION; }
+
+ss_status ss_context_create(int device_id, ss_context** out) {
+    if (!out) return SS_ERR_INVALID_ARGUMENT;
+    *out = nullptr;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) {
+        (void)hipGetLastError();
+        return SS_ERR_DEVICE;
+    }
+    if (device_id < 0 || device_id >= count) return SS_ERR_INVALID_ARGUMENT;
+    if (hipSetDevice(device_id) != hipSuccess) return SS_ERR_DEVICE;
+    ss_context* c = new (std::nothrow) ss_context();
+    if (!c) return SS_ERR_UNKNOWN;
+    c->device = device_id;
+    if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) {
+        delete c;
+        return SS_ERR_DEVICE;
+    }
+    c->stream = c->own_stream;
+    *out = c;
+    return SS_OK;
+}
+
+void ss_context_destroy(ss_context* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipDeviceSynchronize();
+    for (DevBuf* b : {&c->xyz_in, &c->xyz_filt, &c->flags32, &c->offsets, &c->keys_a, &c->keys_b, &c->vals_a, &c->vals_b, &c->cell_count,
+                      &c->cell_start, &c->pos_sorted, &c->temp, &c->aabb_partial, &c->aabb_out, &c->block_flag, &c->block_rank, &c->mc_flag,
+                      &c->mc_rank, &c->vcount, &c->tcount, &c->counter})
+        b->release();
+    c->h_small.release();
+    if (c->ev_ok)
+        for (int i = 0; i < 12; ++i) (void)hipEventDestroy(c->ev[i]);
+    if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+    delete c;
+}
+
+const char* ss_last_error(const ss_context* c) { return c ? c->err.c_str() : "null context"; }
+int ss_last_error_detail(const ss_context* c) { return c ? c->err_detail : 0; }
+
+ss_status ss_context_set_stream(ss_context* c, void* hip_stream) {
+    if (!c) return SS_ERR_INVALID_ARGUMENT;
+    c->stream = hip_stream ? reinterpret_cast<hipStream_t>(hip_stream) : c->own_stream;
+    return SS_OK;
+}
+
+ss_status ss_result_create(ss_context* c, ss_result** out) {
+    if (!c || !out) return SS_ERR_INVALID_ARGUMENT;
+    ss_result* r = new (std::nothrow) ss_result();
+    if (!r) return fail(c, SS_ERR_UNKNOWN, "out of host memory");
+    r->ctx = c;
+    memset(&r->P, 0, sizeof(r->P));
+    memset(&r->grid, 0, sizeof(r->grid));
+    memset(&r->subgrid, 0, sizeof(r->subgrid));
+    memset(&r->stats, 0, sizeof(r->stats));
+    *out = r;
+    return SS_OK;
+}
+
+void ss_result_free(ss_result* r) {
+    if (!r) return;
+    if (r->ctx) (void)hipSetDevice(r->ctx->device);
+    result_release(r);
+    delete r;
+}
+
+ss_status ss_reconstruct_surface_inplace_f32(ss_context* c, const float* xyz, uint64_t n, const ss_params_f32* prm, ss_result* inout) {
+    if (!c || !inout) return SS_ERR_INVALID_ARGUMENT;
+    if (inout->ctx != c) return fail(c, SS_ERR_INVALID_ARGUMENT, "result belongs to a different context");
+    c->err.clear();
+    c->err_detail = 0;
+    return reconstruct_impl(c, xyz, n, prm, inout);
+}
+
+ss_status ss_reconstruct_surface_f32(ss_context* c, const float* xyz, uint64_t n, const ss_params_f32* prm, ss_result** out) {
+    if (!c || !out) return SS_ERR_INVALID_ARGUMENT;
+    *out = nullptr;
+    ss_result* r = nullptr;
+    ss_status s = ss_result_create(c, &r);
+    if (s != SS_OK) return s;
+    s = ss_reconstruct_surface_inplace_f32(c, xyz, n, prm, r);
+    if (s != SS_OK) {
+        ss_result_free(r);
+        return s;
+    }
+    *out = r;
+    return SS_OK;
+}
+
+ss_status ss_grid_for_reconstruction_f32(ss_context* c, const float* xyz, uint64_t n_in, const ss_params_f32* prm, ss_grid_f32* out) {
+    if (!c || !prm || !out) return SS_ERR_INVALID_ARGUMENT;
+    c->err.clear();
+    if (!(prm->cube_size > 0.0f)) return fail(c, SS_ERR_UNKNOWN, "cube size must be positive");
+    if (!(prm->compact_support_radius >= 0.0f)) return fail(c, SS_ERR_UNKNOWN, "compact support radius must be non-negative");
+    if (n_in >= (1ull << 31)) return fail(c, SS_ERR_UNSUPPORTED, "too many particles");
+    SS_HIP(c, hipSetDevice(c->device));
+    float pmin[3] = {0, 0, 0}, pmax[3] = {0, 0, 0};
+    bool have = false;
+    if (!prm->has_particle_aabb && n_in > 0) {
+        // note: lib.rs:476-507 computes the AABB over the particles it is given (no filtering here)
+        const float* d_xyz = nullptr;
+        if (!xyz) return fail(c, SS_ERR_INVALID_ARGUMENT, "particle pointer is null");
+        if (is_device_pointer(xyz)) {
+            d_xyz = xyz;
+        } else {
+            SS_HIP(c, c->xyz_in.reserve(n_in * 12));
+            SS_HIP(c, hipMemcpyAsync(c->xyz_in.p, xyz, n_in * 12, hipMemcpyHostToDevice, c->stream));
+            d_xyz = c->xyz_in.as<float>();
+        }
+        ss_status s = compute_particle_aabb(c, d_xyz, (uint32_t)n_in, pmin, pmax);
+        if (s != SS_OK) return s;
+        have = true;
+    }
+    int gerr = grid_for_reconstruction(prm, have, pmin, pmax, out);
+    if (gerr) return fail(c, SS_ERR_GRID_CONSTRUCTION, "grid construction failed (uniform_grid.rs:147-169)", gerr);
+    return SS_OK;
+}
+
+ss_status ss_result_counts(const ss_result* r, uint64_t* nv, uint64_t* nt) {
+    if (!r || !r->valid) return SS_ERR_INVALID_ARGUMENT;
+    if (nv) *nv = r->n_vertices;
+    if (nt) *nt = r->n_triangles;
+    return SS_OK;
+}
+
+ss_status ss_result_vertices(ss_result* r, const float** xyz, uint64_t* n) {
+    if (!r || !r->valid || !xyz || !n) return SS_ERR_INVALID_ARGUMENT;
+    *n = r->n_vertices;
+    return download<float>(r, r->vertices, r->h_vertices, r->hv, (size_t)r->n_vertices * 3, xyz);
+}
+
+ss_status ss_result_triangles_u32(ss_result* r, const uint32_t** idx, uint64_t* m) {
+    if (!r || !r->valid || !idx || !m) return SS_ERR_INVALID_ARGUMENT;
+    *m = r->n_triangles;
+    return download<uint32_t>(r, r->tri32, r->h_tri32, r->ht32, (size_t)r->n_triangles * 3, idx);
+}
+
+ss_status ss_result_triangles(ss_result* r, const uint64_t** idx, uint64_t* m) {
+    if (!r || !r->valid || !idx || !m) return SS_ERR_INVALID_ARGUMENT;
+    ss_context* c = r->ctx;
+    *m = r->n_triangles;
+    if (!r->ht64) {
+        // widen on the device (HBM bandwidth) rather than on the host
+        const size_t cnt = (size_t)r->n_triangles * 3;
+        SS_HIP(c, hipSetDevice(c->device));
+        SS_HIP(c, r->tri64.reserve(cnt * 8 + 16));
+        ss_launch_widen(r->tri32.as<uint32_t>(), cnt, r->tri64.as<unsigned long long>(), c->stream);
+    }
+    const unsigned long long* p = nullptr;
+    ss_status s = download<unsigned long long>(r, r->tri64, r->h_tri64, r->ht64, (size_t)r->n_triangles * 3, &p);
+    *idx = reinterpret_cast<const uint64_t*>(p);
+    return s;
+}
+
+ss_status ss_result_vertex_keys(ss_result* r, const uint64_t** keys, uint64_t* n) {
+    if (!r || !r->valid || !keys || !n) return SS_ERR_INVALID_ARGUMENT;
+    *n = r->n_vertices;
+    const unsigned long long* p = nullptr;
+    ss_status s = download<unsigned long long>(r, r->vkeys, r->h_vkeys, r->hkeys, (size_t)r->n_vertices, &p);
+    *keys = reinterpret_cast<const uint64_t*>(p);
+    return s;
+}
+
+ss_status ss_result_grid(const ss_result* r, ss_grid_f32* out) {
+    if (!r || !r->valid || !out) return SS_ERR_INVALID_ARGUMENT;
+    *out = r->grid;
+    return SS_OK;
+}
+
+ss_status ss_result_subdomain_grid(const ss_result* r, ss_grid_f32* out, int32_t* present) {
+    if (!r || !r->valid || !out || !present) return SS_ERR_INVALID_ARGUMENT;
+    *out = r->subgrid;
+    *present = 1;
+    return SS_OK;
+}
+
+ss_status ss_result_particle_densities(ss_result* r, const float** rho, uint64_t* n) {
+    if (!r || !r->valid || !rho || !n) return SS_ERR_INVALID_ARGUMENT;
+    *n = r->n_particles;
+    return download<float>(r, r->rho, r->h_rho, r->hrho, (size_t)r->n_particles, rho);
+}
+
+ss_status ss_result_particle_inside_aabb(ss_result* r, const uint8_t** flags, uint64_t* n) {
+    if (!r || !r->valid || !flags || !n) return SS_ERR_INVALID_ARGUMENT;
+    if (!r->has_inside) {
+        *flags = nullptr;
+        *n = 0;
+        return SS_OK;
+    }
+    *n = r->n_input;
+    if (r->n_input == 0) {
+        static const uint8_t dummy = 0;
+        *flags = &dummy;
+        return SS_OK;
+    }
+    return download<uint8_t>(r, r->inside8, r->h_inside, r->hinside, (size_t)r->n_input, flags);
+}
+
+ss_status ss_result_stats(const ss_result* r, ss_stats* out) {
+    if (!r || !r->valid || !out) return SS_ERR_INVALID_ARGUMENT;
+    *out = r->stats;
+    return SS_OK;
+}
+
+ss_status ss_result_device_vertices(const ss_result* r, const float** d, uint64_t* n) {
+    if (!r || !r->valid || !d || !n) return SS_ERR_INVALID_ARGUMENT;
+    *d = r->vertices.as<float>();
+    *n = r->n_vertices;
+    return SS_OK;
+}
+ss_status ss_result_device_triangles_u32(const ss_result* r, const uint32_t** d, uint64_t* n) {
+    if (!r || !r->valid || !d || !n) return SS_ERR_INVALID_ARGUMENT;
+    *d = r->tri32.as<uint32_t>();
+    *n = r->n_triangles;
+    return SS_OK;
+}
+ss_status ss_result_device_particle_densities(const ss_result* r, const float** d, uint64_t* n) {
+    if (!r || !r->valid || !d || !n) return SS_ERR_INVALID_ARGUMENT;
+    *d = r->rho.as<float>();
+    *n = r->n_particles;
+    return SS_OK;
+}
+
+ss_status ss_result_levelset_box(ss_result* r, const int64_t lo[3], const int64_t extent[3], float* out) {
+    if (!r || !r->valid || !lo || !extent || !out) return SS_ERR_INVALID_ARGUMENT;
+    ss_context* c = r->ctx;
+    for (int d = 0; d < 3; ++d)
+        if (extent[d] < 0 || extent[d] > 4096 || lo[d] < -2000000000ll || lo[d] > 2000000000ll) return fail(c, SS_ERR_INVALID_ARGUMENT, "box out of range");
+    const size_t tot = (size_t)extent[0] * extent[1] * extent[2];
+    if (!tot) return SS_OK;
+    SS_HIP(c, hipSetDevice(c->device));
+    DevBuf tmp;
+    SS_HIP(c, tmp.reserve(tot * 4));
+    const int l[3] = {(int)lo[0], (int)lo[1], (int)lo[2]}, e[3] = {(int)extent[0], (int)extent[1], (int)extent[2]};
+    if (r->n_active == 0) {
+        SS_HIP(c, hipMemsetAsync(tmp.p, 0, tot * 4, c->stream));
+    } else {
+        ss_launch_levelset_box(r->P, r->G.as<float>(), r->block_slot.as<uint32_t>(), l, e, tmp.as<float>(), c->stream);
+    }
+    SS_HIP(c, hipMemcpyAsync(out, tmp.p, tot * 4, hipMemcpyDeviceToHost, c->stream));
+    SS_HIP(c, hipStreamSynchronize(c->stream));
+    tmp.release();
+    return SS_OK;
+}
+
+ss_status ss_result_subdomain_stats(ss_result* r, uint64_t* n_occupied, uint64_t* n_sub_particles) {
+    if (!r || !r->valid || !n_occupied || !n_sub_particles) return SS_ERR_INVALID_ARGUMENT;
+    ss_context* c = r->ctx;
+    *n_occupied = 0;
+    *n_sub_particles = 0;
+    const size_t nsub = (size_t)r->P.ns[0] * r->P.ns[1] * r->P.ns[2];
+    if (!nsub || !r->n_particles) return SS_OK;
+    SS_HIP(c, hipSetDevice(c->device));
+    DevBuf tmp;
+    SS_HIP(c, tmp.reserve(nsub * 4));
+    SS_HIP(c, hipMemsetAsync(tmp.p, 0, nsub * 4, c->stream));
+    ss_launch_subdomain_counts(r->P, r->posvol.as<float4>(), tmp.as<uint32_t>(), c->stream);
+    std::vector<uint32_t> h(nsub);
+    SS_HIP(c, hipMemcpyAsync(h.data(), tmp.p, nsub * 4, hipMemcpyDeviceToHost, c->stream));
+    SS_HIP(c, hipStreamSynchronize(c->stream));
+    tmp.release();
+    uint64_t occ = 0, sum = 0;
+    for (size_t i = 0; i < nsub; ++i) {
+        occ += h[i] ? 1 : 0;
+        sum += h[i];
+    }
+    *n_occupied = occ;
+    *n_sub_particles = sum;
+    return SS_OK;
+}
+
+}  // extern "C"

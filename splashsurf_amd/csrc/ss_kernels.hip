@@ -1,0 +1,887 @@
+// ss_kernels.hip -- hand-written gfx950 (CDNA4, wave64) kernels of the surface-reconstruction path.
+//
+// Stage map (reference function -> kernel), citations relative to /root/reference/splashsurf_lib/src/:
+//   K0  aabb.rs:28-52 (par_from_points)                                   -> k_aabb_partial/k_aabb_final
+//   K0b lib.rs:369-406 (particle AABB filter)                             -> k_inside_flags/k_compact_xyz
+//   K1  dense_subdomains.rs:349-494 (decomposition) + neighborhood_search.rs:679-710 (cell map)
+//                                                                        -> k_cell_keys (+ rocPRIM sort), k_gather_sorted
+//   K2  neighborhood_search.rs:345-438 + density_map.rs:150-186          -> k_density
+//   K3  dense_subdomains.rs:784-847 (density_grid_loop_scalar)            -> k_mark_blocks, k_splat
+//   K4  dense_subdomains.rs:1470-1553 (triangulate_cell) classification   -> k_mc_count
+//   K5  same, vertex/triangle emission + dense_subdomains.rs:1603-1749    -> k_mc_emit
+//
+// Design: particles are sorted once by search cell (edge h, stable => ascending
+// original index inside a cell).  Every grid point / cell / edge is owned by exactly one thread which
+// GATHERS its contributions in ascending original particle index -- the summation order of the
+// reference (sorted per-subdomain particle lists, dense_subdomains.rs:476-488) -- so level-set values
+// are bit-identical to the reference's scalar path, independent of subdomain or GPU boundaries, with
+// no float atomics anywhere.
+#include "ss_device.h"
+#include "ss_kernels.h"
+
+// MC table in emitted (winding-flipped) order, see tools/gen_mc_table.py
+__constant__ int8_t c_mc_table[256][16] = {
+#include "mc_table.inc"
+};
+// uniform_grid.rs:825-834
+__constant__ int8_t c_corner[8][3] = {{0, 0, 0}, {1, 0, 0}, {1, 1, 0}, {0, 1, 0}, {0, 0, 1}, {1, 0, 1}, {1, 1, 1}, {0, 1, 1}};
+// uniform_grid.rs:856-869: local edge -> (origin corner, axis)
+__constant__ int8_t c_edge[12][2] = {{0, 0}, {1, 1}, {3, 0}, {0, 1}, {4, 0}, {5, 1}, {7, 0}, {4, 1}, {0, 2}, {1, 2}, {2, 2}, {3, 2}};
+
+// =====================================================================================================
+// K0: bounding box
+// =====================================================================================================
+__global__ __launch_bounds__(256) void k_aabb_partial(const float* __restrict__ xyz, uint32_t n, float* __restrict__ partial) {
+    __shared__ float s_min[3][256];
+    __shared__ float s_max[3][256];
+    float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        for (int d = 0; d < 3; ++d) {
+            float v = xyz[3 * (size_t)i + d];
+            mn[d] = fminf(mn[d], v);
+            mx[d] = fmaxf(mx[d], v);
+        }
+    }
+    for (int d = 0; d < 3; ++d) {
+        s_min[d][threadIdx.x] = mn[d];
+        s_max[d][threadIdx.x] = mx[d];
+    }
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s)
+            for (int d = 0; d < 3; ++d) {
+                s_min[d][threadIdx.x] = fminf(s_min[d][threadIdx.x], s_min[d][threadIdx.x + s]);
+                s_max[d][threadIdx.x] = fmaxf(s_max[d][threadIdx.x], s_max[d][threadIdx.x + s]);
+            }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0)
+        for (int d = 0; d < 3; ++d) {
+            partial[blockIdx.x * 6 + d] = s_min[d][0];
+            partial[blockIdx.x * 6 + 3 + d] = s_max[d][0];
+        }
+}
+
+__global__ __launch_bounds__(256) void k_aabb_final(const float* __restrict__ partial, uint32_t nblocks, float* __restrict__ out6) {
+    __shared__ float s_min[3][256];
+    __shared__ float s_max[3][256];
+    float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (uint32_t i = threadIdx.x; i < nblocks; i += blockDim.x)
+        for (int d = 0; d < 3; ++d) {
+            mn[d] = fminf(mn[d], partial[i * 6 + d]);
+            mx[d] = fmaxf(mx[d], partial[i * 6 + 3 + d]);
+        }
+    for (int d = 0; d < 3; ++d) {
+        s_min[d][threadIdx.x] = mn[d];
+        s_max[d][threadIdx.x] = mx[d];
+    }
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s)
+            for (int d = 0; d < 3; ++d) {
+                s_min[d][threadIdx.x] = fminf(s_min[d][threadIdx.x], s_min[d][threadIdx.x + s]);
+                s_max[d][threadIdx.x] = fmaxf(s_max[d][threadIdx.x], s_max[d][threadIdx.x + s]);
+            }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0)
+        for (int d = 0; d < 3; ++d) {
+            out6[d] = s_min[d][0];
+            out6[3 + d] = s_max[d][0];
+        }
+}
+
+void ss_launch_aabb(const float* d_xyz, uint32_t n, float* d_partial, float* d_out6, hipStream_t st) {
+    uint32_t blocks = (n + 255) / 256;
+    if (blocks > 1024) blocks = 1024;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(k_aabb_partial, dim3(blocks), dim3(256), 0, st, d_xyz, n, d_partial);
+    hipLaunchKernelGGL(k_aabb_final, dim3(1), dim3(256), 0, st, d_partial, blocks, d_out6);
+}
+
+// =====================================================================================================
+// K0b: particle AABB filter (lib.rs:369-406; half-open test aabb.rs:220-222)
+// =====================================================================================================
+__global__ __launch_bounds__(256) void k_inside_flags(const float* __restrict__ xyz, uint32_t n, float3 amin, float3 amax,
+                                                      uint8_t* __restrict__ flags8, uint32_t* __restrict__ flags32) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float x = xyz[3 * (size_t)i], y = xyz[3 * (size_t)i + 1], z = xyz[3 * (size_t)i + 2];
+    bool in = x >= amin.x && y >= amin.y && z >= amin.z && x < amax.x && y < amax.y && z < amax.z;
+    flags8[i] = in ? 1 : 0;
+    flags32[i] = in ? 1u : 0u;
+}
+
+__global__ __launch_bounds__(256) void k_compact_xyz(const float* __restrict__ xyz, uint32_t n, const uint32_t* __restrict__ flags32,
+                                                     const uint32_t* __restrict__ offsets, float* __restrict__ out) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n || !flags32[i]) return;
+    size_t o = offsets[i];
+    out[3 * o] = xyz[3 * (size_t)i];
+    out[3 * o + 1] = xyz[3 * (size_t)i + 1];
+    out[3 * o + 2] = xyz[3 * (size_t)i + 2];
+}
+
+void ss_launch_inside_flags(const float* d_xyz, uint32_t n, const float amin[3], const float amax[3], uint8_t* f8, uint32_t* f32, hipStream_t st) {
+    if (!n) return;
+    hipLaunchKernelGGL(k_inside_flags, dim3((n + 255) / 256), dim3(256), 0, st, d_xyz, n, make_float3(amin[0], amin[1], amin[2]),
+                       make_float3(amax[0], amax[1], amax[2]), f8, f32);
+}
+void ss_launch_compact_xyz(const float* d_xyz, uint32_t n, const uint32_t* f32, const uint32_t* offs, float* out, hipStream_t st) {
+    if (!n) return;
+    hipLaunchKernelGGL(k_compact_xyz, dim3((n + 255) / 256), dim3(256), 0, st, d_xyz, n, f32, offs, out);
+}
+
+// =====================================================================================================
+// K1: search-cell keys.  A particle is filed under the cell it has in the search grid of the
+// subdomain that CONTAINS it (= the subdomain computing its density, dense_subdomains.rs:567-614).
+// =====================================================================================================
+__device__ inline void ss_particle_cell(const SSDev& P, float x, float y, float z, int K[3]) {
+    float p[3] = {x, y, z};
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        int s = ss_container_subdomain_axis(P, p[d], d);
+        int k = ss_search_cell_axis(P, s, p[d], d, nullptr);
+        // clamp into the dense cell array (cannot trigger for particles inside the grid; keeps indexing safe)
+        k = max(P.kmin[d], min(P.kmin[d] + P.kdim[d] - 1, k));
+        K[d] = k;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_cell_keys(SSDev P, const float* __restrict__ xyz, uint32_t* __restrict__ keys,
+                                                   uint32_t* __restrict__ vals, uint32_t* __restrict__ cell_count) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P.n) return;
+    int K[3];
+    ss_particle_cell(P, xyz[3 * (size_t)i], xyz[3 * (size_t)i + 1], xyz[3 * (size_t)i + 2], K);
+    uint32_t key = ss_cell_key(P, K[0], K[1], K[2]);
+    keys[i] = key;
+    vals[i] = i;
+    atomicAdd(&cell_count[key], 1u);
+}
+
+__global__ __launch_bounds__(256) void k_gather_sorted(uint32_t n, const float* __restrict__ xyz, const uint32_t* __restrict__ perm,
+                                                       float4* __restrict__ pos_sorted) {
+    uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    size_t i = perm[p];
+    pos_sorted[p] = make_float4(xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2], 0.0f);
+}
+
+void ss_launch_cell_keys(const SSDev& P, const float* d_xyz, uint32_t* keys, uint32_t* vals, uint32_t* cell_count, hipStream_t st) {
+    if (!P.n) return;
+    hipLaunchKernelGGL(k_cell_keys, dim3((P.n + 255) / 256), dim3(256), 0, st, P, d_xyz, keys, vals, cell_count);
+}
+void ss_launch_gather_sorted(uint32_t n, const float* d_xyz, const uint32_t* perm, float4* pos_sorted, hipStream_t st) {
+    if (!n) return;
+    hipLaunchKernelGGL(k_gather_sorted, dim3((n + 255) / 256), dim3(256), 0, st, n, d_xyz, perm, pos_sorted);
+}
+
+// =====================================================================================================
+// K2: per-particle SPH density.  rho_i = m * (W(0) + sum_j W(|x_j - x_i|)), neighbours visited in the
+// reference's order: the 26 adjacent search cells in (x,y,z)-lexicographic order of the step, then the
+// own cell (uniform_grid.rs:614-643, neighborhood_search.rs:400-405); ascending original index inside
+// a cell (neighborhood_search.rs:692-707).  One thread per particle (sorted order => lanes of a wave
+// share cells and their loads coalesce / hit L1).
+// =====================================================================================================
+__global__ __launch_bounds__(256) void k_density(SSDev P, const float4* __restrict__ pos_sorted, const uint32_t* __restrict__ perm,
+                                                 const uint32_t* __restrict__ cell_start, float* __restrict__ rho,
+                                                 float4* __restrict__ posvol_sorted) {
+    uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= P.n) return;
+    const float4 pi = pos_sorted[p];
+    int K[3];
+    ss_particle_cell(P, pi.x, pi.y, pi.z, K);
+    float acc = P.w0;  // density_map.rs:173
+    for (int pass = 0; pass < 2; ++pass) {
+        for (int sx = -1; sx <= 1; ++sx)
+            for (int sy = -1; sy <= 1; ++sy)
+                for (int sz = -1; sz <= 1; ++sz) {
+                    const bool center = (sx == 0 && sy == 0 && sz == 0);
+                    if ((pass == 0) == center) continue;
+                    const int kx = K[0] + sx, ky = K[1] + sy, kz = K[2] + sz;
+                    if (!ss_cell_in_range(P, kx, ky, kz)) continue;
+                    const uint32_t key = ss_cell_key(P, kx, ky, kz);
+                    const uint32_t qb = cell_start[key], qe = cell_start[key + 1];
+                    for (uint32_t q = qb; q < qe; ++q) {
+                        const float4 pj = pos_sorted[q];
+                        const float dx = pj.x - pi.x, dy = pj.y - pi.y, dz = pj.z - pi.z;
+                        const float d2 = dx * dx + dy * dy + dz * dz;
+                        if (q != p && d2 < P.h2) {  // neighborhood_search.rs:431
+                            const float r = sqrtf(d2);
+                            acc += ss_kernel_evaluate(r, P.h, P.sigma);  // density_map.rs:179-180
+                        }
+                    }
+                }
+    }
+    const float density = acc * P.mass;  // density_map.rs:182
+    rho[perm[p]] = density;
+    posvol_sorted[p] = make_float4(pi.x, pi.y, pi.z, P.mass / density);  // v_i, dense_subdomains.rs:832
+}
+
+void ss_launch_density(const SSDev& P, const float4* pos_sorted, const uint32_t* perm, const uint32_t* cell_start, float* rho,
+                       float4* posvol_sorted, hipStream_t st) {
+    if (!P.n) return;
+    hipLaunchKernelGGL(k_density, dim3((P.n + 255) / 256), dim3(256), 0, st, P, pos_sorted, perm, cell_start, rho, posvol_sorted);
+}
+
+// =====================================================================================================
+// K3 prepare: which 8^3-point level-set blocks can receive a contribution?  One thread per search cell;
+// a non-empty cell marks every block whose points lie within `reach` of the cell's box.
+// =====================================================================================================
+__global__ __launch_bounds__(256) void k_mark_blocks(SSDev P, const uint32_t* __restrict__ cell_start, uint32_t ncells,
+                                                     uint32_t* __restrict__ block_flag) {
+    uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= ncells) return;
+    if (cell_start[c + 1] == cell_start[c]) return;
+    int k[3];
+    k[2] = (int)(c % (uint32_t)P.kdim[2]);
+    k[1] = (int)((c / (uint32_t)P.kdim[2]) % (uint32_t)P.kdim[1]);
+    k[0] = (int)(c / ((uint32_t)P.kdim[2] * (uint32_t)P.kdim[1]));
+    int blo[3], bhi[3];
+    for (int d = 0; d < 3; ++d) {
+        // nominal cell box [K h, (K+1) h] widened by the particle reach, f32 slack and 1e-3 h for
+        // particles filed one cell off their nominal cell by rounding
+        const double K = (double)(k[d] + P.kmin[d]);
+        const double pad = (double)P.reach + (double)P.coord_slack + 1e-3 * (double)P.h;
+        const double lo = K * (double)P.h - pad, hi = (K + 1.0) * (double)P.h + pad;
+        long long i_lo = (long long)floor((lo - (double)P.gmin[d]) / (double)P.cs);      // conservative: one point early
+        long long i_hi = (long long)ceil((hi - (double)P.gmin[d]) / (double)P.cs);       // conservative: one point late
+        if (i_lo < 0) i_lo = 0;
+        if (i_hi > P.np[d] - 1) i_hi = P.np[d] - 1;
+        if (i_lo > i_hi) return;
+        blo[d] = (int)(i_lo / SS_BLOCK);
+        bhi[d] = (int)(i_hi / SS_BLOCK);
+    }
+    for (int bx = blo[0]; bx <= bhi[0]; ++bx)
+        for (int by = blo[1]; by <= bhi[1]; ++by)
+            for (int bz = blo[2]; bz <= bhi[2]; ++bz) block_flag[((size_t)bx * P.nb[1] + by) * P.nb[2] + bz] = 1u;
+}
+
+// MC works on blocks of cells whose origin point lies in block b; it reads the points of blocks b+{0,1}^3
+__global__ __launch_bounds__(256) void k_mark_mc_blocks(SSDev P, const uint32_t* __restrict__ block_flag, uint32_t nblocks,
+                                                        uint32_t* __restrict__ mc_flag) {
+    uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= nblocks) return;
+    int bz = (int)(b % (uint32_t)P.nb[2]);
+    int by = (int)((b / (uint32_t)P.nb[2]) % (uint32_t)P.nb[1]);
+    int bx = (int)(b / ((uint32_t)P.nb[2] * (uint32_t)P.nb[1]));
+    uint32_t f = 0;
+    for (int dx = 0; dx <= 1; ++dx)
+        for (int dy = 0; dy <= 1; ++dy)
+            for (int dz = 0; dz <= 1; ++dz) {
+                int x = bx + dx, y = by + dy, z = bz + dz;
+                if (x < P.nb[0] && y < P.nb[1] && z < P.nb[2]) f |= block_flag[((size_t)x * P.nb[1] + y) * P.nb[2] + z];
+            }
+    mc_flag[b] = f ? 1u : 0u;
+}
+
+__global__ __launch_bounds__(256) void k_compact_blocks(const uint32_t* __restrict__ flag, const uint32_t* __restrict__ rank, uint32_t nblocks,
+                                                        uint32_t* __restrict__ list, uint32_t* __restrict__ slot) {
+    uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= nblocks) return;
+    if (flag[b]) {
+        uint32_t r = rank[b];
+        list[r] = b;
+        slot[b] = r;
+    } else {
+        slot[b] = 0xFFFFFFFFu;
+    }
+}
+
+void ss_launch_mark_blocks(const SSDev& P, const uint32_t* cell_start, uint32_t ncells, uint32_t* block_flag, hipStream_t st) {
+    if (!ncells) return;
+    hipLaunchKernelGGL(k_mark_blocks, dim3((ncells + 255) / 256), dim3(256), 0, st, P, cell_start, ncells, block_flag);
+}
+void ss_launch_mark_mc_blocks(const SSDev& P, const uint32_t* block_flag, uint32_t nblocks, uint32_t* mc_flag, hipStream_t st) {
+    if (!nblocks) return;
+    hipLaunchKernelGGL(k_mark_mc_blocks, dim3((nblocks + 255) / 256), dim3(256), 0, st, P, block_flag, nblocks, mc_flag);
+}
+void ss_launch_compact_blocks(const uint32_t* flag, const uint32_t* rank, uint32_t nblocks, uint32_t* list, uint32_t* slot, hipStream_t st) {
+    if (!nblocks) return;
+    hipLaunchKernelGGL(k_compact_blocks, dim3((nblocks + 255) / 256), dim3(256), 0, st, flag, rank, nblocks, list, slot);
+}
+
+// =====================================================================================================
+// K3: level-set splat in gather form.
+//
+// One 512-thread workgroup (8 waves) per active block of 8x8x8 grid points; wave w owns the 4x4x4
+// sub-block (w>>2, (w>>1)&1, w&1), lane l the point ((l>>4)&3, (l>>2)&3, l&3) of it.
+//   1. gather: the particles inside the block's box dilated by the kernel reach are collected from the
+//      cell-sorted array ((x,y) rows of search cells are contiguous runs) into LDS as (original index,
+//      sorted position) pairs;
+//   2. order: the tile is sorted by ORIGINAL particle index (rank sort for small tiles, bitonic
+//      network otherwise) and the payload (x,y,z,V) loaded in that order -- this reproduces the
+//      reference's per-point summation order;
+//   3. accumulate: per wave, phase A tests 64 tile entries at once against the wave's sub-block box
+//      (ballot), phase B walks the surviving entries in order; every lane evaluates
+//      G += V * W(|x - p|) for its point iff d^2 < 1.01 h^2 (dense_subdomains.rs:828-841).
+// Tiles larger than SS_TILE_CAP are processed in several passes over ascending index ranges
+// (threshold found by bisection), which keeps the summation order exact for arbitrarily dense input.
+// =====================================================================================================
+struct SplatShared {
+    float4 pay[SS_TILE_CAP];
+    uint32_t idx[SS_TILE_CAP];
+    uint32_t src[SS_TILE_CAP];
+    uint32_t row_start[SS_MAX_ROWS];
+    uint32_t row_prefix[SS_MAX_ROWS + 1];
+    uint32_t wave_tot[8];
+    uint32_t count;
+};
+
+// exclusive prefix over s.row_prefix[0..nbatch) (lengths in, prefix out), total in row_prefix[nbatch]
+__device__ inline void splat_row_prefix(SplatShared& s, int nbatch, uint32_t len, int tid) {
+    // tid < 256 participate (4 waves); len is this thread's row length (0 beyond nbatch)
+    const int lane = tid & 63, wave = tid >> 6;
+    uint32_t v = len;
+    if (tid < SS_MAX_ROWS) {
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            uint32_t t = __shfl_up(v, off);
+            if (lane >= off) v += t;
+        }
+        if (lane == 63) s.wave_tot[wave] = v;
+    }
+    __syncthreads();
+    if (tid < SS_MAX_ROWS) {
+        uint32_t base = 0;
+        for (int w = 0; w < wave; ++w) base += s.wave_tot[w];
+        s.row_prefix[tid] = base + v - len;
+        if (tid == nbatch - 1) s.row_prefix[nbatch] = base + v;
+    }
+    __syncthreads();
+}
+
+// Visit every particle of the search cells overlapping the dilated block box; f(src_position, idx) is
+// called for particles inside the box.  All 512 threads must call this (contains barriers).
+template <class F>
+__device__ inline void splat_for_each_candidate(SplatShared& s, const SSDev& P, const float4* __restrict__ posvol,
+                                                const uint32_t* __restrict__ perm, const uint32_t* __restrict__ cell_start,
+                                                const int klo[3], const int khi[3], const float blo[3], const float bhi[3], int tid, F f) {
+    const int ny = khi[1] - klo[1] + 1;
+    const int nrows = (khi[0] - klo[0] + 1) * ny;
+    for (int row_base = 0; row_base < nrows; row_base += SS_MAX_ROWS) {
+        const int nbatch = min(SS_MAX_ROWS, nrows - row_base);
+        uint32_t len = 0;
+        if (tid < nbatch) {
+            const int r = row_base + tid;
+            const int kx = klo[0] + r / ny, ky = klo[1] + r % ny;
+            const uint32_t key_lo = ss_cell_key(P, kx, ky, klo[2]);
+            const uint32_t key_hi = ss_cell_key(P, kx, ky, khi[2]);
+            const uint32_t b = cell_start[key_lo], e = cell_start[key_hi + 1];
+            s.row_start[tid] = b;
+            len = e - b;
+        }
+        __syncthreads();
+        splat_row_prefix(s, nbatch, len, tid);
+        const uint32_t total = s.row_prefix[nbatch];
+        for (uint32_t q = tid; q < total; q += 512) {
+            // binary search: last row r with row_prefix[r] <= q
+            int lo = 0, hi = nbatch - 1;
+            while (lo < hi) {
+                int mid = (lo + hi + 1) >> 1;
+                if (s.row_prefix[mid] <= q)
+                    lo = mid;
+                else
+                    hi = mid - 1;
+            }
+            const uint32_t src = s.row_start[lo] + (q - s.row_prefix[lo]);
+            const float4 pv = posvol[src];
+            if (pv.x >= blo[0] && pv.x <= bhi[0] && pv.y >= blo[1] && pv.y <= bhi[1] && pv.z >= blo[2] && pv.z <= bhi[2]) f(src, perm[src]);
+        }
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(512) void k_splat(SSDev P, const float4* __restrict__ posvol, const uint32_t* __restrict__ perm,
+                                               const uint32_t* __restrict__ cell_start, const uint32_t* __restrict__ active_list,
+                                               uint32_t n_active, float* __restrict__ G, unsigned long long* __restrict__ cand_counter) {
+    __shared__ SplatShared s;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+
+    // XCD-aware mapping: hardware places workgroup w on XCD w % 8; give each XCD a contiguous range of
+    // the (spatially ordered) active list so that neighbouring blocks share an L2.
+    const uint32_t per_xcd = (n_active + 7u) / 8u;
+    const uint32_t logical = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
+    if ((blockIdx.x >> 3) >= per_xcd || logical >= n_active) return;
+    const uint32_t b = active_list[logical];
+    const int bz = (int)(b % (uint32_t)P.nb[2]);
+    const int by = (int)((b / (uint32_t)P.nb[2]) % (uint32_t)P.nb[1]);
+    const int bx = (int)(b / ((uint32_t)P.nb[2] * (uint32_t)P.nb[1]));
+    const int b3[3] = {bx, by, bz};
+
+    // dilated block box and the search cells overlapping it
+    float blo[3], bhi[3];
+    int klo[3], khi[3];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        const int i0 = b3[d] * SS_BLOCK;
+        const int i1 = min(i0 + SS_BLOCK - 1, P.np[d] - 1);
+        const float pad = P.reach + P.coord_slack;
+        blo[d] = (P.gmin[d] + (float)i0 * P.cs) - pad;
+        bhi[d] = (P.gmin[d] + (float)i1 * P.cs) + pad;
+        const double cellpad = 1e-3 * (double)P.h;
+        int a = (int)floor(((double)blo[d] - cellpad) / (double)P.h);
+        int e = (int)floor(((double)bhi[d] + cellpad) / (double)P.h);
+        klo[d] = max(a, P.kmin[d]);
+        khi[d] = min(e, P.kmin[d] + P.kdim[d] - 1);
+    }
+    const bool any_cells = klo[0] <= khi[0] && klo[1] <= khi[1] && klo[2] <= khi[2];
+
+    // this wave's sub-block and this lane's grid point
+    const int g0[3] = {bx * SS_BLOCK + ((wave >> 2) & 1) * 4, by * SS_BLOCK + ((wave >> 1) & 1) * 4, bz * SS_BLOCK + (wave & 1) * 4};
+    const int gl[3] = {g0[0] + ((lane >> 4) & 3), g0[1] + ((lane >> 2) & 3), g0[2] + (lane & 3)};
+    const bool wave_valid = g0[0] < P.np[0] && g0[1] < P.np[1] && g0[2] < P.np[2];
+    // global point coordinates: uniform_grid.rs:418-425 on the GLOBAL grid (dense_subdomains.rs:817-826)
+    const float px = P.gmin[0] + (float)gl[0] * P.cs;
+    const float py = P.gmin[1] + (float)gl[1] * P.cs;
+    const float pz = P.gmin[2] + (float)gl[2] * P.cs;
+    float slo[3], shi[3];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        slo[d] = P.gmin[d] + (float)g0[d] * P.cs;
+        shi[d] = P.gmin[d] + (float)min(g0[d] + 3, P.np[d] - 1) * P.cs;
+    }
+    const float wave_r2 = P.H2 * 1.0001f;
+
+    float acc = 0.0f;  // levelset_grid.fill(0), dense_subdomains.rs:1390
+    long long last = -1;  // particles with original index <= last are already accumulated
+    const long long idx_max = (long long)P.n - 1;
+
+    while (any_cells) {
+        long long T = idx_max;
+        if (tid == 0) s.count = 0;
+        __syncthreads();
+        splat_for_each_candidate(s, P, posvol, perm, cell_start, klo, khi, blo, bhi, tid, [&](uint32_t src, uint32_t idx) {
+            if ((long long)idx > last) {
+                uint32_t pos = atomicAdd(&s.count, 1u);
+                if (pos < SS_TILE_CAP) {
+                    s.idx[pos] = idx;
+                    s.src[pos] = src;
+                }
+            }
+        });
+        uint32_t total = s.count;
+        if (total == 0) break;
+        if (total > SS_TILE_CAP) {
+            // more candidates than LDS slots: find the largest threshold T with
+            // #{last < idx <= T} <= SS_TILE_CAP by bisection (count is monotone in T and grows by
+            // at most one per step, so the bracket closes on exactly SS_TILE_CAP entries)
+            long long lo = last, hi = idx_max;
+            while (hi - lo > 1) {
+                const long long mid = lo + (hi - lo) / 2;
+                __syncthreads();
+                if (tid == 0) s.count = 0;
+                __syncthreads();
+                splat_for_each_candidate(s, P, posvol, perm, cell_start, klo, khi, blo, bhi, tid, [&](uint32_t, uint32_t idx) {
+                    if ((long long)idx > last && (long long)idx <= mid) atomicAdd(&s.count, 1u);
+                });
+                const uint32_t c = s.count;
+                if (c <= SS_TILE_CAP)
+                    lo = mid;
+                else
+                    hi = mid;
+            }
+            T = lo;
+            __syncthreads();
+            if (tid == 0) s.count = 0;
+            __syncthreads();
+            splat_for_each_candidate(s, P, posvol, perm, cell_start, klo, khi, blo, bhi, tid, [&](uint32_t src, uint32_t idx) {
+                if ((long long)idx > last && (long long)idx <= T) {
+                    uint32_t pos = atomicAdd(&s.count, 1u);
+                    if (pos < SS_TILE_CAP) {
+                        s.idx[pos] = idx;
+                        s.src[pos] = src;
+                    }
+                }
+            });
+            total = s.count;
+        }
+        const int n_tile = (int)min(total, (uint32_t)SS_TILE_CAP);
+        if (tid == 0) atomicAdd(cand_counter, (unsigned long long)n_tile);
+
+        // ---- order the tile by original particle index, load payload in that order ----
+        if (n_tile <= 512) {
+            // rank sort: indices are unique, rank = number of smaller indices
+            uint32_t my_idx = 0, my_src = 0, rank = 0;
+            if (tid < n_tile) {
+                my_idx = s.idx[tid];
+                my_src = s.src[tid];
+                for (int k = 0; k < n_tile; ++k) rank += (s.idx[k] < my_idx) ? 1u : 0u;
+                s.pay[rank] = posvol[my_src];
+            }
+        } else {
+            int m = 1024;
+            while (m < n_tile) m <<= 1;
+            for (int e = n_tile + tid; e < m; e += 512) {
+                s.idx[e] = 0xFFFFFFFFu;
+                s.src[e] = 0;
+            }
+            __syncthreads();
+            for (int k = 2; k <= m; k <<= 1)
+                for (int j = k >> 1; j > 0; j >>= 1) {
+                    for (int t = tid; t < (m >> 1); t += 512) {
+                        const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+                        const int l = i | j;
+                        const bool up = (i & k) == 0;
+                        const uint32_t a = s.idx[i], c = s.idx[l];
+                        if ((a > c) == up) {
+                            s.idx[i] = c;
+                            s.idx[l] = a;
+                            const uint32_t sa = s.src[i];
+                            s.src[i] = s.src[l];
+                            s.src[l] = sa;
+                        }
+                    }
+                    __syncthreads();
+                }
+            for (int e = tid; e < n_tile; e += 512) s.pay[e] = posvol[s.src[e]];
+        }
+        __syncthreads();
+
+        // ---- accumulate ----
+        if (wave_valid) {
+            for (int base = 0; base < n_tile; base += 64) {
+                const int c = base + lane;
+                bool pass = false;
+                if (c < n_tile) {
+                    const float4 pv = s.pay[c];
+                    const float ex = fmaxf(fmaxf(slo[0] - pv.x, pv.x - shi[0]) - P.coord_slack, 0.0f);
+                    const float ey = fmaxf(fmaxf(slo[1] - pv.y, pv.y - shi[1]) - P.coord_slack, 0.0f);
+                    const float ez = fmaxf(fmaxf(slo[2] - pv.z, pv.z - shi[2]) - P.coord_slack, 0.0f);
+                    pass = (ex * ex + ey * ey + ez * ez) <= wave_r2;
+                }
+                unsigned long long mask = __ballot(pass);
+                while (mask) {
+                    const int bit = __ffsll((long long)mask) - 1;
+                    mask &= mask - 1;
+                    const float4 pv = s.pay[base + bit];
+                    const float dx = pv.x - px, dy = pv.y - py, dz = pv.z - pz;  // p_i - point, :828
+                    const float d2 = dx * dx + dy * dy + dz * dz;
+                    if (d2 < P.H2) {  // :831
+                        const float r = sqrtf(d2);
+                        const float w = ss_kernel_evaluate(r, P.h, P.sigma);
+                        acc += pv.w * w;  // :837-841
+                    }
+                }
+            }
+        }
+        if (T >= idx_max) break;
+        last = T;
+        __syncthreads();
+    }
+
+    // store: block-local layout (x*8+y)*8+z, i-major / k-fastest like dense_subdomains.rs:839
+    const int lx = ((wave >> 2) & 1) * 4 + ((lane >> 4) & 3);
+    const int ly = ((wave >> 1) & 1) * 4 + ((lane >> 2) & 3);
+    const int lz = (wave & 1) * 4 + (lane & 3);
+    const bool point_valid = gl[0] < P.np[0] && gl[1] < P.np[1] && gl[2] < P.np[2];
+    G[(size_t)logical * SS_BLOCK_POINTS + (size_t)((lx * 8 + ly) * 8 + lz)] = point_valid ? acc : 0.0f;
+}
+
+void ss_launch_splat(const SSDev& P, const float4* posvol, const uint32_t* perm, const uint32_t* cell_start, const uint32_t* active_list,
+                     uint32_t n_active, float* G, unsigned long long* cand_counter, hipStream_t st) {
+    if (!n_active) return;
+    const uint32_t per_xcd = (n_active + 7u) / 8u;
+    hipLaunchKernelGGL(k_splat, dim3(per_xcd * 8u), dim3(512), 0, st, P, posvol, perm, cell_start, active_list, n_active, G, cand_counter);
+}
+
+// =====================================================================================================
+// K4/K5: marching cubes.  One 512-thread workgroup per MC block b: thread t <-> grid point
+// (t>>6, (t>>3)&7, t&7) of block b, owning the cell with that origin and the three edges leaving
+// it in +x/+y/+z.  The 9^3 points needed come from the level-set blocks b+{0,1}^3 (absent => 0).
+// A block's vertices are numbered axis-major; the per-axis crossing masks (one 64-bit ballot per wave)
+// are stored so that neighbouring blocks can compute vertex ids of shared edges without a hash map:
+//   id(point p, axis a) = vbase[block] + #crossings of axes < a + popcount(mask_a below p).
+// =====================================================================================================
+struct McTile {
+    float g[9 * 9 * 9];
+};
+
+__device__ inline void mc_load_tile(McTile& t, const SSDev& P, const float* __restrict__ G, const uint32_t* __restrict__ block_slot, int bx,
+                                    int by, int bz, int tid) {
+    for (int e = tid; e < 729; e += 512) {
+        const int x = e / 81, y = (e / 9) % 9, z = e % 9;
+        const int nbx = bx + (x >> 3), nby = by + (y >> 3), nbz = bz + (z >> 3);
+        float v = 0.0f;
+        if (nbx < P.nb[0] && nby < P.nb[1] && nbz < P.nb[2]) {
+            const uint32_t slot = block_slot[((size_t)nbx * P.nb[1] + nby) * P.nb[2] + nbz];
+            if (slot != 0xFFFFFFFFu) v = G[(size_t)slot * SS_BLOCK_POINTS + (size_t)((((x & 7) * 8) + (y & 7)) * 8 + (z & 7))];
+        }
+        t.g[e] = v;
+    }
+}
+
+// per-thread classification shared by the count and emit kernels
+struct McLocal {
+    int gx, gy, gz;       // global point index of this thread
+    bool cross[3];        // edge leaving the point along axis a crosses the iso-surface
+    int case_index;       // 0 if the cell does not exist
+    int ntri;
+};
+
+__device__ inline McLocal mc_classify(const McTile& t, const SSDev& P, int bx, int by, int bz, int tid) {
+    McLocal L;
+    const int lx = tid >> 6, ly = (tid >> 3) & 7, lz = tid & 7;
+    L.gx = bx * SS_BLOCK + lx;
+    L.gy = by * SS_BLOCK + ly;
+    L.gz = bz * SS_BLOCK + lz;
+    const bool point_exists = L.gx < P.np[0] && L.gy < P.np[1] && L.gz < P.np[2];
+    const float thr = P.threshold;
+    const bool in0 = t.g[(lx * 9 + ly) * 9 + lz] > thr;  // dense_subdomains.rs:1482 (strict >)
+    L.cross[0] = point_exists && (L.gx + 1 < P.np[0]) && (in0 != (t.g[((lx + 1) * 9 + ly) * 9 + lz] > thr));
+    L.cross[1] = point_exists && (L.gy + 1 < P.np[1]) && (in0 != (t.g[(lx * 9 + ly + 1) * 9 + lz] > thr));
+    L.cross[2] = point_exists && (L.gz + 1 < P.np[2]) && (in0 != (t.g[(lx * 9 + ly) * 9 + lz + 1] > thr));
+    L.case_index = 0;
+    const bool cell_exists = L.gx < P.nc[0] && L.gy < P.nc[1] && L.gz < P.nc[2];
+    if (cell_exists) {
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const float v = t.g[((lx + c_corner[c][0]) * 9 + ly + c_corner[c][1]) * 9 + lz + c_corner[c][2]];
+            L.case_index |= (v > thr ? 1 : 0) << c;  // marching_cubes_lut.rs:322-329
+        }
+    }
+    int nt = 0;
+#pragma unroll
+    for (int i = 0; i < 5; ++i) nt += (c_mc_table[L.case_index][3 * i] >= 0) ? 1 : 0;
+    L.ntri = nt;
+    return L;
+}
+
+__global__ __launch_bounds__(512) void k_mc_count(SSDev P, const float* __restrict__ G, const uint32_t* __restrict__ block_slot,
+                                                  const uint32_t* __restrict__ mc_list, uint32_t n_mc, unsigned long long* __restrict__ masks,
+                                                  uint32_t* __restrict__ vcount, uint32_t* __restrict__ tcount) {
+    __shared__ McTile tile;
+    __shared__ uint32_t s_v[8], s_t[8];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t m = blockIdx.x;
+    if (m >= n_mc) return;
+    const uint32_t b = mc_list[m];
+    const int bz = (int)(b % (uint32_t)P.nb[2]);
+    const int by = (int)((b / (uint32_t)P.nb[2]) % (uint32_t)P.nb[1]);
+    const int bx = (int)(b / ((uint32_t)P.nb[2] * (uint32_t)P.nb[1]));
+    mc_load_tile(tile, P, G, block_slot, bx, by, bz, tid);
+    __syncthreads();
+    const McLocal L = mc_classify(tile, P, bx, by, bz, tid);
+    uint32_t nv = 0;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const unsigned long long mk = __ballot(L.cross[a]);
+        if (lane == 0) masks[(size_t)m * 24 + a * 8 + wave] = mk;
+        nv += (uint32_t)__popcll(mk);
+    }
+    // triangles of this wave
+    uint32_t nt = (uint32_t)L.ntri;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) nt += __shfl_xor(nt, off);
+    if (lane == 0) {
+        s_v[wave] = nv;
+        s_t[wave] = nt;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        uint32_t v = 0, t = 0;
+        for (int w = 0; w < 8; ++w) {
+            v += s_v[w];
+            t += s_t[w];
+        }
+        vcount[m] = v;
+        tcount[m] = t;
+    }
+}
+
+__global__ __launch_bounds__(512) void k_mc_emit(SSDev P, const float* __restrict__ G, const uint32_t* __restrict__ block_slot,
+                                                 const uint32_t* __restrict__ mc_list, const uint32_t* __restrict__ mc_slot, uint32_t n_mc,
+                                                 const unsigned long long* __restrict__ masks, const uint32_t* __restrict__ vbase,
+                                                 const uint32_t* __restrict__ tbase, float* __restrict__ vertices,
+                                                 unsigned long long* __restrict__ vkeys, uint32_t* __restrict__ triangles) {
+    __shared__ McTile tile;
+    __shared__ unsigned long long s_mask[8][24];  // [neighbour][axis*8+word]
+    __shared__ uint32_t s_pref[8][24];            // vertices of that neighbour block before (axis, word)
+    __shared__ uint32_t s_vbase[8];
+    __shared__ uint32_t s_twave[8];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t m = blockIdx.x;
+    if (m >= n_mc) return;
+    const uint32_t b = mc_list[m];
+    const int bz = (int)(b % (uint32_t)P.nb[2]);
+    const int by = (int)((b / (uint32_t)P.nb[2]) % (uint32_t)P.nb[1]);
+    const int bx = (int)(b / ((uint32_t)P.nb[2] * (uint32_t)P.nb[1]));
+    mc_load_tile(tile, P, G, block_slot, bx, by, bz, tid);
+    // crossing masks of this block and its 7 upper neighbours
+    if (tid < 8 * 24) {
+        const int nb = tid / 24, w = tid % 24;
+        const int x = bx + ((nb >> 2) & 1), y = by + ((nb >> 1) & 1), z = bz + (nb & 1);
+        unsigned long long mk = 0;
+        uint32_t slot = 0xFFFFFFFFu;
+        if (x < P.nb[0] && y < P.nb[1] && z < P.nb[2]) slot = mc_slot[((size_t)x * P.nb[1] + y) * P.nb[2] + z];
+        if (slot != 0xFFFFFFFFu) mk = masks[(size_t)slot * 24 + w];
+        s_mask[nb][w] = mk;
+        if (w == 0) s_vbase[nb] = (slot != 0xFFFFFFFFu) ? vbase[slot] : 0u;
+    }
+    __syncthreads();
+    if (tid < 8) {
+        uint32_t run = 0;
+        for (int w = 0; w < 24; ++w) {
+            s_pref[tid][w] = run;
+            run += (uint32_t)__popcll(s_mask[tid][w]);
+        }
+    }
+    __syncthreads();
+    const McLocal L = mc_classify(tile, P, bx, by, bz, tid);
+
+    // ---- vertices on the three edges owned by this thread's point (dense_subdomains.rs:1498-1539) ----
+    const int lx = tid >> 6, ly = (tid >> 3) & 7, lz = tid & 7;
+    const int n = P.n_sub_cubes;
+    const int O[3] = {L.gx, L.gy, L.gz};
+    const unsigned long long below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        if (!L.cross[a]) continue;
+        const uint32_t vid = s_vbase[0] + s_pref[0][a * 8 + wave] + (uint32_t)__popcll(s_mask[0][a * 8 + wave] & below);
+        const int tl[3] = {lx + (a == 0), ly + (a == 1), lz + (a == 2)};
+        const float ov = tile.g[(lx * 9 + ly) * 9 + lz];
+        const float tv = tile.g[(tl[0] * 9 + tl[1]) * 9 + tl[2]];
+        const float alpha = (P.threshold - ov) / (tv - ov);  // :1516-1517
+        float vc[3];
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            // coordinates in the marching-cubes grid of the lowest-index subdomain that generates this
+            // vertex ("first patch wins" with patches in ascending flat subdomain index, :1707-1716):
+            // the subdomain of the adjacent cell O - delta, delta_d = 1 on the orthogonal axes where possible
+            int sd;
+            if (d == a)
+                sd = O[d] / n;
+            else
+                sd = (O[d] >= 1) ? (O[d] - 1) / n : 0;
+            const int loc = O[d] - sd * n;
+            const float sub_min = P.gmin[d] + (float)sd * P.sub_size;  // uniform_grid.rs:454-467 on the subdomain grid
+            const float oc = sub_min + (float)loc * P.cs;               // uniform_grid.rs:418-425 on the subdomain MC grid
+            const float tc = sub_min + (float)(loc + (d == a ? 1 : 0)) * P.cs;
+            vc[d] = oc * (1.0f - alpha) + tc * alpha;  // :1518-1519
+        }
+        vertices[3 * (size_t)vid] = vc[0];
+        vertices[3 * (size_t)vid + 1] = vc[1];
+        vertices[3 * (size_t)vid + 2] = vc[2];
+        vkeys[vid] = (((unsigned long long)O[0] * (unsigned long long)P.np[1] + (unsigned long long)O[1]) * (unsigned long long)P.np[2] +
+                      (unsigned long long)O[2]) * 3ull + (unsigned long long)a;
+    }
+
+    // ---- triangles of this thread's cell ----
+    uint32_t incl = (uint32_t)L.ntri;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        uint32_t t = __shfl_up(incl, off);
+        if (lane >= off) incl += t;
+    }
+    if (lane == 63) s_twave[wave] = incl;
+    __syncthreads();
+    uint32_t toff = tbase[m] + incl - (uint32_t)L.ntri;
+    for (int w = 0; w < wave; ++w) toff += s_twave[w];
+    for (int i = 0; i < L.ntri; ++i) {
+        uint32_t tri[3];
+#pragma unroll
+        for (int v = 0; v < 3; ++v) {
+            const int e = c_mc_table[L.case_index][3 * i + v];
+            const int oc = c_edge[e][0], a = c_edge[e][1];
+            const int ox = lx + c_corner[oc][0], oy = ly + c_corner[oc][1], oz = lz + c_corner[oc][2];
+            const int nb = ((ox >> 3) << 2) | ((oy >> 3) << 1) | (oz >> 3);
+            const int p = (((ox & 7) * 8) + (oy & 7)) * 8 + (oz & 7);
+            const int w = p >> 6, bit = p & 63;
+            const unsigned long long bl = (bit == 0) ? 0ull : (~0ull >> (64 - bit));
+            tri[v] = s_vbase[nb] + s_pref[nb][a * 8 + w] + (uint32_t)__popcll(s_mask[nb][a * 8 + w] & bl);
+        }
+        const size_t o = 3 * (size_t)(toff + (uint32_t)i);
+        triangles[o] = tri[0];
+        triangles[o + 1] = tri[1];
+        triangles[o + 2] = tri[2];
+    }
+}
+
+void ss_launch_mc_count(const SSDev& P, const float* G, const uint32_t* block_slot, const uint32_t* mc_list, uint32_t n_mc,
+                        unsigned long long* masks, uint32_t* vcount, uint32_t* tcount, hipStream_t st) {
+    if (!n_mc) return;
+    hipLaunchKernelGGL(k_mc_count, dim3(n_mc), dim3(512), 0, st, P, G, block_slot, mc_list, n_mc, masks, vcount, tcount);
+}
+void ss_launch_mc_emit(const SSDev& P, const float* G, const uint32_t* block_slot, const uint32_t* mc_list, const uint32_t* mc_slot,
+                       uint32_t n_mc, const unsigned long long* masks, const uint32_t* vbase, const uint32_t* tbase, float* vertices,
+                       unsigned long long* vkeys, uint32_t* triangles, hipStream_t st) {
+    if (!n_mc) return;
+    hipLaunchKernelGGL(k_mc_emit, dim3(n_mc), dim3(512), 0, st, P, G, block_slot, mc_list, mc_slot, n_mc, masks, vbase, tbase, vertices, vkeys,
+                       triangles);
+}
+
+// =====================================================================================================
+// helpers: widen triangle indices, level-set box extraction (tests), reference decomposition statistics
+// =====================================================================================================
+__global__ __launch_bounds__(256) void k_widen_u32_u64(const uint32_t* __restrict__ in, size_t n, unsigned long long* __restrict__ out) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = in[i];
+}
+void ss_launch_widen(const uint32_t* in, size_t n, unsigned long long* out, hipStream_t st) {
+    if (!n) return;
+    hipLaunchKernelGGL(k_widen_u32_u64, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, in, n, out);
+}
+
+__global__ __launch_bounds__(256) void k_levelset_box(SSDev P, const float* __restrict__ G, const uint32_t* __restrict__ block_slot, int lo0,
+                                                      int lo1, int lo2, int e0, int e1, int e2, float* __restrict__ out) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    size_t tot = (size_t)e0 * e1 * e2;
+    if (i >= tot) return;
+    int z = (int)(i % e2), y = (int)((i / e2) % e1), x = (int)(i / ((size_t)e2 * e1));
+    int gx = lo0 + x, gy = lo1 + y, gz = lo2 + z;
+    float v = 0.0f;
+    if (gx >= 0 && gy >= 0 && gz >= 0 && gx < P.np[0] && gy < P.np[1] && gz < P.np[2]) {
+        uint32_t slot = block_slot[((size_t)(gx >> 3) * P.nb[1] + (gy >> 3)) * P.nb[2] + (gz >> 3)];
+        if (slot != 0xFFFFFFFFu) v = G[(size_t)slot * SS_BLOCK_POINTS + (size_t)((((gx & 7) * 8) + (gy & 7)) * 8 + (gz & 7))];
+    }
+    out[i] = v;
+}
+void ss_launch_levelset_box(const SSDev& P, const float* G, const uint32_t* block_slot, const int lo[3], const int ext[3], float* out,
+                            hipStream_t st) {
+    size_t tot = (size_t)ext[0] * ext[1] * ext[2];
+    if (!tot) return;
+    hipLaunchKernelGGL(k_levelset_box, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, P, G, block_slot, lo[0], lo[1], lo[2], ext[0],
+                       ext[1], ext[2], out);
+}
+
+// The reference's ghost-margin classification (dense_subdomains.rs:1810-1905), only used to report the
+// decomposition statistics that define the splat kernel's algorithmic bytes.
+__global__ __launch_bounds__(256) void k_subdomain_counts(SSDev P, const float4* __restrict__ pos, uint32_t* __restrict__ counts) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P.n) return;
+    const float4 q = pos[i];
+    const float p[3] = {q.x, q.y, q.z};
+    int sub[3];
+    float min_corner[3], max_corner[3];
+    for (int d = 0; d < 3; ++d) {
+        sub[d] = (int)floorf((p[d] - P.gmin[d]) / P.sub_size);  // uniform_grid.rs:444-451
+        if (sub[d] < 0 || sub[d] >= P.ns[d]) return;            // :1819-1822
+        min_corner[d] = P.gmin[d] + (float)sub[d] * P.sub_size;
+        max_corner[d] = P.gmin[d] + (float)(sub[d] + 1) * P.sub_size;
+    }
+    const float dx = P.sub_size;
+    const int r = (int)ceilf(P.margin / dx);
+    for (int i0 = -r; i0 <= r; ++i0)
+        for (int j0 = -r; j0 <= r; ++j0)
+            for (int k0 = -r; k0 <= r; ++k0) {
+                const int steps[3] = {i0, j0, k0};
+                bool in_margin = true;
+                for (int d = 0; d < 3 && in_margin; ++d) {
+                    const int step = steps[d];
+                    const float off = (float)((step < 0 ? -step : step) - 1);
+                    if (step > 0)
+                        in_margin = ((max_corner[d] + off * dx) - p[d]) < P.margin;
+                    else if (step < 0)
+                        in_margin = (p[d] - (min_corner[d] - off * dx)) < P.margin;
+                }
+                if (!in_margin) continue;
+                const int nx = sub[0] + i0, ny = sub[1] + j0, nz = sub[2] + k0;
+                if (nx < 0 || ny < 0 || nz < 0 || nx >= P.ns[0] || ny >= P.ns[1] || nz >= P.ns[2]) continue;
+                atomicAdd(&counts[((size_t)nx * P.ns[1] + ny) * P.ns[2] + nz], 1u);
+            }
+}
+void ss_launch_subdomain_counts(const SSDev& P, const float4* pos, uint32_t* counts, hipStream_t st) {
+    if (!P.n) return;
+    hipLaunchKernelGGL(k_subdomain_counts, dim3((P.n + 255) / 256), dim3(256), 0, st, P, pos, counts);
+}

@@ -1,0 +1,63 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+for p in (ROOT, os.path.join(ROOT, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+DATA = os.path.join(ROOT, "tests", "data")
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: test needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def load_points(name):
+    return np.load(os.path.join(DATA, name))
+
+
+def load_golden(name):
+    return np.load(os.path.join(GOLD, name + ".npz"), allow_pickle=False)
+
+
+def golden_input(g):
+    """Re-create the input particles of a golden fixture from its description."""
+    import json
+    from splashsurf_amd import workloads as W
+    d = json.loads(str(g["input"]))
+    if d["kind"] == "inline":
+        return np.asarray(d["points"], dtype=np.float32).reshape(-1, 3)
+    if d["kind"] == "file":
+        return load_points(d["file"])
+    if d["kind"] == "workload":
+        if d["name"] == "tank":
+            return W.tank_particles(scale=d["scale"])
+        if d["name"] == "uniform_cube":
+            return W.uniform_cube_particles(d["n"], seed=d["seed"])
+    raise KeyError(d)
+
+
+def golden_params(g):
+    import json
+    return json.loads(str(g["params"]))
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    from oracle import oracle as O
+    O.build()
+    return O
+
+
+@pytest.fixture(scope="session")
+def gpu_ctx():
+    """HIP context on GPU 0. Fails loudly (no CPU fallback) if the library or the GPU is missing."""
+    import splashsurf_amd as S
+    from splashsurf_amd.api import Context
+    S.load_library()
+    return Context(0)

@@ -1,0 +1,53 @@
+"""CPU tests: the C-ABI library loads and exports every symbol include/splashsurf_hip.h declares;
+the Python host mirrors pysplashsurf.reconstruct_surface.  No compute calls (no GPU here)."""
+import ctypes
+import inspect
+import os
+
+import pytest
+
+import __graft_entry__ as G
+
+
+def test_library_exports_all_declared_symbols():
+    lib = G.LIB
+    if not os.path.exists(lib):
+        G.build()
+    L = ctypes.CDLL(lib)
+    syms = G.exported_symbols()
+    assert len(syms) >= 25
+    for s in syms:
+        assert hasattr(L, s), s
+    L.ss_abi_version.restype = ctypes.c_int
+    assert L.ss_abi_version() == 1
+
+
+def test_struct_layouts_match_header():
+    from splashsurf_amd import api
+    assert ctypes.sizeof(api._Params) == 5 * 4 + 4 + 24 + 6 * 4
+    assert ctypes.sizeof(api._Grid) == 28 + 4 + 48  # 7 floats + pad + 6 int64
+    assert ctypes.sizeof(api._Stats) == 9 * 8 + 8 * 8
+
+
+def test_python_signature_mirrors_reference():
+    import splashsurf_amd as S
+    sig = inspect.signature(S.reconstruct_surface)
+    names = list(sig.parameters)
+    # pysplashsurf/src/reconstruction.rs:135-160
+    for n in ["particles", "particle_radius", "rest_density", "smoothing_length", "cube_size", "iso_surface_threshold", "aabb_min",
+              "aabb_max", "multi_threading", "simd", "global_neighborhood_list", "subdomain_grid", "subdomain_grid_auto_disable",
+              "subdomain_num_cubes_per_dim"]:
+        assert n in names, n
+    assert sig.parameters["rest_density"].default == 1000.0
+    assert sig.parameters["iso_surface_threshold"].default == 0.6
+    assert sig.parameters["subdomain_num_cubes_per_dim"].default == 64
+
+
+def test_no_cpu_fallback_without_gpu():
+    """On a box without a GPU the product must fail loudly instead of computing on the CPU."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from splashsurf_amd.api import Context, SplashsurfError
+    with pytest.raises(SplashsurfError):
+        Context(0)

@@ -1,0 +1,113 @@
+"""CPU tests (-m "not gpu"): the oracle against the reference's golden vectors and known answers.
+
+The goldens under tests/golden/ were produced by the reference itself (tools/gen_goldens.py); these
+tests keep the oracle pinned to them on every run.
+"""
+import hashlib
+
+import numpy as np
+import pytest
+
+import mesh_compare as MC
+from conftest import golden_input, golden_params, load_golden
+
+FULL = ["kat1", "edge_empty", "edge_single", "edge_coincident", "edge_aabb_excludes_all", "cube_2366_aabb", "cube_8",
+        "free_particles_125", "cube_2366", "bunny_7705", "config1_double_dam_break", "cube_2366_n16"]
+DIGEST = ["config5_hilbert", "tank_small"]
+
+
+def run_oracle(O, pts, prm):
+    kw = {}
+    if "aabb_min" in prm:
+        kw = dict(aabb_min=np.asarray(prm["aabb_min"], np.float32), aabb_max=np.asarray(prm["aabb_max"], np.float32))
+    par = O.make_params_relative(prm["particle_radius"], prm["smoothing_length"], prm["cube_size"],
+                                 iso_surface_threshold=prm["iso_surface_threshold"],
+                                 subdomain_num_cubes_per_dim=prm.get("subdomain_num_cubes_per_dim", 64), **kw)
+    return O.reconstruct_surface(pts, par)
+
+
+@pytest.mark.parametrize("name", FULL)
+def test_oracle_matches_reference_full(oracle, name):
+    g = load_golden(name)
+    pts = golden_input(g)
+    res = run_oracle(oracle, pts, golden_params(g))
+    assert np.array_equal(res.grid["n_cells"], g["n_cells"])
+    assert np.array_equal(res.grid["aabb_min"].view(np.uint32), g["grid_min"].view(np.uint32))
+    # densities: bit-identical to the reference
+    assert np.array_equal(res.particle_densities.view(np.uint32), g["densities"].view(np.uint32))
+    if "inside" in g.files:
+        assert np.array_equal(res.particle_inside_aabb, g["inside"].astype(bool))
+    cmp = MC.compare_geometric(g["vertices"], g["triangles"], res.vertices, res.triangles, g["grid_min"], g["cell_size"], g["n_points"])
+    assert cmp["ids_equal"] and cmp["triangles_equal"], cmp
+    assert cmp["max_rel_diff"] <= 1e-6, cmp  # only shared-face vertices may differ (by an ulp): "first patch wins"
+
+
+@pytest.mark.parametrize("name", DIGEST)
+def test_oracle_matches_reference_digest(oracle, name):
+    g = load_golden(name)
+    pts = golden_input(g)
+    res = run_oracle(oracle, pts, golden_params(g))
+    assert np.array_equal(res.particle_densities.view(np.uint32), g["densities"].view(np.uint32))
+    ids, vs, tc = MC.canonicalize_geometric(res.vertices, res.triangles, g["grid_min"], g["cell_size"], g["n_points"])
+    assert ids.size == int(g["n_vertices"]) and tc.shape[0] == int(g["n_triangles"])
+    assert hashlib.sha256(ids.astype(np.int64).tobytes()).hexdigest() == str(g["ids_sha256"])
+    assert hashlib.sha256(tc.astype(np.int64).tobytes()).hexdigest() == str(g["triangles_sha256"])
+    sel = g["sample_index"]
+    assert np.array_equal(ids[sel], g["sample_ids"])
+    d = np.abs(vs[sel].astype(np.float64) - g["sample_vertices"].astype(np.float64))
+    assert d.max() <= 1e-6 * max(1.0, np.abs(g["sample_vertices"]).max())
+
+
+def test_kat_known_answer(oracle):
+    """tests/integration_tests/test_simple.rs:71-126: one particle => 6 vertices / 8 triangles, closed manifold."""
+    g = load_golden("kat1")
+    res = run_oracle(oracle, golden_input(g), golden_params(g))
+    assert res.vertices.shape == (6, 3) and res.triangles.shape == (8, 3)
+    assert MC.mesh_is_closed_manifold(res.triangles)
+    assert abs(float(res.particle_densities[0]) - 20371.834) < 1e-2
+
+
+def test_cubic_kernel_properties(oracle):
+    """kernel.rs:143-180: compact support and unit integral (20^3 midpoint rule)."""
+    h = 0.3
+    assert oracle.kernel_evaluate(h, h) == 0.0
+    assert oracle.kernel_evaluate(h, 2 * h) == 0.0
+    assert oracle.kernel_evaluate(h, 0.999 * h) > 0.0
+    n = 20
+    dr = 2 * h / n
+    c = (np.arange(n) + 0.5) * dr - h
+    X, Y, Z = np.meshgrid(c, c, c, indexing="ij")
+    r = np.sqrt(X ** 2 + Y ** 2 + Z ** 2).ravel()
+    w = np.array([oracle.kernel_evaluate(h, ri) for ri in r], dtype=np.float64)
+    assert abs(w.sum() * dr ** 3 - 1.0) < 1e-3
+
+
+def test_mc_table_known_cases(oracle):
+    """marching_cubes_lut.rs:375-451: case 'only corner 0 inside' => [3, 8, 0]; a case and its complement cut the same edges."""
+    t = oracle.mc_table()
+    assert t.shape == (256, 16)
+    assert list(t[1][:4]) == [3, 8, 0, -1]
+    assert t[0][0] == -1 and t[255][0] == -1
+    ntri = (t >= 0).sum(axis=1) // 3
+    assert ntri.max() == 5 and ntri.sum() == 820
+    for c in range(256):
+        assert set(t[c][t[c] >= 0]) == set(t[255 - c][t[255 - c] >= 0])
+
+
+def test_oracle_mesh_closed_on_data(oracle):
+    """test_full.rs:144-157: triangle count + closed/manifold for the double dam break."""
+    g = load_golden("config1_double_dam_break")
+    res = run_oracle(oracle, golden_input(g), golden_params(g))
+    assert res.triangles.shape[0] == 66220 and res.vertices.shape[0] == 33026
+    assert MC.mesh_is_closed_manifold(res.triangles)
+
+
+def test_oracle_s1m_counts(oracle):
+    """config 2 (1M uniform random, 8x over-dense): counts + densities of the reference."""
+    g = load_golden("config2_s1m")
+    res = run_oracle(oracle, golden_input(g), golden_params(g))
+    assert res.vertices.shape[0] == int(g["n_vertices"]) == 76476
+    assert res.triangles.shape[0] == int(g["n_triangles"]) == 152948
+    sel = g["density_sample_index"]
+    assert np.array_equal(res.particle_densities[sel].view(np.uint32), g["density_sample"].view(np.uint32))
+    assert hashlib.sha256(res.particle_densities.tobytes()).hexdigest() == str(g["density_sha256"])
