@@ -89,6 +89,8 @@ struct ss_context {
     // scratch (grow-only, reused across calls = the reference's workspace.rs)
     DevBuf xyz_in, xyz_filt, flags32, offsets, keys_a, keys_b, vals_a, vals_b, cell_count, cell_start, pos_sorted, temp, aabb_partial, aabb_out,
         block_flag, block_rank, mc_flag, mc_rank, vcount, tcount, counter;
+    // per-subdomain particle copies for the density stage
+    DevBuf member_count, copy_offset, sub_count, sub_flag, sub_rank, occ_sub, ckeys_a, ckeys_b, cvals_a, cidx, cpos, cell_count2, cell_start2;
     HostBuf h_small;
     hipEvent_t ev[12];
     bool ev_ok = false;
@@ -102,6 +104,7 @@ struct ss_result {
     bool has_inside = false;
     uint64_t n_input = 0, n_particles = 0, n_vertices = 0, n_triangles = 0;
     uint32_t n_active = 0, n_mc = 0;
+    uint64_t n_occupied_subdomains = 0, n_subdomain_particles = 0;
     ss_stats stats;
     // device results
     DevBuf rho, posvol, perm, inside8, G, block_slot, active_list, mc_list, mc_slot, masks, vbase, tbase, vertices, vkeys, tri32, tri64;
@@ -257,6 +260,9 @@ ss_status make_device_params(ss_context* ctx, const ss_params_f32* prm, const ss
     P.cs = g.cell_size;
     P.n_sub_cubes = (int)prm->subdomain_num_cubes_per_dim;
     P.sub_size = sg.cell_size;
+    P.sub_radius = (int)ceilf(margin / sg.cell_size);  // dense_subdomains.rs:1827-1832
+    if (P.sub_radius < 1 || P.sub_radius > 64) return fail(ctx, SS_ERR_UNSUPPORTED, "ghost margin spans more than 64 subdomains");
+    for (int d = 0; d < 3; ++d) P.sc[d] = (int)ceil(((double)sg.cell_size + 3.0 * (double)margin) / (double)h) + 3;
     P.h = h;
     P.h2 = h * h;
     P.H2 = (h * h) * 1.01f;
@@ -443,9 +449,63 @@ ss_status reconstruct_impl(ss_context* ctx, const float* xyz, uint64_t n_in, con
     }
     SS_HIP(ctx, hipEventRecord(ctx->ev[3], st));
 
-    // ---- K2: densities ----
-    ss_launch_density(P, ctx->pos_sorted.as<float4>(), res->perm.as<uint32_t>(), ctx->cell_start.as<uint32_t>(), res->rho.as<float>(),
-                      res->posvol.as<float4>(), st);
+    // ---- K2: densities (per-subdomain particle copies, exactly the reference's organisation) ----
+    {
+        const size_t nsub = (size_t)P.ns[0] * P.ns[1] * P.ns[2];
+        const double ctot_d = (double)P.sc[0] * P.sc[1] * P.sc[2];
+        SS_HIP(ctx, ctx->member_count.reserve(((size_t)n + 1) * 4));
+        SS_HIP(ctx, ctx->copy_offset.reserve(((size_t)n + 1) * 4));
+        SS_HIP(ctx, ctx->sub_count.reserve((nsub + 1) * 4));
+        SS_HIP(ctx, ctx->sub_flag.reserve((nsub + 1) * 4));
+        SS_HIP(ctx, ctx->sub_rank.reserve((nsub + 1) * 4));
+        SS_HIP(ctx, hipMemsetAsync(ctx->member_count.p, 0, ((size_t)n + 1) * 4, st));
+        SS_HIP(ctx, hipMemsetAsync(ctx->sub_count.p, 0, (nsub + 1) * 4, st));
+        SS_HIP(ctx, hipMemsetAsync(ctx->sub_flag.p, 0, (nsub + 1) * 4, st));
+        SS_HIP(ctx, hipMemsetAsync(res->rho.p, 0, (size_t)n * 4 + 16, st));  // vec![R::zero(); n], dense_subdomains.rs:504
+        ss_launch_classify_count(P, d_xyz, ctx->member_count.as<uint32_t>(), ctx->sub_count.as<uint32_t>(), st);
+        ss_launch_flag_nonzero(ctx->sub_count.as<uint32_t>(), (uint32_t)nsub, ctx->sub_flag.as<uint32_t>(), st);
+        s = exclusive_scan_u32<uint32_t>(ctx, ctx->member_count.as<uint32_t>(), ctx->copy_offset.as<uint32_t>(), (size_t)n + 1);
+        if (s != SS_OK) return s;
+        s = exclusive_scan_u32<uint32_t>(ctx, ctx->sub_flag.as<uint32_t>(), ctx->sub_rank.as<uint32_t>(), nsub + 1);
+        if (s != SS_OK) return s;
+        uint32_t hc[2] = {0, 0};
+        SS_HIP(ctx, hipMemcpyAsync(&hc[0], ctx->copy_offset.as<uint32_t>() + n, 4, hipMemcpyDeviceToHost, st));
+        SS_HIP(ctx, hipMemcpyAsync(&hc[1], ctx->sub_rank.as<uint32_t>() + nsub, 4, hipMemcpyDeviceToHost, st));
+        SS_HIP(ctx, hipStreamSynchronize(st));
+        const uint32_t n_copies = hc[0], n_occ = hc[1];
+        res->n_occupied_subdomains = n_occ;
+        res->n_subdomain_particles = n_copies;
+        if ((double)n_occ * ctot_d > 4.0e9) return fail(ctx, SS_ERR_UNSUPPORTED, "too many (subdomain, search cell) pairs for this build");
+        const size_t ncells2 = (size_t)n_occ * (size_t)ctot_d;
+        if (n_copies > 0) {
+            SS_HIP(ctx, ctx->occ_sub.reserve((size_t)n_occ * 4 + 16));
+            SS_HIP(ctx, ctx->ckeys_a.reserve((size_t)n_copies * 4));
+            SS_HIP(ctx, ctx->ckeys_b.reserve((size_t)n_copies * 4));
+            SS_HIP(ctx, ctx->cvals_a.reserve((size_t)n_copies * 4));
+            SS_HIP(ctx, ctx->cidx.reserve((size_t)n_copies * 4));
+            SS_HIP(ctx, ctx->cpos.reserve((size_t)n_copies * 16));
+            SS_HIP(ctx, ctx->cell_count2.reserve((ncells2 + 1) * 4));
+            SS_HIP(ctx, ctx->cell_start2.reserve((ncells2 + 1) * 4));
+            SS_HIP(ctx, hipMemsetAsync(ctx->cell_count2.p, 0, (ncells2 + 1) * 4, st));
+            ss_launch_occupied_list(ctx->sub_flag.as<uint32_t>(), ctx->sub_rank.as<uint32_t>(), (uint32_t)nsub, ctx->occ_sub.as<uint32_t>(), st);
+            ss_launch_emit_copies(P, d_xyz, ctx->copy_offset.as<uint32_t>(), ctx->sub_rank.as<uint32_t>(), ctx->ckeys_a.as<uint32_t>(),
+                                  ctx->cvals_a.as<uint32_t>(), ctx->cell_count2.as<uint32_t>(), st);
+            s = exclusive_scan_u32<uint32_t>(ctx, ctx->cell_count2.as<uint32_t>(), ctx->cell_start2.as<uint32_t>(), ncells2 + 1);
+            if (s != SS_OK) return s;
+            unsigned bits = 1;
+            while (bits < 32 && ((size_t)1 << bits) < ncells2) ++bits;
+            size_t bytes = 0;
+            SS_HIP(ctx, rocprim::radix_sort_pairs(nullptr, bytes, ctx->ckeys_a.as<uint32_t>(), ctx->ckeys_b.as<uint32_t>(), ctx->cvals_a.as<uint32_t>(),
+                                                  ctx->cidx.as<uint32_t>(), (size_t)n_copies, 0u, bits, st));
+            SS_HIP(ctx, ctx->temp.reserve(bytes));
+            SS_HIP(ctx, rocprim::radix_sort_pairs(ctx->temp.p, bytes, ctx->ckeys_a.as<uint32_t>(), ctx->ckeys_b.as<uint32_t>(), ctx->cvals_a.as<uint32_t>(),
+                                                  ctx->cidx.as<uint32_t>(), (size_t)n_copies, 0u, bits, st));
+            ss_launch_gather_sorted(n_copies, d_xyz, ctx->cidx.as<uint32_t>(), ctx->cpos.as<float4>(), st);
+            ss_launch_density_sub(P, n_copies, ctx->cpos.as<float4>(), ctx->cidx.as<uint32_t>(), ctx->ckeys_b.as<uint32_t>(),
+                                  ctx->cell_start2.as<uint32_t>(), ctx->occ_sub.as<uint32_t>(), res->rho.as<float>(), st);
+        }
+        ss_launch_make_posvol(P, ctx->pos_sorted.as<float4>(), res->perm.as<uint32_t>(), res->rho.as<float>(), res->posvol.as<float4>(), st);
+    }
     SS_HIP(ctx, hipEventRecord(ctx->ev[4], st));
 
     // ---- K3 prepare: active level-set blocks and MC blocks ----
@@ -547,7 +607,8 @@ ss_status reconstruct_impl(ss_context* ctx, const float* xyz, uint64_t n_in, con
     size_t held = 0;
     for (const DevBuf* b : {&ctx->xyz_in, &ctx->xyz_filt, &ctx->flags32, &ctx->offsets, &ctx->keys_a, &ctx->keys_b, &ctx->vals_a, &ctx->cell_count,
                             &ctx->cell_start, &ctx->pos_sorted, &ctx->temp, &ctx->block_flag, &ctx->block_rank, &ctx->mc_flag, &ctx->mc_rank,
-                            &ctx->vcount, &ctx->tcount, &res->rho, &res->posvol, &res->perm, &res->inside8, &res->G, &res->block_slot,
+                            &ctx->vcount, &ctx->tcount, &ctx->member_count, &ctx->copy_offset, &ctx->ckeys_a, &ctx->ckeys_b, &ctx->cvals_a, &ctx->cidx,
+                            &ctx->cpos, &ctx->cell_count2, &ctx->cell_start2, &res->rho, &res->posvol, &res->perm, &res->inside8, &res->G, &res->block_slot,
                             &res->active_list, &res->mc_list, &res->mc_slot, &res->masks, &res->vbase, &res->tbase, &res->vertices, &res->vkeys,
                             &res->tri32})
         held += b->cap;
@@ -614,7 +675,8 @@ void ss_context_destroy(ss_context* c) {
     (void)hipDeviceSynchronize();
     for (DevBuf* b : {&c->xyz_in, &c->xyz_filt, &c->flags32, &c->offsets, &c->keys_a, &c->keys_b, &c->vals_a, &c->vals_b, &c->cell_count,
                       &c->cell_start, &c->pos_sorted, &c->temp, &c->aabb_partial, &c->aabb_out, &c->block_flag, &c->block_rank, &c->mc_flag,
-                      &c->mc_rank, &c->vcount, &c->tcount, &c->counter})
+                      &c->mc_rank, &c->vcount, &c->tcount, &c->counter, &c->member_count, &c->copy_offset, &c->sub_count, &c->sub_flag, &c->sub_rank,
+                      &c->occ_sub, &c->ckeys_a, &c->ckeys_b, &c->cvals_a, &c->cidx, &c->cpos, &c->cell_count2, &c->cell_start2})
         b->release();
     c->h_small.release();
     if (c->ev_ok)
@@ -833,27 +895,8 @@ ss_status ss_result_levelset_box(ss_result* r, const int64_t lo[3], const int64_
 
 ss_status ss_result_subdomain_stats(ss_result* r, uint64_t* n_occupied, uint64_t* n_sub_particles) {
     if (!r || !r->valid || !n_occupied || !n_sub_particles) return SS_ERR_INVALID_ARGUMENT;
-    ss_context* c = r->ctx;
-    *n_occupied = 0;
-    *n_sub_particles = 0;
-    const size_t nsub = (size_t)r->P.ns[0] * r->P.ns[1] * r->P.ns[2];
-    if (!nsub || !r->n_particles) return SS_OK;
-    SS_HIP(c, hipSetDevice(c->device));
-    DevBuf tmp;
-    SS_HIP(c, tmp.reserve(nsub * 4));
-    SS_HIP(c, hipMemsetAsync(tmp.p, 0, nsub * 4, c->stream));
-    ss_launch_subdomain_counts(r->P, r->posvol.as<float4>(), tmp.as<uint32_t>(), c->stream);
-    std::vector<uint32_t> h(nsub);
-    SS_HIP(c, hipMemcpyAsync(h.data(), tmp.p, nsub * 4, hipMemcpyDeviceToHost, c->stream));
-    SS_HIP(c, hipStreamSynchronize(c->stream));
-    tmp.release();
-    uint64_t occ = 0, sum = 0;
-    for (size_t i = 0; i < nsub; ++i) {
-        occ += h[i] ? 1 : 0;
-        sum += h[i];
-    }
-    *n_occupied = occ;
-    *n_sub_particles = sum;
+    *n_occupied = r->n_occupied_subdomains;
+    *n_sub_particles = r->n_subdomain_particles;
     return SS_OK;
 }
 

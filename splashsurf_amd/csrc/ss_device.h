@@ -24,6 +24,8 @@ struct SSDev {
     int n_sub_cubes;
     int ns[3];
     float sub_size;
+    int sub_radius;  // ceil(margin / sub_size): subdomains to check in each direction (dense_subdomains.rs:1827-1832)
+    int sc[3];       // per-subdomain neighbourhood-search grid: table dims (cells of edge h, upper bound)
     // SPH kernel and level-set constants
     float h;          // compact support radius
     float h2;         // h*h                       (neighborhood_search.rs:367)

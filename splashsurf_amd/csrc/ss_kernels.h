@@ -7,8 +7,14 @@ void ss_launch_inside_flags(const float* d_xyz, uint32_t n, const float amin[3],
 void ss_launch_compact_xyz(const float* d_xyz, uint32_t n, const uint32_t* f32, const uint32_t* offs, float* out, hipStream_t st);
 void ss_launch_cell_keys(const SSDev& P, const float* d_xyz, uint32_t* keys, uint32_t* vals, uint32_t* cell_count, hipStream_t st);
 void ss_launch_gather_sorted(uint32_t n, const float* d_xyz, const uint32_t* perm, float4* pos_sorted, hipStream_t st);
-void ss_launch_density(const SSDev& P, const float4* pos_sorted, const uint32_t* perm, const uint32_t* cell_start, float* rho,
-                       float4* posvol_sorted, hipStream_t st);
+void ss_launch_classify_count(const SSDev& P, const float* xyz, uint32_t* member_count, uint32_t* sub_count, hipStream_t st);
+void ss_launch_flag_nonzero(const uint32_t* in, uint32_t n, uint32_t* flag, hipStream_t st);
+void ss_launch_occupied_list(const uint32_t* flag, const uint32_t* rank, uint32_t n, uint32_t* occ_sub, hipStream_t st);
+void ss_launch_emit_copies(const SSDev& P, const float* xyz, const uint32_t* copy_offset, const uint32_t* occ_rank, uint32_t* keys, uint32_t* vals,
+                           uint32_t* cell_count, hipStream_t st);
+void ss_launch_density_sub(const SSDev& P, uint32_t n_copies, const float4* cpos, const uint32_t* cidx, const uint32_t* ckey,
+                           const uint32_t* cell_start, const uint32_t* occ_sub, float* rho, hipStream_t st);
+void ss_launch_make_posvol(const SSDev& P, const float4* pos_sorted, const uint32_t* perm, const float* rho, float4* posvol, hipStream_t st);
 void ss_launch_mark_blocks(const SSDev& P, const uint32_t* cell_start, uint32_t ncells, uint32_t* block_flag, hipStream_t st);
 void ss_launch_mark_mc_blocks(const SSDev& P, const uint32_t* block_flag, uint32_t nblocks, uint32_t* mc_flag, hipStream_t st);
 void ss_launch_compact_blocks(const uint32_t* flag, const uint32_t* rank, uint32_t nblocks, uint32_t* list, uint32_t* slot, hipStream_t st);
@@ -22,4 +28,3 @@ void ss_launch_mc_emit(const SSDev& P, const float* G, const uint32_t* block_slo
 void ss_launch_widen(const uint32_t* in, size_t n, unsigned long long* out, hipStream_t st);
 void ss_launch_levelset_box(const SSDev& P, const float* G, const uint32_t* block_slot, const int lo[3], const int ext[3], float* out,
                             hipStream_t st);
-void ss_launch_subdomain_counts(const SSDev& P, const float4* pos, uint32_t* counts, hipStream_t st);

@@ -5,7 +5,8 @@
 //   K0b lib.rs:369-406 (particle AABB filter)                             -> k_inside_flags/k_compact_xyz
 //   K1  dense_subdomains.rs:349-494 (decomposition) + neighborhood_search.rs:679-710 (cell map)
 //                                                                        -> k_cell_keys (+ rocPRIM sort), k_gather_sorted
-//   K2  neighborhood_search.rs:345-438 + density_map.rs:150-186          -> k_density
+//   K2  dense_subdomains.rs:496-646 + neighborhood_search.rs:345-438 + density_map.rs:150-186
+//                                                                        -> k_classify_count, k_emit_copies, k_density_sub
 //   K3  dense_subdomains.rs:784-847 (density_grid_loop_scalar)            -> k_mark_blocks, k_splat
 //   K4  dense_subdomains.rs:1470-1553 (triangulate_cell) classification   -> k_mc_count
 //   K5  same, vertex/triangle emission + dense_subdomains.rs:1603-1749    -> k_mc_emit
@@ -178,33 +179,148 @@ void ss_launch_gather_sorted(uint32_t n, const float* d_xyz, const uint32_t* per
 }
 
 // =====================================================================================================
-// K2: per-particle SPH density.  rho_i = m * (W(0) + sum_j W(|x_j - x_i|)), neighbours visited in the
-// reference's order: the 26 adjacent search cells in (x,y,z)-lexicographic order of the step, then the
-// own cell (uniform_grid.rs:614-643, neighborhood_search.rs:400-405); ascending original index inside
-// a cell (neighborhood_search.rs:692-707).  One thread per particle (sorted order => lanes of a wave
-// share cells and their loads coalesce / hit L1).
+// K2: per-particle SPH density, organised exactly like the reference (dense_subdomains.rs:496-646):
+// every particle is COPIED into each subdomain it belongs to (owner + ghost margins, classification of
+// dense_subdomains.rs:1810-1905); the copies of a subdomain are binned in THAT subdomain's own
+// neighbourhood-search grid (neighborhood_search.rs:370, cell edge h, origin aligned per subdomain) and
+// the copy that lies inside the subdomain's half-open AABB computes
+//     rho_i = m * (W(0) + sum_j W(|x_j - x_i|))
+// over the 26 adjacent cells in (x,y,z)-lexicographic step order, then the own cell
+// (uniform_grid.rs:614-643, neighborhood_search.rs:400-405), ascending original index inside a cell
+// (neighborhood_search.rs:692-707).  Using the per-subdomain grids (instead of one global grid) is what
+// makes the summation ORDER -- and hence every bit of rho -- identical to the reference even for
+// particles that sit exactly on search-cell boundaries.
 // =====================================================================================================
-__global__ __launch_bounds__(256) void k_density(SSDev P, const float4* __restrict__ pos_sorted, const uint32_t* __restrict__ perm,
-                                                 const uint32_t* __restrict__ cell_start, float* __restrict__ rho,
-                                                 float4* __restrict__ posvol_sorted) {
+template <class F>
+__device__ inline void ss_for_each_member_subdomain(const SSDev& P, const float p[3], F f) {
+    int sub[3];
+    float min_corner[3], max_corner[3];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        sub[d] = (int)floorf((p[d] - P.gmin[d]) / P.sub_size);  // uniform_grid.rs:444-451
+        if (sub[d] < 0 || sub[d] >= P.ns[d]) return;            // dense_subdomains.rs:1819-1822
+        min_corner[d] = P.gmin[d] + (float)sub[d] * P.sub_size;
+        max_corner[d] = P.gmin[d] + (float)(sub[d] + 1) * P.sub_size;
+    }
+    const float dx = P.sub_size;
+    const int r = P.sub_radius;  // ceil(margin / dx), dense_subdomains.rs:1827-1832
+    for (int i0 = -r; i0 <= r; ++i0)
+        for (int j0 = -r; j0 <= r; ++j0)
+            for (int k0 = -r; k0 <= r; ++k0) {
+                const int steps[3] = {i0, j0, k0};
+                bool in_margin = true;
+#pragma unroll
+                for (int d = 0; d < 3; ++d) {  // dense_subdomains.rs:1844-1856
+                    const int step = steps[d];
+                    const float off = (float)((step < 0 ? -step : step) - 1);
+                    if (step > 0)
+                        in_margin = in_margin && (((max_corner[d] + off * dx) - p[d]) < P.margin);
+                    else if (step < 0)
+                        in_margin = in_margin && ((p[d] - (min_corner[d] - off * dx)) < P.margin);
+                }
+                if (!in_margin) continue;
+                const int nx = sub[0] + i0, ny = sub[1] + j0, nz = sub[2] + k0;
+                if (nx < 0 || ny < 0 || nz < 0 || nx >= P.ns[0] || ny >= P.ns[1] || nz >= P.ns[2]) continue;  // :1895-1900
+                f(nx, ny, nz);
+            }
+}
+
+// cell of x in the neighbourhood-search grid of subdomain index s (per axis); neighborhood_search.rs:370
+// applied to the AABB of dense_subdomains.rs:560-565 (uniform_grid.rs:189-201 alignment, :444-451 cell)
+__device__ inline int ss_local_search_cell_axis(const SSDev& P, int s, float x, int d) {
+    const float amin = P.gmin[d] + (float)s * P.sub_size;
+    const float mmin = amin - P.margin * 1.5f;
+    const float aligned = floorf(mmin / P.h) * P.h;
+    const int c = (int)floorf((x - aligned) / P.h);
+    return max(0, min(P.sc[d] - 1, c));
+}
+
+__global__ __launch_bounds__(256) void k_classify_count(SSDev P, const float* __restrict__ xyz, uint32_t* __restrict__ member_count,
+                                                        uint32_t* __restrict__ sub_count) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P.n) return;
+    const float p[3] = {xyz[3 * (size_t)i], xyz[3 * (size_t)i + 1], xyz[3 * (size_t)i + 2]};
+    uint32_t m = 0;
+    ss_for_each_member_subdomain(P, p, [&](int sx, int sy, int sz) {
+        ++m;
+        atomicAdd(&sub_count[((size_t)sx * P.ns[1] + sy) * P.ns[2] + sz], 1u);
+    });
+    member_count[i] = m;
+}
+
+__global__ __launch_bounds__(256) void k_flag_nonzero(const uint32_t* __restrict__ in, uint32_t n, uint32_t* __restrict__ flag) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) flag[i] = in[i] ? 1u : 0u;
+}
+
+__global__ __launch_bounds__(256) void k_occupied_list(const uint32_t* __restrict__ flag, const uint32_t* __restrict__ rank, uint32_t n,
+                                                       uint32_t* __restrict__ occ_sub) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n && flag[i]) occ_sub[rank[i]] = i;
+}
+
+__global__ __launch_bounds__(256) void k_emit_copies(SSDev P, const float* __restrict__ xyz, const uint32_t* __restrict__ copy_offset,
+                                                     const uint32_t* __restrict__ occ_rank, uint32_t* __restrict__ keys,
+                                                     uint32_t* __restrict__ vals, uint32_t* __restrict__ cell_count) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P.n) return;
+    const float p[3] = {xyz[3 * (size_t)i], xyz[3 * (size_t)i + 1], xyz[3 * (size_t)i + 2]};
+    uint32_t o = copy_offset[i];
+    const uint32_t ctot = (uint32_t)(P.sc[0] * P.sc[1] * P.sc[2]);
+    ss_for_each_member_subdomain(P, p, [&](int sx, int sy, int sz) {
+        const uint32_t occ = occ_rank[((size_t)sx * P.ns[1] + sy) * P.ns[2] + sz];
+        const int cx = ss_local_search_cell_axis(P, sx, p[0], 0);
+        const int cy = ss_local_search_cell_axis(P, sy, p[1], 1);
+        const int cz = ss_local_search_cell_axis(P, sz, p[2], 2);
+        const uint32_t key = occ * ctot + (uint32_t)((cx * P.sc[1] + cy) * P.sc[2] + cz);
+        keys[o] = key;
+        vals[o] = i;
+        atomicAdd(&cell_count[key], 1u);
+        ++o;
+    });
+}
+
+__global__ __launch_bounds__(256) void k_density_sub(SSDev P, uint32_t n_copies, const float4* __restrict__ cpos, const uint32_t* __restrict__ cidx,
+                                                     const uint32_t* __restrict__ ckey, const uint32_t* __restrict__ cell_start,
+                                                     const uint32_t* __restrict__ occ_sub, float* __restrict__ rho) {
     uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= P.n) return;
-    const float4 pi = pos_sorted[p];
-    int K[3];
-    ss_particle_cell(P, pi.x, pi.y, pi.z, K);
+    if (p >= n_copies) return;
+    const uint32_t ctot = (uint32_t)(P.sc[0] * P.sc[1] * P.sc[2]);
+    const uint32_t key = ckey[p];
+    const uint32_t occ = key / ctot, cell = key - occ * ctot;
+    const uint32_t flat = occ_sub[occ];
+    const int sz = (int)(flat % (uint32_t)P.ns[2]);
+    const int sy = (int)((flat / (uint32_t)P.ns[2]) % (uint32_t)P.ns[1]);
+    const int sx = (int)(flat / ((uint32_t)P.ns[2] * (uint32_t)P.ns[1]));
+    const float4 pi = cpos[p];
+    // is_inside: half-open AABB of the subdomain (dense_subdomains.rs:567-576, aabb.rs:220-222)
+    {
+        const int s3[3] = {sx, sy, sz};
+        const float x3[3] = {pi.x, pi.y, pi.z};
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            const float lo = P.gmin[d] + (float)s3[d] * P.sub_size;
+            const float hi = P.gmin[d] + (float)(s3[d] + 1) * P.sub_size;
+            if (!(x3[d] >= lo && x3[d] < hi)) return;  // ghost copy: density computed by another subdomain
+        }
+    }
+    const int cz = (int)(cell % (uint32_t)P.sc[2]);
+    const int cy = (int)((cell / (uint32_t)P.sc[2]) % (uint32_t)P.sc[1]);
+    const int cx = (int)(cell / ((uint32_t)P.sc[2] * (uint32_t)P.sc[1]));
+    const uint32_t base = occ * ctot;
     float acc = P.w0;  // density_map.rs:173
     for (int pass = 0; pass < 2; ++pass) {
-        for (int sx = -1; sx <= 1; ++sx)
-            for (int sy = -1; sy <= 1; ++sy)
-                for (int sz = -1; sz <= 1; ++sz) {
-                    const bool center = (sx == 0 && sy == 0 && sz == 0);
+        for (int ox = -1; ox <= 1; ++ox)
+            for (int oy = -1; oy <= 1; ++oy)
+                for (int oz = -1; oz <= 1; ++oz) {
+                    const bool center = (ox == 0 && oy == 0 && oz == 0);
                     if ((pass == 0) == center) continue;
-                    const int kx = K[0] + sx, ky = K[1] + sy, kz = K[2] + sz;
-                    if (!ss_cell_in_range(P, kx, ky, kz)) continue;
-                    const uint32_t key = ss_cell_key(P, kx, ky, kz);
-                    const uint32_t qb = cell_start[key], qe = cell_start[key + 1];
+                    const int nx = cx + ox, ny = cy + oy, nz = cz + oz;
+                    if (nx < 0 || ny < 0 || nz < 0 || nx >= P.sc[0] || ny >= P.sc[1] || nz >= P.sc[2]) continue;
+                    const uint32_t k2 = base + (uint32_t)((nx * P.sc[1] + ny) * P.sc[2] + nz);
+                    const uint32_t qb = cell_start[k2], qe = cell_start[k2 + 1];
                     for (uint32_t q = qb; q < qe; ++q) {
-                        const float4 pj = pos_sorted[q];
+                        const float4 pj = cpos[q];
                         const float dx = pj.x - pi.x, dy = pj.y - pi.y, dz = pj.z - pi.z;
                         const float d2 = dx * dx + dy * dy + dz * dz;
                         if (q != p && d2 < P.h2) {  // neighborhood_search.rs:431
@@ -214,15 +330,43 @@ __global__ __launch_bounds__(256) void k_density(SSDev P, const float4* __restri
                     }
                 }
     }
-    const float density = acc * P.mass;  // density_map.rs:182
-    rho[perm[p]] = density;
-    posvol_sorted[p] = make_float4(pi.x, pi.y, pi.z, P.mass / density);  // v_i, dense_subdomains.rs:832
+    rho[cidx[p]] = acc * P.mass;  // density_map.rs:182, dense_subdomains.rs:596-614
 }
 
-void ss_launch_density(const SSDev& P, const float4* pos_sorted, const uint32_t* perm, const uint32_t* cell_start, float* rho,
-                       float4* posvol_sorted, hipStream_t st) {
+// (x, y, z, V = m / rho) in global-cell order for the splat (v_i of dense_subdomains.rs:832)
+__global__ __launch_bounds__(256) void k_make_posvol(SSDev P, const float4* __restrict__ pos_sorted, const uint32_t* __restrict__ perm,
+                                                     const float* __restrict__ rho, float4* __restrict__ posvol) {
+    uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= P.n) return;
+    const float4 a = pos_sorted[p];
+    posvol[p] = make_float4(a.x, a.y, a.z, P.mass / rho[perm[p]]);
+}
+
+void ss_launch_classify_count(const SSDev& P, const float* xyz, uint32_t* member_count, uint32_t* sub_count, hipStream_t st) {
     if (!P.n) return;
-    hipLaunchKernelGGL(k_density, dim3((P.n + 255) / 256), dim3(256), 0, st, P, pos_sorted, perm, cell_start, rho, posvol_sorted);
+    hipLaunchKernelGGL(k_classify_count, dim3((P.n + 255) / 256), dim3(256), 0, st, P, xyz, member_count, sub_count);
+}
+void ss_launch_flag_nonzero(const uint32_t* in, uint32_t n, uint32_t* flag, hipStream_t st) {
+    if (!n) return;
+    hipLaunchKernelGGL(k_flag_nonzero, dim3((n + 255) / 256), dim3(256), 0, st, in, n, flag);
+}
+void ss_launch_occupied_list(const uint32_t* flag, const uint32_t* rank, uint32_t n, uint32_t* occ_sub, hipStream_t st) {
+    if (!n) return;
+    hipLaunchKernelGGL(k_occupied_list, dim3((n + 255) / 256), dim3(256), 0, st, flag, rank, n, occ_sub);
+}
+void ss_launch_emit_copies(const SSDev& P, const float* xyz, const uint32_t* copy_offset, const uint32_t* occ_rank, uint32_t* keys, uint32_t* vals,
+                           uint32_t* cell_count, hipStream_t st) {
+    if (!P.n) return;
+    hipLaunchKernelGGL(k_emit_copies, dim3((P.n + 255) / 256), dim3(256), 0, st, P, xyz, copy_offset, occ_rank, keys, vals, cell_count);
+}
+void ss_launch_density_sub(const SSDev& P, uint32_t n_copies, const float4* cpos, const uint32_t* cidx, const uint32_t* ckey,
+                           const uint32_t* cell_start, const uint32_t* occ_sub, float* rho, hipStream_t st) {
+    if (!n_copies) return;
+    hipLaunchKernelGGL(k_density_sub, dim3((n_copies + 255) / 256), dim3(256), 0, st, P, n_copies, cpos, cidx, ckey, cell_start, occ_sub, rho);
+}
+void ss_launch_make_posvol(const SSDev& P, const float4* pos_sorted, const uint32_t* perm, const float* rho, float4* posvol, hipStream_t st) {
+    if (!P.n) return;
+    hipLaunchKernelGGL(k_make_posvol, dim3((P.n + 255) / 256), dim3(256), 0, st, P, pos_sorted, perm, rho, posvol);
 }
 
 // =====================================================================================================
@@ -843,45 +987,4 @@ void ss_launch_levelset_box(const SSDev& P, const float* G, const uint32_t* bloc
     if (!tot) return;
     hipLaunchKernelGGL(k_levelset_box, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, P, G, block_slot, lo[0], lo[1], lo[2], ext[0],
                        ext[1], ext[2], out);
-}
-
-// The reference's ghost-margin classification (dense_subdomains.rs:1810-1905), only used to report the
-// decomposition statistics that define the splat kernel's algorithmic bytes.
-__global__ __launch_bounds__(256) void k_subdomain_counts(SSDev P, const float4* __restrict__ pos, uint32_t* __restrict__ counts) {
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= P.n) return;
-    const float4 q = pos[i];
-    const float p[3] = {q.x, q.y, q.z};
-    int sub[3];
-    float min_corner[3], max_corner[3];
-    for (int d = 0; d < 3; ++d) {
-        sub[d] = (int)floorf((p[d] - P.gmin[d]) / P.sub_size);  // uniform_grid.rs:444-451
-        if (sub[d] < 0 || sub[d] >= P.ns[d]) return;            // :1819-1822
-        min_corner[d] = P.gmin[d] + (float)sub[d] * P.sub_size;
-        max_corner[d] = P.gmin[d] + (float)(sub[d] + 1) * P.sub_size;
-    }
-    const float dx = P.sub_size;
-    const int r = (int)ceilf(P.margin / dx);
-    for (int i0 = -r; i0 <= r; ++i0)
-        for (int j0 = -r; j0 <= r; ++j0)
-            for (int k0 = -r; k0 <= r; ++k0) {
-                const int steps[3] = {i0, j0, k0};
-                bool in_margin = true;
-                for (int d = 0; d < 3 && in_margin; ++d) {
-                    const int step = steps[d];
-                    const float off = (float)((step < 0 ? -step : step) - 1);
-                    if (step > 0)
-                        in_margin = ((max_corner[d] + off * dx) - p[d]) < P.margin;
-                    else if (step < 0)
-                        in_margin = (p[d] - (min_corner[d] - off * dx)) < P.margin;
-                }
-                if (!in_margin) continue;
-                const int nx = sub[0] + i0, ny = sub[1] + j0, nz = sub[2] + k0;
-                if (nx < 0 || ny < 0 || nz < 0 || nx >= P.ns[0] || ny >= P.ns[1] || nz >= P.ns[2]) continue;
-                atomicAdd(&counts[((size_t)nx * P.ns[1] + ny) * P.ns[2] + nz], 1u);
-            }
-}
-void ss_launch_subdomain_counts(const SSDev& P, const float4* pos, uint32_t* counts, hipStream_t st) {
-    if (!P.n) return;
-    hipLaunchKernelGGL(k_subdomain_counts, dim3((P.n + 255) / 256), dim3(256), 0, st, P, pos, counts);
 }

@@ -57,6 +57,7 @@ def assert_gpu_equals_oracle(res, orc):
     assert cmp["keys_equal"], cmp
     assert cmp["triangles_equal"], cmp
     assert cmp["vertices_bit_equal"], cmp
+    assert res.subdomain_stats() == (orc.n_subdomains, orc.n_subdomain_particles)
     if orc.particle_inside_aabb is None:
         assert res.particle_inside_aabb is None
     else:
