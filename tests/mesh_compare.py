@@ -98,14 +98,30 @@ def compare_geometric(va, ta, vb, tb, grid_min, cell_size, n_points, tol=1e-3):
     out["ids_equal"] = bool(np.array_equal(ia, ib))
     out["triangles_equal"] = bool(tca.shape == tcb.shape and np.array_equal(tca, tcb))
     if out["ids_equal"] and len(ia):
-        # Within one cluster (same id) the order of vertices is arbitrary; their coordinates agree to
-        # ~tol*cell_size by construction, so a per-row difference is meaningful as an upper bound.
         a = va_s.astype(np.float64)
         b = vb_s.astype(np.float64)
-        out["max_abs_diff"] = float(np.max(np.abs(a - b)))
+        diff = np.max(np.abs(a - b), axis=1)
+        # Clusters with several vertices (all within ~tol*cell_size of one grid point) come in arbitrary
+        # order: pair every vertex with the nearest vertex of the same cluster in the other mesh
+        # (symmetric Hausdorff distance inside the cluster).
+        same_prev = np.concatenate([[False], ia[1:] == ia[:-1]])
+        same_next = np.concatenate([ia[1:] == ia[:-1], [False]])
+        multi = same_prev | same_next
+        if multi.any():
+            idx = np.nonzero(multi)[0]
+            starts = idx[~same_prev[idx]]
+            for s0 in starts:
+                e0 = s0 + 1
+                while e0 < len(ia) and ia[e0] == ia[s0]:
+                    e0 += 1
+                A, B = a[s0:e0], b[s0:e0]
+                d = np.max(np.abs(A[:, None, :] - B[None, :, :]), axis=2)
+                diff[s0:e0] = np.maximum(d.min(axis=1), d.min(axis=0))
+        out["max_abs_diff"] = float(diff.max())
         scale = np.maximum(np.max(np.abs(a), axis=1), 1e-30)
-        out["max_rel_diff"] = float(np.max(np.max(np.abs(a - b), axis=1) / scale))
+        out["max_rel_diff"] = float(np.max(diff / scale))
         out["n_vertices_bit_equal"] = int(np.all(va_s.astype(np.float32) == vb_s.astype(np.float32), axis=1).sum())
+        out["n_multi_cluster_vertices"] = int(multi.sum())
     elif out["ids_equal"]:
         out["max_abs_diff"] = 0.0
         out["max_rel_diff"] = 0.0
