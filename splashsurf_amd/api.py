@@ -86,11 +86,34 @@ def library_path():
     return os.path.join(_HERE, _LIB_NAME)
 
 
+def _preload_hip_runtime():
+    """One HIP runtime per process: PyTorch-ROCm wheels bundle their own libamdhip64/libhsa-runtime64
+    (same SONAMEs as /opt/rocm's).  If torch is installed, load ITS copies first (RTLD_GLOBAL) so that
+    this library and torch (device tensors, streams, RCCL) share a single runtime regardless of import
+    order; without torch the system ROCm runtime is used."""
+    import importlib.util
+    try:
+        spec = importlib.util.find_spec("torch")
+    except Exception:
+        spec = None
+    if not spec or not spec.submodule_search_locations:
+        return
+    libdir = os.path.join(list(spec.submodule_search_locations)[0], "lib")
+    for name in ("librocprofiler-register.so", "libhsa-runtime64.so", "libamdhip64.so"):
+        path = os.path.join(libdir, name)
+        if os.path.exists(path):
+            try:
+                C.CDLL(path, mode=C.RTLD_GLOBAL)
+            except OSError:
+                return
+
+
 def load_library():
     """Load libsplashsurf_hip.so (built in-tree by __graft_entry__.build()). Fails loudly if absent."""
     global _lib
     if _lib is not None:
         return _lib
+    _preload_hip_runtime()
     path = library_path()
     if not os.path.exists(path):
         raise ImportError(
