@@ -90,7 +90,7 @@ struct ss_context {
     DevBuf xyz_in, xyz_filt, flags32, offsets, keys_a, keys_b, vals_a, vals_b, cell_count, cell_start, pos_sorted, temp, aabb_partial, aabb_out,
         block_flag, block_rank, mc_flag, mc_rank, vcount, tcount, counter;
     // per-subdomain particle copies for the density stage
-    DevBuf member_count, copy_offset, sub_count, sub_flag, sub_rank, occ_sub, ckeys_a, ckeys_b, cvals_a, cidx, cpos, cell_count2, cell_start2;
+    DevBuf member_count, copy_offset, sub_flag, sub_rank, occ_sub, ckeys_a, ckeys_b, cvals_a, cidx, cpos, cell_count2, cell_start2;
     HostBuf h_small;
     hipEvent_t ev[12];
     bool ev_ok = false;
@@ -107,7 +107,7 @@ struct ss_result {
     uint64_t n_occupied_subdomains = 0, n_subdomain_particles = 0;
     ss_stats stats;
     // device results
-    DevBuf rho, posvol, perm, inside8, G, block_slot, active_list, mc_list, mc_slot, masks, vbase, tbase, vertices, vkeys, tri32, tri64;
+    DevBuf rho, posvol, perm, inside8, G, blk_minmax, block_slot, active_list, mc_list, mc_slot, masks, vbase, tbase, vertices, vkeys, tri32, tri64;
     // host mirrors
     HostBuf h_vertices, h_tri64, h_tri32, h_rho, h_vkeys, h_inside;
     bool hv = false, ht64 = false, ht32 = false, hrho = false, hkeys = false, hinside = false;
@@ -455,15 +455,12 @@ ss_status reconstruct_impl(ss_context* ctx, const float* xyz, uint64_t n_in, con
         const double ctot_d = (double)P.sc[0] * P.sc[1] * P.sc[2];
         SS_HIP(ctx, ctx->member_count.reserve(((size_t)n + 1) * 4));
         SS_HIP(ctx, ctx->copy_offset.reserve(((size_t)n + 1) * 4));
-        SS_HIP(ctx, ctx->sub_count.reserve((nsub + 1) * 4));
         SS_HIP(ctx, ctx->sub_flag.reserve((nsub + 1) * 4));
         SS_HIP(ctx, ctx->sub_rank.reserve((nsub + 1) * 4));
         SS_HIP(ctx, hipMemsetAsync(ctx->member_count.p, 0, ((size_t)n + 1) * 4, st));
-        SS_HIP(ctx, hipMemsetAsync(ctx->sub_count.p, 0, (nsub + 1) * 4, st));
         SS_HIP(ctx, hipMemsetAsync(ctx->sub_flag.p, 0, (nsub + 1) * 4, st));
         SS_HIP(ctx, hipMemsetAsync(res->rho.p, 0, (size_t)n * 4 + 16, st));  // vec![R::zero(); n], dense_subdomains.rs:504
-        ss_launch_classify_count(P, d_xyz, ctx->member_count.as<uint32_t>(), ctx->sub_count.as<uint32_t>(), st);
-        ss_launch_flag_nonzero(ctx->sub_count.as<uint32_t>(), (uint32_t)nsub, ctx->sub_flag.as<uint32_t>(), st);
+        ss_launch_classify_count(P, d_xyz, ctx->member_count.as<uint32_t>(), ctx->sub_flag.as<uint32_t>(), st);
         s = exclusive_scan_u32<uint32_t>(ctx, ctx->member_count.as<uint32_t>(), ctx->copy_offset.as<uint32_t>(), (size_t)n + 1);
         if (s != SS_OK) return s;
         s = exclusive_scan_u32<uint32_t>(ctx, ctx->sub_flag.as<uint32_t>(), ctx->sub_rank.as<uint32_t>(), nsub + 1);
@@ -508,7 +505,7 @@ ss_status reconstruct_impl(ss_context* ctx, const float* xyz, uint64_t n_in, con
     }
     SS_HIP(ctx, hipEventRecord(ctx->ev[4], st));
 
-    // ---- K3 prepare: active level-set blocks and MC blocks ----
+    // ---- K3 prepare: active level-set blocks ----
     SS_HIP(ctx, ctx->block_flag.reserve((nblocks + 1) * 4));
     SS_HIP(ctx, ctx->block_rank.reserve((nblocks + 1) * 4));
     SS_HIP(ctx, ctx->mc_flag.reserve((nblocks + 1) * 4));
@@ -518,33 +515,37 @@ ss_status reconstruct_impl(ss_context* ctx, const float* xyz, uint64_t n_in, con
     SS_HIP(ctx, hipMemsetAsync(ctx->block_flag.p, 0, (nblocks + 1) * 4, st));
     SS_HIP(ctx, hipMemsetAsync(ctx->mc_flag.p, 0, (nblocks + 1) * 4, st));
     if (n > 0) ss_launch_mark_blocks(P, ctx->cell_start.as<uint32_t>(), (uint32_t)ncells, ctx->block_flag.as<uint32_t>(), st);
-    ss_launch_mark_mc_blocks(P, ctx->block_flag.as<uint32_t>(), (uint32_t)nblocks, ctx->mc_flag.as<uint32_t>(), st);
     s = exclusive_scan_u32<uint32_t>(ctx, ctx->block_flag.as<uint32_t>(), ctx->block_rank.as<uint32_t>(), nblocks + 1);
     if (s != SS_OK) return s;
-    s = exclusive_scan_u32<uint32_t>(ctx, ctx->mc_flag.as<uint32_t>(), ctx->mc_rank.as<uint32_t>(), nblocks + 1);
-    if (s != SS_OK) return s;
-    uint32_t counts2[2] = {0, 0};
-    SS_HIP(ctx, hipMemcpyAsync(&counts2[0], ctx->block_rank.as<uint32_t>() + nblocks, 4, hipMemcpyDeviceToHost, st));
-    SS_HIP(ctx, hipMemcpyAsync(&counts2[1], ctx->mc_rank.as<uint32_t>() + nblocks, 4, hipMemcpyDeviceToHost, st));
+    uint32_t n_active = 0;
+    SS_HIP(ctx, hipMemcpyAsync(&n_active, ctx->block_rank.as<uint32_t>() + nblocks, 4, hipMemcpyDeviceToHost, st));
     SS_HIP(ctx, hipStreamSynchronize(st));
-    const uint32_t n_active = counts2[0], n_mc = counts2[1];
     res->n_active = n_active;
-    res->n_mc = n_mc;
     SS_HIP(ctx, res->active_list.reserve((size_t)n_active * 4 + 16));
-    SS_HIP(ctx, res->mc_list.reserve((size_t)n_mc * 4 + 16));
     SS_HIP(ctx, res->G.reserve((size_t)n_active * SS_BLOCK_POINTS * 4 + 16));
+    SS_HIP(ctx, res->blk_minmax.reserve((size_t)n_active * 8 + 16));
     ss_launch_compact_blocks(ctx->block_flag.as<uint32_t>(), ctx->block_rank.as<uint32_t>(), (uint32_t)nblocks, res->active_list.as<uint32_t>(),
                              res->block_slot.as<uint32_t>(), st);
-    ss_launch_compact_blocks(ctx->mc_flag.as<uint32_t>(), ctx->mc_rank.as<uint32_t>(), (uint32_t)nblocks, res->mc_list.as<uint32_t>(),
-                             res->mc_slot.as<uint32_t>(), st);
     SS_HIP(ctx, ctx->counter.reserve(64));
     SS_HIP(ctx, hipMemsetAsync(ctx->counter.p, 0, 64, st));
     SS_HIP(ctx, hipEventRecord(ctx->ev[5], st));
 
     // ---- K3: level-set splat ----
     ss_launch_splat(P, res->posvol.as<float4>(), res->perm.as<uint32_t>(), ctx->cell_start.as<uint32_t>(), res->active_list.as<uint32_t>(), n_active,
-                    res->G.as<float>(), ctx->counter.as<unsigned long long>(), st);
+                    res->G.as<float>(), res->blk_minmax.as<float2>(), ctx->counter.as<unsigned long long>(), st);
     SS_HIP(ctx, hipEventRecord(ctx->ev[6], st));
+
+    // ---- K4 prepare: MC blocks = blocks whose 2x2x2 level-set neighbourhood straddles the threshold ----
+    ss_launch_mark_mc_blocks(P, res->block_slot.as<uint32_t>(), res->blk_minmax.as<float2>(), (uint32_t)nblocks, ctx->mc_flag.as<uint32_t>(), st);
+    s = exclusive_scan_u32<uint32_t>(ctx, ctx->mc_flag.as<uint32_t>(), ctx->mc_rank.as<uint32_t>(), nblocks + 1);
+    if (s != SS_OK) return s;
+    uint32_t n_mc = 0;
+    SS_HIP(ctx, hipMemcpyAsync(&n_mc, ctx->mc_rank.as<uint32_t>() + nblocks, 4, hipMemcpyDeviceToHost, st));
+    SS_HIP(ctx, hipStreamSynchronize(st));
+    res->n_mc = n_mc;
+    SS_HIP(ctx, res->mc_list.reserve((size_t)n_mc * 4 + 16));
+    ss_launch_compact_blocks(ctx->mc_flag.as<uint32_t>(), ctx->mc_rank.as<uint32_t>(), (uint32_t)nblocks, res->mc_list.as<uint32_t>(),
+                             res->mc_slot.as<uint32_t>(), st);
 
     // ---- K4: MC classification + counts ----
     SS_HIP(ctx, res->masks.reserve((size_t)n_mc * 24 * 8 + 16));
@@ -632,7 +633,7 @@ ss_status download(ss_result* r, const DevBuf& d, HostBuf& h, bool& flag, size_t
 }
 
 void result_release(ss_result* r) {
-    for (DevBuf* b : {&r->rho, &r->posvol, &r->perm, &r->inside8, &r->G, &r->block_slot, &r->active_list, &r->mc_list, &r->mc_slot, &r->masks,
+    for (DevBuf* b : {&r->rho, &r->posvol, &r->perm, &r->inside8, &r->G, &r->blk_minmax, &r->block_slot, &r->active_list, &r->mc_list, &r->mc_slot, &r->masks,
                       &r->vbase, &r->tbase, &r->vertices, &r->vkeys, &r->tri32, &r->tri64})
         b->release();
     for (HostBuf* b : {&r->h_vertices, &r->h_tri64, &r->h_tri32, &r->h_rho, &r->h_vkeys, &r->h_inside}) b->release();
@@ -675,7 +676,7 @@ void ss_context_destroy(ss_context* c) {
     (void)hipDeviceSynchronize();
     for (DevBuf* b : {&c->xyz_in, &c->xyz_filt, &c->flags32, &c->offsets, &c->keys_a, &c->keys_b, &c->vals_a, &c->vals_b, &c->cell_count,
                       &c->cell_start, &c->pos_sorted, &c->temp, &c->aabb_partial, &c->aabb_out, &c->block_flag, &c->block_rank, &c->mc_flag,
-                      &c->mc_rank, &c->vcount, &c->tcount, &c->counter, &c->member_count, &c->copy_offset, &c->sub_count, &c->sub_flag, &c->sub_rank,
+                      &c->mc_rank, &c->vcount, &c->tcount, &c->counter, &c->member_count, &c->copy_offset, &c->sub_flag, &c->sub_rank,
                       &c->occ_sub, &c->ckeys_a, &c->ckeys_b, &c->cvals_a, &c->cidx, &c->cpos, &c->cell_count2, &c->cell_start2})
         b->release();
     c->h_small.release();

@@ -7,8 +7,7 @@ void ss_launch_inside_flags(const float* d_xyz, uint32_t n, const float amin[3],
 void ss_launch_compact_xyz(const float* d_xyz, uint32_t n, const uint32_t* f32, const uint32_t* offs, float* out, hipStream_t st);
 void ss_launch_cell_keys(const SSDev& P, const float* d_xyz, uint32_t* keys, uint32_t* vals, uint32_t* cell_count, hipStream_t st);
 void ss_launch_gather_sorted(uint32_t n, const float* d_xyz, const uint32_t* perm, float4* pos_sorted, hipStream_t st);
-void ss_launch_classify_count(const SSDev& P, const float* xyz, uint32_t* member_count, uint32_t* sub_count, hipStream_t st);
-void ss_launch_flag_nonzero(const uint32_t* in, uint32_t n, uint32_t* flag, hipStream_t st);
+void ss_launch_classify_count(const SSDev& P, const float* xyz, uint32_t* member_count, uint32_t* sub_flag, hipStream_t st);
 void ss_launch_occupied_list(const uint32_t* flag, const uint32_t* rank, uint32_t n, uint32_t* occ_sub, hipStream_t st);
 void ss_launch_emit_copies(const SSDev& P, const float* xyz, const uint32_t* copy_offset, const uint32_t* occ_rank, uint32_t* keys, uint32_t* vals,
                            uint32_t* cell_count, hipStream_t st);
@@ -16,10 +15,11 @@ void ss_launch_density_sub(const SSDev& P, uint32_t n_copies, const float4* cpos
                            const uint32_t* cell_start, const uint32_t* occ_sub, float* rho, hipStream_t st);
 void ss_launch_make_posvol(const SSDev& P, const float4* pos_sorted, const uint32_t* perm, const float* rho, float4* posvol, hipStream_t st);
 void ss_launch_mark_blocks(const SSDev& P, const uint32_t* cell_start, uint32_t ncells, uint32_t* block_flag, hipStream_t st);
-void ss_launch_mark_mc_blocks(const SSDev& P, const uint32_t* block_flag, uint32_t nblocks, uint32_t* mc_flag, hipStream_t st);
+void ss_launch_mark_mc_blocks(const SSDev& P, const uint32_t* block_slot, const float2* blk_minmax, uint32_t nblocks, uint32_t* mc_flag,
+                              hipStream_t st);
 void ss_launch_compact_blocks(const uint32_t* flag, const uint32_t* rank, uint32_t nblocks, uint32_t* list, uint32_t* slot, hipStream_t st);
 void ss_launch_splat(const SSDev& P, const float4* posvol, const uint32_t* perm, const uint32_t* cell_start, const uint32_t* active_list,
-                     uint32_t n_active, float* G, unsigned long long* cand_counter, hipStream_t st);
+                     uint32_t n_active, float* G, float2* blk_minmax, unsigned long long* cand_counter, hipStream_t st);
 void ss_launch_mc_count(const SSDev& P, const float* G, const uint32_t* block_slot, const uint32_t* mc_list, uint32_t n_mc,
                         unsigned long long* masks, uint32_t* vcount, uint32_t* tcount, hipStream_t st);
 void ss_launch_mc_emit(const SSDev& P, const float* G, const uint32_t* block_slot, const uint32_t* mc_list, const uint32_t* mc_slot,

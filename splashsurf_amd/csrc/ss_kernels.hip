@@ -235,22 +235,19 @@ __device__ inline int ss_local_search_cell_axis(const SSDev& P, int s, float x, 
     return max(0, min(P.sc[d] - 1, c));
 }
 
+// member_count[i] = number of subdomains particle i belongs to; sub_flag[s] = 1 for every subdomain with
+// at least one (owned or ghost) particle.  Plain flag stores (all writers store 1): no atomics.
 __global__ __launch_bounds__(256) void k_classify_count(SSDev P, const float* __restrict__ xyz, uint32_t* __restrict__ member_count,
-                                                        uint32_t* __restrict__ sub_count) {
+                                                        uint32_t* __restrict__ sub_flag) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= P.n) return;
     const float p[3] = {xyz[3 * (size_t)i], xyz[3 * (size_t)i + 1], xyz[3 * (size_t)i + 2]};
     uint32_t m = 0;
     ss_for_each_member_subdomain(P, p, [&](int sx, int sy, int sz) {
         ++m;
-        atomicAdd(&sub_count[((size_t)sx * P.ns[1] + sy) * P.ns[2] + sz], 1u);
+        sub_flag[((size_t)sx * P.ns[1] + sy) * P.ns[2] + sz] = 1u;
     });
     member_count[i] = m;
-}
-
-__global__ __launch_bounds__(256) void k_flag_nonzero(const uint32_t* __restrict__ in, uint32_t n, uint32_t* __restrict__ flag) {
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) flag[i] = in[i] ? 1u : 0u;
 }
 
 __global__ __launch_bounds__(256) void k_occupied_list(const uint32_t* __restrict__ flag, const uint32_t* __restrict__ rank, uint32_t n,
@@ -342,13 +339,9 @@ __global__ __launch_bounds__(256) void k_make_posvol(SSDev P, const float4* __re
     posvol[p] = make_float4(a.x, a.y, a.z, P.mass / rho[perm[p]]);
 }
 
-void ss_launch_classify_count(const SSDev& P, const float* xyz, uint32_t* member_count, uint32_t* sub_count, hipStream_t st) {
+void ss_launch_classify_count(const SSDev& P, const float* xyz, uint32_t* member_count, uint32_t* sub_flag, hipStream_t st) {
     if (!P.n) return;
-    hipLaunchKernelGGL(k_classify_count, dim3((P.n + 255) / 256), dim3(256), 0, st, P, xyz, member_count, sub_count);
-}
-void ss_launch_flag_nonzero(const uint32_t* in, uint32_t n, uint32_t* flag, hipStream_t st) {
-    if (!n) return;
-    hipLaunchKernelGGL(k_flag_nonzero, dim3((n + 255) / 256), dim3(256), 0, st, in, n, flag);
+    hipLaunchKernelGGL(k_classify_count, dim3((P.n + 255) / 256), dim3(256), 0, st, P, xyz, member_count, sub_flag);
 }
 void ss_launch_occupied_list(const uint32_t* flag, const uint32_t* rank, uint32_t n, uint32_t* occ_sub, hipStream_t st) {
     if (!n) return;
@@ -402,22 +395,34 @@ __global__ __launch_bounds__(256) void k_mark_blocks(SSDev P, const uint32_t* __
             for (int bz = blo[2]; bz <= bhi[2]; ++bz) block_flag[((size_t)bx * P.nb[1] + by) * P.nb[2] + bz] = 1u;
 }
 
-// MC works on blocks of cells whose origin point lies in block b; it reads the points of blocks b+{0,1}^3
-__global__ __launch_bounds__(256) void k_mark_mc_blocks(SSDev P, const uint32_t* __restrict__ block_flag, uint32_t nblocks,
-                                                        uint32_t* __restrict__ mc_flag) {
+// MC works on blocks of cells whose origin point lies in block b; it reads the points of blocks b+{0,1}^3.
+// A block can only produce triangles if those eight level-set blocks together hold values on both
+// sides of the threshold (absent blocks are all zero); blk_minmax comes from the splat kernel.
+__global__ __launch_bounds__(256) void k_mark_mc_blocks(SSDev P, const uint32_t* __restrict__ block_slot, const float2* __restrict__ blk_minmax,
+                                                        uint32_t nblocks, uint32_t* __restrict__ mc_flag) {
     uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= nblocks) return;
     int bz = (int)(b % (uint32_t)P.nb[2]);
     int by = (int)((b / (uint32_t)P.nb[2]) % (uint32_t)P.nb[1]);
     int bx = (int)(b / ((uint32_t)P.nb[2] * (uint32_t)P.nb[1]));
-    uint32_t f = 0;
+    bool any_in = false, any_out = false;
     for (int dx = 0; dx <= 1; ++dx)
         for (int dy = 0; dy <= 1; ++dy)
             for (int dz = 0; dz <= 1; ++dz) {
                 int x = bx + dx, y = by + dy, z = bz + dz;
-                if (x < P.nb[0] && y < P.nb[1] && z < P.nb[2]) f |= block_flag[((size_t)x * P.nb[1] + y) * P.nb[2] + z];
+                float mn = 0.0f, mx = 0.0f;
+                if (x < P.nb[0] && y < P.nb[1] && z < P.nb[2]) {
+                    const uint32_t slot = block_slot[((size_t)x * P.nb[1] + y) * P.nb[2] + z];
+                    if (slot != 0xFFFFFFFFu) {
+                        const float2 mm = blk_minmax[slot];
+                        mn = mm.x;
+                        mx = mm.y;
+                    }
+                }
+                any_in = any_in || (mx > P.threshold);
+                any_out = any_out || !(mn > P.threshold);
             }
-    mc_flag[b] = f ? 1u : 0u;
+    mc_flag[b] = (any_in && any_out) ? 1u : 0u;
 }
 
 __global__ __launch_bounds__(256) void k_compact_blocks(const uint32_t* __restrict__ flag, const uint32_t* __restrict__ rank, uint32_t nblocks,
@@ -437,9 +442,10 @@ void ss_launch_mark_blocks(const SSDev& P, const uint32_t* cell_start, uint32_t 
     if (!ncells) return;
     hipLaunchKernelGGL(k_mark_blocks, dim3((ncells + 255) / 256), dim3(256), 0, st, P, cell_start, ncells, block_flag);
 }
-void ss_launch_mark_mc_blocks(const SSDev& P, const uint32_t* block_flag, uint32_t nblocks, uint32_t* mc_flag, hipStream_t st) {
+void ss_launch_mark_mc_blocks(const SSDev& P, const uint32_t* block_slot, const float2* blk_minmax, uint32_t nblocks, uint32_t* mc_flag,
+                              hipStream_t st) {
     if (!nblocks) return;
-    hipLaunchKernelGGL(k_mark_mc_blocks, dim3((nblocks + 255) / 256), dim3(256), 0, st, P, block_flag, nblocks, mc_flag);
+    hipLaunchKernelGGL(k_mark_mc_blocks, dim3((nblocks + 255) / 256), dim3(256), 0, st, P, block_slot, blk_minmax, nblocks, mc_flag);
 }
 void ss_launch_compact_blocks(const uint32_t* flag, const uint32_t* rank, uint32_t nblocks, uint32_t* list, uint32_t* slot, hipStream_t st) {
     if (!nblocks) return;
@@ -539,7 +545,8 @@ __device__ inline void splat_for_each_candidate(SplatShared& s, const SSDev& P, 
 
 __global__ __launch_bounds__(512) void k_splat(SSDev P, const float4* __restrict__ posvol, const uint32_t* __restrict__ perm,
                                                const uint32_t* __restrict__ cell_start, const uint32_t* __restrict__ active_list,
-                                               uint32_t n_active, float* __restrict__ G, unsigned long long* __restrict__ cand_counter) {
+                                               uint32_t n_active, float* __restrict__ G, float2* __restrict__ blk_minmax,
+                                               unsigned long long* __restrict__ cand_counter) {
     __shared__ SplatShared s;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 
@@ -720,14 +727,38 @@ __global__ __launch_bounds__(512) void k_splat(SSDev P, const float4* __restrict
     const int ly = ((wave >> 1) & 1) * 4 + ((lane >> 2) & 3);
     const int lz = (wave & 1) * 4 + (lane & 3);
     const bool point_valid = gl[0] < P.np[0] && gl[1] < P.np[1] && gl[2] < P.np[2];
-    G[(size_t)logical * SS_BLOCK_POINTS + (size_t)((lx * 8 + ly) * 8 + lz)] = point_valid ? acc : 0.0f;
+    const float val = point_valid ? acc : 0.0f;
+    G[(size_t)logical * SS_BLOCK_POINTS + (size_t)((lx * 8 + ly) * 8 + lz)] = val;
+    // block-wide min/max of the level-set values (points outside the grid count as 0 = "outside"),
+    // used to skip marching cubes on blocks that cannot contain the iso-surface
+    float mn = val, mx = val;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        mn = fminf(mn, __shfl_xor(mn, off));
+        mx = fmaxf(mx, __shfl_xor(mx, off));
+    }
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(s.row_start);
+    if (lane == 0) {
+        red[wave] = mn;
+        red[8 + wave] = mx;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        for (int w = 1; w < 8; ++w) {
+            mn = fminf(mn, red[w]);
+            mx = fmaxf(mx, red[8 + w]);
+        }
+        blk_minmax[logical] = make_float2(mn, mx);
+    }
 }
 
 void ss_launch_splat(const SSDev& P, const float4* posvol, const uint32_t* perm, const uint32_t* cell_start, const uint32_t* active_list,
-                     uint32_t n_active, float* G, unsigned long long* cand_counter, hipStream_t st) {
+                     uint32_t n_active, float* G, float2* blk_minmax, unsigned long long* cand_counter, hipStream_t st) {
     if (!n_active) return;
     const uint32_t per_xcd = (n_active + 7u) / 8u;
-    hipLaunchKernelGGL(k_splat, dim3(per_xcd * 8u), dim3(512), 0, st, P, posvol, perm, cell_start, active_list, n_active, G, cand_counter);
+    hipLaunchKernelGGL(k_splat, dim3(per_xcd * 8u), dim3(512), 0, st, P, posvol, perm, cell_start, active_list, n_active, G, blk_minmax,
+                       cand_counter);
 }
 
 // =====================================================================================================
@@ -847,6 +878,7 @@ __global__ __launch_bounds__(512) void k_mc_emit(SSDev P, const float* __restric
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t m = blockIdx.x;
     if (m >= n_mc) return;
+    if (vbase[m + 1] == vbase[m] && tbase[m + 1] == tbase[m]) return;  // nothing to emit for this block
     const uint32_t b = mc_list[m];
     const int bz = (int)(b % (uint32_t)P.nb[2]);
     const int by = (int)((b / (uint32_t)P.nb[2]) % (uint32_t)P.nb[1]);
