@@ -106,7 +106,7 @@ def main():
         scale = 1.0 if args.workload == "s10m_tank" else 0.08
         pts = W.tank_slab_particles(rank, world, scale=scale, particle_radius=r)
         n_total = pts.shape[0] * world
-        sharded = D.ShardedReconstruction(ctx, prm, dev)
+        sharded = D.ShardedReconstruction(D.HipEngine(ctx, prm), dev)
         sharded.load_local_particles(pts)
 
         def step():

@@ -156,6 +156,33 @@ ss_status ss_result_levelset_box(ss_result *res, const int64_t lo[3], const int6
  * only needed to price the splat kernel in the reference's algorithmic bytes. */
 ss_status ss_result_subdomain_stats(ss_result *res, uint64_t *n_occupied_subdomains, uint64_t *n_subdomain_particles);
 
+/* -- multi-GPU extension (no counterpart in the single-process reference) --
+ * One process per GPU reconstructs a box of subdomains of ONE global grid.  The host (e.g.
+ * splashsurf_amd/distributed.py over torch.distributed/RCCL) hands each process every particle within
+ * the ghost margin of its box, in ascending GLOBAL particle order:
+ *   ss_shard_begin_f32   grid of the whole job from `domain_min/max` (AABB of all particles), binning,
+ *                        densities of the particles contained in the box's subdomains (others: 0);
+ *   [host exchanges densities: ss_shard_get_densities -> all-reduce -> ss_shard_set_densities]
+ *   ss_shard_finish      level set, marching cubes and numbering for the box; vertices on the box's
+ *                        faces are emitted by both neighbours with identical keys and coordinates.
+ * No other call may be made on the context between the two phases. */
+typedef struct ss_shard_f32 {
+    float domain_min[3]; /* AABB of ALL particles of the job, as Aabb3d::par_from_points would give (aabb.rs:28-52) */
+    float domain_max[3];
+    int64_t sub_lo[3];   /* half-open box of subdomain indices reconstructed by this process */
+    int64_t sub_hi[3];
+} ss_shard_f32;
+ss_status ss_shard_begin_f32(ss_context *ctx, const float *xyz, uint64_t n_particles, const ss_params_f32 *params,
+                             const ss_shard_f32 *shard, ss_result *inout);
+ss_status ss_shard_finish(ss_context *ctx, ss_result *inout);
+/* densities of the particles passed to ss_shard_begin_f32, in their order; dst/src may be host or device memory */
+ss_status ss_shard_get_densities(ss_result *res, float *dst, uint64_t n);
+ss_status ss_shard_set_densities(ss_result *res, const float *src, uint64_t n);
+/* host-only helper: global MC grid, subdomain grid and ghost margin for a given particle AABB
+ * (lib.rs:476-516 + dense_subdomains.rs:89-244); lets every rank derive the same partition */
+ss_status ss_grid_for_domain_f32(const ss_params_f32 *params, const float domain_min[3], const float domain_max[3],
+                                 ss_grid_f32 *grid, ss_grid_f32 *subdomain_grid, float *ghost_margin);
+
 #ifdef __cplusplus
 }
 #endif

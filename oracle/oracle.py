@@ -62,6 +62,10 @@ class SoResult(C.Structure):
     ]
 
 
+class SoShard(C.Structure):
+    _fields_ = [("domain_min", C.c_float * 3), ("domain_max", C.c_float * 3), ("sub_lo", C.c_int64 * 3), ("sub_hi", C.c_int64 * 3)]
+
+
 def build(force=False):
     """Compile the oracle with gcc (no GPU needed)."""
     if force or not os.path.exists(_LIB_PATH) or any(
@@ -94,6 +98,13 @@ def lib():
         L.so_mc_table.restype = C.POINTER(C.c_int8)
         L.so_classify_particle.argtypes = [C.POINTER(SoGrid), C.c_float, C.POINTER(C.c_float), C.POINTER(C.c_int64), C.c_int]
         L.so_classify_particle.restype = C.c_int
+        L.so_grid_for_domain.argtypes = [C.POINTER(SoParams), C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(SoGrid), C.POINTER(SoGrid),
+                                         C.POINTER(C.c_float)]
+        L.so_grid_for_domain.restype = C.c_int
+        L.so_shard_densities.argtypes = [C.c_void_p, C.c_uint64, C.POINTER(SoParams), C.POINTER(SoShard), C.c_void_p]
+        L.so_shard_densities.restype = C.c_int
+        L.so_shard_reconstruct.argtypes = [C.c_void_p, C.c_uint64, C.POINTER(SoParams), C.POINTER(SoShard), C.c_void_p, C.POINTER(SoResult)]
+        L.so_shard_reconstruct.restype = C.c_int
         _lib = L
     return _lib
 
@@ -141,12 +152,58 @@ class OracleResult:
     pass
 
 
+def _make_shard(domain_min, domain_max, sub_lo, sub_hi):
+    s = SoShard()
+    for d in range(3):
+        s.domain_min[d] = np.float32(domain_min[d])
+        s.domain_max[d] = np.float32(domain_max[d])
+        s.sub_lo[d] = int(sub_lo[d])
+        s.sub_hi[d] = int(sub_hi[d])
+    return s
+
+
+def grid_for_domain(params, domain_min, domain_max):
+    g, sg, m = SoGrid(), SoGrid(), C.c_float()
+    a = (C.c_float * 3)(*[float(np.float32(x)) for x in domain_min])
+    b = (C.c_float * 3)(*[float(np.float32(x)) for x in domain_max])
+    rc = lib().so_grid_for_domain(C.byref(params), a, b, C.byref(g), C.byref(sg), C.byref(m))
+    if rc != 0:
+        raise RuntimeError("so_grid_for_domain failed")
+    return _grid_dict(g), _grid_dict(sg), float(m.value)
+
+
+def shard_densities(xyz, params, domain_min, domain_max, sub_lo, sub_hi):
+    xyz = np.ascontiguousarray(xyz, dtype=np.float32).reshape(-1, 3)
+    rho = np.zeros(xyz.shape[0], dtype=np.float32)
+    s = _make_shard(domain_min, domain_max, sub_lo, sub_hi)
+    rc = lib().so_shard_densities(xyz.ctypes.data_as(C.c_void_p), xyz.shape[0], C.byref(params), C.byref(s), rho.ctypes.data_as(C.c_void_p))
+    if rc != 0:
+        raise RuntimeError("so_shard_densities failed with code %d" % rc)
+    return rho
+
+
+def shard_reconstruct(xyz, rho, params, domain_min, domain_max, sub_lo, sub_hi):
+    xyz = np.ascontiguousarray(xyz, dtype=np.float32).reshape(-1, 3)
+    rho = np.ascontiguousarray(rho, dtype=np.float32)
+    s = _make_shard(domain_min, domain_max, sub_lo, sub_hi)
+    res = SoResult()
+    rc = lib().so_shard_reconstruct(xyz.ctypes.data_as(C.c_void_p), xyz.shape[0], C.byref(params), C.byref(s), rho.ctypes.data_as(C.c_void_p),
+                                    C.byref(res))
+    if rc != 0:
+        raise RuntimeError("so_shard_reconstruct failed with code %d" % rc)
+    return _unpack(res)
+
+
 def reconstruct_surface(xyz, params):
     xyz = np.ascontiguousarray(xyz, dtype=np.float32).reshape(-1, 3)
     res = SoResult()
     rc = lib().so_reconstruct_surface(xyz.ctypes.data_as(C.c_void_p), xyz.shape[0], C.byref(params), C.byref(res))
     if rc != 0:
         raise RuntimeError("oracle so_reconstruct_surface failed with code %d" % rc)
+    return _unpack(res)
+
+
+def _unpack(res):
     out = OracleResult()
     try:
         nv, nt, n = int(res.n_vertices), int(res.n_triangles), int(res.n_particles)

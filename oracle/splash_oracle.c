@@ -142,6 +142,23 @@ static inline void grid_unflatten_cell(const so_grid *g, int64_t flat, int64_t i
 /* ------------------------------------------------------------------------------------------
  * Grid set-up (lib.rs:476-516, density_map.rs:551-580)
  * ------------------------------------------------------------------------------------------ */
+static int grid_for_particle_aabb(const float pmin[3], const float pmax[3], const so_params *P, so_grid *out) {
+    /* lib.rs:496-515 for a known particle AABB */
+    float amin[3], amax[3];
+    for (int d = 0; d < 3; ++d) {
+        amin[d] = pmin[d] - P->particle_radius;
+        amax[d] = pmax[d] + P->particle_radius;
+    }
+    float half_supported_cells_real = ceilf(P->compact_support_radius / P->cube_size);
+    const float eps_sqrt = sqrtf(1.1920929e-07f);
+    float kernel_margin = P->cube_size * half_supported_cells_real * (1.0f + eps_sqrt);
+    for (int d = 0; d < 3; ++d) {
+        amin[d] -= kernel_margin;
+        amax[d] += kernel_margin;
+    }
+    return grid_from_aabb(out, amin, amax, P->cube_size);
+}
+
 static int grid_for_reconstruction(const float *xyz, uint64_t n, const so_params *P, so_grid *out) {
     float amin[3], amax[3];
     if (P->has_particle_aabb) { /* lib.rs:484-485 */
@@ -273,7 +290,30 @@ static void subdomains_free(subdomains_t *s) {
     memset(s, 0, sizeof(*s));
 }
 
+/* optional restriction to a box of subdomains (multi-process shard); NULL = all */
+static int classify_particle_boxed(const so_grid *sg, float margin, const float p[3], int64_t *out, int cap, const int64_t *lo,
+                                   const int64_t *hi) {
+    int m = classify_particle(sg, margin, p, out, cap);
+    if (!lo) return m;
+    if (m > cap) m = cap;
+    int k = 0;
+    for (int q = 0; q < m; ++q) {
+        int64_t ijk[3];
+        grid_unflatten_cell(sg, out[q], ijk);
+        if (ijk[0] >= lo[0] && ijk[1] >= lo[1] && ijk[2] >= lo[2] && ijk[0] < hi[0] && ijk[1] < hi[1] && ijk[2] < hi[2]) out[k++] = out[q];
+    }
+    return k;
+}
+
+static int decomposition_boxed(const sd_params *S, const float *xyz, uint64_t n, subdomains_t *out, int nthreads, const int64_t *box_lo,
+                               const int64_t *box_hi);
+
 static int decomposition(const sd_params *S, const float *xyz, uint64_t n, subdomains_t *out, int nthreads) {
+    return decomposition_boxed(S, xyz, n, out, nthreads, NULL, NULL);
+}
+
+static int decomposition_boxed(const sd_params *S, const float *xyz, uint64_t n, subdomains_t *out, int nthreads, const int64_t *box_lo,
+                               const int64_t *box_hi) {
     const so_grid *sg = &S->subdomain_grid;
     int64_t total = sg->n_cells[0] * sg->n_cells[1] * sg->n_cells[2];
     int cap = 27;
@@ -298,7 +338,7 @@ static int decomposition(const sd_params *S, const float *xyz, uint64_t n, subdo
         if (hi > n) hi = n;
         uint64_t *c = counts + (size_t)t * (size_t)total;
         for (uint64_t i = lo; i < hi; ++i) {
-            int m = classify_particle(sg, S->ghost_margin, xyz + 3 * i, buf, cap);
+            int m = classify_particle_boxed(sg, S->ghost_margin, xyz + 3 * i, buf, cap, box_lo, box_hi);
             for (int q = 0; q < m; ++q) c[buf[q]]++;
         }
         free(buf);
@@ -347,7 +387,7 @@ static int decomposition(const sd_params *S, const float *xyz, uint64_t n, subdo
         if (hi > n) hi = n;
         uint64_t *c = counts + (size_t)t * (size_t)total;
         for (uint64_t i = lo; i < hi; ++i) {
-            int m = classify_particle(sg, S->ghost_margin, xyz + 3 * i, buf, cap);
+            int m = classify_particle_boxed(sg, S->ghost_margin, xyz + 3 * i, buf, cap, box_lo, box_hi);
             for (int q = 0; q < m; ++q) out->particles[c[buf[q]]++] = (uint32_t)i;
         }
         free(buf);
@@ -975,6 +1015,101 @@ int64_t so_debug_levelset_subdomain(const float *xyz, uint64_t n, const so_param
     free(rho);
     subdomains_free(&subs);
     return result;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Sharded variant (multi-process): same functions, restricted to a box of subdomains of the grid of
+ * the whole job.  Mirrors include/splashsurf_hip.h ss_shard_begin_f32 / ss_shard_finish.
+ * ------------------------------------------------------------------------------------------ */
+static int shard_setup(const so_params *P, const so_shard *sh, sd_params *S) {
+    if (P->has_particle_aabb) return 4;
+    so_grid initial;
+    if (grid_for_particle_aabb(sh->domain_min, sh->domain_max, P, &initial) != 0) return 1;
+    initialize_parameters(P, &initial, S);
+    for (int d = 0; d < 3; ++d)
+        if (sh->sub_lo[d] < 0 || sh->sub_hi[d] > S->subdomain_grid.n_cells[d] || sh->sub_lo[d] > sh->sub_hi[d]) return 4;
+    return 0;
+}
+
+int so_grid_for_domain(const so_params *P, const float dmin[3], const float dmax[3], so_grid *grid, so_grid *subgrid, float *margin) {
+    so_grid initial;
+    if (grid_for_particle_aabb(dmin, dmax, P, &initial) != 0) return 1;
+    sd_params S;
+    initialize_parameters(P, &initial, &S);
+    *grid = S.global_mc_grid;
+    *subgrid = S.subdomain_grid;
+    if (margin) *margin = S.ghost_margin;
+    return 0;
+}
+
+int so_shard_densities(const float *xyz, uint64_t n, const so_params *P, const so_shard *sh, float *rho_out) {
+    sd_params S;
+    int rc = shard_setup(P, sh, &S);
+    if (rc) return rc;
+    int nthreads = resolve_threads(P);
+    subdomains_t subs;
+    memset(&subs, 0, sizeof(subs));
+    if (decomposition_boxed(&S, xyz, n, &subs, nthreads, sh->sub_lo, sh->sub_hi) != 0) return 4;
+    memset(rho_out, 0, sizeof(float) * (size_t)n);
+    workspace_t *ws = (workspace_t *)calloc((size_t)nthreads, sizeof(workspace_t));
+#pragma omp parallel for schedule(dynamic, 1) num_threads(nthreads)
+    for (int64_t s = 0; s < subs.n_sub; ++s) {
+#ifdef _OPENMP
+        workspace_t *w = &ws[omp_get_thread_num()];
+#else
+        workspace_t *w = &ws[0];
+#endif
+        subdomain_density(&S, xyz, subs.particles + subs.offsets[s], (size_t)(subs.offsets[s + 1] - subs.offsets[s]), subs.flat_index[s], w,
+                          rho_out);
+    }
+    for (int t = 0; t < nthreads; ++t) ws_free(&ws[t]);
+    free(ws);
+    subdomains_free(&subs);
+    return 0;
+}
+
+int so_shard_reconstruct(const float *xyz, uint64_t n, const so_params *P, const so_shard *sh, const float *rho, so_result *out) {
+    memset(out, 0, sizeof(*out));
+    sd_params S;
+    int rc = shard_setup(P, sh, &S);
+    if (rc) return rc;
+    int nthreads = resolve_threads(P);
+    out->threads_used = nthreads;
+    out->n_input = out->n_particles = n;
+    out->grid = S.global_mc_grid;
+    out->subdomain_grid = S.subdomain_grid;
+    subdomains_t subs;
+    memset(&subs, 0, sizeof(subs));
+    if (decomposition_boxed(&S, xyz, n, &subs, nthreads, sh->sub_lo, sh->sub_hi) != 0) return 4;
+    out->n_subdomains = subs.n_sub;
+    out->n_subdomain_particles = subs.offsets[subs.n_sub];
+    workspace_t *ws = (workspace_t *)calloc((size_t)nthreads, sizeof(workspace_t));
+    patch_t *patches = (patch_t *)calloc((size_t)(subs.n_sub ? subs.n_sub : 1), sizeof(patch_t));
+    const int64_t np = S.subdomain_cubes + 1;
+#pragma omp parallel for schedule(dynamic, 1) num_threads(nthreads)
+    for (int64_t s = 0; s < subs.n_sub; ++s) {
+#ifdef _OPENMP
+        workspace_t *w = &ws[omp_get_thread_num()];
+#else
+        workspace_t *w = &ws[0];
+#endif
+        size_t P_s = (size_t)(subs.offsets[s + 1] - subs.offsets[s]);
+        gather_positions_densities(xyz, rho, subs.particles + subs.offsets[s], P_s, w);
+        ws_prepare_levelset(w, np);
+        int64_t sub[3];
+        grid_unflatten_cell(&S.subdomain_grid, subs.flat_index[s], sub);
+        density_grid_loop_scalar(&S, sub, w->pos, w->rho, P_s, w->levelset);
+        triangulate_subdomain(&S, sub, w, &patches[s]);
+    }
+    stitching(patches, subs.n_sub, out);
+    for (int64_t s = 0; s < subs.n_sub; ++s) patch_free(&patches[s]);
+    free(patches);
+    for (int t = 0; t < nthreads; ++t) ws_free(&ws[t]);
+    free(ws);
+    subdomains_free(&subs);
+    out->particle_densities = (float *)malloc(sizeof(float) * (size_t)(n ? n : 1));
+    memcpy(out->particle_densities, rho, sizeof(float) * (size_t)n);
+    return 0;
 }
 
 void so_result_free(so_result *r) {

@@ -76,6 +76,22 @@ const int8_t *so_mc_table(void);
 int so_classify_particle(const so_grid *subdomain_grid, float ghost_margin, const float p[3],
                          int64_t *out, int cap);
 
+/* ---- sharded (multi-process) variant used by the world_size-2 gloo tests: restatement of what
+ *      include/splashsurf_hip.h's ss_shard_* entry points compute, on the CPU ---- */
+typedef struct so_shard {
+    float domain_min[3]; /* AABB of all particles of the job */
+    float domain_max[3];
+    int64_t sub_lo[3];   /* half-open box of subdomain indices handled by this process */
+    int64_t sub_hi[3];
+} so_shard;
+int so_grid_for_domain(const so_params *params, const float domain_min[3], const float domain_max[3], so_grid *grid,
+                       so_grid *subdomain_grid, float *ghost_margin);
+/* densities of the particles whose subdomain lies in the box (others 0) */
+int so_shard_densities(const float *xyz, uint64_t n, const so_params *params, const so_shard *shard, float *rho_out);
+/* level set + MC + stitching of the box's subdomains given densities of all local particles */
+int so_shard_reconstruct(const float *xyz, uint64_t n, const so_params *params, const so_shard *shard, const float *rho,
+                         so_result *out);
+
 #ifdef __cplusplus
 }
 #endif

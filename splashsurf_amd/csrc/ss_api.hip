@@ -92,7 +92,7 @@ struct ss_context {
     // per-subdomain particle copies for the density stage
     DevBuf member_count, copy_offset, sub_flag, sub_rank, occ_sub, ckeys_a, ckeys_b, cvals_a, cidx, cpos, cell_count2, cell_start2;
     HostBuf h_small;
-    hipEvent_t ev[12];
+    hipEvent_t ev[12];  // 0..9 stage boundaries, 10/11 start of phase 2
     bool ev_ok = false;
 };
 
@@ -104,6 +104,8 @@ struct ss_result {
     bool has_inside = false;
     uint64_t n_input = 0, n_particles = 0, n_vertices = 0, n_triangles = 0;
     uint32_t n_active = 0, n_mc = 0;
+    int phase = 0;  // 0 nothing, 1 after phase_begin, 2 complete
+    bool host_input = false;
     uint64_t n_occupied_subdomains = 0, n_subdomain_particles = 0;
     ss_stats stats;
     // device results
@@ -246,7 +248,7 @@ ss_status validate_params(ss_context* ctx, const ss_params_f32* prm, uint64_t n)
 void reset_host_flags(ss_result* r) { r->hv = r->ht64 = r->ht32 = r->hrho = r->hkeys = r->hinside = false; }
 
 ss_status make_device_params(ss_context* ctx, const ss_params_f32* prm, const ss_grid_f32& g, const ss_grid_f32& sg, float mass, float margin,
-                             uint32_t n, SSDev* out) {
+                             uint32_t n, const ss_shard_f32* shard, SSDev* out) {
     SSDev P;
     memset(&P, 0, sizeof(P));
     const float h = prm->compact_support_radius;
@@ -288,6 +290,36 @@ ss_status make_device_params(ss_context* ctx, const ss_params_f32* prm, const ss
     if (ncells > 4.0e9 || nblocks > 4.0e9)
         return fail(ctx, SS_ERR_UNSUPPORTED, "domain too large for the dense cell/block tables of this build (> 4e9 search cells or level-set blocks)");
     P.n = n;
+    // shard region
+    bool full = true;
+    for (int d = 0; d < 3; ++d) {
+        int64_t lo = 0, hi = P.ns[d];
+        if (shard) {
+            lo = shard->sub_lo[d];
+            hi = shard->sub_hi[d];
+            if (lo < 0 || hi > P.ns[d] || lo > hi) return fail(ctx, SS_ERR_INVALID_ARGUMENT, "shard subdomain range outside the subdomain grid");
+        }
+        if (lo != 0 || hi != P.ns[d]) full = false;
+        P.sub_lo[d] = (int)lo;
+        P.sub_hi[d] = (int)hi;
+    }
+    if (!full && (P.n_sub_cubes % SS_BLOCK) != 0)
+        return fail(ctx, SS_ERR_UNSUPPORTED, "sharded reconstruction needs subdomain_num_cubes_per_dim to be a multiple of 8");
+    for (int d = 0; d < 3; ++d) {
+        if (P.sub_lo[d] >= P.sub_hi[d]) {  // empty shard: nothing to reconstruct
+            P.pt_lo[d] = 0;
+            P.pt_hi[d] = -1;
+            P.blk_lo[d] = 0;
+            P.blk_hi[d] = -1;
+            continue;
+        }
+        P.pt_lo[d] = P.sub_lo[d] * P.n_sub_cubes;
+        int hi = P.sub_hi[d] * P.n_sub_cubes;
+        if (hi > P.np[d] - 1) hi = P.np[d] - 1;
+        P.pt_hi[d] = hi;
+        P.blk_lo[d] = P.pt_lo[d] / SS_BLOCK;
+        P.blk_hi[d] = P.pt_hi[d] / SS_BLOCK;
+    }
     *out = P;
     return SS_OK;
 }
@@ -375,9 +407,14 @@ ss_status compute_particle_aabb(ss_context* ctx, const float* d_xyz, uint32_t n,
     return SS_OK;
 }
 
-ss_status reconstruct_impl(ss_context* ctx, const float* xyz, uint64_t n_in, const ss_params_f32* prm, ss_result* res) {
+ss_status phase_finish(ss_context* ctx, ss_result* res);
+
+// Phase 1: staging, grid, binning, densities.  `shard` == nullptr: the whole domain (single process).
+ss_status phase_begin(ss_context* ctx, const float* xyz, uint64_t n_in, const ss_params_f32* prm, const ss_shard_f32* shard, ss_result* res) {
     ss_status s = validate_params(ctx, prm, n_in);
     if (s != SS_OK) return s;
+    if (shard && prm->has_particle_aabb) return fail(ctx, SS_ERR_UNSUPPORTED, "particle_aabb cannot be combined with a shard descriptor");
+    res->phase = 0;
     SS_HIP(ctx, hipSetDevice(ctx->device));
     s = ensure_events(ctx);
     if (s != SS_OK) return s;
@@ -400,21 +437,28 @@ ss_status reconstruct_impl(ss_context* ctx, const float* xyz, uint64_t n_in, con
 
     // ---- grid set-up (lib.rs:409-417, reconstruction.rs:24-29) ----
     float pmin[3] = {0, 0, 0}, pmax[3] = {0, 0, 0};
-    if (!prm->has_particle_aabb && n > 0) {
+    if (shard) {
+        // multi-GPU: the grid is that of the WHOLE job; the caller supplies the AABB of all particles
+        for (int d = 0; d < 3; ++d) {
+            pmin[d] = shard->domain_min[d];
+            pmax[d] = shard->domain_max[d];
+        }
+    } else if (!prm->has_particle_aabb && n > 0) {
         s = compute_particle_aabb(ctx, d_xyz, n, pmin, pmax);
         if (s != SS_OK) return s;
     }
     ss_grid_f32 initial;
-    int gerr = grid_for_reconstruction(prm, n > 0, pmin, pmax, &initial);
+    int gerr = grid_for_reconstruction(prm, shard ? true : (n > 0), pmin, pmax, &initial);
     if (gerr) return fail(ctx, SS_ERR_GRID_CONSTRUCTION, "grid construction failed (uniform_grid.rs:147-169)", gerr);
     float mass = 0, margin = 0;
     initialize_subdomain_parameters(prm, &initial, &res->grid, &res->subgrid, &mass, &margin);
     for (int d = 0; d < 3; ++d)
         if (res->grid.n_points[d] > 2000000000ll) return fail(ctx, SS_ERR_GRID_CONSTRUCTION, "too many grid points per dimension", SS_GRID_INDEX_TYPE_TOO_SMALL);
     SSDev P;
-    s = make_device_params(ctx, prm, res->grid, res->subgrid, mass, margin, n, &P);
+    s = make_device_params(ctx, prm, res->grid, res->subgrid, mass, margin, n, shard, &P);
     if (s != SS_OK) return s;
     res->P = P;
+    res->host_input = host_input;
     SS_HIP(ctx, hipEventRecord(ctx->ev[2], st));
 
     const size_t ncells = (size_t)P.kdim[0] * P.kdim[1] * P.kdim[2];
@@ -501,9 +545,27 @@ ss_status reconstruct_impl(ss_context* ctx, const float* xyz, uint64_t n_in, con
             ss_launch_density_sub(P, n_copies, ctx->cpos.as<float4>(), ctx->cidx.as<uint32_t>(), ctx->ckeys_b.as<uint32_t>(),
                                   ctx->cell_start2.as<uint32_t>(), ctx->occ_sub.as<uint32_t>(), res->rho.as<float>(), st);
         }
-        ss_launch_make_posvol(P, ctx->pos_sorted.as<float4>(), res->perm.as<uint32_t>(), res->rho.as<float>(), res->posvol.as<float4>(), st);
     }
     SS_HIP(ctx, hipEventRecord(ctx->ev[4], st));
+    res->phase = 1;
+    return SS_OK;
+}
+
+// Phase 2: level set, marching cubes, numbering.  Uses res->rho as it is on the device NOW (a
+// multi-GPU host may have filled in the densities of halo particles between the phases).
+ss_status phase_finish(ss_context* ctx, ss_result* res) {
+    if (res->phase != 1) return fail(ctx, SS_ERR_INVALID_ARGUMENT, "ss_shard_finish without a preceding successful ss_shard_begin_f32");
+    SS_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    ss_status s = SS_OK;
+    const SSDev P = res->P;
+    const uint32_t n = P.n;
+    const bool host_input = res->host_input;
+    const size_t ncells = (size_t)P.kdim[0] * P.kdim[1] * P.kdim[2];
+    const size_t nblocks = (size_t)P.nb[0] * P.nb[1] * P.nb[2];
+    SS_HIP(ctx, hipEventRecord(ctx->ev[10], st));
+    ss_launch_make_posvol(P, ctx->pos_sorted.as<float4>(), res->perm.as<uint32_t>(), res->rho.as<float>(), res->posvol.as<float4>(), st);
+    SS_HIP(ctx, hipEventRecord(ctx->ev[11], st));
 
     // ---- K3 prepare: active level-set blocks ----
     SS_HIP(ctx, ctx->block_flag.reserve((nblocks + 1) * 4));
@@ -589,12 +651,12 @@ ss_status reconstruct_impl(ss_context* ctx, const float* xyz, uint64_t n_in, con
     res->n_vertices = nv;
     res->n_triangles = nt;
     ss_stats& S = res->stats;
-    S.ms_total = ev_ms(ctx, 0, 9);
+    S.ms_total = ev_ms(ctx, 0, 4) + ev_ms(ctx, 10, 9);  // both phases (excludes what the host does between them)
     S.ms_upload = host_input ? ev_ms(ctx, 0, 1) : 0.0;
     S.ms_aabb_grid = ev_ms(ctx, 1, 2);
     S.ms_decomposition = ev_ms(ctx, 2, 3);
-    S.ms_density = ev_ms(ctx, 3, 4);
-    S.ms_levelset_prepare = ev_ms(ctx, 4, 5);
+    S.ms_density = ev_ms(ctx, 3, 4) + ev_ms(ctx, 10, 11);
+    S.ms_levelset_prepare = ev_ms(ctx, 11, 5);
     S.ms_levelset = ev_ms(ctx, 5, 6);
     S.ms_marching_cubes = ev_ms(ctx, 6, 7) + ev_ms(ctx, 8, 9);
     S.ms_stitching = ev_ms(ctx, 7, 8);
@@ -615,7 +677,14 @@ ss_status reconstruct_impl(ss_context* ctx, const float* xyz, uint64_t n_in, con
         held += b->cap;
     S.bytes_device_peak = held;
     res->valid = true;
+    res->phase = 2;
     return SS_OK;
+}
+
+ss_status reconstruct_impl(ss_context* ctx, const float* xyz, uint64_t n_in, const ss_params_f32* prm, ss_result* res) {
+    ss_status s = phase_begin(ctx, xyz, n_in, prm, nullptr, res);
+    if (s != SS_OK) return s;
+    return phase_finish(ctx, res);
 }
 
 template <class T>
@@ -735,6 +804,58 @@ ss_status ss_reconstruct_surface_f32(ss_context* c, const float* xyz, uint64_t n
         return s;
     }
     *out = r;
+    return SS_OK;
+}
+
+ss_status ss_shard_begin_f32(ss_context* c, const float* xyz, uint64_t n, const ss_params_f32* prm, const ss_shard_f32* shard, ss_result* inout) {
+    if (!c || !inout || !shard) return SS_ERR_INVALID_ARGUMENT;
+    if (inout->ctx != c) return fail(c, SS_ERR_INVALID_ARGUMENT, "result belongs to a different context");
+    c->err.clear();
+    c->err_detail = 0;
+    return phase_begin(c, xyz, n, prm, shard, inout);
+}
+
+ss_status ss_shard_finish(ss_context* c, ss_result* inout) {
+    if (!c || !inout) return SS_ERR_INVALID_ARGUMENT;
+    if (inout->ctx != c) return fail(c, SS_ERR_INVALID_ARGUMENT, "result belongs to a different context");
+    c->err.clear();
+    return phase_finish(c, inout);
+}
+
+ss_status ss_shard_get_densities(ss_result* r, float* dst, uint64_t n) {
+    if (!r || r->phase < 1 || (!dst && n)) return SS_ERR_INVALID_ARGUMENT;
+    ss_context* c = r->ctx;
+    if (n != r->n_particles) return fail(c, SS_ERR_INVALID_ARGUMENT, "density count mismatch");
+    if (!n) return SS_OK;
+    SS_HIP(c, hipSetDevice(c->device));
+    SS_HIP(c, hipMemcpyAsync(dst, r->rho.p, n * 4, hipMemcpyDefault, c->stream));
+    SS_HIP(c, hipStreamSynchronize(c->stream));
+    return SS_OK;
+}
+
+ss_status ss_shard_set_densities(ss_result* r, const float* src, uint64_t n) {
+    if (!r || r->phase != 1 || (!src && n)) return SS_ERR_INVALID_ARGUMENT;
+    ss_context* c = r->ctx;
+    if (n != r->n_particles) return fail(c, SS_ERR_INVALID_ARGUMENT, "density count mismatch");
+    if (!n) return SS_OK;
+    SS_HIP(c, hipSetDevice(c->device));
+    SS_HIP(c, hipMemcpyAsync(r->rho.p, src, n * 4, hipMemcpyDefault, c->stream));
+    SS_HIP(c, hipStreamSynchronize(c->stream));
+    r->hrho = false;
+    return SS_OK;
+}
+
+ss_status ss_grid_for_domain_f32(const ss_params_f32* prm, const float domain_min[3], const float domain_max[3], ss_grid_f32* grid,
+                                 ss_grid_f32* subdomain_grid, float* ghost_margin) {
+    if (!prm || !domain_min || !domain_max || !grid || !subdomain_grid) return SS_ERR_INVALID_ARGUMENT;
+    if (!(prm->cube_size > 0.0f) || !(prm->compact_support_radius > 0.0f) || prm->subdomain_num_cubes_per_dim < 1) return SS_ERR_UNKNOWN;
+    ss_params_f32 p = *prm;
+    p.has_particle_aabb = 0;
+    ss_grid_f32 initial;
+    if (grid_for_reconstruction(&p, true, domain_min, domain_max, &initial)) return SS_ERR_GRID_CONSTRUCTION;
+    float mass = 0, margin = 0;
+    initialize_subdomain_parameters(&p, &initial, grid, subdomain_grid, &mass, &margin);
+    if (ghost_margin) *ghost_margin = margin;
     return SS_OK;
 }
 

@@ -42,6 +42,10 @@ struct SSDev {
     int kdim[3];
     // level-set blocks
     int nb[3];
+    // shard (multi-GPU): this process reconstructs the subdomains [sub_lo, sub_hi) only.  Full domain: [0, ns).
+    int sub_lo[3], sub_hi[3];
+    int pt_lo[3], pt_hi[3];      // grid points of the shard region, inclusive: [sub_lo*n, min(np-1, sub_hi*n)]
+    int blk_lo[3], blk_hi[3];    // level-set blocks covering those points, inclusive
     uint32_t n;  // particle count (after the AABB filter)
 };
 

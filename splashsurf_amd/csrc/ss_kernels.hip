@@ -221,6 +221,8 @@ __device__ inline void ss_for_each_member_subdomain(const SSDev& P, const float 
                 if (!in_margin) continue;
                 const int nx = sub[0] + i0, ny = sub[1] + j0, nz = sub[2] + k0;
                 if (nx < 0 || ny < 0 || nz < 0 || nx >= P.ns[0] || ny >= P.ns[1] || nz >= P.ns[2]) continue;  // :1895-1900
+                // multi-GPU shard: only the subdomains this process reconstructs
+                if (nx < P.sub_lo[0] || ny < P.sub_lo[1] || nz < P.sub_lo[2] || nx >= P.sub_hi[0] || ny >= P.sub_hi[1] || nz >= P.sub_hi[2]) continue;
                 f(nx, ny, nz);
             }
 }
@@ -387,8 +389,9 @@ __global__ __launch_bounds__(256) void k_mark_blocks(SSDev P, const uint32_t* __
         if (i_lo < 0) i_lo = 0;
         if (i_hi > P.np[d] - 1) i_hi = P.np[d] - 1;
         if (i_lo > i_hi) return;
-        blo[d] = (int)(i_lo / SS_BLOCK);
-        bhi[d] = (int)(i_hi / SS_BLOCK);
+        blo[d] = max((int)(i_lo / SS_BLOCK), P.blk_lo[d]);
+        bhi[d] = min((int)(i_hi / SS_BLOCK), P.blk_hi[d]);
+        if (blo[d] > bhi[d]) return;
     }
     for (int bx = blo[0]; bx <= bhi[0]; ++bx)
         for (int by = blo[1]; by <= bhi[1]; ++by)
@@ -405,6 +408,10 @@ __global__ __launch_bounds__(256) void k_mark_mc_blocks(SSDev P, const uint32_t*
     int bz = (int)(b % (uint32_t)P.nb[2]);
     int by = (int)((b / (uint32_t)P.nb[2]) % (uint32_t)P.nb[1]);
     int bx = (int)(b / ((uint32_t)P.nb[2] * (uint32_t)P.nb[1]));
+    if (bx < P.blk_lo[0] || by < P.blk_lo[1] || bz < P.blk_lo[2] || bx > P.blk_hi[0] || by > P.blk_hi[1] || bz > P.blk_hi[2]) {
+        mc_flag[b] = 0u;
+        return;
+    }
     bool any_in = false, any_out = false;
     for (int dx = 0; dx <= 1; ++dx)
         for (int dy = 0; dy <= 1; ++dy)
@@ -801,14 +808,15 @@ __device__ inline McLocal mc_classify(const McTile& t, const SSDev& P, int bx, i
     L.gx = bx * SS_BLOCK + lx;
     L.gy = by * SS_BLOCK + ly;
     L.gz = bz * SS_BLOCK + lz;
-    const bool point_exists = L.gx < P.np[0] && L.gy < P.np[1] && L.gz < P.np[2];
+    // points / edges / cells of the shard region only (full domain: pt_hi = np - 1)
+    const bool point_exists = L.gx <= P.pt_hi[0] && L.gy <= P.pt_hi[1] && L.gz <= P.pt_hi[2];
     const float thr = P.threshold;
     const bool in0 = t.g[(lx * 9 + ly) * 9 + lz] > thr;  // dense_subdomains.rs:1482 (strict >)
-    L.cross[0] = point_exists && (L.gx + 1 < P.np[0]) && (in0 != (t.g[((lx + 1) * 9 + ly) * 9 + lz] > thr));
-    L.cross[1] = point_exists && (L.gy + 1 < P.np[1]) && (in0 != (t.g[(lx * 9 + ly + 1) * 9 + lz] > thr));
-    L.cross[2] = point_exists && (L.gz + 1 < P.np[2]) && (in0 != (t.g[(lx * 9 + ly) * 9 + lz + 1] > thr));
+    L.cross[0] = point_exists && (L.gx + 1 <= P.pt_hi[0]) && (in0 != (t.g[((lx + 1) * 9 + ly) * 9 + lz] > thr));
+    L.cross[1] = point_exists && (L.gy + 1 <= P.pt_hi[1]) && (in0 != (t.g[(lx * 9 + ly + 1) * 9 + lz] > thr));
+    L.cross[2] = point_exists && (L.gz + 1 <= P.pt_hi[2]) && (in0 != (t.g[(lx * 9 + ly) * 9 + lz + 1] > thr));
     L.case_index = 0;
-    const bool cell_exists = L.gx < P.nc[0] && L.gy < P.nc[1] && L.gz < P.nc[2];
+    const bool cell_exists = L.gx < P.pt_hi[0] && L.gy < P.pt_hi[1] && L.gz < P.pt_hi[2];
     if (cell_exists) {
 #pragma unroll
         for (int c = 0; c < 8; ++c) {

@@ -1,0 +1,239 @@
+"""Multi-GPU surface reconstruction: one process per GPU, torch.distributed (backend "nccl" = RCCL over
+xGMI on the GPU box, "gloo" in the CPU tests).
+
+The reference is single-process; its only natural decomposition is the uniform grid of subdomains
+(SURVEY.md section 8e).  Here the subdomain grid of ONE global domain is cut into contiguous slabs
+along its longest axis, balanced by particle count:
+
+  1. all-gather of particle positions (every rank ends up with the same global array, in global
+     particle order = concatenation by rank -- the summation order of the level set depends on it);
+  2. every rank derives the same global grid and the same slab partition from that array;
+  3. rank r selects the particles within the ghost margin of its slab (ascending global order) and
+     runs phase 1 of the engine: binning + densities of the particles CONTAINED in its slab;
+  4. density exchange: each rank scatters its owned densities into a zero-initialised global vector;
+     one all-reduce(SUM) completes it (every entry has exactly one non-zero contribution, so the sum is
+     exact and the densities stay bit-identical to a single-process run);
+  5. phase 2: level set + marching cubes for the slab.  Vertices on slab faces are produced by both
+     neighbours with identical global edge keys and identical coordinates; `gather_mesh` removes the
+     duplicates by key.
+
+The per-rank engine is pluggable: `HipEngine` drives the C ABI (ss_shard_begin_f32 / ss_shard_finish),
+the CPU tests plug in the oracle (tests/test_distributed.py).
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+
+class ShardDesc:
+    def __init__(self, domain_min, domain_max, sub_lo, sub_hi):
+        self.domain_min = np.asarray(domain_min, dtype=np.float32)
+        self.domain_max = np.asarray(domain_max, dtype=np.float32)
+        self.sub_lo = [int(x) for x in sub_lo]
+        self.sub_hi = [int(x) for x in sub_hi]
+
+
+class _Shard(C.Structure):
+    _fields_ = [("domain_min", C.c_float * 3), ("domain_max", C.c_float * 3), ("sub_lo", C.c_int64 * 3), ("sub_hi", C.c_int64 * 3)]
+
+
+class HipEngine:
+    """Per-rank engine on the HIP library (device tensors in, device-resident mesh out)."""
+
+    def __init__(self, ctx, params):
+        from . import api
+        self.api = api
+        self.ctx = ctx
+        self.params = params
+        self.lib = ctx._lib
+        self.lib.ss_shard_begin_f32.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(api._Params), C.POINTER(_Shard), C.c_void_p]
+        self.lib.ss_shard_finish.argtypes = [C.c_void_p, C.c_void_p]
+        self.lib.ss_shard_get_densities.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
+        self.lib.ss_shard_set_densities.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
+        self.lib.ss_grid_for_domain_f32.argtypes = [C.POINTER(api._Params), C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(api._Grid),
+                                                    C.POINTER(api._Grid), C.POINTER(C.c_float)]
+        h = C.c_void_p()
+        st = self.lib.ss_result_create(ctx._h, C.byref(h))
+        if st != 0:
+            ctx._raise(st)
+        self.result = api.SurfaceReconstruction(ctx, h)
+
+    def grid_for_domain(self, dmin, dmax):
+        p = self.params._c()
+        g, sg, m = self.api._Grid(), self.api._Grid(), C.c_float()
+        a = (C.c_float * 3)(*[float(x) for x in dmin])
+        b = (C.c_float * 3)(*[float(x) for x in dmax])
+        st = self.lib.ss_grid_for_domain_f32(C.byref(p), a, b, C.byref(g), C.byref(sg), C.byref(m))
+        if st != 0:
+            raise RuntimeError("ss_grid_for_domain_f32 failed: %d" % st)
+        return (np.array(list(g.aabb_min), np.float32), float(sg.cell_size), [int(x) for x in sg.n_cells], float(m.value),
+                int(self.params.subdomain_num_cubes_per_dim))
+
+    def _shard(self, sd):
+        s = _Shard()
+        for d in range(3):
+            s.domain_min[d] = float(sd.domain_min[d])
+            s.domain_max[d] = float(sd.domain_max[d])
+            s.sub_lo[d] = sd.sub_lo[d]
+            s.sub_hi[d] = sd.sub_hi[d]
+        return s
+
+    def begin(self, local_pts, shard):
+        """local_pts: contiguous float32 (n,3) tensor on this rank's device. Returns densities (owned computed, others 0)."""
+        if local_pts.is_cuda:
+            torch.cuda.current_stream(local_pts.device).synchronize()
+        p = self.params._c()
+        s = self._shard(shard)
+        n = int(local_pts.shape[0])
+        st = self.lib.ss_shard_begin_f32(self.ctx._h, C.c_void_p(local_pts.data_ptr()), n, C.byref(p), C.byref(s), self.result._h)
+        if st != 0:
+            self.ctx._raise(st)
+        self.result._invalidate()
+        rho = torch.empty(n, dtype=torch.float32, device=local_pts.device)
+        st = self.lib.ss_shard_get_densities(self.result._h, C.c_void_p(rho.data_ptr()), n)
+        if st != 0:
+            self.ctx._raise(st)
+        return rho
+
+    def finish(self, rho):
+        if rho.is_cuda:
+            torch.cuda.current_stream(rho.device).synchronize()
+        st = self.lib.ss_shard_set_densities(self.result._h, C.c_void_p(rho.data_ptr()), int(rho.shape[0]))
+        if st != 0:
+            self.ctx._raise(st)
+        st = self.lib.ss_shard_finish(self.ctx._h, self.result._h)
+        if st != 0:
+            self.ctx._raise(st)
+        self.result._invalidate()
+        return self.result
+
+
+def partition_slabs(coords_axis, gmin_axis, sub_size, ns_axis, world):
+    """Contiguous slabs of subdomain indices along one axis, balanced by owner-particle counts.
+    Deterministic given identical inputs on all ranks. Returns list of (lo, hi)."""
+    s = torch.floor((coords_axis - gmin_axis) / sub_size).to(torch.int64).clamp_(0, ns_axis - 1)
+    hist = torch.bincount(s, minlength=ns_axis).to(torch.float64).cpu().numpy()
+    cum = np.concatenate([[0.0], np.cumsum(hist)])
+    total = cum[-1]
+    bounds = [0]
+    for r in range(1, world):
+        target = total * r / world
+        k = int(np.searchsorted(cum, target, side="left"))
+        # choose the boundary (k-1 or k) closest to the target, keep bounds monotone and leave room for the rest
+        if k > 0 and abs(cum[k - 1] - target) <= abs(cum[min(k, ns_axis)] - target):
+            k -= 1
+        k = max(k, bounds[-1])
+        k = min(k, ns_axis)
+        bounds.append(k)
+    bounds.append(ns_axis)
+    return [(bounds[r], bounds[r + 1]) for r in range(world)]
+
+
+class ShardedStepResult:
+    def __init__(self, local, shard, ids, n_total, timings):
+        self.local = local          # engine result of this rank (SurfaceReconstruction-like)
+        self.shard = shard
+        self.ids = ids              # global particle ids of the local particle set
+        self.n_total = n_total
+        self.timings = timings
+
+    @property
+    def stats(self):
+        return self.local.stats
+
+    def subdomain_stats(self):
+        return self.local.subdomain_stats()
+
+
+class ShardedReconstruction:
+    def __init__(self, engine, device, group=None):
+        self.engine = engine
+        self.device = torch.device(device)
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.local = None
+
+    def load_local_particles(self, pts):
+        """The particles this rank contributes (its share of the input), float32 (n,3)."""
+        t = torch.as_tensor(np.ascontiguousarray(pts, dtype=np.float32)) if not torch.is_tensor(pts) else pts
+        self.local = t.to(self.device).contiguous()
+
+    # -- collectives (padded all-gather so that ranks may hold different counts) --
+    def _all_gather_rows(self, t):
+        if self.world == 1:
+            return t, [int(t.shape[0])]
+        n = torch.tensor([t.shape[0]], dtype=torch.int64, device=self.device)
+        counts = [torch.zeros_like(n) for _ in range(self.world)]
+        dist.all_gather(counts, n, group=self.group)
+        counts = [int(c.item()) for c in counts]
+        m = max(counts)
+        pad = torch.zeros((m,) + tuple(t.shape[1:]), dtype=t.dtype, device=self.device)
+        pad[: t.shape[0]] = t
+        out = torch.empty((self.world * m,) + tuple(t.shape[1:]), dtype=t.dtype, device=self.device)
+        dist.all_gather_into_tensor(out, pad, group=self.group)
+        parts = [out[r * m: r * m + counts[r]] for r in range(self.world)]
+        return torch.cat(parts, dim=0).contiguous(), counts
+
+    def step(self):
+        eng = self.engine
+        # 1. global particle array (global order = concatenation by rank)
+        P_all, counts = self._all_gather_rows(self.local)
+        n_total = int(P_all.shape[0])
+        # 2. global grid + slab partition (identical on every rank)
+        dmin = P_all.min(dim=0).values.cpu().numpy() if n_total else np.zeros(3, np.float32)
+        dmax = P_all.max(dim=0).values.cpu().numpy() if n_total else np.zeros(3, np.float32)
+        gmin, sub_size, ns, margin, n_cubes = eng.grid_for_domain(dmin, dmax)
+        axis = int(np.argmax(ns))
+        slabs = partition_slabs(P_all[:, axis], float(gmin[axis]), sub_size, ns[axis], self.world) if n_total else [(0, ns[axis])] * self.world
+        lo, hi = slabs[self.rank]
+        sub_lo, sub_hi = [0, 0, 0], list(ns)
+        sub_lo[axis], sub_hi[axis] = lo, hi
+        shard = ShardDesc(dmin, dmax, sub_lo, sub_hi)
+        # 3. local particle set: everything within the ghost margin of the slab (conservative interval; the
+        #    engine applies the exact membership rule), ascending global id
+        pad = margin * 1.001 + 1e-6 * max(1.0, float(np.abs(gmin).max()))
+        c_lo = float(gmin[axis]) + lo * sub_size - pad
+        c_hi = float(gmin[axis]) + hi * sub_size + pad
+        if hi > lo and n_total:
+            mask = (P_all[:, axis] >= c_lo) & (P_all[:, axis] <= c_hi)
+            ids = torch.nonzero(mask, as_tuple=False).squeeze(1)
+        else:
+            ids = torch.zeros(0, dtype=torch.int64, device=self.device)
+        L = P_all.index_select(0, ids).contiguous()
+        # 4. phase 1 + density exchange
+        rho_local = eng.begin(L, shard)
+        rho_global = torch.zeros(n_total, dtype=torch.float32, device=self.device)
+        rho_global.index_copy_(0, ids, rho_local)
+        if self.world > 1:
+            dist.all_reduce(rho_global, op=dist.ReduceOp.SUM, group=self.group)
+        rho_local = rho_global.index_select(0, ids).contiguous()
+        # 5. phase 2
+        res = eng.finish(rho_local)
+        self.rho_global = rho_global
+        return ShardedStepResult(res, shard, ids, n_total, {})
+
+    # -- result assembly (tests / consumers that want one mesh) --
+    def gather_mesh(self, step_result):
+        """All ranks: returns (vertices, keys, triangles) of the merged mesh on rank 0 (None elsewhere).
+        Duplicated face vertices are removed by global edge key; the lowest rank's copy is kept."""
+        r = step_result.local
+        v = torch.as_tensor(np.ascontiguousarray(r.mesh.vertices, dtype=np.float32)).to(self.device)
+        k = torch.as_tensor(np.ascontiguousarray(r.vertex_keys).astype(np.int64)).to(self.device)
+        t = torch.as_tensor(np.ascontiguousarray(r.mesh.triangles).astype(np.int64)).to(self.device)
+        V, vc = self._all_gather_rows(v)
+        K, _ = self._all_gather_rows(k)
+        T, tc = self._all_gather_rows(t)
+        if self.rank != 0:
+            return None
+        V, K, T = V.cpu().numpy(), K.cpu().numpy(), T.cpu().numpy()
+        # offset triangle indices by the rank's vertex offset
+        voff = np.concatenate([[0], np.cumsum(vc)])
+        toff = np.concatenate([[0], np.cumsum(tc)])
+        for q in range(len(vc)):
+            T[toff[q]:toff[q + 1]] += voff[q]
+        uk, first = np.unique(K, return_index=True)      # first occurrence = lowest rank
+        remap = np.searchsorted(uk, K)
+        return V[first], uk.astype(np.uint64), remap[T].astype(np.uint64)

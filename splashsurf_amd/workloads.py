@@ -32,9 +32,10 @@ def tank_particles(scale=1.0, particle_radius=0.005):
 
 def tank_slab_particles(rank, world, scale=1.0, particle_radius=0.005):
     """Weak-scaling variant for multi-GPU runs: rank `rank` of `world` gets its own copy of the tank,
-    translated along y by rank * (tank height + 2 * support) so that the union is one big domain."""
+    translated along y by rank * tank height so that the union is one tall fluid column."""
     p = tank_particles(scale, particle_radius)
-    height = 2.0 * scale + 8.0 * particle_radius * 2
+    # tanks are stacked seamlessly (height = ny * spacing), so neighbouring ranks share real halos
+    height = max(1, round(200 * scale)) * 2.0 * particle_radius
     p[:, 1] += np.float32(rank * height)
     return p
 

@@ -7,6 +7,7 @@ reference's own output the comparison allows 1e-5 relative on vertex coordinates
 only absorbs the reference's order-dependent choice of coordinates for vertices on subdomain faces.
 """
 import hashlib
+import os
 
 import numpy as np
 import pytest
@@ -214,3 +215,58 @@ def test_dense_cloud_exceeding_tile_capacity(gpu_ctx, oracle):
     _, orc = run_oracle(oracle, pts, prm)
     assert res.stats["n_block_candidates"] > res.stats["n_active_blocks"] * 2048
     assert_gpu_equals_oracle(res, orc)
+
+
+@pytest.mark.parametrize("case", [("double_dam_break_frame_26_4732_particles.npy", 0.025, 2.0, 1.1, 16, 2),
+                                  ("hilbert_46843_particles.npy", 0.025, 2.0, 0.9, 32, 3)])
+def test_sharded_engine_reproduces_full_reconstruction(oracle, case):
+    """The multi-GPU path on ONE GPU: k pseudo-ranks (one HIP context each) reconstruct slabs of subdomains
+    through ss_shard_begin_f32 / ss_shard_finish with the density exchange done by hand; the merged
+    result must equal the single-process oracle bit for bit."""
+    import torch
+    from splashsurf_amd import distributed as D
+    from splashsurf_amd.api import Context, Parameters
+    fn, r, l, c, n_cubes, k = case
+    pts = np.load(os.path.join(os.path.dirname(__file__), "data", fn))
+    prm = Parameters(particle_radius=r, compact_support_radius=np.float32(2.0 * l * r), cube_size=np.float32(c * r),
+                     subdomain_num_cubes_per_dim=n_cubes, auto_disable=False)
+    engines = [D.HipEngine(Context(0), prm) for _ in range(k)]
+    P_all = torch.from_numpy(pts).to("cuda:0")
+    dmin, dmax = pts.min(axis=0), pts.max(axis=0)
+    gmin, sub_size, ns, margin, _ = engines[0].grid_for_domain(dmin, dmax)
+    axis = int(np.argmax(ns))
+    slabs = D.partition_slabs(P_all[:, axis], float(gmin[axis]), sub_size, ns[axis], k)
+    assert sum(1 for lo, hi in slabs if hi > lo) >= 2
+    rho_global = torch.zeros(pts.shape[0], dtype=torch.float32, device="cuda:0")
+    sel = []
+    for q, (lo, hi) in enumerate(slabs):
+        sub_lo, sub_hi = [0, 0, 0], list(ns)
+        sub_lo[axis], sub_hi[axis] = lo, hi
+        shard = D.ShardDesc(dmin, dmax, sub_lo, sub_hi)
+        pad = margin * 1.001 + 1e-6
+        c_lo, c_hi = float(gmin[axis]) + lo * sub_size - pad, float(gmin[axis]) + hi * sub_size + pad
+        ids = torch.nonzero((P_all[:, axis] >= c_lo) & (P_all[:, axis] <= c_hi), as_tuple=False).squeeze(1) if hi > lo else torch.zeros(0, dtype=torch.int64, device="cuda:0")
+        L = P_all.index_select(0, ids).contiguous()
+        rho_local = engines[q].begin(L, shard)
+        rho_global.index_add_(0, ids, rho_local)  # stands in for the all-reduce: one non-zero contribution per particle
+        sel.append(ids)
+    V, K, T = [], [], []
+    voff = 0
+    for q in range(k):
+        res = engines[q].finish(rho_global.index_select(0, sel[q]).contiguous())
+        V.append(res.mesh.vertices)
+        K.append(res.vertex_keys)
+        T.append(res.mesh.triangles.astype(np.int64) + voff)
+        voff += res.mesh.vertices.shape[0]
+    V, K, T = np.concatenate(V), np.concatenate(K), np.concatenate(T)
+    uk, first = np.unique(K, return_index=True)
+    merged_v, merged_t = V[first], np.searchsorted(uk, K)[T]
+    # duplicates on slab faces are bit-identical
+    order = np.argsort(K, kind="stable")
+    same = K[order][1:] == K[order][:-1]
+    assert same.sum() > 0
+    assert np.array_equal(V[order][1:][same].view(np.uint32), V[order][:-1][same].view(np.uint32))
+    ref = oracle.reconstruct_surface(pts, oracle.make_params(r, np.float32(2.0 * l * r), np.float32(c * r), subdomain_num_cubes_per_dim=n_cubes))
+    assert np.array_equal(rho_global.cpu().numpy().view(np.uint32), ref.particle_densities.view(np.uint32))
+    cmp = MC.compare_keyed(merged_v, uk, merged_t, ref.vertices, ref.vertex_keys, ref.triangles)
+    assert cmp["keys_equal"] and cmp["triangles_equal"] and cmp["vertices_bit_equal"], cmp
