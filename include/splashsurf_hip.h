@@ -96,7 +96,7 @@ typedef struct ss_stats {
     uint64_t n_triangles;
     uint64_t n_active_blocks;         /* level-set blocks of 8^3 points evaluated */
     uint64_t n_block_candidates;      /* sum over blocks of candidate particles (tile sizes) */
-    uint64_t n_density_fixups;        /* particles whose density took the exact-order slow path */
+    uint64_t fast_div_verified;       /* 1 if the splat used the exhaustively verified reciprocal division for this h */
     uint64_t levelset_kernel_launches;
     uint64_t bytes_device_peak;       /* HBM held by the context after this call */
 } ss_stats;

@@ -73,7 +73,7 @@ class _Stats(C.Structure):
         ("n_triangles", C.c_uint64),
         ("n_active_blocks", C.c_uint64),
         ("n_block_candidates", C.c_uint64),
-        ("n_density_fixups", C.c_uint64),
+        ("fast_div_verified", C.c_uint64),
         ("levelset_kernel_launches", C.c_uint64),
         ("bytes_device_peak", C.c_uint64),
     ]

@@ -93,6 +93,9 @@ struct ss_context {
     DevBuf member_count, copy_offset, sub_flag, sub_rank, occ_sub, ckeys_a, ckeys_b, cvals_a, cidx, cpos, cell_count2, cell_start2;
     HostBuf h_small;
     hipEvent_t ev[12];  // 0..9 stage boundaries, 10/11 start of phase 2
+    // exhaustively verified "division by h via reciprocal + 2 FMA" (ss_kernels.hip ss_div_by_h)
+    float fastdiv_h = 0.0f;
+    bool fastdiv_ok = false;
     bool ev_ok = false;
 };
 
@@ -593,8 +596,22 @@ ss_status phase_finish(ss_context* ctx, ss_result* res) {
     SS_HIP(ctx, hipEventRecord(ctx->ev[5], st));
 
     // ---- K3: level-set splat ----
+    if (n_active && ctx->fastdiv_h != P.h) {
+        // once per distinct h: prove on the device that the fast division is exact for this divisor
+        ctx->fastdiv_ok = false;
+        if (P.h > 1.0e-25f && P.h < 1.0e25f) {
+            uint32_t bad = 1;
+            SS_HIP(ctx, hipMemsetAsync(ctx->counter.as<char>() + 32, 0, 4, st));
+            ss_launch_verify_fast_div(P.h, 1.0f / P.h, reinterpret_cast<uint32_t*>(ctx->counter.as<char>() + 32), st);
+            SS_HIP(ctx, hipMemcpyAsync(&bad, ctx->counter.as<char>() + 32, 4, hipMemcpyDeviceToHost, st));
+            SS_HIP(ctx, hipStreamSynchronize(st));
+            ctx->fastdiv_ok = (bad == 0);
+        }
+        ctx->fastdiv_h = P.h;
+        SS_HIP(ctx, hipEventRecord(ctx->ev[5], st));  // keep the one-off check out of the splat timing
+    }
     ss_launch_splat(P, res->posvol.as<float4>(), res->perm.as<uint32_t>(), ctx->cell_start.as<uint32_t>(), res->active_list.as<uint32_t>(), n_active,
-                    res->G.as<float>(), res->blk_minmax.as<float2>(), ctx->counter.as<unsigned long long>(), st);
+                    res->G.as<float>(), res->blk_minmax.as<float2>(), ctx->counter.as<unsigned long long>(), ctx->fastdiv_ok, st);
     SS_HIP(ctx, hipEventRecord(ctx->ev[6], st));
 
     // ---- K4 prepare: MC blocks = blocks whose 2x2x2 level-set neighbourhood straddles the threshold ----
@@ -665,7 +682,7 @@ ss_status phase_finish(ss_context* ctx, ss_result* res) {
     S.n_triangles = nt;
     S.n_active_blocks = n_active;
     S.n_block_candidates = cand;
-    S.n_density_fixups = 0;
+    S.fast_div_verified = ctx->fastdiv_ok ? 1 : 0;
     S.levelset_kernel_launches = n_active ? 1 : 0;
     size_t held = 0;
     for (const DevBuf* b : {&ctx->xyz_in, &ctx->xyz_filt, &ctx->flags32, &ctx->offsets, &ctx->keys_a, &ctx->keys_b, &ctx->vals_a, &ctx->cell_count,

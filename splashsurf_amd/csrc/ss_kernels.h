@@ -19,7 +19,8 @@ void ss_launch_mark_mc_blocks(const SSDev& P, const uint32_t* block_slot, const 
                               hipStream_t st);
 void ss_launch_compact_blocks(const uint32_t* flag, const uint32_t* rank, uint32_t nblocks, uint32_t* list, uint32_t* slot, hipStream_t st);
 void ss_launch_splat(const SSDev& P, const float4* posvol, const uint32_t* perm, const uint32_t* cell_start, const uint32_t* active_list,
-                     uint32_t n_active, float* G, float2* blk_minmax, unsigned long long* cand_counter, hipStream_t st);
+                     uint32_t n_active, float* G, float2* blk_minmax, unsigned long long* cand_counter, bool fast_div, hipStream_t st);
+void ss_launch_verify_fast_div(float h, float rh, uint32_t* bad, hipStream_t st);
 void ss_launch_mc_count(const SSDev& P, const float* G, const uint32_t* block_slot, const uint32_t* mc_list, uint32_t n_mc,
                         unsigned long long* masks, uint32_t* vcount, uint32_t* tcount, hipStream_t st);
 void ss_launch_mc_emit(const SSDev& P, const float* G, const uint32_t* block_slot, const uint32_t* mc_list, const uint32_t* mc_slot,

@@ -476,6 +476,59 @@ void ss_launch_compact_blocks(const uint32_t* flag, const uint32_t* rank, uint32
 // Tiles larger than SS_TILE_CAP are processed in several passes over ascending index ranges
 // (threshold found by bisection), which keeps the summation order exact for arbitrarily dense input.
 // =====================================================================================================
+// ---- exactly rounded building blocks of W(r) for the splat inner loop ---------------------------------
+// sqrt: v_sqrt_f32 is accurate to 1 ulp; one residual test against the two neighbouring floats makes it
+// correctly rounded (this is the sequence hipcc itself emits for sqrtf, minus its denormal scaling,
+// which is kept for the (practically unreachable) tiny inputs through the guard).
+__device__ __forceinline__ float ss_sqrt_rn(float x) {
+    if (x < 1.0e-30f) return sqrtf(x);  // 0, denormals, tiny: generic path
+    const float s = __builtin_amdgcn_sqrtf(x);
+    const float sm = __int_as_float(__float_as_int(s) - 1);
+    const float sp = __int_as_float(__float_as_int(s) + 1);
+    const float rm = __builtin_fmaf(-sm, s, x);
+    const float rp = __builtin_fmaf(-sp, s, x);
+    float r = (rm <= 0.0f) ? sm : s;
+    r = (rp > 0.0f) ? sp : r;
+    return r;
+}
+
+// x / h for the constant h.  FAST: q = fma(fma(-x*rh, h, x), rh, x*rh) with rh = RN(1/h); this is the
+// correctly rounded quotient for every x iff it is for the 2^23 significands of one binade (all steps
+// scale exactly with powers of two), which k_verify_fast_div checks exhaustively for the given h before
+// the fast path is enabled.  Results for q < 2^-13 do not influence W at all (2/3 - q*q rounds to 2/3).
+template <bool FAST>
+__device__ __forceinline__ float ss_div_by_h(float x, float h, float rh) {
+    if (FAST) {
+        const float q0 = x * rh;
+        const float e = __builtin_fmaf(-q0, h, x);
+        return __builtin_fmaf(e, rh, q0);
+    }
+    return x / h;
+}
+
+// kernel.rs:71-81 without branches (both polynomial pieces, then select); same association order
+__device__ __forceinline__ float ss_cubic_function_sel(float q) {
+    const float pi = 3.14159265358979323846f;
+    const float fa = (3.0f / (2.0f * pi)) * ((2.0f / 3.0f) - q * q + 0.5f * q * q * q);
+    const float x = 2.0f - q;
+    const float fb = (1.0f / (4.0f * pi)) * x * x * x;
+    return (q < 1.0f) ? fa : ((q < 2.0f) ? fb : 0.0f);
+}
+
+__global__ __launch_bounds__(256) void k_verify_fast_div(float h, float rh, uint32_t* __restrict__ bad) {
+    // all significands of the binade [2^e, 2^(e+1)) that contains h
+    const uint32_t m = blockIdx.x * blockDim.x + threadIdx.x;  // 0 .. 2^23-1
+    const uint32_t ebits = __float_as_uint(h) & 0x7F800000u;
+    const float x = __uint_as_float(ebits | m);
+    const float q_fast = ss_div_by_h<true>(x, h, rh);
+    const float q_ref = x / h;
+    if (__float_as_uint(q_fast) != __float_as_uint(q_ref)) atomicAdd(bad, 1u);
+}
+
+void ss_launch_verify_fast_div(float h, float rh, uint32_t* bad, hipStream_t st) {
+    hipLaunchKernelGGL(k_verify_fast_div, dim3((1u << 23) / 256), dim3(256), 0, st, h, rh, bad);
+}
+
 struct SplatShared {
     float4 pay[SS_TILE_CAP];
     uint32_t idx[SS_TILE_CAP];
@@ -550,6 +603,7 @@ __device__ inline void splat_for_each_candidate(SplatShared& s, const SSDev& P, 
     }
 }
 
+template <bool FASTDIV>
 __global__ __launch_bounds__(512) void k_splat(SSDev P, const float4* __restrict__ posvol, const uint32_t* __restrict__ perm,
                                                const uint32_t* __restrict__ cell_start, const uint32_t* __restrict__ active_list,
                                                uint32_t n_active, float* __restrict__ G, float2* __restrict__ blk_minmax,
@@ -698,27 +752,68 @@ __global__ __launch_bounds__(512) void k_splat(SSDev P, const float4* __restrict
         __syncthreads();
 
         // ---- accumulate ----
+        // Batches of up to 4 x 64 tile entries.  B1: every lane records, in a private 64-bit mask per
+        // group, which entries are inside its point's support (exact test d^2 < 1.01 h^2).  B2: every lane
+        // walks ITS OWN bits in ascending order (= ascending particle index) and evaluates W only for
+        // them, so the expensive part runs with ~80 % instead of ~50 % of the lanes doing useful work.
         if (wave_valid) {
-            for (int base = 0; base < n_tile; base += 64) {
-                const int c = base + lane;
-                bool pass = false;
-                if (c < n_tile) {
-                    const float4 pv = s.pay[c];
-                    const float ex = fmaxf(fmaxf(slo[0] - pv.x, pv.x - shi[0]) - P.coord_slack, 0.0f);
-                    const float ey = fmaxf(fmaxf(slo[1] - pv.y, pv.y - shi[1]) - P.coord_slack, 0.0f);
-                    const float ez = fmaxf(fmaxf(slo[2] - pv.z, pv.z - shi[2]) - P.coord_slack, 0.0f);
-                    pass = (ex * ex + ey * ey + ez * ez) <= wave_r2;
+            const float rh = 1.0f / P.h;
+            for (int g0 = 0; g0 < n_tile; g0 += 256) {
+                unsigned long long m0 = 0, m1 = 0, m2 = 0, m3 = 0;
+                const int ng = min(4, (n_tile - g0 + 63) >> 6);
+                for (int g = 0; g < ng; ++g) {
+                    const int base = g0 + (g << 6);
+                    const int c = base + lane;
+                    bool pass = false;
+                    float4 pv = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                    if (c < n_tile) {
+                        pv = s.pay[c];
+                        const float ex = fmaxf(fmaxf(slo[0] - pv.x, pv.x - shi[0]) - P.coord_slack, 0.0f);
+                        const float ey = fmaxf(fmaxf(slo[1] - pv.y, pv.y - shi[1]) - P.coord_slack, 0.0f);
+                        const float ez = fmaxf(fmaxf(slo[2] - pv.z, pv.z - shi[2]) - P.coord_slack, 0.0f);
+                        pass = (ex * ex + ey * ey + ez * ez) <= wave_r2;
+                    }
+                    unsigned long long wmask = __ballot(pass);
+                    unsigned long long mine = 0;
+                    while (wmask) {
+                        const int bit = __ffsll((long long)wmask) - 1;
+                        wmask &= wmask - 1;
+                        // broadcast entry `bit` from the lane that holds it (no LDS round trip)
+                        const float cx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pv.x), bit));
+                        const float cy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pv.y), bit));
+                        const float cz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pv.z), bit));
+                        const float dx = cx - px, dy = cy - py, dz = cz - pz;  // p_i - point, :828
+                        const float d2 = dx * dx + dy * dy + dz * dz;
+                        if (d2 < P.H2) mine |= 1ull << bit;  // :831
+                    }
+                    if (g == 0)
+                        m0 = mine;
+                    else if (g == 1)
+                        m1 = mine;
+                    else if (g == 2)
+                        m2 = mine;
+                    else
+                        m3 = mine;
                 }
-                unsigned long long mask = __ballot(pass);
-                while (mask) {
-                    const int bit = __ffsll((long long)mask) - 1;
-                    mask &= mask - 1;
-                    const float4 pv = s.pay[base + bit];
-                    const float dx = pv.x - px, dy = pv.y - py, dz = pv.z - pz;  // p_i - point, :828
-                    const float d2 = dx * dx + dy * dy + dz * dz;
-                    if (d2 < P.H2) {  // :831
-                        const float r = sqrtf(d2);
-                        const float w = ss_kernel_evaluate(r, P.h, P.sigma);
+                // B2
+                int g = 0;
+                unsigned long long m = m0;
+                while (true) {
+                    while (m == 0 && g < ng - 1) {
+                        ++g;
+                        m = (g == 1) ? m1 : ((g == 2) ? m2 : m3);
+                    }
+                    const bool has = m != 0;
+                    if (!__any(has)) break;
+                    if (has) {
+                        const int bit = __ffsll((long long)m) - 1;
+                        m &= m - 1;
+                        const float4 pv = s.pay[g0 + (g << 6) + bit];
+                        const float dx = pv.x - px, dy = pv.y - py, dz = pv.z - pz;
+                        const float d2 = dx * dx + dy * dy + dz * dz;  // same bits as in B1
+                        const float r = ss_sqrt_rn(d2);
+                        const float q = ss_div_by_h<FASTDIV>(r + r, P.h, rh);  // kernel.rs:104
+                        const float w = P.sigma * ss_cubic_function_sel(q);
                         acc += pv.w * w;  // :837-841
                     }
                 }
@@ -761,11 +856,15 @@ __global__ __launch_bounds__(512) void k_splat(SSDev P, const float4* __restrict
 }
 
 void ss_launch_splat(const SSDev& P, const float4* posvol, const uint32_t* perm, const uint32_t* cell_start, const uint32_t* active_list,
-                     uint32_t n_active, float* G, float2* blk_minmax, unsigned long long* cand_counter, hipStream_t st) {
+                     uint32_t n_active, float* G, float2* blk_minmax, unsigned long long* cand_counter, bool fast_div, hipStream_t st) {
     if (!n_active) return;
     const uint32_t per_xcd = (n_active + 7u) / 8u;
-    hipLaunchKernelGGL(k_splat, dim3(per_xcd * 8u), dim3(512), 0, st, P, posvol, perm, cell_start, active_list, n_active, G, blk_minmax,
-                       cand_counter);
+    if (fast_div)
+        hipLaunchKernelGGL(k_splat<true>, dim3(per_xcd * 8u), dim3(512), 0, st, P, posvol, perm, cell_start, active_list, n_active, G, blk_minmax,
+                           cand_counter);
+    else
+        hipLaunchKernelGGL(k_splat<false>, dim3(per_xcd * 8u), dim3(512), 0, st, P, posvol, perm, cell_start, active_list, n_active, G, blk_minmax,
+                           cand_counter);
 }
 
 // =====================================================================================================
