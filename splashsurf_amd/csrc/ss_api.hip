@@ -599,7 +599,7 @@ ss_status phase_finish(ss_context* ctx, ss_result* res) {
     if (n_active && ctx->fastdiv_h != P.h) {
         // once per distinct h: prove on the device that the fast division is exact for this divisor
         ctx->fastdiv_ok = false;
-        if (P.h > 1.0e-25f && P.h < 1.0e25f) {
+        if (P.h > 1.0e-9f && P.h < 1.0e15f) {
             uint32_t bad = 1;
             SS_HIP(ctx, hipMemsetAsync(ctx->counter.as<char>() + 32, 0, 4, st));
             ss_launch_verify_fast_div(P.h, 1.0f / P.h, reinterpret_cast<uint32_t*>(ctx->counter.as<char>() + 32), st);

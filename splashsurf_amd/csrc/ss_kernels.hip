@@ -478,10 +478,9 @@ void ss_launch_compact_blocks(const uint32_t* flag, const uint32_t* rank, uint32
 // =====================================================================================================
 // ---- exactly rounded building blocks of W(r) for the splat inner loop ---------------------------------
 // sqrt: v_sqrt_f32 is accurate to 1 ulp; one residual test against the two neighbouring floats makes it
-// correctly rounded (this is the sequence hipcc itself emits for sqrtf, minus its denormal scaling,
-// which is kept for the (practically unreachable) tiny inputs through the guard).
-__device__ __forceinline__ float ss_sqrt_rn(float x) {
-    if (x < 1.0e-30f) return sqrtf(x);  // 0, denormals, tiny: generic path
+// correctly rounded (the sequence hipcc emits for sqrtf, minus its scaling for inputs below 2^-96, which
+// the caller excludes).
+__device__ __forceinline__ float ss_sqrt_rn_normal(float x) {
     const float s = __builtin_amdgcn_sqrtf(x);
     const float sm = __int_as_float(__float_as_int(s) - 1);
     const float sp = __int_as_float(__float_as_int(s) + 1);
@@ -492,10 +491,6 @@ __device__ __forceinline__ float ss_sqrt_rn(float x) {
     return r;
 }
 
-// x / h for the constant h.  FAST: q = fma(fma(-x*rh, h, x), rh, x*rh) with rh = RN(1/h); this is the
-// correctly rounded quotient for every x iff it is for the 2^23 significands of one binade (all steps
-// scale exactly with powers of two), which k_verify_fast_div checks exhaustively for the given h before
-// the fast path is enabled.  Results for q < 2^-13 do not influence W at all (2/3 - q*q rounds to 2/3).
 template <bool FAST>
 __device__ __forceinline__ float ss_div_by_h(float x, float h, float rh) {
     if (FAST) {
@@ -513,6 +508,18 @@ __device__ __forceinline__ float ss_cubic_function_sel(float q) {
     const float x = 2.0f - q;
     const float fb = (1.0f / (4.0f * pi)) * x * x * x;
     return (q < 1.0f) ? fa : ((q < 2.0f) ? fb : 0.0f);
+}
+
+// W(sqrt(d2)) exactly as kernel.rs:103-106 evaluates it.  For d2 < tiny_d2 = (2^-14 h)^2 the result does
+// not depend on d2 at all: q < 2^-13 makes 2/3 - q*q round to 2/3 and + 0.5*q^3 vanish, i.e. W == W(0)
+// bit for bit.  Selecting w0 there (a) keeps the lean sqrt away from denormal inputs and (b) makes the
+// precision of q irrelevant where the fast division's intermediates could underflow.
+template <bool FAST>
+__device__ __forceinline__ float ss_kernel_w(float d2, float h, float rh, float sigma, float w0, float tiny_d2) {
+    const float r = FAST ? ss_sqrt_rn_normal(d2) : sqrtf(d2);  // generic variant: hipcc's fully guarded sqrt
+    const float q = ss_div_by_h<FAST>(r + r, h, rh);
+    const float w = sigma * ss_cubic_function_sel(q);
+    return (d2 < tiny_d2) ? w0 : w;
 }
 
 __global__ __launch_bounds__(256) void k_verify_fast_div(float h, float rh, uint32_t* __restrict__ bad) {
@@ -655,6 +662,7 @@ __global__ __launch_bounds__(512) void k_splat(SSDev P, const float4* __restrict
         shi[d] = P.gmin[d] + (float)min(g0[d] + 3, P.np[d] - 1) * P.cs;
     }
     const float wave_r2 = P.H2 * 1.0001f;
+    const float tiny_d2 = (P.h * 6.103515625e-05f) * (P.h * 6.103515625e-05f);  // (2^-14 h)^2, see ss_kernel_w
 
     float acc = 0.0f;  // levelset_grid.fill(0), dense_subdomains.rs:1390
     long long last = -1;  // particles with original index <= last are already accumulated
@@ -752,69 +760,35 @@ __global__ __launch_bounds__(512) void k_splat(SSDev P, const float4* __restrict
         __syncthreads();
 
         // ---- accumulate ----
-        // Batches of up to 4 x 64 tile entries.  B1: every lane records, in a private 64-bit mask per
-        // group, which entries are inside its point's support (exact test d^2 < 1.01 h^2).  B2: every lane
-        // walks ITS OWN bits in ascending order (= ascending particle index) and evaluates W only for
-        // them, so the expensive part runs with ~80 % instead of ~50 % of the lanes doing useful work.
+        // Phase A: 64 tile entries at a time are tested against the wave's 4^3 sub-block (distance to box
+        // <= reach) with one ballot.  Phase B: the surviving entries are walked in order (= ascending
+        // particle index); the entry is broadcast from the lane holding it with v_readlane (no LDS round
+        // trip) and every lane evaluates G += V * W(|x - p|) for its point iff d^2 < 1.01 h^2.
         if (wave_valid) {
             const float rh = 1.0f / P.h;
-            for (int g0 = 0; g0 < n_tile; g0 += 256) {
-                unsigned long long m0 = 0, m1 = 0, m2 = 0, m3 = 0;
-                const int ng = min(4, (n_tile - g0 + 63) >> 6);
-                for (int g = 0; g < ng; ++g) {
-                    const int base = g0 + (g << 6);
-                    const int c = base + lane;
-                    bool pass = false;
-                    float4 pv = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-                    if (c < n_tile) {
-                        pv = s.pay[c];
-                        const float ex = fmaxf(fmaxf(slo[0] - pv.x, pv.x - shi[0]) - P.coord_slack, 0.0f);
-                        const float ey = fmaxf(fmaxf(slo[1] - pv.y, pv.y - shi[1]) - P.coord_slack, 0.0f);
-                        const float ez = fmaxf(fmaxf(slo[2] - pv.z, pv.z - shi[2]) - P.coord_slack, 0.0f);
-                        pass = (ex * ex + ey * ey + ez * ez) <= wave_r2;
-                    }
-                    unsigned long long wmask = __ballot(pass);
-                    unsigned long long mine = 0;
-                    while (wmask) {
-                        const int bit = __ffsll((long long)wmask) - 1;
-                        wmask &= wmask - 1;
-                        // broadcast entry `bit` from the lane that holds it (no LDS round trip)
-                        const float cx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pv.x), bit));
-                        const float cy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pv.y), bit));
-                        const float cz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pv.z), bit));
-                        const float dx = cx - px, dy = cy - py, dz = cz - pz;  // p_i - point, :828
-                        const float d2 = dx * dx + dy * dy + dz * dz;
-                        if (d2 < P.H2) mine |= 1ull << bit;  // :831
-                    }
-                    if (g == 0)
-                        m0 = mine;
-                    else if (g == 1)
-                        m1 = mine;
-                    else if (g == 2)
-                        m2 = mine;
-                    else
-                        m3 = mine;
+            for (int base = 0; base < n_tile; base += 64) {
+                const int c = base + lane;
+                bool pass = false;
+                float4 pv = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                if (c < n_tile) {
+                    pv = s.pay[c];
+                    const float ex = fmaxf(fmaxf(slo[0] - pv.x, pv.x - shi[0]) - P.coord_slack, 0.0f);
+                    const float ey = fmaxf(fmaxf(slo[1] - pv.y, pv.y - shi[1]) - P.coord_slack, 0.0f);
+                    const float ez = fmaxf(fmaxf(slo[2] - pv.z, pv.z - shi[2]) - P.coord_slack, 0.0f);
+                    pass = (ex * ex + ey * ey + ez * ez) <= wave_r2;
                 }
-                // B2
-                int g = 0;
-                unsigned long long m = m0;
-                while (true) {
-                    while (m == 0 && g < ng - 1) {
-                        ++g;
-                        m = (g == 1) ? m1 : ((g == 2) ? m2 : m3);
-                    }
-                    const bool has = m != 0;
-                    if (!__any(has)) break;
-                    if (has) {
-                        const int bit = __ffsll((long long)m) - 1;
-                        m &= m - 1;
-                        const float4 pv = s.pay[g0 + (g << 6) + bit];
-                        const float dx = pv.x - px, dy = pv.y - py, dz = pv.z - pz;
-                        const float d2 = dx * dx + dy * dy + dz * dz;  // same bits as in B1
-                        const float r = ss_sqrt_rn(d2);
-                        const float q = ss_div_by_h<FASTDIV>(r + r, P.h, rh);  // kernel.rs:104
-                        const float w = P.sigma * ss_cubic_function_sel(q);
-                        acc += pv.w * w;  // :837-841
+                unsigned long long wmask = __ballot(pass);
+                while (wmask) {
+                    const int bit = __ffsll((long long)wmask) - 1;
+                    wmask &= wmask - 1;
+                    const float cx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pv.x), bit));
+                    const float cy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pv.y), bit));
+                    const float cz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pv.z), bit));
+                    const float cv = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pv.w), bit));
+                    const float dx = cx - px, dy = cy - py, dz = cz - pz;  // p_i - point, :828
+                    const float d2 = dx * dx + dy * dy + dz * dz;
+                    if (d2 < P.H2) {  // :831
+                        acc += cv * ss_kernel_w<FASTDIV>(d2, P.h, rh, P.sigma, P.w0, tiny_d2);  // :832-841
                     }
                 }
             }
