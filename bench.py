@@ -166,6 +166,30 @@ def main():
         },
         "stages_ms": {k: round(v, 4) for k, v in st.items() if k.startswith("ms_")},
     }
+    if world == 1:
+        # secondary figure (never `value`): the same call with HOST-resident input and the mesh copied back
+        # to pinned host memory (H2D + all kernels + D2H), i.e. what a host-only caller of the C ABI sees
+        try:
+            host_pts = pts
+            t_io = []
+            for _ in range(3):
+                t1 = time.perf_counter()
+                r_io = ctx.reconstruct(host_pts, prm, out=out)
+                _v = r_io.mesh.vertices
+                _t = r_io.mesh.triangles_u32
+                t_io.append(time.perf_counter() - t1)
+            line["pcie_inclusive"] = {"value": round(n_total / min(t_io) / 1e6, 3), "unit": "Mparticles/s", "ms_per_step": round(min(t_io) * 1e3, 3),
+                                      "note": "host (pageable numpy) input, vertices + u32 triangles copied to host; best of 3"}
+        except Exception as e:
+            line["pcie_inclusive"] = {"value": None, "note": "failed: %r" % (e,)}
+        # HBM traffic of the splat kernel from rocprofv3 PMC passes (collected offline, see profiles/)
+        try:
+            tr = json.load(open(os.path.join(ROOT, "profiles", "splat_traffic.json"))).get(args.workload)
+            if tr:
+                line["roofline"]["traffic"] = tr["hbm_bytes_per_launch"]
+                line["roofline"]["traffic_note"] = tr["note"]
+        except Exception:
+            pass
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             try:
