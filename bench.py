@@ -34,6 +34,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="s10m_tank")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-sharded", action="store_true", help="run the multi-GPU (sharded) code path even with one rank")
     ap.add_argument("--cpu-sample-scale", type=float, default=0.5, help="tank scale of the CPU-baseline sample (0.5 => 1.25M particles)")
     return ap.parse_args()
 
@@ -79,7 +80,8 @@ def main():
         raise SystemExit("bench.py needs a GPU (no CPU fallback)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    sharded_path = world > 1 or args.force_sharded
+    if sharded_path and "RANK" in os.environ:
         dist.init_process_group(backend="nccl", device_id=dev)
 
     wl = W.WORKLOADS[args.workload]
@@ -88,7 +90,7 @@ def main():
                      cube_size=np.float32(wl["cube_size"] * r), auto_disable=False)
     ctx = Context(local_rank)
 
-    if world == 1:
+    if not sharded_path:
         pts = wl["gen"]()
         n_total = pts.shape[0]
         d_pts = torch.from_numpy(pts).to(dev)
@@ -113,7 +115,7 @@ def main():
             return sharded.step()
 
     def barrier():
-        if world > 1:
+        if dist.is_initialized():
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -166,7 +168,7 @@ def main():
         },
         "stages_ms": {k: round(v, 4) for k, v in st.items() if k.startswith("ms_")},
     }
-    if world == 1:
+    if not sharded_path:
         # secondary figure (never `value`): the same call with HOST-resident input and the mesh copied back
         # to pinned host memory (H2D + all kernels + D2H), i.e. what a host-only caller of the C ABI sees
         try:
@@ -191,13 +193,13 @@ def main():
         except Exception:
             pass
     if rank == 0:
-        if world == 1 and not args.no_cpu_baseline:
+        if not sharded_path and not args.no_cpu_baseline:
             try:
                 line["cpu_baseline"] = cpu_baseline(args.workload, args.cpu_sample_scale)
             except Exception as e:  # the baseline is informative; never lose the measurement because of it
                 line["cpu_baseline"] = {"value": None, "unit": "Mparticles/s", "cores": 0, "kind": "port", "sample": "failed: %r" % (e,)}
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

@@ -5,15 +5,16 @@ The reference is single-process; its only natural decomposition is the uniform g
 (SURVEY.md section 8e).  Here the subdomain grid of ONE global domain is cut into contiguous slabs
 along its longest axis, balanced by particle count:
 
-  1. all-gather of particle positions (every rank ends up with the same global array, in global
-     particle order = concatenation by rank -- the summation order of the level set depends on it);
-  2. every rank derives the same global grid and the same slab partition from that array;
-  3. rank r selects the particles within the ghost margin of its slab (ascending global order) and
-     runs phase 1 of the engine: binning + densities of the particles CONTAINED in its slab;
-  4. density exchange: each rank scatters its owned densities into a zero-initialised global vector;
-     one all-reduce(SUM) completes it (every entry has exactly one non-zero contribution, so the sum is
-     exact and the densities stay bit-identical to a single-process run);
-  5. phase 2: level set + marching cubes for the slab.  Vertices on slab faces are produced by both
+  1. global particle ids = concatenation of the ranks' inputs (the summation order of the level set is
+     "ascending particle index", so ids must be global); global AABB by all-reduce(MIN/MAX);
+  2. every rank derives the same global grid; a histogram of owner subdomains along the axis is
+     all-reduced and cut into `world` slabs of (nearly) equal particle count;
+  3. sparse all-to-all (batched isend/irecv) of (id, position): each particle goes to every rank whose
+     slab + ghost margin contains it -- in a weak-scaling run only thin halo layers travel;
+  4. phase 1 on each rank: binning + densities of the particles CONTAINED in its slab;
+  5. halo density exchange: owners send (id, rho) to the ranks that hold the particle as a ghost
+     (the values are copied, never re-computed, so densities are bit-identical to a single-process run);
+  6. phase 2: level set + marching cubes for the slab.  Vertices on slab faces are produced by both
      neighbours with identical global edge keys and identical coordinates; `gather_mesh` removes the
      duplicates by key.
 
@@ -114,8 +115,13 @@ def partition_slabs(coords_axis, gmin_axis, sub_size, ns_axis, world):
     """Contiguous slabs of subdomain indices along one axis, balanced by owner-particle counts.
     Deterministic given identical inputs on all ranks. Returns list of (lo, hi)."""
     s = torch.floor((coords_axis - gmin_axis) / sub_size).to(torch.int64).clamp_(0, ns_axis - 1)
-    hist = torch.bincount(s, minlength=ns_axis).to(torch.float64).cpu().numpy()
-    cum = np.concatenate([[0.0], np.cumsum(hist)])
+    hist = torch.bincount(s, minlength=ns_axis).cpu().numpy()
+    return slabs_from_histogram(hist, world)
+
+
+def slabs_from_histogram(hist, world):
+    ns_axis = int(len(hist))
+    cum = np.concatenate([[0.0], np.cumsum(np.asarray(hist, dtype=np.float64))])
     total = cum[-1]
     bounds = [0]
     for r in range(1, world):
@@ -161,15 +167,22 @@ class ShardedReconstruction:
         t = torch.as_tensor(np.ascontiguousarray(pts, dtype=np.float32)) if not torch.is_tensor(pts) else pts
         self.local = t.to(self.device).contiguous()
 
-    # -- collectives (padded all-gather so that ranks may hold different counts) --
+    # ---- collectives ----
+    def _all_gather_small(self, t):
+        """all-gather of a small fixed-shape tensor -> stacked (world, ...)"""
+        if self.world == 1:
+            return t.unsqueeze(0)
+        out = [torch.zeros_like(t) for _ in range(self.world)]
+        dist.all_gather(out, t, group=self.group)
+        return torch.stack(out, dim=0)
+
     def _all_gather_rows(self, t):
+        """Padded all-gather of (n_r, ...) tensors with different n_r; returns concatenation + counts."""
         if self.world == 1:
             return t, [int(t.shape[0])]
         n = torch.tensor([t.shape[0]], dtype=torch.int64, device=self.device)
-        counts = [torch.zeros_like(n) for _ in range(self.world)]
-        dist.all_gather(counts, n, group=self.group)
-        counts = [int(c.item()) for c in counts]
-        m = max(counts)
+        counts = [int(c) for c in self._all_gather_small(n).flatten().tolist()]
+        m = max(max(counts), 1)
         pad = torch.zeros((m,) + tuple(t.shape[1:]), dtype=t.dtype, device=self.device)
         pad[: t.shape[0]] = t
         out = torch.empty((self.world * m,) + tuple(t.shape[1:]), dtype=t.dtype, device=self.device)
@@ -177,45 +190,126 @@ class ShardedReconstruction:
         parts = [out[r * m: r * m + counts[r]] for r in range(self.world)]
         return torch.cat(parts, dim=0).contiguous(), counts
 
+    def _exchange(self, send):
+        """Sparse all-to-all: send[q] (k_q, ...) goes to rank q; returns the list received from every rank
+        (point-to-point batch, supported by both RCCL and gloo)."""
+        if self.world == 1:
+            return [send[0]]
+        counts = torch.tensor([int(t.shape[0]) for t in send], dtype=torch.int64, device=self.device)
+        matrix = self._all_gather_small(counts)  # matrix[r][q] = rows rank r sends to rank q
+        recv_counts = [int(c) for c in matrix[:, self.rank].tolist()]
+        ops, recv = [], []
+        for q in range(self.world):
+            if q == self.rank:
+                recv.append(send[q])
+                continue
+            buf = torch.empty((recv_counts[q],) + tuple(send[q].shape[1:]), dtype=send[q].dtype, device=self.device)
+            recv.append(buf)
+            if send[q].shape[0] > 0:
+                ops.append(dist.P2POp(dist.isend, send[q].contiguous(), q, group=self.group))
+            if recv_counts[q] > 0:
+                ops.append(dist.P2POp(dist.irecv, buf, q, group=self.group))
+        if ops:
+            for req in dist.batch_isend_irecv(ops):
+                req.wait()
+        return recv
+
     def step(self):
-        eng = self.engine
-        # 1. global particle array (global order = concatenation by rank)
-        P_all, counts = self._all_gather_rows(self.local)
-        n_total = int(P_all.shape[0])
-        # 2. global grid + slab partition (identical on every rank)
-        dmin = P_all.min(dim=0).values.cpu().numpy() if n_total else np.zeros(3, np.float32)
-        dmax = P_all.max(dim=0).values.cpu().numpy() if n_total else np.zeros(3, np.float32)
+        """One sharded reconstruction.  Only halo layers travel between ranks:
+        positions to the ranks whose slab (+ ghost margin) contains them, then the densities of owned
+        particles to the ranks that hold them as ghosts."""
+        eng, dev, me = self.engine, self.device, self.rank
+        local = self.local
+        # 1. global particle ids = concatenation by rank (defines the summation order of the level set)
+        n_loc = torch.tensor([local.shape[0]], dtype=torch.int64, device=dev)
+        counts = [int(c) for c in self._all_gather_small(n_loc).flatten().tolist()]
+        offset = sum(counts[:me])
+        n_total = sum(counts)
+        gid = torch.arange(offset, offset + local.shape[0], dtype=torch.int64, device=dev)
+        # 2. global particle AABB (identical on every rank)
+        big = torch.finfo(torch.float32).max
+        lo_hi = torch.stack([local.min(dim=0).values if local.shape[0] else torch.full((3,), big, device=dev),
+                             -(local.max(dim=0).values) if local.shape[0] else torch.full((3,), big, device=dev)])
+        if self.world > 1:
+            dist.all_reduce(lo_hi, op=dist.ReduceOp.MIN, group=self.group)
+        dmin = lo_hi[0].cpu().numpy() if n_total else np.zeros(3, np.float32)
+        dmax = (-lo_hi[1]).cpu().numpy() if n_total else np.zeros(3, np.float32)
         gmin, sub_size, ns, margin, n_cubes = eng.grid_for_domain(dmin, dmax)
         axis = int(np.argmax(ns))
-        slabs = partition_slabs(P_all[:, axis], float(gmin[axis]), sub_size, ns[axis], self.world) if n_total else [(0, ns[axis])] * self.world
-        lo, hi = slabs[self.rank]
+        # 3. slab partition balanced by owner counts (histogram all-reduced, so identical everywhere)
+        s_own = torch.floor((local[:, axis] - float(gmin[axis])) / sub_size).to(torch.int64).clamp_(0, ns[axis] - 1)
+        hist = torch.bincount(s_own, minlength=ns[axis]).to(torch.int64)
+        if self.world > 1:
+            dist.all_reduce(hist, op=dist.ReduceOp.SUM, group=self.group)
+        slabs = slabs_from_histogram(hist.cpu().numpy(), self.world)
+        lo, hi = slabs[me]
         sub_lo, sub_hi = [0, 0, 0], list(ns)
         sub_lo[axis], sub_hi[axis] = lo, hi
         shard = ShardDesc(dmin, dmax, sub_lo, sub_hi)
-        # 3. local particle set: everything within the ghost margin of the slab (conservative interval; the
-        #    engine applies the exact membership rule), ascending global id
-        pad = margin * 1.001 + 1e-6 * max(1.0, float(np.abs(gmin).max()))
-        c_lo = float(gmin[axis]) + lo * sub_size - pad
-        c_hi = float(gmin[axis]) + hi * sub_size + pad
-        if hi > lo and n_total:
-            mask = (P_all[:, axis] >= c_lo) & (P_all[:, axis] <= c_hi)
-            ids = torch.nonzero(mask, as_tuple=False).squeeze(1)
-        else:
-            ids = torch.zeros(0, dtype=torch.int64, device=self.device)
-        L = P_all.index_select(0, ids).contiguous()
-        # 4. phase 1 + density exchange
-        rho_local = eng.begin(L, shard)
-        rho_global = torch.zeros(n_total, dtype=torch.float32, device=self.device)
-        rho_global.index_copy_(0, ids, rho_local)
-        if self.world > 1:
-            dist.all_reduce(rho_global, op=dist.ReduceOp.SUM, group=self.group)
-        rho_local = rho_global.index_select(0, ids).contiguous()
-        # 5. phase 2
-        res = eng.finish(rho_local)
-        self.rho_global = rho_global
-        return ShardedStepResult(res, shard, ids, n_total, {})
+        # conservative coordinate interval of a slab incl. ghost margin (the engine applies the exact rule)
+        pad = margin * 1.001 + 1e-6 * max(1.0, float(np.abs(gmin).max()), float(np.abs(dmax).max()))
 
-    # -- result assembly (tests / consumers that want one mesh) --
+        def interval(q):
+            a, b = slabs[q]
+            if b <= a:
+                return None
+            return float(gmin[axis]) + a * sub_size - pad, float(gmin[axis]) + b * sub_size + pad
+
+        def select(coords, q):
+            iv = interval(q)
+            if iv is None:
+                return torch.zeros(coords.shape[0], dtype=torch.bool, device=dev)
+            return (coords >= iv[0]) & (coords <= iv[1])
+
+        # 4. positions to every rank that needs them (owner or ghost)
+        send_gid, send_xyz = [], []
+        for q in range(self.world):
+            m = select(local[:, axis], q)
+            send_gid.append(gid[m])
+            send_xyz.append(local[m])
+        recv_gid = self._exchange(send_gid)
+        recv_xyz = self._exchange(send_xyz)
+        gids = torch.cat(recv_gid)
+        L = torch.cat(recv_xyz)
+        order = torch.argsort(gids)  # ascending global id (ids are unique)
+        gids = gids[order].contiguous()
+        L = L[order].contiguous()
+        # 5. phase 1: densities of the particles contained in this slab (others stay 0)
+        rho = eng.begin(L, shard)
+        owned = rho > 0
+        # 6. halo densities: owners -> ranks holding the particle as a ghost
+        send_gid, send_rho = [], []
+        for q in range(self.world):
+            if q == me:
+                send_gid.append(gids[:0])
+                send_rho.append(rho[:0])
+                continue
+            m = owned & select(L[:, axis], q)
+            send_gid.append(gids[m])
+            send_rho.append(rho[m])
+        recv_gid = self._exchange(send_gid)
+        recv_rho = self._exchange(send_rho)
+        for q in range(self.world):
+            if q == me or recv_gid[q].shape[0] == 0:
+                continue
+            pos = torch.searchsorted(gids, recv_gid[q])
+            rho.index_copy_(0, pos, recv_rho[q])
+        # 7. phase 2
+        res = eng.finish(rho)
+        self.last = dict(gids=gids, rho=rho, owned=owned)
+        return ShardedStepResult(res, shard, gids, n_total, {})
+
+    # ---- result assembly (tests / consumers that want one mesh) ----
+    def gather_densities(self):
+        """Global density vector on every rank (tests): owned entries from every rank, ordered by global id."""
+        g = self.last["gids"][self.last["owned"]]
+        r = self.last["rho"][self.last["owned"]]
+        G, _ = self._all_gather_rows(g)
+        R, _ = self._all_gather_rows(r)
+        out = torch.zeros(int(G.max().item()) + 1 if G.numel() else 0, dtype=torch.float32, device=self.device)
+        out.index_copy_(0, G, R)
+        return out
+
     def gather_mesh(self, step_result):
         """All ranks: returns (vertices, keys, triangles) of the merged mesh on rank 0 (None elsewhere).
         Duplicated face vertices are removed by global edge key; the lowest rank's copy is kept."""
@@ -229,11 +323,10 @@ class ShardedReconstruction:
         if self.rank != 0:
             return None
         V, K, T = V.cpu().numpy(), K.cpu().numpy(), T.cpu().numpy()
-        # offset triangle indices by the rank's vertex offset
         voff = np.concatenate([[0], np.cumsum(vc)])
         toff = np.concatenate([[0], np.cumsum(tc)])
         for q in range(len(vc)):
             T[toff[q]:toff[q + 1]] += voff[q]
-        uk, first = np.unique(K, return_index=True)      # first occurrence = lowest rank
+        uk, first = np.unique(K, return_index=True)  # first occurrence = lowest rank
         remap = np.searchsorted(uk, K)
         return V[first], uk.astype(np.uint64), remap[T].astype(np.uint64)

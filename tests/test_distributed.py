@@ -61,10 +61,11 @@ def _worker(rank, world, port, case, out_path):
         sh.load_local_particles(pts[cut[rank]:cut[rank + 1]])
         step = sh.step()
         merged = sh.gather_mesh(step)
+        rho_global = sh.gather_densities()
         if rank == 0:
             v, k, t = merged
-            np.savez(out_path, vertices=v, keys=k, triangles=t, rho=sh.rho_global.numpy(),
-                     slab=np.array([step.shard.sub_lo, step.shard.sub_hi]))
+            np.savez(out_path, vertices=v, keys=k, triangles=t, rho=rho_global.numpy(),
+                     slab=np.array([step.shard.sub_lo, step.shard.sub_hi]), n_local=np.int64(step.ids.shape[0]))
     finally:
         dist.destroy_process_group()
 
@@ -88,16 +89,16 @@ def _free_port():
     return p
 
 
-@pytest.mark.parametrize("case", ["dam_break_n16", "hilbert_n32", "lattice_n8"])
-def test_two_ranks_reproduce_single_process(tmp_path, oracle, case):
+@pytest.mark.parametrize("case,world", [("dam_break_n16", 2), ("hilbert_n32", 2), ("lattice_n8", 2), ("dam_break_n16", 3)])
+def test_ranks_reproduce_single_process(tmp_path, oracle, case, world):
     import mesh_compare as MC
     out = str(tmp_path / "merged.npz")
-    mp.spawn(_worker, args=(2, _free_port(), case, out), nprocs=2, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), case, out), nprocs=world, join=True)
     got = np.load(out)
     pts, r, l, c, n_cubes = _case(case)
     ref = oracle.reconstruct_surface(pts, oracle.make_params_relative(r, l, c, subdomain_num_cubes_per_dim=n_cubes))
-    # the domain really was split
-    assert got["slab"][1].max() > 0
+    # the domain really was split: rank 0 did not hold all particles
+    assert got["slab"][1].max() > 0 and int(got["n_local"]) < pts.shape[0]
     assert np.array_equal(got["rho"].view(np.uint32), ref.particle_densities.view(np.uint32))
     cmp = MC.compare_keyed(got["vertices"], got["keys"], got["triangles"], ref.vertices, ref.vertex_keys, ref.triangles)
     assert cmp["keys_equal"] and cmp["triangles_equal"], cmp
