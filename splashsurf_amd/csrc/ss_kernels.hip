@@ -510,16 +510,17 @@ __device__ __forceinline__ float ss_cubic_function_sel(float q) {
     return (q < 1.0f) ? fa : ((q < 2.0f) ? fb : 0.0f);
 }
 
-// W(sqrt(d2)) exactly as kernel.rs:103-106 evaluates it.  For d2 < tiny_d2 = (2^-14 h)^2 the result does
-// not depend on d2 at all: q < 2^-13 makes 2/3 - q*q round to 2/3 and + 0.5*q^3 vanish, i.e. W == W(0)
-// bit for bit.  Selecting w0 there (a) keeps the lean sqrt away from denormal inputs and (b) makes the
-// precision of q irrelevant where the fast division's intermediates could underflow.
+// W(sqrt(d2)) exactly as kernel.rs:103-106 evaluates it.
+// FAST variant (enabled by the host only for 1e-9 < h < 1e15 and after k_verify_fast_div passed): lean sqrt
+// and reciprocal division.  Both are exact for normal-range arguments; for d2 below (2^-14 h)^2 -- the
+// only place where v_sqrt_f32 could see a denormal or the division's residual could underflow -- the
+// value of q is irrelevant: any q < 2^-13 makes 2/3 - q*q round to 2/3 and 0.5*q^3 vanish, i.e. W == W(0)
+// bit for bit, and every path yields such a q there (r is never over-estimated).
 template <bool FAST>
-__device__ __forceinline__ float ss_kernel_w(float d2, float h, float rh, float sigma, float w0, float tiny_d2) {
+__device__ __forceinline__ float ss_kernel_w(float d2, float h, float rh, float sigma) {
     const float r = FAST ? ss_sqrt_rn_normal(d2) : sqrtf(d2);  // generic variant: hipcc's fully guarded sqrt
     const float q = ss_div_by_h<FAST>(r + r, h, rh);
-    const float w = sigma * ss_cubic_function_sel(q);
-    return (d2 < tiny_d2) ? w0 : w;
+    return sigma * ss_cubic_function_sel(q);
 }
 
 __global__ __launch_bounds__(256) void k_verify_fast_div(float h, float rh, uint32_t* __restrict__ bad) {
@@ -662,7 +663,6 @@ __global__ __launch_bounds__(512) void k_splat(SSDev P, const float4* __restrict
         shi[d] = P.gmin[d] + (float)min(g0[d] + 3, P.np[d] - 1) * P.cs;
     }
     const float wave_r2 = P.H2 * 1.0001f;
-    const float tiny_d2 = (P.h * 6.103515625e-05f) * (P.h * 6.103515625e-05f);  // (2^-14 h)^2, see ss_kernel_w
 
     float acc = 0.0f;  // levelset_grid.fill(0), dense_subdomains.rs:1390
     long long last = -1;  // particles with original index <= last are already accumulated
@@ -788,7 +788,7 @@ __global__ __launch_bounds__(512) void k_splat(SSDev P, const float4* __restrict
                     const float dx = cx - px, dy = cy - py, dz = cz - pz;  // p_i - point, :828
                     const float d2 = dx * dx + dy * dy + dz * dz;
                     if (d2 < P.H2) {  // :831
-                        acc += cv * ss_kernel_w<FASTDIV>(d2, P.h, rh, P.sigma, P.w0, tiny_d2);  // :832-841
+                        acc += cv * ss_kernel_w<FASTDIV>(d2, P.h, rh, P.sigma);  // :832-841
                     }
                 }
             }

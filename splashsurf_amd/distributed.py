@@ -269,11 +269,10 @@ class ShardedReconstruction:
             send_xyz.append(local[m])
         recv_gid = self._exchange(send_gid)
         recv_xyz = self._exchange(send_xyz)
-        gids = torch.cat(recv_gid)
-        L = torch.cat(recv_xyz)
-        order = torch.argsort(gids)  # ascending global id (ids are unique)
-        gids = gids[order].contiguous()
-        L = L[order].contiguous()
+        # Lists arrive ascending from every source rank and ranks' id ranges are ascending, so the
+        # concatenation by source rank IS the ascending global-id order (no sort needed).
+        gids = torch.cat(recv_gid).contiguous()
+        L = torch.cat(recv_xyz).contiguous()
         # 5. phase 1: densities of the particles contained in this slab (others stay 0)
         rho = eng.begin(L, shard)
         owned = rho > 0

@@ -270,3 +270,26 @@ def test_sharded_engine_reproduces_full_reconstruction(oracle, case):
     assert np.array_equal(rho_global.cpu().numpy().view(np.uint32), ref.particle_densities.view(np.uint32))
     cmp = MC.compare_keyed(merged_v, uk, merged_t, ref.vertices, ref.vertex_keys, ref.triangles)
     assert cmp["keys_equal"] and cmp["triangles_equal"] and cmp["vertices_bit_equal"], cmp
+
+
+def test_full_size_s10m_tank_bit_identical_to_oracle(gpu_ctx, oracle):
+    """BASELINE config 3 at FULL size (10 M particles, ~2.3 G grid cells): the whole result -- 10 M
+    densities, 7.2 M vertices, 14.4 M triangles -- equals the CPU oracle bit for bit; plus the
+    size-independent properties the reference's tests assert (closed manifold mesh) and run-to-run
+    determinism."""
+    from splashsurf_amd import workloads as W
+    wl = W.WORKLOADS["s10m_tank"]
+    pts = wl["gen"]()
+    prm = dict(particle_radius=wl["particle_radius"], smoothing_length=wl["smoothing_length"], cube_size=wl["cube_size"], iso_surface_threshold=0.6)
+    res = run_gpu(gpu_ctx, pts, prm)
+    nv, nt = res.counts()
+    assert nv > 5_000_000 and nt > 10_000_000
+    h1 = hashlib.sha256(res.mesh.vertices.tobytes() + res.mesh.triangles_u32.tobytes() + res.particle_densities.tobytes()).hexdigest()
+    _, orc = run_oracle(oracle, pts, prm)
+    assert_gpu_equals_oracle(res, orc)
+    assert MC.mesh_is_closed_manifold(res.mesh.triangles_u32)
+    keys = res.vertex_keys
+    assert np.unique(keys).size == keys.size
+    res2 = run_gpu(gpu_ctx, pts, prm)
+    h2 = hashlib.sha256(res2.mesh.vertices.tobytes() + res2.mesh.triangles_u32.tobytes() + res2.particle_densities.tobytes()).hexdigest()
+    assert h1 == h2
