@@ -137,6 +137,10 @@ ss_status ss_result_subdomain_grid(const ss_result *res, ss_grid_f32 *out, int32
 ss_status ss_result_particle_densities(ss_result *res, const float **rho, uint64_t *n);
 /* *flags == NULL when no particle AABB was given (Option::None) */
 ss_status ss_result_particle_inside_aabb(ss_result *res, const uint8_t **flags, uint64_t *n);
+/* SurfaceReconstruction::particle_neighbors (lib.rs:256-257) as CSR: neighbours of particle i are
+ * neighbors[row_ptr[i] .. row_ptr[i+1]), global particle indices in the reference's order
+ * (dense_subdomains.rs:617-639).  *row_ptr == NULL when global_neighborhood_list was not requested. */
+ss_status ss_result_particle_neighbors(ss_result *res, const uint64_t **row_ptr, const uint64_t **neighbors, uint64_t *n_particles);
 ss_status ss_result_stats(const ss_result *res, ss_stats *out);
 
 /* -- device-side views (HBM pointers; no copy) -- */

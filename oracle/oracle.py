@@ -25,6 +25,7 @@ class SoParams(C.Structure):
         ("aabb_max", C.c_float * 3),
         ("subdomain_num_cubes_per_dim", C.c_int32),
         ("num_threads", C.c_int32),
+        ("global_neighborhood_list", C.c_int32),
     ]
 
 
@@ -46,6 +47,8 @@ class SoResult(C.Structure):
         ("n_particles", C.c_uint64),
         ("particle_densities", C.POINTER(C.c_float)),
         ("particle_inside_aabb", C.POINTER(C.c_uint8)),
+        ("neighbor_ptr", C.POINTER(C.c_uint64)),
+        ("neighbors", C.POINTER(C.c_uint64)),
         ("n_vertices", C.c_uint64),
         ("vertices", C.POINTER(C.c_float)),
         ("vertex_keys", C.POINTER(C.c_uint64)),
@@ -111,7 +114,7 @@ def lib():
 
 def make_params(particle_radius, compact_support_radius, cube_size, rest_density=1000.0,
                 iso_surface_threshold=0.6, aabb_min=None, aabb_max=None,
-                subdomain_num_cubes_per_dim=64, num_threads=0):
+                subdomain_num_cubes_per_dim=64, num_threads=0, global_neighborhood_list=False):
     """Absolute-unit parameters (lib.rs:197-210). All values are rounded to f32 here."""
     p = SoParams()
     p.particle_radius = np.float32(particle_radius)
@@ -128,6 +131,7 @@ def make_params(particle_radius, compact_support_radius, cube_size, rest_density
         p.has_particle_aabb = 0
     p.subdomain_num_cubes_per_dim = int(subdomain_num_cubes_per_dim)
     p.num_threads = int(num_threads)
+    p.global_neighborhood_list = 1 if global_neighborhood_list else 0
     return p
 
 
@@ -211,6 +215,12 @@ def _unpack(res):
         out.vertex_keys = np.ctypeslib.as_array(res.vertex_keys, shape=(nv,)).copy() if nv else np.zeros((0,), np.uint64)
         out.triangles = np.ctypeslib.as_array(res.triangles, shape=(nt * 3,)).copy().reshape(nt, 3) if nt else np.zeros((0, 3), np.uint64)
         out.particle_densities = np.ctypeslib.as_array(res.particle_densities, shape=(n,)).copy() if n else np.zeros((0,), np.float32)
+        if res.neighbor_ptr:
+            out.neighbor_ptr = np.ctypeslib.as_array(res.neighbor_ptr, shape=(n + 1,)).copy()
+            m = int(out.neighbor_ptr[-1])
+            out.neighbors = np.ctypeslib.as_array(res.neighbors, shape=(m,)).copy() if m else np.zeros(0, np.uint64)
+        else:
+            out.neighbor_ptr = out.neighbors = None
         if res.particle_inside_aabb:
             ni = int(res.n_input)
             out.particle_inside_aabb = np.ctypeslib.as_array(res.particle_inside_aabb, shape=(ni,)).copy().astype(bool) if ni else np.zeros((0,), bool)

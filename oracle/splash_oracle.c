@@ -446,7 +446,7 @@ static void subdomain_aabb(const sd_params *S, const int64_t sub[3], float amin[
 }
 
 static void subdomain_density(const sd_params *S, const float *xyz, const uint32_t *idx, size_t P,
-                              int64_t flat_sub, workspace_t *w, float *global_rho) {
+                              int64_t flat_sub, workspace_t *w, float *global_rho, uint32_t **nb_lists, uint32_t *nb_counts) {
     ws_reserve_particles(w, P);
     for (size_t a = 0; a < P; ++a) { /* gather_subdomain_data :545 */
         const float *p = xyz + 3 * (size_t)idx[a];
@@ -508,6 +508,8 @@ static void subdomain_density(const sd_params *S, const float *xyz, const uint32
         int64_t ci[3];
         grid_enclosing_cell(&sgrid, pi, ci);
         float density = w0; /* density_map.rs:173 */
+        uint32_t *nbl = NULL;
+        size_t nbn = 0, nbcap = 0;
         /* 26 adjacent cells in iproduct order (uniform_grid.rs:614-643), then the own cell
            (neighborhood_search.rs:400-405) */
         for (int pass = 0; pass < 2; ++pass) {
@@ -527,12 +529,23 @@ static void subdomain_density(const sd_params *S, const float *xyz, const uint32
                             if (b != (uint32_t)a && d2 < h2) { /* neighborhood_search.rs:431 */
                                 float r = sqrtf(d2);          /* density_map.rs:179 */
                                 density += kernel_evaluate(&K, r);
+                                if (nb_lists) { /* dense_subdomains.rs:617-639: local -> global index */
+                                    if (nbn == nbcap) {
+                                        nbcap = nbcap ? nbcap * 2 : 64;
+                                        nbl = (uint32_t *)realloc(nbl, sizeof(uint32_t) * nbcap);
+                                    }
+                                    nbl[nbn++] = idx[b];
+                                }
                             }
                         }
                     }
         }
         density *= S->particle_rest_mass; /* density_map.rs:182 */
         global_rho[idx[a]] = density;     /* :596-614 */
+        if (nb_lists) {
+            nb_lists[idx[a]] = nbl;
+            nb_counts[idx[a]] = (uint32_t)nbn;
+        }
     }
 }
 
@@ -923,6 +936,12 @@ int so_reconstruct_surface(const float *xyz_in, uint64_t n_in, const so_params *
     double t2 = now_s();
 
     float *rho = (float *)calloc(n ? n : 1, sizeof(float)); /* :504 */
+    uint32_t **nb_lists = NULL;
+    uint32_t *nb_counts = NULL;
+    if (P->global_neighborhood_list) { /* :505 */
+        nb_lists = (uint32_t **)calloc(n ? n : 1, sizeof(uint32_t *));
+        nb_counts = (uint32_t *)calloc(n ? n : 1, sizeof(uint32_t));
+    }
     workspace_t *ws = (workspace_t *)calloc((size_t)nthreads, sizeof(workspace_t));
 #pragma omp parallel for schedule(dynamic, 1) num_threads(nthreads)
     for (int64_t s = 0; s < subs.n_sub; ++s) {
@@ -932,7 +951,23 @@ int so_reconstruct_surface(const float *xyz_in, uint64_t n_in, const so_params *
         workspace_t *w = &ws[0];
 #endif
         subdomain_density(&S, xyz, subs.particles + subs.offsets[s], (size_t)(subs.offsets[s + 1] - subs.offsets[s]),
-                          subs.flat_index[s], w, rho);
+                          subs.flat_index[s], w, rho, nb_lists, nb_counts);
+    }
+    if (nb_lists) {
+        out->neighbor_ptr = (uint64_t *)malloc(sizeof(uint64_t) * (size_t)(n + 1));
+        uint64_t run = 0;
+        for (uint64_t i = 0; i < n; ++i) {
+            out->neighbor_ptr[i] = run;
+            run += nb_counts[i];
+        }
+        out->neighbor_ptr[n] = run;
+        out->neighbors = (uint64_t *)malloc(sizeof(uint64_t) * (size_t)(run ? run : 1));
+        for (uint64_t i = 0; i < n; ++i) {
+            for (uint32_t q = 0; q < nb_counts[i]; ++q) out->neighbors[out->neighbor_ptr[i] + q] = nb_lists[i][q];
+            free(nb_lists[i]);
+        }
+        free(nb_lists);
+        free(nb_counts);
     }
     double t3 = now_s();
 
@@ -994,7 +1029,7 @@ int64_t so_debug_levelset_subdomain(const float *xyz, uint64_t n, const so_param
         workspace_t *w = &ws[0];
 #endif
         subdomain_density(&S, xyz, subs.particles + subs.offsets[s], (size_t)(subs.offsets[s + 1] - subs.offsets[s]),
-                          subs.flat_index[s], w, rho);
+                          subs.flat_index[s], w, rho, NULL, NULL);
     }
     int64_t result = -1;
     const int64_t np = S.subdomain_cubes + 1;
@@ -1060,7 +1095,7 @@ int so_shard_densities(const float *xyz, uint64_t n, const so_params *P, const s
         workspace_t *w = &ws[0];
 #endif
         subdomain_density(&S, xyz, subs.particles + subs.offsets[s], (size_t)(subs.offsets[s + 1] - subs.offsets[s]), subs.flat_index[s], w,
-                          rho_out);
+                          rho_out, NULL, NULL);
     }
     for (int t = 0; t < nthreads; ++t) ws_free(&ws[t]);
     free(ws);
@@ -1115,6 +1150,8 @@ int so_shard_reconstruct(const float *xyz, uint64_t n, const so_params *P, const
 void so_result_free(so_result *r) {
     free(r->particle_densities);
     free(r->particle_inside_aabb);
+    free(r->neighbor_ptr);
+    free(r->neighbors);
     free(r->vertices);
     free(r->vertex_keys);
     free(r->triangles);

@@ -29,6 +29,7 @@ typedef struct so_params {
     float aabb_max[3];
     int32_t subdomain_num_cubes_per_dim; /* lib.rs:142, default 64 */
     int32_t num_threads;                 /* <=0: all cores (OpenMP) */
+    int32_t global_neighborhood_list;    /* lib.rs:185-188 */
 } so_params;
 
 typedef struct so_grid {
@@ -46,6 +47,8 @@ typedef struct so_result {
     uint64_t n_particles;    /* after the optional AABB filter */
     float *particle_densities;      /* [n_particles] */
     uint8_t *particle_inside_aabb;  /* [n_input] or NULL when no AABB given */
+    uint64_t *neighbor_ptr;         /* [n_particles+1] CSR rows or NULL (dense_subdomains.rs:617-639) */
+    uint64_t *neighbors;            /* global particle indices */
     uint64_t n_vertices;
     float *vertices;         /* [n_vertices*3] */
     uint64_t *vertex_keys;   /* [n_vertices] global edge key = ((gi*NPy+gj)*NPz+gk)*3+axis */

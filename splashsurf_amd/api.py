@@ -145,6 +145,7 @@ def load_library():
     L.ss_result_particle_densities.argtypes = [vp, P(vp), P(u64)]
     L.ss_result_particle_inside_aabb.argtypes = [vp, P(vp), P(u64)]
     L.ss_result_stats.argtypes = [vp, P(_Stats)]
+    L.ss_result_particle_neighbors.argtypes = [vp, P(vp), P(vp), P(u64)]
     L.ss_result_device_vertices.argtypes = [vp, P(vp), P(u64)]
     L.ss_result_device_triangles_u32.argtypes = [vp, P(vp), P(u64)]
     L.ss_result_device_particle_densities.argtypes = [vp, P(vp), P(u64)]
@@ -401,8 +402,29 @@ class SurfaceReconstruction:
         return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_uint8)), shape=(int(n.value),)).copy().astype(bool)
 
     @property
+    def particle_neighbors_csr(self):
+        """(row_ptr uint64[N+1], neighbors uint64[M]) or None when not requested."""
+        if "nb" not in self._cache:
+            rp, nb, n = C.c_void_p(), C.c_void_p(), C.c_uint64()
+            self._check(self._lib.ss_result_particle_neighbors(self._h, C.byref(rp), C.byref(nb), C.byref(n)))
+            if not rp.value:
+                self._cache["nb"] = None
+            else:
+                nrow = int(n.value) + 1
+                row = np.ctypeslib.as_array(C.cast(rp, C.POINTER(C.c_uint64)), shape=(nrow,)).copy()
+                m = int(row[-1])
+                idx = np.ctypeslib.as_array(C.cast(nb, C.POINTER(C.c_uint64)), shape=(m,)).copy() if m else np.zeros(0, np.uint64)
+                self._cache["nb"] = (row, idx)
+        return self._cache["nb"]
+
+    @property
     def particle_neighbors(self):
-        return None  # global_neighborhood_list: SURVEY section 8(f) N1, not provided by this build
+        """`SurfaceReconstruction::particle_neighbors`: list of per-particle neighbour index arrays (None if not requested)."""
+        csr = self.particle_neighbors_csr
+        if csr is None:
+            return None
+        row, idx = csr
+        return [idx[int(row[i]):int(row[i + 1])] for i in range(row.size - 1)]
 
     @property
     def stats(self):
@@ -458,8 +480,6 @@ def reconstruct_surface(particles, *, particle_radius, rest_density=1000.0, smoo
     compact_support_radius = 2 * smoothing_length * particle_radius, cube = cube_size * particle_radius,
     both formed in f64 and then cast to f32 (reconstruction.rs:171-193).
     """
-    if global_neighborhood_list:
-        raise NotImplementedError("global_neighborhood_list is not provided by this build (SURVEY.md 8f, N1)")
     aabb = None
     if aabb_min is not None and aabb_max is not None:
         aabb = (np.asarray(aabb_min, dtype=np.float64), np.asarray(aabb_max, dtype=np.float64))

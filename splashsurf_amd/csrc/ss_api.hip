@@ -90,6 +90,7 @@ struct ss_context {
     DevBuf xyz_in, xyz_filt, flags32, offsets, keys_a, keys_b, vals_a, vals_b, cell_count, cell_start, pos_sorted, temp, aabb_partial, aabb_out,
         block_flag, block_rank, mc_flag, mc_rank, vcount, tcount, counter;
     // per-subdomain particle copies for the density stage
+    DevBuf nb_count, nb_tmp;
     DevBuf member_count, copy_offset, sub_flag, sub_rank, occ_sub, ckeys_a, ckeys_b, cvals_a, cidx, cpos, cell_count2, cell_start2;
     HostBuf h_small;
     hipEvent_t ev[12];  // 0..9 stage boundaries, 10/11 start of phase 2
@@ -107,6 +108,11 @@ struct ss_result {
     bool has_inside = false;
     uint64_t n_input = 0, n_particles = 0, n_vertices = 0, n_triangles = 0;
     uint32_t n_active = 0, n_mc = 0;
+    bool has_neighbors = false;
+    uint64_t n_neighbors = 0;
+    DevBuf nb_ptr, nb_idx, nb_idx64;
+    HostBuf h_nb_ptr, h_nb_idx;
+    bool hnbp = false, hnbi = false;
     int phase = 0;  // 0 nothing, 1 after phase_begin, 2 complete
     bool host_input = false;
     uint64_t n_occupied_subdomains = 0, n_subdomain_particles = 0;
@@ -244,11 +250,10 @@ ss_status validate_params(ss_context* ctx, const ss_params_f32* prm, uint64_t n)
         return fail(ctx, SS_ERR_UNSUPPORTED,
                     "SpatialDecomposition::None (global strategy, reconstruction.rs:65-112) is not provided by this build; "
                     "use the uniform-grid decomposition");
-    if (prm->global_neighborhood_list) return fail(ctx, SS_ERR_UNSUPPORTED, "global_neighborhood_list is not provided by this build");
     return SS_OK;
 }
 
-void reset_host_flags(ss_result* r) { r->hv = r->ht64 = r->ht32 = r->hrho = r->hkeys = r->hinside = false; }
+void reset_host_flags(ss_result* r) { r->hv = r->ht64 = r->ht32 = r->hrho = r->hkeys = r->hinside = r->hnbp = r->hnbi = false; }
 
 ss_status make_device_params(ss_context* ctx, const ss_params_f32* prm, const ss_grid_f32& g, const ss_grid_f32& sg, float mass, float margin,
                              uint32_t n, const ss_shard_f32* shard, SSDev* out) {
@@ -545,8 +550,39 @@ ss_status phase_begin(ss_context* ctx, const float* xyz, uint64_t n_in, const ss
             SS_HIP(ctx, rocprim::radix_sort_pairs(ctx->temp.p, bytes, ctx->ckeys_a.as<uint32_t>(), ctx->ckeys_b.as<uint32_t>(), ctx->cvals_a.as<uint32_t>(),
                                                   ctx->cidx.as<uint32_t>(), (size_t)n_copies, 0u, bits, st));
             ss_launch_gather_sorted(n_copies, d_xyz, ctx->cidx.as<uint32_t>(), ctx->cpos.as<float4>(), st);
+            const bool want_nb = prm->global_neighborhood_list != 0;
+            if (want_nb) {
+                SS_HIP(ctx, ctx->nb_count.reserve(((size_t)n + 1) * 8));
+                SS_HIP(ctx, res->nb_ptr.reserve(((size_t)n + 1) * 8));
+                SS_HIP(ctx, hipMemsetAsync(ctx->nb_count.p, 0, ((size_t)n + 1) * 8, st));
+            }
             ss_launch_density_sub(P, n_copies, ctx->cpos.as<float4>(), ctx->cidx.as<uint32_t>(), ctx->ckeys_b.as<uint32_t>(),
-                                  ctx->cell_start2.as<uint32_t>(), ctx->occ_sub.as<uint32_t>(), res->rho.as<float>(), st);
+                                  ctx->cell_start2.as<uint32_t>(), ctx->occ_sub.as<uint32_t>(), res->rho.as<float>(), want_nb ? 1 : 0,
+                                  ctx->nb_count.as<uint32_t>(), nullptr, nullptr, st);
+            if (want_nb) {
+                // counts (u32, first n+1 entries) -> u64 -> exclusive scan = CSR row pointers
+                SS_HIP(ctx, ctx->nb_tmp.reserve(((size_t)n + 1) * 8));
+                ss_launch_widen(ctx->nb_count.as<uint32_t>(), (size_t)n + 1, ctx->nb_tmp.as<unsigned long long>(), st);
+                s = exclusive_scan_u32<unsigned long long>(ctx, ctx->nb_tmp.as<unsigned long long>(), res->nb_ptr.as<unsigned long long>(), (size_t)n + 1);
+                if (s != SS_OK) return s;
+                unsigned long long total_nb = 0;
+                SS_HIP(ctx, hipMemcpyAsync(&total_nb, res->nb_ptr.as<unsigned long long>() + n, 8, hipMemcpyDeviceToHost, st));
+                SS_HIP(ctx, hipStreamSynchronize(st));
+                if (total_nb >= (1ull << 32)) return fail(ctx, SS_ERR_UNSUPPORTED, "more than 2^32 neighbour entries");
+                res->n_neighbors = total_nb;
+                SS_HIP(ctx, res->nb_idx.reserve((size_t)total_nb * 4 + 16));
+                ss_launch_density_sub(P, n_copies, ctx->cpos.as<float4>(), ctx->cidx.as<uint32_t>(), ctx->ckeys_b.as<uint32_t>(),
+                                      ctx->cell_start2.as<uint32_t>(), ctx->occ_sub.as<uint32_t>(), res->rho.as<float>(), 2, nullptr,
+                                      res->nb_ptr.as<unsigned long long>(), res->nb_idx.as<uint32_t>(), st);
+            }
+            res->has_neighbors = want_nb;
+        } else {
+            res->has_neighbors = prm->global_neighborhood_list != 0;
+            res->n_neighbors = 0;
+            if (res->has_neighbors) {
+                SS_HIP(ctx, res->nb_ptr.reserve(((size_t)n + 1) * 8));
+                SS_HIP(ctx, hipMemsetAsync(res->nb_ptr.p, 0, ((size_t)n + 1) * 8, st));
+            }
         }
     }
     SS_HIP(ctx, hipEventRecord(ctx->ev[4], st));
@@ -722,7 +758,8 @@ void result_release(ss_result* r) {
     for (DevBuf* b : {&r->rho, &r->posvol, &r->perm, &r->inside8, &r->G, &r->blk_minmax, &r->block_slot, &r->active_list, &r->mc_list, &r->mc_slot, &r->masks,
                       &r->vbase, &r->tbase, &r->vertices, &r->vkeys, &r->tri32, &r->tri64})
         b->release();
-    for (HostBuf* b : {&r->h_vertices, &r->h_tri64, &r->h_tri32, &r->h_rho, &r->h_vkeys, &r->h_inside}) b->release();
+    for (HostBuf* b : {&r->h_vertices, &r->h_tri64, &r->h_tri32, &r->h_rho, &r->h_vkeys, &r->h_inside, &r->h_nb_ptr, &r->h_nb_idx}) b->release();
+    for (DevBuf* b : {&r->nb_ptr, &r->nb_idx, &r->nb_idx64}) b->release();
 }
 
 }  // namespace
@@ -763,7 +800,7 @@ void ss_context_destroy(ss_context* c) {
     for (DevBuf* b : {&c->xyz_in, &c->xyz_filt, &c->flags32, &c->offsets, &c->keys_a, &c->keys_b, &c->vals_a, &c->vals_b, &c->cell_count,
                       &c->cell_start, &c->pos_sorted, &c->temp, &c->aabb_partial, &c->aabb_out, &c->block_flag, &c->block_rank, &c->mc_flag,
                       &c->mc_rank, &c->vcount, &c->tcount, &c->counter, &c->member_count, &c->copy_offset, &c->sub_flag, &c->sub_rank,
-                      &c->occ_sub, &c->ckeys_a, &c->ckeys_b, &c->cvals_a, &c->cidx, &c->cpos, &c->cell_count2, &c->cell_start2})
+                      &c->nb_count, &c->nb_tmp, &c->occ_sub, &c->ckeys_a, &c->ckeys_b, &c->cvals_a, &c->cidx, &c->cpos, &c->cell_count2, &c->cell_start2})
         b->release();
     c->h_small.release();
     if (c->ev_ok)
@@ -983,6 +1020,30 @@ ss_status ss_result_particle_inside_aabb(ss_result* r, const uint8_t** flags, ui
         return SS_OK;
     }
     return download<uint8_t>(r, r->inside8, r->h_inside, r->hinside, (size_t)r->n_input, flags);
+}
+
+ss_status ss_result_particle_neighbors(ss_result* r, const uint64_t** row_ptr, const uint64_t** neighbors, uint64_t* n_particles) {
+    if (!r || !r->valid || !row_ptr || !neighbors || !n_particles) return SS_ERR_INVALID_ARGUMENT;
+    ss_context* c = r->ctx;
+    *n_particles = r->n_particles;
+    if (!r->has_neighbors) {  // Option::None (global_neighborhood_list was not requested)
+        *row_ptr = nullptr;
+        *neighbors = nullptr;
+        return SS_OK;
+    }
+    if (!r->hnbi && r->n_neighbors) {
+        SS_HIP(c, hipSetDevice(c->device));
+        SS_HIP(c, r->nb_idx64.reserve((size_t)r->n_neighbors * 8 + 16));
+        ss_launch_widen(r->nb_idx.as<uint32_t>(), (size_t)r->n_neighbors, r->nb_idx64.as<unsigned long long>(), c->stream);
+    }
+    const unsigned long long *p = nullptr, *q = nullptr;
+    ss_status s = download<unsigned long long>(r, r->nb_ptr, r->h_nb_ptr, r->hnbp, (size_t)r->n_particles + 1, &p);
+    if (s != SS_OK) return s;
+    s = download<unsigned long long>(r, r->nb_idx64, r->h_nb_idx, r->hnbi, (size_t)r->n_neighbors, &q);
+    if (s != SS_OK) return s;
+    *row_ptr = reinterpret_cast<const uint64_t*>(p);
+    *neighbors = reinterpret_cast<const uint64_t*>(q);
+    return SS_OK;
 }
 
 ss_status ss_result_stats(const ss_result* r, ss_stats* out) {

@@ -12,7 +12,8 @@ void ss_launch_occupied_list(const uint32_t* flag, const uint32_t* rank, uint32_
 void ss_launch_emit_copies(const SSDev& P, const float* xyz, const uint32_t* copy_offset, const uint32_t* occ_rank, uint32_t* keys, uint32_t* vals,
                            uint32_t* cell_count, hipStream_t st);
 void ss_launch_density_sub(const SSDev& P, uint32_t n_copies, const float4* cpos, const uint32_t* cidx, const uint32_t* ckey,
-                           const uint32_t* cell_start, const uint32_t* occ_sub, float* rho, hipStream_t st);
+                           const uint32_t* cell_start, const uint32_t* occ_sub, float* rho, int mode, uint32_t* nb_count,
+                           const unsigned long long* nb_ptr, uint32_t* nb_idx, hipStream_t st);
 void ss_launch_make_posvol(const SSDev& P, const float4* pos_sorted, const uint32_t* perm, const float* rho, float4* posvol, hipStream_t st);
 void ss_launch_mark_blocks(const SSDev& P, const uint32_t* cell_start, uint32_t ncells, uint32_t* block_flag, hipStream_t st);
 void ss_launch_mark_mc_blocks(const SSDev& P, const uint32_t* block_slot, const float2* blk_minmax, uint32_t nblocks, uint32_t* mc_flag,

@@ -279,9 +279,15 @@ __global__ __launch_bounds__(256) void k_emit_copies(SSDev P, const float* __res
     });
 }
 
+// MODE 0: densities.  MODE 1: densities + neighbour counts (global_neighborhood_list).
+// MODE 2: write the neighbour ids (global particle indices) at nb_ptr[i], in the reference's order
+// (dense_subdomains.rs:617-639: the per-subdomain lists remapped to global indices).
+template <int MODE>
 __global__ __launch_bounds__(256) void k_density_sub(SSDev P, uint32_t n_copies, const float4* __restrict__ cpos, const uint32_t* __restrict__ cidx,
                                                      const uint32_t* __restrict__ ckey, const uint32_t* __restrict__ cell_start,
-                                                     const uint32_t* __restrict__ occ_sub, float* __restrict__ rho) {
+                                                     const uint32_t* __restrict__ occ_sub, float* __restrict__ rho,
+                                                     uint32_t* __restrict__ nb_count, const unsigned long long* __restrict__ nb_ptr,
+                                                     uint32_t* __restrict__ nb_idx) {
     uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= n_copies) return;
     const uint32_t ctot = (uint32_t)(P.sc[0] * P.sc[1] * P.sc[2]);
@@ -308,6 +314,8 @@ __global__ __launch_bounds__(256) void k_density_sub(SSDev P, uint32_t n_copies,
     const int cx = (int)(cell / ((uint32_t)P.sc[2] * (uint32_t)P.sc[1]));
     const uint32_t base = occ * ctot;
     float acc = P.w0;  // density_map.rs:173
+    uint32_t nn = 0;
+    unsigned long long wr = (MODE == 2) ? nb_ptr[cidx[p]] : 0ull;
     for (int pass = 0; pass < 2; ++pass) {
         for (int ox = -1; ox <= 1; ++ox)
             for (int oy = -1; oy <= 1; ++oy)
@@ -323,13 +331,19 @@ __global__ __launch_bounds__(256) void k_density_sub(SSDev P, uint32_t n_copies,
                         const float dx = pj.x - pi.x, dy = pj.y - pi.y, dz = pj.z - pi.z;
                         const float d2 = dx * dx + dy * dy + dz * dz;
                         if (q != p && d2 < P.h2) {  // neighborhood_search.rs:431
-                            const float r = sqrtf(d2);
-                            acc += ss_kernel_evaluate(r, P.h, P.sigma);  // density_map.rs:179-180
+                            if (MODE == 2) {
+                                nb_idx[wr++] = cidx[q];
+                            } else {
+                                const float r = sqrtf(d2);
+                                acc += ss_kernel_evaluate(r, P.h, P.sigma);  // density_map.rs:179-180
+                                ++nn;
+                            }
                         }
                     }
                 }
     }
-    rho[cidx[p]] = acc * P.mass;  // density_map.rs:182, dense_subdomains.rs:596-614
+    if (MODE != 2) rho[cidx[p]] = acc * P.mass;  // density_map.rs:182, dense_subdomains.rs:596-614
+    if (MODE == 1) nb_count[cidx[p]] = nn;
 }
 
 // (x, y, z, V = m / rho) in global-cell order for the splat (v_i of dense_subdomains.rs:832)
@@ -355,9 +369,21 @@ void ss_launch_emit_copies(const SSDev& P, const float* xyz, const uint32_t* cop
     hipLaunchKernelGGL(k_emit_copies, dim3((P.n + 255) / 256), dim3(256), 0, st, P, xyz, copy_offset, occ_rank, keys, vals, cell_count);
 }
 void ss_launch_density_sub(const SSDev& P, uint32_t n_copies, const float4* cpos, const uint32_t* cidx, const uint32_t* ckey,
-                           const uint32_t* cell_start, const uint32_t* occ_sub, float* rho, hipStream_t st) {
+                           const uint32_t* cell_start, const uint32_t* occ_sub, float* rho, int mode, uint32_t* nb_count,
+                           const unsigned long long* nb_ptr, uint32_t* nb_idx, hipStream_t st) {
     if (!n_copies) return;
-    hipLaunchKernelGGL(k_density_sub, dim3((n_copies + 255) / 256), dim3(256), 0, st, P, n_copies, cpos, cidx, ckey, cell_start, occ_sub, rho);
+    const dim3 g((n_copies + 255) / 256), b(256);
+    if (mode == 0)
+        hipLaunchKernelGGL(k_density_sub<0>, g, b, 0, st, P, n_copies, cpos, cidx, ckey, cell_start, occ_sub, rho, nb_count, nb_ptr, nb_idx);
+    else if (mode == 1)
+        hipLaunchKernelGGL(k_density_sub<1>, g, b, 0, st, P, n_copies, cpos, cidx, ckey, cell_start, occ_sub, rho, nb_count, nb_ptr, nb_idx);
+    else
+        hipLaunchKernelGGL(k_density_sub<2>, g, b, 0, st, P, n_copies, cpos, cidx, ckey, cell_start, occ_sub, rho, nb_count, nb_ptr, nb_idx);
+}
+
+__global__ __launch_bounds__(256) void k_widen_u32_u64_generic(const uint32_t* __restrict__ in, size_t n, unsigned long long* __restrict__ out) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = in[i];
 }
 void ss_launch_make_posvol(const SSDev& P, const float4* pos_sorted, const uint32_t* perm, const float* rho, float4* posvol, hipStream_t st) {
     if (!P.n) return;

@@ -293,3 +293,22 @@ def test_full_size_s10m_tank_bit_identical_to_oracle(gpu_ctx, oracle):
     res2 = run_gpu(gpu_ctx, pts, prm)
     h2 = hashlib.sha256(res2.mesh.vertices.tobytes() + res2.mesh.triangles_u32.tobytes() + res2.particle_densities.tobytes()).hexdigest()
     assert h1 == h2
+
+
+@pytest.mark.parametrize("name", ["neighbors_cube_2366_n16", "neighbors_config1"])
+def test_gpu_neighbor_lists_match_reference(gpu_ctx, name):
+    import splashsurf_amd as S
+    g = load_golden(name)
+    prm = golden_params(g)
+    res = S.reconstruct_surface(golden_input(g), particle_radius=prm["particle_radius"], smoothing_length=prm["smoothing_length"],
+                                cube_size=prm["cube_size"], subdomain_grid_auto_disable=False,
+                                subdomain_num_cubes_per_dim=prm["subdomain_num_cubes_per_dim"], global_neighborhood_list=True, context=gpu_ctx)
+    row, idx = res.particle_neighbors_csr
+    assert np.array_equal(row.astype(np.int64), g["row_ptr"])
+    assert np.array_equal(idx.astype(np.int64), g["neighbors"].astype(np.int64))
+    lists = res.particle_neighbors
+    assert len(lists) == g["row_ptr"].size - 1 and lists[0].dtype == np.uint64
+    # without the flag the attribute is None (Option::None, lib.rs:57-60)
+    res2 = S.reconstruct_surface(golden_input(g), particle_radius=prm["particle_radius"], smoothing_length=prm["smoothing_length"],
+                                 cube_size=prm["cube_size"], subdomain_grid_auto_disable=False, context=gpu_ctx)
+    assert res2.particle_neighbors is None

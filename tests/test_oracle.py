@@ -111,3 +111,21 @@ def test_oracle_s1m_counts(oracle):
     sel = g["density_sample_index"]
     assert np.array_equal(res.particle_densities[sel].view(np.uint32), g["density_sample"].view(np.uint32))
     assert hashlib.sha256(res.particle_densities.tobytes()).hexdigest() == str(g["density_sha256"])
+
+
+@pytest.mark.parametrize("name", ["neighbors_cube_2366_n16", "neighbors_config1"])
+def test_oracle_neighbor_lists_match_reference(oracle, name):
+    """global_neighborhood_list=True: per-particle neighbour lists incl. their ORDER equal the reference's
+    (dense_subdomains.rs:617-639)."""
+    g = load_golden(name)
+    prm = golden_params(g)
+    par = oracle.make_params_relative(prm["particle_radius"], prm["smoothing_length"], prm["cube_size"],
+                                      subdomain_num_cubes_per_dim=prm["subdomain_num_cubes_per_dim"], global_neighborhood_list=True)
+    res = oracle.reconstruct_surface(golden_input(g), par)
+    assert np.array_equal(res.neighbor_ptr.astype(np.int64), g["row_ptr"])
+    assert np.array_equal(res.neighbors.astype(np.int64), g["neighbors"].astype(np.int64))
+    # symmetry of the relation d^2 < h^2 (test_neighborhood_search.rs checks the lists against a naive O(N^2) search)
+    ptr, idx = g["row_ptr"], g["neighbors"].astype(np.int64)
+    src = np.repeat(np.arange(ptr.size - 1), np.diff(ptr))
+    a = set(zip(src.tolist(), idx.tolist()))
+    assert all((j, i) in a for (i, j) in list(a)[:5000])

@@ -121,8 +121,33 @@ def save_digest(name, inp_desc, params, ref, n_sample=65536, keep_densities=True
     np.savez_compressed(os.path.join(GOLD, name + ".npz"), **d)
 
 
+def gen_neighbor_goldens(report):
+    for name, fn, r, l, c, n_cubes in [("neighbors_cube_2366_n16", "cube_2366_particles.npy", 0.025, 2.0, 0.75, 16),
+                                       ("neighbors_config1", "double_dam_break_frame_26_4732_particles.npy", 0.025, 2.0, 1.1, 64)]:
+        pts = np.load(os.path.join(DATA, fn))
+        res = pysplashsurf.reconstruct_surface(pts, particle_radius=r, smoothing_length=l, cube_size=c, simd=False, subdomain_grid=True,
+                                               subdomain_grid_auto_disable=False, subdomain_num_cubes_per_dim=n_cubes,
+                                               global_neighborhood_list=True)
+        lists = res.particle_neighbors.get_neighborhood_lists()
+        ptr = np.concatenate([[0], np.cumsum([len(x) for x in lists])]).astype(np.int64)
+        idx = np.concatenate([np.asarray(x, dtype=np.int64) for x in lists]) if ptr[-1] else np.zeros(0, np.int64)
+        par = O.make_params_relative(r, l, c, subdomain_num_cubes_per_dim=n_cubes, global_neighborhood_list=True)
+        orc = O.reconstruct_surface(pts, par)
+        assert np.array_equal(orc.neighbor_ptr.astype(np.int64), ptr) and np.array_equal(orc.neighbors.astype(np.int64), idx), name
+        np.savez_compressed(os.path.join(GOLD, name + ".npz"), row_ptr=ptr, neighbors=idx.astype(np.int32),
+                            params=np.array(json.dumps(dict(particle_radius=r, smoothing_length=l, cube_size=c, iso_surface_threshold=0.6,
+                                                            subdomain_num_cubes_per_dim=n_cubes))),
+                            input=np.array(json.dumps(dict(kind="file", file=fn))))
+        report[name] = dict(n=len(lists), entries=int(ptr[-1]))
+
+
 def main():
     os.makedirs(GOLD, exist_ok=True)
+    if "--neighbors-only" in sys.argv:
+        rep = {}
+        gen_neighbor_goldens(rep)
+        print(rep)
+        return
     report = {}
 
     # ---- G0: known-answer test of the reference (tests/integration_tests/test_simple.rs:71-126)
@@ -214,6 +239,9 @@ def main():
     save_digest("config2_s1m", dict(kind="workload", name="uniform_cube", n=1_000_000, seed=12345),
                 dict(particle_radius=0.01, smoothing_length=2.0, cube_size=1.0, iso_surface_threshold=0.6), ref,
                 keep_densities=False)
+
+    # ---- neighbour lists (global_neighborhood_list=True, dense_subdomains.rs:617-639)
+    gen_neighbor_goldens(report)
 
     # ---- G5: splat micro-fixture (data/density_grid_loop_subdomain_33.json -> npz, inputs only)
     src = "/root/reference/data/density_grid_loop_subdomain_33.json"
