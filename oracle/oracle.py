@@ -108,6 +108,8 @@ def lib():
         L.so_shard_densities.restype = C.c_int
         L.so_shard_reconstruct.argtypes = [C.c_void_p, C.c_uint64, C.POINTER(SoParams), C.POINTER(SoShard), C.c_void_p, C.POINTER(SoResult)]
         L.so_shard_reconstruct.restype = C.c_int
+        L.so_debug_shard_levelset.argtypes = [C.c_void_p, C.c_uint64, C.POINTER(SoParams), C.POINTER(SoShard), C.c_void_p, C.c_int64, C.c_void_p]
+        L.so_debug_shard_levelset.restype = C.c_int64
         _lib = L
     return _lib
 
@@ -196,6 +198,17 @@ def shard_reconstruct(xyz, rho, params, domain_min, domain_max, sub_lo, sub_hi):
     if rc != 0:
         raise RuntimeError("so_shard_reconstruct failed with code %d" % rc)
     return _unpack(res)
+
+
+def shard_levelset(xyz, rho, params, domain_min, domain_max, sub_lo, sub_hi, flat_subdomain):
+    xyz = np.ascontiguousarray(xyz, dtype=np.float32).reshape(-1, 3)
+    rho = np.ascontiguousarray(rho, dtype=np.float32)
+    s = _make_shard(domain_min, domain_max, sub_lo, sub_hi)
+    n = params.subdomain_num_cubes_per_dim + 1
+    out = np.zeros((n, n, n), dtype=np.float32)
+    cnt = lib().so_debug_shard_levelset(xyz.ctypes.data_as(C.c_void_p), xyz.shape[0], C.byref(params), C.byref(s),
+                                        rho.ctypes.data_as(C.c_void_p), int(flat_subdomain), out.ctypes.data_as(C.c_void_p))
+    return cnt, out
 
 
 def reconstruct_surface(xyz, params):

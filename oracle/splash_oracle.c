@@ -1147,6 +1147,33 @@ int so_shard_reconstruct(const float *xyz, uint64_t n, const so_params *P, const
     return 0;
 }
 
+int64_t so_debug_shard_levelset(const float *xyz, uint64_t n, const so_params *P, const so_shard *sh, const float *rho, int64_t flat_subdomain,
+                                float *out_grid) {
+    sd_params S;
+    if (shard_setup(P, sh, &S)) return -2;
+    subdomains_t subs;
+    memset(&subs, 0, sizeof(subs));
+    if (decomposition_boxed(&S, xyz, n, &subs, 1, sh->sub_lo, sh->sub_hi) != 0) return -2;
+    int64_t result = -1;
+    const int64_t np = S.subdomain_cubes + 1;
+    workspace_t w;
+    memset(&w, 0, sizeof(w));
+    for (int64_t s = 0; s < subs.n_sub; ++s) {
+        if (subs.flat_index[s] != flat_subdomain) continue;
+        size_t P_s = (size_t)(subs.offsets[s + 1] - subs.offsets[s]);
+        gather_positions_densities(xyz, rho, subs.particles + subs.offsets[s], P_s, &w);
+        ws_prepare_levelset(&w, np);
+        int64_t sub[3];
+        grid_unflatten_cell(&S.subdomain_grid, flat_subdomain, sub);
+        density_grid_loop_scalar(&S, sub, w.pos, w.rho, P_s, w.levelset);
+        memcpy(out_grid, w.levelset, sizeof(float) * (size_t)(np * np * np));
+        result = (int64_t)P_s;
+    }
+    ws_free(&w);
+    subdomains_free(&subs);
+    return result;
+}
+
 void so_result_free(so_result *r) {
     free(r->particle_densities);
     free(r->particle_inside_aabb);

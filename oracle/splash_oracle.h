@@ -95,6 +95,12 @@ int so_shard_densities(const float *xyz, uint64_t n, const so_params *params, co
 int so_shard_reconstruct(const float *xyz, uint64_t n, const so_params *params, const so_shard *shard, const float *rho,
                          so_result *out);
 
+/* level-set values ((n+1)^3) of one subdomain of the shard for GIVEN densities: the stage-level
+ * observable of density_grid_loop_scalar (dense_subdomains.rs:784-847); returns the subdomain's particle
+ * count or -1 if it has none */
+int64_t so_debug_shard_levelset(const float *xyz, uint64_t n, const so_params *params, const so_shard *shard, const float *rho,
+                                int64_t flat_subdomain, float *out_grid);
+
 #ifdef __cplusplus
 }
 #endif
