@@ -316,31 +316,57 @@ __global__ __launch_bounds__(256) void k_density_sub(SSDev P, uint32_t n_copies,
     float acc = P.w0;  // density_map.rs:173
     uint32_t nn = 0;
     unsigned long long wr = (MODE == 2) ? nb_ptr[cidx[p]] : 0ull;
-    for (int pass = 0; pass < 2; ++pass) {
+    // The 27 cells in the reference's order (step (x,y,z) lexicographic, own cell last) are 11 runs of
+    // the cell-sorted copy array, because cells that differ only in z are contiguous: eight (x,y) rows
+    // of three cells, then z-1 and z+1 of the own row, then the own cell.  All run bounds are fetched
+    // first (independent loads), then the runs are walked.
+    uint32_t rb[11], re[11];
+    {
+        const int z0 = max(cz - 1, 0), z1 = min(cz + 1, P.sc[2] - 1);
+        int k = 0;
+#pragma unroll
         for (int ox = -1; ox <= 1; ++ox)
-            for (int oy = -1; oy <= 1; ++oy)
-                for (int oz = -1; oz <= 1; ++oz) {
-                    const bool center = (ox == 0 && oy == 0 && oz == 0);
-                    if ((pass == 0) == center) continue;
-                    const int nx = cx + ox, ny = cy + oy, nz = cz + oz;
-                    if (nx < 0 || ny < 0 || nz < 0 || nx >= P.sc[0] || ny >= P.sc[1] || nz >= P.sc[2]) continue;
-                    const uint32_t k2 = base + (uint32_t)((nx * P.sc[1] + ny) * P.sc[2] + nz);
-                    const uint32_t qb = cell_start[k2], qe = cell_start[k2 + 1];
-                    for (uint32_t q = qb; q < qe; ++q) {
-                        const float4 pj = cpos[q];
-                        const float dx = pj.x - pi.x, dy = pj.y - pi.y, dz = pj.z - pi.z;
-                        const float d2 = dx * dx + dy * dy + dz * dz;
-                        if (q != p && d2 < P.h2) {  // neighborhood_search.rs:431
-                            if (MODE == 2) {
-                                nb_idx[wr++] = cidx[q];
-                            } else {
-                                const float r = sqrtf(d2);
-                                acc += ss_kernel_evaluate(r, P.h, P.sigma);  // density_map.rs:179-180
-                                ++nn;
-                            }
-                        }
-                    }
+#pragma unroll
+            for (int oy = -1; oy <= 1; ++oy) {
+                if (ox == 0 && oy == 0) continue;
+                const int nx = cx + ox, ny = cy + oy;
+                uint32_t b = 0, e = 0;
+                if (nx >= 0 && ny >= 0 && nx < P.sc[0] && ny < P.sc[1]) {
+                    const uint32_t row = base + (uint32_t)((nx * P.sc[1] + ny) * P.sc[2]);
+                    b = cell_start[row + (uint32_t)z0];
+                    e = cell_start[row + (uint32_t)z1 + 1u];
                 }
+                // rows before the own row come first, rows after it later: slots 0..3 and 6..9
+                const int slot = (k < 4) ? k : k + 2;
+                rb[slot] = b;
+                re[slot] = e;
+                ++k;
+            }
+        const uint32_t row = base + (uint32_t)((cx * P.sc[1] + cy) * P.sc[2]);
+        const uint32_t own_b = cell_start[row + (uint32_t)cz], own_e = cell_start[row + (uint32_t)cz + 1u];
+        rb[4] = (cz > 0) ? cell_start[row + (uint32_t)cz - 1u] : own_b;  // cell z-1 of the own row
+        re[4] = own_b;
+        rb[5] = own_e;                                                   // cell z+1 of the own row
+        re[5] = (cz + 1 < P.sc[2]) ? cell_start[row + (uint32_t)cz + 2u] : own_e;
+        rb[10] = own_b;                                                  // own cell last
+        re[10] = own_e;
+    }
+#pragma unroll
+    for (int run = 0; run < 11; ++run) {
+        for (uint32_t q = rb[run]; q < re[run]; ++q) {
+            const float4 pj = cpos[q];
+            const float dx = pj.x - pi.x, dy = pj.y - pi.y, dz = pj.z - pi.z;
+            const float d2 = dx * dx + dy * dy + dz * dz;
+            if (q != p && d2 < P.h2) {  // neighborhood_search.rs:431
+                if (MODE == 2) {
+                    nb_idx[wr++] = cidx[q];
+                } else {
+                    const float r = sqrtf(d2);
+                    acc += ss_kernel_evaluate(r, P.h, P.sigma);  // density_map.rs:179-180
+                    ++nn;
+                }
+            }
+        }
     }
     if (MODE != 2) rho[cidx[p]] = acc * P.mass;  // density_map.rs:182, dense_subdomains.rs:596-614
     if (MODE == 1) nb_count[cidx[p]] = nn;
