@@ -326,7 +326,8 @@ def test_splat_on_reference_grid_loop_fixture(oracle):
     pts = np.ascontiguousarray(g["subdomain_particles"], dtype=np.float32)
     rho = np.ascontiguousarray(g["subdomain_particle_densities"], dtype=np.float32)
     h, cs, r = float(g["compact_support_radius"]), float(g["cell_size"]), 0.01
-    assert (np.float32(r) + np.float32(r)) ** 3 * np.float32(1000.0) == g["particle_rest_mass"]
+    d = np.float32(r) + np.float32(r)
+    assert (d * d * d) * np.float32(1000.0) == g["particle_rest_mass"]  # kernel.rs:28-30, dense_subdomains.rs:117-118
     gmin, nc = g["global_min"].astype(np.float64), g["global_n_points"] - 1
     margin = cs * np.ceil(np.float32(h) / np.float32(cs)) * (1 + np.sqrt(1.1920929e-07))
     dmin, dmax = gmin + r + margin + 0.5 * cs, gmin + nc * cs - r - margin - 0.5 * cs
