@@ -87,12 +87,11 @@ struct ss_context {
     std::string err;
     int err_detail = 0;
     // scratch (grow-only, reused across calls = the reference's workspace.rs)
-    DevBuf xyz_in, xyz_filt, flags32, offsets, keys_a, keys_b, vals_a, vals_b, cell_count, cell_start, pos_sorted, temp, aabb_partial, aabb_out,
+    DevBuf xyz_in, xyz_filt, flags32, offsets, keys_a, keys_b, vals_a, cell_count, cell_start, pos_sorted, temp, aabb_partial, aabb_out,
         block_flag, block_rank, mc_flag, mc_rank, vcount, tcount, counter;
     // per-subdomain particle copies for the density stage
     DevBuf nb_count, nb_tmp;
     DevBuf member_count, copy_offset, sub_flag, sub_rank, occ_sub, ckeys_a, ckeys_b, cvals_a, cidx, cpos, cell_count2, cell_start2;
-    HostBuf h_small;
     hipEvent_t ev[12];  // 0..9 stage boundaries, 10/11 start of phase 2
     // exhaustively verified "division by h via reciprocal + 2 FMA" (ss_kernels.hip ss_div_by_h)
     float fastdiv_h = 0.0f;
@@ -470,7 +469,6 @@ ss_status phase_begin(ss_context* ctx, const float* xyz, uint64_t n_in, const ss
     SS_HIP(ctx, hipEventRecord(ctx->ev[2], st));
 
     const size_t ncells = (size_t)P.kdim[0] * P.kdim[1] * P.kdim[2];
-    const size_t nblocks = (size_t)P.nb[0] * P.nb[1] * P.nb[2];
 
     // ---- K1: bin + sort (decomposition) ----
     SS_HIP(ctx, res->rho.reserve((size_t)n * 4 + 16));
@@ -797,12 +795,11 @@ void ss_context_destroy(ss_context* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipDeviceSynchronize();
-    for (DevBuf* b : {&c->xyz_in, &c->xyz_filt, &c->flags32, &c->offsets, &c->keys_a, &c->keys_b, &c->vals_a, &c->vals_b, &c->cell_count,
+    for (DevBuf* b : {&c->xyz_in, &c->xyz_filt, &c->flags32, &c->offsets, &c->keys_a, &c->keys_b, &c->vals_a, &c->cell_count,
                       &c->cell_start, &c->pos_sorted, &c->temp, &c->aabb_partial, &c->aabb_out, &c->block_flag, &c->block_rank, &c->mc_flag,
                       &c->mc_rank, &c->vcount, &c->tcount, &c->counter, &c->member_count, &c->copy_offset, &c->sub_flag, &c->sub_rank,
                       &c->nb_count, &c->nb_tmp, &c->occ_sub, &c->ckeys_a, &c->ckeys_b, &c->cvals_a, &c->cidx, &c->cpos, &c->cell_count2, &c->cell_start2})
         b->release();
-    c->h_small.release();
     if (c->ev_ok)
         for (int i = 0; i < 12; ++i) (void)hipEventDestroy(c->ev[i]);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);

@@ -406,11 +406,6 @@ void ss_launch_density_sub(const SSDev& P, uint32_t n_copies, const float4* cpos
     else
         hipLaunchKernelGGL(k_density_sub<2>, g, b, 0, st, P, n_copies, cpos, cidx, ckey, cell_start, occ_sub, rho, nb_count, nb_ptr, nb_idx);
 }
-
-__global__ __launch_bounds__(256) void k_widen_u32_u64_generic(const uint32_t* __restrict__ in, size_t n, unsigned long long* __restrict__ out) {
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) out[i] = in[i];
-}
 void ss_launch_make_posvol(const SSDev& P, const float4* pos_sorted, const uint32_t* perm, const float* rho, float4* posvol, hipStream_t st) {
     if (!P.n) return;
     hipLaunchKernelGGL(k_make_posvol, dim3((P.n + 255) / 256), dim3(256), 0, st, P, pos_sorted, perm, rho, posvol);
