@@ -809,8 +809,10 @@ __global__ __launch_bounds__(512) void k_splat(SSDev P, const float4* __restrict
         // ---- accumulate ----
         // Phase A: 64 tile entries at a time are tested against the wave's 4^3 sub-block (distance to box
         // <= reach) with one ballot.  Phase B: the surviving entries are walked in order (= ascending
-        // particle index); the entry is broadcast from the lane holding it with v_readlane (no LDS round
-        // trip) and every lane evaluates G += V * W(|x - p|) for its point iff d^2 < 1.01 h^2.
+        // particle index) and every lane evaluates G += V * W(|x - p|) for its point iff d^2 < 1.01 h^2.
+        // Measured issue costs on gfx950 (tools/ubench/valu_rates.hip): f32 add/mul ~2.3 cycles per wave64
+        // instruction, fma ~3.5, cmp/cndmask/readlane ~3.7, SGPR-source operands ~3.9, v_pk_* ~6.2,
+        // v_sqrt/v_rcp ~7.4 -- hence LDS broadcast reads (not v_readlane) and no packed math in this loop.
         if (wave_valid) {
             const float rh = 1.0f / P.h;
             for (int base = 0; base < n_tile; base += 64) {
@@ -825,17 +827,23 @@ __global__ __launch_bounds__(512) void k_splat(SSDev P, const float4* __restrict
                     pass = (ex * ex + ey * ey + ez * ez) <= wave_r2;
                 }
                 unsigned long long wmask = __ballot(pass);
-                while (wmask) {
-                    const int bit = __ffsll((long long)wmask) - 1;
-                    wmask &= wmask - 1;
-                    const float cx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pv.x), bit));
-                    const float cy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pv.y), bit));
-                    const float cz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pv.z), bit));
-                    const float cv = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pv.w), bit));
-                    const float dx = cx - px, dy = cy - py, dz = cz - pz;  // p_i - point, :828
-                    const float d2 = dx * dx + dy * dy + dz * dz;
-                    if (d2 < P.H2) {  // :831
-                        acc += cv * ss_kernel_w<FASTDIV>(d2, P.h, rh, P.sigma);  // :832-841
+                if (wmask) {
+                    // Entries are fetched with a wave-uniform LDS read (broadcast: LDS pipe, no VALU issue slot,
+                    // operands arrive in VGPRs) one iteration ahead of their use.
+                    int bit = __ffsll((long long)wmask) - 1;
+                    float4 cur = s.pay[base + bit];
+                    while (true) {
+                        wmask &= wmask - 1;
+                        const int nbit = wmask ? (__ffsll((long long)wmask) - 1) : bit;
+                        const float4 nxt = s.pay[base + nbit];
+                        const float dx = cur.x - px, dy = cur.y - py, dz = cur.z - pz;  // p_i - point, :828
+                        const float d2 = dx * dx + dy * dy + dz * dz;
+                        if (d2 < P.H2) {  // :831
+                            acc += cur.w * ss_kernel_w<FASTDIV>(d2, P.h, rh, P.sigma);  // :832-841
+                        }
+                        if (!wmask) break;
+                        cur = nxt;
+                        bit = nbit;
                     }
                 }
             }
