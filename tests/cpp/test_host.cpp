@@ -1,0 +1,106 @@
+// C++ host test over the C ABI through include/splashsurf_hip.hpp.
+// Mirrors the reference's integration test tests/integration_tests/test_simple.rs:71-126 (known-answer
+// test: one particle => 6 vertices / 8 triangles, closed + manifold) and the error behaviour of
+// lib.rs:289-314 / density_map.rs:555-559.  Exit code 0 = all checks passed.
+#include <cmath>
+#include <cstdio>
+#include <map>
+#include <utility>
+
+#include "splashsurf_hip.hpp"
+
+using namespace splashsurf;
+
+static int failures = 0;
+#define CHECK(cond)                                                          \
+    do {                                                                     \
+        if (!(cond)) {                                                       \
+            std::fprintf(stderr, "CHECK failed: %s (line %d)\n", #cond, __LINE__); \
+            ++failures;                                                      \
+        }                                                                    \
+    } while (0)
+
+// every directed edge once, its reverse once (what check_mesh_consistency asserts, marching_cubes.rs:129-213)
+static bool closed_manifold(const TriMesh3d& m) {
+    std::map<std::pair<uint64_t, uint64_t>, int> edges;
+    for (const auto& t : m.triangles)
+        for (int k = 0; k < 3; ++k) edges[{t[k], t[(k + 1) % 3]}]++;
+    for (const auto& e : edges) {
+        if (e.second != 1) return false;
+        auto r = edges.find({e.first.second, e.first.first});
+        if (r == edges.end() || r->second != 1) return false;
+    }
+    return true;
+}
+
+int main() {
+    Context ctx(0);
+
+    // --- test_simple.rs:71-126 ---
+    {
+        std::vector<Vector3f> particles = {{0.01f, 0.0f, 0.0f}};
+        Parameters p = Parameters::with(1.0f, 1.0f, 1.0f);
+        p.iso_surface_threshold = 0.1f;
+        p.spatial_decomposition.grid.auto_disable = false;
+        SurfaceReconstruction s = ctx.reconstruct_surface(particles, p);
+        CHECK(s.mesh.vertices.size() == 6);
+        CHECK(s.mesh.triangles.size() == 8);
+        CHECK(closed_manifold(s.mesh));
+        CHECK(s.particle_densities && s.particle_densities->size() == 1);
+        CHECK(std::fabs((*s.particle_densities)[0] - 20371.834f) < 1e-2f);
+        CHECK(s.subdomain_grid.has_value());
+        CHECK(s.grid.cells_per_dim[0] == 64 && s.grid.aabb.min[0] == -2.0f && s.grid.aabb.min[1] == -3.0f);
+        CHECK(!s.particle_inside_aabb.has_value());
+        CHECK(!s.particle_neighbors.has_value());
+        for (const auto& v : s.mesh.vertices) {
+            const float r = std::sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+            CHECK(std::fabs(r - 0.89994f) < 2e-3f);
+        }
+        // in-place reuse (lib.rs:340-346) + neighbour lists
+        std::vector<Vector3f> two = {{0.0f, 0.0f, 0.0f}, {0.5f, 0.0f, 0.0f}, {5.0f, 5.0f, 5.0f}};
+        p.global_neighborhood_list = true;
+        ctx.reconstruct_surface_inplace(two, p, s);
+        CHECK(s.particle_neighbors.has_value() && s.particle_neighbors->size() == 3);
+        CHECK((*s.particle_neighbors)[0].size() == 1 && (*s.particle_neighbors)[0][0] == 1);
+        CHECK((*s.particle_neighbors)[1].size() == 1 && (*s.particle_neighbors)[1][0] == 0);
+        CHECK((*s.particle_neighbors)[2].empty());
+        CHECK(closed_manifold(s.mesh));
+    }
+    // --- empty input is Ok with an empty mesh (SURVEY 8b edge behaviour) ---
+    {
+        Parameters p = Parameters::relative(0.025f, 4.0f, 1.0f);
+        SurfaceReconstruction s = ctx.reconstruct_surface({}, p);
+        CHECK(s.mesh.vertices.empty() && s.mesh.triangles.empty());
+        CHECK(s.particle_densities && s.particle_densities->empty());
+        UniformGrid g = ctx.grid_for_reconstruction({}, p);
+        CHECK(g.cells_per_dim[0] == 12);
+    }
+    // --- errors ---
+    {
+        Parameters p = Parameters::relative(0.025f, 4.0f, 1.0f);
+        p.cube_size = 0.0f;
+        try {
+            ctx.reconstruct_surface({{0.0f, 0.0f, 0.0f}}, p);
+            CHECK(false);
+        } catch (const ReconstructionError& e) {
+            CHECK(e.variant == ReconstructionError::Variant::Unknown);  // the reference panics here
+        }
+        p = Parameters::relative(0.025f, 4.0f, 1.0f);
+        p.spatial_decomposition.kind = SpatialDecomposition::Kind::None;
+        try {
+            ctx.reconstruct_surface({{0.0f, 0.0f, 0.0f}}, p);
+            CHECK(false);
+        } catch (const ReconstructionError& e) {
+            CHECK(e.variant == ReconstructionError::Variant::Unsupported);
+        }
+        // particle AABB that excludes everything: Ok, empty mesh, flags all false
+        p = Parameters::relative(0.025f, 4.0f, 1.0f);
+        p.particle_aabb = Aabb3d{{1.0f, 1.0f, 1.0f}, {2.0f, 2.0f, 2.0f}};
+        SurfaceReconstruction s = ctx.reconstruct_surface({{0.3f, 0.2f, 0.1f}, {0.35f, 0.2f, 0.1f}}, p);
+        CHECK(s.mesh.vertices.empty());
+        CHECK(s.particle_inside_aabb && s.particle_inside_aabb->size() == 2 && !(*s.particle_inside_aabb)[0]);
+        CHECK(s.particle_densities && s.particle_densities->empty());
+    }
+    if (failures == 0) std::printf("cpp host: all checks passed\n");
+    return failures == 0 ? 0 : 1;
+}

@@ -347,3 +347,18 @@ def test_splat_on_reference_grid_loop_fixture(oracle):
     assert int((ref != 0).sum()) > 100000
     nbad = int((got.view(np.uint32) != ref.view(np.uint32)).sum())
     assert nbad == 0, "%d of %d level-set values differ (max abs %g)" % (nbad, ref.size, np.abs(got - ref).max())
+
+
+def test_cpp_host_over_c_abi(tmp_path):
+    """A C++ host (include/splashsurf_hip.hpp, mirroring the reference's Rust API) drives the C ABI without
+    Python: the reference's known-answer test (test_simple.rs:71-126), in-place reuse, neighbour lists and
+    the error variants."""
+    import subprocess
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    exe = str(tmp_path / "test_host")
+    libdir = os.path.join(root, "splashsurf_amd")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-I" + os.path.join(root, "include"), os.path.join(root, "tests", "cpp", "test_host.cpp"),
+                           "-L" + libdir, "-lsplashsurf_hip", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib", "-o", exe])
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "all checks passed" in out.stdout
