@@ -13,6 +13,28 @@
  */
 #include "splash_oracle.h"
 
+/* One source, two translation units: -DSO_F64 builds the f64 instantiation (so64_*). */
+#include <float.h>
+#ifdef SO_F64
+typedef double real;
+#define SOT(name) so64_##name
+#define SOFN(name) so64_##name
+#define R_FLOOR floor
+#define R_CEIL ceil
+#define R_SQRT sqrt
+#define R_EPSILON DBL_EPSILON
+#else
+typedef float real;
+#define SOT(name) so_##name
+#define SOFN(name) so_##name
+#define R_FLOOR floorf
+#define R_CEIL ceilf
+#define R_SQRT sqrtf
+#define R_EPSILON FLT_EPSILON
+#endif
+/* literal of the Real type: the reference writes f64 literals converted with R::from_float */
+#define RC(x) ((real)(x))
+
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -34,7 +56,7 @@ static double now_s(void) {
 static const int8_t MC_TABLE[256][16] = {
 #include "../splashsurf_amd/csrc/mc_table.inc"
 };
-const int8_t *so_mc_table(void) { return &MC_TABLE[0][0]; }
+const int8_t *SOFN(mc_table)(void) { return &MC_TABLE[0][0]; }
 
 /* uniform_grid.rs:825-834 */
 static const int8_t CELL_LOCAL_POINT_COORDS[8][3] = {
@@ -47,35 +69,35 @@ static const int8_t CELL_LOCAL_EDGES[12][2] = {{0, 0}, {1, 1}, {3, 0}, {0, 1}, {
  * Cubic spline kernel, scalar path (kernel.rs:58-107)
  * ------------------------------------------------------------------------------------------ */
 typedef struct {
-    float h;
-    float sigma;
+    real h;
+    real sigma;
 } cubic_kernel;
 
-static cubic_kernel kernel_new(float h) { /* kernel.rs:60-68 */
+static cubic_kernel kernel_new(real h) { /* kernel.rs:60-68 */
     cubic_kernel k;
     k.h = h;
-    k.sigma = 8.0f / (h * h * h);
+    k.sigma = RC(8.0) / (h * h * h);
     return k;
 }
 
-static float cubic_function(float q) { /* kernel.rs:71-81 */
-    const float pi = 3.14159265358979323846f;
-    if (q < 1.0f) {
-        return (3.0f / (2.0f * pi)) * ((2.0f / 3.0f) - q * q + 0.5f * q * q * q);
-    } else if (q < 2.0f) {
-        float x = 2.0f - q;
-        return (1.0f / (4.0f * pi)) * x * x * x;
+static real cubic_function(real q) { /* kernel.rs:71-81 */
+    const real pi = RC(3.14159265358979323846);
+    if (q < RC(1.0)) {
+        return (RC(3.0) / (RC(2.0) * pi)) * ((RC(2.0) / RC(3.0)) - q * q + RC(0.5) * q * q * q);
+    } else if (q < RC(2.0)) {
+        real x = RC(2.0) - q;
+        return (RC(1.0) / (RC(4.0) * pi)) * x * x * x;
     } else {
-        return 0.0f;
+        return RC(0.0);
     }
 }
 
-static float kernel_evaluate(const cubic_kernel *k, float r) { /* kernel.rs:103-106 */
-    float q = (r + r) / k->h;
+static real kernel_evaluate(const cubic_kernel *k, real r) { /* kernel.rs:103-106 */
+    real q = (r + r) / k->h;
     return k->sigma * cubic_function(q);
 }
 
-float so_cubic_kernel_evaluate(float h, float r) {
+real SOFN(cubic_kernel_evaluate)(real h, real r) {
     cubic_kernel k = kernel_new(h);
     return kernel_evaluate(&k, r);
 }
@@ -83,56 +105,56 @@ float so_cubic_kernel_evaluate(float h, float r) {
 /* ------------------------------------------------------------------------------------------
  * Uniform grid (uniform_grid.rs)
  * ------------------------------------------------------------------------------------------ */
-static void grid_new(so_grid *g, const float min[3], const int64_t n_cells[3], float cs) {
+static void grid_new(SOT(grid) *g, const real min[3], const int64_t n_cells[3], real cs) {
     /* uniform_grid.rs:203-232, 662-674 */
     for (int d = 0; d < 3; ++d) {
         g->aabb_min[d] = min[d];
         g->n_cells[d] = n_cells[d];
         g->n_points[d] = n_cells[d] + 1;
-        g->aabb_max[d] = min[d] + cs * (float)(double)n_cells[d];
+        g->aabb_max[d] = min[d] + cs * (real)(double)n_cells[d];
     }
     g->cell_size = cs;
 }
 
 /* returns 0 ok, 1 invalid cell size, 2 degenerate, 3 inconsistent (uniform_grid.rs:175-201) */
-static int grid_from_aabb(so_grid *g, const float amin[3], const float amax[3], float cs) {
-    if (!(cs > 0.0f)) return 1;
+static int grid_from_aabb(SOT(grid) *g, const real amin[3], const real amax[3], real cs) {
+    if (!(cs > RC(0.0))) return 1;
     if (amin[0] == amax[0] && amin[1] == amax[1] && amin[2] == amax[2]) return 2; /* aabb.rs:159-161 */
     if (!(amin[0] <= amax[0] && amin[1] <= amax[1] && amin[2] <= amax[2])) return 3; /* aabb.rs:147-149 */
-    float aligned_min[3];
+    real aligned_min[3];
     int64_t n_cells[3];
     for (int d = 0; d < 3; ++d) {
-        aligned_min[d] = floorf(amin[d] / cs) * cs;
-        float n_cells_real = (amax[d] - aligned_min[d]) / cs;
-        int64_t n = (int64_t)(double)ceilf(n_cells_real); /* uniform_grid.rs:647-655 */
+        aligned_min[d] = R_FLOOR(amin[d] / cs) * cs;
+        real n_cells_real = (amax[d] - aligned_min[d]) / cs;
+        int64_t n = (int64_t)(double)R_CEIL(n_cells_real); /* uniform_grid.rs:647-655 */
         n_cells[d] = n < 1 ? 1 : n;
     }
     grid_new(g, aligned_min, n_cells, cs);
     return 0;
 }
 
-static inline float grid_point_coord(const so_grid *g, int64_t i, int d) { /* uniform_grid.rs:418-425 */
-    return g->aabb_min[d] + (float)(double)i * g->cell_size;
+static inline real grid_point_coord(const SOT(grid) *g, int64_t i, int d) { /* uniform_grid.rs:418-425 */
+    return g->aabb_min[d] + (real)(double)i * g->cell_size;
 }
 
-static inline void grid_enclosing_cell(const so_grid *g, const float p[3], int64_t ijk[3]) {
+static inline void grid_enclosing_cell(const SOT(grid) *g, const real p[3], int64_t ijk[3]) {
     /* uniform_grid.rs:444-451 */
     for (int d = 0; d < 3; ++d) {
-        float normalized = (p[d] - g->aabb_min[d]) / g->cell_size;
-        ijk[d] = (int64_t)(double)floorf(normalized);
+        real normalized = (p[d] - g->aabb_min[d]) / g->cell_size;
+        ijk[d] = (int64_t)(double)R_FLOOR(normalized);
     }
 }
 
-static inline int grid_cell_exists(const so_grid *g, const int64_t ijk[3]) { /* uniform_grid.rs:311-319 */
+static inline int grid_cell_exists(const SOT(grid) *g, const int64_t ijk[3]) { /* uniform_grid.rs:311-319 */
     return ijk[0] >= 0 && ijk[1] >= 0 && ijk[2] >= 0 && ijk[0] < g->n_cells[0] &&
            ijk[1] < g->n_cells[1] && ijk[2] < g->n_cells[2];
 }
 
-static inline int64_t grid_flatten_cell(const so_grid *g, const int64_t ijk[3]) { /* uniform_grid.rs:361-365 */
+static inline int64_t grid_flatten_cell(const SOT(grid) *g, const int64_t ijk[3]) { /* uniform_grid.rs:361-365 */
     return ijk[0] * g->n_cells[1] * g->n_cells[2] + ijk[1] * g->n_cells[2] + ijk[2];
 }
 
-static inline void grid_unflatten_cell(const so_grid *g, int64_t flat, int64_t ijk[3]) { /* uniform_grid.rs:399-407 */
+static inline void grid_unflatten_cell(const SOT(grid) *g, int64_t flat, int64_t ijk[3]) { /* uniform_grid.rs:399-407 */
     int64_t nyz = g->n_cells[1] * g->n_cells[2];
     ijk[0] = flat / nyz;
     ijk[1] = (flat - ijk[0] * nyz) / g->n_cells[2];
@@ -142,16 +164,16 @@ static inline void grid_unflatten_cell(const so_grid *g, int64_t flat, int64_t i
 /* ------------------------------------------------------------------------------------------
  * Grid set-up (lib.rs:476-516, density_map.rs:551-580)
  * ------------------------------------------------------------------------------------------ */
-static int grid_for_particle_aabb(const float pmin[3], const float pmax[3], const so_params *P, so_grid *out) {
+static int grid_for_particle_aabb(const real pmin[3], const real pmax[3], const SOT(params) *P, SOT(grid) *out) {
     /* lib.rs:496-515 for a known particle AABB */
-    float amin[3], amax[3];
+    real amin[3], amax[3];
     for (int d = 0; d < 3; ++d) {
         amin[d] = pmin[d] - P->particle_radius;
         amax[d] = pmax[d] + P->particle_radius;
     }
-    float half_supported_cells_real = ceilf(P->compact_support_radius / P->cube_size);
-    const float eps_sqrt = sqrtf(1.1920929e-07f);
-    float kernel_margin = P->cube_size * half_supported_cells_real * (1.0f + eps_sqrt);
+    real half_supported_cells_real = R_CEIL(P->compact_support_radius / P->cube_size);
+    const real eps_sqrt = R_SQRT(R_EPSILON);
+    real kernel_margin = P->cube_size * half_supported_cells_real * (RC(1.0) + eps_sqrt);
     for (int d = 0; d < 3; ++d) {
         amin[d] -= kernel_margin;
         amax[d] += kernel_margin;
@@ -159,8 +181,8 @@ static int grid_for_particle_aabb(const float pmin[3], const float pmax[3], cons
     return grid_from_aabb(out, amin, amax, P->cube_size);
 }
 
-static int grid_for_reconstruction(const float *xyz, uint64_t n, const so_params *P, so_grid *out) {
-    float amin[3], amax[3];
+static int grid_for_reconstruction(const real *xyz, uint64_t n, const SOT(params) *P, SOT(grid) *out) {
+    real amin[3], amax[3];
     if (P->has_particle_aabb) { /* lib.rs:484-485 */
         for (int d = 0; d < 3; ++d) {
             amin[d] = P->aabb_min[d];
@@ -169,12 +191,12 @@ static int grid_for_reconstruction(const float *xyz, uint64_t n, const so_params
     } else {
         /* aabb.rs:28-52: empty -> zeros */
         if (n == 0) {
-            for (int d = 0; d < 3; ++d) amin[d] = amax[d] = 0.0f;
+            for (int d = 0; d < 3; ++d) amin[d] = amax[d] = RC(0.0);
         } else {
             for (int d = 0; d < 3; ++d) amin[d] = amax[d] = xyz[d];
             for (uint64_t i = 1; i < n; ++i)
                 for (int d = 0; d < 3; ++d) {
-                    float v = xyz[3 * i + d];
+                    real v = xyz[3 * i + d];
                     if (v < amin[d]) amin[d] = v;
                     if (v > amax[d]) amax[d] = v;
                 }
@@ -185,9 +207,9 @@ static int grid_for_reconstruction(const float *xyz, uint64_t n, const so_params
         }
     }
     /* density_map.rs:551-580 */
-    float half_supported_cells_real = ceilf(P->compact_support_radius / P->cube_size);
-    const float eps_sqrt = sqrtf(1.1920929e-07f);
-    float kernel_margin = P->cube_size * half_supported_cells_real * (1.0f + eps_sqrt);
+    real half_supported_cells_real = R_CEIL(P->compact_support_radius / P->cube_size);
+    const real eps_sqrt = R_SQRT(R_EPSILON);
+    real kernel_margin = P->cube_size * half_supported_cells_real * (RC(1.0) + eps_sqrt);
     for (int d = 0; d < 3; ++d) { /* lib.rs:513 */
         amin[d] -= kernel_margin;
         amax[d] += kernel_margin;
@@ -199,26 +221,26 @@ static int grid_for_reconstruction(const float *xyz, uint64_t n, const so_params
  * Parameters of the subdomain grid (dense_subdomains.rs:89-244)
  * ------------------------------------------------------------------------------------------ */
 typedef struct {
-    float particle_rest_mass;
-    float h;
-    float threshold;
-    float cube_size;
+    real particle_rest_mass;
+    real h;
+    real threshold;
+    real cube_size;
     int64_t subdomain_cubes;
-    float ghost_margin;
-    so_grid global_mc_grid;
-    so_grid subdomain_grid;
+    real ghost_margin;
+    SOT(grid) global_mc_grid;
+    SOT(grid) subdomain_grid;
 } sd_params;
 
-static int initialize_parameters(const so_params *P, const so_grid *initial_grid, sd_params *S) {
+static int initialize_parameters(const SOT(params) *P, const SOT(grid) *initial_grid, sd_params *S) {
     int64_t nc = P->subdomain_num_cubes_per_dim;
-    float d = P->particle_radius + P->particle_radius; /* kernel.rs:28-30 */
-    float rest_volume = d * d * d;
+    real d = P->particle_radius + P->particle_radius; /* kernel.rs:28-30 */
+    real rest_volume = d * d * d;
     S->particle_rest_mass = rest_volume * P->rest_density; /* dense_subdomains.rs:117-118 */
     S->h = P->compact_support_radius;
     S->threshold = P->iso_surface_threshold;
     S->cube_size = P->cube_size;
     S->subdomain_cubes = nc;
-    S->ghost_margin = ceilf(P->compact_support_radius / P->cube_size) * P->cube_size * 1.01f; /* :120-121 */
+    S->ghost_margin = R_CEIL(P->compact_support_radius / P->cube_size) * P->cube_size * RC(1.01); /* :120-121 */
     int64_t num_sub[3], num_cells[3];
     for (int k = 0; k < 3; ++k) { /* :168-181, 2129-2131 */
         int64_t c = initial_grid->n_cells[k];
@@ -226,7 +248,7 @@ static int initialize_parameters(const so_params *P, const so_grid *initial_grid
         num_cells[k] = num_sub[k] * nc;
     }
     grid_new(&S->global_mc_grid, initial_grid->aabb_min, num_cells, P->cube_size); /* :183-188 */
-    float subdomain_size = P->cube_size * (float)(double)nc;                      /* :207 */
+    real subdomain_size = P->cube_size * (real)(double)nc;                      /* :207 */
     grid_new(&S->subdomain_grid, S->global_mc_grid.aabb_min, num_sub, subdomain_size); /* :209-213 */
     return 0;
 }
@@ -234,13 +256,13 @@ static int initialize_parameters(const so_params *P, const so_grid *initial_grid
 /* ------------------------------------------------------------------------------------------
  * Ghost-margin classification (dense_subdomains.rs:1810-1905)
  * ------------------------------------------------------------------------------------------ */
-static int classify_particle(const so_grid *sg, float margin, const float p[3], int64_t *out, int cap) {
+static int classify_particle(const SOT(grid) *sg, real margin, const real p[3], int64_t *out, int cap) {
     int64_t sub[3];
     grid_enclosing_cell(sg, p, sub);
     if (!grid_cell_exists(sg, sub)) return 0; /* :1819-1822 */
-    float dx = sg->cell_size;
-    int r = (int)(int64_t)(double)ceilf(margin / dx); /* :1827-1832 */
-    float min_corner[3], max_corner[3];                /* uniform_grid.rs:454-467 */
+    real dx = sg->cell_size;
+    int r = (int)(int64_t)(double)R_CEIL(margin / dx); /* :1827-1832 */
+    real min_corner[3], max_corner[3];                /* uniform_grid.rs:454-467 */
     for (int d = 0; d < 3; ++d) {
         min_corner[d] = grid_point_coord(sg, sub[d], d);
         max_corner[d] = grid_point_coord(sg, sub[d] + 1, d);
@@ -253,7 +275,7 @@ static int classify_particle(const so_grid *sg, float margin, const float p[3], 
                 int in_margin = 1;
                 for (int d = 0; d < 3 && in_margin; ++d) { /* :1844-1856 */
                     int step = steps[d];
-                    float off = (float)((step < 0 ? -step : step) - 1);
+                    real off = (real)((step < 0 ? -step : step) - 1);
                     if (step > 0)
                         in_margin = ((max_corner[d] + off * dx) - p[d]) < margin;
                     else if (step < 0)
@@ -268,7 +290,7 @@ static int classify_particle(const so_grid *sg, float margin, const float p[3], 
     return count;
 }
 
-int so_classify_particle(const so_grid *sg, float margin, const float p[3], int64_t *out, int cap) {
+int SOFN(classify_particle)(const SOT(grid) *sg, real margin, const real p[3], int64_t *out, int cap) {
     return classify_particle(sg, margin, p, out, cap);
 }
 
@@ -291,7 +313,7 @@ static void subdomains_free(subdomains_t *s) {
 }
 
 /* optional restriction to a box of subdomains (multi-process shard); NULL = all */
-static int classify_particle_boxed(const so_grid *sg, float margin, const float p[3], int64_t *out, int cap, const int64_t *lo,
+static int classify_particle_boxed(const SOT(grid) *sg, real margin, const real p[3], int64_t *out, int cap, const int64_t *lo,
                                    const int64_t *hi) {
     int m = classify_particle(sg, margin, p, out, cap);
     if (!lo) return m;
@@ -305,20 +327,20 @@ static int classify_particle_boxed(const so_grid *sg, float margin, const float 
     return k;
 }
 
-static int decomposition_boxed(const sd_params *S, const float *xyz, uint64_t n, subdomains_t *out, int nthreads, const int64_t *box_lo,
+static int decomposition_boxed(const sd_params *S, const real *xyz, uint64_t n, subdomains_t *out, int nthreads, const int64_t *box_lo,
                                const int64_t *box_hi);
 
-static int decomposition(const sd_params *S, const float *xyz, uint64_t n, subdomains_t *out, int nthreads) {
+static int decomposition(const sd_params *S, const real *xyz, uint64_t n, subdomains_t *out, int nthreads) {
     return decomposition_boxed(S, xyz, n, out, nthreads, NULL, NULL);
 }
 
-static int decomposition_boxed(const sd_params *S, const float *xyz, uint64_t n, subdomains_t *out, int nthreads, const int64_t *box_lo,
+static int decomposition_boxed(const sd_params *S, const real *xyz, uint64_t n, subdomains_t *out, int nthreads, const int64_t *box_lo,
                                const int64_t *box_hi) {
-    const so_grid *sg = &S->subdomain_grid;
+    const SOT(grid) *sg = &S->subdomain_grid;
     int64_t total = sg->n_cells[0] * sg->n_cells[1] * sg->n_cells[2];
     int cap = 27;
     {
-        int r = (int)(int64_t)(double)ceilf(S->ghost_margin / sg->cell_size);
+        int r = (int)(int64_t)(double)R_CEIL(S->ghost_margin / sg->cell_size);
         cap = (2 * r + 1) * (2 * r + 1) * (2 * r + 1);
     }
     if (nthreads < 1) nthreads = 1;
@@ -402,13 +424,13 @@ static int decomposition_boxed(const sd_params *S, const float *xyz, uint64_t n,
  * neighborhood_search.rs:345-438, density_map.rs:150-186)
  * ------------------------------------------------------------------------------------------ */
 typedef struct {
-    float *pos;        /* gathered positions [P*3] */
-    float *rho;        /* gathered densities [P] */
+    real *pos;        /* gathered positions [P*3] */
+    real *rho;        /* gathered densities [P] */
     uint32_t *cell_of; /* [P] flat search cell */
     uint32_t *cell_start; /* [ncell+1] */
     uint32_t *cell_items; /* [P] local indices grouped by cell, ascending in each */
     size_t cap_p, cap_cells;
-    float *levelset;      /* (n+1)^3 */
+    real *levelset;      /* (n+1)^3 */
     int32_t *edge_to_vertex; /* 3*(n+1)^3 */
     uint32_t *touched;       /* list of edge slots set, for cheap reset */
     size_t n_touched, cap_touched;
@@ -417,8 +439,8 @@ typedef struct {
 static void ws_reserve_particles(workspace_t *w, size_t p) {
     if (p > w->cap_p) {
         size_t c = p + p / 2 + 64;
-        w->pos = (float *)realloc(w->pos, sizeof(float) * 3 * c);
-        w->rho = (float *)realloc(w->rho, sizeof(float) * c);
+        w->pos = (real *)realloc(w->pos, sizeof(real) * 3 * c);
+        w->rho = (real *)realloc(w->rho, sizeof(real) * c);
         w->cell_of = (uint32_t *)realloc(w->cell_of, sizeof(uint32_t) * c);
         w->cell_items = (uint32_t *)realloc(w->cell_items, sizeof(uint32_t) * c);
         w->cap_p = c;
@@ -437,7 +459,7 @@ static void ws_free(workspace_t *w) {
     memset(w, 0, sizeof(*w));
 }
 
-static void subdomain_aabb(const sd_params *S, const int64_t sub[3], float amin[3], float amax[3]) {
+static void subdomain_aabb(const sd_params *S, const int64_t sub[3], real amin[3], real amax[3]) {
     /* uniform_grid.rs:454-467 */
     for (int d = 0; d < 3; ++d) {
         amin[d] = grid_point_coord(&S->subdomain_grid, sub[d], d);
@@ -445,25 +467,25 @@ static void subdomain_aabb(const sd_params *S, const int64_t sub[3], float amin[
     }
 }
 
-static void subdomain_density(const sd_params *S, const float *xyz, const uint32_t *idx, size_t P,
-                              int64_t flat_sub, workspace_t *w, float *global_rho, uint32_t **nb_lists, uint32_t *nb_counts) {
+static void subdomain_density(const sd_params *S, const real *xyz, const uint32_t *idx, size_t P,
+                              int64_t flat_sub, workspace_t *w, real *global_rho, uint32_t **nb_lists, uint32_t *nb_counts) {
     ws_reserve_particles(w, P);
     for (size_t a = 0; a < P; ++a) { /* gather_subdomain_data :545 */
-        const float *p = xyz + 3 * (size_t)idx[a];
+        const real *p = xyz + 3 * (size_t)idx[a];
         w->pos[3 * a] = p[0];
         w->pos[3 * a + 1] = p[1];
         w->pos[3 * a + 2] = p[2];
     }
     int64_t sub[3];
     grid_unflatten_cell(&S->subdomain_grid, flat_sub, sub);
-    float amin[3], amax[3], mmin[3], mmax[3];
+    real amin[3], amax[3], mmin[3], mmax[3];
     subdomain_aabb(S, sub, amin, amax);
-    float grow = S->ghost_margin * 1.5f; /* :560-565 */
+    real grow = S->ghost_margin * RC(1.5); /* :560-565 */
     for (int d = 0; d < 3; ++d) {
         mmin[d] = amin[d] - grow;
         mmax[d] = amax[d] + grow;
     }
-    so_grid sgrid; /* neighborhood_search.rs:370 */
+    SOT(grid) sgrid; /* neighborhood_search.rs:370 */
     int rc = grid_from_aabb(&sgrid, mmin, mmax, S->h);
     if (rc != 0) {
         fprintf(stderr, "oracle: failed to construct search grid\n");
@@ -497,17 +519,17 @@ static void subdomain_density(const sd_params *S, const float *xyz, const uint32
         free(cursor);
     }
     cubic_kernel K = kernel_new(S->h);
-    float h2 = S->h * S->h; /* neighborhood_search.rs:367 */
-    float w0 = kernel_evaluate(&K, 0.0f);
+    real h2 = S->h * S->h; /* neighborhood_search.rs:367 */
+    real w0 = kernel_evaluate(&K, RC(0.0));
     for (size_t a = 0; a < P; ++a) {
-        const float *pi = w->pos + 3 * a;
+        const real *pi = w->pos + 3 * a;
         /* is_inside: half-open AABB test (:567-576, aabb.rs:220-222) */
         int inside = pi[0] >= amin[0] && pi[1] >= amin[1] && pi[2] >= amin[2] && pi[0] < amax[0] &&
                      pi[1] < amax[1] && pi[2] < amax[2];
         if (!inside) continue;
         int64_t ci[3];
         grid_enclosing_cell(&sgrid, pi, ci);
-        float density = w0; /* density_map.rs:173 */
+        real density = w0; /* density_map.rs:173 */
         uint32_t *nbl = NULL;
         size_t nbn = 0, nbcap = 0;
         /* 26 adjacent cells in iproduct order (uniform_grid.rs:614-643), then the own cell
@@ -523,11 +545,11 @@ static void subdomain_density(const sd_params *S, const float *xyz, const uint32
                         size_t f = (size_t)grid_flatten_cell(&sgrid, c);
                         for (uint32_t q = w->cell_start[f]; q < w->cell_start[f + 1]; ++q) {
                             uint32_t b = w->cell_items[q];
-                            const float *pj = w->pos + 3 * (size_t)b;
-                            float dx = pj[0] - pi[0], dy = pj[1] - pi[1], dz = pj[2] - pi[2];
-                            float d2 = dx * dx + dy * dy + dz * dz; /* nalgebra norm_squared: (x2+y2)+z2 */
+                            const real *pj = w->pos + 3 * (size_t)b;
+                            real dx = pj[0] - pi[0], dy = pj[1] - pi[1], dz = pj[2] - pi[2];
+                            real d2 = dx * dx + dy * dy + dz * dz; /* nalgebra norm_squared: (x2+y2)+z2 */
                             if (b != (uint32_t)a && d2 < h2) { /* neighborhood_search.rs:431 */
-                                float r = sqrtf(d2);          /* density_map.rs:179 */
+                                real r = R_SQRT(d2);          /* density_map.rs:179 */
                                 density += kernel_evaluate(&K, r);
                                 if (nb_lists) { /* dense_subdomains.rs:617-639: local -> global index */
                                     if (nbn == nbcap) {
@@ -552,21 +574,21 @@ static void subdomain_density(const sd_params *S, const float *xyz, const uint32
 /* ------------------------------------------------------------------------------------------
  * Level-set evaluation, scalar loop (dense_subdomains.rs:660-693, 784-847)
  * ------------------------------------------------------------------------------------------ */
-static void density_grid_loop_scalar(const sd_params *S, const int64_t sub[3], const float *pos,
-                                     const float *rho, size_t P, float *levelset) {
+static void density_grid_loop_scalar(const sd_params *S, const int64_t sub[3], const real *pos,
+                                     const real *rho, size_t P, real *levelset) {
     const int64_t n = S->subdomain_cubes, np = n + 1;
-    float amin[3], amax[3];
+    real amin[3], amax[3];
     subdomain_aabb(S, sub, amin, amax);
-    so_grid mc; /* :1383-1388 */
+    SOT(grid) mc; /* :1383-1388 */
     int64_t nc3[3] = {n, n, n};
     grid_new(&mc, amin, nc3, S->cube_size);
-    const int64_t cube_radius = (int64_t)(double)ceilf(S->h / S->cube_size); /* :1228 */
-    const float support_sq_margin = (S->h * S->h) * 1.01f;                  /* :1224-1226 */
+    const int64_t cube_radius = (int64_t)(double)R_CEIL(S->h / S->cube_size); /* :1228 */
+    const real support_sq_margin = (S->h * S->h) * RC(1.01);                  /* :1224-1226 */
     cubic_kernel K = kernel_new(S->h);
-    const so_grid *gg = &S->global_mc_grid;
+    const SOT(grid) *gg = &S->global_mc_grid;
     for (size_t a = 0; a < P; ++a) {
-        const float *p = pos + 3 * a;
-        float rho_i = rho[a];
+        const real *p = pos + 3 * a;
+        real rho_i = rho[a];
         int64_t cell[3], lo[3], hi[3];
         grid_enclosing_cell(&mc, p, cell); /* :671 */
         for (int d = 0; d < 3; ++d) {      /* :676-690 */
@@ -580,19 +602,19 @@ static void density_grid_loop_scalar(const sd_params *S, const int64_t sub[3], c
             hi[d] = u;
         }
         for (int64_t i = lo[0]; i < hi[0]; ++i) {
-            float gx = grid_point_coord(gg, sub[0] * n + i, 0); /* :817-826 */
-            float dx = p[0] - gx;
+            real gx = grid_point_coord(gg, sub[0] * n + i, 0); /* :817-826 */
+            real dx = p[0] - gx;
             for (int64_t j = lo[1]; j < hi[1]; ++j) {
-                float gy = grid_point_coord(gg, sub[1] * n + j, 1);
-                float dy = p[1] - gy;
+                real gy = grid_point_coord(gg, sub[1] * n + j, 1);
+                real dy = p[1] - gy;
                 for (int64_t k = lo[2]; k < hi[2]; ++k) {
-                    float gz = grid_point_coord(gg, sub[2] * n + k, 2);
-                    float dz = p[2] - gz;
-                    float d2 = dx * dx + dy * dy + dz * dz; /* :828-829 */
+                    real gz = grid_point_coord(gg, sub[2] * n + k, 2);
+                    real dz = p[2] - gz;
+                    real d2 = dx * dx + dy * dy + dz * dz; /* :828-829 */
                     if (d2 < support_sq_margin) {           /* :831 */
-                        float v_i = S->particle_rest_mass / rho_i;
-                        float r = sqrtf(d2);
-                        float w_ij = kernel_evaluate(&K, r);
+                        real v_i = S->particle_rest_mass / rho_i;
+                        real r = R_SQRT(d2);
+                        real w_ij = kernel_evaluate(&K, r);
                         levelset[(i * np + j) * np + k] += v_i * w_ij; /* :837-841 */
                     }
                 }
@@ -605,7 +627,7 @@ static void density_grid_loop_scalar(const sd_params *S, const int64_t sub[3], c
  * Per-subdomain marching cubes (dense_subdomains.rs:1260-1329, 1470-1578)
  * ------------------------------------------------------------------------------------------ */
 typedef struct {
-    float *vertices;      /* 3 per vertex */
+    real *vertices;      /* 3 per vertex */
     uint64_t *vertex_keys;
     uint8_t *vertex_interior;
     size_t n_vertices, cap_vertices;
@@ -624,15 +646,15 @@ static void patch_free(patch_t *p) {
     memset(p, 0, sizeof(*p));
 }
 
-static void patch_push_vertex(patch_t *p, const float v[3], uint64_t key, int interior) {
+static void patch_push_vertex(patch_t *p, const real v[3], uint64_t key, int interior) {
     if (p->n_vertices == p->cap_vertices) {
         size_t c = p->cap_vertices ? p->cap_vertices * 2 : 1024;
-        p->vertices = (float *)realloc(p->vertices, sizeof(float) * 3 * c);
+        p->vertices = (real *)realloc(p->vertices, sizeof(real) * 3 * c);
         p->vertex_keys = (uint64_t *)realloc(p->vertex_keys, sizeof(uint64_t) * c);
         p->vertex_interior = (uint8_t *)realloc(p->vertex_interior, c);
         p->cap_vertices = c;
     }
-    memcpy(p->vertices + 3 * p->n_vertices, v, sizeof(float) * 3);
+    memcpy(p->vertices + 3 * p->n_vertices, v, sizeof(real) * 3);
     p->vertex_keys[p->n_vertices] = key;
     p->vertex_interior[p->n_vertices] = (uint8_t)interior;
     p->n_vertices++;
@@ -654,14 +676,14 @@ static void patch_push_triangle(patch_t *p, const uint32_t t[3], int interior) {
 
 static void triangulate_subdomain(const sd_params *S, const int64_t sub[3], workspace_t *w, patch_t *patch) {
     const int64_t n = S->subdomain_cubes, np = n + 1;
-    const float *G = w->levelset;
-    const float t = S->threshold;
-    float amin[3], amax[3];
+    const real *G = w->levelset;
+    const real t = S->threshold;
+    real amin[3], amax[3];
     subdomain_aabb(S, sub, amin, amax);
-    so_grid mc;
+    SOT(grid) mc;
     int64_t nc3[3] = {n, n, n};
     grid_new(&mc, amin, nc3, S->cube_size);
-    const so_grid *gg = &S->global_mc_grid;
+    const SOT(grid) *gg = &S->global_mc_grid;
     const uint64_t NPy = (uint64_t)gg->n_points[1], NPz = (uint64_t)gg->n_points[2];
     w->n_touched = 0;
     for (int64_t i = 0; i < n; ++i)
@@ -673,7 +695,7 @@ static void triangulate_subdomain(const sd_params *S, const int64_t sub[3], work
                     int64_t pi = i + CELL_LOCAL_POINT_COORDS[c][0];
                     int64_t pj = j + CELL_LOCAL_POINT_COORDS[c][1];
                     int64_t pk = k + CELL_LOCAL_POINT_COORDS[c][2];
-                    float v = G[(pi * np + pj) * np + pk];
+                    real v = G[(pi * np + pj) * np + pk];
                     inside[c] = v > t;
                     any |= inside[c];
                     case_index |= inside[c] << c; /* marching_cubes_lut.rs:322-329 */
@@ -695,13 +717,13 @@ static void triangulate_subdomain(const sd_params *S, const int64_t sub[3], work
                             int64_t tg[3] = {o[0], o[1], o[2]};
                             tg[axis] += 1;
                             size_t flat_t = (size_t)((tg[0] * np + tg[1]) * np + tg[2]);
-                            float ov = G[flat_o], tv = G[flat_t];
-                            float alpha = (t - ov) / (tv - ov); /* :1516-1517 */
-                            float vc[3];
+                            real ov = G[flat_o], tv = G[flat_t];
+                            real alpha = (t - ov) / (tv - ov); /* :1516-1517 */
+                            real vc[3];
                             for (int d = 0; d < 3; ++d) {
-                                float oc_ = grid_point_coord(&mc, o[d], d);
-                                float tc_ = grid_point_coord(&mc, tg[d], d);
-                                vc[d] = oc_ * (1.0f - alpha) + tc_ * alpha; /* :1518-1519 */
+                                real oc_ = grid_point_coord(&mc, o[d], d);
+                                real tc_ = grid_point_coord(&mc, tg[d], d);
+                                vc[d] = oc_ * (RC(1.0) - alpha) + tc_ * alpha; /* :1518-1519 */
                             }
                             /* uniform_grid.rs:332-338 */
                             int boundary = 0;
@@ -732,18 +754,18 @@ static void triangulate_subdomain(const sd_params *S, const int64_t sub[3], work
 static void ws_prepare_levelset(workspace_t *w, int64_t np) {
     size_t tot = (size_t)(np * np * np);
     if (!w->levelset) {
-        w->levelset = (float *)malloc(sizeof(float) * tot);
+        w->levelset = (real *)malloc(sizeof(real) * tot);
         w->edge_to_vertex = (int32_t *)malloc(sizeof(int32_t) * 3 * tot);
         for (size_t q = 0; q < 3 * tot; ++q) w->edge_to_vertex[q] = -1;
     }
-    memset(w->levelset, 0, sizeof(float) * tot); /* :1390-1391 */
+    memset(w->levelset, 0, sizeof(real) * tot); /* :1390-1391 */
 }
 
-static void gather_positions_densities(const float *xyz, const float *rho, const uint32_t *idx, size_t P,
+static void gather_positions_densities(const real *xyz, const real *rho, const uint32_t *idx, size_t P,
                                        workspace_t *w) {
     ws_reserve_particles(w, P);
     for (size_t a = 0; a < P; ++a) {
-        const float *p = xyz + 3 * (size_t)idx[a];
+        const real *p = xyz + 3 * (size_t)idx[a];
         w->pos[3 * a] = p[0];
         w->pos[3 * a + 1] = p[1];
         w->pos[3 * a + 2] = p[2];
@@ -790,7 +812,7 @@ static uint64_t *map_find_or_insert(u64map *m, uint64_t key, int *inserted) {
     }
 }
 
-static int stitching(patch_t *patches, int64_t n_patches, so_result *out) {
+static int stitching(patch_t *patches, int64_t n_patches, SOT(result) *out) {
     size_t total_iv = 0, total_it = 0, total_ev = 0, total_et = 0;
     for (int64_t s = 0; s < n_patches; ++s) {
         total_iv += patches[s].vertex_inside_count;
@@ -799,7 +821,7 @@ static int stitching(patch_t *patches, int64_t n_patches, so_result *out) {
         total_et += patches[s].n_triangles - patches[s].triangle_inside_count;
     }
     size_t vcap = total_iv + total_ev, tcap = total_it + total_et;
-    float *V = (float *)malloc(sizeof(float) * 3 * (vcap ? vcap : 1));
+    real *V = (real *)malloc(sizeof(real) * 3 * (vcap ? vcap : 1));
     uint64_t *VK = (uint64_t *)malloc(sizeof(uint64_t) * (vcap ? vcap : 1));
     uint64_t *T = (uint64_t *)malloc(sizeof(uint64_t) * 3 * (tcap ? tcap : 1));
     u64map map;
@@ -812,7 +834,7 @@ static int stitching(patch_t *patches, int64_t n_patches, so_result *out) {
         for (size_t v = 0; v < p->n_vertices; ++v) {
             if (p->vertex_interior[v]) { /* :1652-1669 */
                 size_t g = v_off + new_local++;
-                memcpy(V + 3 * g, p->vertices + 3 * v, sizeof(float) * 3);
+                memcpy(V + 3 * g, p->vertices + 3 * v, sizeof(real) * 3);
                 VK[g] = p->vertex_keys[v];
                 l2g[v] = g;
             } else { /* :1693-1718, first patch wins */
@@ -820,7 +842,7 @@ static int stitching(patch_t *patches, int64_t n_patches, so_result *out) {
                 uint64_t *slot = map_find_or_insert(&map, p->vertex_keys[v], &inserted);
                 if (inserted) {
                     size_t g = total_iv + ext_v++;
-                    memcpy(V + 3 * g, p->vertices + 3 * v, sizeof(float) * 3);
+                    memcpy(V + 3 * g, p->vertices + 3 * v, sizeof(real) * 3);
                     VK[g] = p->vertex_keys[v];
                     *slot = g;
                 }
@@ -856,7 +878,7 @@ static int stitching(patch_t *patches, int64_t n_patches, so_result *out) {
 /* ------------------------------------------------------------------------------------------
  * Entry points (lib.rs:330-473, reconstruction.rs:17-62)
  * ------------------------------------------------------------------------------------------ */
-static int resolve_threads(const so_params *P) {
+static int resolve_threads(const SOT(params) *P) {
 #ifdef _OPENMP
     int t = P->num_threads > 0 ? P->num_threads : omp_get_max_threads();
     return t < 1 ? 1 : t;
@@ -866,7 +888,7 @@ static int resolve_threads(const so_params *P) {
 #endif
 }
 
-int so_grid_for_reconstruction(const float *xyz, uint64_t n, const so_params *P, so_grid *out) {
+int SOFN(grid_for_reconstruction)(const real *xyz, uint64_t n, const SOT(params) *P, SOT(grid) *out) {
     if (P->has_particle_aabb) {
         /* grid only depends on the AABB in this case */
         return grid_for_reconstruction(xyz, n, P, out) ? 1 : 0;
@@ -874,7 +896,7 @@ int so_grid_for_reconstruction(const float *xyz, uint64_t n, const so_params *P,
     return grid_for_reconstruction(xyz, n, P, out) ? 1 : 0;
 }
 
-static float *filter_particles(const float *xyz, uint64_t n, const so_params *P, so_result *out, uint64_t *n_out) {
+static real *filter_particles(const real *xyz, uint64_t n, const SOT(params) *P, SOT(result) *out, uint64_t *n_out) {
     /* lib.rs:369-406 */
     if (!P->has_particle_aabb) {
         out->particle_inside_aabb = NULL;
@@ -884,17 +906,17 @@ static float *filter_particles(const float *xyz, uint64_t n, const so_params *P,
     uint8_t *inside = (uint8_t *)malloc(n ? n : 1);
     uint64_t cnt = 0;
     for (uint64_t i = 0; i < n; ++i) {
-        const float *p = xyz + 3 * i;
+        const real *p = xyz + 3 * i;
         int in = p[0] >= P->aabb_min[0] && p[1] >= P->aabb_min[1] && p[2] >= P->aabb_min[2] &&
                  p[0] < P->aabb_max[0] && p[1] < P->aabb_max[1] && p[2] < P->aabb_max[2];
         inside[i] = (uint8_t)in;
         cnt += (uint64_t)in;
     }
-    float *f = (float *)malloc(sizeof(float) * 3 * (cnt ? cnt : 1));
+    real *f = (real *)malloc(sizeof(real) * 3 * (cnt ? cnt : 1));
     uint64_t k = 0;
     for (uint64_t i = 0; i < n; ++i)
         if (inside[i]) {
-            memcpy(f + 3 * k, xyz + 3 * i, sizeof(float) * 3);
+            memcpy(f + 3 * k, xyz + 3 * i, sizeof(real) * 3);
             ++k;
         }
     out->particle_inside_aabb = inside;
@@ -902,19 +924,19 @@ static float *filter_particles(const float *xyz, uint64_t n, const so_params *P,
     return f;
 }
 
-int so_reconstruct_surface(const float *xyz_in, uint64_t n_in, const so_params *P, so_result *out) {
+int SOFN(reconstruct_surface)(const real *xyz_in, uint64_t n_in, const SOT(params) *P, SOT(result) *out) {
     memset(out, 0, sizeof(*out));
-    if (!(P->cube_size > 0.0f) || !(P->compact_support_radius >= 0.0f)) return 4; /* reference panics */
+    if (!(P->cube_size > RC(0.0)) || !(P->compact_support_radius >= RC(0.0))) return 4; /* reference panics */
     double t0 = now_s();
     int nthreads = resolve_threads(P);
     out->threads_used = nthreads;
     out->n_input = n_in;
     uint64_t n = 0;
-    float *filtered = filter_particles(xyz_in, n_in, P, out, &n);
-    const float *xyz = filtered ? filtered : xyz_in;
+    real *filtered = filter_particles(xyz_in, n_in, P, out, &n);
+    const real *xyz = filtered ? filtered : xyz_in;
     out->n_particles = n;
 
-    so_grid initial;
+    SOT(grid) initial;
     if (grid_for_reconstruction(xyz, n, P, &initial) != 0) {
         free(filtered);
         return 1;
@@ -935,7 +957,7 @@ int so_reconstruct_surface(const float *xyz_in, uint64_t n_in, const so_params *
     out->n_subdomain_particles = subs.offsets[subs.n_sub];
     double t2 = now_s();
 
-    float *rho = (float *)calloc(n ? n : 1, sizeof(float)); /* :504 */
+    real *rho = (real *)calloc(n ? n : 1, sizeof(real)); /* :504 */
     uint32_t **nb_lists = NULL;
     uint32_t *nb_counts = NULL;
     if (P->global_neighborhood_list) { /* :505 */
@@ -1008,9 +1030,9 @@ int so_reconstruct_surface(const float *xyz_in, uint64_t n_in, const so_params *
     return 0;
 }
 
-int64_t so_debug_levelset_subdomain(const float *xyz, uint64_t n, const so_params *P, int64_t flat_subdomain,
-                                    float *out_grid) {
-    so_grid initial;
+int64_t SOFN(debug_levelset_subdomain)(const real *xyz, uint64_t n, const SOT(params) *P, int64_t flat_subdomain,
+                                    real *out_grid) {
+    SOT(grid) initial;
     if (P->has_particle_aabb) return -2; /* not supported by this debug entry */
     if (grid_for_reconstruction(xyz, n, P, &initial) != 0) return -2;
     sd_params S;
@@ -1019,7 +1041,7 @@ int64_t so_debug_levelset_subdomain(const float *xyz, uint64_t n, const so_param
     subdomains_t subs;
     memset(&subs, 0, sizeof(subs));
     if (decomposition(&S, xyz, n, &subs, nthreads) != 0) return -2;
-    float *rho = (float *)calloc(n ? n : 1, sizeof(float));
+    real *rho = (real *)calloc(n ? n : 1, sizeof(real));
     workspace_t *ws = (workspace_t *)calloc((size_t)nthreads, sizeof(workspace_t));
 #pragma omp parallel for schedule(dynamic, 1) num_threads(nthreads)
     for (int64_t s = 0; s < subs.n_sub; ++s) {
@@ -1042,7 +1064,7 @@ int64_t so_debug_levelset_subdomain(const float *xyz, uint64_t n, const so_param
         int64_t sub[3];
         grid_unflatten_cell(&S.subdomain_grid, flat_subdomain, sub);
         density_grid_loop_scalar(&S, sub, w->pos, w->rho, P_s, w->levelset);
-        memcpy(out_grid, w->levelset, sizeof(float) * (size_t)(np * np * np));
+        memcpy(out_grid, w->levelset, sizeof(real) * (size_t)(np * np * np));
         result = (int64_t)P_s;
     }
     for (int t = 0; t < nthreads; ++t) ws_free(&ws[t]);
@@ -1056,9 +1078,9 @@ int64_t so_debug_levelset_subdomain(const float *xyz, uint64_t n, const so_param
  * Sharded variant (multi-process): same functions, restricted to a box of subdomains of the grid of
  * the whole job.  Mirrors include/splashsurf_hip.h ss_shard_begin_f32 / ss_shard_finish.
  * ------------------------------------------------------------------------------------------ */
-static int shard_setup(const so_params *P, const so_shard *sh, sd_params *S) {
+static int shard_setup(const SOT(params) *P, const SOT(shard) *sh, sd_params *S) {
     if (P->has_particle_aabb) return 4;
-    so_grid initial;
+    SOT(grid) initial;
     if (grid_for_particle_aabb(sh->domain_min, sh->domain_max, P, &initial) != 0) return 1;
     initialize_parameters(P, &initial, S);
     for (int d = 0; d < 3; ++d)
@@ -1066,8 +1088,8 @@ static int shard_setup(const so_params *P, const so_shard *sh, sd_params *S) {
     return 0;
 }
 
-int so_grid_for_domain(const so_params *P, const float dmin[3], const float dmax[3], so_grid *grid, so_grid *subgrid, float *margin) {
-    so_grid initial;
+int SOFN(grid_for_domain)(const SOT(params) *P, const real dmin[3], const real dmax[3], SOT(grid) *grid, SOT(grid) *subgrid, real *margin) {
+    SOT(grid) initial;
     if (grid_for_particle_aabb(dmin, dmax, P, &initial) != 0) return 1;
     sd_params S;
     initialize_parameters(P, &initial, &S);
@@ -1077,7 +1099,7 @@ int so_grid_for_domain(const so_params *P, const float dmin[3], const float dmax
     return 0;
 }
 
-int so_shard_densities(const float *xyz, uint64_t n, const so_params *P, const so_shard *sh, float *rho_out) {
+int SOFN(shard_densities)(const real *xyz, uint64_t n, const SOT(params) *P, const SOT(shard) *sh, real *rho_out) {
     sd_params S;
     int rc = shard_setup(P, sh, &S);
     if (rc) return rc;
@@ -1085,7 +1107,7 @@ int so_shard_densities(const float *xyz, uint64_t n, const so_params *P, const s
     subdomains_t subs;
     memset(&subs, 0, sizeof(subs));
     if (decomposition_boxed(&S, xyz, n, &subs, nthreads, sh->sub_lo, sh->sub_hi) != 0) return 4;
-    memset(rho_out, 0, sizeof(float) * (size_t)n);
+    memset(rho_out, 0, sizeof(real) * (size_t)n);
     workspace_t *ws = (workspace_t *)calloc((size_t)nthreads, sizeof(workspace_t));
 #pragma omp parallel for schedule(dynamic, 1) num_threads(nthreads)
     for (int64_t s = 0; s < subs.n_sub; ++s) {
@@ -1103,7 +1125,7 @@ int so_shard_densities(const float *xyz, uint64_t n, const so_params *P, const s
     return 0;
 }
 
-int so_shard_reconstruct(const float *xyz, uint64_t n, const so_params *P, const so_shard *sh, const float *rho, so_result *out) {
+int SOFN(shard_reconstruct)(const real *xyz, uint64_t n, const SOT(params) *P, const SOT(shard) *sh, const real *rho, SOT(result) *out) {
     memset(out, 0, sizeof(*out));
     sd_params S;
     int rc = shard_setup(P, sh, &S);
@@ -1142,13 +1164,13 @@ int so_shard_reconstruct(const float *xyz, uint64_t n, const so_params *P, const
     for (int t = 0; t < nthreads; ++t) ws_free(&ws[t]);
     free(ws);
     subdomains_free(&subs);
-    out->particle_densities = (float *)malloc(sizeof(float) * (size_t)(n ? n : 1));
-    memcpy(out->particle_densities, rho, sizeof(float) * (size_t)n);
+    out->particle_densities = (real *)malloc(sizeof(real) * (size_t)(n ? n : 1));
+    memcpy(out->particle_densities, rho, sizeof(real) * (size_t)n);
     return 0;
 }
 
-int64_t so_debug_shard_levelset(const float *xyz, uint64_t n, const so_params *P, const so_shard *sh, const float *rho, int64_t flat_subdomain,
-                                float *out_grid) {
+int64_t SOFN(debug_shard_levelset)(const real *xyz, uint64_t n, const SOT(params) *P, const SOT(shard) *sh, const real *rho, int64_t flat_subdomain,
+                                real *out_grid) {
     sd_params S;
     if (shard_setup(P, sh, &S)) return -2;
     subdomains_t subs;
@@ -1166,7 +1188,7 @@ int64_t so_debug_shard_levelset(const float *xyz, uint64_t n, const so_params *P
         int64_t sub[3];
         grid_unflatten_cell(&S.subdomain_grid, flat_subdomain, sub);
         density_grid_loop_scalar(&S, sub, w.pos, w.rho, P_s, w.levelset);
-        memcpy(out_grid, w.levelset, sizeof(float) * (size_t)(np * np * np));
+        memcpy(out_grid, w.levelset, sizeof(real) * (size_t)(np * np * np));
         result = (int64_t)P_s;
     }
     ws_free(&w);
@@ -1174,7 +1196,7 @@ int64_t so_debug_shard_levelset(const float *xyz, uint64_t n, const so_params *P
     return result;
 }
 
-void so_result_free(so_result *r) {
+void SOFN(result_free)(SOT(result) *r) {
     free(r->particle_densities);
     free(r->particle_inside_aabb);
     free(r->neighbor_ptr);

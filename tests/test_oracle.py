@@ -129,3 +129,23 @@ def test_oracle_neighbor_lists_match_reference(oracle, name):
     src = np.repeat(np.arange(ptr.size - 1), np.diff(ptr))
     a = set(zip(src.tolist(), idx.tolist()))
     assert all((j, i) in a for (i, j) in list(a)[:5000])
+
+
+F64 = ["f64_kat1", "f64_cube_2366_n16", "f64_free_particles_125", "f64_config1", "f64_tank_small"]
+
+
+@pytest.mark.parametrize("name", F64)
+def test_oracle_f64_matches_reference(oracle, name):
+    """reconstruct_surface::<i64, f64>: densities bit-identical (64-bit patterns), mesh identical."""
+    g = load_golden(name)
+    prm = golden_params(g)
+    pts = golden_input(g).astype(np.float64)
+    par = oracle.make_params_relative(prm["particle_radius"], prm["smoothing_length"], prm["cube_size"],
+                                      iso_surface_threshold=prm["iso_surface_threshold"],
+                                      subdomain_num_cubes_per_dim=prm["subdomain_num_cubes_per_dim"], dtype=np.float64)
+    res = oracle.reconstruct_surface(pts, par)
+    assert res.vertices.dtype == np.float64
+    assert np.array_equal(res.particle_densities.view(np.uint64), g["densities"].view(np.uint64))
+    assert np.array_equal(res.grid["aabb_min"].view(np.uint64), g["grid_min"].view(np.uint64))
+    cmp = MC.compare_geometric(g["vertices"], g["triangles"], res.vertices, res.triangles, g["grid_min"], g["cell_size"], g["n_points"])
+    assert cmp["ids_equal"] and cmp["triangles_equal"] and cmp["max_rel_diff"] <= 1e-14, cmp
