@@ -154,7 +154,7 @@ def gen_f64_goldens(report):
     for name, desc, pts, r, l, c, t, n_cubes in cases:
         if pts is None:
             pts = np.load(os.path.join(DATA, desc["file"])) if desc["kind"] == "file" else W.tank_particles(scale=desc["scale"])
-        pts = np.ascontiguousarray(pts, dtype=np.float64)  # f32 data widened exactly: same input for every implementation
+        pts = np.ascontiguousarray(np.asarray(pts, dtype=np.float32), dtype=np.float64)  # f32 data widened exactly: same input for every implementation
         res = pysplashsurf.reconstruct_surface(pts, particle_radius=r, smoothing_length=l, cube_size=c, iso_surface_threshold=t, simd=False,
                                                subdomain_grid=True, subdomain_grid_auto_disable=False, subdomain_num_cubes_per_dim=n_cubes)
         rv = np.asarray(res.mesh.vertices, dtype=np.float64).reshape(-1, 3)
