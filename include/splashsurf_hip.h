@@ -79,6 +79,33 @@ typedef struct ss_grid_f32 {
     int64_t n_cells[3];
 } ss_grid_f32;
 
+/* The same for the reference's f64 instantiation (reconstruct_surface::<i64, f64>; pysplashsurf dispatches
+ * on the array dtype, pysplashsurf/src/reconstruction.rs:187-206; the CLI has --double-precision). */
+typedef struct ss_params_f64 {
+    double particle_radius;
+    double rest_density;
+    double compact_support_radius;
+    double cube_size;
+    double iso_surface_threshold;
+    int32_t has_particle_aabb;
+    double aabb_min[3];
+    double aabb_max[3];
+    int32_t enable_multi_threading;
+    int32_t enable_simd;
+    int32_t decomposition;
+    uint32_t subdomain_num_cubes_per_dim;
+    int32_t auto_disable;
+    int32_t global_neighborhood_list;
+} ss_params_f64;
+
+typedef struct ss_grid_f64 {
+    double aabb_min[3];
+    double aabb_max[3];
+    double cell_size;
+    int64_t n_points[3];
+    int64_t n_cells[3];
+} ss_grid_f64;
+
 /* Stage timings (milliseconds, HIP events on the context's stream) with the reference's profiling
  * scope names (README.md:198-231; dense_subdomains.rs `profile!` scopes) plus device-specific rows. */
 typedef struct ss_stats {
@@ -122,6 +149,14 @@ ss_status ss_reconstruct_surface_inplace_f32(ss_context *ctx, const float *xyz, 
 ss_status ss_grid_for_reconstruction_f32(ss_context *ctx, const float *xyz, uint64_t n_particles,
                                          const ss_params_f32 *params, ss_grid_f32 *out);
 
+/* f64 instantiation of the boundary (xyz: N x 3 contiguous f64, host or device) */
+ss_status ss_reconstruct_surface_f64(ss_context *ctx, const double *xyz, uint64_t n_particles,
+                                     const ss_params_f64 *params, ss_result **out);
+ss_status ss_reconstruct_surface_inplace_f64(ss_context *ctx, const double *xyz, uint64_t n_particles,
+                                             const ss_params_f64 *params, ss_result *inout);
+ss_status ss_grid_for_reconstruction_f64(ss_context *ctx, const double *xyz, uint64_t n_particles,
+                                         const ss_params_f64 *params, ss_grid_f64 *out);
+
 ss_status ss_result_create(ss_context *ctx, ss_result **out);
 void ss_result_free(ss_result *res);
 
@@ -142,6 +177,14 @@ ss_status ss_result_particle_inside_aabb(ss_result *res, const uint8_t **flags, 
  * (dense_subdomains.rs:617-639).  *row_ptr == NULL when global_neighborhood_list was not requested. */
 ss_status ss_result_particle_neighbors(ss_result *res, const uint64_t **row_ptr, const uint64_t **neighbors, uint64_t *n_particles);
 ss_status ss_result_stats(const ss_result *res, ss_stats *out);
+/* 1 if the result holds an f64 reconstruction (then only the *_f64 value accessors apply), else 0 */
+int ss_result_is_f64(const ss_result *res);
+/* value accessors of an f64 result (the index/flag/stat accessors above are type independent) */
+ss_status ss_result_vertices_f64(ss_result *res, const double **xyz, uint64_t *n_vertices);
+ss_status ss_result_particle_densities_f64(ss_result *res, const double **rho, uint64_t *n);
+ss_status ss_result_grid_f64(const ss_result *res, ss_grid_f64 *out);
+ss_status ss_result_subdomain_grid_f64(const ss_result *res, ss_grid_f64 *out, int32_t *present);
+ss_status ss_result_levelset_box_f64(ss_result *res, const int64_t lo[3], const int64_t extent[3], double *out);
 
 /* -- device-side views (HBM pointers; no copy) -- */
 ss_status ss_result_device_vertices(const ss_result *res, const float **d_xyz, uint64_t *n_vertices);
@@ -176,6 +219,12 @@ typedef struct ss_shard_f32 {
     int64_t sub_lo[3];   /* half-open box of subdomain indices reconstructed by this process */
     int64_t sub_hi[3];
 } ss_shard_f32;
+typedef struct ss_shard_f64 { /* reserved: the shard entry points are provided for f32 in this build */
+    double domain_min[3];
+    double domain_max[3];
+    int64_t sub_lo[3];
+    int64_t sub_hi[3];
+} ss_shard_f64;
 ss_status ss_shard_begin_f32(ss_context *ctx, const float *xyz, uint64_t n_particles, const ss_params_f32 *params,
                              const ss_shard_f32 *shard, ss_result *inout);
 ss_status ss_shard_finish(ss_context *ctx, ss_result *inout);

@@ -57,6 +57,35 @@ class _Grid(C.Structure):
     ]
 
 
+class _Params64(C.Structure):
+    _fields_ = [
+        ("particle_radius", C.c_double),
+        ("rest_density", C.c_double),
+        ("compact_support_radius", C.c_double),
+        ("cube_size", C.c_double),
+        ("iso_surface_threshold", C.c_double),
+        ("has_particle_aabb", C.c_int32),
+        ("aabb_min", C.c_double * 3),
+        ("aabb_max", C.c_double * 3),
+        ("enable_multi_threading", C.c_int32),
+        ("enable_simd", C.c_int32),
+        ("decomposition", C.c_int32),
+        ("subdomain_num_cubes_per_dim", C.c_uint32),
+        ("auto_disable", C.c_int32),
+        ("global_neighborhood_list", C.c_int32),
+    ]
+
+
+class _Grid64(C.Structure):
+    _fields_ = [
+        ("aabb_min", C.c_double * 3),
+        ("aabb_max", C.c_double * 3),
+        ("cell_size", C.c_double),
+        ("n_points", C.c_int64 * 3),
+        ("n_cells", C.c_int64 * 3),
+    ]
+
+
 class _Stats(C.Structure):
     _fields_ = [
         ("ms_total", C.c_double),
@@ -152,6 +181,15 @@ def load_library():
     L.ss_result_vertex_keys.argtypes = [vp, P(vp), P(u64)]
     L.ss_result_levelset_box.argtypes = [vp, P(C.c_int64), P(C.c_int64), vp]
     L.ss_result_subdomain_stats.argtypes = [vp, P(u64), P(u64)]
+    L.ss_reconstruct_surface_f64.argtypes = [vp, vp, u64, P(_Params64), P(vp)]
+    L.ss_reconstruct_surface_inplace_f64.argtypes = [vp, vp, u64, P(_Params64), vp]
+    L.ss_grid_for_reconstruction_f64.argtypes = [vp, vp, u64, P(_Params64), P(_Grid64)]
+    L.ss_result_is_f64.argtypes = [vp]
+    L.ss_result_vertices_f64.argtypes = [vp, P(vp), P(u64)]
+    L.ss_result_particle_densities_f64.argtypes = [vp, P(vp), P(u64)]
+    L.ss_result_grid_f64.argtypes = [vp, P(_Grid64)]
+    L.ss_result_subdomain_grid_f64.argtypes = [vp, P(_Grid64), P(i32)]
+    L.ss_result_levelset_box_f64.argtypes = [vp, P(C.c_int64), P(C.c_int64), vp]
     if L.ss_abi_version() != 1:
         raise ImportError("libsplashsurf_hip.so ABI version mismatch")
     _lib = L
@@ -165,11 +203,12 @@ class Parameters:
                  iso_surface_threshold=0.6, particle_aabb=None, enable_multi_threading=True, enable_simd=True,
                  subdomain_grid=True, subdomain_num_cubes_per_dim=64, auto_disable=True,
                  global_neighborhood_list=False):
-        self.particle_radius = np.float32(particle_radius)
-        self.rest_density = np.float32(rest_density)
-        self.compact_support_radius = np.float32(compact_support_radius)
-        self.cube_size = np.float32(cube_size)
-        self.iso_surface_threshold = np.float32(iso_surface_threshold)
+        # kept in double; converted to the Real type of the call (f32 or f64) in _c()
+        self.particle_radius = float(particle_radius)
+        self.rest_density = float(rest_density)
+        self.compact_support_radius = float(compact_support_radius)
+        self.cube_size = float(cube_size)
+        self.iso_surface_threshold = float(iso_surface_threshold)
         self.particle_aabb = particle_aabb
         self.enable_multi_threading = bool(enable_multi_threading)
         self.enable_simd = bool(enable_simd)
@@ -179,23 +218,25 @@ class Parameters:
         self.global_neighborhood_list = bool(global_neighborhood_list)
 
     @classmethod
-    def new_relative(cls, particle_radius, relative_compact_support_radius, relative_cube_size, **kw):
-        """lib.rs:216-226"""
-        r = np.float32(particle_radius)
-        return cls(r, r * np.float32(relative_compact_support_radius), r * np.float32(relative_cube_size), **kw)
+    def new_relative(cls, particle_radius, relative_compact_support_radius, relative_cube_size, dtype=np.float32, **kw):
+        """lib.rs:216-226 (products formed in the Real type `dtype`)"""
+        t = np.dtype(dtype).type
+        r = t(particle_radius)
+        return cls(r, r * t(relative_compact_support_radius), r * t(relative_cube_size), **kw)
 
-    def _c(self):
-        p = _Params()
-        p.particle_radius = self.particle_radius
-        p.rest_density = self.rest_density
-        p.compact_support_radius = self.compact_support_radius
-        p.cube_size = self.cube_size
-        p.iso_surface_threshold = self.iso_surface_threshold
+    def _c(self, f64=False):
+        p = _Params64() if f64 else _Params()
+        t = np.float64 if f64 else np.float32
+        p.particle_radius = t(self.particle_radius)
+        p.rest_density = t(self.rest_density)
+        p.compact_support_radius = t(self.compact_support_radius)
+        p.cube_size = t(self.cube_size)
+        p.iso_surface_threshold = t(self.iso_surface_threshold)
         if self.particle_aabb is not None:
             p.has_particle_aabb = 1
             for d in range(3):
-                p.aabb_min[d] = np.float32(self.particle_aabb[0][d])
-                p.aabb_max[d] = np.float32(self.particle_aabb[1][d])
+                p.aabb_min[d] = t(self.particle_aabb[0][d])
+                p.aabb_max[d] = t(self.particle_aabb[1][d])
         p.enable_multi_threading = int(self.enable_multi_threading)
         p.enable_simd = int(self.enable_simd)
         p.decomposition = 1 if self.subdomain_grid else 0
@@ -207,16 +248,17 @@ class Parameters:
 
 class Aabb3d:
     def __init__(self, mn, mx):
-        self.min = np.array(mn, dtype=np.float32)
-        self.max = np.array(mx, dtype=np.float32)
+        self.min = np.asarray(mn) if isinstance(mn, np.ndarray) else np.array(mn, dtype=np.float32)
+        self.max = np.asarray(mx) if isinstance(mx, np.ndarray) else np.array(mx, dtype=np.float32)
 
 
 class UniformGrid:
     """`UniformGrid<i64, f32>` view (pysplashsurf.pyi UniformGrid)."""
 
     def __init__(self, g):
-        self.aabb = Aabb3d(list(g.aabb_min), list(g.aabb_max))
-        self.cell_size = np.float32(g.cell_size)
+        t = np.float64 if isinstance(g, _Grid64) else np.float32
+        self.aabb = Aabb3d(np.array(list(g.aabb_min), dtype=t), np.array(list(g.aabb_max), dtype=t))
+        self.cell_size = t(g.cell_size)
         self.npoints_per_dim = [int(x) for x in g.n_points]
         self.ncells_per_dim = [int(x) for x in g.n_cells]
 
@@ -277,37 +319,42 @@ class Context:
     def _as_ptr(particles):
         """Accept a float32 (N,3) numpy array (host) or anything with `data_ptr()` (torch tensor, host or HBM)."""
         if hasattr(particles, "data_ptr"):
-            if tuple(particles.shape[1:]) != (3,) or str(particles.dtype) != "torch.float32" or not particles.is_contiguous():
-                raise TypeError("particles tensor must be contiguous float32 of shape (N, 3)")
-            return C.c_void_p(particles.data_ptr()), int(particles.shape[0]), particles
+            dt = str(particles.dtype)
+            if tuple(particles.shape[1:]) != (3,) or dt not in ("torch.float32", "torch.float64") or not particles.is_contiguous():
+                raise TypeError("particles tensor must be contiguous float32/float64 of shape (N, 3)")
+            return C.c_void_p(particles.data_ptr()), int(particles.shape[0]), particles, dt == "torch.float64"
         a = np.asarray(particles)
-        if a.dtype != np.float32:
-            raise TypeError("unsupported particle dtype %s (only float32 is supported by this build)" % a.dtype)
+        if a.dtype not in (np.float32, np.float64):  # pysplashsurf/src/reconstruction.rs:187-206 rejects other dtypes as well
+            raise TypeError("unsupported particle dtype %s (float32 and float64 are supported)" % a.dtype)
         if a.ndim != 2 or a.shape[1] != 3:
             raise ValueError("particles must have shape (N, 3)")
         a = np.ascontiguousarray(a)
-        return C.c_void_p(a.ctypes.data), int(a.shape[0]), a
+        return C.c_void_p(a.ctypes.data), int(a.shape[0]), a, a.dtype == np.float64
 
     def reconstruct(self, particles, parameters, out=None):
-        ptr, n, keep = self._as_ptr(particles)
-        p = parameters._c()
+        """dtype dispatch like pysplashsurf (reconstruction.rs:187-206): float32 -> <i64,f32>, float64 -> <i64,f64>."""
+        ptr, n, keep, f64 = self._as_ptr(particles)
+        p = parameters._c(f64)
+        fn = self._lib.ss_reconstruct_surface_f64 if f64 else self._lib.ss_reconstruct_surface_f32
+        fn_in = self._lib.ss_reconstruct_surface_inplace_f64 if f64 else self._lib.ss_reconstruct_surface_inplace_f32
         if out is None:
             h = C.c_void_p()
-            st = self._lib.ss_reconstruct_surface_f32(self._h, ptr, n, C.byref(p), C.byref(h))
+            st = fn(self._h, ptr, n, C.byref(p), C.byref(h))
             if st != 0:
                 self._raise(st)
             return SurfaceReconstruction(self, h)
-        st = self._lib.ss_reconstruct_surface_inplace_f32(self._h, ptr, n, C.byref(p), out._h)
+        st = fn_in(self._h, ptr, n, C.byref(p), out._h)
         if st != 0:
             self._raise(st)
         out._invalidate()
         return out
 
     def grid_for_reconstruction(self, particles, parameters):
-        ptr, n, keep = self._as_ptr(particles)
-        p = parameters._c()
-        g = _Grid()
-        st = self._lib.ss_grid_for_reconstruction_f32(self._h, ptr, n, C.byref(p), C.byref(g))
+        ptr, n, keep, f64 = self._as_ptr(particles)
+        p = parameters._c(f64)
+        g = _Grid64() if f64 else _Grid()
+        fn = self._lib.ss_grid_for_reconstruction_f64 if f64 else self._lib.ss_grid_for_reconstruction_f32
+        st = fn(self._h, ptr, n, C.byref(p), C.byref(g))
         if st != 0:
             self._raise(st)
         return UniformGrid(g)
@@ -353,9 +400,16 @@ class SurfaceReconstruction:
         self._check(self._lib.ss_result_counts(self._h, C.byref(nv), C.byref(nt)))
         return int(nv.value), int(nt.value)
 
+    @property
+    def is_f64(self):
+        return bool(self._lib.ss_result_is_f64(self._h))
+
     def _vertices(self):
         if "v" not in self._cache:
-            self._cache["v"] = self._host_array(self._lib.ss_result_vertices, C.c_float, 3, np.float32)
+            if self.is_f64:
+                self._cache["v"] = self._host_array(self._lib.ss_result_vertices_f64, C.c_double, 3, np.float64)
+            else:
+                self._cache["v"] = self._host_array(self._lib.ss_result_vertices, C.c_float, 3, np.float32)
         return self._cache["v"]
 
     def _triangles(self):
@@ -376,21 +430,26 @@ class SurfaceReconstruction:
 
     @property
     def grid(self):
-        g = _Grid()
-        self._check(self._lib.ss_result_grid(self._h, C.byref(g)))
+        f64 = self.is_f64
+        g = _Grid64() if f64 else _Grid()
+        self._check((self._lib.ss_result_grid_f64 if f64 else self._lib.ss_result_grid)(self._h, C.byref(g)))
         return UniformGrid(g)
 
     @property
     def subdomain_grid(self):
-        g = _Grid()
+        f64 = self.is_f64
+        g = _Grid64() if f64 else _Grid()
         present = C.c_int32()
-        self._check(self._lib.ss_result_subdomain_grid(self._h, C.byref(g), C.byref(present)))
+        self._check((self._lib.ss_result_subdomain_grid_f64 if f64 else self._lib.ss_result_subdomain_grid)(self._h, C.byref(g), C.byref(present)))
         return UniformGrid(g) if present.value else None
 
     @property
     def particle_densities(self):
         if "rho" not in self._cache:
-            self._cache["rho"] = self._host_array(self._lib.ss_result_particle_densities, C.c_float, 1, np.float32)
+            if self.is_f64:
+                self._cache["rho"] = self._host_array(self._lib.ss_result_particle_densities_f64, C.c_double, 1, np.float64)
+            else:
+                self._cache["rho"] = self._host_array(self._lib.ss_result_particle_densities, C.c_float, 1, np.float32)
         return self._cache["rho"]
 
     @property
@@ -435,8 +494,10 @@ class SurfaceReconstruction:
     def levelset_box(self, lo, extent):
         lo_a = (C.c_int64 * 3)(*[int(x) for x in lo])
         ex_a = (C.c_int64 * 3)(*[int(x) for x in extent])
-        out = np.zeros(tuple(int(x) for x in extent), dtype=np.float32)
-        self._check(self._lib.ss_result_levelset_box(self._h, lo_a, ex_a, out.ctypes.data_as(C.c_void_p)))
+        f64 = self.is_f64
+        out = np.zeros(tuple(int(x) for x in extent), dtype=np.float64 if f64 else np.float32)
+        fn = self._lib.ss_result_levelset_box_f64 if f64 else self._lib.ss_result_levelset_box
+        self._check(fn(self._h, lo_a, ex_a, out.ctypes.data_as(C.c_void_p)))
         return out
 
     def subdomain_stats(self):
@@ -486,8 +547,8 @@ def reconstruct_surface(particles, *, particle_radius, rest_density=1000.0, smoo
     r = float(particle_radius)
     prm = Parameters(
         particle_radius=r, rest_density=float(rest_density),
-        compact_support_radius=np.float32(2.0 * float(smoothing_length) * r),
-        cube_size=np.float32(float(cube_size) * r),
+        compact_support_radius=2.0 * float(smoothing_length) * r,   # f64 products, cast to the Real type of
+        cube_size=float(cube_size) * r,                              # the call (reconstruction.rs:171-193)
         iso_surface_threshold=float(iso_surface_threshold), particle_aabb=aabb,
         enable_multi_threading=multi_threading, enable_simd=simd, subdomain_grid=subdomain_grid,
         subdomain_num_cubes_per_dim=subdomain_num_cubes_per_dim, auto_disable=subdomain_grid_auto_disable,

@@ -102,8 +102,11 @@ struct ss_context {
 struct ss_result {
     ss_context* ctx = nullptr;
     bool valid = false;
-    SSDev P;
-    ss_grid_f32 grid, subgrid;
+    bool is_f64 = false;  // Real type of the reconstruction held by this result
+    SSDevT<float> P32;
+    SSDevT<double> P64;
+    ss_grid_f32 grid32, sub32;
+    ss_grid_f64 grid64, sub64;
     bool has_inside = false;
     uint64_t n_input = 0, n_particles = 0, n_vertices = 0, n_triangles = 0;
     uint32_t n_active = 0, n_mc = 0;
@@ -143,27 +146,43 @@ ss_status fail(ss_context* ctx, ss_status st, const std::string& msg, int detail
     return st;
 }
 
+// C structs per Real type
+template <class R> struct TypesOf;
+template <> struct TypesOf<float> { using params = ss_params_f32; using grid = ss_grid_f32; using shard = ss_shard_f32; };
+template <> struct TypesOf<double> { using params = ss_params_f64; using grid = ss_grid_f64; using shard = ss_shard_f64; };
+template <class R> SSDevT<R>& dev_params(ss_result* r);
+template <> SSDevT<float>& dev_params<float>(ss_result* r) { return r->P32; }
+template <> SSDevT<double>& dev_params<double>(ss_result* r) { return r->P64; }
+template <class R> typename TypesOf<R>::grid& result_grid(ss_result* r);
+template <> ss_grid_f32& result_grid<float>(ss_result* r) { return r->grid32; }
+template <> ss_grid_f64& result_grid<double>(ss_result* r) { return r->grid64; }
+template <class R> typename TypesOf<R>::grid& result_subgrid(ss_result* r);
+template <> ss_grid_f32& result_subgrid<float>(ss_result* r) { return r->sub32; }
+template <> ss_grid_f64& result_subgrid<double>(ss_result* r) { return r->sub64; }
+
 // ---- uniform grid, host restatement (uniform_grid.rs:175-232, 647-674) ----
-void grid_new(ss_grid_f32* g, const float mn[3], const int64_t nc[3], float cs) {
+template <class R>
+void grid_new(typename TypesOf<R>::grid* g, const R mn[3], const int64_t nc[3], R cs) {
     for (int d = 0; d < 3; ++d) {
         g->aabb_min[d] = mn[d];
         g->n_cells[d] = nc[d];
         g->n_points[d] = nc[d] + 1;
-        g->aabb_max[d] = mn[d] + cs * (float)(double)nc[d];
+        g->aabb_max[d] = mn[d] + cs * (R)(double)nc[d];
     }
     g->cell_size = cs;
 }
 
-int grid_from_aabb(ss_grid_f32* g, const float amin[3], const float amax[3], float cs) {
-    if (!(cs > 0.0f)) return SS_GRID_INVALID_CELL_SIZE;
+template <class R>
+int grid_from_aabb(typename TypesOf<R>::grid* g, const R amin[3], const R amax[3], R cs) {
+    if (!(cs > R(0.0))) return SS_GRID_INVALID_CELL_SIZE;
     if (amin[0] == amax[0] && amin[1] == amax[1] && amin[2] == amax[2]) return SS_GRID_DEGENERATE_AABB;
     if (!(amin[0] <= amax[0] && amin[1] <= amax[1] && amin[2] <= amax[2])) return SS_GRID_INCONSISTENT_AABB;
-    float aligned[3];
+    R aligned[3];
     int64_t nc[3];
     for (int d = 0; d < 3; ++d) {
-        aligned[d] = floorf(amin[d] / cs) * cs;
-        float n_real = (amax[d] - aligned[d]) / cs;
-        double c = (double)ceilf(n_real);
+        aligned[d] = ss_floor(amin[d] / cs) * cs;
+        R n_real = (amax[d] - aligned[d]) / cs;
+        double c = (double)ss_ceil(n_real);
         if (!(c < 2147483000.0)) return SS_GRID_INDEX_TYPE_TOO_SMALL;  // this build indexes points with i32 per dimension
         int64_t n = (int64_t)c;
         nc[d] = n < 1 ? 1 : n;
@@ -173,8 +192,9 @@ int grid_from_aabb(ss_grid_f32* g, const float amin[3], const float amax[3], flo
 }
 
 // lib.rs:476-516 given the particle AABB (already computed on the device or supplied by the user)
-int grid_for_reconstruction(const ss_params_f32* prm, bool have_particles, const float pmin[3], const float pmax[3], ss_grid_f32* out) {
-    float amin[3], amax[3];
+template <class R>
+int grid_for_reconstruction(const typename TypesOf<R>::params* prm, bool have_particles, const R pmin[3], const R pmax[3], typename TypesOf<R>::grid* out) {
+    R amin[3], amax[3];
     if (prm->has_particle_aabb) {
         for (int d = 0; d < 3; ++d) {
             amin[d] = prm->aabb_min[d];
@@ -182,15 +202,15 @@ int grid_for_reconstruction(const ss_params_f32* prm, bool have_particles, const
         }
     } else {
         for (int d = 0; d < 3; ++d) {
-            amin[d] = have_particles ? pmin[d] : 0.0f;  // aabb.rs:28-31: empty -> zeros
-            amax[d] = have_particles ? pmax[d] : 0.0f;
+            amin[d] = have_particles ? pmin[d] : R(0.0);  // aabb.rs:28-31: empty -> zeros
+            amax[d] = have_particles ? pmax[d] : R(0.0);
             amin[d] -= prm->particle_radius;  // lib.rs:496
             amax[d] += prm->particle_radius;
         }
     }
-    const float half_cells = ceilf(prm->compact_support_radius / prm->cube_size);  // density_map.rs:563
-    const float eps_sqrt = sqrtf(1.1920929e-07f);
-    const float kernel_margin = prm->cube_size * half_cells * (1.0f + eps_sqrt);  // density_map.rs:572-573
+    const R half_cells = ss_ceil(prm->compact_support_radius / prm->cube_size);  // density_map.rs:563
+    const R eps_sqrt = ss_sqrt(std::numeric_limits<R>::epsilon());
+    const R kernel_margin = prm->cube_size * half_cells * (R(1.0) + eps_sqrt);  // density_map.rs:572-573
     for (int d = 0; d < 3; ++d) {
         amin[d] -= kernel_margin;  // lib.rs:513
         amax[d] += kernel_margin;
@@ -199,12 +219,13 @@ int grid_for_reconstruction(const ss_params_f32* prm, bool have_particles, const
 }
 
 // dense_subdomains.rs:89-244
-void initialize_subdomain_parameters(const ss_params_f32* prm, const ss_grid_f32* initial, ss_grid_f32* global_grid, ss_grid_f32* sub_grid,
-                                     float* mass, float* margin) {
+template <class R>
+void initialize_subdomain_parameters(const typename TypesOf<R>::params* prm, const typename TypesOf<R>::grid* initial, typename TypesOf<R>::grid* global_grid, typename TypesOf<R>::grid* sub_grid,
+                                     R* mass, R* margin) {
     const int64_t n = (int64_t)prm->subdomain_num_cubes_per_dim;
-    const float d = prm->particle_radius + prm->particle_radius;  // kernel.rs:28-30
+    const R d = prm->particle_radius + prm->particle_radius;  // kernel.rs:28-30
     *mass = (d * d * d) * prm->rest_density;
-    *margin = ceilf(prm->compact_support_radius / prm->cube_size) * prm->cube_size * 1.01f;
+    *margin = ss_ceil(prm->compact_support_radius / prm->cube_size) * prm->cube_size * R(1.01);
     int64_t nsub[3], ncell[3];
     for (int k = 0; k < 3; ++k) {
         int64_t c = initial->n_cells[k];
@@ -213,7 +234,7 @@ void initialize_subdomain_parameters(const ss_params_f32* prm, const ss_grid_f32
         ncell[k] = nsub[k] * n;
     }
     grid_new(global_grid, initial->aabb_min, ncell, prm->cube_size);
-    const float sub_size = prm->cube_size * (float)(double)n;
+    const R sub_size = prm->cube_size * (R)(double)n;
     grid_new(sub_grid, global_grid->aabb_min, nsub, sub_size);
 }
 
@@ -236,7 +257,8 @@ ss_status exclusive_scan_u32(ss_context* ctx, const T* in, T* out, size_t n) {
     return SS_OK;
 }
 
-ss_status validate_params(ss_context* ctx, const ss_params_f32* prm, uint64_t n) {
+template <class PRM>
+ss_status validate_params(ss_context* ctx, const PRM* prm, uint64_t n) {
     if (!prm) return fail(ctx, SS_ERR_INVALID_ARGUMENT, "parameters pointer is null");
     if (n >= (1ull << 31)) return fail(ctx, SS_ERR_UNSUPPORTED, "more than 2^31-1 particles per call are not supported by this build");
     // the reference panics for these (density_map.rs:555-559); report instead of aborting the host
@@ -254,11 +276,12 @@ ss_status validate_params(ss_context* ctx, const ss_params_f32* prm, uint64_t n)
 
 void reset_host_flags(ss_result* r) { r->hv = r->ht64 = r->ht32 = r->hrho = r->hkeys = r->hinside = r->hnbp = r->hnbi = false; }
 
-ss_status make_device_params(ss_context* ctx, const ss_params_f32* prm, const ss_grid_f32& g, const ss_grid_f32& sg, float mass, float margin,
-                             uint32_t n, const ss_shard_f32* shard, SSDev* out) {
-    SSDev P;
+template <class R>
+ss_status make_device_params(ss_context* ctx, const typename TypesOf<R>::params* prm, const typename TypesOf<R>::grid& g, const typename TypesOf<R>::grid& sg, R mass, R margin,
+                             uint32_t n, const typename TypesOf<R>::shard* shard, SSDevT<R>* out) {
+    SSDevT<R> P;
     memset(&P, 0, sizeof(P));
-    const float h = prm->compact_support_radius;
+    const R h = prm->compact_support_radius;
     for (int d = 0; d < 3; ++d) {
         P.gmin[d] = g.aabb_min[d];
         P.np[d] = (int)g.n_points[d];
@@ -269,21 +292,21 @@ ss_status make_device_params(ss_context* ctx, const ss_params_f32* prm, const ss
     P.cs = g.cell_size;
     P.n_sub_cubes = (int)prm->subdomain_num_cubes_per_dim;
     P.sub_size = sg.cell_size;
-    P.sub_radius = (int)ceilf(margin / sg.cell_size);  // dense_subdomains.rs:1827-1832
+    P.sub_radius = (int)ss_ceil(margin / sg.cell_size);  // dense_subdomains.rs:1827-1832
     if (P.sub_radius < 1 || P.sub_radius > 64) return fail(ctx, SS_ERR_UNSUPPORTED, "ghost margin spans more than 64 subdomains");
     for (int d = 0; d < 3; ++d) P.sc[d] = (int)ceil(((double)sg.cell_size + 3.0 * (double)margin) / (double)h) + 3;
     P.h = h;
     P.h2 = h * h;
-    P.H2 = (h * h) * 1.01f;
-    P.sigma = 8.0f / (h * h * h);
-    P.w0 = ss_kernel_evaluate(0.0f, h, P.sigma);
+    P.H2 = (h * h) * R(1.01);
+    P.sigma = R(8.0) / (h * h * h);
+    P.w0 = ss_kernel_evaluate(R(0.0), h, P.sigma);
     P.mass = mass;
     P.threshold = prm->iso_surface_threshold;
     P.margin = margin;
-    P.reach = sqrtf(1.01f) * h * 1.0001f;
-    float amax = 0.0f;
-    for (int d = 0; d < 3; ++d) amax = fmaxf(amax, fmaxf(fabsf(g.aabb_min[d]), fabsf(g.aabb_max[d])));
-    P.coord_slack = 16.0f * 1.1920929e-07f * amax + 1e-30f;
+    P.reach = ss_sqrt(R(1.01)) * h * R(1.0001);
+    R amax = R(0.0);
+    for (int d = 0; d < 3; ++d) amax = ss_max(amax, ss_max(std::fabs(g.aabb_min[d]), std::fabs(g.aabb_max[d])));
+    P.coord_slack = R(16.0) * std::numeric_limits<R>::epsilon() * amax + 1e-30f;
     double ncells = 1.0, nblocks = 1.0;
     for (int d = 0; d < 3; ++d) {
         const double lo = (double)g.aabb_min[d] - 1.5 * (double)margin, hi = (double)g.aabb_max[d] + 1.5 * (double)margin;
@@ -348,10 +371,11 @@ float ev_ms(ss_context* ctx, int a, int b) {
 }
 
 // Uploads (if needed) and filters the particles; returns device pointer to the particles used
-ss_status stage_particles(ss_context* ctx, const float* xyz, uint64_t n_in, const ss_params_f32* prm, ss_result* res, const float** d_used,
+template <class R>
+ss_status stage_particles(ss_context* ctx, const R* xyz, uint64_t n_in, const typename TypesOf<R>::params* prm, ss_result* res, const R** d_used,
                           uint32_t* n_used) {
     hipStream_t st = ctx->stream;
-    const float* d_xyz = nullptr;
+    const R* d_xyz = nullptr;
     if (n_in == 0) {
         *d_used = nullptr;
         *n_used = 0;
@@ -364,9 +388,9 @@ ss_status stage_particles(ss_context* ctx, const float* xyz, uint64_t n_in, cons
     if (is_device_pointer(xyz)) {
         d_xyz = xyz;
     } else {
-        SS_HIP(ctx, ctx->xyz_in.reserve(n_in * 12));
-        SS_HIP(ctx, hipMemcpyAsync(ctx->xyz_in.p, xyz, n_in * 12, hipMemcpyHostToDevice, st));
-        d_xyz = ctx->xyz_in.as<float>();
+        SS_HIP(ctx, ctx->xyz_in.reserve(n_in * 3 * sizeof(R)));
+        SS_HIP(ctx, hipMemcpyAsync(ctx->xyz_in.p, xyz, n_in * 3 * sizeof(R), hipMemcpyHostToDevice, st));
+        d_xyz = ctx->xyz_in.as<R>();
     }
     if (!prm->has_particle_aabb) {
         *d_used = d_xyz;
@@ -387,9 +411,9 @@ ss_status stage_particles(ss_context* ctx, const float* xyz, uint64_t n_in, cons
     uint32_t cnt = 0;
     SS_HIP(ctx, hipMemcpyAsync(&cnt, ctx->offsets.as<uint32_t>() + n_in, 4, hipMemcpyDeviceToHost, st));
     SS_HIP(ctx, hipStreamSynchronize(st));
-    SS_HIP(ctx, ctx->xyz_filt.reserve((size_t)cnt * 12 + 16));
-    ss_launch_compact_xyz(d_xyz, (uint32_t)n_in, ctx->flags32.as<uint32_t>(), ctx->offsets.as<uint32_t>(), ctx->xyz_filt.as<float>(), st);
-    *d_used = ctx->xyz_filt.as<float>();
+    SS_HIP(ctx, ctx->xyz_filt.reserve((size_t)cnt * 3 * sizeof(R) + 16));
+    ss_launch_compact_xyz(d_xyz, (uint32_t)n_in, ctx->flags32.as<uint32_t>(), ctx->offsets.as<uint32_t>(), ctx->xyz_filt.as<R>(), st);
+    *d_used = ctx->xyz_filt.as<R>();
     *n_used = cnt;
     if (res) res->has_inside = true;
     if (!res) {
@@ -399,13 +423,14 @@ ss_status stage_particles(ss_context* ctx, const float* xyz, uint64_t n_in, cons
     return SS_OK;
 }
 
-ss_status compute_particle_aabb(ss_context* ctx, const float* d_xyz, uint32_t n, float pmin[3], float pmax[3]) {
+template <class R>
+ss_status compute_particle_aabb(ss_context* ctx, const R* d_xyz, uint32_t n, R pmin[3], R pmax[3]) {
     hipStream_t st = ctx->stream;
-    SS_HIP(ctx, ctx->aabb_partial.reserve(1024 * 6 * 4));
-    SS_HIP(ctx, ctx->aabb_out.reserve(6 * 4));
-    ss_launch_aabb(d_xyz, n, ctx->aabb_partial.as<float>(), ctx->aabb_out.as<float>(), st);
-    float h6[6];
-    SS_HIP(ctx, hipMemcpyAsync(h6, ctx->aabb_out.p, 24, hipMemcpyDeviceToHost, st));
+    SS_HIP(ctx, ctx->aabb_partial.reserve(1024 * 6 * sizeof(R)));
+    SS_HIP(ctx, ctx->aabb_out.reserve(6 * sizeof(R)));
+    ss_launch_aabb(d_xyz, n, ctx->aabb_partial.as<R>(), ctx->aabb_out.as<R>(), st);
+    R h6[6];
+    SS_HIP(ctx, hipMemcpyAsync(h6, ctx->aabb_out.p, 6 * sizeof(R), hipMemcpyDeviceToHost, st));
     SS_HIP(ctx, hipStreamSynchronize(st));
     for (int d = 0; d < 3; ++d) {
         pmin[d] = h6[d];
@@ -414,10 +439,12 @@ ss_status compute_particle_aabb(ss_context* ctx, const float* d_xyz, uint32_t n,
     return SS_OK;
 }
 
+template <class R>
 ss_status phase_finish(ss_context* ctx, ss_result* res);
 
 // Phase 1: staging, grid, binning, densities.  `shard` == nullptr: the whole domain (single process).
-ss_status phase_begin(ss_context* ctx, const float* xyz, uint64_t n_in, const ss_params_f32* prm, const ss_shard_f32* shard, ss_result* res) {
+template <class R>
+ss_status phase_begin(ss_context* ctx, const R* xyz, uint64_t n_in, const typename TypesOf<R>::params* prm, const typename TypesOf<R>::shard* shard, ss_result* res) {
     ss_status s = validate_params(ctx, prm, n_in);
     if (s != SS_OK) return s;
     if (shard && prm->has_particle_aabb) return fail(ctx, SS_ERR_UNSUPPORTED, "particle_aabb cannot be combined with a shard descriptor");
@@ -435,7 +462,7 @@ ss_status phase_begin(ss_context* ctx, const float* xyz, uint64_t n_in, const ss
 
     const bool host_input = n_in > 0 && xyz && !is_device_pointer(xyz);
     SS_HIP(ctx, hipEventRecord(ctx->ev[0], st));
-    const float* d_xyz = nullptr;
+    const R* d_xyz = nullptr;
     uint32_t n = 0;
     s = stage_particles(ctx, xyz, n_in, prm, res, &d_xyz, &n);
     if (s != SS_OK) return s;
@@ -443,7 +470,7 @@ ss_status phase_begin(ss_context* ctx, const float* xyz, uint64_t n_in, const ss
     SS_HIP(ctx, hipEventRecord(ctx->ev[1], st));
 
     // ---- grid set-up (lib.rs:409-417, reconstruction.rs:24-29) ----
-    float pmin[3] = {0, 0, 0}, pmax[3] = {0, 0, 0};
+    R pmin[3] = {0, 0, 0}, pmax[3] = {0, 0, 0};
     if (shard) {
         // multi-GPU: the grid is that of the WHOLE job; the caller supplies the AABB of all particles
         for (int d = 0; d < 3; ++d) {
@@ -454,25 +481,26 @@ ss_status phase_begin(ss_context* ctx, const float* xyz, uint64_t n_in, const ss
         s = compute_particle_aabb(ctx, d_xyz, n, pmin, pmax);
         if (s != SS_OK) return s;
     }
-    ss_grid_f32 initial;
+    typename TypesOf<R>::grid initial;
     int gerr = grid_for_reconstruction(prm, shard ? true : (n > 0), pmin, pmax, &initial);
     if (gerr) return fail(ctx, SS_ERR_GRID_CONSTRUCTION, "grid construction failed (uniform_grid.rs:147-169)", gerr);
-    float mass = 0, margin = 0;
-    initialize_subdomain_parameters(prm, &initial, &res->grid, &res->subgrid, &mass, &margin);
+    R mass = 0, margin = 0;
+    initialize_subdomain_parameters(prm, &initial, &result_grid<R>(res), &result_subgrid<R>(res), &mass, &margin);
     for (int d = 0; d < 3; ++d)
-        if (res->grid.n_points[d] > 2000000000ll) return fail(ctx, SS_ERR_GRID_CONSTRUCTION, "too many grid points per dimension", SS_GRID_INDEX_TYPE_TOO_SMALL);
-    SSDev P;
-    s = make_device_params(ctx, prm, res->grid, res->subgrid, mass, margin, n, shard, &P);
+        if (result_grid<R>(res).n_points[d] > 2000000000ll) return fail(ctx, SS_ERR_GRID_CONSTRUCTION, "too many grid points per dimension", SS_GRID_INDEX_TYPE_TOO_SMALL);
+    SSDevT<R> P;
+    s = make_device_params<R>(ctx, prm, result_grid<R>(res), result_subgrid<R>(res), mass, margin, n, shard, &P);
     if (s != SS_OK) return s;
-    res->P = P;
+    dev_params<R>(res) = P;
+    res->is_f64 = sizeof(R) == 8;
     res->host_input = host_input;
     SS_HIP(ctx, hipEventRecord(ctx->ev[2], st));
 
     const size_t ncells = (size_t)P.kdim[0] * P.kdim[1] * P.kdim[2];
 
     // ---- K1: bin + sort (decomposition) ----
-    SS_HIP(ctx, res->rho.reserve((size_t)n * 4 + 16));
-    SS_HIP(ctx, res->posvol.reserve((size_t)n * 16 + 16));
+    SS_HIP(ctx, res->rho.reserve((size_t)n * sizeof(R) + 16));
+    SS_HIP(ctx, res->posvol.reserve((size_t)n * sizeof(ss_real4<R>) + 32));
     SS_HIP(ctx, res->perm.reserve((size_t)n * 4 + 16));
     SS_HIP(ctx, ctx->cell_count.reserve((ncells + 1) * 4));
     SS_HIP(ctx, ctx->cell_start.reserve((ncells + 1) * 4));
@@ -481,7 +509,7 @@ ss_status phase_begin(ss_context* ctx, const float* xyz, uint64_t n_in, const ss
         SS_HIP(ctx, ctx->keys_a.reserve((size_t)n * 4));
         SS_HIP(ctx, ctx->keys_b.reserve((size_t)n * 4));
         SS_HIP(ctx, ctx->vals_a.reserve((size_t)n * 4));
-        SS_HIP(ctx, ctx->pos_sorted.reserve((size_t)n * 16));
+        SS_HIP(ctx, ctx->pos_sorted.reserve((size_t)n * sizeof(ss_real4<R>)));
         ss_launch_cell_keys(P, d_xyz, ctx->keys_a.as<uint32_t>(), ctx->vals_a.as<uint32_t>(), ctx->cell_count.as<uint32_t>(), st);
     }
     s = exclusive_scan_u32<uint32_t>(ctx, ctx->cell_count.as<uint32_t>(), ctx->cell_start.as<uint32_t>(), ncells + 1);
@@ -495,7 +523,7 @@ ss_status phase_begin(ss_context* ctx, const float* xyz, uint64_t n_in, const ss
         SS_HIP(ctx, ctx->temp.reserve(bytes));
         SS_HIP(ctx, rocprim::radix_sort_pairs(ctx->temp.p, bytes, ctx->keys_a.as<uint32_t>(), ctx->keys_b.as<uint32_t>(), ctx->vals_a.as<uint32_t>(),
                                               res->perm.as<uint32_t>(), (size_t)n, 0u, bits, st));
-        ss_launch_gather_sorted(n, d_xyz, res->perm.as<uint32_t>(), ctx->pos_sorted.as<float4>(), st);
+        ss_launch_gather_sorted(n, d_xyz, res->perm.as<uint32_t>(), ctx->pos_sorted.as<ss_real4<R>>(), st);
     }
     SS_HIP(ctx, hipEventRecord(ctx->ev[3], st));
 
@@ -509,7 +537,7 @@ ss_status phase_begin(ss_context* ctx, const float* xyz, uint64_t n_in, const ss
         SS_HIP(ctx, ctx->sub_rank.reserve((nsub + 1) * 4));
         SS_HIP(ctx, hipMemsetAsync(ctx->member_count.p, 0, ((size_t)n + 1) * 4, st));
         SS_HIP(ctx, hipMemsetAsync(ctx->sub_flag.p, 0, (nsub + 1) * 4, st));
-        SS_HIP(ctx, hipMemsetAsync(res->rho.p, 0, (size_t)n * 4 + 16, st));  // vec![R::zero(); n], dense_subdomains.rs:504
+        SS_HIP(ctx, hipMemsetAsync(res->rho.p, 0, (size_t)n * sizeof(R) + 16, st));  // vec![R::zero(); n], dense_subdomains.rs:504
         ss_launch_classify_count(P, d_xyz, ctx->member_count.as<uint32_t>(), ctx->sub_flag.as<uint32_t>(), st);
         s = exclusive_scan_u32<uint32_t>(ctx, ctx->member_count.as<uint32_t>(), ctx->copy_offset.as<uint32_t>(), (size_t)n + 1);
         if (s != SS_OK) return s;
@@ -530,7 +558,7 @@ ss_status phase_begin(ss_context* ctx, const float* xyz, uint64_t n_in, const ss
             SS_HIP(ctx, ctx->ckeys_b.reserve((size_t)n_copies * 4));
             SS_HIP(ctx, ctx->cvals_a.reserve((size_t)n_copies * 4));
             SS_HIP(ctx, ctx->cidx.reserve((size_t)n_copies * 4));
-            SS_HIP(ctx, ctx->cpos.reserve((size_t)n_copies * 16));
+            SS_HIP(ctx, ctx->cpos.reserve((size_t)n_copies * sizeof(ss_real4<R>)));
             SS_HIP(ctx, ctx->cell_count2.reserve((ncells2 + 1) * 4));
             SS_HIP(ctx, ctx->cell_start2.reserve((ncells2 + 1) * 4));
             SS_HIP(ctx, hipMemsetAsync(ctx->cell_count2.p, 0, (ncells2 + 1) * 4, st));
@@ -547,15 +575,15 @@ ss_status phase_begin(ss_context* ctx, const float* xyz, uint64_t n_in, const ss
             SS_HIP(ctx, ctx->temp.reserve(bytes));
             SS_HIP(ctx, rocprim::radix_sort_pairs(ctx->temp.p, bytes, ctx->ckeys_a.as<uint32_t>(), ctx->ckeys_b.as<uint32_t>(), ctx->cvals_a.as<uint32_t>(),
                                                   ctx->cidx.as<uint32_t>(), (size_t)n_copies, 0u, bits, st));
-            ss_launch_gather_sorted(n_copies, d_xyz, ctx->cidx.as<uint32_t>(), ctx->cpos.as<float4>(), st);
+            ss_launch_gather_sorted(n_copies, d_xyz, ctx->cidx.as<uint32_t>(), ctx->cpos.as<ss_real4<R>>(), st);
             const bool want_nb = prm->global_neighborhood_list != 0;
             if (want_nb) {
                 SS_HIP(ctx, ctx->nb_count.reserve(((size_t)n + 1) * 8));
                 SS_HIP(ctx, res->nb_ptr.reserve(((size_t)n + 1) * 8));
                 SS_HIP(ctx, hipMemsetAsync(ctx->nb_count.p, 0, ((size_t)n + 1) * 8, st));
             }
-            ss_launch_density_sub(P, n_copies, ctx->cpos.as<float4>(), ctx->cidx.as<uint32_t>(), ctx->ckeys_b.as<uint32_t>(),
-                                  ctx->cell_start2.as<uint32_t>(), ctx->occ_sub.as<uint32_t>(), res->rho.as<float>(), want_nb ? 1 : 0,
+            ss_launch_density_sub(P, n_copies, ctx->cpos.as<ss_real4<R>>(), ctx->cidx.as<uint32_t>(), ctx->ckeys_b.as<uint32_t>(),
+                                  ctx->cell_start2.as<uint32_t>(), ctx->occ_sub.as<uint32_t>(), res->rho.as<R>(), want_nb ? 1 : 0,
                                   ctx->nb_count.as<uint32_t>(), nullptr, nullptr, st);
             if (want_nb) {
                 // counts (u32, first n+1 entries) -> u64 -> exclusive scan = CSR row pointers
@@ -569,8 +597,8 @@ ss_status phase_begin(ss_context* ctx, const float* xyz, uint64_t n_in, const ss
                 if (total_nb >= (1ull << 32)) return fail(ctx, SS_ERR_UNSUPPORTED, "more than 2^32 neighbour entries");
                 res->n_neighbors = total_nb;
                 SS_HIP(ctx, res->nb_idx.reserve((size_t)total_nb * 4 + 16));
-                ss_launch_density_sub(P, n_copies, ctx->cpos.as<float4>(), ctx->cidx.as<uint32_t>(), ctx->ckeys_b.as<uint32_t>(),
-                                      ctx->cell_start2.as<uint32_t>(), ctx->occ_sub.as<uint32_t>(), res->rho.as<float>(), 2, nullptr,
+                ss_launch_density_sub(P, n_copies, ctx->cpos.as<ss_real4<R>>(), ctx->cidx.as<uint32_t>(), ctx->ckeys_b.as<uint32_t>(),
+                                      ctx->cell_start2.as<uint32_t>(), ctx->occ_sub.as<uint32_t>(), res->rho.as<R>(), 2, nullptr,
                                       res->nb_ptr.as<unsigned long long>(), res->nb_idx.as<uint32_t>(), st);
             }
             res->has_neighbors = want_nb;
@@ -590,18 +618,19 @@ ss_status phase_begin(ss_context* ctx, const float* xyz, uint64_t n_in, const ss
 
 // Phase 2: level set, marching cubes, numbering.  Uses res->rho as it is on the device NOW (a
 // multi-GPU host may have filled in the densities of halo particles between the phases).
+template <class R>
 ss_status phase_finish(ss_context* ctx, ss_result* res) {
     if (res->phase != 1) return fail(ctx, SS_ERR_INVALID_ARGUMENT, "ss_shard_finish without a preceding successful ss_shard_begin_f32");
     SS_HIP(ctx, hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
     ss_status s = SS_OK;
-    const SSDev P = res->P;
+    const SSDevT<R> P = dev_params<R>(res);
     const uint32_t n = P.n;
     const bool host_input = res->host_input;
     const size_t ncells = (size_t)P.kdim[0] * P.kdim[1] * P.kdim[2];
     const size_t nblocks = (size_t)P.nb[0] * P.nb[1] * P.nb[2];
     SS_HIP(ctx, hipEventRecord(ctx->ev[10], st));
-    ss_launch_make_posvol(P, ctx->pos_sorted.as<float4>(), res->perm.as<uint32_t>(), res->rho.as<float>(), res->posvol.as<float4>(), st);
+    ss_launch_make_posvol(P, ctx->pos_sorted.as<ss_real4<R>>(), res->perm.as<uint32_t>(), res->rho.as<R>(), res->posvol.as<ss_real4<R>>(), st);
     SS_HIP(ctx, hipEventRecord(ctx->ev[11], st));
 
     // ---- K3 prepare: active level-set blocks ----
@@ -621,8 +650,8 @@ ss_status phase_finish(ss_context* ctx, ss_result* res) {
     SS_HIP(ctx, hipStreamSynchronize(st));
     res->n_active = n_active;
     SS_HIP(ctx, res->active_list.reserve((size_t)n_active * 4 + 16));
-    SS_HIP(ctx, res->G.reserve((size_t)n_active * SS_BLOCK_POINTS * 4 + 16));
-    SS_HIP(ctx, res->blk_minmax.reserve((size_t)n_active * 8 + 16));
+    SS_HIP(ctx, res->G.reserve((size_t)n_active * SS_BLOCK_POINTS * sizeof(R) + 16));
+    SS_HIP(ctx, res->blk_minmax.reserve((size_t)n_active * 2 * sizeof(R) + 16));
     ss_launch_compact_blocks(ctx->block_flag.as<uint32_t>(), ctx->block_rank.as<uint32_t>(), (uint32_t)nblocks, res->active_list.as<uint32_t>(),
                              res->block_slot.as<uint32_t>(), st);
     SS_HIP(ctx, ctx->counter.reserve(64));
@@ -630,13 +659,13 @@ ss_status phase_finish(ss_context* ctx, ss_result* res) {
     SS_HIP(ctx, hipEventRecord(ctx->ev[5], st));
 
     // ---- K3: level-set splat ----
-    if (n_active && ctx->fastdiv_h != P.h) {
+    if constexpr (sizeof(R) == 4) if (n_active && ctx->fastdiv_h != P.h) {
         // once per distinct h: prove on the device that the fast division is exact for this divisor
         ctx->fastdiv_ok = false;
-        if (P.h > 1.0e-9f && P.h < 1.0e15f) {
+        if (P.h > R(1.0e-9) && P.h < R(1.0e15)) {
             uint32_t bad = 1;
             SS_HIP(ctx, hipMemsetAsync(ctx->counter.as<char>() + 32, 0, 4, st));
-            ss_launch_verify_fast_div(P.h, 1.0f / P.h, reinterpret_cast<uint32_t*>(ctx->counter.as<char>() + 32), st);
+            ss_launch_verify_fast_div(P.h, R(1.0) / P.h, reinterpret_cast<uint32_t*>(ctx->counter.as<char>() + 32), st);
             SS_HIP(ctx, hipMemcpyAsync(&bad, ctx->counter.as<char>() + 32, 4, hipMemcpyDeviceToHost, st));
             SS_HIP(ctx, hipStreamSynchronize(st));
             ctx->fastdiv_ok = (bad == 0);
@@ -644,12 +673,12 @@ ss_status phase_finish(ss_context* ctx, ss_result* res) {
         ctx->fastdiv_h = P.h;
         SS_HIP(ctx, hipEventRecord(ctx->ev[5], st));  // keep the one-off check out of the splat timing
     }
-    ss_launch_splat(P, res->posvol.as<float4>(), res->perm.as<uint32_t>(), ctx->cell_start.as<uint32_t>(), res->active_list.as<uint32_t>(), n_active,
-                    res->G.as<float>(), res->blk_minmax.as<float2>(), ctx->counter.as<unsigned long long>(), ctx->fastdiv_ok, st);
+    ss_launch_splat(P, res->posvol.as<ss_real4<R>>(), res->perm.as<uint32_t>(), ctx->cell_start.as<uint32_t>(), res->active_list.as<uint32_t>(), n_active,
+                    res->G.as<R>(), res->blk_minmax.as<ss_real2<R>>(), ctx->counter.as<unsigned long long>(), sizeof(R) == 4 && ctx->fastdiv_ok, st);
     SS_HIP(ctx, hipEventRecord(ctx->ev[6], st));
 
     // ---- K4 prepare: MC blocks = blocks whose 2x2x2 level-set neighbourhood straddles the threshold ----
-    ss_launch_mark_mc_blocks(P, res->block_slot.as<uint32_t>(), res->blk_minmax.as<float2>(), (uint32_t)nblocks, ctx->mc_flag.as<uint32_t>(), st);
+    ss_launch_mark_mc_blocks(P, res->block_slot.as<uint32_t>(), res->blk_minmax.as<ss_real2<R>>(), (uint32_t)nblocks, ctx->mc_flag.as<uint32_t>(), st);
     s = exclusive_scan_u32<uint32_t>(ctx, ctx->mc_flag.as<uint32_t>(), ctx->mc_rank.as<uint32_t>(), nblocks + 1);
     if (s != SS_OK) return s;
     uint32_t n_mc = 0;
@@ -668,7 +697,7 @@ ss_status phase_finish(ss_context* ctx, ss_result* res) {
     SS_HIP(ctx, res->tbase.reserve(((size_t)n_mc + 1) * 4));
     SS_HIP(ctx, hipMemsetAsync(ctx->vcount.p, 0, ((size_t)n_mc + 1) * 4, st));
     SS_HIP(ctx, hipMemsetAsync(ctx->tcount.p, 0, ((size_t)n_mc + 1) * 4, st));
-    ss_launch_mc_count(P, res->G.as<float>(), res->block_slot.as<uint32_t>(), res->mc_list.as<uint32_t>(), n_mc, res->masks.as<unsigned long long>(),
+    ss_launch_mc_count(P, res->G.as<R>(), res->block_slot.as<uint32_t>(), res->mc_list.as<uint32_t>(), n_mc, res->masks.as<unsigned long long>(),
                        ctx->vcount.as<uint32_t>(), ctx->tcount.as<uint32_t>(), st);
     SS_HIP(ctx, hipEventRecord(ctx->ev[7], st));
     // ---- "stitching": global numbering by prefix sums ----
@@ -684,13 +713,13 @@ ss_status phase_finish(ss_context* ctx, ss_result* res) {
     SS_HIP(ctx, hipStreamSynchronize(st));
     const uint64_t nv = totals[0], nt = totals[1];
     if (nt * 3 >= (1ull << 32)) return fail(ctx, SS_ERR_UNSUPPORTED, "more than 2^32/3 triangles in one call are not supported by this build");
-    SS_HIP(ctx, res->vertices.reserve(nv * 12 + 16));
+    SS_HIP(ctx, res->vertices.reserve(nv * 3 * sizeof(R) + 16));
     SS_HIP(ctx, res->vkeys.reserve(nv * 8 + 16));
     SS_HIP(ctx, res->tri32.reserve(nt * 12 + 16));
     SS_HIP(ctx, hipEventRecord(ctx->ev[8], st));
     // ---- K5: emission ----
-    ss_launch_mc_emit(P, res->G.as<float>(), res->block_slot.as<uint32_t>(), res->mc_list.as<uint32_t>(), res->mc_slot.as<uint32_t>(), n_mc,
-                      res->masks.as<unsigned long long>(), res->vbase.as<uint32_t>(), res->tbase.as<uint32_t>(), res->vertices.as<float>(),
+    ss_launch_mc_emit(P, res->G.as<R>(), res->block_slot.as<uint32_t>(), res->mc_list.as<uint32_t>(), res->mc_slot.as<uint32_t>(), n_mc,
+                      res->masks.as<unsigned long long>(), res->vbase.as<uint32_t>(), res->tbase.as<uint32_t>(), res->vertices.as<R>(),
                       res->vkeys.as<unsigned long long>(), res->tri32.as<uint32_t>(), st);
     SS_HIP(ctx, hipEventRecord(ctx->ev[9], st));
     SS_HIP(ctx, hipStreamSynchronize(st));
@@ -732,10 +761,11 @@ ss_status phase_finish(ss_context* ctx, ss_result* res) {
     return SS_OK;
 }
 
-ss_status reconstruct_impl(ss_context* ctx, const float* xyz, uint64_t n_in, const ss_params_f32* prm, ss_result* res) {
-    ss_status s = phase_begin(ctx, xyz, n_in, prm, nullptr, res);
+template <class R>
+ss_status reconstruct_impl(ss_context* ctx, const R* xyz, uint64_t n_in, const typename TypesOf<R>::params* prm, ss_result* res) {
+    ss_status s = phase_begin<R>(ctx, xyz, n_in, prm, nullptr, res);
     if (s != SS_OK) return s;
-    return phase_finish(ctx, res);
+    return phase_finish<R>(ctx, res);
 }
 
 template <class T>
@@ -758,6 +788,98 @@ void result_release(ss_result* r) {
         b->release();
     for (HostBuf* b : {&r->h_vertices, &r->h_tri64, &r->h_tri32, &r->h_rho, &r->h_vkeys, &r->h_inside, &r->h_nb_ptr, &r->h_nb_idx}) b->release();
     for (DevBuf* b : {&r->nb_ptr, &r->nb_idx, &r->nb_idx64}) b->release();
+}
+
+extern "C" ss_status ss_result_create(ss_context* c, ss_result** out);
+extern "C" void ss_result_free(ss_result* r);
+
+template <class R>
+ss_status reconstruct_inplace_abi(ss_context* c, const R* xyz, uint64_t n, const typename TypesOf<R>::params* prm, ss_result* inout) {
+    if (!c || !inout) return SS_ERR_INVALID_ARGUMENT;
+    if (inout->ctx != c) return fail(c, SS_ERR_INVALID_ARGUMENT, "result belongs to a different context");
+    c->err.clear();
+    c->err_detail = 0;
+    return reconstruct_impl<R>(c, xyz, n, prm, inout);
+}
+
+template <class R>
+ss_status reconstruct_abi(ss_context* c, const R* xyz, uint64_t n, const typename TypesOf<R>::params* prm, ss_result** out) {
+    if (!c || !out) return SS_ERR_INVALID_ARGUMENT;
+    *out = nullptr;
+    ss_result* r = nullptr;
+    ss_status s = ss_result_create(c, &r);
+    if (s != SS_OK) return s;
+    s = reconstruct_inplace_abi<R>(c, xyz, n, prm, r);
+    if (s != SS_OK) {
+        ss_result_free(r);
+        return s;
+    }
+    *out = r;
+    return SS_OK;
+}
+
+template <class R>
+ss_status grid_for_reconstruction_abi(ss_context* c, const R* xyz, uint64_t n_in, const typename TypesOf<R>::params* prm,
+                                      typename TypesOf<R>::grid* out) {
+    if (!c || !prm || !out) return SS_ERR_INVALID_ARGUMENT;
+    c->err.clear();
+    if (!(prm->cube_size > R(0.0))) return fail(c, SS_ERR_UNKNOWN, "cube size must be positive");
+    if (!(prm->compact_support_radius >= R(0.0))) return fail(c, SS_ERR_UNKNOWN, "compact support radius must be non-negative");
+    if (n_in >= (1ull << 31)) return fail(c, SS_ERR_UNSUPPORTED, "too many particles");
+    SS_HIP(c, hipSetDevice(c->device));
+    R pmin[3] = {0, 0, 0}, pmax[3] = {0, 0, 0};
+    bool have = false;
+    if (!prm->has_particle_aabb && n_in > 0) {
+        // note: lib.rs:476-507 computes the AABB over the particles it is given (no filtering here)
+        const R* d_xyz = nullptr;
+        if (!xyz) return fail(c, SS_ERR_INVALID_ARGUMENT, "particle pointer is null");
+        if (is_device_pointer(xyz)) {
+            d_xyz = xyz;
+        } else {
+            SS_HIP(c, c->xyz_in.reserve(n_in * 3 * sizeof(R)));
+            SS_HIP(c, hipMemcpyAsync(c->xyz_in.p, xyz, n_in * 3 * sizeof(R), hipMemcpyHostToDevice, c->stream));
+            d_xyz = c->xyz_in.as<R>();
+        }
+        ss_status s = compute_particle_aabb<R>(c, d_xyz, (uint32_t)n_in, pmin, pmax);
+        if (s != SS_OK) return s;
+        have = true;
+    }
+    int gerr = grid_for_reconstruction<R>(prm, have, pmin, pmax, out);
+    if (gerr) return fail(c, SS_ERR_GRID_CONSTRUCTION, "grid construction failed (uniform_grid.rs:147-169)", gerr);
+    return SS_OK;
+}
+
+template <class R>
+ss_status levelset_box_impl(ss_result* r, const int64_t lo[3], const int64_t extent[3], R* out) {
+    ss_context* c = r->ctx;
+    for (int d = 0; d < 3; ++d)
+        if (extent[d] < 0 || extent[d] > 4096 || lo[d] < -2000000000ll || lo[d] > 2000000000ll) return fail(c, SS_ERR_INVALID_ARGUMENT, "box out of range");
+    const size_t tot = (size_t)extent[0] * extent[1] * extent[2];
+    if (!tot) return SS_OK;
+    SS_HIP(c, hipSetDevice(c->device));
+    DevBuf tmp;
+    SS_HIP(c, tmp.reserve(tot * sizeof(R)));
+    const int l[3] = {(int)lo[0], (int)lo[1], (int)lo[2]}, e[3] = {(int)extent[0], (int)extent[1], (int)extent[2]};
+    if (r->n_active == 0) {
+        SS_HIP(c, hipMemsetAsync(tmp.p, 0, tot * sizeof(R), c->stream));
+    } else {
+        ss_launch_levelset_box<R>(dev_params<R>(r), r->G.as<R>(), r->block_slot.as<uint32_t>(), l, e, tmp.as<R>(), c->stream);
+    }
+    SS_HIP(c, hipMemcpyAsync(out, tmp.p, tot * sizeof(R), hipMemcpyDeviceToHost, c->stream));
+    SS_HIP(c, hipStreamSynchronize(c->stream));
+    tmp.release();
+    return SS_OK;
+}
+
+template <class G1, class G2>
+void convert_grid(const G1& a, G2* b) {
+    for (int d = 0; d < 3; ++d) {
+        b->aabb_min[d] = (decltype(b->cell_size))a.aabb_min[d];
+        b->aabb_max[d] = (decltype(b->cell_size))a.aabb_max[d];
+        b->n_points[d] = a.n_points[d];
+        b->n_cells[d] = a.n_cells[d];
+    }
+    b->cell_size = (decltype(b->cell_size))a.cell_size;
 }
 
 }  // namespace
@@ -820,9 +942,12 @@ ss_status ss_result_create(ss_context* c, ss_result** out) {
     ss_result* r = new (std::nothrow) ss_result();
     if (!r) return fail(c, SS_ERR_UNKNOWN, "out of host memory");
     r->ctx = c;
-    memset(&r->P, 0, sizeof(r->P));
-    memset(&r->grid, 0, sizeof(r->grid));
-    memset(&r->subgrid, 0, sizeof(r->subgrid));
+    memset(&r->P32, 0, sizeof(r->P32));
+    memset(&r->P64, 0, sizeof(r->P64));
+    memset(&r->grid32, 0, sizeof(r->grid32));
+    memset(&r->sub32, 0, sizeof(r->sub32));
+    memset(&r->grid64, 0, sizeof(r->grid64));
+    memset(&r->sub64, 0, sizeof(r->sub64));
     memset(&r->stats, 0, sizeof(r->stats));
     *out = r;
     return SS_OK;
@@ -836,26 +961,16 @@ void ss_result_free(ss_result* r) {
 }
 
 ss_status ss_reconstruct_surface_inplace_f32(ss_context* c, const float* xyz, uint64_t n, const ss_params_f32* prm, ss_result* inout) {
-    if (!c || !inout) return SS_ERR_INVALID_ARGUMENT;
-    if (inout->ctx != c) return fail(c, SS_ERR_INVALID_ARGUMENT, "result belongs to a different context");
-    c->err.clear();
-    c->err_detail = 0;
-    return reconstruct_impl(c, xyz, n, prm, inout);
+    return reconstruct_inplace_abi<float>(c, xyz, n, prm, inout);
 }
-
+ss_status ss_reconstruct_surface_inplace_f64(ss_context* c, const double* xyz, uint64_t n, const ss_params_f64* prm, ss_result* inout) {
+    return reconstruct_inplace_abi<double>(c, xyz, n, prm, inout);
+}
 ss_status ss_reconstruct_surface_f32(ss_context* c, const float* xyz, uint64_t n, const ss_params_f32* prm, ss_result** out) {
-    if (!c || !out) return SS_ERR_INVALID_ARGUMENT;
-    *out = nullptr;
-    ss_result* r = nullptr;
-    ss_status s = ss_result_create(c, &r);
-    if (s != SS_OK) return s;
-    s = ss_reconstruct_surface_inplace_f32(c, xyz, n, prm, r);
-    if (s != SS_OK) {
-        ss_result_free(r);
-        return s;
-    }
-    *out = r;
-    return SS_OK;
+    return reconstruct_abi<float>(c, xyz, n, prm, out);
+}
+ss_status ss_reconstruct_surface_f64(ss_context* c, const double* xyz, uint64_t n, const ss_params_f64* prm, ss_result** out) {
+    return reconstruct_abi<double>(c, xyz, n, prm, out);
 }
 
 ss_status ss_shard_begin_f32(ss_context* c, const float* xyz, uint64_t n, const ss_params_f32* prm, const ss_shard_f32* shard, ss_result* inout) {
@@ -863,18 +978,18 @@ ss_status ss_shard_begin_f32(ss_context* c, const float* xyz, uint64_t n, const 
     if (inout->ctx != c) return fail(c, SS_ERR_INVALID_ARGUMENT, "result belongs to a different context");
     c->err.clear();
     c->err_detail = 0;
-    return phase_begin(c, xyz, n, prm, shard, inout);
+    return phase_begin<float>(c, xyz, n, prm, shard, inout);
 }
 
 ss_status ss_shard_finish(ss_context* c, ss_result* inout) {
     if (!c || !inout) return SS_ERR_INVALID_ARGUMENT;
     if (inout->ctx != c) return fail(c, SS_ERR_INVALID_ARGUMENT, "result belongs to a different context");
     c->err.clear();
-    return phase_finish(c, inout);
+    return inout->is_f64 ? phase_finish<double>(c, inout) : phase_finish<float>(c, inout);
 }
 
 ss_status ss_shard_get_densities(ss_result* r, float* dst, uint64_t n) {
-    if (!r || r->phase < 1 || (!dst && n)) return SS_ERR_INVALID_ARGUMENT;
+    if (!r || r->phase < 1 || r->is_f64 || (!dst && n)) return SS_ERR_INVALID_ARGUMENT;
     ss_context* c = r->ctx;
     if (n != r->n_particles) return fail(c, SS_ERR_INVALID_ARGUMENT, "density count mismatch");
     if (!n) return SS_OK;
@@ -885,7 +1000,7 @@ ss_status ss_shard_get_densities(ss_result* r, float* dst, uint64_t n) {
 }
 
 ss_status ss_shard_set_densities(ss_result* r, const float* src, uint64_t n) {
-    if (!r || r->phase != 1 || (!src && n)) return SS_ERR_INVALID_ARGUMENT;
+    if (!r || r->phase != 1 || r->is_f64 || (!src && n)) return SS_ERR_INVALID_ARGUMENT;
     ss_context* c = r->ctx;
     if (n != r->n_particles) return fail(c, SS_ERR_INVALID_ARGUMENT, "density count mismatch");
     if (!n) return SS_OK;
@@ -903,41 +1018,21 @@ ss_status ss_grid_for_domain_f32(const ss_params_f32* prm, const float domain_mi
     ss_params_f32 p = *prm;
     p.has_particle_aabb = 0;
     ss_grid_f32 initial;
-    if (grid_for_reconstruction(&p, true, domain_min, domain_max, &initial)) return SS_ERR_GRID_CONSTRUCTION;
+    if (grid_for_reconstruction<float>(&p, true, domain_min, domain_max, &initial)) return SS_ERR_GRID_CONSTRUCTION;
     float mass = 0, margin = 0;
-    initialize_subdomain_parameters(&p, &initial, grid, subdomain_grid, &mass, &margin);
+    initialize_subdomain_parameters<float>(&p, &initial, grid, subdomain_grid, &mass, &margin);
     if (ghost_margin) *ghost_margin = margin;
     return SS_OK;
 }
 
 ss_status ss_grid_for_reconstruction_f32(ss_context* c, const float* xyz, uint64_t n_in, const ss_params_f32* prm, ss_grid_f32* out) {
-    if (!c || !prm || !out) return SS_ERR_INVALID_ARGUMENT;
-    c->err.clear();
-    if (!(prm->cube_size > 0.0f)) return fail(c, SS_ERR_UNKNOWN, "cube size must be positive");
-    if (!(prm->compact_support_radius >= 0.0f)) return fail(c, SS_ERR_UNKNOWN, "compact support radius must be non-negative");
-    if (n_in >= (1ull << 31)) return fail(c, SS_ERR_UNSUPPORTED, "too many particles");
-    SS_HIP(c, hipSetDevice(c->device));
-    float pmin[3] = {0, 0, 0}, pmax[3] = {0, 0, 0};
-    bool have = false;
-    if (!prm->has_particle_aabb && n_in > 0) {
-        // note: lib.rs:476-507 computes the AABB over the particles it is given (no filtering here)
-        const float* d_xyz = nullptr;
-        if (!xyz) return fail(c, SS_ERR_INVALID_ARGUMENT, "particle pointer is null");
-        if (is_device_pointer(xyz)) {
-            d_xyz = xyz;
-        } else {
-            SS_HIP(c, c->xyz_in.reserve(n_in * 12));
-            SS_HIP(c, hipMemcpyAsync(c->xyz_in.p, xyz, n_in * 12, hipMemcpyHostToDevice, c->stream));
-            d_xyz = c->xyz_in.as<float>();
-        }
-        ss_status s = compute_particle_aabb(c, d_xyz, (uint32_t)n_in, pmin, pmax);
-        if (s != SS_OK) return s;
-        have = true;
-    }
-    int gerr = grid_for_reconstruction(prm, have, pmin, pmax, out);
-    if (gerr) return fail(c, SS_ERR_GRID_CONSTRUCTION, "grid construction failed (uniform_grid.rs:147-169)", gerr);
-    return SS_OK;
+    return grid_for_reconstruction_abi<float>(c, xyz, n_in, prm, out);
 }
+ss_status ss_grid_for_reconstruction_f64(ss_context* c, const double* xyz, uint64_t n_in, const ss_params_f64* prm, ss_grid_f64* out) {
+    return grid_for_reconstruction_abi<double>(c, xyz, n_in, prm, out);
+}
+
+int ss_result_is_f64(const ss_result* r) { return (r && r->is_f64) ? 1 : 0; }
 
 ss_status ss_result_counts(const ss_result* r, uint64_t* nv, uint64_t* nt) {
     if (!r || !r->valid) return SS_ERR_INVALID_ARGUMENT;
@@ -946,8 +1041,14 @@ ss_status ss_result_counts(const ss_result* r, uint64_t* nv, uint64_t* nt) {
     return SS_OK;
 }
 
+ss_status ss_result_vertices_f64(ss_result* r, const double** xyz, uint64_t* n) {
+    if (!r || !r->valid || !r->is_f64 || !xyz || !n) return SS_ERR_INVALID_ARGUMENT;
+    *n = r->n_vertices;
+    return download<double>(r, r->vertices, r->h_vertices, r->hv, (size_t)r->n_vertices * 3, xyz);
+}
+
 ss_status ss_result_vertices(ss_result* r, const float** xyz, uint64_t* n) {
-    if (!r || !r->valid || !xyz || !n) return SS_ERR_INVALID_ARGUMENT;
+    if (!r || !r->valid || r->is_f64 || !xyz || !n) return SS_ERR_INVALID_ARGUMENT;
     *n = r->n_vertices;
     return download<float>(r, r->vertices, r->h_vertices, r->hv, (size_t)r->n_vertices * 3, xyz);
 }
@@ -986,19 +1087,50 @@ ss_status ss_result_vertex_keys(ss_result* r, const uint64_t** keys, uint64_t* n
 
 ss_status ss_result_grid(const ss_result* r, ss_grid_f32* out) {
     if (!r || !r->valid || !out) return SS_ERR_INVALID_ARGUMENT;
-    *out = r->grid;
+    if (r->is_f64)
+        convert_grid(r->grid64, out);  // rounded to f32
+    else
+        *out = r->grid32;
+    return SS_OK;
+}
+
+ss_status ss_result_grid_f64(const ss_result* r, ss_grid_f64* out) {
+    if (!r || !r->valid || !out) return SS_ERR_INVALID_ARGUMENT;
+    if (r->is_f64)
+        *out = r->grid64;
+    else
+        convert_grid(r->grid32, out);  // exact
+    return SS_OK;
+}
+
+ss_status ss_result_subdomain_grid_f64(const ss_result* r, ss_grid_f64* out, int32_t* present) {
+    if (!r || !r->valid || !out || !present) return SS_ERR_INVALID_ARGUMENT;
+    if (r->is_f64)
+        *out = r->sub64;
+    else
+        convert_grid(r->sub32, out);
+    *present = 1;
     return SS_OK;
 }
 
 ss_status ss_result_subdomain_grid(const ss_result* r, ss_grid_f32* out, int32_t* present) {
     if (!r || !r->valid || !out || !present) return SS_ERR_INVALID_ARGUMENT;
-    *out = r->subgrid;
+    if (r->is_f64)
+        convert_grid(r->sub64, out);
+    else
+        *out = r->sub32;
     *present = 1;
     return SS_OK;
 }
 
+ss_status ss_result_particle_densities_f64(ss_result* r, const double** rho, uint64_t* n) {
+    if (!r || !r->valid || !r->is_f64 || !rho || !n) return SS_ERR_INVALID_ARGUMENT;
+    *n = r->n_particles;
+    return download<double>(r, r->rho, r->h_rho, r->hrho, (size_t)r->n_particles, rho);
+}
+
 ss_status ss_result_particle_densities(ss_result* r, const float** rho, uint64_t* n) {
-    if (!r || !r->valid || !rho || !n) return SS_ERR_INVALID_ARGUMENT;
+    if (!r || !r->valid || r->is_f64 || !rho || !n) return SS_ERR_INVALID_ARGUMENT;
     *n = r->n_particles;
     return download<float>(r, r->rho, r->h_rho, r->hrho, (size_t)r->n_particles, rho);
 }
@@ -1050,7 +1182,7 @@ ss_status ss_result_stats(const ss_result* r, ss_stats* out) {
 }
 
 ss_status ss_result_device_vertices(const ss_result* r, const float** d, uint64_t* n) {
-    if (!r || !r->valid || !d || !n) return SS_ERR_INVALID_ARGUMENT;
+    if (!r || !r->valid || r->is_f64 || !d || !n) return SS_ERR_INVALID_ARGUMENT;
     *d = r->vertices.as<float>();
     *n = r->n_vertices;
     return SS_OK;
@@ -1062,32 +1194,20 @@ ss_status ss_result_device_triangles_u32(const ss_result* r, const uint32_t** d,
     return SS_OK;
 }
 ss_status ss_result_device_particle_densities(const ss_result* r, const float** d, uint64_t* n) {
-    if (!r || !r->valid || !d || !n) return SS_ERR_INVALID_ARGUMENT;
+    if (!r || !r->valid || r->is_f64 || !d || !n) return SS_ERR_INVALID_ARGUMENT;
     *d = r->rho.as<float>();
     *n = r->n_particles;
     return SS_OK;
 }
 
 ss_status ss_result_levelset_box(ss_result* r, const int64_t lo[3], const int64_t extent[3], float* out) {
-    if (!r || !r->valid || !lo || !extent || !out) return SS_ERR_INVALID_ARGUMENT;
-    ss_context* c = r->ctx;
-    for (int d = 0; d < 3; ++d)
-        if (extent[d] < 0 || extent[d] > 4096 || lo[d] < -2000000000ll || lo[d] > 2000000000ll) return fail(c, SS_ERR_INVALID_ARGUMENT, "box out of range");
-    const size_t tot = (size_t)extent[0] * extent[1] * extent[2];
-    if (!tot) return SS_OK;
-    SS_HIP(c, hipSetDevice(c->device));
-    DevBuf tmp;
-    SS_HIP(c, tmp.reserve(tot * 4));
-    const int l[3] = {(int)lo[0], (int)lo[1], (int)lo[2]}, e[3] = {(int)extent[0], (int)extent[1], (int)extent[2]};
-    if (r->n_active == 0) {
-        SS_HIP(c, hipMemsetAsync(tmp.p, 0, tot * 4, c->stream));
-    } else {
-        ss_launch_levelset_box(r->P, r->G.as<float>(), r->block_slot.as<uint32_t>(), l, e, tmp.as<float>(), c->stream);
-    }
-    SS_HIP(c, hipMemcpyAsync(out, tmp.p, tot * 4, hipMemcpyDeviceToHost, c->stream));
-    SS_HIP(c, hipStreamSynchronize(c->stream));
-    tmp.release();
-    return SS_OK;
+    if (!r || !r->valid || r->is_f64 || !lo || !extent || !out) return SS_ERR_INVALID_ARGUMENT;
+    return levelset_box_impl<float>(r, lo, extent, out);
+}
+
+ss_status ss_result_levelset_box_f64(ss_result* r, const int64_t lo[3], const int64_t extent[3], double* out) {
+    if (!r || !r->valid || !r->is_f64 || !lo || !extent || !out) return SS_ERR_INVALID_ARGUMENT;
+    return levelset_box_impl<double>(r, lo, extent, out);
 }
 
 ss_status ss_result_subdomain_stats(ss_result* r, uint64_t* n_occupied, uint64_t* n_sub_particles) {

@@ -16,7 +16,7 @@
 // GATHERS its contributions in ascending original particle index -- the summation order of the
 // reference (sorted per-subdomain particle lists, dense_subdomains.rs:476-488) -- so level-set values
 // are bit-identical to the reference's scalar path, independent of subdomain or GPU boundaries, with
-// no float atomics anywhere.
+// no R atomics anywhere.
 #include "ss_device.h"
 #include "ss_kernels.h"
 
@@ -32,15 +32,16 @@ __constant__ int8_t c_edge[12][2] = {{0, 0}, {1, 1}, {3, 0}, {0, 1}, {4, 0}, {5,
 // =====================================================================================================
 // K0: bounding box
 // =====================================================================================================
-__global__ __launch_bounds__(256) void k_aabb_partial(const float* __restrict__ xyz, uint32_t n, float* __restrict__ partial) {
-    __shared__ float s_min[3][256];
-    __shared__ float s_max[3][256];
-    float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+template <class R>
+__global__ __launch_bounds__(256) void k_aabb_partial(const R* __restrict__ xyz, uint32_t n, R* __restrict__ partial) {
+    __shared__ R s_min[3][256];
+    __shared__ R s_max[3][256];
+    R mn[3] = {std::numeric_limits<R>::infinity(), std::numeric_limits<R>::infinity(), std::numeric_limits<R>::infinity()}, mx[3] = {-std::numeric_limits<R>::infinity(), -std::numeric_limits<R>::infinity(), -std::numeric_limits<R>::infinity()};
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         for (int d = 0; d < 3; ++d) {
-            float v = xyz[3 * (size_t)i + d];
-            mn[d] = fminf(mn[d], v);
-            mx[d] = fmaxf(mx[d], v);
+            R v = xyz[3 * (size_t)i + d];
+            mn[d] = ss_min(mn[d], v);
+            mx[d] = ss_max(mx[d], v);
         }
     }
     for (int d = 0; d < 3; ++d) {
@@ -51,8 +52,8 @@ __global__ __launch_bounds__(256) void k_aabb_partial(const float* __restrict__ 
     for (int s = 128; s > 0; s >>= 1) {
         if ((int)threadIdx.x < s)
             for (int d = 0; d < 3; ++d) {
-                s_min[d][threadIdx.x] = fminf(s_min[d][threadIdx.x], s_min[d][threadIdx.x + s]);
-                s_max[d][threadIdx.x] = fmaxf(s_max[d][threadIdx.x], s_max[d][threadIdx.x + s]);
+                s_min[d][threadIdx.x] = ss_min(s_min[d][threadIdx.x], s_min[d][threadIdx.x + s]);
+                s_max[d][threadIdx.x] = ss_max(s_max[d][threadIdx.x], s_max[d][threadIdx.x + s]);
             }
         __syncthreads();
     }
@@ -63,14 +64,15 @@ __global__ __launch_bounds__(256) void k_aabb_partial(const float* __restrict__ 
         }
 }
 
-__global__ __launch_bounds__(256) void k_aabb_final(const float* __restrict__ partial, uint32_t nblocks, float* __restrict__ out6) {
-    __shared__ float s_min[3][256];
-    __shared__ float s_max[3][256];
-    float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+template <class R>
+__global__ __launch_bounds__(256) void k_aabb_final(const R* __restrict__ partial, uint32_t nblocks, R* __restrict__ out6) {
+    __shared__ R s_min[3][256];
+    __shared__ R s_max[3][256];
+    R mn[3] = {std::numeric_limits<R>::infinity(), std::numeric_limits<R>::infinity(), std::numeric_limits<R>::infinity()}, mx[3] = {-std::numeric_limits<R>::infinity(), -std::numeric_limits<R>::infinity(), -std::numeric_limits<R>::infinity()};
     for (uint32_t i = threadIdx.x; i < nblocks; i += blockDim.x)
         for (int d = 0; d < 3; ++d) {
-            mn[d] = fminf(mn[d], partial[i * 6 + d]);
-            mx[d] = fmaxf(mx[d], partial[i * 6 + 3 + d]);
+            mn[d] = ss_min(mn[d], partial[i * 6 + d]);
+            mx[d] = ss_max(mx[d], partial[i * 6 + 3 + d]);
         }
     for (int d = 0; d < 3; ++d) {
         s_min[d][threadIdx.x] = mn[d];
@@ -80,8 +82,8 @@ __global__ __launch_bounds__(256) void k_aabb_final(const float* __restrict__ pa
     for (int s = 128; s > 0; s >>= 1) {
         if ((int)threadIdx.x < s)
             for (int d = 0; d < 3; ++d) {
-                s_min[d][threadIdx.x] = fminf(s_min[d][threadIdx.x], s_min[d][threadIdx.x + s]);
-                s_max[d][threadIdx.x] = fmaxf(s_max[d][threadIdx.x], s_max[d][threadIdx.x + s]);
+                s_min[d][threadIdx.x] = ss_min(s_min[d][threadIdx.x], s_min[d][threadIdx.x + s]);
+                s_max[d][threadIdx.x] = ss_max(s_max[d][threadIdx.x], s_max[d][threadIdx.x + s]);
             }
         __syncthreads();
     }
@@ -92,29 +94,32 @@ __global__ __launch_bounds__(256) void k_aabb_final(const float* __restrict__ pa
         }
 }
 
-void ss_launch_aabb(const float* d_xyz, uint32_t n, float* d_partial, float* d_out6, hipStream_t st) {
+template <class R>
+void ss_launch_aabb(const R* d_xyz, uint32_t n, R* d_partial, R* d_out6, hipStream_t st) {
     uint32_t blocks = (n + 255) / 256;
     if (blocks > 1024) blocks = 1024;
     if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL(k_aabb_partial, dim3(blocks), dim3(256), 0, st, d_xyz, n, d_partial);
-    hipLaunchKernelGGL(k_aabb_final, dim3(1), dim3(256), 0, st, d_partial, blocks, d_out6);
+    hipLaunchKernelGGL(k_aabb_partial<R>, dim3(blocks), dim3(256), 0, st, d_xyz, n, d_partial);
+    hipLaunchKernelGGL(k_aabb_final<R>, dim3(1), dim3(256), 0, st, d_partial, blocks, d_out6);
 }
 
 // =====================================================================================================
 // K0b: particle AABB filter (lib.rs:369-406; half-open test aabb.rs:220-222)
 // =====================================================================================================
-__global__ __launch_bounds__(256) void k_inside_flags(const float* __restrict__ xyz, uint32_t n, float3 amin, float3 amax,
-                                                      uint8_t* __restrict__ flags8, uint32_t* __restrict__ flags32) {
+template <class R>
+__global__ __launch_bounds__(256) void k_inside_flags(const R* __restrict__ xyz, uint32_t n, R a0, R a1, R a2, R b0, R b1,
+                                                      R b2, uint8_t* __restrict__ flags8, uint32_t* __restrict__ flags32) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    float x = xyz[3 * (size_t)i], y = xyz[3 * (size_t)i + 1], z = xyz[3 * (size_t)i + 2];
-    bool in = x >= amin.x && y >= amin.y && z >= amin.z && x < amax.x && y < amax.y && z < amax.z;
+    R x = xyz[3 * (size_t)i], y = xyz[3 * (size_t)i + 1], z = xyz[3 * (size_t)i + 2];
+    bool in = x >= a0 && y >= a1 && z >= a2 && x < b0 && y < b1 && z < b2;
     flags8[i] = in ? 1 : 0;
     flags32[i] = in ? 1u : 0u;
 }
 
-__global__ __launch_bounds__(256) void k_compact_xyz(const float* __restrict__ xyz, uint32_t n, const uint32_t* __restrict__ flags32,
-                                                     const uint32_t* __restrict__ offsets, float* __restrict__ out) {
+template <class R>
+__global__ __launch_bounds__(256) void k_compact_xyz(const R* __restrict__ xyz, uint32_t n, const uint32_t* __restrict__ flags32,
+                                                     const uint32_t* __restrict__ offsets, R* __restrict__ out) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n || !flags32[i]) return;
     size_t o = offsets[i];
@@ -123,33 +128,37 @@ __global__ __launch_bounds__(256) void k_compact_xyz(const float* __restrict__ x
     out[3 * o + 2] = xyz[3 * (size_t)i + 2];
 }
 
-void ss_launch_inside_flags(const float* d_xyz, uint32_t n, const float amin[3], const float amax[3], uint8_t* f8, uint32_t* f32, hipStream_t st) {
+template <class R>
+void ss_launch_inside_flags(const R* d_xyz, uint32_t n, const R amin[3], const R amax[3], uint8_t* f8, uint32_t* f32, hipStream_t st) {
     if (!n) return;
-    hipLaunchKernelGGL(k_inside_flags, dim3((n + 255) / 256), dim3(256), 0, st, d_xyz, n, make_float3(amin[0], amin[1], amin[2]),
-                       make_float3(amax[0], amax[1], amax[2]), f8, f32);
+    hipLaunchKernelGGL(k_inside_flags<R>, dim3((n + 255) / 256), dim3(256), 0, st, d_xyz, n, amin[0], amin[1], amin[2], amax[0], amax[1], amax[2], f8,
+                       f32);
 }
-void ss_launch_compact_xyz(const float* d_xyz, uint32_t n, const uint32_t* f32, const uint32_t* offs, float* out, hipStream_t st) {
+template <class R>
+void ss_launch_compact_xyz(const R* d_xyz, uint32_t n, const uint32_t* f32, const uint32_t* offs, R* out, hipStream_t st) {
     if (!n) return;
-    hipLaunchKernelGGL(k_compact_xyz, dim3((n + 255) / 256), dim3(256), 0, st, d_xyz, n, f32, offs, out);
+    hipLaunchKernelGGL(k_compact_xyz<R>, dim3((n + 255) / 256), dim3(256), 0, st, d_xyz, n, f32, offs, out);
 }
 
 // =====================================================================================================
 // K1: search-cell keys.  A particle is filed under the cell it has in the search grid of the
 // subdomain that CONTAINS it (= the subdomain computing its density, dense_subdomains.rs:567-614).
 // =====================================================================================================
-__device__ inline void ss_particle_cell(const SSDev& P, float x, float y, float z, int K[3]) {
-    float p[3] = {x, y, z};
+template <class R>
+__device__ inline void ss_particle_cell(const SSDevT<R>& P, R x, R y, R z, int K[3]) {
+    R p[3] = {x, y, z};
 #pragma unroll
     for (int d = 0; d < 3; ++d) {
         int s = ss_container_subdomain_axis(P, p[d], d);
-        int k = ss_search_cell_axis(P, s, p[d], d, nullptr);
+        int k = ss_search_cell_axis(P, s, p[d], d);
         // clamp into the dense cell array (cannot trigger for particles inside the grid; keeps indexing safe)
         k = max(P.kmin[d], min(P.kmin[d] + P.kdim[d] - 1, k));
         K[d] = k;
     }
 }
 
-__global__ __launch_bounds__(256) void k_cell_keys(SSDev P, const float* __restrict__ xyz, uint32_t* __restrict__ keys,
+template <class R>
+__global__ __launch_bounds__(256) void k_cell_keys(SSDevT<R> P, const R* __restrict__ xyz, uint32_t* __restrict__ keys,
                                                    uint32_t* __restrict__ vals, uint32_t* __restrict__ cell_count) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= P.n) return;
@@ -161,21 +170,24 @@ __global__ __launch_bounds__(256) void k_cell_keys(SSDev P, const float* __restr
     atomicAdd(&cell_count[key], 1u);
 }
 
-__global__ __launch_bounds__(256) void k_gather_sorted(uint32_t n, const float* __restrict__ xyz, const uint32_t* __restrict__ perm,
-                                                       float4* __restrict__ pos_sorted) {
+template <class R>
+__global__ __launch_bounds__(256) void k_gather_sorted(uint32_t n, const R* __restrict__ xyz, const uint32_t* __restrict__ perm,
+                                                       ss_real4<R>* __restrict__ pos_sorted) {
     uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= n) return;
     size_t i = perm[p];
-    pos_sorted[p] = make_float4(xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2], 0.0f);
+    pos_sorted[p] = ss_make4(xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2], R(0.0));
 }
 
-void ss_launch_cell_keys(const SSDev& P, const float* d_xyz, uint32_t* keys, uint32_t* vals, uint32_t* cell_count, hipStream_t st) {
+template <class R>
+void ss_launch_cell_keys(const SSDevT<R>& P, const R* d_xyz, uint32_t* keys, uint32_t* vals, uint32_t* cell_count, hipStream_t st) {
     if (!P.n) return;
-    hipLaunchKernelGGL(k_cell_keys, dim3((P.n + 255) / 256), dim3(256), 0, st, P, d_xyz, keys, vals, cell_count);
+    hipLaunchKernelGGL(k_cell_keys<R>, dim3((P.n + 255) / 256), dim3(256), 0, st, P, d_xyz, keys, vals, cell_count);
 }
-void ss_launch_gather_sorted(uint32_t n, const float* d_xyz, const uint32_t* perm, float4* pos_sorted, hipStream_t st) {
+template <class R>
+void ss_launch_gather_sorted(uint32_t n, const R* d_xyz, const uint32_t* perm, ss_real4<R>* pos_sorted, hipStream_t st) {
     if (!n) return;
-    hipLaunchKernelGGL(k_gather_sorted, dim3((n + 255) / 256), dim3(256), 0, st, n, d_xyz, perm, pos_sorted);
+    hipLaunchKernelGGL(k_gather_sorted<R>, dim3((n + 255) / 256), dim3(256), 0, st, n, d_xyz, perm, pos_sorted);
 }
 
 // =====================================================================================================
@@ -191,18 +203,18 @@ void ss_launch_gather_sorted(uint32_t n, const float* d_xyz, const uint32_t* per
 // makes the summation ORDER -- and hence every bit of rho -- identical to the reference even for
 // particles that sit exactly on search-cell boundaries.
 // =====================================================================================================
-template <class F>
-__device__ inline void ss_for_each_member_subdomain(const SSDev& P, const float p[3], F f) {
+template <class R, class F>
+__device__ inline void ss_for_each_member_subdomain(const SSDevT<R>& P, const R p[3], F f) {
     int sub[3];
-    float min_corner[3], max_corner[3];
+    R min_corner[3], max_corner[3];
 #pragma unroll
     for (int d = 0; d < 3; ++d) {
-        sub[d] = (int)floorf((p[d] - P.gmin[d]) / P.sub_size);  // uniform_grid.rs:444-451
+        sub[d] = (int)ss_floor((p[d] - P.gmin[d]) / P.sub_size);  // uniform_grid.rs:444-451
         if (sub[d] < 0 || sub[d] >= P.ns[d]) return;            // dense_subdomains.rs:1819-1822
-        min_corner[d] = P.gmin[d] + (float)sub[d] * P.sub_size;
-        max_corner[d] = P.gmin[d] + (float)(sub[d] + 1) * P.sub_size;
+        min_corner[d] = P.gmin[d] + (R)sub[d] * P.sub_size;
+        max_corner[d] = P.gmin[d] + (R)(sub[d] + 1) * P.sub_size;
     }
-    const float dx = P.sub_size;
+    const R dx = P.sub_size;
     const int r = P.sub_radius;  // ceil(margin / dx), dense_subdomains.rs:1827-1832
     for (int i0 = -r; i0 <= r; ++i0)
         for (int j0 = -r; j0 <= r; ++j0)
@@ -212,7 +224,7 @@ __device__ inline void ss_for_each_member_subdomain(const SSDev& P, const float 
 #pragma unroll
                 for (int d = 0; d < 3; ++d) {  // dense_subdomains.rs:1844-1856
                     const int step = steps[d];
-                    const float off = (float)((step < 0 ? -step : step) - 1);
+                    const R off = (R)((step < 0 ? -step : step) - 1);
                     if (step > 0)
                         in_margin = in_margin && (((max_corner[d] + off * dx) - p[d]) < P.margin);
                     else if (step < 0)
@@ -229,21 +241,23 @@ __device__ inline void ss_for_each_member_subdomain(const SSDev& P, const float 
 
 // cell of x in the neighbourhood-search grid of subdomain index s (per axis); neighborhood_search.rs:370
 // applied to the AABB of dense_subdomains.rs:560-565 (uniform_grid.rs:189-201 alignment, :444-451 cell)
-__device__ inline int ss_local_search_cell_axis(const SSDev& P, int s, float x, int d) {
-    const float amin = P.gmin[d] + (float)s * P.sub_size;
-    const float mmin = amin - P.margin * 1.5f;
-    const float aligned = floorf(mmin / P.h) * P.h;
-    const int c = (int)floorf((x - aligned) / P.h);
+template <class R>
+__device__ inline int ss_local_search_cell_axis(const SSDevT<R>& P, int s, R x, int d) {
+    const R amin = P.gmin[d] + (R)s * P.sub_size;
+    const R mmin = amin - P.margin * R(1.5);
+    const R aligned = ss_floor(mmin / P.h) * P.h;
+    const int c = (int)ss_floor((x - aligned) / P.h);
     return max(0, min(P.sc[d] - 1, c));
 }
 
 // member_count[i] = number of subdomains particle i belongs to; sub_flag[s] = 1 for every subdomain with
 // at least one (owned or ghost) particle.  Plain flag stores (all writers store 1): no atomics.
-__global__ __launch_bounds__(256) void k_classify_count(SSDev P, const float* __restrict__ xyz, uint32_t* __restrict__ member_count,
+template <class R>
+__global__ __launch_bounds__(256) void k_classify_count(SSDevT<R> P, const R* __restrict__ xyz, uint32_t* __restrict__ member_count,
                                                         uint32_t* __restrict__ sub_flag) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= P.n) return;
-    const float p[3] = {xyz[3 * (size_t)i], xyz[3 * (size_t)i + 1], xyz[3 * (size_t)i + 2]};
+    const R p[3] = {xyz[3 * (size_t)i], xyz[3 * (size_t)i + 1], xyz[3 * (size_t)i + 2]};
     uint32_t m = 0;
     ss_for_each_member_subdomain(P, p, [&](int sx, int sy, int sz) {
         ++m;
@@ -258,12 +272,13 @@ __global__ __launch_bounds__(256) void k_occupied_list(const uint32_t* __restric
     if (i < n && flag[i]) occ_sub[rank[i]] = i;
 }
 
-__global__ __launch_bounds__(256) void k_emit_copies(SSDev P, const float* __restrict__ xyz, const uint32_t* __restrict__ copy_offset,
+template <class R>
+__global__ __launch_bounds__(256) void k_emit_copies(SSDevT<R> P, const R* __restrict__ xyz, const uint32_t* __restrict__ copy_offset,
                                                      const uint32_t* __restrict__ occ_rank, uint32_t* __restrict__ keys,
                                                      uint32_t* __restrict__ vals, uint32_t* __restrict__ cell_count) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= P.n) return;
-    const float p[3] = {xyz[3 * (size_t)i], xyz[3 * (size_t)i + 1], xyz[3 * (size_t)i + 2]};
+    const R p[3] = {xyz[3 * (size_t)i], xyz[3 * (size_t)i + 1], xyz[3 * (size_t)i + 2]};
     uint32_t o = copy_offset[i];
     const uint32_t ctot = (uint32_t)(P.sc[0] * P.sc[1] * P.sc[2]);
     ss_for_each_member_subdomain(P, p, [&](int sx, int sy, int sz) {
@@ -282,10 +297,10 @@ __global__ __launch_bounds__(256) void k_emit_copies(SSDev P, const float* __res
 // MODE 0: densities.  MODE 1: densities + neighbour counts (global_neighborhood_list).
 // MODE 2: write the neighbour ids (global particle indices) at nb_ptr[i], in the reference's order
 // (dense_subdomains.rs:617-639: the per-subdomain lists remapped to global indices).
-template <int MODE>
-__global__ __launch_bounds__(256) void k_density_sub(SSDev P, uint32_t n_copies, const float4* __restrict__ cpos, const uint32_t* __restrict__ cidx,
+template <class R, int MODE>
+__global__ __launch_bounds__(256) void k_density_sub(SSDevT<R> P, uint32_t n_copies, const ss_real4<R>* __restrict__ cpos, const uint32_t* __restrict__ cidx,
                                                      const uint32_t* __restrict__ ckey, const uint32_t* __restrict__ cell_start,
-                                                     const uint32_t* __restrict__ occ_sub, float* __restrict__ rho,
+                                                     const uint32_t* __restrict__ occ_sub, R* __restrict__ rho,
                                                      uint32_t* __restrict__ nb_count, const unsigned long long* __restrict__ nb_ptr,
                                                      uint32_t* __restrict__ nb_idx) {
     uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
@@ -297,15 +312,15 @@ __global__ __launch_bounds__(256) void k_density_sub(SSDev P, uint32_t n_copies,
     const int sz = (int)(flat % (uint32_t)P.ns[2]);
     const int sy = (int)((flat / (uint32_t)P.ns[2]) % (uint32_t)P.ns[1]);
     const int sx = (int)(flat / ((uint32_t)P.ns[2] * (uint32_t)P.ns[1]));
-    const float4 pi = cpos[p];
+    const ss_real4<R> pi = cpos[p];
     // is_inside: half-open AABB of the subdomain (dense_subdomains.rs:567-576, aabb.rs:220-222)
     {
         const int s3[3] = {sx, sy, sz};
-        const float x3[3] = {pi.x, pi.y, pi.z};
+        const R x3[3] = {pi.x, pi.y, pi.z};
 #pragma unroll
         for (int d = 0; d < 3; ++d) {
-            const float lo = P.gmin[d] + (float)s3[d] * P.sub_size;
-            const float hi = P.gmin[d] + (float)(s3[d] + 1) * P.sub_size;
+            const R lo = P.gmin[d] + (R)s3[d] * P.sub_size;
+            const R hi = P.gmin[d] + (R)(s3[d] + 1) * P.sub_size;
             if (!(x3[d] >= lo && x3[d] < hi)) return;  // ghost copy: density computed by another subdomain
         }
     }
@@ -313,7 +328,7 @@ __global__ __launch_bounds__(256) void k_density_sub(SSDev P, uint32_t n_copies,
     const int cy = (int)((cell / (uint32_t)P.sc[2]) % (uint32_t)P.sc[1]);
     const int cx = (int)(cell / ((uint32_t)P.sc[2] * (uint32_t)P.sc[1]));
     const uint32_t base = occ * ctot;
-    float acc = P.w0;  // density_map.rs:173
+    R acc = P.w0;  // density_map.rs:173
     uint32_t nn = 0;
     unsigned long long wr = (MODE == 2) ? nb_ptr[cidx[p]] : 0ull;
     // The 27 cells in the reference's order (step (x,y,z) lexicographic, own cell last) are 11 runs of
@@ -354,14 +369,14 @@ __global__ __launch_bounds__(256) void k_density_sub(SSDev P, uint32_t n_copies,
 #pragma unroll
     for (int run = 0; run < 11; ++run) {
         for (uint32_t q = rb[run]; q < re[run]; ++q) {
-            const float4 pj = cpos[q];
-            const float dx = pj.x - pi.x, dy = pj.y - pi.y, dz = pj.z - pi.z;
-            const float d2 = dx * dx + dy * dy + dz * dz;
+            const ss_real4<R> pj = cpos[q];
+            const R dx = pj.x - pi.x, dy = pj.y - pi.y, dz = pj.z - pi.z;
+            const R d2 = dx * dx + dy * dy + dz * dz;
             if (q != p && d2 < P.h2) {  // neighborhood_search.rs:431
                 if (MODE == 2) {
                     nb_idx[wr++] = cidx[q];
                 } else {
-                    const float r = sqrtf(d2);
+                    const R r = ss_sqrt(d2);
                     acc += ss_kernel_evaluate(r, P.h, P.sigma);  // density_map.rs:179-180
                     ++nn;
                 }
@@ -373,49 +388,55 @@ __global__ __launch_bounds__(256) void k_density_sub(SSDev P, uint32_t n_copies,
 }
 
 // (x, y, z, V = m / rho) in global-cell order for the splat (v_i of dense_subdomains.rs:832)
-__global__ __launch_bounds__(256) void k_make_posvol(SSDev P, const float4* __restrict__ pos_sorted, const uint32_t* __restrict__ perm,
-                                                     const float* __restrict__ rho, float4* __restrict__ posvol) {
+template <class R>
+__global__ __launch_bounds__(256) void k_make_posvol(SSDevT<R> P, const ss_real4<R>* __restrict__ pos_sorted, const uint32_t* __restrict__ perm,
+                                                     const R* __restrict__ rho, ss_real4<R>* __restrict__ posvol) {
     uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= P.n) return;
-    const float4 a = pos_sorted[p];
-    posvol[p] = make_float4(a.x, a.y, a.z, P.mass / rho[perm[p]]);
+    const ss_real4<R> a = pos_sorted[p];
+    posvol[p] = ss_make4(a.x, a.y, a.z, P.mass / rho[perm[p]]);
 }
 
-void ss_launch_classify_count(const SSDev& P, const float* xyz, uint32_t* member_count, uint32_t* sub_flag, hipStream_t st) {
+template <class R>
+void ss_launch_classify_count(const SSDevT<R>& P, const R* xyz, uint32_t* member_count, uint32_t* sub_flag, hipStream_t st) {
     if (!P.n) return;
-    hipLaunchKernelGGL(k_classify_count, dim3((P.n + 255) / 256), dim3(256), 0, st, P, xyz, member_count, sub_flag);
+    hipLaunchKernelGGL(k_classify_count<R>, dim3((P.n + 255) / 256), dim3(256), 0, st, P, xyz, member_count, sub_flag);
 }
 void ss_launch_occupied_list(const uint32_t* flag, const uint32_t* rank, uint32_t n, uint32_t* occ_sub, hipStream_t st) {
     if (!n) return;
     hipLaunchKernelGGL(k_occupied_list, dim3((n + 255) / 256), dim3(256), 0, st, flag, rank, n, occ_sub);
 }
-void ss_launch_emit_copies(const SSDev& P, const float* xyz, const uint32_t* copy_offset, const uint32_t* occ_rank, uint32_t* keys, uint32_t* vals,
+template <class R>
+void ss_launch_emit_copies(const SSDevT<R>& P, const R* xyz, const uint32_t* copy_offset, const uint32_t* occ_rank, uint32_t* keys, uint32_t* vals,
                            uint32_t* cell_count, hipStream_t st) {
     if (!P.n) return;
-    hipLaunchKernelGGL(k_emit_copies, dim3((P.n + 255) / 256), dim3(256), 0, st, P, xyz, copy_offset, occ_rank, keys, vals, cell_count);
+    hipLaunchKernelGGL(k_emit_copies<R>, dim3((P.n + 255) / 256), dim3(256), 0, st, P, xyz, copy_offset, occ_rank, keys, vals, cell_count);
 }
-void ss_launch_density_sub(const SSDev& P, uint32_t n_copies, const float4* cpos, const uint32_t* cidx, const uint32_t* ckey,
-                           const uint32_t* cell_start, const uint32_t* occ_sub, float* rho, int mode, uint32_t* nb_count,
+template <class R>
+void ss_launch_density_sub(const SSDevT<R>& P, uint32_t n_copies, const ss_real4<R>* cpos, const uint32_t* cidx, const uint32_t* ckey,
+                           const uint32_t* cell_start, const uint32_t* occ_sub, R* rho, int mode, uint32_t* nb_count,
                            const unsigned long long* nb_ptr, uint32_t* nb_idx, hipStream_t st) {
     if (!n_copies) return;
     const dim3 g((n_copies + 255) / 256), b(256);
     if (mode == 0)
-        hipLaunchKernelGGL(k_density_sub<0>, g, b, 0, st, P, n_copies, cpos, cidx, ckey, cell_start, occ_sub, rho, nb_count, nb_ptr, nb_idx);
+        hipLaunchKernelGGL((k_density_sub<R, 0>), g, b, 0, st, P, n_copies, cpos, cidx, ckey, cell_start, occ_sub, rho, nb_count, nb_ptr, nb_idx);
     else if (mode == 1)
-        hipLaunchKernelGGL(k_density_sub<1>, g, b, 0, st, P, n_copies, cpos, cidx, ckey, cell_start, occ_sub, rho, nb_count, nb_ptr, nb_idx);
+        hipLaunchKernelGGL((k_density_sub<R, 1>), g, b, 0, st, P, n_copies, cpos, cidx, ckey, cell_start, occ_sub, rho, nb_count, nb_ptr, nb_idx);
     else
-        hipLaunchKernelGGL(k_density_sub<2>, g, b, 0, st, P, n_copies, cpos, cidx, ckey, cell_start, occ_sub, rho, nb_count, nb_ptr, nb_idx);
+        hipLaunchKernelGGL((k_density_sub<R, 2>), g, b, 0, st, P, n_copies, cpos, cidx, ckey, cell_start, occ_sub, rho, nb_count, nb_ptr, nb_idx);
 }
-void ss_launch_make_posvol(const SSDev& P, const float4* pos_sorted, const uint32_t* perm, const float* rho, float4* posvol, hipStream_t st) {
+template <class R>
+void ss_launch_make_posvol(const SSDevT<R>& P, const ss_real4<R>* pos_sorted, const uint32_t* perm, const R* rho, ss_real4<R>* posvol, hipStream_t st) {
     if (!P.n) return;
-    hipLaunchKernelGGL(k_make_posvol, dim3((P.n + 255) / 256), dim3(256), 0, st, P, pos_sorted, perm, rho, posvol);
+    hipLaunchKernelGGL(k_make_posvol<R>, dim3((P.n + 255) / 256), dim3(256), 0, st, P, pos_sorted, perm, rho, posvol);
 }
 
 // =====================================================================================================
 // K3 prepare: which 8^3-point level-set blocks can receive a contribution?  One thread per search cell;
 // a non-empty cell marks every block whose points lie within `reach` of the cell's box.
 // =====================================================================================================
-__global__ __launch_bounds__(256) void k_mark_blocks(SSDev P, const uint32_t* __restrict__ cell_start, uint32_t ncells,
+template <class R>
+__global__ __launch_bounds__(256) void k_mark_blocks(SSDevT<R> P, const uint32_t* __restrict__ cell_start, uint32_t ncells,
                                                      uint32_t* __restrict__ block_flag) {
     uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= ncells) return;
@@ -448,7 +469,8 @@ __global__ __launch_bounds__(256) void k_mark_blocks(SSDev P, const uint32_t* __
 // MC works on blocks of cells whose origin point lies in block b; it reads the points of blocks b+{0,1}^3.
 // A block can only produce triangles if those eight level-set blocks together hold values on both
 // sides of the threshold (absent blocks are all zero); blk_minmax comes from the splat kernel.
-__global__ __launch_bounds__(256) void k_mark_mc_blocks(SSDev P, const uint32_t* __restrict__ block_slot, const float2* __restrict__ blk_minmax,
+template <class R>
+__global__ __launch_bounds__(256) void k_mark_mc_blocks(SSDevT<R> P, const uint32_t* __restrict__ block_slot, const ss_real2<R>* __restrict__ blk_minmax,
                                                         uint32_t nblocks, uint32_t* __restrict__ mc_flag) {
     uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= nblocks) return;
@@ -464,11 +486,11 @@ __global__ __launch_bounds__(256) void k_mark_mc_blocks(SSDev P, const uint32_t*
         for (int dy = 0; dy <= 1; ++dy)
             for (int dz = 0; dz <= 1; ++dz) {
                 int x = bx + dx, y = by + dy, z = bz + dz;
-                float mn = 0.0f, mx = 0.0f;
+                R mn = R(0.0), mx = R(0.0);
                 if (x < P.nb[0] && y < P.nb[1] && z < P.nb[2]) {
                     const uint32_t slot = block_slot[((size_t)x * P.nb[1] + y) * P.nb[2] + z];
                     if (slot != 0xFFFFFFFFu) {
-                        const float2 mm = blk_minmax[slot];
+                        const ss_real2<R> mm = blk_minmax[slot];
                         mn = mm.x;
                         mx = mm.y;
                     }
@@ -492,14 +514,16 @@ __global__ __launch_bounds__(256) void k_compact_blocks(const uint32_t* __restri
     }
 }
 
-void ss_launch_mark_blocks(const SSDev& P, const uint32_t* cell_start, uint32_t ncells, uint32_t* block_flag, hipStream_t st) {
+template <class R>
+void ss_launch_mark_blocks(const SSDevT<R>& P, const uint32_t* cell_start, uint32_t ncells, uint32_t* block_flag, hipStream_t st) {
     if (!ncells) return;
-    hipLaunchKernelGGL(k_mark_blocks, dim3((ncells + 255) / 256), dim3(256), 0, st, P, cell_start, ncells, block_flag);
+    hipLaunchKernelGGL(k_mark_blocks<R>, dim3((ncells + 255) / 256), dim3(256), 0, st, P, cell_start, ncells, block_flag);
 }
-void ss_launch_mark_mc_blocks(const SSDev& P, const uint32_t* block_slot, const float2* blk_minmax, uint32_t nblocks, uint32_t* mc_flag,
+template <class R>
+void ss_launch_mark_mc_blocks(const SSDevT<R>& P, const uint32_t* block_slot, const ss_real2<R>* blk_minmax, uint32_t nblocks, uint32_t* mc_flag,
                               hipStream_t st) {
     if (!nblocks) return;
-    hipLaunchKernelGGL(k_mark_mc_blocks, dim3((nblocks + 255) / 256), dim3(256), 0, st, P, block_slot, blk_minmax, nblocks, mc_flag);
+    hipLaunchKernelGGL(k_mark_mc_blocks<R>, dim3((nblocks + 255) / 256), dim3(256), 0, st, P, block_slot, blk_minmax, nblocks, mc_flag);
 }
 void ss_launch_compact_blocks(const uint32_t* flag, const uint32_t* rank, uint32_t nblocks, uint32_t* list, uint32_t* slot, hipStream_t st) {
     if (!nblocks) return;
@@ -520,12 +544,12 @@ void ss_launch_compact_blocks(const uint32_t* flag, const uint32_t* rank, uint32
 //   3. accumulate: per wave, phase A tests 64 tile entries at once against the wave's sub-block box
 //      (ballot), phase B walks the surviving entries in order; every lane evaluates
 //      G += V * W(|x - p|) for its point iff d^2 < 1.01 h^2 (dense_subdomains.rs:828-841).
-// Tiles larger than SS_TILE_CAP are processed in several passes over ascending index ranges
+// Tiles larger than SSTileCap<R>::value are processed in several passes over ascending index ranges
 // (threshold found by bisection), which keeps the summation order exact for arbitrarily dense input.
 // =====================================================================================================
 // ---- exactly rounded building blocks of W(r) for the splat inner loop ---------------------------------
 // sqrt: v_sqrt_f32 is accurate to 1 ulp; one residual test against the two neighbouring floats makes it
-// correctly rounded (the sequence hipcc emits for sqrtf, minus its scaling for inputs below 2^-96, which
+// correctly rounded (the sequence hipcc emits for ss_sqrt, minus its scaling for inputs below 2^-96, which
 // the caller excludes).
 __device__ __forceinline__ float ss_sqrt_rn_normal(float x) {
     const float s = __builtin_amdgcn_sqrtf(x);
@@ -538,23 +562,26 @@ __device__ __forceinline__ float ss_sqrt_rn_normal(float x) {
     return r;
 }
 
-template <bool FAST>
-__device__ __forceinline__ float ss_div_by_h(float x, float h, float rh) {
-    if (FAST) {
+template <class R, bool FAST>
+__device__ __forceinline__ R ss_div_by_h(R x, R h, R rh) {
+    if constexpr (FAST) {
+        static_assert(sizeof(R) == 4, "the verified reciprocal division exists for f32 only");
         const float q0 = x * rh;
         const float e = __builtin_fmaf(-q0, h, x);
         return __builtin_fmaf(e, rh, q0);
+    } else {
+        return x / h;
     }
-    return x / h;
 }
 
 // kernel.rs:71-81 without branches (both polynomial pieces, then select); same association order
-__device__ __forceinline__ float ss_cubic_function_sel(float q) {
-    const float pi = 3.14159265358979323846f;
-    const float fa = (3.0f / (2.0f * pi)) * ((2.0f / 3.0f) - q * q + 0.5f * q * q * q);
-    const float x = 2.0f - q;
-    const float fb = (1.0f / (4.0f * pi)) * x * x * x;
-    return (q < 1.0f) ? fa : ((q < 2.0f) ? fb : 0.0f);
+template <class R>
+__device__ __forceinline__ R ss_cubic_function_sel(R q) {
+    const R pi = R(3.14159265358979323846);
+    const R fa = (R(3.0) / (R(2.0) * pi)) * ((R(2.0) / R(3.0)) - q * q + R(0.5) * q * q * q);
+    const R x = R(2.0) - q;
+    const R fb = (R(1.0) / (R(4.0) * pi)) * x * x * x;
+    return (q < R(1.0)) ? fa : ((q < R(2.0)) ? fb : R(0.0));
 }
 
 // W(sqrt(d2)) exactly as kernel.rs:103-106 evaluates it.
@@ -563,11 +590,15 @@ __device__ __forceinline__ float ss_cubic_function_sel(float q) {
 // only place where v_sqrt_f32 could see a denormal or the division's residual could underflow -- the
 // value of q is irrelevant: any q < 2^-13 makes 2/3 - q*q round to 2/3 and 0.5*q^3 vanish, i.e. W == W(0)
 // bit for bit, and every path yields such a q there (r is never over-estimated).
-template <bool FAST>
-__device__ __forceinline__ float ss_kernel_w(float d2, float h, float rh, float sigma) {
-    const float r = FAST ? ss_sqrt_rn_normal(d2) : sqrtf(d2);  // generic variant: hipcc's fully guarded sqrt
-    const float q = ss_div_by_h<FAST>(r + r, h, rh);
-    return sigma * ss_cubic_function_sel(q);
+template <class R, bool FAST>
+__device__ __forceinline__ R ss_kernel_w(R d2, R h, R rh, R sigma) {
+    R r;
+    if constexpr (FAST)
+        r = ss_sqrt_rn_normal(d2);
+    else
+        r = ss_sqrt(d2);  // generic variant: hipcc's fully guarded, correctly rounded sqrt
+    const R q = ss_div_by_h<R, FAST>(r + r, h, rh);
+    return sigma * ss_cubic_function_sel<R>(q);
 }
 
 __global__ __launch_bounds__(256) void k_verify_fast_div(float h, float rh, uint32_t* __restrict__ bad) {
@@ -575,7 +606,7 @@ __global__ __launch_bounds__(256) void k_verify_fast_div(float h, float rh, uint
     const uint32_t m = blockIdx.x * blockDim.x + threadIdx.x;  // 0 .. 2^23-1
     const uint32_t ebits = __float_as_uint(h) & 0x7F800000u;
     const float x = __uint_as_float(ebits | m);
-    const float q_fast = ss_div_by_h<true>(x, h, rh);
+    const float q_fast = ss_div_by_h<float, true>(x, h, rh);
     const float q_ref = x / h;
     if (__float_as_uint(q_fast) != __float_as_uint(q_ref)) atomicAdd(bad, 1u);
 }
@@ -584,10 +615,11 @@ void ss_launch_verify_fast_div(float h, float rh, uint32_t* bad, hipStream_t st)
     hipLaunchKernelGGL(k_verify_fast_div, dim3((1u << 23) / 256), dim3(256), 0, st, h, rh, bad);
 }
 
+template <class R>
 struct SplatShared {
-    float4 pay[SS_TILE_CAP];
-    uint32_t idx[SS_TILE_CAP];
-    uint32_t src[SS_TILE_CAP];
+    ss_real4<R> pay[SSTileCap<R>::value];
+    uint32_t idx[SSTileCap<R>::value];
+    uint32_t src[SSTileCap<R>::value];
     uint32_t row_start[SS_MAX_ROWS];
     uint32_t row_prefix[SS_MAX_ROWS + 1];
     uint32_t wave_tot[8];
@@ -595,7 +627,8 @@ struct SplatShared {
 };
 
 // exclusive prefix over s.row_prefix[0..nbatch) (lengths in, prefix out), total in row_prefix[nbatch]
-__device__ inline void splat_row_prefix(SplatShared& s, int nbatch, uint32_t len, int tid) {
+template <class R>
+__device__ inline void splat_row_prefix(SplatShared<R>& s, int nbatch, uint32_t len, int tid) {
     // tid < 256 participate (4 waves); len is this thread's row length (0 beyond nbatch)
     const int lane = tid & 63, wave = tid >> 6;
     uint32_t v = len;
@@ -619,10 +652,10 @@ __device__ inline void splat_row_prefix(SplatShared& s, int nbatch, uint32_t len
 
 // Visit every particle of the search cells overlapping the dilated block box; f(src_position, idx) is
 // called for particles inside the box.  All 512 threads must call this (contains barriers).
-template <class F>
-__device__ inline void splat_for_each_candidate(SplatShared& s, const SSDev& P, const float4* __restrict__ posvol,
+template <class R, class F>
+__device__ inline void splat_for_each_candidate(SplatShared<R>& s, const SSDevT<R>& P, const ss_real4<R>* __restrict__ posvol,
                                                 const uint32_t* __restrict__ perm, const uint32_t* __restrict__ cell_start,
-                                                const int klo[3], const int khi[3], const float blo[3], const float bhi[3], int tid, F f) {
+                                                const int klo[3], const int khi[3], const R blo[3], const R bhi[3], int tid, F f) {
     const int ny = khi[1] - klo[1] + 1;
     const int nrows = (khi[0] - klo[0] + 1) * ny;
     for (int row_base = 0; row_base < nrows; row_base += SS_MAX_ROWS) {
@@ -651,19 +684,19 @@ __device__ inline void splat_for_each_candidate(SplatShared& s, const SSDev& P, 
                     hi = mid - 1;
             }
             const uint32_t src = s.row_start[lo] + (q - s.row_prefix[lo]);
-            const float4 pv = posvol[src];
+            const ss_real4<R> pv = posvol[src];
             if (pv.x >= blo[0] && pv.x <= bhi[0] && pv.y >= blo[1] && pv.y <= bhi[1] && pv.z >= blo[2] && pv.z <= bhi[2]) f(src, perm[src]);
         }
         __syncthreads();
     }
 }
 
-template <bool FASTDIV>
-__global__ __launch_bounds__(512) void k_splat(SSDev P, const float4* __restrict__ posvol, const uint32_t* __restrict__ perm,
+template <class R, bool FASTDIV>
+__global__ __launch_bounds__(512) void k_splat(SSDevT<R> P, const ss_real4<R>* __restrict__ posvol, const uint32_t* __restrict__ perm,
                                                const uint32_t* __restrict__ cell_start, const uint32_t* __restrict__ active_list,
-                                               uint32_t n_active, float* __restrict__ G, float2* __restrict__ blk_minmax,
+                                               uint32_t n_active, R* __restrict__ G, ss_real2<R>* __restrict__ blk_minmax,
                                                unsigned long long* __restrict__ cand_counter) {
-    __shared__ SplatShared s;
+    __shared__ SplatShared<R> s;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 
     // XCD-aware mapping: hardware places workgroup w on XCD w % 8; give each XCD a contiguous range of
@@ -678,15 +711,15 @@ __global__ __launch_bounds__(512) void k_splat(SSDev P, const float4* __restrict
     const int b3[3] = {bx, by, bz};
 
     // dilated block box and the search cells overlapping it
-    float blo[3], bhi[3];
+    R blo[3], bhi[3];
     int klo[3], khi[3];
 #pragma unroll
     for (int d = 0; d < 3; ++d) {
         const int i0 = b3[d] * SS_BLOCK;
         const int i1 = min(i0 + SS_BLOCK - 1, P.np[d] - 1);
-        const float pad = P.reach + P.coord_slack;
-        blo[d] = (P.gmin[d] + (float)i0 * P.cs) - pad;
-        bhi[d] = (P.gmin[d] + (float)i1 * P.cs) + pad;
+        const R pad = P.reach + P.coord_slack;
+        blo[d] = (P.gmin[d] + (R)i0 * P.cs) - pad;
+        bhi[d] = (P.gmin[d] + (R)i1 * P.cs) + pad;
         const double cellpad = 1e-3 * (double)P.h;
         int a = (int)floor(((double)blo[d] - cellpad) / (double)P.h);
         int e = (int)floor(((double)bhi[d] + cellpad) / (double)P.h);
@@ -700,18 +733,18 @@ __global__ __launch_bounds__(512) void k_splat(SSDev P, const float4* __restrict
     const int gl[3] = {g0[0] + ((lane >> 4) & 3), g0[1] + ((lane >> 2) & 3), g0[2] + (lane & 3)};
     const bool wave_valid = g0[0] < P.np[0] && g0[1] < P.np[1] && g0[2] < P.np[2];
     // global point coordinates: uniform_grid.rs:418-425 on the GLOBAL grid (dense_subdomains.rs:817-826)
-    const float px = P.gmin[0] + (float)gl[0] * P.cs;
-    const float py = P.gmin[1] + (float)gl[1] * P.cs;
-    const float pz = P.gmin[2] + (float)gl[2] * P.cs;
-    float slo[3], shi[3];
+    const R px = P.gmin[0] + (R)gl[0] * P.cs;
+    const R py = P.gmin[1] + (R)gl[1] * P.cs;
+    const R pz = P.gmin[2] + (R)gl[2] * P.cs;
+    R slo[3], shi[3];
 #pragma unroll
     for (int d = 0; d < 3; ++d) {
-        slo[d] = P.gmin[d] + (float)g0[d] * P.cs;
-        shi[d] = P.gmin[d] + (float)min(g0[d] + 3, P.np[d] - 1) * P.cs;
+        slo[d] = P.gmin[d] + (R)g0[d] * P.cs;
+        shi[d] = P.gmin[d] + (R)min(g0[d] + 3, P.np[d] - 1) * P.cs;
     }
-    const float wave_r2 = P.H2 * 1.0001f;
+    const R wave_r2 = P.H2 * R(1.0001);
 
-    float acc = 0.0f;  // levelset_grid.fill(0), dense_subdomains.rs:1390
+    R acc = R(0.0);  // levelset_grid.fill(0), dense_subdomains.rs:1390
     long long last = -1;  // particles with original index <= last are already accumulated
     const long long idx_max = (long long)P.n - 1;
 
@@ -722,7 +755,7 @@ __global__ __launch_bounds__(512) void k_splat(SSDev P, const float4* __restrict
         splat_for_each_candidate(s, P, posvol, perm, cell_start, klo, khi, blo, bhi, tid, [&](uint32_t src, uint32_t idx) {
             if ((long long)idx > last) {
                 uint32_t pos = atomicAdd(&s.count, 1u);
-                if (pos < SS_TILE_CAP) {
+                if (pos < SSTileCap<R>::value) {
                     s.idx[pos] = idx;
                     s.src[pos] = src;
                 }
@@ -730,10 +763,10 @@ __global__ __launch_bounds__(512) void k_splat(SSDev P, const float4* __restrict
         });
         uint32_t total = s.count;
         if (total == 0) break;
-        if (total > SS_TILE_CAP) {
+        if (total > SSTileCap<R>::value) {
             // more candidates than LDS slots: find the largest threshold T with
-            // #{last < idx <= T} <= SS_TILE_CAP by bisection (count is monotone in T and grows by
-            // at most one per step, so the bracket closes on exactly SS_TILE_CAP entries)
+            // #{last < idx <= T} <= SSTileCap<R>::value by bisection (count is monotone in T and grows by
+            // at most one per step, so the bracket closes on exactly SSTileCap<R>::value entries)
             long long lo = last, hi = idx_max;
             while (hi - lo > 1) {
                 const long long mid = lo + (hi - lo) / 2;
@@ -744,7 +777,7 @@ __global__ __launch_bounds__(512) void k_splat(SSDev P, const float4* __restrict
                     if ((long long)idx > last && (long long)idx <= mid) atomicAdd(&s.count, 1u);
                 });
                 const uint32_t c = s.count;
-                if (c <= SS_TILE_CAP)
+                if (c <= SSTileCap<R>::value)
                     lo = mid;
                 else
                     hi = mid;
@@ -756,7 +789,7 @@ __global__ __launch_bounds__(512) void k_splat(SSDev P, const float4* __restrict
             splat_for_each_candidate(s, P, posvol, perm, cell_start, klo, khi, blo, bhi, tid, [&](uint32_t src, uint32_t idx) {
                 if ((long long)idx > last && (long long)idx <= T) {
                     uint32_t pos = atomicAdd(&s.count, 1u);
-                    if (pos < SS_TILE_CAP) {
+                    if (pos < SSTileCap<R>::value) {
                         s.idx[pos] = idx;
                         s.src[pos] = src;
                     }
@@ -764,7 +797,7 @@ __global__ __launch_bounds__(512) void k_splat(SSDev P, const float4* __restrict
             });
             total = s.count;
         }
-        const int n_tile = (int)min(total, (uint32_t)SS_TILE_CAP);
+        const int n_tile = (int)min(total, (uint32_t)SSTileCap<R>::value);
         if (tid == 0) atomicAdd(cand_counter, (unsigned long long)n_tile);
 
         // ---- order the tile by original particle index, load payload in that order ----
@@ -814,16 +847,16 @@ __global__ __launch_bounds__(512) void k_splat(SSDev P, const float4* __restrict
         // instruction, fma ~3.5, cmp/cndmask/readlane ~3.7, SGPR-source operands ~3.9, v_pk_* ~6.2,
         // v_sqrt/v_rcp ~7.4 -- hence LDS broadcast reads (not v_readlane) and no packed math in this loop.
         if (wave_valid) {
-            const float rh = 1.0f / P.h;
+            const R rh = R(1.0) / P.h;
             for (int base = 0; base < n_tile; base += 64) {
                 const int c = base + lane;
                 bool pass = false;
-                float4 pv = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                ss_real4<R> pv = ss_make4(R(0.0), R(0.0), R(0.0), R(0.0));
                 if (c < n_tile) {
                     pv = s.pay[c];
-                    const float ex = fmaxf(fmaxf(slo[0] - pv.x, pv.x - shi[0]) - P.coord_slack, 0.0f);
-                    const float ey = fmaxf(fmaxf(slo[1] - pv.y, pv.y - shi[1]) - P.coord_slack, 0.0f);
-                    const float ez = fmaxf(fmaxf(slo[2] - pv.z, pv.z - shi[2]) - P.coord_slack, 0.0f);
+                    const R ex = ss_max(ss_max(slo[0] - pv.x, pv.x - shi[0]) - P.coord_slack, R(0.0));
+                    const R ey = ss_max(ss_max(slo[1] - pv.y, pv.y - shi[1]) - P.coord_slack, R(0.0));
+                    const R ez = ss_max(ss_max(slo[2] - pv.z, pv.z - shi[2]) - P.coord_slack, R(0.0));
                     pass = (ex * ex + ey * ey + ez * ez) <= wave_r2;
                 }
                 unsigned long long wmask = __ballot(pass);
@@ -831,15 +864,15 @@ __global__ __launch_bounds__(512) void k_splat(SSDev P, const float4* __restrict
                     // Entries are fetched with a wave-uniform LDS read (broadcast: LDS pipe, no VALU issue slot,
                     // operands arrive in VGPRs) one iteration ahead of their use.
                     int bit = __ffsll((long long)wmask) - 1;
-                    float4 cur = s.pay[base + bit];
+                    ss_real4<R> cur = s.pay[base + bit];
                     while (true) {
                         wmask &= wmask - 1;
                         const int nbit = wmask ? (__ffsll((long long)wmask) - 1) : bit;
-                        const float4 nxt = s.pay[base + nbit];
-                        const float dx = cur.x - px, dy = cur.y - py, dz = cur.z - pz;  // p_i - point, :828
-                        const float d2 = dx * dx + dy * dy + dz * dz;
+                        const ss_real4<R> nxt = s.pay[base + nbit];
+                        const R dx = cur.x - px, dy = cur.y - py, dz = cur.z - pz;  // p_i - point, :828
+                        const R d2 = dx * dx + dy * dy + dz * dz;
                         if (d2 < P.H2) {  // :831
-                            acc += cur.w * ss_kernel_w<FASTDIV>(d2, P.h, rh, P.sigma);  // :832-841
+                            acc += cur.w * ss_kernel_w<R, FASTDIV>(d2, P.h, rh, P.sigma);  // :832-841
                         }
                         if (!wmask) break;
                         cur = nxt;
@@ -858,18 +891,18 @@ __global__ __launch_bounds__(512) void k_splat(SSDev P, const float4* __restrict
     const int ly = ((wave >> 1) & 1) * 4 + ((lane >> 2) & 3);
     const int lz = (wave & 1) * 4 + (lane & 3);
     const bool point_valid = gl[0] < P.np[0] && gl[1] < P.np[1] && gl[2] < P.np[2];
-    const float val = point_valid ? acc : 0.0f;
+    const R val = point_valid ? acc : R(0.0);
     G[(size_t)logical * SS_BLOCK_POINTS + (size_t)((lx * 8 + ly) * 8 + lz)] = val;
     // block-wide min/max of the level-set values (points outside the grid count as 0 = "outside"),
     // used to skip marching cubes on blocks that cannot contain the iso-surface
-    float mn = val, mx = val;
+    R mn = val, mx = val;
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
-        mn = fminf(mn, __shfl_xor(mn, off));
-        mx = fmaxf(mx, __shfl_xor(mx, off));
+        mn = ss_min(mn, __shfl_xor(mn, off));
+        mx = ss_max(mx, __shfl_xor(mx, off));
     }
     __syncthreads();
-    float* red = reinterpret_cast<float*>(s.row_start);
+    R* red = reinterpret_cast<R*>(s.row_prefix);  // 16 values, scratch no longer in use
     if (lane == 0) {
         red[wave] = mn;
         red[8 + wave] = mx;
@@ -877,23 +910,27 @@ __global__ __launch_bounds__(512) void k_splat(SSDev P, const float4* __restrict
     __syncthreads();
     if (tid == 0) {
         for (int w = 1; w < 8; ++w) {
-            mn = fminf(mn, red[w]);
-            mx = fmaxf(mx, red[8 + w]);
+            mn = ss_min(mn, red[w]);
+            mx = ss_max(mx, red[8 + w]);
         }
-        blk_minmax[logical] = make_float2(mn, mx);
+        blk_minmax[logical] = ss_make2(mn, mx);
     }
 }
 
-void ss_launch_splat(const SSDev& P, const float4* posvol, const uint32_t* perm, const uint32_t* cell_start, const uint32_t* active_list,
-                     uint32_t n_active, float* G, float2* blk_minmax, unsigned long long* cand_counter, bool fast_div, hipStream_t st) {
+template <class R>
+void ss_launch_splat(const SSDevT<R>& P, const ss_real4<R>* posvol, const uint32_t* perm, const uint32_t* cell_start, const uint32_t* active_list,
+                     uint32_t n_active, R* G, ss_real2<R>* blk_minmax, unsigned long long* cand_counter, bool fast_div, hipStream_t st) {
     if (!n_active) return;
     const uint32_t per_xcd = (n_active + 7u) / 8u;
-    if (fast_div)
-        hipLaunchKernelGGL(k_splat<true>, dim3(per_xcd * 8u), dim3(512), 0, st, P, posvol, perm, cell_start, active_list, n_active, G, blk_minmax,
-                           cand_counter);
-    else
-        hipLaunchKernelGGL(k_splat<false>, dim3(per_xcd * 8u), dim3(512), 0, st, P, posvol, perm, cell_start, active_list, n_active, G, blk_minmax,
-                           cand_counter);
+    if constexpr (sizeof(R) == 4) {
+        if (fast_div) {
+            hipLaunchKernelGGL((k_splat<R, true>), dim3(per_xcd * 8u), dim3(512), 0, st, P, posvol, perm, cell_start, active_list, n_active, G,
+                               blk_minmax, cand_counter);
+            return;
+        }
+    }
+    hipLaunchKernelGGL((k_splat<R, false>), dim3(per_xcd * 8u), dim3(512), 0, st, P, posvol, perm, cell_start, active_list, n_active, G, blk_minmax,
+                       cand_counter);
 }
 
 // =====================================================================================================
@@ -904,16 +941,18 @@ void ss_launch_splat(const SSDev& P, const float4* posvol, const uint32_t* perm,
 // are stored so that neighbouring blocks can compute vertex ids of shared edges without a hash map:
 //   id(point p, axis a) = vbase[block] + #crossings of axes < a + popcount(mask_a below p).
 // =====================================================================================================
+template <class R>
 struct McTile {
-    float g[9 * 9 * 9];
+    R g[9 * 9 * 9];
 };
 
-__device__ inline void mc_load_tile(McTile& t, const SSDev& P, const float* __restrict__ G, const uint32_t* __restrict__ block_slot, int bx,
+template <class R>
+__device__ inline void mc_load_tile(McTile<R>& t, const SSDevT<R>& P, const R* __restrict__ G, const uint32_t* __restrict__ block_slot, int bx,
                                     int by, int bz, int tid) {
     for (int e = tid; e < 729; e += 512) {
         const int x = e / 81, y = (e / 9) % 9, z = e % 9;
         const int nbx = bx + (x >> 3), nby = by + (y >> 3), nbz = bz + (z >> 3);
-        float v = 0.0f;
+        R v = R(0.0);
         if (nbx < P.nb[0] && nby < P.nb[1] && nbz < P.nb[2]) {
             const uint32_t slot = block_slot[((size_t)nbx * P.nb[1] + nby) * P.nb[2] + nbz];
             if (slot != 0xFFFFFFFFu) v = G[(size_t)slot * SS_BLOCK_POINTS + (size_t)((((x & 7) * 8) + (y & 7)) * 8 + (z & 7))];
@@ -930,7 +969,8 @@ struct McLocal {
     int ntri;
 };
 
-__device__ inline McLocal mc_classify(const McTile& t, const SSDev& P, int bx, int by, int bz, int tid) {
+template <class R>
+__device__ inline McLocal mc_classify(const McTile<R>& t, const SSDevT<R>& P, int bx, int by, int bz, int tid) {
     McLocal L;
     const int lx = tid >> 6, ly = (tid >> 3) & 7, lz = tid & 7;
     L.gx = bx * SS_BLOCK + lx;
@@ -938,7 +978,7 @@ __device__ inline McLocal mc_classify(const McTile& t, const SSDev& P, int bx, i
     L.gz = bz * SS_BLOCK + lz;
     // points / edges / cells of the shard region only (full domain: pt_hi = np - 1)
     const bool point_exists = L.gx <= P.pt_hi[0] && L.gy <= P.pt_hi[1] && L.gz <= P.pt_hi[2];
-    const float thr = P.threshold;
+    const R thr = P.threshold;
     const bool in0 = t.g[(lx * 9 + ly) * 9 + lz] > thr;  // dense_subdomains.rs:1482 (strict >)
     L.cross[0] = point_exists && (L.gx + 1 <= P.pt_hi[0]) && (in0 != (t.g[((lx + 1) * 9 + ly) * 9 + lz] > thr));
     L.cross[1] = point_exists && (L.gy + 1 <= P.pt_hi[1]) && (in0 != (t.g[(lx * 9 + ly + 1) * 9 + lz] > thr));
@@ -948,7 +988,7 @@ __device__ inline McLocal mc_classify(const McTile& t, const SSDev& P, int bx, i
     if (cell_exists) {
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
-            const float v = t.g[((lx + c_corner[c][0]) * 9 + ly + c_corner[c][1]) * 9 + lz + c_corner[c][2]];
+            const R v = t.g[((lx + c_corner[c][0]) * 9 + ly + c_corner[c][1]) * 9 + lz + c_corner[c][2]];
             L.case_index |= (v > thr ? 1 : 0) << c;  // marching_cubes_lut.rs:322-329
         }
     }
@@ -959,10 +999,11 @@ __device__ inline McLocal mc_classify(const McTile& t, const SSDev& P, int bx, i
     return L;
 }
 
-__global__ __launch_bounds__(512) void k_mc_count(SSDev P, const float* __restrict__ G, const uint32_t* __restrict__ block_slot,
+template <class R>
+__global__ __launch_bounds__(512) void k_mc_count(SSDevT<R> P, const R* __restrict__ G, const uint32_t* __restrict__ block_slot,
                                                   const uint32_t* __restrict__ mc_list, uint32_t n_mc, unsigned long long* __restrict__ masks,
                                                   uint32_t* __restrict__ vcount, uint32_t* __restrict__ tcount) {
-    __shared__ McTile tile;
+    __shared__ McTile<R> tile;
     __shared__ uint32_t s_v[8], s_t[8];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t m = blockIdx.x;
@@ -1001,12 +1042,13 @@ __global__ __launch_bounds__(512) void k_mc_count(SSDev P, const float* __restri
     }
 }
 
-__global__ __launch_bounds__(512) void k_mc_emit(SSDev P, const float* __restrict__ G, const uint32_t* __restrict__ block_slot,
+template <class R>
+__global__ __launch_bounds__(512) void k_mc_emit(SSDevT<R> P, const R* __restrict__ G, const uint32_t* __restrict__ block_slot,
                                                  const uint32_t* __restrict__ mc_list, const uint32_t* __restrict__ mc_slot, uint32_t n_mc,
                                                  const unsigned long long* __restrict__ masks, const uint32_t* __restrict__ vbase,
-                                                 const uint32_t* __restrict__ tbase, float* __restrict__ vertices,
+                                                 const uint32_t* __restrict__ tbase, R* __restrict__ vertices,
                                                  unsigned long long* __restrict__ vkeys, uint32_t* __restrict__ triangles) {
-    __shared__ McTile tile;
+    __shared__ McTile<R> tile;
     __shared__ unsigned long long s_mask[8][24];  // [neighbour][axis*8+word]
     __shared__ uint32_t s_pref[8][24];            // vertices of that neighbour block before (axis, word)
     __shared__ uint32_t s_vbase[8];
@@ -1052,10 +1094,10 @@ __global__ __launch_bounds__(512) void k_mc_emit(SSDev P, const float* __restric
         if (!L.cross[a]) continue;
         const uint32_t vid = s_vbase[0] + s_pref[0][a * 8 + wave] + (uint32_t)__popcll(s_mask[0][a * 8 + wave] & below);
         const int tl[3] = {lx + (a == 0), ly + (a == 1), lz + (a == 2)};
-        const float ov = tile.g[(lx * 9 + ly) * 9 + lz];
-        const float tv = tile.g[(tl[0] * 9 + tl[1]) * 9 + tl[2]];
-        const float alpha = (P.threshold - ov) / (tv - ov);  // :1516-1517
-        float vc[3];
+        const R ov = tile.g[(lx * 9 + ly) * 9 + lz];
+        const R tv = tile.g[(tl[0] * 9 + tl[1]) * 9 + tl[2]];
+        const R alpha = (P.threshold - ov) / (tv - ov);  // :1516-1517
+        R vc[3];
 #pragma unroll
         for (int d = 0; d < 3; ++d) {
             // coordinates in the marching-cubes grid of the lowest-index subdomain that generates this
@@ -1067,10 +1109,10 @@ __global__ __launch_bounds__(512) void k_mc_emit(SSDev P, const float* __restric
             else
                 sd = (O[d] >= 1) ? (O[d] - 1) / n : 0;
             const int loc = O[d] - sd * n;
-            const float sub_min = P.gmin[d] + (float)sd * P.sub_size;  // uniform_grid.rs:454-467 on the subdomain grid
-            const float oc = sub_min + (float)loc * P.cs;               // uniform_grid.rs:418-425 on the subdomain MC grid
-            const float tc = sub_min + (float)(loc + (d == a ? 1 : 0)) * P.cs;
-            vc[d] = oc * (1.0f - alpha) + tc * alpha;  // :1518-1519
+            const R sub_min = P.gmin[d] + (R)sd * P.sub_size;  // uniform_grid.rs:454-467 on the subdomain grid
+            const R oc = sub_min + (R)loc * P.cs;               // uniform_grid.rs:418-425 on the subdomain MC grid
+            const R tc = sub_min + (R)(loc + (d == a ? 1 : 0)) * P.cs;
+            vc[d] = oc * (R(1.0) - alpha) + tc * alpha;  // :1518-1519
         }
         vertices[3 * (size_t)vid] = vc[0];
         vertices[3 * (size_t)vid + 1] = vc[1];
@@ -1110,16 +1152,18 @@ __global__ __launch_bounds__(512) void k_mc_emit(SSDev P, const float* __restric
     }
 }
 
-void ss_launch_mc_count(const SSDev& P, const float* G, const uint32_t* block_slot, const uint32_t* mc_list, uint32_t n_mc,
+template <class R>
+void ss_launch_mc_count(const SSDevT<R>& P, const R* G, const uint32_t* block_slot, const uint32_t* mc_list, uint32_t n_mc,
                         unsigned long long* masks, uint32_t* vcount, uint32_t* tcount, hipStream_t st) {
     if (!n_mc) return;
-    hipLaunchKernelGGL(k_mc_count, dim3(n_mc), dim3(512), 0, st, P, G, block_slot, mc_list, n_mc, masks, vcount, tcount);
+    hipLaunchKernelGGL(k_mc_count<R>, dim3(n_mc), dim3(512), 0, st, P, G, block_slot, mc_list, n_mc, masks, vcount, tcount);
 }
-void ss_launch_mc_emit(const SSDev& P, const float* G, const uint32_t* block_slot, const uint32_t* mc_list, const uint32_t* mc_slot,
-                       uint32_t n_mc, const unsigned long long* masks, const uint32_t* vbase, const uint32_t* tbase, float* vertices,
+template <class R>
+void ss_launch_mc_emit(const SSDevT<R>& P, const R* G, const uint32_t* block_slot, const uint32_t* mc_list, const uint32_t* mc_slot,
+                       uint32_t n_mc, const unsigned long long* masks, const uint32_t* vbase, const uint32_t* tbase, R* vertices,
                        unsigned long long* vkeys, uint32_t* triangles, hipStream_t st) {
     if (!n_mc) return;
-    hipLaunchKernelGGL(k_mc_emit, dim3(n_mc), dim3(512), 0, st, P, G, block_slot, mc_list, mc_slot, n_mc, masks, vbase, tbase, vertices, vkeys,
+    hipLaunchKernelGGL(k_mc_emit<R>, dim3(n_mc), dim3(512), 0, st, P, G, block_slot, mc_list, mc_slot, n_mc, masks, vbase, tbase, vertices, vkeys,
                        triangles);
 }
 
@@ -1135,24 +1179,58 @@ void ss_launch_widen(const uint32_t* in, size_t n, unsigned long long* out, hipS
     hipLaunchKernelGGL(k_widen_u32_u64, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, in, n, out);
 }
 
-__global__ __launch_bounds__(256) void k_levelset_box(SSDev P, const float* __restrict__ G, const uint32_t* __restrict__ block_slot, int lo0,
-                                                      int lo1, int lo2, int e0, int e1, int e2, float* __restrict__ out) {
+template <class R>
+__global__ __launch_bounds__(256) void k_levelset_box(SSDevT<R> P, const R* __restrict__ G, const uint32_t* __restrict__ block_slot, int lo0,
+                                                      int lo1, int lo2, int e0, int e1, int e2, R* __restrict__ out) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     size_t tot = (size_t)e0 * e1 * e2;
     if (i >= tot) return;
     int z = (int)(i % e2), y = (int)((i / e2) % e1), x = (int)(i / ((size_t)e2 * e1));
     int gx = lo0 + x, gy = lo1 + y, gz = lo2 + z;
-    float v = 0.0f;
+    R v = R(0.0);
     if (gx >= 0 && gy >= 0 && gz >= 0 && gx < P.np[0] && gy < P.np[1] && gz < P.np[2]) {
         uint32_t slot = block_slot[((size_t)(gx >> 3) * P.nb[1] + (gy >> 3)) * P.nb[2] + (gz >> 3)];
         if (slot != 0xFFFFFFFFu) v = G[(size_t)slot * SS_BLOCK_POINTS + (size_t)((((gx & 7) * 8) + (gy & 7)) * 8 + (gz & 7))];
     }
     out[i] = v;
 }
-void ss_launch_levelset_box(const SSDev& P, const float* G, const uint32_t* block_slot, const int lo[3], const int ext[3], float* out,
+template <class R>
+void ss_launch_levelset_box(const SSDevT<R>& P, const R* G, const uint32_t* block_slot, const int lo[3], const int ext[3], R* out,
                             hipStream_t st) {
     size_t tot = (size_t)ext[0] * ext[1] * ext[2];
     if (!tot) return;
-    hipLaunchKernelGGL(k_levelset_box, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, P, G, block_slot, lo[0], lo[1], lo[2], ext[0],
+    hipLaunchKernelGGL(k_levelset_box<R>, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, P, G, block_slot, lo[0], lo[1], lo[2], ext[0],
                        ext[1], ext[2], out);
 }
+
+// ---- explicit instantiations of the launch wrappers (f32: reconstruct_surface::<i64,f32>, f64: ::<i64,f64>) ----
+template void ss_launch_aabb<float>(const float* d_xyz, uint32_t n, float* d_partial, float* d_out6, hipStream_t st);
+template void ss_launch_aabb<double>(const double* d_xyz, uint32_t n, double* d_partial, double* d_out6, hipStream_t st);
+template void ss_launch_inside_flags<float>(const float* d_xyz, uint32_t n, const float amin[3], const float amax[3], uint8_t* f8, uint32_t* f32, hipStream_t st);
+template void ss_launch_inside_flags<double>(const double* d_xyz, uint32_t n, const double amin[3], const double amax[3], uint8_t* f8, uint32_t* f32, hipStream_t st);
+template void ss_launch_compact_xyz<float>(const float* d_xyz, uint32_t n, const uint32_t* f32, const uint32_t* offs, float* out, hipStream_t st);
+template void ss_launch_compact_xyz<double>(const double* d_xyz, uint32_t n, const uint32_t* f32, const uint32_t* offs, double* out, hipStream_t st);
+template void ss_launch_cell_keys<float>(const SSDevT<float>& P, const float* d_xyz, uint32_t* keys, uint32_t* vals, uint32_t* cell_count, hipStream_t st);
+template void ss_launch_cell_keys<double>(const SSDevT<double>& P, const double* d_xyz, uint32_t* keys, uint32_t* vals, uint32_t* cell_count, hipStream_t st);
+template void ss_launch_gather_sorted<float>(uint32_t n, const float* d_xyz, const uint32_t* perm, ss_real4<float>* pos_sorted, hipStream_t st);
+template void ss_launch_gather_sorted<double>(uint32_t n, const double* d_xyz, const uint32_t* perm, ss_real4<double>* pos_sorted, hipStream_t st);
+template void ss_launch_classify_count<float>(const SSDevT<float>& P, const float* xyz, uint32_t* member_count, uint32_t* sub_flag, hipStream_t st);
+template void ss_launch_classify_count<double>(const SSDevT<double>& P, const double* xyz, uint32_t* member_count, uint32_t* sub_flag, hipStream_t st);
+template void ss_launch_emit_copies<float>(const SSDevT<float>& P, const float* xyz, const uint32_t* copy_offset, const uint32_t* occ_rank, uint32_t* keys, uint32_t* vals, uint32_t* cell_count, hipStream_t st);
+template void ss_launch_emit_copies<double>(const SSDevT<double>& P, const double* xyz, const uint32_t* copy_offset, const uint32_t* occ_rank, uint32_t* keys, uint32_t* vals, uint32_t* cell_count, hipStream_t st);
+template void ss_launch_density_sub<float>(const SSDevT<float>& P, uint32_t n_copies, const ss_real4<float>* cpos, const uint32_t* cidx, const uint32_t* ckey, const uint32_t* cell_start, const uint32_t* occ_sub, float* rho, int mode, uint32_t* nb_count, const unsigned long long* nb_ptr, uint32_t* nb_idx, hipStream_t st);
+template void ss_launch_density_sub<double>(const SSDevT<double>& P, uint32_t n_copies, const ss_real4<double>* cpos, const uint32_t* cidx, const uint32_t* ckey, const uint32_t* cell_start, const uint32_t* occ_sub, double* rho, int mode, uint32_t* nb_count, const unsigned long long* nb_ptr, uint32_t* nb_idx, hipStream_t st);
+template void ss_launch_make_posvol<float>(const SSDevT<float>& P, const ss_real4<float>* pos_sorted, const uint32_t* perm, const float* rho, ss_real4<float>* posvol, hipStream_t st);
+template void ss_launch_make_posvol<double>(const SSDevT<double>& P, const ss_real4<double>* pos_sorted, const uint32_t* perm, const double* rho, ss_real4<double>* posvol, hipStream_t st);
+template void ss_launch_mark_blocks<float>(const SSDevT<float>& P, const uint32_t* cell_start, uint32_t ncells, uint32_t* block_flag, hipStream_t st);
+template void ss_launch_mark_blocks<double>(const SSDevT<double>& P, const uint32_t* cell_start, uint32_t ncells, uint32_t* block_flag, hipStream_t st);
+template void ss_launch_mark_mc_blocks<float>(const SSDevT<float>& P, const uint32_t* block_slot, const ss_real2<float>* blk_minmax, uint32_t nblocks, uint32_t* mc_flag, hipStream_t st);
+template void ss_launch_mark_mc_blocks<double>(const SSDevT<double>& P, const uint32_t* block_slot, const ss_real2<double>* blk_minmax, uint32_t nblocks, uint32_t* mc_flag, hipStream_t st);
+template void ss_launch_splat<float>(const SSDevT<float>& P, const ss_real4<float>* posvol, const uint32_t* perm, const uint32_t* cell_start, const uint32_t* active_list, uint32_t n_active, float* G, ss_real2<float>* blk_minmax, unsigned long long* cand_counter, bool fast_div, hipStream_t st);
+template void ss_launch_splat<double>(const SSDevT<double>& P, const ss_real4<double>* posvol, const uint32_t* perm, const uint32_t* cell_start, const uint32_t* active_list, uint32_t n_active, double* G, ss_real2<double>* blk_minmax, unsigned long long* cand_counter, bool fast_div, hipStream_t st);
+template void ss_launch_mc_count<float>(const SSDevT<float>& P, const float* G, const uint32_t* block_slot, const uint32_t* mc_list, uint32_t n_mc, unsigned long long* masks, uint32_t* vcount, uint32_t* tcount, hipStream_t st);
+template void ss_launch_mc_count<double>(const SSDevT<double>& P, const double* G, const uint32_t* block_slot, const uint32_t* mc_list, uint32_t n_mc, unsigned long long* masks, uint32_t* vcount, uint32_t* tcount, hipStream_t st);
+template void ss_launch_mc_emit<float>(const SSDevT<float>& P, const float* G, const uint32_t* block_slot, const uint32_t* mc_list, const uint32_t* mc_slot, uint32_t n_mc, const unsigned long long* masks, const uint32_t* vbase, const uint32_t* tbase, float* vertices, unsigned long long* vkeys, uint32_t* triangles, hipStream_t st);
+template void ss_launch_mc_emit<double>(const SSDevT<double>& P, const double* G, const uint32_t* block_slot, const uint32_t* mc_list, const uint32_t* mc_slot, uint32_t n_mc, const unsigned long long* masks, const uint32_t* vbase, const uint32_t* tbase, double* vertices, unsigned long long* vkeys, uint32_t* triangles, hipStream_t st);
+template void ss_launch_levelset_box<float>(const SSDevT<float>& P, const float* G, const uint32_t* block_slot, const int lo[3], const int ext[3], float* out, hipStream_t st);
+template void ss_launch_levelset_box<double>(const SSDevT<double>& P, const double* G, const uint32_t* block_slot, const int lo[3], const int ext[3], double* out, hipStream_t st);

@@ -43,16 +43,22 @@ def run_oracle(O, pts, prm):
     return par, O.reconstruct_surface(pts, par)
 
 
+def _bits(a):
+    a = np.ascontiguousarray(a)
+    return a.view(np.uint64 if a.dtype == np.float64 else np.uint32)
+
+
 def assert_gpu_equals_oracle(res, orc):
     g = res.grid
     assert list(g.ncells_per_dim) == list(orc.grid["n_cells"])
-    assert np.array_equal(g.aabb.min.view(np.uint32), orc.grid["aabb_min"].view(np.uint32))
-    assert np.array_equal(g.aabb.max.view(np.uint32), orc.grid["aabb_max"].view(np.uint32))
+    assert g.aabb.min.dtype == orc.grid["aabb_min"].dtype
+    assert np.array_equal(_bits(g.aabb.min), _bits(orc.grid["aabb_min"]))
+    assert np.array_equal(_bits(g.aabb.max), _bits(orc.grid["aabb_max"]))
     sg = res.subdomain_grid
     assert list(sg.ncells_per_dim) == list(orc.subdomain_grid["n_cells"])
     rho = res.particle_densities
-    assert rho.shape == orc.particle_densities.shape
-    nbad = int((rho.view(np.uint32) != orc.particle_densities.view(np.uint32)).sum())
+    assert rho.shape == orc.particle_densities.shape and rho.dtype == orc.particle_densities.dtype
+    nbad = int((_bits(rho) != _bits(orc.particle_densities)).sum())
     assert nbad == 0, "%d of %d densities differ from the oracle" % (nbad, rho.size)
     cmp = MC.compare_keyed(res.mesh.vertices, res.vertex_keys, res.mesh.triangles, orc.vertices, orc.vertex_keys, orc.triangles)
     assert cmp["keys_equal"], cmp
@@ -191,8 +197,8 @@ def test_error_behaviour(gpu_ctx):
     with pytest.raises(SplashsurfError) as e:
         S.reconstruct_surface(pts, particle_radius=0.025, smoothing_length=2.0, cube_size=1.0, subdomain_grid=False, context=gpu_ctx)
     assert e.value.status == 7
-    with pytest.raises(TypeError):
-        S.reconstruct_surface(pts.astype(np.float64), particle_radius=0.025, smoothing_length=2.0, cube_size=1.0, context=gpu_ctx)
+    with pytest.raises(TypeError):  # only float32 / float64 arrays, like pysplashsurf (reconstruction.rs:187-206)
+        S.reconstruct_surface(pts.astype(np.float16), particle_radius=0.025, smoothing_length=2.0, cube_size=1.0, context=gpu_ctx)
 
 
 def test_grid_for_reconstruction(gpu_ctx, oracle):
@@ -362,3 +368,53 @@ def test_cpp_host_over_c_abi(tmp_path):
     out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "all checks passed" in out.stdout
+
+
+F64 = ["f64_kat1", "f64_cube_2366_n16", "f64_free_particles_125", "f64_config1", "f64_tank_small"]
+
+
+@pytest.mark.parametrize("name", F64)
+def test_gpu_f64_bit_identical_to_oracle_and_reference(gpu_ctx, oracle, name):
+    """reconstruct_surface::<i64, f64>: float64 arrays take the f64 instantiation of every kernel; densities,
+    vertices (64-bit patterns) and triangle sets equal the f64 oracle, which is pinned to the reference's f64 path."""
+    import splashsurf_amd as S
+    g = load_golden(name)
+    prm = golden_params(g)
+    pts = golden_input(g).astype(np.float64)
+    res = S.reconstruct_surface(pts, particle_radius=prm["particle_radius"], smoothing_length=prm["smoothing_length"], cube_size=prm["cube_size"],
+                                iso_surface_threshold=prm["iso_surface_threshold"], subdomain_grid_auto_disable=False,
+                                subdomain_num_cubes_per_dim=prm["subdomain_num_cubes_per_dim"], context=gpu_ctx)
+    assert res.is_f64 and res.mesh.vertices.dtype == np.float64 and res.particle_densities.dtype == np.float64
+    par = oracle.make_params_relative(prm["particle_radius"], prm["smoothing_length"], prm["cube_size"],
+                                      iso_surface_threshold=prm["iso_surface_threshold"],
+                                      subdomain_num_cubes_per_dim=prm["subdomain_num_cubes_per_dim"], dtype=np.float64)
+    orc = oracle.reconstruct_surface(pts, par)
+    assert_gpu_equals_oracle(res, orc)
+    # and the reference's own f64 output
+    assert np.array_equal(res.particle_densities.view(np.uint64), g["densities"].view(np.uint64))
+    cmp = MC.compare_geometric(g["vertices"], g["triangles"], res.mesh.vertices, res.mesh.triangles, g["grid_min"], g["cell_size"], g["n_points"])
+    assert cmp["ids_equal"] and cmp["triangles_equal"] and cmp["max_rel_diff"] <= 1e-13, cmp
+    # f32 results are still f32 afterwards (buffers are shared between the instantiations)
+    res32 = S.reconstruct_surface(pts.astype(np.float32), particle_radius=prm["particle_radius"], smoothing_length=prm["smoothing_length"],
+                                  cube_size=prm["cube_size"], iso_surface_threshold=prm["iso_surface_threshold"],
+                                  subdomain_grid_auto_disable=False, subdomain_num_cubes_per_dim=prm["subdomain_num_cubes_per_dim"], context=gpu_ctx)
+    assert not res32.is_f64 and res32.mesh.vertices.dtype == np.float32
+
+
+def test_gpu_f64_levelset_bit_identical(gpu_ctx, oracle):
+    import splashsurf_amd as S
+    g = load_golden("f64_config1")
+    prm = golden_params(g)
+    pts = golden_input(g).astype(np.float64)
+    res = S.reconstruct_surface(pts, particle_radius=prm["particle_radius"], smoothing_length=prm["smoothing_length"], cube_size=prm["cube_size"],
+                                subdomain_grid_auto_disable=False, context=gpu_ctx)
+    par = oracle.make_params_relative(prm["particle_radius"], prm["smoothing_length"], prm["cube_size"], dtype=np.float64)
+    ns = res.subdomain_grid.ncells_per_dim
+    for flat in range(ns[0] * ns[1] * ns[2]):
+        cnt, ref = oracle.levelset_subdomain(pts, par, flat)
+        if cnt < 0:
+            continue
+        s3 = (flat // (ns[1] * ns[2]), (flat // ns[2]) % ns[1], flat % ns[2])
+        got = res.levelset_box([s3[0] * 64, s3[1] * 64, s3[2] * 64], [65] * 3)
+        assert got.dtype == np.float64
+        assert int((got.view(np.uint64) != ref.view(np.uint64)).sum()) == 0
