@@ -121,6 +121,8 @@ def main():
 
     for _ in range(args.warmup):
         step()
+    if sharded_path:
+        sharded.timings = {}
     barrier()
     t0 = time.perf_counter()
     k3_ms = []
@@ -192,6 +194,8 @@ def main():
                 line["roofline"]["traffic_note"] = tr["note"]
         except Exception:
             pass
+    if sharded_path and getattr(last, "timings", None):
+        line["sharded_step_ms"] = {k: round(v / args.steps, 3) for k, v in last.timings.items()}
     if rank == 0:
         if not sharded_path and not args.no_cpu_baseline:
             try:

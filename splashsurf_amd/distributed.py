@@ -214,10 +214,28 @@ class ShardedReconstruction:
                 req.wait()
         return recv
 
+    def _tick(self, name):
+        """Optional per-phase timing of step() (SPLASH_PROFILE_SHARDED=1): wall time incl. device sync."""
+        if not self._profile:
+            return
+        import time
+        if self.device.type == "cuda":
+            torch.cuda.synchronize(self.device)
+        now = time.perf_counter()
+        self.timings[name] = self.timings.get(name, 0.0) + (now - self._t_last) * 1e3
+        self._t_last = now
+
     def step(self):
         """One sharded reconstruction.  Only halo layers travel between ranks:
         positions to the ranks whose slab (+ ghost margin) contains them, then the densities of owned
         particles to the ranks that hold them as ghosts."""
+        import os
+        import time
+        self._profile = bool(os.environ.get("SPLASH_PROFILE_SHARDED"))
+        self.timings = getattr(self, "timings", {}) if self._profile else {}
+        if self._profile and self.device.type == "cuda":
+            torch.cuda.synchronize(self.device)
+        self._t_last = time.perf_counter()
         eng, dev, me = self.engine, self.device, self.rank
         local = self.local
         # 1. global particle ids = concatenation by rank (defines the summation order of the level set)
@@ -228,14 +246,20 @@ class ShardedReconstruction:
         gid = torch.arange(offset, offset + local.shape[0], dtype=torch.int64, device=dev)
         # 2. global particle AABB (identical on every rank)
         big = torch.finfo(torch.float32).max
-        lo_hi = torch.stack([local.min(dim=0).values if local.shape[0] else torch.full((3,), big, device=dev),
-                             -(local.max(dim=0).values) if local.shape[0] else torch.full((3,), big, device=dev)])
+        if local.shape[0]:
+            # full reductions over the three strided columns (a dim-0 reduction of an (N,3) tensor runs
+            # on 3 threads' worth of parallelism in torch and costs ~6 ms per call at 10M particles)
+            mm = [torch.aminmax(local[:, d]) for d in range(3)]
+            lo_hi = torch.stack([torch.stack([m.min for m in mm]), -torch.stack([m.max for m in mm])])
+        else:
+            lo_hi = torch.full((2, 3), big, device=dev)
         if self.world > 1:
             dist.all_reduce(lo_hi, op=dist.ReduceOp.MIN, group=self.group)
         dmin = lo_hi[0].cpu().numpy() if n_total else np.zeros(3, np.float32)
         dmax = (-lo_hi[1]).cpu().numpy() if n_total else np.zeros(3, np.float32)
         gmin, sub_size, ns, margin, n_cubes = eng.grid_for_domain(dmin, dmax)
         axis = int(np.argmax(ns))
+        self._tick("1_ids_aabb_grid")
         # 3. slab partition balanced by owner counts (histogram all-reduced, so identical everywhere)
         s_own = torch.floor((local[:, axis] - float(gmin[axis])) / sub_size).to(torch.int64).clamp_(0, ns[axis] - 1)
         hist = torch.bincount(s_own, minlength=ns[axis]).to(torch.int64)
@@ -261,6 +285,7 @@ class ShardedReconstruction:
                 return torch.zeros(coords.shape[0], dtype=torch.bool, device=dev)
             return (coords >= iv[0]) & (coords <= iv[1])
 
+        self._tick("2_partition")
         # 4. positions to every rank that needs them (owner or ghost)
         send_gid, send_xyz = [], []
         for q in range(self.world):
@@ -273,8 +298,10 @@ class ShardedReconstruction:
         # concatenation by source rank IS the ascending global-id order (no sort needed).
         gids = torch.cat(recv_gid).contiguous()
         L = torch.cat(recv_xyz).contiguous()
+        self._tick("3_position_exchange")
         # 5. phase 1: densities of the particles contained in this slab (others stay 0)
         rho = eng.begin(L, shard)
+        self._tick("4_phase1_binning_densities")
         owned = rho > 0
         # 6. halo densities: owners -> ranks holding the particle as a ghost
         send_gid, send_rho = [], []
@@ -293,10 +320,12 @@ class ShardedReconstruction:
                 continue
             pos = torch.searchsorted(gids, recv_gid[q])
             rho.index_copy_(0, pos, recv_rho[q])
+        self._tick("5_density_exchange")
         # 7. phase 2
         res = eng.finish(rho)
+        self._tick("6_phase2_levelset_mc")
         self.last = dict(gids=gids, rho=rho, owned=owned)
-        return ShardedStepResult(res, shard, gids, n_total, {})
+        return ShardedStepResult(res, shard, gids, n_total, dict(self.timings))
 
     # ---- result assembly (tests / consumers that want one mesh) ----
     def gather_densities(self):
