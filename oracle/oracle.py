@@ -27,6 +27,7 @@ def _make_structs(real):
             ("subdomain_num_cubes_per_dim", C.c_int32),
             ("num_threads", C.c_int32),
             ("global_neighborhood_list", C.c_int32),
+            ("global_strategy", C.c_int32),
         ]
 
     class Grid(C.Structure):
@@ -61,6 +62,8 @@ def _make_structs(real):
             ("t_reconstruction", C.c_double),
             ("t_stitching", C.c_double),
             ("threads_used", C.c_int32),
+            ("used_global_strategy", C.c_int32),
+            ("global_levelset", C.POINTER(real)),
         ]
 
     class Shard(C.Structure):
@@ -129,8 +132,11 @@ def lib():
 
 def make_params(particle_radius, compact_support_radius, cube_size, rest_density=1000.0,
                 iso_surface_threshold=0.6, aabb_min=None, aabb_max=None,
-                subdomain_num_cubes_per_dim=64, num_threads=0, global_neighborhood_list=False, dtype=np.float32):
-    """Absolute-unit parameters (lib.rs:197-210), rounded to `dtype` (float32: so_*, float64: so64_*)."""
+                subdomain_num_cubes_per_dim=64, num_threads=0, global_neighborhood_list=False, dtype=np.float32,
+                subdomain_grid=True, subdomain_grid_auto_disable=False):
+    """Absolute-unit parameters (lib.rs:197-210), rounded to `dtype` (float32: so_*, float64: so64_*).
+    subdomain_grid=False: SpatialDecomposition::None; subdomain_grid_auto_disable=True: the reference's
+    default rule (global strategy when the domain has <= 1.2 n cells per dimension, lib.rs:421-441)."""
     _, npdt, _, (Pm, _, _, _) = _flavour(np.dtype(dtype))
     p = Pm()
     p.particle_radius = npdt(particle_radius)
@@ -148,6 +154,7 @@ def make_params(particle_radius, compact_support_radius, cube_size, rest_density
     p.subdomain_num_cubes_per_dim = int(subdomain_num_cubes_per_dim)
     p.num_threads = int(num_threads)
     p.global_neighborhood_list = 1 if global_neighborhood_list else 0
+    p.global_strategy = 1 if not subdomain_grid else (2 if subdomain_grid_auto_disable else 0)
     return p
 
 
@@ -272,6 +279,15 @@ def _unpack(res, params):
         out.timings = dict(total=res.t_total, decomposition=res.t_decomposition, density=res.t_density,
                            reconstruction=res.t_reconstruction, stitching=res.t_stitching)
         out.threads_used = int(res.threads_used)
+        out.used_global_strategy = bool(res.used_global_strategy)
+        if out.used_global_strategy:
+            out.subdomain_grid = None
+            npts = [int(x) for x in res.grid.n_points]
+            tot = npts[0] * npts[1] * npts[2]
+            out.global_levelset = (np.ctypeslib.as_array(res.global_levelset, shape=(tot,)).copy().reshape(npts)
+                                   if res.global_levelset and tot else None)
+        else:
+            out.global_levelset = None
     finally:
         _fn(params, "result_free")(C.byref(res))
     return out

@@ -878,6 +878,295 @@ static int stitching(patch_t *patches, int64_t n_patches, SOT(result) *out) {
 /* ------------------------------------------------------------------------------------------
  * Entry points (lib.rs:330-473, reconstruction.rs:17-62)
  * ------------------------------------------------------------------------------------------ */
+/* ------------------------------------------------------------------------------------------
+ * Global (non-decomposed) strategy, SURVEY rows A14/A15: reconstruction.rs:65-194 with
+ * enable_multi_threading = false, i.e. the reference's *sequential* functions, which are the only
+ * deterministic ones of this strategy (the parallel variants fill dashmaps / merge thread-local maps in
+ * thread-timing order).  Hash maps of the reference (cell -> particles, point -> value, cell -> CellData)
+ * are replaced by dense arrays over the grid; missing map entries and zeros are interchangeable in every
+ * test the reference performs on them (narrow_band_extraction.rs:79-88, 161-176).
+ * ------------------------------------------------------------------------------------------ */
+static int global_densities_and_neighbors(const SOT(grid) *grid, const real *xyz, uint64_t n, const SOT(params) *P, real mass,
+                                          int nthreads, real *rho, uint64_t **out_ptr, uint64_t **out_nb) {
+    /* neighborhood_search.rs:148-230 (sequential spatial hashing on domain = grid.aabb(), cell size h)
+       + density_map.rs:113-186 */
+    const real h = P->compact_support_radius;
+    if (!(h > RC(0.0))) return 4; /* assert, neighborhood_search.rs:159-162 */
+    SOT(grid) sgrid;
+    if (grid_from_aabb(&sgrid, grid->aabb_min, grid->aabb_max, h) != 0) return 4; /* asserts :163-170, expect :176 */
+    size_t ncell = (size_t)(sgrid.n_cells[0] * sgrid.n_cells[1] * sgrid.n_cells[2]);
+    uint32_t *cell_start = (uint32_t *)calloc(ncell + 1, sizeof(uint32_t));
+    uint32_t *cell_of = (uint32_t *)malloc(sizeof(uint32_t) * (n ? n : 1));
+    uint32_t *items = (uint32_t *)malloc(sizeof(uint32_t) * (n ? n : 1));
+    for (uint64_t a = 0; a < n; ++a) { /* neighborhood_search.rs:655-676: ascending particle index per cell */
+        int64_t c[3];
+        grid_enclosing_cell(&sgrid, xyz + 3 * a, c);
+        if (!grid_cell_exists(&sgrid, c)) { /* get_cell(..).unwrap() */
+            free(cell_start); free(cell_of); free(items);
+            return 4;
+        }
+        cell_of[a] = (uint32_t)grid_flatten_cell(&sgrid, c);
+        cell_start[cell_of[a] + 1]++;
+    }
+    for (size_t c = 0; c < ncell; ++c) cell_start[c + 1] += cell_start[c];
+    {
+        uint32_t *cursor = (uint32_t *)malloc(sizeof(uint32_t) * (ncell ? ncell : 1));
+        memcpy(cursor, cell_start, sizeof(uint32_t) * ncell);
+        for (uint64_t a = 0; a < n; ++a) items[cursor[cell_of[a]]++] = (uint32_t)a;
+        free(cursor);
+    }
+    cubic_kernel K = kernel_new(h);
+    const real h2 = h * h;
+    const real w0 = kernel_evaluate(&K, RC(0.0));
+    uint64_t *ptr = (uint64_t *)calloc((size_t)n + 1, sizeof(uint64_t));
+    for (int pass = 0; pass < 2; ++pass) { /* pass 0: counts + densities, pass 1: lists */
+        uint64_t *nb = NULL;
+        if (pass == 1) {
+            uint64_t run = 0;
+            for (uint64_t a = 0; a < n; ++a) {
+                uint64_t c = ptr[a];
+                ptr[a] = run;
+                run += c;
+            }
+            ptr[n] = run;
+            nb = (uint64_t *)malloc(sizeof(uint64_t) * (size_t)(run ? run : 1));
+            *out_nb = nb;
+        }
+#pragma omp parallel for schedule(static) num_threads(nthreads)
+        for (int64_t a = 0; a < (int64_t)n; ++a) {
+            const real *pi = xyz + 3 * a;
+            int64_t ci[3];
+            grid_enclosing_cell(&sgrid, pi, ci);
+            real density = w0;
+            uint64_t cnt = 0;
+            /* cells_adjacent_to_cell (26, iproduct order) chained with the cell itself (:189-197) */
+            for (int ph = 0; ph < 2; ++ph)
+                for (int sx = -1; sx <= 1; ++sx)
+                    for (int sy = -1; sy <= 1; ++sy)
+                        for (int sz = -1; sz <= 1; ++sz) {
+                            int is_center = (sx == 0 && sy == 0 && sz == 0);
+                            if ((ph == 0) == is_center) continue;
+                            int64_t c[3] = {ci[0] + sx, ci[1] + sy, ci[2] + sz};
+                            if (!grid_cell_exists(&sgrid, c)) continue;
+                            size_t f = (size_t)grid_flatten_cell(&sgrid, c);
+                            for (uint32_t q = cell_start[f]; q < cell_start[f + 1]; ++q) {
+                                uint32_t b = items[q];
+                                if ((int64_t)b == a) continue; /* :216-218 */
+                                const real *pj = xyz + 3 * (size_t)b;
+                                real dx = pj[0] - pi[0], dy = pj[1] - pi[1], dz = pj[2] - pi[2];
+                                real d2 = dx * dx + dy * dy + dz * dz;
+                                if (d2 < h2) { /* :221 */
+                                    if (pass == 0)
+                                        density += kernel_evaluate(&K, R_SQRT(d2)); /* density_map.rs:176-180 */
+                                    else
+                                        nb[ptr[a] + cnt] = b;
+                                    ++cnt;
+                                }
+                            }
+                        }
+            if (pass == 0) {
+                rho[a] = density * mass; /* density_map.rs:182 */
+                ptr[a] = cnt;
+            }
+        }
+    }
+    *out_ptr = ptr;
+    free(cell_start);
+    free(cell_of);
+    free(items);
+    return 0;
+}
+
+/* density_map.rs:364-412, 582-737 (SparseDensityMapGenerator, sequential) into a dense array */
+static int global_density_map(const SOT(grid) *grid, const real *xyz, const real *rho, uint64_t n, const SOT(params) *P, real mass,
+                              real *levelset) {
+    const real h = P->compact_support_radius, cs = P->cube_size;
+    /* compute_kernel_evaluation_radius, density_map.rs:551-580 */
+    const real half_supported_cells_real = R_CEIL(h / cs);
+    const int64_t half_supported_cells = (int64_t)(double)half_supported_cells_real;
+    const int64_t supported_points = 1 + (half_supported_cells * 2 + 1);
+    const real radius = cs * half_supported_cells_real * (RC(1.0) + R_SQRT(R_EPSILON));
+    const real radius_sq = radius * radius;
+    cubic_kernel K = kernel_new(h);
+    real amin[3], amax[3]; /* allowed domain :606-613 */
+    const real neg = -radius;
+    for (int d = 0; d < 3; ++d) {
+        amin[d] = grid->aabb_min[d] - neg;
+        amax[d] = grid->aabb_max[d] + neg;
+    }
+    if ((amin[0] == amax[0] && amin[1] == amax[1] && amin[2] == amax[2]) ||
+        !(amin[0] <= amax[0] && amin[1] <= amax[1] && amin[2] <= amax[2]))
+        return 2; /* DensityMapError::InvalidDomain :615-627 */
+    const int64_t npy = grid->n_points[1], npz = grid->n_points[2];
+    for (uint64_t a = 0; a < n; ++a) { /* ascending particle order :389-396 */
+        const real *p = xyz + 3 * a;
+        if (!(p[0] >= amin[0] && p[1] >= amin[1] && p[2] >= amin[2] && p[0] < amax[0] && p[1] < amax[1] && p[2] < amax[2]))
+            continue; /* :648-651 */
+        int64_t cell[3], lo[3], hi[3];
+        grid_enclosing_cell(grid, p, cell);
+        for (int d = 0; d < 3; ++d) {
+            lo[d] = cell[d] - half_supported_cells;
+            hi[d] = lo[d] + supported_points;
+        }
+        const real volume = mass / rho[a]; /* :688 */
+        real mp[3];
+        for (int d = 0; d < 3; ++d) mp[d] = grid_point_coord(grid, lo[d], d);
+        real dx = mp[0] - p[0] - cs; /* :694-697 */
+        for (int64_t i = lo[0]; i != hi[0]; ++i) {
+            dx += cs;
+            const real dxdx = dx * dx;
+            real dy = mp[1] - p[1] - cs;
+            for (int64_t j = lo[1]; j != hi[1]; ++j) {
+                dy += cs;
+                const real dydy = dy * dy;
+                real dz = mp[2] - p[2] - cs;
+                for (int64_t k = lo[2]; k != hi[2]; ++k) {
+                    dz += cs;
+                    const real dzdz = dz * dz;
+                    const real r2 = dxdx + dydy + dzdz;
+                    if (r2 < radius_sq) {
+                        const real contribution = volume * kernel_evaluate(&K, R_SQRT(r2));
+                        levelset[(i * npy + j) * npz + k] += contribution; /* :722-726 */
+                    }
+                }
+            }
+        }
+    }
+    return 0;
+}
+
+/* narrow_band_extraction.rs:8-219 + triangulation.rs:23-95.  Output order is canonical (the reference's
+   is hash-map order): vertices by ascending edge key, triangles by ascending flat cell index. */
+static int global_marching_cubes(const SOT(grid) *grid, const real *G, real t, SOT(result) *out) {
+    const int64_t np[3] = {grid->n_points[0], grid->n_points[1], grid->n_points[2]};
+    const int64_t nc[3] = {grid->n_cells[0], grid->n_cells[1], grid->n_cells[2]};
+    const size_t npts = (size_t)(np[0] * np[1] * np[2]);
+    /* vertex id of the edge starting at a point in +axis direction, -1 = no iso-surface vertex */
+    int64_t *edge_vertex = (int64_t *)malloc(sizeof(int64_t) * 3 * (npts ? npts : 1));
+    uint64_t nv = 0;
+    for (size_t q = 0; q < 3 * npts; ++q) edge_vertex[q] = -1;
+    for (int pass = 0; pass < 2; ++pass) {
+        if (pass == 1) {
+            out->n_vertices = nv;
+            out->vertices = (real *)malloc(sizeof(real) * 3 * (size_t)(nv ? nv : 1));
+            out->vertex_keys = (uint64_t *)malloc(sizeof(uint64_t) * (size_t)(nv ? nv : 1));
+            nv = 0;
+        }
+        for (int64_t i = 0; i < np[0]; ++i)
+            for (int64_t j = 0; j < np[1]; ++j)
+                for (int64_t k = 0; k < np[2]; ++k) {
+                    const int64_t o[3] = {i, j, k};
+                    const size_t fo = (size_t)((i * np[1] + j) * np[2] + k);
+                    for (int axis = 0; axis < 3; ++axis) {
+                        if (o[axis] + 1 >= np[axis]) continue; /* get_point_neighbor: no neighbour outside the grid */
+                        int64_t q[3] = {i, j, k};
+                        q[axis] += 1;
+                        const size_t fq = (size_t)((q[0] * np[1] + q[1]) * np[2] + q[2]);
+                        const real vo = G[fo], vq = G[fq];
+                        /* the edge is visited from its endpoint with value >= t towards a neighbour < t (:69-92) */
+                        int from_o = !(vo < t) && (vq < t);
+                        int from_q = !(vq < t) && (vo < t);
+                        if (!from_o && !from_q) continue;
+                        if (pass == 0) {
+                            ++nv;
+                            continue;
+                        }
+                        const int64_t *pp = from_o ? o : q, *nn = from_o ? q : o;
+                        const real pv = from_o ? vo : vq, nvv = from_o ? vq : vo;
+                        const real alpha = (t - pv) / (nvv - pv); /* :95 */
+                        for (int d = 0; d < 3; ++d) {
+                            const real pc = grid_point_coord(grid, pp[d], d), ncd = grid_point_coord(grid, nn[d], d);
+                            out->vertices[3 * nv + d] = pc * (RC(1.0) - alpha) + ncd * alpha; /* :96-99 */
+                        }
+                        out->vertex_keys[nv] = (uint64_t)fo * 3u + (uint64_t)axis;
+                        edge_vertex[3 * fo + (size_t)axis] = (int64_t)nv;
+                        ++nv;
+                    }
+                }
+    }
+    /* cells: every existing cell adjacent to an edge with a vertex (:107-129); corner flags (:115-127, 161-176) */
+    uint64_t nt = 0, cap = 1024;
+    uint64_t *tris = (uint64_t *)malloc(sizeof(uint64_t) * 3 * cap);
+    int rc = 0;
+    for (int64_t i = 0; i < nc[0] && !rc; ++i)
+        for (int64_t j = 0; j < nc[1] && !rc; ++j)
+            for (int64_t k = 0; k < nc[2] && !rc; ++k) {
+                int64_t ev[12];
+                int any = 0;
+                for (int e = 0; e < 12; ++e) {
+                    const int oc = CELL_LOCAL_EDGES[e][0], axis = CELL_LOCAL_EDGES[e][1];
+                    const int64_t o[3] = {i + CELL_LOCAL_POINT_COORDS[oc][0], j + CELL_LOCAL_POINT_COORDS[oc][1],
+                                          k + CELL_LOCAL_POINT_COORDS[oc][2]};
+                    ev[e] = edge_vertex[3 * (size_t)((o[0] * np[1] + o[1]) * np[2] + o[2]) + (size_t)axis];
+                    any |= ev[e] >= 0;
+                }
+                if (!any) continue;
+                int case_index = 0;
+                for (int c = 0; c < 8; ++c) {
+                    const int64_t pc[3] = {i + CELL_LOCAL_POINT_COORDS[c][0], j + CELL_LOCAL_POINT_COORDS[c][1],
+                                           k + CELL_LOCAL_POINT_COORDS[c][2]};
+                    const real v = G[(pc[0] * np[1] + pc[1]) * np[2] + pc[2]];
+                    int above = v > t; /* :161-170 */
+                    if (!above && !(v < t)) {
+                        /* v == t: marked Above only through a crossing edge of this cell that starts at it (:115-127) */
+                        for (int e = 0; e < 12 && !above; ++e) {
+                            if (ev[e] < 0) continue;
+                            const int oc = CELL_LOCAL_EDGES[e][0], axis = CELL_LOCAL_EDGES[e][1];
+                            int tc[3] = {CELL_LOCAL_POINT_COORDS[oc][0], CELL_LOCAL_POINT_COORDS[oc][1], CELL_LOCAL_POINT_COORDS[oc][2]};
+                            int is_o = tc[0] == CELL_LOCAL_POINT_COORDS[c][0] && tc[1] == CELL_LOCAL_POINT_COORDS[c][1] &&
+                                       tc[2] == CELL_LOCAL_POINT_COORDS[c][2];
+                            tc[axis] += 1;
+                            int is_t = tc[0] == CELL_LOCAL_POINT_COORDS[c][0] && tc[1] == CELL_LOCAL_POINT_COORDS[c][1] &&
+                                       tc[2] == CELL_LOCAL_POINT_COORDS[c][2];
+                            if (is_o || is_t) above = 1; /* the other endpoint is < t, so this corner is the >= t one */
+                        }
+                    }
+                    case_index |= above << c;
+                }
+                const int8_t *row = MC_TABLE[case_index];
+                for (int tri = 0; tri < 5 && row[3 * tri] >= 0; ++tri) {
+                    if (nt == cap) {
+                        cap *= 2;
+                        tris = (uint64_t *)realloc(tris, sizeof(uint64_t) * 3 * cap);
+                    }
+                    for (int v = 0; v < 3; ++v) {
+                        const int64_t id = ev[row[3 * tri + v]];
+                        if (id < 0) rc = 3; /* "Missing iso surface vertex", triangulation.rs:62-95 */
+                        tris[3 * nt + (size_t)v] = (uint64_t)id;
+                    }
+                    ++nt;
+                }
+            }
+    free(edge_vertex);
+    out->n_triangles = nt;
+    out->triangles = tris;
+    return rc;
+}
+
+static int reconstruct_surface_global(const real *xyz, uint64_t n, const SOT(params) *P, const SOT(grid) *grid, int nthreads,
+                                      SOT(result) *out) {
+    /* reconstruction.rs:65-194 */
+    const real d = P->particle_radius + P->particle_radius; /* kernel.rs:28-30 Volume::cube_particle */
+    const real mass = d * d * d * P->rest_density;
+    out->grid = *grid;
+    memset(&out->subdomain_grid, 0, sizeof(out->subdomain_grid));
+    double t1 = now_s();
+    real *rho = (real *)calloc(n ? n : 1, sizeof(real));
+    out->particle_densities = rho;
+    int rc = global_densities_and_neighbors(grid, xyz, n, P, mass, nthreads, rho, &out->neighbor_ptr, &out->neighbors);
+    if (rc) return rc;
+    double t2 = now_s();
+    const size_t npts = (size_t)(grid->n_points[0] * grid->n_points[1] * grid->n_points[2]);
+    real *G = (real *)calloc(npts ? npts : 1, sizeof(real));
+    rc = global_density_map(grid, xyz, rho, n, P, mass, G);
+    if (!rc) rc = global_marching_cubes(grid, G, P->iso_surface_threshold, out);
+    out->global_levelset = G;
+    double t3 = now_s();
+    out->t_density = t2 - t1;
+    out->t_reconstruction = t3 - t2;
+    return rc;
+}
+
 static int resolve_threads(const SOT(params) *P) {
 #ifdef _OPENMP
     int t = P->num_threads > 0 ? P->num_threads : omp_get_max_threads();
@@ -940,6 +1229,25 @@ int SOFN(reconstruct_surface)(const real *xyz_in, uint64_t n_in, const SOT(param
     if (grid_for_reconstruction(xyz, n, P, &initial) != 0) {
         free(filtered);
         return 1;
+    }
+    /* strategy choice, lib.rs:419-462 */
+    int use_decomposition = 1;
+    if (P->global_strategy == 1) {
+        use_decomposition = 0; /* SpatialDecomposition::None */
+    } else if (P->global_strategy == 2) { /* UniformGrid with auto_disable */
+        int64_t max_cubes = initial.n_cells[0];
+        if (initial.n_cells[1] > max_cubes) max_cubes = initial.n_cells[1];
+        if (initial.n_cells[2] > max_cubes) max_cubes = initial.n_cells[2];
+        uint32_t with_margin = (uint32_t)(1.2 * (double)P->subdomain_num_cubes_per_dim);
+        uint32_t mc32 = max_cubes > (int64_t)UINT32_MAX ? UINT32_MAX : (uint32_t)max_cubes;
+        use_decomposition = mc32 > with_margin;
+    }
+    if (!use_decomposition) {
+        int rc = reconstruct_surface_global(xyz, n, P, &initial, nthreads, out);
+        free(filtered);
+        out->used_global_strategy = 1;
+        out->t_total = now_s() - t0;
+        return rc;
     }
     sd_params S;
     initialize_parameters(P, &initial, &S);
@@ -1204,5 +1512,6 @@ void SOFN(result_free)(SOT(result) *r) {
     free(r->vertices);
     free(r->vertex_keys);
     free(r->triangles);
+    free(r->global_levelset);
     memset(r, 0, sizeof(*r));
 }

@@ -12,6 +12,8 @@ typedef struct SOT(params) {
     int32_t subdomain_num_cubes_per_dim; /* lib.rs:142, default 64 */
     int32_t num_threads;                 /* <=0: all cores (OpenMP) */
     int32_t global_neighborhood_list;    /* lib.rs:185-188 */
+    int32_t global_strategy; /* 0: subdomain grid (UniformGrid, auto_disable=false); 1: SpatialDecomposition::None;
+                                2: UniformGrid with auto_disable=true (lib.rs:419-462) */
 } SOT(params);
 
 typedef struct SOT(grid) {
@@ -40,6 +42,8 @@ typedef struct SOT(result) {
     uint64_t n_subdomain_particles; /* sum over subdomains incl. ghosts */
     double t_total, t_decomposition, t_density, t_reconstruction, t_stitching; /* seconds */
     int32_t threads_used;
+    int32_t used_global_strategy;  /* 1: reconstruct_surface_global ran (subdomain_grid is all zero = None) */
+    SO_REAL *global_levelset;      /* global strategy only: dense level-set values over grid.n_points (missing map entries = 0) */
 } SOT(result);
 
 /* returns 0 on success; 1 grid construction error; 4 other */

@@ -149,3 +149,56 @@ def test_oracle_f64_matches_reference(oracle, name):
     assert np.array_equal(res.grid["aabb_min"].view(np.uint64), g["grid_min"].view(np.uint64))
     cmp = MC.compare_geometric(g["vertices"], g["triangles"], res.vertices, res.triangles, g["grid_min"], g["cell_size"], g["n_points"])
     assert cmp["ids_equal"] and cmp["triangles_equal"] and cmp["max_rel_diff"] <= 1e-14, cmp
+
+
+GLOBAL = ["global_kat1", "global_edge_empty", "global_cube_8", "global_cube_2366", "global_cube_2366_auto_disable",
+          "global_cube_2366_aabb", "global_free_particles_125", "global_config1", "global_f64_cube_2366", "global_f64_config1"]
+
+
+def run_oracle_global(O, g):
+    """Oracle run of a `global_*` golden (rows A14/A15): parameters as stored, dtype from the golden's arrays."""
+    prm = golden_params(g)
+    dt = g["densities"].dtype.type
+    pts = golden_input(g).astype(dt)
+    kw = {}
+    if "aabb_min" in prm:
+        kw = dict(aabb_min=np.asarray(prm["aabb_min"], dt), aabb_max=np.asarray(prm["aabb_max"], dt))
+    par = O.make_params_relative(prm["particle_radius"], prm["smoothing_length"], prm["cube_size"],
+                                 iso_surface_threshold=prm["iso_surface_threshold"], dtype=dt,
+                                 subdomain_grid=prm.get("subdomain_grid", True),
+                                 subdomain_grid_auto_disable=prm.get("subdomain_grid_auto_disable", False), **kw)
+    return O.reconstruct_surface(pts, par), dt
+
+
+@pytest.mark.parametrize("name", GLOBAL)
+def test_oracle_global_strategy_matches_reference(oracle, name):
+    """reconstruct_surface_global (reconstruction.rs:65-194, sequential functions): densities, neighbour lists and
+    vertex coordinates bit-identical to the reference, same triangles; `subdomain_grid` is None."""
+    g = load_golden(name)
+    res, dt = run_oracle_global(oracle, g)
+    U = np.uint32 if dt == np.float32 else np.uint64
+    assert res.used_global_strategy and res.subdomain_grid is None
+    assert np.array_equal(res.grid["n_cells"], g["n_cells"])
+    assert np.array_equal(res.grid["aabb_min"].view(U), g["grid_min"].view(U))
+    assert np.array_equal(res.grid["aabb_max"].view(U), g["grid_max"].view(U))
+    assert np.array_equal(res.particle_densities.view(U), g["densities"].view(U))
+    assert np.array_equal(res.neighbor_ptr.astype(np.int64), g["row_ptr"])
+    assert np.array_equal(res.neighbors.astype(np.int64), g["neighbors"].astype(np.int64))
+    if "inside" in g.files:
+        assert np.array_equal(res.particle_inside_aabb, g["inside"].astype(bool))
+    assert res.vertices.shape[0] == g["vertices"].shape[0] and res.triangles.shape[0] == g["triangles"].shape[0]
+    if res.vertices.shape[0]:
+        cmp = MC.compare_geometric(g["vertices"], g["triangles"], res.vertices, res.triangles, g["grid_min"], g["cell_size"], g["n_points"])
+        assert cmp["ids_equal"] and cmp["triangles_equal"] and cmp["max_rel_diff"] == 0.0, cmp
+        assert MC.mesh_is_closed_manifold(res.triangles)
+
+
+def test_oracle_auto_disable_rule(oracle):
+    """lib.rs:421-441: the decomposition is used iff max cells per dim > (1.2 n) as u32."""
+    g = load_golden("global_cube_2366")
+    pts = golden_input(g)
+    for n_cubes, expect_global in ((64, True), (48, True), (41, False), (16, False)):
+        # the domain has 50 cells along y: 50 > (1.2*41) as u32 = 49 -> decomposition; 50 > 57 false -> global
+        par = oracle.make_params_relative(0.025, 2.0, 0.75, subdomain_num_cubes_per_dim=n_cubes, subdomain_grid_auto_disable=True)
+        res = oracle.reconstruct_surface(pts, par)
+        assert res.used_global_strategy == expect_global, n_cubes

@@ -175,11 +175,94 @@ def gen_f64_goldens(report):
         report[name] = cmp
 
 
+def gen_global_goldens(report):
+    """Global (non-decomposed) strategy, SURVEY rows A14/A15: `subdomain_grid=False` or the auto-disable rule for
+    small domains (lib.rs:419-462).  Generated with multi_threading=False: only the reference's sequential
+    functions are deterministic for this strategy (its parallel variants fill hash maps in thread-timing order);
+    the difference to a multi-threaded reference run is recorded in the report as the reference's own noise."""
+    cases = [
+        # name, input, r, l, c, t, dtype, kwargs of pysplashsurf / oracle
+        ("global_kat1", dict(kind="inline", points=[[0.01, 0.0, 0.0]]), 1.0, 0.5, 1.0, 0.1, np.float32, dict(subdomain_grid=False)),
+        ("global_edge_empty", dict(kind="inline", points=[]), 0.025, 2.0, 1.0, 0.6, np.float32, dict(subdomain_grid=False)),
+        ("global_cube_8", dict(kind="file", file="cube_8_particles.npy"), 0.025, 2.0, 1.0, 0.6, np.float32, dict(subdomain_grid=False)),
+        ("global_cube_2366", dict(kind="file", file="cube_2366_particles.npy"), 0.025, 2.0, 0.75, 0.6, np.float32, dict(subdomain_grid=False)),
+        ("global_cube_2366_auto_disable", dict(kind="file", file="cube_2366_particles.npy"), 0.025, 2.0, 0.75, 0.6, np.float32,
+         dict(subdomain_grid=True, subdomain_grid_auto_disable=True)),
+        ("global_cube_2366_aabb", dict(kind="file", file="cube_2366_particles.npy"), 0.025, 2.0, 0.75, 0.6, np.float32,
+         dict(subdomain_grid=False, aabb_min=[0.8, 0.0, 0.8], aabb_max=[1.2, 0.5, 1.5])),
+        ("global_free_particles_125", dict(kind="file", file="free_particles_125_particles.npy"), 0.025, 2.0, 1.0, 0.6, np.float32,
+         dict(subdomain_grid=False)),
+        ("global_config1", dict(kind="file", file="double_dam_break_frame_26_4732_particles.npy"), 0.025, 2.0, 1.1, 0.6, np.float32,
+         dict(subdomain_grid=False)),
+        ("global_f64_cube_2366", dict(kind="file", file="cube_2366_particles.npy"), 0.025, 2.0, 0.75, 0.6, np.float64, dict(subdomain_grid=False)),
+        ("global_f64_config1", dict(kind="file", file="double_dam_break_frame_26_4732_particles.npy"), 0.025, 2.0, 1.1, 0.6, np.float64,
+         dict(subdomain_grid=False)),
+    ]
+    for name, desc, r, l, c, t, dt, kw in cases:
+        if desc["kind"] == "inline":
+            pts = np.asarray(desc["points"], dtype=np.float32).reshape(-1, 3)
+        else:
+            pts = np.load(os.path.join(DATA, desc["file"]))
+        pts = np.ascontiguousarray(np.asarray(pts, dtype=np.float32), dtype=dt)
+        U = np.uint32 if dt == np.float32 else np.uint64
+        res = pysplashsurf.reconstruct_surface(pts, particle_radius=r, smoothing_length=l, cube_size=c, iso_surface_threshold=t, simd=False,
+                                               multi_threading=False, **kw)
+        res_mt = pysplashsurf.reconstruct_surface(pts, particle_radius=r, smoothing_length=l, cube_size=c, iso_surface_threshold=t, simd=False,
+                                                  multi_threading=True, **kw)
+        rv = np.asarray(res.mesh.vertices, dtype=dt).reshape(-1, 3)
+        rt = np.asarray(res.mesh.triangles).astype(np.int64).reshape(-1, 3)
+        rd = np.asarray(res.particle_densities, dtype=dt)
+        gmin = np.asarray(res.grid.aabb.min, dtype=dt)
+        okw = {k: (np.asarray(v, dtype=dt) if k.startswith("aabb") else v) for k, v in kw.items()}
+        orc = O.reconstruct_surface(pts, O.make_params_relative(r, l, c, iso_surface_threshold=t, dtype=dt, **okw))
+        assert orc.used_global_strategy, name
+        assert np.array_equal(np.asarray(res.grid.ncells_per_dim), orc.grid["n_cells"]), name
+        assert np.array_equal(gmin.view(U), orc.grid["aabb_min"].view(U)), name
+        assert np.array_equal(rd.view(U), orc.particle_densities.view(U)), name + ": rho not bit-identical"
+        lists = res.particle_neighbors.get_neighborhood_lists()
+        ptr = np.concatenate([[0], np.cumsum([len(x) for x in lists])]).astype(np.int64)
+        idx = np.concatenate([np.asarray(x, dtype=np.int64) for x in lists]) if ptr[-1] else np.zeros(0, np.int64)
+        assert np.array_equal(orc.neighbor_ptr.astype(np.int64), ptr) and np.array_equal(orc.neighbors.astype(np.int64), idx), name
+        extra = {}
+        if res.particle_inside_aabb is not None:
+            inside = np.asarray(res.particle_inside_aabb).astype(np.uint8)
+            assert np.array_equal(inside.astype(bool), orc.particle_inside_aabb), name
+            extra["inside"] = inside
+        if rv.shape[0]:
+            cmp = MC.compare_geometric(rv, rt, orc.vertices, orc.triangles, gmin, dt(res.grid.cell_size), res.grid.npoints_per_dim)
+            # the global strategy has no "first patch wins" freedom: coordinates must be bit-identical
+            assert cmp["ids_equal"] and cmp["triangles_equal"] and cmp["max_rel_diff"] == 0.0, (name, cmp)
+        else:
+            assert orc.vertices.shape[0] == 0 and orc.triangles.shape[0] == 0
+            cmp = dict(ids_equal=True, triangles_equal=True, max_rel_diff=0.0)
+        mt_rho = np.asarray(res_mt.particle_densities, dtype=dt)
+        mt_v = np.asarray(res_mt.mesh.vertices, dtype=dt).reshape(-1, 3)
+        cmp["reference_mt_vs_st"] = dict(
+            rho_bit_equal=bool(np.array_equal(mt_rho.view(U), rd.view(U))),
+            rho_max_rel=float(np.max(np.abs(mt_rho - rd) / np.maximum(np.abs(rd), 1e-30))) if rd.size else 0.0,
+            same_vertex_count=bool(mt_v.shape[0] == rv.shape[0]))
+        prm = dict(particle_radius=r, smoothing_length=l, cube_size=c, iso_surface_threshold=t,
+                   **{k: v for k, v in kw.items()})
+        np.savez_compressed(os.path.join(GOLD, name + ".npz"), vertices=rv, triangles=rt.astype(np.int32), densities=rd, grid_min=gmin,
+                            grid_max=np.asarray(res.grid.aabb.max, dtype=dt), cell_size=dt(res.grid.cell_size),
+                            n_cells=np.asarray(res.grid.ncells_per_dim, dtype=np.int64),
+                            n_points=np.asarray(res.grid.npoints_per_dim, dtype=np.int64),
+                            row_ptr=ptr, neighbors=idx.astype(np.int32),
+                            params=np.array(json.dumps(prm)), input=np.array(json.dumps(desc)), **extra)
+        report[name] = cmp
+
+
 def main():
     os.makedirs(GOLD, exist_ok=True)
     if "--f64-only" in sys.argv:
         rep = {}
         gen_f64_goldens(rep)
+        for k, v in rep.items():
+            print(k, v)
+        return
+    if "--global-only" in sys.argv:
+        rep = {}
+        gen_global_goldens(rep)
         for k, v in rep.items():
             print(k, v)
         return
@@ -284,6 +367,8 @@ def main():
     gen_neighbor_goldens(report)
     # ---- f64 instantiation
     gen_f64_goldens(report)
+    # ---- global (non-decomposed) strategy, rows A14/A15
+    gen_global_goldens(report)
 
     # ---- G5: splat micro-fixture (data/density_grid_loop_subdomain_33.json -> npz, inputs only)
     src = "/root/reference/data/density_grid_loop_subdomain_33.json"
