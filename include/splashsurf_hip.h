@@ -62,11 +62,15 @@ typedef struct ss_params_f32 {
     int32_t has_particle_aabb;    /* Option<Aabb3d> */
     float aabb_min[3];
     float aabb_max[3];
-    int32_t enable_multi_threading; /* accepted for API parity; the GPU path is always parallel */
+    int32_t enable_multi_threading; /* accepted for API parity; the GPU path is always parallel.  Results of the global
+                                     * strategy are those of the reference with enable_multi_threading = false (its only
+                                     * deterministic mode, reconstruction.rs:65-194) */
     int32_t enable_simd;            /* accepted for API parity; results follow the reference's scalar path */
-    int32_t decomposition;          /* 0 = SpatialDecomposition::None, 1 = UniformGrid */
+    int32_t decomposition;          /* 0 = SpatialDecomposition::None (global strategy, reconstruction.rs:65-112),
+                                     * 1 = UniformGrid (subdomain grid, the optimised path) */
     uint32_t subdomain_num_cubes_per_dim; /* default 64 */
-    int32_t auto_disable;           /* GridDecompositionParameters::auto_disable */
+    int32_t auto_disable;           /* GridDecompositionParameters::auto_disable: global strategy when the domain has
+                                     * <= (1.2 n) cells per dimension (lib.rs:421-441) */
     int32_t global_neighborhood_list;
 } ss_params_f32;
 
@@ -167,7 +171,7 @@ ss_status ss_result_vertices(ss_result *res, const float **xyz, uint64_t *n_vert
 ss_status ss_result_triangles(ss_result *res, const uint64_t **indices, uint64_t *n_triangles); /* mesh.triangles as [usize;3] */
 ss_status ss_result_triangles_u32(ss_result *res, const uint32_t **indices, uint64_t *n_triangles);
 ss_status ss_result_grid(const ss_result *res, ss_grid_f32 *out);
-/* returns SS_OK and *present = 1 if spatial decomposition was used (always, in this build) */
+/* *present = 1 if the subdomain grid was used, 0 (Option::None) after the global strategy (lib.rs:249-250) */
 ss_status ss_result_subdomain_grid(const ss_result *res, ss_grid_f32 *out, int32_t *present);
 ss_status ss_result_particle_densities(ss_result *res, const float **rho, uint64_t *n);
 /* *flags == NULL when no particle AABB was given (Option::None) */

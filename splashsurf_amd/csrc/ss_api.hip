@@ -8,6 +8,8 @@
 
 #include <string.h>
 
+#include <algorithm>
+#include <climits>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -20,6 +22,7 @@
 #include "../../include/splashsurf_hip.h"
 #include "ss_device.h"
 #include "ss_kernels.h"
+#include "ss_global.h"
 
 namespace {
 
@@ -97,6 +100,7 @@ struct ss_context {
     float fastdiv_h = 0.0f;
     bool fastdiv_ok = false;
     bool ev_ok = false;
+    DevBuf gboxes;  // global strategy: stencil boxes per particle chunk
 };
 
 struct ss_result {
@@ -105,6 +109,8 @@ struct ss_result {
     bool is_f64 = false;  // Real type of the reconstruction held by this result
     SSDevT<float> P32;
     SSDevT<double> P64;
+    SSGlobT<float> Q32;   // parameters of the global strategy (valid when global_strategy)
+    SSGlobT<double> Q64;
     ss_grid_f32 grid32, sub32;
     ss_grid_f64 grid64, sub64;
     bool has_inside = false;
@@ -115,6 +121,7 @@ struct ss_result {
     DevBuf nb_ptr, nb_idx, nb_idx64;
     HostBuf h_nb_ptr, h_nb_idx;
     bool hnbp = false, hnbi = false;
+    bool global_strategy = false;  // reconstruct_surface_global ran: subdomain_grid is None, G is dense over grid.n_points
     int phase = 0;  // 0 nothing, 1 after phase_begin, 2 complete
     bool host_input = false;
     uint64_t n_occupied_subdomains = 0, n_subdomain_particles = 0;
@@ -267,10 +274,6 @@ ss_status validate_params(ss_context* ctx, const PRM* prm, uint64_t n) {
     if (!(prm->compact_support_radius > 0.0f)) return fail(ctx, SS_ERR_UNKNOWN, "search radius for neighborhood search has to be positive");
     if (prm->subdomain_num_cubes_per_dim < 1 || prm->subdomain_num_cubes_per_dim > (1u << 20))
         return fail(ctx, SS_ERR_INVALID_ARGUMENT, "subdomain_num_cubes_per_dim out of range");
-    if (prm->decomposition == 0)
-        return fail(ctx, SS_ERR_UNSUPPORTED,
-                    "SpatialDecomposition::None (global strategy, reconstruction.rs:65-112) is not provided by this build; "
-                    "use the uniform-grid decomposition");
     return SS_OK;
 }
 
@@ -439,6 +442,224 @@ ss_status compute_particle_aabb(ss_context* ctx, const R* d_xyz, uint32_t n, R p
     return SS_OK;
 }
 
+// ---- strategy choice (lib.rs:419-462) ----
+template <class R>
+bool use_global_strategy(const typename TypesOf<R>::params* prm, const typename TypesOf<R>::grid& initial) {
+    if (prm->decomposition == 0) return true;  // SpatialDecomposition::None
+    if (!prm->auto_disable) return false;
+    int64_t max_cubes = std::max(initial.n_cells[0], std::max(initial.n_cells[1], initial.n_cells[2]));
+    const uint32_t with_margin = (uint32_t)(1.2 * (double)prm->subdomain_num_cubes_per_dim);
+    const uint32_t mc = max_cubes > (int64_t)UINT32_MAX ? UINT32_MAX : (uint32_t)max_cubes;
+    return !(mc > with_margin);
+}
+
+// ---- global (non-decomposed) strategy: reconstruct_surface_global (reconstruction.rs:65-194), kernels in ss_global.hip ----
+template <class R>
+ss_status reconstruct_global(ss_context* ctx, const typename TypesOf<R>::params* prm, const typename TypesOf<R>::grid& grid, const R* d_xyz, uint32_t n,
+                             bool host_input, ss_result* res) {
+    hipStream_t st = ctx->stream;
+    ss_status s = SS_OK;
+    result_grid<R>(res) = grid;
+    memset(&result_subgrid<R>(res), 0, sizeof(typename TypesOf<R>::grid));
+    res->is_f64 = sizeof(R) == 8;
+    res->global_strategy = true;
+    res->host_input = host_input;
+    res->n_occupied_subdomains = res->n_subdomain_particles = 0;
+    res->n_active = res->n_mc = 0;
+
+    SSGlobT<R> Q;
+    memset(&Q, 0, sizeof(Q));
+    const R h = prm->compact_support_radius, cs = prm->cube_size;
+    double npts_d = 1.0, ncell_d = 1.0;
+    for (int d = 0; d < 3; ++d) {
+        if (grid.n_points[d] > 2000000000ll) return fail(ctx, SS_ERR_GRID_CONSTRUCTION, "too many grid points per dimension", SS_GRID_INDEX_TYPE_TOO_SMALL);
+        Q.gmin[d] = grid.aabb_min[d];
+        Q.np[d] = (int)grid.n_points[d];
+        Q.nc[d] = (int)grid.n_cells[d];
+        npts_d *= (double)grid.n_points[d];
+        ncell_d *= (double)grid.n_cells[d];
+    }
+    if (npts_d >= 2.0e9)
+        return fail(ctx, SS_ERR_UNSUPPORTED,
+                    "global (non-decomposed) strategy: the dense level-set array of this build holds < 2e9 grid points; use the uniform-grid decomposition");
+    Q.cs = cs;
+    Q.h = h;
+    Q.h2 = h * h;
+    Q.sigma = R(8.0) / (h * h * h);
+    Q.w0 = ss_kernel_evaluate(R(0.0), h, Q.sigma);
+    {
+        const R d2 = prm->particle_radius + prm->particle_radius;  // Volume::cube_particle (kernel.rs:28-30)
+        Q.mass = d2 * d2 * d2 * prm->rest_density;
+    }
+    Q.threshold = prm->iso_surface_threshold;
+    Q.n = n;
+    // neighbourhood-search grid over grid.aabb() (neighborhood_search.rs:163-176)
+    typename TypesOf<R>::grid sgrid;
+    if (grid_from_aabb<R>(&sgrid, grid.aabb_min, grid.aabb_max, h) != 0)
+        return fail(ctx, SS_ERR_UNKNOWN, "domain for neighborhood search has to be consistent and not degenerate (reference: assert)");
+    double scell_d = 1.0;
+    for (int d = 0; d < 3; ++d) {
+        Q.smin[d] = sgrid.aabb_min[d];
+        if (sgrid.n_cells[d] > 2000000000ll) return fail(ctx, SS_ERR_UNSUPPORTED, "search grid too large");
+        Q.snc[d] = (int)sgrid.n_cells[d];
+        scell_d *= (double)sgrid.n_cells[d];
+    }
+    if (scell_d >= 4.0e9) return fail(ctx, SS_ERR_UNSUPPORTED, "search grid too large for the dense cell table of this build");
+    // SparseDensityMapGenerator::try_new (density_map.rs:582-640)
+    const R half_real = ss_ceil(h / cs);
+    Q.half_cells = (int)half_real;
+    Q.supported = 2 * Q.half_cells + 2;
+    const R radius = cs * half_real * (R(1.0) + ss_sqrt(std::numeric_limits<R>::epsilon()));
+    Q.radius_sq = radius * radius;
+    const R neg = -radius;
+    bool degenerate = true, consistent = true;
+    for (int d = 0; d < 3; ++d) {
+        Q.amin[d] = grid.aabb_min[d] - neg;  // grow_uniformly(-radius), aabb.rs:257-260
+        Q.amax[d] = grid.aabb_max[d] + neg;
+        degenerate = degenerate && Q.amin[d] == Q.amax[d];
+        consistent = consistent && Q.amin[d] <= Q.amax[d];
+    }
+    if (sizeof(R) == 4)
+        res->Q32 = *reinterpret_cast<SSGlobT<float>*>(&Q);
+    else
+        res->Q64 = *reinterpret_cast<SSGlobT<double>*>(&Q);
+    SS_HIP(ctx, hipEventRecord(ctx->ev[2], st));
+
+    const size_t npts = (size_t)npts_d, ncell = (size_t)ncell_d, nscell = (size_t)scell_d;
+    // ---- neighbourhood search + densities ----
+    SS_HIP(ctx, ctx->counter.reserve(64));
+    SS_HIP(ctx, hipMemsetAsync(ctx->counter.p, 0, 64, st));
+    uint32_t* d_err = ctx->counter.as<uint32_t>();
+    SS_HIP(ctx, res->rho.reserve((size_t)n * sizeof(R) + 16));
+    SS_HIP(ctx, res->perm.reserve((size_t)n * 4 + 16));
+    SS_HIP(ctx, ctx->cell_count.reserve((nscell + 1) * 4));
+    SS_HIP(ctx, ctx->cell_start.reserve((nscell + 1) * 4));
+    SS_HIP(ctx, hipMemsetAsync(ctx->cell_count.p, 0, (nscell + 1) * 4, st));
+    SS_HIP(ctx, res->nb_ptr.reserve(((size_t)n + 1) * 8));
+    res->has_neighbors = true;  // the global strategy always returns the neighbour lists (reconstruction.rs:107-108)
+    res->n_neighbors = 0;
+    if (n > 0) {
+        SS_HIP(ctx, ctx->keys_a.reserve((size_t)n * 4));
+        SS_HIP(ctx, ctx->keys_b.reserve((size_t)n * 4));
+        SS_HIP(ctx, ctx->vals_a.reserve((size_t)n * 4));
+        ssg_launch_cell_keys<R>(Q, d_xyz, ctx->keys_a.as<uint32_t>(), ctx->vals_a.as<uint32_t>(), ctx->cell_count.as<uint32_t>(), d_err, st);
+        s = exclusive_scan_u32<uint32_t>(ctx, ctx->cell_count.as<uint32_t>(), ctx->cell_start.as<uint32_t>(), nscell + 1);
+        if (s != SS_OK) return s;
+        unsigned bits = 1;
+        while (bits < 32 && ((size_t)1 << bits) < nscell) ++bits;
+        size_t bytes = 0;
+        SS_HIP(ctx, rocprim::radix_sort_pairs(nullptr, bytes, ctx->keys_a.as<uint32_t>(), ctx->keys_b.as<uint32_t>(), ctx->vals_a.as<uint32_t>(),
+                                              res->perm.as<uint32_t>(), (size_t)n, 0u, bits, st));
+        SS_HIP(ctx, ctx->temp.reserve(bytes));
+        SS_HIP(ctx, rocprim::radix_sort_pairs(ctx->temp.p, bytes, ctx->keys_a.as<uint32_t>(), ctx->keys_b.as<uint32_t>(), ctx->vals_a.as<uint32_t>(),
+                                              res->perm.as<uint32_t>(), (size_t)n, 0u, bits, st));
+        uint32_t herr = 0;
+        SS_HIP(ctx, hipMemcpyAsync(&herr, d_err, 4, hipMemcpyDeviceToHost, st));
+        SS_HIP(ctx, hipStreamSynchronize(st));
+        if (herr & 1u) return fail(ctx, SS_ERR_UNKNOWN, "particle outside the neighborhood-search grid (reference: panic in get_cell().unwrap())");
+        SS_HIP(ctx, hipEventRecord(ctx->ev[3], st));
+        SS_HIP(ctx, ctx->nb_count.reserve(((size_t)n + 1) * 8));
+        SS_HIP(ctx, ctx->nb_tmp.reserve(((size_t)n + 1) * 8));
+        SS_HIP(ctx, hipMemsetAsync(ctx->nb_count.p, 0, ((size_t)n + 1) * 8, st));
+        ssg_launch_density<R>(Q, d_xyz, ctx->cell_start.as<uint32_t>(), res->perm.as<uint32_t>(), res->rho.as<R>(), 0, ctx->nb_count.as<uint32_t>(), nullptr,
+                              nullptr, st);
+        ss_launch_widen(ctx->nb_count.as<uint32_t>(), (size_t)n + 1, ctx->nb_tmp.as<unsigned long long>(), st);
+        s = exclusive_scan_u32<unsigned long long>(ctx, ctx->nb_tmp.as<unsigned long long>(), res->nb_ptr.as<unsigned long long>(), (size_t)n + 1);
+        if (s != SS_OK) return s;
+        unsigned long long total_nb = 0;
+        SS_HIP(ctx, hipMemcpyAsync(&total_nb, res->nb_ptr.as<unsigned long long>() + n, 8, hipMemcpyDeviceToHost, st));
+        SS_HIP(ctx, hipStreamSynchronize(st));
+        if (total_nb >= (1ull << 32)) return fail(ctx, SS_ERR_UNSUPPORTED, "more than 2^32 neighbour entries");
+        res->n_neighbors = total_nb;
+        SS_HIP(ctx, res->nb_idx.reserve((size_t)total_nb * 4 + 16));
+        ssg_launch_density<R>(Q, d_xyz, ctx->cell_start.as<uint32_t>(), res->perm.as<uint32_t>(), res->rho.as<R>(), 2, nullptr,
+                              res->nb_ptr.as<unsigned long long>(), res->nb_idx.as<uint32_t>(), st);
+    } else {
+        SS_HIP(ctx, hipMemsetAsync(res->nb_ptr.p, 0, 8, st));
+        SS_HIP(ctx, hipEventRecord(ctx->ev[3], st));
+    }
+    SS_HIP(ctx, hipEventRecord(ctx->ev[4], st));
+
+    // ---- sparse density map -> dense level-set array (density_map.rs:364-412) ----
+    if (degenerate || !consistent)
+        return fail(ctx, SS_ERR_DENSITY_MAP,
+                    "the allowed domain of particles is inconsistent/degenerate (DensityMapError::InvalidDomain, density_map.rs:615-627)");
+    const size_t n_chunks = ((size_t)n + SS_GCHUNK - 1) / SS_GCHUNK;
+    const double tiles_d = std::ceil(Q.np[0] / 8.0) * std::ceil(Q.np[1] / 8.0) * std::ceil(Q.np[2] / 8.0);
+    if (tiles_d * (double)n_chunks > 8.0e9)
+        return fail(ctx, SS_ERR_UNSUPPORTED,
+                    "global (non-decomposed) strategy: input too large for this build (level-set tiles x particle chunks > 8e9); "
+                    "use the uniform-grid decomposition, which is the path optimised for large inputs");
+    SS_HIP(ctx, res->G.reserve(npts * sizeof(R) + 16));
+    SS_HIP(ctx, ctx->gboxes.reserve(n_chunks * 6 * sizeof(int) + 16));
+    ssg_launch_chunk_boxes<R>(Q, d_xyz, ctx->gboxes.as<int>(), st);
+    SS_HIP(ctx, hipEventRecord(ctx->ev[5], st));
+    ssg_launch_levelset<R>(Q, d_xyz, res->rho.as<R>(), ctx->gboxes.as<int>(), res->G.as<R>(), st);
+    SS_HIP(ctx, hipEventRecord(ctx->ev[6], st));
+
+    // ---- marching cubes (narrow_band_extraction.rs, triangulation.rs) ----
+    SS_HIP(ctx, res->masks.reserve(npts + 16));
+    SS_HIP(ctx, ctx->vcount.reserve((npts + 1) * 4));
+    SS_HIP(ctx, ctx->tcount.reserve((ncell + 1) * 4));
+    SS_HIP(ctx, res->vbase.reserve((npts + 1) * 4));
+    SS_HIP(ctx, res->tbase.reserve((ncell + 1) * 4));
+    SS_HIP(ctx, hipMemsetAsync(ctx->vcount.as<uint32_t>() + npts, 0, 4, st));
+    SS_HIP(ctx, hipMemsetAsync(ctx->tcount.as<uint32_t>() + ncell, 0, 4, st));
+    ssg_launch_edge_masks<R>(Q, res->G.as<R>(), res->masks.as<uint8_t>(), ctx->vcount.as<uint32_t>(), st);
+    ssg_launch_cell_count<R>(Q, res->G.as<R>(), res->masks.as<uint8_t>(), ctx->tcount.as<uint32_t>(), d_err, st);
+    SS_HIP(ctx, hipEventRecord(ctx->ev[7], st));
+    s = exclusive_scan_u32<uint32_t>(ctx, ctx->vcount.as<uint32_t>(), res->vbase.as<uint32_t>(), npts + 1);
+    if (s != SS_OK) return s;
+    s = exclusive_scan_u32<uint32_t>(ctx, ctx->tcount.as<uint32_t>(), res->tbase.as<uint32_t>(), ncell + 1);
+    if (s != SS_OK) return s;
+    uint32_t totals[2] = {0, 0}, herr = 0;
+    SS_HIP(ctx, hipMemcpyAsync(&totals[0], res->vbase.as<uint32_t>() + npts, 4, hipMemcpyDeviceToHost, st));
+    SS_HIP(ctx, hipMemcpyAsync(&totals[1], res->tbase.as<uint32_t>() + ncell, 4, hipMemcpyDeviceToHost, st));
+    SS_HIP(ctx, hipMemcpyAsync(&herr, d_err, 4, hipMemcpyDeviceToHost, st));
+    SS_HIP(ctx, hipStreamSynchronize(st));
+    if (herr & 2u) return fail(ctx, SS_ERR_MARCHING_CUBES, "missing iso surface vertex at an edge (TriangulationError, triangulation.rs:62-95)");
+    const uint64_t nv = totals[0], nt = totals[1];
+    if (nt * 3 >= (1ull << 32)) return fail(ctx, SS_ERR_UNSUPPORTED, "more than 2^32/3 triangles in one call are not supported by this build");
+    SS_HIP(ctx, res->vertices.reserve(nv * 3 * sizeof(R) + 16));
+    SS_HIP(ctx, res->vkeys.reserve(nv * 8 + 16));
+    SS_HIP(ctx, res->tri32.reserve(nt * 12 + 16));
+    SS_HIP(ctx, hipEventRecord(ctx->ev[8], st));
+    ssg_launch_emit_vertices<R>(Q, res->G.as<R>(), res->masks.as<uint8_t>(), res->vbase.as<uint32_t>(), res->vertices.as<R>(), res->vkeys.as<unsigned long long>(), st);
+    ssg_launch_emit_triangles<R>(Q, res->G.as<R>(), res->masks.as<uint8_t>(), res->vbase.as<uint32_t>(), ctx->tcount.as<uint32_t>(), res->tbase.as<uint32_t>(),
+                                 res->tri32.as<uint32_t>(), st);
+    SS_HIP(ctx, hipEventRecord(ctx->ev[9], st));
+    SS_HIP(ctx, hipStreamSynchronize(st));
+    {
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return fail(ctx, SS_ERR_DEVICE, std::string("kernel launch failed: ") + hipGetErrorString(e));
+    }
+    res->n_vertices = nv;
+    res->n_triangles = nt;
+    ss_stats& S = res->stats;
+    S.ms_total = ev_ms(ctx, 0, 9);
+    S.ms_upload = host_input ? ev_ms(ctx, 0, 1) : 0.0;
+    S.ms_aabb_grid = ev_ms(ctx, 1, 2);
+    S.ms_decomposition = ev_ms(ctx, 2, 3);  // cell -> particle map of the neighbourhood search
+    S.ms_density = ev_ms(ctx, 3, 4);
+    S.ms_levelset_prepare = ev_ms(ctx, 4, 5);
+    S.ms_levelset = ev_ms(ctx, 5, 6);
+    S.ms_marching_cubes = ev_ms(ctx, 6, 7) + ev_ms(ctx, 8, 9);
+    S.ms_stitching = ev_ms(ctx, 7, 8);
+    S.n_particles = n;
+    S.n_vertices = nv;
+    S.n_triangles = nt;
+    S.levelset_kernel_launches = 1;
+    size_t held = 0;
+    for (const DevBuf* b : {&ctx->xyz_in, &ctx->xyz_filt, &ctx->keys_a, &ctx->keys_b, &ctx->vals_a, &ctx->cell_count, &ctx->cell_start, &ctx->temp, &ctx->vcount,
+                            &ctx->tcount, &ctx->gboxes, &ctx->nb_count, &ctx->nb_tmp, &res->rho, &res->perm, &res->inside8, &res->G, &res->masks, &res->vbase,
+                            &res->tbase, &res->vertices, &res->vkeys, &res->tri32, &res->nb_ptr, &res->nb_idx})
+        held += b->cap;
+    S.bytes_device_peak = held;
+    res->valid = true;
+    res->phase = 2;
+    return SS_OK;
+}
+
 template <class R>
 ss_status phase_finish(ss_context* ctx, ss_result* res);
 
@@ -484,6 +705,12 @@ ss_status phase_begin(ss_context* ctx, const R* xyz, uint64_t n_in, const typena
     typename TypesOf<R>::grid initial;
     int gerr = grid_for_reconstruction(prm, shard ? true : (n > 0), pmin, pmax, &initial);
     if (gerr) return fail(ctx, SS_ERR_GRID_CONSTRUCTION, "grid construction failed (uniform_grid.rs:147-169)", gerr);
+    res->global_strategy = false;
+    if (use_global_strategy<R>(prm, initial)) {
+        if (shard)
+            return fail(ctx, SS_ERR_UNSUPPORTED, "the multi-GPU shard extension needs the uniform-grid decomposition (decomposition=1, auto_disable=0)");
+        return reconstruct_global<R>(ctx, prm, initial, d_xyz, n, host_input, res);
+    }
     R mass = 0, margin = 0;
     initialize_subdomain_parameters(prm, &initial, &result_grid<R>(res), &result_subgrid<R>(res), &mass, &margin);
     for (int d = 0; d < 3; ++d)
@@ -765,6 +992,7 @@ template <class R>
 ss_status reconstruct_impl(ss_context* ctx, const R* xyz, uint64_t n_in, const typename TypesOf<R>::params* prm, ss_result* res) {
     ss_status s = phase_begin<R>(ctx, xyz, n_in, prm, nullptr, res);
     if (s != SS_OK) return s;
+    if (res->phase == 2) return SS_OK;  // the global strategy completes in one go
     return phase_finish<R>(ctx, res);
 }
 
@@ -860,6 +1088,25 @@ ss_status levelset_box_impl(ss_result* r, const int64_t lo[3], const int64_t ext
     DevBuf tmp;
     SS_HIP(c, tmp.reserve(tot * sizeof(R)));
     const int l[3] = {(int)lo[0], (int)lo[1], (int)lo[2]}, e[3] = {(int)extent[0], (int)extent[1], (int)extent[2]};
+    if (r->global_strategy) {
+        // dense array over grid.n_points; small by construction, sliced on the host
+        const typename TypesOf<R>::grid& g = result_grid<R>(r);
+        const size_t npts = (size_t)g.n_points[0] * g.n_points[1] * g.n_points[2];
+        std::vector<R> host(npts ? npts : 1);
+        SS_HIP(c, hipMemcpyAsync(host.data(), r->G.p, npts * sizeof(R), hipMemcpyDeviceToHost, c->stream));
+        SS_HIP(c, hipStreamSynchronize(c->stream));
+        for (int64_t x = 0; x < extent[0]; ++x)
+            for (int64_t y = 0; y < extent[1]; ++y)
+                for (int64_t z = 0; z < extent[2]; ++z) {
+                    const int64_t gx = lo[0] + x, gy = lo[1] + y, gz = lo[2] + z;
+                    R v = R(0.0);
+                    if (gx >= 0 && gy >= 0 && gz >= 0 && gx < g.n_points[0] && gy < g.n_points[1] && gz < g.n_points[2])
+                        v = host[((size_t)gx * g.n_points[1] + gy) * g.n_points[2] + gz];
+                    out[((size_t)x * extent[1] + y) * extent[2] + z] = v;
+                }
+        tmp.release();
+        return SS_OK;
+    }
     if (r->n_active == 0) {
         SS_HIP(c, hipMemsetAsync(tmp.p, 0, tot * sizeof(R), c->stream));
     } else {
@@ -1109,7 +1356,7 @@ ss_status ss_result_subdomain_grid_f64(const ss_result* r, ss_grid_f64* out, int
         *out = r->sub64;
     else
         convert_grid(r->sub32, out);
-    *present = 1;
+    *present = r->global_strategy ? 0 : 1;  // None for the global strategy (lib.rs:249-250)
     return SS_OK;
 }
 
@@ -1119,7 +1366,7 @@ ss_status ss_result_subdomain_grid(const ss_result* r, ss_grid_f32* out, int32_t
         convert_grid(r->sub64, out);
     else
         *out = r->sub32;
-    *present = 1;
+    *present = r->global_strategy ? 0 : 1;
     return SS_OK;
 }
 

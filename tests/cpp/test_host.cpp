@@ -66,6 +66,24 @@ int main() {
         CHECK((*s.particle_neighbors)[2].empty());
         CHECK(closed_manifold(s.mesh));
     }
+    // --- the same known answer with the global strategy (test_simple.rs:71-126 runs both), then the auto-disable rule ---
+    {
+        std::vector<Vector3f> particles = {{0.01f, 0.0f, 0.0f}};
+        Parameters p = Parameters::with(1.0f, 1.0f, 1.0f);
+        p.iso_surface_threshold = 0.1f;
+        p.spatial_decomposition.kind = SpatialDecomposition::Kind::None;
+        SurfaceReconstruction s = ctx.reconstruct_surface(particles, p);
+        CHECK(s.mesh.vertices.size() == 6);
+        CHECK(s.mesh.triangles.size() == 8);
+        CHECK(closed_manifold(s.mesh));
+        CHECK(!s.subdomain_grid.has_value());                    // lib.rs:249-250
+        CHECK(s.grid.cells_per_dim[0] == 5 && s.grid.cells_per_dim[1] == 6 && s.grid.aabb.min[0] == -2.0f);  // not padded to subdomains
+        CHECK(s.particle_neighbors.has_value() && s.particle_neighbors->size() == 1);  // always Some for this strategy (reconstruction.rs:107-108)
+        CHECK(std::fabs((*s.particle_densities)[0] - 20371.834f) < 1e-2f);
+        p.spatial_decomposition.kind = SpatialDecomposition::Kind::UniformGrid;  // default auto_disable = true: 6 cells <= 76 -> global
+        SurfaceReconstruction a = ctx.reconstruct_surface(particles, p);
+        CHECK(!a.subdomain_grid.has_value() && a.mesh.vertices.size() == 6);
+    }
     // --- empty input is Ok with an empty mesh (SURVEY 8b edge behaviour) ---
     {
         Parameters p = Parameters::relative(0.025f, 4.0f, 1.0f);
@@ -84,14 +102,6 @@ int main() {
             CHECK(false);
         } catch (const ReconstructionError& e) {
             CHECK(e.variant == ReconstructionError::Variant::Unknown);  // the reference panics here
-        }
-        p = Parameters::relative(0.025f, 4.0f, 1.0f);
-        p.spatial_decomposition.kind = SpatialDecomposition::Kind::None;
-        try {
-            ctx.reconstruct_surface({{0.0f, 0.0f, 0.0f}}, p);
-            CHECK(false);
-        } catch (const ReconstructionError& e) {
-            CHECK(e.variant == ReconstructionError::Variant::Unsupported);
         }
         // particle AABB that excludes everything: Ok, empty mesh, flags all false
         p = Parameters::relative(0.025f, 4.0f, 1.0f);

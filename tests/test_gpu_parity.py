@@ -194,9 +194,6 @@ def test_error_behaviour(gpu_ctx):
     with pytest.raises(SplashsurfError) as e:
         S.reconstruct_surface(pts, particle_radius=0.025, smoothing_length=2.0, cube_size=0.0, context=gpu_ctx)
     assert e.value.status == 4  # the reference panics (density_map.rs:555-559)
-    with pytest.raises(SplashsurfError) as e:
-        S.reconstruct_surface(pts, particle_radius=0.025, smoothing_length=2.0, cube_size=1.0, subdomain_grid=False, context=gpu_ctx)
-    assert e.value.status == 7
     with pytest.raises(TypeError):  # only float32 / float64 arrays, like pysplashsurf (reconstruction.rs:187-206)
         S.reconstruct_surface(pts.astype(np.float16), particle_radius=0.025, smoothing_length=2.0, cube_size=1.0, context=gpu_ctx)
 
@@ -418,3 +415,86 @@ def test_gpu_f64_levelset_bit_identical(gpu_ctx, oracle):
         got = res.levelset_box([s3[0] * 64, s3[1] * 64, s3[2] * 64], [65] * 3)
         assert got.dtype == np.float64
         assert int((got.view(np.uint64) != ref.view(np.uint64)).sum()) == 0
+
+
+# ---- global (non-decomposed) strategy, SURVEY rows A14/A15 ----
+GLOBAL = ["global_kat1", "global_edge_empty", "global_cube_8", "global_cube_2366", "global_cube_2366_auto_disable",
+          "global_cube_2366_aabb", "global_free_particles_125", "global_config1", "global_f64_cube_2366", "global_f64_config1"]
+
+
+def _run_global(gpu_ctx, oracle, g):
+    import splashsurf_amd as S
+    prm = golden_params(g)
+    dt = g["densities"].dtype.type
+    pts = golden_input(g).astype(dt)
+    kw = {}
+    if "aabb_min" in prm:
+        kw = dict(aabb_min=prm["aabb_min"], aabb_max=prm["aabb_max"])
+    res = S.reconstruct_surface(pts, particle_radius=prm["particle_radius"], smoothing_length=prm["smoothing_length"], cube_size=prm["cube_size"],
+                                iso_surface_threshold=prm["iso_surface_threshold"], subdomain_grid=prm.get("subdomain_grid", True),
+                                subdomain_grid_auto_disable=prm.get("subdomain_grid_auto_disable", False), context=gpu_ctx, **kw)
+    okw = {k: np.asarray(v, dt) for k, v in kw.items()}
+    par = oracle.make_params_relative(prm["particle_radius"], prm["smoothing_length"], prm["cube_size"], iso_surface_threshold=prm["iso_surface_threshold"],
+                                      dtype=dt, subdomain_grid=prm.get("subdomain_grid", True),
+                                      subdomain_grid_auto_disable=prm.get("subdomain_grid_auto_disable", False), **okw)
+    return res, oracle.reconstruct_surface(pts, par), dt
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", GLOBAL)
+def test_gpu_global_strategy_bit_identical_to_oracle_and_reference(gpu_ctx, oracle, name):
+    """reconstruct_surface_global on the GPU: densities, neighbour lists, level-set values, vertices (coordinates AND
+    order = ascending edge key) and triangles are bit-identical to the oracle, hence to the reference's sequential path
+    (the goldens come from the reference itself and are checked here as well)."""
+    g = load_golden(name)
+    res, orc, dt = _run_global(gpu_ctx, oracle, g)
+    U = np.uint32 if dt == np.float32 else np.uint64
+    assert orc.used_global_strategy and res.subdomain_grid is None
+    assert list(res.grid.ncells_per_dim) == list(g["n_cells"])
+    assert np.array_equal(np.asarray(res.grid.aabb.min, dtype=dt).view(U), g["grid_min"].view(U))
+    assert np.array_equal(np.asarray(res.grid.aabb.max, dtype=dt).view(U), g["grid_max"].view(U))
+    # reference goldens
+    assert np.array_equal(res.particle_densities.view(U), g["densities"].view(U))
+    ptr, idx = res.particle_neighbors_csr
+    assert np.array_equal(ptr.astype(np.int64), g["row_ptr"]) and np.array_equal(idx.astype(np.int64), g["neighbors"].astype(np.int64))
+    if "inside" in g.files:
+        assert np.array_equal(res.particle_inside_aabb, g["inside"].astype(bool))
+    # oracle: everything bit-identical including order
+    assert np.array_equal(res.vertex_keys, orc.vertex_keys)
+    assert np.array_equal(res.mesh.vertices.view(U), orc.vertices.view(U))
+    assert np.array_equal(res.mesh.triangles, orc.triangles)
+    if orc.global_levelset is not None:
+        npts = [int(x) for x in g["n_points"]]
+        got = res.levelset_box([0, 0, 0], npts)
+        assert int((got.view(U) != orc.global_levelset.view(U)).sum()) == 0
+    # the reference's mesh (hash-map order) under geometric canonicalisation
+    if g["vertices"].shape[0]:
+        cmp = MC.compare_geometric(g["vertices"], g["triangles"], res.mesh.vertices, res.mesh.triangles, g["grid_min"], g["cell_size"], g["n_points"])
+        assert cmp["ids_equal"] and cmp["triangles_equal"] and cmp["max_rel_diff"] == 0.0, cmp
+    else:
+        assert res.mesh.vertices.shape[0] == 0 and res.mesh.triangles.shape[0] == 0
+
+
+@pytest.mark.gpu
+def test_gpu_auto_disable_rule(gpu_ctx):
+    """lib.rs:421-441: decomposition iff max cells per dim > (1.2 n) as u32; default parameters follow the reference (auto_disable on)."""
+    import splashsurf_amd as S
+    pts = golden_input(load_golden("global_cube_2366"))
+    for n_cubes, expect_global in ((64, True), (48, True), (41, False), (16, False)):
+        res = S.reconstruct_surface(pts, particle_radius=0.025, smoothing_length=2.0, cube_size=0.75, subdomain_num_cubes_per_dim=n_cubes, context=gpu_ctx)
+        assert (res.subdomain_grid is None) == expect_global, n_cubes
+        assert MC.mesh_is_closed_manifold(res.mesh.triangles)
+
+
+@pytest.mark.gpu
+def test_gpu_global_strategy_medium_input(gpu_ctx, oracle):
+    """SpatialDecomposition::None on a domain well beyond the auto-disable size (bunny, 127x130x154 cells)."""
+    import splashsurf_amd as S
+    pts = golden_input(load_golden("bunny_7705"))
+    res = S.reconstruct_surface(pts, particle_radius=0.025, smoothing_length=2.0, cube_size=0.5, subdomain_grid=False, context=gpu_ctx)
+    orc = oracle.reconstruct_surface(pts, oracle.make_params_relative(0.025, 2.0, 0.5, subdomain_grid=False))
+    assert np.array_equal(res.particle_densities.view(np.uint32), orc.particle_densities.view(np.uint32))
+    assert np.array_equal(res.vertex_keys, orc.vertex_keys)
+    assert np.array_equal(res.mesh.vertices.view(np.uint32), orc.vertices.view(np.uint32))
+    assert np.array_equal(res.mesh.triangles, orc.triangles)
+    assert res.mesh.vertices.shape[0] == 73638
