@@ -265,6 +265,11 @@ def main():
         gen_global_goldens(rep)
         for k, v in rep.items():
             print(k, v)
+        path = os.path.join(GOLD, "GENERATION_REPORT.json")
+        full = json.load(open(path)) if os.path.exists(path) else {}
+        full.update(rep)
+        with open(path, "w") as f:
+            json.dump(full, f, indent=1, default=lambda o: o.tolist() if hasattr(o, "tolist") else str(o))
         return
     if "--neighbors-only" in sys.argv:
         rep = {}
