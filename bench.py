@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- headline benchmark of the MI355X surface-reconstruction path.
 
-    python bench.py --gpus N --steps K --warmup W [--workload s10m_tank|s1m|s10m_cube|tank_small]
+    python bench.py --gpus N --steps K --warmup W [--workload s10m_tank|s1m|s10m_cube|s40m_tank|tank_small]
 
 A "step" is one full pass of the hot path (ss_reconstruct_surface_f32: binning, densities, level-set
 splat, marching cubes, global numbering) over one batch of synthetic particles that is ALREADY

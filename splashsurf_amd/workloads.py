@@ -45,5 +45,6 @@ WORKLOADS = {
     "s1m": dict(gen=lambda: uniform_cube_particles(1_000_000, 12345), particle_radius=0.01, smoothing_length=2.0, cube_size=1.0),
     "s10m_tank": dict(gen=lambda: tank_particles(1.0), particle_radius=0.005, smoothing_length=2.0, cube_size=0.5),
     "s10m_cube": dict(gen=lambda: uniform_cube_particles(10_000_000, 12346), particle_radius=0.005, smoothing_length=2.0, cube_size=0.5),
+    "s40m_tank": dict(gen=lambda: tank_particles(4.0 ** (1.0 / 3.0)), particle_radius=0.005, smoothing_length=2.0, cube_size=0.5),
     "tank_small": dict(gen=lambda: tank_particles(0.08), particle_radius=0.005, smoothing_length=2.0, cube_size=0.5),
 }
