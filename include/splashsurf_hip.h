@@ -240,6 +240,55 @@ ss_status ss_shard_set_densities(ss_result *res, const float *src, uint64_t n);
 ss_status ss_grid_for_domain_f32(const ss_params_f32 *params, const float domain_min[3], const float domain_max[3],
                                  ss_grid_f32 *grid, ss_grid_f32 *subdomain_grid, float *ghost_margin);
 
+/* =====================================================================================================
+ * Post-processing: the stages of the reference's pipeline that consume the mesh right after the
+ * reconstruction (splashsurf/src/reconstruct.rs:1085-1345).  Every array argument may be a host pointer or an HBM
+ * pointer (e.g. ss_result_device_vertices); HBM pointers are used in place.  Triangles are uint32 triples (the
+ * device-native index type, ss_result_triangles_u32 / ss_result_device_triangles_u32).
+ * ===================================================================================================== */
+
+/* TriMesh3d::vertex_vertex_connectivity (splashsurf_lib/src/mesh.rs:290-306) as CSR: the neighbours of vertex i are
+ * neighbors[row_ptr[i] .. row_ptr[i+1]) in the reference's first-occurrence order.  row_ptr: n_vertices + 1 entries;
+ * neighbors: caller-allocated, capacity 6 * n_triangles always suffices; *n_entries = entries written (or required). */
+ss_status ss_post_vertex_connectivity(ss_context *ctx, uint64_t n_vertices, const uint32_t *triangles, uint64_t n_triangles, uint64_t *row_ptr,
+                                      uint32_t *neighbors, uint64_t neighbors_capacity, uint64_t *n_entries);
+/* TriMesh3d::vertex_normals (mesh.rs:782-796, 868-886): area-weighted, normalised; summation in triangle order */
+ss_status ss_post_vertex_normals_f32(ss_context *ctx, const float *vertices, uint64_t n_vertices, const uint32_t *triangles, uint64_t n_triangles, float *normals);
+ss_status ss_post_vertex_normals_f64(ss_context *ctx, const double *vertices, uint64_t n_vertices, const uint32_t *triangles, uint64_t n_triangles, double *normals);
+/* postprocessing::par_laplacian_smoothing_inplace (splashsurf_lib/src/postprocessing.rs:17-52); weights == NULL: all 1 */
+ss_status ss_post_laplacian_smoothing_f32(ss_context *ctx, float *vertices, uint64_t n_vertices, const uint64_t *row_ptr, const uint32_t *neighbors, uint32_t iterations,
+                                          float beta, const float *weights);
+ss_status ss_post_laplacian_smoothing_f64(ss_context *ctx, double *vertices, uint64_t n_vertices, const uint64_t *row_ptr, const uint32_t *neighbors, uint32_t iterations,
+                                          double beta, const double *weights);
+/* postprocessing::par_laplacian_smoothing_normals_inplace (postprocessing.rs:55-96) */
+ss_status ss_post_smooth_normals_f32(ss_context *ctx, float *normals, uint64_t n_vertices, const uint64_t *row_ptr, const uint32_t *neighbors, uint32_t iterations);
+ss_status ss_post_smooth_normals_f64(ss_context *ctx, double *normals, uint64_t n_vertices, const uint64_t *row_ptr, const uint32_t *neighbors, uint32_t iterations);
+/* distance-weighted neighbour count per particle (splashsurf/src/reconstruct.rs:1189-1204); neighbour lists as CSR with
+ * uint32 indices (ss_result_device_particle_neighbors) */
+ss_status ss_post_weighted_neighbor_counts_f32(ss_context *ctx, const float *xyz, uint64_t n, const uint64_t *nb_row_ptr, const uint32_t *nb_indices, float h, float *out);
+ss_status ss_post_weighted_neighbor_counts_f64(ss_context *ctx, const double *xyz, uint64_t n, const uint64_t *nb_row_ptr, const uint32_t *nb_indices, double h, double *out);
+/* smoothing weights from interpolated counts: clamp, / normalization, smooth-step (reconstruct.rs:1219-1232) */
+ss_status ss_post_smoothing_weights_f32(ss_context *ctx, const float *wnn, uint64_t n, float normalization, float *out);
+ss_status ss_post_smoothing_weights_f64(ss_context *ctx, const double *wnn, uint64_t n, double normalization, double *out);
+/* SphInterpolator::interpolate_{scalar,vector}_quantity (splashsurf_lib/src/sph_interpolation.rs:205-259); dim = 1 or 3.
+ * Sums run over a uniform cell grid (the reference: an rstar R-tree), i.e. same terms, other order: ~1e-6 relative in f32 */
+ss_status ss_post_sph_interpolate_f32(ss_context *ctx, const float *xyz, const float *rho, uint64_t n, float rest_mass, float h, const float *values, int32_t dim,
+                                      const float *points, uint64_t n_points, int32_t first_order_correction, float *out);
+ss_status ss_post_sph_interpolate_f64(ss_context *ctx, const double *xyz, const double *rho, uint64_t n, double rest_mass, double h, const double *values, int32_t dim,
+                                      const double *points, uint64_t n_points, int32_t first_order_correction, double *out);
+/* SphInterpolator::interpolate_normals (sph_interpolation.rs:72-113) */
+ss_status ss_post_sph_normals_f32(ss_context *ctx, const float *xyz, const float *rho, uint64_t n, float rest_mass, float h, const float *points, uint64_t n_points,
+                                  float *out);
+ss_status ss_post_sph_normals_f64(ss_context *ctx, const double *xyz, const double *rho, uint64_t n, double rest_mass, double h, const double *points, uint64_t n_points,
+                                  double *out);
+/* HBM views of the neighbour lists of a reconstruction (NULL when absent): CSR rows (uint64) and uint32 indices */
+ss_status ss_result_device_particle_neighbors(const ss_result *res, const uint64_t **row_ptr, const uint32_t **neighbors, uint64_t *n_particles, uint64_t *n_entries);
+/* copies of the reconstruction's arrays into caller buffers (host or HBM; element type = the result's Real type):
+ * the post-processing stages modify their arrays in place while the ss_result keeps the raw mesh */
+ss_status ss_result_copy_vertices(ss_result *res, void *dst);                  /* n_vertices x 3 */
+ss_status ss_result_copy_triangles_u32(ss_result *res, uint32_t *dst);         /* n_triangles x 3 */
+ss_status ss_result_copy_particle_densities(ss_result *res, void *dst);        /* n_particles */
+
 #ifdef __cplusplus
 }
 #endif

@@ -87,7 +87,7 @@ def build(force=False):
     """Compile the oracle with gcc (no GPU needed)."""
     if force or not os.path.exists(_LIB_PATH) or any(
         os.path.getmtime(os.path.join(_HERE, f)) > os.path.getmtime(_LIB_PATH)
-        for f in ("splash_oracle.c", "splash_oracle.h")
+        for f in ("splash_oracle.c", "splash_post.c", "splash_oracle.h", "splash_oracle_decl.h")
     ):
         subprocess.check_call(["make", "-C", _HERE, "-s", "-B"])
     return _LIB_PATH
@@ -336,3 +336,123 @@ def canonical_mesh(vertices, vertex_keys, triangles):
         t = np.stack([t[rows, amin], t[rows, (amin + 1) % 3], t[rows, (amin + 2) % 3]], axis=1)
         t = t[np.lexsort((t[:, 2], t[:, 1], t[:, 0]))]
     return v, k, t
+
+
+# ---------------------------------------------------------------------------------------------------
+# post-processing oracle (oracle/splash_post.c)
+# ---------------------------------------------------------------------------------------------------
+def _post(name, dtype):
+    L = lib()
+    return getattr(L, ("so64_post_" if np.dtype(dtype) == np.float64 else "so_post_") + name)
+
+
+def _vp(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def post_vertex_connectivity(n_vertices, triangles):
+    """mesh.rs:290-306 -> (row_ptr uint64[V+1], neighbors uint32[M])"""
+    tris = np.ascontiguousarray(triangles, dtype=np.uint64).reshape(-1, 3)
+    row, nb = C.POINTER(C.c_uint64)(), C.POINTER(C.c_uint32)()
+    fn = _post("vertex_connectivity", np.float32)
+    fn.argtypes = [C.c_uint64, C.c_void_p, C.c_uint64, C.POINTER(C.POINTER(C.c_uint64)), C.POINTER(C.POINTER(C.c_uint32))]
+    fn.restype = C.c_int
+    fn(int(n_vertices), _vp(tris), tris.shape[0], C.byref(row), C.byref(nb))
+    free = _post("free", np.float32)
+    free.argtypes = [C.c_void_p]
+    free.restype = None
+    row_np = np.ctypeslib.as_array(row, shape=(int(n_vertices) + 1,)).copy()
+    m = int(row_np[-1])
+    nb_np = np.ctypeslib.as_array(nb, shape=(max(m, 1),)).copy()[:m]
+    free(C.cast(row, C.c_void_p))
+    free(C.cast(nb, C.c_void_p))
+    return row_np, nb_np
+
+
+def post_vertex_normals(vertices, triangles):
+    v = np.ascontiguousarray(vertices)
+    assert v.dtype in (np.float32, np.float64)
+    tris = np.ascontiguousarray(triangles, dtype=np.uint64).reshape(-1, 3)
+    out = np.zeros_like(v)
+    fn = _post("vertex_normals", v.dtype)
+    fn.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p]
+    fn.restype = None
+    fn(_vp(v), v.shape[0], _vp(tris), tris.shape[0], _vp(out))
+    return out
+
+
+def post_laplacian_smoothing(vertices, row_ptr, nbrs, iterations, beta, weights):
+    v = np.ascontiguousarray(vertices).copy()
+    creal = C.c_double if v.dtype == np.float64 else C.c_float
+    row = np.ascontiguousarray(row_ptr, dtype=np.uint64)
+    nb = np.ascontiguousarray(nbrs, dtype=np.uint32)
+    w = np.ascontiguousarray(weights, dtype=v.dtype)
+    fn = _post("laplacian_smoothing", v.dtype)
+    fn.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint32, creal, C.c_void_p]
+    fn.restype = None
+    fn(_vp(v), v.shape[0], _vp(row), _vp(nb), int(iterations), creal(float(v.dtype.type(beta))), _vp(w))
+    return v
+
+
+def post_smooth_normals(normals, row_ptr, nbrs, iterations):
+    nrm = np.ascontiguousarray(normals).copy()
+    row = np.ascontiguousarray(row_ptr, dtype=np.uint64)
+    nb = np.ascontiguousarray(nbrs, dtype=np.uint32)
+    fn = _post("smooth_normals", nrm.dtype)
+    fn.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint32]
+    fn.restype = None
+    fn(_vp(nrm), nrm.shape[0], _vp(row), _vp(nb), int(iterations))
+    return nrm
+
+
+def post_weighted_neighbor_counts(xyz, nb_ptr, nb_idx, h):
+    x = np.ascontiguousarray(xyz)
+    creal = C.c_double if x.dtype == np.float64 else C.c_float
+    ptr = np.ascontiguousarray(nb_ptr, dtype=np.uint64)
+    idx = np.ascontiguousarray(nb_idx, dtype=np.uint64)
+    out = np.zeros(x.shape[0], dtype=x.dtype)
+    fn = _post("weighted_neighbor_counts", x.dtype)
+    fn.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, creal, C.c_void_p]
+    fn.restype = None
+    fn(_vp(x), x.shape[0], _vp(ptr), _vp(idx), creal(float(x.dtype.type(h))), _vp(out))
+    return out
+
+
+def post_smoothing_weights(wnn, normalization):
+    a = np.ascontiguousarray(wnn)
+    creal = C.c_double if a.dtype == np.float64 else C.c_float
+    out = np.zeros_like(a)
+    fn = _post("smoothing_weights", a.dtype)
+    fn.argtypes = [C.c_void_p, C.c_uint64, creal, C.c_void_p]
+    fn.restype = None
+    fn(_vp(a), a.shape[0], creal(float(a.dtype.type(normalization))), _vp(out))
+    return out
+
+
+def post_sph_interpolate(xyz, rho, rest_mass, h, values, points, first_order_correction):
+    x = np.ascontiguousarray(xyz)
+    creal = C.c_double if x.dtype == np.float64 else C.c_float
+    r = np.ascontiguousarray(rho, dtype=x.dtype)
+    vals = np.ascontiguousarray(values, dtype=x.dtype)
+    dim = 1 if vals.ndim == 1 else int(vals.shape[1])
+    pts = np.ascontiguousarray(points, dtype=x.dtype)
+    out = np.zeros((pts.shape[0],) if dim == 1 else (pts.shape[0], dim), dtype=x.dtype)
+    fn = _post("sph_interpolate", x.dtype)
+    fn.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, creal, creal, C.c_void_p, C.c_int, C.c_void_p, C.c_uint64, C.c_int, C.c_void_p]
+    fn.restype = None
+    fn(_vp(x), _vp(r), x.shape[0], creal(float(x.dtype.type(rest_mass))), creal(float(x.dtype.type(h))), _vp(vals), dim, _vp(pts), pts.shape[0],
+       1 if first_order_correction else 0, _vp(out))
+    return out
+
+
+def post_sph_normals(xyz, rho, rest_mass, h, points):
+    x = np.ascontiguousarray(xyz)
+    creal = C.c_double if x.dtype == np.float64 else C.c_float
+    r = np.ascontiguousarray(rho, dtype=x.dtype)
+    pts = np.ascontiguousarray(points, dtype=x.dtype)
+    out = np.zeros_like(pts)
+    fn = _post("sph_normals", x.dtype)
+    fn.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, creal, creal, C.c_void_p, C.c_uint64, C.c_void_p]
+    fn.restype = None
+    fn(_vp(x), _vp(r), x.shape[0], creal(float(x.dtype.type(rest_mass))), creal(float(x.dtype.type(h))), _vp(pts), pts.shape[0], _vp(out))
+    return out

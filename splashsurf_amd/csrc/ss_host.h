@@ -1,0 +1,145 @@
+// ss_host.h -- host-side state shared by the translation units of libsplashsurf_hip.so (ss_api.hip, ss_post.hip):
+// grow-only device/pinned buffers, the context (= the reference's thread pool + workspace.rs) and the result object.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <string>
+
+#include "../../include/splashsurf_hip.h"
+#include "ss_device.h"
+#include "ss_global.h"
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    hipError_t reserve(size_t bytes) {
+        if (bytes <= cap) return hipSuccess;
+        if (p) {
+            hipError_t e = hipFree(p);
+            p = nullptr;
+            cap = 0;
+            if (e != hipSuccess) return e;
+        }
+        size_t want = bytes + bytes / 8 + 256;
+        hipError_t e = hipMalloc(&p, want);
+        if (e != hipSuccess) {
+            p = nullptr;
+            return e;
+        }
+        cap = want;
+        return hipSuccess;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+    template <class T>
+    T* as() const {
+        return reinterpret_cast<T*>(p);
+    }
+};
+
+struct HostBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    hipError_t reserve(size_t bytes) {
+        if (bytes <= cap) return hipSuccess;
+        if (p) (void)hipHostFree(p);
+        p = nullptr;
+        cap = 0;
+        size_t want = bytes + bytes / 8 + 256;
+        hipError_t e = hipHostMalloc(&p, want, hipHostMallocDefault);
+        if (e != hipSuccess) {
+            p = nullptr;
+            return e;
+        }
+        cap = want;
+        return hipSuccess;
+    }
+    void release() {
+        if (p) (void)hipHostFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+};
+
+struct ss_context {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipStream_t own_stream = nullptr;
+    std::string err;
+    int err_detail = 0;
+    // scratch (grow-only, reused across calls = the reference's workspace.rs)
+    DevBuf xyz_in, xyz_filt, flags32, offsets, keys_a, keys_b, vals_a, cell_count, cell_start, pos_sorted, temp, aabb_partial, aabb_out,
+        block_flag, block_rank, mc_flag, mc_rank, vcount, tcount, counter;
+    // per-subdomain particle copies for the density stage
+    DevBuf nb_count, nb_tmp;
+    DevBuf member_count, copy_offset, sub_flag, sub_rank, occ_sub, ckeys_a, ckeys_b, cvals_a, cidx, cpos, cell_count2, cell_start2;
+    hipEvent_t ev[12];  // 0..9 stage boundaries, 10/11 start of phase 2
+    // exhaustively verified "division by h via reciprocal + 2 FMA" (ss_kernels.hip ss_div_by_h)
+    float fastdiv_h = 0.0f;
+    bool fastdiv_ok = false;
+    bool ev_ok = false;
+    DevBuf gboxes;  // global strategy: stencil boxes per particle chunk
+};
+
+struct ss_result {
+    ss_context* ctx = nullptr;
+    bool valid = false;
+    bool is_f64 = false;  // Real type of the reconstruction held by this result
+    SSDevT<float> P32;
+    SSDevT<double> P64;
+    SSGlobT<float> Q32;   // parameters of the global strategy (valid when global_strategy)
+    SSGlobT<double> Q64;
+    ss_grid_f32 grid32, sub32;
+    ss_grid_f64 grid64, sub64;
+    bool has_inside = false;
+    uint64_t n_input = 0, n_particles = 0, n_vertices = 0, n_triangles = 0;
+    uint32_t n_active = 0, n_mc = 0;
+    bool has_neighbors = false;
+    uint64_t n_neighbors = 0;
+    DevBuf nb_ptr, nb_idx, nb_idx64;
+    HostBuf h_nb_ptr, h_nb_idx;
+    bool hnbp = false, hnbi = false;
+    bool global_strategy = false;  // reconstruct_surface_global ran: subdomain_grid is None, G is dense over grid.n_points
+    int phase = 0;  // 0 nothing, 1 after phase_begin, 2 complete
+    bool host_input = false;
+    uint64_t n_occupied_subdomains = 0, n_subdomain_particles = 0;
+    ss_stats stats;
+    // device results
+    DevBuf rho, posvol, perm, inside8, G, blk_minmax, block_slot, active_list, mc_list, mc_slot, masks, vbase, tbase, vertices, vkeys, tri32, tri64;
+    // host mirrors
+    HostBuf h_vertices, h_tri64, h_tri32, h_rho, h_vkeys, h_inside;
+    bool hv = false, ht64 = false, ht32 = false, hrho = false, hkeys = false, hinside = false;
+};
+
+#define SS_HIP(ctx, call)                                                                              \
+    do {                                                                                               \
+        hipError_t _e = (call);                                                                        \
+        if (_e != hipSuccess) {                                                                        \
+            (ctx)->err = std::string("HIP error: ") + hipGetErrorString(_e) + " at " #call;            \
+            (void)hipGetLastError();                                                                   \
+            return SS_ERR_DEVICE;                                                                      \
+        }                                                                                              \
+    } while (0)
+
+inline ss_status fail(ss_context* ctx, ss_status st, const std::string& msg, int detail = 0) {
+    if (ctx) {
+        ctx->err = msg;
+        ctx->err_detail = detail;
+    }
+    return st;
+}
+
+
+inline bool is_device_pointer(const void* p) {
+    hipPointerAttribute_t attr;
+    hipError_t e = hipPointerGetAttributes(&attr, p);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        return false;
+    }
+    return attr.type == hipMemoryTypeDevice || attr.type == hipMemoryTypeManaged;
+}

@@ -1,0 +1,397 @@
+"""Post-processing on the GPU: the Python mirror of the reference's post-processing API.
+
+Names and argument meaning follow pysplashsurf (citations relative to /root/reference/):
+
+    TriMesh3d.vertex_vertex_connectivity / vertex_normals_parallel   pysplashsurf/src/mesh.rs, splashsurf_lib/src/mesh.rs:290-306, 868-953
+    laplacian_smoothing_parallel                                      pysplashsurf/src/postprocessing.rs:111-164
+    laplacian_smoothing_normals_parallel                              pysplashsurf/src/postprocessing.rs:166-210
+    SphInterpolator                                                   pysplashsurf/src/sph_interpolation.rs, splashsurf_lib/src/sph_interpolation.rs
+    reconstruction_pipeline                                           pysplashsurf/src/pipeline.rs:162-340, splashsurf/src/reconstruct.rs:1022-1345
+
+All compute runs in libsplashsurf_hip.so (csrc/ss_post.hip) through the `ss_post_*` C ABI; there is no CPU fallback.
+Arrays may be numpy arrays (staged by the library) or CUDA/HIP torch tensors (used in place, zero copy).
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import api
+
+_configured = False
+
+
+def _lib():
+    global _configured
+    L = api.load_library()
+    if not _configured:
+        vp, u64, u32, i32, f32, f64 = C.c_void_p, C.c_uint64, C.c_uint32, C.c_int32, C.c_float, C.c_double
+        L.ss_post_vertex_connectivity.argtypes = [vp, u64, vp, u64, vp, vp, u64, C.POINTER(u64)]
+        for suf, real in (("_f32", f32), ("_f64", f64)):
+            getattr(L, "ss_post_vertex_normals" + suf).argtypes = [vp, vp, u64, vp, u64, vp]
+            getattr(L, "ss_post_laplacian_smoothing" + suf).argtypes = [vp, vp, u64, vp, vp, u32, real, vp]
+            getattr(L, "ss_post_smooth_normals" + suf).argtypes = [vp, vp, u64, vp, vp, u32]
+            getattr(L, "ss_post_weighted_neighbor_counts" + suf).argtypes = [vp, vp, u64, vp, vp, real, vp]
+            getattr(L, "ss_post_smoothing_weights" + suf).argtypes = [vp, vp, u64, real, vp]
+            getattr(L, "ss_post_sph_interpolate" + suf).argtypes = [vp, vp, vp, u64, real, real, vp, i32, vp, u64, i32, vp]
+            getattr(L, "ss_post_sph_normals" + suf).argtypes = [vp, vp, vp, u64, real, real, vp, u64, vp]
+        L.ss_result_device_particle_neighbors.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(u64), C.POINTER(u64)]
+        L.ss_result_copy_vertices.argtypes = [vp, vp]
+        L.ss_result_copy_triangles_u32.argtypes = [vp, vp]
+        L.ss_result_copy_particle_densities.argtypes = [vp, vp]
+        _configured = True
+    return L
+
+
+def _is_tensor(a):
+    return type(a).__module__.startswith("torch")
+
+
+def _ptr(a):
+    """Raw pointer of a contiguous numpy array or torch tensor (None -> NULL)."""
+    if a is None:
+        return None
+    if _is_tensor(a):
+        assert a.is_contiguous()
+        return C.c_void_p(a.data_ptr())
+    assert a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _np_dtype(a):
+    if _is_tensor(a):
+        import torch
+        return {torch.float32: np.float32, torch.float64: np.float64, torch.uint32: np.uint32, torch.int32: np.int32, torch.int64: np.int64,
+                torch.uint64: np.uint64}[a.dtype]
+    return a.dtype.type
+
+
+def _real_suffix(a):
+    dt = _np_dtype(a)
+    if dt == np.float32:
+        return "_f32", C.c_float
+    if dt == np.float64:
+        return "_f64", C.c_double
+    raise TypeError("float32 or float64 arrays expected, got %r" % (dt,))
+
+
+def _as_real(a, like=None):
+    """contiguous float array: tensors pass through, everything else becomes numpy (dtype of `like` if given)."""
+    if _is_tensor(a):
+        return a.contiguous()
+    a = np.asarray(a)
+    dt = _np_dtype(like) if like is not None else (a.dtype.type if a.dtype in (np.float32, np.float64) else None)
+    if dt is None:
+        raise TypeError("float32 or float64 arrays expected, got %r" % (a.dtype,))
+    return np.ascontiguousarray(a, dtype=dt)
+
+
+def _empty_like(a, shape):
+    if _is_tensor(a):
+        import torch
+        return torch.empty(shape, dtype=a.dtype, device=a.device)
+    return np.empty(shape, dtype=a.dtype)
+
+
+def _tris_u32(t):
+    if _is_tensor(t):
+        import torch
+        assert t.dtype in (torch.int32, torch.uint32), "device triangles must be 32-bit"
+        return t.contiguous()
+    t = np.asarray(t)
+    if t.size and int(t.max()) >= 2 ** 32:
+        raise ValueError("vertex index does not fit 32 bits")
+    return np.ascontiguousarray(t, dtype=np.uint32).reshape(-1, 3)
+
+
+def _ctx(context):
+    return context if context is not None else api.default_context()
+
+
+def _check(ctx, st):
+    if st != 0:
+        ctx._raise(st)
+
+
+class VertexVertexConnectivity:
+    """CSR form of `Vec<Vec<usize>>` returned by TriMesh3d::vertex_vertex_connectivity (mesh.rs:290-306)."""
+
+    def __init__(self, row_ptr, neighbors):
+        self.row_ptr = row_ptr      # uint64[V+1]
+        self.neighbors = neighbors  # uint32[M]
+
+    def _host(self):
+        row = self.row_ptr.cpu().numpy() if _is_tensor(self.row_ptr) else self.row_ptr
+        nb = self.neighbors.cpu().numpy() if _is_tensor(self.neighbors) else self.neighbors
+        return row.astype(np.int64), nb
+
+    def copy_connectivity(self):
+        row, nb = self._host()
+        return [nb[row[i]:row[i + 1]].astype(np.uint64) for i in range(row.size - 1)]
+
+    take_connectivity = copy_connectivity
+
+
+def vertex_vertex_connectivity(n_vertices, triangles, context=None):
+    """TriMesh3d::vertex_vertex_connectivity: neighbours in the reference's first-occurrence order."""
+    ctx = _ctx(context)
+    L = _lib()
+    t = _tris_u32(triangles)
+    nt = int(t.shape[0])
+    nv = int(n_vertices)
+    cap = max(6 * nt, 1)
+    if _is_tensor(t):
+        import torch
+        row = torch.empty(nv + 1, dtype=torch.int64, device=t.device)
+        nb = torch.empty(cap, dtype=torch.int32, device=t.device)
+    else:
+        row = np.empty(nv + 1, dtype=np.uint64)
+        nb = np.empty(cap, dtype=np.uint32)
+    n_entries = C.c_uint64()
+    _check(ctx, L.ss_post_vertex_connectivity(ctx._h, nv, _ptr(t), nt, _ptr(row), _ptr(nb), cap, C.byref(n_entries)))
+    return VertexVertexConnectivity(row, nb[:int(n_entries.value)])
+
+
+def vertex_normals(vertices, triangles, context=None):
+    """TriMesh3d::vertex_normals (area-weighted, normalised; sequential summation order of mesh.rs:782-796)."""
+    ctx = _ctx(context)
+    L = _lib()
+    v = _as_real(vertices)
+    t = _tris_u32(triangles)
+    suf, _ = _real_suffix(v)
+    out = _empty_like(v, tuple(v.shape))
+    _check(ctx, getattr(L, "ss_post_vertex_normals" + suf)(ctx._h, _ptr(v), int(v.shape[0]), _ptr(t), int(t.shape[0]), _ptr(out)))
+    return out
+
+
+class TriMesh3d:
+    """TriMesh3d of pysplashsurf: `.vertices` (V,3 float), `.triangles` (T,3 uint64)."""
+
+    def __init__(self, vertices, triangles, context=None):
+        self.vertices = vertices
+        self.triangles = triangles
+        self._context = context
+
+    @property
+    def dtype(self):
+        return np.dtype(_np_dtype(self.vertices))
+
+    def copy(self):
+        v = self.vertices.clone() if _is_tensor(self.vertices) else np.array(self.vertices, copy=True)
+        t = self.triangles.clone() if _is_tensor(self.triangles) else np.array(self.triangles, copy=True)
+        return TriMesh3d(v, t, self._context)
+
+    def vertex_vertex_connectivity(self):
+        return vertex_vertex_connectivity(int(self.vertices.shape[0]), self.triangles, self._context)
+
+    def vertex_normals_parallel(self):
+        return vertex_normals(self.vertices, self.triangles, self._context)
+
+
+def laplacian_smoothing_parallel(mesh, vertex_connectivity, *, iterations, beta=1.0, weights, context=None):
+    """Laplacian smoothing of mesh vertices with feature weights, in place (postprocessing.rs:17-52)."""
+    ctx = _ctx(context if context is not None else getattr(mesh, "_context", None))
+    L = _lib()
+    v = mesh.vertices
+    if not _is_tensor(v):
+        if not (isinstance(v, np.ndarray) and v.flags["C_CONTIGUOUS"] and v.flags["WRITEABLE"] and v.dtype in (np.float32, np.float64)):
+            v = np.array(v, dtype=v.dtype if getattr(v, "dtype", None) in (np.float32, np.float64) else np.float32, order="C")
+            mesh.vertices = v
+    suf, real = _real_suffix(v)
+    w = None if weights is None else _as_real(weights, like=v)
+    beta = float(_np_dtype(v)(beta))
+    _check(ctx, getattr(L, "ss_post_laplacian_smoothing" + suf)(ctx._h, _ptr(v), int(v.shape[0]), _ptr(vertex_connectivity.row_ptr), _ptr(vertex_connectivity.neighbors),
+                                                                int(iterations), real(beta), _ptr(w)))
+
+
+def laplacian_smoothing_normals_parallel(normals, vertex_connectivity, *, iterations, context=None):
+    """Laplacian smoothing of a normal field, in place (postprocessing.rs:55-96)."""
+    ctx = _ctx(context)
+    L = _lib()
+    suf, _ = _real_suffix(normals)
+    if not _is_tensor(normals):
+        assert normals.flags["C_CONTIGUOUS"] and normals.flags["WRITEABLE"]
+    _check(ctx, getattr(L, "ss_post_smooth_normals" + suf)(ctx._h, _ptr(normals), int(normals.shape[0]), _ptr(vertex_connectivity.row_ptr),
+                                                           _ptr(vertex_connectivity.neighbors), int(iterations)))
+
+
+class SphInterpolator:
+    """SphInterpolator(particle_positions, particle_densities, particle_rest_mass, compact_support_radius)."""
+
+    def __init__(self, particle_positions, particle_densities, particle_rest_mass, compact_support_radius, context=None):
+        self._ctx = _ctx(context)
+        self._x = _as_real(particle_positions)
+        self._rho = _as_real(particle_densities, like=self._x)
+        if int(self._x.shape[0]) != int(self._rho.shape[0]):
+            raise ValueError("one density value per particle is required")
+        dt = _np_dtype(self._x)
+        self._mass = float(dt(particle_rest_mass))
+        self._h = float(dt(compact_support_radius))
+
+    def interpolate_normals(self, interpolation_points):
+        L = _lib()
+        p = _as_real(interpolation_points, like=self._x)
+        suf, real = _real_suffix(self._x)
+        out = _empty_like(p, tuple(p.shape))
+        _check(self._ctx, getattr(L, "ss_post_sph_normals" + suf)(self._ctx._h, _ptr(self._x), _ptr(self._rho), int(self._x.shape[0]), real(self._mass), real(self._h),
+                                                                  _ptr(p), int(p.shape[0]), _ptr(out)))
+        return out
+
+    def interpolate_quantity(self, particle_quantity, interpolation_points, *, first_order_correction=False):
+        L = _lib()
+        q = _as_real(particle_quantity, like=self._x)
+        p = _as_real(interpolation_points, like=self._x)
+        if int(q.shape[0]) != int(self._x.shape[0]):
+            raise ValueError("one value per particle is required")
+        dim = 1 if len(q.shape) == 1 else int(q.shape[1])
+        suf, real = _real_suffix(self._x)
+        out = _empty_like(p, (int(p.shape[0]),) if dim == 1 else (int(p.shape[0]), dim))
+        _check(self._ctx, getattr(L, "ss_post_sph_interpolate" + suf)(self._ctx._h, _ptr(self._x), _ptr(self._rho), int(self._x.shape[0]), real(self._mass),
+                                                                      real(self._h), _ptr(q), dim, _ptr(p), int(p.shape[0]), 1 if first_order_correction else 0,
+                                                                      _ptr(out)))
+        return out
+
+
+def weighted_neighbor_counts(particle_positions, nb_row_ptr, nb_indices_u32, compact_support_radius, context=None):
+    """Distance-weighted neighbour count per particle (splashsurf/src/reconstruct.rs:1189-1204)."""
+    ctx = _ctx(context)
+    L = _lib()
+    x = _as_real(particle_positions)
+    suf, real = _real_suffix(x)
+    out = _empty_like(x, (int(x.shape[0]),))
+    h = float(_np_dtype(x)(compact_support_radius))
+    _check(ctx, getattr(L, "ss_post_weighted_neighbor_counts" + suf)(ctx._h, _ptr(x), int(x.shape[0]), nb_row_ptr if isinstance(nb_row_ptr, C.c_void_p) else _ptr(nb_row_ptr),
+                                                                     nb_indices_u32 if isinstance(nb_indices_u32, C.c_void_p) else _ptr(nb_indices_u32), real(h), _ptr(out)))
+    return out
+
+
+def smoothing_weights(vertex_weighted_num_neighbors, normalization=13.0, context=None):
+    """Smooth-step of the normalised, interpolated neighbour counts (splashsurf/src/reconstruct.rs:1219-1232)."""
+    ctx = _ctx(context)
+    L = _lib()
+    a = _as_real(vertex_weighted_num_neighbors)
+    suf, real = _real_suffix(a)
+    out = _empty_like(a, tuple(a.shape))
+    _check(ctx, getattr(L, "ss_post_smoothing_weights" + suf)(ctx._h, _ptr(a), int(a.shape[0]), real(float(_np_dtype(a)(normalization))), _ptr(out)))
+    return out
+
+
+class MeshWithData:
+    """MeshWithData of pysplashsurf: `.mesh` plus named per-vertex attributes."""
+
+    def __init__(self, mesh):
+        self.mesh = mesh
+        self.point_attributes = {}
+        self.cell_attributes = {}
+
+    @property
+    def nvertices(self):
+        return int(self.mesh.vertices.shape[0])
+
+    @property
+    def ncells(self):
+        return int(self.mesh.triangles.shape[0])
+
+
+_UNSUPPORTED = dict(check_mesh_closed=False, check_mesh_manifold=False, check_mesh_orientation=False, check_mesh_debug=False, mesh_cleanup=False,
+                    mesh_cleanup_snap_dist=None, decimate_barnacles=False, keep_vertices=False, generate_quads=False, mesh_aabb_min=None, mesh_aabb_max=None)
+
+
+def reconstruction_pipeline(particles, *, attributes_to_interpolate=None, particle_radius, rest_density=1000.0, smoothing_length, cube_size,
+                            iso_surface_threshold=0.6, aabb_min=None, aabb_max=None, multi_threading=True, simd=True, subdomain_grid=True,
+                            subdomain_grid_auto_disable=True, subdomain_num_cubes_per_dim=64, compute_normals=False, sph_normals=False,
+                            normals_smoothing_iters=None, mesh_smoothing_iters=None, mesh_smoothing_weights=True,
+                            mesh_smoothing_weights_normalization=13.0, output_mesh_smoothing_weights=False, output_raw_normals=False,
+                            output_raw_mesh=False, quad_max_edge_diag_ratio=1.75, quad_max_normal_angle=10.0, quad_max_interior_angle=135.0,
+                            mesh_aabb_clamp_vertices=True, context=None, **unsupported):
+    """pysplashsurf.reconstruction_pipeline (splashsurf/src/reconstruct.rs:1022-1345): reconstruction followed by the
+    post-processing stages provided on the GPU -- smoothing weights, weighted Laplacian smoothing, normals (mesh or
+    SPH), normal smoothing, attribute interpolation.  The mesh stays in HBM between the stages.  Mesh cleanup,
+    barnacle decimation, quad conversion, AABB clamping and the mesh checks are not provided and raise.
+    Returns (MeshWithData, SurfaceReconstruction) with numpy arrays."""
+    import torch
+    for k, v in unsupported.items():
+        if k not in _UNSUPPORTED:
+            raise TypeError("unexpected keyword argument %r" % k)
+        if v != _UNSUPPORTED[k]:
+            raise NotImplementedError("post-processing option %r is not provided by this build" % k)
+    ctx = _ctx(context)
+    L = _lib()
+    p = np.asarray(particles)
+    if p.dtype not in (np.float32, np.float64):
+        raise TypeError("particles must be a float32 or float64 array")
+    p = np.ascontiguousarray(p).reshape(-1, 3)
+    dt = p.dtype.type
+    tdt = torch.float32 if dt == np.float32 else torch.float64
+    dev = torch.device("cuda", ctx.device_id)
+    # reconstruct.rs:1029-1034: neighbour lists are needed for the smoothing weights
+    rec = api.reconstruct_surface(p, particle_radius=particle_radius, rest_density=rest_density, smoothing_length=smoothing_length, cube_size=cube_size,
+                                  iso_surface_threshold=iso_surface_threshold, aabb_min=aabb_min, aabb_max=aabb_max, multi_threading=multi_threading,
+                                  simd=simd, global_neighborhood_list=bool(mesh_smoothing_weights), subdomain_grid=subdomain_grid,
+                                  subdomain_grid_auto_disable=subdomain_grid_auto_disable, subdomain_num_cubes_per_dim=subdomain_num_cubes_per_dim, context=ctx)
+    nv, nt = rec.counts()
+    # the mesh in HBM (the stages work in place; the reconstruction keeps the raw mesh)
+    d_v = torch.empty((nv, 3), dtype=tdt, device=dev)
+    d_t = torch.empty((nt, 3), dtype=torch.int32, device=dev)
+    _check(ctx, L.ss_result_copy_vertices(rec._h, _ptr(d_v)))
+    _check(ctx, L.ss_result_copy_triangles_u32(rec._h, _ptr(d_t)))
+    mesh_with_data = MeshWithData(None)
+    raw_vertices = rec.mesh.vertices if output_raw_mesh else None
+
+    attrs = dict(attributes_to_interpolate or {})
+    interpolator_required = bool(mesh_smoothing_weights) or bool(sph_normals) or bool(attrs)
+    inside = rec.particle_inside_aabb
+    interp = None
+    d_x = None
+    h = dt(2.0 * float(smoothing_length) * float(particle_radius))  # compact support radius as the binding forms it
+    if interpolator_required:
+        filtered = p if inside is None else np.ascontiguousarray(p[inside])
+        d_x = torch.from_numpy(filtered).to(dev)
+        d_rho = torch.empty((int(filtered.shape[0]),), dtype=tdt, device=dev)
+        _check(ctx, L.ss_result_copy_particle_densities(rec._h, _ptr(d_rho)))
+        # reconstruct.rs:1126-1129: sphere volume here (the reconstruction itself uses the cube volume)
+        r = dt(particle_radius)
+        rest_volume = dt(4.0) * dt(np.pi / 3.0) * (r * r * r)
+        rest_mass = rest_volume * dt(rest_density)
+        interp = SphInterpolator(d_x, d_rho, rest_mass, h, context=ctx)
+
+    connectivity = None
+    if normals_smoothing_iters is not None or mesh_smoothing_iters is not None:
+        connectivity = vertex_vertex_connectivity(nv, d_t, ctx)
+
+    weights = None
+    if mesh_smoothing_weights:
+        row, idx, n_p, n_e = C.c_void_p(), C.c_void_p(), C.c_uint64(), C.c_uint64()
+        _check(ctx, L.ss_result_device_particle_neighbors(rec._h, C.byref(row), C.byref(idx), C.byref(n_p), C.byref(n_e)))
+        wnc = weighted_neighbor_counts(d_x, row, idx if idx.value else C.c_void_p(0), h, ctx) if int(n_p.value) else torch.empty((0,), dtype=tdt, device=dev)
+        vertex_wnn = interp.interpolate_quantity(wnc, d_v, first_order_correction=True)
+        weights = smoothing_weights(vertex_wnn, mesh_smoothing_weights_normalization, ctx)
+        if output_mesh_smoothing_weights:
+            mesh_with_data.point_attributes["wnn"] = vertex_wnn.cpu().numpy()
+            mesh_with_data.point_attributes["sw"] = weights.cpu().numpy()
+
+    d_mesh = TriMesh3d(d_v, d_t, ctx)
+    if mesh_smoothing_iters is not None:
+        laplacian_smoothing_parallel(d_mesh, connectivity, iterations=int(mesh_smoothing_iters), beta=1.0, weights=weights, context=ctx)
+
+    if compute_normals:
+        normals = interp.interpolate_normals(d_v) if sph_normals else vertex_normals(d_v, d_t, ctx)
+        if normals_smoothing_iters is not None:
+            smoothed = normals.clone()
+            laplacian_smoothing_normals_parallel(smoothed, connectivity, iterations=int(normals_smoothing_iters), context=ctx)
+            mesh_with_data.point_attributes["normals"] = smoothed.cpu().numpy()
+            if output_raw_normals:
+                mesh_with_data.point_attributes["raw_normals"] = normals.cpu().numpy()
+        else:
+            mesh_with_data.point_attributes["normals"] = normals.cpu().numpy()
+
+    for name, values in attrs.items():
+        vals = np.asarray(values)
+        if vals.dtype == np.uint64:
+            raise NotImplementedError("interpolation of u64 attributes is unimplemented in the reference as well (reconstruct.rs:1383)")
+        vals = np.ascontiguousarray(vals if inside is None else vals[inside], dtype=dt)
+        mesh_with_data.point_attributes[name] = interp.interpolate_quantity(torch.from_numpy(vals).to(dev), d_v, first_order_correction=True).cpu().numpy()
+
+    mesh_with_data.mesh = TriMesh3d(d_v.cpu().numpy(), d_t.cpu().numpy().astype(np.uint32).astype(np.uint64), ctx)
+    if output_raw_mesh:
+        mesh_with_data.raw_vertices = raw_vertices
+    return mesh_with_data, rec

@@ -252,6 +252,95 @@ def gen_global_goldens(report):
         report[name] = cmp
 
 
+def gen_post_goldens(report):
+    """Post-processing stages.  Stage goldens hold the reference's own mesh (its vertex / triangle order
+    matters for connectivity and summation order) and the outputs of the reference functions on it; the oracle
+    (oracle/splash_post.c) is checked while generating: connectivity / smoothing / normal smoothing bit-identical,
+    vertex normals and SPH interpolation within the documented tolerances."""
+    cases = [("post_cube_2366", "cube_2366_particles.npy", 0.025, 2.0, 0.75, np.float32),
+             ("post_f64_cube_2366", "cube_2366_particles.npy", 0.025, 2.0, 0.75, np.float64)]
+    for name, fn, r, l, c, dt in cases:
+        U = np.uint32 if dt == np.float32 else np.uint64
+        tol = 2e-6 if dt == np.float32 else 1e-14
+        pts = np.ascontiguousarray(np.load(os.path.join(DATA, fn)).astype(np.float32), dtype=dt)
+        res = pysplashsurf.reconstruct_surface(pts, particle_radius=r, smoothing_length=l, cube_size=c, simd=False, subdomain_grid=True,
+                                               subdomain_grid_auto_disable=False, global_neighborhood_list=True)
+        mesh = res.mesh
+        V = np.asarray(mesh.vertices).copy()
+        T = np.asarray(mesh.triangles).copy()
+        rho = np.asarray(res.particle_densities).copy()
+        nl = res.particle_neighbors.get_neighborhood_lists()
+        nb_ptr = np.concatenate([[0], np.cumsum([len(x) for x in nl])]).astype(np.uint64)
+        nb_idx = np.concatenate([np.asarray(x, dtype=np.uint64) for x in nl])
+        conn = mesh.vertex_vertex_connectivity()
+        lists = conn.copy_connectivity()
+        row = np.concatenate([[0], np.cumsum([len(x) for x in lists])]).astype(np.uint64)
+        nbr = np.concatenate([np.asarray(x, dtype=np.uint32) for x in lists])
+        orow, onbr = O.post_vertex_connectivity(V.shape[0], T)
+        assert np.array_equal(row, orow) and np.array_equal(nbr, onbr), name
+        normals = np.asarray(mesh.vertex_normals_parallel()).copy()
+        onormals = O.post_vertex_normals(V, T)
+        assert np.abs(normals - onormals).max() <= tol, name
+        rng = np.random.default_rng(5)
+        w = rng.random(V.shape[0]).astype(dt)
+        m2 = mesh.copy()
+        pysplashsurf.laplacian_smoothing_parallel(m2, conn, iterations=5, beta=1.0, weights=w)
+        smoothed = np.asarray(m2.vertices).copy()
+        assert np.array_equal(smoothed.view(U), O.post_laplacian_smoothing(V, row, nbr, 5, 1.0, w).view(U)), name
+        m3 = mesh.copy()
+        pysplashsurf.laplacian_smoothing_parallel(m3, conn, iterations=4, beta=0.7, weights=np.ones(V.shape[0], dt))
+        smoothed_b = np.asarray(m3.vertices).copy()
+        assert np.array_equal(smoothed_b.view(U), O.post_laplacian_smoothing(V, row, nbr, 4, 0.7, np.ones(V.shape[0], dt)).view(U)), name
+        n2 = normals.copy()
+        pysplashsurf.laplacian_smoothing_normals_parallel(n2, conn, iterations=3)
+        assert np.array_equal(n2.view(U), O.post_smooth_normals(normals, row, nbr, 3).view(U)), name
+        h = dt(2.0 * l * r)
+        rr = dt(r)
+        mass = dt(4.0) * dt(np.pi / 3.0) * (rr * rr * rr) * dt(1000.0)
+        interp = pysplashsurf.SphInterpolator(pts, rho, float(mass), float(h))
+        sph_normals = np.asarray(interp.interpolate_normals(V)).copy()
+        assert np.abs(sph_normals - O.post_sph_normals(pts, rho, mass, h, V)).max() <= 20 * tol, name
+        q = rng.random(pts.shape[0]).astype(dt)
+        qv = rng.random((pts.shape[0], 3)).astype(dt)
+        sph_q = np.asarray(interp.interpolate_quantity(q, V, first_order_correction=False)).copy()
+        sph_qc = np.asarray(interp.interpolate_quantity(q, V, first_order_correction=True)).copy()
+        sph_v = np.asarray(interp.interpolate_quantity(qv, V, first_order_correction=True)).copy()
+        for a, b in ((sph_q, O.post_sph_interpolate(pts, rho, mass, h, q, V, False)), (sph_qc, O.post_sph_interpolate(pts, rho, mass, h, q, V, True)),
+                     (sph_v, O.post_sph_interpolate(pts, rho, mass, h, qv, V, True))):
+            assert np.max(np.abs(a - b) / np.maximum(np.abs(a), 1e-30)) <= 20 * tol, name
+        # the CLI recipe through the reference's own pipeline (reconstruct.rs:1022-1345)
+        mwd, rec = pysplashsurf.reconstruction_pipeline(pts, particle_radius=r, smoothing_length=l, cube_size=c, simd=False, subdomain_grid=True,
+                                                        subdomain_grid_auto_disable=False, mesh_smoothing_iters=25, mesh_smoothing_weights=True,
+                                                        mesh_smoothing_weights_normalization=13.0, compute_normals=True, sph_normals=False,
+                                                        normals_smoothing_iters=10, output_mesh_smoothing_weights=True, output_raw_normals=True,
+                                                        output_raw_mesh=True)
+        pa = mwd.point_attributes
+        raw = np.asarray(rec.mesh.vertices).copy()
+        # weighted neighbour counts + weights: oracle on the pipeline's own raw mesh
+        wnc = O.post_weighted_neighbor_counts(pts, nb_ptr, nb_idx, h)
+        wnn_o = O.post_sph_interpolate(pts, rho, mass, h, wnc, raw, True)
+        assert np.max(np.abs(wnn_o - np.asarray(pa["wnn"])) / np.maximum(np.abs(np.asarray(pa["wnn"])), 1e-30)) <= 50 * tol, name
+        sw_from_ref_wnn = O.post_smoothing_weights(np.asarray(pa["wnn"]).astype(dt), 13.0)
+        sw_ref = np.asarray(pa["sw"])
+        sw_bits_equal = float(np.mean(sw_from_ref_wnn.view(U) == sw_ref.view(U)))
+        assert np.abs(sw_from_ref_wnn - sw_ref).max() <= 4 * np.finfo(dt).eps, (name, np.abs(sw_from_ref_wnn - sw_ref).max())
+        mwd2, _ = pysplashsurf.reconstruction_pipeline(pts, particle_radius=r, smoothing_length=l, cube_size=c, simd=False, subdomain_grid=True,
+                                                       subdomain_grid_auto_disable=False, compute_normals=True, sph_normals=True, mesh_smoothing_weights=False)
+        np.savez_compressed(
+            os.path.join(GOLD, name + ".npz"), vertices=V, triangles=T.astype(np.int32), densities=rho, nb_row_ptr=nb_ptr.astype(np.int64),
+            nb_indices=nb_idx.astype(np.int32), conn_row_ptr=row.astype(np.int64), conn_neighbors=nbr.astype(np.int32), normals=normals, weights=w,
+            smoothed_5_w=smoothed, smoothed_4_b07=smoothed_b, smoothed_normals_3=n2, sph_normals=sph_normals, q=q, qv=qv, sph_q=sph_q, sph_q_corrected=sph_qc,
+            sph_v_corrected=sph_v, pipe_raw_vertices=raw, pipe_vertices=np.asarray(mwd.mesh.vertices), pipe_wnn=np.asarray(pa["wnn"]), pipe_sw=sw_ref,
+            pipe_normals=np.asarray(pa["normals"]), pipe_raw_normals=np.asarray(pa["raw_normals"]), pipe_sph_normals=np.asarray(mwd2.point_attributes["normals"]),
+            pipe_sph_vertices=np.asarray(mwd2.mesh.vertices),
+            grid_min=np.asarray(res.grid.aabb.min, dtype=dt), cell_size=dt(res.grid.cell_size), n_points=np.asarray(res.grid.npoints_per_dim, dtype=np.int64),
+            params=np.array(json.dumps(dict(particle_radius=r, smoothing_length=l, cube_size=c, iso_surface_threshold=0.6, rest_density=1000.0,
+                                            rest_mass=float(mass), compact_support_radius=float(h)))),
+            input=np.array(json.dumps(dict(kind="file", file=fn))))
+        report[name] = dict(n_vertices=int(V.shape[0]), max_valence=int(max(len(x) for x in lists)), normals_parallel_vs_sequential=float(np.abs(normals - onormals).max()),
+                            sph_normals_vs_oracle=float(np.abs(sph_normals - O.post_sph_normals(pts, rho, mass, h, V)).max()), sw_bits_equal_fraction=sw_bits_equal)
+
+
 def main():
     os.makedirs(GOLD, exist_ok=True)
     if "--f64-only" in sys.argv:
@@ -259,6 +348,17 @@ def main():
         gen_f64_goldens(rep)
         for k, v in rep.items():
             print(k, v)
+        return
+    if "--post-only" in sys.argv:
+        rep = {}
+        gen_post_goldens(rep)
+        for k, v in rep.items():
+            print(k, v)
+        path = os.path.join(GOLD, "GENERATION_REPORT.json")
+        full = json.load(open(path)) if os.path.exists(path) else {}
+        full.update(rep)
+        with open(path, "w") as f:
+            json.dump(full, f, indent=1, default=lambda o: o.tolist() if hasattr(o, "tolist") else str(o))
         return
     if "--global-only" in sys.argv:
         rep = {}
@@ -374,6 +474,8 @@ def main():
     gen_f64_goldens(report)
     # ---- global (non-decomposed) strategy, rows A14/A15
     gen_global_goldens(report)
+    # ---- post-processing stages
+    gen_post_goldens(report)
 
     # ---- G5: splat micro-fixture (data/density_grid_loop_subdomain_33.json -> npz, inputs only)
     src = "/root/reference/data/density_grid_loop_subdomain_33.json"
