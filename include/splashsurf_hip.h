@@ -223,7 +223,7 @@ typedef struct ss_shard_f32 {
     int64_t sub_lo[3];   /* half-open box of subdomain indices reconstructed by this process */
     int64_t sub_hi[3];
 } ss_shard_f32;
-typedef struct ss_shard_f64 { /* reserved: the shard entry points are provided for f32 in this build */
+typedef struct ss_shard_f64 {
     double domain_min[3];
     double domain_max[3];
     int64_t sub_lo[3];
@@ -231,14 +231,20 @@ typedef struct ss_shard_f64 { /* reserved: the shard entry points are provided f
 } ss_shard_f64;
 ss_status ss_shard_begin_f32(ss_context *ctx, const float *xyz, uint64_t n_particles, const ss_params_f32 *params,
                              const ss_shard_f32 *shard, ss_result *inout);
+ss_status ss_shard_begin_f64(ss_context *ctx, const double *xyz, uint64_t n_particles, const ss_params_f64 *params,
+                             const ss_shard_f64 *shard, ss_result *inout);
 ss_status ss_shard_finish(ss_context *ctx, ss_result *inout);
-/* densities of the particles passed to ss_shard_begin_f32, in their order; dst/src may be host or device memory */
+/* densities of the particles passed to ss_shard_begin_*, in their order; dst/src may be host or device memory */
 ss_status ss_shard_get_densities(ss_result *res, float *dst, uint64_t n);
 ss_status ss_shard_set_densities(ss_result *res, const float *src, uint64_t n);
+ss_status ss_shard_get_densities_f64(ss_result *res, double *dst, uint64_t n);
+ss_status ss_shard_set_densities_f64(ss_result *res, const double *src, uint64_t n);
 /* host-only helper: global MC grid, subdomain grid and ghost margin for a given particle AABB
  * (lib.rs:476-516 + dense_subdomains.rs:89-244); lets every rank derive the same partition */
 ss_status ss_grid_for_domain_f32(const ss_params_f32 *params, const float domain_min[3], const float domain_max[3],
                                  ss_grid_f32 *grid, ss_grid_f32 *subdomain_grid, float *ghost_margin);
+ss_status ss_grid_for_domain_f64(const ss_params_f64 *params, const double domain_min[3], const double domain_max[3],
+                                 ss_grid_f64 *grid, ss_grid_f64 *subdomain_grid, double *ghost_margin);
 
 /* =====================================================================================================
  * Post-processing: the stages of the reference's pipeline that consume the mesh right after the

@@ -3,7 +3,8 @@
 // Mirrors the reference's Rust API for this path so that C++ callers (and the parity tests in
 // tests/cpp/) read like the reference's own code (citations: /root/reference/splashsurf_lib/src/):
 //
-//   splashsurf::Parameters                      <->  Parameters<f32>            lib.rs:158-243
+// Every type is a template on the Real type (float / double) with the f32 instantiation under the plain name:
+//   splashsurf::Parameters = ParametersT<float>  <->  Parameters<f32>;  ParametersT<double> <-> Parameters<f64>   lib.rs:158-243
 //   splashsurf::SpatialDecomposition            <->  SpatialDecomposition       lib.rs:121-154
 //   splashsurf::UniformGrid / Aabb3d            <->  UniformGrid<i64,f32>       uniform_grid.rs:128-142
 //   splashsurf::TriMesh3d                       <->  TriMesh3d<f32>             mesh.rs:187-193
@@ -27,11 +28,38 @@
 
 namespace splashsurf {
 
-using Vector3f = std::array<float, 3>;
-
-struct Aabb3d {
-    Vector3f min{0, 0, 0}, max{0, 0, 0};
+// C-ABI bindings per Real type (reconstruct_surface::<i64, f32> / ::<i64, f64>, reconstruct.rs:982-1007)
+template <class R> struct Abi;
+template <> struct Abi<float> {
+    using params = ss_params_f32;
+    using grid = ss_grid_f32;
+    static ss_status reconstruct_inplace(ss_context* c, const float* xyz, uint64_t n, const params* p, ss_result* r) { return ss_reconstruct_surface_inplace_f32(c, xyz, n, p, r); }
+    static ss_status grid_for_reconstruction(ss_context* c, const float* xyz, uint64_t n, const params* p, grid* g) { return ss_grid_for_reconstruction_f32(c, xyz, n, p, g); }
+    static ss_status result_grid(const ss_result* r, grid* g) { return ss_result_grid(r, g); }
+    static ss_status result_subdomain_grid(const ss_result* r, grid* g, int32_t* present) { return ss_result_subdomain_grid(r, g, present); }
+    static ss_status vertices(ss_result* r, const float** v, uint64_t* n) { return ss_result_vertices(r, v, n); }
+    static ss_status densities(ss_result* r, const float** v, uint64_t* n) { return ss_result_particle_densities(r, v, n); }
 };
+template <> struct Abi<double> {
+    using params = ss_params_f64;
+    using grid = ss_grid_f64;
+    static ss_status reconstruct_inplace(ss_context* c, const double* xyz, uint64_t n, const params* p, ss_result* r) { return ss_reconstruct_surface_inplace_f64(c, xyz, n, p, r); }
+    static ss_status grid_for_reconstruction(ss_context* c, const double* xyz, uint64_t n, const params* p, grid* g) { return ss_grid_for_reconstruction_f64(c, xyz, n, p, g); }
+    static ss_status result_grid(const ss_result* r, grid* g) { return ss_result_grid_f64(r, g); }
+    static ss_status result_subdomain_grid(const ss_result* r, grid* g, int32_t* present) { return ss_result_subdomain_grid_f64(r, g, present); }
+    static ss_status vertices(ss_result* r, const double** v, uint64_t* n) { return ss_result_vertices_f64(r, v, n); }
+    static ss_status densities(ss_result* r, const double** v, uint64_t* n) { return ss_result_particle_densities_f64(r, v, n); }
+};
+
+template <class R> using Vector3 = std::array<R, 3>;
+using Vector3f = Vector3<float>;
+using Vector3d = Vector3<double>;
+
+template <class R>
+struct Aabb3dT {
+    Vector3<R> min{0, 0, 0}, max{0, 0, 0};
+};
+using Aabb3d = Aabb3dT<float>;
 
 struct GridDecompositionParameters {  // lib.rs:139-154
     uint32_t subdomain_num_cubes_per_dim = 64;
@@ -43,33 +71,34 @@ struct SpatialDecomposition {  // lib.rs:121-136 (default: UniformGrid)
     GridDecompositionParameters grid{};
 };
 
-struct Parameters {  // lib.rs:158-189
-    float particle_radius = 0.0f;
-    float rest_density = 1000.0f;
-    float compact_support_radius = 0.0f;
-    float cube_size = 0.0f;
-    float iso_surface_threshold = 0.6f;
-    std::optional<Aabb3d> particle_aabb;
+template <class R>
+struct ParametersT {  // lib.rs:158-189
+    R particle_radius = R(0.0);
+    R rest_density = R(1000.0);
+    R compact_support_radius = R(0.0);
+    R cube_size = R(0.0);
+    R iso_surface_threshold = R(0.6);
+    std::optional<Aabb3dT<R>> particle_aabb;
     bool enable_multi_threading = true;
     bool enable_simd = true;
     SpatialDecomposition spatial_decomposition{};
     bool global_neighborhood_list = false;
 
     // Parameters::new (lib.rs:197-210): absolute units
-    static Parameters with(float particle_radius, float compact_support_radius, float cube_size) {
-        Parameters p;
+    static ParametersT with(R particle_radius, R compact_support_radius, R cube_size) {
+        ParametersT p;
         p.particle_radius = particle_radius;
         p.compact_support_radius = compact_support_radius;
         p.cube_size = cube_size;
         return p;
     }
     // Parameters::new_relative (lib.rs:216-226)
-    static Parameters relative(float particle_radius, float relative_compact_support_radius, float relative_cube_size) {
+    static ParametersT relative(R particle_radius, R relative_compact_support_radius, R relative_cube_size) {
         return with(particle_radius, particle_radius * relative_compact_support_radius, particle_radius * relative_cube_size);
     }
 
-    ss_params_f32 to_c() const {
-        ss_params_f32 c{};
+    typename Abi<R>::params to_c() const {
+        typename Abi<R>::params c{};
         c.particle_radius = particle_radius;
         c.rest_density = rest_density;
         c.compact_support_radius = compact_support_radius;
@@ -90,13 +119,15 @@ struct Parameters {  // lib.rs:158-189
         return c;
     }
 };
+using Parameters = ParametersT<float>;
 
-struct UniformGrid {  // uniform_grid.rs:128-142
-    Aabb3d aabb;
-    float cell_size = 0.0f;
+template <class R>
+struct UniformGridT {  // uniform_grid.rs:128-142
+    Aabb3dT<R> aabb;
+    R cell_size = R(0.0);
     std::array<int64_t, 3> points_per_dim{0, 0, 0}, cells_per_dim{0, 0, 0};
-    static UniformGrid from_c(const ss_grid_f32& g) {
-        UniformGrid u;
+    static UniformGridT from_c(const typename Abi<R>::grid& g) {
+        UniformGridT u;
         for (int d = 0; d < 3; ++d) {
             u.aabb.min[d] = g.aabb_min[d];
             u.aabb.max[d] = g.aabb_max[d];
@@ -107,11 +138,14 @@ struct UniformGrid {  // uniform_grid.rs:128-142
         return u;
     }
 };
+using UniformGrid = UniformGridT<float>;
 
-struct TriMesh3d {  // mesh.rs:187-193
-    std::vector<Vector3f> vertices;
+template <class R>
+struct TriMesh3dT {  // mesh.rs:187-193
+    std::vector<Vector3<R>> vertices;
     std::vector<std::array<uint64_t, 3>> triangles;  // [usize; 3]
 };
+using TriMesh3d = TriMesh3dT<float>;
 
 class ReconstructionError : public std::runtime_error {  // lib.rs:289-314
   public:
@@ -122,15 +156,17 @@ class ReconstructionError : public std::runtime_error {  // lib.rs:289-314
     int detail;  // GridConstructionError sub-code (uniform_grid.rs:147-169)
 };
 
-struct SurfaceReconstruction {  // lib.rs:247-262
-    UniformGrid grid;
-    std::optional<UniformGrid> subdomain_grid;
-    std::optional<std::vector<float>> particle_densities;
+template <class R>
+struct SurfaceReconstructionT {  // lib.rs:247-262
+    UniformGridT<R> grid;
+    std::optional<UniformGridT<R>> subdomain_grid;
+    std::optional<std::vector<R>> particle_densities;
     std::optional<std::vector<bool>> particle_inside_aabb;
     std::optional<std::vector<std::vector<uint64_t>>> particle_neighbors;
-    TriMesh3d mesh;
+    TriMesh3dT<R> mesh;
     ss_stats stats{};
 };
+using SurfaceReconstruction = SurfaceReconstructionT<float>;
 
 class Context {  // replaces initialize_thread_pool (lib.rs:321-326) + the reconstruction workspace
   public:
@@ -150,31 +186,33 @@ class Context {  // replaces initialize_thread_pool (lib.rs:321-326) + the recon
         if (ctx_) ss_context_destroy(ctx_);
     }
 
-    // reconstruct_surface::<i64, f32> (lib.rs:330-337)
-    SurfaceReconstruction reconstruct_surface(const std::vector<Vector3f>& particle_positions, const Parameters& parameters) {
-        SurfaceReconstruction out;
+    // reconstruct_surface::<i64, R> (lib.rs:330-337), R = float or double
+    template <class R>
+    SurfaceReconstructionT<R> reconstruct_surface(const std::vector<Vector3<R>>& particle_positions, const ParametersT<R>& parameters) {
+        SurfaceReconstructionT<R> out;
         reconstruct_surface_inplace(particle_positions, parameters, out);
         return out;
     }
 
     // reconstruct_surface_inplace (lib.rs:340-473): clears and refills `output_surface`, device/pinned buffers are reused
-    void reconstruct_surface_inplace(const std::vector<Vector3f>& particle_positions, const Parameters& parameters,
-                                     SurfaceReconstruction& output_surface) {
-        const ss_params_f32 p = parameters.to_c();
-        const float* xyz = particle_positions.empty() ? nullptr : particle_positions[0].data();
-        check(ss_reconstruct_surface_inplace_f32(ctx_, xyz, particle_positions.size(), &p, res_));
-        ss_grid_f32 g{};
-        check(ss_result_grid(res_, &g));
-        output_surface.grid = UniformGrid::from_c(g);
+    template <class R>
+    void reconstruct_surface_inplace(const std::vector<Vector3<R>>& particle_positions, const ParametersT<R>& parameters,
+                                     SurfaceReconstructionT<R>& output_surface) {
+        const typename Abi<R>::params p = parameters.to_c();
+        const R* xyz = particle_positions.empty() ? nullptr : particle_positions[0].data();
+        check(Abi<R>::reconstruct_inplace(ctx_, xyz, particle_positions.size(), &p, res_));
+        typename Abi<R>::grid g{};
+        check(Abi<R>::result_grid(res_, &g));
+        output_surface.grid = UniformGridT<R>::from_c(g);
         int32_t present = 0;
-        check(ss_result_subdomain_grid(res_, &g, &present));
+        check(Abi<R>::result_subdomain_grid(res_, &g, &present));
         if (present)
-            output_surface.subdomain_grid = UniformGrid::from_c(g);
+            output_surface.subdomain_grid = UniformGridT<R>::from_c(g);
         else
             output_surface.subdomain_grid.reset();
-        const float* v = nullptr;
+        const R* v = nullptr;
         uint64_t nv = 0;
-        check(ss_result_vertices(res_, &v, &nv));
+        check(Abi<R>::vertices(res_, &v, &nv));
         output_surface.mesh.vertices.resize(nv);
         for (uint64_t i = 0; i < nv; ++i) output_surface.mesh.vertices[i] = {v[3 * i], v[3 * i + 1], v[3 * i + 2]};
         const uint64_t* t = nullptr;
@@ -182,10 +220,10 @@ class Context {  // replaces initialize_thread_pool (lib.rs:321-326) + the recon
         check(ss_result_triangles(res_, &t, &nt));
         output_surface.mesh.triangles.resize(nt);
         for (uint64_t i = 0; i < nt; ++i) output_surface.mesh.triangles[i] = {t[3 * i], t[3 * i + 1], t[3 * i + 2]};
-        const float* rho = nullptr;
+        const R* rho = nullptr;
         uint64_t n = 0;
-        check(ss_result_particle_densities(res_, &rho, &n));
-        output_surface.particle_densities = std::vector<float>(rho, rho + n);
+        check(Abi<R>::densities(res_, &rho, &n));
+        output_surface.particle_densities = std::vector<R>(rho, rho + n);
         const uint8_t* inside = nullptr;
         uint64_t ni = 0;
         check(ss_result_particle_inside_aabb(res_, &inside, &ni));
@@ -207,12 +245,21 @@ class Context {  // replaces initialize_thread_pool (lib.rs:321-326) + the recon
     }
 
     // grid_for_reconstruction (lib.rs:476-516)
+    template <class R>
+    UniformGridT<R> grid_for_reconstruction(const std::vector<Vector3<R>>& particle_positions, const ParametersT<R>& parameters) {
+        const typename Abi<R>::params p = parameters.to_c();
+        typename Abi<R>::grid g{};
+        const R* xyz = particle_positions.empty() ? nullptr : particle_positions[0].data();
+        check(Abi<R>::grid_for_reconstruction(ctx_, xyz, particle_positions.size(), &p, &g));
+        return UniformGridT<R>::from_c(g);
+    }
+
+    // f32 conveniences so that braced initialiser lists keep working: ctx.reconstruct_surface({{0, 0, 0}}, p)
+    SurfaceReconstruction reconstruct_surface(const std::vector<Vector3f>& particle_positions, const Parameters& parameters) {
+        return reconstruct_surface<float>(particle_positions, parameters);
+    }
     UniformGrid grid_for_reconstruction(const std::vector<Vector3f>& particle_positions, const Parameters& parameters) {
-        const ss_params_f32 p = parameters.to_c();
-        ss_grid_f32 g{};
-        const float* xyz = particle_positions.empty() ? nullptr : particle_positions[0].data();
-        check(ss_grid_for_reconstruction_f32(ctx_, xyz, particle_positions.size(), &p, &g));
-        return UniformGrid::from_c(g);
+        return grid_for_reconstruction<float>(particle_positions, parameters);
     }
 
     ss_context* raw() { return ctx_; }

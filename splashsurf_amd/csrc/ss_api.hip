@@ -1085,12 +1085,61 @@ ss_status ss_reconstruct_surface_f64(ss_context* c, const double* xyz, uint64_t 
     return reconstruct_abi<double>(c, xyz, n, prm, out);
 }
 
-ss_status ss_shard_begin_f32(ss_context* c, const float* xyz, uint64_t n, const ss_params_f32* prm, const ss_shard_f32* shard, ss_result* inout) {
+extern "C++" {
+namespace {
+template <class R>
+ss_status shard_begin_abi(ss_context* c, const R* xyz, uint64_t n, const typename TypesOf<R>::params* prm, const typename TypesOf<R>::shard* shard, ss_result* inout) {
     if (!c || !inout || !shard) return SS_ERR_INVALID_ARGUMENT;
     if (inout->ctx != c) return fail(c, SS_ERR_INVALID_ARGUMENT, "result belongs to a different context");
     c->err.clear();
     c->err_detail = 0;
-    return phase_begin<float>(c, xyz, n, prm, shard, inout);
+    return phase_begin<R>(c, xyz, n, prm, shard, inout);
+}
+template <class R>
+ss_status shard_get_densities_abi(ss_result* r, R* dst, uint64_t n) {
+    if (!r || r->phase < 1 || r->is_f64 != (sizeof(R) == 8) || (!dst && n)) return SS_ERR_INVALID_ARGUMENT;
+    ss_context* c = r->ctx;
+    if (n != r->n_particles) return fail(c, SS_ERR_INVALID_ARGUMENT, "density count mismatch");
+    if (!n) return SS_OK;
+    SS_HIP(c, hipSetDevice(c->device));
+    SS_HIP(c, hipMemcpyAsync(dst, r->rho.p, n * sizeof(R), hipMemcpyDefault, c->stream));
+    SS_HIP(c, hipStreamSynchronize(c->stream));
+    return SS_OK;
+}
+template <class R>
+ss_status shard_set_densities_abi(ss_result* r, const R* src, uint64_t n) {
+    if (!r || r->phase != 1 || r->is_f64 != (sizeof(R) == 8) || (!src && n)) return SS_ERR_INVALID_ARGUMENT;
+    ss_context* c = r->ctx;
+    if (n != r->n_particles) return fail(c, SS_ERR_INVALID_ARGUMENT, "density count mismatch");
+    if (!n) return SS_OK;
+    SS_HIP(c, hipSetDevice(c->device));
+    SS_HIP(c, hipMemcpyAsync(r->rho.p, src, n * sizeof(R), hipMemcpyDefault, c->stream));
+    SS_HIP(c, hipStreamSynchronize(c->stream));
+    r->hrho = false;
+    return SS_OK;
+}
+template <class R>
+ss_status grid_for_domain_abi(const typename TypesOf<R>::params* prm, const R domain_min[3], const R domain_max[3], typename TypesOf<R>::grid* grid,
+                              typename TypesOf<R>::grid* subdomain_grid, R* ghost_margin) {
+    if (!prm || !domain_min || !domain_max || !grid || !subdomain_grid) return SS_ERR_INVALID_ARGUMENT;
+    if (!(prm->cube_size > R(0.0)) || !(prm->compact_support_radius > R(0.0)) || prm->subdomain_num_cubes_per_dim < 1) return SS_ERR_UNKNOWN;
+    typename TypesOf<R>::params p = *prm;
+    p.has_particle_aabb = 0;
+    typename TypesOf<R>::grid initial;
+    if (grid_for_reconstruction<R>(&p, true, domain_min, domain_max, &initial)) return SS_ERR_GRID_CONSTRUCTION;
+    R mass = 0, margin = 0;
+    initialize_subdomain_parameters<R>(&p, &initial, grid, subdomain_grid, &mass, &margin);
+    if (ghost_margin) *ghost_margin = margin;
+    return SS_OK;
+}
+}  // namespace
+}  // extern "C++"
+
+ss_status ss_shard_begin_f32(ss_context* c, const float* xyz, uint64_t n, const ss_params_f32* prm, const ss_shard_f32* shard, ss_result* inout) {
+    return shard_begin_abi<float>(c, xyz, n, prm, shard, inout);
+}
+ss_status ss_shard_begin_f64(ss_context* c, const double* xyz, uint64_t n, const ss_params_f64* prm, const ss_shard_f64* shard, ss_result* inout) {
+    return shard_begin_abi<double>(c, xyz, n, prm, shard, inout);
 }
 
 ss_status ss_shard_finish(ss_context* c, ss_result* inout) {
@@ -1100,41 +1149,18 @@ ss_status ss_shard_finish(ss_context* c, ss_result* inout) {
     return inout->is_f64 ? phase_finish<double>(c, inout) : phase_finish<float>(c, inout);
 }
 
-ss_status ss_shard_get_densities(ss_result* r, float* dst, uint64_t n) {
-    if (!r || r->phase < 1 || r->is_f64 || (!dst && n)) return SS_ERR_INVALID_ARGUMENT;
-    ss_context* c = r->ctx;
-    if (n != r->n_particles) return fail(c, SS_ERR_INVALID_ARGUMENT, "density count mismatch");
-    if (!n) return SS_OK;
-    SS_HIP(c, hipSetDevice(c->device));
-    SS_HIP(c, hipMemcpyAsync(dst, r->rho.p, n * 4, hipMemcpyDefault, c->stream));
-    SS_HIP(c, hipStreamSynchronize(c->stream));
-    return SS_OK;
-}
-
-ss_status ss_shard_set_densities(ss_result* r, const float* src, uint64_t n) {
-    if (!r || r->phase != 1 || r->is_f64 || (!src && n)) return SS_ERR_INVALID_ARGUMENT;
-    ss_context* c = r->ctx;
-    if (n != r->n_particles) return fail(c, SS_ERR_INVALID_ARGUMENT, "density count mismatch");
-    if (!n) return SS_OK;
-    SS_HIP(c, hipSetDevice(c->device));
-    SS_HIP(c, hipMemcpyAsync(r->rho.p, src, n * 4, hipMemcpyDefault, c->stream));
-    SS_HIP(c, hipStreamSynchronize(c->stream));
-    r->hrho = false;
-    return SS_OK;
-}
+ss_status ss_shard_get_densities(ss_result* r, float* dst, uint64_t n) { return shard_get_densities_abi<float>(r, dst, n); }
+ss_status ss_shard_get_densities_f64(ss_result* r, double* dst, uint64_t n) { return shard_get_densities_abi<double>(r, dst, n); }
+ss_status ss_shard_set_densities(ss_result* r, const float* src, uint64_t n) { return shard_set_densities_abi<float>(r, src, n); }
+ss_status ss_shard_set_densities_f64(ss_result* r, const double* src, uint64_t n) { return shard_set_densities_abi<double>(r, src, n); }
 
 ss_status ss_grid_for_domain_f32(const ss_params_f32* prm, const float domain_min[3], const float domain_max[3], ss_grid_f32* grid,
                                  ss_grid_f32* subdomain_grid, float* ghost_margin) {
-    if (!prm || !domain_min || !domain_max || !grid || !subdomain_grid) return SS_ERR_INVALID_ARGUMENT;
-    if (!(prm->cube_size > 0.0f) || !(prm->compact_support_radius > 0.0f) || prm->subdomain_num_cubes_per_dim < 1) return SS_ERR_UNKNOWN;
-    ss_params_f32 p = *prm;
-    p.has_particle_aabb = 0;
-    ss_grid_f32 initial;
-    if (grid_for_reconstruction<float>(&p, true, domain_min, domain_max, &initial)) return SS_ERR_GRID_CONSTRUCTION;
-    float mass = 0, margin = 0;
-    initialize_subdomain_parameters<float>(&p, &initial, grid, subdomain_grid, &mass, &margin);
-    if (ghost_margin) *ghost_margin = margin;
-    return SS_OK;
+    return grid_for_domain_abi<float>(prm, domain_min, domain_max, grid, subdomain_grid, ghost_margin);
+}
+ss_status ss_grid_for_domain_f64(const ss_params_f64* prm, const double domain_min[3], const double domain_max[3], ss_grid_f64* grid,
+                                 ss_grid_f64* subdomain_grid, double* ghost_margin) {
+    return grid_for_domain_abi<double>(prm, domain_min, domain_max, grid, subdomain_grid, ghost_margin);
 }
 
 ss_status ss_grid_for_reconstruction_f32(ss_context* c, const float* xyz, uint64_t n_in, const ss_params_f32* prm, ss_grid_f32* out) {

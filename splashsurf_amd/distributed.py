@@ -30,8 +30,9 @@ import torch.distributed as dist
 
 class ShardDesc:
     def __init__(self, domain_min, domain_max, sub_lo, sub_hi):
-        self.domain_min = np.asarray(domain_min, dtype=np.float32)
-        self.domain_max = np.asarray(domain_max, dtype=np.float32)
+        dt = np.float64 if np.asarray(domain_min).dtype == np.float64 else np.float32
+        self.domain_min = np.asarray(domain_min, dtype=dt)
+        self.domain_max = np.asarray(domain_max, dtype=dt)
         self.sub_lo = [int(x) for x in sub_lo]
         self.sub_hi = [int(x) for x in sub_hi]
 
@@ -40,21 +41,32 @@ class _Shard(C.Structure):
     _fields_ = [("domain_min", C.c_float * 3), ("domain_max", C.c_float * 3), ("sub_lo", C.c_int64 * 3), ("sub_hi", C.c_int64 * 3)]
 
 
+class _Shard64(C.Structure):
+    _fields_ = [("domain_min", C.c_double * 3), ("domain_max", C.c_double * 3), ("sub_lo", C.c_int64 * 3), ("sub_hi", C.c_int64 * 3)]
+
+
 class HipEngine:
     """Per-rank engine on the HIP library (device tensors in, device-resident mesh out)."""
 
-    def __init__(self, ctx, params):
+    def __init__(self, ctx, params, dtype=np.float32):
         from . import api
         self.api = api
         self.ctx = ctx
         self.params = params
+        self.f64 = np.dtype(dtype) == np.float64  # Real type of the job: f32 -> ss_shard_*_f32, f64 -> *_f64
+        self.np_dtype = np.float64 if self.f64 else np.float32
+        self.torch_dtype = torch.float64 if self.f64 else torch.float32
         self.lib = ctx._lib
-        self.lib.ss_shard_begin_f32.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(api._Params), C.POINTER(_Shard), C.c_void_p]
-        self.lib.ss_shard_finish.argtypes = [C.c_void_p, C.c_void_p]
-        self.lib.ss_shard_get_densities.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
-        self.lib.ss_shard_set_densities.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
+        vp, u64 = C.c_void_p, C.c_uint64
+        self.lib.ss_shard_begin_f32.argtypes = [vp, vp, u64, C.POINTER(api._Params), C.POINTER(_Shard), vp]
+        self.lib.ss_shard_begin_f64.argtypes = [vp, vp, u64, C.POINTER(api._Params64), C.POINTER(_Shard64), vp]
+        self.lib.ss_shard_finish.argtypes = [vp, vp]
+        for name in ("ss_shard_get_densities", "ss_shard_set_densities", "ss_shard_get_densities_f64", "ss_shard_set_densities_f64"):
+            getattr(self.lib, name).argtypes = [vp, vp, u64]
         self.lib.ss_grid_for_domain_f32.argtypes = [C.POINTER(api._Params), C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(api._Grid),
                                                     C.POINTER(api._Grid), C.POINTER(C.c_float)]
+        self.lib.ss_grid_for_domain_f64.argtypes = [C.POINTER(api._Params64), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(api._Grid64),
+                                                    C.POINTER(api._Grid64), C.POINTER(C.c_double)]
         h = C.c_void_p()
         st = self.lib.ss_result_create(ctx._h, C.byref(h))
         if st != 0:
@@ -62,18 +74,20 @@ class HipEngine:
         self.result = api.SurfaceReconstruction(ctx, h)
 
     def grid_for_domain(self, dmin, dmax):
-        p = self.params._c()
-        g, sg, m = self.api._Grid(), self.api._Grid(), C.c_float()
-        a = (C.c_float * 3)(*[float(x) for x in dmin])
-        b = (C.c_float * 3)(*[float(x) for x in dmax])
-        st = self.lib.ss_grid_for_domain_f32(C.byref(p), a, b, C.byref(g), C.byref(sg), C.byref(m))
+        p = self.params._c(self.f64)
+        G, creal = (self.api._Grid64, C.c_double) if self.f64 else (self.api._Grid, C.c_float)
+        g, sg, m = G(), G(), creal()
+        a = (creal * 3)(*[float(x) for x in dmin])
+        b = (creal * 3)(*[float(x) for x in dmax])
+        fn = self.lib.ss_grid_for_domain_f64 if self.f64 else self.lib.ss_grid_for_domain_f32
+        st = fn(C.byref(p), a, b, C.byref(g), C.byref(sg), C.byref(m))
         if st != 0:
-            raise RuntimeError("ss_grid_for_domain_f32 failed: %d" % st)
-        return (np.array(list(g.aabb_min), np.float32), float(sg.cell_size), [int(x) for x in sg.n_cells], float(m.value),
+            raise RuntimeError("ss_grid_for_domain failed: %d" % st)
+        return (np.array(list(g.aabb_min), self.np_dtype), float(sg.cell_size), [int(x) for x in sg.n_cells], float(m.value),
                 int(self.params.subdomain_num_cubes_per_dim))
 
     def _shard(self, sd):
-        s = _Shard()
+        s = _Shard64() if self.f64 else _Shard()
         for d in range(3):
             s.domain_min[d] = float(sd.domain_min[d])
             s.domain_max[d] = float(sd.domain_max[d])
@@ -82,18 +96,21 @@ class HipEngine:
         return s
 
     def begin(self, local_pts, shard):
-        """local_pts: contiguous float32 (n,3) tensor on this rank's device. Returns densities (owned computed, others 0)."""
+        """local_pts: contiguous (n,3) tensor of the job's Real type on this rank's device.  Returns densities (owned computed, others 0)."""
+        assert local_pts.dtype == self.torch_dtype
         if local_pts.is_cuda:
             torch.cuda.current_stream(local_pts.device).synchronize()
-        p = self.params._c()
+        p = self.params._c(self.f64)
         s = self._shard(shard)
         n = int(local_pts.shape[0])
-        st = self.lib.ss_shard_begin_f32(self.ctx._h, C.c_void_p(local_pts.data_ptr()), n, C.byref(p), C.byref(s), self.result._h)
+        fn = self.lib.ss_shard_begin_f64 if self.f64 else self.lib.ss_shard_begin_f32
+        st = fn(self.ctx._h, C.c_void_p(local_pts.data_ptr()), n, C.byref(p), C.byref(s), self.result._h)
         if st != 0:
             self.ctx._raise(st)
         self.result._invalidate()
-        rho = torch.empty(n, dtype=torch.float32, device=local_pts.device)
-        st = self.lib.ss_shard_get_densities(self.result._h, C.c_void_p(rho.data_ptr()), n)
+        rho = torch.empty(n, dtype=self.torch_dtype, device=local_pts.device)
+        fn = self.lib.ss_shard_get_densities_f64 if self.f64 else self.lib.ss_shard_get_densities
+        st = fn(self.result._h, C.c_void_p(rho.data_ptr()), n)
         if st != 0:
             self.ctx._raise(st)
         return rho
@@ -101,7 +118,8 @@ class HipEngine:
     def finish(self, rho):
         if rho.is_cuda:
             torch.cuda.current_stream(rho.device).synchronize()
-        st = self.lib.ss_shard_set_densities(self.result._h, C.c_void_p(rho.data_ptr()), int(rho.shape[0]))
+        fn = self.lib.ss_shard_set_densities_f64 if self.f64 else self.lib.ss_shard_set_densities
+        st = fn(self.result._h, C.c_void_p(rho.data_ptr()), int(rho.shape[0]))
         if st != 0:
             self.ctx._raise(st)
         st = self.lib.ss_shard_finish(self.ctx._h, self.result._h)
@@ -163,8 +181,10 @@ class ShardedReconstruction:
         self.local = None
 
     def load_local_particles(self, pts):
-        """The particles this rank contributes (its share of the input), float32 (n,3)."""
-        t = torch.as_tensor(np.ascontiguousarray(pts, dtype=np.float32)) if not torch.is_tensor(pts) else pts
+        """The particles this rank contributes (its share of the input), (n,3) in the engine's Real type (float32 unless the
+        engine was created for float64)."""
+        dt = getattr(self.engine, "np_dtype", np.float32)
+        t = torch.as_tensor(np.ascontiguousarray(pts, dtype=dt)) if not torch.is_tensor(pts) else pts
         self.local = t.to(self.device).contiguous()
 
     # ---- collectives ----
@@ -245,18 +265,19 @@ class ShardedReconstruction:
         n_total = sum(counts)
         gid = torch.arange(offset, offset + local.shape[0], dtype=torch.int64, device=dev)
         # 2. global particle AABB (identical on every rank)
-        big = torch.finfo(torch.float32).max
+        big = torch.finfo(local.dtype).max
         if local.shape[0]:
             # full reductions over the three strided columns (a dim-0 reduction of an (N,3) tensor runs
             # on 3 threads' worth of parallelism in torch and costs ~6 ms per call at 10M particles)
             mm = [torch.aminmax(local[:, d]) for d in range(3)]
             lo_hi = torch.stack([torch.stack([m.min for m in mm]), -torch.stack([m.max for m in mm])])
         else:
-            lo_hi = torch.full((2, 3), big, device=dev)
+            lo_hi = torch.full((2, 3), big, dtype=local.dtype, device=dev)
         if self.world > 1:
             dist.all_reduce(lo_hi, op=dist.ReduceOp.MIN, group=self.group)
-        dmin = lo_hi[0].cpu().numpy() if n_total else np.zeros(3, np.float32)
-        dmax = (-lo_hi[1]).cpu().numpy() if n_total else np.zeros(3, np.float32)
+        np_dt = np.float64 if local.dtype == torch.float64 else np.float32
+        dmin = lo_hi[0].cpu().numpy() if n_total else np.zeros(3, np_dt)
+        dmax = (-lo_hi[1]).cpu().numpy() if n_total else np.zeros(3, np_dt)
         gmin, sub_size, ns, margin, n_cubes = eng.grid_for_domain(dmin, dmax)
         axis = int(np.argmax(ns))
         self._tick("1_ids_aabb_grid")
@@ -334,7 +355,7 @@ class ShardedReconstruction:
         r = self.last["rho"][self.last["owned"]]
         G, _ = self._all_gather_rows(g)
         R, _ = self._all_gather_rows(r)
-        out = torch.zeros(int(G.max().item()) + 1 if G.numel() else 0, dtype=torch.float32, device=self.device)
+        out = torch.zeros(int(G.max().item()) + 1 if G.numel() else 0, dtype=r.dtype, device=self.device)
         out.index_copy_(0, G, R)
         return out
 

@@ -84,6 +84,19 @@ int main() {
         SurfaceReconstruction a = ctx.reconstruct_surface(particles, p);
         CHECK(!a.subdomain_grid.has_value() && a.mesh.vertices.size() == 6);
     }
+    // --- reconstruct_surface::<i64, f64>: the known answer in double precision ---
+    {
+        std::vector<Vector3d> particles = {{0.01, 0.0, 0.0}};
+        ParametersT<double> p = ParametersT<double>::with(1.0, 1.0, 1.0);
+        p.iso_surface_threshold = 0.1;
+        p.spatial_decomposition.grid.auto_disable = false;
+        SurfaceReconstructionT<double> s = ctx.reconstruct_surface(particles, p);
+        CHECK(s.mesh.vertices.size() == 6 && s.mesh.triangles.size() == 8);
+        CHECK(s.particle_densities && std::fabs((*s.particle_densities)[0] - 20371.83271) < 1e-4);
+        CHECK(s.grid.cells_per_dim[0] == 64 && s.grid.aabb.min[0] == -2.0);
+        UniformGridT<double> g = ctx.grid_for_reconstruction(particles, p);
+        CHECK(g.cells_per_dim[0] == 5);
+    }
     // --- empty input is Ok with an empty mesh (SURVEY 8b edge behaviour) ---
     {
         Parameters p = Parameters::relative(0.025f, 4.0f, 1.0f);

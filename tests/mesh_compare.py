@@ -78,9 +78,11 @@ def compare_keyed(va, ka, ta, vb, kb, tb):
     out["keys_equal"] = bool(np.array_equal(ka, kb))
     out["triangles_equal"] = bool(ta.shape == tb.shape and np.array_equal(ta, tb))
     if out["keys_equal"] and len(ka):
-        a32 = np.ascontiguousarray(va, dtype=np.float32)
-        b32 = np.ascontiguousarray(vb, dtype=np.float32)
-        out["vertices_bit_equal"] = bool(np.array_equal(a32.view(np.uint32), b32.view(np.uint32)))
+        both64 = np.asarray(va).dtype == np.float64 and np.asarray(vb).dtype == np.float64
+        dt, U = (np.float64, np.uint64) if both64 else (np.float32, np.uint32)  # f64 meshes are compared as 64-bit patterns
+        a32 = np.ascontiguousarray(va, dtype=dt)
+        b32 = np.ascontiguousarray(vb, dtype=dt)
+        out["vertices_bit_equal"] = bool(np.array_equal(a32.view(U), b32.view(U)))
         out["n_vertices_differing"] = int(np.any(a32 != b32, axis=1).sum())
         out["max_abs_diff"] = float(np.max(np.abs(a32.astype(np.float64) - b32.astype(np.float64))))
     else:

@@ -220,8 +220,9 @@ def test_dense_cloud_exceeding_tile_capacity(gpu_ctx, oracle):
     assert_gpu_equals_oracle(res, orc)
 
 
-@pytest.mark.parametrize("case", [("double_dam_break_frame_26_4732_particles.npy", 0.025, 2.0, 1.1, 16, 2),
-                                  ("hilbert_46843_particles.npy", 0.025, 2.0, 0.9, 32, 3)])
+@pytest.mark.parametrize("case", [("double_dam_break_frame_26_4732_particles.npy", 0.025, 2.0, 1.1, 16, 2, np.float32),
+                                  ("hilbert_46843_particles.npy", 0.025, 2.0, 0.9, 32, 3, np.float32),
+                                  ("double_dam_break_frame_26_4732_particles.npy", 0.025, 2.0, 1.1, 16, 3, np.float64)])
 def test_sharded_engine_reproduces_full_reconstruction(oracle, case):
     """The multi-GPU path on ONE GPU: k pseudo-ranks (one HIP context each) reconstruct slabs of subdomains
     through ss_shard_begin_f32 / ss_shard_finish with the density exchange done by hand; the merged
@@ -229,18 +230,19 @@ def test_sharded_engine_reproduces_full_reconstruction(oracle, case):
     import torch
     from splashsurf_amd import distributed as D
     from splashsurf_amd.api import Context, Parameters
-    fn, r, l, c, n_cubes, k = case
-    pts = np.load(os.path.join(os.path.dirname(__file__), "data", fn))
-    prm = Parameters(particle_radius=r, compact_support_radius=np.float32(2.0 * l * r), cube_size=np.float32(c * r),
+    fn, r, l, c, n_cubes, k, dt = case
+    U = np.uint32 if dt == np.float32 else np.uint64
+    pts = np.load(os.path.join(os.path.dirname(__file__), "data", fn)).astype(dt)
+    prm = Parameters(particle_radius=r, compact_support_radius=dt(2.0 * l * r), cube_size=dt(c * r),
                      subdomain_num_cubes_per_dim=n_cubes, auto_disable=False)
-    engines = [D.HipEngine(Context(0), prm) for _ in range(k)]
+    engines = [D.HipEngine(Context(0), prm, dtype=dt) for _ in range(k)]
     P_all = torch.from_numpy(pts).to("cuda:0")
     dmin, dmax = pts.min(axis=0), pts.max(axis=0)
     gmin, sub_size, ns, margin, _ = engines[0].grid_for_domain(dmin, dmax)
     axis = int(np.argmax(ns))
     slabs = D.partition_slabs(P_all[:, axis], float(gmin[axis]), sub_size, ns[axis], k)
     assert sum(1 for lo, hi in slabs if hi > lo) >= 2
-    rho_global = torch.zeros(pts.shape[0], dtype=torch.float32, device="cuda:0")
+    rho_global = torch.zeros(pts.shape[0], dtype=torch.float32 if dt == np.float32 else torch.float64, device="cuda:0")
     sel = []
     for q, (lo, hi) in enumerate(slabs):
         sub_lo, sub_hi = [0, 0, 0], list(ns)
@@ -268,9 +270,9 @@ def test_sharded_engine_reproduces_full_reconstruction(oracle, case):
     order = np.argsort(K, kind="stable")
     same = K[order][1:] == K[order][:-1]
     assert same.sum() > 0
-    assert np.array_equal(V[order][1:][same].view(np.uint32), V[order][:-1][same].view(np.uint32))
-    ref = oracle.reconstruct_surface(pts, oracle.make_params(r, np.float32(2.0 * l * r), np.float32(c * r), subdomain_num_cubes_per_dim=n_cubes))
-    assert np.array_equal(rho_global.cpu().numpy().view(np.uint32), ref.particle_densities.view(np.uint32))
+    assert np.array_equal(V[order][1:][same].view(U), V[order][:-1][same].view(U))
+    ref = oracle.reconstruct_surface(pts, oracle.make_params(r, dt(2.0 * l * r), dt(c * r), subdomain_num_cubes_per_dim=n_cubes, dtype=dt))
+    assert np.array_equal(rho_global.cpu().numpy().view(U), ref.particle_densities.view(U))
     cmp = MC.compare_keyed(merged_v, uk, merged_t, ref.vertices, ref.vertex_keys, ref.triangles)
     assert cmp["keys_equal"] and cmp["triangles_equal"] and cmp["vertices_bit_equal"], cmp
 
