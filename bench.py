@@ -179,11 +179,11 @@ def main():
             for _ in range(3):
                 t1 = time.perf_counter()
                 r_io = ctx.reconstruct(host_pts, prm, out=out)
-                _v = r_io.mesh.vertices
-                _t = r_io.mesh.triangles_u32
+                _v, _t = r_io.mesh_views()  # D2H into the library's pinned host buffers, no further copy
                 t_io.append(time.perf_counter() - t1)
             line["pcie_inclusive"] = {"value": round(n_total / min(t_io) / 1e6, 3), "unit": "Mparticles/s", "ms_per_step": round(min(t_io) * 1e3, 3),
-                                      "note": "host (pageable numpy) input, vertices + u32 triangles copied to host; best of 3"}
+                                      "note": "host (pageable numpy) input via ss_reconstruct_surface_inplace_f32, vertices + u32 triangles fetched through "
+                                              "ss_result_vertices / ss_result_triangles_u32 (pinned host buffers); best of 3"}
         except Exception as e:
             line["pcie_inclusive"] = {"value": None, "note": "failed: %r" % (e,)}
         # HBM traffic of the splat kernel from rocprofv3 PMC passes (collected offline, see profiles/)

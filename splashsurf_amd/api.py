@@ -385,15 +385,28 @@ class SurfaceReconstruction:
         if st != 0:
             self._ctx._raise(st)
 
-    def _host_array(self, fn, ctype, width, dtype):
+    def _host_array(self, fn, ctype, width, dtype, copy=True):
         ptr, n = C.c_void_p(), C.c_uint64()
         self._check(fn(self._h, C.byref(ptr), C.byref(n)))
         cnt = int(n.value) * width
         if cnt == 0 or not ptr.value:
             shape = (0, width) if width > 1 else (0,)
             return np.zeros(shape, dtype=dtype)
-        arr = np.ctypeslib.as_array(C.cast(ptr, C.POINTER(ctype)), shape=(cnt,)).copy()
+        arr = np.ctypeslib.as_array(C.cast(ptr, C.POINTER(ctype)), shape=(cnt,))
+        if copy:
+            arr = arr.copy()
         return arr.reshape(-1, width) if width > 1 else arr
+
+    def mesh_views(self):
+        """(vertices, triangles_u32) as zero-copy numpy views of the library's pinned host buffers -- what a host
+        caller of the C ABI gets from ss_result_vertices / ss_result_triangles_u32.  Valid only until this result is
+        reused by another reconstruction or freed; use `.mesh.vertices` / `.mesh.triangles` for owning copies."""
+        if self.is_f64:
+            v = self._host_array(self._lib.ss_result_vertices_f64, C.c_double, 3, np.float64, copy=False)
+        else:
+            v = self._host_array(self._lib.ss_result_vertices, C.c_float, 3, np.float32, copy=False)
+        t = self._host_array(self._lib.ss_result_triangles_u32, C.c_uint32, 3, np.uint32, copy=False)
+        return v, t
 
     def counts(self):
         nv, nt = C.c_uint64(), C.c_uint64()
