@@ -179,6 +179,8 @@ class ShardedReconstruction:
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.local = None
+        import os
+        self._exchange_mode = "allgather" if os.environ.get("SPLASH_EXCHANGE", "p2p") == "allgather" else "p2p"
 
     def load_local_particles(self, pts):
         """The particles this rank contributes (its share of the input), (n,3) in the engine's Real type (float32 unless the
@@ -188,13 +190,34 @@ class ShardedReconstruction:
         self.local = t.to(self.device).contiguous()
 
     # ---- collectives ----
+    # RCCL ("nccl") moves device tensors directly.  gloo (CPU tests, and the 2-processes-on-one-GPU test) only moves
+    # host memory: device tensors are staged through the host for the collective and brought back.
+    def _stage(self):
+        return self.device.type == "cuda" and dist.is_initialized() and dist.get_backend(self.group) == "gloo"
+
     def _all_gather_small(self, t):
         """all-gather of a small fixed-shape tensor -> stacked (world, ...)"""
         if self.world == 1:
             return t.unsqueeze(0)
+        if self._stage():
+            th = t.cpu()
+            out = [torch.zeros_like(th) for _ in range(self.world)]
+            dist.all_gather(out, th, group=self.group)
+            return torch.stack(out, dim=0).to(self.device)
         out = [torch.zeros_like(t) for _ in range(self.world)]
         dist.all_gather(out, t, group=self.group)
         return torch.stack(out, dim=0)
+
+    def _all_reduce(self, t, op):
+        if self.world == 1:
+            return t
+        if self._stage():
+            th = t.cpu()
+            dist.all_reduce(th, op=op, group=self.group)
+            t.copy_(th)
+            return t
+        dist.all_reduce(t, op=op, group=self.group)
+        return t
 
     def _all_gather_rows(self, t):
         """Padded all-gather of (n_r, ...) tensors with different n_r; returns concatenation + counts."""
@@ -203,35 +226,67 @@ class ShardedReconstruction:
         n = torch.tensor([t.shape[0]], dtype=torch.int64, device=self.device)
         counts = [int(c) for c in self._all_gather_small(n).flatten().tolist()]
         m = max(max(counts), 1)
-        pad = torch.zeros((m,) + tuple(t.shape[1:]), dtype=t.dtype, device=self.device)
-        pad[: t.shape[0]] = t
-        out = torch.empty((self.world * m,) + tuple(t.shape[1:]), dtype=t.dtype, device=self.device)
-        dist.all_gather_into_tensor(out, pad, group=self.group)
-        parts = [out[r * m: r * m + counts[r]] for r in range(self.world)]
-        return torch.cat(parts, dim=0).contiguous(), counts
+        stage = self._stage()
+        dev = torch.device("cpu") if stage else self.device
+        pad = torch.zeros((m,) + tuple(t.shape[1:]), dtype=t.dtype, device=dev)
+        pad[: t.shape[0]] = t.to(dev)
+        out = [torch.zeros_like(pad) for _ in range(self.world)]
+        dist.all_gather(out, pad, group=self.group)
+        parts = [out[r][: counts[r]] for r in range(self.world)]
+        return torch.cat(parts, dim=0).contiguous().to(self.device), counts
 
     def _exchange(self, send):
-        """Sparse all-to-all: send[q] (k_q, ...) goes to rank q; returns the list received from every rank
-        (point-to-point batch, supported by both RCCL and gloo)."""
+        """Sparse all-to-all: send[q] (k_q, ...) goes to rank q; returns the list received from every rank.
+        Default transport: one batch of point-to-point isend/irecv (RCCL and gloo).  SPLASH_EXCHANGE=allgather (or a
+        failing point-to-point batch) switches to a padded all-gather of every rank's outgoing rows, from which each
+        rank keeps its part -- more bytes on the wire, but only the most basic collective."""
         if self.world == 1:
             return [send[0]]
         counts = torch.tensor([int(t.shape[0]) for t in send], dtype=torch.int64, device=self.device)
         matrix = self._all_gather_small(counts)  # matrix[r][q] = rows rank r sends to rank q
+        if self._exchange_mode == "p2p":
+            try:
+                return self._exchange_p2p(send, matrix)
+            except RuntimeError as e:  # symmetric failures (unsupported transport): every rank falls back
+                import warnings
+                warnings.warn("point-to-point halo exchange failed (%s); falling back to all-gather" % (str(e).splitlines()[0],))
+                self._exchange_mode = "allgather"
+        return self._exchange_allgather(send, matrix)
+
+    def _exchange_p2p(self, send, matrix):
         recv_counts = [int(c) for c in matrix[:, self.rank].tolist()]
+        stage = self._stage()
+        dev = torch.device("cpu") if stage else self.device
         ops, recv = [], []
         for q in range(self.world):
             if q == self.rank:
                 recv.append(send[q])
                 continue
-            buf = torch.empty((recv_counts[q],) + tuple(send[q].shape[1:]), dtype=send[q].dtype, device=self.device)
+            buf = torch.empty((recv_counts[q],) + tuple(send[q].shape[1:]), dtype=send[q].dtype, device=dev)
             recv.append(buf)
             if send[q].shape[0] > 0:
-                ops.append(dist.P2POp(dist.isend, send[q].contiguous(), q, group=self.group))
+                ops.append(dist.P2POp(dist.isend, send[q].to(dev).contiguous(), q, group=self.group))
             if recv_counts[q] > 0:
                 ops.append(dist.P2POp(dist.irecv, buf, q, group=self.group))
         if ops:
             for req in dist.batch_isend_irecv(ops):
                 req.wait()
+        return [b.to(self.device) for b in recv] if stage else recv
+
+    def _exchange_allgather(self, send, matrix):
+        me = self.rank
+        outgoing = torch.cat([send[q] for q in range(self.world) if q != me], dim=0) if self.world > 1 else send[0][:0]
+        everything, _ = self._all_gather_rows(outgoing.contiguous())
+        m = matrix.cpu().numpy()
+        recv, base = [], 0
+        for r in range(self.world):
+            row_total = int(m[r].sum() - m[r][r])  # rank r's outgoing rows, ordered by destination (self skipped)
+            if r == me:
+                recv.append(send[me])
+            else:
+                off = base + int(sum(m[r][q] for q in range(me) if q != r))
+                recv.append(everything[off:off + int(m[r][me])])
+            base += row_total
         return recv
 
     def _tick(self, name):
@@ -273,8 +328,7 @@ class ShardedReconstruction:
             lo_hi = torch.stack([torch.stack([m.min for m in mm]), -torch.stack([m.max for m in mm])])
         else:
             lo_hi = torch.full((2, 3), big, dtype=local.dtype, device=dev)
-        if self.world > 1:
-            dist.all_reduce(lo_hi, op=dist.ReduceOp.MIN, group=self.group)
+        lo_hi = self._all_reduce(lo_hi, dist.ReduceOp.MIN)
         np_dt = np.float64 if local.dtype == torch.float64 else np.float32
         dmin = lo_hi[0].cpu().numpy() if n_total else np.zeros(3, np_dt)
         dmax = (-lo_hi[1]).cpu().numpy() if n_total else np.zeros(3, np_dt)
@@ -284,8 +338,7 @@ class ShardedReconstruction:
         # 3. slab partition balanced by owner counts (histogram all-reduced, so identical everywhere)
         s_own = torch.floor((local[:, axis] - float(gmin[axis])) / sub_size).to(torch.int64).clamp_(0, ns[axis] - 1)
         hist = torch.bincount(s_own, minlength=ns[axis]).to(torch.int64)
-        if self.world > 1:
-            dist.all_reduce(hist, op=dist.ReduceOp.SUM, group=self.group)
+        hist = self._all_reduce(hist, dist.ReduceOp.SUM)
         slabs = slabs_from_histogram(hist.cpu().numpy(), self.world)
         lo, hi = slabs[me]
         sub_lo, sub_hi = [0, 0, 0], list(ns)

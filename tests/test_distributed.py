@@ -44,7 +44,8 @@ class OracleEngine:
         return res
 
 
-def _worker(rank, world, port, case, out_path):
+def _worker(rank, world, port, case, out_path, exchange="p2p"):
+    os.environ["SPLASH_EXCHANGE"] = exchange
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -89,11 +90,12 @@ def _free_port():
     return p
 
 
-@pytest.mark.parametrize("case,world", [("dam_break_n16", 2), ("hilbert_n32", 2), ("lattice_n8", 2), ("dam_break_n16", 3)])
-def test_ranks_reproduce_single_process(tmp_path, oracle, case, world):
+@pytest.mark.parametrize("case,world,exchange", [("dam_break_n16", 2, "p2p"), ("hilbert_n32", 2, "p2p"), ("lattice_n8", 2, "p2p"), ("dam_break_n16", 3, "p2p"),
+                                                 ("dam_break_n16", 3, "allgather")])
+def test_ranks_reproduce_single_process(tmp_path, oracle, case, world, exchange):
     import mesh_compare as MC
     out = str(tmp_path / "merged.npz")
-    mp.spawn(_worker, args=(world, _free_port(), case, out), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), case, out, exchange), nprocs=world, join=True)
     got = np.load(out)
     pts, r, l, c, n_cubes = _case(case)
     ref = oracle.reconstruct_surface(pts, oracle.make_params_relative(r, l, c, subdomain_num_cubes_per_dim=n_cubes))
@@ -119,3 +121,52 @@ def test_partition_is_balanced_and_contiguous():
     # more ranks than subdomains: trailing ranks get empty slabs, nothing is lost
     slabs = partition_slabs(x, 0.0, 5.0, 2, 4)
     assert slabs[-1][1] == 2 and sum(hi - lo for lo, hi in slabs) == 2
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# GPU: two real processes, both on GPU 0, exchanging halos over gloo, each driving the HIP shard ABI
+# (ss_shard_begin_f32 / ss_shard_finish) -- everything of the N > 1 bench path except RCCL's own transport,
+# which needs a second GPU (RCCL refuses two ranks on one device).
+# ---------------------------------------------------------------------------------------------------------------
+def _gpu_worker(rank, world, port, case, out_path):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from splashsurf_amd import distributed as D
+        from splashsurf_amd.api import Context, Parameters
+        pts, r, l, c, n_cubes = _case(case)
+        torch.cuda.set_device(0)
+        dev = torch.device("cuda", 0)
+        prm = Parameters(particle_radius=r, compact_support_radius=np.float32(2.0 * l * r), cube_size=np.float32(c * r),
+                         subdomain_num_cubes_per_dim=n_cubes, auto_disable=False)
+        cut = [0] + [int(round(pts.shape[0] * (k + 1) / world)) for k in range(world)]
+        sh = D.ShardedReconstruction(D.HipEngine(Context(0), prm), dev)
+        sh.load_local_particles(pts[cut[rank]:cut[rank + 1]])
+        for _ in range(2):  # second step reuses every buffer
+            step = sh.step()
+        merged = sh.gather_mesh(step)
+        rho_global = sh.gather_densities()
+        if rank == 0:
+            v, k, t = merged
+            np.savez(out_path, vertices=v, keys=k, triangles=t, rho=rho_global.cpu().numpy(),
+                     slab=np.array([step.shard.sub_lo, step.shard.sub_hi]), n_local=np.int64(step.ids.shape[0]))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case,world", [("dam_break_n16", 2), ("hilbert_n32", 3)])
+def test_gpu_ranks_on_one_device_reproduce_single_process(tmp_path, oracle, case, world):
+    import mesh_compare as MC
+    out = str(tmp_path / "merged_gpu.npz")
+    mp.spawn(_gpu_worker, args=(world, _free_port(), case, out), nprocs=world, join=True)
+    got = np.load(out)
+    pts, r, l, c, n_cubes = _case(case)
+    ref = oracle.reconstruct_surface(pts, oracle.make_params_relative(r, l, c, subdomain_num_cubes_per_dim=n_cubes))
+    assert got["slab"][1].max() > 0 and int(got["n_local"]) < pts.shape[0]
+    assert np.array_equal(got["rho"].view(np.uint32), ref.particle_densities.view(np.uint32))
+    cmp = MC.compare_keyed(got["vertices"], got["keys"], got["triangles"], ref.vertices, ref.vertex_keys, ref.triangles)
+    assert cmp["keys_equal"] and cmp["triangles_equal"] and cmp["vertices_bit_equal"], cmp
