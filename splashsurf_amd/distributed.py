@@ -333,7 +333,15 @@ class ShardedReconstruction:
         dmin = lo_hi[0].cpu().numpy() if n_total else np.zeros(3, np_dt)
         dmax = (-lo_hi[1]).cpu().numpy() if n_total else np.zeros(3, np_dt)
         gmin, sub_size, ns, margin, n_cubes = eng.grid_for_domain(dmin, dmax)
-        axis = int(np.argmax(ns))
+        # slab axis: the longest axis of the subdomain grid; among equally long axes the one along which the ranks'
+        # inputs are already separated (smallest local/global extent, maximised over ranks), so that fewer particles move
+        ext = torch.zeros(3, dtype=torch.float64, device=dev)
+        if local.shape[0] and n_total:
+            span = torch.tensor([max(float(dmax[d] - dmin[d]), 1e-300) for d in range(3)], dtype=torch.float64, device=dev)
+            ext = torch.stack([(mm[d].max - mm[d].min).to(torch.float64) for d in range(3)]) / span
+        ext = self._all_reduce(ext, dist.ReduceOp.MAX).cpu().numpy()
+        longest = max(ns)
+        axis = min((d for d in range(3) if ns[d] == longest), key=lambda d: (ext[d], d))
         self._tick("1_ids_aabb_grid")
         # 3. slab partition balanced by owner counts (histogram all-reduced, so identical everywhere)
         s_own = torch.floor((local[:, axis] - float(gmin[axis])) / sub_size).to(torch.int64).clamp_(0, ns[axis] - 1)

@@ -58,6 +58,9 @@ def _worker(rank, world, port, case, out_path, exchange="p2p"):
         par = O.make_params_relative(r, l, c, subdomain_num_cubes_per_dim=n_cubes, num_threads=2)
         # contiguous split of the input: global particle order = concatenation by rank
         cut = [0] + [int(round(pts.shape[0] * (k + 1) / world)) for k in range(world)]
+        if case == "tank_slabs":  # the bench's weak-scaling input: one tank per rank, stacked along y
+            from splashsurf_amd import workloads as W
+            cut = [0] + [int(x) for x in np.cumsum([W.tank_slab_particles(k, world, scale=0.06).shape[0] for k in range(world)])]
         sh = D.ShardedReconstruction(OracleEngine(O, par), "cpu")
         sh.load_local_particles(pts[cut[rank]:cut[rank + 1]])
         step = sh.step()
@@ -77,6 +80,9 @@ def _case(name):
         return np.load(os.path.join(data, "double_dam_break_frame_26_4732_particles.npy")), 0.025, 2.0, 1.1, 16
     if name == "hilbert_n32":
         return np.load(os.path.join(data, "hilbert_46843_particles.npy"))[::4].copy(), 0.025, 2.0, 1.0, 32
+    if name == "tank_slabs":
+        from splashsurf_amd import workloads as W
+        return np.concatenate([W.tank_slab_particles(k, 2, scale=0.06) for k in range(2)]), 0.005, 2.0, 0.5, 64
     if name == "lattice_n8":
         return np.load(os.path.join(data, "cube_2366_particles.npy")), 0.025, 2.0, 0.75, 8
     raise KeyError(name)
@@ -91,7 +97,7 @@ def _free_port():
 
 
 @pytest.mark.parametrize("case,world,exchange", [("dam_break_n16", 2, "p2p"), ("hilbert_n32", 2, "p2p"), ("lattice_n8", 2, "p2p"), ("dam_break_n16", 3, "p2p"),
-                                                 ("dam_break_n16", 3, "allgather")])
+                                                 ("dam_break_n16", 3, "allgather"), ("tank_slabs", 2, "p2p")])
 def test_ranks_reproduce_single_process(tmp_path, oracle, case, world, exchange):
     import mesh_compare as MC
     out = str(tmp_path / "merged.npz")
@@ -106,6 +112,14 @@ def test_ranks_reproduce_single_process(tmp_path, oracle, case, world, exchange)
     assert cmp["keys_equal"] and cmp["triangles_equal"], cmp
     # face vertices: each rank's lowest-index subdomain wins; identical to the single-process choice
     assert cmp["vertices_bit_equal"], cmp
+    if case == "tank_slabs":
+        # equally long axes: the slabs are cut along y, where the ranks' inputs are already separated
+        par = oracle.make_params_relative(r, l, c, subdomain_num_cubes_per_dim=n_cubes)
+        _, sg, _ = oracle.grid_for_domain(par, pts.min(axis=0), pts.max(axis=0))
+        ns = [int(x) for x in sg["n_cells"]]
+        hi = [int(x) for x in got["slab"][1]]
+        assert ns[0] == ns[1] == ns[2], ns  # the tie this case is about
+        assert hi[0] == ns[0] and hi[2] == ns[2] and 0 < hi[1] < ns[1], (hi, ns)
 
 
 def test_partition_is_balanced_and_contiguous():
