@@ -246,6 +246,22 @@ ss_status ss_grid_for_domain_f32(const ss_params_f32 *params, const float domain
 ss_status ss_grid_for_domain_f64(const ss_params_f64 *params, const double domain_min[3], const double domain_max[3],
                                  ss_grid_f64 *grid, ss_grid_f64 *subdomain_grid, double *ghost_margin);
 
+/* -- stand-alone entry points on the stages of the global strategy --
+ * marching_cubes::triangulate_density_map on a dense array of function values (marching_cubes.rs:100-127;
+ * pysplashsurf.marching_cubes): values[(i*ny + j)*nz + k] at grid point translation + (i,j,k)*cube_size, host or HBM
+ * pointer; the mesh is read through the ss_result accessors (vertices by ascending edge key). */
+ss_status ss_marching_cubes_f32(ss_context *ctx, const float *values, const int64_t n_points[3], float iso_surface_threshold, float cube_size,
+                                const float translation[3] /* NULL: origin */, ss_result *inout);
+ss_status ss_marching_cubes_f64(ss_context *ctx, const double *values, const int64_t n_points[3], double iso_surface_threshold, double cube_size,
+                                const double translation[3], ss_result *inout);
+/* neighborhood_search::neighborhood_search_spatial_hashing (neighborhood_search.rs:131-230; pysplashsurf exposes the
+ * parallel variant, whose per-cell order depends on thread timing): lists via ss_result_particle_neighbors, in the
+ * order of the reference's sequential function.  Particles outside `domain` are an error (the reference panics). */
+ss_status ss_neighborhood_search_f32(ss_context *ctx, const float *xyz, uint64_t n_particles, const float domain_min[3], const float domain_max[3],
+                                     float search_radius, ss_result *inout);
+ss_status ss_neighborhood_search_f64(ss_context *ctx, const double *xyz, uint64_t n_particles, const double domain_min[3], const double domain_max[3],
+                                     double search_radius, ss_result *inout);
+
 /* =====================================================================================================
  * Post-processing: the stages of the reference's pipeline that consume the mesh right after the
  * reconstruction (splashsurf/src/reconstruct.rs:1085-1345).  Every array argument may be a host pointer or an HBM

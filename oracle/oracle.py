@@ -293,6 +293,36 @@ def _unpack(res, params):
     return out
 
 
+def marching_cubes(values, iso_surface_threshold, cube_size, translation=None):
+    """pysplashsurf.marching_cubes on a dense array; raises RuntimeError(code) on the reference's error paths."""
+    vals = np.ascontiguousarray(values)
+    assert vals.ndim == 3 and vals.dtype in (np.float32, np.float64)
+    pre, npdt, creal, (_, _, Rs, _) = _flavour(vals.dtype)
+    fn = getattr(lib(), pre + "marching_cubes")
+    fn.argtypes = [C.c_void_p, C.POINTER(C.c_int64), creal, creal, C.POINTER(creal), C.POINTER(Rs)]
+    fn.restype = C.c_int
+    res = Rs()
+    npts = (C.c_int64 * 3)(*[int(x) for x in vals.shape])
+    tr = (creal * 3)(*([float(npdt(x)) for x in translation] if translation is not None else [0.0, 0.0, 0.0]))
+    rc = fn(vals.ctypes.data_as(C.c_void_p), npts, creal(float(npdt(iso_surface_threshold))), creal(float(npdt(cube_size))), tr, C.byref(res))
+    if rc != 0:
+        getattr(lib(), pre + "result_free").argtypes = [C.POINTER(Rs)]
+        getattr(lib(), pre + "result_free")(C.byref(res))
+        raise RuntimeError("oracle marching_cubes failed with code %d" % rc)
+    out = OracleResult()
+    try:
+        nv, nt = int(res.n_vertices), int(res.n_triangles)
+        out.vertices = np.ctypeslib.as_array(res.vertices, shape=(nv * 3,)).copy().reshape(nv, 3) if nv else np.zeros((0, 3), npdt)
+        out.vertex_keys = np.ctypeslib.as_array(res.vertex_keys, shape=(nv,)).copy() if nv else np.zeros((0,), np.uint64)
+        out.triangles = np.ctypeslib.as_array(res.triangles, shape=(nt * 3,)).copy().reshape(nt, 3) if nt else np.zeros((0, 3), np.uint64)
+        out.grid = _grid_dict(res.grid, npdt)
+    finally:
+        fr = getattr(lib(), pre + "result_free")
+        fr.argtypes = [C.POINTER(Rs)]
+        fr(C.byref(res))
+    return out
+
+
 def grid_for_reconstruction(xyz, params):
     xyz = _xyz(xyz, params)
     npdt = _flavour(params)[1]

@@ -1167,6 +1167,23 @@ static int reconstruct_surface_global(const real *xyz, uint64_t n, const SOT(par
     return rc;
 }
 
+/* stand-alone marching cubes on a dense array (marching_cubes.rs:100-127 with DensityMap::Dense; pysplashsurf.marching_cubes):
+   grid = UniformGrid::new(translation, n_points - 1, cube_size).  Returns 0, 1 (grid error) or 3 (triangulation error). */
+int SOFN(marching_cubes)(const real *values, const int64_t n_points[3], real threshold, real cube_size, const real translation[3], SOT(result) *out) {
+    memset(out, 0, sizeof(*out));
+    if (!(cube_size > RC(0.0))) return 1;
+    int64_t nc[3];
+    for (int d = 0; d < 3; ++d) {
+        if (n_points[d] < 2) return 1;
+        nc[d] = n_points[d] - 1;
+    }
+    SOT(grid) g;
+    grid_new(&g, translation, nc, cube_size);
+    out->grid = g;
+    out->used_global_strategy = 1;
+    return global_marching_cubes(&g, values, threshold, out);
+}
+
 static int resolve_threads(const SOT(params) *P) {
 #ifdef _OPENMP
     int t = P->num_threads > 0 ? P->num_threads : omp_get_max_threads();

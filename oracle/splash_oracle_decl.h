@@ -53,6 +53,10 @@ void SOFN(result_free)(SOT(result) *r);
 /* lib.rs:476-516 */
 int SOFN(grid_for_reconstruction)(const SO_REAL *xyz, uint64_t n, const SOT(params) *params, SOT(grid) *out);
 
+/* stand-alone marching cubes on a dense value array (marching_cubes.rs:100-127); 0 ok, 1 grid error, 3 triangulation error */
+int SOFN(marching_cubes)(const SO_REAL *values, const int64_t n_points[3], SO_REAL threshold, SO_REAL cube_size, const SO_REAL translation[3],
+                         SOT(result) *out);
+
 /* Debug/observability entry points used by the parity tests */
 /* level-set values (65^3, flat (i*np+j)*np+k) of one subdomain given final densities; returns particle count of the subdomain or -1 if unoccupied */
 int64_t SOFN(debug_levelset_subdomain)(const SO_REAL *xyz, uint64_t n, const SOT(params) *params,

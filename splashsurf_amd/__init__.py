@@ -13,6 +13,9 @@ from .api import (  # noqa: F401
     reconstruct_surface,
     reconstruct_surface_abs,
     grid_for_reconstruction,
+    marching_cubes,
+    neighborhood_search_spatial_hashing_parallel,
+    Aabb3d,
     library_path,
     load_library,
 )

@@ -569,6 +569,82 @@ def reconstruct_surface(particles, *, particle_radius, rest_density=1000.0, smoo
     return reconstruct_surface_abs(particles, prm, context=context)
 
 
+def _new_result(ctx):
+    h = C.c_void_p()
+    st = ctx._lib.ss_result_create(ctx._h, C.byref(h))
+    if st != 0:
+        ctx._raise(st)
+    return SurfaceReconstruction(ctx, h)
+
+
+def marching_cubes(values, *, iso_surface_threshold, cube_size, translation=None, return_grid=False, context=None):
+    """`pysplashsurf.marching_cubes` (pysplashsurf/src/marching_cubes.rs:58-127): marching cubes on a dense 3D array of
+    function values at the points translation + (i, j, k) * cube_size; the reference's global-strategy triangulation
+    (marching_cubes.rs:100-127).  Returns the TriMesh3d (vertices in ascending edge-key order), optionally with the grid."""
+    ctx = context or default_context()
+    L = ctx._lib
+    if hasattr(values, "data_ptr"):  # torch tensor (host or HBM)
+        vals = values.contiguous()
+        if str(vals.dtype) not in ("torch.float32", "torch.float64"):
+            raise TypeError("values must be float32 or float64")
+        f64 = str(vals.dtype) == "torch.float64"
+        ptr = C.c_void_p(vals.data_ptr())
+    else:
+        vals = np.asarray(values)
+        if vals.dtype not in (np.float32, np.float64):
+            raise TypeError("values must be float32 or float64")
+        vals = np.ascontiguousarray(vals)
+        f64 = vals.dtype == np.float64
+        ptr = C.c_void_p(vals.ctypes.data)
+    if len(vals.shape) != 3:
+        raise ValueError("values must be a 3D array")
+    real = C.c_double if f64 else C.c_float
+    dt = np.float64 if f64 else np.float32
+    npts = (C.c_int64 * 3)(*[int(x) for x in vals.shape])
+    tr = None if translation is None else (real * 3)(*[float(dt(x)) for x in translation])
+    res = _new_result(ctx)
+    fn = L.ss_marching_cubes_f64 if f64 else L.ss_marching_cubes_f32
+    fn.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_int64), real, real, C.c_void_p, C.c_void_p]
+    st = fn(ctx._h, ptr, npts, real(float(dt(iso_surface_threshold))), real(float(dt(cube_size))), tr, res._h)
+    if st != 0:
+        ctx._raise(st)
+    return (res.mesh, res.grid) if return_grid else res.mesh
+
+
+class NeighborhoodLists:
+    """pysplashsurf.NeighborhoodLists: per-particle neighbour index lists."""
+
+    def __init__(self, result):
+        self._result = result
+
+    @property
+    def csr(self):
+        return self._result.particle_neighbors_csr
+
+    def get_neighborhood_lists(self):
+        return self._result.particle_neighbors
+
+
+def neighborhood_search_spatial_hashing_parallel(particle_positions, domain, search_radius, context=None):
+    """`pysplashsurf.neighborhood_search_spatial_hashing_parallel(particle_positions, domain, search_radius)`; lists come
+    in the order of the reference's sequential function (neighborhood_search.rs:131-230) -- the parallel one's per-cell
+    order depends on thread timing."""
+    ctx = context or default_context()
+    L = ctx._lib
+    ptr, n, keep, f64 = ctx._as_ptr(particle_positions)
+    real = C.c_double if f64 else C.c_float
+    dt = np.float64 if f64 else np.float32
+    lo = (real * 3)(*[float(dt(x)) for x in domain.min])
+    hi = (real * 3)(*[float(dt(x)) for x in domain.max])
+    res = _new_result(ctx)
+    fn = L.ss_neighborhood_search_f64 if f64 else L.ss_neighborhood_search_f32
+    fn.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(real), C.POINTER(real), real, C.c_void_p]
+    st = fn(ctx._h, ptr, n, lo, hi, real(float(dt(search_radius))), res._h)
+    if st != 0:
+        ctx._raise(st)
+    return NeighborhoodLists(res)
+
+
 def grid_for_reconstruction(particles, parameters, context=None):
     """`splashsurf_lib::grid_for_reconstruction` (lib.rs:476-516)."""
     ctx = context or default_context()

@@ -318,6 +318,117 @@ bool use_global_strategy(const typename TypesOf<R>::params* prm, const typename 
     return !(mc > with_margin);
 }
 
+// marching cubes of the global strategy on the dense level-set array res->G (narrow_band_extraction.rs, triangulation.rs);
+// records events 7..9; also serves ss_marching_cubes_* (triangulate_density_map on DensityMap::Dense, marching_cubes.rs:100-127)
+template <class R>
+ss_status global_marching_cubes(ss_context* ctx, const SSGlobT<R>& Q, ss_result* res, uint64_t* nv_out, uint64_t* nt_out) {
+    hipStream_t st = ctx->stream;
+    ss_status s = SS_OK;
+    const size_t npts = (size_t)Q.np[0] * Q.np[1] * Q.np[2], ncell = (size_t)Q.nc[0] * Q.nc[1] * Q.nc[2];
+    SS_HIP(ctx, ctx->counter.reserve(64));
+    uint32_t* d_err = ctx->counter.as<uint32_t>();
+    SS_HIP(ctx, res->masks.reserve(npts + 16));
+    SS_HIP(ctx, ctx->vcount.reserve((npts + 1) * 4));
+    SS_HIP(ctx, ctx->tcount.reserve((ncell + 1) * 4));
+    SS_HIP(ctx, res->vbase.reserve((npts + 1) * 4));
+    SS_HIP(ctx, res->tbase.reserve((ncell + 1) * 4));
+    SS_HIP(ctx, hipMemsetAsync(ctx->vcount.as<uint32_t>() + npts, 0, 4, st));
+    SS_HIP(ctx, hipMemsetAsync(ctx->tcount.as<uint32_t>() + ncell, 0, 4, st));
+    ssg_launch_edge_masks<R>(Q, res->G.as<R>(), res->masks.as<uint8_t>(), ctx->vcount.as<uint32_t>(), st);
+    ssg_launch_cell_count<R>(Q, res->G.as<R>(), res->masks.as<uint8_t>(), ctx->tcount.as<uint32_t>(), d_err, st);
+    SS_HIP(ctx, hipEventRecord(ctx->ev[7], st));
+    s = exclusive_scan_u32<uint32_t>(ctx, ctx->vcount.as<uint32_t>(), res->vbase.as<uint32_t>(), npts + 1);
+    if (s != SS_OK) return s;
+    s = exclusive_scan_u32<uint32_t>(ctx, ctx->tcount.as<uint32_t>(), res->tbase.as<uint32_t>(), ncell + 1);
+    if (s != SS_OK) return s;
+    uint32_t totals[2] = {0, 0}, herr = 0;
+    SS_HIP(ctx, hipMemcpyAsync(&totals[0], res->vbase.as<uint32_t>() + npts, 4, hipMemcpyDeviceToHost, st));
+    SS_HIP(ctx, hipMemcpyAsync(&totals[1], res->tbase.as<uint32_t>() + ncell, 4, hipMemcpyDeviceToHost, st));
+    SS_HIP(ctx, hipMemcpyAsync(&herr, d_err, 4, hipMemcpyDeviceToHost, st));
+    SS_HIP(ctx, hipStreamSynchronize(st));
+    if (herr & 2u) return fail(ctx, SS_ERR_MARCHING_CUBES, "missing iso surface vertex at an edge (TriangulationError, triangulation.rs:62-95)");
+    const uint64_t nv = totals[0], nt = totals[1];
+    *nv_out = nv;
+    *nt_out = nt;
+    if (nt * 3 >= (1ull << 32)) return fail(ctx, SS_ERR_UNSUPPORTED, "more than 2^32/3 triangles in one call are not supported by this build");
+    SS_HIP(ctx, res->vertices.reserve(nv * 3 * sizeof(R) + 16));
+    SS_HIP(ctx, res->vkeys.reserve(nv * 8 + 16));
+    SS_HIP(ctx, res->tri32.reserve(nt * 12 + 16));
+    SS_HIP(ctx, hipEventRecord(ctx->ev[8], st));
+    ssg_launch_emit_vertices<R>(Q, res->G.as<R>(), res->masks.as<uint8_t>(), res->vbase.as<uint32_t>(), res->vertices.as<R>(), res->vkeys.as<unsigned long long>(), st);
+    ssg_launch_emit_triangles<R>(Q, res->G.as<R>(), res->masks.as<uint8_t>(), res->vbase.as<uint32_t>(), ctx->tcount.as<uint32_t>(), res->tbase.as<uint32_t>(),
+                                 res->tri32.as<uint32_t>(), st);
+    SS_HIP(ctx, hipEventRecord(ctx->ev[9], st));
+    SS_HIP(ctx, hipStreamSynchronize(st));
+    {
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return fail(ctx, SS_ERR_DEVICE, std::string("kernel launch failed: ") + hipGetErrorString(e));
+    }
+    return SS_OK;
+}
+
+// neighbourhood search on the grid Q.smin/Q.snc (cell size Q.h) + densities; fills res->rho, res->nb_ptr, res->nb_idx
+// (neighborhood_search.rs:148-230, density_map.rs:113-186); records event 3 after the cell map is built
+template <class R>
+ss_status global_search_and_densities(ss_context* ctx, const SSGlobT<R>& Q, const R* d_xyz, ss_result* res) {
+    hipStream_t st = ctx->stream;
+    ss_status s = SS_OK;
+    const uint32_t n = Q.n;
+    const size_t nscell = (size_t)Q.snc[0] * Q.snc[1] * Q.snc[2];
+    SS_HIP(ctx, ctx->counter.reserve(64));
+    SS_HIP(ctx, hipMemsetAsync(ctx->counter.p, 0, 64, st));
+    uint32_t* d_err = ctx->counter.as<uint32_t>();
+    SS_HIP(ctx, res->rho.reserve((size_t)n * sizeof(R) + 16));
+    SS_HIP(ctx, res->perm.reserve((size_t)n * 4 + 16));
+    SS_HIP(ctx, ctx->cell_count.reserve((nscell + 1) * 4));
+    SS_HIP(ctx, ctx->cell_start.reserve((nscell + 1) * 4));
+    SS_HIP(ctx, hipMemsetAsync(ctx->cell_count.p, 0, (nscell + 1) * 4, st));
+    SS_HIP(ctx, res->nb_ptr.reserve(((size_t)n + 1) * 8));
+    res->has_neighbors = true;  // the global strategy always returns the neighbour lists (reconstruction.rs:107-108)
+    res->n_neighbors = 0;
+    if (n > 0) {
+        SS_HIP(ctx, ctx->keys_a.reserve((size_t)n * 4));
+        SS_HIP(ctx, ctx->keys_b.reserve((size_t)n * 4));
+        SS_HIP(ctx, ctx->vals_a.reserve((size_t)n * 4));
+        ssg_launch_cell_keys<R>(Q, d_xyz, ctx->keys_a.as<uint32_t>(), ctx->vals_a.as<uint32_t>(), ctx->cell_count.as<uint32_t>(), d_err, st);
+        s = exclusive_scan_u32<uint32_t>(ctx, ctx->cell_count.as<uint32_t>(), ctx->cell_start.as<uint32_t>(), nscell + 1);
+        if (s != SS_OK) return s;
+        unsigned bits = 1;
+        while (bits < 32 && ((size_t)1 << bits) < nscell) ++bits;
+        size_t bytes = 0;
+        SS_HIP(ctx, rocprim::radix_sort_pairs(nullptr, bytes, ctx->keys_a.as<uint32_t>(), ctx->keys_b.as<uint32_t>(), ctx->vals_a.as<uint32_t>(),
+                                              res->perm.as<uint32_t>(), (size_t)n, 0u, bits, st));
+        SS_HIP(ctx, ctx->temp.reserve(bytes));
+        SS_HIP(ctx, rocprim::radix_sort_pairs(ctx->temp.p, bytes, ctx->keys_a.as<uint32_t>(), ctx->keys_b.as<uint32_t>(), ctx->vals_a.as<uint32_t>(),
+                                              res->perm.as<uint32_t>(), (size_t)n, 0u, bits, st));
+        uint32_t herr = 0;
+        SS_HIP(ctx, hipMemcpyAsync(&herr, d_err, 4, hipMemcpyDeviceToHost, st));
+        SS_HIP(ctx, hipStreamSynchronize(st));
+        if (herr & 1u) return fail(ctx, SS_ERR_UNKNOWN, "particle outside the neighborhood-search grid (reference: panic in get_cell().unwrap())");
+        SS_HIP(ctx, hipEventRecord(ctx->ev[3], st));
+        SS_HIP(ctx, ctx->nb_count.reserve(((size_t)n + 1) * 8));
+        SS_HIP(ctx, ctx->nb_tmp.reserve(((size_t)n + 1) * 8));
+        SS_HIP(ctx, hipMemsetAsync(ctx->nb_count.p, 0, ((size_t)n + 1) * 8, st));
+        ssg_launch_density<R>(Q, d_xyz, ctx->cell_start.as<uint32_t>(), res->perm.as<uint32_t>(), res->rho.as<R>(), 0, ctx->nb_count.as<uint32_t>(), nullptr,
+                              nullptr, st);
+        ss_launch_widen(ctx->nb_count.as<uint32_t>(), (size_t)n + 1, ctx->nb_tmp.as<unsigned long long>(), st);
+        s = exclusive_scan_u32<unsigned long long>(ctx, ctx->nb_tmp.as<unsigned long long>(), res->nb_ptr.as<unsigned long long>(), (size_t)n + 1);
+        if (s != SS_OK) return s;
+        unsigned long long total_nb = 0;
+        SS_HIP(ctx, hipMemcpyAsync(&total_nb, res->nb_ptr.as<unsigned long long>() + n, 8, hipMemcpyDeviceToHost, st));
+        SS_HIP(ctx, hipStreamSynchronize(st));
+        if (total_nb >= (1ull << 32)) return fail(ctx, SS_ERR_UNSUPPORTED, "more than 2^32 neighbour entries");
+        res->n_neighbors = total_nb;
+        SS_HIP(ctx, res->nb_idx.reserve((size_t)total_nb * 4 + 16));
+        ssg_launch_density<R>(Q, d_xyz, ctx->cell_start.as<uint32_t>(), res->perm.as<uint32_t>(), res->rho.as<R>(), 2, nullptr,
+                              res->nb_ptr.as<unsigned long long>(), res->nb_idx.as<uint32_t>(), st);
+    } else {
+        SS_HIP(ctx, hipMemsetAsync(res->nb_ptr.p, 0, 8, st));
+        SS_HIP(ctx, hipEventRecord(ctx->ev[3], st));
+    }
+    return SS_OK;
+}
+
 // ---- global (non-decomposed) strategy: reconstruct_surface_global (reconstruction.rs:65-194), kernels in ss_global.hip ----
 template <class R>
 ss_status reconstruct_global(ss_context* ctx, const typename TypesOf<R>::params* prm, const typename TypesOf<R>::grid& grid, const R* d_xyz, uint32_t n,
@@ -390,59 +501,10 @@ ss_status reconstruct_global(ss_context* ctx, const typename TypesOf<R>::params*
         res->Q64 = *reinterpret_cast<SSGlobT<double>*>(&Q);
     SS_HIP(ctx, hipEventRecord(ctx->ev[2], st));
 
-    const size_t npts = (size_t)npts_d, ncell = (size_t)ncell_d, nscell = (size_t)scell_d;
+    const size_t npts = (size_t)npts_d;
     // ---- neighbourhood search + densities ----
-    SS_HIP(ctx, ctx->counter.reserve(64));
-    SS_HIP(ctx, hipMemsetAsync(ctx->counter.p, 0, 64, st));
-    uint32_t* d_err = ctx->counter.as<uint32_t>();
-    SS_HIP(ctx, res->rho.reserve((size_t)n * sizeof(R) + 16));
-    SS_HIP(ctx, res->perm.reserve((size_t)n * 4 + 16));
-    SS_HIP(ctx, ctx->cell_count.reserve((nscell + 1) * 4));
-    SS_HIP(ctx, ctx->cell_start.reserve((nscell + 1) * 4));
-    SS_HIP(ctx, hipMemsetAsync(ctx->cell_count.p, 0, (nscell + 1) * 4, st));
-    SS_HIP(ctx, res->nb_ptr.reserve(((size_t)n + 1) * 8));
-    res->has_neighbors = true;  // the global strategy always returns the neighbour lists (reconstruction.rs:107-108)
-    res->n_neighbors = 0;
-    if (n > 0) {
-        SS_HIP(ctx, ctx->keys_a.reserve((size_t)n * 4));
-        SS_HIP(ctx, ctx->keys_b.reserve((size_t)n * 4));
-        SS_HIP(ctx, ctx->vals_a.reserve((size_t)n * 4));
-        ssg_launch_cell_keys<R>(Q, d_xyz, ctx->keys_a.as<uint32_t>(), ctx->vals_a.as<uint32_t>(), ctx->cell_count.as<uint32_t>(), d_err, st);
-        s = exclusive_scan_u32<uint32_t>(ctx, ctx->cell_count.as<uint32_t>(), ctx->cell_start.as<uint32_t>(), nscell + 1);
-        if (s != SS_OK) return s;
-        unsigned bits = 1;
-        while (bits < 32 && ((size_t)1 << bits) < nscell) ++bits;
-        size_t bytes = 0;
-        SS_HIP(ctx, rocprim::radix_sort_pairs(nullptr, bytes, ctx->keys_a.as<uint32_t>(), ctx->keys_b.as<uint32_t>(), ctx->vals_a.as<uint32_t>(),
-                                              res->perm.as<uint32_t>(), (size_t)n, 0u, bits, st));
-        SS_HIP(ctx, ctx->temp.reserve(bytes));
-        SS_HIP(ctx, rocprim::radix_sort_pairs(ctx->temp.p, bytes, ctx->keys_a.as<uint32_t>(), ctx->keys_b.as<uint32_t>(), ctx->vals_a.as<uint32_t>(),
-                                              res->perm.as<uint32_t>(), (size_t)n, 0u, bits, st));
-        uint32_t herr = 0;
-        SS_HIP(ctx, hipMemcpyAsync(&herr, d_err, 4, hipMemcpyDeviceToHost, st));
-        SS_HIP(ctx, hipStreamSynchronize(st));
-        if (herr & 1u) return fail(ctx, SS_ERR_UNKNOWN, "particle outside the neighborhood-search grid (reference: panic in get_cell().unwrap())");
-        SS_HIP(ctx, hipEventRecord(ctx->ev[3], st));
-        SS_HIP(ctx, ctx->nb_count.reserve(((size_t)n + 1) * 8));
-        SS_HIP(ctx, ctx->nb_tmp.reserve(((size_t)n + 1) * 8));
-        SS_HIP(ctx, hipMemsetAsync(ctx->nb_count.p, 0, ((size_t)n + 1) * 8, st));
-        ssg_launch_density<R>(Q, d_xyz, ctx->cell_start.as<uint32_t>(), res->perm.as<uint32_t>(), res->rho.as<R>(), 0, ctx->nb_count.as<uint32_t>(), nullptr,
-                              nullptr, st);
-        ss_launch_widen(ctx->nb_count.as<uint32_t>(), (size_t)n + 1, ctx->nb_tmp.as<unsigned long long>(), st);
-        s = exclusive_scan_u32<unsigned long long>(ctx, ctx->nb_tmp.as<unsigned long long>(), res->nb_ptr.as<unsigned long long>(), (size_t)n + 1);
-        if (s != SS_OK) return s;
-        unsigned long long total_nb = 0;
-        SS_HIP(ctx, hipMemcpyAsync(&total_nb, res->nb_ptr.as<unsigned long long>() + n, 8, hipMemcpyDeviceToHost, st));
-        SS_HIP(ctx, hipStreamSynchronize(st));
-        if (total_nb >= (1ull << 32)) return fail(ctx, SS_ERR_UNSUPPORTED, "more than 2^32 neighbour entries");
-        res->n_neighbors = total_nb;
-        SS_HIP(ctx, res->nb_idx.reserve((size_t)total_nb * 4 + 16));
-        ssg_launch_density<R>(Q, d_xyz, ctx->cell_start.as<uint32_t>(), res->perm.as<uint32_t>(), res->rho.as<R>(), 2, nullptr,
-                              res->nb_ptr.as<unsigned long long>(), res->nb_idx.as<uint32_t>(), st);
-    } else {
-        SS_HIP(ctx, hipMemsetAsync(res->nb_ptr.p, 0, 8, st));
-        SS_HIP(ctx, hipEventRecord(ctx->ev[3], st));
-    }
+    s = global_search_and_densities<R>(ctx, Q, d_xyz, res);
+    if (s != SS_OK) return s;
     SS_HIP(ctx, hipEventRecord(ctx->ev[4], st));
 
     // ---- sparse density map -> dense level-set array (density_map.rs:364-412) ----
@@ -463,41 +525,9 @@ ss_status reconstruct_global(ss_context* ctx, const typename TypesOf<R>::params*
     SS_HIP(ctx, hipEventRecord(ctx->ev[6], st));
 
     // ---- marching cubes (narrow_band_extraction.rs, triangulation.rs) ----
-    SS_HIP(ctx, res->masks.reserve(npts + 16));
-    SS_HIP(ctx, ctx->vcount.reserve((npts + 1) * 4));
-    SS_HIP(ctx, ctx->tcount.reserve((ncell + 1) * 4));
-    SS_HIP(ctx, res->vbase.reserve((npts + 1) * 4));
-    SS_HIP(ctx, res->tbase.reserve((ncell + 1) * 4));
-    SS_HIP(ctx, hipMemsetAsync(ctx->vcount.as<uint32_t>() + npts, 0, 4, st));
-    SS_HIP(ctx, hipMemsetAsync(ctx->tcount.as<uint32_t>() + ncell, 0, 4, st));
-    ssg_launch_edge_masks<R>(Q, res->G.as<R>(), res->masks.as<uint8_t>(), ctx->vcount.as<uint32_t>(), st);
-    ssg_launch_cell_count<R>(Q, res->G.as<R>(), res->masks.as<uint8_t>(), ctx->tcount.as<uint32_t>(), d_err, st);
-    SS_HIP(ctx, hipEventRecord(ctx->ev[7], st));
-    s = exclusive_scan_u32<uint32_t>(ctx, ctx->vcount.as<uint32_t>(), res->vbase.as<uint32_t>(), npts + 1);
+    uint64_t nv = 0, nt = 0;
+    s = global_marching_cubes<R>(ctx, Q, res, &nv, &nt);
     if (s != SS_OK) return s;
-    s = exclusive_scan_u32<uint32_t>(ctx, ctx->tcount.as<uint32_t>(), res->tbase.as<uint32_t>(), ncell + 1);
-    if (s != SS_OK) return s;
-    uint32_t totals[2] = {0, 0}, herr = 0;
-    SS_HIP(ctx, hipMemcpyAsync(&totals[0], res->vbase.as<uint32_t>() + npts, 4, hipMemcpyDeviceToHost, st));
-    SS_HIP(ctx, hipMemcpyAsync(&totals[1], res->tbase.as<uint32_t>() + ncell, 4, hipMemcpyDeviceToHost, st));
-    SS_HIP(ctx, hipMemcpyAsync(&herr, d_err, 4, hipMemcpyDeviceToHost, st));
-    SS_HIP(ctx, hipStreamSynchronize(st));
-    if (herr & 2u) return fail(ctx, SS_ERR_MARCHING_CUBES, "missing iso surface vertex at an edge (TriangulationError, triangulation.rs:62-95)");
-    const uint64_t nv = totals[0], nt = totals[1];
-    if (nt * 3 >= (1ull << 32)) return fail(ctx, SS_ERR_UNSUPPORTED, "more than 2^32/3 triangles in one call are not supported by this build");
-    SS_HIP(ctx, res->vertices.reserve(nv * 3 * sizeof(R) + 16));
-    SS_HIP(ctx, res->vkeys.reserve(nv * 8 + 16));
-    SS_HIP(ctx, res->tri32.reserve(nt * 12 + 16));
-    SS_HIP(ctx, hipEventRecord(ctx->ev[8], st));
-    ssg_launch_emit_vertices<R>(Q, res->G.as<R>(), res->masks.as<uint8_t>(), res->vbase.as<uint32_t>(), res->vertices.as<R>(), res->vkeys.as<unsigned long long>(), st);
-    ssg_launch_emit_triangles<R>(Q, res->G.as<R>(), res->masks.as<uint8_t>(), res->vbase.as<uint32_t>(), ctx->tcount.as<uint32_t>(), res->tbase.as<uint32_t>(),
-                                 res->tri32.as<uint32_t>(), st);
-    SS_HIP(ctx, hipEventRecord(ctx->ev[9], st));
-    SS_HIP(ctx, hipStreamSynchronize(st));
-    {
-        hipError_t e = hipGetLastError();
-        if (e != hipSuccess) return fail(ctx, SS_ERR_DEVICE, std::string("kernel launch failed: ") + hipGetErrorString(e));
-    }
     res->n_vertices = nv;
     res->n_triangles = nt;
     ss_stats& S = res->stats;
@@ -861,6 +891,149 @@ ss_status reconstruct_impl(ss_context* ctx, const R* xyz, uint64_t n_in, const t
     return phase_finish<R>(ctx, res);
 }
 
+// ---- stand-alone entry points on the global strategy's stages ----
+// marching_cubes::triangulate_density_map on a dense value array (marching_cubes.rs:100-127; pysplashsurf.marching_cubes)
+template <class R>
+ss_status marching_cubes_impl(ss_context* ctx, const R* values, const int64_t n_points[3], R threshold, R cube_size, const R translation[3], ss_result* res) {
+    if (!ctx || !res || !n_points) return SS_ERR_INVALID_ARGUMENT;
+    if (res->ctx != ctx) return fail(ctx, SS_ERR_INVALID_ARGUMENT, "result belongs to a different context");
+    ctx->err.clear();
+    ctx->err_detail = 0;
+    if (!(cube_size > R(0.0))) return fail(ctx, SS_ERR_GRID_CONSTRUCTION, "cube size must be positive (uniform_grid.rs:147-169)", SS_GRID_INVALID_CELL_SIZE);
+    double npts_d = 1.0;
+    for (int d = 0; d < 3; ++d) {
+        if (n_points[d] < 2 || n_points[d] > 2000000000ll) return fail(ctx, SS_ERR_GRID_CONSTRUCTION, "every dimension of the value array needs at least 2 points");
+        npts_d *= (double)n_points[d];
+    }
+    if (npts_d >= 2.0e9) return fail(ctx, SS_ERR_UNSUPPORTED, "value array too large for this build (< 2e9 points)");
+    if (!values) return fail(ctx, SS_ERR_INVALID_ARGUMENT, "values pointer is null");
+    SS_HIP(ctx, hipSetDevice(ctx->device));
+    ss_status s = ensure_events(ctx);
+    if (s != SS_OK) return s;
+    hipStream_t st = ctx->stream;
+    res->valid = false;
+    res->phase = 0;
+    reset_host_flags(res);
+    memset(&res->stats, 0, sizeof(res->stats));
+    res->n_input = res->n_particles = 0;
+    res->n_vertices = res->n_triangles = 0;
+    res->has_inside = false;
+    res->has_neighbors = false;
+    res->n_neighbors = 0;
+    res->is_f64 = sizeof(R) == 8;
+    res->global_strategy = true;
+    res->host_input = !is_device_pointer(values);
+    typename TypesOf<R>::grid& g = result_grid<R>(res);
+    R mn[3] = {R(0.0), R(0.0), R(0.0)};
+    int64_t nc[3];
+    for (int d = 0; d < 3; ++d) {
+        if (translation) mn[d] = translation[d];
+        nc[d] = n_points[d] - 1;
+    }
+    grid_new<R>(&g, mn, nc, cube_size);  // UniformGrid::new (uniform_grid.rs:203-232): min = translation, no alignment
+    memset(&result_subgrid<R>(res), 0, sizeof(typename TypesOf<R>::grid));
+    SSGlobT<R> Q;
+    memset(&Q, 0, sizeof(Q));
+    for (int d = 0; d < 3; ++d) {
+        Q.gmin[d] = g.aabb_min[d];
+        Q.np[d] = (int)n_points[d];
+        Q.nc[d] = (int)nc[d];
+    }
+    Q.cs = cube_size;
+    Q.threshold = threshold;
+    if (sizeof(R) == 4)
+        res->Q32 = *reinterpret_cast<SSGlobT<float>*>(&Q);
+    else
+        res->Q64 = *reinterpret_cast<SSGlobT<double>*>(&Q);
+    const size_t npts = (size_t)npts_d;
+    SS_HIP(ctx, hipEventRecord(ctx->ev[0], st));
+    SS_HIP(ctx, res->G.reserve(npts * sizeof(R) + 16));
+    SS_HIP(ctx, hipMemcpyAsync(res->G.p, values, npts * sizeof(R), hipMemcpyDefault, st));
+    SS_HIP(ctx, ctx->counter.reserve(64));
+    SS_HIP(ctx, hipMemsetAsync(ctx->counter.p, 0, 64, st));
+    SS_HIP(ctx, hipEventRecord(ctx->ev[6], st));
+    uint64_t nv = 0, nt = 0;
+    s = global_marching_cubes<R>(ctx, Q, res, &nv, &nt);
+    if (s != SS_OK) return s;
+    res->n_vertices = nv;
+    res->n_triangles = nt;
+    ss_stats& S = res->stats;
+    S.ms_total = ev_ms(ctx, 0, 9);
+    S.ms_upload = res->host_input ? ev_ms(ctx, 0, 6) : 0.0;
+    S.ms_marching_cubes = ev_ms(ctx, 6, 7) + ev_ms(ctx, 8, 9);
+    S.ms_stitching = ev_ms(ctx, 7, 8);
+    S.n_vertices = nv;
+    S.n_triangles = nt;
+    res->valid = true;
+    res->phase = 2;
+    return SS_OK;
+}
+
+// neighborhood_search::neighborhood_search_spatial_hashing (neighborhood_search.rs:131-230): lists in the order of the
+// reference's sequential function; the result carries only the neighbour lists
+template <class R>
+ss_status neighborhood_search_impl(ss_context* ctx, const R* xyz, uint64_t n_in, const R domain_min[3], const R domain_max[3], R search_radius, ss_result* res) {
+    if (!ctx || !res || !domain_min || !domain_max) return SS_ERR_INVALID_ARGUMENT;
+    if (res->ctx != ctx) return fail(ctx, SS_ERR_INVALID_ARGUMENT, "result belongs to a different context");
+    ctx->err.clear();
+    ctx->err_detail = 0;
+    if (!(search_radius > R(0.0))) return fail(ctx, SS_ERR_UNKNOWN, "search radius for neighborhood search has to be positive (reference: assert)");
+    if (n_in >= (1ull << 31)) return fail(ctx, SS_ERR_UNSUPPORTED, "too many particles");
+    if (n_in && !xyz) return fail(ctx, SS_ERR_INVALID_ARGUMENT, "particle pointer is null");
+    SS_HIP(ctx, hipSetDevice(ctx->device));
+    ss_status s = ensure_events(ctx);
+    if (s != SS_OK) return s;
+    hipStream_t st = ctx->stream;
+    res->valid = false;
+    res->phase = 0;
+    reset_host_flags(res);
+    memset(&res->stats, 0, sizeof(res->stats));
+    res->n_input = res->n_particles = n_in;
+    res->n_vertices = res->n_triangles = 0;
+    res->has_inside = false;
+    res->is_f64 = sizeof(R) == 8;
+    res->global_strategy = true;
+    memset(&result_grid<R>(res), 0, sizeof(typename TypesOf<R>::grid));
+    memset(&result_subgrid<R>(res), 0, sizeof(typename TypesOf<R>::grid));
+    typename TypesOf<R>::grid sgrid;
+    if (grid_from_aabb<R>(&sgrid, domain_min, domain_max, search_radius) != 0)
+        return fail(ctx, SS_ERR_UNKNOWN, "domain for neighborhood search has to be consistent and not degenerate (reference: assert)");
+    SSGlobT<R> Q;
+    memset(&Q, 0, sizeof(Q));
+    double scell_d = 1.0;
+    for (int d = 0; d < 3; ++d) {
+        Q.smin[d] = sgrid.aabb_min[d];
+        if (sgrid.n_cells[d] > 2000000000ll) return fail(ctx, SS_ERR_UNSUPPORTED, "search grid too large");
+        Q.snc[d] = (int)sgrid.n_cells[d];
+        scell_d *= (double)sgrid.n_cells[d];
+    }
+    if (scell_d >= 4.0e9) return fail(ctx, SS_ERR_UNSUPPORTED, "search grid too large for the dense cell table of this build");
+    const R h = search_radius;
+    Q.h = h;
+    Q.h2 = h * h;
+    Q.sigma = R(8.0) / (h * h * h);
+    Q.w0 = ss_kernel_evaluate(R(0.0), h, Q.sigma);
+    Q.mass = R(1.0);
+    Q.n = (uint32_t)n_in;
+    SS_HIP(ctx, hipEventRecord(ctx->ev[0], st));
+    const R* d_xyz = xyz;
+    if (n_in && !is_device_pointer(xyz)) {
+        SS_HIP(ctx, ctx->xyz_in.reserve(n_in * 3 * sizeof(R)));
+        SS_HIP(ctx, hipMemcpyAsync(ctx->xyz_in.p, xyz, n_in * 3 * sizeof(R), hipMemcpyHostToDevice, st));
+        d_xyz = ctx->xyz_in.as<R>();
+    }
+    s = global_search_and_densities<R>(ctx, Q, d_xyz, res);
+    if (s != SS_OK) return s;
+    SS_HIP(ctx, hipEventRecord(ctx->ev[4], st));
+    SS_HIP(ctx, hipStreamSynchronize(st));
+    res->stats.ms_total = ev_ms(ctx, 0, 4);
+    res->stats.ms_density = ev_ms(ctx, 3, 4);
+    res->stats.n_particles = n_in;
+    res->valid = true;
+    res->phase = 2;
+    return SS_OK;
+}
+
 template <class T>
 ss_status download(ss_result* r, const DevBuf& d, HostBuf& h, bool& flag, size_t count, const T** out) {
     ss_context* ctx = r->ctx;
@@ -1161,6 +1334,23 @@ ss_status ss_grid_for_domain_f32(const ss_params_f32* prm, const float domain_mi
 ss_status ss_grid_for_domain_f64(const ss_params_f64* prm, const double domain_min[3], const double domain_max[3], ss_grid_f64* grid,
                                  ss_grid_f64* subdomain_grid, double* ghost_margin) {
     return grid_for_domain_abi<double>(prm, domain_min, domain_max, grid, subdomain_grid, ghost_margin);
+}
+
+ss_status ss_marching_cubes_f32(ss_context* c, const float* values, const int64_t n_points[3], float iso_surface_threshold, float cube_size, const float translation[3],
+                                ss_result* inout) {
+    return marching_cubes_impl<float>(c, values, n_points, iso_surface_threshold, cube_size, translation, inout);
+}
+ss_status ss_marching_cubes_f64(ss_context* c, const double* values, const int64_t n_points[3], double iso_surface_threshold, double cube_size,
+                                const double translation[3], ss_result* inout) {
+    return marching_cubes_impl<double>(c, values, n_points, iso_surface_threshold, cube_size, translation, inout);
+}
+ss_status ss_neighborhood_search_f32(ss_context* c, const float* xyz, uint64_t n, const float domain_min[3], const float domain_max[3], float search_radius,
+                                     ss_result* inout) {
+    return neighborhood_search_impl<float>(c, xyz, n, domain_min, domain_max, search_radius, inout);
+}
+ss_status ss_neighborhood_search_f64(ss_context* c, const double* xyz, uint64_t n, const double domain_min[3], const double domain_max[3], double search_radius,
+                                     ss_result* inout) {
+    return neighborhood_search_impl<double>(c, xyz, n, domain_min, domain_max, search_radius, inout);
 }
 
 ss_status ss_grid_for_reconstruction_f32(ss_context* c, const float* xyz, uint64_t n_in, const ss_params_f32* prm, ss_grid_f32* out) {

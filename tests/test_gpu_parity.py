@@ -500,3 +500,51 @@ def test_gpu_global_strategy_medium_input(gpu_ctx, oracle):
     assert np.array_equal(res.mesh.vertices.view(np.uint32), orc.vertices.view(np.uint32))
     assert np.array_equal(res.mesh.triangles, orc.triangles)
     assert res.mesh.vertices.shape[0] == 73638
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("where", ["host", "hbm"])
+def test_gpu_dense_marching_cubes(gpu_ctx, oracle, where):
+    """ss_marching_cubes_* (pysplashsurf.marching_cubes): identical to the oracle incl. order, to the reference's mesh
+    under canonicalisation; the reference's triangulation error is reported as SS_ERR_MARCHING_CUBES."""
+    import torch
+    import splashsurf_amd as S
+    from splashsurf_amd.api import SplashsurfError
+    g = load_golden("marching_cubes_dense")
+    for dt, tag in ((np.float32, "f32"), (np.float64, "f64")):
+        U = np.uint32 if dt == np.float32 else np.uint64
+        vals = np.ascontiguousarray(g["values"].astype(dt))
+        arg = torch.from_numpy(vals).cuda() if where == "hbm" else vals
+        mesh, grid = S.marching_cubes(arg, iso_surface_threshold=float(g["threshold"]), cube_size=float(g["cube_size"]), translation=list(g["translation"]),
+                                      return_grid=True, context=gpu_ctx)
+        orc = oracle.marching_cubes(vals, float(g["threshold"]), float(g["cube_size"]), g["translation"])
+        assert list(grid.npoints_per_dim) == list(vals.shape) and np.array_equal(np.asarray(grid.aabb.min, dtype=dt), g["translation"].astype(dt))
+        assert mesh.vertices.dtype == dt
+        assert np.array_equal(mesh.vertices.view(U), orc.vertices.view(U)) and np.array_equal(mesh.triangles, orc.triangles)
+        cmp = MC.compare_geometric(g["v_" + tag], g["t_" + tag].astype(np.int64), mesh.vertices, mesh.triangles, orc.grid["aabb_min"], dt(g["cube_size"]),
+                                   np.array(vals.shape))
+        assert cmp["ids_equal"] and cmp["triangles_equal"] and cmp["max_rel_diff"] == 0.0, cmp
+    with pytest.raises(SplashsurfError) as e:
+        S.marching_cubes(g["eq_values"], iso_surface_threshold=1.0, cube_size=1.0, context=gpu_ctx)
+    assert e.value.status == 3
+    with pytest.raises(SplashsurfError):
+        S.marching_cubes(np.zeros((1, 4, 4), np.float32), iso_surface_threshold=0.5, cube_size=1.0, context=gpu_ctx)
+
+
+@pytest.mark.gpu
+def test_gpu_neighborhood_search_standalone(gpu_ctx):
+    """ss_neighborhood_search_*: the lists of the reference's sequential search (golden from the reference's global path)."""
+    import splashsurf_amd as S
+    for name in ("global_cube_2366", "global_f64_cube_2366"):
+        g = load_golden(name)
+        dt = g["densities"].dtype.type
+        pts = golden_input(g).astype(dt)
+        h = dt(2.0 * 2.0 * 0.025)
+        nl = S.neighborhood_search_spatial_hashing_parallel(pts, S.Aabb3d(g["grid_min"], g["grid_max"]), h, context=gpu_ctx)
+        ptr, idx = nl.csr
+        assert np.array_equal(ptr.astype(np.int64), g["row_ptr"]) and np.array_equal(idx.astype(np.int64), g["neighbors"].astype(np.int64))
+        lists = nl.get_neighborhood_lists()
+        assert len(lists) == pts.shape[0] and all(i not in set(l.tolist()) for i, l in list(enumerate(lists))[:50])
+    from splashsurf_amd.api import SplashsurfError
+    with pytest.raises(SplashsurfError):  # particle outside the domain: the reference panics
+        S.neighborhood_search_spatial_hashing_parallel(pts, S.Aabb3d(g["grid_min"], g["grid_min"] + 0.1), h, context=gpu_ctx)

@@ -202,3 +202,18 @@ def test_oracle_auto_disable_rule(oracle):
         par = oracle.make_params_relative(0.025, 2.0, 0.75, subdomain_num_cubes_per_dim=n_cubes, subdomain_grid_auto_disable=True)
         res = oracle.reconstruct_surface(pts, par)
         assert res.used_global_strategy == expect_global, n_cubes
+
+
+def test_oracle_dense_marching_cubes_matches_reference(oracle):
+    """pysplashsurf.marching_cubes on a dense array (rows A15): vertex coordinates bit-identical, same triangles; an
+    array whose values equal the threshold hits the reference's triangulation error ("missing iso surface vertex")."""
+    g = load_golden("marching_cubes_dense")
+    for dt, tag in ((np.float32, "f32"), (np.float64, "f64")):
+        vals = np.ascontiguousarray(g["values"].astype(dt))
+        res = oracle.marching_cubes(vals, float(g["threshold"]), float(g["cube_size"]), g["translation"])
+        assert np.array_equal(res.grid["aabb_min"], g["translation"].astype(dt))  # UniformGrid::new does not align the origin
+        cmp = MC.compare_geometric(g["v_" + tag], g["t_" + tag].astype(np.int64), res.vertices, res.triangles, res.grid["aabb_min"], dt(g["cube_size"]),
+                                   np.array(vals.shape))
+        assert cmp["ids_equal"] and cmp["triangles_equal"] and cmp["max_rel_diff"] == 0.0, cmp
+    with pytest.raises(RuntimeError, match="code 3"):
+        oracle.marching_cubes(g["eq_values"], 1.0, 1.0)
