@@ -1,0 +1,92 @@
+"""File formats: splashsurf_amd.io against files written by the reference itself (tests/golden/io/,
+produced with the reference's CLI: `convert --particles` and `reconstruct -o mesh.{vtk,ply,obj}`)."""
+import os
+
+import numpy as np
+import pytest
+
+import mesh_compare as MC
+from conftest import load_golden, load_points
+
+IO_DIR = os.path.join(os.path.dirname(__file__), "golden", "io")
+
+
+def _g(name):
+    return os.path.join(IO_DIR, name)
+
+
+def test_particle_readers_agree_with_the_reference_files():
+    from splashsurf_amd import io as IO
+    ref = load_points("free_particles_125_particles.npy")
+    for ext in ("json", "vtk", "bgeo"):  # the same particles written by the reference's CLI in three formats
+        p = IO.particles_from_file(_g("free_particles_125_particles_out." + ext))
+        assert p.dtype == np.float32 and np.array_equal(p.view(np.uint32), ref.view(np.uint32)), ext
+    cube = load_points("cube_8_particles.npy")
+    assert np.array_equal(IO.particles_from_file(_g("cube8.xyz")), cube)
+    assert np.array_equal(IO.particles_from_file(_g("cube8.json")), cube)
+    assert IO.particles_from_file(_g("cube8.json"), dtype=np.float64).dtype == np.float64
+    with pytest.raises(ValueError):
+        IO.particles_from_file(_g("mesh_plain.obj"))
+
+
+def test_particle_writers_reproduce_the_reference_files_byte_for_byte(tmp_path):
+    from splashsurf_amd import io as IO
+    p = IO.particles_from_file(_g("free_particles_125_particles_out.bgeo"))
+    for ext in ("vtk", "json"):
+        out = str(tmp_path / ("p." + ext))
+        IO.particles_to_file(p, out)
+        assert open(out, "rb").read() == open(_g("free_particles_125_particles_out." + ext), "rb").read(), ext
+    out = str(tmp_path / "p.xyz")
+    IO.particles_to_file(p, out)
+    assert np.array_equal(IO.particles_from_file(out), p)
+
+
+@pytest.mark.parametrize("kind", ["plain", "attr"])
+def test_mesh_formats_round_trip_and_match_reference_bytes(tmp_path, kind):
+    """The reference wrote the same mesh as vtk, ply and obj: the readers agree on it, and each writer reproduces the
+    reference's file byte for byte from what another format's reader returned."""
+    from splashsurf_amd import io as IO
+    mv, mp, mo = (IO.mesh_from_file(_g("mesh_%s.%s" % (kind, e))) for e in ("vtk", "ply", "obj"))
+    assert mv.vertices.dtype == np.float32 and mv.triangles.dtype == np.uint64
+    for m in (mp, mo):
+        assert np.array_equal(m.vertices, mv.vertices) and np.array_equal(m.triangles, mv.triangles)
+    assert list(mv.point_attributes) == list(mp.point_attributes) == (["wnn", "sw", "normals"] if kind == "attr" else [])
+    for k in mv.point_attributes:
+        assert np.array_equal(mv.point_attributes[k], mp.point_attributes[k])
+    if kind == "attr":
+        assert np.array_equal(mo.point_attributes["normals"], mv.point_attributes["normals"])
+    for ext, src in (("vtk", mp), ("ply", mv), ("obj", mp)):
+        out = str(tmp_path / ("m." + ext))
+        IO.mesh_to_file(src, out)
+        assert open(out, "rb").read() == open(_g("mesh_%s.%s" % (kind, ext)), "rb").read(), ext
+
+
+def test_reference_cli_mesh_equals_library_goldens():
+    """The mesh the reference's CLI wrote for cube_8 (global strategy) is the mesh of the `global_cube_8` golden."""
+    from splashsurf_amd import io as IO
+    m = IO.mesh_from_file(_g("mesh_plain.vtk"))
+    g = load_golden("global_cube_8")
+    cmp = MC.compare_geometric(g["vertices"], g["triangles"], m.vertices, m.triangles, g["grid_min"], g["cell_size"], g["n_points"])
+    assert cmp["ids_equal"] and cmp["triangles_equal"] and cmp["max_rel_diff"] == 0.0
+
+
+def test_display_formatting_follows_rust():
+    from splashsurf_amd.io import _fmt_display, _fmt_json
+    assert [_fmt_display(np.float32(x)) for x in (1.0, 0.5, -0.0, 1e-7, 123456790.0, 0.1)] == ["1", "0.5", "-0", "0.0000001", "123456790", "0.1"]
+    assert [_fmt_json(x) for x in (1.0, 1e-7, 1e16, 0.1, float(np.float32(0.1)))] == ["1.0", "1e-7", "1e16", "0.1", "0.10000000149011612"]
+
+
+@pytest.mark.gpu
+def test_gpu_file_to_file_matches_the_reference_cli(gpu_ctx, tmp_path):
+    """particles file -> reconstruction on the GPU -> mesh file: equal to what the reference's CLI wrote for the same
+    input and parameters (`reconstruct cube8.xyz -r 0.025 -l 2.0 -c 1.0 --subdomain-grid=off`)."""
+    import splashsurf_amd as S
+    from splashsurf_amd import io as IO
+    pts = IO.particles_from_file(_g("cube8.xyz"))
+    res = S.reconstruct_surface(pts, particle_radius=0.025, smoothing_length=2.0, cube_size=1.0, subdomain_grid=False, context=gpu_ctx)
+    out = str(tmp_path / "mesh.ply")
+    IO.mesh_to_file(res.mesh, out)
+    mine, ref = IO.mesh_from_file(out), IO.mesh_from_file(_g("mesh_plain.ply"))
+    g = res.grid
+    cmp = MC.compare_geometric(ref.vertices, ref.triangles, mine.vertices, mine.triangles, g.aabb.min, g.cell_size, g.npoints_per_dim)
+    assert cmp["ids_equal"] and cmp["triangles_equal"] and cmp["max_rel_diff"] == 0.0, cmp

@@ -1,0 +1,29 @@
+#!/bin/bash
+# Regenerates tests/golden/io/ with the REFERENCE's own CLI (inside its pre-built wheel; build container only).
+# One python process per CLI call: the reference initialises its logger once per process.
+set -e
+ROOT=$(cd "$(dirname "$0")/.." && pwd)
+OUT=$ROOT/tests/golden/io
+TMP=$(mktemp -d)
+mkdir -p "$OUT"
+cat > "$TMP/run_ss.py" <<'PY'
+import sys
+sys.path.insert(0, sys.argv[1])
+from oracle_env import pysplashsurf as ps
+ps.run_splashsurf(['splashsurf'] + sys.argv[2:])
+PY
+ss() { python "$TMP/run_ss.py" "$ROOT/tools" "$@" > /dev/null; }
+python - "$ROOT" "$OUT" <<'PY'
+import sys, json, numpy as np
+root, out = sys.argv[1], sys.argv[2]
+p = np.load(root + '/tests/data/cube_8_particles.npy')
+json.dump([[float(v) for v in row] for row in p], open(out + '/cube8.json', 'w'))
+p.astype('<f4').tofile(out + '/cube8.xyz')
+PY
+SRC=/root/reference/data/free_particles_125_particles.vtk
+for ext in json vtk bgeo; do ss convert --particles "$SRC" -o "$OUT/free_particles_125_particles_out.$ext" --overwrite -q; done
+for ext in vtk ply obj; do
+  ss reconstruct "$OUT/cube8.json" -o "$OUT/mesh_attr.$ext" -r 0.025 -l 2.0 -c 1.0 --normals=on --mesh-smoothing-weights=on --mesh-smoothing-iters=2 --output-smoothing-weights=on --subdomain-grid=off -q
+  ss reconstruct "$OUT/cube8.xyz" -o "$OUT/mesh_plain.$ext" -r 0.025 -l 2.0 -c 1.0 --subdomain-grid=off -q
+done
+ls -la "$OUT"
