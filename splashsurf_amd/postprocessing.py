@@ -275,6 +275,33 @@ def smoothing_weights(vertex_weighted_num_neighbors, normalization=13.0, context
     return out
 
 
+def clamp_with_aabb(vertices, triangles, aabb_min, aabb_max, *, clamp_vertices=True, keep_vertices=False, point_attributes=None):
+    """`Mesh3d::par_clamp_with_aabb` (splashsurf_lib/src/mesh.rs:333-371, keep_cells :323-331, 392-440): keeps the
+    triangles with at least one vertex inside the half-open AABB, drops unreferenced vertices (unless keep_vertices),
+    relabels, and clamps the remaining vertices to the box.  Host-side numpy (the last step of the pipeline).
+    Returns (vertices, triangles, point_attributes)."""
+    v = np.asarray(vertices)
+    t = np.asarray(triangles).astype(np.int64).reshape(-1, 3)
+    lo = np.asarray(aabb_min, dtype=v.dtype)
+    hi = np.asarray(aabb_max, dtype=v.dtype)
+    inside = np.all((v >= lo) & (v < hi), axis=1)  # Aabb3d::contains_point (aabb.rs:220-222)
+    keep_t = inside[t].any(axis=1) if t.size else np.zeros(0, bool)
+    t = t[keep_t]
+    attrs = dict(point_attributes or {})
+    if not keep_vertices:
+        keep_v = np.zeros(v.shape[0], bool)
+        keep_v[t.reshape(-1)] = True
+        label = np.cumsum(keep_v) - 1
+        t = label[t]
+        v = v[keep_v]
+        attrs = {k: np.asarray(a)[keep_v] for k, a in attrs.items()}
+    else:
+        v = v.copy()
+    if clamp_vertices:
+        v = np.minimum(np.maximum(v, lo), hi)
+    return np.ascontiguousarray(v), t.astype(np.uint64), attrs
+
+
 class MeshWithData:
     """MeshWithData of pysplashsurf: `.mesh` plus named per-vertex attributes."""
 
@@ -293,7 +320,7 @@ class MeshWithData:
 
 
 _UNSUPPORTED = dict(check_mesh_closed=False, check_mesh_manifold=False, check_mesh_orientation=False, check_mesh_debug=False, mesh_cleanup=False,
-                    mesh_cleanup_snap_dist=None, decimate_barnacles=False, keep_vertices=False, generate_quads=False, mesh_aabb_min=None, mesh_aabb_max=None)
+                    mesh_cleanup_snap_dist=None, decimate_barnacles=False, generate_quads=False)
 
 
 def reconstruction_pipeline(particles, *, attributes_to_interpolate=None, particle_radius, rest_density=1000.0, smoothing_length, cube_size,
@@ -302,11 +329,11 @@ def reconstruction_pipeline(particles, *, attributes_to_interpolate=None, partic
                             normals_smoothing_iters=None, mesh_smoothing_iters=None, mesh_smoothing_weights=True,
                             mesh_smoothing_weights_normalization=13.0, output_mesh_smoothing_weights=False, output_raw_normals=False,
                             output_raw_mesh=False, quad_max_edge_diag_ratio=1.75, quad_max_normal_angle=10.0, quad_max_interior_angle=135.0,
-                            mesh_aabb_clamp_vertices=True, context=None, **unsupported):
+                            mesh_aabb_min=None, mesh_aabb_max=None, mesh_aabb_clamp_vertices=True, keep_vertices=False, context=None, **unsupported):
     """pysplashsurf.reconstruction_pipeline (splashsurf/src/reconstruct.rs:1022-1345): reconstruction followed by the
     post-processing stages provided on the GPU -- smoothing weights, weighted Laplacian smoothing, normals (mesh or
-    SPH), normal smoothing, attribute interpolation.  The mesh stays in HBM between the stages.  Mesh cleanup,
-    barnacle decimation, quad conversion, AABB clamping and the mesh checks are not provided and raise.
+    SPH), normal smoothing, attribute interpolation, clamping to a mesh AABB.  The mesh stays in HBM between the device
+    stages.  Mesh cleanup, barnacle decimation, quad conversion and the mesh checks are not provided and raise.
     Returns (MeshWithData, SurfaceReconstruction) with numpy arrays."""
     import torch
     for k, v in unsupported.items():
@@ -391,7 +418,11 @@ def reconstruction_pipeline(particles, *, attributes_to_interpolate=None, partic
         vals = np.ascontiguousarray(vals if inside is None else vals[inside], dtype=dt)
         mesh_with_data.point_attributes[name] = interp.interpolate_quantity(torch.from_numpy(vals).to(dev), d_v, first_order_correction=True).cpu().numpy()
 
-    mesh_with_data.mesh = TriMesh3d(d_v.cpu().numpy(), d_t.cpu().numpy().astype(np.uint32).astype(np.uint64), ctx)
+    out_v, out_t = d_v.cpu().numpy(), d_t.cpu().numpy().astype(np.uint32).astype(np.uint64)
+    if mesh_aabb_min is not None and mesh_aabb_max is not None:  # reconstruct.rs:1395-1409
+        out_v, out_t, mesh_with_data.point_attributes = clamp_with_aabb(out_v, out_t, mesh_aabb_min, mesh_aabb_max, clamp_vertices=mesh_aabb_clamp_vertices,
+                                                                        keep_vertices=keep_vertices, point_attributes=mesh_with_data.point_attributes)
+    mesh_with_data.mesh = TriMesh3d(out_v, out_t, ctx)
     if output_raw_mesh:
         mesh_with_data.raw_vertices = raw_vertices
     return mesh_with_data, rec

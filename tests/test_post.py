@@ -180,3 +180,22 @@ def test_gpu_pipeline_matches_oracle_and_reference(gpu_ctx, oracle, name):
     assert np.abs(mwd2.point_attributes["normals"][b] - g["pipe_sph_normals"][a]).max() <= (1e-4 if loose else 1e-12)
     with pytest.raises(NotImplementedError):
         PP.reconstruction_pipeline(pts, particle_radius=0.025, smoothing_length=2.0, cube_size=0.75, mesh_cleanup=True, context=gpu_ctx)
+
+
+def test_clamp_with_aabb_matches_reference(oracle):
+    """Mesh3d::par_clamp_with_aabb through the reference's pipeline (mesh_aabb_min/max): same vertices, same triangles,
+    same order; point attributes are filtered with the vertices."""
+    from splashsurf_amd.postprocessing import clamp_with_aabb
+    g = load_golden("post_clamp_cube_2366")
+    raw_v, raw_t = g["raw_v"], g["raw_t"].astype(np.uint64)
+    lo, hi = g["aabb"]
+    normals = oracle.post_vertex_normals(raw_v, raw_t)
+    for clamp in (1, 0):
+        v, t, attrs = clamp_with_aabb(raw_v, raw_t, lo, hi, clamp_vertices=bool(clamp), point_attributes={"normals": normals})
+        assert np.array_equal(v.view(np.uint32), g["clamp%d_v" % clamp].view(np.uint32))
+        assert np.array_equal(t.astype(np.int64), g["clamp%d_t" % clamp].astype(np.int64))
+        assert np.abs(attrs["normals"] - g["clamp%d_normals" % clamp]).max() <= 2e-6
+        if clamp:
+            assert np.all(v >= lo) and np.all(v <= hi)
+    v, t, _ = clamp_with_aabb(raw_v, raw_t, lo, hi, keep_vertices=True)
+    assert v.shape == raw_v.shape and t.shape[0] == g["clamp1_t"].shape[0]
