@@ -27,15 +27,20 @@
 namespace {
 
 // ---- host/device argument staging ----
+// scratch from the context's grow-only pool (no hipMalloc/hipFree per call once the pool is warm)
+inline ss_status pool_alloc(ss_context* ctx, size_t bytes, void** out) {
+    if (ctx->post_pool_next >= (int)(sizeof(ctx->post_pool) / sizeof(ctx->post_pool[0]))) return fail(ctx, SS_ERR_UNKNOWN, "post-processing scratch pool exhausted");
+    DevBuf& b = ctx->post_pool[ctx->post_pool_next++];
+    SS_HIP(ctx, b.reserve(bytes ? bytes : 16));
+    *out = b.p;
+    return SS_OK;
+}
+
 template <class T>
 struct DevArg {
     T* d = nullptr;        // device pointer to use
     void* host = nullptr;  // caller's host pointer (nullptr: the caller passed a device pointer)
     size_t n = 0;
-    bool owned = false;
-    ~DevArg() {
-        if (owned && d) (void)hipFree(const_cast<void*>(static_cast<const void*>(d)));
-    }
     // mode: 0 input, 1 output, 2 in/out
     ss_status init(ss_context* ctx, const T* p, size_t count, int mode) {
         n = count;
@@ -47,9 +52,9 @@ struct DevArg {
         }
         host = const_cast<void*>(static_cast<const void*>(p));
         void* raw = nullptr;
-        SS_HIP(ctx, hipMalloc(&raw, count * sizeof(T)));
+        ss_status s = pool_alloc(ctx, count * sizeof(T), &raw);
+        if (s != SS_OK) return s;
         d = static_cast<T*>(raw);
-        owned = true;
         if (mode != 1) SS_HIP(ctx, hipMemcpyAsync(raw, p, count * sizeof(T), hipMemcpyHostToDevice, ctx->stream));
         return SS_OK;
     }
@@ -64,13 +69,7 @@ struct DevArg {
 
 struct TmpBuf {
     void* p = nullptr;
-    ~TmpBuf() {
-        if (p) (void)hipFree(p);
-    }
-    ss_status alloc(ss_context* ctx, size_t bytes) {
-        SS_HIP(ctx, hipMalloc(&p, bytes ? bytes : 16));
-        return SS_OK;
-    }
+    ss_status alloc(ss_context* ctx, size_t bytes) { return pool_alloc(ctx, bytes, &p); }
     template <class T>
     T* as() const {
         return reinterpret_cast<T*>(p);
@@ -466,6 +465,7 @@ ss_status begin_call(ss_context* c) {
     c->err.clear();
     c->err_detail = 0;
     SS_HIP(c, hipSetDevice(c->device));
+    c->post_pool_next = 0;
     return SS_OK;
 }
 
