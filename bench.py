@@ -215,6 +215,28 @@ def main():
             out = outs[0]
         except Exception as e:
             line["pcie_pipelined"] = {"value": None, "note": "failed: %r" % (e,)}
+        # BASELINE.json configs[1] (1 M uniform-random particles) measured in the same run, HBM-resident like `value`
+        if args.workload != "s1m":
+            try:
+                w1 = W.WORKLOADS["s1m"]
+                p1 = Parameters(particle_radius=w1["particle_radius"], compact_support_radius=np.float32(2.0 * w1["smoothing_length"] * w1["particle_radius"]),
+                                cube_size=np.float32(w1["cube_size"] * w1["particle_radius"]), auto_disable=False)
+                d1 = torch.from_numpy(w1["gen"]()).to(dev)
+                o1 = None
+                for _ in range(2):
+                    o1 = ctx.reconstruct(d1, p1, out=o1)
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for _ in range(args.steps):
+                    o1 = ctx.reconstruct(d1, p1, out=o1)
+                torch.cuda.synchronize()
+                dt1 = (time.perf_counter() - t1) / args.steps
+                line["other_configs"] = {"s1m": {"value": round(d1.shape[0] / dt1 / 1e6, 3), "unit": "Mparticles/s", "ms_per_step": round(dt1 * 1e3, 3),
+                                                 "n_particles": int(d1.shape[0]), "n_vertices": int(o1.stats["n_vertices"]),
+                                                 "note": "BASELINE.json configs[1]: 1 M uniform-random particles in the unit cube, r=0.01, cell=1.0"}}
+                del d1, o1
+            except Exception as e:
+                line["other_configs"] = {"s1m": {"value": None, "note": "failed: %r" % (e,)}}
         # HBM traffic of the splat kernel from rocprofv3 PMC passes (collected offline, see profiles/)
         try:
             tr = json.load(open(os.path.join(ROOT, "profiles", "splat_traffic.json"))).get(args.workload)
