@@ -1,0 +1,75 @@
+"""The reference's own integration tests, run against the HIP path.
+
+splashsurf_lib/tests/integration_tests/test_full.rs:144-157 (data files, parameters, triangle-count ranges, closed /
+manifold check), test_subdomains.rs:78-106 (single particle at three resolutions: triangle, vertex and subdomain count
+ranges) and test_simple.rs:71-126 are restated with the same inputs and assertions; on top of the reference's own
+(loose) assertions every result is compared with the oracle bit for bit."""
+import numpy as np
+import pytest
+
+import mesh_compare as MC
+from conftest import load_points
+
+pytestmark = pytest.mark.gpu
+
+# (test name, data file, particle_radius, relative compact support, relative cube size, threshold, strategy, aabb, min tris, max tris)
+FULL = [
+    ("bunny_global", "bunny_frame_14_7705_particles.npy", 0.025, 4.0, 0.75, 0.6, "global", None, 60000, 80000),
+    ("bunny_grid", "bunny_frame_14_7705_particles.npy", 0.025, 4.0, 0.75, 0.6, "grid", None, 60000, 80000),
+    ("hexecontahedron_grid", "pentagonal_hexecontahedron_32286_particles.npy", 0.025, 4.0, 0.75, 0.6, "grid", None, 550000, 650000),
+    ("hilbert_grid", "hilbert_46843_particles.npy", 0.025, 4.0, 0.75, 0.6, "grid", None, 360000, 400000),
+    ("hilbert2_grid", "hilbert2_7954_particles.npy", 0.025, 4.0, 1.1, 0.6, "grid", None, 90000, 100000),
+    ("octocat_grid", "octocat_32614_particles.npy", 0.025, 4.0, 0.75, 0.6, "grid", None, 140000, 180000),
+    ("knot_global", "sailors_knot_19539_particles.npy", 0.025, 4.0, 1.1, 0.6, "global", None, 40000, 70000),
+    ("knot_grid", "sailors_knot_19539_particles.npy", 0.025, 4.0, 1.1, 0.6, "grid", None, 40000, 70000),
+    ("free_particles_01", "free_particles_1000_particles.npy", 0.5, 4.0, 1.5, 0.45, "global", None, 21000, 25000),
+    ("free_particles_02", "free_particles_125_particles.npy", 0.5, 4.0, 1.5, 0.45, "global", ([-10.0, -10.0, -10.0], [210.0, 210.0, 210.0]), 1500, 1600),
+]
+
+
+def _params(r, h_rel, c_rel, t, strategy, aabb):
+    """test_full.rs:19-57: absolute parameters formed in the Real type (f32)."""
+    from splashsurf_amd.api import Parameters
+    r32 = np.float32(r)
+    return Parameters(particle_radius=r32, rest_density=1000.0, compact_support_radius=r32 * np.float32(h_rel), cube_size=r32 * np.float32(c_rel),
+                      iso_surface_threshold=t, particle_aabb=None if aabb is None else (np.asarray(aabb[0], np.float64), np.asarray(aabb[1], np.float64)),
+                      enable_multi_threading=False, enable_simd=False, subdomain_grid=(strategy == "grid"), subdomain_num_cubes_per_dim=64, auto_disable=False)
+
+
+def _oracle_params(O, r, h_rel, c_rel, t, strategy, aabb):
+    r32 = np.float32(r)
+    kw = {} if aabb is None else dict(aabb_min=np.asarray(aabb[0], np.float32), aabb_max=np.asarray(aabb[1], np.float32))
+    return O.make_params(r32, r32 * np.float32(h_rel), r32 * np.float32(c_rel), iso_surface_threshold=t, subdomain_grid=(strategy == "grid"), **kw)
+
+
+@pytest.mark.parametrize("case", FULL, ids=[c[0] for c in FULL])
+def test_full_rs(gpu_ctx, oracle, case):
+    import splashsurf_amd as S
+    name, fn, r, h_rel, c_rel, t, strategy, aabb, lo, hi = case
+    pts = load_points(fn)
+    res = S.reconstruct_surface_abs(pts, _params(r, h_rel, c_rel, t, strategy, aabb), context=gpu_ctx)
+    n_tris = res.mesh.triangles.shape[0]
+    assert lo < n_tris < hi, "number of triangles %d outside the reference's range (%d, %d)" % (n_tris, lo, hi)  # test_full.rs:120-131
+    assert MC.mesh_is_closed_manifold(res.mesh.triangles)                                                       # test_full.rs:133-140
+    assert (res.subdomain_grid is None) == (strategy == "global")
+    orc = oracle.reconstruct_surface(pts, _oracle_params(oracle, r, h_rel, c_rel, t, strategy, aabb))
+    assert np.array_equal(res.particle_densities.view(np.uint32), orc.particle_densities.view(np.uint32))
+    cmp = MC.compare_keyed(res.mesh.vertices, res.vertex_keys, res.mesh.triangles, orc.vertices, orc.vertex_keys, orc.triangles)
+    assert cmp["keys_equal"] and cmp["triangles_equal"] and cmp["vertices_bit_equal"], cmp
+
+
+@pytest.mark.parametrize("cube_size_rel,tris,verts,subdomains", [(0.5, (240, 260), (120, 135), (1, 2)), (0.1, (5700, 6000), (2800, 3000), (7, 10)),
+                                                                  (0.025, (90000, 100000), (45000, 48000), (330, 350))])
+def test_subdomains_rs_single_particle(gpu_ctx, cube_size_rel, tris, verts, subdomains):
+    """test_subdomains.rs:78-106; the parameters are f64 expressions narrowed to f32 there (`4.0 * particle_radius`)."""
+    import splashsurf_amd as S
+    from splashsurf_amd.api import Parameters
+    r = 0.025
+    prm = Parameters(particle_radius=np.float32(r), rest_density=1000.0, compact_support_radius=np.float32(4.0 * r), cube_size=np.float32(cube_size_rel * r),
+                     iso_surface_threshold=0.6, subdomain_grid=True, subdomain_num_cubes_per_dim=64, auto_disable=False)
+    res = S.reconstruct_surface_abs(np.zeros((1, 3), np.float32), prm, context=gpu_ctx)
+    assert tris[0] <= res.mesh.triangles.shape[0] < tris[1]
+    assert verts[0] <= res.mesh.vertices.shape[0] < verts[1]
+    assert MC.mesh_is_closed_manifold(res.mesh.triangles)
+    n_sub = int(np.prod(res.subdomain_grid.ncells_per_dim))
+    assert subdomains[0] <= n_sub < subdomains[1]

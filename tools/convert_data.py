@@ -50,6 +50,12 @@ FILES = {
     "cube_2366_particles": ("cube_2366_particles.vtk", read_vtk_points),
     "free_particles_125_particles": ("free_particles_125_particles.vtk", read_vtk_points),
     "bunny_frame_14_7705_particles": ("bunny_frame_14_7705_particles.vtk", read_vtk_points),
+    # data sets of the reference's test_full.rs
+    "pentagonal_hexecontahedron_32286_particles": ("pentagonal_hexecontahedron_32286_particles.bgeo", read_bgeo_points),
+    "hilbert2_7954_particles": ("hilbert2_7954_particles.vtk", read_vtk_points),
+    "octocat_32614_particles": ("octocat_32614_particles.bgeo", read_bgeo_points),
+    "sailors_knot_19539_particles": ("sailors_knot_19539_particles.vtk", read_vtk_points),
+    "free_particles_1000_particles": ("free_particles_1000_particles.vtk", read_vtk_points),
 }
 
 if __name__ == "__main__":
