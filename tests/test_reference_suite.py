@@ -73,3 +73,45 @@ def test_subdomains_rs_single_particle(gpu_ctx, cube_size_rel, tris, verts, subd
     assert MC.mesh_is_closed_manifold(res.mesh.triangles)
     n_sub = int(np.prod(res.subdomain_grid.ncells_per_dim))
     assert subdomains[0] <= n_sub < subdomains[1]
+
+
+def _nb_cases(sr):
+    """generate_simple_test_cases of test_neighborhood_search.rs:11-84 (coordinates formed in f32 like the Rust literals)."""
+    f = np.float32
+    sr = f(sr)
+    one = f(1.0)
+    return [
+        ([[1, 1, 1], [one + sr, one + sr, one + sr]], [[], []]),
+        ([[1, 1, 1], [one + f(0.9999) * sr, 1, 1]], [[1], [0]]),
+        ([[1, 1, 1], [one + sr, 1, 1]], [[1], [0]]),
+        ([[1, 1, 1], [one + sr * f(1.0001), 1, 1]], [[], []]),
+        ([[1, 1, 1], [one + f(0.9) * sr, 1, 1], [one - f(0.9) * sr, 1, 1], [1, one + f(0.2) * sr, 1]], [[1, 2, 3], [0, 3], [0, 3], [0, 1, 2]]),
+        ([[1, 1, 1], [one + f(0.9) * sr, 1, 1], [one - f(0.9) * sr, 1, 1], [one - f(0.8) * sr, 1, f(-0.2) * sr], [1, one + f(0.2) * sr, 1], [1, one - f(0.2) * sr, 1],
+          [1, one + f(0.2) * sr, one + f(0.2) * sr], [1, one - f(0.2) * sr, one - f(0.2) * sr]],
+         [[1, 2, 4, 5, 6, 7], [0, 4, 5, 6, 7], [0, 4, 5, 6, 7], [], [0, 1, 2, 5, 6, 7], [0, 1, 2, 4, 6, 7], [0, 1, 2, 4, 5, 7], [0, 1, 2, 4, 5, 6]]),
+    ]
+
+
+def test_neighborhood_search_rs_simple_cases(gpu_ctx):
+    """test_neighborhood_search.rs:105-128: known-answer neighbour sets, domain = AABB of the points grown by the radius."""
+    import splashsurf_amd as S
+    sr = np.float32(0.3)
+    for pts, solution in _nb_cases(0.3):
+        p = np.array(pts, dtype=np.float32)
+        dom = S.Aabb3d(p.min(axis=0) - sr, p.max(axis=0) + sr)
+        lists = S.neighborhood_search_spatial_hashing_parallel(p, dom, sr, context=gpu_ctx).get_neighborhood_lists()
+        assert [sorted(int(j) for j in l) for l in lists] == [sorted(s) for s in solution], (pts, lists)
+
+
+def test_neighborhood_search_rs_against_naive(gpu_ctx):
+    """test_neighborhood_search.rs (data-file variant): spatial hashing equals the brute-force search on a data set."""
+    import splashsurf_amd as S
+    p = load_points("cube_2366_particles.npy")
+    sr = np.float32(0.1)
+    lists = S.neighborhood_search_spatial_hashing_parallel(p, S.Aabb3d(p.min(axis=0) - sr, p.max(axis=0) + sr), sr, context=gpu_ctx).get_neighborhood_lists()
+    d = p[:, None, :] - p[None, :, :]
+    d2 = (d[..., 0] * d[..., 0] + d[..., 1] * d[..., 1]) + d[..., 2] * d[..., 2]  # f32, nalgebra's association
+    nb = d2 < sr * sr
+    np.fill_diagonal(nb, False)
+    for i in range(0, p.shape[0], 7):
+        assert sorted(int(j) for j in lists[i]) == np.nonzero(nb[i])[0].tolist()
