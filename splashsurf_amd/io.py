@@ -408,6 +408,8 @@ def mesh_from_file(path, dtype=np.float32):
                 normals.append([float(x) for x in t[1:4]])
             elif t[0] == "f":
                 tris.append([int(x.split("/")[0]) - 1 for x in t[1:4]])
+        if normals and len(normals) != len(verts):  # obj_format.rs:152-157 (the reference asserts)
+            raise ValueError("length of vertex and vertex normal array doesn't match")
         attrs = {"normals": np.asarray(normals, dtype=dtype).reshape(-1, 3)} if normals else {}
         return MeshWithData(np.asarray(verts, dtype=dtype).reshape(-1, 3), np.asarray(tris, dtype=np.int64).reshape(-1, 3), attrs)
     raise ValueError('Unsupported file format extension "%s" for reading surface meshes' % e)

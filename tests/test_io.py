@@ -90,3 +90,15 @@ def test_gpu_file_to_file_matches_the_reference_cli(gpu_ctx, tmp_path):
     g = res.grid
     cmp = MC.compare_geometric(ref.vertices, ref.triangles, mine.vertices, mine.triangles, g.aabb.min, g.cell_size, g.npoints_per_dim)
     assert cmp["ids_equal"] and cmp["triangles_equal"] and cmp["max_rel_diff"] == 0.0, cmp
+
+
+def test_reference_reader_unit_tests():
+    """ply_format.rs:270-312 (cube.ply, cube_normals.ply written by Blender, ASCII) and obj_format.rs:167-192 (icosphere.obj)."""
+    from splashsurf_amd import io as IO
+    m = IO.mesh_from_file(_g("cube.ply"))
+    assert m.vertices.shape == (24, 3) and m.triangles.shape == (12, 3)
+    m = IO.mesh_from_file(_g("cube_normals.ply"))
+    assert m.vertices.shape == (24, 3) and m.triangles.shape == (12, 3) and m.point_attributes["normals"].shape == (24, 3)
+    m = IO.mesh_from_file(_g("icosphere.obj"))
+    assert m.vertices.shape == (42, 3) and m.triangles.shape == (80, 3)
+    assert MC.mesh_is_closed_manifold(m.triangles)

@@ -217,3 +217,24 @@ def test_oracle_dense_marching_cubes_matches_reference(oracle):
         assert cmp["ids_equal"] and cmp["triangles_equal"] and cmp["max_rel_diff"] == 0.0, cmp
     with pytest.raises(RuntimeError, match="code 3"):
         oracle.marching_cubes(g["eq_values"], 1.0, 1.0)
+
+
+def _single_cell_values():
+    """marching_cubes.rs:352-361 (test_interpolate_cell_data): corner values of one unit cell, array[i][j][k]."""
+    v = np.zeros((2, 2, 2), np.float64)
+    for ijk, val in (([0, 0, 0], 0.0), ([1, 0, 0], 0.75), ([1, 1, 0], 1.0), ([0, 1, 0], 0.5), ([0, 0, 1], 0.0), ([1, 0, 1], 0.0), ([1, 1, 1], 1.0), ([0, 1, 1], 0.0)):
+        v[tuple(ijk)] = val
+    return v
+
+
+# local edges 0, 3, 5, 6, 9, 11 of the cell (marching_cubes.rs:387-392) as global edge keys (lower point flat index * 3 + axis)
+SINGLE_CELL_KEYS = [0, 1, 8, 9, 14, 16]
+
+
+def test_oracle_single_cell_known_answer(oracle):
+    """The reference's unit test of the narrow-band extraction (marching_cubes.rs:325-398): threshold 0.25 on one cell
+    gives 6 iso-surface vertices on edges 0, 3, 5, 6, 9, 11."""
+    res = oracle.marching_cubes(_single_cell_values(), 0.25, 1.0)
+    assert res.vertices.shape[0] == 6 and sorted(int(k) for k in res.vertex_keys) == SINGLE_CELL_KEYS
+    empty = oracle.marching_cubes(np.zeros((2, 2, 2)), 0.25, 1.0)
+    assert empty.vertices.shape[0] == 0 and empty.triangles.shape[0] == 0

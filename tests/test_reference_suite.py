@@ -115,3 +115,17 @@ def test_neighborhood_search_rs_against_naive(gpu_ctx):
     np.fill_diagonal(nb, False)
     for i in range(0, p.shape[0], 7):
         assert sorted(int(j) for j in lists[i]) == np.nonzero(nb[i])[0].tolist()
+
+
+def test_marching_cubes_rs_single_cell(gpu_ctx, oracle):
+    """marching_cubes.rs:325-398 (test_interpolate_cell_data) on the GPU: 6 vertices on edges 0, 3, 5, 6, 9, 11; empty map -> empty mesh."""
+    import splashsurf_amd as S
+    from test_oracle import SINGLE_CELL_KEYS, _single_cell_values
+    vals = _single_cell_values()
+    mesh, grid = S.marching_cubes(vals, iso_surface_threshold=0.25, cube_size=1.0, return_grid=True, context=gpu_ctx)
+    assert np.array_equal(np.asarray(grid.aabb.max), [1.0, 1.0, 1.0])
+    orc = oracle.marching_cubes(vals, 0.25, 1.0)
+    assert mesh.vertices.shape[0] == 6 and np.array_equal(mesh.vertices, orc.vertices) and np.array_equal(mesh.triangles, orc.triangles)
+    assert sorted(int(k) for k in orc.vertex_keys) == SINGLE_CELL_KEYS
+    empty = S.marching_cubes(np.zeros((2, 2, 2)), iso_surface_threshold=0.25, cube_size=1.0, context=gpu_ctx)
+    assert empty.vertices.shape[0] == 0 and empty.triangles.shape[0] == 0
