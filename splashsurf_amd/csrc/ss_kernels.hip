@@ -597,8 +597,27 @@ __device__ __forceinline__ R ss_kernel_w(R d2, R h, R rh, R sigma) {
         r = ss_sqrt_rn_normal(d2);
     else
         r = ss_sqrt(d2);  // generic variant: hipcc's fully guarded, correctly rounded sqrt
-    const R q = ss_div_by_h<R, FAST>(r + r, h, rh);
-    return sigma * ss_cubic_function_sel<R>(q);
+    if constexpr (FAST) {
+        // q = RN((r + r) / h) = RN(r / (h/2)): halving h and doubling its reciprocal are exact, so the division verified for
+        // the divisor h (all significands) serves h/2 as well and the doubling of r is not needed
+        const R q = ss_div_by_h<R, true>(r, R(0.5) * h, rh + rh);
+        // kernel.rs:71-81.  The outer piece (1 <= q < 2) is evaluated for every lane; the inner piece only if some lane of
+        // the wave needs it (a wave-uniform branch): about three quarters of the tile entries a wave visits lie farther
+        // than h/2 from all of its 64 points.
+        const R pi = R(3.14159265358979323846);
+        const R x = R(2.0) - q;
+        const R fb = (R(1.0) / (R(4.0) * pi)) * x * x * x;
+        R f = (q < R(2.0)) ? fb : R(0.0);
+        const bool inner = q < R(1.0);
+        if (__ballot(inner)) {
+            const R fa = (R(3.0) / (R(2.0) * pi)) * ((R(2.0) / R(3.0)) - q * q + R(0.5) * q * q * q);
+            f = inner ? fa : f;
+        }
+        return sigma * f;
+    } else {
+        const R q = ss_div_by_h<R, false>(r + r, h, rh);
+        return sigma * ss_cubic_function_sel<R>(q);
+    }
 }
 
 __global__ __launch_bounds__(256) void k_verify_fast_div(float h, float rh, uint32_t* __restrict__ bad) {
@@ -863,20 +882,32 @@ __global__ __launch_bounds__(512) void k_splat(SSDevT<R> P, const ss_real4<R>* _
                 if (wmask) {
                     // Entries are fetched with a wave-uniform LDS read (broadcast: LDS pipe, no VALU issue slot,
                     // operands arrive in VGPRs) one iteration ahead of their use.
+                    // two entries per trip, ping-ponging between two register sets (no loop-carried copies)
                     int bit = __ffsll((long long)wmask) - 1;
-                    ss_real4<R> cur = s.pay[base + bit];
+                    ss_real4<R> ea = s.pay[base + bit];
                     while (true) {
                         wmask &= wmask - 1;
-                        const int nbit = wmask ? (__ffsll((long long)wmask) - 1) : bit;
-                        const ss_real4<R> nxt = s.pay[base + nbit];
-                        const R dx = cur.x - px, dy = cur.y - py, dz = cur.z - pz;  // p_i - point, :828
-                        const R d2 = dx * dx + dy * dy + dz * dz;
-                        if (d2 < P.H2) {  // :831
-                            acc += cur.w * ss_kernel_w<R, FASTDIV>(d2, P.h, rh, P.sigma);  // :832-841
+                        const int bit_b = wmask ? (__ffsll((long long)wmask) - 1) : bit;
+                        const ss_real4<R> eb = s.pay[base + bit_b];
+                        {
+                            const R dx = ea.x - px, dy = ea.y - py, dz = ea.z - pz;  // p_i - point, :828
+                            const R d2 = dx * dx + dy * dy + dz * dz;
+                            if (d2 < P.H2) {  // :831
+                                acc += ea.w * ss_kernel_w<R, FASTDIV>(d2, P.h, rh, P.sigma);  // :832-841
+                            }
                         }
                         if (!wmask) break;
-                        cur = nxt;
-                        bit = nbit;
+                        wmask &= wmask - 1;
+                        bit = wmask ? (__ffsll((long long)wmask) - 1) : bit_b;
+                        ea = s.pay[base + bit];
+                        {
+                            const R dx = eb.x - px, dy = eb.y - py, dz = eb.z - pz;
+                            const R d2 = dx * dx + dy * dy + dz * dz;
+                            if (d2 < P.H2) {
+                                acc += eb.w * ss_kernel_w<R, FASTDIV>(d2, P.h, rh, P.sigma);
+                            }
+                        }
+                        if (!wmask) break;
                     }
                 }
             }
