@@ -605,9 +605,9 @@ __device__ __forceinline__ R ss_kernel_w(R d2, R h, R rh, R sigma) {
         // the wave needs it (a wave-uniform branch): about three quarters of the tile entries a wave visits lie farther
         // than h/2 from all of its 64 points.
         const R pi = R(3.14159265358979323846);
-        const R x = R(2.0) - q;
-        const R fb = (R(1.0) / (R(4.0) * pi)) * x * x * x;
-        R f = (q < R(2.0)) ? fb : R(0.0);
+        // q >= 2 (d^2 in [h^2, 1.01 h^2)) must give exactly 0: clamping x = 2 - q at 0 does, since c*0*0*0 == +0
+        const R x = ss_max(R(2.0) - q, R(0.0));
+        R f = (R(1.0) / (R(4.0) * pi)) * x * x * x;
         const bool inner = q < R(1.0);
         if (__ballot(inner)) {
             const R fa = (R(3.0) / (R(2.0) * pi)) * ((R(2.0) / R(3.0)) - q * q + R(0.5) * q * q * q);
