@@ -33,6 +33,9 @@ def parse():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="s10m_tank")
+    ap.add_argument("--main-only", action="store_true",
+                    help="only the timed steps of the named workload (no host-input variants, no other configs, no CPU baseline): "
+                         "the command to profile, so that rocprofv3's per-kernel averages are those of this workload")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-sharded", action="store_true", help="run the multi-GPU (sharded) code path even with one rank")
     ap.add_argument("--cpu-sample-scale", type=float, default=0.5, help="tank scale of the CPU-baseline sample (0.5 => 1.25M particles)")
@@ -170,7 +173,7 @@ def main():
         },
         "stages_ms": {k: round(v, 4) for k, v in st.items() if k.startswith("ms_")},
     }
-    if not sharded_path:
+    if not sharded_path and not args.main_only:
         # secondary figure (never `value`): the same call with HOST-resident input and the mesh copied back
         # to pinned host memory (H2D + all kernels + D2H), i.e. what a host-only caller of the C ABI sees
         try:
@@ -237,6 +240,7 @@ def main():
                 del d1, o1
             except Exception as e:
                 line["other_configs"] = {"s1m": {"value": None, "note": "failed: %r" % (e,)}}
+    if not sharded_path:
         # HBM traffic of the splat kernel from rocprofv3 PMC passes (collected offline, see profiles/)
         try:
             tr = json.load(open(os.path.join(ROOT, "profiles", "splat_traffic.json"))).get(args.workload)
@@ -248,7 +252,7 @@ def main():
     if sharded_path and getattr(last, "timings", None):
         line["sharded_step_ms"] = {k: round(v / args.steps, 3) for k, v in last.timings.items()}
     if rank == 0:
-        if not sharded_path and not args.no_cpu_baseline:
+        if not sharded_path and not args.no_cpu_baseline and not args.main_only:
             try:
                 line["cpu_baseline"] = cpu_baseline(args.workload, args.cpu_sample_scale)
             except Exception as e:  # the baseline is informative; never lose the measurement because of it
