@@ -605,8 +605,11 @@ __device__ __forceinline__ R ss_kernel_w(R d2, R h, R rh, R sigma) {
         // the wave needs it (a wave-uniform branch): about three quarters of the tile entries a wave visits lie farther
         // than h/2 from all of its 64 points.
         const R pi = R(3.14159265358979323846);
-        // q >= 2 (d^2 in [h^2, 1.01 h^2)) must give exactly 0: clamping x = 2 - q at 0 does, since c*0*0*0 == +0
-        const R x = ss_max(R(2.0) - q, R(0.0));
+        // q >= 2 (d^2 in [h^2, 1.01 h^2)) must give exactly 0: clamping x = 2 - q at 0 does, since c*0*0*0 == +0.  The
+        // clamp to [0, 1] is the subtraction's output modifier (no extra instruction); its upper bound only touches lanes
+        // with q < 1, whose value is replaced by the inner piece below.
+        R x;
+        asm("v_sub_f32_e64 %0, 2.0, %1 clamp" : "=v"(x) : "v"(q));
         R f = (R(1.0) / (R(4.0) * pi)) * x * x * x;
         const bool inner = q < R(1.0);
         if (__ballot(inner)) {
