@@ -795,8 +795,23 @@ ss_status phase_finish(ss_context* ctx, ss_result* res) {
         ctx->fastdiv_h = P.h;
         SS_HIP(ctx, hipEventRecord(ctx->ev[5], st));  // keep the one-off check out of the splat timing
     }
+    // small-tile kernel first; blocks it could not hold are flagged, compacted in order and handed to the large-tile kernel
+    SS_HIP(ctx, ctx->splat_overflow.reserve(((size_t)n_active + 1) * 4 * 4 + 64));
+    uint32_t* ov_flag = ctx->splat_overflow.as<uint32_t>();
+    uint32_t* ov_rank = ov_flag + ((size_t)n_active + 1);
+    uint32_t* ov_list = ov_rank + ((size_t)n_active + 1);
+    uint32_t* ov_slot = ov_list + ((size_t)n_active + 1);
+    SS_HIP(ctx, hipMemsetAsync(ov_flag + n_active, 0, 4, st));
+    const bool fast = sizeof(R) == 4 && ctx->fastdiv_ok;
     ss_launch_splat(P, res->posvol.as<ss_real4<R>>(), res->perm.as<uint32_t>(), ctx->cell_start.as<uint32_t>(), res->active_list.as<uint32_t>(), n_active,
-                    res->G.as<R>(), res->blk_minmax.as<ss_real2<R>>(), ctx->counter.as<unsigned long long>(), sizeof(R) == 4 && ctx->fastdiv_ok, st);
+                    res->G.as<R>(), res->blk_minmax.as<ss_real2<R>>(), ctx->counter.as<unsigned long long>(), ov_flag, fast, st);
+    if (n_active) {
+        s = exclusive_scan_u32<uint32_t>(ctx, ov_flag, ov_rank, (size_t)n_active + 1);
+        if (s != SS_OK) return s;
+        ss_launch_compact_blocks(ov_flag, ov_rank, n_active, ov_list, ov_slot, st);
+        ss_launch_splat_large(P, res->posvol.as<ss_real4<R>>(), res->perm.as<uint32_t>(), ctx->cell_start.as<uint32_t>(), res->active_list.as<uint32_t>(), n_active,
+                              res->G.as<R>(), res->blk_minmax.as<ss_real2<R>>(), ctx->counter.as<unsigned long long>(), ov_list, ov_rank + n_active, fast, st);
+    }
     SS_HIP(ctx, hipEventRecord(ctx->ev[6], st));
 
     // ---- K4 prepare: MC blocks = blocks whose 2x2x2 level-set neighbourhood straddles the threshold ----
@@ -1205,7 +1220,7 @@ void ss_context_destroy(ss_context* c) {
     for (DevBuf* b : {&c->xyz_in, &c->xyz_filt, &c->flags32, &c->offsets, &c->keys_a, &c->keys_b, &c->vals_a, &c->cell_count,
                       &c->cell_start, &c->pos_sorted, &c->temp, &c->aabb_partial, &c->aabb_out, &c->block_flag, &c->block_rank, &c->mc_flag,
                       &c->mc_rank, &c->vcount, &c->tcount, &c->counter, &c->member_count, &c->copy_offset, &c->sub_flag, &c->sub_rank,
-                      &c->nb_count, &c->nb_tmp, &c->occ_sub, &c->ckeys_a, &c->ckeys_b, &c->cvals_a, &c->cidx, &c->cpos, &c->cell_count2, &c->cell_start2, &c->gboxes})
+                      &c->nb_count, &c->nb_tmp, &c->occ_sub, &c->ckeys_a, &c->ckeys_b, &c->cvals_a, &c->cidx, &c->cpos, &c->cell_count2, &c->cell_start2, &c->gboxes, &c->splat_overflow})
         b->release();
     for (DevBuf& b : c->post_pool) b.release();
     if (c->ev_ok)

@@ -83,6 +83,7 @@ struct ss_context {
     bool fastdiv_ok = false;
     bool ev_ok = false;
     DevBuf gboxes;  // global strategy: stencil boxes per particle chunk
+    DevBuf splat_overflow;  // queue of level-set blocks whose tile does not fit the small splat kernel
     // post-processing: grow-only scratch slots handed out in call order (reset at the start of every ss_post_* call)
     DevBuf post_pool[24];
     int post_pool_next = 0;
