@@ -803,8 +803,11 @@ ss_status phase_finish(ss_context* ctx, ss_result* res) {
     uint32_t* ov_slot = ov_list + ((size_t)n_active + 1);
     SS_HIP(ctx, hipMemsetAsync(ov_flag + n_active, 0, 4, st));
     const bool fast = sizeof(R) == 4 && ctx->fastdiv_ok;
-    ss_launch_splat(P, res->posvol.as<ss_real4<R>>(), res->perm.as<uint32_t>(), ctx->cell_start.as<uint32_t>(), res->active_list.as<uint32_t>(), n_active,
-                    res->G.as<R>(), res->blk_minmax.as<ss_real2<R>>(), ctx->counter.as<unsigned long long>(), ov_flag, fast, st);
+    SS_HIP(ctx, ctx->splat_tiles.reserve((size_t)n_active * ss_splat_tile_entries() * sizeof(ss_real4<R>) + 64));
+    SS_HIP(ctx, ctx->splat_counts.reserve(((size_t)n_active + 1) * 4));
+    ss_launch_splat_small(P, res->posvol.as<ss_real4<R>>(), res->perm.as<uint32_t>(), ctx->cell_start.as<uint32_t>(), res->active_list.as<uint32_t>(), n_active,
+                          ctx->splat_tiles.as<ss_real4<R>>(), ctx->splat_counts.as<uint32_t>(), res->G.as<R>(), res->blk_minmax.as<ss_real2<R>>(),
+                          ctx->counter.as<unsigned long long>(), ov_flag, fast, st);
     if (n_active) {
         s = exclusive_scan_u32<uint32_t>(ctx, ov_flag, ov_rank, (size_t)n_active + 1);
         if (s != SS_OK) return s;
@@ -1220,7 +1223,7 @@ void ss_context_destroy(ss_context* c) {
     for (DevBuf* b : {&c->xyz_in, &c->xyz_filt, &c->flags32, &c->offsets, &c->keys_a, &c->keys_b, &c->vals_a, &c->cell_count,
                       &c->cell_start, &c->pos_sorted, &c->temp, &c->aabb_partial, &c->aabb_out, &c->block_flag, &c->block_rank, &c->mc_flag,
                       &c->mc_rank, &c->vcount, &c->tcount, &c->counter, &c->member_count, &c->copy_offset, &c->sub_flag, &c->sub_rank,
-                      &c->nb_count, &c->nb_tmp, &c->occ_sub, &c->ckeys_a, &c->ckeys_b, &c->cvals_a, &c->cidx, &c->cpos, &c->cell_count2, &c->cell_start2, &c->gboxes, &c->splat_overflow})
+                      &c->nb_count, &c->nb_tmp, &c->occ_sub, &c->ckeys_a, &c->ckeys_b, &c->cvals_a, &c->cidx, &c->cpos, &c->cell_count2, &c->cell_start2, &c->gboxes, &c->splat_overflow, &c->splat_tiles, &c->splat_counts})
         b->release();
     for (DevBuf& b : c->post_pool) b.release();
     if (c->ev_ok)

@@ -83,7 +83,8 @@ struct ss_context {
     bool fastdiv_ok = false;
     bool ev_ok = false;
     DevBuf gboxes;  // global strategy: stencil boxes per particle chunk
-    DevBuf splat_overflow;  // queue of level-set blocks whose tile does not fit the small splat kernel
+    DevBuf splat_overflow;  // flags / queue of level-set blocks whose tile does not fit a slot of the small-tile path
+    DevBuf splat_tiles, splat_counts;  // index-ordered candidate tiles (fixed slots) written by k_splat_gather, read by k_splat_accumulate
     // post-processing: grow-only scratch slots handed out in call order (reset at the start of every ss_post_* call)
     DevBuf post_pool[24];
     int post_pool_next = 0;

@@ -718,6 +718,58 @@ __device__ inline bool splat_for_each_candidate(S& s, const SSDevT<R>& P, const 
     return true;
 }
 
+// Accumulation of one wave's 4^3 sub-block over an index-ordered tile in LDS (dense_subdomains.rs:817-841).
+template <class R, bool FASTDIV>
+__device__ __forceinline__ R splat_accumulate_wave(const SSDevT<R>& P, const ss_real4<R>* pay, int n_tile, int lane, R px, R py, R pz, const R slo[3],
+                                                   const R shi[3], R wave_r2, R acc) {
+    const R rh = R(1.0) / P.h;
+    for (int base = 0; base < n_tile; base += 64) {
+        const int c = base + lane;
+        bool pass = false;
+        ss_real4<R> pv = ss_make4(R(0.0), R(0.0), R(0.0), R(0.0));
+        if (c < n_tile) {
+            pv = pay[c];
+            const R ex = ss_max(ss_max(slo[0] - pv.x, pv.x - shi[0]) - P.coord_slack, R(0.0));
+            const R ey = ss_max(ss_max(slo[1] - pv.y, pv.y - shi[1]) - P.coord_slack, R(0.0));
+            const R ez = ss_max(ss_max(slo[2] - pv.z, pv.z - shi[2]) - P.coord_slack, R(0.0));
+            pass = (ex * ex + ey * ey + ez * ez) <= wave_r2;
+        }
+        unsigned long long wmask = __ballot(pass);
+        if (wmask) {
+            // Entries are fetched with a wave-uniform LDS read (broadcast: LDS pipe, no VALU issue slot,
+            // operands arrive in VGPRs) one iteration ahead of their use.
+            // two entries per trip, ping-ponging between two register sets (no loop-carried copies)
+            int bit = __ffsll((long long)wmask) - 1;
+            ss_real4<R> ea = pay[base + bit];
+            while (true) {
+                wmask &= wmask - 1;
+                const int bit_b = wmask ? (__ffsll((long long)wmask) - 1) : bit;
+                const ss_real4<R> eb = pay[base + bit_b];
+                {
+                    const R dx = ea.x - px, dy = ea.y - py, dz = ea.z - pz;  // p_i - point, :828
+                    const R d2 = dx * dx + dy * dy + dz * dz;
+                    if (d2 < P.H2) {  // :831
+                        acc += ea.w * ss_kernel_w<R, FASTDIV>(d2, P.h, rh, P.sigma);  // :832-841
+                    }
+                }
+                if (!wmask) break;
+                wmask &= wmask - 1;
+                bit = wmask ? (__ffsll((long long)wmask) - 1) : bit_b;
+                ea = pay[base + bit];
+                {
+                    const R dx = eb.x - px, dy = eb.y - py, dz = eb.z - pz;
+                    const R d2 = dx * dx + dy * dy + dz * dz;
+                    if (d2 < P.H2) {
+                        acc += eb.w * ss_kernel_w<R, FASTDIV>(d2, P.h, rh, P.sigma);
+                    }
+                }
+                if (!wmask) break;
+            }
+        }
+    }
+    return acc;
+}
+
 // One level-set block.  MULTIPASS = false: a tile that does not fit CAP entries is left untouched and `false` is
 // returned (the caller queues the block for the large-tile kernel); MULTIPASS = true: such tiles are processed in
 // several passes over ascending index ranges.
@@ -926,53 +978,7 @@ __device__ __forceinline__ bool splat_block(SplatShared<R, CAP>& s, const SSDevT
         // Measured issue costs on gfx950 (tools/ubench/valu_rates.hip): f32 add/mul ~2.3 cycles per wave64
         // instruction, fma ~3.5, cmp/cndmask/readlane ~3.7, SGPR-source operands ~3.9, v_pk_* ~6.2,
         // v_sqrt/v_rcp ~7.4 -- hence LDS broadcast reads (not v_readlane) and no packed math in this loop.
-        if (wave_valid) {
-            const R rh = R(1.0) / P.h;
-            for (int base = 0; base < n_tile; base += 64) {
-                const int c = base + lane;
-                bool pass = false;
-                ss_real4<R> pv = ss_make4(R(0.0), R(0.0), R(0.0), R(0.0));
-                if (c < n_tile) {
-                    pv = s.pay[c];
-                    const R ex = ss_max(ss_max(slo[0] - pv.x, pv.x - shi[0]) - P.coord_slack, R(0.0));
-                    const R ey = ss_max(ss_max(slo[1] - pv.y, pv.y - shi[1]) - P.coord_slack, R(0.0));
-                    const R ez = ss_max(ss_max(slo[2] - pv.z, pv.z - shi[2]) - P.coord_slack, R(0.0));
-                    pass = (ex * ex + ey * ey + ez * ez) <= wave_r2;
-                }
-                unsigned long long wmask = __ballot(pass);
-                if (wmask) {
-                    // Entries are fetched with a wave-uniform LDS read (broadcast: LDS pipe, no VALU issue slot,
-                    // operands arrive in VGPRs) one iteration ahead of their use.
-                    // two entries per trip, ping-ponging between two register sets (no loop-carried copies)
-                    int bit = __ffsll((long long)wmask) - 1;
-                    ss_real4<R> ea = s.pay[base + bit];
-                    while (true) {
-                        wmask &= wmask - 1;
-                        const int bit_b = wmask ? (__ffsll((long long)wmask) - 1) : bit;
-                        const ss_real4<R> eb = s.pay[base + bit_b];
-                        {
-                            const R dx = ea.x - px, dy = ea.y - py, dz = ea.z - pz;  // p_i - point, :828
-                            const R d2 = dx * dx + dy * dy + dz * dz;
-                            if (d2 < P.H2) {  // :831
-                                acc += ea.w * ss_kernel_w<R, FASTDIV>(d2, P.h, rh, P.sigma);  // :832-841
-                            }
-                        }
-                        if (!wmask) break;
-                        wmask &= wmask - 1;
-                        bit = wmask ? (__ffsll((long long)wmask) - 1) : bit_b;
-                        ea = s.pay[base + bit];
-                        {
-                            const R dx = eb.x - px, dy = eb.y - py, dz = eb.z - pz;
-                            const R d2 = dx * dx + dy * dy + dz * dz;
-                            if (d2 < P.H2) {
-                                acc += eb.w * ss_kernel_w<R, FASTDIV>(d2, P.h, rh, P.sigma);
-                            }
-                        }
-                        if (!wmask) break;
-                    }
-                }
-            }
-        }
+        if (wave_valid) acc = splat_accumulate_wave<R, FASTDIV>(P, s.pay, n_tile, lane, px, py, pz, slo, shi, wave_r2, acc);
         if (T >= idx_max) break;
         last = T;
         __syncthreads();
@@ -1008,6 +1014,200 @@ __device__ __forceinline__ bool splat_block(SplatShared<R, CAP>& s, const SSDevT
         blk_minmax[logical] = ss_make2(mn, mx);
     }
     return true;
+}
+
+// =====================================================================================================
+// Small-tile path in two kernels.  The gather of a block's candidates is a chain of dependent loads (search-cell rows ->
+// particles) with little arithmetic; the accumulation is pure VALU work.  k_splat_gather gives every block ONE WAVE (no
+// workgroup barriers, 32 blocks in flight per CU) and leaves the index-ordered tile (x, y, z, V) in a fixed slot of
+// SS_WTILE entries in HBM; k_splat_accumulate streams the slot into LDS with one coalesced read and does the arithmetic.
+// Blocks whose tile does not fit a slot are flagged for k_splat_large.
+// =====================================================================================================
+#define SS_WTILE 384
+
+__device__ __forceinline__ void ss_wave_lds_sync() {
+    // LDS operations of one wave complete in order; this only stops the compiler from moving them across
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+template <class R>
+__global__ __launch_bounds__(256) void k_splat_gather(SSDevT<R> P, const ss_real4<R>* __restrict__ posvol, const uint32_t* __restrict__ perm,
+                                                      const uint32_t* __restrict__ cell_start, const uint32_t* __restrict__ active_list, uint32_t n_active,
+                                                      ss_real4<R>* __restrict__ tiles, uint32_t* __restrict__ counts, uint32_t* __restrict__ overflow_flag) {
+    __shared__ uint32_t s_idx[4][SS_WTILE];
+    __shared__ uint32_t s_src[4][SS_WTILE];
+    __shared__ uint32_t s_row_start[4][64];
+    __shared__ uint32_t s_row_prefix[4][65];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    // XCD-aware mapping of groups of four consecutive blocks (see k_splat_accumulate)
+    const uint32_t n_groups = (n_active + 3u) / 4u;
+    const uint32_t per_xcd = (n_groups + 7u) / 8u;
+    const uint32_t group = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
+    if ((blockIdx.x >> 3) >= per_xcd || group >= n_groups) return;
+    const uint32_t logical = group * 4u + (uint32_t)w;
+    if (logical >= n_active) return;
+    const uint32_t b = active_list[logical];
+    const int b3[3] = {(int)(b / ((uint32_t)P.nb[2] * (uint32_t)P.nb[1])), (int)((b / (uint32_t)P.nb[2]) % (uint32_t)P.nb[1]), (int)(b % (uint32_t)P.nb[2])};
+    R blo[3], bhi[3];
+    int klo[3], khi[3];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {  // dilated block box and the search cells overlapping it (as in splat_block)
+        const int i0 = b3[d] * SS_BLOCK;
+        const int i1 = min(i0 + SS_BLOCK - 1, P.np[d] - 1);
+        const R pad = P.reach + P.coord_slack;
+        blo[d] = (P.gmin[d] + (R)i0 * P.cs) - pad;
+        bhi[d] = (P.gmin[d] + (R)i1 * P.cs) + pad;
+        const double cellpad = 1e-3 * (double)P.h;
+        const int a = (int)floor(((double)blo[d] - cellpad) / (double)P.h);
+        const int e = (int)floor(((double)bhi[d] + cellpad) / (double)P.h);
+        klo[d] = max(a, P.kmin[d]);
+        khi[d] = min(e, P.kmin[d] + P.kdim[d] - 1);
+    }
+    uint32_t count = 0;
+    bool overflow = false;
+    if (klo[0] <= khi[0] && klo[1] <= khi[1] && klo[2] <= khi[2]) {
+        const int ny = khi[1] - klo[1] + 1;
+        const int nrows = (khi[0] - klo[0] + 1) * ny;
+        if (nrows > 64) {
+            overflow = true;
+        } else {
+            // row table: (x, y) rows of search cells are contiguous runs of the cell-sorted particle array
+            uint32_t len = 0;
+            if (lane < nrows) {
+                const int kx = klo[0] + lane / ny, ky = klo[1] + lane % ny;
+                const uint32_t rb = cell_start[ss_cell_key(P, kx, ky, klo[2])];
+                const uint32_t re = cell_start[ss_cell_key(P, kx, ky, khi[2]) + 1u];
+                s_row_start[w][lane] = rb;
+                len = re - rb;
+            }
+            uint32_t incl = len;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const uint32_t t = __shfl_up(incl, off);
+                if (lane >= off) incl += t;
+            }
+            s_row_prefix[w][lane] = incl - len;
+            const uint32_t total = __shfl(incl, 63);
+            if (lane == 0) s_row_prefix[w][64] = total;
+            ss_wave_lds_sync();
+            if (total > 3u * SS_WTILE) {
+                overflow = true;  // a box holds roughly 40 % of the particles of the rows it overlaps: over-dense block
+            } else {
+                for (uint32_t q0 = 0; q0 < total; q0 += 64u) {
+                    const uint32_t q = q0 + (uint32_t)lane;
+                    bool inside = false;
+                    uint32_t src = 0, id = 0;
+                    if (q < total) {
+                        int lo = 0, hi = nrows - 1;  // last row r with row_prefix[r] <= q
+                        while (lo < hi) {
+                            const int mid = (lo + hi + 1) >> 1;
+                            if (s_row_prefix[w][mid] <= q)
+                                lo = mid;
+                            else
+                                hi = mid - 1;
+                        }
+                        src = s_row_start[w][lo] + (q - s_row_prefix[w][lo]);
+                        const ss_real4<R> pv = posvol[src];
+                        id = perm[src];
+                        inside = pv.x >= blo[0] && pv.x <= bhi[0] && pv.y >= blo[1] && pv.y <= bhi[1] && pv.z >= blo[2] && pv.z <= bhi[2];
+                    }
+                    const unsigned long long m = __ballot(inside);
+                    const uint32_t pos = count + (uint32_t)__popcll(m & ((lane == 0) ? 0ull : (~0ull >> (64 - lane))));
+                    if (inside && pos < SS_WTILE) {
+                        s_idx[w][pos] = id;
+                        s_src[w][pos] = src;
+                    }
+                    count += (uint32_t)__popcll(m);
+                }
+                if (count > SS_WTILE) {
+                    overflow = true;
+                } else {
+                    ss_wave_lds_sync();
+                    // rank sort by original particle index (unique), payload written in that order
+                    ss_real4<R>* slot = tiles + (size_t)logical * SS_WTILE;
+                    for (uint32_t e = (uint32_t)lane; e < count; e += 64u) {
+                        const uint32_t my = s_idx[w][e];
+                        uint32_t rank = 0;
+                        for (uint32_t k = 0; k < count; ++k) rank += (s_idx[w][k] < my) ? 1u : 0u;
+                        slot[rank] = posvol[s_src[w][e]];
+                    }
+                }
+            }
+        }
+    }
+    if (lane == 0) {
+        counts[logical] = overflow ? 0u : count;
+        overflow_flag[logical] = overflow ? 1u : 0u;
+    }
+}
+
+template <class R, bool FASTDIV>
+__global__ __launch_bounds__(512) void k_splat_accumulate(SSDevT<R> P, const ss_real4<R>* __restrict__ tiles, const uint32_t* __restrict__ counts,
+                                                          const uint32_t* __restrict__ overflow_flag, const uint32_t* __restrict__ active_list,
+                                                          uint32_t n_active, R* __restrict__ G, ss_real2<R>* __restrict__ blk_minmax,
+                                                          unsigned long long* __restrict__ cand_counter) {
+    __shared__ ss_real4<R> s_pay[SS_WTILE];
+    __shared__ R s_red[16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // XCD-aware mapping: hardware places workgroup w on XCD w % 8; give each XCD a contiguous range of
+    // the (spatially ordered) active list so that neighbouring blocks share an L2.
+    const uint32_t per_xcd = (n_active + 7u) / 8u;
+    const uint32_t logical = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
+    if ((blockIdx.x >> 3) >= per_xcd || logical >= n_active) return;
+    if (overflow_flag[logical]) return;  // k_splat_large's block
+    const int n_tile = (int)counts[logical];
+    const ss_real4<R>* slot = tiles + (size_t)logical * SS_WTILE;
+    if (tid < n_tile) s_pay[tid] = slot[tid];
+    if (tid == 0 && n_tile) atomicAdd(cand_counter, (unsigned long long)n_tile);
+    const uint32_t b = active_list[logical];
+    const int bz = (int)(b % (uint32_t)P.nb[2]);
+    const int by = (int)((b / (uint32_t)P.nb[2]) % (uint32_t)P.nb[1]);
+    const int bx = (int)(b / ((uint32_t)P.nb[2] * (uint32_t)P.nb[1]));
+    // this wave's sub-block and this lane's grid point
+    const int g0[3] = {bx * SS_BLOCK + ((wave >> 2) & 1) * 4, by * SS_BLOCK + ((wave >> 1) & 1) * 4, bz * SS_BLOCK + (wave & 1) * 4};
+    const int gl[3] = {g0[0] + ((lane >> 4) & 3), g0[1] + ((lane >> 2) & 3), g0[2] + (lane & 3)};
+    const bool wave_valid = g0[0] < P.np[0] && g0[1] < P.np[1] && g0[2] < P.np[2];
+    // global point coordinates: uniform_grid.rs:418-425 on the GLOBAL grid (dense_subdomains.rs:817-826)
+    const R px = P.gmin[0] + (R)gl[0] * P.cs;
+    const R py = P.gmin[1] + (R)gl[1] * P.cs;
+    const R pz = P.gmin[2] + (R)gl[2] * P.cs;
+    R slo[3], shi[3];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        slo[d] = P.gmin[d] + (R)g0[d] * P.cs;
+        shi[d] = P.gmin[d] + (R)min(g0[d] + 3, P.np[d] - 1) * P.cs;
+    }
+    const R wave_r2 = P.H2 * R(1.0001);
+    __syncthreads();
+    R acc = R(0.0);  // levelset_grid.fill(0), dense_subdomains.rs:1390
+    if (wave_valid && n_tile) acc = splat_accumulate_wave<R, FASTDIV>(P, s_pay, n_tile, lane, px, py, pz, slo, shi, wave_r2, acc);
+    // store: block-local layout (x*8+y)*8+z, i-major / k-fastest like dense_subdomains.rs:839
+    const int lx = ((wave >> 2) & 1) * 4 + ((lane >> 4) & 3);
+    const int ly = ((wave >> 1) & 1) * 4 + ((lane >> 2) & 3);
+    const int lz = (wave & 1) * 4 + (lane & 3);
+    const bool point_valid = gl[0] < P.np[0] && gl[1] < P.np[1] && gl[2] < P.np[2];
+    const R val = point_valid ? acc : R(0.0);
+    G[(size_t)logical * SS_BLOCK_POINTS + (size_t)((lx * 8 + ly) * 8 + lz)] = val;
+    R mn = val, mx = val;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        mn = ss_min(mn, __shfl_xor(mn, off));
+        mx = ss_max(mx, __shfl_xor(mx, off));
+    }
+    if (lane == 0) {
+        s_red[wave] = mn;
+        s_red[8 + wave] = mx;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        for (int q = 1; q < 8; ++q) {
+            mn = ss_min(mn, s_red[q]);
+            mx = ss_max(mx, s_red[8 + q]);
+        }
+        blk_minmax[logical] = ss_make2(mn, mx);
+    }
 }
 
 template <class R, bool FASTDIV>
@@ -1063,6 +1263,26 @@ void ss_launch_splat(const SSDevT<R>& P, const ss_real4<R>* posvol, const uint32
     hipLaunchKernelGGL((k_splat<R, false>), dim3(per_xcd * 8u), dim3(512), 0, st, P, posvol, perm, cell_start, active_list, n_active, G, blk_minmax,
                        cand_counter, overflow_flag);
 }
+
+template <class R>
+void ss_launch_splat_small(const SSDevT<R>& P, const ss_real4<R>* posvol, const uint32_t* perm, const uint32_t* cell_start, const uint32_t* active_list,
+                           uint32_t n_active, ss_real4<R>* tiles, uint32_t* counts, R* G, ss_real2<R>* blk_minmax, unsigned long long* cand_counter,
+                           uint32_t* overflow_flag, bool fast_div, hipStream_t st) {
+    if (!n_active) return;
+    const uint32_t n_groups = (n_active + 3u) / 4u;
+    hipLaunchKernelGGL(k_splat_gather<R>, dim3(((n_groups + 7u) / 8u) * 8u), dim3(256), 0, st, P, posvol, perm, cell_start, active_list, n_active, tiles, counts,
+                       overflow_flag);
+    const dim3 grid(((n_active + 7u) / 8u) * 8u);
+    if constexpr (sizeof(R) == 4) {
+        if (fast_div) {
+            hipLaunchKernelGGL((k_splat_accumulate<R, true>), grid, dim3(512), 0, st, P, tiles, counts, overflow_flag, active_list, n_active, G, blk_minmax,
+                               cand_counter);
+            return;
+        }
+    }
+    hipLaunchKernelGGL((k_splat_accumulate<R, false>), grid, dim3(512), 0, st, P, tiles, counts, overflow_flag, active_list, n_active, G, blk_minmax, cand_counter);
+}
+size_t ss_splat_tile_entries() { return SS_WTILE; }
 
 // second launch: the queued over-dense blocks (overflow_count lives on the device; an empty queue costs one trivial launch)
 template <class R>
@@ -1376,8 +1596,10 @@ template void ss_launch_mark_blocks<double>(const SSDevT<double>& P, const uint3
 template void ss_launch_mark_mc_blocks<float>(const SSDevT<float>& P, const uint32_t* block_slot, const ss_real2<float>* blk_minmax, uint32_t nblocks, uint32_t* mc_flag, hipStream_t st);
 template void ss_launch_mark_mc_blocks<double>(const SSDevT<double>& P, const uint32_t* block_slot, const ss_real2<double>* blk_minmax, uint32_t nblocks, uint32_t* mc_flag, hipStream_t st);
 template void ss_launch_splat<float>(const SSDevT<float>& P, const ss_real4<float>* posvol, const uint32_t* perm, const uint32_t* cell_start, const uint32_t* active_list, uint32_t n_active, float* G, ss_real2<float>* blk_minmax, unsigned long long* cand_counter, uint32_t* overflow_flag, bool fast_div, hipStream_t st);
+template void ss_launch_splat_small<float>(const SSDevT<float>& P, const ss_real4<float>* posvol, const uint32_t* perm, const uint32_t* cell_start, const uint32_t* active_list, uint32_t n_active, ss_real4<float>* tiles, uint32_t* counts, float* G, ss_real2<float>* blk_minmax, unsigned long long* cand_counter, uint32_t* overflow_flag, bool fast_div, hipStream_t st);
 template void ss_launch_splat_large<float>(const SSDevT<float>& P, const ss_real4<float>* posvol, const uint32_t* perm, const uint32_t* cell_start, const uint32_t* active_list, uint32_t n_active, float* G, ss_real2<float>* blk_minmax, unsigned long long* cand_counter, const uint32_t* overflow_list, const uint32_t* overflow_count, bool fast_div, hipStream_t st);
 template void ss_launch_splat<double>(const SSDevT<double>& P, const ss_real4<double>* posvol, const uint32_t* perm, const uint32_t* cell_start, const uint32_t* active_list, uint32_t n_active, double* G, ss_real2<double>* blk_minmax, unsigned long long* cand_counter, uint32_t* overflow_flag, bool fast_div, hipStream_t st);
+template void ss_launch_splat_small<double>(const SSDevT<double>& P, const ss_real4<double>* posvol, const uint32_t* perm, const uint32_t* cell_start, const uint32_t* active_list, uint32_t n_active, ss_real4<double>* tiles, uint32_t* counts, double* G, ss_real2<double>* blk_minmax, unsigned long long* cand_counter, uint32_t* overflow_flag, bool fast_div, hipStream_t st);
 template void ss_launch_splat_large<double>(const SSDevT<double>& P, const ss_real4<double>* posvol, const uint32_t* perm, const uint32_t* cell_start, const uint32_t* active_list, uint32_t n_active, double* G, ss_real2<double>* blk_minmax, unsigned long long* cand_counter, const uint32_t* overflow_list, const uint32_t* overflow_count, bool fast_div, hipStream_t st);
 template void ss_launch_mc_count<float>(const SSDevT<float>& P, const float* G, const uint32_t* block_slot, const uint32_t* mc_list, uint32_t n_mc, unsigned long long* masks, uint32_t* vcount, uint32_t* tcount, hipStream_t st);
 template void ss_launch_mc_count<double>(const SSDevT<double>& P, const double* G, const uint32_t* block_slot, const uint32_t* mc_list, uint32_t n_mc, unsigned long long* masks, uint32_t* vcount, uint32_t* tcount, hipStream_t st);
