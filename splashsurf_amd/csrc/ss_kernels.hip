@@ -674,13 +674,10 @@ __device__ inline void splat_row_prefix(S& s, int nbatch, uint32_t len, int tid)
 
 // Visit every particle of the search cells overlapping the dilated block box; f(sorted position, idx, payload) is
 // called for particles inside the box.  All 512 threads must call this (contains barriers).
-// row_limit > 0: give up (return false, nothing visited) as soon as a batch of rows holds more than row_limit particles --
-// the small-tile kernel's cheap way of recognising over-dense blocks before it loads a single particle.
 template <class R, class S, class F>
-__device__ inline bool splat_for_each_candidate(S& s, const SSDevT<R>& P, const ss_real4<R>* __restrict__ posvol,
+__device__ inline void splat_for_each_candidate(S& s, const SSDevT<R>& P, const ss_real4<R>* __restrict__ posvol,
                                                 const uint32_t* __restrict__ perm, const uint32_t* __restrict__ cell_start,
-                                                const int klo[3], const int khi[3], const R blo[3], const R bhi[3], int tid, F f,
-                                                uint32_t row_limit = 0u) {
+                                                const int klo[3], const int khi[3], const R blo[3], const R bhi[3], int tid, F f) {
     const int ny = khi[1] - klo[1] + 1;
     const int nrows = (khi[0] - klo[0] + 1) * ny;
     for (int row_base = 0; row_base < nrows; row_base += SS_MAX_ROWS) {
@@ -698,7 +695,6 @@ __device__ inline bool splat_for_each_candidate(S& s, const SSDevT<R>& P, const 
         __syncthreads();
         splat_row_prefix(s, nbatch, len, tid);
         const uint32_t total = s.row_prefix[nbatch];
-        if (row_limit && total > row_limit) return false;  // uniform
         for (uint32_t q = tid; q < total; q += 512) {
             // binary search: last row r with row_prefix[r] <= q
             int lo = 0, hi = nbatch - 1;
@@ -715,7 +711,6 @@ __device__ inline bool splat_for_each_candidate(S& s, const SSDevT<R>& P, const 
         }
         __syncthreads();
     }
-    return true;
 }
 
 // Accumulation of one wave's 4^3 sub-block over an index-ordered tile in LDS (dense_subdomains.rs:817-841).
@@ -770,11 +765,10 @@ __device__ __forceinline__ R splat_accumulate_wave(const SSDevT<R>& P, const ss_
     return acc;
 }
 
-// One level-set block.  MULTIPASS = false: a tile that does not fit CAP entries is left untouched and `false` is
-// returned (the caller queues the block for the large-tile kernel); MULTIPASS = true: such tiles are processed in
-// several passes over ascending index ranges.
-template <class R, bool FASTDIV, int CAP, bool MULTIPASS>
-__device__ __forceinline__ bool splat_block(SplatShared<R, CAP>& s, const SSDevT<R>& P, const ss_real4<R>* __restrict__ posvol,
+// One level-set block of the large-tile path: tiles that do not fit CAP entries are processed in several passes over
+// ascending index ranges.
+template <class R, bool FASTDIV, int CAP>
+__device__ __forceinline__ void splat_block(SplatShared<R, CAP>& s, const SSDevT<R>& P, const ss_real4<R>* __restrict__ posvol,
                                             const uint32_t* __restrict__ perm, const uint32_t* __restrict__ cell_start, uint32_t b, uint32_t logical,
                                             R* __restrict__ G, ss_real2<R>* __restrict__ blk_minmax, unsigned long long* __restrict__ cand_counter) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -825,23 +819,17 @@ __device__ __forceinline__ bool splat_block(SplatShared<R, CAP>& s, const SSDevT
         long long T = idx_max;
         if (tid == 0) s.count = 0;
         __syncthreads();
-        // (a box holds roughly 40 % of the particles of the search-cell rows it overlaps)
-        const bool visited = splat_for_each_candidate<R>(s, P, posvol, perm, cell_start, klo, khi, blo, bhi, tid, [&](uint32_t src, uint32_t idx, const ss_real4<R>& pv) {
+        splat_for_each_candidate<R>(s, P, posvol, perm, cell_start, klo, khi, blo, bhi, tid, [&](uint32_t src, uint32_t idx, const ss_real4<R>&) {
             if ((long long)idx > last) {
                 uint32_t pos = atomicAdd(&s.count, 1u);
                 if (pos < CAP) {
                     s.idx[pos] = idx;
-                    if constexpr (MULTIPASS)
-                        s.src[pos] = src;  // large tiles: payload fetched again after the sort (cheaper than permuting 2048 entries in LDS)
-                    else
-                        s.pay[pos] = pv;   // small tiles: payload staged in arrival order and ordered in LDS below (no second trip to L2)
+                    s.src[pos] = src;  // payload fetched after the sort (cheaper than permuting 2048 entries inside LDS: measured)
                 }
             }
-        }, MULTIPASS ? 0u : 3u * (uint32_t)CAP);
-        if (!visited) return false;
+        });
         uint32_t total = s.count;
         if (total == 0) break;
-        if (!MULTIPASS && total > (uint32_t)CAP) return false;  // uniform: every thread reads the same count
         if (total > CAP) {
             // more candidates than LDS slots: find the largest threshold T with
             // #{last < idx <= T} <= CAP by bisection (count is monotone in T and grows by
@@ -879,95 +867,41 @@ __device__ __forceinline__ bool splat_block(SplatShared<R, CAP>& s, const SSDevT
         const int n_tile = (int)min(total, (uint32_t)CAP);
         if (tid == 0) atomicAdd(cand_counter, (unsigned long long)n_tile);
 
-        // ---- order the tile by original particle index ----
-        if constexpr (!MULTIPASS) {
-            // small tiles: the payload is already in LDS (arrival order); permute it through registers
-            if (n_tile <= 512) {
-                // rank sort: indices are unique, rank = number of smaller indices
-                uint32_t rank = 0;
-                ss_real4<R> mine = ss_make4(R(0.0), R(0.0), R(0.0), R(0.0));
-                if (tid < n_tile) {
-                    const uint32_t my_idx = s.idx[tid];
-                    mine = s.pay[tid];
-                    for (int k = 0; k < n_tile; ++k) rank += (s.idx[k] < my_idx) ? 1u : 0u;
-                }
-                __syncthreads();
-                if (tid < n_tile) s.pay[rank] = mine;
-            } else {
-                int m = 1024;
-                while (m < n_tile) m <<= 1;
-                for (int e = tid; e < m; e += 512) {
-                    if (e >= n_tile) s.idx[e] = 0xFFFFFFFFu;
-                    s.src[e] = (uint32_t)e;  // arrival position of the payload
-                }
-                __syncthreads();
-                for (int k = 2; k <= m; k <<= 1)
-                    for (int j = k >> 1; j > 0; j >>= 1) {
-                        for (int t = tid; t < (m >> 1); t += 512) {
-                            const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
-                            const int l = i | j;
-                            const bool up = (i & k) == 0;
-                            const uint32_t a = s.idx[i], c = s.idx[l];
-                            if ((a > c) == up) {
-                                s.idx[i] = c;
-                                s.idx[l] = a;
-                                const uint32_t sa = s.src[i];
-                                s.src[i] = s.src[l];
-                                s.src[l] = sa;
-                            }
-                        }
-                        __syncthreads();
-                    }
-                ss_real4<R> moved[(CAP + 511) / 512];
-#pragma unroll
-                for (int j = 0; j < (CAP + 511) / 512; ++j) {
-                    const int e = tid + 512 * j;
-                    if (e < n_tile) moved[j] = s.pay[s.src[e]];
-                }
-                __syncthreads();
-#pragma unroll
-                for (int j = 0; j < (CAP + 511) / 512; ++j) {
-                    const int e = tid + 512 * j;
-                    if (e < n_tile) s.pay[e] = moved[j];
-                }
+        // ---- order the tile by original particle index: sort (index, sorted position), fetch the payload in that order ----
+        if (n_tile <= 512) {
+            uint32_t my_idx = 0, my_src = 0, rank = 0;
+            if (tid < n_tile) {
+                my_idx = s.idx[tid];
+                my_src = s.src[tid];
+                for (int k = 0; k < n_tile; ++k) rank += (s.idx[k] < my_idx) ? 1u : 0u;
+                s.pay[rank] = posvol[my_src];
             }
         } else {
-            // large tiles: sort (index, sorted position) and fetch the payload in that order
-            if (n_tile <= 512) {
-                uint32_t my_idx = 0, my_src = 0, rank = 0;
-                if (tid < n_tile) {
-                    my_idx = s.idx[tid];
-                    my_src = s.src[tid];
-                    for (int k = 0; k < n_tile; ++k) rank += (s.idx[k] < my_idx) ? 1u : 0u;
-                    s.pay[rank] = posvol[my_src];
-                }
-            } else {
-                int m = 1024;
-                while (m < n_tile) m <<= 1;
-                for (int e = n_tile + tid; e < m; e += 512) {
-                    s.idx[e] = 0xFFFFFFFFu;
-                    s.src[e] = 0;
-                }
-                __syncthreads();
-                for (int k = 2; k <= m; k <<= 1)
-                    for (int j = k >> 1; j > 0; j >>= 1) {
-                        for (int t = tid; t < (m >> 1); t += 512) {
-                            const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
-                            const int l = i | j;
-                            const bool up = (i & k) == 0;
-                            const uint32_t a = s.idx[i], c = s.idx[l];
-                            if ((a > c) == up) {
-                                s.idx[i] = c;
-                                s.idx[l] = a;
-                                const uint32_t sa = s.src[i];
-                                s.src[i] = s.src[l];
-                                s.src[l] = sa;
-                            }
-                        }
-                        __syncthreads();
-                    }
-                for (int e = tid; e < n_tile; e += 512) s.pay[e] = posvol[s.src[e]];
+            int m = 1024;
+            while (m < n_tile) m <<= 1;
+            for (int e = n_tile + tid; e < m; e += 512) {
+                s.idx[e] = 0xFFFFFFFFu;
+                s.src[e] = 0;
             }
+            __syncthreads();
+            for (int k = 2; k <= m; k <<= 1)
+                for (int j = k >> 1; j > 0; j >>= 1) {
+                    for (int t = tid; t < (m >> 1); t += 512) {
+                        const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+                        const int l = i | j;
+                        const bool up = (i & k) == 0;
+                        const uint32_t a = s.idx[i], c = s.idx[l];
+                        if ((a > c) == up) {
+                            s.idx[i] = c;
+                            s.idx[l] = a;
+                            const uint32_t sa = s.src[i];
+                            s.src[i] = s.src[l];
+                            s.src[l] = sa;
+                        }
+                    }
+                    __syncthreads();
+                }
+            for (int e = tid; e < n_tile; e += 512) s.pay[e] = posvol[s.src[e]];
         }
         __syncthreads();
 
@@ -1013,7 +947,6 @@ __device__ __forceinline__ bool splat_block(SplatShared<R, CAP>& s, const SSDevT
         }
         blk_minmax[logical] = ss_make2(mn, mx);
     }
-    return true;
 }
 
 // =====================================================================================================
@@ -1210,23 +1143,6 @@ __global__ __launch_bounds__(512) void k_splat_accumulate(SSDevT<R> P, const ss_
     }
 }
 
-template <class R, bool FASTDIV>
-__global__ __launch_bounds__(512) void k_splat(SSDevT<R> P, const ss_real4<R>* __restrict__ posvol, const uint32_t* __restrict__ perm,
-                                               const uint32_t* __restrict__ cell_start, const uint32_t* __restrict__ active_list,
-                                               uint32_t n_active, R* __restrict__ G, ss_real2<R>* __restrict__ blk_minmax,
-                                               unsigned long long* __restrict__ cand_counter, uint32_t* __restrict__ overflow_flag) {
-    // Small-tile kernel: half the LDS of the large-tile one, hence more workgroups per CU to hide the latency of the gather
-    // phase; blocks whose tile does not fit are queued for k_splat_large.
-    __shared__ SplatShared<R, SSTileCap<R>::value / 2> s;
-    // XCD-aware mapping: hardware places workgroup w on XCD w % 8; give each XCD a contiguous range of
-    // the (spatially ordered) active list so that neighbouring blocks share an L2.
-    const uint32_t per_xcd = (n_active + 7u) / 8u;
-    const uint32_t logical = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
-    if ((blockIdx.x >> 3) >= per_xcd || logical >= n_active) return;
-    const bool done = splat_block<R, FASTDIV, SSTileCap<R>::value / 2, false>(s, P, posvol, perm, cell_start, active_list[logical], logical, G, blk_minmax, cand_counter);
-    if (threadIdx.x == 0) overflow_flag[logical] = done ? 0u : 1u;
-}
-
 // Blocks with more candidates than the small tile holds (over-dense regions).  The queue is the flag array compacted in
 // order (scan + k_compact_blocks), so it is spatially ordered like the active list; persistent workgroups walk it, each
 // XCD a contiguous range.
@@ -1242,26 +1158,10 @@ __global__ __launch_bounds__(512) void k_splat_large(SSDevT<R> P, const ss_real4
         const uint32_t it = xcd * per_xcd + j;
         if (it < n) {
             const uint32_t logical = overflow_list[it];
-            splat_block<R, FASTDIV, SSTileCap<R>::value, true>(s, P, posvol, perm, cell_start, active_list[logical], logical, G, blk_minmax, cand_counter);
+            splat_block<R, FASTDIV, SSTileCap<R>::value>(s, P, posvol, perm, cell_start, active_list[logical], logical, G, blk_minmax, cand_counter);
         }
         __syncthreads();
     }
-}
-
-template <class R>
-void ss_launch_splat(const SSDevT<R>& P, const ss_real4<R>* posvol, const uint32_t* perm, const uint32_t* cell_start, const uint32_t* active_list,
-                     uint32_t n_active, R* G, ss_real2<R>* blk_minmax, unsigned long long* cand_counter, uint32_t* overflow_flag, bool fast_div, hipStream_t st) {
-    if (!n_active) return;
-    const uint32_t per_xcd = (n_active + 7u) / 8u;
-    if constexpr (sizeof(R) == 4) {
-        if (fast_div) {
-            hipLaunchKernelGGL((k_splat<R, true>), dim3(per_xcd * 8u), dim3(512), 0, st, P, posvol, perm, cell_start, active_list, n_active, G, blk_minmax,
-                               cand_counter, overflow_flag);
-            return;
-        }
-    }
-    hipLaunchKernelGGL((k_splat<R, false>), dim3(per_xcd * 8u), dim3(512), 0, st, P, posvol, perm, cell_start, active_list, n_active, G, blk_minmax,
-                       cand_counter, overflow_flag);
 }
 
 template <class R>
@@ -1595,10 +1495,8 @@ template void ss_launch_mark_blocks<float>(const SSDevT<float>& P, const uint32_
 template void ss_launch_mark_blocks<double>(const SSDevT<double>& P, const uint32_t* cell_start, uint32_t ncells, uint32_t* block_flag, hipStream_t st);
 template void ss_launch_mark_mc_blocks<float>(const SSDevT<float>& P, const uint32_t* block_slot, const ss_real2<float>* blk_minmax, uint32_t nblocks, uint32_t* mc_flag, hipStream_t st);
 template void ss_launch_mark_mc_blocks<double>(const SSDevT<double>& P, const uint32_t* block_slot, const ss_real2<double>* blk_minmax, uint32_t nblocks, uint32_t* mc_flag, hipStream_t st);
-template void ss_launch_splat<float>(const SSDevT<float>& P, const ss_real4<float>* posvol, const uint32_t* perm, const uint32_t* cell_start, const uint32_t* active_list, uint32_t n_active, float* G, ss_real2<float>* blk_minmax, unsigned long long* cand_counter, uint32_t* overflow_flag, bool fast_div, hipStream_t st);
 template void ss_launch_splat_small<float>(const SSDevT<float>& P, const ss_real4<float>* posvol, const uint32_t* perm, const uint32_t* cell_start, const uint32_t* active_list, uint32_t n_active, ss_real4<float>* tiles, uint32_t* counts, float* G, ss_real2<float>* blk_minmax, unsigned long long* cand_counter, uint32_t* overflow_flag, bool fast_div, hipStream_t st);
 template void ss_launch_splat_large<float>(const SSDevT<float>& P, const ss_real4<float>* posvol, const uint32_t* perm, const uint32_t* cell_start, const uint32_t* active_list, uint32_t n_active, float* G, ss_real2<float>* blk_minmax, unsigned long long* cand_counter, const uint32_t* overflow_list, const uint32_t* overflow_count, bool fast_div, hipStream_t st);
-template void ss_launch_splat<double>(const SSDevT<double>& P, const ss_real4<double>* posvol, const uint32_t* perm, const uint32_t* cell_start, const uint32_t* active_list, uint32_t n_active, double* G, ss_real2<double>* blk_minmax, unsigned long long* cand_counter, uint32_t* overflow_flag, bool fast_div, hipStream_t st);
 template void ss_launch_splat_small<double>(const SSDevT<double>& P, const ss_real4<double>* posvol, const uint32_t* perm, const uint32_t* cell_start, const uint32_t* active_list, uint32_t n_active, ss_real4<double>* tiles, uint32_t* counts, double* G, ss_real2<double>* blk_minmax, unsigned long long* cand_counter, uint32_t* overflow_flag, bool fast_div, hipStream_t st);
 template void ss_launch_splat_large<double>(const SSDevT<double>& P, const ss_real4<double>* posvol, const uint32_t* perm, const uint32_t* cell_start, const uint32_t* active_list, uint32_t n_active, double* G, ss_real2<double>* blk_minmax, unsigned long long* cand_counter, const uint32_t* overflow_list, const uint32_t* overflow_count, bool fast_div, hipStream_t st);
 template void ss_launch_mc_count<float>(const SSDevT<float>& P, const float* G, const uint32_t* block_slot, const uint32_t* mc_list, uint32_t n_mc, unsigned long long* masks, uint32_t* vcount, uint32_t* tcount, hipStream_t st);
