@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define SS_ABI_VERSION 1
+#define SS_ABI_VERSION 2
 
 /* Return codes; 1..4 mirror ReconstructionError (lib.rs:289-314). */
 typedef enum ss_status {
@@ -130,6 +130,9 @@ typedef struct ss_stats {
     uint64_t fast_div_verified;       /* 1 if the splat used the exhaustively verified reciprocal division for this h */
     uint64_t levelset_kernel_launches;
     uint64_t bytes_device_peak;       /* HBM held by the context after this call */
+    double ms_levelset_gather;        /* part of ms_levelset: k_splat_gather (candidate tiles, one wave per block) */
+    double ms_levelset_accumulate;    /* part of ms_levelset: k_splat_accumulate (the arithmetic; the dominant kernel) */
+    uint64_t n_large_tile_blocks;     /* blocks handled by the large-tile kernel (over-dense tiles) */
 } ss_stats;
 
 typedef struct ss_context ss_context;

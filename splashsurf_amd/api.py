@@ -105,6 +105,9 @@ class _Stats(C.Structure):
         ("fast_div_verified", C.c_uint64),
         ("levelset_kernel_launches", C.c_uint64),
         ("bytes_device_peak", C.c_uint64),
+        ("ms_levelset_gather", C.c_double),
+        ("ms_levelset_accumulate", C.c_double),
+        ("n_large_tile_blocks", C.c_uint64),
     ]
 
 
@@ -190,7 +193,7 @@ def load_library():
     L.ss_result_grid_f64.argtypes = [vp, P(_Grid64)]
     L.ss_result_subdomain_grid_f64.argtypes = [vp, P(_Grid64), P(i32)]
     L.ss_result_levelset_box_f64.argtypes = [vp, P(C.c_int64), P(C.c_int64), vp]
-    if L.ss_abi_version() != 1:
+    if L.ss_abi_version() != 2:
         raise ImportError("libsplashsurf_hip.so ABI version mismatch")
     _lib = L
     return L

@@ -224,7 +224,7 @@ ss_status make_device_params(ss_context* ctx, const typename TypesOf<R>::params*
 
 ss_status ensure_events(ss_context* ctx) {
     if (ctx->ev_ok) return SS_OK;
-    for (int i = 0; i < 12; ++i) SS_HIP(ctx, hipEventCreate(&ctx->ev[i]));
+    for (int i = 0; i < 14; ++i) SS_HIP(ctx, hipEventCreate(&ctx->ev[i]));
     ctx->ev_ok = true;
     return SS_OK;
 }
@@ -807,7 +807,7 @@ ss_status phase_finish(ss_context* ctx, ss_result* res) {
     SS_HIP(ctx, ctx->splat_counts.reserve(((size_t)n_active + 1) * 4));
     ss_launch_splat_small(P, res->posvol.as<ss_real4<R>>(), res->perm.as<uint32_t>(), ctx->cell_start.as<uint32_t>(), res->active_list.as<uint32_t>(), n_active,
                           ctx->splat_tiles.as<ss_real4<R>>(), ctx->splat_counts.as<uint32_t>(), res->G.as<R>(), res->blk_minmax.as<ss_real2<R>>(),
-                          ctx->counter.as<unsigned long long>(), ov_flag, fast, st);
+                          ctx->counter.as<unsigned long long>(), ov_flag, fast, ctx->ev[12], ctx->ev[13], st);
     if (n_active) {
         s = exclusive_scan_u32<uint32_t>(ctx, ov_flag, ov_rank, (size_t)n_active + 1);
         if (s != SS_OK) return s;
@@ -850,6 +850,8 @@ ss_status phase_finish(ss_context* ctx, ss_result* res) {
     SS_HIP(ctx, hipMemcpyAsync(&totals[0], res->vbase.as<uint32_t>() + n_mc, 4, hipMemcpyDeviceToHost, st));
     SS_HIP(ctx, hipMemcpyAsync(&totals[1], res->tbase.as<uint32_t>() + n_mc, 4, hipMemcpyDeviceToHost, st));
     SS_HIP(ctx, hipMemcpyAsync(&cand, ctx->counter.p, 8, hipMemcpyDeviceToHost, st));
+    uint32_t n_large = 0;
+    if (n_active) SS_HIP(ctx, hipMemcpyAsync(&n_large, ctx->splat_overflow.as<uint32_t>() + ((size_t)n_active + 1) + n_active, 4, hipMemcpyDeviceToHost, st));
     SS_HIP(ctx, hipStreamSynchronize(st));
     const uint64_t nv = totals[0], nt = totals[1];
     if (nt * 3 >= (1ull << 32)) return fail(ctx, SS_ERR_UNSUPPORTED, "more than 2^32/3 triangles in one call are not supported by this build");
@@ -878,6 +880,8 @@ ss_status phase_finish(ss_context* ctx, ss_result* res) {
     S.ms_density = ev_ms(ctx, 3, 4) + ev_ms(ctx, 10, 11);
     S.ms_levelset_prepare = ev_ms(ctx, 11, 5);
     S.ms_levelset = ev_ms(ctx, 5, 6);
+    S.ms_levelset_gather = ev_ms(ctx, 5, 12);
+    S.ms_levelset_accumulate = ev_ms(ctx, 12, 13);
     S.ms_marching_cubes = ev_ms(ctx, 6, 7) + ev_ms(ctx, 8, 9);
     S.ms_stitching = ev_ms(ctx, 7, 8);
     S.n_particles = n;
@@ -885,6 +889,7 @@ ss_status phase_finish(ss_context* ctx, ss_result* res) {
     S.n_triangles = nt;
     S.n_active_blocks = n_active;
     S.n_block_candidates = cand;
+    S.n_large_tile_blocks = n_large;
     S.fast_div_verified = ctx->fastdiv_ok ? 1 : 0;
     S.levelset_kernel_launches = n_active ? 1 : 0;
     size_t held = 0;
@@ -1227,7 +1232,7 @@ void ss_context_destroy(ss_context* c) {
         b->release();
     for (DevBuf& b : c->post_pool) b.release();
     if (c->ev_ok)
-        for (int i = 0; i < 12; ++i) (void)hipEventDestroy(c->ev[i]);
+        for (int i = 0; i < 14; ++i) (void)hipEventDestroy(c->ev[i]);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
 }

@@ -1167,20 +1167,28 @@ __global__ __launch_bounds__(512) void k_splat_large(SSDevT<R> P, const ss_real4
 template <class R>
 void ss_launch_splat_small(const SSDevT<R>& P, const ss_real4<R>* posvol, const uint32_t* perm, const uint32_t* cell_start, const uint32_t* active_list,
                            uint32_t n_active, ss_real4<R>* tiles, uint32_t* counts, R* G, ss_real2<R>* blk_minmax, unsigned long long* cand_counter,
-                           uint32_t* overflow_flag, bool fast_div, hipStream_t st) {
-    if (!n_active) return;
-    const uint32_t n_groups = (n_active + 3u) / 4u;
-    hipLaunchKernelGGL(k_splat_gather<R>, dim3(((n_groups + 7u) / 8u) * 8u), dim3(256), 0, st, P, posvol, perm, cell_start, active_list, n_active, tiles, counts,
-                       overflow_flag);
-    const dim3 grid(((n_active + 7u) / 8u) * 8u);
-    if constexpr (sizeof(R) == 4) {
-        if (fast_div) {
-            hipLaunchKernelGGL((k_splat_accumulate<R, true>), grid, dim3(512), 0, st, P, tiles, counts, overflow_flag, active_list, n_active, G, blk_minmax,
-                               cand_counter);
-            return;
-        }
+                           uint32_t* overflow_flag, bool fast_div, hipEvent_t ev_after_gather, hipEvent_t ev_after_accumulate, hipStream_t st) {
+    if (n_active) {
+        const uint32_t n_groups = (n_active + 3u) / 4u;
+        hipLaunchKernelGGL(k_splat_gather<R>, dim3(((n_groups + 7u) / 8u) * 8u), dim3(256), 0, st, P, posvol, perm, cell_start, active_list, n_active, tiles, counts,
+                           overflow_flag);
     }
-    hipLaunchKernelGGL((k_splat_accumulate<R, false>), grid, dim3(512), 0, st, P, tiles, counts, overflow_flag, active_list, n_active, G, blk_minmax, cand_counter);
+    (void)hipEventRecord(ev_after_gather, st);
+    if (n_active) {
+        const dim3 grid(((n_active + 7u) / 8u) * 8u);
+        bool launched = false;
+        if constexpr (sizeof(R) == 4) {
+            if (fast_div) {
+                hipLaunchKernelGGL((k_splat_accumulate<R, true>), grid, dim3(512), 0, st, P, tiles, counts, overflow_flag, active_list, n_active, G, blk_minmax,
+                                   cand_counter);
+                launched = true;
+            }
+        }
+        if (!launched)
+            hipLaunchKernelGGL((k_splat_accumulate<R, false>), grid, dim3(512), 0, st, P, tiles, counts, overflow_flag, active_list, n_active, G, blk_minmax,
+                               cand_counter);
+    }
+    (void)hipEventRecord(ev_after_accumulate, st);
 }
 size_t ss_splat_tile_entries() { return SS_WTILE; }
 
@@ -1495,9 +1503,9 @@ template void ss_launch_mark_blocks<float>(const SSDevT<float>& P, const uint32_
 template void ss_launch_mark_blocks<double>(const SSDevT<double>& P, const uint32_t* cell_start, uint32_t ncells, uint32_t* block_flag, hipStream_t st);
 template void ss_launch_mark_mc_blocks<float>(const SSDevT<float>& P, const uint32_t* block_slot, const ss_real2<float>* blk_minmax, uint32_t nblocks, uint32_t* mc_flag, hipStream_t st);
 template void ss_launch_mark_mc_blocks<double>(const SSDevT<double>& P, const uint32_t* block_slot, const ss_real2<double>* blk_minmax, uint32_t nblocks, uint32_t* mc_flag, hipStream_t st);
-template void ss_launch_splat_small<float>(const SSDevT<float>& P, const ss_real4<float>* posvol, const uint32_t* perm, const uint32_t* cell_start, const uint32_t* active_list, uint32_t n_active, ss_real4<float>* tiles, uint32_t* counts, float* G, ss_real2<float>* blk_minmax, unsigned long long* cand_counter, uint32_t* overflow_flag, bool fast_div, hipStream_t st);
+template void ss_launch_splat_small<float>(const SSDevT<float>& P, const ss_real4<float>* posvol, const uint32_t* perm, const uint32_t* cell_start, const uint32_t* active_list, uint32_t n_active, ss_real4<float>* tiles, uint32_t* counts, float* G, ss_real2<float>* blk_minmax, unsigned long long* cand_counter, uint32_t* overflow_flag, bool fast_div, hipEvent_t ev_after_gather, hipEvent_t ev_after_accumulate, hipStream_t st);
 template void ss_launch_splat_large<float>(const SSDevT<float>& P, const ss_real4<float>* posvol, const uint32_t* perm, const uint32_t* cell_start, const uint32_t* active_list, uint32_t n_active, float* G, ss_real2<float>* blk_minmax, unsigned long long* cand_counter, const uint32_t* overflow_list, const uint32_t* overflow_count, bool fast_div, hipStream_t st);
-template void ss_launch_splat_small<double>(const SSDevT<double>& P, const ss_real4<double>* posvol, const uint32_t* perm, const uint32_t* cell_start, const uint32_t* active_list, uint32_t n_active, ss_real4<double>* tiles, uint32_t* counts, double* G, ss_real2<double>* blk_minmax, unsigned long long* cand_counter, uint32_t* overflow_flag, bool fast_div, hipStream_t st);
+template void ss_launch_splat_small<double>(const SSDevT<double>& P, const ss_real4<double>* posvol, const uint32_t* perm, const uint32_t* cell_start, const uint32_t* active_list, uint32_t n_active, ss_real4<double>* tiles, uint32_t* counts, double* G, ss_real2<double>* blk_minmax, unsigned long long* cand_counter, uint32_t* overflow_flag, bool fast_div, hipEvent_t ev_after_gather, hipEvent_t ev_after_accumulate, hipStream_t st);
 template void ss_launch_splat_large<double>(const SSDevT<double>& P, const ss_real4<double>* posvol, const uint32_t* perm, const uint32_t* cell_start, const uint32_t* active_list, uint32_t n_active, double* G, ss_real2<double>* blk_minmax, unsigned long long* cand_counter, const uint32_t* overflow_list, const uint32_t* overflow_count, bool fast_div, hipStream_t st);
 template void ss_launch_mc_count<float>(const SSDevT<float>& P, const float* G, const uint32_t* block_slot, const uint32_t* mc_list, uint32_t n_mc, unsigned long long* masks, uint32_t* vcount, uint32_t* tcount, hipStream_t st);
 template void ss_launch_mc_count<double>(const SSDevT<double>& P, const double* G, const uint32_t* block_slot, const uint32_t* mc_list, uint32_t n_mc, unsigned long long* masks, uint32_t* vcount, uint32_t* tcount, hipStream_t st);
