@@ -1,0 +1,105 @@
+"""CLI shim with the reference binary's `reconstruct` flags (splashsurf/src/reconstruct.rs:36-380, 604-965)."""
+import os
+
+import numpy as np
+import pytest
+
+from splashsurf_amd import cli
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _parse(*argv):
+    return cli.build_parser().parse_args(["reconstruct", *argv])
+
+
+def test_flag_spelling_and_defaults_follow_the_reference():
+    a = _parse("in.vtk", "-r=0.025", "-l", "2.0", "-c=0.5")
+    assert (a.particle_radius, a.smoothing_length, a.cube_size) == (0.025, 2.0, 0.5)
+    # defaults: reconstruct.rs:60 (rest density), :69 (threshold), :160 (subdomain cubes), :255 (normalization)
+    assert a.rest_density == 1000.0 and a.surface_threshold == 0.6 and a.subdomain_cubes == 64
+    assert a.mesh_smoothing_weights_normalization == 13.0
+    assert a.subdomain_grid is True and a.subdomain_grid_auto_disable is True and a.mt_particles is True and a.simd is True
+    assert a.double_precision is False and a.normals is False and a.mesh_smoothing_weights is False and a.mesh_cleanup is None
+    b = _parse("in.vtk", "-r", "0.01", "-l", "2", "-c", "1", "-d=on", "--normals=ON", "--sph-normals=on", "--mesh-smoothing-iters=25",
+               "--mesh-smoothing-weights=on", "--mesh-cleanup=off", "--particle-aabb-min", "-1", "0", "0", "--particle-aabb-max", "1", "1", "1",
+               "-a", "velocity", "--interpolate_attribute", "density", "-n", "4", "--mt-files=on", "-t", "0.55")
+    assert b.double_precision and b.normals and b.sph_normals and b.mesh_smoothing_iters == 25 and b.mesh_smoothing_weights
+    assert b.particle_aabb_min == [-1.0, 0.0, 0.0] and b.interpolate_attributes == ["velocity", "density"] and b.surface_threshold == 0.55
+    with pytest.raises(SystemExit):
+        _parse("in.vtk", "-r", "0.01", "-l", "2", "-c", "1", "--normals=maybe")
+
+
+def test_parameter_conversion_mirrors_the_binary():
+    a = _parse("in.vtk", "-r", "0.01", "-l", "2", "-c", "1", "--subdomain-grid-auto-disable=off", "--mesh-smoothing-weights=on")
+    kw = cli.pipeline_kwargs(a)
+    # reconstruct.rs:633-636: the binary hands `!flag` to GridDecompositionParameters::auto_disable
+    assert kw["subdomain_grid_auto_disable"] is True
+    assert cli.pipeline_kwargs(_parse("in.vtk", "-r", "0.01", "-l", "2", "-c", "1"))["subdomain_grid_auto_disable"] is False
+    assert kw["mesh_smoothing_weights"] is True and kw["compute_normals"] is False and kw["mesh_smoothing_iters"] is None
+    # radius-relative lengths go through unchanged (the pipeline scales them as reconstruct.rs:627-628 does)
+    assert (kw["particle_radius"], kw["smoothing_length"], kw["cube_size"]) == (0.01, 2.0, 1.0)
+
+
+def test_unprovided_stages_fail_loudly():
+    base = ["in.vtk", "-r", "0.01", "-l", "2", "-c", "1"]
+    for extra in (["--mesh-cleanup=on"], ["--decimate-barnacles=on"], ["--generate-quads=on"], ["--check-mesh=on"], ["--check-mesh-closed=on"],
+                  ["--mesh-cleanup-snap-dist", "0.1"]):
+        with pytest.raises(cli.CliError):
+            cli.pipeline_kwargs(_parse(*base, *extra))
+    # the reference switches cleanup on implicitly with smoothing (reconstruct.rs:201-214): an explicit off is required here
+    with pytest.raises(cli.CliError):
+        cli.pipeline_kwargs(_parse(*base, "--mesh-smoothing-iters=5"))
+    cli.pipeline_kwargs(_parse(*base, "--mesh-smoothing-iters=5", "--mesh-cleanup=off"))
+    cli.pipeline_kwargs(_parse(*base, "--mesh-smoothing-iters=0"))
+    with pytest.raises(cli.CliError):
+        cli.pipeline_kwargs(_parse(*base, "--mesh-aabb-min", "1", "0", "0", "--mesh-aabb-max", "0", "1", "1"))
+
+
+def test_output_names_and_sequences(tmp_path):
+    d = tmp_path / "in"
+    d.mkdir()
+    for i in (1, 2, 10, 11):
+        (d / ("frame_%d.xyz" % i)).write_bytes(b"")
+    (d / "frame_x.xyz").write_bytes(b"")
+    (d / "single.xyz").write_bytes(b"")
+    base = ["-r", "0.01", "-l", "2", "-c", "1"]
+    # single file: "<stem>_surface.vtk" in the working directory unless --output-dir is given (reconstruct.rs:930-945)
+    assert cli.collect_paths(_parse(str(d / "single.xyz"), *base)) == [(str(d / "single.xyz"), "single_surface.vtk")]
+    out = tmp_path / "o" / "deep"
+    pairs = cli.collect_paths(_parse(str(d / "single.xyz"), *base, "--output-dir", str(out), "-o", "m.ply"))
+    assert pairs == [(str(d / "single.xyz"), str(out / "m.ply"))] and out.is_dir()
+    # sequences: natural order, index range inclusive, default pattern "<stem with surface_{}>.vtk" (reconstruct.rs:903-927, 783-842)
+    seq = cli.collect_paths(_parse(str(d / "frame_{}.xyz"), *base, "-s", "2", "-e=10", "--output-dir", str(out)))
+    assert seq == [(str(d / "frame_2.xyz"), str(out / "frame_surface_2.vtk")), (str(d / "frame_10.xyz"), str(out / "frame_surface_10.vtk"))]
+    allf = cli.collect_paths(_parse(str(d / "frame_{}.xyz"), *base, "-o", str(out / "s{}.obj")))
+    assert [os.path.basename(b) for _, b in allf] == ["s1.obj", "s2.obj", "s10.obj", "s11.obj"]
+    with pytest.raises(cli.CliError):
+        cli.collect_paths(_parse(str(d / "frame_{}.xyz"), *base, "-o", "fixed.vtk"))
+    with pytest.raises(cli.CliError):
+        cli.collect_paths(_parse(str(d / "frame_{}.xyz"), *base, "-s", "5", "-e", "2"))
+    with pytest.raises(cli.CliError):
+        cli.collect_paths(_parse(str(d / "missing.xyz"), *base))
+    with pytest.raises(cli.CliError):
+        cli.collect_paths(_parse(str(tmp_path / "nodir" / "a.xyz"), *base))
+
+
+@pytest.mark.gpu
+def test_cli_end_to_end_matches_the_library_call(tmp_path):
+    import splashsurf_amd as S
+    from splashsurf_amd import io
+    p = np.load(os.path.join(HERE, "data", "double_dam_break_frame_26_4732_particles.npy")).astype(np.float32)
+    src = tmp_path / "dam_7.xyz"
+    io.particles_to_file(p, str(src))
+    rc = cli.main(["reconstruct", str(tmp_path / "dam_{}.xyz"), "-r=0.025", "-l=2.0", "-c=1.1", "--output-dir", str(tmp_path / "out"),
+                   "--normals=on", "--mesh-smoothing-iters=3", "--mesh-smoothing-weights=on", "--mesh-cleanup=off", "--output-raw-mesh=on"])
+    assert rc == 0
+    raw = io.mesh_from_file(str(tmp_path / "out" / "raw_dam_surface_7.vtk"))
+    out = io.mesh_from_file(str(tmp_path / "out" / "dam_surface_7.vtk"))
+    rec = S.reconstruct_surface(p, particle_radius=0.025, smoothing_length=2.0, cube_size=1.1, subdomain_grid_auto_disable=False)  # the binary's default (see the inversion above)
+    assert np.array_equal(raw.vertices, rec.mesh.vertices) and np.array_equal(raw.triangles, rec.mesh.triangles)
+    assert raw.vertices.shape == (33026, 3) and raw.triangles.shape == (66220, 3)
+    assert out.vertices.shape == raw.vertices.shape and "normals" in out.point_attributes
+    assert not np.array_equal(out.vertices, raw.vertices)  # smoothed
+    # error path: exit code 1, nothing written
+    assert cli.main(["reconstruct", str(src), "-r=0.025", "-l=2.0", "-c=1.1", "--mesh-cleanup=on"]) == 1
