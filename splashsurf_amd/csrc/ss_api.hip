@@ -623,6 +623,7 @@ ss_status phase_begin(ss_context* ctx, const R* xyz, uint64_t n_in, const typena
     // ---- K1: bin + sort (decomposition) ----
     SS_HIP(ctx, res->rho.reserve((size_t)n * sizeof(R) + 16));
     SS_HIP(ctx, res->posvol.reserve((size_t)n * sizeof(ss_real4<R>) + 32));
+    SS_HIP(ctx, res->posvol_by_index.reserve((size_t)n * sizeof(ss_real4<R>) + 32));
     SS_HIP(ctx, res->perm.reserve((size_t)n * 4 + 16));
     SS_HIP(ctx, ctx->cell_count.reserve((ncells + 1) * 4));
     SS_HIP(ctx, ctx->cell_start.reserve((ncells + 1) * 4));
@@ -752,7 +753,7 @@ ss_status phase_finish(ss_context* ctx, ss_result* res) {
     const size_t ncells = (size_t)P.kdim[0] * P.kdim[1] * P.kdim[2];
     const size_t nblocks = (size_t)P.nb[0] * P.nb[1] * P.nb[2];
     SS_HIP(ctx, hipEventRecord(ctx->ev[10], st));
-    ss_launch_make_posvol(P, ctx->pos_sorted.as<ss_real4<R>>(), res->perm.as<uint32_t>(), res->rho.as<R>(), res->posvol.as<ss_real4<R>>(), st);
+    ss_launch_make_posvol(P, ctx->pos_sorted.as<ss_real4<R>>(), res->perm.as<uint32_t>(), res->rho.as<R>(), res->posvol.as<ss_real4<R>>(), res->posvol_by_index.as<ss_real4<R>>(), st);
     SS_HIP(ctx, hipEventRecord(ctx->ev[11], st));
 
     // ---- K3 prepare: active level-set blocks ----
@@ -812,7 +813,7 @@ ss_status phase_finish(ss_context* ctx, ss_result* res) {
         s = exclusive_scan_u32<uint32_t>(ctx, ov_flag, ov_rank, (size_t)n_active + 1);
         if (s != SS_OK) return s;
         ss_launch_compact_blocks(ov_flag, ov_rank, n_active, ov_list, ov_slot, st);
-        ss_launch_splat_large(P, res->posvol.as<ss_real4<R>>(), res->perm.as<uint32_t>(), ctx->cell_start.as<uint32_t>(), res->active_list.as<uint32_t>(), n_active,
+        ss_launch_splat_large(P, res->posvol.as<ss_real4<R>>(), res->posvol_by_index.as<ss_real4<R>>(), res->perm.as<uint32_t>(), ctx->cell_start.as<uint32_t>(), res->active_list.as<uint32_t>(), n_active,
                               res->G.as<R>(), res->blk_minmax.as<ss_real2<R>>(), ctx->counter.as<unsigned long long>(), ov_list, ov_rank + n_active, fast, st);
     }
     SS_HIP(ctx, hipEventRecord(ctx->ev[6], st));
@@ -896,7 +897,7 @@ ss_status phase_finish(ss_context* ctx, ss_result* res) {
     for (const DevBuf* b : {&ctx->xyz_in, &ctx->xyz_filt, &ctx->flags32, &ctx->offsets, &ctx->keys_a, &ctx->keys_b, &ctx->vals_a, &ctx->cell_count,
                             &ctx->cell_start, &ctx->pos_sorted, &ctx->temp, &ctx->block_flag, &ctx->block_rank, &ctx->mc_flag, &ctx->mc_rank,
                             &ctx->vcount, &ctx->tcount, &ctx->member_count, &ctx->copy_offset, &ctx->ckeys_a, &ctx->ckeys_b, &ctx->cvals_a, &ctx->cidx,
-                            &ctx->cpos, &ctx->cell_count2, &ctx->cell_start2, &res->rho, &res->posvol, &res->perm, &res->inside8, &res->G, &res->block_slot,
+                            &ctx->cpos, &ctx->cell_count2, &ctx->cell_start2, &res->rho, &res->posvol, &res->posvol_by_index, &res->perm, &res->inside8, &res->G, &res->block_slot,
                             &res->active_list, &res->mc_list, &res->mc_slot, &res->masks, &res->vbase, &res->tbase, &res->vertices, &res->vkeys,
                             &res->tri32})
         held += b->cap;
@@ -1072,7 +1073,7 @@ ss_status download(ss_result* r, const DevBuf& d, HostBuf& h, bool& flag, size_t
 }
 
 void result_release(ss_result* r) {
-    for (DevBuf* b : {&r->rho, &r->posvol, &r->perm, &r->inside8, &r->G, &r->blk_minmax, &r->block_slot, &r->active_list, &r->mc_list, &r->mc_slot, &r->masks,
+    for (DevBuf* b : {&r->rho, &r->posvol, &r->posvol_by_index, &r->perm, &r->inside8, &r->G, &r->blk_minmax, &r->block_slot, &r->active_list, &r->mc_list, &r->mc_slot, &r->masks,
                       &r->vbase, &r->tbase, &r->vertices, &r->vkeys, &r->tri32, &r->tri64})
         b->release();
     for (HostBuf* b : {&r->h_vertices, &r->h_tri64, &r->h_tri32, &r->h_rho, &r->h_vkeys, &r->h_inside, &r->h_nb_ptr, &r->h_nb_idx}) b->release();

@@ -17,9 +17,8 @@
 #define SS_BLOCK_POINTS 512
 #define SS_MAX_ROWS 256         // (x,y) search-cell rows per batch while gathering a tile
 
-// candidate particles staged in LDS per pass of the splat kernel (16 B resp. 32 B payload each)
-template <class R> struct SSTileCap { static constexpr int value = 2048; };
-template <> struct SSTileCap<double> { static constexpr int value = 1024; };
+// candidate particles (4-byte index keys) held in LDS per pass of the large-tile splat kernel
+template <class R> struct SSTileCap { static constexpr int value = 8192; };
 
 template <class R> struct SSVec;
 template <> struct SSVec<float> { using v2 = float2; using v4 = float4; };

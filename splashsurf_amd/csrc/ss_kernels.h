@@ -21,7 +21,7 @@ void ss_launch_emit_copies(const SSDevT<R>& P, const R* xyz, const uint32_t* cop
 template <class R>
 void ss_launch_density_sub(const SSDevT<R>& P, uint32_t n_copies, const ss_real4<R>* cpos, const uint32_t* cidx, const uint32_t* ckey, const uint32_t* cell_start, const uint32_t* occ_sub, R* rho, int mode, uint32_t* nb_count, const unsigned long long* nb_ptr, uint32_t* nb_idx, hipStream_t st);
 template <class R>
-void ss_launch_make_posvol(const SSDevT<R>& P, const ss_real4<R>* pos_sorted, const uint32_t* perm, const R* rho, ss_real4<R>* posvol, hipStream_t st);
+void ss_launch_make_posvol(const SSDevT<R>& P, const ss_real4<R>* pos_sorted, const uint32_t* perm, const R* rho, ss_real4<R>* posvol, ss_real4<R>* posvol_by_index, hipStream_t st);
 template <class R>
 void ss_launch_mark_blocks(const SSDevT<R>& P, const uint32_t* cell_start, uint32_t ncells, uint32_t* block_flag, hipStream_t st);
 template <class R>
@@ -32,7 +32,7 @@ template <class R>
 void ss_launch_splat_small(const SSDevT<R>& P, const ss_real4<R>* posvol, const uint32_t* perm, const uint32_t* cell_start, const uint32_t* active_list, uint32_t n_active, ss_real4<R>* tiles, uint32_t* counts, R* G, ss_real2<R>* blk_minmax, unsigned long long* cand_counter, uint32_t* overflow_flag, bool fast_div, hipEvent_t ev_after_gather, hipEvent_t ev_after_accumulate, hipStream_t st);
 size_t ss_splat_tile_entries();
 template <class R>
-void ss_launch_splat_large(const SSDevT<R>& P, const ss_real4<R>* posvol, const uint32_t* perm, const uint32_t* cell_start, const uint32_t* active_list, uint32_t n_active, R* G, ss_real2<R>* blk_minmax, unsigned long long* cand_counter, const uint32_t* overflow_list, const uint32_t* overflow_count, bool fast_div, hipStream_t st);
+void ss_launch_splat_large(const SSDevT<R>& P, const ss_real4<R>* posvol, const ss_real4<R>* posvol_by_index, const uint32_t* perm, const uint32_t* cell_start, const uint32_t* active_list, uint32_t n_active, R* G, ss_real2<R>* blk_minmax, unsigned long long* cand_counter, const uint32_t* overflow_list, const uint32_t* overflow_count, bool fast_div, hipStream_t st);
 template <class R>
 void ss_launch_mc_count(const SSDevT<R>& P, const R* G, const uint32_t* block_slot, const uint32_t* mc_list, uint32_t n_mc, unsigned long long* masks, uint32_t* vcount, uint32_t* tcount, hipStream_t st);
 template <class R>

@@ -390,11 +390,14 @@ __global__ __launch_bounds__(256) void k_density_sub(SSDevT<R> P, uint32_t n_cop
 // (x, y, z, V = m / rho) in global-cell order for the splat (v_i of dense_subdomains.rs:832)
 template <class R>
 __global__ __launch_bounds__(256) void k_make_posvol(SSDevT<R> P, const ss_real4<R>* __restrict__ pos_sorted, const uint32_t* __restrict__ perm,
-                                                     const R* __restrict__ rho, ss_real4<R>* __restrict__ posvol) {
+                                                     const R* __restrict__ rho, ss_real4<R>* __restrict__ posvol, ss_real4<R>* __restrict__ posvol_by_index) {
     uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= P.n) return;
     const ss_real4<R> a = pos_sorted[p];
-    posvol[p] = ss_make4(a.x, a.y, a.z, P.mass / rho[perm[p]]);
+    const uint32_t i = perm[p];
+    const ss_real4<R> v = ss_make4(a.x, a.y, a.z, P.mass / rho[i]);
+    posvol[p] = v;
+    posvol_by_index[i] = v;  // the large-tile path sorts particle indices only and fetches the payload through this copy
 }
 
 template <class R>
@@ -426,9 +429,10 @@ void ss_launch_density_sub(const SSDevT<R>& P, uint32_t n_copies, const ss_real4
         hipLaunchKernelGGL((k_density_sub<R, 2>), g, b, 0, st, P, n_copies, cpos, cidx, ckey, cell_start, occ_sub, rho, nb_count, nb_ptr, nb_idx);
 }
 template <class R>
-void ss_launch_make_posvol(const SSDevT<R>& P, const ss_real4<R>* pos_sorted, const uint32_t* perm, const R* rho, ss_real4<R>* posvol, hipStream_t st) {
+void ss_launch_make_posvol(const SSDevT<R>& P, const ss_real4<R>* pos_sorted, const uint32_t* perm, const R* rho, ss_real4<R>* posvol,
+                           ss_real4<R>* posvol_by_index, hipStream_t st) {
     if (!P.n) return;
-    hipLaunchKernelGGL(k_make_posvol<R>, dim3((P.n + 255) / 256), dim3(256), 0, st, P, pos_sorted, perm, rho, posvol);
+    hipLaunchKernelGGL(k_make_posvol<R>, dim3((P.n + 255) / 256), dim3(256), 0, st, P, pos_sorted, perm, rho, posvol, posvol_by_index);
 }
 
 // =====================================================================================================
@@ -637,11 +641,11 @@ void ss_launch_verify_fast_div(float h, float rh, uint32_t* bad, hipStream_t st)
     hipLaunchKernelGGL(k_verify_fast_div, dim3((1u << 23) / 256), dim3(256), 0, st, h, rh, bad);
 }
 
+#define SS_PAY_CHUNK 512
 template <class R, int CAP>
 struct SplatShared {
-    ss_real4<R> pay[CAP];
-    uint32_t idx[CAP];
-    uint32_t src[CAP];
+    ss_real4<R> pay[SS_PAY_CHUNK];  // payload of 512 consecutive entries of the ordered tile
+    uint32_t idx[CAP];               // original particle indices of the tile (the sort keys)
     uint32_t row_start[SS_MAX_ROWS];
     uint32_t row_prefix[SS_MAX_ROWS + 1];
     uint32_t wave_tot[8];
@@ -769,7 +773,7 @@ __device__ __forceinline__ R splat_accumulate_wave(const SSDevT<R>& P, const ss_
 // ascending index ranges.
 template <class R, bool FASTDIV, int CAP>
 __device__ __forceinline__ void splat_block(SplatShared<R, CAP>& s, const SSDevT<R>& P, const ss_real4<R>* __restrict__ posvol,
-                                            const uint32_t* __restrict__ perm, const uint32_t* __restrict__ cell_start, uint32_t b, uint32_t logical,
+                                            const ss_real4<R>* __restrict__ posvol_by_index, const uint32_t* __restrict__ perm, const uint32_t* __restrict__ cell_start, uint32_t b, uint32_t logical,
                                             R* __restrict__ G, ss_real2<R>* __restrict__ blk_minmax, unsigned long long* __restrict__ cand_counter) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int bz = (int)(b % (uint32_t)P.nb[2]);
@@ -819,13 +823,10 @@ __device__ __forceinline__ void splat_block(SplatShared<R, CAP>& s, const SSDevT
         long long T = idx_max;
         if (tid == 0) s.count = 0;
         __syncthreads();
-        splat_for_each_candidate<R>(s, P, posvol, perm, cell_start, klo, khi, blo, bhi, tid, [&](uint32_t src, uint32_t idx, const ss_real4<R>&) {
+        splat_for_each_candidate<R>(s, P, posvol, perm, cell_start, klo, khi, blo, bhi, tid, [&](uint32_t, uint32_t idx, const ss_real4<R>&) {
             if ((long long)idx > last) {
                 uint32_t pos = atomicAdd(&s.count, 1u);
-                if (pos < CAP) {
-                    s.idx[pos] = idx;
-                    s.src[pos] = src;  // payload fetched after the sort (cheaper than permuting 2048 entries inside LDS: measured)
-                }
+                if (pos < CAP) s.idx[pos] = idx;  // keys only; the payload is fetched after the sort through posvol_by_index
             }
         });
         uint32_t total = s.count;
@@ -853,13 +854,10 @@ __device__ __forceinline__ void splat_block(SplatShared<R, CAP>& s, const SSDevT
             __syncthreads();
             if (tid == 0) s.count = 0;
             __syncthreads();
-            splat_for_each_candidate<R>(s, P, posvol, perm, cell_start, klo, khi, blo, bhi, tid, [&](uint32_t src, uint32_t idx, const ss_real4<R>&) {
+            splat_for_each_candidate<R>(s, P, posvol, perm, cell_start, klo, khi, blo, bhi, tid, [&](uint32_t, uint32_t idx, const ss_real4<R>&) {
                 if ((long long)idx > last && (long long)idx <= T) {
                     uint32_t pos = atomicAdd(&s.count, 1u);
-                    if (pos < CAP) {
-                        s.idx[pos] = idx;
-                        s.src[pos] = src;
-                    }
+                    if (pos < CAP) s.idx[pos] = idx;
                 }
             });
             total = s.count;
@@ -867,22 +865,26 @@ __device__ __forceinline__ void splat_block(SplatShared<R, CAP>& s, const SSDevT
         const int n_tile = (int)min(total, (uint32_t)CAP);
         if (tid == 0) atomicAdd(cand_counter, (unsigned long long)n_tile);
 
-        // ---- order the tile by original particle index: sort (index, sorted position), fetch the payload in that order ----
-        if (n_tile <= 512) {
-            uint32_t my_idx = 0, my_src = 0, rank = 0;
+        // ---- order the tile by original particle index (keys only), then stream the payload in that order ----
+        // Phase A of the accumulation: 64 tile entries at a time are tested against the wave's 4^3 sub-block (distance to
+        // box <= reach) with one ballot.  Phase B: the surviving entries are walked in order (= ascending particle index)
+        // and every lane evaluates G += V * W(|x - p|) for its point iff d^2 < 1.01 h^2.
+        // Measured issue costs on gfx950 (tools/ubench/valu_rates.hip): f32 add/mul ~2.3 cycles per wave64
+        // instruction, fma ~3.5, cmp/cndmask/readlane ~3.7, SGPR-source operands ~3.9, v_pk_* ~6.2,
+        // v_sqrt/v_rcp ~7.4 -- hence LDS broadcast reads (not v_readlane) and no packed math in this loop.
+        if (n_tile <= SS_PAY_CHUNK) {
             if (tid < n_tile) {
-                my_idx = s.idx[tid];
-                my_src = s.src[tid];
+                const uint32_t my_idx = s.idx[tid];
+                uint32_t rank = 0;
                 for (int k = 0; k < n_tile; ++k) rank += (s.idx[k] < my_idx) ? 1u : 0u;
-                s.pay[rank] = posvol[my_src];
+                s.pay[rank] = posvol_by_index[my_idx];
             }
+            __syncthreads();
+            if (wave_valid) acc = splat_accumulate_wave<R, FASTDIV>(P, s.pay, n_tile, lane, px, py, pz, slo, shi, wave_r2, acc);
         } else {
             int m = 1024;
             while (m < n_tile) m <<= 1;
-            for (int e = n_tile + tid; e < m; e += 512) {
-                s.idx[e] = 0xFFFFFFFFu;
-                s.src[e] = 0;
-            }
+            for (int e = n_tile + tid; e < m; e += 512) s.idx[e] = 0xFFFFFFFFu;
             __syncthreads();
             for (int k = 2; k <= m; k <<= 1)
                 for (int j = k >> 1; j > 0; j >>= 1) {
@@ -894,25 +896,18 @@ __device__ __forceinline__ void splat_block(SplatShared<R, CAP>& s, const SSDevT
                         if ((a > c) == up) {
                             s.idx[i] = c;
                             s.idx[l] = a;
-                            const uint32_t sa = s.src[i];
-                            s.src[i] = s.src[l];
-                            s.src[l] = sa;
                         }
                     }
                     __syncthreads();
                 }
-            for (int e = tid; e < n_tile; e += 512) s.pay[e] = posvol[s.src[e]];
+            for (int c0 = 0; c0 < n_tile; c0 += SS_PAY_CHUNK) {
+                const int nc = min(SS_PAY_CHUNK, n_tile - c0);
+                if (tid < nc) s.pay[tid] = posvol_by_index[s.idx[c0 + tid]];
+                __syncthreads();
+                if (wave_valid) acc = splat_accumulate_wave<R, FASTDIV>(P, s.pay, nc, lane, px, py, pz, slo, shi, wave_r2, acc);
+                __syncthreads();
+            }
         }
-        __syncthreads();
-
-        // ---- accumulate ----
-        // Phase A: 64 tile entries at a time are tested against the wave's 4^3 sub-block (distance to box
-        // <= reach) with one ballot.  Phase B: the surviving entries are walked in order (= ascending
-        // particle index) and every lane evaluates G += V * W(|x - p|) for its point iff d^2 < 1.01 h^2.
-        // Measured issue costs on gfx950 (tools/ubench/valu_rates.hip): f32 add/mul ~2.3 cycles per wave64
-        // instruction, fma ~3.5, cmp/cndmask/readlane ~3.7, SGPR-source operands ~3.9, v_pk_* ~6.2,
-        // v_sqrt/v_rcp ~7.4 -- hence LDS broadcast reads (not v_readlane) and no packed math in this loop.
-        if (wave_valid) acc = splat_accumulate_wave<R, FASTDIV>(P, s.pay, n_tile, lane, px, py, pz, slo, shi, wave_r2, acc);
         if (T >= idx_max) break;
         last = T;
         __syncthreads();
@@ -1147,7 +1142,8 @@ __global__ __launch_bounds__(512) void k_splat_accumulate(SSDevT<R> P, const ss_
 // order (scan + k_compact_blocks), so it is spatially ordered like the active list; persistent workgroups walk it, each
 // XCD a contiguous range.
 template <class R, bool FASTDIV>
-__global__ __launch_bounds__(512) void k_splat_large(SSDevT<R> P, const ss_real4<R>* __restrict__ posvol, const uint32_t* __restrict__ perm,
+__global__ __launch_bounds__(512) void k_splat_large(SSDevT<R> P, const ss_real4<R>* __restrict__ posvol, const ss_real4<R>* __restrict__ posvol_by_index,
+                                                     const uint32_t* __restrict__ perm,
                                                      const uint32_t* __restrict__ cell_start, const uint32_t* __restrict__ active_list,
                                                      R* __restrict__ G, ss_real2<R>* __restrict__ blk_minmax, unsigned long long* __restrict__ cand_counter,
                                                      const uint32_t* __restrict__ overflow_list, const uint32_t* __restrict__ overflow_count) {
@@ -1158,7 +1154,7 @@ __global__ __launch_bounds__(512) void k_splat_large(SSDevT<R> P, const ss_real4
         const uint32_t it = xcd * per_xcd + j;
         if (it < n) {
             const uint32_t logical = overflow_list[it];
-            splat_block<R, FASTDIV, SSTileCap<R>::value>(s, P, posvol, perm, cell_start, active_list[logical], logical, G, blk_minmax, cand_counter);
+            splat_block<R, FASTDIV, SSTileCap<R>::value>(s, P, posvol, posvol_by_index, perm, cell_start, active_list[logical], logical, G, blk_minmax, cand_counter);
         }
         __syncthreads();
     }
@@ -1194,19 +1190,19 @@ size_t ss_splat_tile_entries() { return SS_WTILE; }
 
 // second launch: the queued over-dense blocks (overflow_count lives on the device; an empty queue costs one trivial launch)
 template <class R>
-void ss_launch_splat_large(const SSDevT<R>& P, const ss_real4<R>* posvol, const uint32_t* perm, const uint32_t* cell_start, const uint32_t* active_list,
-                           uint32_t n_active, R* G, ss_real2<R>* blk_minmax, unsigned long long* cand_counter, const uint32_t* overflow_list,
+void ss_launch_splat_large(const SSDevT<R>& P, const ss_real4<R>* posvol, const ss_real4<R>* posvol_by_index, const uint32_t* perm, const uint32_t* cell_start,
+                           const uint32_t* active_list, uint32_t n_active, R* G, ss_real2<R>* blk_minmax, unsigned long long* cand_counter, const uint32_t* overflow_list,
                            const uint32_t* overflow_count, bool fast_div, hipStream_t st) {
     if (!n_active) return;
     const dim3 grid(4096);  // persistent workgroups over the queue
     if constexpr (sizeof(R) == 4) {
         if (fast_div) {
-            hipLaunchKernelGGL((k_splat_large<R, true>), grid, dim3(512), 0, st, P, posvol, perm, cell_start, active_list, G, blk_minmax, cand_counter, overflow_list,
+            hipLaunchKernelGGL((k_splat_large<R, true>), grid, dim3(512), 0, st, P, posvol, posvol_by_index, perm, cell_start, active_list, G, blk_minmax, cand_counter, overflow_list,
                                overflow_count);
             return;
         }
     }
-    hipLaunchKernelGGL((k_splat_large<R, false>), grid, dim3(512), 0, st, P, posvol, perm, cell_start, active_list, G, blk_minmax, cand_counter, overflow_list,
+    hipLaunchKernelGGL((k_splat_large<R, false>), grid, dim3(512), 0, st, P, posvol, posvol_by_index, perm, cell_start, active_list, G, blk_minmax, cand_counter, overflow_list,
                        overflow_count);
 }
 
@@ -1497,16 +1493,16 @@ template void ss_launch_emit_copies<float>(const SSDevT<float>& P, const float* 
 template void ss_launch_emit_copies<double>(const SSDevT<double>& P, const double* xyz, const uint32_t* copy_offset, const uint32_t* occ_rank, uint32_t* keys, uint32_t* vals, uint32_t* cell_count, hipStream_t st);
 template void ss_launch_density_sub<float>(const SSDevT<float>& P, uint32_t n_copies, const ss_real4<float>* cpos, const uint32_t* cidx, const uint32_t* ckey, const uint32_t* cell_start, const uint32_t* occ_sub, float* rho, int mode, uint32_t* nb_count, const unsigned long long* nb_ptr, uint32_t* nb_idx, hipStream_t st);
 template void ss_launch_density_sub<double>(const SSDevT<double>& P, uint32_t n_copies, const ss_real4<double>* cpos, const uint32_t* cidx, const uint32_t* ckey, const uint32_t* cell_start, const uint32_t* occ_sub, double* rho, int mode, uint32_t* nb_count, const unsigned long long* nb_ptr, uint32_t* nb_idx, hipStream_t st);
-template void ss_launch_make_posvol<float>(const SSDevT<float>& P, const ss_real4<float>* pos_sorted, const uint32_t* perm, const float* rho, ss_real4<float>* posvol, hipStream_t st);
-template void ss_launch_make_posvol<double>(const SSDevT<double>& P, const ss_real4<double>* pos_sorted, const uint32_t* perm, const double* rho, ss_real4<double>* posvol, hipStream_t st);
+template void ss_launch_make_posvol<float>(const SSDevT<float>& P, const ss_real4<float>* pos_sorted, const uint32_t* perm, const float* rho, ss_real4<float>* posvol, ss_real4<float>* posvol_by_index, hipStream_t st);
+template void ss_launch_make_posvol<double>(const SSDevT<double>& P, const ss_real4<double>* pos_sorted, const uint32_t* perm, const double* rho, ss_real4<double>* posvol, ss_real4<double>* posvol_by_index, hipStream_t st);
 template void ss_launch_mark_blocks<float>(const SSDevT<float>& P, const uint32_t* cell_start, uint32_t ncells, uint32_t* block_flag, hipStream_t st);
 template void ss_launch_mark_blocks<double>(const SSDevT<double>& P, const uint32_t* cell_start, uint32_t ncells, uint32_t* block_flag, hipStream_t st);
 template void ss_launch_mark_mc_blocks<float>(const SSDevT<float>& P, const uint32_t* block_slot, const ss_real2<float>* blk_minmax, uint32_t nblocks, uint32_t* mc_flag, hipStream_t st);
 template void ss_launch_mark_mc_blocks<double>(const SSDevT<double>& P, const uint32_t* block_slot, const ss_real2<double>* blk_minmax, uint32_t nblocks, uint32_t* mc_flag, hipStream_t st);
 template void ss_launch_splat_small<float>(const SSDevT<float>& P, const ss_real4<float>* posvol, const uint32_t* perm, const uint32_t* cell_start, const uint32_t* active_list, uint32_t n_active, ss_real4<float>* tiles, uint32_t* counts, float* G, ss_real2<float>* blk_minmax, unsigned long long* cand_counter, uint32_t* overflow_flag, bool fast_div, hipEvent_t ev_after_gather, hipEvent_t ev_after_accumulate, hipStream_t st);
-template void ss_launch_splat_large<float>(const SSDevT<float>& P, const ss_real4<float>* posvol, const uint32_t* perm, const uint32_t* cell_start, const uint32_t* active_list, uint32_t n_active, float* G, ss_real2<float>* blk_minmax, unsigned long long* cand_counter, const uint32_t* overflow_list, const uint32_t* overflow_count, bool fast_div, hipStream_t st);
+template void ss_launch_splat_large<float>(const SSDevT<float>& P, const ss_real4<float>* posvol, const ss_real4<float>* posvol_by_index, const uint32_t* perm, const uint32_t* cell_start, const uint32_t* active_list, uint32_t n_active, float* G, ss_real2<float>* blk_minmax, unsigned long long* cand_counter, const uint32_t* overflow_list, const uint32_t* overflow_count, bool fast_div, hipStream_t st);
 template void ss_launch_splat_small<double>(const SSDevT<double>& P, const ss_real4<double>* posvol, const uint32_t* perm, const uint32_t* cell_start, const uint32_t* active_list, uint32_t n_active, ss_real4<double>* tiles, uint32_t* counts, double* G, ss_real2<double>* blk_minmax, unsigned long long* cand_counter, uint32_t* overflow_flag, bool fast_div, hipEvent_t ev_after_gather, hipEvent_t ev_after_accumulate, hipStream_t st);
-template void ss_launch_splat_large<double>(const SSDevT<double>& P, const ss_real4<double>* posvol, const uint32_t* perm, const uint32_t* cell_start, const uint32_t* active_list, uint32_t n_active, double* G, ss_real2<double>* blk_minmax, unsigned long long* cand_counter, const uint32_t* overflow_list, const uint32_t* overflow_count, bool fast_div, hipStream_t st);
+template void ss_launch_splat_large<double>(const SSDevT<double>& P, const ss_real4<double>* posvol, const ss_real4<double>* posvol_by_index, const uint32_t* perm, const uint32_t* cell_start, const uint32_t* active_list, uint32_t n_active, double* G, ss_real2<double>* blk_minmax, unsigned long long* cand_counter, const uint32_t* overflow_list, const uint32_t* overflow_count, bool fast_div, hipStream_t st);
 template void ss_launch_mc_count<float>(const SSDevT<float>& P, const float* G, const uint32_t* block_slot, const uint32_t* mc_list, uint32_t n_mc, unsigned long long* masks, uint32_t* vcount, uint32_t* tcount, hipStream_t st);
 template void ss_launch_mc_count<double>(const SSDevT<double>& P, const double* G, const uint32_t* block_slot, const uint32_t* mc_list, uint32_t n_mc, unsigned long long* masks, uint32_t* vcount, uint32_t* tcount, hipStream_t st);
 template void ss_launch_mc_emit<float>(const SSDevT<float>& P, const float* G, const uint32_t* block_slot, const uint32_t* mc_list, const uint32_t* mc_slot, uint32_t n_mc, const unsigned long long* masks, const uint32_t* vbase, const uint32_t* tbase, float* vertices, unsigned long long* vkeys, uint32_t* triangles, hipStream_t st);

@@ -212,11 +212,15 @@ def test_dense_cloud_exceeding_tile_capacity(gpu_ctx, oracle):
     """Over-dense input (many more candidates per level-set block than LDS slots): the multi-pass
     ordered accumulation must still be bit-identical to the oracle."""
     from splashsurf_amd import workloads as W
-    pts = (W.uniform_cube_particles(60000, seed=99) * np.float32(0.25)).astype(np.float32)
+    pts = (W.uniform_cube_particles(100000, seed=99) * np.float32(0.25)).astype(np.float32)
     prm = dict(particle_radius=0.01, smoothing_length=2.0, cube_size=1.0, iso_surface_threshold=0.6)
+    # a block in the middle of the cloud sees the particles of a (7 cells + 2 x 4 cells)^3 box: more than two passes of
+    # the 8192 index keys the large-tile kernel holds in LDS
+    box = np.all(np.abs(pts - np.float32(0.125)) <= np.float32(0.075), axis=1).sum()
+    assert box > 2 * 8192
     res = run_gpu(gpu_ctx, pts, prm)
     _, orc = run_oracle(oracle, pts, prm)
-    assert res.stats["n_block_candidates"] > res.stats["n_active_blocks"] * 2048
+    assert res.stats["n_large_tile_blocks"] > 0 and res.stats["n_block_candidates"] > res.stats["n_active_blocks"] * 4096
     assert_gpu_equals_oracle(res, orc)
 
 
