@@ -558,6 +558,27 @@ ss_status reconstruct_global(ss_context* ctx, const typename TypesOf<R>::params*
 template <class R>
 ss_status phase_finish(ss_context* ctx, ss_result* res);
 
+// Once per distinct h (f32 only): prove on the device that the reciprocal division used inside W is exact for this divisor
+// (k_verify_fast_div); the density and splat kernels use their generic variants otherwise.
+template <class R>
+static ss_status ensure_fast_div(ss_context* ctx, R h, hipStream_t st) {
+    if constexpr (sizeof(R) == 4) {
+        if (ctx->fastdiv_h == h) return SS_OK;
+        ctx->fastdiv_ok = false;
+        if (h > R(1.0e-9) && h < R(1.0e15)) {
+            uint32_t bad = 1;
+            SS_HIP(ctx, ctx->fastdiv_scratch.reserve(64));
+            SS_HIP(ctx, hipMemsetAsync(ctx->fastdiv_scratch.p, 0, 4, st));
+            ss_launch_verify_fast_div(h, R(1.0) / h, ctx->fastdiv_scratch.as<uint32_t>(), st);
+            SS_HIP(ctx, hipMemcpyAsync(&bad, ctx->fastdiv_scratch.p, 4, hipMemcpyDeviceToHost, st));
+            SS_HIP(ctx, hipStreamSynchronize(st));
+            ctx->fastdiv_ok = (bad == 0);
+        }
+        ctx->fastdiv_h = h;
+    }
+    return SS_OK;
+}
+
 // Phase 1: staging, grid, binning, densities.  `shard` == nullptr: the whole domain (single process).
 template <class R>
 ss_status phase_begin(ss_context* ctx, const R* xyz, uint64_t n_in, const typename TypesOf<R>::params* prm, const typename TypesOf<R>::shard* shard, ss_result* res) {
@@ -681,7 +702,7 @@ ss_status phase_begin(ss_context* ctx, const R* xyz, uint64_t n_in, const typena
             SS_HIP(ctx, ctx->ckeys_b.reserve((size_t)n_copies * 4));
             SS_HIP(ctx, ctx->cvals_a.reserve((size_t)n_copies * 4));
             SS_HIP(ctx, ctx->cidx.reserve((size_t)n_copies * 4));
-            SS_HIP(ctx, ctx->cpos.reserve((size_t)n_copies * sizeof(ss_real4<R>)));
+            SS_HIP(ctx, ctx->cpos.reserve(((size_t)n_copies + 16) * sizeof(ss_real4<R>)));  // + padding: k_density_sub reads whole chunks
             SS_HIP(ctx, ctx->cell_count2.reserve((ncells2 + 1) * 4));
             SS_HIP(ctx, ctx->cell_start2.reserve((ncells2 + 1) * 4));
             SS_HIP(ctx, hipMemsetAsync(ctx->cell_count2.p, 0, (ncells2 + 1) * 4, st));
@@ -705,9 +726,11 @@ ss_status phase_begin(ss_context* ctx, const R* xyz, uint64_t n_in, const typena
                 SS_HIP(ctx, res->nb_ptr.reserve(((size_t)n + 1) * 8));
                 SS_HIP(ctx, hipMemsetAsync(ctx->nb_count.p, 0, ((size_t)n + 1) * 8, st));
             }
+            s = ensure_fast_div<R>(ctx, P.h, st);
+            if (s != SS_OK) return s;
             ss_launch_density_sub(P, n_copies, ctx->cpos.as<ss_real4<R>>(), ctx->cidx.as<uint32_t>(), ctx->ckeys_b.as<uint32_t>(),
                                   ctx->cell_start2.as<uint32_t>(), ctx->occ_sub.as<uint32_t>(), res->rho.as<R>(), want_nb ? 1 : 0,
-                                  ctx->nb_count.as<uint32_t>(), nullptr, nullptr, st);
+                                  ctx->nb_count.as<uint32_t>(), nullptr, nullptr, sizeof(R) == 4 && ctx->fastdiv_ok, st);
             if (want_nb) {
                 // counts (u32, first n+1 entries) -> u64 -> exclusive scan = CSR row pointers
                 SS_HIP(ctx, ctx->nb_tmp.reserve(((size_t)n + 1) * 8));
@@ -722,7 +745,7 @@ ss_status phase_begin(ss_context* ctx, const R* xyz, uint64_t n_in, const typena
                 SS_HIP(ctx, res->nb_idx.reserve((size_t)total_nb * 4 + 16));
                 ss_launch_density_sub(P, n_copies, ctx->cpos.as<ss_real4<R>>(), ctx->cidx.as<uint32_t>(), ctx->ckeys_b.as<uint32_t>(),
                                       ctx->cell_start2.as<uint32_t>(), ctx->occ_sub.as<uint32_t>(), res->rho.as<R>(), 2, nullptr,
-                                      res->nb_ptr.as<unsigned long long>(), res->nb_idx.as<uint32_t>(), st);
+                                      res->nb_ptr.as<unsigned long long>(), res->nb_idx.as<uint32_t>(), false, st);
             }
             res->has_neighbors = want_nb;
         } else {
@@ -782,19 +805,11 @@ ss_status phase_finish(ss_context* ctx, ss_result* res) {
     SS_HIP(ctx, hipEventRecord(ctx->ev[5], st));
 
     // ---- K3: level-set splat ----
-    if constexpr (sizeof(R) == 4) if (n_active && ctx->fastdiv_h != P.h) {
-        // once per distinct h: prove on the device that the fast division is exact for this divisor
-        ctx->fastdiv_ok = false;
-        if (P.h > R(1.0e-9) && P.h < R(1.0e15)) {
-            uint32_t bad = 1;
-            SS_HIP(ctx, hipMemsetAsync(ctx->counter.as<char>() + 32, 0, 4, st));
-            ss_launch_verify_fast_div(P.h, R(1.0) / P.h, reinterpret_cast<uint32_t*>(ctx->counter.as<char>() + 32), st);
-            SS_HIP(ctx, hipMemcpyAsync(&bad, ctx->counter.as<char>() + 32, 4, hipMemcpyDeviceToHost, st));
-            SS_HIP(ctx, hipStreamSynchronize(st));
-            ctx->fastdiv_ok = (bad == 0);
-        }
-        ctx->fastdiv_h = P.h;
-        SS_HIP(ctx, hipEventRecord(ctx->ev[5], st));  // keep the one-off check out of the splat timing
+    {
+        const bool checked_now = sizeof(R) == 4 && ctx->fastdiv_h != (float)P.h;
+        ss_status fs = ensure_fast_div<R>(ctx, P.h, st);  // normally done before the densities already
+        if (fs != SS_OK) return fs;
+        if (checked_now) SS_HIP(ctx, hipEventRecord(ctx->ev[5], st));  // keep the one-off check out of the splat timing
     }
     // small-tile kernel first; blocks it could not hold are flagged, compacted in order and handed to the large-tile kernel
     SS_HIP(ctx, ctx->splat_overflow.reserve(((size_t)n_active + 1) * 4 * 4 + 64));
@@ -1229,7 +1244,7 @@ void ss_context_destroy(ss_context* c) {
     for (DevBuf* b : {&c->xyz_in, &c->xyz_filt, &c->flags32, &c->offsets, &c->keys_a, &c->keys_b, &c->vals_a, &c->cell_count,
                       &c->cell_start, &c->pos_sorted, &c->temp, &c->aabb_partial, &c->aabb_out, &c->block_flag, &c->block_rank, &c->mc_flag,
                       &c->mc_rank, &c->vcount, &c->tcount, &c->counter, &c->member_count, &c->copy_offset, &c->sub_flag, &c->sub_rank,
-                      &c->nb_count, &c->nb_tmp, &c->occ_sub, &c->ckeys_a, &c->ckeys_b, &c->cvals_a, &c->cidx, &c->cpos, &c->cell_count2, &c->cell_start2, &c->gboxes, &c->splat_overflow, &c->splat_tiles, &c->splat_counts})
+                      &c->nb_count, &c->nb_tmp, &c->occ_sub, &c->ckeys_a, &c->ckeys_b, &c->cvals_a, &c->cidx, &c->cpos, &c->cell_count2, &c->cell_start2, &c->gboxes, &c->fastdiv_scratch, &c->splat_overflow, &c->splat_tiles, &c->splat_counts})
         b->release();
     for (DevBuf& b : c->post_pool) b.release();
     if (c->ev_ok)

@@ -79,6 +79,7 @@ struct ss_context {
     DevBuf member_count, copy_offset, sub_flag, sub_rank, occ_sub, ckeys_a, ckeys_b, cvals_a, cidx, cpos, cell_count2, cell_start2;
     hipEvent_t ev[14];  // 0..9 stage boundaries, 10/11 start of phase 2
     // exhaustively verified "division by h via reciprocal + 2 FMA" (ss_kernels.hip ss_div_by_h)
+    DevBuf fastdiv_scratch;
     float fastdiv_h = 0.0f;
     bool fastdiv_ok = false;
     bool ev_ok = false;

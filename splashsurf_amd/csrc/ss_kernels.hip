@@ -294,15 +294,106 @@ __global__ __launch_bounds__(256) void k_emit_copies(SSDevT<R> P, const R* __res
     });
 }
 
+// ---- exactly rounded building blocks of W(r) for the density and splat inner loops ---------------------------------
+// sqrt: v_sqrt_f32 is accurate to 1 ulp; one residual test against the two neighbouring floats makes it
+// correctly rounded (the sequence hipcc emits for ss_sqrt, minus its scaling for inputs below 2^-96, which
+// the caller excludes).
+__device__ __forceinline__ float ss_sqrt_rn_normal(float x) {
+    const float s = __builtin_amdgcn_sqrtf(x);
+    const float sm = __int_as_float(__float_as_int(s) - 1);
+    const float sp = __int_as_float(__float_as_int(s) + 1);
+    const float rm = __builtin_fmaf(-sm, s, x);
+    const float rp = __builtin_fmaf(-sp, s, x);
+    float r = (rm <= 0.0f) ? sm : s;
+    r = (rp > 0.0f) ? sp : r;
+    return r;
+}
+
+template <class R, bool FAST>
+__device__ __forceinline__ R ss_div_by_h(R x, R h, R rh) {
+    if constexpr (FAST) {
+        static_assert(sizeof(R) == 4, "the verified reciprocal division exists for f32 only");
+        const float q0 = x * rh;
+        const float e = __builtin_fmaf(-q0, h, x);
+        return __builtin_fmaf(e, rh, q0);
+    } else {
+        return x / h;
+    }
+}
+
+// kernel.rs:71-81 without branches (both polynomial pieces, then select); same association order
+template <class R>
+__device__ __forceinline__ R ss_cubic_function_sel(R q) {
+    const R pi = R(3.14159265358979323846);
+    const R fa = (R(3.0) / (R(2.0) * pi)) * ((R(2.0) / R(3.0)) - q * q + R(0.5) * q * q * q);
+    const R x = R(2.0) - q;
+    const R fb = (R(1.0) / (R(4.0) * pi)) * x * x * x;
+    return (q < R(1.0)) ? fa : ((q < R(2.0)) ? fb : R(0.0));
+}
+
+// W(sqrt(d2)) exactly as kernel.rs:103-106 evaluates it.
+// FAST variant (enabled by the host only for 1e-9 < h < 1e15 and after k_verify_fast_div passed): lean sqrt
+// and reciprocal division.  Both are exact for normal-range arguments; for d2 below (2^-14 h)^2 -- the
+// only place where v_sqrt_f32 could see a denormal or the division's residual could underflow -- the
+// value of q is irrelevant: any q < 2^-13 makes 2/3 - q*q round to 2/3 and 0.5*q^3 vanish, i.e. W == W(0)
+// bit for bit, and every path yields such a q there (r is never over-estimated).
+template <class R, bool FAST>
+__device__ __forceinline__ R ss_kernel_w(R d2, R h, R rh, R sigma) {
+    R r;
+    if constexpr (FAST)
+        r = ss_sqrt_rn_normal(d2);
+    else
+        r = ss_sqrt(d2);  // generic variant: hipcc's fully guarded, correctly rounded sqrt
+    if constexpr (FAST) {
+        // q = RN((r + r) / h) = RN(r / (h/2)): halving h and doubling its reciprocal are exact, so the division verified for
+        // the divisor h (all significands) serves h/2 as well and the doubling of r is not needed
+        const R q = ss_div_by_h<R, true>(r, R(0.5) * h, rh + rh);
+        // kernel.rs:71-81.  The outer piece (1 <= q < 2) is evaluated for every lane; the inner piece only if some lane of
+        // the wave needs it (a wave-uniform branch): about three quarters of the tile entries a wave visits lie farther
+        // than h/2 from all of its 64 points.
+        const R pi = R(3.14159265358979323846);
+        // q >= 2 (d^2 in [h^2, 1.01 h^2)) must give exactly 0: clamping x = 2 - q at 0 does, since c*0*0*0 == +0.  The
+        // clamp to [0, 1] is the subtraction's output modifier (no extra instruction); its upper bound only touches lanes
+        // with q < 1, whose value is replaced by the inner piece below.
+        R x;
+        asm("v_sub_f32_e64 %0, 2.0, %1 clamp" : "=v"(x) : "v"(q));
+        R f = (R(1.0) / (R(4.0) * pi)) * x * x * x;
+        const bool inner = q < R(1.0);
+        if (__ballot(inner)) {
+            const R fa = (R(3.0) / (R(2.0) * pi)) * ((R(2.0) / R(3.0)) - q * q + R(0.5) * q * q * q);
+            f = inner ? fa : f;
+        }
+        return sigma * f;
+    } else {
+        const R q = ss_div_by_h<R, false>(r + r, h, rh);
+        return sigma * ss_cubic_function_sel<R>(q);
+    }
+}
+
+// Only ~15 % of the candidates of a particle's 27 cells are neighbours, but in a wave of 64 particles nearly every candidate
+// step has SOME lane with a neighbour, so evaluating W inside the candidate loop makes every lane pay for it at every step.
+// The loop therefore only computes d^2 and appends it to a per-lane queue in LDS (unconditional store, the fill count
+// advances on a hit); W is evaluated for the queued values in lock-step once some lane's queue runs full.  Each lane still
+// adds its neighbours' W in candidate order, i.e. in the reference's order.
+template <class R> struct SSDensityQueue {
+    // 16 KiB of LDS per 256-thread workgroup either way.  Measured on S10M-cube / S1M / S10M-tank (density stage, ms):
+    // cap 32: 21.1 / 1.66 / 3.97; 24: 18.1 / 1.49 / 3.73; 16: 17.4 / 1.53 / 3.69; 12: 17.6 / 1.49 / 3.69 -- the candidate
+    // loads (12 B per lane and candidate through the 64 B/clk L1 return path) want more waves in flight than a deep queue allows.
+    static constexpr int cap = sizeof(R) == 4 ? 16 : 8;
+    static constexpr int chunk = 4;  // candidates between two fill checks
+};
 // MODE 0: densities.  MODE 1: densities + neighbour counts (global_neighborhood_list).
 // MODE 2: write the neighbour ids (global particle indices) at nb_ptr[i], in the reference's order
 // (dense_subdomains.rs:617-639: the per-subdomain lists remapped to global indices).
-template <class R, int MODE>
+template <class R, int MODE, bool FAST>
 __global__ __launch_bounds__(256) void k_density_sub(SSDevT<R> P, uint32_t n_copies, const ss_real4<R>* __restrict__ cpos, const uint32_t* __restrict__ cidx,
                                                      const uint32_t* __restrict__ ckey, const uint32_t* __restrict__ cell_start,
                                                      const uint32_t* __restrict__ occ_sub, R* __restrict__ rho,
                                                      uint32_t* __restrict__ nb_count, const unsigned long long* __restrict__ nb_ptr,
                                                      uint32_t* __restrict__ nb_idx) {
+    constexpr int QC = SSDensityQueue<R>::cap, QD = SSDensityQueue<R>::chunk;
+    __shared__ R s_q[(MODE == 2) ? 1 : QC][256];
+    const int tid = threadIdx.x;
     uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= n_copies) return;
     const uint32_t ctot = (uint32_t)(P.sc[0] * P.sc[1] * P.sc[2]);
@@ -366,23 +457,43 @@ __global__ __launch_bounds__(256) void k_density_sub(SSDevT<R> P, uint32_t n_cop
         rb[10] = own_b;                                                  // own cell last
         re[10] = own_e;
     }
+    const R rh = R(1.0) / P.h;
+    uint32_t cnt = 0;  // fill of this lane's queue
+    auto flush = [&]() {
+        for (uint32_t k = 0; __any(k < cnt); ++k)
+            if (k < cnt) acc += ss_kernel_w<R, FAST>(s_q[(MODE == 2) ? 0 : k][tid], P.h, rh, P.sigma);  // density_map.rs:179-180
+        nn += cnt;
+        cnt = 0;
+    };
 #pragma unroll
     for (int run = 0; run < 11; ++run) {
-        for (uint32_t q = rb[run]; q < re[run]; ++q) {
-            const ss_real4<R> pj = cpos[q];
-            const R dx = pj.x - pi.x, dy = pj.y - pi.y, dz = pj.z - pi.z;
-            const R d2 = dx * dx + dy * dy + dz * dz;
-            if (q != p && d2 < P.h2) {  // neighborhood_search.rs:431
+        const uint32_t e = re[run];
+        for (uint32_t q = rb[run]; q < e; q += (uint32_t)QD) {
+            if (MODE != 2)
+                if (__any(cnt > (uint32_t)(QC - QD))) flush();
+            // QD candidates per trip, loads issued together from one base address; slots beyond the run are predicated
+            // off (they read the next cells' copies -- cpos is padded by QD entries at its end)
+            const ss_real4<R>* cq = cpos + q;
+            ss_real4<R> pj[QD];
+#pragma unroll
+            for (int j = 0; j < QD; ++j) pj[j] = cq[j];
+#pragma unroll
+            for (int j = 0; j < QD; ++j) {
+                const uint32_t qq = q + (uint32_t)j;
+                const R dx = pj[j].x - pi.x, dy = pj[j].y - pi.y, dz = pj[j].z - pi.z;
+                const R d2 = dx * dx + dy * dy + dz * dz;
+                bool hit = qq < e && d2 < P.h2;  // neighborhood_search.rs:431
+                if (run == 10) hit = hit && qq != p;  // the particle itself sits in its own cell (the last run)
                 if (MODE == 2) {
-                    nb_idx[wr++] = cidx[q];
+                    if (hit) nb_idx[wr++] = cidx[qq];
                 } else {
-                    const R r = ss_sqrt(d2);
-                    acc += ss_kernel_evaluate(r, P.h, P.sigma);  // density_map.rs:179-180
-                    ++nn;
+                    s_q[(MODE == 2) ? 0 : cnt][tid] = d2;
+                    cnt += hit ? 1u : 0u;
                 }
             }
         }
     }
+    if (MODE != 2) flush();
     if (MODE != 2) rho[cidx[p]] = acc * P.mass;  // density_map.rs:182, dense_subdomains.rs:596-614
     if (MODE == 1) nb_count[cidx[p]] = nn;
 }
@@ -418,15 +529,24 @@ void ss_launch_emit_copies(const SSDevT<R>& P, const R* xyz, const uint32_t* cop
 template <class R>
 void ss_launch_density_sub(const SSDevT<R>& P, uint32_t n_copies, const ss_real4<R>* cpos, const uint32_t* cidx, const uint32_t* ckey,
                            const uint32_t* cell_start, const uint32_t* occ_sub, R* rho, int mode, uint32_t* nb_count,
-                           const unsigned long long* nb_ptr, uint32_t* nb_idx, hipStream_t st) {
+                           const unsigned long long* nb_ptr, uint32_t* nb_idx, bool fast_div, hipStream_t st) {
     if (!n_copies) return;
     const dim3 g((n_copies + 255) / 256), b(256);
+    if constexpr (sizeof(R) == 4) {
+        if (fast_div && mode != 2) {  // lean exact sqrt and verified reciprocal division inside W (see ss_kernel_w)
+            if (mode == 0)
+                hipLaunchKernelGGL((k_density_sub<R, 0, true>), g, b, 0, st, P, n_copies, cpos, cidx, ckey, cell_start, occ_sub, rho, nb_count, nb_ptr, nb_idx);
+            else
+                hipLaunchKernelGGL((k_density_sub<R, 1, true>), g, b, 0, st, P, n_copies, cpos, cidx, ckey, cell_start, occ_sub, rho, nb_count, nb_ptr, nb_idx);
+            return;
+        }
+    }
     if (mode == 0)
-        hipLaunchKernelGGL((k_density_sub<R, 0>), g, b, 0, st, P, n_copies, cpos, cidx, ckey, cell_start, occ_sub, rho, nb_count, nb_ptr, nb_idx);
+        hipLaunchKernelGGL((k_density_sub<R, 0, false>), g, b, 0, st, P, n_copies, cpos, cidx, ckey, cell_start, occ_sub, rho, nb_count, nb_ptr, nb_idx);
     else if (mode == 1)
-        hipLaunchKernelGGL((k_density_sub<R, 1>), g, b, 0, st, P, n_copies, cpos, cidx, ckey, cell_start, occ_sub, rho, nb_count, nb_ptr, nb_idx);
+        hipLaunchKernelGGL((k_density_sub<R, 1, false>), g, b, 0, st, P, n_copies, cpos, cidx, ckey, cell_start, occ_sub, rho, nb_count, nb_ptr, nb_idx);
     else
-        hipLaunchKernelGGL((k_density_sub<R, 2>), g, b, 0, st, P, n_copies, cpos, cidx, ckey, cell_start, occ_sub, rho, nb_count, nb_ptr, nb_idx);
+        hipLaunchKernelGGL((k_density_sub<R, 2, false>), g, b, 0, st, P, n_copies, cpos, cidx, ckey, cell_start, occ_sub, rho, nb_count, nb_ptr, nb_idx);
 }
 template <class R>
 void ss_launch_make_posvol(const SSDevT<R>& P, const ss_real4<R>* pos_sorted, const uint32_t* perm, const R* rho, ss_real4<R>* posvol,
@@ -551,82 +671,6 @@ void ss_launch_compact_blocks(const uint32_t* flag, const uint32_t* rank, uint32
 // Tiles larger than SSTileCap<R>::value are processed in several passes over ascending index ranges
 // (threshold found by bisection), which keeps the summation order exact for arbitrarily dense input.
 // =====================================================================================================
-// ---- exactly rounded building blocks of W(r) for the splat inner loop ---------------------------------
-// sqrt: v_sqrt_f32 is accurate to 1 ulp; one residual test against the two neighbouring floats makes it
-// correctly rounded (the sequence hipcc emits for ss_sqrt, minus its scaling for inputs below 2^-96, which
-// the caller excludes).
-__device__ __forceinline__ float ss_sqrt_rn_normal(float x) {
-    const float s = __builtin_amdgcn_sqrtf(x);
-    const float sm = __int_as_float(__float_as_int(s) - 1);
-    const float sp = __int_as_float(__float_as_int(s) + 1);
-    const float rm = __builtin_fmaf(-sm, s, x);
-    const float rp = __builtin_fmaf(-sp, s, x);
-    float r = (rm <= 0.0f) ? sm : s;
-    r = (rp > 0.0f) ? sp : r;
-    return r;
-}
-
-template <class R, bool FAST>
-__device__ __forceinline__ R ss_div_by_h(R x, R h, R rh) {
-    if constexpr (FAST) {
-        static_assert(sizeof(R) == 4, "the verified reciprocal division exists for f32 only");
-        const float q0 = x * rh;
-        const float e = __builtin_fmaf(-q0, h, x);
-        return __builtin_fmaf(e, rh, q0);
-    } else {
-        return x / h;
-    }
-}
-
-// kernel.rs:71-81 without branches (both polynomial pieces, then select); same association order
-template <class R>
-__device__ __forceinline__ R ss_cubic_function_sel(R q) {
-    const R pi = R(3.14159265358979323846);
-    const R fa = (R(3.0) / (R(2.0) * pi)) * ((R(2.0) / R(3.0)) - q * q + R(0.5) * q * q * q);
-    const R x = R(2.0) - q;
-    const R fb = (R(1.0) / (R(4.0) * pi)) * x * x * x;
-    return (q < R(1.0)) ? fa : ((q < R(2.0)) ? fb : R(0.0));
-}
-
-// W(sqrt(d2)) exactly as kernel.rs:103-106 evaluates it.
-// FAST variant (enabled by the host only for 1e-9 < h < 1e15 and after k_verify_fast_div passed): lean sqrt
-// and reciprocal division.  Both are exact for normal-range arguments; for d2 below (2^-14 h)^2 -- the
-// only place where v_sqrt_f32 could see a denormal or the division's residual could underflow -- the
-// value of q is irrelevant: any q < 2^-13 makes 2/3 - q*q round to 2/3 and 0.5*q^3 vanish, i.e. W == W(0)
-// bit for bit, and every path yields such a q there (r is never over-estimated).
-template <class R, bool FAST>
-__device__ __forceinline__ R ss_kernel_w(R d2, R h, R rh, R sigma) {
-    R r;
-    if constexpr (FAST)
-        r = ss_sqrt_rn_normal(d2);
-    else
-        r = ss_sqrt(d2);  // generic variant: hipcc's fully guarded, correctly rounded sqrt
-    if constexpr (FAST) {
-        // q = RN((r + r) / h) = RN(r / (h/2)): halving h and doubling its reciprocal are exact, so the division verified for
-        // the divisor h (all significands) serves h/2 as well and the doubling of r is not needed
-        const R q = ss_div_by_h<R, true>(r, R(0.5) * h, rh + rh);
-        // kernel.rs:71-81.  The outer piece (1 <= q < 2) is evaluated for every lane; the inner piece only if some lane of
-        // the wave needs it (a wave-uniform branch): about three quarters of the tile entries a wave visits lie farther
-        // than h/2 from all of its 64 points.
-        const R pi = R(3.14159265358979323846);
-        // q >= 2 (d^2 in [h^2, 1.01 h^2)) must give exactly 0: clamping x = 2 - q at 0 does, since c*0*0*0 == +0.  The
-        // clamp to [0, 1] is the subtraction's output modifier (no extra instruction); its upper bound only touches lanes
-        // with q < 1, whose value is replaced by the inner piece below.
-        R x;
-        asm("v_sub_f32_e64 %0, 2.0, %1 clamp" : "=v"(x) : "v"(q));
-        R f = (R(1.0) / (R(4.0) * pi)) * x * x * x;
-        const bool inner = q < R(1.0);
-        if (__ballot(inner)) {
-            const R fa = (R(3.0) / (R(2.0) * pi)) * ((R(2.0) / R(3.0)) - q * q + R(0.5) * q * q * q);
-            f = inner ? fa : f;
-        }
-        return sigma * f;
-    } else {
-        const R q = ss_div_by_h<R, false>(r + r, h, rh);
-        return sigma * ss_cubic_function_sel<R>(q);
-    }
-}
-
 __global__ __launch_bounds__(256) void k_verify_fast_div(float h, float rh, uint32_t* __restrict__ bad) {
     // all significands of the binade [2^e, 2^(e+1)) that contains h
     const uint32_t m = blockIdx.x * blockDim.x + threadIdx.x;  // 0 .. 2^23-1
@@ -639,6 +683,13 @@ __global__ __launch_bounds__(256) void k_verify_fast_div(float h, float rh, uint
 
 void ss_launch_verify_fast_div(float h, float rh, uint32_t* bad, hipStream_t st) {
     hipLaunchKernelGGL(k_verify_fast_div, dim3((1u << 23) / 256), dim3(256), 0, st, h, rh, bad);
+}
+
+__device__ __forceinline__ void ss_wave_lds_sync() {
+    // LDS operations of one wave complete in order; this only stops the compiler from moving them across
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
 #define SS_PAY_CHUNK 512
@@ -886,6 +937,9 @@ __device__ __forceinline__ void splat_block(SplatShared<R, CAP>& s, const SSDevT
             while (m < n_tile) m <<= 1;
             for (int e = n_tile + tid; e < m; e += 512) s.idx[e] = 0xFFFFFFFFu;
             __syncthreads();
+            // bitonic network, one workgroup barrier per stage.  (Running the stages with distance j <= 64 wave-synchronously
+            // -- they stay inside the 128 keys one wave covers -- needs 15 instead of 66 barriers for 2048 keys but was
+            // measured slower, 41.2 instead of 35.2 ms on S10M-cube: the dependent LDS round trips of one wave no longer overlap.)
             for (int k = 2; k <= m; k <<= 1)
                 for (int j = k >> 1; j > 0; j >>= 1) {
                     for (int t = tid; t < (m >> 1); t += 512) {
@@ -952,13 +1006,6 @@ __device__ __forceinline__ void splat_block(SplatShared<R, CAP>& s, const SSDevT
 // Blocks whose tile does not fit a slot are flagged for k_splat_large.
 // =====================================================================================================
 #define SS_WTILE 384
-
-__device__ __forceinline__ void ss_wave_lds_sync() {
-    // LDS operations of one wave complete in order; this only stops the compiler from moving them across
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
 
 template <class R>
 __global__ __launch_bounds__(256) void k_splat_gather(SSDevT<R> P, const ss_real4<R>* __restrict__ posvol, const uint32_t* __restrict__ perm,
@@ -1491,8 +1538,8 @@ template void ss_launch_classify_count<float>(const SSDevT<float>& P, const floa
 template void ss_launch_classify_count<double>(const SSDevT<double>& P, const double* xyz, uint32_t* member_count, uint32_t* sub_flag, hipStream_t st);
 template void ss_launch_emit_copies<float>(const SSDevT<float>& P, const float* xyz, const uint32_t* copy_offset, const uint32_t* occ_rank, uint32_t* keys, uint32_t* vals, uint32_t* cell_count, hipStream_t st);
 template void ss_launch_emit_copies<double>(const SSDevT<double>& P, const double* xyz, const uint32_t* copy_offset, const uint32_t* occ_rank, uint32_t* keys, uint32_t* vals, uint32_t* cell_count, hipStream_t st);
-template void ss_launch_density_sub<float>(const SSDevT<float>& P, uint32_t n_copies, const ss_real4<float>* cpos, const uint32_t* cidx, const uint32_t* ckey, const uint32_t* cell_start, const uint32_t* occ_sub, float* rho, int mode, uint32_t* nb_count, const unsigned long long* nb_ptr, uint32_t* nb_idx, hipStream_t st);
-template void ss_launch_density_sub<double>(const SSDevT<double>& P, uint32_t n_copies, const ss_real4<double>* cpos, const uint32_t* cidx, const uint32_t* ckey, const uint32_t* cell_start, const uint32_t* occ_sub, double* rho, int mode, uint32_t* nb_count, const unsigned long long* nb_ptr, uint32_t* nb_idx, hipStream_t st);
+template void ss_launch_density_sub<float>(const SSDevT<float>& P, uint32_t n_copies, const ss_real4<float>* cpos, const uint32_t* cidx, const uint32_t* ckey, const uint32_t* cell_start, const uint32_t* occ_sub, float* rho, int mode, uint32_t* nb_count, const unsigned long long* nb_ptr, uint32_t* nb_idx, bool fast_div, hipStream_t st);
+template void ss_launch_density_sub<double>(const SSDevT<double>& P, uint32_t n_copies, const ss_real4<double>* cpos, const uint32_t* cidx, const uint32_t* ckey, const uint32_t* cell_start, const uint32_t* occ_sub, double* rho, int mode, uint32_t* nb_count, const unsigned long long* nb_ptr, uint32_t* nb_idx, bool fast_div, hipStream_t st);
 template void ss_launch_make_posvol<float>(const SSDevT<float>& P, const ss_real4<float>* pos_sorted, const uint32_t* perm, const float* rho, ss_real4<float>* posvol, ss_real4<float>* posvol_by_index, hipStream_t st);
 template void ss_launch_make_posvol<double>(const SSDevT<double>& P, const ss_real4<double>* pos_sorted, const uint32_t* perm, const double* rho, ss_real4<double>* posvol, ss_real4<double>* posvol_by_index, hipStream_t st);
 template void ss_launch_mark_blocks<float>(const SSDevT<float>& P, const uint32_t* cell_start, uint32_t ncells, uint32_t* block_flag, hipStream_t st);
