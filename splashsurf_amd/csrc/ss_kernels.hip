@@ -703,6 +703,17 @@ struct SplatShared {
     uint32_t count;
 };
 
+// Conservative block-level filter of the splat: does the particle lie within reach of the box spanned by the block's grid
+// points [plo, phi]?  Same expression as the per-wave test in splat_accumulate_wave on a box that contains every wave's
+// sub-block, and all operations involved are monotone under rounding, so whatever a wave accepts passes here as well.
+template <class R>
+__device__ __forceinline__ bool ss_within_reach_of_block(const SSDevT<R>& P, const ss_real4<R>& pv, const R plo[3], const R phi[3]) {
+    const R ex = ss_max(ss_max(plo[0] - pv.x, pv.x - phi[0]) - P.coord_slack, R(0.0));
+    const R ey = ss_max(ss_max(plo[1] - pv.y, pv.y - phi[1]) - P.coord_slack, R(0.0));
+    const R ez = ss_max(ss_max(plo[2] - pv.z, pv.z - phi[2]) - P.coord_slack, R(0.0));
+    return (ex * ex + ey * ey + ez * ez) <= P.H2 * R(1.0001);
+}
+
 // exclusive prefix over s.row_prefix[0..nbatch) (lengths in, prefix out), total in row_prefix[nbatch]
 template <class S>
 __device__ inline void splat_row_prefix(S& s, int nbatch, uint32_t len, int tid) {
@@ -728,11 +739,11 @@ __device__ inline void splat_row_prefix(S& s, int nbatch, uint32_t len, int tid)
 }
 
 // Visit every particle of the search cells overlapping the dilated block box; f(sorted position, idx, payload) is
-// called for particles inside the box.  All 512 threads must call this (contains barriers).
+// called for particles within reach of the block's points.  All 512 threads must call this (contains barriers).
 template <class R, class S, class F>
 __device__ inline void splat_for_each_candidate(S& s, const SSDevT<R>& P, const ss_real4<R>* __restrict__ posvol,
                                                 const uint32_t* __restrict__ perm, const uint32_t* __restrict__ cell_start,
-                                                const int klo[3], const int khi[3], const R blo[3], const R bhi[3], int tid, F f) {
+                                                const int klo[3], const int khi[3], const R plo[3], const R phi[3], int tid, F f) {
     const int ny = khi[1] - klo[1] + 1;
     const int nrows = (khi[0] - klo[0] + 1) * ny;
     for (int row_base = 0; row_base < nrows; row_base += SS_MAX_ROWS) {
@@ -762,7 +773,7 @@ __device__ inline void splat_for_each_candidate(S& s, const SSDevT<R>& P, const 
             }
             const uint32_t src = s.row_start[lo] + (q - s.row_prefix[lo]);
             const ss_real4<R> pv = posvol[src];
-            if (pv.x >= blo[0] && pv.x <= bhi[0] && pv.y >= blo[1] && pv.y <= bhi[1] && pv.z >= blo[2] && pv.z <= bhi[2]) f(src, perm[src], pv);
+            if (ss_within_reach_of_block<R>(P, pv, plo, phi)) f(src, perm[src], pv);
         }
         __syncthreads();
     }
@@ -832,16 +843,18 @@ __device__ __forceinline__ void splat_block(SplatShared<R, CAP>& s, const SSDevT
     const int bx = (int)(b / ((uint32_t)P.nb[2] * (uint32_t)P.nb[1]));
     const int b3[3] = {bx, by, bz};
 
-    // dilated block box and the search cells overlapping it
-    R blo[3], bhi[3];
+    // box of the block's points, dilated by the reach: the search cells overlapping it
+    R blo[3], bhi[3], plo[3], phi[3];
     int klo[3], khi[3];
 #pragma unroll
     for (int d = 0; d < 3; ++d) {
         const int i0 = b3[d] * SS_BLOCK;
         const int i1 = min(i0 + SS_BLOCK - 1, P.np[d] - 1);
         const R pad = P.reach + P.coord_slack;
-        blo[d] = (P.gmin[d] + (R)i0 * P.cs) - pad;
-        bhi[d] = (P.gmin[d] + (R)i1 * P.cs) + pad;
+        plo[d] = P.gmin[d] + (R)i0 * P.cs;
+        phi[d] = P.gmin[d] + (R)i1 * P.cs;
+        blo[d] = plo[d] - pad;
+        bhi[d] = phi[d] + pad;
         const double cellpad = 1e-3 * (double)P.h;
         int a = (int)floor(((double)blo[d] - cellpad) / (double)P.h);
         int e = (int)floor(((double)bhi[d] + cellpad) / (double)P.h);
@@ -874,7 +887,7 @@ __device__ __forceinline__ void splat_block(SplatShared<R, CAP>& s, const SSDevT
         long long T = idx_max;
         if (tid == 0) s.count = 0;
         __syncthreads();
-        splat_for_each_candidate<R>(s, P, posvol, perm, cell_start, klo, khi, blo, bhi, tid, [&](uint32_t, uint32_t idx, const ss_real4<R>&) {
+        splat_for_each_candidate<R>(s, P, posvol, perm, cell_start, klo, khi, plo, phi, tid, [&](uint32_t, uint32_t idx, const ss_real4<R>&) {
             if ((long long)idx > last) {
                 uint32_t pos = atomicAdd(&s.count, 1u);
                 if (pos < CAP) s.idx[pos] = idx;  // keys only; the payload is fetched after the sort through posvol_by_index
@@ -892,7 +905,7 @@ __device__ __forceinline__ void splat_block(SplatShared<R, CAP>& s, const SSDevT
                 __syncthreads();
                 if (tid == 0) s.count = 0;
                 __syncthreads();
-                splat_for_each_candidate<R>(s, P, posvol, perm, cell_start, klo, khi, blo, bhi, tid, [&](uint32_t, uint32_t idx, const ss_real4<R>&) {
+                splat_for_each_candidate<R>(s, P, posvol, perm, cell_start, klo, khi, plo, phi, tid, [&](uint32_t, uint32_t idx, const ss_real4<R>&) {
                     if ((long long)idx > last && (long long)idx <= mid) atomicAdd(&s.count, 1u);
                 });
                 const uint32_t c = s.count;
@@ -905,7 +918,7 @@ __device__ __forceinline__ void splat_block(SplatShared<R, CAP>& s, const SSDevT
             __syncthreads();
             if (tid == 0) s.count = 0;
             __syncthreads();
-            splat_for_each_candidate<R>(s, P, posvol, perm, cell_start, klo, khi, blo, bhi, tid, [&](uint32_t, uint32_t idx, const ss_real4<R>&) {
+            splat_for_each_candidate<R>(s, P, posvol, perm, cell_start, klo, khi, plo, phi, tid, [&](uint32_t, uint32_t idx, const ss_real4<R>&) {
                 if ((long long)idx > last && (long long)idx <= T) {
                     uint32_t pos = atomicAdd(&s.count, 1u);
                     if (pos < CAP) s.idx[pos] = idx;
@@ -1025,15 +1038,17 @@ __global__ __launch_bounds__(256) void k_splat_gather(SSDevT<R> P, const ss_real
     if (logical >= n_active) return;
     const uint32_t b = active_list[logical];
     const int b3[3] = {(int)(b / ((uint32_t)P.nb[2] * (uint32_t)P.nb[1])), (int)((b / (uint32_t)P.nb[2]) % (uint32_t)P.nb[1]), (int)(b % (uint32_t)P.nb[2])};
-    R blo[3], bhi[3];
+    R blo[3], bhi[3], plo[3], phi[3];
     int klo[3], khi[3];
 #pragma unroll
     for (int d = 0; d < 3; ++d) {  // dilated block box and the search cells overlapping it (as in splat_block)
         const int i0 = b3[d] * SS_BLOCK;
         const int i1 = min(i0 + SS_BLOCK - 1, P.np[d] - 1);
         const R pad = P.reach + P.coord_slack;
-        blo[d] = (P.gmin[d] + (R)i0 * P.cs) - pad;
-        bhi[d] = (P.gmin[d] + (R)i1 * P.cs) + pad;
+        plo[d] = P.gmin[d] + (R)i0 * P.cs;
+        phi[d] = P.gmin[d] + (R)i1 * P.cs;
+        blo[d] = plo[d] - pad;
+        bhi[d] = phi[d] + pad;
         const double cellpad = 1e-3 * (double)P.h;
         const int a = (int)floor(((double)blo[d] - cellpad) / (double)P.h);
         const int e = (int)floor(((double)bhi[d] + cellpad) / (double)P.h);
@@ -1067,8 +1082,8 @@ __global__ __launch_bounds__(256) void k_splat_gather(SSDevT<R> P, const ss_real
             const uint32_t total = __shfl(incl, 63);
             if (lane == 0) s_row_prefix[w][64] = total;
             ss_wave_lds_sync();
-            if (total > 3u * SS_WTILE) {
-                overflow = true;  // a box holds roughly 40 % of the particles of the rows it overlaps: over-dense block
+            if (total > 4u * SS_WTILE) {
+                overflow = true;  // about 30 % of the particles of the overlapped rows are within reach: over-dense block
             } else {
                 for (uint32_t q0 = 0; q0 < total; q0 += 64u) {
                     const uint32_t q = q0 + (uint32_t)lane;
@@ -1086,7 +1101,7 @@ __global__ __launch_bounds__(256) void k_splat_gather(SSDevT<R> P, const ss_real
                         src = s_row_start[w][lo] + (q - s_row_prefix[w][lo]);
                         const ss_real4<R> pv = posvol[src];
                         id = perm[src];
-                        inside = pv.x >= blo[0] && pv.x <= bhi[0] && pv.y >= blo[1] && pv.y <= bhi[1] && pv.z >= blo[2] && pv.z <= bhi[2];
+                        inside = ss_within_reach_of_block<R>(P, pv, plo, phi);
                     }
                     const unsigned long long m = __ballot(inside);
                     const uint32_t pos = count + (uint32_t)__popcll(m & ((lane == 0) ? 0ull : (~0ull >> (64 - lane))));
