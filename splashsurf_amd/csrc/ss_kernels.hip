@@ -377,8 +377,8 @@ __device__ __forceinline__ R ss_kernel_w(R d2, R h, R rh, R sigma) {
 // adds its neighbours' W in candidate order, i.e. in the reference's order.
 template <class R> struct SSDensityQueue {
     // 16 KiB of LDS per 256-thread workgroup either way.  Measured on S10M-cube / S1M / S10M-tank (density stage, ms):
-    // cap 32: 21.1 / 1.66 / 3.97; 24: 18.1 / 1.49 / 3.73; 16: 17.4 / 1.53 / 3.69; 12: 17.6 / 1.49 / 3.69 -- the candidate
-    // loads (12 B per lane and candidate through the 64 B/clk L1 return path) want more waves in flight than a deep queue allows.
+    // cap 32: 21.1 / 1.66 / 3.97; 24: 18.1 / 1.49 / 3.73; 16: 17.4 / 1.53 / 3.69; 12: 17.6 / 1.49 / 3.69 -- a deeper queue is
+    // fuller when it is flushed but leaves fewer waves per SIMD to cover the dependent chains of the W evaluation.
     static constexpr int cap = sizeof(R) == 4 ? 16 : 8;
     static constexpr int chunk = 4;  // candidates between two fill checks
 };
