@@ -7,7 +7,7 @@
 //                                                                        -> k_cell_keys (+ rocPRIM sort), k_gather_sorted
 //   K2  dense_subdomains.rs:496-646 + neighborhood_search.rs:345-438 + density_map.rs:150-186
 //                                                                        -> k_classify_count, k_emit_copies, k_density_sub
-//   K3  dense_subdomains.rs:784-847 (density_grid_loop_scalar)            -> k_mark_blocks, k_splat
+//   K3  dense_subdomains.rs:784-847 (density_grid_loop_scalar)            -> k_mark_blocks, k_splat_gather, k_splat_accumulate, k_splat_large
 //   K4  dense_subdomains.rs:1470-1553 (triangulate_cell) classification   -> k_mc_count
 //   K5  same, vertex/triangle emission + dense_subdomains.rs:1603-1749    -> k_mc_emit
 //
@@ -657,19 +657,19 @@ void ss_launch_compact_blocks(const uint32_t* flag, const uint32_t* rank, uint32
 // =====================================================================================================
 // K3: level-set splat in gather form.
 //
-// One 512-thread workgroup (8 waves) per active block of 8x8x8 grid points; wave w owns the 4x4x4
-// sub-block (w>>2, (w>>1)&1, w&1), lane l the point ((l>>4)&3, (l>>2)&3, l&3) of it.
-//   1. gather: the particles inside the block's box dilated by the kernel reach are collected from the
-//      cell-sorted array ((x,y) rows of search cells are contiguous runs) into LDS as (original index,
-//      sorted position) pairs;
-//   2. order: the tile is sorted by ORIGINAL particle index (rank sort for small tiles, bitonic
-//      network otherwise) and the payload (x,y,z,V) loaded in that order -- this reproduces the
-//      reference's per-point summation order;
-//   3. accumulate: per wave, phase A tests 64 tile entries at once against the wave's sub-block box
-//      (ballot), phase B walks the surviving entries in order; every lane evaluates
-//      G += V * W(|x - p|) for its point iff d^2 < 1.01 h^2 (dense_subdomains.rs:828-841).
-// Tiles larger than SSTileCap<R>::value are processed in several passes over ascending index ranges
-// (threshold found by bisection), which keeps the summation order exact for arbitrarily dense input.
+// Work unit: one active block of 8x8x8 grid points; in the accumulating kernels a 512-thread workgroup (8 waves) owns it,
+// wave w the 4x4x4 sub-block (w>>2, (w>>1)&1, w&1), lane l the point ((l>>4)&3, (l>>2)&3, l&3) of it.
+//   1. gather: the particles within reach of the block's points are collected from the cell-sorted array ((x,y) rows of
+//      search cells are contiguous runs);
+//   2. order: the tile is sorted by ORIGINAL particle index and the payload (x,y,z,V) fetched in that order -- this
+//      reproduces the reference's per-point summation order;
+//   3. accumulate: per wave, phase A tests 64 tile entries at once against the wave's sub-block box (ballot), phase B walks
+//      the surviving entries in order; every lane evaluates G += V * W(|x - p|) for its point iff d^2 < 1.01 h^2
+//      (dense_subdomains.rs:828-841).
+// Tiles of up to SS_WTILE entries: steps 1-2 by ONE WAVE per block (k_splat_gather, ordered tile left in an HBM slot), step 3
+// by k_splat_accumulate.  Larger tiles: k_splat_large does all three steps per workgroup with up to SSTileCap<R>::value
+// index keys in LDS, in several passes over ascending index ranges (threshold found by bisection) if a tile is larger
+// still, which keeps the summation order exact for arbitrarily dense input.
 // =====================================================================================================
 __global__ __launch_bounds__(256) void k_verify_fast_div(float h, float rh, uint32_t* __restrict__ bad) {
     // all significands of the binade [2^e, 2^(e+1)) that contains h
