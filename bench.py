@@ -254,6 +254,15 @@ def main():
             if tr and tr.get("kernel", "").startswith(line["roofline"]["kernel"]):
                 line["roofline"]["traffic"] = tr["hbm_bytes_per_launch"]
                 line["roofline"]["traffic_note"] = tr["note"]
+                if tr.get("valu_insts_per_launch") and line["roofline"]["kernel_ms"] > 0:
+                    # the kernel's real bound (informative): share of the VALU issue slots it uses, 1024 SIMDs, one wave64
+                    # instruction per 2 cycles, at the device's maximum engine clock
+                    props = torch.cuda.get_device_properties(dev)
+                    clock_hz = float(getattr(props, "clock_rate", 2400000)) * 1e3
+                    n_simd = 4 * int(props.multi_processor_count)
+                    slots = line["roofline"]["kernel_ms"] * 1e-3 * clock_hz * n_simd / 2.0
+                    line["roofline"]["valu"] = {"insts_per_launch": tr["valu_insts_per_launch"], "issue_slots_frac": round(tr["valu_insts_per_launch"] / slots, 4),
+                                                "clock_ghz": round(clock_hz * 1e-9, 3), "simds": n_simd, "note": tr.get("valu_note", "")}
         except Exception:
             pass
     if sharded_path and getattr(last, "timings", None):
