@@ -4,10 +4,9 @@
 
 Only the `reconstruct` subcommand exists.  Flags are spelled as in the reference (`--normals=on`, `-r 0.025`, ...).
 Differences, all of them loud:
-  * `--mesh-cleanup`, `--decimate-barnacles`, `--generate-quads` and the `--check-mesh*` family are not provided by the
-    device pipeline (sequential half-edge algorithms); switching one of them on is an error.  The reference enables
-    `--mesh-cleanup` implicitly when `--mesh-smoothing-iters` is given (reconstruct.rs:201-214); here that combination
-    requires an explicit `--mesh-cleanup=off`, so that nobody gets a different mesh without having asked for it.
+  * `--decimate-barnacles`, `--generate-quads` and the `--check-mesh*` family are not provided; switching one of them
+    on is an error.  `--mesh-cleanup` follows the reference's default (on as soon as `--mesh-smoothing-iters` is given and
+    not 0, reconstruct.rs:201-214) and runs as a host stage (see postprocessing.reconstruction_pipeline).
   * `--mt-files`, `--mt-particles`, `-n/--num-threads` and `--simd` are accepted and ignored: the work runs on the GPU.
 """
 import argparse
@@ -156,11 +155,9 @@ def _aabb(lo, hi, what):
 def pipeline_kwargs(args):
     """reconstruct.rs:604-698 (ReconstructionRunnerArgs::try_from) in terms of `reconstruction_pipeline`'s keywords."""
     unsupported = []
-    if args.mesh_cleanup is True or args.mesh_cleanup_snap_dist is not None:
-        unsupported.append("--mesh-cleanup")
-    if args.mesh_cleanup is None and args.mesh_smoothing_iters not in (None, 0):
-        raise CliError("the reference enables --mesh-cleanup implicitly when --mesh-smoothing-iters is given; mesh cleanup is not provided "
-                       "by this build: pass --mesh-cleanup=off explicitly to smooth the raw marching cubes mesh")
+    mesh_cleanup = args.mesh_cleanup
+    if mesh_cleanup is None:  # reconstruct.rs:201-214: "off" for 0 iterations, "on" as soon as the option is present
+        mesh_cleanup = args.mesh_smoothing_iters not in (None, 0)
     if args.decimate_barnacles:
         unsupported.append("--decimate-barnacles")
     if args.generate_quads:
@@ -181,7 +178,8 @@ def pipeline_kwargs(args):
         normals_smoothing_iters=args.normals_smoothing_iters, mesh_smoothing_iters=args.mesh_smoothing_iters,
         mesh_smoothing_weights=args.mesh_smoothing_weights, mesh_smoothing_weights_normalization=args.mesh_smoothing_weights_normalization,
         output_mesh_smoothing_weights=args.output_smoothing_weights, output_raw_normals=args.output_raw_normals, output_raw_mesh=args.output_raw_mesh,
-        mesh_aabb_min=mmin, mesh_aabb_max=mmax, mesh_aabb_clamp_vertices=args.mesh_aabb_clamp_verts, keep_vertices=args.keep_verts)
+        mesh_aabb_min=mmin, mesh_aabb_max=mmax, mesh_aabb_clamp_vertices=args.mesh_aabb_clamp_verts, keep_vertices=args.keep_verts,
+        mesh_cleanup=mesh_cleanup, mesh_cleanup_snap_dist=args.mesh_cleanup_snap_dist)
 
 
 def read_particles_with_attributes(path, names, dtype):

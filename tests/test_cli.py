@@ -43,15 +43,16 @@ def test_parameter_conversion_mirrors_the_binary():
 
 def test_unprovided_stages_fail_loudly():
     base = ["in.vtk", "-r", "0.01", "-l", "2", "-c", "1"]
-    for extra in (["--mesh-cleanup=on"], ["--decimate-barnacles=on"], ["--generate-quads=on"], ["--check-mesh=on"], ["--check-mesh-closed=on"],
-                  ["--mesh-cleanup-snap-dist", "0.1"]):
+    for extra in (["--decimate-barnacles=on"], ["--generate-quads=on"], ["--check-mesh=on"], ["--check-mesh-closed=on"]):
         with pytest.raises(cli.CliError):
             cli.pipeline_kwargs(_parse(*base, *extra))
-    # the reference switches cleanup on implicitly with smoothing (reconstruct.rs:201-214): an explicit off is required here
-    with pytest.raises(cli.CliError):
-        cli.pipeline_kwargs(_parse(*base, "--mesh-smoothing-iters=5"))
-    cli.pipeline_kwargs(_parse(*base, "--mesh-smoothing-iters=5", "--mesh-cleanup=off"))
-    cli.pipeline_kwargs(_parse(*base, "--mesh-smoothing-iters=0"))
+    # mesh cleanup: the binary's default is "on" as soon as --mesh-smoothing-iters is present and not 0 (reconstruct.rs:201-214)
+    assert cli.pipeline_kwargs(_parse(*base))["mesh_cleanup"] is False
+    assert cli.pipeline_kwargs(_parse(*base, "--mesh-smoothing-iters=5"))["mesh_cleanup"] is True
+    assert cli.pipeline_kwargs(_parse(*base, "--mesh-smoothing-iters=0"))["mesh_cleanup"] is False
+    assert cli.pipeline_kwargs(_parse(*base, "--mesh-smoothing-iters=5", "--mesh-cleanup=off"))["mesh_cleanup"] is False
+    kw = cli.pipeline_kwargs(_parse(*base, "--mesh-cleanup=on", "--mesh-cleanup-snap-dist", "0.5", "--keep-verts=on"))
+    assert kw["mesh_cleanup"] is True and kw["mesh_cleanup_snap_dist"] == 0.5 and kw["keep_vertices"] is True
     with pytest.raises(cli.CliError):
         cli.pipeline_kwargs(_parse(*base, "--mesh-aabb-min", "1", "0", "0", "--mesh-aabb-max", "0", "1", "1"))
 
@@ -101,5 +102,9 @@ def test_cli_end_to_end_matches_the_library_call(tmp_path):
     assert raw.vertices.shape == (33026, 3) and raw.triangles.shape == (66220, 3)
     assert out.vertices.shape == raw.vertices.shape and "normals" in out.point_attributes
     assert not np.array_equal(out.vertices, raw.vertices)  # smoothed
+    # the binary's default recipe: smoothing switches the (host-side) mesh cleanup on
+    assert cli.main(["reconstruct", str(src), "-r=0.025", "-l=2.0", "-c=1.1", "-o", str(tmp_path / "clean.obj"), "--mesh-smoothing-iters=3"]) == 0
+    clean = io.mesh_from_file(str(tmp_path / "clean.obj"))
+    assert 0 < clean.vertices.shape[0] < raw.vertices.shape[0] and clean.triangles.max() < clean.vertices.shape[0]
     # error path: exit code 1, nothing written
-    assert cli.main(["reconstruct", str(src), "-r=0.025", "-l=2.0", "-c=1.1", "--mesh-cleanup=on"]) == 1
+    assert cli.main(["reconstruct", str(src), "-r=0.025", "-l=2.0", "-c=1.1", "--decimate-barnacles=on"]) == 1

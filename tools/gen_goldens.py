@@ -341,6 +341,37 @@ def gen_post_goldens(report):
                             sph_normals_vs_oracle=float(np.abs(sph_normals - O.post_sph_normals(pts, rho, mass, h, V)).max()), sw_bits_equal_fraction=sw_bits_equal)
 
 
+def gen_cleanup_goldens(report):
+    """postprocessing::marching_cubes_cleanup (a host stage of the product): the reference's own raw mesh -- in ITS vertex and
+    triangle order, on which the result depends -- and the mesh the reference makes of it.  The mesh is kept small
+    (int32 triangles, one data set per Real type)."""
+    cases = [("cleanup_bunny", "bunny_frame_14_7705_particles.npy", 0.025, 2.0, 1.0, np.float32, None, False),
+             ("cleanup_bunny_snap_keep", "bunny_frame_14_7705_particles.npy", 0.025, 2.0, 1.0, np.float32, 0.35, True),
+             ("cleanup_f64_cube", "cube_2366_particles.npy", 0.025, 2.0, 0.75, np.float64, None, False)]
+    for name, fn, r, l, c, dt, snap, keep in cases:
+        pts = np.ascontiguousarray(np.load(os.path.join(DATA, fn)).astype(np.float32), dtype=dt)
+        # the reference's pipeline: raw mesh (rec.mesh, in the order of THIS run), cleanup, three unweighted smoothing passes
+        # with the connectivity the cleanup returned -- which pins that connectivity's order, the wheel does not hand it out
+        mwd, res = pysplashsurf.reconstruction_pipeline(pts, particle_radius=r, smoothing_length=l, cube_size=c, simd=False, subdomain_grid=True,
+                                                        subdomain_grid_auto_disable=False, mesh_cleanup=True, mesh_cleanup_snap_dist=snap,
+                                                        keep_vertices=keep, mesh_smoothing_iters=3, mesh_smoothing_weights=False)
+        mesh = res.mesh
+        V = np.asarray(mesh.vertices).copy()
+        T = np.asarray(mesh.triangles).copy()
+        SV = np.asarray(mwd.mesh.vertices).copy()
+        m2 = mesh.copy()
+        pysplashsurf.marching_cubes_cleanup(m2, res.grid, max_rel_snap_dist=snap, max_iter=5, keep_vertices=keep)
+        CV = np.asarray(m2.vertices).copy()
+        CT = np.asarray(m2.triangles).copy()
+        assert np.array_equal(CT, np.asarray(mwd.mesh.triangles)) and CV.shape == SV.shape, name
+        np.savez_compressed(os.path.join(GOLD, name + ".npz"), vertices=V, triangles=T.astype(np.int32), clean_vertices=CV, clean_triangles=CT.astype(np.int32), clean_smoothed_3=SV,
+                            grid_min=np.asarray(res.grid.aabb.min, dtype=dt), grid_max=np.asarray(res.grid.aabb.max, dtype=dt), cell_size=dt(res.grid.cell_size),
+                            n_points=np.asarray(res.grid.npoints_per_dim, dtype=np.int64), n_cells=np.asarray(res.grid.ncells_per_dim, dtype=np.int64),
+                            params=np.array(json.dumps(dict(particle_radius=r, smoothing_length=l, cube_size=c, max_rel_snap_dist=snap, keep_vertices=keep, max_iter=5))),
+                            input=np.array(json.dumps(dict(kind="file", file=fn))))
+        report[name] = dict(n_vertices=int(V.shape[0]), n_triangles=int(T.shape[0]), n_clean_vertices=int(CV.shape[0]), n_clean_triangles=int(CT.shape[0]))
+
+
 def main():
     os.makedirs(GOLD, exist_ok=True)
     if "--f64-only" in sys.argv:
@@ -348,6 +379,17 @@ def main():
         gen_f64_goldens(rep)
         for k, v in rep.items():
             print(k, v)
+        return
+    if "--cleanup-only" in sys.argv:
+        rep = {}
+        gen_cleanup_goldens(rep)
+        for k, v in rep.items():
+            print(k, v)
+        path = os.path.join(GOLD, "GENERATION_REPORT.json")
+        full = json.load(open(path)) if os.path.exists(path) else {}
+        full.update(rep)
+        with open(path, "w") as f:
+            json.dump(full, f, indent=1, default=lambda o: o.tolist() if hasattr(o, "tolist") else str(o))
         return
     if "--post-only" in sys.argv:
         rep = {}
