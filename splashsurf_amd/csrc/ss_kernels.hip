@@ -693,6 +693,7 @@ __device__ __forceinline__ void ss_wave_lds_sync() {
 }
 
 #define SS_PAY_CHUNK 512
+#define SS_WAVE_LIST 66  // survivors of one 64-entry batch per wave (+ 2 slots the read-ahead may touch)
 template <class R, int CAP>
 struct SplatShared {
     ss_real4<R> pay[SS_PAY_CHUNK];  // payload of 512 consecutive entries of the ordered tile
@@ -780,8 +781,63 @@ __device__ inline void splat_for_each_candidate(S& s, const SSDevT<R>& P, const 
 }
 
 // Accumulation of one wave's 4^3 sub-block over an index-ordered tile in LDS (dense_subdomains.rs:817-841).
+// Phase A tests 64 tile entries at once against the sub-block's box; the survivors are compacted IN ORDER into the wave's
+// own list `wl` (SS_WAVE_LIST entries), which phase B then walks front to back with a plain counter -- the scalar unit is
+// shared by the four SIMDs of a CU and walking a 64-bit survivor mask cost 14 scalar instructions per entry.
 template <class R, bool FASTDIV>
-__device__ __forceinline__ R splat_accumulate_wave(const SSDevT<R>& P, const ss_real4<R>* pay, int n_tile, int lane, R px, R py, R pz, const R slo[3],
+__device__ __forceinline__ R splat_accumulate_wave(const SSDevT<R>& P, const ss_real4<R>* pay, ss_real4<R>* wl, int n_tile, int lane, R px, R py, R pz,
+                                                   const R slo[3], const R shi[3], R wave_r2, R acc) {
+    const R rh = R(1.0) / P.h;
+    for (int base = 0; base < n_tile; base += 64) {
+        const int c = base + lane;
+        bool pass = false;
+        ss_real4<R> pv = ss_make4(R(0.0), R(0.0), R(0.0), R(0.0));
+        if (c < n_tile) {
+            pv = pay[c];
+            const R ex = ss_max(ss_max(slo[0] - pv.x, pv.x - shi[0]) - P.coord_slack, R(0.0));
+            const R ey = ss_max(ss_max(slo[1] - pv.y, pv.y - shi[1]) - P.coord_slack, R(0.0));
+            const R ez = ss_max(ss_max(slo[2] - pv.z, pv.z - shi[2]) - P.coord_slack, R(0.0));
+            pass = (ex * ex + ey * ey + ez * ez) <= wave_r2;
+        }
+        const unsigned long long wmask = __ballot(pass);
+        if (wmask) {
+            const int cnt = __popcll(wmask);
+            ss_wave_lds_sync();  // the previous batch's reads of wl are done
+            if (pass) wl[__builtin_amdgcn_mbcnt_hi((uint32_t)(wmask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)wmask, 0u))] = pv;
+            ss_wave_lds_sync();
+            // Entries are fetched with a wave-uniform LDS read (broadcast: LDS pipe, no VALU issue slot, operands arrive in
+            // VGPRs) one iteration ahead of their use; two entries per trip, ping-ponging between two register sets (no
+            // loop-carried copies).  Reads past cnt stay inside wl and are not used.
+            ss_real4<R> ea = wl[0];
+            for (int k = 0;; k += 2) {
+                const ss_real4<R> eb = wl[k + 1];
+                {
+                    const R dx = ea.x - px, dy = ea.y - py, dz = ea.z - pz;  // p_i - point, :828
+                    const R d2 = dx * dx + dy * dy + dz * dz;
+                    if (d2 < P.H2) {  // :831
+                        acc += ea.w * ss_kernel_w<R, FASTDIV>(d2, P.h, rh, P.sigma);  // :832-841
+                    }
+                }
+                if (k + 1 >= cnt) break;
+                ea = wl[k + 2];
+                {
+                    const R dx = eb.x - px, dy = eb.y - py, dz = eb.z - pz;
+                    const R d2 = dx * dx + dy * dy + dz * dz;
+                    if (d2 < P.H2) {
+                        acc += eb.w * ss_kernel_w<R, FASTDIV>(d2, P.h, rh, P.sigma);
+                    }
+                }
+                if (k + 2 >= cnt) break;
+            }
+        }
+    }
+    return acc;
+}
+
+// The same accumulation walking the survivor bit mask of each 64-entry batch directly (no per-wave list): the variant of the
+// large-tile kernel, which measured slower with the list (S10M-cube level set 37.2 instead of 32.8 ms).
+template <class R, bool FASTDIV>
+__device__ __forceinline__ R splat_accumulate_wave_mask(const SSDevT<R>& P, const ss_real4<R>* pay, int n_tile, int lane, R px, R py, R pz, const R slo[3],
                                                    const R shi[3], R wave_r2, R acc) {
     const R rh = R(1.0) / P.h;
     for (int base = 0; base < n_tile; base += 64) {
@@ -944,7 +1000,7 @@ __device__ __forceinline__ void splat_block(SplatShared<R, CAP>& s, const SSDevT
                 s.pay[rank] = posvol_by_index[my_idx];
             }
             __syncthreads();
-            if (wave_valid) acc = splat_accumulate_wave<R, FASTDIV>(P, s.pay, n_tile, lane, px, py, pz, slo, shi, wave_r2, acc);
+            if (wave_valid) acc = splat_accumulate_wave_mask<R, FASTDIV>(P, s.pay, n_tile, lane, px, py, pz, slo, shi, wave_r2, acc);
         } else {
             int m = 1024;
             while (m < n_tile) m <<= 1;
@@ -971,7 +1027,7 @@ __device__ __forceinline__ void splat_block(SplatShared<R, CAP>& s, const SSDevT
                 const int nc = min(SS_PAY_CHUNK, n_tile - c0);
                 if (tid < nc) s.pay[tid] = posvol_by_index[s.idx[c0 + tid]];
                 __syncthreads();
-                if (wave_valid) acc = splat_accumulate_wave<R, FASTDIV>(P, s.pay, nc, lane, px, py, pz, slo, shi, wave_r2, acc);
+                if (wave_valid) acc = splat_accumulate_wave_mask<R, FASTDIV>(P, s.pay, nc, lane, px, py, pz, slo, shi, wave_r2, acc);
                 __syncthreads();
             }
         }
@@ -1139,6 +1195,7 @@ __global__ __launch_bounds__(512) void k_splat_accumulate(SSDevT<R> P, const ss_
                                                           uint32_t n_active, R* __restrict__ G, ss_real2<R>* __restrict__ blk_minmax,
                                                           unsigned long long* __restrict__ cand_counter) {
     __shared__ ss_real4<R> s_pay[SS_WTILE];
+    __shared__ ss_real4<R> s_wl[8][SS_WAVE_LIST];
     __shared__ R s_red[16];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // XCD-aware mapping: hardware places workgroup w on XCD w % 8; give each XCD a contiguous range of
@@ -1172,7 +1229,7 @@ __global__ __launch_bounds__(512) void k_splat_accumulate(SSDevT<R> P, const ss_
     const R wave_r2 = P.H2 * R(1.0001);
     __syncthreads();
     R acc = R(0.0);  // levelset_grid.fill(0), dense_subdomains.rs:1390
-    if (wave_valid && n_tile) acc = splat_accumulate_wave<R, FASTDIV>(P, s_pay, n_tile, lane, px, py, pz, slo, shi, wave_r2, acc);
+    if (wave_valid && n_tile) acc = splat_accumulate_wave<R, FASTDIV>(P, s_pay, s_wl[wave], n_tile, lane, px, py, pz, slo, shi, wave_r2, acc);
     // store: block-local layout (x*8+y)*8+z, i-major / k-fastest like dense_subdomains.rs:839
     const int lx = ((wave >> 2) & 1) * 4 + ((lane >> 4) & 3);
     const int ly = ((wave >> 1) & 1) * 4 + ((lane >> 2) & 3);
