@@ -221,6 +221,9 @@ def test_dense_cloud_exceeding_tile_capacity(gpu_ctx, oracle):
     res = run_gpu(gpu_ctx, pts, prm)
     _, orc = run_oracle(oracle, pts, prm)
     assert res.stats["n_large_tile_blocks"] > 0 and res.stats["n_block_candidates"] > res.stats["n_active_blocks"] * 4096
+    st = res.stats  # stage timers of the three splat kernels (HIP events on the library's stream)
+    assert st["ms_levelset_gather"] > 0.0 and st["ms_levelset_accumulate"] > 0.0
+    assert st["ms_levelset"] >= st["ms_levelset_gather"] + st["ms_levelset_accumulate"]
     assert_gpu_equals_oracle(res, orc)
 
 
