@@ -273,3 +273,17 @@ def test_gpu_pipeline_with_mesh_cleanup(gpu_ctx, oracle):
     e = np.sort(np.concatenate([ct[:, [0, 1]], ct[:, [1, 2]], ct[:, [2, 0]]]), axis=1)
     _, counts = np.unique(e, axis=0, return_counts=True)
     assert np.all(counts == 2)
+
+
+def test_cpp_cleanup_over_c_abi(tmp_path):
+    """The C++ mirror (include/splashsurf_hip.hpp, splashsurf::postprocessing::marching_cubes_cleanup) over the C ABI on a
+    small known case: a host stage, so this runs without a device."""
+    import subprocess
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    exe = str(tmp_path / "test_cleanup_host")
+    libdir = os.path.join(root, "splashsurf_amd")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-I" + os.path.join(root, "include"), os.path.join(root, "tests", "cpp", "test_cleanup_host.cpp"),
+                           "-L" + libdir, "-lsplashsurf_hip", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib", "-o", exe])
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "cleanup host test ok" in out.stdout
