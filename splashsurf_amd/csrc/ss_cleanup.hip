@@ -16,6 +16,54 @@
 
 namespace {
 
+// Outgoing half-edges of a vertex: valence is 4..8 almost everywhere on a marching cubes mesh, so the first ten entries live
+// inline and only larger rings touch the heap (the reference's Vec<Vec<usize>> costs one allocation per vertex).
+class Ring {
+  public:
+    Ring() = default;
+    Ring(const Ring& o) { assign(o); }
+    Ring& operator=(const Ring& o) {
+        if (this != &o) assign(o);
+        return *this;
+    }
+    ~Ring() { delete[] heap_; }
+    size_t size() const { return n_; }
+    const uint32_t* begin() const { return data(); }
+    const uint32_t* end() const { return data() + n_; }
+    void clear() { n_ = 0; }
+    void push_back(uint32_t v) {
+        if (n_ == cap_) grow();
+        data()[n_++] = v;
+    }
+    void remove_value(uint32_t x) {  // Vec::retain(|h| *h != x)
+        uint32_t* d = data();
+        uint32_t w = 0;
+        for (uint32_t r = 0; r < n_; ++r)
+            if (d[r] != x) d[w++] = d[r];
+        n_ = w;
+    }
+
+  private:
+    static constexpr uint32_t kInline = 10;
+    uint32_t* data() { return heap_ ? heap_ : inline_; }
+    const uint32_t* data() const { return heap_ ? heap_ : inline_; }
+    void assign(const Ring& o) {
+        n_ = 0;
+        for (uint32_t v : o) push_back(v);
+    }
+    void grow() {
+        const uint32_t nc = cap_ * 2;
+        uint32_t* h = new uint32_t[nc];
+        std::memcpy(h, data(), n_ * sizeof(uint32_t));
+        delete[] heap_;
+        heap_ = h;
+        cap_ = nc;
+    }
+    uint32_t inline_[kInline];
+    uint32_t* heap_ = nullptr;
+    uint32_t n_ = 0, cap_ = kInline;
+};
+
 struct HalfEdge {  // halfedge_mesh.rs:17-30 (`idx` is the position in the array)
     uint32_t to;
     int32_t face;  // -1: boundary
@@ -28,7 +76,7 @@ struct HalfEdgeMesh {
     std::vector<std::array<R, 3>> vertices;
     std::vector<std::array<uint32_t, 3>> triangles;
     std::vector<HalfEdge> he;
-    std::vector<std::vector<uint32_t>> vmap;  // vertex_half_edge_map
+    std::vector<Ring> vmap;  // vertex_half_edge_map
     std::vector<uint8_t> removed_v, removed_t;
 
     // halfedge_mesh.rs:134-147: first outgoing half-edge of `from` that points to `to`
@@ -42,8 +90,7 @@ struct HalfEdgeMesh {
     void build(const R* v, uint64_t nv, const uint32_t* t, uint64_t nt) {
         vertices.resize(nv);
         for (uint64_t i = 0; i < nv; ++i) vertices[i] = {v[3 * i], v[3 * i + 1], v[3 * i + 2]};
-        vmap.assign(nv, {});
-        for (auto& m : vmap) m.reserve(5);
+        vmap.assign(nv, Ring());
         triangles.resize(nt);
         he.reserve(nt * 3);
         for (uint64_t f = 0; f < nt; ++f) {
@@ -115,8 +162,8 @@ struct HalfEdgeMesh {
         const HalfEdge eonn = he[eonn_idx];
         const uint32_t v_pos = en.to, v_neg = eon.to;
 
-        const std::vector<uint32_t> conn_from = vmap[v_from];
-        std::vector<uint32_t> conn_to = vmap[v_to];
+        const Ring conn_from = vmap[v_from];
+        Ring conn_to = vmap[v_to];
 
         if (e.face >= 0) removed_t[(size_t)e.face] = 1;
         if (eo.face >= 0) removed_t[(size_t)eo.face] = 1;
@@ -145,13 +192,8 @@ struct HalfEdgeMesh {
             he[ono].opposite = onno;
             he[onno].opposite = ono;
         }
-        {
-            std::vector<uint32_t> kept;
-            kept.reserve(conn_to.size() + conn_from.size());
-            for (uint32_t hh : conn_to)
-                if (hh != en_idx && hh != eo_idx) kept.push_back(hh);
-            conn_to.swap(kept);
-        }
+        conn_to.remove_value(en_idx);
+        conn_to.remove_value(eo_idx);
         for (uint32_t hh : conn_from)
             if (hh != e_idx && hh != eon_idx) conn_to.push_back(hh);
         for (uint32_t hh : conn_to) {
@@ -160,14 +202,8 @@ struct HalfEdgeMesh {
         }
         vmap[v_to] = conn_to;
         vmap[v_from].clear();
-        auto drop = [](std::vector<uint32_t>& m, uint32_t x) {
-            size_t w = 0;
-            for (size_t r = 0; r < m.size(); ++r)
-                if (m[r] != x) m[w++] = m[r];
-            m.resize(w);
-        };
-        drop(vmap[v_pos], enn_idx);
-        drop(vmap[v_neg], eonn_idx);
+        vmap[v_pos].remove_value(enn_idx);
+        vmap[v_neg].remove_value(eonn_idx);
     }
 };
 
