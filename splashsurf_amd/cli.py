@@ -4,8 +4,9 @@
 
 Only the `reconstruct` subcommand exists.  Flags are spelled as in the reference (`--normals=on`, `-r 0.025`, ...).
 Differences, all of them loud:
-  * `--decimate-barnacles`, `--generate-quads` and the `--check-mesh*` family are not provided; switching one of them
-    on is an error.  `--mesh-cleanup` follows the reference's default (on as soon as `--mesh-smoothing-iters` is given and
+  * `--decimate-barnacles` and `--generate-quads` are not provided; switching one of them on is an error.  The
+    `--check-mesh*` options run on the host; a finding fails the frame with the reference's message.  `--mesh-cleanup`
+    follows the reference's default (on as soon as `--mesh-smoothing-iters` is given and
     not 0, reconstruct.rs:201-214) and runs as a host stage (see postprocessing.reconstruction_pipeline).
   * `--mt-files`, `--mt-particles`, `-n/--num-threads` and `--simd` are accepted and ignored: the work runs on the GPU.
 """
@@ -162,8 +163,6 @@ def pipeline_kwargs(args):
         unsupported.append("--decimate-barnacles")
     if args.generate_quads:
         unsupported.append("--generate-quads")
-    if args.check_mesh or args.check_mesh_closed or args.check_mesh_manifold or args.check_mesh_orientation or args.check_mesh_debug:
-        unsupported.append("--check-mesh*")
     if unsupported:
         raise CliError("not provided by this build: " + ", ".join(unsupported))
     pmin, pmax = _aabb(args.particle_aabb_min, args.particle_aabb_max, "particle AABB")
@@ -179,7 +178,10 @@ def pipeline_kwargs(args):
         mesh_smoothing_weights=args.mesh_smoothing_weights, mesh_smoothing_weights_normalization=args.mesh_smoothing_weights_normalization,
         output_mesh_smoothing_weights=args.output_smoothing_weights, output_raw_normals=args.output_raw_normals, output_raw_mesh=args.output_raw_mesh,
         mesh_aabb_min=mmin, mesh_aabb_max=mmax, mesh_aabb_clamp_vertices=args.mesh_aabb_clamp_verts, keep_vertices=args.keep_verts,
-        mesh_cleanup=mesh_cleanup, mesh_cleanup_snap_dist=args.mesh_cleanup_snap_dist)
+        mesh_cleanup=mesh_cleanup, mesh_cleanup_snap_dist=args.mesh_cleanup_snap_dist,
+        # reconstruct.rs:660-666: --check-mesh switches the three checks on together
+        check_mesh_closed=args.check_mesh or args.check_mesh_closed, check_mesh_manifold=args.check_mesh or args.check_mesh_manifold,
+        check_mesh_orientation=args.check_mesh or args.check_mesh_orientation, check_mesh_debug=args.check_mesh_debug)
 
 
 def read_particles_with_attributes(path, names, dtype):
@@ -220,9 +222,10 @@ def run_reconstruct(args, log=None):
 
 def main(argv=None):
     args = build_parser().parse_args(argv)
+    from .postprocessing import MeshCheckError
     try:
         run_reconstruct(args)
-    except CliError as e:
+    except (CliError, MeshCheckError) as e:
         print("error: %s" % e, file=sys.stderr)
         return 1
     return 0

@@ -197,6 +197,79 @@ def marching_cubes_cleanup(vertices, triangles, grid, max_rel_snap_dist=None, ma
     return out_v[:n_v].copy(), out_t[:n_t].astype(np.uint64), VertexVertexConnectivity(row[:n_v + 1].copy(), idx[:n_c].copy())
 
 
+def check_mesh_consistency(vertices, triangles, check_closed=True, check_manifold=True, debug=False):
+    """`marching_cubes::check_mesh_consistency` (marching_cubes.rs:129-213): boundary edges (one incident triangle),
+    non-manifold edges (more than two) and non-manifold vertices (more than one triangle fan, mesh.rs:1007-1088).
+    Host-side numpy / scipy.  Returns None if nothing was found, otherwise the reference's summary lines (its `debug`
+    per-edge details depend on the grid and on hash order and are not reproduced)."""
+    t = np.asarray(_to_numpy(triangles)).reshape(-1, 3).astype(np.int64)
+    nt = int(t.shape[0])
+    nv = int(np.asarray(_to_numpy(vertices)).reshape(-1, 3).shape[0])
+    if nt == 0:
+        return None
+    e = np.concatenate([t[:, [0, 1]], t[:, [1, 2]], t[:, [2, 0]]], axis=0)  # compute_edge_information (mesh.rs:955-997)
+    key = np.minimum(e[:, 0], e[:, 1]) * np.int64(nv) + np.maximum(e[:, 0], e[:, 1])
+    _, counts = np.unique(key, return_counts=True)
+    n_boundary = int(np.count_nonzero(counts == 1))
+    n_non_manifold_edges = int(np.count_nonzero(counts > 2))
+    n_non_manifold_vertices = 0
+    if check_manifold:
+        # a vertex is manifold iff its incident triangles form ONE fan, i.e. are connected through edges at that vertex:
+        # nodes = (triangle, corner) incidences, joined when two incidences of the same vertex share an edge (vertex, w)
+        from scipy.sparse import coo_matrix
+        from scipy.sparse.csgraph import connected_components
+        corner = np.arange(3 * nt, dtype=np.int64)                     # node id = 3 * triangle + local corner
+        v = t.reshape(-1)                                              # vertex of the incidence
+        w1 = np.roll(t, -1, axis=1).reshape(-1)                        # the two other vertices of the triangle
+        w2 = np.roll(t, -2, axis=1).reshape(-1)
+        node = np.concatenate([corner, corner])
+        ekey = np.concatenate([v * np.int64(nv) + w1, v * np.int64(nv) + w2])
+        order = np.argsort(ekey, kind="stable")
+        ks, ns = ekey[order], node[order]
+        same = ks[1:] == ks[:-1]
+        g = coo_matrix((np.ones(int(same.sum()), dtype=np.int8), (ns[:-1][same], ns[1:][same])), shape=(3 * nt, 3 * nt))
+        _, label = connected_components(g, directed=False)
+        pairs = np.unique(np.stack([v, label.astype(np.int64)], axis=1), axis=0)  # (vertex, component)
+        _, fans = np.unique(pairs[:, 0], return_counts=True)
+        n_non_manifold_vertices = int(np.count_nonzero(fans > 1))
+    if (not check_closed or n_boundary == 0) and (not check_manifold or (n_non_manifold_edges == 0 and n_non_manifold_vertices == 0)):
+        return None
+    lines = []
+    if check_closed and n_boundary:
+        lines.append("Mesh is not closed. It has %d boundary edges (edges that are connected to only one triangle)." % n_boundary)
+    if check_manifold and n_non_manifold_edges:
+        lines.append("Mesh is not manifold. It has %d non-manifold edges (edges that are connected to more than two triangles)." % n_non_manifold_edges)
+    if check_manifold and n_non_manifold_vertices:
+        lines.append("Mesh is not manifold. It has %d non-manifold vertices (vertices with more than one triangle fan)." % n_non_manifold_vertices)
+    return "\n".join(lines)
+
+
+def check_mesh_orientation(vertices, triangles):
+    """The binary's `--check-mesh-orientation` (reconstruct.rs:1480-1540): faces whose normal is flipped (angle > 0.99 pi)
+    against the area-weighted normal of one of their vertices.  Returns None or the reference's summary line."""
+    v = np.asarray(_to_numpy(vertices), dtype=np.float64).reshape(-1, 3)
+    t = np.asarray(_to_numpy(triangles)).reshape(-1, 3).astype(np.int64)
+    if t.shape[0] == 0:
+        return None
+    cr = np.cross(v[t[:, 1]] - v[t[:, 0]], v[t[:, 2]] - v[t[:, 1]])  # tri_normal_ijk: (v1 - v0) x (v2 - v1), normalised
+    tn = cr / np.maximum(np.linalg.norm(cr, axis=1, keepdims=True), 1e-300)
+    vn = np.zeros_like(v)
+    for c in range(3):
+        np.add.at(vn, t[:, c], cr)  # area-weighted sum (mesh.rs:782-796), then normalised
+    vn /= np.maximum(np.linalg.norm(vn, axis=1, keepdims=True), 1e-300)
+    flipped = np.zeros(t.shape[0], dtype=bool)
+    for c in range(3):
+        cosang = np.clip(np.einsum("ij,ij->i", vn[t[:, c]], tn), -1.0, 1.0)
+        flipped |= np.arccos(cosang) > np.pi * 0.99
+    n = int(np.count_nonzero(flipped))
+    if n == 0:
+        return None
+    return "Mesh is not consistently oriented. Found %d faces with normals flipped relative to adjacent vertices." % n
+
+
+check_mesh_orientation_fn = check_mesh_orientation  # the pipeline has a keyword of the same name
+
+
 def vertex_normals(vertices, triangles, context=None):
     """TriMesh3d::vertex_normals (area-weighted, normalised; sequential summation order of mesh.rs:782-796)."""
     ctx = _ctx(context)
@@ -365,8 +438,11 @@ class MeshWithData:
         return int(self.mesh.triangles.shape[0])
 
 
-_UNSUPPORTED = dict(check_mesh_closed=False, check_mesh_manifold=False, check_mesh_orientation=False, check_mesh_debug=False, decimate_barnacles=False,
-                    generate_quads=False)
+_UNSUPPORTED = dict(decimate_barnacles=False, generate_quads=False)
+
+
+class MeshCheckError(RuntimeError):
+    """A `check_mesh_*` option of the pipeline found a problem (reconstruct.rs:1446-1540: the binary fails the frame)."""
 
 
 def reconstruction_pipeline(particles, *, attributes_to_interpolate=None, particle_radius, rest_density=1000.0, smoothing_length, cube_size,
@@ -376,7 +452,8 @@ def reconstruction_pipeline(particles, *, attributes_to_interpolate=None, partic
                             mesh_smoothing_weights_normalization=13.0, output_mesh_smoothing_weights=False, output_raw_normals=False,
                             output_raw_mesh=False, quad_max_edge_diag_ratio=1.75, quad_max_normal_angle=10.0, quad_max_interior_angle=135.0,
                             mesh_aabb_min=None, mesh_aabb_max=None, mesh_aabb_clamp_vertices=True, keep_vertices=False, mesh_cleanup=False,
-                            mesh_cleanup_snap_dist=None, context=None, **unsupported):
+                            mesh_cleanup_snap_dist=None, check_mesh_closed=False, check_mesh_manifold=False, check_mesh_orientation=False,
+                            check_mesh_debug=False, context=None, **unsupported):
     """pysplashsurf.reconstruction_pipeline (splashsurf/src/reconstruct.rs:1022-1345): reconstruction followed by the
     post-processing stages provided on the GPU -- smoothing weights, weighted Laplacian smoothing, normals (mesh or
     SPH), normal smoothing, attribute interpolation, clamping to a mesh AABB.  The mesh stays in HBM between the device
@@ -384,8 +461,9 @@ def reconstruction_pipeline(particles, *, attributes_to_interpolate=None, partic
     mesh goes to the host, is simplified there and returns to HBM together with the connectivity the cleanup produced.  Its
     result depends on the vertex and triangle ORDER of the raw mesh; the reference's order follows the iteration order of a
     concurrent hash map over the subdomains (dense_subdomains.rs:387-424), ours is the canonical order of this library, so
-    cleaned meshes agree with the reference's as surfaces but not vertex by vertex.  Barnacle decimation, quad conversion
-    and the mesh checks are not provided and raise.
+    cleaned meshes agree with the reference's as surfaces but not vertex by vertex.  The `check_mesh_*` options run on the
+    final mesh on the host and raise MeshCheckError like the binary fails the frame.  Barnacle decimation and quad
+    conversion are not provided and raise.
     Returns (MeshWithData, SurfaceReconstruction) with numpy arrays."""
     import torch
     for k, v in unsupported.items():
@@ -482,6 +560,15 @@ def reconstruction_pipeline(particles, *, attributes_to_interpolate=None, partic
         out_v, out_t, mesh_with_data.point_attributes = clamp_with_aabb(out_v, out_t, mesh_aabb_min, mesh_aabb_max, clamp_vertices=mesh_aabb_clamp_vertices,
                                                                         keep_vertices=keep_vertices, point_attributes=mesh_with_data.point_attributes)
     mesh_with_data.mesh = TriMesh3d(out_v, out_t, ctx)
+    if check_mesh_closed or check_mesh_manifold:  # reconstruct.rs:1446-1478
+        problems = check_mesh_consistency(out_v, out_t, check_closed=check_mesh_closed, check_manifold=check_mesh_manifold, debug=check_mesh_debug)
+        if problems:
+            raise MeshCheckError("Checked mesh for problems (holes: %s, non-manifold edges/vertices: %s), problems were found!\n%s"
+                                 % (str(bool(check_mesh_closed)).lower(), str(bool(check_mesh_manifold)).lower(), problems))
+    if check_mesh_orientation:  # reconstruct.rs:1480-1540
+        problems = check_mesh_orientation_fn(out_v, out_t)
+        if problems:
+            raise MeshCheckError("Checked mesh orientation (flipped normals), problems were found!\n" + problems)
     if output_raw_mesh:
         mesh_with_data.raw_vertices = raw_vertices
     return mesh_with_data, rec

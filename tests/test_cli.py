@@ -43,9 +43,13 @@ def test_parameter_conversion_mirrors_the_binary():
 
 def test_unprovided_stages_fail_loudly():
     base = ["in.vtk", "-r", "0.01", "-l", "2", "-c", "1"]
-    for extra in (["--decimate-barnacles=on"], ["--generate-quads=on"], ["--check-mesh=on"], ["--check-mesh-closed=on"]):
+    for extra in (["--decimate-barnacles=on"], ["--generate-quads=on"]):
         with pytest.raises(cli.CliError):
             cli.pipeline_kwargs(_parse(*base, *extra))
+    kw = cli.pipeline_kwargs(_parse(*base, "--check-mesh=on"))  # reconstruct.rs:660-666: the three checks together
+    assert kw["check_mesh_closed"] and kw["check_mesh_manifold"] and kw["check_mesh_orientation"] and not kw["check_mesh_debug"]
+    kw = cli.pipeline_kwargs(_parse(*base, "--check-mesh-closed=on"))
+    assert kw["check_mesh_closed"] and not kw["check_mesh_manifold"] and not kw["check_mesh_orientation"]
     # mesh cleanup: the binary's default is "on" as soon as --mesh-smoothing-iters is present and not 0 (reconstruct.rs:201-214)
     assert cli.pipeline_kwargs(_parse(*base))["mesh_cleanup"] is False
     assert cli.pipeline_kwargs(_parse(*base, "--mesh-smoothing-iters=5"))["mesh_cleanup"] is True
@@ -103,7 +107,7 @@ def test_cli_end_to_end_matches_the_library_call(tmp_path):
     assert out.vertices.shape == raw.vertices.shape and "normals" in out.point_attributes
     assert not np.array_equal(out.vertices, raw.vertices)  # smoothed
     # the binary's default recipe: smoothing switches the (host-side) mesh cleanup on
-    assert cli.main(["reconstruct", str(src), "-r=0.025", "-l=2.0", "-c=1.1", "-o", str(tmp_path / "clean.obj"), "--mesh-smoothing-iters=3"]) == 0
+    assert cli.main(["reconstruct", str(src), "-r=0.025", "-l=2.0", "-c=1.1", "-o", str(tmp_path / "clean.obj"), "--mesh-smoothing-iters=3", "--check-mesh=on"]) == 0
     clean = io.mesh_from_file(str(tmp_path / "clean.obj"))
     assert 0 < clean.vertices.shape[0] < raw.vertices.shape[0] and clean.triangles.max() < clean.vertices.shape[0]
     # error path: exit code 1, nothing written

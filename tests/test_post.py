@@ -287,3 +287,40 @@ def test_cpp_cleanup_over_c_abi(tmp_path):
     out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "cleanup host test ok" in out.stdout
+
+
+def _apply_mesh_check_mutation(T, ops):
+    """The edits of tools/gen_goldens.py (apply_mesh_check_mutation), replayed on the same raw mesh."""
+    for op in ops:
+        if op[0] == "copy_face":
+            T[op[1]] = T[op[2]]
+        elif op[0] == "merge_vertices":
+            (fa, ca), (where, cb) = op[1], op[2]
+            fb = len(T) // 2 if where == "half" else len(T) // 3
+            a, b = int(T[fa, ca]), int(T[fb, cb])
+            T[T == b] = a
+    return T
+
+
+def test_mesh_checks_give_the_reference_messages():
+    """marching_cubes::check_mesh_consistency (marching_cubes.rs:129-213): holes, non-manifold edges and non-manifold
+    vertices on edited copies of a raw mesh -- the same findings, worded as the reference words them."""
+    from splashsurf_amd import postprocessing as PP
+    fx = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "mesh_check_messages.json")))
+    g = load_golden(fx["base"][:-4])
+    V = g["vertices"]
+    for name, ops in fx["mutations"].items():
+        T = _apply_mesh_check_mutation(g["triangles"].astype(np.uint64).copy(), ops)
+        for key, expect in fx["messages"][name].items():
+            closed, manifold = key == "closed=1,manifold=1" or key.startswith("closed=1"), key.endswith("manifold=1")
+            assert PP.check_mesh_consistency(V, T, check_closed=closed, check_manifold=manifold) == expect, (name, key)
+    assert fx["messages"]["good"]["closed=1,manifold=1"] is None and "boundary edges" in fx["messages"]["duplicate_face"]["closed=1,manifold=1"]
+    # orientation (reconstruct.rs:1480-1540): a consistently oriented closed mesh passes; a lone flipped face on a flat patch is found
+    assert PP.check_mesh_orientation(V, g["triangles"]) is None
+    quad_v = np.array([[0, 0, 0], [1, 0, 0], [1, 1, 0], [0, 1, 0], [2, 0, 0], [2, 1, 0]], dtype=np.float32)
+    quad_t = np.array([[0, 1, 2], [0, 2, 3], [1, 4, 5], [1, 5, 2]], dtype=np.uint64)
+    assert PP.check_mesh_orientation(quad_v, quad_t) is None
+    flipped = quad_t.copy()
+    flipped[3] = flipped[3][::-1]
+    msg = PP.check_mesh_orientation(quad_v, flipped)
+    assert msg is not None and msg.startswith("Mesh is not consistently oriented. Found ")

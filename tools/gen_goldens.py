@@ -372,11 +372,65 @@ def gen_cleanup_goldens(report):
         report[name] = dict(n_vertices=int(V.shape[0]), n_triangles=int(T.shape[0]), n_clean_vertices=int(CV.shape[0]), n_clean_triangles=int(CT.shape[0]))
 
 
+
+MESH_CHECK_MUTATIONS = {
+    # name -> list of (op, args) replayed by tests/test_post.py on the raw mesh of tests/golden/cleanup_bunny.npz
+    "good": [],
+    "duplicate_face": [("copy_face", 0, 1)],
+    "bow_tie": [("merge_vertices", (0, 0), ("half", 0))],
+    "several": [("copy_face", 0, 1), ("copy_face", 5, 1), ("merge_vertices", (10, 0), ("third", 1))],
+}
+
+
+def apply_mesh_check_mutation(T, ops):
+    """In-place edits of a triangle array (shared with the test)."""
+    for op in ops:
+        if op[0] == "copy_face":
+            T[op[1]] = T[op[2]]
+        elif op[0] == "merge_vertices":
+            (fa, ca), (where, cb) = op[1], op[2]
+            fb = len(T) // 2 if where == "half" else len(T) // 3
+            a, b = int(T[fa, ca]), int(T[fb, cb])
+            T[T == b] = a
+    return T
+
+
+def gen_mesh_check_goldens(report):
+    """marching_cubes::check_mesh_consistency: the reference's messages for edited copies of the raw mesh stored in
+    cleanup_bunny.npz (the wheel cannot build a mesh from arrays, but the arrays of one of its meshes are writeable)."""
+    g = np.load(os.path.join(GOLD, "cleanup_bunny.npz"))
+    V, T = g["vertices"], g["triangles"].astype(np.uint64)
+    prm = json.loads(str(g["params"]))
+    pts = np.load(os.path.join(DATA, json.loads(str(g["input"]))["file"])).astype(np.float32)
+    rec = pysplashsurf.reconstruct_surface(pts, particle_radius=prm["particle_radius"], smoothing_length=prm["smoothing_length"], cube_size=prm["cube_size"],
+                                           simd=False, subdomain_grid=True, subdomain_grid_auto_disable=False)
+    out = {}
+    for name, ops in MESH_CHECK_MUTATIONS.items():
+        m = rec.mesh.copy()
+        assert m.vertices.shape == V.shape and m.triangles.shape == T.shape
+        m.vertices[...] = V
+        m.triangles[...] = T
+        apply_mesh_check_mutation(m.triangles, ops)
+        out[name] = {}
+        for closed, manifold in ((True, True), (True, False), (False, True)):
+            out[name]["closed=%d,manifold=%d" % (closed, manifold)] = pysplashsurf.check_mesh_consistency(m, rec.grid, check_closed=closed, check_manifold=manifold,
+                                                                                                           debug=False)
+    with open(os.path.join(GOLD, "mesh_check_messages.json"), "w") as f:
+        json.dump(dict(base="cleanup_bunny.npz", mutations={k: [list(o) for o in v] for k, v in MESH_CHECK_MUTATIONS.items()}, messages=out), f, indent=1)
+    report["mesh_check_messages"] = {k: v["closed=1,manifold=1"] for k, v in out.items()}
+
+
 def main():
     os.makedirs(GOLD, exist_ok=True)
     if "--f64-only" in sys.argv:
         rep = {}
         gen_f64_goldens(rep)
+        for k, v in rep.items():
+            print(k, v)
+        return
+    if "--mesh-checks-only" in sys.argv:
+        rep = {}
+        gen_mesh_check_goldens(rep)
         for k, v in rep.items():
             print(k, v)
         return
