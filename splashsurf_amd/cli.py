@@ -185,18 +185,15 @@ def pipeline_kwargs(args):
 
 
 def read_particles_with_attributes(path, names, dtype):
-    """splashsurf/src/io.rs read_particle_positions_with_attributes: attributes come from VTK point data only."""
+    """splashsurf/src/io.rs:68-190 read_particle_positions_with_attributes: attributes come from VTK point data or BGEO."""
     from . import io
     particles = io.particles_from_file(path, dtype=dtype)
     attrs = {}
     if names:
-        if io._ext(path) != "vtk":
-            raise CliError("attributes can only be read from VTK files")
-        data = io._read_vtk(path)["point_data"]
-        for n in names:
-            if n not in data:
-                raise CliError('attribute "%s" not found in "%s"' % (n, path))
-            attrs[n] = np.asarray(data[n])
+        try:
+            attrs = io.particle_attributes_from_file(path, list(names))
+        except ValueError as e:
+            raise CliError(str(e))
     return particles, attrs
 
 

@@ -6,7 +6,7 @@ layouts of the reference's `splashsurf_lib::io` (citations relative to /root/ref
 
 Formats: legacy VTK (`vtk_format.rs`, written like the vtkio crate does: version 4.2, BINARY big-endian,
 UNSTRUCTURED_GRID), raw little-endian XYZ triples (`xyz_format.rs`), PLY (`ply_format.rs`), OBJ (`obj_format.rs`),
-BGEO v5 particles, optionally gzip-compressed (`bgeo_format.rs`, read only), JSON arrays (`json_format.rs`).
+BGEO v5 particles and point attributes, optionally gzip-compressed (`bgeo_format.rs`), JSON arrays (`json_format.rs`).
 The writers reproduce the reference's files byte for byte (tests/golden/io/ holds files written by the reference).
 Plain host-side Python/numpy: file IO is not on the GPU path.
 """
@@ -270,25 +270,71 @@ def _read_ply(path):
 # ------------------------------------------------------------------------------------------------------------
 # BGEO (v5, particles)
 # ------------------------------------------------------------------------------------------------------------
-def _read_bgeo_points(path):
+def _read_bgeo(path, want_attributes=False):
+    """BGEO version 5 as the reference parses it (bgeo_format.rs:365-640): header, point attribute definitions, then per
+    point x, y, z, an unnamed float ("unknown" in the reference) and the named attributes.  Returns (positions,
+    {name: array}) with float attributes as float32, integer ones as uint64, 3-vectors as (N, 3) float32
+    (bgeo_format.rs:332-350)."""
     raw = open(path, "rb").read()
     if raw[:2] == b"\x1f\x8b":
         raw = gzip.decompress(raw)
+    if raw[:4] == b"\x7fNSJ":
+        raise ValueError("unsupported BGEO format version (the new JSON-like BGEO format)")
     if raw[:5] != b"BgeoV" or struct.unpack(">i", raw[5:9])[0] != 5:
         raise ValueError("unsupported BGEO file (expected version 5)")
     n_points, _n_prims, _n_pg, _n_prg, n_pattr = struct.unpack(">5i", raw[9:29])
     off = 41
     psize = 4
+    defs = []
     for _ in range(n_pattr):
         (ln,) = struct.unpack(">H", raw[off:off + 2])
+        name = raw[off + 2:off + 2 + ln].decode("utf-8")
         off += 2 + ln
         (size,) = struct.unpack(">H", raw[off:off + 2])
         off += 2
-        off += 4          # attribute type
-        off += 4 * size   # default value
+        (atype,) = struct.unpack(">i", raw[off:off + 4])
+        off += 4
+        if atype not in (0, 1, 5):  # Float, Int, Vector; strings are rejected by the reference as well
+            raise ValueError("unsupported BGEO attribute type %d of attribute '%s'" % (atype, name))
+        off += 4 * size   # default values
+        defs.append((name, size, atype, psize))
         psize += size
     data = np.frombuffer(raw, dtype=">f4", count=psize * n_points, offset=off).reshape(n_points, psize)
-    return data[:, :3].astype(np.float32)
+    positions = data[:, :3].astype(np.float32)
+    attrs = {}
+    if want_attributes:
+        ints = np.frombuffer(raw, dtype=">i4", count=psize * n_points, offset=off).reshape(n_points, psize)
+        for name, size, atype, col in defs:
+            if atype == 1:
+                a = ints[:, col:col + size]
+                if a.size and int(a.min()) < 0:
+                    raise ValueError('Failed to convert attribute "%s": failed to convert integer attribute' % name)
+                attrs[name] = a.astype(np.uint64).reshape(n_points) if size == 1 else a.astype(np.uint64)
+            elif atype == 0:
+                a = data[:, col:col + size].astype(np.float32)
+                attrs[name] = a.reshape(n_points) if size == 1 else a
+            else:
+                if size != 3:
+                    attrs[name] = ValueError('Failed to convert attribute "%s": unsupported vector attribute size: %d' % (name, size))
+                else:
+                    attrs[name] = data[:, col:col + 3].astype(np.float32)
+    return positions, attrs
+
+
+def _read_bgeo_points(path):
+    return _read_bgeo(path)[0]
+
+
+def _bgeo_bytes(particles):
+    """particles_to_bgeo (bgeo_format.rs:108-257): no named attributes, the unnamed float is 1.0, end bytes 00 ff."""
+    p = np.ascontiguousarray(particles, dtype=np.float32).reshape(-1, 3)
+    n = int(p.shape[0])
+    if n > 2 ** 31 - 1:
+        raise ValueError("number of particles (%d) is too large for bgeo format (max %d)" % (n, 2 ** 31 - 1))
+    rec = np.empty((n, 4), dtype=">f4")
+    rec[:, :3] = p
+    rec[:, 3] = 1.0
+    return b"Bgeo" + b"V" + struct.pack(">i", 5) + struct.pack(">8i", n, 0, 0, 0, 0, 0, 0, 0) + rec.tobytes() + b"\x00\xff"
 
 
 # ------------------------------------------------------------------------------------------------------------
@@ -320,8 +366,29 @@ def particles_from_file(path, dtype=np.float32):
     return np.ascontiguousarray(p, dtype=dtype)
 
 
+def particle_attributes_from_file(path, names):
+    """Point attributes of a particle file as the binary reads them for `-a` (splashsurf/src/io.rs:68-190): legacy VTK
+    point data or BGEO attributes.  Returns {name: array}; a missing name is an error."""
+    e = _ext(path)
+    if e == "vtk":
+        data = _read_vtk(path)["point_data"]
+    elif e == "bgeo":
+        data = _read_bgeo(path, want_attributes=True)[1]
+    else:
+        raise ValueError('Unsupported file format extension "%s" for reading attributes (VTK and BGEO carry attributes)' % e)
+    missing = [n for n in names if n not in data]
+    if missing:
+        raise ValueError('Missing attribute(s) "%s" in input file' % '", "'.join(missing))
+    out = {}
+    for n in names:
+        if isinstance(data[n], Exception):
+            raise data[n]
+        out[n] = np.asarray(data[n])
+    return out
+
+
 def particles_to_file(particles, path):
-    """vtk / json as the reference's CLI writes them (splashsurf/src/io.rs:200-230), plus raw xyz."""
+    """vtk / json / bgeo as the reference's CLI writes them (splashsurf/src/io.rs:200-230), plus raw xyz."""
     p = np.ascontiguousarray(particles)
     e = _ext(path)
     if e == "vtk":  # vtk_format.rs:159-169: one VERTEX cell per particle
@@ -335,6 +402,8 @@ def particles_to_file(particles, path):
         data = ("[" + ",".join(rows) + "]").encode("ascii")
     elif e == "xyz":
         data = p.astype("<f4").tobytes()
+    elif e == "bgeo":  # the binary compresses by default (flate2 "fast"); the deflate stream is zlib's here, the content the same
+        data = gzip.compress(_bgeo_bytes(p), compresslevel=1, mtime=0)
     else:
         raise ValueError('Unsupported file format extension "%s" for writing particles' % e)
     with open(path, "wb") as f:

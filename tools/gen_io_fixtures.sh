@@ -27,3 +27,18 @@ for ext in vtk ply obj; do
   ss reconstruct "$OUT/cube8.xyz" -o "$OUT/mesh_plain.$ext" -r 0.025 -l 2.0 -c 1.0 --subdomain-grid=off -q
 done
 ls -la "$OUT"
+# BGEO point attributes: the reference's own data file (copied to tests/data/) through `reconstruct -a density -a velocity`;
+# the interpolated attributes at the output vertices pin OUR reading of the attribute columns (tests/test_io.py).
+BG=$ROOT/tests/data/dam_break_frame_9_6859_particles.bgeo
+ss reconstruct "$BG" -o "$TMP/bgeo_attr.vtk" -r 0.025 -l 2.0 -c 1.0 -a density -a velocity --mesh-cleanup=off -q
+python - "$ROOT" "$TMP/bgeo_attr.vtk" "$OUT/bgeo_attributes_reference.npz" <<'PY'
+import sys, numpy as np
+sys.path.insert(0, sys.argv[1])
+from splashsurf_amd import io
+m = io.mesh_from_file(sys.argv[2])
+n = m.vertices.shape[0]
+sel = np.arange(0, n, max(1, n // 400))
+np.savez_compressed(sys.argv[3], vertices=m.vertices[sel], density=m.point_attributes["density"][sel], velocity=m.point_attributes["velocity"][sel],
+                    n_vertices=np.int64(n))
+print("bgeo attribute golden:", n, "vertices,", sel.size, "kept")
+PY
