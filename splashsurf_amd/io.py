@@ -5,7 +5,7 @@ layouts of the reference's `splashsurf_lib::io` (citations relative to /root/ref
     mesh_from_file / mesh_to_file               splashsurf/src/io.rs:245-305
 
 Formats: legacy VTK (`vtk_format.rs`, written like the vtkio crate does: version 4.2, BINARY big-endian,
-UNSTRUCTURED_GRID), raw little-endian XYZ triples (`xyz_format.rs`), PLY (`ply_format.rs`), OBJ (`obj_format.rs`),
+UNSTRUCTURED_GRID), XML VTK `.vtu` (read only), raw little-endian XYZ triples (`xyz_format.rs`), PLY (`ply_format.rs`), OBJ (`obj_format.rs`),
 BGEO v5 particles and point attributes, optionally gzip-compressed (`bgeo_format.rs`), JSON arrays (`json_format.rs`).
 The writers reproduce the reference's files byte for byte (tests/golden/io/ holds files written by the reference).
 Plain host-side Python/numpy: file IO is not on the GPU path.
@@ -155,6 +155,108 @@ def _read_vtk(path, points_only=False):
     if out["points"] is None:
         raise ValueError("VTK file has no POINTS section")
     return out
+
+
+_VTU_TYPES = {"Float32": "f4", "Float64": "f8", "Int8": "i1", "UInt8": "u1", "Int16": "i2", "UInt16": "u2", "Int32": "i4", "UInt32": "u4",
+              "Int64": "i8", "UInt64": "u8"}
+
+
+def _read_vtu(path):
+    """XML VTK UnstructuredGrid (`.vtu`, what vtkio reads for the reference: vtk_format.rs:40-140): first Piece; data arrays
+    in ascii, inline base64 ("binary") or appended (raw / base64) form, 32- or 64-bit block headers, optional
+    vtkZLibDataCompressor.  Returns dict(points, point_data) like _read_vtk."""
+    import base64
+    import re
+    import xml.etree.ElementTree as ET
+    import zlib
+    raw = open(path, "rb").read()
+    appended, enc = None, None
+    m = re.search(rb"<AppendedData[^>]*>", raw)
+    xml_part = raw
+    if m:
+        enc = re.search(rb'encoding="(\w+)"', m.group(0))
+        enc = enc.group(1).decode() if enc else "base64"
+        start = raw.index(b"_", m.end()) + 1
+        end = raw.rindex(b"</AppendedData>")
+        appended = raw[start:end]
+        xml_part = raw[:m.start()] + raw[end + len(b"</AppendedData>"):]
+    root = ET.fromstring(xml_part)
+    if root.tag != "VTKFile" or root.get("type") != "UnstructuredGrid":
+        raise ValueError("VTK file does not contain supported data set pieces")
+    bo = "<" if root.get("byte_order", "LittleEndian") == "LittleEndian" else ">"
+    hdr = bo + ("u8" if root.get("header_type", "UInt32") == "UInt64" else "u4")
+    hsize = np.dtype(hdr).itemsize
+    compressed = root.get("compressor") is not None
+    if compressed and root.get("compressor") != "vtkZLibDataCompressor":
+        raise NotImplementedError("VTU compressor %s is not supported" % root.get("compressor"))
+    piece = root.find("./UnstructuredGrid/Piece")
+    if piece is None:
+        raise ValueError('VTK file does not contain a supported "piece".')
+    n_points = int(piece.get("NumberOfPoints"))
+
+    def decode_blocks(buf, is_base64):
+        """One data array from `buf` (positioned at its header): returns the decoded payload bytes."""
+        def take(nbytes, pos):
+            if not is_base64:
+                return buf[pos:pos + nbytes], pos + nbytes
+            # base64 encodes header and payload as separate, individually padded streams
+            nchar = ((nbytes + 2) // 3) * 4
+            return base64.b64decode(buf[pos:pos + nchar])[:nbytes], pos + nchar
+        if not compressed:
+            h, pos = take(hsize, 0)
+            n = int(np.frombuffer(h, dtype=hdr)[0])
+            if is_base64:  # header and data share one base64 stream here
+                nchar = ((hsize + n + 2) // 3) * 4
+                return base64.b64decode(buf[:nchar])[hsize:hsize + n]
+            return buf[pos:pos + n]
+        h, pos = take(3 * hsize, 0)
+        nblocks, _bsize, _last = (int(x) for x in np.frombuffer(h, dtype=hdr))
+        if is_base64:  # the whole header (3 + nblocks words) is one base64 stream, the compressed blocks another
+            hbytes = (3 + nblocks) * hsize
+            nchar = ((hbytes + 2) // 3) * 4
+            sizes = np.frombuffer(base64.b64decode(buf[:nchar])[3 * hsize:hbytes], dtype=hdr)
+            data = base64.b64decode(buf[nchar:nchar + ((int(sizes.sum()) + 2) // 3) * 4])
+            pos = 0
+        else:
+            sizes = np.frombuffer(buf[pos:pos + nblocks * hsize], dtype=hdr)
+            data = buf
+            pos += nblocks * hsize
+        out = []
+        for sz in sizes:
+            out.append(zlib.decompress(data[pos:pos + int(sz)]))
+            pos += int(sz)
+        return b"".join(out)
+
+    def array_of(da):
+        ty = _VTU_TYPES.get(da.get("type"))
+        if ty is None:
+            raise ValueError("unsupported VTU data type %s" % da.get("type"))
+        ncomp = int(da.get("NumberOfComponents", "1"))
+        fmt = da.get("format", "ascii")
+        if fmt == "ascii":
+            vals = np.array((da.text or "").split(), dtype=np.float64).astype(np.dtype(ty))
+        elif fmt == "binary":
+            vals = np.frombuffer(decode_blocks("".join((da.text or "").split()).encode(), True), dtype=bo + ty)
+        elif fmt == "appended":
+            if appended is None:
+                raise ValueError("VTU file refers to appended data but has no AppendedData section")
+            off = int(da.get("offset", "0"))
+            vals = np.frombuffer(decode_blocks(appended[off:], enc == "base64"), dtype=bo + ty)
+        else:
+            raise ValueError("unsupported VTU data array format %s" % fmt)
+        return vals.reshape(-1, ncomp) if ncomp > 1 else vals
+
+    pts_da = piece.find("./Points/DataArray")
+    if pts_da is None:
+        raise ValueError("VTU file has no Points array")
+    out = dict(points=np.asarray(array_of(pts_da)).reshape(n_points, 3), cells=None, point_data={})
+    pd = piece.find("./PointData")
+    if pd is not None:
+        for da in pd.findall("./DataArray"):
+            a = np.asarray(array_of(da))
+            out["point_data"][da.get("Name")] = a.astype(a.dtype.newbyteorder("="))
+    return out
+
 
 
 def _vtk_bytes(title, points, cells_flat, n_cells, cell_type, point_attributes):
@@ -346,7 +448,7 @@ def particles_from_file(path, dtype=np.float32):
     if e == "vtk":
         p = _read_vtk(path, points_only=True)["points"]
     elif e == "vtu":
-        raise NotImplementedError("XML VTK files (.vtu) are not supported by this reader")
+        p = _read_vtu(path)["points"]
     elif e == "xyz":  # xyz_format.rs:10-36: native-endian f32 triples, trailing partial record ignored
         raw = np.fromfile(path, dtype=np.float32)
         p = raw[: (raw.size // 3) * 3].reshape(-1, 3)
@@ -372,6 +474,8 @@ def particle_attributes_from_file(path, names):
     e = _ext(path)
     if e == "vtk":
         data = _read_vtk(path)["point_data"]
+    elif e == "vtu":
+        data = _read_vtu(path)["point_data"]
     elif e == "bgeo":
         data = _read_bgeo(path, want_attributes=True)[1]
     else:

@@ -141,3 +141,26 @@ def test_bgeo_attributes_match_the_reference_cli(oracle):
     vel = oracle.post_sph_interpolate(pts, res.particle_densities, mass, h, attrs["velocity"], V, True)
     assert np.max(np.abs(dens - g["density"]) / np.abs(g["density"])) < 2e-5
     assert np.max(np.abs(vel - g["velocity"])) < 2e-5 * max(1.0, float(np.abs(g["velocity"]).max()))
+
+
+def test_vtu_particle_files_of_the_reference():
+    """XML VTK (`.vtu`): the reference's own test files (vtk_format.rs:425-449 checks the particle counts 8 / 250 / 250):
+    appended raw data with zlib-compressed blocks and 64-bit headers, and the base64-encoded uncompressed variant of the
+    same 250 particles."""
+    from splashsurf_amd import io as IO
+    d = os.path.join(os.path.dirname(__file__), "data")
+    cube = IO.particles_from_file(os.path.join(d, "cube_8_particles.vtu"))
+    assert cube.shape == (8, 3) and cube.dtype == np.float32
+    assert np.array_equal(cube, load_points("cube_8_particles.npy"))  # the same particles as the reference's legacy .vtk
+    a = IO.particles_from_file(os.path.join(d, "fluid_250_particles.vtu"), dtype=np.float64)
+    b = IO.particles_from_file(os.path.join(d, "fluid_encoded_250_particles.vtu"), dtype=np.float64)
+    assert a.shape == (250, 3) and a.dtype == np.float64 and np.array_equal(a, b)
+    names = ["velocity", "pressure", "density", "index"]
+    xa = IO.particle_attributes_from_file(os.path.join(d, "fluid_250_particles.vtu"), names)
+    xb = IO.particle_attributes_from_file(os.path.join(d, "fluid_encoded_250_particles.vtu"), names)
+    for n in names:
+        assert np.array_equal(xa[n], xb[n]), n
+    assert xa["velocity"].shape == (250, 3) and np.array_equal(np.sort(xa["index"]), np.arange(1, 251))
+    assert 520.0 < xa["density"].min() and xa["density"].max() < 1022.0  # RangeMin / RangeMax stated in the encoded file
+    with pytest.raises(ValueError):
+        IO.particle_attributes_from_file(os.path.join(d, "cube_8_particles.vtu"), ["temperature"])
