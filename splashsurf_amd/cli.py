@@ -2,7 +2,7 @@
 (splashsurf/src/reconstruct.rs:36-380), routed to the file formats of `splashsurf_amd.io` and to
 `postprocessing.reconstruction_pipeline` (reconstruction and post-processing stages on the MI355X).
 
-Only the `reconstruct` subcommand exists.  Flags are spelled as in the reference (`--normals=on`, `-r 0.025`, ...).
+The `reconstruct` subcommand and the small `convert` subcommand (splashsurf/src/convert.rs) exist.  Flags are spelled as in the reference (`--normals=on`, `-r 0.025`, ...).
 Differences, all of them loud:
   * `--decimate-barnacles` and `--generate-quads` are not provided; switching one of them on is an error.  The
     `--check-mesh*` options run on the host; a finding fails the frame with the reference's message.  `--mesh-cleanup`
@@ -82,6 +82,14 @@ def build_parser():
     p.add_argument("--output-raw-mesh", default=False, **sw)
     for name in ("--check-mesh", "--check-mesh-closed", "--check-mesh-manifold", "--check-mesh-orientation", "--check-mesh-debug"):
         p.add_argument(name, default=False, **sw)
+    cv = sub.add_parser("convert", help="convert particle or mesh files between the supported formats (convert.rs:13-47)")
+    src = cv.add_mutually_exclusive_group()
+    src.add_argument("--particles", dest="input_particles")
+    src.add_argument("--mesh", dest="input_mesh")
+    cv.add_argument("-o", dest="output_file", required=True)
+    cv.add_argument("--overwrite", action="store_true")
+    cv.add_argument("--domain-min", type=float, nargs=3, metavar=("X_MIN", "Y_MIN", "Z_MIN"))
+    cv.add_argument("--domain-max", type=float, nargs=3, metavar=("X_MAX", "Y_MAX", "Z_MAX"))
     return ap
 
 
@@ -217,10 +225,36 @@ def run_reconstruct(args, log=None):
     return written
 
 
+def run_convert(args):
+    """splashsurf/src/convert.rs:49-147: f32 throughout, particles optionally filtered by a half-open box (aabb.rs:220-222)."""
+    from . import io
+    if not args.overwrite and os.path.exists(args.output_file):
+        raise CliError('Aborting: Output file "%s" already exists. Use overwrite flag to ignore this.' % args.output_file)
+    if (args.domain_min is None) != (args.domain_max is None):
+        raise CliError("--domain-min and --domain-max have to be given together")
+    try:
+        if args.input_particles is not None:
+            p = io.particles_from_file(args.input_particles, dtype=np.float32)
+            if args.domain_min is not None:
+                lo, hi = np.asarray(args.domain_min, np.float32), np.asarray(args.domain_max, np.float32)
+                p = p[np.all(p >= lo, axis=1) & np.all(p < hi, axis=1)]
+            io.particles_to_file(p, args.output_file)
+        elif args.input_mesh is not None:
+            io.mesh_to_file(io.mesh_from_file(args.input_mesh, dtype=np.float32), args.output_file)
+        else:
+            raise CliError("Aborting: No input file specified, either a particle or mesh input file has to be specified.")
+    except (ValueError, NotImplementedError, OSError) as e:
+        raise CliError(str(e))
+    return [args.output_file]
+
+
 def main(argv=None):
     args = build_parser().parse_args(argv)
     from .postprocessing import MeshCheckError
     try:
+        if args.command == "convert":
+            run_convert(args)
+            return 0
         run_reconstruct(args)
     except (CliError, MeshCheckError) as e:
         print("error: %s" % e, file=sys.stderr)

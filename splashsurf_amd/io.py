@@ -94,8 +94,8 @@ def _read_vtk(path, points_only=False):
     points_only: stop after the POINTS section (enough for particles; also accepts version 5 files, whose CELLS layout
     this reader does not parse)."""
     raw = open(path, "rb").read()
-    if raw.lstrip().startswith(b"<"):
-        raise NotImplementedError("XML VTK files (.vtu) are not supported by this reader")
+    if raw.lstrip().startswith(b"<"):  # XML VTK under a .vtk name
+        return _read_vtu(path)
     r = _VtkReader(raw)
     header = r.line()
     if header is None or not header.lower().startswith("# vtk datafile"):

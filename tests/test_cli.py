@@ -112,3 +112,25 @@ def test_cli_end_to_end_matches_the_library_call(tmp_path):
     assert 0 < clean.vertices.shape[0] < raw.vertices.shape[0] and clean.triangles.max() < clean.vertices.shape[0]
     # error path: exit code 1, nothing written
     assert cli.main(["reconstruct", str(src), "-r=0.025", "-l=2.0", "-c=1.1", "--decimate-barnacles=on"]) == 1
+
+
+def test_convert_subcommand(tmp_path):
+    """splashsurf/src/convert.rs: particle and mesh files between formats, domain filter, overwrite guard -- host only."""
+    from splashsurf_amd import io
+    gold = os.path.join(HERE, "golden", "io")
+    src = os.path.join(gold, "free_particles_125_particles_out.vtk")
+    out = str(tmp_path / "p.json")
+    assert cli.main(["convert", "--particles", src, "-o", out]) == 0
+    assert open(out, "rb").read() == open(os.path.join(gold, "free_particles_125_particles_out.json"), "rb").read()  # what the reference's convert wrote
+    assert cli.main(["convert", "--particles", src, "-o", out]) == 1          # exists, no --overwrite
+    p_all = io.particles_from_file(src)
+    lo, hi = p_all.min(axis=0), np.median(p_all, axis=0)  # a box that keeps part of the particles; the upper bounds are exclusive
+    assert cli.main(["convert", "--particles", src, "-o", out, "--overwrite", "--domain-min", *[repr(float(x)) for x in lo],
+                     "--domain-max", *[repr(float(x)) for x in hi]]) == 0
+    p_box = io.particles_from_file(out)
+    keep = np.all(p_all >= lo, axis=1) & np.all(p_all < hi, axis=1)
+    assert 0 < p_box.shape[0] < p_all.shape[0] and np.array_equal(p_box, p_all[keep])
+    mesh_out = str(tmp_path / "m.ply")
+    assert cli.main(["convert", "--mesh", os.path.join(gold, "mesh_plain.vtk"), "-o", mesh_out]) == 0
+    assert open(mesh_out, "rb").read() == open(os.path.join(gold, "mesh_plain.ply"), "rb").read()
+    assert cli.main(["convert", "-o", str(tmp_path / "x.vtk")]) == 1            # no input
