@@ -446,14 +446,13 @@ ss_status reconstruct_global(ss_context* ctx, const typename TypesOf<R>::params*
     SSGlobT<R> Q;
     memset(&Q, 0, sizeof(Q));
     const R h = prm->compact_support_radius, cs = prm->cube_size;
-    double npts_d = 1.0, ncell_d = 1.0;
+    double npts_d = 1.0;
     for (int d = 0; d < 3; ++d) {
         if (grid.n_points[d] > 2000000000ll) return fail(ctx, SS_ERR_GRID_CONSTRUCTION, "too many grid points per dimension", SS_GRID_INDEX_TYPE_TOO_SMALL);
         Q.gmin[d] = grid.aabb_min[d];
         Q.np[d] = (int)grid.n_points[d];
         Q.nc[d] = (int)grid.n_cells[d];
         npts_d *= (double)grid.n_points[d];
-        ncell_d *= (double)grid.n_cells[d];
     }
     if (npts_d >= 2.0e9)
         return fail(ctx, SS_ERR_UNSUPPORTED,
