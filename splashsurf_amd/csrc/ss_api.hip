@@ -164,6 +164,7 @@ ss_status make_device_params(ss_context* ctx, const typename TypesOf<R>::params*
     if (P.sub_radius < 1 || P.sub_radius > 64) return fail(ctx, SS_ERR_UNSUPPORTED, "ghost margin spans more than 64 subdomains");
     for (int d = 0; d < 3; ++d) P.sc[d] = (int)ceil(((double)sg.cell_size + 3.0 * (double)margin) / (double)h) + 3;
     P.h = h;
+    P.inv_h = 1.0 / (double)h;
     P.h2 = h * h;
     P.H2 = (h * h) * R(1.01);
     P.sigma = R(8.0) / (h * h * h);

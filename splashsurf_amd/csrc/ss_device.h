@@ -57,6 +57,7 @@ struct SSDevT {
     int sc[3];       // per-subdomain neighbourhood-search grid: table dims (cells of edge h, upper bound)
     // SPH kernel and level-set constants
     R h;          // compact support radius
+    double inv_h; // 1/h in double: block -> search-cell ranges without a division per wave
     R h2;         // h*h                       (neighborhood_search.rs:367)
     R H2;         // h*h*1.01                  (dense_subdomains.rs:1224-1226)
     R sigma;      // 8/(h*h*h)                 (kernel.rs:60-68)

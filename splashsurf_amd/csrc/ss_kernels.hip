@@ -911,9 +911,11 @@ __device__ __forceinline__ void splat_block(SplatShared<R, CAP>& s, const SSDevT
         phi[d] = P.gmin[d] + (R)i1 * P.cs;
         blo[d] = plo[d] - pad;
         bhi[d] = phi[d] + pad;
+        // cells overlapping [blo, bhi]; the pad of 1e-3 cells dwarfs the rounding of the product (< 1e-12 cells), so the
+        // range can only be a superset of the exact one -- every candidate is tested individually anyway
         const double cellpad = 1e-3 * (double)P.h;
-        int a = (int)floor(((double)blo[d] - cellpad) / (double)P.h);
-        int e = (int)floor(((double)bhi[d] + cellpad) / (double)P.h);
+        int a = (int)floor(((double)blo[d] - cellpad) * P.inv_h);
+        int e = (int)floor(((double)bhi[d] + cellpad) * P.inv_h);
         klo[d] = max(a, P.kmin[d]);
         khi[d] = min(e, P.kmin[d] + P.kdim[d] - 1);
     }
@@ -1106,8 +1108,8 @@ __global__ __launch_bounds__(256) void k_splat_gather(SSDevT<R> P, const ss_real
         blo[d] = plo[d] - pad;
         bhi[d] = phi[d] + pad;
         const double cellpad = 1e-3 * (double)P.h;
-        const int a = (int)floor(((double)blo[d] - cellpad) / (double)P.h);
-        const int e = (int)floor(((double)bhi[d] + cellpad) / (double)P.h);
+        const int a = (int)floor(((double)blo[d] - cellpad) * P.inv_h);  // see splat_block
+        const int e = (int)floor(((double)bhi[d] + cellpad) * P.inv_h);
         klo[d] = max(a, P.kmin[d]);
         khi[d] = min(e, P.kmin[d] + P.kdim[d] - 1);
     }
