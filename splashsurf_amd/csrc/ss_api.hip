@@ -800,6 +800,8 @@ ss_status phase_finish(ss_context* ctx, ss_result* res) {
     SS_HIP(ctx, res->blk_minmax.reserve((size_t)n_active * 2 * sizeof(R) + 16));
     ss_launch_compact_blocks(ctx->block_flag.as<uint32_t>(), ctx->block_rank.as<uint32_t>(), (uint32_t)nblocks, res->active_list.as<uint32_t>(),
                              res->block_slot.as<uint32_t>(), st);
+    SS_HIP(ctx, res->active_xyz.reserve((size_t)n_active * 12 + 16));
+    ss_launch_block_coords(P, res->active_list.as<uint32_t>(), n_active, res->active_xyz.as<uint32_t>(), st);
     SS_HIP(ctx, ctx->counter.reserve(64));
     SS_HIP(ctx, hipMemsetAsync(ctx->counter.p, 0, 64, st));
     SS_HIP(ctx, hipEventRecord(ctx->ev[5], st));
@@ -821,14 +823,14 @@ ss_status phase_finish(ss_context* ctx, ss_result* res) {
     const bool fast = sizeof(R) == 4 && ctx->fastdiv_ok;
     SS_HIP(ctx, ctx->splat_tiles.reserve((size_t)n_active * ss_splat_tile_entries() * sizeof(ss_real4<R>) + 64));
     SS_HIP(ctx, ctx->splat_counts.reserve(((size_t)n_active + 1) * 4));
-    ss_launch_splat_small(P, res->posvol.as<ss_real4<R>>(), res->perm.as<uint32_t>(), ctx->cell_start.as<uint32_t>(), res->active_list.as<uint32_t>(), n_active,
+    ss_launch_splat_small(P, res->posvol.as<ss_real4<R>>(), res->perm.as<uint32_t>(), ctx->cell_start.as<uint32_t>(), res->active_xyz.as<uint32_t>(), n_active,
                           ctx->splat_tiles.as<ss_real4<R>>(), ctx->splat_counts.as<uint32_t>(), res->G.as<R>(), res->blk_minmax.as<ss_real2<R>>(),
                           ctx->counter.as<unsigned long long>(), ov_flag, fast, ctx->ev[12], ctx->ev[13], st);
     if (n_active) {
         s = exclusive_scan_u32<uint32_t>(ctx, ov_flag, ov_rank, (size_t)n_active + 1);
         if (s != SS_OK) return s;
         ss_launch_compact_blocks(ov_flag, ov_rank, n_active, ov_list, ov_slot, st);
-        ss_launch_splat_large(P, res->posvol.as<ss_real4<R>>(), res->posvol_by_index.as<ss_real4<R>>(), res->perm.as<uint32_t>(), ctx->cell_start.as<uint32_t>(), res->active_list.as<uint32_t>(), n_active,
+        ss_launch_splat_large(P, res->posvol.as<ss_real4<R>>(), res->posvol_by_index.as<ss_real4<R>>(), res->perm.as<uint32_t>(), ctx->cell_start.as<uint32_t>(), res->active_xyz.as<uint32_t>(), n_active,
                               res->G.as<R>(), res->blk_minmax.as<ss_real2<R>>(), ctx->counter.as<unsigned long long>(), ov_list, ov_rank + n_active, fast, st);
     }
     SS_HIP(ctx, hipEventRecord(ctx->ev[6], st));
@@ -1088,7 +1090,7 @@ ss_status download(ss_result* r, const DevBuf& d, HostBuf& h, bool& flag, size_t
 }
 
 void result_release(ss_result* r) {
-    for (DevBuf* b : {&r->rho, &r->posvol, &r->posvol_by_index, &r->perm, &r->inside8, &r->G, &r->blk_minmax, &r->block_slot, &r->active_list, &r->mc_list, &r->mc_slot, &r->masks,
+    for (DevBuf* b : {&r->rho, &r->posvol, &r->posvol_by_index, &r->perm, &r->inside8, &r->G, &r->blk_minmax, &r->block_slot, &r->active_list, &r->active_xyz, &r->mc_list, &r->mc_slot, &r->masks,
                       &r->vbase, &r->tbase, &r->vertices, &r->vkeys, &r->tri32, &r->tri64})
         b->release();
     for (HostBuf* b : {&r->h_vertices, &r->h_tri64, &r->h_tri32, &r->h_rho, &r->h_vkeys, &r->h_inside, &r->h_nb_ptr, &r->h_nb_idx}) b->release();

@@ -704,6 +704,22 @@ struct SplatShared {
     uint32_t count;
 };
 
+// (bx, by, bz) of every active block, so that the splat kernels need no integer divisions per wave
+template <class R>
+__global__ __launch_bounds__(256) void k_block_coords(SSDevT<R> P, const uint32_t* __restrict__ active_list, uint32_t n_active, uint32_t* __restrict__ xyz) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_active) return;
+    const uint32_t b = active_list[i];
+    xyz[3 * (size_t)i + 0] = b / ((uint32_t)P.nb[2] * (uint32_t)P.nb[1]);
+    xyz[3 * (size_t)i + 1] = (b / (uint32_t)P.nb[2]) % (uint32_t)P.nb[1];
+    xyz[3 * (size_t)i + 2] = b % (uint32_t)P.nb[2];
+}
+template <class R>
+void ss_launch_block_coords(const SSDevT<R>& P, const uint32_t* active_list, uint32_t n_active, uint32_t* xyz, hipStream_t st) {
+    if (!n_active) return;
+    hipLaunchKernelGGL(k_block_coords<R>, dim3((n_active + 255) / 256), dim3(256), 0, st, P, active_list, n_active, xyz);
+}
+
 // Conservative block-level filter of the splat: does the particle lie within reach of the box spanned by the block's grid
 // points [plo, phi]?  Same expression as the per-wave test in splat_accumulate_wave on a box that contains every wave's
 // sub-block, and all operations involved are monotone under rounding, so whatever a wave accepts passes here as well.
@@ -891,12 +907,10 @@ __device__ __forceinline__ R splat_accumulate_wave_mask(const SSDevT<R>& P, cons
 // ascending index ranges.
 template <class R, bool FASTDIV, int CAP>
 __device__ __forceinline__ void splat_block(SplatShared<R, CAP>& s, const SSDevT<R>& P, const ss_real4<R>* __restrict__ posvol,
-                                            const ss_real4<R>* __restrict__ posvol_by_index, const uint32_t* __restrict__ perm, const uint32_t* __restrict__ cell_start, uint32_t b, uint32_t logical,
-                                            R* __restrict__ G, ss_real2<R>* __restrict__ blk_minmax, unsigned long long* __restrict__ cand_counter) {
+                                            const ss_real4<R>* __restrict__ posvol_by_index, const uint32_t* __restrict__ perm, const uint32_t* __restrict__ cell_start,
+                                            const uint32_t* __restrict__ bxyz, uint32_t logical, R* __restrict__ G, ss_real2<R>* __restrict__ blk_minmax, unsigned long long* __restrict__ cand_counter) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int bz = (int)(b % (uint32_t)P.nb[2]);
-    const int by = (int)((b / (uint32_t)P.nb[2]) % (uint32_t)P.nb[1]);
-    const int bx = (int)(b / ((uint32_t)P.nb[2] * (uint32_t)P.nb[1]));
+    const int bx = (int)bxyz[0], by = (int)bxyz[1], bz = (int)bxyz[2];
     const int b3[3] = {bx, by, bz};
 
     // box of the block's points, dilated by the reach: the search cells overlapping it
@@ -1080,7 +1094,7 @@ __device__ __forceinline__ void splat_block(SplatShared<R, CAP>& s, const SSDevT
 
 template <class R>
 __global__ __launch_bounds__(256) void k_splat_gather(SSDevT<R> P, const ss_real4<R>* __restrict__ posvol, const uint32_t* __restrict__ perm,
-                                                      const uint32_t* __restrict__ cell_start, const uint32_t* __restrict__ active_list, uint32_t n_active,
+                                                      const uint32_t* __restrict__ cell_start, const uint32_t* __restrict__ active_xyz, uint32_t n_active,
                                                       ss_real4<R>* __restrict__ tiles, uint32_t* __restrict__ counts, uint32_t* __restrict__ overflow_flag) {
     __shared__ uint32_t s_idx[4][SS_WTILE];
     __shared__ uint32_t s_src[4][SS_WTILE];
@@ -1094,8 +1108,7 @@ __global__ __launch_bounds__(256) void k_splat_gather(SSDevT<R> P, const ss_real
     if ((blockIdx.x >> 3) >= per_xcd || group >= n_groups) return;
     const uint32_t logical = group * 4u + (uint32_t)w;
     if (logical >= n_active) return;
-    const uint32_t b = active_list[logical];
-    const int b3[3] = {(int)(b / ((uint32_t)P.nb[2] * (uint32_t)P.nb[1])), (int)((b / (uint32_t)P.nb[2]) % (uint32_t)P.nb[1]), (int)(b % (uint32_t)P.nb[2])};
+    const int b3[3] = {(int)active_xyz[3 * (size_t)logical], (int)active_xyz[3 * (size_t)logical + 1], (int)active_xyz[3 * (size_t)logical + 2]};
     R blo[3], bhi[3], plo[3], phi[3];
     int klo[3], khi[3];
 #pragma unroll
@@ -1193,7 +1206,7 @@ __global__ __launch_bounds__(256) void k_splat_gather(SSDevT<R> P, const ss_real
 
 template <class R, bool FASTDIV>
 __global__ __launch_bounds__(512) void k_splat_accumulate(SSDevT<R> P, const ss_real4<R>* __restrict__ tiles, const uint32_t* __restrict__ counts,
-                                                          const uint32_t* __restrict__ overflow_flag, const uint32_t* __restrict__ active_list,
+                                                          const uint32_t* __restrict__ overflow_flag, const uint32_t* __restrict__ active_xyz,
                                                           uint32_t n_active, R* __restrict__ G, ss_real2<R>* __restrict__ blk_minmax,
                                                           unsigned long long* __restrict__ cand_counter) {
     __shared__ ss_real4<R> s_pay[SS_WTILE];
@@ -1210,10 +1223,7 @@ __global__ __launch_bounds__(512) void k_splat_accumulate(SSDevT<R> P, const ss_
     const ss_real4<R>* slot = tiles + (size_t)logical * SS_WTILE;
     if (tid < n_tile) s_pay[tid] = slot[tid];
     if (tid == 0 && n_tile) atomicAdd(cand_counter, (unsigned long long)n_tile);
-    const uint32_t b = active_list[logical];
-    const int bz = (int)(b % (uint32_t)P.nb[2]);
-    const int by = (int)((b / (uint32_t)P.nb[2]) % (uint32_t)P.nb[1]);
-    const int bx = (int)(b / ((uint32_t)P.nb[2] * (uint32_t)P.nb[1]));
+    const int bx = (int)active_xyz[3 * (size_t)logical], by = (int)active_xyz[3 * (size_t)logical + 1], bz = (int)active_xyz[3 * (size_t)logical + 2];
     // this wave's sub-block and this lane's grid point
     const int g0[3] = {bx * SS_BLOCK + ((wave >> 2) & 1) * 4, by * SS_BLOCK + ((wave >> 1) & 1) * 4, bz * SS_BLOCK + (wave & 1) * 4};
     const int gl[3] = {g0[0] + ((lane >> 4) & 3), g0[1] + ((lane >> 2) & 3), g0[2] + (lane & 3)};
@@ -1265,7 +1275,7 @@ __global__ __launch_bounds__(512) void k_splat_accumulate(SSDevT<R> P, const ss_
 template <class R, bool FASTDIV>
 __global__ __launch_bounds__(512) void k_splat_large(SSDevT<R> P, const ss_real4<R>* __restrict__ posvol, const ss_real4<R>* __restrict__ posvol_by_index,
                                                      const uint32_t* __restrict__ perm,
-                                                     const uint32_t* __restrict__ cell_start, const uint32_t* __restrict__ active_list,
+                                                     const uint32_t* __restrict__ cell_start, const uint32_t* __restrict__ active_xyz,
                                                      R* __restrict__ G, ss_real2<R>* __restrict__ blk_minmax, unsigned long long* __restrict__ cand_counter,
                                                      const uint32_t* __restrict__ overflow_list, const uint32_t* __restrict__ overflow_count) {
     __shared__ SplatShared<R, SSTileCap<R>::value> s;
@@ -1275,19 +1285,20 @@ __global__ __launch_bounds__(512) void k_splat_large(SSDevT<R> P, const ss_real4
         const uint32_t it = xcd * per_xcd + j;
         if (it < n) {
             const uint32_t logical = overflow_list[it];
-            splat_block<R, FASTDIV, SSTileCap<R>::value>(s, P, posvol, posvol_by_index, perm, cell_start, active_list[logical], logical, G, blk_minmax, cand_counter);
+            splat_block<R, FASTDIV, SSTileCap<R>::value>(s, P, posvol, posvol_by_index, perm, cell_start, active_xyz + 3 * (size_t)logical, logical, G, blk_minmax,
+                                                         cand_counter);
         }
         __syncthreads();
     }
 }
 
 template <class R>
-void ss_launch_splat_small(const SSDevT<R>& P, const ss_real4<R>* posvol, const uint32_t* perm, const uint32_t* cell_start, const uint32_t* active_list,
+void ss_launch_splat_small(const SSDevT<R>& P, const ss_real4<R>* posvol, const uint32_t* perm, const uint32_t* cell_start, const uint32_t* active_xyz,
                            uint32_t n_active, ss_real4<R>* tiles, uint32_t* counts, R* G, ss_real2<R>* blk_minmax, unsigned long long* cand_counter,
                            uint32_t* overflow_flag, bool fast_div, hipEvent_t ev_after_gather, hipEvent_t ev_after_accumulate, hipStream_t st) {
     if (n_active) {
         const uint32_t n_groups = (n_active + 3u) / 4u;
-        hipLaunchKernelGGL(k_splat_gather<R>, dim3(((n_groups + 7u) / 8u) * 8u), dim3(256), 0, st, P, posvol, perm, cell_start, active_list, n_active, tiles, counts,
+        hipLaunchKernelGGL(k_splat_gather<R>, dim3(((n_groups + 7u) / 8u) * 8u), dim3(256), 0, st, P, posvol, perm, cell_start, active_xyz, n_active, tiles, counts,
                            overflow_flag);
     }
     (void)hipEventRecord(ev_after_gather, st);
@@ -1296,13 +1307,13 @@ void ss_launch_splat_small(const SSDevT<R>& P, const ss_real4<R>* posvol, const 
         bool launched = false;
         if constexpr (sizeof(R) == 4) {
             if (fast_div) {
-                hipLaunchKernelGGL((k_splat_accumulate<R, true>), grid, dim3(512), 0, st, P, tiles, counts, overflow_flag, active_list, n_active, G, blk_minmax,
+                hipLaunchKernelGGL((k_splat_accumulate<R, true>), grid, dim3(512), 0, st, P, tiles, counts, overflow_flag, active_xyz, n_active, G, blk_minmax,
                                    cand_counter);
                 launched = true;
             }
         }
         if (!launched)
-            hipLaunchKernelGGL((k_splat_accumulate<R, false>), grid, dim3(512), 0, st, P, tiles, counts, overflow_flag, active_list, n_active, G, blk_minmax,
+            hipLaunchKernelGGL((k_splat_accumulate<R, false>), grid, dim3(512), 0, st, P, tiles, counts, overflow_flag, active_xyz, n_active, G, blk_minmax,
                                cand_counter);
     }
     (void)hipEventRecord(ev_after_accumulate, st);
@@ -1312,18 +1323,18 @@ size_t ss_splat_tile_entries() { return SS_WTILE; }
 // second launch: the queued over-dense blocks (overflow_count lives on the device; an empty queue costs one trivial launch)
 template <class R>
 void ss_launch_splat_large(const SSDevT<R>& P, const ss_real4<R>* posvol, const ss_real4<R>* posvol_by_index, const uint32_t* perm, const uint32_t* cell_start,
-                           const uint32_t* active_list, uint32_t n_active, R* G, ss_real2<R>* blk_minmax, unsigned long long* cand_counter, const uint32_t* overflow_list,
+                           const uint32_t* active_xyz, uint32_t n_active, R* G, ss_real2<R>* blk_minmax, unsigned long long* cand_counter, const uint32_t* overflow_list,
                            const uint32_t* overflow_count, bool fast_div, hipStream_t st) {
     if (!n_active) return;
     const dim3 grid(4096);  // persistent workgroups over the queue
     if constexpr (sizeof(R) == 4) {
         if (fast_div) {
-            hipLaunchKernelGGL((k_splat_large<R, true>), grid, dim3(512), 0, st, P, posvol, posvol_by_index, perm, cell_start, active_list, G, blk_minmax, cand_counter, overflow_list,
+            hipLaunchKernelGGL((k_splat_large<R, true>), grid, dim3(512), 0, st, P, posvol, posvol_by_index, perm, cell_start, active_xyz, G, blk_minmax, cand_counter, overflow_list,
                                overflow_count);
             return;
         }
     }
-    hipLaunchKernelGGL((k_splat_large<R, false>), grid, dim3(512), 0, st, P, posvol, posvol_by_index, perm, cell_start, active_list, G, blk_minmax, cand_counter, overflow_list,
+    hipLaunchKernelGGL((k_splat_large<R, false>), grid, dim3(512), 0, st, P, posvol, posvol_by_index, perm, cell_start, active_xyz, G, blk_minmax, cand_counter, overflow_list,
                        overflow_count);
 }
 
@@ -1614,16 +1625,18 @@ template void ss_launch_emit_copies<float>(const SSDevT<float>& P, const float* 
 template void ss_launch_emit_copies<double>(const SSDevT<double>& P, const double* xyz, const uint32_t* copy_offset, const uint32_t* occ_rank, uint32_t* keys, uint32_t* vals, uint32_t* cell_count, hipStream_t st);
 template void ss_launch_density_sub<float>(const SSDevT<float>& P, uint32_t n_copies, const ss_real4<float>* cpos, const uint32_t* cidx, const uint32_t* ckey, const uint32_t* cell_start, const uint32_t* occ_sub, float* rho, int mode, uint32_t* nb_count, const unsigned long long* nb_ptr, uint32_t* nb_idx, bool fast_div, hipStream_t st);
 template void ss_launch_density_sub<double>(const SSDevT<double>& P, uint32_t n_copies, const ss_real4<double>* cpos, const uint32_t* cidx, const uint32_t* ckey, const uint32_t* cell_start, const uint32_t* occ_sub, double* rho, int mode, uint32_t* nb_count, const unsigned long long* nb_ptr, uint32_t* nb_idx, bool fast_div, hipStream_t st);
+template void ss_launch_block_coords<float>(const SSDevT<float>& P, const uint32_t* active_list, uint32_t n_active, uint32_t* xyz, hipStream_t st);
+template void ss_launch_block_coords<double>(const SSDevT<double>& P, const uint32_t* active_list, uint32_t n_active, uint32_t* xyz, hipStream_t st);
 template void ss_launch_make_posvol<float>(const SSDevT<float>& P, const ss_real4<float>* pos_sorted, const uint32_t* perm, const float* rho, ss_real4<float>* posvol, ss_real4<float>* posvol_by_index, hipStream_t st);
 template void ss_launch_make_posvol<double>(const SSDevT<double>& P, const ss_real4<double>* pos_sorted, const uint32_t* perm, const double* rho, ss_real4<double>* posvol, ss_real4<double>* posvol_by_index, hipStream_t st);
 template void ss_launch_mark_blocks<float>(const SSDevT<float>& P, const uint32_t* cell_start, uint32_t ncells, uint32_t* block_flag, hipStream_t st);
 template void ss_launch_mark_blocks<double>(const SSDevT<double>& P, const uint32_t* cell_start, uint32_t ncells, uint32_t* block_flag, hipStream_t st);
 template void ss_launch_mark_mc_blocks<float>(const SSDevT<float>& P, const uint32_t* block_slot, const ss_real2<float>* blk_minmax, uint32_t nblocks, uint32_t* mc_flag, hipStream_t st);
 template void ss_launch_mark_mc_blocks<double>(const SSDevT<double>& P, const uint32_t* block_slot, const ss_real2<double>* blk_minmax, uint32_t nblocks, uint32_t* mc_flag, hipStream_t st);
-template void ss_launch_splat_small<float>(const SSDevT<float>& P, const ss_real4<float>* posvol, const uint32_t* perm, const uint32_t* cell_start, const uint32_t* active_list, uint32_t n_active, ss_real4<float>* tiles, uint32_t* counts, float* G, ss_real2<float>* blk_minmax, unsigned long long* cand_counter, uint32_t* overflow_flag, bool fast_div, hipEvent_t ev_after_gather, hipEvent_t ev_after_accumulate, hipStream_t st);
-template void ss_launch_splat_large<float>(const SSDevT<float>& P, const ss_real4<float>* posvol, const ss_real4<float>* posvol_by_index, const uint32_t* perm, const uint32_t* cell_start, const uint32_t* active_list, uint32_t n_active, float* G, ss_real2<float>* blk_minmax, unsigned long long* cand_counter, const uint32_t* overflow_list, const uint32_t* overflow_count, bool fast_div, hipStream_t st);
-template void ss_launch_splat_small<double>(const SSDevT<double>& P, const ss_real4<double>* posvol, const uint32_t* perm, const uint32_t* cell_start, const uint32_t* active_list, uint32_t n_active, ss_real4<double>* tiles, uint32_t* counts, double* G, ss_real2<double>* blk_minmax, unsigned long long* cand_counter, uint32_t* overflow_flag, bool fast_div, hipEvent_t ev_after_gather, hipEvent_t ev_after_accumulate, hipStream_t st);
-template void ss_launch_splat_large<double>(const SSDevT<double>& P, const ss_real4<double>* posvol, const ss_real4<double>* posvol_by_index, const uint32_t* perm, const uint32_t* cell_start, const uint32_t* active_list, uint32_t n_active, double* G, ss_real2<double>* blk_minmax, unsigned long long* cand_counter, const uint32_t* overflow_list, const uint32_t* overflow_count, bool fast_div, hipStream_t st);
+template void ss_launch_splat_small<float>(const SSDevT<float>& P, const ss_real4<float>* posvol, const uint32_t* perm, const uint32_t* cell_start, const uint32_t* active_xyz, uint32_t n_active, ss_real4<float>* tiles, uint32_t* counts, float* G, ss_real2<float>* blk_minmax, unsigned long long* cand_counter, uint32_t* overflow_flag, bool fast_div, hipEvent_t ev_after_gather, hipEvent_t ev_after_accumulate, hipStream_t st);
+template void ss_launch_splat_large<float>(const SSDevT<float>& P, const ss_real4<float>* posvol, const ss_real4<float>* posvol_by_index, const uint32_t* perm, const uint32_t* cell_start, const uint32_t* active_xyz, uint32_t n_active, float* G, ss_real2<float>* blk_minmax, unsigned long long* cand_counter, const uint32_t* overflow_list, const uint32_t* overflow_count, bool fast_div, hipStream_t st);
+template void ss_launch_splat_small<double>(const SSDevT<double>& P, const ss_real4<double>* posvol, const uint32_t* perm, const uint32_t* cell_start, const uint32_t* active_xyz, uint32_t n_active, ss_real4<double>* tiles, uint32_t* counts, double* G, ss_real2<double>* blk_minmax, unsigned long long* cand_counter, uint32_t* overflow_flag, bool fast_div, hipEvent_t ev_after_gather, hipEvent_t ev_after_accumulate, hipStream_t st);
+template void ss_launch_splat_large<double>(const SSDevT<double>& P, const ss_real4<double>* posvol, const ss_real4<double>* posvol_by_index, const uint32_t* perm, const uint32_t* cell_start, const uint32_t* active_xyz, uint32_t n_active, double* G, ss_real2<double>* blk_minmax, unsigned long long* cand_counter, const uint32_t* overflow_list, const uint32_t* overflow_count, bool fast_div, hipStream_t st);
 template void ss_launch_mc_count<float>(const SSDevT<float>& P, const float* G, const uint32_t* block_slot, const uint32_t* mc_list, uint32_t n_mc, unsigned long long* masks, uint32_t* vcount, uint32_t* tcount, hipStream_t st);
 template void ss_launch_mc_count<double>(const SSDevT<double>& P, const double* G, const uint32_t* block_slot, const uint32_t* mc_list, uint32_t n_mc, unsigned long long* masks, uint32_t* vcount, uint32_t* tcount, hipStream_t st);
 template void ss_launch_mc_emit<float>(const SSDevT<float>& P, const float* G, const uint32_t* block_slot, const uint32_t* mc_list, const uint32_t* mc_slot, uint32_t n_mc, const unsigned long long* masks, const uint32_t* vbase, const uint32_t* tbase, float* vertices, unsigned long long* vkeys, uint32_t* triangles, hipStream_t st);
