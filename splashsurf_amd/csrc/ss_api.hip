@@ -855,7 +855,9 @@ ss_status phase_finish(ss_context* ctx, ss_result* res) {
     SS_HIP(ctx, res->tbase.reserve(((size_t)n_mc + 1) * 4));
     SS_HIP(ctx, hipMemsetAsync(ctx->vcount.p, 0, ((size_t)n_mc + 1) * 4, st));
     SS_HIP(ctx, hipMemsetAsync(ctx->tcount.p, 0, ((size_t)n_mc + 1) * 4, st));
-    ss_launch_mc_count(P, res->G.as<R>(), res->block_slot.as<uint32_t>(), res->mc_list.as<uint32_t>(), n_mc, res->masks.as<unsigned long long>(),
+    SS_HIP(ctx, res->mc_xyz.reserve((size_t)n_mc * 12 + 16));
+    ss_launch_block_coords(P, res->mc_list.as<uint32_t>(), n_mc, res->mc_xyz.as<uint32_t>(), st);
+    ss_launch_mc_count(P, res->G.as<R>(), res->block_slot.as<uint32_t>(), res->mc_xyz.as<uint32_t>(), n_mc, res->masks.as<unsigned long long>(),
                        ctx->vcount.as<uint32_t>(), ctx->tcount.as<uint32_t>(), st);
     SS_HIP(ctx, hipEventRecord(ctx->ev[7], st));
     // ---- "stitching": global numbering by prefix sums ----
@@ -878,7 +880,7 @@ ss_status phase_finish(ss_context* ctx, ss_result* res) {
     SS_HIP(ctx, res->tri32.reserve(nt * 12 + 16));
     SS_HIP(ctx, hipEventRecord(ctx->ev[8], st));
     // ---- K5: emission ----
-    ss_launch_mc_emit(P, res->G.as<R>(), res->block_slot.as<uint32_t>(), res->mc_list.as<uint32_t>(), res->mc_slot.as<uint32_t>(), n_mc,
+    ss_launch_mc_emit(P, res->G.as<R>(), res->block_slot.as<uint32_t>(), res->mc_xyz.as<uint32_t>(), res->mc_slot.as<uint32_t>(), n_mc,
                       res->masks.as<unsigned long long>(), res->vbase.as<uint32_t>(), res->tbase.as<uint32_t>(), res->vertices.as<R>(),
                       res->vkeys.as<unsigned long long>(), res->tri32.as<uint32_t>(), st);
     SS_HIP(ctx, hipEventRecord(ctx->ev[9], st));
@@ -1090,7 +1092,7 @@ ss_status download(ss_result* r, const DevBuf& d, HostBuf& h, bool& flag, size_t
 }
 
 void result_release(ss_result* r) {
-    for (DevBuf* b : {&r->rho, &r->posvol, &r->posvol_by_index, &r->perm, &r->inside8, &r->G, &r->blk_minmax, &r->block_slot, &r->active_list, &r->active_xyz, &r->mc_list, &r->mc_slot, &r->masks,
+    for (DevBuf* b : {&r->rho, &r->posvol, &r->posvol_by_index, &r->perm, &r->inside8, &r->G, &r->blk_minmax, &r->block_slot, &r->active_list, &r->active_xyz, &r->mc_xyz, &r->mc_list, &r->mc_slot, &r->masks,
                       &r->vbase, &r->tbase, &r->vertices, &r->vkeys, &r->tri32, &r->tri64})
         b->release();
     for (HostBuf* b : {&r->h_vertices, &r->h_tri64, &r->h_tri32, &r->h_rho, &r->h_vkeys, &r->h_inside, &r->h_nb_ptr, &r->h_nb_idx}) b->release();

@@ -115,7 +115,7 @@ struct ss_result {
     uint64_t n_occupied_subdomains = 0, n_subdomain_particles = 0;
     ss_stats stats;
     // device results
-    DevBuf rho, posvol, posvol_by_index, perm, inside8, G, blk_minmax, block_slot, active_list, active_xyz, mc_list, mc_slot, masks, vbase, tbase, vertices, vkeys, tri32, tri64;
+    DevBuf rho, posvol, posvol_by_index, perm, inside8, G, blk_minmax, block_slot, active_list, active_xyz, mc_list, mc_xyz, mc_slot, masks, vbase, tbase, vertices, vkeys, tri32, tri64;
     // host mirrors
     HostBuf h_vertices, h_tri64, h_tri32, h_rho, h_vkeys, h_inside;
     bool hv = false, ht64 = false, ht32 = false, hrho = false, hkeys = false, hinside = false;

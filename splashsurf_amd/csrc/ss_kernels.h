@@ -36,9 +36,9 @@ size_t ss_splat_tile_entries();
 template <class R>
 void ss_launch_splat_large(const SSDevT<R>& P, const ss_real4<R>* posvol, const ss_real4<R>* posvol_by_index, const uint32_t* perm, const uint32_t* cell_start, const uint32_t* active_xyz, uint32_t n_active, R* G, ss_real2<R>* blk_minmax, unsigned long long* cand_counter, const uint32_t* overflow_list, const uint32_t* overflow_count, bool fast_div, hipStream_t st);
 template <class R>
-void ss_launch_mc_count(const SSDevT<R>& P, const R* G, const uint32_t* block_slot, const uint32_t* mc_list, uint32_t n_mc, unsigned long long* masks, uint32_t* vcount, uint32_t* tcount, hipStream_t st);
+void ss_launch_mc_count(const SSDevT<R>& P, const R* G, const uint32_t* block_slot, const uint32_t* mc_xyz, uint32_t n_mc, unsigned long long* masks, uint32_t* vcount, uint32_t* tcount, hipStream_t st);
 template <class R>
-void ss_launch_mc_emit(const SSDevT<R>& P, const R* G, const uint32_t* block_slot, const uint32_t* mc_list, const uint32_t* mc_slot, uint32_t n_mc, const unsigned long long* masks, const uint32_t* vbase, const uint32_t* tbase, R* vertices, unsigned long long* vkeys, uint32_t* triangles, hipStream_t st);
+void ss_launch_mc_emit(const SSDevT<R>& P, const R* G, const uint32_t* block_slot, const uint32_t* mc_xyz, const uint32_t* mc_slot, uint32_t n_mc, const unsigned long long* masks, const uint32_t* vbase, const uint32_t* tbase, R* vertices, unsigned long long* vkeys, uint32_t* triangles, hipStream_t st);
 void ss_launch_widen(const uint32_t* in, size_t n, unsigned long long* out, hipStream_t st);
 template <class R>
 void ss_launch_levelset_box(const SSDevT<R>& P, const R* G, const uint32_t* block_slot, const int lo[3], const int ext[3], R* out, hipStream_t st);

@@ -1406,17 +1406,14 @@ __device__ inline McLocal mc_classify(const McTile<R>& t, const SSDevT<R>& P, in
 
 template <class R>
 __global__ __launch_bounds__(512) void k_mc_count(SSDevT<R> P, const R* __restrict__ G, const uint32_t* __restrict__ block_slot,
-                                                  const uint32_t* __restrict__ mc_list, uint32_t n_mc, unsigned long long* __restrict__ masks,
+                                                  const uint32_t* __restrict__ mc_xyz, uint32_t n_mc, unsigned long long* __restrict__ masks,
                                                   uint32_t* __restrict__ vcount, uint32_t* __restrict__ tcount) {
     __shared__ McTile<R> tile;
     __shared__ uint32_t s_v[8], s_t[8];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t m = blockIdx.x;
     if (m >= n_mc) return;
-    const uint32_t b = mc_list[m];
-    const int bz = (int)(b % (uint32_t)P.nb[2]);
-    const int by = (int)((b / (uint32_t)P.nb[2]) % (uint32_t)P.nb[1]);
-    const int bx = (int)(b / ((uint32_t)P.nb[2] * (uint32_t)P.nb[1]));
+    const int bx = (int)mc_xyz[3 * (size_t)m], by = (int)mc_xyz[3 * (size_t)m + 1], bz = (int)mc_xyz[3 * (size_t)m + 2];  // k_block_coords
     mc_load_tile(tile, P, G, block_slot, bx, by, bz, tid);
     __syncthreads();
     const McLocal L = mc_classify(tile, P, bx, by, bz, tid);
@@ -1449,7 +1446,7 @@ __global__ __launch_bounds__(512) void k_mc_count(SSDevT<R> P, const R* __restri
 
 template <class R>
 __global__ __launch_bounds__(512) void k_mc_emit(SSDevT<R> P, const R* __restrict__ G, const uint32_t* __restrict__ block_slot,
-                                                 const uint32_t* __restrict__ mc_list, const uint32_t* __restrict__ mc_slot, uint32_t n_mc,
+                                                 const uint32_t* __restrict__ mc_xyz, const uint32_t* __restrict__ mc_slot, uint32_t n_mc,
                                                  const unsigned long long* __restrict__ masks, const uint32_t* __restrict__ vbase,
                                                  const uint32_t* __restrict__ tbase, R* __restrict__ vertices,
                                                  unsigned long long* __restrict__ vkeys, uint32_t* __restrict__ triangles) {
@@ -1462,10 +1459,7 @@ __global__ __launch_bounds__(512) void k_mc_emit(SSDevT<R> P, const R* __restric
     const uint32_t m = blockIdx.x;
     if (m >= n_mc) return;
     if (vbase[m + 1] == vbase[m] && tbase[m + 1] == tbase[m]) return;  // nothing to emit for this block
-    const uint32_t b = mc_list[m];
-    const int bz = (int)(b % (uint32_t)P.nb[2]);
-    const int by = (int)((b / (uint32_t)P.nb[2]) % (uint32_t)P.nb[1]);
-    const int bx = (int)(b / ((uint32_t)P.nb[2] * (uint32_t)P.nb[1]));
+    const int bx = (int)mc_xyz[3 * (size_t)m], by = (int)mc_xyz[3 * (size_t)m + 1], bz = (int)mc_xyz[3 * (size_t)m + 2];  // k_block_coords
     mc_load_tile(tile, P, G, block_slot, bx, by, bz, tid);
     // crossing masks of this block and its 7 upper neighbours
     if (tid < 8 * 24) {
@@ -1558,17 +1552,17 @@ __global__ __launch_bounds__(512) void k_mc_emit(SSDevT<R> P, const R* __restric
 }
 
 template <class R>
-void ss_launch_mc_count(const SSDevT<R>& P, const R* G, const uint32_t* block_slot, const uint32_t* mc_list, uint32_t n_mc,
+void ss_launch_mc_count(const SSDevT<R>& P, const R* G, const uint32_t* block_slot, const uint32_t* mc_xyz, uint32_t n_mc,
                         unsigned long long* masks, uint32_t* vcount, uint32_t* tcount, hipStream_t st) {
     if (!n_mc) return;
-    hipLaunchKernelGGL(k_mc_count<R>, dim3(n_mc), dim3(512), 0, st, P, G, block_slot, mc_list, n_mc, masks, vcount, tcount);
+    hipLaunchKernelGGL(k_mc_count<R>, dim3(n_mc), dim3(512), 0, st, P, G, block_slot, mc_xyz, n_mc, masks, vcount, tcount);
 }
 template <class R>
-void ss_launch_mc_emit(const SSDevT<R>& P, const R* G, const uint32_t* block_slot, const uint32_t* mc_list, const uint32_t* mc_slot,
+void ss_launch_mc_emit(const SSDevT<R>& P, const R* G, const uint32_t* block_slot, const uint32_t* mc_xyz, const uint32_t* mc_slot,
                        uint32_t n_mc, const unsigned long long* masks, const uint32_t* vbase, const uint32_t* tbase, R* vertices,
                        unsigned long long* vkeys, uint32_t* triangles, hipStream_t st) {
     if (!n_mc) return;
-    hipLaunchKernelGGL(k_mc_emit<R>, dim3(n_mc), dim3(512), 0, st, P, G, block_slot, mc_list, mc_slot, n_mc, masks, vbase, tbase, vertices, vkeys,
+    hipLaunchKernelGGL(k_mc_emit<R>, dim3(n_mc), dim3(512), 0, st, P, G, block_slot, mc_xyz, mc_slot, n_mc, masks, vbase, tbase, vertices, vkeys,
                        triangles);
 }
 
@@ -1637,9 +1631,9 @@ template void ss_launch_splat_small<float>(const SSDevT<float>& P, const ss_real
 template void ss_launch_splat_large<float>(const SSDevT<float>& P, const ss_real4<float>* posvol, const ss_real4<float>* posvol_by_index, const uint32_t* perm, const uint32_t* cell_start, const uint32_t* active_xyz, uint32_t n_active, float* G, ss_real2<float>* blk_minmax, unsigned long long* cand_counter, const uint32_t* overflow_list, const uint32_t* overflow_count, bool fast_div, hipStream_t st);
 template void ss_launch_splat_small<double>(const SSDevT<double>& P, const ss_real4<double>* posvol, const uint32_t* perm, const uint32_t* cell_start, const uint32_t* active_xyz, uint32_t n_active, ss_real4<double>* tiles, uint32_t* counts, double* G, ss_real2<double>* blk_minmax, unsigned long long* cand_counter, uint32_t* overflow_flag, bool fast_div, hipEvent_t ev_after_gather, hipEvent_t ev_after_accumulate, hipStream_t st);
 template void ss_launch_splat_large<double>(const SSDevT<double>& P, const ss_real4<double>* posvol, const ss_real4<double>* posvol_by_index, const uint32_t* perm, const uint32_t* cell_start, const uint32_t* active_xyz, uint32_t n_active, double* G, ss_real2<double>* blk_minmax, unsigned long long* cand_counter, const uint32_t* overflow_list, const uint32_t* overflow_count, bool fast_div, hipStream_t st);
-template void ss_launch_mc_count<float>(const SSDevT<float>& P, const float* G, const uint32_t* block_slot, const uint32_t* mc_list, uint32_t n_mc, unsigned long long* masks, uint32_t* vcount, uint32_t* tcount, hipStream_t st);
-template void ss_launch_mc_count<double>(const SSDevT<double>& P, const double* G, const uint32_t* block_slot, const uint32_t* mc_list, uint32_t n_mc, unsigned long long* masks, uint32_t* vcount, uint32_t* tcount, hipStream_t st);
-template void ss_launch_mc_emit<float>(const SSDevT<float>& P, const float* G, const uint32_t* block_slot, const uint32_t* mc_list, const uint32_t* mc_slot, uint32_t n_mc, const unsigned long long* masks, const uint32_t* vbase, const uint32_t* tbase, float* vertices, unsigned long long* vkeys, uint32_t* triangles, hipStream_t st);
-template void ss_launch_mc_emit<double>(const SSDevT<double>& P, const double* G, const uint32_t* block_slot, const uint32_t* mc_list, const uint32_t* mc_slot, uint32_t n_mc, const unsigned long long* masks, const uint32_t* vbase, const uint32_t* tbase, double* vertices, unsigned long long* vkeys, uint32_t* triangles, hipStream_t st);
+template void ss_launch_mc_count<float>(const SSDevT<float>& P, const float* G, const uint32_t* block_slot, const uint32_t* mc_xyz, uint32_t n_mc, unsigned long long* masks, uint32_t* vcount, uint32_t* tcount, hipStream_t st);
+template void ss_launch_mc_count<double>(const SSDevT<double>& P, const double* G, const uint32_t* block_slot, const uint32_t* mc_xyz, uint32_t n_mc, unsigned long long* masks, uint32_t* vcount, uint32_t* tcount, hipStream_t st);
+template void ss_launch_mc_emit<float>(const SSDevT<float>& P, const float* G, const uint32_t* block_slot, const uint32_t* mc_xyz, const uint32_t* mc_slot, uint32_t n_mc, const unsigned long long* masks, const uint32_t* vbase, const uint32_t* tbase, float* vertices, unsigned long long* vkeys, uint32_t* triangles, hipStream_t st);
+template void ss_launch_mc_emit<double>(const SSDevT<double>& P, const double* G, const uint32_t* block_slot, const uint32_t* mc_xyz, const uint32_t* mc_slot, uint32_t n_mc, const unsigned long long* masks, const uint32_t* vbase, const uint32_t* tbase, double* vertices, unsigned long long* vkeys, uint32_t* triangles, hipStream_t st);
 template void ss_launch_levelset_box<float>(const SSDevT<float>& P, const float* G, const uint32_t* block_slot, const int lo[3], const int ext[3], float* out, hipStream_t st);
 template void ss_launch_levelset_box<double>(const SSDevT<double>& P, const double* G, const uint32_t* block_slot, const int lo[3], const int ext[3], double* out, hipStream_t st);
