@@ -129,6 +129,19 @@ ss_status exclusive_scan_u32(ss_context* ctx, const T* in, T* out, size_t n) {
     return SS_OK;
 }
 
+struct WidenU32 {
+    __host__ __device__ unsigned long long operator()(uint32_t v) const { return (unsigned long long)v; }
+};
+// sum of n 32-bit counts as a 64-bit value at *out (device)
+static ss_status sum_u32_to_u64(ss_context* ctx, const uint32_t* in, size_t n, unsigned long long* out) {
+    auto it = rocprim::make_transform_iterator(in, WidenU32());
+    size_t bytes = 0;
+    SS_HIP(ctx, rocprim::reduce(nullptr, bytes, it, out, 0ull, n, rocprim::plus<unsigned long long>(), ctx->stream));
+    SS_HIP(ctx, ctx->temp.reserve(bytes));
+    SS_HIP(ctx, rocprim::reduce(ctx->temp.p, bytes, it, out, 0ull, n, rocprim::plus<unsigned long long>(), ctx->stream));
+    return SS_OK;
+}
+
 template <class PRM>
 ss_status validate_params(ss_context* ctx, const PRM* prm, uint64_t n) {
     if (!prm) return fail(ctx, SS_ERR_INVALID_ARGUMENT, "parameters pointer is null");
@@ -834,6 +847,10 @@ ss_status phase_finish(ss_context* ctx, ss_result* res) {
                               res->G.as<R>(), res->blk_minmax.as<ss_real2<R>>(), ctx->counter.as<unsigned long long>(), ov_list, ov_rank + n_active, fast, st);
     }
     SS_HIP(ctx, hipEventRecord(ctx->ev[6], st));
+    if (n_active) {  // candidates of the small tiles (the large-tile kernel adds its own to counter[0])
+        s = sum_u32_to_u64(ctx, ctx->splat_counts.as<uint32_t>(), n_active, ctx->counter.as<unsigned long long>() + 1);
+        if (s != SS_OK) return s;
+    }
 
     // ---- K4 prepare: MC blocks = blocks whose 2x2x2 level-set neighbourhood straddles the threshold ----
     ss_launch_mark_mc_blocks(P, res->block_slot.as<uint32_t>(), res->blk_minmax.as<ss_real2<R>>(), (uint32_t)nblocks, ctx->mc_flag.as<uint32_t>(), st);
@@ -866,10 +883,10 @@ ss_status phase_finish(ss_context* ctx, ss_result* res) {
     s = exclusive_scan_u32<uint32_t>(ctx, ctx->tcount.as<uint32_t>(), res->tbase.as<uint32_t>(), (size_t)n_mc + 1);
     if (s != SS_OK) return s;
     uint32_t totals[2] = {0, 0};
-    unsigned long long cand = 0;
     SS_HIP(ctx, hipMemcpyAsync(&totals[0], res->vbase.as<uint32_t>() + n_mc, 4, hipMemcpyDeviceToHost, st));
     SS_HIP(ctx, hipMemcpyAsync(&totals[1], res->tbase.as<uint32_t>() + n_mc, 4, hipMemcpyDeviceToHost, st));
-    SS_HIP(ctx, hipMemcpyAsync(&cand, ctx->counter.p, 8, hipMemcpyDeviceToHost, st));
+    unsigned long long cand2[2] = {0, 0};
+    SS_HIP(ctx, hipMemcpyAsync(cand2, ctx->counter.p, 16, hipMemcpyDeviceToHost, st));
     uint32_t n_large = 0;
     if (n_active) SS_HIP(ctx, hipMemcpyAsync(&n_large, ctx->splat_overflow.as<uint32_t>() + ((size_t)n_active + 1) + n_active, 4, hipMemcpyDeviceToHost, st));
     SS_HIP(ctx, hipStreamSynchronize(st));
@@ -908,7 +925,7 @@ ss_status phase_finish(ss_context* ctx, ss_result* res) {
     S.n_vertices = nv;
     S.n_triangles = nt;
     S.n_active_blocks = n_active;
-    S.n_block_candidates = cand;
+    S.n_block_candidates = cand2[0] + cand2[1];
     S.n_large_tile_blocks = n_large;
     S.fast_div_verified = ctx->fastdiv_ok ? 1 : 0;
     S.levelset_kernel_launches = n_active ? 1 : 0;

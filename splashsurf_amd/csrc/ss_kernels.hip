@@ -1222,7 +1222,6 @@ __global__ __launch_bounds__(512) void k_splat_accumulate(SSDevT<R> P, const ss_
     const int n_tile = (int)counts[logical];
     const ss_real4<R>* slot = tiles + (size_t)logical * SS_WTILE;
     if (tid < n_tile) s_pay[tid] = slot[tid];
-    if (tid == 0 && n_tile) atomicAdd(cand_counter, (unsigned long long)n_tile);
     const int bx = (int)active_xyz[3 * (size_t)logical], by = (int)active_xyz[3 * (size_t)logical + 1], bz = (int)active_xyz[3 * (size_t)logical + 2];
     // this wave's sub-block and this lane's grid point
     const int g0[3] = {bx * SS_BLOCK + ((wave >> 2) & 1) * 4, by * SS_BLOCK + ((wave >> 1) & 1) * 4, bz * SS_BLOCK + (wave & 1) * 4};
