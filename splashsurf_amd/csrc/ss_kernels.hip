@@ -1204,6 +1204,30 @@ __global__ __launch_bounds__(256) void k_splat_gather(SSDevT<R> P, const ss_real
     }
 }
 
+// Wave-wide min / max of an f32 ending in lane 63, with DPP row shifts and row broadcasts (12 VALU for both against ~50 for
+// the ds_bpermute shuffles of __shfl_xor): after row_shr 1, 2, 4, 8 lane 15 of every row holds its row's result,
+// row_bcast15 folds rows 0 -> 1 and 2 -> 3, row_bcast31 folds lane 31 into rows 2 and 3.  Lanes without a source keep `old`.
+template <bool IS_MAX>
+__device__ __forceinline__ float ss_wave_reduce_to_lane63(float v) {
+    auto step = [](float x, int ctrl_sel) -> float {
+        const int b = __float_as_int(x);
+        int t;
+        switch (ctrl_sel) {
+            case 0: t = __builtin_amdgcn_update_dpp(b, b, 0x111, 0xF, 0xF, false); break;  // row_shr:1
+            case 1: t = __builtin_amdgcn_update_dpp(b, b, 0x112, 0xF, 0xF, false); break;  // row_shr:2
+            case 2: t = __builtin_amdgcn_update_dpp(b, b, 0x114, 0xF, 0xF, false); break;  // row_shr:4
+            case 3: t = __builtin_amdgcn_update_dpp(b, b, 0x118, 0xF, 0xF, false); break;  // row_shr:8
+            case 4: t = __builtin_amdgcn_update_dpp(b, b, 0x142, 0xA, 0xF, false); break;  // row_bcast:15 into rows 1 and 3
+            default: t = __builtin_amdgcn_update_dpp(b, b, 0x143, 0xC, 0xF, false); break; // row_bcast:31 into rows 2 and 3
+        }
+        const float y = __int_as_float(t);
+        return IS_MAX ? fmaxf(x, y) : fminf(x, y);
+    };
+#pragma unroll
+    for (int i = 0; i < 6; ++i) v = step(v, i);
+    return v;
+}
+
 template <class R, bool FASTDIV>
 __global__ __launch_bounds__(512) void k_splat_accumulate(SSDevT<R> P, const ss_real4<R>* __restrict__ tiles, const uint32_t* __restrict__ counts,
                                                           const uint32_t* __restrict__ overflow_flag, const uint32_t* __restrict__ active_xyz,
@@ -1249,17 +1273,28 @@ __global__ __launch_bounds__(512) void k_splat_accumulate(SSDevT<R> P, const ss_
     const R val = point_valid ? acc : R(0.0);
     G[(size_t)logical * SS_BLOCK_POINTS + (size_t)((lx * 8 + ly) * 8 + lz)] = val;
     R mn = val, mx = val;
+    if constexpr (sizeof(R) == 4) {
+        mn = ss_wave_reduce_to_lane63<false>(mn);
+        mx = ss_wave_reduce_to_lane63<true>(mx);
+        if (lane == 63) {
+            s_red[wave] = mn;
+            s_red[8 + wave] = mx;
+        }
+    } else {
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        mn = ss_min(mn, __shfl_xor(mn, off));
-        mx = ss_max(mx, __shfl_xor(mx, off));
-    }
-    if (lane == 0) {
-        s_red[wave] = mn;
-        s_red[8 + wave] = mx;
+        for (int off = 32; off > 0; off >>= 1) {
+            mn = ss_min(mn, __shfl_xor(mn, off));
+            mx = ss_max(mx, __shfl_xor(mx, off));
+        }
+        if (lane == 0) {
+            s_red[wave] = mn;
+            s_red[8 + wave] = mx;
+        }
     }
     __syncthreads();
     if (tid == 0) {
+        mn = s_red[0];
+        mx = s_red[8];
         for (int q = 1; q < 8; ++q) {
             mn = ss_min(mn, s_red[q]);
             mx = ss_max(mx, s_red[8 + q]);
