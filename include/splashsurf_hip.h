@@ -327,6 +327,7 @@ ss_status ss_result_device_particle_neighbors(const ss_result *res, const uint64
 ss_status ss_result_copy_vertices(ss_result *res, void *dst);                  /* n_vertices x 3 */
 ss_status ss_result_copy_triangles_u32(ss_result *res, uint32_t *dst);         /* n_triangles x 3 */
 ss_status ss_result_copy_particle_densities(ss_result *res, void *dst);        /* n_particles */
+ss_status ss_result_copy_vertex_keys(ss_result *res, uint64_t *dst);           /* n_vertices global edge keys (ss_result_vertex_keys) */
 
 #ifdef __cplusplus
 }

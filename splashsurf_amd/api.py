@@ -9,6 +9,7 @@ reconstruction.rs:171-193), same result attributes (`.mesh.vertices`, `.mesh.tri
 There is NO CPU fallback: if libsplashsurf_hip.so is missing or no GPU is visible the call fails loudly.
 """
 import ctypes as C
+import weakref
 import json
 import os
 
@@ -283,6 +284,15 @@ class TriMesh3d:
         return self._owner._triangles_u32()
 
 
+def sync_tensor_producer(t):
+    """Stream-ordering contract of the C ABI for device pointers (include/splashsurf_hip.h, "Stream ordering"): the
+    library runs on its own non-blocking HIP stream, so whatever produced a device buffer must have completed before
+    the pointer is handed over.  For a torch CUDA tensor that is torch's current stream on the tensor's device."""
+    if getattr(t, "is_cuda", False):
+        import torch
+        torch.cuda.current_stream(t.device).synchronize()
+
+
 class Context:
     """Owns the HIP context/stream and reusable device buffers (the reference's thread pool + workspace)."""
 
@@ -294,9 +304,12 @@ class Context:
             raise SplashsurfError(st, "ss_context_create failed (no usable HIP device %d?)" % device_id)
         self._h = h
         self.device_id = device_id
+        self._results = weakref.WeakSet()  # live SurfaceReconstruction objects: freed before the context goes away
 
     def close(self):
         if getattr(self, "_h", None):
+            for r in list(getattr(self, "_results", ())):
+                r._free()
             self._lib.ss_context_destroy(self._h)
             self._h = None
 
@@ -318,13 +331,15 @@ class Context:
         if st != 0:
             self._raise(st)
 
-    @staticmethod
-    def _as_ptr(particles):
+    def _as_ptr(self, particles):
         """Accept a float32 (N,3) numpy array (host) or anything with `data_ptr()` (torch tensor, host or HBM)."""
         if hasattr(particles, "data_ptr"):
             dt = str(particles.dtype)
             if tuple(particles.shape[1:]) != (3,) or dt not in ("torch.float32", "torch.float64") or not particles.is_contiguous():
                 raise TypeError("particles tensor must be contiguous float32/float64 of shape (N, 3)")
+            if getattr(particles, "is_cuda", False) and particles.device.index != self.device_id:
+                raise ValueError("particles live on cuda:%s but this Context drives device %d" % (particles.device.index, self.device_id))
+            sync_tensor_producer(particles)
             return C.c_void_p(particles.data_ptr()), int(particles.shape[0]), particles, dt == "torch.float64"
         a = np.asarray(particles)
         if a.dtype not in (np.float32, np.float64):  # pysplashsurf/src/reconstruction.rs:187-206 rejects other dtypes as well
@@ -372,14 +387,20 @@ class SurfaceReconstruction:
         self._h = handle
         self._cache = {}
         self.mesh = TriMesh3d(self)
+        ctx._results.add(self)
 
     def _invalidate(self):
         self._cache = {}
 
+    def _free(self):
+        if self._h:
+            self._lib.ss_result_free(self._h)  # only needs hipSetDevice; valid as long as the context still exists
+            self._h = None
+
     def __del__(self):
         try:
-            if self._h and self._ctx._h:
-                self._lib.ss_result_free(self._h)
+            if self._ctx._h:
+                self._free()
             self._h = None
         except Exception:
             pass
@@ -400,7 +421,7 @@ class SurfaceReconstruction:
             arr = arr.copy()
         return arr.reshape(-1, width) if width > 1 else arr
 
-    def mesh_views(self):
+    def mesh_views(self, u64=False):
         """(vertices, triangles_u32) as zero-copy numpy views of the library's pinned host buffers -- what a host
         caller of the C ABI gets from ss_result_vertices / ss_result_triangles_u32.  Valid only until this result is
         reused by another reconstruction or freed; use `.mesh.vertices` / `.mesh.triangles` for owning copies."""
@@ -408,7 +429,10 @@ class SurfaceReconstruction:
             v = self._host_array(self._lib.ss_result_vertices_f64, C.c_double, 3, np.float64, copy=False)
         else:
             v = self._host_array(self._lib.ss_result_vertices, C.c_float, 3, np.float32, copy=False)
-        t = self._host_array(self._lib.ss_result_triangles_u32, C.c_uint32, 3, np.uint32, copy=False)
+        if u64:  # the reference's index type ([usize; 3], lib.rs:247-262): widened on the device, 24 B per triangle over PCIe
+            t = self._host_array(self._lib.ss_result_triangles, C.c_uint64, 3, np.uint64, copy=False)
+        else:
+            t = self._host_array(self._lib.ss_result_triangles_u32, C.c_uint32, 3, np.uint32, copy=False)
         return v, t
 
     def counts(self):

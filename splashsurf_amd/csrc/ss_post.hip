@@ -761,6 +761,10 @@ ss_status ss_result_copy_triangles_u32(ss_result* r, uint32_t* dst) {
     if (!r) return SS_ERR_INVALID_ARGUMENT;
     return copy_out(r, r->tri32.p, dst, (size_t)r->n_triangles * 12);
 }
+ss_status ss_result_copy_vertex_keys(ss_result* r, uint64_t* dst) {
+    if (!r) return SS_ERR_INVALID_ARGUMENT;
+    return copy_out(r, r->vkeys.p, dst, (size_t)r->n_vertices * 8);
+}
 ss_status ss_result_copy_particle_densities(ss_result* r, void* dst) {
     if (!r) return SS_ERR_INVALID_ARGUMENT;
     return copy_out(r, r->rho.p, dst, (size_t)r->n_particles * (r->is_f64 ? 8 : 4));

@@ -1,27 +1,40 @@
-"""Multi-GPU surface reconstruction: one process per GPU, torch.distributed (backend "nccl" = RCCL over
-xGMI on the GPU box, "gloo" in the CPU tests).
+"""Multi-GPU surface reconstruction, host mirror: one process per GPU over torch.distributed (backend "nccl" = RCCL
+over xGMI on a GPU node, "gloo" in the CPU tests).
 
 The reference is single-process; its only natural decomposition is the uniform grid of subdomains
-(SURVEY.md section 8e).  Here the subdomain grid of ONE global domain is cut into contiguous slabs
-along its longest axis, balanced by particle count:
+(dense_subdomains.rs:349-494 builds it, :1582-1598 iterates it in parallel).  Here the subdomain
+grid of ONE global domain is cut into `world` axis-aligned BRICKS of subdomains by recursive coordinate bisection over
+the histogram of owner subdomains, i.e. balanced by particle count.  One sharded reconstruction ("step"):
 
-  1. global particle ids = concatenation of the ranks' inputs (the summation order of the level set is
-     "ascending particle index", so ids must be global); global AABB by all-reduce(MIN/MAX);
-  2. every rank derives the same global grid; a histogram of owner subdomains along the axis is
-     all-reduced and cut into `world` slabs of (nearly) equal particle count;
-  3. sparse all-to-all (batched isend/irecv) of (id, position): each particle goes to every rank whose
-     slab + ghost margin contains it -- in a weak-scaling run only thin halo layers travel;
-  4. phase 1 on each rank: binning + densities of the particles CONTAINED in its slab;
-  5. halo density exchange: owners send (id, rho) to the ranks that hold the particle as a ghost
-     (the values are copied, never re-computed, so densities are bit-identical to a single-process run);
-  6. phase 2: level set + marching cubes for the slab.  Vertices on slab faces are produced by both
-     neighbours with identical global edge keys and identical coordinates; `gather_mesh` removes the
-     duplicates by key.
+  1. global particle ids = concatenation of the ranks' inputs (the summation order of the level set is "ascending
+     particle index", so ids must be global); global AABB by all-reduce(MIN/MAX);
+  2. every rank derives the same global grid; the 3-D histogram of owner subdomains is all-reduced and bisected
+     (`bricks_from_histogram`), so every rank holds the same partition;
+  3. sparse all-to-all #1, one message per neighbour: (id, position) of every particle inside the neighbour's brick
+     grown by the ghost margin -- only halo layers travel once the input is roughly where it belongs;
+  4. phase 1 on each rank: binning + densities of the particles CONTAINED in its brick (ss_shard_begin);
+  5. sparse all-to-all #2: owners send (id, rho) to the ranks that hold the particle as a ghost (values are copied,
+     never recomputed, so densities are bit-identical to a single-process run);
+  6. phase 2: level set + marching cubes of the brick (ss_shard_finish).  Vertices on brick faces are produced by every
+     adjacent rank with identical global edge keys and identical coordinates;
+  7. assembly (`assemble`): a face vertex belongs to the LOWEST rank whose brick holds its edge (the rule of
+     globalize_local_edge, dense_subdomains.rs:1260-1329: the lower-side patch owns a boundary edge); counts are
+     all-gathered into global vertex / triangle offsets, owners tell the other ranks the global ids of shared
+     vertices (sparse all-to-all #3, keyed by the global edge key -- the hash join of `stitching`,
+     dense_subdomains.rs:1693-1733, as a sort + binary search), triangles are rewritten to global ids.  The mesh is
+     then the concatenation over ranks of (owned vertices, triangles); nothing is de-duplicated after the fact.
 
-The per-rank engine is pluggable: `HipEngine` drives the C ABI (ss_shard_begin_f32 / ss_shard_finish),
-the CPU tests plug in the oracle (tests/test_distributed.py).
+The per-rank engine is pluggable: `HipEngine` drives the C ABI (ss_shard_begin_f32 / ss_shard_finish), the CPU tests
+plug in the oracle (tests/test_distributed.py).  The same algorithm runs natively (RCCL inside the library, no Python on
+the data path) behind `ss_dist_reconstruct_*` (include/splashsurf_hip.h); this module is its host-side mirror and the
+transport of the CPU tests.
+
+A failing point-to-point exchange RAISES.  `SPLASH_EXCHANGE=allgather` selects the padded all-gather transport
+explicitly (more bytes on the wire, only the most basic collective); nothing falls back silently.
 """
 import ctypes as C
+import os
+import time
 
 import numpy as np
 import torch
@@ -63,6 +76,8 @@ class HipEngine:
         self.lib.ss_shard_finish.argtypes = [vp, vp]
         for name in ("ss_shard_get_densities", "ss_shard_set_densities", "ss_shard_get_densities_f64", "ss_shard_set_densities_f64"):
             getattr(self.lib, name).argtypes = [vp, vp, u64]
+        for name in ("ss_result_copy_vertices", "ss_result_copy_triangles_u32", "ss_result_copy_vertex_keys"):
+            getattr(self.lib, name).argtypes = [vp, vp]
         self.lib.ss_grid_for_domain_f32.argtypes = [C.POINTER(api._Params), C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(api._Grid),
                                                     C.POINTER(api._Grid), C.POINTER(C.c_float)]
         self.lib.ss_grid_for_domain_f64.argtypes = [C.POINTER(api._Params64), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(api._Grid64),
@@ -98,8 +113,7 @@ class HipEngine:
     def begin(self, local_pts, shard):
         """local_pts: contiguous (n,3) tensor of the job's Real type on this rank's device.  Returns densities (owned computed, others 0)."""
         assert local_pts.dtype == self.torch_dtype
-        if local_pts.is_cuda:
-            torch.cuda.current_stream(local_pts.device).synchronize()
+        self.api.sync_tensor_producer(local_pts)
         p = self.params._c(self.f64)
         s = self._shard(shard)
         n = int(local_pts.shape[0])
@@ -116,8 +130,7 @@ class HipEngine:
         return rho
 
     def finish(self, rho):
-        if rho.is_cuda:
-            torch.cuda.current_stream(rho.device).synchronize()
+        self.api.sync_tensor_producer(rho)
         fn = self.lib.ss_shard_set_densities_f64 if self.f64 else self.lib.ss_shard_set_densities
         st = fn(self.result._h, C.c_void_p(rho.data_ptr()), int(rho.shape[0]))
         if st != 0:
@@ -128,16 +141,84 @@ class HipEngine:
         self.result._invalidate()
         return self.result
 
+    def device_mesh(self, device):
+        """(vertices (V,3) Real, keys (V,) int64, triangles (T,3) int64) of the last finish() as tensors on `device`; the
+        mesh does not leave HBM when `device` is this context's GPU."""
+        nv, nt = self.result.counts()
+        v = torch.empty((nv, 3), dtype=self.torch_dtype, device=device)
+        k = torch.empty((nv,), dtype=torch.int64, device=device)
+        t32 = torch.empty((nt, 3), dtype=torch.int32, device=device)
+        for fn, buf in ((self.lib.ss_result_copy_vertices, v), (self.lib.ss_result_copy_vertex_keys, k), (self.lib.ss_result_copy_triangles_u32, t32)):
+            if buf.numel():
+                st = fn(self.result._h, C.c_void_p(buf.data_ptr()))
+                if st != 0:
+                    self.ctx._raise(st)
+        return v, k, t32.to(torch.int64) & 0xFFFFFFFF
 
-def partition_slabs(coords_axis, gmin_axis, sub_size, ns_axis, world):
-    """Contiguous slabs of subdomain indices along one axis, balanced by owner-particle counts.
-    Deterministic given identical inputs on all ranks. Returns list of (lo, hi)."""
-    s = torch.floor((coords_axis - gmin_axis) / sub_size).to(torch.int64).clamp_(0, ns_axis - 1)
-    hist = torch.bincount(s, minlength=ns_axis).cpu().numpy()
-    return slabs_from_histogram(hist, world)
+
+# ---------------------------------------------------------------------------------------------------------------------
+# partition: recursive coordinate bisection of the subdomain grid, balanced by owner-particle counts
+# ---------------------------------------------------------------------------------------------------------------------
+def bricks_from_histogram(hist3, world, tol=0.02, axis_pref=(0.0, 0.0, 0.0)):
+    """Cut the subdomain grid (shape ns of `hist3`, owner-particle count per subdomain) into `world` axis-aligned bricks
+    [lo, hi) by recursive bisection: a box that has to serve k ranks is cut into parts for k//2 and k - k//2 ranks at the
+    whole-subdomain plane that splits its particles closest to that ratio; among the axes whose best cut is within `tol`
+    (fraction of the box's particles) of the best one, the cut with the smallest area (least halo) wins, then the axis with
+    the smallest `axis_pref` (the caller passes how far the ranks' inputs extend along each axis: cutting where the inputs
+    are already separated moves the fewest particles).  Pure integer /
+    float64 arithmetic on identical inputs, so every rank derives the same partition.  Ranks that cannot get a subdomain
+    (more ranks than subdomains in their box) receive empty bricks (lo == hi on one axis)."""
+    hist3 = np.asarray(hist3, dtype=np.float64)
+    ns = hist3.shape
+    out = [None] * world
+
+    def split(lo, hi, r0, r1):
+        k = r1 - r0
+        if k == 1:
+            out[r0] = (tuple(lo), tuple(hi))
+            return
+        k1 = k // 2
+        frac = k1 / k
+        box = hist3[lo[0]:hi[0], lo[1]:hi[1], lo[2]:hi[2]]
+        total = float(box.sum())
+        ext = [hi[d] - lo[d] for d in range(3)]
+        cands = []
+        for a in range(3):
+            if ext[a] < 2:
+                continue
+            marg = box.sum(axis=tuple(d for d in range(3) if d != a))
+            cum = np.concatenate([[0.0], np.cumsum(marg)])
+            if total > 0:
+                c = int(np.argmin(np.abs(cum[1:ext[a]] - total * frac))) + 1
+                err = abs(cum[c] - total * frac) / total
+            else:
+                c = min(max(int(round(ext[a] * frac)), 1), ext[a] - 1)
+                err = 0.0
+            area = 1
+            for d in range(3):
+                if d != a:
+                    area *= ext[d]
+            cands.append((err, area, a, c))
+        if not cands:  # a single subdomain for several ranks: the first gets it, the others get empty bricks
+            out[r0] = (tuple(lo), tuple(hi))
+            for r in range(r0 + 1, r1):
+                out[r] = (tuple(hi[:1]) + tuple(lo[1:]), tuple(hi))
+            return
+        best = min(c[0] for c in cands)
+        err, area, a, c = min((x for x in cands if x[0] <= best + tol), key=lambda x: (x[1], axis_pref[x[2]], x[0], x[2]))
+        mid_hi = list(hi)
+        mid_hi[a] = lo[a] + c
+        mid_lo = list(lo)
+        mid_lo[a] = lo[a] + c
+        split(list(lo), mid_hi, r0, r0 + k1)
+        split(mid_lo, list(hi), r0 + k1, r1)
+
+    split([0, 0, 0], list(ns), 0, world)
+    return out
 
 
 def slabs_from_histogram(hist, world):
+    """1-D special case (kept for callers that want slabs along one axis): contiguous ranges of layers balanced by count."""
     ns_axis = int(len(hist))
     cum = np.concatenate([[0.0], np.cumsum(np.asarray(hist, dtype=np.float64))])
     total = cum[-1]
@@ -145,7 +226,6 @@ def slabs_from_histogram(hist, world):
     for r in range(1, world):
         target = total * r / world
         k = int(np.searchsorted(cum, target, side="left"))
-        # choose the boundary (k-1 or k) closest to the target, keep bounds monotone and leave room for the rest
         if k > 0 and abs(cum[k - 1] - target) <= abs(cum[min(k, ns_axis)] - target):
             k -= 1
         k = max(k, bounds[-1])
@@ -155,13 +235,30 @@ def slabs_from_histogram(hist, world):
     return [(bounds[r], bounds[r + 1]) for r in range(world)]
 
 
+def partition_slabs(coords_axis, gmin_axis, sub_size, ns_axis, world):
+    s = torch.floor((coords_axis - gmin_axis) / sub_size).to(torch.int64).clamp_(0, ns_axis - 1)
+    hist = torch.bincount(s, minlength=ns_axis).cpu().numpy()
+    return slabs_from_histogram(hist, world)
+
+
+class ShardedMesh:
+    """This rank's part of the assembled mesh: the vertices it OWNS (global ids vertex_offset .. vertex_offset + V_owned),
+    their edge keys, and its triangles with GLOBAL vertex ids (global triangle ids triangle_offset ..)."""
+
+    def __init__(self, vertices, keys, triangles, vertex_offset, triangle_offset, n_vertices_total, n_triangles_total):
+        self.vertices, self.keys, self.triangles = vertices, keys, triangles
+        self.vertex_offset, self.triangle_offset = vertex_offset, triangle_offset
+        self.n_vertices_total, self.n_triangles_total = n_vertices_total, n_triangles_total
+
+
 class ShardedStepResult:
-    def __init__(self, local, shard, ids, n_total, timings):
+    def __init__(self, local, shard, ids, n_total, timings, balance):
         self.local = local          # engine result of this rank (SurfaceReconstruction-like)
         self.shard = shard
         self.ids = ids              # global particle ids of the local particle set
         self.n_total = n_total
         self.timings = timings
+        self.balance = balance      # per-rank owned / held particle counts and bricks (identical on every rank)
 
     @property
     def stats(self):
@@ -179,8 +276,11 @@ class ShardedReconstruction:
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.local = None
-        import os
-        self._exchange_mode = "allgather" if os.environ.get("SPLASH_EXCHANGE", "p2p") == "allgather" else "p2p"
+        mode = os.environ.get("SPLASH_EXCHANGE", "p2p")
+        if mode not in ("p2p", "allgather"):
+            raise ValueError("SPLASH_EXCHANGE must be 'p2p' or 'allgather', not %r" % mode)
+        self._exchange_mode = mode
+        self.exchange_bytes = 0  # payload bytes this rank sent in the last step()
 
     def load_local_particles(self, pts):
         """The particles this rank contributes (its share of the input), (n,3) in the engine's Real type (float32 unless the
@@ -237,20 +337,15 @@ class ShardedReconstruction:
 
     def _exchange(self, send):
         """Sparse all-to-all: send[q] (k_q, ...) goes to rank q; returns the list received from every rank.
-        Default transport: one batch of point-to-point isend/irecv (RCCL and gloo).  SPLASH_EXCHANGE=allgather (or a
-        failing point-to-point batch) switches to a padded all-gather of every rank's outgoing rows, from which each
-        rank keeps its part -- more bytes on the wire, but only the most basic collective."""
+        Transport: one batch of point-to-point isend/irecv (RCCL and gloo); SPLASH_EXCHANGE=allgather selects a padded
+        all-gather of every rank's outgoing rows instead.  Errors propagate -- there is no silent fallback."""
         if self.world == 1:
             return [send[0]]
+        self.exchange_bytes += sum(int(t.numel()) * t.element_size() for q, t in enumerate(send) if q != self.rank)
         counts = torch.tensor([int(t.shape[0]) for t in send], dtype=torch.int64, device=self.device)
         matrix = self._all_gather_small(counts)  # matrix[r][q] = rows rank r sends to rank q
         if self._exchange_mode == "p2p":
-            try:
-                return self._exchange_p2p(send, matrix)
-            except RuntimeError as e:  # symmetric failures (unsupported transport): every rank falls back
-                import warnings
-                warnings.warn("point-to-point halo exchange failed (%s); falling back to all-gather" % (str(e).splitlines()[0],))
-                self._exchange_mode = "allgather"
+            return self._exchange_p2p(send, matrix)
         return self._exchange_allgather(send, matrix)
 
     def _exchange_p2p(self, send, matrix):
@@ -290,28 +385,36 @@ class ShardedReconstruction:
         return recv
 
     def _tick(self, name):
-        """Optional per-phase timing of step() (SPLASH_PROFILE_SHARDED=1): wall time incl. device sync."""
+        """Per-phase wall time of step() incl. device sync (SPLASH_PROFILE_SHARDED=1 or profile=True)."""
         if not self._profile:
             return
-        import time
         if self.device.type == "cuda":
             torch.cuda.synchronize(self.device)
         now = time.perf_counter()
         self.timings[name] = self.timings.get(name, 0.0) + (now - self._t_last) * 1e3
         self._t_last = now
 
-    def step(self):
-        """One sharded reconstruction.  Only halo layers travel between ranks:
-        positions to the ranks whose slab (+ ghost margin) contains them, then the densities of owned
-        particles to the ranks that hold them as ghosts."""
-        import os
-        import time
-        self._profile = bool(os.environ.get("SPLASH_PROFILE_SHARDED"))
+    # rows = [id (int64 as two int32) | payload viewed as int32]: ids and payload travel in ONE message per neighbour
+    @staticmethod
+    def _pack(gid, payload, width):
+        p = payload.reshape(gid.shape[0], width).contiguous().view(torch.int32)
+        return torch.cat([gid.contiguous().view(torch.int32).reshape(-1, 2), p], dim=1).contiguous()
+
+    @staticmethod
+    def _unpack(rows, dtype, width):
+        gid = rows[:, :2].contiguous().view(torch.int64).reshape(-1)
+        pay = rows[:, 2:].contiguous().view(dtype).reshape(-1, width) if width > 1 else rows[:, 2:].contiguous().view(dtype).reshape(-1)
+        return gid, pay
+
+    def step(self, profile=None):
+        """One sharded reconstruction (docstring of this module, steps 1-6)."""
+        self._profile = bool(os.environ.get("SPLASH_PROFILE_SHARDED")) if profile is None else bool(profile)
         self.timings = getattr(self, "timings", {}) if self._profile else {}
         if self._profile and self.device.type == "cuda":
             torch.cuda.synchronize(self.device)
         self._t_last = time.perf_counter()
-        eng, dev, me = self.engine, self.device, self.rank
+        self.exchange_bytes = 0
+        eng, dev, me, world = self.engine, self.device, self.rank, self.world
         local = self.local
         # 1. global particle ids = concatenation by rank (defines the summation order of the level set)
         n_loc = torch.tensor([local.shape[0]], dtype=torch.int64, device=dev)
@@ -319,7 +422,7 @@ class ShardedReconstruction:
         offset = sum(counts[:me])
         n_total = sum(counts)
         gid = torch.arange(offset, offset + local.shape[0], dtype=torch.int64, device=dev)
-        # 2. global particle AABB (identical on every rank)
+        # global particle AABB (identical on every rank)
         big = torch.finfo(local.dtype).max
         if local.shape[0]:
             # full reductions over the three strided columns (a dim-0 reduction of an (N,3) tensor runs
@@ -333,83 +436,158 @@ class ShardedReconstruction:
         dmin = lo_hi[0].cpu().numpy() if n_total else np.zeros(3, np_dt)
         dmax = (-lo_hi[1]).cpu().numpy() if n_total else np.zeros(3, np_dt)
         gmin, sub_size, ns, margin, n_cubes = eng.grid_for_domain(dmin, dmax)
-        # slab axis: the longest axis of the subdomain grid; among equally long axes the one along which the ranks'
-        # inputs are already separated (smallest local/global extent, maximised over ranks), so that fewer particles move
+        self._grid = dict(ns=list(ns), n_cubes=int(n_cubes))
+        self._tick("1_ids_aabb_grid")
+        # 2. bricks balanced by owner counts (histogram all-reduced, so identical everywhere)
+        sub = [torch.floor((local[:, d] - float(gmin[d])) / sub_size).to(torch.int64).clamp_(0, ns[d] - 1) for d in range(3)]
+        flat = (sub[0] * ns[1] + sub[1]) * ns[2] + sub[2]
+        hist = torch.bincount(flat, minlength=ns[0] * ns[1] * ns[2]).to(torch.int64)
+        hist = self._all_reduce(hist, dist.ReduceOp.SUM)
+        hist3 = hist.cpu().numpy().reshape(ns)
+        # tie-break between equally good cuts: the axis along which the ranks' inputs are already separated (smallest
+        # local / global extent, maximised over ranks), so that fewer particles move
         ext = torch.zeros(3, dtype=torch.float64, device=dev)
         if local.shape[0] and n_total:
             span = torch.tensor([max(float(dmax[d] - dmin[d]), 1e-300) for d in range(3)], dtype=torch.float64, device=dev)
             ext = torch.stack([(mm[d].max - mm[d].min).to(torch.float64) for d in range(3)]) / span
         ext = self._all_reduce(ext, dist.ReduceOp.MAX).cpu().numpy()
-        longest = max(ns)
-        axis = min((d for d in range(3) if ns[d] == longest), key=lambda d: (ext[d], d))
-        self._tick("1_ids_aabb_grid")
-        # 3. slab partition balanced by owner counts (histogram all-reduced, so identical everywhere)
-        s_own = torch.floor((local[:, axis] - float(gmin[axis])) / sub_size).to(torch.int64).clamp_(0, ns[axis] - 1)
-        hist = torch.bincount(s_own, minlength=ns[axis]).to(torch.int64)
-        hist = self._all_reduce(hist, dist.ReduceOp.SUM)
-        slabs = slabs_from_histogram(hist.cpu().numpy(), self.world)
-        lo, hi = slabs[me]
-        sub_lo, sub_hi = [0, 0, 0], list(ns)
-        sub_lo[axis], sub_hi[axis] = lo, hi
-        shard = ShardDesc(dmin, dmax, sub_lo, sub_hi)
-        # conservative coordinate interval of a slab incl. ghost margin (the engine applies the exact rule)
+        bricks = bricks_from_histogram(hist3, world, axis_pref=tuple(round(float(e), 3) for e in ext))
+        self._bricks = bricks
+        lo, hi = bricks[me]
+        shard = ShardDesc(dmin, dmax, lo, hi)
+        # conservative coordinate box of a brick incl. ghost margin (the engine applies the exact rule)
         pad = margin * 1.001 + 1e-6 * max(1.0, float(np.abs(gmin).max()), float(np.abs(dmax).max()))
 
-        def interval(q):
-            a, b = slabs[q]
-            if b <= a:
-                return None
-            return float(gmin[axis]) + a * sub_size - pad, float(gmin[axis]) + b * sub_size + pad
-
-        def select(coords, q):
-            iv = interval(q)
-            if iv is None:
-                return torch.zeros(coords.shape[0], dtype=torch.bool, device=dev)
-            return (coords >= iv[0]) & (coords <= iv[1])
+        def select(xyz, q):
+            a, b = bricks[q]
+            if any(b[d] <= a[d] for d in range(3)):
+                return torch.zeros(xyz.shape[0], dtype=torch.bool, device=dev)
+            m = None
+            for d in range(3):
+                c = xyz[:, d]
+                md = (c >= float(gmin[d]) + a[d] * sub_size - pad) & (c <= float(gmin[d]) + b[d] * sub_size + pad)
+                m = md if m is None else (m & md)
+            return m
 
         self._tick("2_partition")
-        # 4. positions to every rank that needs them (owner or ghost)
-        send_gid, send_xyz = [], []
-        for q in range(self.world):
-            m = select(local[:, axis], q)
-            send_gid.append(gid[m])
-            send_xyz.append(local[m])
-        recv_gid = self._exchange(send_gid)
-        recv_xyz = self._exchange(send_xyz)
+        # 3. (id, position) to every rank that needs the particle (owner or ghost), one message per destination
+        width = 3
+        send = []
+        for q in range(world):
+            m = select(local, q)
+            send.append(self._pack(gid[m], local[m], width))
+        recv = self._exchange(send)
         # Lists arrive ascending from every source rank and ranks' id ranges are ascending, so the
         # concatenation by source rank IS the ascending global-id order (no sort needed).
-        gids = torch.cat(recv_gid).contiguous()
-        L = torch.cat(recv_xyz).contiguous()
+        rows = torch.cat(recv).contiguous()
+        gids, L = self._unpack(rows, local.dtype, width)
+        L = L.contiguous()
         self._tick("3_position_exchange")
-        # 5. phase 1: densities of the particles contained in this slab (others stay 0)
+        # 4. phase 1: densities of the particles contained in this brick (others stay 0)
         rho = eng.begin(L, shard)
         self._tick("4_phase1_binning_densities")
         owned = rho > 0
-        # 6. halo densities: owners -> ranks holding the particle as a ghost
-        send_gid, send_rho = [], []
-        for q in range(self.world):
+        # 5. halo densities: owners -> ranks holding the particle as a ghost
+        send = []
+        for q in range(world):
             if q == me:
-                send_gid.append(gids[:0])
-                send_rho.append(rho[:0])
+                send.append(self._pack(gids[:0], rho[:0], 1))
                 continue
-            m = owned & select(L[:, axis], q)
-            send_gid.append(gids[m])
-            send_rho.append(rho[m])
-        recv_gid = self._exchange(send_gid)
-        recv_rho = self._exchange(send_rho)
-        for q in range(self.world):
-            if q == me or recv_gid[q].shape[0] == 0:
+            m = owned & select(L, q)
+            send.append(self._pack(gids[m], rho[m], 1))
+        recv = self._exchange(send)
+        for q in range(world):
+            if q == me or recv[q].shape[0] == 0:
                 continue
-            pos = torch.searchsorted(gids, recv_gid[q])
-            rho.index_copy_(0, pos, recv_rho[q])
+            g_q, r_q = self._unpack(recv[q], rho.dtype, 1)
+            pos = torch.searchsorted(gids, g_q)
+            rho.index_copy_(0, pos, r_q)
         self._tick("5_density_exchange")
-        # 7. phase 2
+        # 6. phase 2
         res = eng.finish(rho)
         self._tick("6_phase2_levelset_mc")
         self.last = dict(gids=gids, rho=rho, owned=owned)
-        return ShardedStepResult(res, shard, gids, n_total, dict(self.timings))
+        # load balance of the partition (identical on every rank): owned / held particles per rank
+        mine = torch.tensor([int(owned.sum().item()), int(gids.shape[0])], dtype=torch.int64, device=dev)
+        per_rank = self._all_gather_small(mine).cpu().numpy()
+        own = per_rank[:, 0].astype(np.float64)
+        balance = dict(owned=[int(x) for x in per_rank[:, 0]], held=[int(x) for x in per_rank[:, 1]],
+                       bricks=[[list(a), list(b)] for a, b in bricks],
+                       imbalance_owned=float(own.max() / max(own.mean(), 1.0)),
+                       imbalance_held=float(per_rank[:, 1].max() / max(per_rank[:, 1].mean(), 1.0)))
+        return ShardedStepResult(res, shard, gids, n_total, dict(self.timings), balance)
 
-    # ---- result assembly (tests / consumers that want one mesh) ----
+    # ---- result assembly ----
+    def _local_mesh(self, step_result):
+        if hasattr(self.engine, "device_mesh"):
+            return self.engine.device_mesh(self.device)
+        r = step_result.local
+        v = torch.as_tensor(np.ascontiguousarray(r.mesh.vertices)).to(self.device)
+        k = torch.as_tensor(np.ascontiguousarray(r.vertex_keys).astype(np.int64)).to(self.device)
+        t = torch.as_tensor(np.ascontiguousarray(r.mesh.triangles).astype(np.int64)).to(self.device)
+        return v, k, t
+
+    def assemble(self, step_result):
+        """Step 7 of the module docstring.  Returns this rank's `ShardedMesh`; runs on the device of this rank."""
+        dev, me, world = self.device, self.rank, self.world
+        v, k, t = self._local_mesh(step_result)
+        ns, n = self._grid["ns"], self._grid["n_cubes"]
+        npd = [ns[d] * n + 1 for d in range(3)]  # points per dimension of the global grid
+        # key = ((gi*NPy + gj)*NPz + gk)*3 + axis  (include/splashsurf_hip.h: ss_result_vertex_keys)
+        axis = k % 3
+        p = k // 3
+        g2 = p % npd[2]
+        g1 = (p // npd[2]) % npd[1]
+        g0 = p // (npd[2] * npd[1])
+        g = [g0, g1, g2]
+
+        def holds(q):  # does rank q's brick (closed box of grid points) contain both end points of the edge?
+            a, b = self._bricks[q]
+            if any(b[d] <= a[d] for d in range(3)):
+                return torch.zeros(k.shape[0], dtype=torch.bool, device=dev)
+            m = torch.ones(k.shape[0], dtype=torch.bool, device=dev)
+            for d in range(3):
+                m &= (g[d] >= a[d] * n) & (g[d] + (axis == d).to(torch.int64) <= b[d] * n)
+            return m
+
+        owner = torch.full((k.shape[0],), world, dtype=torch.int64, device=dev)
+        holder = []
+        for q in range(world - 1, -1, -1):
+            hq = holds(q)
+            holder.append(hq)
+            owner = torch.where(hq, torch.full_like(owner, q), owner)
+        holder = holder[::-1]
+        if k.shape[0] and not bool(holder[me].all()):
+            raise RuntimeError("rank %d emitted a vertex outside its brick" % me)
+        mine = owner == me
+        n_owned = int(mine.sum().item())
+        cnt = torch.tensor([n_owned, int(t.shape[0])], dtype=torch.int64, device=dev)
+        allc = self._all_gather_small(cnt).cpu().numpy()
+        voff = int(allc[:me, 0].sum())
+        toff = int(allc[:me, 1].sum())
+        gid_local = torch.full((k.shape[0],), -1, dtype=torch.int64, device=dev)
+        gid_local[mine] = voff + torch.arange(n_owned, dtype=torch.int64, device=dev)
+        # owners -> the other ranks holding the edge: (key, global id)
+        send = []
+        for q in range(world):
+            if q == me:
+                send.append(torch.zeros((0, 2), dtype=torch.int64, device=dev))
+                continue
+            m = mine & holder[q]
+            send.append(torch.stack([k[m], gid_local[m]], dim=1).contiguous())
+        recv = self._exchange(send) if world > 1 else [send[0]]
+        got = torch.cat([recv[q] for q in range(world) if q != me], dim=0) if world > 1 else send[0]
+        need = ~mine
+        if bool(need.any()):
+            order = torch.argsort(got[:, 0])
+            sk, sg = got[order, 0].contiguous(), got[order, 1]
+            pos = torch.searchsorted(sk, k[need]).clamp_(max=max(int(sk.shape[0]) - 1, 0))
+            if sk.shape[0] == 0 or not bool((sk[pos] == k[need]).all()):
+                raise RuntimeError("rank %d: a shared face vertex was not emitted by its owner rank (level sets differ between ranks)" % me)
+            gid_local[need] = sg[pos]
+        tri = gid_local[t] if t.shape[0] else t
+        return ShardedMesh(v[mine], k[mine], tri, voff, toff, int(allc[:, 0].sum()), int(allc[:, 1].sum()))
+
     def gather_densities(self):
         """Global density vector on every rank (tests): owned entries from every rank, ordered by global id."""
         g = self.last["gids"][self.last["owned"]]
@@ -421,22 +599,13 @@ class ShardedReconstruction:
         return out
 
     def gather_mesh(self, step_result):
-        """All ranks: returns (vertices, keys, triangles) of the merged mesh on rank 0 (None elsewhere).
-        Duplicated face vertices are removed by global edge key; the lowest rank's copy is kept."""
-        r = step_result.local
-        v = torch.as_tensor(np.ascontiguousarray(r.mesh.vertices, dtype=np.float32)).to(self.device)
-        k = torch.as_tensor(np.ascontiguousarray(r.vertex_keys).astype(np.int64)).to(self.device)
-        t = torch.as_tensor(np.ascontiguousarray(r.mesh.triangles).astype(np.int64)).to(self.device)
-        V, vc = self._all_gather_rows(v)
-        K, _ = self._all_gather_rows(k)
-        T, tc = self._all_gather_rows(t)
+        """All ranks: the assembled mesh (vertices, keys, triangles) as numpy arrays on rank 0 (None elsewhere) -- the
+        concatenation over ranks of what `assemble` left on each of them."""
+        m = self.assemble(step_result)
+        V, _ = self._all_gather_rows(m.vertices)
+        K, _ = self._all_gather_rows(m.keys)
+        T, _ = self._all_gather_rows(m.triangles)
         if self.rank != 0:
             return None
-        V, K, T = V.cpu().numpy(), K.cpu().numpy(), T.cpu().numpy()
-        voff = np.concatenate([[0], np.cumsum(vc)])
-        toff = np.concatenate([[0], np.cumsum(tc)])
-        for q in range(len(vc)):
-            T[toff[q]:toff[q + 1]] += voff[q]
-        uk, first = np.unique(K, return_index=True)  # first occurrence = lowest rank
-        remap = np.searchsorted(uk, K)
-        return V[first], uk.astype(np.uint64), remap[T].astype(np.uint64)
+        assert V.shape[0] == m.n_vertices_total and T.shape[0] == m.n_triangles_total
+        return V.cpu().numpy(), K.cpu().numpy().astype(np.uint64), T.cpu().numpy().astype(np.uint64)

@@ -53,6 +53,7 @@ def _ptr(a):
         return None
     if _is_tensor(a):
         assert a.is_contiguous()
+        api.sync_tensor_producer(a)
         return C.c_void_p(a.data_ptr())
     assert a.flags["C_CONTIGUOUS"]
     return a.ctypes.data_as(C.c_void_p)

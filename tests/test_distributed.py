@@ -97,7 +97,9 @@ def _free_port():
 
 
 @pytest.mark.parametrize("case,world,exchange", [("dam_break_n16", 2, "p2p"), ("hilbert_n32", 2, "p2p"), ("lattice_n8", 2, "p2p"), ("dam_break_n16", 3, "p2p"),
-                                                 ("dam_break_n16", 3, "allgather"), ("tank_slabs", 2, "p2p")])
+                                                 ("dam_break_n16", 3, "allgather"), ("tank_slabs", 2, "p2p"),
+                                                 # four and five bricks: cuts along two axes, edges shared by up to four ranks
+                                                 ("dam_break_n16", 4, "p2p"), ("hilbert_n32", 5, "p2p")])
 def test_ranks_reproduce_single_process(tmp_path, oracle, case, world, exchange):
     import mesh_compare as MC
     out = str(tmp_path / "merged.npz")
@@ -113,13 +115,13 @@ def test_ranks_reproduce_single_process(tmp_path, oracle, case, world, exchange)
     # face vertices: each rank's lowest-index subdomain wins; identical to the single-process choice
     assert cmp["vertices_bit_equal"], cmp
     if case == "tank_slabs":
-        # equally long axes: the slabs are cut along y, where the ranks' inputs are already separated
+        # a 2x2x2 subdomain grid: exactly one axis is cut, into two bricks of one layer each
         par = oracle.make_params_relative(r, l, c, subdomain_num_cubes_per_dim=n_cubes)
         _, sg, _ = oracle.grid_for_domain(par, pts.min(axis=0), pts.max(axis=0))
         ns = [int(x) for x in sg["n_cells"]]
         hi = [int(x) for x in got["slab"][1]]
-        assert ns[0] == ns[1] == ns[2], ns  # the tie this case is about
-        assert hi[0] == ns[0] and hi[2] == ns[2] and 0 < hi[1] < ns[1], (hi, ns)
+        assert ns[0] == ns[1] == ns[2] == 2, ns
+        assert sorted(hi) == [1, 2, 2], (hi, ns)
 
 
 def test_partition_is_balanced_and_contiguous():
@@ -135,6 +137,43 @@ def test_partition_is_balanced_and_contiguous():
     # more ranks than subdomains: trailing ranks get empty slabs, nothing is lost
     slabs = partition_slabs(x, 0.0, 5.0, 2, 4)
     assert slabs[-1][1] == 2 and sum(hi - lo for lo, hi in slabs) == 2
+
+
+def _brick_cells(b):
+    (a0, a1, a2), (b0, b1, b2) = b
+    return max(b0 - a0, 0) * max(b1 - a1, 0) * max(b2 - a2, 0)
+
+
+@pytest.mark.parametrize("world", [1, 2, 3, 4, 5, 8, 16])
+def test_bricks_tile_the_grid_and_balance(world):
+    """Recursive bisection of the subdomain grid: bricks are disjoint, cover every subdomain, and split the particles of
+    an S40M-tank-shaped histogram (two separated fluid blocks, whole-subdomain cut planes) within 15 % of the mean."""
+    sys.path.insert(0, ROOT)
+    from splashsurf_amd.distributed import bricks_from_histogram
+    ns = (40, 21, 40)
+    hist = np.zeros(ns, dtype=np.int64)
+    hist[0:13, 0:20, 0:20] = 4800
+    hist[12, :, :] //= 2       # partially filled boundary layers
+    hist[0:13, 19, 0:20] //= 3
+    hist[27:40, 0:20, 20:40] = 4800
+    hist[27, :, :] //= 4
+    bricks = bricks_from_histogram(hist, world, axis_pref=(0.1, 1.0, 1.0))
+    assert len(bricks) == world
+    cover = np.zeros(ns, dtype=np.int32)
+    own = []
+    for a, b in bricks:
+        cover[a[0]:b[0], a[1]:b[1], a[2]:b[2]] += 1
+        own.append(int(hist[a[0]:b[0], a[1]:b[1], a[2]:b[2]].sum()))
+    assert (cover == 1).all()
+    assert sum(own) == int(hist.sum())
+    if world <= 8:
+        assert max(own) <= 1.15 * (sum(own) / world), own
+    # more ranks than subdomains: the surplus ranks get empty bricks, nothing is lost or duplicated
+    tiny = bricks_from_histogram(np.ones((1, 2, 1)), 5)
+    assert sum(_brick_cells(b) for b in tiny) == 2 and sum(1 for b in tiny if _brick_cells(b) == 0) == 3
+    # an empty domain still yields a valid tiling
+    empty = bricks_from_histogram(np.zeros((3, 3, 3)), 4)
+    assert sum(_brick_cells(b) for b in empty) == 27
 
 
 # ---------------------------------------------------------------------------------------------------------------

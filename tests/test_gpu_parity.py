@@ -284,6 +284,86 @@ def test_sharded_engine_reproduces_full_reconstruction(oracle, case):
     assert cmp["keys_equal"] and cmp["triangles_equal"] and cmp["vertices_bit_equal"], cmp
 
 
+def _pseudo_rank_bricks(pts, prm, k, dt=np.float32):
+    """k pseudo-ranks (one HIP context each, all on GPU 0) reconstruct the bricks `bricks_from_histogram` cuts for k ranks,
+    through ss_shard_begin / ss_shard_finish with the density exchange done by hand.  Returns the merged mesh
+    (vertices, keys, triangles), the global density vector and the bricks."""
+    import torch
+    from splashsurf_amd import distributed as D
+    from splashsurf_amd.api import Context
+    engines = [D.HipEngine(Context(0), prm, dtype=dt) for _ in range(k)]
+    P_all = torch.from_numpy(pts).to("cuda:0")
+    dmin, dmax = pts.min(axis=0), pts.max(axis=0)
+    gmin, sub_size, ns, margin, _ = engines[0].grid_for_domain(dmin, dmax)
+    sub = [torch.floor((P_all[:, d] - float(gmin[d])) / sub_size).to(torch.int64).clamp_(0, ns[d] - 1) for d in range(3)]
+    hist3 = torch.bincount((sub[0] * ns[1] + sub[1]) * ns[2] + sub[2], minlength=ns[0] * ns[1] * ns[2]).cpu().numpy().reshape(ns)
+    bricks = D.bricks_from_histogram(hist3, k)
+    rho_global = torch.zeros(pts.shape[0], dtype=torch.float32 if dt == np.float32 else torch.float64, device="cuda:0")
+    sel = []
+    pad = margin * 1.001 + 1e-6
+    for q, (lo, hi) in enumerate(bricks):
+        m = torch.ones(P_all.shape[0], dtype=torch.bool, device="cuda:0")
+        for d in range(3):
+            m &= (P_all[:, d] >= float(gmin[d]) + lo[d] * sub_size - pad) & (P_all[:, d] <= float(gmin[d]) + hi[d] * sub_size + pad)
+        if any(hi[d] <= lo[d] for d in range(3)):
+            m &= False
+        ids = torch.nonzero(m, as_tuple=False).squeeze(1)
+        L = P_all.index_select(0, ids).contiguous()
+        rho_local = engines[q].begin(L, D.ShardDesc(dmin, dmax, lo, hi))
+        rho_global.index_add_(0, ids, rho_local)  # stands in for the exchange: one non-zero contribution per particle
+        sel.append(ids)
+    V, K, T = [], [], []
+    voff = 0
+    for q in range(k):
+        res = engines[q].finish(rho_global.index_select(0, sel[q]).contiguous())
+        V.append(res.mesh.vertices)
+        K.append(res.vertex_keys)
+        T.append(res.mesh.triangles.astype(np.int64) + voff)
+        voff += res.mesh.vertices.shape[0]
+    for e in engines:
+        e.result._free()
+        e.ctx.close()
+    return np.concatenate(V), np.concatenate(K), np.concatenate(T), rho_global.cpu().numpy(), bricks
+
+
+def test_config4_s40m_tank(gpu_ctx):
+    """BASELINE config 4 (S40M-tank, 39.8 M particles): (a) the full cloud once on ONE GPU -- closed manifold mesh, unique
+    edge keys, every density positive; (b) a 1.24 M-particle crop of the same tank cut into the 4 and 8 bricks the
+    multi-GPU path uses (pseudo-ranks on one device through the shard ABI) equals the direct reconstruction bit for bit."""
+    import splashsurf_amd as S
+    from splashsurf_amd import workloads as W
+    from splashsurf_amd.api import Parameters
+    wl = W.WORKLOADS["s40m_tank"]
+    kw = dict(particle_radius=wl["particle_radius"], smoothing_length=wl["smoothing_length"], cube_size=wl["cube_size"], iso_surface_threshold=0.6)
+    pts = wl["gen"]()
+    assert pts.shape[0] > 39_000_000
+    res = run_gpu(gpu_ctx, pts, kw)
+    nv, nt = res.counts()
+    assert nv > 15_000_000 and nt > 30_000_000
+    assert res.stats["n_large_tile_blocks"] == 0
+    tri = res.mesh.triangles_u32
+    assert MC.mesh_is_closed_manifold(tri)
+    keys = res.vertex_keys
+    assert np.unique(keys).size == keys.size
+    rho = res.particle_densities
+    assert rho.shape[0] == pts.shape[0] and float(rho.min()) > 0.0
+    del res, tri, keys, rho, pts
+    # (b) bricks == direct on a >= 1 M crop
+    crop = W.tank_particles(0.5)
+    assert crop.shape[0] >= 1_000_000
+    direct = run_gpu(gpu_ctx, crop, kw)
+    r = wl["particle_radius"]
+    prm = Parameters(particle_radius=r, compact_support_radius=np.float32(2.0 * wl["smoothing_length"] * r), cube_size=np.float32(wl["cube_size"] * r),
+                     auto_disable=False, enable_simd=False)
+    for k in (4, 8):
+        V, K, T, rho_g, bricks = _pseudo_rank_bricks(crop, prm, k)
+        assert sum(1 for lo, hi in bricks if all(hi[d] > lo[d] for d in range(3))) == k
+        assert np.array_equal(rho_g.view(np.uint32), direct.particle_densities.view(np.uint32))
+        uk, first = np.unique(K, return_index=True)
+        cmp = MC.compare_keyed(V[first], uk, np.searchsorted(uk, K)[T], direct.mesh.vertices, direct.vertex_keys, direct.mesh.triangles)
+        assert cmp["keys_equal"] and cmp["triangles_equal"] and cmp["vertices_bit_equal"], cmp
+
+
 def test_full_size_s10m_tank_bit_identical_to_oracle(gpu_ctx, oracle):
     """BASELINE config 3 at FULL size (10 M particles, ~2.3 G grid cells): the whole result -- 10 M
     densities, 7.2 M vertices, 14.4 M triangles -- equals the CPU oracle bit for bit; plus the
