@@ -42,7 +42,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default=None, help="default: s10m_tank at 1 GPU, s40m_tank (fixed size, sharded) at N > 1")
     ap.add_argument("--scaling", choices=["strong", "weak"], default="strong", help="N > 1 only: fixed total size (default) or one tank per rank")
-    ap.add_argument("--simd", type=int, choices=[0, 1], default=None,
+    ap.add_argument("--simd", type=int, choices=[0, 1, 2], default=None,
                     help="Parameters::enable_simd for the headline value (default: the library default, see DESIGN.md section 5)")
     ap.add_argument("--main-only", action="store_true",
                     help="only the timed steps of the named workload (no host-input variants, no other configs, no CPU baseline): "
@@ -78,7 +78,7 @@ def make_params(wl, simd=None, **over):
     r = wl["particle_radius"]
     kw = dict(particle_radius=r, compact_support_radius=np.float32(2.0 * wl["smoothing_length"] * r), cube_size=np.float32(wl["cube_size"] * r), auto_disable=False)
     if simd is not None:
-        kw["enable_simd"] = bool(simd)
+        kw["enable_simd"] = int(simd)
     kw.update(over)
     return Parameters(**kw)
 
@@ -314,7 +314,7 @@ def main():
         "config": {
             "workload": workload, "n_particles": int(n_total), "particle_radius": r, "smoothing_length": wl["smoothing_length"],
             "cube_size": wl["cube_size"], "n_vertices": int(last_stats["n_vertices"]), "n_triangles": int(last_stats["n_triangles"]),
-            "enable_simd": bool(prm.enable_simd),
+            "enable_simd": int(prm.enable_simd), "arith_mode": int(last_stats.get("arith_mode", -1)),
             "input": "HBM-resident (x,y,z) f32 (the task contract's definition of `value`; host-to-host figures: e2e_host_u64, pcie_inclusive)",
             "output": "mesh in HBM (vertices f32, triangles u32, global edge keys)", "parallelism": parallelism,
         },
@@ -345,7 +345,7 @@ def attach_traffic(line, workload, dev):
     try:
         tr = json.load(open(os.path.join(ROOT, "profiles", "splat_traffic.json"))).get(workload)
         if isinstance(tr, dict) and "simd" in tr and "scalar" in tr:
-            tr = tr["simd" if line["config"].get("enable_simd") else "scalar"]
+            tr = tr[{0: "scalar", 1: "simd", 2: "simd_hw"}[int(line["config"].get("enable_simd", 0))]]
         if tr and tr.get("kernel", "").startswith(line["roofline"]["kernel"]):
             line["roofline"]["traffic"] = tr["hbm_bytes_per_launch"]
             line["roofline"]["traffic_note"] = tr["note"]
@@ -369,17 +369,27 @@ def single_gpu_extras(line, args, ctx, prm, wl, workload, pts, d_pts, out, dev, 
     from splashsurf_amd.api import Context
     n_total = pts.shape[0]
     nsc = int(prm.subdomain_num_cubes_per_dim) + 1
-    # --- the other arithmetic mode of the same workload (Parameters::enable_simd), with its own roofline ---
-    try:
-        other = make_params(wl, simd=not prm.enable_simd)
-        dt_o, o_o, k3_o = timed_direct(ctx, other, d_pts, max(3, args.steps // 2), 1, sync)
-        n_occ_o, n_subp_o = o_o.subdomain_stats()
-        line["other_arithmetic_mode"] = {"enable_simd": bool(other.enable_simd), "value": round(n_total / dt_o / 1e6, 3), "unit": "Mparticles/s",
-                                         "ms_per_step": round(dt_o * 1e3, 3), "roofline": splat_roofline(o_o.stats, n_occ_o, n_subp_o, nsc, *k3_o),
-                                         "n_vertices": int(o_o.stats["n_vertices"]), "n_triangles": int(o_o.stats["n_triangles"])}
-        out = ctx.reconstruct(d_pts, prm, out=o_o)
-    except Exception as e:
-        line["other_arithmetic_mode"] = {"value": None, "note": "failed: %r" % (e,)}
+    # --- the other arithmetic modes of the same workload (Parameters::enable_simd: 0 scalar bit-exact, 1 the reference's
+    #     default SIMD arithmetic, 2 the same with v_sqrt_f32), each with its own roofline ---
+    modes = {}
+    names = {0: "scalar_bit_exact", 1: "simd", 2: "simd_hw_sqrt"}
+    for m in (0, 1, 2):
+        if m == int(prm.enable_simd):
+            modes[names[m]] = {"enable_simd": m, "value": line["value"], "unit": "Mparticles/s", "ms_per_step": line["ms_per_step"],
+                               "roofline": dict(line["roofline"]), "headline": True}
+            continue
+        try:
+            other = make_params(wl, simd=m)
+            other.enable_simd = m
+            dt_o, o_o, k3_o = timed_direct(ctx, other, d_pts, max(3, args.steps // 2), 1, sync)
+            n_occ_o, n_subp_o = o_o.subdomain_stats()
+            modes[names[m]] = {"enable_simd": m, "value": round(n_total / dt_o / 1e6, 3), "unit": "Mparticles/s", "ms_per_step": round(dt_o * 1e3, 3),
+                               "roofline": splat_roofline(o_o.stats, n_occ_o, n_subp_o, nsc, *k3_o), "arith_mode": int(o_o.stats.get("arith_mode", -1)),
+                               "n_vertices": int(o_o.stats["n_vertices"]), "n_triangles": int(o_o.stats["n_triangles"])}
+            del o_o
+        except Exception as e:
+            modes[names[m]] = {"enable_simd": m, "value": None, "note": "failed: %r" % (e,)}
+    line["arithmetic_modes"] = modes
     # --- host-resident input -> host-resident output through the C ABI's host accessors ---
     host_pts = pts
     for key, u64, note in (("e2e_host_u64", True, "pageable host (numpy) input via ss_reconstruct_surface_inplace_f32; vertices through ss_result_vertices and "

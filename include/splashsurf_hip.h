@@ -20,6 +20,12 @@
  * memory lazily by the accessors that return host pointers; free with `ss_result_free`.
  * One context may be used by one thread at a time; several contexts (also on several GPUs) may
  * coexist.  All functions return an `ss_status`; `ss_last_error` gives the message.
+ *
+ * Stream ordering: every context runs on its own non-blocking HIP stream (or the one given to
+ * ss_context_set_stream) and synchronises it before returning, so OUTPUTS are complete on return.  DEVICE-pointer
+ * INPUTS must be complete before the call: whatever produced them on another stream has to have finished (or the
+ * library has to be put on that stream with ss_context_set_stream).  splashsurf_amd/api.py synchronises torch's
+ * current stream before handing a tensor over.
  */
 #ifndef SPLASHSURF_HIP_H
 #define SPLASHSURF_HIP_H
@@ -30,7 +36,7 @@
 extern "C" {
 #endif
 
-#define SS_ABI_VERSION 2
+#define SS_ABI_VERSION 3
 
 /* Return codes; 1..4 mirror ReconstructionError (lib.rs:289-314). */
 typedef enum ss_status {
@@ -65,7 +71,21 @@ typedef struct ss_params_f32 {
     int32_t enable_multi_threading; /* accepted for API parity; the GPU path is always parallel.  Results of the global
                                      * strategy are those of the reference with enable_multi_threading = false (its only
                                      * deterministic mode, reconstruction.rs:65-194) */
-    int32_t enable_simd;            /* accepted for API parity; results follow the reference's scalar path */
+    int32_t enable_simd;            /* Parameters::enable_simd (lib.rs:179-181; the reference's default is true), f32 only -- the
+                                     * reference's SIMD loop exists for <i64, f32> alone (dense_subdomains.rs:1413-1415):
+                                     * 0  level set by the scalar loop (dense_subdomains.rs:784-847, kernel.rs:58-107), bit-identical
+                                     *    to the reference with enable_simd = false;
+                                     * 1  the arithmetic of the AVX2+FMA loop (dense_subdomains.rs:991-1133, kernel.rs:319-378) for
+                                     *    EVERY (particle, grid point) pair: d^2 by two fma, support d^2 < h^2, correctly rounded sqrt,
+                                     *    q = r * (1/h), v = max(1 - q, 0), fma polynomial with sigma = 8/(pi h^3), fma accumulate.
+                                     *    The reference itself mixes three arithmetics under this flag (vector lanes, unfused
+                                     *    remainder lanes, the scalar loop for sparse subdomains), so its values on shared subdomain
+                                     *    faces depend on the subdomain; this library computes every global grid point once.  Meshes
+                                     *    agree with the reference's enable_simd = true output in topology and to ~1e-6 relative in
+                                     *    vertex positions;
+                                     * 2  (extension) as 1 with the hardware v_sqrt_f32 (<= 1 ulp) instead of the correctly rounded
+                                     *    root: the fastest mode, same tolerance class.
+                                     * Particle densities never depend on this flag (they do not in the reference either). */
     int32_t decomposition;          /* 0 = SpatialDecomposition::None (global strategy, reconstruction.rs:65-112),
                                      * 1 = UniformGrid (subdomain grid, the optimised path) */
     uint32_t subdomain_num_cubes_per_dim; /* default 64 */
@@ -130,9 +150,13 @@ typedef struct ss_stats {
     uint64_t fast_div_verified;       /* 1 if the splat used the exhaustively verified reciprocal division for this h */
     uint64_t levelset_kernel_launches;
     uint64_t bytes_device_peak;       /* HBM held by the context after this call */
-    double ms_levelset_gather;        /* part of ms_levelset: k_splat_gather (candidate tiles, one wave per block) */
+    double ms_levelset_gather;        /* part of ms_levelset: k_splat_count + offsets + k_splat_gather[_large] (index-ordered candidate tiles) */
     double ms_levelset_accumulate;    /* part of ms_levelset: k_splat_accumulate (the arithmetic; the dominant kernel) */
-    uint64_t n_large_tile_blocks;     /* blocks handled by the large-tile kernel (over-dense tiles) */
+    uint64_t n_large_tile_blocks;     /* blocks whose candidate tile (> 384 entries) was ordered by the workgroup-level gather */
+    uint64_t arith_mode;              /* arithmetic of the level-set accumulation that ran: 0 scalar (generic sqrt/divide), 1 scalar
+                                       * (lean exact sqrt + verified reciprocal division), 2 / 3 SIMD with correctly rounded sqrt
+                                       * (generic / lean), 4 SIMD with v_sqrt_f32 */
+    uint64_t bytes_tile_arena;        /* bytes of index-ordered candidate tiles written and re-read by the splat (exact size) */
 } ss_stats;
 
 typedef struct ss_context ss_context;

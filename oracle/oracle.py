@@ -28,6 +28,7 @@ def _make_structs(real):
             ("num_threads", C.c_int32),
             ("global_neighborhood_list", C.c_int32),
             ("global_strategy", C.c_int32),
+            ("enable_simd", C.c_int32),
         ]
 
     class Grid(C.Structure):
@@ -133,10 +134,12 @@ def lib():
 def make_params(particle_radius, compact_support_radius, cube_size, rest_density=1000.0,
                 iso_surface_threshold=0.6, aabb_min=None, aabb_max=None,
                 subdomain_num_cubes_per_dim=64, num_threads=0, global_neighborhood_list=False, dtype=np.float32,
-                subdomain_grid=True, subdomain_grid_auto_disable=False):
+                subdomain_grid=True, subdomain_grid_auto_disable=False, simd=0):
     """Absolute-unit parameters (lib.rs:197-210), rounded to `dtype` (float32: so_*, float64: so64_*).
     subdomain_grid=False: SpatialDecomposition::None; subdomain_grid_auto_disable=True: the reference's
-    default rule (global strategy when the domain has <= 1.2 n cells per dimension, lib.rs:421-441)."""
+    default rule (global strategy when the domain has <= 1.2 n cells per dimension, lib.rs:421-441).
+    simd: 0 = scalar level-set loop (Parameters::enable_simd = false); 1 = the reference's AVX2+FMA loop for dense
+    subdomains, f32 only (enable_simd = true on x86-64); 2 = that arithmetic applied uniformly (splash_oracle_decl.h)."""
     _, npdt, _, (Pm, _, _, _) = _flavour(np.dtype(dtype))
     p = Pm()
     p.particle_radius = npdt(particle_radius)
@@ -155,6 +158,7 @@ def make_params(particle_radius, compact_support_radius, cube_size, rest_density
     p.num_threads = int(num_threads)
     p.global_neighborhood_list = 1 if global_neighborhood_list else 0
     p.global_strategy = 1 if not subdomain_grid else (2 if subdomain_grid_auto_disable else 0)
+    p.enable_simd = int(simd)
     return p
 
 

@@ -623,6 +623,105 @@ static void density_grid_loop_scalar(const sd_params *S, const int64_t sub[3], c
     }
 }
 
+#ifndef SO_F64
+/* ------------------------------------------------------------------------------------------
+ * Level-set evaluation, AVX2+FMA loop (dense_subdomains.rs:991-1133) with CubicSplineKernelAvxF32
+ * (kernel.rs:319-378), restated lane by lane with fmaf.  `uniform` != 0: mode 2 of so_params.enable_simd
+ * (every lane takes the fused vector path).
+ * ------------------------------------------------------------------------------------------ */
+typedef struct {
+    float inv_h, sigma, sigma2, sigma6, sigma12;
+} avx_kernel;
+
+static avx_kernel avx_kernel_new(float h) { /* kernel.rs:327-337 */
+    avx_kernel k;
+    const float pi = 3.14159265358979323846f; /* std::f32::consts::PI */
+    k.inv_h = 1.0f / h;
+    const float rrr = h * h * h;
+    k.sigma = 8.0f / (pi * rrr);
+    k.sigma2 = 2.0f * k.sigma;
+    k.sigma6 = 6.0f * k.sigma;
+    k.sigma12 = 12.0f * k.sigma;
+    return k;
+}
+
+static inline float avx_kernel_evaluate(const avx_kernel *K, float r) { /* kernel.rs:341-377 */
+    const float q = r * K->inv_h;
+    float v = 1.0f - q;
+    v = v > 0.0f ? v : 0.0f; /* _mm256_max_ps(v, zero) */
+    const float v2 = v * v;
+    const float v3 = v2 * v;
+    const float res_outer = v3 * K->sigma2;
+    float res_inner = K->sigma;
+    res_inner = fmaf(-v, K->sigma6, res_inner);  /* _mm256_fnmadd_ps */
+    res_inner = fmaf(v2, K->sigma12, res_inner); /* _mm256_fmadd_ps */
+    res_inner = fmaf(-v3, K->sigma6, res_inner);
+    return (q <= 0.5f) ? res_inner : res_outer; /* _CMP_LE_OQ + blendv */
+}
+
+float so_avx_kernel_evaluate(float h, float r) {
+    const avx_kernel K = avx_kernel_new(h);
+    return avx_kernel_evaluate(&K, r);
+}
+
+static void density_grid_loop_avx(const sd_params *S, const int64_t sub[3], const float *pos, const float *rho, size_t P,
+                                  float *levelset, int uniform) {
+    const int64_t n = S->subdomain_cubes, np = n + 1;
+    float amin[3], amax[3];
+    subdomain_aabb(S, sub, amin, amax);
+    SOT(grid) mc;
+    int64_t nc3[3] = {n, n, n};
+    grid_new(&mc, amin, nc3, S->cube_size);
+    const int64_t cube_radius = (int64_t)(double)R_CEIL(S->h / S->cube_size);
+    const avx_kernel K = avx_kernel_new(S->h); /* :1023 */
+    const SOT(grid) *gg = &S->global_mc_grid;
+    const float cube_size = gg->cell_size;     /* :1035 */
+    const float support_sq = S->h * S->h;      /* :1037-1038 */
+    for (size_t a = 0; a < P; ++a) {
+        const float *p = pos + 3 * a;
+        const float v_i = S->particle_rest_mass / rho[a]; /* :1045 */
+        int64_t cell[3], lo[3], hi[3];
+        grid_enclosing_cell(&mc, p, cell);
+        for (int d = 0; d < 3; ++d) { /* particle_influence_aabb, :660-693 */
+            int64_t l = cell[d] - cube_radius;
+            if (l < 0) l = 0;
+            if (l > np) l = np;
+            int64_t u = cell[d] + cube_radius + 2;
+            if (u > np) u = np;
+            if (u < 0) u = 0;
+            lo[d] = l;
+            hi[d] = u;
+        }
+        if (hi[2] < lo[2]) continue;
+        const int64_t remainder = uniform ? 0 : (hi[2] - lo[2]) % 8; /* :1051-1052 */
+        const int64_t upper_k_aligned = hi[2] - remainder;
+        for (int64_t i = lo[0]; i < hi[0]; ++i) {
+            const int32_t global_i = (int32_t)sub[0] * (int32_t)n + (int32_t)i; /* :1110 */
+            const float grid_x = (float)global_i * cube_size + gg->aabb_min[0]; /* :1113, scalar Rust: mul then add */
+            const float dx = p[0] - grid_x;
+            for (int64_t j = lo[1]; j < hi[1]; ++j) {
+                const int32_t global_j = (int32_t)sub[1] * (int32_t)n + (int32_t)j;
+                const float grid_y = (float)global_j * cube_size + gg->aabb_min[1];
+                const float dy = p[1] - grid_y;
+                for (int64_t k = lo[2]; k < hi[2]; ++k) {
+                    const int32_t global_k = (int32_t)sub[2] * (int32_t)n + (int32_t)k;     /* :1067-1068 */
+                    const float grid_z = fmaf((float)global_k, cube_size, gg->aabb_min[2]); /* :1069 _mm256_fmadd_ps */
+                    const float dz = p[2] - grid_z;
+                    const float dist_sq = fmaf(dz, dz, fmaf(dx, dx, dy * dy));               /* :1077-1080 */
+                    if (!(dist_sq < support_sq)) continue; /* :1083-1086, 1091: masked lanes contribute +0 */
+                    const float w = avx_kernel_evaluate(&K, sqrtf(dist_sq)); /* :1089-1090 */
+                    float *g = &levelset[(i * np + j) * np + k];
+                    if (k < upper_k_aligned)
+                        *g = fmaf(w, v_i, *g); /* :1101-1107 */
+                    else
+                        *g += w * v_i;         /* remainder lanes, :1111-1124: mul, then scalar += */
+                }
+            }
+        }
+    }
+}
+#endif
+
 /* ------------------------------------------------------------------------------------------
  * Per-subdomain marching cubes (dense_subdomains.rs:1260-1329, 1470-1578)
  * ------------------------------------------------------------------------------------------ */
@@ -1320,6 +1419,14 @@ int SOFN(reconstruct_surface)(const real *xyz_in, uint64_t n_in, const SOT(param
 
     patch_t *patches = (patch_t *)calloc((size_t)(subs.n_sub ? subs.n_sub : 1), sizeof(patch_t));
     const int64_t np = S.subdomain_cubes + 1;
+    size_t max_particles = 0; /* dense_subdomains.rs:1241-1253 */
+    for (int64_t s = 0; s < subs.n_sub; ++s) {
+        size_t P_s = (size_t)(subs.offsets[s + 1] - subs.offsets[s]);
+        if (P_s > max_particles) max_particles = P_s;
+    }
+    size_t sparse_limit = max_particles / (100 / 5);
+    if (sparse_limit < 100) sparse_limit = 100;
+    (void)sparse_limit;
 #pragma omp parallel for schedule(dynamic, 1) num_threads(nthreads)
     for (int64_t s = 0; s < subs.n_sub; ++s) {
 #ifdef _OPENMP
@@ -1332,7 +1439,12 @@ int SOFN(reconstruct_surface)(const real *xyz_in, uint64_t n_in, const SOT(param
         ws_prepare_levelset(w, np);
         int64_t sub[3];
         grid_unflatten_cell(&S.subdomain_grid, subs.flat_index[s], sub);
-        density_grid_loop_scalar(&S, sub, w->pos, w->rho, P_s, w->levelset);
+#ifndef SO_F64
+        if (P->enable_simd == 2 || (P->enable_simd == 1 && P_s > sparse_limit)) /* :1590-1596, :1413-1415 */
+            density_grid_loop_avx(&S, sub, w->pos, w->rho, P_s, w->levelset, P->enable_simd == 2);
+        else
+#endif
+            density_grid_loop_scalar(&S, sub, w->pos, w->rho, P_s, w->levelset);
         triangulate_subdomain(&S, sub, w, &patches[s]);
     }
     double t4 = now_s();
@@ -1388,7 +1500,17 @@ int64_t SOFN(debug_levelset_subdomain)(const real *xyz, uint64_t n, const SOT(pa
         ws_prepare_levelset(w, np);
         int64_t sub[3];
         grid_unflatten_cell(&S.subdomain_grid, flat_subdomain, sub);
-        density_grid_loop_scalar(&S, sub, w->pos, w->rho, P_s, w->levelset);
+#ifndef SO_F64
+        size_t max_particles = 0;
+        for (int64_t q = 0; q < subs.n_sub; ++q)
+            if ((size_t)(subs.offsets[q + 1] - subs.offsets[q]) > max_particles) max_particles = (size_t)(subs.offsets[q + 1] - subs.offsets[q]);
+        size_t sparse_limit = max_particles / (100 / 5);
+        if (sparse_limit < 100) sparse_limit = 100;
+        if (P->enable_simd == 2 || (P->enable_simd == 1 && P_s > sparse_limit))
+            density_grid_loop_avx(&S, sub, w->pos, w->rho, P_s, w->levelset, P->enable_simd == 2);
+        else
+#endif
+            density_grid_loop_scalar(&S, sub, w->pos, w->rho, P_s, w->levelset);
         memcpy(out_grid, w->levelset, sizeof(real) * (size_t)(np * np * np));
         result = (int64_t)P_s;
     }

@@ -14,6 +14,13 @@ typedef struct SOT(params) {
     int32_t global_neighborhood_list;    /* lib.rs:185-188 */
     int32_t global_strategy; /* 0: subdomain grid (UniformGrid, auto_disable=false); 1: SpatialDecomposition::None;
                                 2: UniformGrid with auto_disable=true (lib.rs:419-462) */
+    int32_t enable_simd;     /* Parameters::enable_simd (lib.rs:179-181).  0: every subdomain runs density_grid_loop_scalar.
+                                1: f32 only, DENSE subdomains run the restatement of density_grid_loop_avx
+                                (dense_subdomains.rs:991-1133) incl. its unfused remainder lanes; sparse subdomains
+                                (<= max(100, max_particles/20) particles, :1248-1253, :1590-1596) stay scalar.
+                                2 (no counterpart in the reference): the AVX arithmetic applied uniformly to EVERY
+                                (particle, grid point) pair -- all lanes fused, no sparse/dense distinction -- which is
+                                what one value per global grid point means; correctly rounded sqrt. */
 } SOT(params);
 
 typedef struct SOT(grid) {

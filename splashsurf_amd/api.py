@@ -109,6 +109,8 @@ class _Stats(C.Structure):
         ("ms_levelset_gather", C.c_double),
         ("ms_levelset_accumulate", C.c_double),
         ("n_large_tile_blocks", C.c_uint64),
+        ("arith_mode", C.c_uint64),
+        ("bytes_tile_arena", C.c_uint64),
     ]
 
 
@@ -194,7 +196,7 @@ def load_library():
     L.ss_result_grid_f64.argtypes = [vp, P(_Grid64)]
     L.ss_result_subdomain_grid_f64.argtypes = [vp, P(_Grid64), P(i32)]
     L.ss_result_levelset_box_f64.argtypes = [vp, P(C.c_int64), P(C.c_int64), vp]
-    if L.ss_abi_version() != 2:
+    if L.ss_abi_version() != 3:
         raise ImportError("libsplashsurf_hip.so ABI version mismatch")
     _lib = L
     return L
@@ -215,7 +217,7 @@ class Parameters:
         self.iso_surface_threshold = float(iso_surface_threshold)
         self.particle_aabb = particle_aabb
         self.enable_multi_threading = bool(enable_multi_threading)
-        self.enable_simd = bool(enable_simd)
+        self.enable_simd = int(enable_simd)  # 0 scalar, 1 (True) the reference's SIMD arithmetic, 2 the same with v_sqrt_f32 (splashsurf_hip.h)
         self.subdomain_grid = bool(subdomain_grid)
         self.subdomain_num_cubes_per_dim = int(subdomain_num_cubes_per_dim)
         self.auto_disable = bool(auto_disable)

@@ -185,7 +185,23 @@ ss_status make_device_params(ss_context* ctx, const typename TypesOf<R>::params*
     P.mass = mass;
     P.threshold = prm->iso_surface_threshold;
     P.margin = margin;
-    P.reach = ss_sqrt(R(1.01)) * h * R(1.0001);
+    // Parameters::enable_simd (lib.rs:179-181): the SIMD loop of the reference exists for <i64, f32> only (dense_subdomains.rs:1413-1415)
+    const int simd = (sizeof(R) == 4) ? (prm->enable_simd == 2 ? 2 : (prm->enable_simd != 0 ? 1 : 0)) : 0;
+    P.arith = simd == 2 ? SS_ARITH_SIMD_HW : (simd == 1 ? SS_ARITH_SIMD : SS_ARITH_GENERIC);  // refined by choose_arith() once the device checks ran
+    // support of a particle on the grid: d^2 < 1.01 h^2 in the scalar loop (:1224-1226, :831), d^2 < h^2 in the SIMD loop (:1037-1038, :1083)
+    const R support_factor = simd ? R(1.0) : R(1.01);
+    P.reach = ss_sqrt(support_factor) * h * R(1.0001);
+    P.R2 = ((h * h) * support_factor) * R(1.0001);
+    {   // CubicSplineKernelAvxF32::new (kernel.rs:327-337), in f32 like the reference
+        const float hf = (float)h;
+        const float pi_f = 3.14159265358979323846f;
+        const float sig = 8.0f / (pi_f * (hf * hf * hf));
+        P.avx_inv_h = (R)(1.0f / hf);
+        P.avx_sigma = (R)sig;
+        P.avx_sigma2 = (R)(2.0f * sig);
+        P.avx_sigma6 = (R)(6.0f * sig);
+        P.avx_sigma12 = (R)(12.0f * sig);
+    }
     R amax = R(0.0);
     for (int d = 0; d < 3; ++d) amax = ss_max(amax, ss_max(std::fabs(g.aabb_min[d]), std::fabs(g.aabb_max[d])));
     P.coord_slack = R(16.0) * std::numeric_limits<R>::epsilon() * amax + 1e-30f;
@@ -819,38 +835,58 @@ ss_status phase_finish(ss_context* ctx, ss_result* res) {
     SS_HIP(ctx, hipMemsetAsync(ctx->counter.p, 0, 64, st));
     SS_HIP(ctx, hipEventRecord(ctx->ev[5], st));
 
-    // ---- K3: level-set splat ----
+    // ---- K3: level-set splat (count -> arena offsets -> gather/order -> accumulate; ss_kernels.hip) ----
     {
         const bool checked_now = sizeof(R) == 4 && ctx->fastdiv_h != (float)P.h;
         ss_status fs = ensure_fast_div<R>(ctx, P.h, st);  // normally done before the densities already
         if (fs != SS_OK) return fs;
         if (checked_now) SS_HIP(ctx, hipEventRecord(ctx->ev[5], st));  // keep the one-off check out of the splat timing
     }
-    // small-tile kernel first; blocks it could not hold are flagged, compacted in order and handed to the large-tile kernel
+    SSDevT<R> PK = P;
+    if (sizeof(R) == 4) {
+        const bool lean_ok = P.h > R(1.0e-9) && P.h < R(1.0e15);  // range in which the lean exact sqrt needs no scaling
+        if (P.arith == SS_ARITH_GENERIC && ctx->fastdiv_ok) PK.arith = SS_ARITH_FAST;
+        if (P.arith == SS_ARITH_SIMD && lean_ok) PK.arith = SS_ARITH_SIMD_LEAN;
+    }
     SS_HIP(ctx, ctx->splat_overflow.reserve(((size_t)n_active + 1) * 4 * 4 + 64));
-    uint32_t* ov_flag = ctx->splat_overflow.as<uint32_t>();
-    uint32_t* ov_rank = ov_flag + ((size_t)n_active + 1);
-    uint32_t* ov_list = ov_rank + ((size_t)n_active + 1);
-    uint32_t* ov_slot = ov_list + ((size_t)n_active + 1);
-    SS_HIP(ctx, hipMemsetAsync(ov_flag + n_active, 0, 4, st));
-    const bool fast = sizeof(R) == 4 && ctx->fastdiv_ok;
-    SS_HIP(ctx, ctx->splat_tiles.reserve((size_t)n_active * ss_splat_tile_entries() * sizeof(ss_real4<R>) + 64));
+    uint32_t* lg_flag = ctx->splat_overflow.as<uint32_t>();
+    uint32_t* lg_rank = lg_flag + ((size_t)n_active + 1);
+    uint32_t* lg_list = lg_rank + ((size_t)n_active + 1);
+    uint32_t* lg_slot = lg_list + ((size_t)n_active + 1);
     SS_HIP(ctx, ctx->splat_counts.reserve(((size_t)n_active + 1) * 4));
-    ss_launch_splat_small(P, res->posvol.as<ss_real4<R>>(), res->perm.as<uint32_t>(), ctx->cell_start.as<uint32_t>(), res->active_xyz.as<uint32_t>(), n_active,
-                          ctx->splat_tiles.as<ss_real4<R>>(), ctx->splat_counts.as<uint32_t>(), res->G.as<R>(), res->blk_minmax.as<ss_real2<R>>(),
-                          ctx->counter.as<unsigned long long>(), ov_flag, fast, ctx->ev[12], ctx->ev[13], st);
+    SS_HIP(ctx, ctx->splat_off.reserve(((size_t)n_active + 1) * 8));
+    uint64_t n_cand = 0;
+    uint32_t n_large = 0;
     if (n_active) {
-        s = exclusive_scan_u32<uint32_t>(ctx, ov_flag, ov_rank, (size_t)n_active + 1);
+        SS_HIP(ctx, hipMemsetAsync(lg_flag + n_active, 0, 4, st));
+        SS_HIP(ctx, hipMemsetAsync(ctx->splat_counts.as<uint32_t>() + n_active, 0, 4, st));
+        ss_launch_splat_count(PK, res->posvol.as<ss_real4<R>>(), ctx->cell_start.as<uint32_t>(), res->active_xyz.as<uint32_t>(), n_active,
+                              ctx->splat_counts.as<uint32_t>(), lg_flag, st);
+        {   // tile_off = exclusive scan of the counts in 64 bits (the arena of S40M-tank holds > 2^32 bytes)
+            auto it = rocprim::make_transform_iterator(ctx->splat_counts.as<uint32_t>(), WidenU32());
+            size_t bytes = 0;
+            SS_HIP(ctx, rocprim::exclusive_scan(nullptr, bytes, it, ctx->splat_off.as<unsigned long long>(), 0ull, (size_t)n_active + 1, rocprim::plus<unsigned long long>(), st));
+            SS_HIP(ctx, ctx->temp.reserve(bytes));
+            SS_HIP(ctx, rocprim::exclusive_scan(ctx->temp.p, bytes, it, ctx->splat_off.as<unsigned long long>(), 0ull, (size_t)n_active + 1, rocprim::plus<unsigned long long>(), st));
+        }
+        s = exclusive_scan_u32<uint32_t>(ctx, lg_flag, lg_rank, (size_t)n_active + 1);
         if (s != SS_OK) return s;
-        ss_launch_compact_blocks(ov_flag, ov_rank, n_active, ov_list, ov_slot, st);
-        ss_launch_splat_large(P, res->posvol.as<ss_real4<R>>(), res->posvol_by_index.as<ss_real4<R>>(), res->perm.as<uint32_t>(), ctx->cell_start.as<uint32_t>(), res->active_xyz.as<uint32_t>(), n_active,
-                              res->G.as<R>(), res->blk_minmax.as<ss_real2<R>>(), ctx->counter.as<unsigned long long>(), ov_list, ov_rank + n_active, fast, st);
+        unsigned long long h_total = 0;
+        SS_HIP(ctx, hipMemcpyAsync(&h_total, ctx->splat_off.as<unsigned long long>() + n_active, 8, hipMemcpyDeviceToHost, st));
+        SS_HIP(ctx, hipMemcpyAsync(&n_large, lg_rank + n_active, 4, hipMemcpyDeviceToHost, st));
+        SS_HIP(ctx, hipStreamSynchronize(st));
+        n_cand = h_total;
+        SS_HIP(ctx, ctx->splat_tiles.reserve((size_t)n_cand * sizeof(ss_real4<R>) + 64));
+        if (n_large) ss_launch_compact_blocks(lg_flag, lg_rank, n_active, lg_list, lg_slot, st);
+        ss_launch_splat_gather(PK, res->posvol.as<ss_real4<R>>(), res->posvol_by_index.as<ss_real4<R>>(), res->perm.as<uint32_t>(), ctx->cell_start.as<uint32_t>(),
+                               res->active_xyz.as<uint32_t>(), n_active, ctx->splat_counts.as<uint32_t>(), ctx->splat_off.as<unsigned long long>(),
+                               ctx->splat_tiles.as<ss_real4<R>>(), lg_list, n_large, st);
     }
+    SS_HIP(ctx, hipEventRecord(ctx->ev[12], st));
+    ss_launch_splat_accumulate(PK, ctx->splat_tiles.as<ss_real4<R>>(), ctx->splat_off.as<unsigned long long>(), ctx->splat_counts.as<uint32_t>(),
+                               res->active_xyz.as<uint32_t>(), n_active, res->G.as<R>(), res->blk_minmax.as<ss_real2<R>>(), st);
+    SS_HIP(ctx, hipEventRecord(ctx->ev[13], st));
     SS_HIP(ctx, hipEventRecord(ctx->ev[6], st));
-    if (n_active) {  // candidates of the small tiles (the large-tile kernel adds its own to counter[0])
-        s = sum_u32_to_u64(ctx, ctx->splat_counts.as<uint32_t>(), n_active, ctx->counter.as<unsigned long long>() + 1);
-        if (s != SS_OK) return s;
-    }
 
     // ---- K4 prepare: MC blocks = blocks whose 2x2x2 level-set neighbourhood straddles the threshold ----
     ss_launch_mark_mc_blocks(P, res->block_slot.as<uint32_t>(), res->blk_minmax.as<ss_real2<R>>(), (uint32_t)nblocks, ctx->mc_flag.as<uint32_t>(), st);
@@ -885,10 +921,6 @@ ss_status phase_finish(ss_context* ctx, ss_result* res) {
     uint32_t totals[2] = {0, 0};
     SS_HIP(ctx, hipMemcpyAsync(&totals[0], res->vbase.as<uint32_t>() + n_mc, 4, hipMemcpyDeviceToHost, st));
     SS_HIP(ctx, hipMemcpyAsync(&totals[1], res->tbase.as<uint32_t>() + n_mc, 4, hipMemcpyDeviceToHost, st));
-    unsigned long long cand2[2] = {0, 0};
-    SS_HIP(ctx, hipMemcpyAsync(cand2, ctx->counter.p, 16, hipMemcpyDeviceToHost, st));
-    uint32_t n_large = 0;
-    if (n_active) SS_HIP(ctx, hipMemcpyAsync(&n_large, ctx->splat_overflow.as<uint32_t>() + ((size_t)n_active + 1) + n_active, 4, hipMemcpyDeviceToHost, st));
     SS_HIP(ctx, hipStreamSynchronize(st));
     const uint64_t nv = totals[0], nt = totals[1];
     if (nt * 3 >= (1ull << 32)) return fail(ctx, SS_ERR_UNSUPPORTED, "more than 2^32/3 triangles in one call are not supported by this build");
@@ -925,15 +957,17 @@ ss_status phase_finish(ss_context* ctx, ss_result* res) {
     S.n_vertices = nv;
     S.n_triangles = nt;
     S.n_active_blocks = n_active;
-    S.n_block_candidates = cand2[0] + cand2[1];
+    S.n_block_candidates = n_cand;
     S.n_large_tile_blocks = n_large;
     S.fast_div_verified = ctx->fastdiv_ok ? 1 : 0;
+    S.arith_mode = (uint64_t)PK.arith;
+    S.bytes_tile_arena = (uint64_t)n_cand * sizeof(ss_real4<R>);
     S.levelset_kernel_launches = n_active ? 1 : 0;
     size_t held = 0;
     for (const DevBuf* b : {&ctx->xyz_in, &ctx->xyz_filt, &ctx->flags32, &ctx->offsets, &ctx->keys_a, &ctx->keys_b, &ctx->vals_a, &ctx->cell_count,
                             &ctx->cell_start, &ctx->pos_sorted, &ctx->temp, &ctx->block_flag, &ctx->block_rank, &ctx->mc_flag, &ctx->mc_rank,
                             &ctx->vcount, &ctx->tcount, &ctx->member_count, &ctx->copy_offset, &ctx->ckeys_a, &ctx->ckeys_b, &ctx->cvals_a, &ctx->cidx,
-                            &ctx->cpos, &ctx->cell_count2, &ctx->cell_start2, &res->rho, &res->posvol, &res->posvol_by_index, &res->perm, &res->inside8, &res->G, &res->block_slot,
+                            &ctx->cpos, &ctx->cell_count2, &ctx->cell_start2, &res->rho, &res->posvol, &ctx->splat_tiles, &ctx->splat_counts, &ctx->splat_off, &ctx->splat_overflow, &res->posvol_by_index, &res->perm, &res->inside8, &res->G, &res->block_slot,
                             &res->active_list, &res->mc_list, &res->mc_slot, &res->masks, &res->vbase, &res->tbase, &res->vertices, &res->vkeys,
                             &res->tri32})
         held += b->cap;
@@ -1265,7 +1299,7 @@ void ss_context_destroy(ss_context* c) {
     for (DevBuf* b : {&c->xyz_in, &c->xyz_filt, &c->flags32, &c->offsets, &c->keys_a, &c->keys_b, &c->vals_a, &c->cell_count,
                       &c->cell_start, &c->pos_sorted, &c->temp, &c->aabb_partial, &c->aabb_out, &c->block_flag, &c->block_rank, &c->mc_flag,
                       &c->mc_rank, &c->vcount, &c->tcount, &c->counter, &c->member_count, &c->copy_offset, &c->sub_flag, &c->sub_rank,
-                      &c->nb_count, &c->nb_tmp, &c->occ_sub, &c->ckeys_a, &c->ckeys_b, &c->cvals_a, &c->cidx, &c->cpos, &c->cell_count2, &c->cell_start2, &c->gboxes, &c->fastdiv_scratch, &c->splat_overflow, &c->splat_tiles, &c->splat_counts})
+                      &c->nb_count, &c->nb_tmp, &c->occ_sub, &c->ckeys_a, &c->ckeys_b, &c->cvals_a, &c->cidx, &c->cpos, &c->cell_count2, &c->cell_start2, &c->gboxes, &c->fastdiv_scratch, &c->splat_overflow, &c->splat_tiles, &c->splat_counts, &c->splat_off})
         b->release();
     for (DevBuf& b : c->post_pool) b.release();
     if (c->ev_ok)

@@ -16,6 +16,16 @@
 #define SS_BLOCK 8              // level-set block edge in grid points (8^3 = 512 points)
 #define SS_BLOCK_POINTS 512
 #define SS_MAX_ROWS 256         // (x,y) search-cell rows per batch while gathering a tile
+#define SS_WTILE 384            // tile entries one wave orders in LDS (k_splat_gather) = chunk of the accumulate kernel
+
+// Arithmetic of the level-set accumulation G += V * W(|x - p|)  (Parameters::enable_simd, lib.rs:179-181):
+//   GENERIC / FAST   the reference's scalar loop (dense_subdomains.rs:784-847, kernel.rs:58-107), bit for bit; FAST = lean exact
+//                    sqrt + device-verified reciprocal division, GENERIC = hipcc's correctly rounded sqrt / divide
+//   SIMD*            the reference's AVX2+FMA loop (dense_subdomains.rs:991-1133, kernel.rs:319-378) applied to every (particle,
+//                    point) pair: d^2 by two fma, mask d^2 < h^2, q = r * (1/h), v = max(1 - q, 0), fma polynomial, fma accumulate.
+//                    SIMD / SIMD_LEAN use a correctly rounded sqrt like _mm256_sqrt_ps (generic / lean variant), SIMD_HW the raw
+//                    v_sqrt_f32 (<= 1 ulp), requested with enable_simd = 2.
+enum : int { SS_ARITH_GENERIC = 0, SS_ARITH_FAST = 1, SS_ARITH_SIMD = 2, SS_ARITH_SIMD_LEAN = 3, SS_ARITH_SIMD_HW = 4 };
 
 // candidate particles (4-byte index keys) held in LDS per pass of the large-tile splat kernel
 template <class R> struct SSTileCap { static constexpr int value = 8192; };
@@ -65,7 +75,11 @@ struct SSDevT {
     R mass;       // rest mass                 (dense_subdomains.rs:117-118)
     R threshold;  // iso-surface threshold
     R margin;     // ghost particle margin     (dense_subdomains.rs:120-121)
-    R reach;      // conservative reach of a particle: sqrt(1.01)*h*(1+1e-4)
+    R reach;      // conservative reach of a particle: sqrt(support^2)*(1+1e-4), support^2 = 1.01 h^2 (scalar) or h^2 (SIMD arithmetic)
+    R R2;         // support^2 * (1+1e-4): squared reach of the conservative block / wave filters of the splat
+    // Parameters::enable_simd: constants of CubicSplineKernelAvxF32 (kernel.rs:327-337), formed in f32 like the reference does
+    R avx_inv_h, avx_sigma, avx_sigma2, avx_sigma6, avx_sigma12;
+    int arith;    // SS_ARITH_* of the level-set accumulation chosen for this call
     R coord_slack;  // absolute slack covering rounding of coordinates in conservative tests
     // dense array of search cells (edge h), absolute cell coordinate K in [kmin, kmin+kdim)
     int kmin[3];

@@ -84,8 +84,8 @@ struct ss_context {
     bool fastdiv_ok = false;
     bool ev_ok = false;
     DevBuf gboxes;  // global strategy: stencil boxes per particle chunk
-    DevBuf splat_overflow;  // flags / queue of level-set blocks whose tile does not fit a slot of the small-tile path
-    DevBuf splat_tiles, splat_counts;  // index-ordered candidate tiles (fixed slots) written by k_splat_gather, read by k_splat_accumulate
+    DevBuf splat_overflow;  // flags / ranks / list of level-set blocks whose tile is ordered by the workgroup-level gather
+    DevBuf splat_tiles, splat_counts, splat_off;  // tile arena (index-ordered candidates of every block, exact size), per-block counts and 64-bit offsets
     // post-processing: grow-only scratch slots handed out in call order (reset at the start of every ss_post_* call)
     DevBuf post_pool[24];
     int post_pool_next = 0;

@@ -31,10 +31,11 @@ void ss_launch_verify_fast_div(float h, float rh, uint32_t* bad, hipStream_t st)
 template <class R>
 void ss_launch_block_coords(const SSDevT<R>& P, const uint32_t* active_list, uint32_t n_active, uint32_t* xyz, hipStream_t st);
 template <class R>
-void ss_launch_splat_small(const SSDevT<R>& P, const ss_real4<R>* posvol, const uint32_t* perm, const uint32_t* cell_start, const uint32_t* active_xyz, uint32_t n_active, ss_real4<R>* tiles, uint32_t* counts, R* G, ss_real2<R>* blk_minmax, unsigned long long* cand_counter, uint32_t* overflow_flag, bool fast_div, hipEvent_t ev_after_gather, hipEvent_t ev_after_accumulate, hipStream_t st);
-size_t ss_splat_tile_entries();
+void ss_launch_splat_count(const SSDevT<R>& P, const ss_real4<R>* posvol, const uint32_t* cell_start, const uint32_t* active_xyz, uint32_t n_active, uint32_t* counts, uint32_t* large_flag, hipStream_t st);
 template <class R>
-void ss_launch_splat_large(const SSDevT<R>& P, const ss_real4<R>* posvol, const ss_real4<R>* posvol_by_index, const uint32_t* perm, const uint32_t* cell_start, const uint32_t* active_xyz, uint32_t n_active, R* G, ss_real2<R>* blk_minmax, unsigned long long* cand_counter, const uint32_t* overflow_list, const uint32_t* overflow_count, bool fast_div, hipStream_t st);
+void ss_launch_splat_gather(const SSDevT<R>& P, const ss_real4<R>* posvol, const ss_real4<R>* posvol_by_index, const uint32_t* perm, const uint32_t* cell_start, const uint32_t* active_xyz, uint32_t n_active, const uint32_t* counts, const unsigned long long* tile_off, ss_real4<R>* arena, const uint32_t* large_list, uint32_t n_large, hipStream_t st);
+template <class R>
+void ss_launch_splat_accumulate(const SSDevT<R>& P, const ss_real4<R>* arena, const unsigned long long* tile_off, const uint32_t* counts, const uint32_t* active_xyz, uint32_t n_active, R* G, ss_real2<R>* blk_minmax, hipStream_t st);
 template <class R>
 void ss_launch_mc_count(const SSDevT<R>& P, const R* G, const uint32_t* block_slot, const uint32_t* mc_xyz, uint32_t n_mc, unsigned long long* masks, uint32_t* vcount, uint32_t* tcount, hipStream_t st);
 template <class R>

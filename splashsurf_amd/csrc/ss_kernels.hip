@@ -7,7 +7,7 @@
 //                                                                        -> k_cell_keys (+ rocPRIM sort), k_gather_sorted
 //   K2  dense_subdomains.rs:496-646 + neighborhood_search.rs:345-438 + density_map.rs:150-186
 //                                                                        -> k_classify_count, k_emit_copies, k_density_sub
-//   K3  dense_subdomains.rs:784-847 (density_grid_loop_scalar)            -> k_mark_blocks, k_splat_gather, k_splat_accumulate, k_splat_large
+//   K3  dense_subdomains.rs:784-847 (density_grid_loop_scalar)            -> k_mark_blocks, k_splat_count, k_splat_gather[_large], k_splat_accumulate
 //   K4  dense_subdomains.rs:1470-1553 (triangulate_cell) classification   -> k_mc_count
 //   K5  same, vertex/triangle emission + dense_subdomains.rs:1603-1749    -> k_mc_emit
 //
@@ -657,19 +657,22 @@ void ss_launch_compact_blocks(const uint32_t* flag, const uint32_t* rank, uint32
 // =====================================================================================================
 // K3: level-set splat in gather form.
 //
-// Work unit: one active block of 8x8x8 grid points; in the accumulating kernels a 512-thread workgroup (8 waves) owns it,
-// wave w the 4x4x4 sub-block (w>>2, (w>>1)&1, w&1), lane l the point ((l>>4)&3, (l>>2)&3, l&3) of it.
-//   1. gather: the particles within reach of the block's points are collected from the cell-sorted array ((x,y) rows of
-//      search cells are contiguous runs);
-//   2. order: the tile is sorted by ORIGINAL particle index and the payload (x,y,z,V) fetched in that order -- this
-//      reproduces the reference's per-point summation order;
-//   3. accumulate: per wave, phase A tests 64 tile entries at once against the wave's sub-block box (ballot), phase B walks
-//      the surviving entries in order; every lane evaluates G += V * W(|x - p|) for its point iff d^2 < 1.01 h^2
-//      (dense_subdomains.rs:828-841).
-// Tiles of up to SS_WTILE entries: steps 1-2 by ONE WAVE per block (k_splat_gather, ordered tile left in an HBM slot), step 3
-// by k_splat_accumulate.  Larger tiles: k_splat_large does all three steps per workgroup with up to SSTileCap<R>::value
-// index keys in LDS, in several passes over ascending index ranges (threshold found by bisection) if a tile is larger
-// still, which keeps the summation order exact for arbitrarily dense input.
+// Work unit: one active block of 8x8x8 grid points.
+//   1. count   (k_splat_count, ONE WAVE per block): how many particles lie within reach of the block's points?  The (x, y)
+//      rows of search cells touching the dilated block box are contiguous runs of the cell-sorted particle array; the wave
+//      streams them and tests every particle against the box spanned by the block's points.  An exclusive scan of the counts
+//      gives every block its range in one tile arena of EXACTLY the total size (no fixed slots, no size limit per block).
+//   2. gather + order: the same scan again, survivors compacted into LDS, sorted by ORIGINAL particle index -- the
+//      reference's per-point summation order (sorted per-subdomain particle lists, dense_subdomains.rs:476-488) -- and the
+//      payload (x, y, z, V) written to the block's arena range in that order.  Up to SS_WTILE survivors: one wave per block
+//      (k_splat_gather: no workgroup barrier, rank sort by wave-wide compares).  More (over-dense input): one 512-thread
+//      workgroup per block (k_splat_gather_large: up to SSTileCap index keys in LDS per pass, bitonic network; even larger
+//      tiles in several passes over ascending index ranges found by bisection, so any input density stays exact).
+//   3. accumulate (k_splat_accumulate, 512 threads per block): wave w owns the 4x4x4 sub-block (w>>2, (w>>1)&1, w&1), lane l
+//      the point ((l>>4)&3, (l>>2)&3, l&3) of it.  The block's tile is streamed through LDS in chunks of SS_WTILE entries (the
+//      next chunk is in flight while the current one is used); per wave, phase A tests 64 tile entries at once against the
+//      wave's sub-block box (ballot), phase B walks the survivors in order and every lane evaluates G += V * W(|x - p|) for
+//      its point (dense_subdomains.rs:828-841 / :1077-1107, selected by the ARITH template parameter).
 // =====================================================================================================
 __global__ __launch_bounds__(256) void k_verify_fast_div(float h, float rh, uint32_t* __restrict__ bad) {
     // all significands of the binade [2^e, 2^(e+1)) that contains h
@@ -692,11 +695,9 @@ __device__ __forceinline__ void ss_wave_lds_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-#define SS_PAY_CHUNK 512
 #define SS_WAVE_LIST 66  // survivors of one 64-entry batch per wave (+ 2 slots the read-ahead may touch)
 template <class R, int CAP>
 struct SplatShared {
-    ss_real4<R> pay[SS_PAY_CHUNK];  // payload of 512 consecutive entries of the ordered tile
     uint32_t idx[CAP];               // original particle indices of the tile (the sort keys)
     uint32_t row_start[SS_MAX_ROWS];
     uint32_t row_prefix[SS_MAX_ROWS + 1];
@@ -728,9 +729,162 @@ __device__ __forceinline__ bool ss_within_reach_of_block(const SSDevT<R>& P, con
     const R ex = ss_max(ss_max(plo[0] - pv.x, pv.x - phi[0]) - P.coord_slack, R(0.0));
     const R ey = ss_max(ss_max(plo[1] - pv.y, pv.y - phi[1]) - P.coord_slack, R(0.0));
     const R ez = ss_max(ss_max(plo[2] - pv.z, pv.z - phi[2]) - P.coord_slack, R(0.0));
-    return (ex * ex + ey * ey + ez * ez) <= P.H2 * R(1.0001);
+    return (ex * ex + ey * ey + ez * ez) <= P.R2;
 }
 
+// box of the block's points [plo, phi] and the search cells [klo, khi] overlapping it once dilated by the reach
+template <class R>
+__device__ __forceinline__ bool splat_block_box(const SSDevT<R>& P, const int b3[3], R plo[3], R phi[3], int klo[3], int khi[3]) {
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        const int i0 = b3[d] * SS_BLOCK;
+        const int i1 = min(i0 + SS_BLOCK - 1, P.np[d] - 1);
+        const R pad = P.reach + P.coord_slack;
+        plo[d] = P.gmin[d] + (R)i0 * P.cs;
+        phi[d] = P.gmin[d] + (R)i1 * P.cs;
+        // cells overlapping [plo - pad, phi + pad]; the pad of 1e-3 cells dwarfs the rounding of the product (< 1e-12 cells), so
+        // the range can only be a superset of the exact one -- every candidate is tested individually anyway
+        const double cellpad = 1e-3 * (double)P.h;
+        const int a = (int)floor(((double)(plo[d] - pad) - cellpad) * P.inv_h);
+        const int e = (int)floor(((double)(phi[d] + pad) + cellpad) * P.inv_h);
+        klo[d] = max(a, P.kmin[d]);
+        khi[d] = min(e, P.kmin[d] + P.kdim[d] - 1);
+    }
+    return klo[0] <= khi[0] && klo[1] <= khi[1] && klo[2] <= khi[2];
+}
+
+// ---- one wave visits every particle of the search-cell rows overlapping a block's dilated box -------------------------------
+// f(inside, src, id) is called in lock-step for 64 candidates at a time (inside = within reach of the block's points, src =
+// position in the cell-sorted arrays, id = original particle index if NEED_ID).  Rows are handled 64 at a time (a block
+// overlaps more than 64 rows only when the cube size approaches the support radius).
+template <class R, bool NEED_ID, class F>
+__device__ __forceinline__ void splat_wave_scan(const SSDevT<R>& P, const ss_real4<R>* __restrict__ posvol, const uint32_t* __restrict__ perm,
+                                                const uint32_t* __restrict__ cell_start, const int klo[3], const int khi[3], const R plo[3], const R phi[3],
+                                                uint32_t* s_row_start, uint32_t* s_row_prefix, int lane, F f) {
+    const int ny = khi[1] - klo[1] + 1;
+    const int nrows = (khi[0] - klo[0] + 1) * ny;
+    for (int row_base = 0; row_base < nrows; row_base += 64) {
+        const int nb = min(64, nrows - row_base);
+        uint32_t len = 0;
+        if (lane < nb) {
+            const int r = row_base + lane;
+            const int kx = klo[0] + r / ny, ky = klo[1] + r % ny;
+            const uint32_t rb = cell_start[ss_cell_key(P, kx, ky, klo[2])];
+            const uint32_t re = cell_start[ss_cell_key(P, kx, ky, khi[2]) + 1u];
+            s_row_start[lane] = rb;
+            len = re - rb;
+        }
+        uint32_t incl = len;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t t = __shfl_up(incl, off);
+            if (lane >= off) incl += t;
+        }
+        s_row_prefix[lane] = incl - len;
+        const uint32_t total = __shfl(incl, 63);
+        ss_wave_lds_sync();
+        for (uint32_t q0 = 0; q0 < total; q0 += 64u) {
+            const uint32_t q = q0 + (uint32_t)lane;
+            bool inside = false;
+            uint32_t src = 0, id = 0;
+            if (q < total) {
+                int lo = 0, hi = nb - 1;  // last row r with row_prefix[r] <= q
+                while (lo < hi) {
+                    const int mid = (lo + hi + 1) >> 1;
+                    if (s_row_prefix[mid] <= q)
+                        lo = mid;
+                    else
+                        hi = mid - 1;
+                }
+                src = s_row_start[lo] + (q - s_row_prefix[lo]);
+                const ss_real4<R> pv = posvol[src];
+                if (NEED_ID) id = perm[src];
+                inside = ss_within_reach_of_block<R>(P, pv, plo, phi);
+            }
+            f(inside, src, id);
+        }
+        ss_wave_lds_sync();  // the next batch overwrites the row tables
+    }
+}
+
+// XCD-aware mapping of groups of four consecutive blocks to 256-thread workgroups (one wave per block): hardware places
+// workgroup w on XCD w % 8; every XCD gets a contiguous range of the spatially ordered active list, so neighbouring blocks
+// (which share most of their candidate rows) share an L2.
+__device__ __forceinline__ bool splat_wave_block(uint32_t n_active, uint32_t* logical) {
+    const uint32_t n_groups = (n_active + 3u) / 4u;
+    const uint32_t per_xcd = (n_groups + 7u) / 8u;
+    const uint32_t group = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
+    if ((blockIdx.x >> 3) >= per_xcd || group >= n_groups) return false;
+    *logical = group * 4u + (threadIdx.x >> 6);
+    return *logical < n_active;
+}
+
+// step 1: counts[b] = particles within reach of block b; large_flag[b] = the tile needs the workgroup-level gather
+template <class R>
+__global__ __launch_bounds__(256) void k_splat_count(SSDevT<R> P, const ss_real4<R>* __restrict__ posvol, const uint32_t* __restrict__ cell_start,
+                                                     const uint32_t* __restrict__ active_xyz, uint32_t n_active, uint32_t* __restrict__ counts,
+                                                     uint32_t* __restrict__ large_flag) {
+    __shared__ uint32_t s_row_start[4][64];
+    __shared__ uint32_t s_row_prefix[4][64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    uint32_t logical;
+    if (!splat_wave_block(n_active, &logical)) return;
+    const int b3[3] = {(int)active_xyz[3 * (size_t)logical], (int)active_xyz[3 * (size_t)logical + 1], (int)active_xyz[3 * (size_t)logical + 2]};
+    R plo[3], phi[3];
+    int klo[3], khi[3];
+    uint32_t count = 0;
+    if (splat_block_box<R>(P, b3, plo, phi, klo, khi))
+        splat_wave_scan<R, false>(P, posvol, nullptr, cell_start, klo, khi, plo, phi, s_row_start[w], s_row_prefix[w], lane,
+                                  [&](bool inside, uint32_t, uint32_t) { count += (uint32_t)__popcll(__ballot(inside)); });
+    if (lane == 0) {
+        counts[logical] = count;
+        large_flag[logical] = (count > (uint32_t)SS_WTILE) ? 1u : 0u;
+    }
+}
+
+// step 2, tiles of up to SS_WTILE entries: one wave per block
+template <class R>
+__global__ __launch_bounds__(256) void k_splat_gather(SSDevT<R> P, const ss_real4<R>* __restrict__ posvol, const uint32_t* __restrict__ perm,
+                                                      const uint32_t* __restrict__ cell_start, const uint32_t* __restrict__ active_xyz, uint32_t n_active,
+                                                      const uint32_t* __restrict__ counts, const unsigned long long* __restrict__ tile_off,
+                                                      ss_real4<R>* __restrict__ arena) {
+    __shared__ uint32_t s_idx[4][SS_WTILE];
+    __shared__ uint32_t s_src[4][SS_WTILE];
+    __shared__ uint32_t s_row_start[4][64];
+    __shared__ uint32_t s_row_prefix[4][64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    uint32_t logical;
+    if (!splat_wave_block(n_active, &logical)) return;
+    const uint32_t expect = counts[logical];
+    if (expect == 0u || expect > (uint32_t)SS_WTILE) return;  // nothing to do / k_splat_gather_large's block
+    const int b3[3] = {(int)active_xyz[3 * (size_t)logical], (int)active_xyz[3 * (size_t)logical + 1], (int)active_xyz[3 * (size_t)logical + 2]};
+    R plo[3], phi[3];
+    int klo[3], khi[3];
+    (void)splat_block_box<R>(P, b3, plo, phi, klo, khi);
+    uint32_t count = 0;
+    const unsigned long long below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    splat_wave_scan<R, true>(P, posvol, perm, cell_start, klo, khi, plo, phi, s_row_start[w], s_row_prefix[w], lane, [&](bool inside, uint32_t src, uint32_t id) {
+        const unsigned long long m = __ballot(inside);
+        const uint32_t pos = count + (uint32_t)__popcll(m & below);
+        if (inside && pos < (uint32_t)SS_WTILE) {  // pos < expect by construction (same test as the count pass)
+            s_idx[w][pos] = id;
+            s_src[w][pos] = src;
+        }
+        count += (uint32_t)__popcll(m);
+    });
+    ss_wave_lds_sync();
+    count = min(count, (uint32_t)SS_WTILE);
+    // rank sort by original particle index (unique), payload written in that order
+    ss_real4<R>* tile = arena + tile_off[logical];
+    for (uint32_t e = (uint32_t)lane; e < count; e += 64u) {
+        const uint32_t my = s_idx[w][e];
+        uint32_t rank = 0;
+        for (uint32_t k = 0; k < count; ++k) rank += (s_idx[w][k] < my) ? 1u : 0u;
+        tile[rank] = posvol[s_src[w][e]];
+    }
+}
+
+// ---- workgroup-level candidate scan of the large-tile gather --------------------------------------------------------------
 // exclusive prefix over s.row_prefix[0..nbatch) (lengths in, prefix out), total in row_prefix[nbatch]
 template <class S>
 __device__ inline void splat_row_prefix(S& s, int nbatch, uint32_t len, int tid) {
@@ -755,8 +909,8 @@ __device__ inline void splat_row_prefix(S& s, int nbatch, uint32_t len, int tid)
     __syncthreads();
 }
 
-// Visit every particle of the search cells overlapping the dilated block box; f(sorted position, idx, payload) is
-// called for particles within reach of the block's points.  All 512 threads must call this (contains barriers).
+// Visit every particle of the search cells overlapping the dilated block box; f(idx) is called for particles within reach of
+// the block's points.  All 512 threads must call this (contains barriers).
 template <class R, class S, class F>
 __device__ inline void splat_for_each_candidate(S& s, const SSDevT<R>& P, const ss_real4<R>* __restrict__ posvol,
                                                 const uint32_t* __restrict__ perm, const uint32_t* __restrict__ cell_start,
@@ -790,241 +944,86 @@ __device__ inline void splat_for_each_candidate(S& s, const SSDevT<R>& P, const 
             }
             const uint32_t src = s.row_start[lo] + (q - s.row_prefix[lo]);
             const ss_real4<R> pv = posvol[src];
-            if (ss_within_reach_of_block<R>(P, pv, plo, phi)) f(src, perm[src], pv);
+            if (ss_within_reach_of_block<R>(P, pv, plo, phi)) f(perm[src]);
         }
         __syncthreads();
     }
 }
 
-// Accumulation of one wave's 4^3 sub-block over an index-ordered tile in LDS (dense_subdomains.rs:817-841).
-// Phase A tests 64 tile entries at once against the sub-block's box; the survivors are compacted IN ORDER into the wave's
-// own list `wl` (SS_WAVE_LIST entries), which phase B then walks front to back with a plain counter -- the scalar unit is
-// shared by the four SIMDs of a CU and walking a 64-bit survivor mask cost 14 scalar instructions per entry.
-template <class R, bool FASTDIV>
-__device__ __forceinline__ R splat_accumulate_wave(const SSDevT<R>& P, const ss_real4<R>* pay, ss_real4<R>* wl, int n_tile, int lane, R px, R py, R pz,
-                                                   const R slo[3], const R shi[3], R wave_r2, R acc) {
-    const R rh = R(1.0) / P.h;
-    for (int base = 0; base < n_tile; base += 64) {
-        const int c = base + lane;
-        bool pass = false;
-        ss_real4<R> pv = ss_make4(R(0.0), R(0.0), R(0.0), R(0.0));
-        if (c < n_tile) {
-            pv = pay[c];
-            const R ex = ss_max(ss_max(slo[0] - pv.x, pv.x - shi[0]) - P.coord_slack, R(0.0));
-            const R ey = ss_max(ss_max(slo[1] - pv.y, pv.y - shi[1]) - P.coord_slack, R(0.0));
-            const R ez = ss_max(ss_max(slo[2] - pv.z, pv.z - shi[2]) - P.coord_slack, R(0.0));
-            pass = (ex * ex + ey * ey + ez * ez) <= wave_r2;
-        }
-        const unsigned long long wmask = __ballot(pass);
-        if (wmask) {
-            const int cnt = __popcll(wmask);
-            ss_wave_lds_sync();  // the previous batch's reads of wl are done
-            if (pass) wl[__builtin_amdgcn_mbcnt_hi((uint32_t)(wmask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)wmask, 0u))] = pv;
-            ss_wave_lds_sync();
-            // Entries are fetched with a wave-uniform LDS read (broadcast: LDS pipe, no VALU issue slot, operands arrive in
-            // VGPRs) one iteration ahead of their use; two entries per trip, ping-ponging between two register sets (no
-            // loop-carried copies).  Reads past cnt stay inside wl and are not used.
-            ss_real4<R> ea = wl[0];
-            for (int k = 0;; k += 2) {
-                const ss_real4<R> eb = wl[k + 1];
-                {
-                    const R dx = ea.x - px, dy = ea.y - py, dz = ea.z - pz;  // p_i - point, :828
-                    const R d2 = dx * dx + dy * dy + dz * dz;
-                    if (d2 < P.H2) {  // :831
-                        acc += ea.w * ss_kernel_w<R, FASTDIV>(d2, P.h, rh, P.sigma);  // :832-841
-                    }
-                }
-                if (k + 1 >= cnt) break;
-                ea = wl[k + 2];
-                {
-                    const R dx = eb.x - px, dy = eb.y - py, dz = eb.z - pz;
-                    const R d2 = dx * dx + dy * dy + dz * dz;
-                    if (d2 < P.H2) {
-                        acc += eb.w * ss_kernel_w<R, FASTDIV>(d2, P.h, rh, P.sigma);
-                    }
-                }
-                if (k + 2 >= cnt) break;
-            }
-        }
-    }
-    return acc;
-}
-
-// The same accumulation walking the survivor bit mask of each 64-entry batch directly (no per-wave list): the variant of the
-// large-tile kernel, which measured slower with the list (S10M-cube level set 37.2 instead of 32.8 ms).
-template <class R, bool FASTDIV>
-__device__ __forceinline__ R splat_accumulate_wave_mask(const SSDevT<R>& P, const ss_real4<R>* pay, int n_tile, int lane, R px, R py, R pz, const R slo[3],
-                                                   const R shi[3], R wave_r2, R acc) {
-    const R rh = R(1.0) / P.h;
-    for (int base = 0; base < n_tile; base += 64) {
-        const int c = base + lane;
-        bool pass = false;
-        ss_real4<R> pv = ss_make4(R(0.0), R(0.0), R(0.0), R(0.0));
-        if (c < n_tile) {
-            pv = pay[c];
-            const R ex = ss_max(ss_max(slo[0] - pv.x, pv.x - shi[0]) - P.coord_slack, R(0.0));
-            const R ey = ss_max(ss_max(slo[1] - pv.y, pv.y - shi[1]) - P.coord_slack, R(0.0));
-            const R ez = ss_max(ss_max(slo[2] - pv.z, pv.z - shi[2]) - P.coord_slack, R(0.0));
-            pass = (ex * ex + ey * ey + ez * ez) <= wave_r2;
-        }
-        unsigned long long wmask = __ballot(pass);
-        if (wmask) {
-            // Entries are fetched with a wave-uniform LDS read (broadcast: LDS pipe, no VALU issue slot,
-            // operands arrive in VGPRs) one iteration ahead of their use.
-            // two entries per trip, ping-ponging between two register sets (no loop-carried copies)
-            int bit = __ffsll((long long)wmask) - 1;
-            ss_real4<R> ea = pay[base + bit];
-            while (true) {
-                wmask &= wmask - 1;
-                const int bit_b = wmask ? (__ffsll((long long)wmask) - 1) : bit;
-                const ss_real4<R> eb = pay[base + bit_b];
-                {
-                    const R dx = ea.x - px, dy = ea.y - py, dz = ea.z - pz;  // p_i - point, :828
-                    const R d2 = dx * dx + dy * dy + dz * dz;
-                    if (d2 < P.H2) {  // :831
-                        acc += ea.w * ss_kernel_w<R, FASTDIV>(d2, P.h, rh, P.sigma);  // :832-841
-                    }
-                }
-                if (!wmask) break;
-                wmask &= wmask - 1;
-                bit = wmask ? (__ffsll((long long)wmask) - 1) : bit_b;
-                ea = pay[base + bit];
-                {
-                    const R dx = eb.x - px, dy = eb.y - py, dz = eb.z - pz;
-                    const R d2 = dx * dx + dy * dy + dz * dz;
-                    if (d2 < P.H2) {
-                        acc += eb.w * ss_kernel_w<R, FASTDIV>(d2, P.h, rh, P.sigma);
-                    }
-                }
-                if (!wmask) break;
-            }
-        }
-    }
-    return acc;
-}
-
-// One level-set block of the large-tile path: tiles that do not fit CAP entries are processed in several passes over
-// ascending index ranges.
-template <class R, bool FASTDIV, int CAP>
-__device__ __forceinline__ void splat_block(SplatShared<R, CAP>& s, const SSDevT<R>& P, const ss_real4<R>* __restrict__ posvol,
-                                            const ss_real4<R>* __restrict__ posvol_by_index, const uint32_t* __restrict__ perm, const uint32_t* __restrict__ cell_start,
-                                            const uint32_t* __restrict__ bxyz, uint32_t logical, R* __restrict__ G, ss_real2<R>* __restrict__ blk_minmax, unsigned long long* __restrict__ cand_counter) {
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int bx = (int)bxyz[0], by = (int)bxyz[1], bz = (int)bxyz[2];
-    const int b3[3] = {bx, by, bz};
-
-    // box of the block's points, dilated by the reach: the search cells overlapping it
-    R blo[3], bhi[3], plo[3], phi[3];
+// step 2, tiles of more than SS_WTILE entries (over-dense input): one 512-thread workgroup per block.  Only the particle
+// INDICES (the sort keys) go through LDS, up to CAP per pass; the payload is fetched in sorted order from the copy of
+// (x, y, z, V) kept in original particle order.  Tiles beyond CAP are written in several passes over ascending index ranges.
+template <class R, int CAP>
+__global__ __launch_bounds__(512) void k_splat_gather_large(SSDevT<R> P, const ss_real4<R>* __restrict__ posvol, const ss_real4<R>* __restrict__ posvol_by_index,
+                                                            const uint32_t* __restrict__ perm, const uint32_t* __restrict__ cell_start,
+                                                            const uint32_t* __restrict__ active_xyz, const uint32_t* __restrict__ large_list, uint32_t n_large,
+                                                            const uint32_t* __restrict__ counts, const unsigned long long* __restrict__ tile_off,
+                                                            ss_real4<R>* __restrict__ arena) {
+    __shared__ SplatShared<R, CAP> s;
+    const int tid = threadIdx.x;
+    // XCD-aware: every XCD a contiguous range of the (spatially ordered) list
+    const uint32_t per_xcd = (n_large + 7u) / 8u;
+    const uint32_t it = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
+    if ((blockIdx.x >> 3) >= per_xcd || it >= n_large) return;
+    const uint32_t logical = large_list[it];
+    const uint32_t expect = counts[logical];
+    ss_real4<R>* tile = arena + tile_off[logical];
+    const int b3[3] = {(int)active_xyz[3 * (size_t)logical], (int)active_xyz[3 * (size_t)logical + 1], (int)active_xyz[3 * (size_t)logical + 2]};
+    R plo[3], phi[3];
     int klo[3], khi[3];
-#pragma unroll
-    for (int d = 0; d < 3; ++d) {
-        const int i0 = b3[d] * SS_BLOCK;
-        const int i1 = min(i0 + SS_BLOCK - 1, P.np[d] - 1);
-        const R pad = P.reach + P.coord_slack;
-        plo[d] = P.gmin[d] + (R)i0 * P.cs;
-        phi[d] = P.gmin[d] + (R)i1 * P.cs;
-        blo[d] = plo[d] - pad;
-        bhi[d] = phi[d] + pad;
-        // cells overlapping [blo, bhi]; the pad of 1e-3 cells dwarfs the rounding of the product (< 1e-12 cells), so the
-        // range can only be a superset of the exact one -- every candidate is tested individually anyway
-        const double cellpad = 1e-3 * (double)P.h;
-        int a = (int)floor(((double)blo[d] - cellpad) * P.inv_h);
-        int e = (int)floor(((double)bhi[d] + cellpad) * P.inv_h);
-        klo[d] = max(a, P.kmin[d]);
-        khi[d] = min(e, P.kmin[d] + P.kdim[d] - 1);
-    }
-    const bool any_cells = klo[0] <= khi[0] && klo[1] <= khi[1] && klo[2] <= khi[2];
-
-    // this wave's sub-block and this lane's grid point
-    const int g0[3] = {bx * SS_BLOCK + ((wave >> 2) & 1) * 4, by * SS_BLOCK + ((wave >> 1) & 1) * 4, bz * SS_BLOCK + (wave & 1) * 4};
-    const int gl[3] = {g0[0] + ((lane >> 4) & 3), g0[1] + ((lane >> 2) & 3), g0[2] + (lane & 3)};
-    const bool wave_valid = g0[0] < P.np[0] && g0[1] < P.np[1] && g0[2] < P.np[2];
-    // global point coordinates: uniform_grid.rs:418-425 on the GLOBAL grid (dense_subdomains.rs:817-826)
-    const R px = P.gmin[0] + (R)gl[0] * P.cs;
-    const R py = P.gmin[1] + (R)gl[1] * P.cs;
-    const R pz = P.gmin[2] + (R)gl[2] * P.cs;
-    R slo[3], shi[3];
-#pragma unroll
-    for (int d = 0; d < 3; ++d) {
-        slo[d] = P.gmin[d] + (R)g0[d] * P.cs;
-        shi[d] = P.gmin[d] + (R)min(g0[d] + 3, P.np[d] - 1) * P.cs;
-    }
-    const R wave_r2 = P.H2 * R(1.0001);
-
-    R acc = R(0.0);  // levelset_grid.fill(0), dense_subdomains.rs:1390
-    long long last = -1;  // particles with original index <= last are already accumulated
+    if (!splat_block_box<R>(P, b3, plo, phi, klo, khi)) return;
+    long long last = -1;  // particles with original index <= last are already written
     const long long idx_max = (long long)P.n - 1;
-
-    while (any_cells) {
+    uint32_t written = 0;
+    while (written < expect) {
         long long T = idx_max;
-        if (tid == 0) s.count = 0;
-        __syncthreads();
-        splat_for_each_candidate<R>(s, P, posvol, perm, cell_start, klo, khi, plo, phi, tid, [&](uint32_t, uint32_t idx, const ss_real4<R>&) {
-            if ((long long)idx > last) {
-                uint32_t pos = atomicAdd(&s.count, 1u);
-                if (pos < CAP) s.idx[pos] = idx;  // keys only; the payload is fetched after the sort through posvol_by_index
-            }
-        });
-        uint32_t total = s.count;
-        if (total == 0) break;
-        if (total > CAP) {
-            // more candidates than LDS slots: find the largest threshold T with
-            // #{last < idx <= T} <= CAP by bisection (count is monotone in T and grows by
-            // at most one per step, so the bracket closes on exactly CAP entries)
+        uint32_t total = expect - written;
+        if (total > (uint32_t)CAP) {
+            // more candidates left than LDS slots: find the largest threshold T with #{last < idx <= T} <= CAP by bisection
+            // (the count is monotone in T and grows by at most one per step, so the bracket closes on exactly CAP entries)
             long long lo = last, hi = idx_max;
             while (hi - lo > 1) {
                 const long long mid = lo + (hi - lo) / 2;
                 __syncthreads();
                 if (tid == 0) s.count = 0;
                 __syncthreads();
-                splat_for_each_candidate<R>(s, P, posvol, perm, cell_start, klo, khi, plo, phi, tid, [&](uint32_t, uint32_t idx, const ss_real4<R>&) {
+                splat_for_each_candidate<R>(s, P, posvol, perm, cell_start, klo, khi, plo, phi, tid, [&](uint32_t idx) {
                     if ((long long)idx > last && (long long)idx <= mid) atomicAdd(&s.count, 1u);
                 });
                 const uint32_t c = s.count;
-                if (c <= CAP)
+                if (c <= (uint32_t)CAP)
                     lo = mid;
                 else
                     hi = mid;
             }
             T = lo;
-            __syncthreads();
-            if (tid == 0) s.count = 0;
-            __syncthreads();
-            splat_for_each_candidate<R>(s, P, posvol, perm, cell_start, klo, khi, plo, phi, tid, [&](uint32_t, uint32_t idx, const ss_real4<R>&) {
-                if ((long long)idx > last && (long long)idx <= T) {
-                    uint32_t pos = atomicAdd(&s.count, 1u);
-                    if (pos < CAP) s.idx[pos] = idx;
-                }
-            });
-            total = s.count;
         }
-        const int n_tile = (int)min(total, (uint32_t)CAP);
-        if (tid == 0) atomicAdd(cand_counter, (unsigned long long)n_tile);
-
-        // ---- order the tile by original particle index (keys only), then stream the payload in that order ----
-        // Phase A of the accumulation: 64 tile entries at a time are tested against the wave's 4^3 sub-block (distance to
-        // box <= reach) with one ballot.  Phase B: the surviving entries are walked in order (= ascending particle index)
-        // and every lane evaluates G += V * W(|x - p|) for its point iff d^2 < 1.01 h^2.
-        // Measured issue costs on gfx950 (tools/ubench/valu_rates.hip): f32 add/mul ~2.3 cycles per wave64
-        // instruction, fma ~3.5, cmp/cndmask/readlane ~3.7, SGPR-source operands ~3.9, v_pk_* ~6.2,
-        // v_sqrt/v_rcp ~7.4 -- hence LDS broadcast reads (not v_readlane) and no packed math in this loop.
-        if (n_tile <= SS_PAY_CHUNK) {
+        __syncthreads();
+        if (tid == 0) s.count = 0;
+        __syncthreads();
+        splat_for_each_candidate<R>(s, P, posvol, perm, cell_start, klo, khi, plo, phi, tid, [&](uint32_t idx) {
+            if ((long long)idx > last && (long long)idx <= T) {
+                const uint32_t pos = atomicAdd(&s.count, 1u);
+                if (pos < (uint32_t)CAP) s.idx[pos] = idx;
+            }
+        });
+        const int n_tile = (int)min(s.count, (uint32_t)CAP);
+        if (n_tile == 0) break;  // cannot happen (the count pass saw `expect` candidates); never spin
+        if (n_tile <= 512) {
             if (tid < n_tile) {
                 const uint32_t my_idx = s.idx[tid];
                 uint32_t rank = 0;
                 for (int k = 0; k < n_tile; ++k) rank += (s.idx[k] < my_idx) ? 1u : 0u;
-                s.pay[rank] = posvol_by_index[my_idx];
+                tile[written + rank] = posvol_by_index[my_idx];
             }
-            __syncthreads();
-            if (wave_valid) acc = splat_accumulate_wave_mask<R, FASTDIV>(P, s.pay, n_tile, lane, px, py, pz, slo, shi, wave_r2, acc);
         } else {
             int m = 1024;
             while (m < n_tile) m <<= 1;
             for (int e = n_tile + tid; e < m; e += 512) s.idx[e] = 0xFFFFFFFFu;
             __syncthreads();
             // bitonic network, one workgroup barrier per stage.  (Running the stages with distance j <= 64 wave-synchronously
-            // -- they stay inside the 128 keys one wave covers -- needs 15 instead of 66 barriers for 2048 keys but was
-            // measured slower, 41.2 instead of 35.2 ms on S10M-cube: the dependent LDS round trips of one wave no longer overlap.)
+            // needs 15 instead of 66 barriers for 2048 keys but measured slower: the dependent LDS round trips of one wave no
+            // longer overlap.)
             for (int k = 2; k <= m; k <<= 1)
                 for (int j = k >> 1; j > 0; j >>= 1) {
                     for (int t = tid; t < (m >> 1); t += 512) {
@@ -1039,169 +1038,100 @@ __device__ __forceinline__ void splat_block(SplatShared<R, CAP>& s, const SSDevT
                     }
                     __syncthreads();
                 }
-            for (int c0 = 0; c0 < n_tile; c0 += SS_PAY_CHUNK) {
-                const int nc = min(SS_PAY_CHUNK, n_tile - c0);
-                if (tid < nc) s.pay[tid] = posvol_by_index[s.idx[c0 + tid]];
-                __syncthreads();
-                if (wave_valid) acc = splat_accumulate_wave_mask<R, FASTDIV>(P, s.pay, nc, lane, px, py, pz, slo, shi, wave_r2, acc);
-                __syncthreads();
-            }
+            for (int e = tid; e < n_tile; e += 512) tile[written + (uint32_t)e] = posvol_by_index[s.idx[e]];
         }
-        if (T >= idx_max) break;
+        written += (uint32_t)n_tile;
         last = T;
         __syncthreads();
     }
-
-    // store: block-local layout (x*8+y)*8+z, i-major / k-fastest like dense_subdomains.rs:839
-    const int lx = ((wave >> 2) & 1) * 4 + ((lane >> 4) & 3);
-    const int ly = ((wave >> 1) & 1) * 4 + ((lane >> 2) & 3);
-    const int lz = (wave & 1) * 4 + (lane & 3);
-    const bool point_valid = gl[0] < P.np[0] && gl[1] < P.np[1] && gl[2] < P.np[2];
-    const R val = point_valid ? acc : R(0.0);
-    G[(size_t)logical * SS_BLOCK_POINTS + (size_t)((lx * 8 + ly) * 8 + lz)] = val;
-    // block-wide min/max of the level-set values (points outside the grid count as 0 = "outside"),
-    // used to skip marching cubes on blocks that cannot contain the iso-surface
-    R mn = val, mx = val;
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        mn = ss_min(mn, __shfl_xor(mn, off));
-        mx = ss_max(mx, __shfl_xor(mx, off));
-    }
-    __syncthreads();
-    R* red = reinterpret_cast<R*>(s.row_prefix);  // 16 values, scratch no longer in use
-    if (lane == 0) {
-        red[wave] = mn;
-        red[8 + wave] = mx;
-    }
-    __syncthreads();
-    if (tid == 0) {
-        for (int w = 1; w < 8; ++w) {
-            mn = ss_min(mn, red[w]);
-            mx = ss_max(mx, red[8 + w]);
-        }
-        blk_minmax[logical] = ss_make2(mn, mx);
-    }
 }
 
-// =====================================================================================================
-// Small-tile path in two kernels.  The gather of a block's candidates is a chain of dependent loads (search-cell rows ->
-// particles) with little arithmetic; the accumulation is pure VALU work.  k_splat_gather gives every block ONE WAVE (no
-// workgroup barriers, 32 blocks in flight per CU) and leaves the index-ordered tile (x, y, z, V) in a fixed slot of
-// SS_WTILE entries in HBM; k_splat_accumulate streams the slot into LDS with one coalesced read and does the arithmetic.
-// Blocks whose tile does not fit a slot are flagged for k_splat_large.
-// =====================================================================================================
-#define SS_WTILE 384
-
-template <class R>
-__global__ __launch_bounds__(256) void k_splat_gather(SSDevT<R> P, const ss_real4<R>* __restrict__ posvol, const uint32_t* __restrict__ perm,
-                                                      const uint32_t* __restrict__ cell_start, const uint32_t* __restrict__ active_xyz, uint32_t n_active,
-                                                      ss_real4<R>* __restrict__ tiles, uint32_t* __restrict__ counts, uint32_t* __restrict__ overflow_flag) {
-    __shared__ uint32_t s_idx[4][SS_WTILE];
-    __shared__ uint32_t s_src[4][SS_WTILE];
-    __shared__ uint32_t s_row_start[4][64];
-    __shared__ uint32_t s_row_prefix[4][65];
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    // XCD-aware mapping of groups of four consecutive blocks (see k_splat_accumulate)
-    const uint32_t n_groups = (n_active + 3u) / 4u;
-    const uint32_t per_xcd = (n_groups + 7u) / 8u;
-    const uint32_t group = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
-    if ((blockIdx.x >> 3) >= per_xcd || group >= n_groups) return;
-    const uint32_t logical = group * 4u + (uint32_t)w;
-    if (logical >= n_active) return;
-    const int b3[3] = {(int)active_xyz[3 * (size_t)logical], (int)active_xyz[3 * (size_t)logical + 1], (int)active_xyz[3 * (size_t)logical + 2]};
-    R blo[3], bhi[3], plo[3], phi[3];
-    int klo[3], khi[3];
-#pragma unroll
-    for (int d = 0; d < 3; ++d) {  // dilated block box and the search cells overlapping it (as in splat_block)
-        const int i0 = b3[d] * SS_BLOCK;
-        const int i1 = min(i0 + SS_BLOCK - 1, P.np[d] - 1);
-        const R pad = P.reach + P.coord_slack;
-        plo[d] = P.gmin[d] + (R)i0 * P.cs;
-        phi[d] = P.gmin[d] + (R)i1 * P.cs;
-        blo[d] = plo[d] - pad;
-        bhi[d] = phi[d] + pad;
-        const double cellpad = 1e-3 * (double)P.h;
-        const int a = (int)floor(((double)blo[d] - cellpad) * P.inv_h);  // see splat_block
-        const int e = (int)floor(((double)bhi[d] + cellpad) * P.inv_h);
-        klo[d] = max(a, P.kmin[d]);
-        khi[d] = min(e, P.kmin[d] + P.kdim[d] - 1);
+// ---- arithmetic of one (tile entry, grid point) pair ------------------------------------------------------------------------
+// CubicSplineKernelAvxF32::evaluate (kernel.rs:341-377), one lane of it
+__device__ __forceinline__ float ss_kernel_w_avx(const SSDevT<float>& P, float r) {
+    const float q = r * P.avx_inv_h;
+    // v = max(1 - q, 0): the clamp to [0, 1] is the subtraction's output modifier; q >= 0, so the upper bound never acts
+    float v;
+    asm("v_sub_f32_e64 %0, 1.0, %1 clamp" : "=v"(v) : "v"(q));
+    const float v2 = v * v;
+    const float v3 = v2 * v;
+    float w = v3 * P.avx_sigma2;  // outer piece
+    const bool inner = q <= 0.5f;
+    if (__ballot(inner)) {  // wave-uniform: most entries a wave visits are farther than h/2 from all of its points
+        asm volatile("; inner spline piece" ::);  // keeps the compiler from if-converting this block into five always-executed VALU ops
+        float ri = __builtin_fmaf(-v, P.avx_sigma6, P.avx_sigma);
+        ri = __builtin_fmaf(v2, P.avx_sigma12, ri);
+        ri = __builtin_fmaf(-v3, P.avx_sigma6, ri);
+        w = inner ? ri : w;
     }
-    uint32_t count = 0;
-    bool overflow = false;
-    if (klo[0] <= khi[0] && klo[1] <= khi[1] && klo[2] <= khi[2]) {
-        const int ny = khi[1] - klo[1] + 1;
-        const int nrows = (khi[0] - klo[0] + 1) * ny;
-        if (nrows > 64) {
-            overflow = true;
-        } else {
-            // row table: (x, y) rows of search cells are contiguous runs of the cell-sorted particle array
-            uint32_t len = 0;
-            if (lane < nrows) {
-                const int kx = klo[0] + lane / ny, ky = klo[1] + lane % ny;
-                const uint32_t rb = cell_start[ss_cell_key(P, kx, ky, klo[2])];
-                const uint32_t re = cell_start[ss_cell_key(P, kx, ky, khi[2]) + 1u];
-                s_row_start[w][lane] = rb;
-                len = re - rb;
-            }
-            uint32_t incl = len;
-#pragma unroll
-            for (int off = 1; off < 64; off <<= 1) {
-                const uint32_t t = __shfl_up(incl, off);
-                if (lane >= off) incl += t;
-            }
-            s_row_prefix[w][lane] = incl - len;
-            const uint32_t total = __shfl(incl, 63);
-            if (lane == 0) s_row_prefix[w][64] = total;
+    return w;
+}
+
+template <class R, int ARITH>
+__device__ __forceinline__ R ss_splat_pair(const SSDevT<R>& P, R rh, const ss_real4<R>& e, R px, R py, R pz, R acc) {
+    const R dx = e.x - px, dy = e.y - py, dz = e.z - pz;  // p_i - point, :828 / :1072-1074
+    if constexpr (ARITH >= SS_ARITH_SIMD) {
+        static_assert(sizeof(R) == 4, "the reference's SIMD loop exists for f32 only (dense_subdomains.rs:1413-1415)");
+        const float d2 = __builtin_fmaf(dz, dz, __builtin_fmaf(dx, dx, dy * dy));  // :1077-1080
+        if (d2 < P.h2) {                                                            // :1083
+            float r;
+            if constexpr (ARITH == SS_ARITH_SIMD)
+                r = ss_sqrt(d2);
+            else if constexpr (ARITH == SS_ARITH_SIMD_LEAN)
+                r = ss_sqrt_rn_normal(d2);  // below (2^-25 h)^2 any r rounds v = 1 - q to 1: the value of W does not depend on it
+            else
+                r = __builtin_amdgcn_sqrtf(d2);
+            acc = __builtin_fmaf(ss_kernel_w_avx(P, r), e.w, acc);  // :1101-1107
+        }
+    } else {
+        const R d2 = dx * dx + dy * dy + dz * dz;
+        if (d2 < P.H2) {  // :831
+            acc += e.w * ss_kernel_w<R, ARITH == SS_ARITH_FAST>(d2, P.h, rh, P.sigma);  // :832-841
+        }
+    }
+    return acc;
+}
+
+// Accumulation of one wave's 4^3 sub-block over an index-ordered chunk of the tile in LDS (dense_subdomains.rs:817-841).
+// Phase A tests 64 tile entries at once against the sub-block's box; the survivors are compacted IN ORDER into the wave's
+// own list `wl` (SS_WAVE_LIST entries), which phase B then walks front to back with a plain counter -- the scalar unit is
+// shared by the four SIMDs of a CU and walking a 64-bit survivor mask cost 14 scalar instructions per entry.
+template <class R, int ARITH>
+__device__ __forceinline__ R splat_accumulate_wave(const SSDevT<R>& P, const ss_real4<R>* pay, ss_real4<R>* wl, int n_tile, int lane, R px, R py, R pz,
+                                                   const R slo[3], const R shi[3], R acc) {
+    const R rh = R(1.0) / P.h;
+    for (int base = 0; base < n_tile; base += 64) {
+        const int c = base + lane;
+        bool pass = false;
+        ss_real4<R> pv = ss_make4(R(0.0), R(0.0), R(0.0), R(0.0));
+        if (c < n_tile) {
+            pv = pay[c];
+            const R ex = ss_max(ss_max(slo[0] - pv.x, pv.x - shi[0]) - P.coord_slack, R(0.0));
+            const R ey = ss_max(ss_max(slo[1] - pv.y, pv.y - shi[1]) - P.coord_slack, R(0.0));
+            const R ez = ss_max(ss_max(slo[2] - pv.z, pv.z - shi[2]) - P.coord_slack, R(0.0));
+            pass = (ex * ex + ey * ey + ez * ez) <= P.R2;
+        }
+        const unsigned long long wmask = __ballot(pass);
+        if (wmask) {
+            const int cnt = __popcll(wmask);
+            ss_wave_lds_sync();  // the previous batch's reads of wl are done
+            if (pass) wl[__builtin_amdgcn_mbcnt_hi((uint32_t)(wmask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)wmask, 0u))] = pv;
             ss_wave_lds_sync();
-            if (total > 4u * SS_WTILE) {
-                overflow = true;  // about 30 % of the particles of the overlapped rows are within reach: over-dense block
-            } else {
-                for (uint32_t q0 = 0; q0 < total; q0 += 64u) {
-                    const uint32_t q = q0 + (uint32_t)lane;
-                    bool inside = false;
-                    uint32_t src = 0, id = 0;
-                    if (q < total) {
-                        int lo = 0, hi = nrows - 1;  // last row r with row_prefix[r] <= q
-                        while (lo < hi) {
-                            const int mid = (lo + hi + 1) >> 1;
-                            if (s_row_prefix[w][mid] <= q)
-                                lo = mid;
-                            else
-                                hi = mid - 1;
-                        }
-                        src = s_row_start[w][lo] + (q - s_row_prefix[w][lo]);
-                        const ss_real4<R> pv = posvol[src];
-                        id = perm[src];
-                        inside = ss_within_reach_of_block<R>(P, pv, plo, phi);
-                    }
-                    const unsigned long long m = __ballot(inside);
-                    const uint32_t pos = count + (uint32_t)__popcll(m & ((lane == 0) ? 0ull : (~0ull >> (64 - lane))));
-                    if (inside && pos < SS_WTILE) {
-                        s_idx[w][pos] = id;
-                        s_src[w][pos] = src;
-                    }
-                    count += (uint32_t)__popcll(m);
-                }
-                if (count > SS_WTILE) {
-                    overflow = true;
-                } else {
-                    ss_wave_lds_sync();
-                    // rank sort by original particle index (unique), payload written in that order
-                    ss_real4<R>* slot = tiles + (size_t)logical * SS_WTILE;
-                    for (uint32_t e = (uint32_t)lane; e < count; e += 64u) {
-                        const uint32_t my = s_idx[w][e];
-                        uint32_t rank = 0;
-                        for (uint32_t k = 0; k < count; ++k) rank += (s_idx[w][k] < my) ? 1u : 0u;
-                        slot[rank] = posvol[s_src[w][e]];
-                    }
-                }
+            // Entries are fetched with a wave-uniform LDS read (broadcast: LDS pipe, no VALU issue slot, operands arrive in
+            // VGPRs) one iteration ahead of their use; two entries per trip, ping-ponging between two register sets (no
+            // loop-carried copies).  Reads past cnt stay inside wl and are not used.
+            ss_real4<R> ea = wl[0];
+            for (int k = 0;; k += 2) {
+                const ss_real4<R> eb = wl[k + 1];
+                acc = ss_splat_pair<R, ARITH>(P, rh, ea, px, py, pz, acc);
+                if (k + 1 >= cnt) break;
+                ea = wl[k + 2];
+                acc = ss_splat_pair<R, ARITH>(P, rh, eb, px, py, pz, acc);
+                if (k + 2 >= cnt) break;
             }
         }
     }
-    if (lane == 0) {
-        counts[logical] = overflow ? 0u : count;
-        overflow_flag[logical] = overflow ? 1u : 0u;
-    }
+    return acc;
 }
 
 // Wave-wide min / max of an f32 ending in lane 63, with DPP row shifts and row broadcasts (12 VALU for both against ~50 for
@@ -1228,11 +1158,11 @@ __device__ __forceinline__ float ss_wave_reduce_to_lane63(float v) {
     return v;
 }
 
-template <class R, bool FASTDIV>
-__global__ __launch_bounds__(512) void k_splat_accumulate(SSDevT<R> P, const ss_real4<R>* __restrict__ tiles, const uint32_t* __restrict__ counts,
-                                                          const uint32_t* __restrict__ overflow_flag, const uint32_t* __restrict__ active_xyz,
-                                                          uint32_t n_active, R* __restrict__ G, ss_real2<R>* __restrict__ blk_minmax,
-                                                          unsigned long long* __restrict__ cand_counter) {
+// step 3
+template <class R, int ARITH>
+__global__ __launch_bounds__(512) void k_splat_accumulate(SSDevT<R> P, const ss_real4<R>* __restrict__ arena, const unsigned long long* __restrict__ tile_off,
+                                                          const uint32_t* __restrict__ counts, const uint32_t* __restrict__ active_xyz, uint32_t n_active,
+                                                          R* __restrict__ G, ss_real2<R>* __restrict__ blk_minmax) {
     __shared__ ss_real4<R> s_pay[SS_WTILE];
     __shared__ ss_real4<R> s_wl[8][SS_WAVE_LIST];
     __shared__ R s_red[16];
@@ -1242,29 +1172,39 @@ __global__ __launch_bounds__(512) void k_splat_accumulate(SSDevT<R> P, const ss_
     const uint32_t per_xcd = (n_active + 7u) / 8u;
     const uint32_t logical = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
     if ((blockIdx.x >> 3) >= per_xcd || logical >= n_active) return;
-    if (overflow_flag[logical]) return;  // k_splat_large's block
     const int n_tile = (int)counts[logical];
-    const ss_real4<R>* slot = tiles + (size_t)logical * SS_WTILE;
-    if (tid < n_tile) s_pay[tid] = slot[tid];
+    const ss_real4<R>* tile = arena + tile_off[logical];
+    ss_real4<R> nxt = ss_make4(R(0.0), R(0.0), R(0.0), R(0.0));
+    if (tid < min(n_tile, SS_WTILE)) nxt = tile[tid];  // first chunk in flight while the coordinates are set up
     const int bx = (int)active_xyz[3 * (size_t)logical], by = (int)active_xyz[3 * (size_t)logical + 1], bz = (int)active_xyz[3 * (size_t)logical + 2];
     // this wave's sub-block and this lane's grid point
     const int g0[3] = {bx * SS_BLOCK + ((wave >> 2) & 1) * 4, by * SS_BLOCK + ((wave >> 1) & 1) * 4, bz * SS_BLOCK + (wave & 1) * 4};
     const int gl[3] = {g0[0] + ((lane >> 4) & 3), g0[1] + ((lane >> 2) & 3), g0[2] + (lane & 3)};
     const bool wave_valid = g0[0] < P.np[0] && g0[1] < P.np[1] && g0[2] < P.np[2];
-    // global point coordinates: uniform_grid.rs:418-425 on the GLOBAL grid (dense_subdomains.rs:817-826)
+    // global point coordinates: uniform_grid.rs:418-425 on the GLOBAL grid (dense_subdomains.rs:817-826); the SIMD loop of the
+    // reference forms z with one fma (:1069), x and y like the scalar loop (:1113-1114)
     const R px = P.gmin[0] + (R)gl[0] * P.cs;
     const R py = P.gmin[1] + (R)gl[1] * P.cs;
-    const R pz = P.gmin[2] + (R)gl[2] * P.cs;
+    R pz;
+    if constexpr (ARITH >= SS_ARITH_SIMD)
+        pz = __builtin_fmaf((R)gl[2], P.cs, P.gmin[2]);
+    else
+        pz = P.gmin[2] + (R)gl[2] * P.cs;
     R slo[3], shi[3];
 #pragma unroll
     for (int d = 0; d < 3; ++d) {
         slo[d] = P.gmin[d] + (R)g0[d] * P.cs;
         shi[d] = P.gmin[d] + (R)min(g0[d] + 3, P.np[d] - 1) * P.cs;
     }
-    const R wave_r2 = P.H2 * R(1.0001);
-    __syncthreads();
     R acc = R(0.0);  // levelset_grid.fill(0), dense_subdomains.rs:1390
-    if (wave_valid && n_tile) acc = splat_accumulate_wave<R, FASTDIV>(P, s_pay, s_wl[wave], n_tile, lane, px, py, pz, slo, shi, wave_r2, acc);
+    for (int c0 = 0; c0 < n_tile; c0 += SS_WTILE) {
+        const int nc = min(SS_WTILE, n_tile - c0);
+        if (tid < nc) s_pay[tid] = nxt;
+        __syncthreads();
+        if (c0 + SS_WTILE + tid < n_tile && tid < SS_WTILE) nxt = tile[c0 + SS_WTILE + tid];  // next chunk in flight during the arithmetic
+        if (wave_valid) acc = splat_accumulate_wave<R, ARITH>(P, s_pay, s_wl[wave], nc, lane, px, py, pz, slo, shi, acc);
+        if (c0 + SS_WTILE < n_tile) __syncthreads();  // s_pay is overwritten by the next trip
+    }
     // store: block-local layout (x*8+y)*8+z, i-major / k-fastest like dense_subdomains.rs:839
     const int lx = ((wave >> 2) & 1) * 4 + ((lane >> 4) & 3);
     const int ly = ((wave >> 1) & 1) * 4 + ((lane >> 2) & 3);
@@ -1272,6 +1212,8 @@ __global__ __launch_bounds__(512) void k_splat_accumulate(SSDevT<R> P, const ss_
     const bool point_valid = gl[0] < P.np[0] && gl[1] < P.np[1] && gl[2] < P.np[2];
     const R val = point_valid ? acc : R(0.0);
     G[(size_t)logical * SS_BLOCK_POINTS + (size_t)((lx * 8 + ly) * 8 + lz)] = val;
+    // block-wide min/max of the level-set values (points outside the grid count as 0 = "outside"),
+    // used to skip marching cubes on blocks that cannot contain the iso-surface
     R mn = val, mx = val;
     if constexpr (sizeof(R) == 4) {
         mn = ss_wave_reduce_to_lane63<false>(mn);
@@ -1303,73 +1245,42 @@ __global__ __launch_bounds__(512) void k_splat_accumulate(SSDevT<R> P, const ss_
     }
 }
 
-// Blocks with more candidates than the small tile holds (over-dense regions).  The queue is the flag array compacted in
-// order (scan + k_compact_blocks), so it is spatially ordered like the active list; persistent workgroups walk it, each
-// XCD a contiguous range.
-template <class R, bool FASTDIV>
-__global__ __launch_bounds__(512) void k_splat_large(SSDevT<R> P, const ss_real4<R>* __restrict__ posvol, const ss_real4<R>* __restrict__ posvol_by_index,
-                                                     const uint32_t* __restrict__ perm,
-                                                     const uint32_t* __restrict__ cell_start, const uint32_t* __restrict__ active_xyz,
-                                                     R* __restrict__ G, ss_real2<R>* __restrict__ blk_minmax, unsigned long long* __restrict__ cand_counter,
-                                                     const uint32_t* __restrict__ overflow_list, const uint32_t* __restrict__ overflow_count) {
-    __shared__ SplatShared<R, SSTileCap<R>::value> s;
-    const uint32_t n = *overflow_count;
-    const uint32_t per_xcd = (n + 7u) / 8u, xcd = blockIdx.x & 7u, stride = gridDim.x >> 3;
-    for (uint32_t j = blockIdx.x >> 3; j < per_xcd; j += stride) {
-        const uint32_t it = xcd * per_xcd + j;
-        if (it < n) {
-            const uint32_t logical = overflow_list[it];
-            splat_block<R, FASTDIV, SSTileCap<R>::value>(s, P, posvol, posvol_by_index, perm, cell_start, active_xyz + 3 * (size_t)logical, logical, G, blk_minmax,
-                                                         cand_counter);
-        }
-        __syncthreads();
-    }
-}
-
 template <class R>
-void ss_launch_splat_small(const SSDevT<R>& P, const ss_real4<R>* posvol, const uint32_t* perm, const uint32_t* cell_start, const uint32_t* active_xyz,
-                           uint32_t n_active, ss_real4<R>* tiles, uint32_t* counts, R* G, ss_real2<R>* blk_minmax, unsigned long long* cand_counter,
-                           uint32_t* overflow_flag, bool fast_div, hipEvent_t ev_after_gather, hipEvent_t ev_after_accumulate, hipStream_t st) {
-    if (n_active) {
-        const uint32_t n_groups = (n_active + 3u) / 4u;
-        hipLaunchKernelGGL(k_splat_gather<R>, dim3(((n_groups + 7u) / 8u) * 8u), dim3(256), 0, st, P, posvol, perm, cell_start, active_xyz, n_active, tiles, counts,
-                           overflow_flag);
-    }
-    (void)hipEventRecord(ev_after_gather, st);
-    if (n_active) {
-        const dim3 grid(((n_active + 7u) / 8u) * 8u);
-        bool launched = false;
-        if constexpr (sizeof(R) == 4) {
-            if (fast_div) {
-                hipLaunchKernelGGL((k_splat_accumulate<R, true>), grid, dim3(512), 0, st, P, tiles, counts, overflow_flag, active_xyz, n_active, G, blk_minmax,
-                                   cand_counter);
-                launched = true;
-            }
-        }
-        if (!launched)
-            hipLaunchKernelGGL((k_splat_accumulate<R, false>), grid, dim3(512), 0, st, P, tiles, counts, overflow_flag, active_xyz, n_active, G, blk_minmax,
-                               cand_counter);
-    }
-    (void)hipEventRecord(ev_after_accumulate, st);
-}
-size_t ss_splat_tile_entries() { return SS_WTILE; }
-
-// second launch: the queued over-dense blocks (overflow_count lives on the device; an empty queue costs one trivial launch)
-template <class R>
-void ss_launch_splat_large(const SSDevT<R>& P, const ss_real4<R>* posvol, const ss_real4<R>* posvol_by_index, const uint32_t* perm, const uint32_t* cell_start,
-                           const uint32_t* active_xyz, uint32_t n_active, R* G, ss_real2<R>* blk_minmax, unsigned long long* cand_counter, const uint32_t* overflow_list,
-                           const uint32_t* overflow_count, bool fast_div, hipStream_t st) {
+void ss_launch_splat_count(const SSDevT<R>& P, const ss_real4<R>* posvol, const uint32_t* cell_start, const uint32_t* active_xyz, uint32_t n_active,
+                           uint32_t* counts, uint32_t* large_flag, hipStream_t st) {
     if (!n_active) return;
-    const dim3 grid(4096);  // persistent workgroups over the queue
+    const uint32_t n_groups = (n_active + 3u) / 4u;
+    hipLaunchKernelGGL(k_splat_count<R>, dim3(((n_groups + 7u) / 8u) * 8u), dim3(256), 0, st, P, posvol, cell_start, active_xyz, n_active, counts, large_flag);
+}
+
+template <class R>
+void ss_launch_splat_gather(const SSDevT<R>& P, const ss_real4<R>* posvol, const ss_real4<R>* posvol_by_index, const uint32_t* perm, const uint32_t* cell_start,
+                            const uint32_t* active_xyz, uint32_t n_active, const uint32_t* counts, const unsigned long long* tile_off, ss_real4<R>* arena,
+                            const uint32_t* large_list, uint32_t n_large, hipStream_t st) {
+    if (!n_active) return;
+    const uint32_t n_groups = (n_active + 3u) / 4u;
+    hipLaunchKernelGGL(k_splat_gather<R>, dim3(((n_groups + 7u) / 8u) * 8u), dim3(256), 0, st, P, posvol, perm, cell_start, active_xyz, n_active, counts, tile_off,
+                       arena);
+    if (n_large)
+        hipLaunchKernelGGL((k_splat_gather_large<R, SSTileCap<R>::value>), dim3(((n_large + 7u) / 8u) * 8u), dim3(512), 0, st, P, posvol, posvol_by_index, perm,
+                           cell_start, active_xyz, large_list, n_large, counts, tile_off, arena);
+}
+
+template <class R>
+void ss_launch_splat_accumulate(const SSDevT<R>& P, const ss_real4<R>* arena, const unsigned long long* tile_off, const uint32_t* counts,
+                                const uint32_t* active_xyz, uint32_t n_active, R* G, ss_real2<R>* blk_minmax, hipStream_t st) {
+    if (!n_active) return;
+    const dim3 grid(((n_active + 7u) / 8u) * 8u), block(512);
     if constexpr (sizeof(R) == 4) {
-        if (fast_div) {
-            hipLaunchKernelGGL((k_splat_large<R, true>), grid, dim3(512), 0, st, P, posvol, posvol_by_index, perm, cell_start, active_xyz, G, blk_minmax, cand_counter, overflow_list,
-                               overflow_count);
-            return;
+        switch (P.arith) {
+            case SS_ARITH_FAST: hipLaunchKernelGGL((k_splat_accumulate<R, SS_ARITH_FAST>), grid, block, 0, st, P, arena, tile_off, counts, active_xyz, n_active, G, blk_minmax); return;
+            case SS_ARITH_SIMD: hipLaunchKernelGGL((k_splat_accumulate<R, SS_ARITH_SIMD>), grid, block, 0, st, P, arena, tile_off, counts, active_xyz, n_active, G, blk_minmax); return;
+            case SS_ARITH_SIMD_LEAN: hipLaunchKernelGGL((k_splat_accumulate<R, SS_ARITH_SIMD_LEAN>), grid, block, 0, st, P, arena, tile_off, counts, active_xyz, n_active, G, blk_minmax); return;
+            case SS_ARITH_SIMD_HW: hipLaunchKernelGGL((k_splat_accumulate<R, SS_ARITH_SIMD_HW>), grid, block, 0, st, P, arena, tile_off, counts, active_xyz, n_active, G, blk_minmax); return;
+            default: break;
         }
     }
-    hipLaunchKernelGGL((k_splat_large<R, false>), grid, dim3(512), 0, st, P, posvol, posvol_by_index, perm, cell_start, active_xyz, G, blk_minmax, cand_counter, overflow_list,
-                       overflow_count);
+    hipLaunchKernelGGL((k_splat_accumulate<R, SS_ARITH_GENERIC>), grid, block, 0, st, P, arena, tile_off, counts, active_xyz, n_active, G, blk_minmax);
 }
 
 // =====================================================================================================
@@ -1661,10 +1572,12 @@ template void ss_launch_mark_blocks<float>(const SSDevT<float>& P, const uint32_
 template void ss_launch_mark_blocks<double>(const SSDevT<double>& P, const uint32_t* cell_start, uint32_t ncells, uint32_t* block_flag, hipStream_t st);
 template void ss_launch_mark_mc_blocks<float>(const SSDevT<float>& P, const uint32_t* block_slot, const ss_real2<float>* blk_minmax, uint32_t nblocks, uint32_t* mc_flag, hipStream_t st);
 template void ss_launch_mark_mc_blocks<double>(const SSDevT<double>& P, const uint32_t* block_slot, const ss_real2<double>* blk_minmax, uint32_t nblocks, uint32_t* mc_flag, hipStream_t st);
-template void ss_launch_splat_small<float>(const SSDevT<float>& P, const ss_real4<float>* posvol, const uint32_t* perm, const uint32_t* cell_start, const uint32_t* active_xyz, uint32_t n_active, ss_real4<float>* tiles, uint32_t* counts, float* G, ss_real2<float>* blk_minmax, unsigned long long* cand_counter, uint32_t* overflow_flag, bool fast_div, hipEvent_t ev_after_gather, hipEvent_t ev_after_accumulate, hipStream_t st);
-template void ss_launch_splat_large<float>(const SSDevT<float>& P, const ss_real4<float>* posvol, const ss_real4<float>* posvol_by_index, const uint32_t* perm, const uint32_t* cell_start, const uint32_t* active_xyz, uint32_t n_active, float* G, ss_real2<float>* blk_minmax, unsigned long long* cand_counter, const uint32_t* overflow_list, const uint32_t* overflow_count, bool fast_div, hipStream_t st);
-template void ss_launch_splat_small<double>(const SSDevT<double>& P, const ss_real4<double>* posvol, const uint32_t* perm, const uint32_t* cell_start, const uint32_t* active_xyz, uint32_t n_active, ss_real4<double>* tiles, uint32_t* counts, double* G, ss_real2<double>* blk_minmax, unsigned long long* cand_counter, uint32_t* overflow_flag, bool fast_div, hipEvent_t ev_after_gather, hipEvent_t ev_after_accumulate, hipStream_t st);
-template void ss_launch_splat_large<double>(const SSDevT<double>& P, const ss_real4<double>* posvol, const ss_real4<double>* posvol_by_index, const uint32_t* perm, const uint32_t* cell_start, const uint32_t* active_xyz, uint32_t n_active, double* G, ss_real2<double>* blk_minmax, unsigned long long* cand_counter, const uint32_t* overflow_list, const uint32_t* overflow_count, bool fast_div, hipStream_t st);
+template void ss_launch_splat_count<float>(const SSDevT<float>& P, const ss_real4<float>* posvol, const uint32_t* cell_start, const uint32_t* active_xyz, uint32_t n_active, uint32_t* counts, uint32_t* large_flag, hipStream_t st);
+template void ss_launch_splat_count<double>(const SSDevT<double>& P, const ss_real4<double>* posvol, const uint32_t* cell_start, const uint32_t* active_xyz, uint32_t n_active, uint32_t* counts, uint32_t* large_flag, hipStream_t st);
+template void ss_launch_splat_gather<float>(const SSDevT<float>& P, const ss_real4<float>* posvol, const ss_real4<float>* posvol_by_index, const uint32_t* perm, const uint32_t* cell_start, const uint32_t* active_xyz, uint32_t n_active, const uint32_t* counts, const unsigned long long* tile_off, ss_real4<float>* arena, const uint32_t* large_list, uint32_t n_large, hipStream_t st);
+template void ss_launch_splat_gather<double>(const SSDevT<double>& P, const ss_real4<double>* posvol, const ss_real4<double>* posvol_by_index, const uint32_t* perm, const uint32_t* cell_start, const uint32_t* active_xyz, uint32_t n_active, const uint32_t* counts, const unsigned long long* tile_off, ss_real4<double>* arena, const uint32_t* large_list, uint32_t n_large, hipStream_t st);
+template void ss_launch_splat_accumulate<float>(const SSDevT<float>& P, const ss_real4<float>* arena, const unsigned long long* tile_off, const uint32_t* counts, const uint32_t* active_xyz, uint32_t n_active, float* G, ss_real2<float>* blk_minmax, hipStream_t st);
+template void ss_launch_splat_accumulate<double>(const SSDevT<double>& P, const ss_real4<double>* arena, const unsigned long long* tile_off, const uint32_t* counts, const uint32_t* active_xyz, uint32_t n_active, double* G, ss_real2<double>* blk_minmax, hipStream_t st);
 template void ss_launch_mc_count<float>(const SSDevT<float>& P, const float* G, const uint32_t* block_slot, const uint32_t* mc_xyz, uint32_t n_mc, unsigned long long* masks, uint32_t* vcount, uint32_t* tcount, hipStream_t st);
 template void ss_launch_mc_count<double>(const SSDevT<double>& P, const double* G, const uint32_t* block_slot, const uint32_t* mc_xyz, uint32_t n_mc, unsigned long long* masks, uint32_t* vcount, uint32_t* tcount, hipStream_t st);
 template void ss_launch_mc_emit<float>(const SSDevT<float>& P, const float* G, const uint32_t* block_slot, const uint32_t* mc_xyz, const uint32_t* mc_slot, uint32_t n_mc, const unsigned long long* masks, const uint32_t* vbase, const uint32_t* tbase, float* vertices, unsigned long long* vkeys, uint32_t* triangles, hipStream_t st);

@@ -194,7 +194,7 @@ def _gpu_worker(rank, world, port, case, out_path):
         torch.cuda.set_device(0)
         dev = torch.device("cuda", 0)
         prm = Parameters(particle_radius=r, compact_support_radius=np.float32(2.0 * l * r), cube_size=np.float32(c * r),
-                         subdomain_num_cubes_per_dim=n_cubes, auto_disable=False)
+                         subdomain_num_cubes_per_dim=n_cubes, auto_disable=False, enable_simd=False)
         cut = [0] + [int(round(pts.shape[0] * (k + 1) / world)) for k in range(world)]
         sh = D.ShardedReconstruction(D.HipEngine(Context(0), prm), dev)
         sh.load_local_particles(pts[cut[rank]:cut[rank + 1]])

@@ -42,8 +42,15 @@ for i in range(36):
         rest_density=[1000.0, 1.0, 650.0][i % 3], f64=(i % 5 == 4), strategy=["grid", "grid", "global"][i % 3], aabb=(i % 7 == 3)))
 
 
-@pytest.mark.parametrize("case", CASES, ids=lambda c: "%s-%s-c%.2g-n%d-%s%s" % (c["kind"], c["strategy"], c["c"], c["n_cubes"], "f64" if c["f64"] else "f32",
-                                                                                 "-aabb" if c["aabb"] else ""))
+# the same sweep with the reference's default arithmetic (Parameters::enable_simd = true): GPU enable_simd = 1 against the
+# oracle's uniform-SIMD mode 2, bit for bit (subdomain grid, f32 -- the only instantiation the reference's SIMD loop exists for)
+SIMD_CASES = [dict(c, simd=1) for c in CASES if c["strategy"] == "grid" and not c["f64"]]
+for c in CASES:
+    c["simd"] = 0
+
+
+@pytest.mark.parametrize("case", CASES + SIMD_CASES, ids=lambda c: "%s-%s-c%.2g-n%d-%s%s%s" % (c["kind"], c["strategy"], c["c"], c["n_cubes"], "f64" if c["f64"] else "f32",
+                                                                                                "-aabb" if c["aabb"] else "", "-simd" if c["simd"] else ""))
 def test_random_configuration_bit_identical(gpu_ctx, oracle, case):
     import splashsurf_amd as S
     dt = np.float64 if case["f64"] else np.float32
@@ -58,9 +65,10 @@ def test_random_configuration_bit_identical(gpu_ctx, oracle, case):
     glob = case["strategy"] == "global"
     res = S.reconstruct_surface(pts, particle_radius=case["r"], rest_density=case["rest_density"], smoothing_length=case["l"], cube_size=case["c"],
                                 iso_surface_threshold=case["t"], subdomain_grid=not glob, subdomain_grid_auto_disable=False,
-                                subdomain_num_cubes_per_dim=case["n_cubes"], global_neighborhood_list=True, context=gpu_ctx, **kw)
+                                subdomain_num_cubes_per_dim=case["n_cubes"], global_neighborhood_list=True, context=gpu_ctx, simd=case["simd"], **kw)
     par = oracle.make_params_relative(case["r"], case["l"], case["c"], iso_surface_threshold=case["t"], rest_density=case["rest_density"],
-                                      subdomain_num_cubes_per_dim=case["n_cubes"], global_neighborhood_list=True, dtype=dt, subdomain_grid=not glob, **okw)
+                                      subdomain_num_cubes_per_dim=case["n_cubes"], global_neighborhood_list=True, dtype=dt, subdomain_grid=not glob,
+                                      simd=2 if case["simd"] else 0, **okw)
     orc = oracle.reconstruct_surface(pts, par)
     U = np.uint64 if case["f64"] else np.uint32
     if glob:

@@ -22,7 +22,7 @@ FULL = ["kat1", "edge_empty", "edge_single", "edge_coincident", "edge_aabb_exclu
 DIGEST = ["config5_hilbert", "tank_small", "config2_s1m"]
 
 
-def run_gpu(ctx, pts, prm):
+def run_gpu(ctx, pts, prm, simd=False):
     import splashsurf_amd as S
     kw = {}
     if "aabb_min" in prm:
@@ -30,7 +30,7 @@ def run_gpu(ctx, pts, prm):
     return S.reconstruct_surface(pts, particle_radius=prm["particle_radius"], smoothing_length=prm["smoothing_length"],
                                  cube_size=prm["cube_size"], iso_surface_threshold=prm["iso_surface_threshold"],
                                  subdomain_grid=True, subdomain_grid_auto_disable=False,
-                                 subdomain_num_cubes_per_dim=prm.get("subdomain_num_cubes_per_dim", 64), context=ctx, **kw)
+                                 subdomain_num_cubes_per_dim=prm.get("subdomain_num_cubes_per_dim", 64), context=ctx, simd=simd, **kw)
 
 
 def run_oracle(O, pts, prm):
@@ -241,7 +241,7 @@ def test_sharded_engine_reproduces_full_reconstruction(oracle, case):
     U = np.uint32 if dt == np.float32 else np.uint64
     pts = np.load(os.path.join(os.path.dirname(__file__), "data", fn)).astype(dt)
     prm = Parameters(particle_radius=r, compact_support_radius=dt(2.0 * l * r), cube_size=dt(c * r),
-                     subdomain_num_cubes_per_dim=n_cubes, auto_disable=False)
+                     subdomain_num_cubes_per_dim=n_cubes, auto_disable=False, enable_simd=False)
     engines = [D.HipEngine(Context(0), prm, dtype=dt) for _ in range(k)]
     P_all = torch.from_numpy(pts).to("cuda:0")
     dmin, dmax = pts.min(axis=0), pts.max(axis=0)
@@ -431,7 +431,7 @@ def test_splat_on_reference_grid_loop_fixture(oracle):
     flat = (sub[0] * ns[1] + sub[1]) * ns[2] + sub[2]
     cnt, ref = oracle.shard_levelset(pts, rho, opar, dmin, dmax, sub, [s + 1 for s in sub], flat)
     assert cnt == pts.shape[0]  # every particle of the fixture is a member of that subdomain
-    eng = D.HipEngine(Context(0), Parameters(particle_radius=r, compact_support_radius=np.float32(h), cube_size=np.float32(cs), auto_disable=False))
+    eng = D.HipEngine(Context(0), Parameters(particle_radius=r, compact_support_radius=np.float32(h), cube_size=np.float32(cs), auto_disable=False, enable_simd=False))
     shard = D.ShardDesc(dmin, dmax, sub, [s + 1 for s in sub])
     eng.begin(torch.from_numpy(pts).to("cuda:0"), shard)
     res = eng.finish(torch.from_numpy(rho).to("cuda:0"))

@@ -238,3 +238,41 @@ def test_oracle_single_cell_known_answer(oracle):
     assert res.vertices.shape[0] == 6 and sorted(int(k) for k in res.vertex_keys) == SINGLE_CELL_KEYS
     empty = oracle.marching_cubes(np.zeros((2, 2, 2)), 0.25, 1.0)
     assert empty.vertices.shape[0] == 0 and empty.triangles.shape[0] == 0
+
+
+# ---- the reference's default arithmetic: Parameters::enable_simd = true (goldens: tools/gen_goldens_simd.py) ----
+@pytest.mark.parametrize("name", ["simd_kat1", "simd_cube_2366_n16", "simd_config1_double_dam_break"])
+@pytest.mark.parametrize("mode", [1, 2])
+def test_oracle_simd_modes_match_reference_simd(oracle, name, mode):
+    """Mode 1 (lane-by-lane restatement of density_grid_loop_avx, dense_subdomains.rs:991-1133, with its unfused remainder
+    lanes and the scalar loop for sparse subdomains) reproduces the wheel's simd=True mesh up to the reference's own freedom
+    on subdomain faces; mode 2 (that arithmetic applied uniformly = what the HIP library computes) keeps the topology and
+    stays within the north-star tolerance."""
+    g = load_golden(name)
+    prm = golden_params(g)
+    pts = golden_input(g)
+    par = oracle.make_params_relative(prm["particle_radius"], prm["smoothing_length"], prm["cube_size"], iso_surface_threshold=prm["iso_surface_threshold"],
+                                      subdomain_num_cubes_per_dim=prm["subdomain_num_cubes_per_dim"], simd=mode)
+    res = oracle.reconstruct_surface(pts, par)
+    assert hashlib.sha256(res.particle_densities.tobytes()).hexdigest() == str(g["density_sha256"])  # densities do not depend on simd
+    cmp = MC.compare_geometric(g["vertices"], g["triangles"], res.vertices, res.triangles, g["grid_min"], g["cell_size"], g["n_points"])
+    assert cmp["ids_equal"] and cmp["triangles_equal"], cmp
+    assert cmp["max_rel_diff"] <= (1e-6 if mode == 1 else 1e-5), cmp
+    if mode == 1:
+        assert cmp["n_vertices_bit_equal"] >= 0.99 * g["vertices"].shape[0]
+
+
+def test_oracle_avx_kernel_against_scalar_kernel(oracle):
+    """kernel.rs:381-481 (the reference's AVX-vs-scalar kernel test): the (1 - q) form with sigma = 8/(pi h^3) equals the scalar
+    cubic spline within 5e-6 absolute or 1e-5 relative, and vanishes outside the support."""
+    import ctypes
+    L = oracle.lib()
+    L.so_avx_kernel_evaluate.argtypes = [ctypes.c_float, ctypes.c_float]
+    L.so_avx_kernel_evaluate.restype = ctypes.c_float
+    for h in (0.025, 0.1, 1.0, 3.0):
+        for r in np.linspace(0.0, 1.25 * h, 101):
+            a = float(L.so_avx_kernel_evaluate(np.float32(h), np.float32(r)))
+            b = float(oracle.kernel_evaluate(h, r))
+            assert abs(a - b) <= max(5e-6, 1e-5 * abs(b)), (h, r, a, b)
+            if r > h:
+                assert a == 0.0

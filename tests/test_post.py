@@ -147,7 +147,7 @@ def test_gpu_pipeline_matches_oracle_and_reference(gpu_ctx, oracle, name):
     g, dt, prm, pts = _case(name)
     U = np.uint32 if dt == np.float32 else np.uint64
     mwd, rec = PP.reconstruction_pipeline(pts, particle_radius=prm["particle_radius"], smoothing_length=prm["smoothing_length"], cube_size=prm["cube_size"],
-                                          subdomain_grid=True, subdomain_grid_auto_disable=False, mesh_smoothing_iters=25, mesh_smoothing_weights=True,
+                                          subdomain_grid=True, subdomain_grid_auto_disable=False, simd=False, mesh_smoothing_iters=25, mesh_smoothing_weights=True,
                                           mesh_smoothing_weights_normalization=13.0, compute_normals=True, sph_normals=False, normals_smoothing_iters=10,
                                           output_mesh_smoothing_weights=True, output_raw_normals=True, output_raw_mesh=True, context=gpu_ctx)
     raw_v, T = rec.mesh.vertices, rec.mesh.triangles
@@ -176,7 +176,7 @@ def test_gpu_pipeline_matches_oracle_and_reference(gpu_ctx, oracle, name):
     assert np.abs(pa["normals"][b] - g["pipe_normals"][a]).max() <= (2e-3 if loose else 1e-10)
     # SPH normals variant, no smoothing
     mwd2, _ = PP.reconstruction_pipeline(pts, particle_radius=prm["particle_radius"], smoothing_length=prm["smoothing_length"], cube_size=prm["cube_size"],
-                                         subdomain_grid=True, subdomain_grid_auto_disable=False, compute_normals=True, sph_normals=True, mesh_smoothing_weights=False,
+                                         subdomain_grid=True, subdomain_grid_auto_disable=False, simd=False, compute_normals=True, sph_normals=True, mesh_smoothing_weights=False,
                                          context=gpu_ctx)
     assert np.abs(mwd2.point_attributes["normals"][b] - g["pipe_sph_normals"][a]).max() <= (1e-4 if loose else 1e-12)
     with pytest.raises(NotImplementedError):
