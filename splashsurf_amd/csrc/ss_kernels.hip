@@ -753,6 +753,26 @@ __device__ __forceinline__ bool splat_block_box(const SSDevT<R>& P, const int b3
     return klo[0] <= khi[0] && klo[1] <= khi[1] && klo[2] <= khi[2];
 }
 
+// z-range of search cells of the (x, y) row (kx, ky) that can hold a particle within reach of the box [plo, phi]: the cells of
+// a row form the slab [kx h, (kx+1) h] x [ky h, (ky+1) h]; with its distance d_xy to the box's (x, y) rectangle only
+// sqrt(reach^2 - d_xy^2) is left along z, which trims the corner rows of the dilated box (a quarter to a third of the
+// candidates).  eps covers the rounding of the products and particles filed one cell off their nominal cell by rounding.
+template <class R>
+__device__ __forceinline__ bool splat_row_z_range(const SSDevT<R>& P, int kx, int ky, const int klo[3], const int khi[3], const R plo[3], const R phi[3],
+                                                  int* zlo, int* zhi) {
+    const R eps = P.coord_slack + R(2.0e-3) * P.h;
+    const R ex = ss_max(ss_max(plo[0] - (R)(kx + 1) * P.h, (R)kx * P.h - phi[0]) - eps, R(0.0));
+    const R ey = ss_max(ss_max(plo[1] - (R)(ky + 1) * P.h, (R)ky * P.h - phi[1]) - eps, R(0.0));
+    const R left = P.reach * P.reach - (ex * ex + ey * ey);
+    if (left < R(0.0)) return false;
+    const R rz = ss_sqrt(left) + eps;
+    const int a = (int)floor((double)(plo[2] - rz) * P.inv_h);
+    const int b = (int)floor((double)(phi[2] + rz) * P.inv_h);
+    *zlo = max(a, klo[2]);
+    *zhi = min(b, khi[2]);
+    return *zlo <= *zhi;
+}
+
 // ---- one wave visits every particle of the search-cell rows overlapping a block's dilated box -------------------------------
 // f(inside, src, id) is called in lock-step for 64 candidates at a time (inside = within reach of the block's points, src =
 // position in the cell-sorted arrays, id = original particle index if NEED_ID).  Rows are handled 64 at a time (a block
@@ -769,8 +789,12 @@ __device__ __forceinline__ void splat_wave_scan(const SSDevT<R>& P, const ss_rea
         if (lane < nb) {
             const int r = row_base + lane;
             const int kx = klo[0] + r / ny, ky = klo[1] + r % ny;
-            const uint32_t rb = cell_start[ss_cell_key(P, kx, ky, klo[2])];
-            const uint32_t re = cell_start[ss_cell_key(P, kx, ky, khi[2]) + 1u];
+            int zlo, zhi;
+            uint32_t rb = 0, re = 0;
+            if (splat_row_z_range<R>(P, kx, ky, klo, khi, plo, phi, &zlo, &zhi)) {
+                rb = cell_start[ss_cell_key(P, kx, ky, zlo)];
+                re = cell_start[ss_cell_key(P, kx, ky, zhi) + 1u];
+            }
             s_row_start[lane] = rb;
             len = re - rb;
         }
@@ -923,9 +947,12 @@ __device__ inline void splat_for_each_candidate(S& s, const SSDevT<R>& P, const 
         if (tid < nbatch) {
             const int r = row_base + tid;
             const int kx = klo[0] + r / ny, ky = klo[1] + r % ny;
-            const uint32_t key_lo = ss_cell_key(P, kx, ky, klo[2]);
-            const uint32_t key_hi = ss_cell_key(P, kx, ky, khi[2]);
-            const uint32_t b = cell_start[key_lo], e = cell_start[key_hi + 1];
+            int zlo, zhi;
+            uint32_t b = 0, e = 0;
+            if (splat_row_z_range<R>(P, kx, ky, klo, khi, plo, phi, &zlo, &zhi)) {
+                b = cell_start[ss_cell_key(P, kx, ky, zlo)];
+                e = cell_start[ss_cell_key(P, kx, ky, zhi) + 1u];
+            }
             s.row_start[tid] = b;
             len = e - b;
         }
@@ -1271,16 +1298,18 @@ void ss_launch_splat_accumulate(const SSDevT<R>& P, const ss_real4<R>* arena, co
                                 const uint32_t* active_xyz, uint32_t n_active, R* G, ss_real2<R>* blk_minmax, hipStream_t st) {
     if (!n_active) return;
     const dim3 grid(((n_active + 7u) / 8u) * 8u), block(512);
+#define SS_ACC(A) hipLaunchKernelGGL((k_splat_accumulate<R, A>), grid, block, 0, st, P, arena, tile_off, counts, active_xyz, n_active, G, blk_minmax)
     if constexpr (sizeof(R) == 4) {
         switch (P.arith) {
-            case SS_ARITH_FAST: hipLaunchKernelGGL((k_splat_accumulate<R, SS_ARITH_FAST>), grid, block, 0, st, P, arena, tile_off, counts, active_xyz, n_active, G, blk_minmax); return;
-            case SS_ARITH_SIMD: hipLaunchKernelGGL((k_splat_accumulate<R, SS_ARITH_SIMD>), grid, block, 0, st, P, arena, tile_off, counts, active_xyz, n_active, G, blk_minmax); return;
-            case SS_ARITH_SIMD_LEAN: hipLaunchKernelGGL((k_splat_accumulate<R, SS_ARITH_SIMD_LEAN>), grid, block, 0, st, P, arena, tile_off, counts, active_xyz, n_active, G, blk_minmax); return;
-            case SS_ARITH_SIMD_HW: hipLaunchKernelGGL((k_splat_accumulate<R, SS_ARITH_SIMD_HW>), grid, block, 0, st, P, arena, tile_off, counts, active_xyz, n_active, G, blk_minmax); return;
+            case SS_ARITH_FAST: SS_ACC(SS_ARITH_FAST); return;
+            case SS_ARITH_SIMD: SS_ACC(SS_ARITH_SIMD); return;
+            case SS_ARITH_SIMD_LEAN: SS_ACC(SS_ARITH_SIMD_LEAN); return;
+            case SS_ARITH_SIMD_HW: SS_ACC(SS_ARITH_SIMD_HW); return;
             default: break;
         }
     }
-    hipLaunchKernelGGL((k_splat_accumulate<R, SS_ARITH_GENERIC>), grid, block, 0, st, P, arena, tile_off, counts, active_xyz, n_active, G, blk_minmax);
+    SS_ACC(SS_ARITH_GENERIC);
+#undef SS_ACC
 }
 
 // =====================================================================================================

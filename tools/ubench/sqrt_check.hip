@@ -58,6 +58,31 @@ __global__ void k(unsigned long long* out, uint32_t lo_exp, uint32_t hi_exp) {
     }
     atomicAdd(&out[0], exact); atomicAdd(&out[1], high); atomicAdd(&out[2], low); atomicAdd(&out[3], other); atomicAdd(&out[4], vs_lib);
 }
+// the AMDGPU backend's other correctly rounded form: Goldschmidt step on v_rsq_f32 + residual correction (ss_sqrt_rn_rsq)
+__device__ __forceinline__ float sqrt_rn_rsq(float x) {
+    const float y = __builtin_amdgcn_rsqf(x);
+    float s = x * y;
+    float h = 0.5f * y;
+    const float e = __builtin_fmaf(-h, s, 0.5f);
+    h = __builtin_fmaf(h, e, h);
+    s = __builtin_fmaf(s, e, s);
+    const float d = __builtin_fmaf(-s, s, x);
+    return __builtin_fmaf(d, h, s);
+}
+__global__ void k3(unsigned long long* out) {
+    const uint32_t m = blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned long long bad_hi = 0, bad_mid = 0, bad_lo = 0;
+    for (uint32_t e = 1; e <= 254; ++e) {
+        const float x = __uint_as_float((e << 23) | m);
+        const float ref = sqrt_rn(x, __builtin_amdgcn_sqrtf(x));
+        if (__float_as_int(ref) != __float_as_int(sqrt_rn_rsq(x))) {
+            if (e >= 230) ++bad_hi; else if (e >= 30) ++bad_mid; else ++bad_lo;
+        }
+    }
+    atomicAdd(&out[0], bad_hi);
+    atomicAdd(&out[1], bad_mid);
+    atomicAdd(&out[2], bad_lo);
+}
 int main() {
     unsigned long long* d; hipMalloc(&d, 64); hipMemset(d, 0, 64);
     k<<<(1u << 23) / 256, 256>>>(d, 1, 254);
@@ -65,5 +90,9 @@ int main() {
     unsigned long long h[8]; hipMemcpy(h, d, 64, hipMemcpyDeviceToHost);
     printf("v_sqrt_f32 over all positive normals: exact %llu, one ulp high %llu, one ulp low %llu, other %llu; fix-up vs __fsqrt_rn mismatches %llu\n", h[0], h[1], h[2], h[3], h[4]);
     printf("branch-free fix-up vs compare/select fix-up: %llu mismatches for x >= 2^-97, %llu below (residual underflow); zero/denormal inputs outside [0, 1e-15): %llu\n", h[5], h[7], h[6]);
+    hipMemset(d, 0, 64);
+    k3<<<(1u << 23) / 256, 256>>>(d);
+    hipMemcpy(h, d, 64, hipMemcpyDeviceToHost);
+    printf("rsq/Goldschmidt form vs v_sqrt fix-up form: mismatches %llu for x >= 2^103, %llu for 2^-97 <= x < 2^103, %llu below 2^-97\n", h[0], h[1], h[2]);
     return 0;
 }
