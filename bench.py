@@ -223,22 +223,67 @@ def main():
             pts = np.ascontiguousarray(full[cut[rank]:cut[rank + 1]])
             del full
             workload_desc = "%s, fixed size; rank r holds the r-th contiguous 1/%d of the cloud" % (workload, world)
-        engine = D.HipEngine(ctx, prm)
-        sharded = D.ShardedReconstruction(engine, dev)
-        sharded.load_local_particles(pts)
-        exchange_kind = "torch.distributed/%s isend-irecv" % (dist.get_backend() if dist.is_initialized() else "none")
+        # transport of the exchanges: the library's own RCCL path (ss_dist_*, csrc/ss_dist.hip) unless --exchange torch; with "auto"
+        # a failing native set-up is reported LOUDLY (stderr + the "exchange" object of the JSON line) and the torch path runs
+        native, native_error = None, None
+        if args.exchange in ("auto", "native"):
+            try:
+                comm = D.NativeComm.rccl(ctx, rank=rank, world=world) if dist.is_initialized() or world == 1 else None
+                native = D.NativeSharded(comm, prm)
+                native.step(torch.from_numpy(pts).to(dev))  # first call doubles as the self-test of the RCCL plumbing
+                native.assemble()
+            except Exception as e:
+                native_error = repr(e)
+                native = None
+                if args.exchange == "native":
+                    raise
+                print("[bench] rank %d: NATIVE RCCL EXCHANGE FAILED (%s) -- falling back to torch.distributed" % (rank, native_error), file=sys.stderr, flush=True)
+            if world > 1:  # every rank must take the same path
+                ok = torch.tensor([1 if native is not None else 0], dtype=torch.int32, device=dev)
+                dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+                if int(ok.item()) == 0:
+                    native = None
+        d_local = torch.from_numpy(pts).to(dev)
+        timings = {}
+        if native is not None:
+            exchange_kind = "native: grouped ncclSend/ncclRecv + ncclAllGather/ncclAllReduce inside libsplashsurf_hip.so (ss_dist_reconstruct_f32)"
+
+            def do_step(profile):
+                res_ = native.step(d_local)
+                info_ = native.assemble()
+                if profile:
+                    for k_ in ("ms_partition", "ms_position_exchange", "ms_density_exchange", "ms_assembly"):
+                        timings[k_] = timings.get(k_, 0.0) + info_[k_]
+                return res_, info_["bytes_sent_positions"] + info_["bytes_sent_densities"] + info_["bytes_sent_assembly"]
+        else:
+            engine = D.HipEngine(ctx, prm)
+            sharded = D.ShardedReconstruction(engine, dev)
+            sharded.load_local_particles(d_local)
+            exchange_kind = "torch.distributed/%s isend-irecv (splashsurf_amd/distributed.py)" % (dist.get_backend() if dist.is_initialized() else "none")
+            if native_error:
+                exchange_kind += "; native RCCL path failed: " + native_error
+
+            def do_step(profile):
+                r_ = sharded.step(profile=profile)
+                sharded.assemble(r_)
+                if profile:
+                    timings.update(sharded.timings)
+                return r_.local, sharded.exchange_bytes
+
         for _ in range(args.warmup):
-            sharded.step(profile=False)
-        sharded.timings = {}
+            do_step(False)
+        timings.clear()
+        if native is None:
+            sharded.timings = {}
         barrier()
         t0 = time.perf_counter()
         k3_ms = []
-        last = None
+        last_local = None
         xbytes = 0
         for _ in range(args.steps):
-            last = sharded.step(profile=True)
-            xbytes += sharded.exchange_bytes
-            s_ = last.stats
+            last_local, xb = do_step(True)
+            xbytes += xb
+            s_ = last_local.stats
             t_acc = s_.get("ms_levelset_accumulate", 0.0)
             k3_ms.append((t_acc, s_["ms_levelset"] - s_.get("ms_levelset_gather", 0.0) - t_acc))
         barrier()
@@ -247,29 +292,35 @@ def main():
             tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
             dt = float(tmax.item())
-        last_stats = last.stats
-        n_occ, n_subp = last.subdomain_stats()
+        last_stats = last_local.stats
+        n_occ, n_subp = last_local.subdomain_stats()
         k3_acc, k3_large = (float(v) for v in np.mean(np.asarray(k3_ms), axis=0))
         roof = splat_roofline(last_stats, n_occ, n_subp, nsc, k3_acc, k3_large)
+        bal = native.partition() if native is not None else sharded.last_balance
         # per-rank rows: K3 roofline fraction, owned / held particles, active blocks, mesh size, exchange bytes
         mine = torch.tensor([roof["frac"], roof["kernel_ms"], roof["algorithmic_bytes"], float(last_stats["n_active_blocks"]), float(last_stats["n_vertices"]),
                              float(last_stats["n_triangles"]), float(xbytes) / max(args.steps, 1), float(last_stats["ms_total"])], dtype=torch.float64, device=dev)
-        rows = sharded._all_gather_small(mine).cpu().numpy()
-        bal = last.balance
+        if world > 1:
+            rows_l = [torch.zeros_like(mine) for _ in range(world)]
+            dist.all_gather(rows_l, mine)
+            rows = torch.stack(rows_l).cpu().numpy()
+        else:
+            rows = mine.unsqueeze(0).cpu().numpy()
         per_rank = [{"rank": q, "k3_frac": round(float(rows[q, 0]), 5), "k3_ms": round(float(rows[q, 1]), 3), "k3_algorithmic_bytes": float(rows[q, 2]),
                      "owned_particles": bal["owned"][q], "held_particles": bal["held"][q], "active_blocks": int(rows[q, 3]),
                      "vertices": int(rows[q, 4]), "triangles": int(rows[q, 5]), "exchange_bytes_sent_per_step": int(rows[q, 6]),
                      "device_ms": round(float(rows[q, 7]), 3), "brick": bal["bricks"][q]} for q in range(world)]
         blocks = rows[:, 3]
+        xkeys = ("ms_position_exchange", "ms_density_exchange", "ms_assembly") if native is not None else ("3_position_exchange", "5_density_exchange")
         extra = {
             "per_rank": per_rank,
             "load_balance": {"imbalance_owned_particles": round(bal["imbalance_owned"], 4), "imbalance_held_particles": round(bal["imbalance_held"], 4),
                              "imbalance_active_blocks": round(float(blocks.max() / max(blocks.mean(), 1.0)), 4),
                              "note": "max / mean over ranks; bricks of the subdomain grid from recursive bisection of the owner histogram"},
             "exchange": {"kind": exchange_kind, "bytes_sent_per_step_all_ranks": int(rows[:, 6].sum()),
-                         "ms_per_step": round((last.timings.get("3_position_exchange", 0.0) + last.timings.get("5_density_exchange", 0.0)) / max(args.steps, 1), 3),
+                         "ms_per_step": round(sum(timings.get(k_, 0.0) for k_ in xkeys) / max(args.steps, 1), 3),
                          "rccl_world_size": dist.get_world_size() if dist.is_initialized() else 1},
-            "sharded_step_ms": {k: round(v / max(args.steps, 1), 3) for k, v in last.timings.items()},
+            "sharded_step_ms": {k: round(v / max(args.steps, 1), 3) for k, v in timings.items()},
         }
         # triangles are disjoint between ranks; shared face vertices are counted by every holder
         tot = torch.tensor([float(last_stats["n_vertices"]), float(last_stats["n_triangles"])], dtype=torch.float64, device=dev)

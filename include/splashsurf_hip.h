@@ -273,6 +273,63 @@ ss_status ss_grid_for_domain_f32(const ss_params_f32 *params, const float domain
 ss_status ss_grid_for_domain_f64(const ss_params_f64 *params, const double domain_min[3], const double domain_max[3],
                                  ss_grid_f64 *grid, ss_grid_f64 *subdomain_grid, double *ghost_margin);
 
+/* -- multi-GPU, native (csrc/ss_dist.hip): the whole sharded reconstruction of SURVEY.md section 8e behind the C ABI --
+ * One process (or host thread) per GPU calls ss_dist_reconstruct_* with ITS share of the particles (any split; global
+ * particle order = concatenation by rank); the library cuts the subdomain grid (dense_subdomains.rs:349-494, the unit the
+ * reference parallelises over, :1582-1598) into `world` bricks balanced by particle count, moves halo positions and halo
+ * densities between the ranks itself -- grouped ncclSend/ncclRecv and small ncclAllGather/ncclAllReduce on the context's
+ * stream, RCCL over xGMI -- and runs ss_shard_begin / ss_shard_finish on the brick.  ss_dist_assemble then numbers the mesh
+ * globally: a vertex on a brick face belongs to the lowest rank holding its edge (the rule of globalize_local_edge,
+ * dense_subdomains.rs:1260-1329), the other holders learn its global id from the owner (the join of `stitching`,
+ * dense_subdomains.rs:1693-1733), triangles carry global ids; the mesh is the concatenation over ranks of (owned vertices,
+ * triangles).  Densities, level set and mesh are bit-identical to a single-GPU call on the union of the inputs.
+ * A communicator is bound to one context; collective calls must be made by every rank.  A peer that never shows up makes the
+ * call fail with SS_ERR_DEVICE after SPLASH_COMM_TIMEOUT_S seconds (default 120) instead of hanging. */
+typedef struct ss_comm ss_comm;
+#define SS_COMM_ID_BYTES 128
+/* rank 0 creates an id (ncclGetUniqueId) and hands it to the other ranks out of band (MPI, a socket, a file, torch's store) */
+ss_status ss_comm_unique_id(uint8_t id[SS_COMM_ID_BYTES]);
+ss_status ss_comm_create_rccl(ss_context *ctx, const uint8_t id[SS_COMM_ID_BYTES], int rank, int world, ss_comm **out);
+/* adopt a communicator the host already owns (ncclComm_t passed as void*); ss_comm_destroy leaves it alive */
+ss_status ss_comm_adopt_rccl(ss_context *ctx, void *nccl_comm, int rank, int world, ss_comm **out);
+/* in-process group without RCCL: `world` communicators for `world` contexts on ONE device, each driven by its own host
+ * thread (how the tests run the whole algorithm on a single-GPU box; RCCL refuses two ranks on one device) */
+ss_status ss_comm_create_local_group(ss_context *const *ctxs, int world, ss_comm **out /* world entries */);
+void ss_comm_destroy(ss_comm *comm);
+
+typedef struct ss_dist_info {
+    int32_t rank, world;
+    int64_t brick_lo[3], brick_hi[3];    /* this rank's half-open box of subdomain indices */
+    uint64_t n_total;                    /* particles of the whole job */
+    uint64_t n_held;                     /* particles this rank holds (owned + ghosts) */
+    uint64_t n_owned;                    /* particles contained in this rank's brick */
+    uint64_t bytes_sent_positions, bytes_sent_densities, bytes_sent_assembly; /* payload this rank sent to OTHER ranks */
+    double ms_partition, ms_position_exchange, ms_density_exchange, ms_assembly; /* host wall time incl. device waits */
+    uint64_t n_vertices_owned, vertex_offset, n_vertices_total;  /* after ss_dist_assemble */
+    uint64_t n_triangles, triangle_offset, n_triangles_total;
+} ss_dist_info;
+
+/* xyz_local: this rank's n_local x 3 particles (host or HBM).  On return `inout` holds the brick's reconstruction: its mesh with
+ * local indices (ss_result_*), densities of the held particles (ss_result_particle_densities: owned + received halo values). */
+ss_status ss_dist_reconstruct_f32(ss_comm *comm, const float *xyz_local, uint64_t n_local, const ss_params_f32 *params, ss_result *inout);
+ss_status ss_dist_reconstruct_f64(ss_comm *comm, const double *xyz_local, uint64_t n_local, const ss_params_f64 *params, ss_result *inout);
+ss_status ss_dist_assemble(ss_comm *comm, ss_result *inout);
+ss_status ss_dist_get_info(const ss_comm *comm, ss_dist_info *out);
+/* host-only: the partition rule by itself -- recursive bisection of the subdomain grid (owner-particle count per subdomain,
+ * x-major like the subdomain grid) into `world` bricks, bricks[6*world] = (lo[3], hi[3]); axis_preference breaks ties
+ * between equally good cuts (smaller = preferred; NULL: none) */
+ss_status ss_dist_partition(const uint32_t *histogram, const int64_t n_subdomains[3], int world, const double axis_preference[3], int64_t *bricks);
+/* the partition of the last call, identical on every rank: bricks[6*world] = (lo[3], hi[3]) per rank, owned / held particle
+ * counts per rank (any pointer may be NULL) */
+ss_status ss_dist_get_partition(const ss_comm *comm, int64_t *bricks, uint64_t *owned, uint64_t *held);
+/* copies into caller buffers (host or HBM): global ids of the held particles (ascending, n_held); after ss_dist_assemble the
+ * owned vertices (n_vertices_owned x 3, the job's Real type), their global edge keys, and this rank's triangles with GLOBAL
+ * vertex ids (n_triangles x 3 uint64) */
+ss_status ss_dist_copy_global_ids(ss_comm *comm, uint64_t *dst);
+ss_status ss_dist_copy_vertices(ss_comm *comm, void *dst);
+ss_status ss_dist_copy_vertex_keys(ss_comm *comm, uint64_t *dst);
+ss_status ss_dist_copy_triangles(ss_comm *comm, uint64_t *dst);
+
 /* -- stand-alone entry points on the stages of the global strategy --
  * marching_cubes::triangulate_density_map on a dense array of function values (marching_cubes.rs:100-127;
  * pysplashsurf.marching_cubes): values[(i*ny + j)*nz + k] at grid point translation + (i,j,k)*cube_size, host or HBM

@@ -1,0 +1,1124 @@
+// ss_dist.hip -- the multi-GPU reconstruction behind the C ABI: one process (or host thread) per GPU,
+// every exchange inside the library -- RCCL point-to-point / collectives over xGMI, no host-language code on the data path.
+//
+// The reference is single-process; its unit of parallelism is the subdomain (dense_subdomains.rs:349-494 builds the
+// decomposition, :1582-1598 iterates it with rayon).  Here the subdomain grid of ONE global domain is cut into `world`
+// axis-aligned bricks of subdomains by recursive bisection of the owner histogram (balanced by particle count); rank r
+// reconstructs brick r through the two-phase shard entry points of ss_api.hip (ss_shard_begin_* / ss_shard_finish):
+//   1. global particle ids = concatenation of the ranks' inputs (defines the level set's summation order); global AABB;
+//   2. owner histogram all-reduced, bricks derived identically on every rank (rcb_split);
+//   3. sparse all-to-all #1 (grouped ncclSend/ncclRecv): (id, position) of every particle inside a brick grown by the ghost margin;
+//   4. phase 1: binning + densities of the particles contained in the brick;
+//   5. sparse all-to-all #2: (id, rho) from the owner to the ranks holding the particle as a ghost (copied, never recomputed);
+//   6. phase 2: level set + marching cubes of the brick;
+//   7. ss_dist_assemble: a vertex on a brick face belongs to the LOWEST rank whose brick holds its edge (the rule of
+//      globalize_local_edge, dense_subdomains.rs:1260-1329); counts are all-gathered into global vertex / triangle offsets,
+//      owners send (edge key, global id) of shared vertices to the other holders (sparse all-to-all #3; the receiving side is
+//      the hash join of `stitching`, dense_subdomains.rs:1693-1733, as a radix sort + binary search), triangles are rewritten
+//      to global ids.  The mesh is the concatenation over ranks of (owned vertices, triangles).
+// splashsurf_amd/distributed.py is the host-side mirror of the same algorithm over torch.distributed (gloo in the CPU tests).
+//
+// Transports: RCCL (loaded with dlopen at first use, so single-GPU users need no RCCL), and an in-process group of host
+// threads sharing one device (tests: the whole algorithm runs on a 1-GPU box; RCCL refuses two ranks on one device).
+#include <hip/hip_runtime.h>
+
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <condition_variable>
+#include <cstdlib>
+#include <cstring>
+#include <memory>
+#include <mutex>
+#include <thread>
+#include <string>
+#include <vector>
+
+#include <rocprim/rocprim.hpp>
+
+#include "../../include/splashsurf_hip.h"
+#include "ss_host.h"
+#include "ss_kernels.h"
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------------------------------
+// transports
+// ---------------------------------------------------------------------------------------------------------------------
+struct RcclApi {
+    void* handle = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;
+    ncclResult_t (*CommGetAsyncError)(ncclComm_t, ncclResult_t*) = nullptr;
+    ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+    std::string error;
+};
+
+RcclApi* rccl_api() {
+    static RcclApi api;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        // prefer a copy that is already in the process (PyTorch-ROCm bundles its own librccl.so): one RCCL per process
+        const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+        for (const char* n : names)
+            if ((api.handle = dlopen(n, RTLD_NOW | RTLD_NOLOAD | RTLD_GLOBAL))) break;
+        if (!api.handle)
+            for (const char* n : names)
+                if ((api.handle = dlopen(n, RTLD_NOW | RTLD_GLOBAL))) break;
+        if (!api.handle) {
+            api.error = std::string("RCCL not found: ") + (dlerror() ? dlerror() : "dlopen failed");
+            return;
+        }
+        bool ok = true;
+        auto sym = [&](const char* name) {
+            void* p = dlsym(api.handle, name);
+            if (!p) {
+                ok = false;
+                api.error = std::string("RCCL symbol missing: ") + name;
+            }
+            return p;
+        };
+        api.GetUniqueId = reinterpret_cast<decltype(api.GetUniqueId)>(sym("ncclGetUniqueId"));
+        api.CommInitRank = reinterpret_cast<decltype(api.CommInitRank)>(sym("ncclCommInitRank"));
+        api.CommDestroy = reinterpret_cast<decltype(api.CommDestroy)>(sym("ncclCommDestroy"));
+        api.CommAbort = reinterpret_cast<decltype(api.CommAbort)>(sym("ncclCommAbort"));
+        api.CommGetAsyncError = reinterpret_cast<decltype(api.CommGetAsyncError)>(sym("ncclCommGetAsyncError"));
+        api.AllGather = reinterpret_cast<decltype(api.AllGather)>(sym("ncclAllGather"));
+        api.AllReduce = reinterpret_cast<decltype(api.AllReduce)>(sym("ncclAllReduce"));
+        api.Send = reinterpret_cast<decltype(api.Send)>(sym("ncclSend"));
+        api.Recv = reinterpret_cast<decltype(api.Recv)>(sym("ncclRecv"));
+        api.GroupStart = reinterpret_cast<decltype(api.GroupStart)>(sym("ncclGroupStart"));
+        api.GroupEnd = reinterpret_cast<decltype(api.GroupEnd)>(sym("ncclGroupEnd"));
+        api.GetErrorString = reinterpret_cast<decltype(api.GetErrorString)>(sym("ncclGetErrorString"));
+        if (!ok) api.handle = nullptr;
+    });
+    return &api;
+}
+
+// host threads sharing one device: barrier + tables of what every rank published
+struct LocalGroup {
+    int world = 0;
+    std::mutex m;
+    std::condition_variable cv;
+    int arrived = 0;
+    uint64_t generation = 0;
+    bool failed = false;
+    std::vector<std::vector<uint8_t>> host;          // allgather_host slots
+    std::vector<const uint8_t*> send_ptr;            // exchange: device send buffers
+    std::vector<std::vector<uint64_t>> send_off;     // exchange: byte offsets per destination (world + 1)
+    std::vector<const uint32_t*> red_ptr;            // allreduce: device buffers
+    bool barrier(double timeout_s) {
+        std::unique_lock<std::mutex> lk(m);
+        if (failed) return false;
+        const uint64_t gen = generation;
+        if (++arrived == world) {
+            arrived = 0;
+            ++generation;
+            cv.notify_all();
+            return true;
+        }
+        const bool ok = cv.wait_for(lk, std::chrono::duration<double>(timeout_s), [&] { return generation != gen || failed; });
+        if (!ok) {
+            failed = true;  // a rank never arrived: release everybody with an error instead of hanging
+            cv.notify_all();
+        }
+        return ok && !failed;
+    }
+};
+
+__global__ __launch_bounds__(256) void k_sum_peers_u32(const uint32_t* const* __restrict__ peers, int world, size_t n, uint32_t* __restrict__ out) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t s = 0;
+    for (int q = 0; q < world; ++q) s += peers[q][i];
+    out[i] = s;
+}
+
+}  // namespace
+
+struct ss_comm {
+    ss_context* ctx = nullptr;
+    int rank = 0, world = 1;
+    int kind = 0;  // 0 in-process group, 1 RCCL
+    ncclComm_t nccl = nullptr;
+    bool own_nccl = false;
+    std::shared_ptr<LocalGroup> group;
+    double timeout_s = 120.0;
+    // scratch
+    DevBuf small_dev, small_dev2, red_tmp, peers_dev;
+    HostBuf small_host;
+    // state of the last ss_dist_reconstruct / ss_dist_assemble
+    DevBuf xyz_in, hist, flags, offs, sendbuf, recvbuf, gids, L, owned, sort_tmp, keys_a, keys_b, vals_a, vals_b, owner, holder, gid_local, mine_off, tri64, vown, kown, err;
+    bool is_f64 = false;
+    std::vector<int64_t> bricks;  // world x 6 (lo[3], hi[3])
+    int ns[3] = {0, 0, 0};
+    int n_cubes = 0;
+    std::vector<uint64_t> per_rank_owned, per_rank_held;
+    ss_dist_info info;
+    bool assembled = false;
+};
+
+namespace {
+
+ss_status comm_fail(ss_comm* c, const std::string& msg) { return fail(c->ctx, SS_ERR_DEVICE, msg); }
+
+// wait for the context's stream, but never forever: a peer that died leaves RCCL kernels spinning
+ss_status wait_stream(ss_comm* c, const char* what) {
+    ss_context* ctx = c->ctx;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (;;) {
+        hipError_t e = hipStreamQuery(ctx->stream);
+        if (e == hipSuccess) break;
+        if (e != hipErrorNotReady) {
+            (void)hipGetLastError();
+            return comm_fail(c, std::string("HIP error while waiting for ") + what + ": " + hipGetErrorString(e));
+        }
+        if (c->kind == 1 && c->nccl) {
+            ncclResult_t ar = ncclSuccess;
+            if (rccl_api()->CommGetAsyncError(c->nccl, &ar) == ncclSuccess && ar != ncclSuccess && ar != ncclInProgress)
+                return comm_fail(c, std::string("RCCL asynchronous error during ") + what + ": " + rccl_api()->GetErrorString(ar));
+        }
+        const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        if (dt > c->timeout_s) {
+            if (c->kind == 1 && c->nccl) (void)rccl_api()->CommAbort(c->nccl), c->nccl = nullptr;
+            return comm_fail(c, std::string("timeout (") + std::to_string((int)c->timeout_s) + " s, SPLASH_COMM_TIMEOUT_S) waiting for " + what +
+                                    ": a peer rank did not take part in the exchange");
+        }
+        if (dt > 0.002) std::this_thread::sleep_for(std::chrono::microseconds(50));
+    }
+    return SS_OK;
+}
+
+#define SS_NCCL(c, call)                                                                                             \
+    do {                                                                                                             \
+        ncclResult_t _r = (call);                                                                                    \
+        if (_r != ncclSuccess && _r != ncclInProgress)                                                               \
+            return comm_fail(c, std::string("RCCL error: ") + rccl_api()->GetErrorString(_r) + " at " #call);        \
+    } while (0)
+
+// every rank contributes `bytes` of host data; out receives world * bytes (rank-major)
+ss_status comm_allgather_host(ss_comm* c, const void* in, size_t bytes, void* out) {
+    if (c->world == 1 && c->kind == 0) {  // (a one-rank RCCL communicator still goes through RCCL: the plumbing is exercised on a 1-GPU box)
+        memcpy(out, in, bytes);
+        return SS_OK;
+    }
+    ss_context* ctx = c->ctx;
+    if (c->kind == 0) {
+        LocalGroup& g = *c->group;
+        {
+            std::lock_guard<std::mutex> lk(g.m);
+            g.host[c->rank].assign((const uint8_t*)in, (const uint8_t*)in + bytes);
+        }
+        if (!g.barrier(c->timeout_s)) return comm_fail(c, "in-process group: a rank did not reach the all-gather");
+        for (int q = 0; q < c->world; ++q) {
+            if (g.host[q].size() != bytes) return comm_fail(c, "in-process group: all-gather size mismatch");
+            memcpy((uint8_t*)out + (size_t)q * bytes, g.host[q].data(), bytes);
+        }
+        if (!g.barrier(c->timeout_s)) return comm_fail(c, "in-process group: a rank did not leave the all-gather");
+        return SS_OK;
+    }
+    SS_HIP(ctx, c->small_dev.reserve(bytes + 64));
+    SS_HIP(ctx, c->small_dev2.reserve(bytes * (size_t)c->world + 64));
+    SS_HIP(ctx, hipMemcpyAsync(c->small_dev.p, in, bytes, hipMemcpyHostToDevice, ctx->stream));
+    SS_NCCL(c, rccl_api()->AllGather(c->small_dev.p, c->small_dev2.p, bytes, ncclInt8, c->nccl, ctx->stream));
+    ss_status s = wait_stream(c, "ncclAllGather");
+    if (s != SS_OK) return s;
+    SS_HIP(ctx, hipMemcpy(out, c->small_dev2.p, bytes * (size_t)c->world, hipMemcpyDeviceToHost));
+    return SS_OK;
+}
+
+// in-place sum of a device array of n uint32 over all ranks
+ss_status comm_allreduce_sum_u32(ss_comm* c, uint32_t* dev, size_t n) {
+    if ((c->world == 1 && c->kind == 0) || n == 0) return SS_OK;
+    ss_context* ctx = c->ctx;
+    if (c->kind == 1) {
+        SS_NCCL(c, rccl_api()->AllReduce(dev, dev, n, ncclUint32, ncclSum, c->nccl, ctx->stream));
+        return wait_stream(c, "ncclAllReduce");
+    }
+    LocalGroup& g = *c->group;
+    SS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    {
+        std::lock_guard<std::mutex> lk(g.m);
+        g.red_ptr[c->rank] = dev;
+    }
+    if (!g.barrier(c->timeout_s)) return comm_fail(c, "in-process group: a rank did not reach the all-reduce");
+    SS_HIP(ctx, c->red_tmp.reserve(n * 4 + 64));
+    SS_HIP(ctx, c->peers_dev.reserve((size_t)c->world * sizeof(void*) + 64));
+    SS_HIP(ctx, hipMemcpyAsync(c->peers_dev.p, g.red_ptr.data(), (size_t)c->world * sizeof(void*), hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(k_sum_peers_u32, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, c->peers_dev.as<const uint32_t*>(), c->world, n,
+                       c->red_tmp.as<uint32_t>());
+    SS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (!g.barrier(c->timeout_s)) return comm_fail(c, "in-process group: a rank did not finish the all-reduce");  // everybody has read everybody
+    SS_HIP(ctx, hipMemcpyAsync(dev, c->red_tmp.p, n * 4, hipMemcpyDeviceToDevice, ctx->stream));
+    SS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return SS_OK;
+}
+
+// Sparse all-to-all of device byte ranges: send[send_off[q] .. send_off[q+1]) goes to rank q and lands at
+// recv[recv_off[r] ..) of the receiver, r = the sender.  RCCL: ONE group of ncclSend / ncclRecv (pairs with nothing to say are
+// skipped on both sides, which both sides know from the all-gathered count matrix).
+ss_status comm_exchange(ss_comm* c, const uint8_t* send, const uint64_t* send_off, uint8_t* recv, const uint64_t* recv_off) {
+    ss_context* ctx = c->ctx;
+    const int me = c->rank;
+    const uint64_t self_bytes = send_off[me + 1] - send_off[me];
+    if (self_bytes != recv_off[me + 1] - recv_off[me]) return comm_fail(c, "exchange: inconsistent self segment");
+    if (self_bytes) SS_HIP(ctx, hipMemcpyAsync(recv + recv_off[me], send + send_off[me], self_bytes, hipMemcpyDeviceToDevice, ctx->stream));
+    if (c->world == 1) return SS_OK;
+    if (c->kind == 1) {
+        SS_NCCL(c, rccl_api()->GroupStart());
+        for (int q = 0; q < c->world; ++q) {
+            if (q == me) continue;
+            const uint64_t sb = send_off[q + 1] - send_off[q], rb = recv_off[q + 1] - recv_off[q];
+            if (sb) SS_NCCL(c, rccl_api()->Send(send + send_off[q], sb, ncclInt8, q, c->nccl, ctx->stream));
+            if (rb) SS_NCCL(c, rccl_api()->Recv(recv + recv_off[q], rb, ncclInt8, q, c->nccl, ctx->stream));
+        }
+        SS_NCCL(c, rccl_api()->GroupEnd());
+        return wait_stream(c, "grouped ncclSend/ncclRecv");
+    }
+    LocalGroup& g = *c->group;
+    SS_HIP(ctx, hipStreamSynchronize(ctx->stream));  // the send buffer is complete
+    {
+        std::lock_guard<std::mutex> lk(g.m);
+        g.send_ptr[me] = send;
+        g.send_off[me].assign(send_off, send_off + c->world + 1);
+    }
+    if (!g.barrier(c->timeout_s)) return comm_fail(c, "in-process group: a rank did not reach the exchange");
+    for (int q = 0; q < c->world; ++q) {
+        if (q == me) continue;
+        const uint64_t rb = recv_off[q + 1] - recv_off[q];
+        const uint64_t sb = g.send_off[q][me + 1] - g.send_off[q][me];
+        if (rb != sb) return comm_fail(c, "in-process group: exchange size mismatch");
+        if (rb) SS_HIP(ctx, hipMemcpyAsync(recv + recv_off[q], g.send_ptr[q] + g.send_off[q][me], rb, hipMemcpyDeviceToDevice, ctx->stream));
+    }
+    SS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (!g.barrier(c->timeout_s)) return comm_fail(c, "in-process group: a rank did not finish the exchange");
+    return SS_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// partition: recursive coordinate bisection of the subdomain grid (same rule as distributed.py: bricks_from_histogram)
+// ---------------------------------------------------------------------------------------------------------------------
+void rcb_split(const std::vector<double>& hist, const int ns[3], const int lo[3], const int hi[3], int r0, int r1, const double pref[3], double tol,
+               std::vector<int64_t>& out) {
+    const int k = r1 - r0;
+    auto put = [&](int r, const int a[3], const int b[3]) {
+        for (int d = 0; d < 3; ++d) {
+            out[(size_t)r * 6 + d] = a[d];
+            out[(size_t)r * 6 + 3 + d] = b[d];
+        }
+    };
+    if (k == 1) {
+        put(r0, lo, hi);
+        return;
+    }
+    const int k1 = k / 2;
+    const double frac = (double)k1 / (double)k;
+    const int ext[3] = {hi[0] - lo[0], hi[1] - lo[1], hi[2] - lo[2]};
+    std::vector<double> marg[3];
+    double total = 0.0;
+    for (int d = 0; d < 3; ++d) marg[d].assign((size_t)std::max(ext[d], 0), 0.0);
+    for (int x = lo[0]; x < hi[0]; ++x)
+        for (int y = lo[1]; y < hi[1]; ++y)
+            for (int z = lo[2]; z < hi[2]; ++z) {
+                const double v = hist[((size_t)x * ns[1] + y) * ns[2] + z];
+                marg[0][x - lo[0]] += v;
+                marg[1][y - lo[1]] += v;
+                marg[2][z - lo[2]] += v;
+                total += v;
+            }
+    struct Cand { double err; long long area; int axis, cut; };
+    std::vector<Cand> cands;
+    for (int a = 0; a < 3; ++a) {
+        if (ext[a] < 2) continue;
+        int cut;
+        double err = 0.0;
+        if (total > 0.0) {
+            double cum = 0.0, best = 1e300;
+            cut = 1;
+            for (int c = 1; c < ext[a]; ++c) {
+                cum += marg[a][c - 1];
+                const double e = std::fabs(cum - total * frac);
+                if (e < best) {
+                    best = e;
+                    cut = c;
+                }
+            }
+            err = best / total;
+        } else {
+            cut = std::min(std::max((int)std::floor(ext[a] * frac + 0.5), 1), ext[a] - 1);
+        }
+        long long area = 1;
+        for (int d = 0; d < 3; ++d)
+            if (d != a) area *= ext[d];
+        cands.push_back({err, area, a, cut});
+    }
+    if (cands.empty()) {  // a single subdomain for several ranks: the first gets it, the others get empty bricks
+        put(r0, lo, hi);
+        int elo[3] = {hi[0], lo[1], lo[2]};
+        for (int r = r0 + 1; r < r1; ++r) put(r, elo, hi);
+        return;
+    }
+    double best = 1e300;
+    for (const Cand& c : cands) best = std::min(best, c.err);
+    const Cand* pick = nullptr;
+    for (const Cand& c : cands) {
+        if (c.err > best + tol) continue;
+        if (!pick || c.area < pick->area || (c.area == pick->area && (pref[c.axis] < pref[pick->axis] || (pref[c.axis] == pref[pick->axis] && (c.err < pick->err || (c.err == pick->err && c.axis < pick->axis))))))
+            pick = &c;
+    }
+    int mid_hi[3] = {hi[0], hi[1], hi[2]}, mid_lo[3] = {lo[0], lo[1], lo[2]};
+    mid_hi[pick->axis] = lo[pick->axis] + pick->cut;
+    mid_lo[pick->axis] = lo[pick->axis] + pick->cut;
+    rcb_split(hist, ns, lo, mid_hi, r0, r0 + k1, pref, tol, out);
+    rcb_split(hist, ns, mid_lo, hi, r0 + k1, r1, pref, tol, out);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// kernels
+// ---------------------------------------------------------------------------------------------------------------------
+struct DistBox {  // coordinate box of a brick grown by the ghost margin (conservative; the engine applies the exact rule)
+    double lo[3], hi[3];
+    int empty;
+};
+
+template <class R>
+__global__ __launch_bounds__(256) void k_owner_hist(const R* __restrict__ xyz, uint64_t n, R g0, R g1, R g2, R sub_size, int ns0, int ns1, int ns2,
+                                                    uint32_t* __restrict__ hist) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const R g[3] = {g0, g1, g2};
+    const int ns[3] = {ns0, ns1, ns2};
+    int s[3];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        int v = (int)ss_floor((xyz[3 * i + d] - g[d]) / sub_size);
+        s[d] = max(0, min(ns[d] - 1, v));
+    }
+    atomicAdd(&hist[((size_t)s[0] * ns1 + s[1]) * ns2 + s[2]], 1u);
+}
+
+// flags[i] = particle i lies in the box (and is owned, if `owned` is given)
+template <class R>
+__global__ __launch_bounds__(256) void k_box_flags(const R* __restrict__ xyz, uint64_t n, DistBox box, const uint32_t* __restrict__ owned, uint32_t* __restrict__ flags) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i > n) return;
+    uint32_t f = 0;
+    if (i < n && !box.empty) {
+        const double x = (double)xyz[3 * i], y = (double)xyz[3 * i + 1], z = (double)xyz[3 * i + 2];
+        f = (x >= box.lo[0] && x <= box.hi[0] && y >= box.lo[1] && y <= box.hi[1] && z >= box.lo[2] && z <= box.hi[2]) ? 1u : 0u;
+        if (owned) f &= owned[i];
+    }
+    flags[i] = f;  // entry n: 0, so that the exclusive scan ends with the count
+}
+
+// rows[off[i]] = (id0 + i or ids[i], payload[i]) for flagged i; payload_words 32-bit words per element
+__global__ __launch_bounds__(256) void k_pack_rows(uint64_t n, const uint32_t* __restrict__ flags, const uint32_t* __restrict__ offs, uint64_t id0,
+                                                   const unsigned long long* __restrict__ ids, const uint32_t* __restrict__ payload, int payload_words,
+                                                   uint32_t* __restrict__ rows) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n || !flags[i]) return;
+    const unsigned long long id = ids ? ids[i] : (unsigned long long)(id0 + i);
+    uint32_t* dst = rows + (size_t)offs[i] * (size_t)(2 + payload_words);
+    dst[0] = (uint32_t)id;
+    dst[1] = (uint32_t)(id >> 32);
+    for (int w = 0; w < payload_words; ++w) dst[2 + w] = payload[(size_t)i * payload_words + w];
+}
+
+__global__ __launch_bounds__(256) void k_unpack_rows(uint64_t n, const uint32_t* __restrict__ rows, int payload_words, unsigned long long* __restrict__ ids,
+                                                     uint32_t* __restrict__ payload) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t* src = rows + (size_t)i * (size_t)(2 + payload_words);
+    ids[i] = (unsigned long long)src[0] | ((unsigned long long)src[1] << 32);
+    for (int w = 0; w < payload_words; ++w) payload[(size_t)i * payload_words + w] = src[2 + w];
+}
+
+template <class R>
+__global__ __launch_bounds__(256) void k_owned_flags(const R* __restrict__ rho, uint64_t n, uint32_t* __restrict__ owned) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) owned[i] = rho[i] > R(0.0) ? 1u : 0u;
+}
+
+__device__ inline long long dist_lower_bound(const unsigned long long* __restrict__ a, long long n, unsigned long long key) {
+    long long lo = 0, hi = n;
+    while (lo < hi) {
+        const long long mid = (lo + hi) >> 1;
+        if (a[mid] < key)
+            lo = mid + 1;
+        else
+            hi = mid;
+    }
+    return lo;
+}
+
+// received (id, rho) rows -> rho[position of id among the held ids]
+__global__ __launch_bounds__(256) void k_scatter_density(uint64_t n_rows, const uint32_t* __restrict__ rows, int payload_words, const unsigned long long* __restrict__ gids,
+                                                         uint64_t n_held, uint32_t* __restrict__ rho_words, uint32_t* __restrict__ err) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_rows) return;
+    const uint32_t* src = rows + (size_t)i * (size_t)(2 + payload_words);
+    const unsigned long long id = (unsigned long long)src[0] | ((unsigned long long)src[1] << 32);
+    const long long pos = dist_lower_bound(gids, (long long)n_held, id);
+    if (pos >= (long long)n_held || gids[pos] != id) {
+        atomicOr(err, 1u);  // a density arrived for a particle this rank does not hold
+        return;
+    }
+    for (int w = 0; w < payload_words; ++w) rho_words[(size_t)pos * payload_words + w] = src[2 + w];
+}
+
+struct DistBricks {  // closed boxes of grid points of every rank's brick; world <= 64
+    int lo[64][3], hi[64][3];
+    int empty[64];
+    int world;
+};
+
+// owner[v] = lowest rank whose brick holds the edge of vertex v; holder[v] = bit mask of all such ranks
+__global__ __launch_bounds__(256) void k_vertex_owner(uint64_t nv, const unsigned long long* __restrict__ keys, DistBricks B, unsigned long long np1, unsigned long long np2,
+                                                      uint32_t* __restrict__ owner, unsigned long long* __restrict__ holder) {
+    const uint64_t v = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= nv) return;
+    const unsigned long long k = keys[v];  // ((gi*NPy + gj)*NPz + gk)*3 + axis
+    const int axis = (int)(k % 3ull);
+    const unsigned long long p = k / 3ull;
+    const int g[3] = {(int)(p / (np2 * np1)), (int)((p / np2) % np1), (int)(p % np2)};
+    unsigned long long mask = 0;
+    uint32_t own = 0xFFFFFFFFu;
+    for (int q = B.world - 1; q >= 0; --q) {
+        if (B.empty[q]) continue;
+        bool in = true;
+#pragma unroll
+        for (int d = 0; d < 3; ++d) in = in && g[d] >= B.lo[q][d] && g[d] + (axis == d ? 1 : 0) <= B.hi[q][d];
+        if (in) {
+            mask |= 1ull << q;
+            own = (uint32_t)q;
+        }
+    }
+    owner[v] = own;
+    holder[v] = mask;
+}
+
+// flags[v] = owner[v] == me (&& rank q also holds it, q >= 0); entry nv: 0
+__global__ __launch_bounds__(256) void k_vertex_flags(uint64_t nv, const uint32_t* __restrict__ owner, const unsigned long long* __restrict__ holder, uint32_t me, int q,
+                                                      uint32_t* __restrict__ flags) {
+    const uint64_t v = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (v > nv) return;
+    uint32_t f = 0;
+    if (v < nv) f = (owner[v] == me && (q < 0 || ((holder[v] >> q) & 1ull))) ? 1u : 0u;
+    flags[v] = f;
+}
+
+__global__ __launch_bounds__(256) void k_owned_gids(uint64_t nv, const uint32_t* __restrict__ mine, const uint32_t* __restrict__ mine_off, unsigned long long voff,
+                                                    unsigned long long* __restrict__ gid_local) {
+    const uint64_t v = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (v < nv) gid_local[v] = mine[v] ? voff + mine_off[v] : ~0ull;
+}
+
+// vertices owned elsewhere: global id from the sorted (key, id) pairs the owners sent
+__global__ __launch_bounds__(256) void k_resolve_shared(uint64_t nv, const unsigned long long* __restrict__ keys, const uint32_t* __restrict__ mine,
+                                                        const unsigned long long* __restrict__ rkeys, const unsigned long long* __restrict__ rids, uint64_t n_recv,
+                                                        unsigned long long* __restrict__ gid_local, uint32_t* __restrict__ err) {
+    const uint64_t v = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= nv || mine[v]) return;
+    const long long pos = dist_lower_bound(rkeys, (long long)n_recv, keys[v]);
+    if (pos >= (long long)n_recv || rkeys[pos] != keys[v]) {
+        atomicOr(err, 2u);  // the owner rank did not emit this face vertex: level sets differ between ranks
+        return;
+    }
+    gid_local[v] = rids[pos];
+}
+
+__global__ __launch_bounds__(256) void k_global_triangles(uint64_t n3, const uint32_t* __restrict__ tri32, const unsigned long long* __restrict__ gid_local,
+                                                          unsigned long long* __restrict__ tri64) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n3) tri64[i] = gid_local[tri32[i]];
+}
+
+template <class R>
+__global__ __launch_bounds__(256) void k_compact_owned(uint64_t nv, const uint32_t* __restrict__ mine, const uint32_t* __restrict__ mine_off, const R* __restrict__ vertices,
+                                                       const unsigned long long* __restrict__ keys, R* __restrict__ vown, unsigned long long* __restrict__ kown) {
+    const uint64_t v = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= nv || !mine[v]) return;
+    const size_t o = mine_off[v];
+    vown[3 * o] = vertices[3 * v];
+    vown[3 * o + 1] = vertices[3 * v + 1];
+    vown[3 * o + 2] = vertices[3 * v + 2];
+    kown[o] = keys[v];
+}
+
+inline dim3 grid_for(uint64_t n) { return dim3((unsigned)((n + 255) / 256)); }
+
+ss_status scan_u32(ss_comm* c, const uint32_t* in, uint32_t* out, size_t n) {
+    ss_context* ctx = c->ctx;
+    size_t bytes = 0;
+    SS_HIP(ctx, rocprim::exclusive_scan(nullptr, bytes, in, out, 0u, n, rocprim::plus<uint32_t>(), ctx->stream));
+    SS_HIP(ctx, c->sort_tmp.reserve(bytes + 64));
+    SS_HIP(ctx, rocprim::exclusive_scan(c->sort_tmp.p, bytes, in, out, 0u, n, rocprim::plus<uint32_t>(), ctx->stream));
+    return SS_OK;
+}
+
+template <class R> struct DistTypes;
+template <> struct DistTypes<float> {
+    using params = ss_params_f32; using grid = ss_grid_f32; using shard = ss_shard_f32;
+    static ss_status grid_for_domain(const params* p, const float* a, const float* b, grid* g, grid* sg, float* m) { return ss_grid_for_domain_f32(p, a, b, g, sg, m); }
+    static ss_status begin(ss_context* c, const float* x, uint64_t n, const params* p, const shard* s, ss_result* r) { return ss_shard_begin_f32(c, x, n, p, s, r); }
+};
+template <> struct DistTypes<double> {
+    using params = ss_params_f64; using grid = ss_grid_f64; using shard = ss_shard_f64;
+    static ss_status grid_for_domain(const params* p, const double* a, const double* b, grid* g, grid* sg, double* m) { return ss_grid_for_domain_f64(p, a, b, g, sg, m); }
+    static ss_status begin(ss_context* c, const double* x, uint64_t n, const params* p, const shard* s, ss_result* r) { return ss_shard_begin_f64(c, x, n, p, s, r); }
+};
+
+double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+// Packs, for every destination rank, the flagged elements into consecutive rows of c->sendbuf, exchanges them and leaves the
+// received rows (ordered by source rank) in c->recvbuf.  flags_for(q) fills c->flags (n + 1 entries) for destination q;
+// destinations for which it returns false send nothing.
+template <class FlagsFor>
+ss_status pack_and_exchange(ss_comm* c, uint64_t n, uint64_t id0, const unsigned long long* ids, const uint32_t* payload, int payload_words, FlagsFor flags_for,
+                            uint64_t* n_recv_rows, uint64_t* bytes_sent) {
+    ss_context* ctx = c->ctx;
+    hipStream_t st = ctx->stream;
+    const int world = c->world, me = c->rank;
+    const size_t row_bytes = (size_t)(2 + payload_words) * 4;
+    SS_HIP(ctx, c->flags.reserve((n + 1) * 4 + 64));
+    SS_HIP(ctx, c->offs.reserve((size_t)world * (n + 1) * 4 + 64));
+    SS_HIP(ctx, c->keys_a.reserve((size_t)world * (n + 1) * 4 + 64));  // the flags of every destination, consumed by the pack kernels once the counts are known
+    std::vector<uint32_t> cnt((size_t)world, 0u);
+    std::vector<char> active((size_t)world, 0);
+    for (int q = 0; q < world; ++q) {
+        if (!flags_for(q)) continue;
+        active[q] = 1;
+        uint32_t* offs_q = c->offs.as<uint32_t>() + (size_t)q * (n + 1);
+        ss_status s = scan_u32(c, c->flags.as<uint32_t>(), offs_q, n + 1);
+        if (s != SS_OK) return s;
+        SS_HIP(ctx, hipMemcpyAsync(&cnt[q], offs_q + n, 4, hipMemcpyDeviceToHost, st));
+        SS_HIP(ctx, hipMemcpyAsync(c->keys_a.as<uint32_t>() + (size_t)q * (n + 1), c->flags.p, (n + 1) * 4, hipMemcpyDeviceToDevice, st));
+    }
+    SS_HIP(ctx, hipStreamSynchronize(st));
+    std::vector<uint64_t> send_off((size_t)world + 1, 0), send_rows((size_t)world, 0);
+    for (int q = 0; q < world; ++q) {
+        send_rows[q] = cnt[q];
+        send_off[q + 1] = send_off[q] + (uint64_t)cnt[q] * row_bytes;
+    }
+    SS_HIP(ctx, c->sendbuf.reserve(send_off[world] + 64));
+    for (int q = 0; q < world; ++q) {
+        if (!active[q] || !cnt[q]) continue;
+        hipLaunchKernelGGL(k_pack_rows, grid_for(n), dim3(256), 0, st, n, c->keys_a.as<uint32_t>() + (size_t)q * (n + 1), c->offs.as<uint32_t>() + (size_t)q * (n + 1), id0, ids,
+                           payload, payload_words, reinterpret_cast<uint32_t*>(c->sendbuf.as<uint8_t>() + send_off[q]));
+    }
+    // matrix[r][q] = rows rank r sends to rank q
+    std::vector<uint64_t> matrix((size_t)world * world, 0);
+    ss_status s = comm_allgather_host(c, send_rows.data(), (size_t)world * 8, matrix.data());
+    if (s != SS_OK) return s;
+    std::vector<uint64_t> recv_off((size_t)world + 1, 0);
+    for (int r = 0; r < world; ++r) recv_off[r + 1] = recv_off[r] + matrix[(size_t)r * world + me] * row_bytes;
+    SS_HIP(ctx, c->recvbuf.reserve(recv_off[world] + 64));
+    s = comm_exchange(c, c->sendbuf.as<uint8_t>(), send_off.data(), c->recvbuf.as<uint8_t>(), recv_off.data());
+    if (s != SS_OK) return s;
+    *n_recv_rows = recv_off[world] / row_bytes;
+    if (bytes_sent) *bytes_sent += send_off[world] - (send_off[me + 1] - send_off[me]);
+    return SS_OK;
+}
+
+template <class R>
+ss_status dist_reconstruct(ss_comm* c, const R* xyz_in, uint64_t n_local, const typename DistTypes<R>::params* prm, ss_result* res) {
+    using T = DistTypes<R>;
+    if (!c || !prm || !res) return SS_ERR_INVALID_ARGUMENT;
+    ss_context* ctx = c->ctx;
+    if (res->ctx != ctx) return fail(ctx, SS_ERR_INVALID_ARGUMENT, "result belongs to a different context than the communicator");
+    if (c->world > 64) return fail(ctx, SS_ERR_UNSUPPORTED, "more than 64 ranks are not supported by this build");
+    if (prm->has_particle_aabb) return fail(ctx, SS_ERR_UNSUPPORTED, "particle_aabb cannot be combined with the multi-GPU reconstruction");
+    if (n_local >= (1ull << 31)) return fail(ctx, SS_ERR_UNSUPPORTED, "more than 2^31-1 particles per rank");
+    ctx->err.clear();
+    SS_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    const int world = c->world, me = c->rank;
+    c->assembled = false;
+    c->is_f64 = sizeof(R) == 8;
+    memset(&c->info, 0, sizeof(c->info));
+    c->info.rank = me;
+    c->info.world = world;
+    double t0 = now_ms();
+
+    // ---- 1. global ids, global AABB ----
+    const R* d_xyz = xyz_in;
+    if (n_local && !is_device_pointer(xyz_in)) {
+        SS_HIP(ctx, c->xyz_in.reserve(n_local * 3 * sizeof(R) + 64));
+        SS_HIP(ctx, hipMemcpyAsync(c->xyz_in.p, xyz_in, n_local * 3 * sizeof(R), hipMemcpyHostToDevice, st));
+        d_xyz = c->xyz_in.as<R>();
+    }
+    struct Head { uint64_t n; double lo[3], hi[3]; } mine_head, zero_head;
+    memset(&zero_head, 0, sizeof(zero_head));
+    mine_head = zero_head;
+    mine_head.n = n_local;
+    if (n_local) {
+        SS_HIP(ctx, ctx->aabb_partial.reserve(1024 * 6 * sizeof(R)));
+        SS_HIP(ctx, ctx->aabb_out.reserve(6 * sizeof(R)));
+        ss_launch_aabb<R>(d_xyz, (uint32_t)n_local, ctx->aabb_partial.as<R>(), ctx->aabb_out.as<R>(), st);
+        R h6[6];
+        SS_HIP(ctx, hipMemcpyAsync(h6, ctx->aabb_out.p, 6 * sizeof(R), hipMemcpyDeviceToHost, st));
+        SS_HIP(ctx, hipStreamSynchronize(st));
+        for (int d = 0; d < 3; ++d) {
+            mine_head.lo[d] = (double)h6[d];
+            mine_head.hi[d] = (double)h6[3 + d];
+        }
+    }
+    std::vector<Head> heads((size_t)world);
+    ss_status s = comm_allgather_host(c, &mine_head, sizeof(Head), heads.data());
+    if (s != SS_OK) return s;
+    uint64_t id0 = 0, n_total = 0;
+    R dmin[3] = {0, 0, 0}, dmax[3] = {0, 0, 0};
+    bool any = false;
+    double pref[3] = {0.0, 0.0, 0.0};
+    for (int q = 0; q < world; ++q) {
+        if (q < me) id0 += heads[q].n;
+        n_total += heads[q].n;
+        if (!heads[q].n) continue;
+        for (int d = 0; d < 3; ++d) {
+            const R a = (R)heads[q].lo[d], b = (R)heads[q].hi[d];  // exact: they were R values
+            dmin[d] = any ? ss_min(dmin[d], a) : a;
+            dmax[d] = any ? ss_max(dmax[d], b) : b;
+        }
+        any = true;
+    }
+    for (int q = 0; q < world && any; ++q) {  // how far every rank's input extends along each axis: the tie-break of the bisection
+        if (!heads[q].n) continue;
+        for (int d = 0; d < 3; ++d) {
+            const double span = std::max((double)dmax[d] - (double)dmin[d], 1e-300);
+            pref[d] = std::max(pref[d], std::round(1000.0 * (heads[q].hi[d] - heads[q].lo[d]) / span) / 1000.0);
+        }
+    }
+    c->info.n_total = n_total;
+    typename T::grid grid, subgrid;
+    R margin = 0;
+    s = T::grid_for_domain(prm, dmin, dmax, &grid, &subgrid, &margin);
+    if (s != SS_OK) return fail(ctx, s, "grid construction failed for the global domain");
+    const int ns[3] = {(int)subgrid.n_cells[0], (int)subgrid.n_cells[1], (int)subgrid.n_cells[2]};
+    const double nsub_d = (double)ns[0] * ns[1] * ns[2];
+    if (nsub_d > 2.0e9) return fail(ctx, SS_ERR_UNSUPPORTED, "subdomain grid too large for the partition histogram");
+    const size_t nsub = (size_t)nsub_d;
+    for (int d = 0; d < 3; ++d) c->ns[d] = ns[d];
+    c->n_cubes = (int)prm->subdomain_num_cubes_per_dim;
+
+    // ---- 2. bricks from the all-reduced owner histogram ----
+    SS_HIP(ctx, c->hist.reserve(nsub * 4 + 64));
+    SS_HIP(ctx, hipMemsetAsync(c->hist.p, 0, nsub * 4, st));
+    if (n_local)
+        hipLaunchKernelGGL(k_owner_hist<R>, grid_for(n_local), dim3(256), 0, st, d_xyz, n_local, grid.aabb_min[0], grid.aabb_min[1], grid.aabb_min[2], subgrid.cell_size, ns[0],
+                           ns[1], ns[2], c->hist.as<uint32_t>());
+    s = comm_allreduce_sum_u32(c, c->hist.as<uint32_t>(), nsub);
+    if (s != SS_OK) return s;
+    std::vector<uint32_t> h_hist(nsub);
+    SS_HIP(ctx, hipMemcpyAsync(h_hist.data(), c->hist.p, nsub * 4, hipMemcpyDeviceToHost, st));
+    SS_HIP(ctx, hipStreamSynchronize(st));
+    std::vector<double> hist_d(nsub);
+    for (size_t i = 0; i < nsub; ++i) hist_d[i] = (double)h_hist[i];
+    c->bricks.assign((size_t)world * 6, 0);
+    {
+        const int lo0[3] = {0, 0, 0};
+        rcb_split(hist_d, ns, lo0, ns, 0, world, pref, 0.02, c->bricks);
+    }
+    const int64_t* my_lo = &c->bricks[(size_t)me * 6];
+    const int64_t* my_hi = my_lo + 3;
+    for (int d = 0; d < 3; ++d) {
+        c->info.brick_lo[d] = my_lo[d];
+        c->info.brick_hi[d] = my_hi[d];
+    }
+    double amax = 1.0;
+    for (int d = 0; d < 3; ++d) amax = std::max(amax, std::max(std::fabs((double)grid.aabb_min[d]), std::fabs((double)dmax[d])));
+    const double pad = (double)margin * 1.001 + 1e-6 * amax;
+    std::vector<DistBox> boxes((size_t)world);
+    for (int q = 0; q < world; ++q) {
+        DistBox& b = boxes[q];
+        b.empty = 0;
+        for (int d = 0; d < 3; ++d) {
+            const int64_t a = c->bricks[(size_t)q * 6 + d], e = c->bricks[(size_t)q * 6 + 3 + d];
+            if (e <= a) b.empty = 1;
+            b.lo[d] = (double)grid.aabb_min[d] + (double)a * (double)subgrid.cell_size - pad;
+            b.hi[d] = (double)grid.aabb_min[d] + (double)e * (double)subgrid.cell_size + pad;
+        }
+    }
+    c->info.ms_partition = now_ms() - t0;
+    t0 = now_ms();
+
+    // ---- 3. positions to every rank that needs the particle (owner or ghost) ----
+    uint64_t n_held = 0;
+    const int pos_words = 3 * (int)(sizeof(R) / 4);
+    s = pack_and_exchange(c, n_local, id0, nullptr, reinterpret_cast<const uint32_t*>(d_xyz), pos_words,
+                          [&](int q) {
+                              if (boxes[q].empty) return false;
+                              hipLaunchKernelGGL(k_box_flags<R>, grid_for(n_local + 1), dim3(256), 0, st, d_xyz, n_local, boxes[q], (const uint32_t*)nullptr, c->flags.as<uint32_t>());
+                              return true;
+                          },
+                          &n_held, &c->info.bytes_sent_positions);
+    if (s != SS_OK) return s;
+    if (n_held >= (1ull << 31)) return fail(ctx, SS_ERR_UNSUPPORTED, "more than 2^31-1 particles held by one rank");
+    // Rows arrive ascending from every source rank and the ranks' id ranges ascend, so the concatenation by source rank IS the
+    // ascending global-id order the engine needs (no sort).
+    SS_HIP(ctx, c->gids.reserve(n_held * 8 + 64));
+    SS_HIP(ctx, c->L.reserve(n_held * 3 * sizeof(R) + 64));
+    if (n_held)
+        hipLaunchKernelGGL(k_unpack_rows, grid_for(n_held), dim3(256), 0, st, n_held, c->recvbuf.as<uint32_t>(), pos_words, c->gids.as<unsigned long long>(), c->L.as<uint32_t>());
+    SS_HIP(ctx, hipStreamSynchronize(st));
+    c->info.n_held = n_held;
+    c->info.ms_position_exchange = now_ms() - t0;
+
+    // ---- 4. phase 1: binning + densities of the particles contained in this brick ----
+    typename T::shard shard;
+    for (int d = 0; d < 3; ++d) {
+        shard.domain_min[d] = dmin[d];
+        shard.domain_max[d] = dmax[d];
+        shard.sub_lo[d] = my_lo[d];
+        shard.sub_hi[d] = my_hi[d];
+    }
+    s = T::begin(ctx, c->L.as<R>(), n_held, prm, &shard, res);
+    if (s != SS_OK) return s;
+    t0 = now_ms();
+
+    // ---- 5. halo densities: owners -> ranks holding the particle as a ghost ----
+    SS_HIP(ctx, c->owned.reserve((n_held + 1) * 4 + 64));
+    if (n_held) hipLaunchKernelGGL(k_owned_flags<R>, grid_for(n_held), dim3(256), 0, st, res->rho.as<R>(), n_held, c->owned.as<uint32_t>());
+    {
+        size_t bytes = 0;
+        SS_HIP(ctx, c->small_dev.reserve(64));
+        if (n_held) {
+            SS_HIP(ctx, rocprim::reduce(nullptr, bytes, c->owned.as<uint32_t>(), c->small_dev.as<uint32_t>(), 0u, (size_t)n_held, rocprim::plus<uint32_t>(), st));
+            SS_HIP(ctx, c->sort_tmp.reserve(bytes + 64));
+            SS_HIP(ctx, rocprim::reduce(c->sort_tmp.p, bytes, c->owned.as<uint32_t>(), c->small_dev.as<uint32_t>(), 0u, (size_t)n_held, rocprim::plus<uint32_t>(), st));
+            uint32_t h_owned = 0;
+            SS_HIP(ctx, hipMemcpyAsync(&h_owned, c->small_dev.p, 4, hipMemcpyDeviceToHost, st));
+            SS_HIP(ctx, hipStreamSynchronize(st));
+            c->info.n_owned = h_owned;
+        }
+    }
+    uint64_t n_rho_rows = 0;
+    const int rho_words = (int)(sizeof(R) / 4);
+    s = pack_and_exchange(c, n_held, 0, c->gids.as<unsigned long long>(), reinterpret_cast<const uint32_t*>(res->rho.as<R>()), rho_words,
+                          [&](int q) {
+                              if (q == me || boxes[q].empty) return false;
+                              hipLaunchKernelGGL(k_box_flags<R>, grid_for(n_held + 1), dim3(256), 0, st, c->L.as<R>(), n_held, boxes[q], c->owned.as<uint32_t>(), c->flags.as<uint32_t>());
+                              return true;
+                          },
+                          &n_rho_rows, &c->info.bytes_sent_densities);
+    if (s != SS_OK) return s;
+    SS_HIP(ctx, c->err.reserve(64));
+    SS_HIP(ctx, hipMemsetAsync(c->err.p, 0, 4, st));
+    if (n_rho_rows)
+        hipLaunchKernelGGL(k_scatter_density, grid_for(n_rho_rows), dim3(256), 0, st, n_rho_rows, c->recvbuf.as<uint32_t>(), rho_words, c->gids.as<unsigned long long>(), n_held,
+                           res->rho.as<uint32_t>(), c->err.as<uint32_t>());
+    uint32_t h_err = 0;
+    SS_HIP(ctx, hipMemcpyAsync(&h_err, c->err.p, 4, hipMemcpyDeviceToHost, st));
+    SS_HIP(ctx, hipStreamSynchronize(st));
+    if (h_err) return fail(ctx, SS_ERR_UNKNOWN, "halo density exchange: a density arrived for a particle this rank does not hold");
+    res->hrho = false;
+    c->info.ms_density_exchange = now_ms() - t0;
+
+    // ---- 6. phase 2: level set + marching cubes of the brick ----
+    s = ss_shard_finish(ctx, res);
+    if (s != SS_OK) return s;
+
+    // load balance of the partition, identical on every rank
+    uint64_t pair[2] = {c->info.n_owned, c->info.n_held};
+    std::vector<uint64_t> pairs((size_t)world * 2);
+    s = comm_allgather_host(c, pair, sizeof(pair), pairs.data());
+    if (s != SS_OK) return s;
+    c->per_rank_owned.assign((size_t)world, 0);
+    c->per_rank_held.assign((size_t)world, 0);
+    for (int q = 0; q < world; ++q) {
+        c->per_rank_owned[q] = pairs[(size_t)q * 2];
+        c->per_rank_held[q] = pairs[(size_t)q * 2 + 1];
+    }
+    return SS_OK;
+}
+
+template <class R>
+ss_status dist_assemble(ss_comm* c, ss_result* res) {
+    ss_context* ctx = c->ctx;
+    if (!res->valid || res->phase != 2 || res->global_strategy) return fail(ctx, SS_ERR_INVALID_ARGUMENT, "ss_dist_assemble needs the result of ss_dist_reconstruct");
+    SS_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    const int world = c->world, me = c->rank;
+    const uint64_t nv = res->n_vertices, nt = res->n_triangles;
+    const double t0 = now_ms();
+    DistBricks B;
+    memset(&B, 0, sizeof(B));
+    B.world = world;
+    const int n = c->n_cubes;
+    for (int q = 0; q < world; ++q) {
+        B.empty[q] = 0;
+        for (int d = 0; d < 3; ++d) {
+            const int64_t a = c->bricks[(size_t)q * 6 + d], e = c->bricks[(size_t)q * 6 + 3 + d];
+            if (e <= a) B.empty[q] = 1;
+            B.lo[q][d] = (int)(a * n);
+            B.hi[q][d] = (int)(e * n);
+        }
+    }
+    const unsigned long long np1 = (unsigned long long)c->ns[1] * n + 1ull, np2 = (unsigned long long)c->ns[2] * n + 1ull;
+    SS_HIP(ctx, c->owner.reserve(nv * 4 + 64));
+    SS_HIP(ctx, c->holder.reserve(nv * 8 + 64));
+    SS_HIP(ctx, c->gid_local.reserve(nv * 8 + 64));
+    SS_HIP(ctx, c->mine_off.reserve((nv + 1) * 4 + 64));
+    SS_HIP(ctx, c->vals_a.reserve((nv + 1) * 4 + 64));  // mine flags
+    const unsigned long long* keys = res->vkeys.as<unsigned long long>();
+    if (nv) hipLaunchKernelGGL(k_vertex_owner, grid_for(nv), dim3(256), 0, st, nv, keys, B, np1, np2, c->owner.as<uint32_t>(), c->holder.as<unsigned long long>());
+    uint32_t* mine = c->vals_a.as<uint32_t>();
+    hipLaunchKernelGGL(k_vertex_flags, grid_for(nv + 1), dim3(256), 0, st, nv, c->owner.as<uint32_t>(), c->holder.as<unsigned long long>(), (uint32_t)me, -1, mine);
+    ss_status s = scan_u32(c, mine, c->mine_off.as<uint32_t>(), nv + 1);
+    if (s != SS_OK) return s;
+    uint32_t n_owned = 0;
+    SS_HIP(ctx, hipMemcpyAsync(&n_owned, c->mine_off.as<uint32_t>() + nv, 4, hipMemcpyDeviceToHost, st));
+    SS_HIP(ctx, hipStreamSynchronize(st));
+    uint64_t cnt[2] = {n_owned, nt};
+    std::vector<uint64_t> all((size_t)world * 2);
+    s = comm_allgather_host(c, cnt, sizeof(cnt), all.data());
+    if (s != SS_OK) return s;
+    uint64_t voff = 0, toff = 0, vtot = 0, ttot = 0;
+    for (int q = 0; q < world; ++q) {
+        if (q < me) {
+            voff += all[(size_t)q * 2];
+            toff += all[(size_t)q * 2 + 1];
+        }
+        vtot += all[(size_t)q * 2];
+        ttot += all[(size_t)q * 2 + 1];
+    }
+    if (nv) hipLaunchKernelGGL(k_owned_gids, grid_for(nv), dim3(256), 0, st, nv, mine, c->mine_off.as<uint32_t>(), (unsigned long long)voff, c->gid_local.as<unsigned long long>());
+    // owners -> the other ranks holding the edge: (key, global id)
+    uint64_t n_rows = 0;
+    s = pack_and_exchange(c, nv, 0, keys, reinterpret_cast<const uint32_t*>(c->gid_local.as<unsigned long long>()), 2,
+                          [&](int q) {
+                              if (q == me || B.empty[q]) return false;
+                              hipLaunchKernelGGL(k_vertex_flags, grid_for(nv + 1), dim3(256), 0, st, nv, c->owner.as<uint32_t>(), c->holder.as<unsigned long long>(), (uint32_t)me, q,
+                                                 c->flags.as<uint32_t>());
+                              return true;
+                          },
+                          &n_rows, &c->info.bytes_sent_assembly);
+    if (s != SS_OK) return s;
+    SS_HIP(ctx, c->err.reserve(64));
+    SS_HIP(ctx, hipMemsetAsync(c->err.p, 0, 4, st));
+    if (n_rows || nv) {
+        // received rows: (key, id) -> sort by key, then every vertex owned elsewhere looks its key up
+        SS_HIP(ctx, c->keys_b.reserve((n_rows + 1) * 8 * 2 + 64));
+        SS_HIP(ctx, c->vals_b.reserve((n_rows + 1) * 8 * 2 + 64));
+        unsigned long long* rk = c->keys_b.as<unsigned long long>();
+        unsigned long long* rk_sorted = rk + (n_rows + 1);
+        unsigned long long* ri = c->vals_b.as<unsigned long long>();
+        unsigned long long* ri_sorted = ri + (n_rows + 1);
+        if (n_rows) {
+            hipLaunchKernelGGL(k_unpack_rows, grid_for(n_rows), dim3(256), 0, st, n_rows, c->recvbuf.as<uint32_t>(), 2, rk, reinterpret_cast<uint32_t*>(ri));
+            size_t bytes = 0;
+            SS_HIP(ctx, rocprim::radix_sort_pairs(nullptr, bytes, rk, rk_sorted, ri, ri_sorted, (size_t)n_rows, 0u, 64u, st));
+            SS_HIP(ctx, c->sort_tmp.reserve(bytes + 64));
+            SS_HIP(ctx, rocprim::radix_sort_pairs(c->sort_tmp.p, bytes, rk, rk_sorted, ri, ri_sorted, (size_t)n_rows, 0u, 64u, st));
+        }
+        if (nv)
+            hipLaunchKernelGGL(k_resolve_shared, grid_for(nv), dim3(256), 0, st, nv, keys, mine, rk_sorted, ri_sorted, n_rows, c->gid_local.as<unsigned long long>(),
+                               c->err.as<uint32_t>());
+    }
+    SS_HIP(ctx, c->tri64.reserve(nt * 24 + 64));
+    if (nt) hipLaunchKernelGGL(k_global_triangles, grid_for(nt * 3), dim3(256), 0, st, nt * 3, res->tri32.as<uint32_t>(), c->gid_local.as<unsigned long long>(), c->tri64.as<unsigned long long>());
+    SS_HIP(ctx, c->vown.reserve((size_t)n_owned * 3 * sizeof(R) + 64));
+    SS_HIP(ctx, c->kown.reserve((size_t)n_owned * 8 + 64));
+    if (nv) hipLaunchKernelGGL(k_compact_owned<R>, grid_for(nv), dim3(256), 0, st, nv, mine, c->mine_off.as<uint32_t>(), res->vertices.as<R>(), keys, c->vown.as<R>(), c->kown.as<unsigned long long>());
+    uint32_t h_err = 0;
+    SS_HIP(ctx, hipMemcpyAsync(&h_err, c->err.p, 4, hipMemcpyDeviceToHost, st));
+    SS_HIP(ctx, hipStreamSynchronize(st));
+    if (h_err) return fail(ctx, SS_ERR_UNKNOWN, "mesh assembly: a shared face vertex was not emitted by its owner rank (level sets differ between ranks)");
+    c->info.n_vertices_owned = n_owned;
+    c->info.vertex_offset = voff;
+    c->info.n_vertices_total = vtot;
+    c->info.n_triangles = nt;
+    c->info.triangle_offset = toff;
+    c->info.n_triangles_total = ttot;
+    c->info.ms_assembly = now_ms() - t0;
+    c->assembled = true;
+    return SS_OK;
+}
+
+ss_status copy_to_caller(ss_comm* c, const void* src, void* dst, size_t bytes) {
+    ss_context* ctx = c->ctx;
+    if (!bytes) return SS_OK;
+    if (!dst) return SS_ERR_INVALID_ARGUMENT;
+    SS_HIP(ctx, hipSetDevice(ctx->device));
+    SS_HIP(ctx, hipMemcpyAsync(dst, src, bytes, is_device_pointer(dst) ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, ctx->stream));
+    SS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return SS_OK;
+}
+
+void comm_release(ss_comm* c) {
+    for (DevBuf* b : {&c->small_dev, &c->small_dev2, &c->red_tmp, &c->peers_dev, &c->xyz_in, &c->hist, &c->flags, &c->offs, &c->sendbuf, &c->recvbuf, &c->gids, &c->L, &c->owned,
+                      &c->sort_tmp, &c->keys_a, &c->keys_b, &c->vals_a, &c->vals_b, &c->owner, &c->holder, &c->gid_local, &c->mine_off, &c->tri64, &c->vown, &c->kown, &c->err})
+        b->release();
+    c->small_host.release();
+}
+
+double env_timeout() {
+    const char* e = getenv("SPLASH_COMM_TIMEOUT_S");
+    const double v = e ? atof(e) : 120.0;
+    return v > 0.0 ? v : 120.0;
+}
+
+}  // namespace
+
+// =====================================================================================================================
+// C ABI
+// =====================================================================================================================
+extern "C" {
+
+ss_status ss_comm_unique_id(uint8_t id[SS_COMM_ID_BYTES]) {
+    if (!id) return SS_ERR_INVALID_ARGUMENT;
+    RcclApi* api = rccl_api();
+    if (!api->handle) return SS_ERR_DEVICE;
+    ncclUniqueId u;
+    if (api->GetUniqueId(&u) != ncclSuccess) return SS_ERR_DEVICE;
+    static_assert(sizeof(u) == SS_COMM_ID_BYTES, "ncclUniqueId size");
+    memcpy(id, &u, SS_COMM_ID_BYTES);
+    return SS_OK;
+}
+
+ss_status ss_comm_create_rccl(ss_context* ctx, const uint8_t id[SS_COMM_ID_BYTES], int rank, int world, ss_comm** out) {
+    if (!ctx || !id || !out || world < 1 || rank < 0 || rank >= world) return SS_ERR_INVALID_ARGUMENT;
+    *out = nullptr;
+    RcclApi* api = rccl_api();
+    if (!api->handle) return fail(ctx, SS_ERR_DEVICE, api->error.empty() ? "RCCL not available" : api->error);
+    SS_HIP(ctx, hipSetDevice(ctx->device));
+    ncclUniqueId u;
+    memcpy(&u, id, SS_COMM_ID_BYTES);
+    ncclComm_t comm = nullptr;
+    ncclResult_t r = api->CommInitRank(&comm, world, u, rank);
+    if (r != ncclSuccess) return fail(ctx, SS_ERR_DEVICE, std::string("ncclCommInitRank failed: ") + api->GetErrorString(r));
+    ss_comm* c = new (std::nothrow) ss_comm();
+    if (!c) return SS_ERR_UNKNOWN;
+    c->ctx = ctx;
+    c->rank = rank;
+    c->world = world;
+    c->kind = 1;
+    c->nccl = comm;
+    c->own_nccl = true;
+    c->timeout_s = env_timeout();
+    *out = c;
+    return SS_OK;
+}
+
+ss_status ss_comm_adopt_rccl(ss_context* ctx, void* nccl_comm, int rank, int world, ss_comm** out) {
+    if (!ctx || !nccl_comm || !out || world < 1 || rank < 0 || rank >= world) return SS_ERR_INVALID_ARGUMENT;
+    *out = nullptr;
+    RcclApi* api = rccl_api();
+    if (!api->handle) return fail(ctx, SS_ERR_DEVICE, api->error.empty() ? "RCCL not available" : api->error);
+    ss_comm* c = new (std::nothrow) ss_comm();
+    if (!c) return SS_ERR_UNKNOWN;
+    c->ctx = ctx;
+    c->rank = rank;
+    c->world = world;
+    c->kind = 1;
+    c->nccl = reinterpret_cast<ncclComm_t>(nccl_comm);
+    c->own_nccl = false;
+    c->timeout_s = env_timeout();
+    *out = c;
+    return SS_OK;
+}
+
+ss_status ss_comm_create_local_group(ss_context* const* ctxs, int world, ss_comm** out) {
+    if (!ctxs || !out || world < 1 || world > 64) return SS_ERR_INVALID_ARGUMENT;
+    auto g = std::make_shared<LocalGroup>();
+    g->world = world;
+    g->host.resize((size_t)world);
+    g->send_ptr.assign((size_t)world, nullptr);
+    g->send_off.resize((size_t)world);
+    g->red_ptr.assign((size_t)world, nullptr);
+    for (int q = 0; q < world; ++q) {
+        if (!ctxs[q]) return SS_ERR_INVALID_ARGUMENT;
+        ss_comm* c = new (std::nothrow) ss_comm();
+        if (!c) return SS_ERR_UNKNOWN;
+        c->ctx = ctxs[q];
+        c->rank = q;
+        c->world = world;
+        c->kind = 0;
+        c->group = g;
+        c->timeout_s = env_timeout();
+        out[q] = c;
+    }
+    return SS_OK;
+}
+
+void ss_comm_destroy(ss_comm* c) {
+    if (!c) return;
+    if (c->ctx) (void)hipSetDevice(c->ctx->device);
+    comm_release(c);
+    if (c->kind == 1 && c->nccl && c->own_nccl) (void)rccl_api()->CommDestroy(c->nccl);
+    delete c;
+}
+
+ss_status ss_dist_reconstruct_f32(ss_comm* comm, const float* xyz_local, uint64_t n_local, const ss_params_f32* params, ss_result* inout) {
+    return dist_reconstruct<float>(comm, xyz_local, n_local, params, inout);
+}
+ss_status ss_dist_reconstruct_f64(ss_comm* comm, const double* xyz_local, uint64_t n_local, const ss_params_f64* params, ss_result* inout) {
+    return dist_reconstruct<double>(comm, xyz_local, n_local, params, inout);
+}
+
+ss_status ss_dist_assemble(ss_comm* comm, ss_result* inout) {
+    if (!comm || !inout) return SS_ERR_INVALID_ARGUMENT;
+    if (inout->ctx != comm->ctx) return fail(comm->ctx, SS_ERR_INVALID_ARGUMENT, "result belongs to a different context than the communicator");
+    comm->ctx->err.clear();
+    return inout->is_f64 ? dist_assemble<double>(comm, inout) : dist_assemble<float>(comm, inout);
+}
+
+ss_status ss_dist_partition(const uint32_t* histogram, const int64_t n_subdomains[3], int world, const double axis_preference[3], int64_t* bricks) {
+    if (!histogram || !n_subdomains || !bricks || world < 1 || world > 64) return SS_ERR_INVALID_ARGUMENT;
+    const int ns[3] = {(int)n_subdomains[0], (int)n_subdomains[1], (int)n_subdomains[2]};
+    if (ns[0] < 1 || ns[1] < 1 || ns[2] < 1 || (double)ns[0] * ns[1] * ns[2] > 2.0e9) return SS_ERR_INVALID_ARGUMENT;
+    const size_t nsub = (size_t)ns[0] * ns[1] * ns[2];
+    std::vector<double> h(nsub);
+    for (size_t i = 0; i < nsub; ++i) h[i] = (double)histogram[i];
+    const double pref[3] = {axis_preference ? axis_preference[0] : 0.0, axis_preference ? axis_preference[1] : 0.0, axis_preference ? axis_preference[2] : 0.0};
+    std::vector<int64_t> out((size_t)world * 6, 0);
+    const int lo0[3] = {0, 0, 0};
+    rcb_split(h, ns, lo0, ns, 0, world, pref, 0.02, out);
+    for (size_t i = 0; i < out.size(); ++i) bricks[i] = out[i];
+    return SS_OK;
+}
+
+ss_status ss_dist_get_info(const ss_comm* comm, ss_dist_info* out) {
+    if (!comm || !out) return SS_ERR_INVALID_ARGUMENT;
+    *out = comm->info;
+    return SS_OK;
+}
+
+ss_status ss_dist_get_partition(const ss_comm* comm, int64_t* bricks, uint64_t* owned, uint64_t* held) {
+    if (!comm || comm->bricks.size() != (size_t)comm->world * 6) return SS_ERR_INVALID_ARGUMENT;
+    for (size_t i = 0; bricks && i < comm->bricks.size(); ++i) bricks[i] = comm->bricks[i];
+    for (int q = 0; q < comm->world; ++q) {
+        if (owned) owned[q] = q < (int)comm->per_rank_owned.size() ? comm->per_rank_owned[q] : 0;
+        if (held) held[q] = q < (int)comm->per_rank_held.size() ? comm->per_rank_held[q] : 0;
+    }
+    return SS_OK;
+}
+
+ss_status ss_dist_copy_global_ids(ss_comm* comm, uint64_t* dst) {
+    if (!comm) return SS_ERR_INVALID_ARGUMENT;
+    return copy_to_caller(comm, comm->gids.p, dst, (size_t)comm->info.n_held * 8);
+}
+ss_status ss_dist_copy_vertices(ss_comm* comm, void* dst) {
+    if (!comm || !comm->assembled) return SS_ERR_INVALID_ARGUMENT;
+    return copy_to_caller(comm, comm->vown.p, dst, (size_t)comm->info.n_vertices_owned * 3 * (comm->is_f64 ? 8 : 4));
+}
+ss_status ss_dist_copy_vertex_keys(ss_comm* comm, uint64_t* dst) {
+    if (!comm || !comm->assembled) return SS_ERR_INVALID_ARGUMENT;
+    return copy_to_caller(comm, comm->kown.p, dst, (size_t)comm->info.n_vertices_owned * 8);
+}
+ss_status ss_dist_copy_triangles(ss_comm* comm, uint64_t* dst) {
+    if (!comm || !comm->assembled) return SS_ERR_INVALID_ARGUMENT;
+    return copy_to_caller(comm, comm->tri64.p, dst, (size_t)comm->info.n_triangles * 24);
+}
+
+}  // extern "C"

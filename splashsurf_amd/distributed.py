@@ -192,7 +192,7 @@ def bricks_from_histogram(hist3, world, tol=0.02, axis_pref=(0.0, 0.0, 0.0)):
                 c = int(np.argmin(np.abs(cum[1:ext[a]] - total * frac))) + 1
                 err = abs(cum[c] - total * frac) / total
             else:
-                c = min(max(int(round(ext[a] * frac)), 1), ext[a] - 1)
+                c = min(max(int(np.floor(ext[a] * frac + 0.5)), 1), ext[a] - 1)
                 err = 0.0
             area = 1
             for d in range(3):
@@ -515,6 +515,7 @@ class ShardedReconstruction:
                        bricks=[[list(a), list(b)] for a, b in bricks],
                        imbalance_owned=float(own.max() / max(own.mean(), 1.0)),
                        imbalance_held=float(per_rank[:, 1].max() / max(per_rank[:, 1].mean(), 1.0)))
+        self.last_balance = balance
         return ShardedStepResult(res, shard, gids, n_total, dict(self.timings), balance)
 
     # ---- result assembly ----
@@ -609,3 +610,156 @@ class ShardedReconstruction:
             return None
         assert V.shape[0] == m.n_vertices_total and T.shape[0] == m.n_triangles_total
         return V.cpu().numpy(), K.cpu().numpy().astype(np.uint64), T.cpu().numpy().astype(np.uint64)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# the same algorithm inside the library: ss_dist_* (csrc/ss_dist.hip), RCCL behind the C ABI -- no Python on the data path
+# ---------------------------------------------------------------------------------------------------------------------
+class _DistInfo(C.Structure):
+    _fields_ = [("rank", C.c_int32), ("world", C.c_int32), ("brick_lo", C.c_int64 * 3), ("brick_hi", C.c_int64 * 3), ("n_total", C.c_uint64),
+                ("n_held", C.c_uint64), ("n_owned", C.c_uint64), ("bytes_sent_positions", C.c_uint64), ("bytes_sent_densities", C.c_uint64),
+                ("bytes_sent_assembly", C.c_uint64), ("ms_partition", C.c_double), ("ms_position_exchange", C.c_double), ("ms_density_exchange", C.c_double),
+                ("ms_assembly", C.c_double), ("n_vertices_owned", C.c_uint64), ("vertex_offset", C.c_uint64), ("n_vertices_total", C.c_uint64),
+                ("n_triangles", C.c_uint64), ("triangle_offset", C.c_uint64), ("n_triangles_total", C.c_uint64)]
+
+
+def _dist_lib(ctx):
+    L = ctx._lib
+    if not getattr(L, "_dist_configured", False):
+        from . import api
+        vp, u64, i32 = C.c_void_p, C.c_uint64, C.c_int
+        L.ss_comm_unique_id.argtypes = [vp]
+        L.ss_comm_create_rccl.argtypes = [vp, vp, i32, i32, C.POINTER(vp)]
+        L.ss_comm_adopt_rccl.argtypes = [vp, vp, i32, i32, C.POINTER(vp)]
+        L.ss_comm_create_local_group.argtypes = [C.POINTER(vp), i32, C.POINTER(vp)]
+        L.ss_comm_destroy.argtypes = [vp]
+        L.ss_comm_destroy.restype = None
+        L.ss_dist_reconstruct_f32.argtypes = [vp, vp, u64, C.POINTER(api._Params), vp]
+        L.ss_dist_reconstruct_f64.argtypes = [vp, vp, u64, C.POINTER(api._Params64), vp]
+        L.ss_dist_assemble.argtypes = [vp, vp]
+        L.ss_dist_get_info.argtypes = [vp, C.POINTER(_DistInfo)]
+        L.ss_dist_get_partition.argtypes = [vp, C.POINTER(C.c_int64), C.POINTER(u64), C.POINTER(u64)]
+        for name in ("ss_dist_copy_global_ids", "ss_dist_copy_vertices", "ss_dist_copy_vertex_keys", "ss_dist_copy_triangles"):
+            getattr(L, name).argtypes = [vp, vp]
+        L._dist_configured = True
+    return L
+
+
+class NativeComm:
+    """`ss_comm`: a communicator bound to one Context.  `NativeComm.rccl(ctx)`: one rank per process, RCCL; the unique id
+    travels through torch.distributed's default group (any backend).  `NativeComm.local_group(ctxs)`: one communicator per
+    context for host threads sharing a device (tests)."""
+
+    def __init__(self, ctx, handle, rank, world, kind):
+        self.ctx, self._h, self.rank, self.world, self.kind = ctx, handle, rank, world, kind
+
+    @classmethod
+    def rccl(cls, ctx, rank=None, world=None):
+        L = _dist_lib(ctx)
+        rank = dist.get_rank() if rank is None else rank
+        world = dist.get_world_size() if world is None else world
+        uid = (C.c_uint8 * 128)()
+        if rank == 0:
+            st = L.ss_comm_unique_id(uid)
+            if st != 0:
+                raise RuntimeError("ss_comm_unique_id failed (RCCL not loadable?)")
+        if world > 1:
+            box = [bytes(uid)]
+            dist.broadcast_object_list(box, src=0)
+            uid = (C.c_uint8 * 128).from_buffer_copy(box[0])
+        h = C.c_void_p()
+        st = L.ss_comm_create_rccl(ctx._h, uid, int(rank), int(world), C.byref(h))
+        if st != 0:
+            ctx._raise(st)
+        return cls(ctx, h, rank, world, "rccl")
+
+    @classmethod
+    def local_group(cls, ctxs):
+        L = _dist_lib(ctxs[0])
+        n = len(ctxs)
+        hs = (C.c_void_p * n)(*[c._h for c in ctxs])
+        out = (C.c_void_p * n)()
+        st = L.ss_comm_create_local_group(hs, n, out)
+        if st != 0:
+            raise RuntimeError("ss_comm_create_local_group failed: %d" % st)
+        return [cls(ctxs[q], C.c_void_p(out[q]), q, n, "local") for q in range(n)]
+
+    def destroy(self):
+        if self._h:
+            self.ctx._lib.ss_comm_destroy(self._h)
+            self._h = None
+
+
+class NativeSharded:
+    """Per-rank driver of ss_dist_reconstruct_* / ss_dist_assemble.  `particles`: this rank's share, (n,3) numpy array or
+    torch tensor (host or this rank's GPU) of float32 / float64."""
+
+    def __init__(self, comm, params):
+        from . import api
+        self.api, self.comm, self.ctx, self.params = api, comm, comm.ctx, params
+        self.lib = _dist_lib(comm.ctx)
+        h = C.c_void_p()
+        st = self.lib.ss_result_create(self.ctx._h, C.byref(h))
+        if st != 0:
+            self.ctx._raise(st)
+        self.result = api.SurfaceReconstruction(self.ctx, h)
+        self._keep = None
+
+    def step(self, particles):
+        ptr, n, keep, f64 = self.ctx._as_ptr(particles)
+        self._keep, self.f64 = keep, f64
+        p = self.params._c(f64)
+        fn = self.lib.ss_dist_reconstruct_f64 if f64 else self.lib.ss_dist_reconstruct_f32
+        st = fn(self.comm._h, ptr, n, C.byref(p), self.result._h)
+        if st != 0:
+            self.ctx._raise(st)
+        self.result._invalidate()
+        return self.result
+
+    def assemble(self):
+        st = self.lib.ss_dist_assemble(self.comm._h, self.result._h)
+        if st != 0:
+            self.ctx._raise(st)
+        return self.info()
+
+    def info(self):
+        i = _DistInfo()
+        self.lib.ss_dist_get_info(self.comm._h, C.byref(i))
+        d = {k: getattr(i, k) for k, _ in _DistInfo._fields_ if not k.startswith("brick")}
+        d["brick"] = [list(i.brick_lo), list(i.brick_hi)]
+        return d
+
+    def partition(self):
+        w = self.comm.world
+        b, o, h = (C.c_int64 * (6 * w))(), (C.c_uint64 * w)(), (C.c_uint64 * w)()
+        st = self.lib.ss_dist_get_partition(self.comm._h, b, o, h)
+        if st != 0:
+            raise RuntimeError("ss_dist_get_partition failed")
+        own = np.array(list(o), dtype=np.float64)
+        held = np.array(list(h), dtype=np.float64)
+        return dict(bricks=[[list(b[6 * q:6 * q + 3]), list(b[6 * q + 3:6 * q + 6])] for q in range(w)], owned=[int(x) for x in o], held=[int(x) for x in h],
+                    imbalance_owned=float(own.max() / max(own.mean(), 1.0)), imbalance_held=float(held.max() / max(held.mean(), 1.0)))
+
+    def _copy(self, fn, count, dtype):
+        out = np.empty(count, dtype=dtype)
+        if out.size:
+            st = fn(self.comm._h, out.ctypes.data_as(C.c_void_p))
+            if st != 0:
+                self.ctx._raise(st)
+        return out
+
+    def global_ids(self):
+        return self._copy(self.lib.ss_dist_copy_global_ids, self.info()["n_held"], np.uint64)
+
+    def mesh_piece(self):
+        """(owned vertices, their edge keys, triangles with global vertex ids) of this rank, as numpy arrays."""
+        i = self.info()
+        dt = np.float64 if self.f64 else np.float32
+        v = self._copy(self.lib.ss_dist_copy_vertices, i["n_vertices_owned"] * 3, dt).reshape(-1, 3)
+        k = self._copy(self.lib.ss_dist_copy_vertex_keys, i["n_vertices_owned"], np.uint64)
+        t = self._copy(self.lib.ss_dist_copy_triangles, i["n_triangles"] * 3, np.uint64).reshape(-1, 3)
+        return v, k, t
+
+    def close(self):
+        self.result._free()
+        self.comm.destroy()

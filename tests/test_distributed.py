@@ -124,6 +124,40 @@ def test_ranks_reproduce_single_process(tmp_path, oracle, case, world, exchange)
         assert sorted(hi) == [1, 2, 2], (hi, ns)
 
 
+def test_native_partition_rule_equals_the_host_mirror():
+    """ss_dist_partition (csrc/ss_dist.hip, host-only code: runs without a GPU) cuts the same bricks as
+    distributed.bricks_from_histogram on random and on structured histograms."""
+    import ctypes as C
+    sys.path.insert(0, ROOT)
+    import __graft_entry__ as G
+    from splashsurf_amd.distributed import bricks_from_histogram
+    if not os.path.exists(G.LIB):
+        G.build()
+    L = C.CDLL(G.LIB)
+    L.ss_dist_partition.argtypes = [C.c_void_p, C.POINTER(C.c_int64), C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
+    rng = np.random.default_rng(5)
+    for trial in range(40):
+        ns = tuple(int(x) for x in rng.integers(1, 9, size=3))
+        kind = trial % 4
+        if kind == 0:
+            hist = rng.integers(0, 5000, size=ns)
+        elif kind == 1:
+            hist = (rng.random(ns) < 0.3) * rng.integers(1, 100000, size=ns)
+        elif kind == 2:
+            hist = np.zeros(ns, np.int64)
+        else:
+            hist = np.full(ns, 777)
+        hist = np.ascontiguousarray(hist, dtype=np.uint32)
+        pref = tuple(round(float(x), 3) for x in rng.random(3)) if trial % 2 else (0.0, 0.0, 0.0)
+        for world in (1, 2, 3, 5, 8, 13):
+            want = bricks_from_histogram(hist, world, axis_pref=pref)
+            out = (C.c_int64 * (6 * world))()
+            st = L.ss_dist_partition(hist.ctypes.data_as(C.c_void_p), (C.c_int64 * 3)(*ns), world, (C.c_double * 3)(*pref), out)
+            assert st == 0
+            got = [(tuple(out[6 * q:6 * q + 3]), tuple(out[6 * q + 3:6 * q + 6])) for q in range(world)]
+            assert got == [(tuple(a), tuple(b)) for a, b in want], (ns, world, pref, got, want)
+
+
 def test_partition_is_balanced_and_contiguous():
     sys.path.insert(0, ROOT)
     from splashsurf_amd.distributed import partition_slabs

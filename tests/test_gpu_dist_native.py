@@ -1,0 +1,162 @@
+"""GPU tests of the NATIVE multi-GPU path (-m gpu): ss_dist_reconstruct_* / ss_dist_assemble (csrc/ss_dist.hip), the whole
+sharded reconstruction behind the C ABI.
+
+A 1-GPU box cannot run two RCCL ranks (RCCL refuses two ranks on one device), so the algorithm is exercised with the library's
+in-process transport: k host threads, one HIP context and one communicator each, all on GPU 0 -- brick partition, the three
+sparse all-to-alls (positions, halo densities, shared-vertex ids), both phases of the engine and the rank-owned mesh assembly
+run exactly as they do over RCCL; only the byte transport differs (device-to-device copies instead of ncclSend/ncclRecv).
+The merged result must equal the single-context reconstruction bit for bit.  A one-rank RCCL communicator additionally drives
+the real RCCL library (dlopen, ncclCommInitRank, ncclAllGather / ncclAllReduce on the context's stream)."""
+import os
+import threading
+
+import numpy as np
+import pytest
+
+import mesh_compare as MC
+
+pytestmark = pytest.mark.gpu
+
+DATA = os.path.join(os.path.dirname(__file__), "data")
+
+
+def _case(name):
+    from splashsurf_amd import workloads as W
+    if name == "dam_break_n16":
+        return np.load(os.path.join(DATA, "double_dam_break_frame_26_4732_particles.npy")), 0.025, 2.0, 1.1, 16
+    if name == "hilbert_n32":
+        return np.load(os.path.join(DATA, "hilbert_46843_particles.npy"))[::3].copy(), 0.025, 2.0, 0.9, 32
+    if name == "tank_crop":
+        return W.tank_particles(0.2), 0.005, 2.0, 0.5, 64
+    raise KeyError(name)
+
+
+def _params(r, l, c, n_cubes, dt, simd):
+    from splashsurf_amd.api import Parameters
+    return Parameters(particle_radius=r, compact_support_radius=dt(2.0 * l * r), cube_size=dt(c * r), subdomain_num_cubes_per_dim=n_cubes, auto_disable=False,
+                      enable_simd=simd)
+
+
+def _run_ranks(pts, prm, world, transport="local"):
+    """Returns per-rank dicts (info, partition, gids, rho, mesh piece).  Rank r contributes the r-th contiguous slice of pts."""
+    from splashsurf_amd import distributed as D
+    from splashsurf_amd.api import Context
+    ctxs = [Context(0) for _ in range(world)]
+    comms = D.NativeComm.local_group(ctxs) if transport == "local" else [D.NativeComm.rccl(ctxs[0], rank=0, world=1)]
+    cut = [int(round(pts.shape[0] * k / world)) for k in range(world + 1)]
+    out, errors = [None] * world, []
+
+    def worker(q):
+        try:
+            sh = D.NativeSharded(comms[q], prm)
+            for _ in range(2):  # the second step reuses every buffer
+                res = sh.step(np.ascontiguousarray(pts[cut[q]:cut[q + 1]]))
+                info = sh.assemble()
+            out[q] = dict(info=info, partition=sh.partition(), gids=sh.global_ids(), rho=res.particle_densities.copy(), piece=sh.mesh_piece(),
+                          local_counts=res.counts(), stats=res.stats)
+            sh.result._free()
+        except Exception as e:  # a failing rank must not leave the others waiting for the timeout silently
+            errors.append((q, repr(e)))
+
+    th = [threading.Thread(target=worker, args=(q,)) for q in range(world)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    for c in comms:
+        c.destroy()
+    for c in ctxs:
+        c.close()
+    assert not errors, errors
+    return out
+
+
+def _check_against_direct(pts, prm, ranks, gpu_ctx):
+    direct = gpu_ctx.reconstruct(pts, prm)
+    U = np.uint32 if pts.dtype == np.float32 else np.uint64
+    world = len(ranks)
+    # partition: identical on every rank, bricks tile the subdomain grid
+    for r in ranks[1:]:
+        assert r["partition"]["bricks"] == ranks[0]["partition"]["bricks"]
+    ns = direct.subdomain_grid.ncells_per_dim
+    cover = np.zeros(tuple(int(x) for x in ns), np.int32)
+    for lo, hi in ranks[0]["partition"]["bricks"]:
+        cover[lo[0]:hi[0], lo[1]:hi[1], lo[2]:hi[2]] += 1
+    assert (cover == 1).all()
+    assert sum(ranks[0]["partition"]["owned"]) == pts.shape[0]
+    # densities: every particle is owned by exactly one rank; owned values and received halo values equal the direct run
+    rho_ref = direct.particle_densities
+    seen = np.zeros(pts.shape[0], np.int32)
+    for q, r in enumerate(ranks):
+        g = r["gids"].astype(np.int64)
+        assert np.all(np.diff(g) > 0)  # ascending global ids
+        assert np.array_equal(r["rho"].view(U), rho_ref[g].view(U)), "rank %d: densities of held particles differ" % q
+        assert r["info"]["n_held"] == g.size and r["info"]["n_total"] == pts.shape[0]
+    assert sum(r["info"]["n_owned"] for r in ranks) == pts.shape[0]
+    # mesh: concatenation over ranks of (owned vertices, triangles with global ids)
+    V = np.concatenate([r["piece"][0] for r in ranks])
+    K = np.concatenate([r["piece"][1] for r in ranks])
+    T = np.concatenate([r["piece"][2] for r in ranks])
+    voff = 0
+    for r in ranks:
+        assert r["info"]["vertex_offset"] == voff
+        voff += r["info"]["n_vertices_owned"]
+        assert r["info"]["n_vertices_total"] == V.shape[0] and r["info"]["n_triangles_total"] == T.shape[0]
+    assert np.unique(K).size == K.size  # every vertex exists once: nothing to de-duplicate
+    assert V.shape[0] == direct.counts()[0] and T.shape[0] == direct.counts()[1]
+    cmp = MC.compare_keyed(V, K, T, direct.mesh.vertices, direct.vertex_keys, direct.mesh.triangles)
+    assert cmp["keys_equal"] and cmp["triangles_equal"] and cmp["vertices_bit_equal"], cmp
+    if world > 1:
+        assert sum(r["local_counts"][0] for r in ranks) > V.shape[0]  # face vertices really were emitted by several ranks
+        assert any(r["info"]["bytes_sent_positions"] > 0 for r in ranks) and any(r["info"]["bytes_sent_assembly"] > 0 for r in ranks)
+    return direct
+
+
+@pytest.mark.parametrize("case,world,dt,simd", [("dam_break_n16", 2, np.float32, 0), ("dam_break_n16", 3, np.float32, 1), ("hilbert_n32", 4, np.float32, 0),
+                                                ("hilbert_n32", 8, np.float32, 1), ("dam_break_n16", 5, np.float64, 0), ("tank_crop", 8, np.float32, 1)])
+def test_native_ranks_reproduce_single_context(gpu_ctx, case, world, dt, simd):
+    pts, r, l, c, n_cubes = _case(case)
+    pts = np.ascontiguousarray(pts, dtype=dt)
+    prm = _params(r, l, c, n_cubes, dt, simd)
+    ranks = _run_ranks(pts, prm, world)
+    _check_against_direct(pts, prm, ranks, gpu_ctx)
+    if case == "tank_crop":
+        assert ranks[0]["partition"]["imbalance_owned"] <= 1.15, ranks[0]["partition"]
+
+
+def test_native_more_ranks_than_subdomains(gpu_ctx):
+    """Six ranks, a 1x1x2 subdomain grid: four ranks get empty bricks and still take part in every collective."""
+    pts = np.load(os.path.join(DATA, "cube_2366_particles.npy")).astype(np.float32)
+    prm = _params(0.025, 2.0, 0.75, 64, np.float32, 0)
+    ranks = _run_ranks(pts, prm, 6)
+    direct = _check_against_direct(pts, prm, ranks, gpu_ctx)
+    n_sub = int(np.prod(direct.subdomain_grid.ncells_per_dim))
+    assert sum(1 for r in ranks if r["info"]["n_owned"] == 0) >= 6 - n_sub
+
+
+def test_native_one_rank_rccl(gpu_ctx):
+    """The RCCL transport itself with a one-rank communicator: dlopen of librccl, ncclGetUniqueId / ncclCommInitRank, the small
+    collectives on the context's stream.  (Two ranks need two GPUs.)"""
+    pts, r, l, c, n_cubes = _case("dam_break_n16")
+    pts = pts.astype(np.float32)
+    prm = _params(r, l, c, n_cubes, np.float32, 1)
+    ranks = _run_ranks(pts, prm, 1, transport="rccl")
+    _check_against_direct(pts, prm, ranks, gpu_ctx)
+
+
+def test_native_missing_peer_times_out_loudly(monkeypatch):
+    """A rank that never calls in makes the others fail with an error after SPLASH_COMM_TIMEOUT_S instead of hanging."""
+    from splashsurf_amd import distributed as D
+    from splashsurf_amd.api import Context, SplashsurfError
+    monkeypatch.setenv("SPLASH_COMM_TIMEOUT_S", "2")
+    pts, r, l, c, n_cubes = _case("dam_break_n16")
+    ctxs = [Context(0), Context(0)]
+    comms = D.NativeComm.local_group(ctxs)
+    sh = D.NativeSharded(comms[0], _params(r, l, c, n_cubes, np.float32, 0))
+    with pytest.raises(SplashsurfError):
+        sh.step(pts[:2000].astype(np.float32))  # rank 1 never shows up
+    sh.result._free()
+    for cm in comms:
+        cm.destroy()
+    for cx in ctxs:
+        cx.close()
