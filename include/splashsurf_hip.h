@@ -156,7 +156,8 @@ typedef struct ss_stats {
     uint64_t arith_mode;              /* arithmetic of the level-set accumulation that ran: 0 scalar (generic sqrt/divide), 1 scalar
                                        * (lean exact sqrt + verified reciprocal division), 2 / 3 SIMD with correctly rounded sqrt
                                        * (generic / lean), 4 SIMD with v_sqrt_f32 */
-    uint64_t bytes_tile_arena;        /* bytes of index-ordered candidate tiles written and re-read by the splat (exact size) */
+    uint64_t bytes_tile_arena;        /* bytes of index-ordered candidate tiles written by the gather and re-read by the accumulate kernel */
+    uint64_t bytes_tile_arena_reserved; /* size of the arena those tiles live in (ranges sized by a cheap per-block upper bound) */
 } ss_stats;
 
 typedef struct ss_context ss_context;

@@ -111,6 +111,7 @@ class _Stats(C.Structure):
         ("n_large_tile_blocks", C.c_uint64),
         ("arith_mode", C.c_uint64),
         ("bytes_tile_arena", C.c_uint64),
+        ("bytes_tile_arena_reserved", C.c_uint64),
     ]
 
 

@@ -855,32 +855,36 @@ ss_status phase_finish(ss_context* ctx, ss_result* res) {
     uint32_t* lg_slot = lg_list + ((size_t)n_active + 1);
     SS_HIP(ctx, ctx->splat_counts.reserve(((size_t)n_active + 1) * 4));
     SS_HIP(ctx, ctx->splat_off.reserve(((size_t)n_active + 1) * 8));
-    uint64_t n_cand = 0;
-    uint32_t n_large = 0;
+    uint64_t n_reserved = 0;
+    SS_HIP(ctx, ctx->splat_bound.reserve(((size_t)n_active + 1) * 4));
+    SS_HIP(ctx, ctx->counter.reserve(64));
+    SS_HIP(ctx, hipMemsetAsync(ctx->counter.p, 0, 64, st));
     if (n_active) {
-        SS_HIP(ctx, hipMemsetAsync(lg_flag + n_active, 0, 4, st));
-        SS_HIP(ctx, hipMemsetAsync(ctx->splat_counts.as<uint32_t>() + n_active, 0, 4, st));
-        ss_launch_splat_count(PK, res->posvol.as<ss_real4<R>>(), ctx->cell_start.as<uint32_t>(), res->active_xyz.as<uint32_t>(), n_active,
-                              ctx->splat_counts.as<uint32_t>(), lg_flag, st);
-        {   // tile_off = exclusive scan of the counts in 64 bits (the arena of S40M-tank holds > 2^32 bytes)
-            auto it = rocprim::make_transform_iterator(ctx->splat_counts.as<uint32_t>(), WidenU32());
+        ss_launch_splat_bounds(PK, ctx->cell_start.as<uint32_t>(), res->active_xyz.as<uint32_t>(), n_active, ctx->splat_bound.as<uint32_t>(), st);
+        {   // tile_off = exclusive scan of the bounds in 64 bits (the arena of S40M-tank holds > 2^32 bytes)
+            auto it = rocprim::make_transform_iterator(ctx->splat_bound.as<uint32_t>(), WidenU32());
             size_t bytes = 0;
             SS_HIP(ctx, rocprim::exclusive_scan(nullptr, bytes, it, ctx->splat_off.as<unsigned long long>(), 0ull, (size_t)n_active + 1, rocprim::plus<unsigned long long>(), st));
             SS_HIP(ctx, ctx->temp.reserve(bytes));
             SS_HIP(ctx, rocprim::exclusive_scan(ctx->temp.p, bytes, it, ctx->splat_off.as<unsigned long long>(), 0ull, (size_t)n_active + 1, rocprim::plus<unsigned long long>(), st));
         }
-        s = exclusive_scan_u32<uint32_t>(ctx, lg_flag, lg_rank, (size_t)n_active + 1);
-        if (s != SS_OK) return s;
         unsigned long long h_total = 0;
         SS_HIP(ctx, hipMemcpyAsync(&h_total, ctx->splat_off.as<unsigned long long>() + n_active, 8, hipMemcpyDeviceToHost, st));
-        SS_HIP(ctx, hipMemcpyAsync(&n_large, lg_rank + n_active, 4, hipMemcpyDeviceToHost, st));
         SS_HIP(ctx, hipStreamSynchronize(st));
-        n_cand = h_total;
-        SS_HIP(ctx, ctx->splat_tiles.reserve((size_t)n_cand * sizeof(ss_real4<R>) + 64));
-        if (n_large) ss_launch_compact_blocks(lg_flag, lg_rank, n_active, lg_list, lg_slot, st);
-        ss_launch_splat_gather(PK, res->posvol.as<ss_real4<R>>(), res->posvol_by_index.as<ss_real4<R>>(), res->perm.as<uint32_t>(), ctx->cell_start.as<uint32_t>(),
-                               res->active_xyz.as<uint32_t>(), n_active, ctx->splat_counts.as<uint32_t>(), ctx->splat_off.as<unsigned long long>(),
-                               ctx->splat_tiles.as<ss_real4<R>>(), lg_list, n_large, st);
+        n_reserved = h_total;
+        SS_HIP(ctx, ctx->splat_tiles.reserve((size_t)n_reserved * sizeof(ss_real4<R>) + 64));
+        SS_HIP(ctx, hipMemsetAsync(lg_flag + n_active, 0, 4, st));
+        ss_launch_splat_gather(PK, res->posvol.as<ss_real4<R>>(), res->perm.as<uint32_t>(), ctx->cell_start.as<uint32_t>(), res->active_xyz.as<uint32_t>(), n_active,
+                               ctx->splat_off.as<unsigned long long>(), ctx->splat_tiles.as<ss_real4<R>>(), ctx->splat_counts.as<uint32_t>(), lg_flag, st);
+        // over-dense blocks: flags -> ordered list on the device; the workgroup-level gather reads its length there
+        s = exclusive_scan_u32<uint32_t>(ctx, lg_flag, lg_rank, (size_t)n_active + 1);
+        if (s != SS_OK) return s;
+        ss_launch_compact_blocks(lg_flag, lg_rank, n_active, lg_list, lg_slot, st);
+        ss_launch_splat_gather_large(PK, res->posvol.as<ss_real4<R>>(), res->posvol_by_index.as<ss_real4<R>>(), res->perm.as<uint32_t>(), ctx->cell_start.as<uint32_t>(),
+                                     res->active_xyz.as<uint32_t>(), lg_list, lg_rank + n_active, ctx->splat_counts.as<uint32_t>(), ctx->splat_off.as<unsigned long long>(),
+                                     ctx->splat_tiles.as<ss_real4<R>>(), st);
+        s = sum_u32_to_u64(ctx, ctx->splat_counts.as<uint32_t>(), n_active, ctx->counter.as<unsigned long long>());  // tile entries in use (statistics)
+        if (s != SS_OK) return s;
     }
     SS_HIP(ctx, hipEventRecord(ctx->ev[12], st));
     ss_launch_splat_accumulate(PK, ctx->splat_tiles.as<ss_real4<R>>(), ctx->splat_off.as<unsigned long long>(), ctx->splat_counts.as<uint32_t>(),
@@ -921,6 +925,10 @@ ss_status phase_finish(ss_context* ctx, ss_result* res) {
     uint32_t totals[2] = {0, 0};
     SS_HIP(ctx, hipMemcpyAsync(&totals[0], res->vbase.as<uint32_t>() + n_mc, 4, hipMemcpyDeviceToHost, st));
     SS_HIP(ctx, hipMemcpyAsync(&totals[1], res->tbase.as<uint32_t>() + n_mc, 4, hipMemcpyDeviceToHost, st));
+    unsigned long long n_cand = 0;
+    uint32_t n_large = 0;
+    SS_HIP(ctx, hipMemcpyAsync(&n_cand, ctx->counter.p, 8, hipMemcpyDeviceToHost, st));
+    if (n_active) SS_HIP(ctx, hipMemcpyAsync(&n_large, lg_rank + n_active, 4, hipMemcpyDeviceToHost, st));
     SS_HIP(ctx, hipStreamSynchronize(st));
     const uint64_t nv = totals[0], nt = totals[1];
     if (nt * 3 >= (1ull << 32)) return fail(ctx, SS_ERR_UNSUPPORTED, "more than 2^32/3 triangles in one call are not supported by this build");
@@ -962,12 +970,13 @@ ss_status phase_finish(ss_context* ctx, ss_result* res) {
     S.fast_div_verified = ctx->fastdiv_ok ? 1 : 0;
     S.arith_mode = (uint64_t)PK.arith;
     S.bytes_tile_arena = (uint64_t)n_cand * sizeof(ss_real4<R>);
+    S.bytes_tile_arena_reserved = (uint64_t)n_reserved * sizeof(ss_real4<R>);
     S.levelset_kernel_launches = n_active ? 1 : 0;
     size_t held = 0;
     for (const DevBuf* b : {&ctx->xyz_in, &ctx->xyz_filt, &ctx->flags32, &ctx->offsets, &ctx->keys_a, &ctx->keys_b, &ctx->vals_a, &ctx->cell_count,
                             &ctx->cell_start, &ctx->pos_sorted, &ctx->temp, &ctx->block_flag, &ctx->block_rank, &ctx->mc_flag, &ctx->mc_rank,
                             &ctx->vcount, &ctx->tcount, &ctx->member_count, &ctx->copy_offset, &ctx->ckeys_a, &ctx->ckeys_b, &ctx->cvals_a, &ctx->cidx,
-                            &ctx->cpos, &ctx->cell_count2, &ctx->cell_start2, &res->rho, &res->posvol, &ctx->splat_tiles, &ctx->splat_counts, &ctx->splat_off, &ctx->splat_overflow, &res->posvol_by_index, &res->perm, &res->inside8, &res->G, &res->block_slot,
+                            &ctx->cpos, &ctx->cell_count2, &ctx->cell_start2, &res->rho, &res->posvol, &ctx->splat_tiles, &ctx->splat_counts, &ctx->splat_off, &ctx->splat_bound, &ctx->splat_overflow, &res->posvol_by_index, &res->perm, &res->inside8, &res->G, &res->block_slot,
                             &res->active_list, &res->mc_list, &res->mc_slot, &res->masks, &res->vbase, &res->tbase, &res->vertices, &res->vkeys,
                             &res->tri32})
         held += b->cap;
@@ -1299,7 +1308,7 @@ void ss_context_destroy(ss_context* c) {
     for (DevBuf* b : {&c->xyz_in, &c->xyz_filt, &c->flags32, &c->offsets, &c->keys_a, &c->keys_b, &c->vals_a, &c->cell_count,
                       &c->cell_start, &c->pos_sorted, &c->temp, &c->aabb_partial, &c->aabb_out, &c->block_flag, &c->block_rank, &c->mc_flag,
                       &c->mc_rank, &c->vcount, &c->tcount, &c->counter, &c->member_count, &c->copy_offset, &c->sub_flag, &c->sub_rank,
-                      &c->nb_count, &c->nb_tmp, &c->occ_sub, &c->ckeys_a, &c->ckeys_b, &c->cvals_a, &c->cidx, &c->cpos, &c->cell_count2, &c->cell_start2, &c->gboxes, &c->fastdiv_scratch, &c->splat_overflow, &c->splat_tiles, &c->splat_counts, &c->splat_off})
+                      &c->nb_count, &c->nb_tmp, &c->occ_sub, &c->ckeys_a, &c->ckeys_b, &c->cvals_a, &c->cidx, &c->cpos, &c->cell_count2, &c->cell_start2, &c->gboxes, &c->fastdiv_scratch, &c->splat_overflow, &c->splat_tiles, &c->splat_counts, &c->splat_off, &c->splat_bound})
         b->release();
     for (DevBuf& b : c->post_pool) b.release();
     if (c->ev_ok)

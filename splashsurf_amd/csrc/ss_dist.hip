@@ -757,7 +757,9 @@ ss_status dist_reconstruct(ss_comm* c, const R* xyz_in, uint64_t n_local, const 
     const int pos_words = 3 * (int)(sizeof(R) / 4);
     s = pack_and_exchange(c, n_local, id0, nullptr, reinterpret_cast<const uint32_t*>(d_xyz), pos_words,
                           [&](int q) {
-                              if (boxes[q].empty) return false;
+                              if (boxes[q].empty || !n_local) return false;
+                              for (int d = 0; d < 3; ++d)  // nothing of this rank's input can lie in a box that misses its bounding box
+                                  if (mine_head.hi[d] < boxes[q].lo[d] || mine_head.lo[d] > boxes[q].hi[d]) return false;
                               hipLaunchKernelGGL(k_box_flags<R>, grid_for(n_local + 1), dim3(256), 0, st, d_xyz, n_local, boxes[q], (const uint32_t*)nullptr, c->flags.as<uint32_t>());
                               return true;
                           },
@@ -806,7 +808,9 @@ ss_status dist_reconstruct(ss_comm* c, const R* xyz_in, uint64_t n_local, const 
     const int rho_words = (int)(sizeof(R) / 4);
     s = pack_and_exchange(c, n_held, 0, c->gids.as<unsigned long long>(), reinterpret_cast<const uint32_t*>(res->rho.as<R>()), rho_words,
                           [&](int q) {
-                              if (q == me || boxes[q].empty) return false;
+                              if (q == me || boxes[q].empty || boxes[me].empty || !n_held) return false;
+                              for (int d = 0; d < 3; ++d)  // held particles lie inside this rank's grown box: only overlapping boxes can want them
+                                  if (boxes[me].hi[d] < boxes[q].lo[d] || boxes[me].lo[d] > boxes[q].hi[d]) return false;
                               hipLaunchKernelGGL(k_box_flags<R>, grid_for(n_held + 1), dim3(256), 0, st, c->L.as<R>(), n_held, boxes[q], c->owned.as<uint32_t>(), c->flags.as<uint32_t>());
                               return true;
                           },
@@ -897,7 +901,9 @@ ss_status dist_assemble(ss_comm* c, ss_result* res) {
     uint64_t n_rows = 0;
     s = pack_and_exchange(c, nv, 0, keys, reinterpret_cast<const uint32_t*>(c->gid_local.as<unsigned long long>()), 2,
                           [&](int q) {
-                              if (q == me || B.empty[q]) return false;
+                              if (q == me || B.empty[q] || B.empty[me] || !nv) return false;
+                              for (int d = 0; d < 3; ++d)  // closed point boxes that do not even touch share no edge
+                                  if (B.hi[me][d] < B.lo[q][d] || B.lo[me][d] > B.hi[q][d]) return false;
                               hipLaunchKernelGGL(k_vertex_flags, grid_for(nv + 1), dim3(256), 0, st, nv, c->owner.as<uint32_t>(), c->holder.as<unsigned long long>(), (uint32_t)me, q,
                                                  c->flags.as<uint32_t>());
                               return true;

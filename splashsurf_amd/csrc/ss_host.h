@@ -85,7 +85,7 @@ struct ss_context {
     bool ev_ok = false;
     DevBuf gboxes;  // global strategy: stencil boxes per particle chunk
     DevBuf splat_overflow;  // flags / ranks / list of level-set blocks whose tile is ordered by the workgroup-level gather
-    DevBuf splat_tiles, splat_counts, splat_off;  // tile arena (index-ordered candidates of every block, exact size), per-block counts and 64-bit offsets
+    DevBuf splat_tiles, splat_counts, splat_off, splat_bound;  // tile arena (index-ordered candidates of every block), per-block counts, 64-bit offsets, size bounds
     // post-processing: grow-only scratch slots handed out in call order (reset at the start of every ss_post_* call)
     DevBuf post_pool[24];
     int post_pool_next = 0;

@@ -658,11 +658,12 @@ void ss_launch_compact_blocks(const uint32_t* flag, const uint32_t* rank, uint32
 // K3: level-set splat in gather form.
 //
 // Work unit: one active block of 8x8x8 grid points.
-//   1. count   (k_splat_count, ONE WAVE per block): how many particles lie within reach of the block's points?  The (x, y)
-//      rows of search cells touching the dilated block box are contiguous runs of the cell-sorted particle array; the wave
-//      streams them and tests every particle against the box spanned by the block's points.  An exclusive scan of the counts
-//      gives every block its range in one tile arena of EXACTLY the total size (no fixed slots, no size limit per block).
-//   2. gather + order: the same scan again, survivors compacted into LDS, sorted by ORIGINAL particle index -- the
+//   1. bounds  (k_splat_bounds, one thread per block): the (x, y) rows of search cells touching the dilated block box are
+//      contiguous runs of the cell-sorted particle array; their total length (rows trimmed to the sphere's z extent) bounds the
+//      block's tile size from above at the price of two table look-ups per row.  An exclusive scan of the bounds gives every
+//      block its range in ONE tile arena (no fixed slots, no size limit per block; only the entries in use are touched).
+//   2. gather + order (ONE WAVE per block): the wave streams the rows, tests every particle against the box spanned by the
+//      block's points, compacts the survivors into LDS, sorts them by ORIGINAL particle index -- the
 //      reference's per-point summation order (sorted per-subdomain particle lists, dense_subdomains.rs:476-488) -- and the
 //      payload (x, y, z, V) written to the block's arena range in that order.  Up to SS_WTILE survivors: one wave per block
 //      (k_splat_gather: no workgroup barrier, rank sort by wave-wide compares).  More (over-dense input): one 512-thread
@@ -843,35 +844,37 @@ __device__ __forceinline__ bool splat_wave_block(uint32_t n_active, uint32_t* lo
     return *logical < n_active;
 }
 
-// step 1: counts[b] = particles within reach of block b; large_flag[b] = the tile needs the workgroup-level gather
+// step 1: bound[b] = particles in the (z-trimmed) search-cell rows a block's dilated box overlaps -- an upper bound of its tile
+// size that costs two table look-ups per row instead of a distance test per particle.  The exclusive scan of the bounds
+// places every block's tile in the arena; only counts[b] <= bound[b] entries of a range are ever written or read.
 template <class R>
-__global__ __launch_bounds__(256) void k_splat_count(SSDevT<R> P, const ss_real4<R>* __restrict__ posvol, const uint32_t* __restrict__ cell_start,
-                                                     const uint32_t* __restrict__ active_xyz, uint32_t n_active, uint32_t* __restrict__ counts,
-                                                     uint32_t* __restrict__ large_flag) {
-    __shared__ uint32_t s_row_start[4][64];
-    __shared__ uint32_t s_row_prefix[4][64];
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    uint32_t logical;
-    if (!splat_wave_block(n_active, &logical)) return;
-    const int b3[3] = {(int)active_xyz[3 * (size_t)logical], (int)active_xyz[3 * (size_t)logical + 1], (int)active_xyz[3 * (size_t)logical + 2]};
-    R plo[3], phi[3];
-    int klo[3], khi[3];
-    uint32_t count = 0;
-    if (splat_block_box<R>(P, b3, plo, phi, klo, khi))
-        splat_wave_scan<R, false>(P, posvol, nullptr, cell_start, klo, khi, plo, phi, s_row_start[w], s_row_prefix[w], lane,
-                                  [&](bool inside, uint32_t, uint32_t) { count += (uint32_t)__popcll(__ballot(inside)); });
-    if (lane == 0) {
-        counts[logical] = count;
-        large_flag[logical] = (count > (uint32_t)SS_WTILE) ? 1u : 0u;
+__global__ __launch_bounds__(256) void k_splat_bounds(SSDevT<R> P, const uint32_t* __restrict__ cell_start, const uint32_t* __restrict__ active_xyz, uint32_t n_active,
+                                                      uint32_t* __restrict__ bound) {
+    const uint32_t logical = blockIdx.x * blockDim.x + threadIdx.x;
+    if (logical > n_active) return;
+    uint32_t u = 0;
+    if (logical < n_active) {
+        const int b3[3] = {(int)active_xyz[3 * (size_t)logical], (int)active_xyz[3 * (size_t)logical + 1], (int)active_xyz[3 * (size_t)logical + 2]};
+        R plo[3], phi[3];
+        int klo[3], khi[3];
+        if (splat_block_box<R>(P, b3, plo, phi, klo, khi))
+            for (int kx = klo[0]; kx <= khi[0]; ++kx)
+                for (int ky = klo[1]; ky <= khi[1]; ++ky) {
+                    int zlo, zhi;
+                    if (splat_row_z_range<R>(P, kx, ky, klo, khi, plo, phi, &zlo, &zhi))
+                        u += cell_start[ss_cell_key(P, kx, ky, zhi) + 1u] - cell_start[ss_cell_key(P, kx, ky, zlo)];
+                }
     }
+    bound[logical] = u;  // entry n_active: 0, so that the exclusive scan ends with the arena size
 }
 
-// step 2, tiles of up to SS_WTILE entries: one wave per block
+// step 2, one wave per block: scan, filter, count; a tile of up to SS_WTILE entries is ordered and written right away, a larger one
+// (over-dense input) only reports its size and is left to the workgroup-level kernel below
 template <class R>
 __global__ __launch_bounds__(256) void k_splat_gather(SSDevT<R> P, const ss_real4<R>* __restrict__ posvol, const uint32_t* __restrict__ perm,
                                                       const uint32_t* __restrict__ cell_start, const uint32_t* __restrict__ active_xyz, uint32_t n_active,
-                                                      const uint32_t* __restrict__ counts, const unsigned long long* __restrict__ tile_off,
-                                                      ss_real4<R>* __restrict__ arena) {
+                                                      const unsigned long long* __restrict__ tile_off, ss_real4<R>* __restrict__ arena, uint32_t* __restrict__ counts,
+                                                      uint32_t* __restrict__ large_flag) {
     __shared__ uint32_t s_idx[4][SS_WTILE];
     __shared__ uint32_t s_src[4][SS_WTILE];
     __shared__ uint32_t s_row_start[4][64];
@@ -879,25 +882,28 @@ __global__ __launch_bounds__(256) void k_splat_gather(SSDevT<R> P, const ss_real
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     uint32_t logical;
     if (!splat_wave_block(n_active, &logical)) return;
-    const uint32_t expect = counts[logical];
-    if (expect == 0u || expect > (uint32_t)SS_WTILE) return;  // nothing to do / k_splat_gather_large's block
     const int b3[3] = {(int)active_xyz[3 * (size_t)logical], (int)active_xyz[3 * (size_t)logical + 1], (int)active_xyz[3 * (size_t)logical + 2]};
     R plo[3], phi[3];
     int klo[3], khi[3];
-    (void)splat_block_box<R>(P, b3, plo, phi, klo, khi);
     uint32_t count = 0;
-    const unsigned long long below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-    splat_wave_scan<R, true>(P, posvol, perm, cell_start, klo, khi, plo, phi, s_row_start[w], s_row_prefix[w], lane, [&](bool inside, uint32_t src, uint32_t id) {
-        const unsigned long long m = __ballot(inside);
-        const uint32_t pos = count + (uint32_t)__popcll(m & below);
-        if (inside && pos < (uint32_t)SS_WTILE) {  // pos < expect by construction (same test as the count pass)
-            s_idx[w][pos] = id;
-            s_src[w][pos] = src;
-        }
-        count += (uint32_t)__popcll(m);
-    });
+    if (splat_block_box<R>(P, b3, plo, phi, klo, khi)) {
+        const unsigned long long below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+        splat_wave_scan<R, true>(P, posvol, perm, cell_start, klo, khi, plo, phi, s_row_start[w], s_row_prefix[w], lane, [&](bool inside, uint32_t src, uint32_t id) {
+            const unsigned long long m = __ballot(inside);
+            const uint32_t pos = count + (uint32_t)__popcll(m & below);
+            if (inside && pos < (uint32_t)SS_WTILE) {
+                s_idx[w][pos] = id;
+                s_src[w][pos] = src;
+            }
+            count += (uint32_t)__popcll(m);
+        });
+    }
+    if (lane == 0) {
+        counts[logical] = count;
+        large_flag[logical] = (count > (uint32_t)SS_WTILE) ? 1u : 0u;
+    }
+    if (count > (uint32_t)SS_WTILE) return;
     ss_wave_lds_sync();
-    count = min(count, (uint32_t)SS_WTILE);
     // rank sort by original particle index (unique), payload written in that order
     ss_real4<R>* tile = arena + tile_off[logical];
     for (uint32_t e = (uint32_t)lane; e < count; e += 64u) {
@@ -981,21 +987,11 @@ __device__ inline void splat_for_each_candidate(S& s, const SSDevT<R>& P, const 
 // INDICES (the sort keys) go through LDS, up to CAP per pass; the payload is fetched in sorted order from the copy of
 // (x, y, z, V) kept in original particle order.  Tiles beyond CAP are written in several passes over ascending index ranges.
 template <class R, int CAP>
-__global__ __launch_bounds__(512) void k_splat_gather_large(SSDevT<R> P, const ss_real4<R>* __restrict__ posvol, const ss_real4<R>* __restrict__ posvol_by_index,
-                                                            const uint32_t* __restrict__ perm, const uint32_t* __restrict__ cell_start,
-                                                            const uint32_t* __restrict__ active_xyz, const uint32_t* __restrict__ large_list, uint32_t n_large,
-                                                            const uint32_t* __restrict__ counts, const unsigned long long* __restrict__ tile_off,
-                                                            ss_real4<R>* __restrict__ arena) {
-    __shared__ SplatShared<R, CAP> s;
+__device__ __forceinline__ void splat_gather_large_block(SplatShared<R, CAP>& s, const SSDevT<R>& P, const ss_real4<R>* __restrict__ posvol,
+                                                         const ss_real4<R>* __restrict__ posvol_by_index, const uint32_t* __restrict__ perm,
+                                                         const uint32_t* __restrict__ cell_start, const uint32_t* __restrict__ bxyz, uint32_t expect, ss_real4<R>* __restrict__ tile) {
     const int tid = threadIdx.x;
-    // XCD-aware: every XCD a contiguous range of the (spatially ordered) list
-    const uint32_t per_xcd = (n_large + 7u) / 8u;
-    const uint32_t it = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
-    if ((blockIdx.x >> 3) >= per_xcd || it >= n_large) return;
-    const uint32_t logical = large_list[it];
-    const uint32_t expect = counts[logical];
-    ss_real4<R>* tile = arena + tile_off[logical];
-    const int b3[3] = {(int)active_xyz[3 * (size_t)logical], (int)active_xyz[3 * (size_t)logical + 1], (int)active_xyz[3 * (size_t)logical + 2]};
+    const int b3[3] = {(int)bxyz[0], (int)bxyz[1], (int)bxyz[2]};
     R plo[3], phi[3];
     int klo[3], khi[3];
     if (!splat_block_box<R>(P, b3, plo, phi, klo, khi)) return;
@@ -1069,6 +1065,27 @@ __global__ __launch_bounds__(512) void k_splat_gather_large(SSDevT<R> P, const s
         }
         written += (uint32_t)n_tile;
         last = T;
+        __syncthreads();
+    }
+}
+
+template <class R, int CAP>
+__global__ __launch_bounds__(512) void k_splat_gather_large(SSDevT<R> P, const ss_real4<R>* __restrict__ posvol, const ss_real4<R>* __restrict__ posvol_by_index,
+                                                            const uint32_t* __restrict__ perm, const uint32_t* __restrict__ cell_start,
+                                                            const uint32_t* __restrict__ active_xyz, const uint32_t* __restrict__ large_list,
+                                                            const uint32_t* __restrict__ n_large_dev, const uint32_t* __restrict__ counts,
+                                                            const unsigned long long* __restrict__ tile_off, ss_real4<R>* __restrict__ arena) {
+    __shared__ SplatShared<R, CAP> s;
+    // the list lives on the device (the host never waits for its length; an empty list costs one trivial launch); persistent
+    // workgroups walk it, every XCD a contiguous range of the spatially ordered list
+    const uint32_t n_large = *n_large_dev;
+    const uint32_t per_xcd = (n_large + 7u) / 8u, xcd = blockIdx.x & 7u, stride = gridDim.x >> 3;
+    for (uint32_t j = blockIdx.x >> 3; j < per_xcd; j += stride) {
+        const uint32_t it = xcd * per_xcd + j;
+        if (it < n_large) {
+            const uint32_t logical = large_list[it];
+            splat_gather_large_block<R, CAP>(s, P, posvol, posvol_by_index, perm, cell_start, active_xyz + 3 * (size_t)logical, counts[logical], arena + tile_off[logical]);
+        }
         __syncthreads();
     }
 }
@@ -1273,24 +1290,26 @@ __global__ __launch_bounds__(512) void k_splat_accumulate(SSDevT<R> P, const ss_
 }
 
 template <class R>
-void ss_launch_splat_count(const SSDevT<R>& P, const ss_real4<R>* posvol, const uint32_t* cell_start, const uint32_t* active_xyz, uint32_t n_active,
-                           uint32_t* counts, uint32_t* large_flag, hipStream_t st) {
-    if (!n_active) return;
-    const uint32_t n_groups = (n_active + 3u) / 4u;
-    hipLaunchKernelGGL(k_splat_count<R>, dim3(((n_groups + 7u) / 8u) * 8u), dim3(256), 0, st, P, posvol, cell_start, active_xyz, n_active, counts, large_flag);
+void ss_launch_splat_bounds(const SSDevT<R>& P, const uint32_t* cell_start, const uint32_t* active_xyz, uint32_t n_active, uint32_t* bound, hipStream_t st) {
+    hipLaunchKernelGGL(k_splat_bounds<R>, dim3((n_active + 1u + 255u) / 256u), dim3(256), 0, st, P, cell_start, active_xyz, n_active, bound);
 }
 
 template <class R>
-void ss_launch_splat_gather(const SSDevT<R>& P, const ss_real4<R>* posvol, const ss_real4<R>* posvol_by_index, const uint32_t* perm, const uint32_t* cell_start,
-                            const uint32_t* active_xyz, uint32_t n_active, const uint32_t* counts, const unsigned long long* tile_off, ss_real4<R>* arena,
-                            const uint32_t* large_list, uint32_t n_large, hipStream_t st) {
+void ss_launch_splat_gather(const SSDevT<R>& P, const ss_real4<R>* posvol, const uint32_t* perm, const uint32_t* cell_start, const uint32_t* active_xyz, uint32_t n_active,
+                            const unsigned long long* tile_off, ss_real4<R>* arena, uint32_t* counts, uint32_t* large_flag, hipStream_t st) {
     if (!n_active) return;
     const uint32_t n_groups = (n_active + 3u) / 4u;
-    hipLaunchKernelGGL(k_splat_gather<R>, dim3(((n_groups + 7u) / 8u) * 8u), dim3(256), 0, st, P, posvol, perm, cell_start, active_xyz, n_active, counts, tile_off,
-                       arena);
-    if (n_large)
-        hipLaunchKernelGGL((k_splat_gather_large<R, SSTileCap<R>::value>), dim3(((n_large + 7u) / 8u) * 8u), dim3(512), 0, st, P, posvol, posvol_by_index, perm,
-                           cell_start, active_xyz, large_list, n_large, counts, tile_off, arena);
+    hipLaunchKernelGGL(k_splat_gather<R>, dim3(((n_groups + 7u) / 8u) * 8u), dim3(256), 0, st, P, posvol, perm, cell_start, active_xyz, n_active, tile_off, arena, counts,
+                       large_flag);
+}
+
+// the blocks k_splat_gather flagged (list and its length on the device)
+template <class R>
+void ss_launch_splat_gather_large(const SSDevT<R>& P, const ss_real4<R>* posvol, const ss_real4<R>* posvol_by_index, const uint32_t* perm, const uint32_t* cell_start,
+                                  const uint32_t* active_xyz, const uint32_t* large_list, const uint32_t* n_large_dev, const uint32_t* counts,
+                                  const unsigned long long* tile_off, ss_real4<R>* arena, hipStream_t st) {
+    hipLaunchKernelGGL((k_splat_gather_large<R, SSTileCap<R>::value>), dim3(2048), dim3(512), 0, st, P, posvol, posvol_by_index, perm, cell_start, active_xyz, large_list,
+                       n_large_dev, counts, tile_off, arena);
 }
 
 template <class R>
@@ -1601,10 +1620,12 @@ template void ss_launch_mark_blocks<float>(const SSDevT<float>& P, const uint32_
 template void ss_launch_mark_blocks<double>(const SSDevT<double>& P, const uint32_t* cell_start, uint32_t ncells, uint32_t* block_flag, hipStream_t st);
 template void ss_launch_mark_mc_blocks<float>(const SSDevT<float>& P, const uint32_t* block_slot, const ss_real2<float>* blk_minmax, uint32_t nblocks, uint32_t* mc_flag, hipStream_t st);
 template void ss_launch_mark_mc_blocks<double>(const SSDevT<double>& P, const uint32_t* block_slot, const ss_real2<double>* blk_minmax, uint32_t nblocks, uint32_t* mc_flag, hipStream_t st);
-template void ss_launch_splat_count<float>(const SSDevT<float>& P, const ss_real4<float>* posvol, const uint32_t* cell_start, const uint32_t* active_xyz, uint32_t n_active, uint32_t* counts, uint32_t* large_flag, hipStream_t st);
-template void ss_launch_splat_count<double>(const SSDevT<double>& P, const ss_real4<double>* posvol, const uint32_t* cell_start, const uint32_t* active_xyz, uint32_t n_active, uint32_t* counts, uint32_t* large_flag, hipStream_t st);
-template void ss_launch_splat_gather<float>(const SSDevT<float>& P, const ss_real4<float>* posvol, const ss_real4<float>* posvol_by_index, const uint32_t* perm, const uint32_t* cell_start, const uint32_t* active_xyz, uint32_t n_active, const uint32_t* counts, const unsigned long long* tile_off, ss_real4<float>* arena, const uint32_t* large_list, uint32_t n_large, hipStream_t st);
-template void ss_launch_splat_gather<double>(const SSDevT<double>& P, const ss_real4<double>* posvol, const ss_real4<double>* posvol_by_index, const uint32_t* perm, const uint32_t* cell_start, const uint32_t* active_xyz, uint32_t n_active, const uint32_t* counts, const unsigned long long* tile_off, ss_real4<double>* arena, const uint32_t* large_list, uint32_t n_large, hipStream_t st);
+template void ss_launch_splat_bounds<float>(const SSDevT<float>& P, const uint32_t* cell_start, const uint32_t* active_xyz, uint32_t n_active, uint32_t* bound, hipStream_t st);
+template void ss_launch_splat_gather<float>(const SSDevT<float>& P, const ss_real4<float>* posvol, const uint32_t* perm, const uint32_t* cell_start, const uint32_t* active_xyz, uint32_t n_active, const unsigned long long* tile_off, ss_real4<float>* arena, uint32_t* counts, uint32_t* large_flag, hipStream_t st);
+template void ss_launch_splat_gather_large<float>(const SSDevT<float>& P, const ss_real4<float>* posvol, const ss_real4<float>* posvol_by_index, const uint32_t* perm, const uint32_t* cell_start, const uint32_t* active_xyz, const uint32_t* large_list, const uint32_t* n_large_dev, const uint32_t* counts, const unsigned long long* tile_off, ss_real4<float>* arena, hipStream_t st);
+template void ss_launch_splat_bounds<double>(const SSDevT<double>& P, const uint32_t* cell_start, const uint32_t* active_xyz, uint32_t n_active, uint32_t* bound, hipStream_t st);
+template void ss_launch_splat_gather<double>(const SSDevT<double>& P, const ss_real4<double>* posvol, const uint32_t* perm, const uint32_t* cell_start, const uint32_t* active_xyz, uint32_t n_active, const unsigned long long* tile_off, ss_real4<double>* arena, uint32_t* counts, uint32_t* large_flag, hipStream_t st);
+template void ss_launch_splat_gather_large<double>(const SSDevT<double>& P, const ss_real4<double>* posvol, const ss_real4<double>* posvol_by_index, const uint32_t* perm, const uint32_t* cell_start, const uint32_t* active_xyz, const uint32_t* large_list, const uint32_t* n_large_dev, const uint32_t* counts, const unsigned long long* tile_off, ss_real4<double>* arena, hipStream_t st);
 template void ss_launch_splat_accumulate<float>(const SSDevT<float>& P, const ss_real4<float>* arena, const unsigned long long* tile_off, const uint32_t* counts, const uint32_t* active_xyz, uint32_t n_active, float* G, ss_real2<float>* blk_minmax, hipStream_t st);
 template void ss_launch_splat_accumulate<double>(const SSDevT<double>& P, const ss_real4<double>* arena, const unsigned long long* tile_off, const uint32_t* counts, const uint32_t* active_xyz, uint32_t n_active, double* G, ss_real2<double>* blk_minmax, hipStream_t st);
 template void ss_launch_mc_count<float>(const SSDevT<float>& P, const float* G, const uint32_t* block_slot, const uint32_t* mc_xyz, uint32_t n_mc, unsigned long long* masks, uint32_t* vcount, uint32_t* tcount, hipStream_t st);
