@@ -71,7 +71,7 @@ def _run_ranks(pts, prm, world, transport="local"):
     return out
 
 
-def _check_against_direct(pts, prm, ranks, gpu_ctx):
+def _check_against_direct(pts, prm, ranks, gpu_ctx, expect_shared=True):
     direct = gpu_ctx.reconstruct(pts, prm)
     U = np.uint32 if pts.dtype == np.float32 else np.uint64
     world = len(ranks)
@@ -107,8 +107,10 @@ def _check_against_direct(pts, prm, ranks, gpu_ctx):
     cmp = MC.compare_keyed(V, K, T, direct.mesh.vertices, direct.vertex_keys, direct.mesh.triangles)
     assert cmp["keys_equal"] and cmp["triangles_equal"] and cmp["vertices_bit_equal"], cmp
     if world > 1:
-        assert sum(r["local_counts"][0] for r in ranks) >= V.shape[0]  # (> when the surface crosses a brick face: shared vertices are emitted by every holder)
-        assert any(r["info"]["bytes_sent_positions"] > 0 for r in ranks) and any(r["info"]["bytes_sent_assembly"] > 0 for r in ranks)
+        assert any(r["info"]["bytes_sent_positions"] > 0 for r in ranks)
+        if expect_shared:  # the surface crosses brick faces: shared vertices are emitted by every holder and resolved through the owner
+            assert sum(r["local_counts"][0] for r in ranks) > V.shape[0]
+            assert any(r["info"]["bytes_sent_assembly"] > 0 for r in ranks)
     return direct
 
 
@@ -129,7 +131,7 @@ def test_native_more_ranks_than_subdomains(gpu_ctx):
     pts = np.load(os.path.join(DATA, "cube_2366_particles.npy")).astype(np.float32)
     prm = _params(0.025, 2.0, 0.75, 64, np.float32, 0)
     ranks = _run_ranks(pts, prm, 6)
-    direct = _check_against_direct(pts, prm, ranks, gpu_ctx)
+    direct = _check_against_direct(pts, prm, ranks, gpu_ctx, expect_shared=False)
     n_sub = int(np.prod(direct.subdomain_grid.ncells_per_dim))
     assert sum(1 for r in ranks if r["info"]["n_owned"] == 0) >= 6 - n_sub
 
