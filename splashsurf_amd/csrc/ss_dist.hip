@@ -405,7 +405,16 @@ __global__ __launch_bounds__(256) void k_owner_hist(const R* __restrict__ xyz, u
         int v = (int)ss_floor((xyz[3 * i + d] - g[d]) / sub_size);
         s[d] = max(0, min(ns[d] - 1, v));
     }
-    atomicAdd(&hist[((size_t)s[0] * ns1 + s[1]) * ns2 + s[2]], 1u);
+    // consecutive particles mostly share their subdomain: one atomic per distinct bin of a wave instead of one per particle
+    const uint32_t bin = (uint32_t)(((size_t)s[0] * ns1 + s[1]) * ns2 + s[2]);
+    unsigned long long todo = __ballot(true);
+    while (todo) {
+        const int leader = __ffsll((long long)todo) - 1;
+        const uint32_t lbin = (uint32_t)__shfl((int)bin, leader);
+        const unsigned long long same = __ballot(bin == lbin) & todo;
+        if ((int)(threadIdx.x & 63) == leader) atomicAdd(&hist[lbin], (uint32_t)__popcll(same));
+        todo &= ~same;
+    }
 }
 
 // flags[i] = particle i lies in the box (and is owned, if `owned` is given)
