@@ -868,6 +868,28 @@ __global__ __launch_bounds__(256) void k_splat_bounds(SSDevT<R> P, const uint32_
     bound[logical] = u;  // entry n_active: 0, so that the exclusive scan ends with the arena size
 }
 
+template <class R, int E>
+__device__ __forceinline__ void splat_rank_and_write(const uint32_t* s_idx, const uint32_t* s_src, uint32_t count, int lane, const ss_real4<R>* __restrict__ posvol,
+                                                     ss_real4<R>* __restrict__ tile) {
+    uint32_t my[E], rank[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const uint32_t i = (uint32_t)(e * 64 + lane);
+        my[e] = (i < count) ? s_idx[i] : 0u;
+        rank[e] = 0u;
+    }
+    for (uint32_t k = 0; k < count; ++k) {
+        const uint32_t v = s_idx[k];
+#pragma unroll
+        for (int e = 0; e < E; ++e) rank[e] += (v < my[e]) ? 1u : 0u;
+    }
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const uint32_t i = (uint32_t)(e * 64 + lane);
+        if (i < count) tile[rank[e]] = posvol[s_src[i]];
+    }
+}
+
 // step 2, one wave per block: scan, filter, count; a tile of up to SS_WTILE entries is ordered and written right away, a larger one
 // (over-dense input) only reports its size and is left to the workgroup-level kernel below
 template <class R>
@@ -907,12 +929,16 @@ __global__ __launch_bounds__(256) void k_splat_gather(SSDevT<R> P, const ss_real
     // rank sort by original particle index (unique), payload written in that order.  (An in-register bitonic network -- 28 / 36 /
     // 45 dependent stages through ds_bpermute for 128 / 256 / 512 keys -- issues a third of the instructions but measured
     // slower, 4.1 instead of 3.3 ms on S10M-tank: the rank sort's LDS broadcast reads are independent and pipeline.)
+    // Every lane ranks all of its (up to six) elements in ONE pass over the keys: one broadcast read serves them all.
     ss_real4<R>* tile = arena + tile_off[logical];
-    for (uint32_t e = (uint32_t)lane; e < count; e += 64u) {
-        const uint32_t my = s_idx[w][e];
-        uint32_t rank = 0;
-        for (uint32_t k = 0; k < count; ++k) rank += (s_idx[w][k] < my) ? 1u : 0u;
-        tile[rank] = posvol[s_src[w][e]];
+    switch ((count + 63u) >> 6) {
+        case 0: break;
+        case 1: splat_rank_and_write<R, 1>(s_idx[w], s_src[w], count, lane, posvol, tile); break;
+        case 2: splat_rank_and_write<R, 2>(s_idx[w], s_src[w], count, lane, posvol, tile); break;
+        case 3: splat_rank_and_write<R, 3>(s_idx[w], s_src[w], count, lane, posvol, tile); break;
+        case 4: splat_rank_and_write<R, 4>(s_idx[w], s_src[w], count, lane, posvol, tile); break;
+        case 5: splat_rank_and_write<R, 5>(s_idx[w], s_src[w], count, lane, posvol, tile); break;
+        default: splat_rank_and_write<R, 6>(s_idx[w], s_src[w], count, lane, posvol, tile); break;
     }
 }
 
