@@ -151,13 +151,15 @@ typedef struct ss_stats {
     uint64_t levelset_kernel_launches;
     uint64_t bytes_device_peak;       /* HBM held by the context after this call */
     double ms_levelset_gather;        /* part of ms_levelset: k_splat_count + offsets + k_splat_gather[_large] (index-ordered candidate tiles) */
-    double ms_levelset_accumulate;    /* part of ms_levelset: k_splat_accumulate (the arithmetic; the dominant kernel) */
+    double ms_levelset_accumulate;    /* part of ms_levelset: k_splat_accumulate (the arithmetic; the dominant kernel), both passes */
     uint64_t n_large_tile_blocks;     /* blocks whose candidate tile (> 384 entries) was ordered by the workgroup-level gather */
     uint64_t arith_mode;              /* arithmetic of the level-set accumulation that ran: 0 scalar (generic sqrt/divide), 1 scalar
                                        * (lean exact sqrt + verified reciprocal division), 2 / 3 SIMD with correctly rounded sqrt
                                        * (generic / lean), 4 SIMD with v_sqrt_f32 */
     uint64_t bytes_tile_arena;        /* bytes of index-ordered candidate tiles written by the gather and re-read by the accumulate kernel */
     uint64_t bytes_tile_arena_reserved; /* size of the arena those tiles live in (ranges sized by a cheap per-block upper bound) */
+    uint64_t n_truncated_blocks;      /* active blocks left with truncated (lower-bound) level-set values: inside the fluid, never read by MC */
+    uint64_t n_completed_blocks;      /* truncated blocks next to the surface that the second splat pass evaluated in full */
 } ss_stats;
 
 typedef struct ss_context ss_context;
@@ -169,6 +171,14 @@ ss_status ss_context_create(int device_id, ss_context **out);
 void ss_context_destroy(ss_context *ctx);
 const char *ss_last_error(const ss_context *ctx);
 int ss_last_error_detail(const ss_context *ctx);
+/* Context options.  SS_OPTION_FULL_LEVELSET (default 0): 1 = evaluate the level set completely at every grid point of every
+ * active block.  By default a 4x4x4 sub-block whose running values have all passed the iso-surface threshold stops
+ * accumulating (all terms are >= 0, so it is known to lie inside the fluid), and only those truncated blocks that marching
+ * cubes reads -- blocks next to a sign change -- are completed by a second pass: mesh, densities and every level-set value
+ * that influences them are unchanged, values deep inside the fluid are lower bounds.  Set it before ss_result_levelset_box
+ * is used to inspect values away from the surface. */
+enum { SS_OPTION_FULL_LEVELSET = 1 };
+ss_status ss_context_set_option(ss_context *ctx, int option, int value);
 /* use an existing HIP stream (hipStream_t passed as void*); NULL = context's own stream */
 ss_status ss_context_set_stream(ss_context *ctx, void *hip_stream);
 

@@ -112,6 +112,8 @@ class _Stats(C.Structure):
         ("arith_mode", C.c_uint64),
         ("bytes_tile_arena", C.c_uint64),
         ("bytes_tile_arena_reserved", C.c_uint64),
+        ("n_truncated_blocks", C.c_uint64),
+        ("n_completed_blocks", C.c_uint64),
     ]
 
 
@@ -329,6 +331,14 @@ class Context:
             raise GridConstructionError(st, msg)
         raise SplashsurfError(st, msg)
 
+    def set_full_levelset(self, on=True):
+        """SS_OPTION_FULL_LEVELSET: evaluate the level set completely everywhere (no early exit inside the fluid); needed before
+        `SurfaceReconstruction.levelset_box` is used to look at values away from the surface."""
+        self._lib.ss_context_set_option.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        st = self._lib.ss_context_set_option(self._h, 1, 1 if on else 0)
+        if st != 0:
+            self._raise(st)
+
     def set_stream(self, hip_stream_ptr):
         st = self._lib.ss_context_set_stream(self._h, C.c_void_p(hip_stream_ptr))
         if st != 0:
@@ -535,6 +545,9 @@ class SurfaceReconstruction:
         return {k: getattr(s, k) for k, _ in _Stats._fields_}
 
     def levelset_box(self, lo, extent):
+        if self.stats.get("n_truncated_blocks", 0):
+            raise RuntimeError("this reconstruction stopped accumulating inside the fluid (values there are lower bounds); call "
+                               "Context.set_full_levelset(True) before reconstructing to inspect the complete level set")
         lo_a = (C.c_int64 * 3)(*[int(x) for x in lo])
         ex_a = (C.c_int64 * 3)(*[int(x) for x in extent])
         f64 = self.is_f64

@@ -254,7 +254,7 @@ ss_status make_device_params(ss_context* ctx, const typename TypesOf<R>::params*
 
 ss_status ensure_events(ss_context* ctx) {
     if (ctx->ev_ok) return SS_OK;
-    for (int i = 0; i < 14; ++i) SS_HIP(ctx, hipEventCreate(&ctx->ev[i]));
+    for (int i = 0; i < 16; ++i) SS_HIP(ctx, hipEventCreate(&ctx->ev[i]));
     ctx->ev_ok = true;
     return SS_OK;
 }
@@ -887,13 +887,33 @@ ss_status phase_finish(ss_context* ctx, ss_result* res) {
         if (s != SS_OK) return s;
     }
     SS_HIP(ctx, hipEventRecord(ctx->ev[12], st));
+    // first pass: every active block; sub-blocks that turn out to lie inside the fluid stop early (ss_kernels.hip, splat_accumulate_wave)
+    SS_HIP(ctx, ctx->splat_trunc.reserve(((size_t)n_active + 1) * 4 * 4 + 64));
+    uint32_t* tr_flag = ctx->splat_trunc.as<uint32_t>();          // block carries truncated values
+    uint32_t* rd_flag = tr_flag + ((size_t)n_active + 1);         // ... and marching cubes will read it
+    uint32_t* rd_rank = rd_flag + ((size_t)n_active + 1);
+    uint32_t* rd_list = rd_rank + ((size_t)n_active + 1);
     ss_launch_splat_accumulate(PK, ctx->splat_tiles.as<ss_real4<R>>(), ctx->splat_off.as<unsigned long long>(), ctx->splat_counts.as<uint32_t>(),
-                               res->active_xyz.as<uint32_t>(), n_active, res->G.as<R>(), res->blk_minmax.as<ss_real2<R>>(), st);
+                               res->active_xyz.as<uint32_t>(), n_active, res->G.as<R>(), res->blk_minmax.as<ss_real2<R>>(), tr_flag, ctx->full_levelset, nullptr, nullptr, st);
     SS_HIP(ctx, hipEventRecord(ctx->ev[13], st));
-    SS_HIP(ctx, hipEventRecord(ctx->ev[6], st));
 
     // ---- K4 prepare: MC blocks = blocks whose 2x2x2 level-set neighbourhood straddles the threshold ----
     ss_launch_mark_mc_blocks(P, res->block_slot.as<uint32_t>(), res->blk_minmax.as<ss_real2<R>>(), (uint32_t)nblocks, ctx->mc_flag.as<uint32_t>(), st);
+    // second pass of the splat: truncated blocks that marching cubes is going to read are completed (list and count stay on the device)
+    SS_HIP(ctx, hipEventRecord(ctx->ev[14], st));
+    if (n_active && !ctx->full_levelset) {
+        SS_HIP(ctx, hipMemsetAsync(rd_flag, 0, ((size_t)n_active + 1) * 4, st));
+        ss_launch_mark_redo_blocks(P, ctx->mc_flag.as<uint32_t>(), res->block_slot.as<uint32_t>(), tr_flag, (uint32_t)nblocks, rd_flag, st);
+        s = exclusive_scan_u32<uint32_t>(ctx, rd_flag, rd_rank, (size_t)n_active + 1);
+        if (s != SS_OK) return s;
+        ss_launch_compact_blocks(rd_flag, rd_rank, n_active, rd_list, lg_slot, st);
+        ss_launch_splat_accumulate(PK, ctx->splat_tiles.as<ss_real4<R>>(), ctx->splat_off.as<unsigned long long>(), ctx->splat_counts.as<uint32_t>(),
+                                   res->active_xyz.as<uint32_t>(), n_active, res->G.as<R>(), res->blk_minmax.as<ss_real2<R>>(), tr_flag, true, rd_list, rd_rank + n_active, st);
+        s = sum_u32_to_u64(ctx, tr_flag, n_active, ctx->counter.as<unsigned long long>() + 1);  // blocks still truncated (statistics)
+        if (s != SS_OK) return s;
+    }
+    SS_HIP(ctx, hipEventRecord(ctx->ev[15], st));
+    SS_HIP(ctx, hipEventRecord(ctx->ev[6], st));
     s = exclusive_scan_u32<uint32_t>(ctx, ctx->mc_flag.as<uint32_t>(), ctx->mc_rank.as<uint32_t>(), nblocks + 1);
     if (s != SS_OK) return s;
     uint32_t n_mc = 0;
@@ -929,6 +949,12 @@ ss_status phase_finish(ss_context* ctx, ss_result* res) {
     uint32_t n_large = 0;
     SS_HIP(ctx, hipMemcpyAsync(&n_cand, ctx->counter.p, 8, hipMemcpyDeviceToHost, st));
     if (n_active) SS_HIP(ctx, hipMemcpyAsync(&n_large, lg_rank + n_active, 4, hipMemcpyDeviceToHost, st));
+    unsigned long long n_trunc_left = 0;
+    uint32_t n_redo = 0;
+    if (n_active && !ctx->full_levelset) {
+        SS_HIP(ctx, hipMemcpyAsync(&n_trunc_left, ctx->counter.as<unsigned long long>() + 1, 8, hipMemcpyDeviceToHost, st));
+        SS_HIP(ctx, hipMemcpyAsync(&n_redo, rd_rank + n_active, 4, hipMemcpyDeviceToHost, st));
+    }
     SS_HIP(ctx, hipStreamSynchronize(st));
     const uint64_t nv = totals[0], nt = totals[1];
     if (nt * 3 >= (1ull << 32)) return fail(ctx, SS_ERR_UNSUPPORTED, "more than 2^32/3 triangles in one call are not supported by this build");
@@ -958,7 +984,7 @@ ss_status phase_finish(ss_context* ctx, ss_result* res) {
     S.ms_levelset_prepare = ev_ms(ctx, 11, 5);
     S.ms_levelset = ev_ms(ctx, 5, 6);
     S.ms_levelset_gather = ev_ms(ctx, 5, 12);
-    S.ms_levelset_accumulate = ev_ms(ctx, 12, 13);
+    S.ms_levelset_accumulate = ev_ms(ctx, 12, 13) + ev_ms(ctx, 14, 15);  // both passes of k_splat_accumulate (the second incl. its block selection)
     S.ms_marching_cubes = ev_ms(ctx, 6, 7) + ev_ms(ctx, 8, 9);
     S.ms_stitching = ev_ms(ctx, 7, 8);
     S.n_particles = n;
@@ -971,6 +997,8 @@ ss_status phase_finish(ss_context* ctx, ss_result* res) {
     S.arith_mode = (uint64_t)PK.arith;
     S.bytes_tile_arena = (uint64_t)n_cand * sizeof(ss_real4<R>);
     S.bytes_tile_arena_reserved = (uint64_t)n_reserved * sizeof(ss_real4<R>);
+    S.n_truncated_blocks = n_trunc_left;
+    S.n_completed_blocks = n_redo;
     S.levelset_kernel_launches = n_active ? 1 : 0;
     size_t held = 0;
     for (const DevBuf* b : {&ctx->xyz_in, &ctx->xyz_filt, &ctx->flags32, &ctx->offsets, &ctx->keys_a, &ctx->keys_b, &ctx->vals_a, &ctx->cell_count,
@@ -1308,17 +1336,26 @@ void ss_context_destroy(ss_context* c) {
     for (DevBuf* b : {&c->xyz_in, &c->xyz_filt, &c->flags32, &c->offsets, &c->keys_a, &c->keys_b, &c->vals_a, &c->cell_count,
                       &c->cell_start, &c->pos_sorted, &c->temp, &c->aabb_partial, &c->aabb_out, &c->block_flag, &c->block_rank, &c->mc_flag,
                       &c->mc_rank, &c->vcount, &c->tcount, &c->counter, &c->member_count, &c->copy_offset, &c->sub_flag, &c->sub_rank,
-                      &c->nb_count, &c->nb_tmp, &c->occ_sub, &c->ckeys_a, &c->ckeys_b, &c->cvals_a, &c->cidx, &c->cpos, &c->cell_count2, &c->cell_start2, &c->gboxes, &c->fastdiv_scratch, &c->splat_overflow, &c->splat_tiles, &c->splat_counts, &c->splat_off, &c->splat_bound})
+                      &c->nb_count, &c->nb_tmp, &c->occ_sub, &c->ckeys_a, &c->ckeys_b, &c->cvals_a, &c->cidx, &c->cpos, &c->cell_count2, &c->cell_start2, &c->gboxes, &c->fastdiv_scratch, &c->splat_overflow, &c->splat_tiles, &c->splat_counts, &c->splat_off, &c->splat_bound, &c->splat_trunc})
         b->release();
     for (DevBuf& b : c->post_pool) b.release();
     if (c->ev_ok)
-        for (int i = 0; i < 14; ++i) (void)hipEventDestroy(c->ev[i]);
+        for (int i = 0; i < 16; ++i) (void)hipEventDestroy(c->ev[i]);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
 }
 
 const char* ss_last_error(const ss_context* c) { return c ? c->err.c_str() : "null context"; }
 int ss_last_error_detail(const ss_context* c) { return c ? c->err_detail : 0; }
+
+ss_status ss_context_set_option(ss_context* c, int option, int value) {
+    if (!c) return SS_ERR_INVALID_ARGUMENT;
+    if (option == SS_OPTION_FULL_LEVELSET) {
+        c->full_levelset = value != 0;
+        return SS_OK;
+    }
+    return fail(c, SS_ERR_INVALID_ARGUMENT, "unknown context option");
+}
 
 ss_status ss_context_set_stream(ss_context* c, void* hip_stream) {
     if (!c) return SS_ERR_INVALID_ARGUMENT;

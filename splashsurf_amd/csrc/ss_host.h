@@ -77,7 +77,8 @@ struct ss_context {
     // per-subdomain particle copies for the density stage
     DevBuf nb_count, nb_tmp;
     DevBuf member_count, copy_offset, sub_flag, sub_rank, occ_sub, ckeys_a, ckeys_b, cvals_a, cidx, cpos, cell_count2, cell_start2;
-    hipEvent_t ev[14];  // 0..9 stage boundaries, 10/11 start of phase 2
+    hipEvent_t ev[16];  // 0..9 stage boundaries, 10/11 start of phase 2, 12..15 inside the splat
+    bool full_levelset = false;  // SS_OPTION_FULL_LEVELSET: no early exit in the splat (complete level-set values everywhere)
     // exhaustively verified "division by h via reciprocal + 2 FMA" (ss_kernels.hip ss_div_by_h)
     DevBuf fastdiv_scratch;
     float fastdiv_h = 0.0f;
@@ -85,6 +86,7 @@ struct ss_context {
     bool ev_ok = false;
     DevBuf gboxes;  // global strategy: stencil boxes per particle chunk
     DevBuf splat_overflow;  // flags / ranks / list of level-set blocks whose tile is ordered by the workgroup-level gather
+    DevBuf splat_trunc;  // per active block: truncated flag, needed-by-MC flag, its scan and the list of blocks to complete
     DevBuf splat_tiles, splat_counts, splat_off, splat_bound;  // tile arena (index-ordered candidates of every block), per-block counts, 64-bit offsets, size bounds
     // post-processing: grow-only scratch slots handed out in call order (reset at the start of every ss_post_* call)
     DevBuf post_pool[24];

@@ -1168,9 +1168,16 @@ __device__ __forceinline__ R ss_splat_pair(const SSDevT<R>& P, R rh, const ss_re
 // Phase A tests 64 tile entries at once against the sub-block's box; the survivors are compacted IN ORDER into the wave's
 // own list `wl` (SS_WAVE_LIST entries), which phase B then walks front to back with a plain counter -- the scalar unit is
 // shared by the four SIMDs of a CU and walking a 64-bit survivor mask cost 14 scalar instructions per entry.
-template <class R, int ARITH>
+//
+// EARLY (the first pass over all blocks): every term of the sum is >= 0 and rounding is monotone, so a running value above the
+// iso-surface threshold can only grow -- as soon as ALL points of the wave are above it, the wave is known to lie inside the
+// fluid and stops (`done`).  Such a sub-block carries truncated values; marching cubes never reads values of a block that is
+// not next to a sign change, and the few truncated blocks that ARE next to one are recomputed in full by the second pass
+// (k_splat_accumulate_list, see k_mark_redo_blocks).  Deep inside the fluid -- most blocks of a bulk of fluid -- this saves
+// the last third of the tile.
+template <class R, int ARITH, bool EARLY>
 __device__ __forceinline__ R splat_accumulate_wave(const SSDevT<R>& P, const ss_real4<R>* pay, ss_real4<R>* wl, int n_tile, int lane, R px, R py, R pz,
-                                                   const R slo[3], const R shi[3], R acc) {
+                                                   const R slo[3], const R shi[3], R acc, bool lane_counts, bool& done) {
     const R rh = R(1.0) / P.h;
     for (int base = 0; base < n_tile; base += 64) {
         const int c = base + lane;
@@ -1199,6 +1206,12 @@ __device__ __forceinline__ R splat_accumulate_wave(const SSDevT<R>& P, const ss_
                 if (k + 1 >= cnt) break;
                 ea = wl[k + 2];
                 acc = ss_splat_pair<R, ARITH>(P, rh, eb, px, py, pz, acc);
+                if constexpr (EARLY) {
+                    if (__ballot(acc > P.threshold || !lane_counts) == ~0ull) {  // dense_subdomains.rs:1482: inside <=> value > threshold
+                        done = true;
+                        return acc;
+                    }
+                }
                 if (k + 2 >= cnt) break;
             }
         }
@@ -1231,28 +1244,31 @@ __device__ __forceinline__ float ss_wave_reduce_to_lane63(float v) {
 }
 
 // step 3
-template <class R, int ARITH>
-__global__ __launch_bounds__(512) void k_splat_accumulate(SSDevT<R> P, const ss_real4<R>* __restrict__ arena, const unsigned long long* __restrict__ tile_off,
-                                                          const uint32_t* __restrict__ counts, const uint32_t* __restrict__ active_xyz, uint32_t n_active,
-                                                          R* __restrict__ G, ss_real2<R>* __restrict__ blk_minmax) {
-    __shared__ ss_real4<R> s_pay[SS_WTILE];
-    __shared__ ss_real4<R> s_wl[8][SS_WAVE_LIST];
-    __shared__ R s_red[16];
+template <class R>
+struct SplatAccShared {
+    ss_real4<R> pay[SS_WTILE];
+    ss_real4<R> wl[8][SS_WAVE_LIST];
+    R red[16];
+    uint32_t trunc;
+};
+
+template <class R, int ARITH, bool EARLY>
+__device__ __forceinline__ void splat_accumulate_block(SplatAccShared<R>& sh, const SSDevT<R>& P, uint32_t logical, const ss_real4<R>* __restrict__ arena,
+                                                       const unsigned long long* __restrict__ tile_off, const uint32_t* __restrict__ counts,
+                                                       const uint32_t* __restrict__ active_xyz, R* __restrict__ G, ss_real2<R>* __restrict__ blk_minmax,
+                                                       uint32_t* __restrict__ trunc) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    // XCD-aware mapping: hardware places workgroup w on XCD w % 8; give each XCD a contiguous range of
-    // the (spatially ordered) active list so that neighbouring blocks share an L2.
-    const uint32_t per_xcd = (n_active + 7u) / 8u;
-    const uint32_t logical = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
-    if ((blockIdx.x >> 3) >= per_xcd || logical >= n_active) return;
     const int n_tile = (int)counts[logical];
     const ss_real4<R>* tile = arena + tile_off[logical];
     ss_real4<R> nxt = ss_make4(R(0.0), R(0.0), R(0.0), R(0.0));
     if (tid < min(n_tile, SS_WTILE)) nxt = tile[tid];  // first chunk in flight while the coordinates are set up
+    if (tid == 0) sh.trunc = 0u;
     const int bx = (int)active_xyz[3 * (size_t)logical], by = (int)active_xyz[3 * (size_t)logical + 1], bz = (int)active_xyz[3 * (size_t)logical + 2];
     // this wave's sub-block and this lane's grid point
     const int g0[3] = {bx * SS_BLOCK + ((wave >> 2) & 1) * 4, by * SS_BLOCK + ((wave >> 1) & 1) * 4, bz * SS_BLOCK + (wave & 1) * 4};
     const int gl[3] = {g0[0] + ((lane >> 4) & 3), g0[1] + ((lane >> 2) & 3), g0[2] + (lane & 3)};
     const bool wave_valid = g0[0] < P.np[0] && g0[1] < P.np[1] && g0[2] < P.np[2];
+    const bool point_valid = gl[0] < P.np[0] && gl[1] < P.np[1] && gl[2] < P.np[2];
     // global point coordinates: uniform_grid.rs:418-425 on the GLOBAL grid (dense_subdomains.rs:817-826); the SIMD loop of the
     // reference forms z with one fma (:1069), x and y like the scalar loop (:1113-1114)
     const R px = P.gmin[0] + (R)gl[0] * P.cs;
@@ -1269,30 +1285,32 @@ __global__ __launch_bounds__(512) void k_splat_accumulate(SSDevT<R> P, const ss_
         shi[d] = P.gmin[d] + (R)min(g0[d] + 3, P.np[d] - 1) * P.cs;
     }
     R acc = R(0.0);  // levelset_grid.fill(0), dense_subdomains.rs:1390
+    bool done = false;
     for (int c0 = 0; c0 < n_tile; c0 += SS_WTILE) {
         const int nc = min(SS_WTILE, n_tile - c0);
-        if (tid < nc) s_pay[tid] = nxt;
+        if (tid < nc) sh.pay[tid] = nxt;
         __syncthreads();
         if (c0 + SS_WTILE + tid < n_tile && tid < SS_WTILE) nxt = tile[c0 + SS_WTILE + tid];  // next chunk in flight during the arithmetic
-        if (wave_valid) acc = splat_accumulate_wave<R, ARITH>(P, s_pay, s_wl[wave], nc, lane, px, py, pz, slo, shi, acc);
-        if (c0 + SS_WTILE < n_tile) __syncthreads();  // s_pay is overwritten by the next trip
+        if (wave_valid && !done) acc = splat_accumulate_wave<R, ARITH, EARLY>(P, sh.pay, sh.wl[wave], nc, lane, px, py, pz, slo, shi, acc, point_valid, done);
+        if (c0 + SS_WTILE < n_tile) __syncthreads();  // pay is overwritten by the next trip
     }
+    if (EARLY && done && lane == 0) atomicOr(&sh.trunc, 1u);
     // store: block-local layout (x*8+y)*8+z, i-major / k-fastest like dense_subdomains.rs:839
     const int lx = ((wave >> 2) & 1) * 4 + ((lane >> 4) & 3);
     const int ly = ((wave >> 1) & 1) * 4 + ((lane >> 2) & 3);
     const int lz = (wave & 1) * 4 + (lane & 3);
-    const bool point_valid = gl[0] < P.np[0] && gl[1] < P.np[1] && gl[2] < P.np[2];
     const R val = point_valid ? acc : R(0.0);
     G[(size_t)logical * SS_BLOCK_POINTS + (size_t)((lx * 8 + ly) * 8 + lz)] = val;
-    // block-wide min/max of the level-set values (points outside the grid count as 0 = "outside"),
-    // used to skip marching cubes on blocks that cannot contain the iso-surface
+    // block-wide min/max of the level-set values (points outside the grid count as 0 = "outside"), used to skip marching cubes
+    // on blocks that cannot contain the iso-surface; a truncated wave reports values that are all above the threshold, like
+    // its complete values would be
     R mn = val, mx = val;
     if constexpr (sizeof(R) == 4) {
         mn = ss_wave_reduce_to_lane63<false>(mn);
         mx = ss_wave_reduce_to_lane63<true>(mx);
         if (lane == 63) {
-            s_red[wave] = mn;
-            s_red[8 + wave] = mx;
+            sh.red[wave] = mn;
+            sh.red[8 + wave] = mx;
         }
     } else {
 #pragma unroll
@@ -1301,20 +1319,69 @@ __global__ __launch_bounds__(512) void k_splat_accumulate(SSDevT<R> P, const ss_
             mx = ss_max(mx, __shfl_xor(mx, off));
         }
         if (lane == 0) {
-            s_red[wave] = mn;
-            s_red[8 + wave] = mx;
+            sh.red[wave] = mn;
+            sh.red[8 + wave] = mx;
         }
     }
     __syncthreads();
     if (tid == 0) {
-        mn = s_red[0];
-        mx = s_red[8];
+        mn = sh.red[0];
+        mx = sh.red[8];
         for (int q = 1; q < 8; ++q) {
-            mn = ss_min(mn, s_red[q]);
-            mx = ss_max(mx, s_red[8 + q]);
+            mn = ss_min(mn, sh.red[q]);
+            mx = ss_max(mx, sh.red[8 + q]);
         }
         blk_minmax[logical] = ss_make2(mn, mx);
+        trunc[logical] = EARLY ? sh.trunc : 0u;
     }
+}
+
+// first pass: every active block, early exit for sub-blocks inside the fluid (unless the caller wants the complete level set)
+template <class R, int ARITH, bool EARLY>
+__global__ __launch_bounds__(512) void k_splat_accumulate(SSDevT<R> P, const ss_real4<R>* __restrict__ arena, const unsigned long long* __restrict__ tile_off,
+                                                          const uint32_t* __restrict__ counts, const uint32_t* __restrict__ active_xyz, uint32_t n_active,
+                                                          R* __restrict__ G, ss_real2<R>* __restrict__ blk_minmax, uint32_t* __restrict__ trunc) {
+    __shared__ SplatAccShared<R> sh;
+    // XCD-aware mapping: hardware places workgroup w on XCD w % 8; give each XCD a contiguous range of
+    // the (spatially ordered) active list so that neighbouring blocks share an L2.
+    const uint32_t per_xcd = (n_active + 7u) / 8u;
+    const uint32_t logical = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
+    if ((blockIdx.x >> 3) >= per_xcd || logical >= n_active) return;
+    splat_accumulate_block<R, ARITH, EARLY>(sh, P, logical, arena, tile_off, counts, active_xyz, G, blk_minmax, trunc);
+}
+
+// second pass: the truncated blocks marching cubes will read (list and its length on the device), in full
+template <class R, int ARITH>
+__global__ __launch_bounds__(512) void k_splat_accumulate_list(SSDevT<R> P, const ss_real4<R>* __restrict__ arena, const unsigned long long* __restrict__ tile_off,
+                                                               const uint32_t* __restrict__ counts, const uint32_t* __restrict__ active_xyz,
+                                                               const uint32_t* __restrict__ list, const uint32_t* __restrict__ n_list_dev, R* __restrict__ G,
+                                                               ss_real2<R>* __restrict__ blk_minmax, uint32_t* __restrict__ trunc) {
+    __shared__ SplatAccShared<R> sh;
+    const uint32_t n = *n_list_dev;
+    for (uint32_t it = blockIdx.x; it < n; it += gridDim.x) {
+        splat_accumulate_block<R, ARITH, false>(sh, P, list[it], arena, tile_off, counts, active_xyz, G, blk_minmax, trunc);
+        __syncthreads();
+    }
+}
+
+// A truncated block has to be completed iff marching cubes reads it: MC block m reads the level-set blocks m + {0,1}^3, and only
+// MC blocks whose eight blocks straddle the threshold are triangulated (k_mark_mc_blocks).
+template <class R>
+__global__ __launch_bounds__(256) void k_mark_redo_blocks(SSDevT<R> P, const uint32_t* __restrict__ mc_flag, const uint32_t* __restrict__ block_slot,
+                                                          const uint32_t* __restrict__ trunc, uint32_t nblocks, uint32_t* __restrict__ redo_flag) {
+    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= nblocks || !mc_flag[b]) return;
+    const int bz = (int)(b % (uint32_t)P.nb[2]);
+    const int by = (int)((b / (uint32_t)P.nb[2]) % (uint32_t)P.nb[1]);
+    const int bx = (int)(b / ((uint32_t)P.nb[2] * (uint32_t)P.nb[1]));
+    for (int dx = 0; dx <= 1; ++dx)
+        for (int dy = 0; dy <= 1; ++dy)
+            for (int dz = 0; dz <= 1; ++dz) {
+                const int x = bx + dx, y = by + dy, z = bz + dz;
+                if (x >= P.nb[0] || y >= P.nb[1] || z >= P.nb[2]) continue;
+                const uint32_t slot = block_slot[((size_t)x * P.nb[1] + y) * P.nb[2] + z];
+                if (slot != 0xFFFFFFFFu && trunc[slot]) redo_flag[slot] = 1u;  // plain flag stores (all writers store 1)
+            }
 }
 
 template <class R>
@@ -1340,12 +1407,23 @@ void ss_launch_splat_gather_large(const SSDevT<R>& P, const ss_real4<R>* posvol,
                        n_large_dev, counts, tile_off, arena);
 }
 
+// list == nullptr: first pass over all n_active blocks (early exit unless full_levelset); otherwise the second pass over the
+// device-side list of truncated blocks marching cubes needs
 template <class R>
 void ss_launch_splat_accumulate(const SSDevT<R>& P, const ss_real4<R>* arena, const unsigned long long* tile_off, const uint32_t* counts,
-                                const uint32_t* active_xyz, uint32_t n_active, R* G, ss_real2<R>* blk_minmax, hipStream_t st) {
+                                const uint32_t* active_xyz, uint32_t n_active, R* G, ss_real2<R>* blk_minmax, uint32_t* trunc, bool full_levelset,
+                                const uint32_t* list, const uint32_t* n_list_dev, hipStream_t st) {
     if (!n_active) return;
-    const dim3 grid(((n_active + 7u) / 8u) * 8u), block(512);
-#define SS_ACC(A) hipLaunchKernelGGL((k_splat_accumulate<R, A>), grid, block, 0, st, P, arena, tile_off, counts, active_xyz, n_active, G, blk_minmax)
+    const dim3 grid(((n_active + 7u) / 8u) * 8u), block(512), lgrid(2048);
+#define SS_ACC(A)                                                                                                                                   \
+    do {                                                                                                                                            \
+        if (list)                                                                                                                                   \
+            hipLaunchKernelGGL((k_splat_accumulate_list<R, A>), lgrid, block, 0, st, P, arena, tile_off, counts, active_xyz, list, n_list_dev, G, blk_minmax, trunc); \
+        else if (full_levelset)                                                                                                                     \
+            hipLaunchKernelGGL((k_splat_accumulate<R, A, false>), grid, block, 0, st, P, arena, tile_off, counts, active_xyz, n_active, G, blk_minmax, trunc); \
+        else                                                                                                                                        \
+            hipLaunchKernelGGL((k_splat_accumulate<R, A, true>), grid, block, 0, st, P, arena, tile_off, counts, active_xyz, n_active, G, blk_minmax, trunc);  \
+    } while (0)
     if constexpr (sizeof(R) == 4) {
         switch (P.arith) {
             case SS_ARITH_FAST: SS_ACC(SS_ARITH_FAST); return;
@@ -1357,6 +1435,13 @@ void ss_launch_splat_accumulate(const SSDevT<R>& P, const ss_real4<R>* arena, co
     }
     SS_ACC(SS_ARITH_GENERIC);
 #undef SS_ACC
+}
+
+template <class R>
+void ss_launch_mark_redo_blocks(const SSDevT<R>& P, const uint32_t* mc_flag, const uint32_t* block_slot, const uint32_t* trunc, uint32_t nblocks, uint32_t* redo_flag,
+                                hipStream_t st) {
+    if (!nblocks) return;
+    hipLaunchKernelGGL(k_mark_redo_blocks<R>, dim3((nblocks + 255) / 256), dim3(256), 0, st, P, mc_flag, block_slot, trunc, nblocks, redo_flag);
 }
 
 // =====================================================================================================
@@ -1654,8 +1739,10 @@ template void ss_launch_splat_gather_large<float>(const SSDevT<float>& P, const 
 template void ss_launch_splat_bounds<double>(const SSDevT<double>& P, const uint32_t* cell_start, const uint32_t* active_xyz, uint32_t n_active, uint32_t* bound, hipStream_t st);
 template void ss_launch_splat_gather<double>(const SSDevT<double>& P, const ss_real4<double>* posvol, const uint32_t* perm, const uint32_t* cell_start, const uint32_t* active_xyz, uint32_t n_active, const unsigned long long* tile_off, ss_real4<double>* arena, uint32_t* counts, uint32_t* large_flag, hipStream_t st);
 template void ss_launch_splat_gather_large<double>(const SSDevT<double>& P, const ss_real4<double>* posvol, const ss_real4<double>* posvol_by_index, const uint32_t* perm, const uint32_t* cell_start, const uint32_t* active_xyz, const uint32_t* large_list, const uint32_t* n_large_dev, const uint32_t* counts, const unsigned long long* tile_off, ss_real4<double>* arena, hipStream_t st);
-template void ss_launch_splat_accumulate<float>(const SSDevT<float>& P, const ss_real4<float>* arena, const unsigned long long* tile_off, const uint32_t* counts, const uint32_t* active_xyz, uint32_t n_active, float* G, ss_real2<float>* blk_minmax, hipStream_t st);
-template void ss_launch_splat_accumulate<double>(const SSDevT<double>& P, const ss_real4<double>* arena, const unsigned long long* tile_off, const uint32_t* counts, const uint32_t* active_xyz, uint32_t n_active, double* G, ss_real2<double>* blk_minmax, hipStream_t st);
+template void ss_launch_splat_accumulate<float>(const SSDevT<float>& P, const ss_real4<float>* arena, const unsigned long long* tile_off, const uint32_t* counts, const uint32_t* active_xyz, uint32_t n_active, float* G, ss_real2<float>* blk_minmax, uint32_t* trunc, bool full_levelset, const uint32_t* list, const uint32_t* n_list_dev, hipStream_t st);
+template void ss_launch_mark_redo_blocks<float>(const SSDevT<float>& P, const uint32_t* mc_flag, const uint32_t* block_slot, const uint32_t* trunc, uint32_t nblocks, uint32_t* redo_flag, hipStream_t st);
+template void ss_launch_splat_accumulate<double>(const SSDevT<double>& P, const ss_real4<double>* arena, const unsigned long long* tile_off, const uint32_t* counts, const uint32_t* active_xyz, uint32_t n_active, double* G, ss_real2<double>* blk_minmax, uint32_t* trunc, bool full_levelset, const uint32_t* list, const uint32_t* n_list_dev, hipStream_t st);
+template void ss_launch_mark_redo_blocks<double>(const SSDevT<double>& P, const uint32_t* mc_flag, const uint32_t* block_slot, const uint32_t* trunc, uint32_t nblocks, uint32_t* redo_flag, hipStream_t st);
 template void ss_launch_mc_count<float>(const SSDevT<float>& P, const float* G, const uint32_t* block_slot, const uint32_t* mc_xyz, uint32_t n_mc, unsigned long long* masks, uint32_t* vcount, uint32_t* tcount, hipStream_t st);
 template void ss_launch_mc_count<double>(const SSDevT<double>& P, const double* G, const uint32_t* block_slot, const uint32_t* mc_xyz, uint32_t n_mc, unsigned long long* masks, uint32_t* vcount, uint32_t* tcount, hipStream_t st);
 template void ss_launch_mc_emit<float>(const SSDevT<float>& P, const float* G, const uint32_t* block_slot, const uint32_t* mc_xyz, const uint32_t* mc_slot, uint32_t n_mc, const unsigned long long* masks, const uint32_t* vbase, const uint32_t* tbase, float* vertices, unsigned long long* vkeys, uint32_t* triangles, hipStream_t st);

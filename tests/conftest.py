@@ -61,3 +61,15 @@ def gpu_ctx():
     from splashsurf_amd.api import Context
     S.load_library()
     return Context(0)
+
+
+@pytest.fixture(scope="session")
+def full_levelset_ctx():
+    """A second context with SS_OPTION_FULL_LEVELSET: no early exit inside the fluid, every level-set value complete --
+    for the tests that compare whole 65^3 level-set arrays (the default context only completes what marching cubes reads)."""
+    import splashsurf_amd as S
+    from splashsurf_amd.api import Context
+    S.load_library()
+    ctx = Context(0)
+    ctx.set_full_levelset(True)
+    return ctx

@@ -129,14 +129,14 @@ def test_gpu_bit_identical_to_oracle_large(gpu_ctx, oracle, name):
 
 
 @pytest.mark.parametrize("name", ["config1_double_dam_break", "cube_2366_n16", "tank_small"])
-def test_levelset_bit_identical_per_subdomain(gpu_ctx, oracle, name):
+def test_levelset_bit_identical_per_subdomain(full_levelset_ctx, oracle, name):
     """The splat kernel alone: level-set values of every occupied subdomain (65^3 incl. shared faces)
     equal the oracle's density_grid_loop_scalar restatement bit for bit."""
     g = load_golden(name)
     pts = golden_input(g)
     prm = golden_params(g)
     par, _ = run_oracle(oracle, pts, prm)
-    res = run_gpu(gpu_ctx, pts, prm)
+    res = run_gpu(full_levelset_ctx, pts, prm)
     n = prm.get("subdomain_num_cubes_per_dim", 64)
     ns = res.subdomain_grid.ncells_per_dim
     checked = 0
@@ -431,7 +431,9 @@ def test_splat_on_reference_grid_loop_fixture(oracle):
     flat = (sub[0] * ns[1] + sub[1]) * ns[2] + sub[2]
     cnt, ref = oracle.shard_levelset(pts, rho, opar, dmin, dmax, sub, [s + 1 for s in sub], flat)
     assert cnt == pts.shape[0]  # every particle of the fixture is a member of that subdomain
-    eng = D.HipEngine(Context(0), Parameters(particle_radius=r, compact_support_radius=np.float32(h), cube_size=np.float32(cs), auto_disable=False, enable_simd=False))
+    ctx = Context(0)
+    ctx.set_full_levelset(True)
+    eng = D.HipEngine(ctx, Parameters(particle_radius=r, compact_support_radius=np.float32(h), cube_size=np.float32(cs), auto_disable=False, enable_simd=False))
     shard = D.ShardDesc(dmin, dmax, sub, [s + 1 for s in sub])
     eng.begin(torch.from_numpy(pts).to("cuda:0"), shard)
     res = eng.finish(torch.from_numpy(rho).to("cuda:0"))
@@ -487,7 +489,8 @@ def test_gpu_f64_bit_identical_to_oracle_and_reference(gpu_ctx, oracle, name):
     assert not res32.is_f64 and res32.mesh.vertices.dtype == np.float32
 
 
-def test_gpu_f64_levelset_bit_identical(gpu_ctx, oracle):
+def test_gpu_f64_levelset_bit_identical(full_levelset_ctx, oracle):
+    gpu_ctx = full_levelset_ctx
     import splashsurf_amd as S
     g = load_golden("f64_config1")
     prm = golden_params(g)

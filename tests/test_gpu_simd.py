@@ -95,7 +95,8 @@ def _levelsets(res, oracle, pts, par):
         yield flat, ref, res.levelset_box([s3[0] * n, s3[1] * n, s3[2] * n], [n + 1] * 3)
 
 
-def test_simd_levelset_bit_identical_per_subdomain(gpu_ctx, oracle):
+def test_simd_levelset_bit_identical_per_subdomain(full_levelset_ctx, oracle):
+    gpu_ctx = full_levelset_ctx
     """Every level-set value of config 1 (all four 65^3 subdomains, faces included) equals the uniform-SIMD oracle bit for bit."""
     g = load_golden("simd_config1_double_dam_break")
     pts, prm = golden_input(g), golden_params(g)
@@ -109,8 +110,9 @@ def test_simd_levelset_bit_identical_per_subdomain(gpu_ctx, oracle):
 
 
 @pytest.mark.parametrize("name", ["simd_config1_double_dam_break", "simd_tank_small", "simd_config5_hilbert"])
-def test_simd_hw_sqrt_within_the_references_own_tolerance(gpu_ctx, oracle, name):
+def test_simd_hw_sqrt_within_the_references_own_tolerance(full_levelset_ctx, oracle, name):
     """enable_simd = 2 (v_sqrt_f32 instead of the correctly rounded root)."""
+    gpu_ctx = full_levelset_ctx
     g = load_golden(name)
     pts, prm = golden_input(g), golden_params(g)
     res = _run_gpu(gpu_ctx, pts, prm, 2)
@@ -149,7 +151,9 @@ def test_simd_on_reference_grid_loop_fixture(oracle):
     sub = [int(x) for x in g["subdomain_ijk"]]
     out = {}
     for simd in (0, 1, 2):
-        eng = D.HipEngine(Context(0), Parameters(particle_radius=r, compact_support_radius=np.float32(h), cube_size=np.float32(cs), auto_disable=False, enable_simd=simd))
+        ctx = Context(0)
+        ctx.set_full_levelset(True)
+        eng = D.HipEngine(ctx, Parameters(particle_radius=r, compact_support_radius=np.float32(h), cube_size=np.float32(cs), auto_disable=False, enable_simd=simd))
         shard = D.ShardDesc(dmin, dmax, sub, [s + 1 for s in sub])
         t = torch.from_numpy(pts).to("cuda:0")
         eng.begin(t, shard)
@@ -160,3 +164,27 @@ def test_simd_on_reference_grid_loop_fixture(oracle):
     assert out[0].max() > 0.6
     for simd in (1, 2):
         assert float(np.abs(out[simd].astype(np.float64) - out[0].astype(np.float64)).max()) < 100 * np.finfo(np.float32).eps
+
+
+@pytest.mark.parametrize("simd", [0, 1, 2])
+def test_early_exit_inside_the_fluid_changes_no_output(gpu_ctx, full_levelset_ctx, simd):
+    """The default splat stops a 4^3 sub-block once all of its running values have passed the threshold and completes only the
+    truncated blocks next to a sign change; SS_OPTION_FULL_LEVELSET evaluates everything.  Densities, vertices, triangles and
+    edge keys must be identical bit for bit; the default run really did truncate blocks, and it refuses to hand out level-set
+    values."""
+    from splashsurf_amd import workloads as W
+    pts = W.tank_particles(0.3)
+    prm = dict(particle_radius=0.005, smoothing_length=2.0, cube_size=0.5, iso_surface_threshold=0.6)
+    a = _run_gpu(gpu_ctx, pts, prm, simd)
+    b = _run_gpu(full_levelset_ctx, pts, prm, simd)
+    sa, sb = a.stats, b.stats
+    assert sb["n_truncated_blocks"] == 0 and sb["n_completed_blocks"] == 0
+    assert sa["n_truncated_blocks"] > 0.3 * sa["n_active_blocks"], sa  # a bulk of fluid: most blocks are interior
+    assert 0 < sa["n_completed_blocks"] < 0.2 * sa["n_active_blocks"], sa
+    assert np.array_equal(a.particle_densities.view(np.uint32), b.particle_densities.view(np.uint32))
+    assert np.array_equal(a.vertex_keys, b.vertex_keys)
+    assert np.array_equal(a.mesh.vertices.view(np.uint32), b.mesh.vertices.view(np.uint32))
+    assert np.array_equal(a.mesh.triangles_u32, b.mesh.triangles_u32)
+    with pytest.raises(RuntimeError):
+        a.levelset_box([0, 0, 0], [8, 8, 8])
+    b.levelset_box([0, 0, 0], [8, 8, 8])
