@@ -192,6 +192,8 @@ ss_status make_device_params(ss_context* ctx, const typename TypesOf<R>::params*
     const R support_factor = simd ? R(1.0) : R(1.01);
     P.reach = ss_sqrt(support_factor) * h * R(1.0001);
     P.R2 = ((h * h) * support_factor) * R(1.0001);
+    P.R2near = (R(0.625) * h) * (R(0.625) * h);
+    P.thr_inside = prm->iso_surface_threshold * R(1.0001);
     {   // CubicSplineKernelAvxF32::new (kernel.rs:327-337), in f32 like the reference
         const float hf = (float)h;
         const float pi_f = 3.14159265358979323846f;
@@ -842,6 +844,7 @@ ss_status phase_finish(ss_context* ctx, ss_result* res) {
         if (fs != SS_OK) return fs;
         if (checked_now) SS_HIP(ctx, hipEventRecord(ctx->ev[5], st));  // keep the one-off check out of the splat timing
     }
+    const R prm_threshold = P.threshold;
     SSDevT<R> PK = P;
     if (sizeof(R) == 4) {
         const bool lean_ok = P.h > R(1.0e-9) && P.h < R(1.0e15);  // range in which the lean exact sqrt needs no scaling
@@ -887,21 +890,23 @@ ss_status phase_finish(ss_context* ctx, ss_result* res) {
         if (s != SS_OK) return s;
     }
     SS_HIP(ctx, hipEventRecord(ctx->ev[12], st));
-    // first pass: every active block; sub-blocks that turn out to lie inside the fluid stop early (ss_kernels.hip, splat_accumulate_wave)
+    // first pass: every active block; sub-blocks that a cheap lower bound certifies to lie inside the fluid are not evaluated in full
+    // (ss_kernels.hip, splat_accumulate_block).  Small jobs skip the two-pass scheme: its extra launches cost more than it saves there.
+    const bool full_ls = ctx->full_levelset || n_active < 16384u || !(prm_threshold > R(0.0));
     SS_HIP(ctx, ctx->splat_trunc.reserve(((size_t)n_active + 1) * 4 * 4 + 64));
     uint32_t* tr_flag = ctx->splat_trunc.as<uint32_t>();          // block carries truncated values
     uint32_t* rd_flag = tr_flag + ((size_t)n_active + 1);         // ... and marching cubes will read it
     uint32_t* rd_rank = rd_flag + ((size_t)n_active + 1);
     uint32_t* rd_list = rd_rank + ((size_t)n_active + 1);
     ss_launch_splat_accumulate(PK, ctx->splat_tiles.as<ss_real4<R>>(), ctx->splat_off.as<unsigned long long>(), ctx->splat_counts.as<uint32_t>(),
-                               res->active_xyz.as<uint32_t>(), n_active, res->G.as<R>(), res->blk_minmax.as<ss_real2<R>>(), tr_flag, ctx->full_levelset, nullptr, nullptr, st);
+                               res->active_xyz.as<uint32_t>(), n_active, res->G.as<R>(), res->blk_minmax.as<ss_real2<R>>(), tr_flag, full_ls, nullptr, nullptr, st);
     SS_HIP(ctx, hipEventRecord(ctx->ev[13], st));
 
     // ---- K4 prepare: MC blocks = blocks whose 2x2x2 level-set neighbourhood straddles the threshold ----
     ss_launch_mark_mc_blocks(P, res->block_slot.as<uint32_t>(), res->blk_minmax.as<ss_real2<R>>(), (uint32_t)nblocks, ctx->mc_flag.as<uint32_t>(), st);
     // second pass of the splat: truncated blocks that marching cubes is going to read are completed (list and count stay on the device)
     SS_HIP(ctx, hipEventRecord(ctx->ev[14], st));
-    if (n_active && !ctx->full_levelset) {
+    if (n_active && !full_ls) {
         SS_HIP(ctx, hipMemsetAsync(rd_flag, 0, ((size_t)n_active + 1) * 4, st));
         ss_launch_mark_redo_blocks(P, ctx->mc_flag.as<uint32_t>(), res->block_slot.as<uint32_t>(), tr_flag, (uint32_t)nblocks, rd_flag, st);
         s = exclusive_scan_u32<uint32_t>(ctx, rd_flag, rd_rank, (size_t)n_active + 1);
@@ -951,7 +956,7 @@ ss_status phase_finish(ss_context* ctx, ss_result* res) {
     if (n_active) SS_HIP(ctx, hipMemcpyAsync(&n_large, lg_rank + n_active, 4, hipMemcpyDeviceToHost, st));
     unsigned long long n_trunc_left = 0;
     uint32_t n_redo = 0;
-    if (n_active && !ctx->full_levelset) {
+    if (n_active && !full_ls) {
         SS_HIP(ctx, hipMemcpyAsync(&n_trunc_left, ctx->counter.as<unsigned long long>() + 1, 8, hipMemcpyDeviceToHost, st));
         SS_HIP(ctx, hipMemcpyAsync(&n_redo, rd_rank + n_active, 4, hipMemcpyDeviceToHost, st));
     }

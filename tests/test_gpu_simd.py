@@ -168,8 +168,9 @@ def test_simd_on_reference_grid_loop_fixture(oracle):
 
 @pytest.mark.parametrize("simd", [0, 1, 2])
 def test_early_exit_inside_the_fluid_changes_no_output(gpu_ctx, full_levelset_ctx, simd):
-    """The default splat stops a 4^3 sub-block once all of its running values have passed the threshold and completes only the
-    truncated blocks next to a sign change; SS_OPTION_FULL_LEVELSET evaluates everything.  Densities, vertices, triangles and
+    """The default splat certifies 4^3 sub-blocks inside the fluid with a cheap lower bound (the sum over the nearby particles) and
+    evaluates in full only what is not certified plus the certified blocks next to a sign change; SS_OPTION_FULL_LEVELSET evaluates
+    everything.  Densities, vertices, triangles and
     edge keys must be identical bit for bit; the default run really did truncate blocks, and it refuses to hand out level-set
     values."""
     from splashsurf_amd import workloads as W
@@ -179,8 +180,8 @@ def test_early_exit_inside_the_fluid_changes_no_output(gpu_ctx, full_levelset_ct
     b = _run_gpu(full_levelset_ctx, pts, prm, simd)
     sa, sb = a.stats, b.stats
     assert sb["n_truncated_blocks"] == 0 and sb["n_completed_blocks"] == 0
-    assert sa["n_truncated_blocks"] > 0.3 * sa["n_active_blocks"], sa  # a bulk of fluid: most blocks are interior
-    assert 0 < sa["n_completed_blocks"] < 0.2 * sa["n_active_blocks"], sa
+    assert sa["n_truncated_blocks"] + sa["n_completed_blocks"] > 0.3 * sa["n_active_blocks"], sa  # a bulk of fluid: many blocks are interior
+    assert 0 < sa["n_completed_blocks"] < 0.5 * sa["n_active_blocks"], sa
     assert np.array_equal(a.particle_densities.view(np.uint32), b.particle_densities.view(np.uint32))
     assert np.array_equal(a.vertex_keys, b.vertex_keys)
     assert np.array_equal(a.mesh.vertices.view(np.uint32), b.mesh.vertices.view(np.uint32))
