@@ -158,6 +158,7 @@ typedef struct ss_stats {
                                        * (generic / lean), 4 SIMD with v_sqrt_f32 */
     uint64_t bytes_tile_arena;        /* bytes of index-ordered candidate tiles written by the gather and re-read by the accumulate kernel */
     uint64_t bytes_tile_arena_reserved; /* size of the arena those tiles live in (ranges sized by a cheap per-block upper bound) */
+    uint64_t n_certified_subblocks;   /* 4x4x4 sub-blocks the classification pass of the splat certified to lie inside the fluid */
     uint64_t n_truncated_blocks;      /* active blocks left with truncated (lower-bound) level-set values: inside the fluid, never read by MC */
     uint64_t n_completed_blocks;      /* truncated blocks next to the surface that the second splat pass evaluated in full */
 } ss_stats;

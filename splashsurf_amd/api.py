@@ -112,6 +112,7 @@ class _Stats(C.Structure):
         ("arith_mode", C.c_uint64),
         ("bytes_tile_arena", C.c_uint64),
         ("bytes_tile_arena_reserved", C.c_uint64),
+        ("n_certified_subblocks", C.c_uint64),
         ("n_truncated_blocks", C.c_uint64),
         ("n_completed_blocks", C.c_uint64),
     ]

@@ -132,6 +132,18 @@ ss_status exclusive_scan_u32(ss_context* ctx, const T* in, T* out, size_t n) {
 struct WidenU32 {
     __host__ __device__ unsigned long long operator()(uint32_t v) const { return (unsigned long long)v; }
 };
+struct NonZeroU32 {
+    __host__ __device__ unsigned long long operator()(uint32_t v) const { return v ? 1ull : 0ull; }
+};
+// number of non-zero entries among n 32-bit values as a 64-bit value at *out (device)
+static ss_status count_nonzero_u32(ss_context* ctx, const uint32_t* in, size_t n, unsigned long long* out) {
+    auto it = rocprim::make_transform_iterator(in, NonZeroU32());
+    size_t bytes = 0;
+    SS_HIP(ctx, rocprim::reduce(nullptr, bytes, it, out, 0ull, n, rocprim::plus<unsigned long long>(), ctx->stream));
+    SS_HIP(ctx, ctx->temp.reserve(bytes));
+    SS_HIP(ctx, rocprim::reduce(ctx->temp.p, bytes, it, out, 0ull, n, rocprim::plus<unsigned long long>(), ctx->stream));
+    return SS_OK;
+}
 // sum of n 32-bit counts as a 64-bit value at *out (device)
 static ss_status sum_u32_to_u64(ss_context* ctx, const uint32_t* in, size_t n, unsigned long long* out) {
     auto it = rocprim::make_transform_iterator(in, WidenU32());
@@ -892,7 +904,26 @@ ss_status phase_finish(ss_context* ctx, ss_result* res) {
     SS_HIP(ctx, hipEventRecord(ctx->ev[12], st));
     // first pass: every active block; sub-blocks that a cheap lower bound certifies to lie inside the fluid are not evaluated in full
     // (ss_kernels.hip, splat_accumulate_block).  Small jobs skip the two-pass scheme: its extra launches cost more than it saves there.
-    const bool full_ls = ctx->full_levelset || n_active < 16384u || !(prm_threshold > R(0.0));
+    // ... and so do workloads where the previous call certified too few sub-blocks to pay for the classification pass (break-even:
+    // 35 % of the sub-blocks); such a workload is probed again every 16th call.
+    uint64_t early_key = (uint64_t)n * 0x9E3779B97F4A7C15ull;
+    {
+        uint64_t hb = 0, cb = 0;
+        memcpy(&hb, &P.h, sizeof(R));
+        memcpy(&cb, &P.cs, sizeof(R));
+        early_key ^= hb * 0xC2B2AE3D27D4EB4Full ^ (cb << 1);
+    }
+    if (ctx->early_key != early_key) {
+        ctx->early_key = early_key;
+        ctx->early_enabled = true;
+        ctx->early_skipped = 0;
+    }
+    bool probe = ctx->early_enabled;
+    if (!probe && ++ctx->early_skipped >= 16) {
+        probe = true;
+        ctx->early_skipped = 0;
+    }
+    const bool full_ls = ctx->full_levelset || n_active < 16384u || !(prm_threshold > R(0.0)) || !probe;
     SS_HIP(ctx, ctx->splat_trunc.reserve(((size_t)n_active + 1) * 4 * 4 + 64));
     uint32_t* tr_flag = ctx->splat_trunc.as<uint32_t>();          // block carries truncated values
     uint32_t* rd_flag = tr_flag + ((size_t)n_active + 1);         // ... and marching cubes will read it
@@ -901,6 +932,10 @@ ss_status phase_finish(ss_context* ctx, ss_result* res) {
     ss_launch_splat_accumulate(PK, ctx->splat_tiles.as<ss_real4<R>>(), ctx->splat_off.as<unsigned long long>(), ctx->splat_counts.as<uint32_t>(),
                                res->active_xyz.as<uint32_t>(), n_active, res->G.as<R>(), res->blk_minmax.as<ss_real2<R>>(), tr_flag, full_ls, nullptr, nullptr, st);
     SS_HIP(ctx, hipEventRecord(ctx->ev[13], st));
+    if (n_active && !full_ls) {
+        s = sum_u32_to_u64(ctx, tr_flag, n_active, ctx->counter.as<unsigned long long>() + 2);  // certified sub-blocks (decides the next call's strategy)
+        if (s != SS_OK) return s;
+    }
 
     // ---- K4 prepare: MC blocks = blocks whose 2x2x2 level-set neighbourhood straddles the threshold ----
     ss_launch_mark_mc_blocks(P, res->block_slot.as<uint32_t>(), res->blk_minmax.as<ss_real2<R>>(), (uint32_t)nblocks, ctx->mc_flag.as<uint32_t>(), st);
@@ -914,7 +949,7 @@ ss_status phase_finish(ss_context* ctx, ss_result* res) {
         ss_launch_compact_blocks(rd_flag, rd_rank, n_active, rd_list, lg_slot, st);
         ss_launch_splat_accumulate(PK, ctx->splat_tiles.as<ss_real4<R>>(), ctx->splat_off.as<unsigned long long>(), ctx->splat_counts.as<uint32_t>(),
                                    res->active_xyz.as<uint32_t>(), n_active, res->G.as<R>(), res->blk_minmax.as<ss_real2<R>>(), tr_flag, true, rd_list, rd_rank + n_active, st);
-        s = sum_u32_to_u64(ctx, tr_flag, n_active, ctx->counter.as<unsigned long long>() + 1);  // blocks still truncated (statistics)
+        s = count_nonzero_u32(ctx, tr_flag, n_active, ctx->counter.as<unsigned long long>() + 1);  // blocks still truncated (statistics)
         if (s != SS_OK) return s;
     }
     SS_HIP(ctx, hipEventRecord(ctx->ev[15], st));
@@ -954,11 +989,12 @@ ss_status phase_finish(ss_context* ctx, ss_result* res) {
     uint32_t n_large = 0;
     SS_HIP(ctx, hipMemcpyAsync(&n_cand, ctx->counter.p, 8, hipMemcpyDeviceToHost, st));
     if (n_active) SS_HIP(ctx, hipMemcpyAsync(&n_large, lg_rank + n_active, 4, hipMemcpyDeviceToHost, st));
-    unsigned long long n_trunc_left = 0;
+    unsigned long long n_trunc_left = 0, n_cert_waves = 0;
     uint32_t n_redo = 0;
     if (n_active && !full_ls) {
         SS_HIP(ctx, hipMemcpyAsync(&n_trunc_left, ctx->counter.as<unsigned long long>() + 1, 8, hipMemcpyDeviceToHost, st));
         SS_HIP(ctx, hipMemcpyAsync(&n_redo, rd_rank + n_active, 4, hipMemcpyDeviceToHost, st));
+        SS_HIP(ctx, hipMemcpyAsync(&n_cert_waves, ctx->counter.as<unsigned long long>() + 2, 8, hipMemcpyDeviceToHost, st));
     }
     SS_HIP(ctx, hipStreamSynchronize(st));
     const uint64_t nv = totals[0], nt = totals[1];
@@ -1002,6 +1038,11 @@ ss_status phase_finish(ss_context* ctx, ss_result* res) {
     S.arith_mode = (uint64_t)PK.arith;
     S.bytes_tile_arena = (uint64_t)n_cand * sizeof(ss_real4<R>);
     S.bytes_tile_arena_reserved = (uint64_t)n_reserved * sizeof(ss_real4<R>);
+    if (n_active && !full_ls) {
+        const double frac = (double)n_cert_waves / (8.0 * (double)n_active);
+        ctx->early_enabled = frac > (ctx->early_enabled ? 0.30 : 0.35);
+    }
+    S.n_certified_subblocks = n_cert_waves;
     S.n_truncated_blocks = n_trunc_left;
     S.n_completed_blocks = n_redo;
     S.levelset_kernel_launches = n_active ? 1 : 0;

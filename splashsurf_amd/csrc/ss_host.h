@@ -78,6 +78,11 @@ struct ss_context {
     DevBuf nb_count, nb_tmp;
     DevBuf member_count, copy_offset, sub_flag, sub_rank, occ_sub, ckeys_a, ckeys_b, cvals_a, cidx, cpos, cell_count2, cell_start2;
     hipEvent_t ev[16];  // 0..9 stage boundaries, 10/11 start of phase 2, 12..15 inside the splat
+    // the two-pass splat pays off when enough sub-blocks get certified 'inside' (bulk fluid); thin structures do not -- decided per
+    // workload from the previous call's statistics, re-probed now and then
+    uint64_t early_key = 0;
+    bool early_enabled = true;
+    int early_skipped = 0;
     bool full_levelset = false;  // SS_OPTION_FULL_LEVELSET: no early exit in the splat (complete level-set values everywhere)
     // exhaustively verified "division by h via reciprocal + 2 FMA" (ss_kernels.hip ss_div_by_h)
     DevBuf fastdiv_scratch;

@@ -1304,7 +1304,7 @@ __device__ __forceinline__ void splat_accumulate_block(SplatAccShared<R>& sh, co
             if (c0 + SS_WTILE < n_tile) __syncthreads();  // pay is overwritten by the next trip
         }
     }
-    if (EARLY && done && lane == 0) atomicOr(&sh.trunc, 1u);
+    if (EARLY && done && lane == 0) atomicAdd(&sh.trunc, 1u);  // number of certified sub-blocks of this block
     // store: block-local layout (x*8+y)*8+z, i-major / k-fastest like dense_subdomains.rs:839
     const int lx = ((wave >> 2) & 1) * 4 + ((lane >> 4) & 3);
     const int ly = ((wave >> 1) & 1) * 4 + ((lane >> 2) & 3);
