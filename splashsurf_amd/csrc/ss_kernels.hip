@@ -1280,13 +1280,16 @@ __device__ __forceinline__ void splat_accumulate_block(SplatAccShared<R>& sh, co
         __syncthreads();
         if (wave_valid && n_tile) {
             if constexpr (EARLY) {
-                // Classification pass: the sum over the entries CLOSE to the sub-block only (box distance <= 0.625 h, about a third of
-                // the tile, but >= 84 % of every point's kernel mass).  Every term is >= 0, so it bounds the level set from below
+                // Classification pass: the sum over the entries CLOSE to the sub-block only (box distance <= 0.56 h, about a quarter of
+                // the tile, but >= 74 % of every point's kernel mass).  Every term is >= 0, so it bounds the level set from below
                 // whatever the order: if it exceeds the threshold (with a margin covering the rounding of either summation) at all 64
                 // points, the sub-block lies inside the fluid -- marching cubes only needs that fact, unless the block is next to
                 // a sign change, in which case the second pass (k_splat_accumulate_list) evaluates it in full.  Otherwise the exact
                 // sum in the reference's order follows right away.
-                acc = splat_accumulate_wave<R, ARITH>(P, sh.pay, sh.wl[wave], n_tile, lane, px, py, pz, slo, shi, P.R2near, R(0.0));
+                // A lower bound needs no particular arithmetic either: f32 jobs use the cheapest variant (fma, v_sqrt_f32; within ~1e-6
+                // relative of every other mode's terms, far inside the margin of thr_inside).
+                constexpr int CLS = (sizeof(R) == 4) ? SS_ARITH_SIMD_HW : ARITH;
+                acc = splat_accumulate_wave<R, CLS>(P, sh.pay, sh.wl[wave], n_tile, lane, px, py, pz, slo, shi, P.R2near, R(0.0));
                 done = __ballot(acc > P.thr_inside || !point_valid) == ~0ull;
                 if (!done) acc = splat_accumulate_wave<R, ARITH>(P, sh.pay, sh.wl[wave], n_tile, lane, px, py, pz, slo, shi, P.R2, R(0.0));
             } else {
