@@ -1275,39 +1275,40 @@ __device__ __forceinline__ void splat_accumulate_block(SplatAccShared<R>& sh, co
     }
     R acc = R(0.0);  // levelset_grid.fill(0), dense_subdomains.rs:1390
     bool done = false;
-    if (n_tile <= SS_WTILE) {
-        if (tid < n_tile) sh.pay[tid] = nxt;
-        __syncthreads();
-        if (wave_valid && n_tile) {
-            if constexpr (EARLY) {
-                // Classification pass: the sum over the entries CLOSE to the sub-block only (box distance <= 0.56 h, about a quarter of
-                // the tile, but >= 74 % of every point's kernel mass).  Every term is >= 0, so it bounds the level set from below
-                // whatever the order: if it exceeds the threshold (with a margin covering the rounding of either summation) at all 64
-                // points, the sub-block lies inside the fluid -- marching cubes only needs that fact, unless the block is next to
-                // a sign change, in which case the second pass (k_splat_accumulate_list) evaluates it in full.  Otherwise the exact
-                // sum in the reference's order follows right away.
-                // A lower bound needs no particular arithmetic either: f32 jobs use the cheapest variant (fma, v_sqrt_f32; within ~1e-6
-                // relative of every other mode's terms, far inside the margin of thr_inside).
-                constexpr int CLS = (sizeof(R) == 4) ? SS_ARITH_SIMD_HW : ARITH;
-                acc = splat_accumulate_wave<R, CLS>(P, sh.pay, sh.wl[wave], n_tile, lane, px, py, pz, slo, shi, P.R2near, R(0.0));
-                done = __ballot(acc > P.thr_inside || !point_valid) == ~0ull;
-                if (!done) acc = splat_accumulate_wave<R, ARITH>(P, sh.pay, sh.wl[wave], n_tile, lane, px, py, pz, slo, shi, P.R2, R(0.0));
-            } else {
-                acc = splat_accumulate_wave<R, ARITH>(P, sh.pay, sh.wl[wave], n_tile, lane, px, py, pz, slo, shi, P.R2, R(0.0));
-            }
+    // The tile streams through LDS in chunks of SS_WTILE entries (one chunk for all but over-dense blocks), up to twice:
+    //  pass 0 (EARLY only), classification: the sum over the entries CLOSE to the sub-block only (box distance <= 0.56 h, about a
+    //   quarter of the tile, but >= 74 % of every point's kernel mass).  Every term is >= 0, so it bounds the level set from below
+    //   whatever the order and whatever the arithmetic -- f32 jobs use the cheapest variant (fma, v_sqrt_f32; within ~1e-6 relative
+    //   of every other mode's terms, far inside the margin of thr_inside).  If it exceeds the threshold at all 64 points, the
+    //   sub-block lies inside the fluid: marching cubes only needs that fact, unless the block is next to a sign change, in which
+    //   case the second kernel pass (k_splat_accumulate_list) evaluates it in full.
+    //  pass 1, the exact sum in the reference's order, for the waves pass 0 did not certify.
+    constexpr int CLS = (sizeof(R) == 4) ? SS_ARITH_SIMD_HW : ARITH;
+    const int n_chunks = (n_tile + SS_WTILE - 1) / SS_WTILE;
+    for (int pass = EARLY ? 0 : 1; pass < 2; ++pass) {
+        if (pass == 1 && EARLY) {
+            done = wave_valid ? (__ballot(acc > P.thr_inside || !point_valid) == ~0ull) : true;
+            if (!__syncthreads_or(done ? 0 : 1)) break;  // every sub-block of this block is certified
+            if (!done) acc = R(0.0);
+            if (n_chunks > 1 && tid < SS_WTILE) nxt = tile[tid];  // over-dense block: the tile is streamed a second time
         }
-    } else {
-        // over-dense block: the tile streams through LDS in chunks (exact sum only)
         for (int c0 = 0; c0 < n_tile; c0 += SS_WTILE) {
             const int nc = min(SS_WTILE, n_tile - c0);
-            if (tid < nc) sh.pay[tid] = nxt;
-            __syncthreads();
-            if (c0 + SS_WTILE + tid < n_tile && tid < SS_WTILE) nxt = tile[c0 + SS_WTILE + tid];  // next chunk in flight during the arithmetic
-            if (wave_valid) acc = splat_accumulate_wave<R, ARITH>(P, sh.pay, sh.wl[wave], nc, lane, px, py, pz, slo, shi, P.R2, acc);
-            if (c0 + SS_WTILE < n_tile) __syncthreads();  // pay is overwritten by the next trip
+            if (n_chunks > 1 || pass == (EARLY ? 0 : 1)) {  // a single chunk stays in LDS between the passes
+                if (tid < nc) sh.pay[tid] = nxt;
+                __syncthreads();
+                if (c0 + SS_WTILE + tid < n_tile && tid < SS_WTILE) nxt = tile[c0 + SS_WTILE + tid];  // next chunk in flight during the arithmetic
+            }
+            if (wave_valid && !done) {
+                if (pass == 0)
+                    acc = splat_accumulate_wave<R, CLS>(P, sh.pay, sh.wl[wave], nc, lane, px, py, pz, slo, shi, P.R2near, acc);
+                else
+                    acc = splat_accumulate_wave<R, ARITH>(P, sh.pay, sh.wl[wave], nc, lane, px, py, pz, slo, shi, P.R2, acc);
+            }
+            if (n_chunks > 1) __syncthreads();  // pay is overwritten by the next chunk
         }
     }
-    if (EARLY && done && lane == 0) atomicAdd(&sh.trunc, 1u);  // number of certified sub-blocks of this block
+    if (EARLY && done && wave_valid && lane == 0) atomicAdd(&sh.trunc, 1u);  // number of certified sub-blocks of this block
     // store: block-local layout (x*8+y)*8+z, i-major / k-fastest like dense_subdomains.rs:839
     const int lx = ((wave >> 2) & 1) * 4 + ((lane >> 4) & 3);
     const int ly = ((wave >> 1) & 1) * 4 + ((lane >> 2) & 3);
