@@ -1288,7 +1288,8 @@ __device__ __forceinline__ void splat_accumulate_block(SplatAccShared<R>& sh, co
     for (int pass = EARLY ? 0 : 1; pass < 2; ++pass) {
         if (pass == 1 && EARLY) {
             done = wave_valid ? (__ballot(acc > P.thr_inside || !point_valid) == ~0ull) : true;
-            if (!__syncthreads_or(done ? 0 : 1)) break;  // every sub-block of this block is certified
+            // (a single chunk stays in LDS: its waves go on independently, no workgroup barrier between the passes)
+            if (n_chunks > 1 && !__syncthreads_or(done ? 0 : 1)) break;  // every sub-block of this block is certified: no second stream
             if (!done) acc = R(0.0);
             if (n_chunks > 1 && tid < SS_WTILE) nxt = tile[tid];  // over-dense block: the tile is streamed a second time
         }
