@@ -122,8 +122,11 @@ def splat_roofline(st, n_occ, n_subp, nsc, k3_acc_ms, k3_large_ms):
     return {
         "kernel": name, "bound": "hbm", "achieved": round(achieved, 2), "peak": 8000.0, "unit": "GB/s",
         "frac": round(achieved / 8000.0, 5), "traffic": None, "algorithmic_bytes": alg_bytes, "kernel_ms": round(k3 * 1e3, 4),
-        "note": "algorithmic bytes = 16 B x %d subdomain particles + 4 B x %d subdomains x %d^3 points; the kernel is FP32-VALU bound at this "
-                "cube radius (DESIGN.md section 5)" % (n_subp, n_occ, nsc),
+        "launches_ms": {"k_splat_accumulate (first pass, all active blocks)": round(k3_acc_ms - float(st.get("ms_levelset_accumulate_pass2", 0.0)), 4),
+                        "k_splat_accumulate_list (second pass, certified blocks next to the surface; incl. its block selection)": round(float(st.get("ms_levelset_accumulate_pass2", 0.0)), 4)},
+        "note": "algorithmic bytes = 16 B x %d subdomain particles + 4 B x %d subdomains x %d^3 points; kernel_ms = HIP events around both launches of the "
+                "accumulate kernel on the library's stream (launches_ms; the last step's split); the kernel is FP32-VALU bound at this cube radius "
+                "(DESIGN.md section 5)" % (n_subp, n_occ, nsc),
     }
 
 

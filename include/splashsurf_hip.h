@@ -161,6 +161,7 @@ typedef struct ss_stats {
     uint64_t n_certified_subblocks;   /* 4x4x4 sub-blocks the classification pass of the splat certified to lie inside the fluid */
     uint64_t n_truncated_blocks;      /* active blocks left with truncated (lower-bound) level-set values: inside the fluid, never read by MC */
     uint64_t n_completed_blocks;      /* truncated blocks next to the surface that the second splat pass evaluated in full */
+    double ms_levelset_accumulate_pass2; /* part of ms_levelset_accumulate: block selection + k_splat_accumulate_list (the second pass) */
 } ss_stats;
 
 typedef struct ss_context ss_context;

@@ -115,6 +115,7 @@ class _Stats(C.Structure):
         ("n_certified_subblocks", C.c_uint64),
         ("n_truncated_blocks", C.c_uint64),
         ("n_completed_blocks", C.c_uint64),
+        ("ms_levelset_accumulate_pass2", C.c_double),
     ]
 
 

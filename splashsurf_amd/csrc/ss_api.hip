@@ -1042,6 +1042,7 @@ ss_status phase_finish(ss_context* ctx, ss_result* res) {
         const double frac = (double)n_cert_waves / (8.0 * (double)n_active);
         ctx->early_enabled = frac > (ctx->early_enabled ? 0.30 : 0.35);
     }
+    S.ms_levelset_accumulate_pass2 = ev_ms(ctx, 14, 15);
     S.n_certified_subblocks = n_cert_waves;
     S.n_truncated_blocks = n_trunc_left;
     S.n_completed_blocks = n_redo;

@@ -26,7 +26,7 @@ def test_struct_layouts_match_header():
     from splashsurf_amd import api
     assert ctypes.sizeof(api._Params) == 5 * 4 + 4 + 24 + 6 * 4
     assert ctypes.sizeof(api._Grid) == 28 + 4 + 48  # 7 floats + pad + 6 int64
-    assert ctypes.sizeof(api._Stats) == 9 * 8 + 8 * 8 + 3 * 8 + 6 * 8  # + gather/accumulate timings, large-tile block count (ABI 2), arithmetic mode and arena bytes used / reserved (ABI 3)
+    assert ctypes.sizeof(api._Stats) == 9 * 8 + 8 * 8 + 3 * 8 + 7 * 8  # + gather/accumulate timings, large-tile block count (ABI 2), arithmetic mode and arena bytes used / reserved (ABI 3)
 
 
 def test_python_signature_mirrors_reference():

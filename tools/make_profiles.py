@@ -53,18 +53,22 @@ def main():
                 k, ms, v.get("FETCH_SIZE", 0), v.get("WRITE_SIZE", 0), hbm, rate, v.get("SQ_INSTS_VALU", 0), v.get("SQ_INSTS_SALU", 0), v.get("SQ_INSTS_LDS", 0),
                 v.get("SQ_WAVES", 0), v.get("SQ_INSTS_VALU", 0) / slots if slots else 0.0))
             if k.startswith("k_splat_accumulate"):
+                t = traffic["s10m_tank"].setdefault(mname, {
+                    "kernel": "k_splat_accumulate (both launches: first pass + k_splat_accumulate_list)", "hbm_bytes_per_launch": 0.0, "fetch_size_bytes_reported": 0.0,
+                    "write_size_bytes": 0.0, "kernel_ms_rocprof_avg": 0.0, "valu_insts_per_launch": 0.0, "launches": {},
+                    "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, --kernel-include-regex 'k_splat|k_density_sub') on S10M-tank, per step = sum over the "
+                            "two launches of the accumulate kernel; read side doubled per MI355X_MICROARCH.md (gfx950 FETCH_SIZE counts 128-B requests as 64 B); the "
+                            "accumulate kernel re-reads the index-ordered block tiles the gather kernel wrote (DESIGN.md section 5, profiles/r02_pmc_s10m_tank.md)",
+                    "valu_note": "SQ_INSTS_VALU of both launches per step (profiles/r02_pmc_s10m_tank.md); a SIMD-32 issues one wave64 VALU instruction per 2 cycles at best"})
+                t["hbm_bytes_per_launch"] += hbm
+                t["fetch_size_bytes_reported"] += v.get("FETCH_SIZE", 0.0) * 1024
+                t["write_size_bytes"] += v.get("WRITE_SIZE", 0.0) * 1024
+                t["kernel_ms_rocprof_avg"] += ms
+                t["valu_insts_per_launch"] += v.get("SQ_INSTS_VALU", 0.0)
+                t["launches"][k] = {"ms_rocprof_avg": ms, "hbm_bytes": hbm, "valu_insts": v.get("SQ_INSTS_VALU", 0.0)}
                 g = {c: sum(x) / len(x) for c, x in vals.get("k_splat_gather<float>", {}).items()}
-                traffic["s10m_tank"][mname] = {
-                    "kernel": k, "hbm_bytes_per_launch": hbm, "fetch_size_bytes_reported": v.get("FETCH_SIZE", 0.0) * 1024, "write_size_bytes": v.get("WRITE_SIZE", 0.0) * 1024,
-                    "kernel_ms_rocprof_avg": ms,
-                    "other_kernels": {"k_splat_gather<float>": {"fetch_size_bytes_reported": g.get("FETCH_SIZE", 0.0) * 1024, "write_size_bytes": g.get("WRITE_SIZE", 0.0) * 1024,
-                                                                "hbm_bytes_per_launch": 2.0 * g.get("FETCH_SIZE", 0.0) * 1024 + g.get("WRITE_SIZE", 0.0) * 1024}},
-                    "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, --kernel-include-regex 'k_splat|k_density_sub') on S10M-tank, per launch; read side "
-                            "doubled per MI355X_MICROARCH.md (gfx950 FETCH_SIZE counts 128-B requests as 64 B); the accumulate kernel re-reads the index-ordered block tiles "
-                            "the gather kernel wrote (DESIGN.md section 5, profiles/r02_pmc_s10m_tank.md)",
-                    "valu_insts_per_launch": v.get("SQ_INSTS_VALU", 0.0),
-                    "valu_note": "SQ_INSTS_VALU of k_splat_accumulate per launch (profiles/r02_pmc_s10m_tank.md); a SIMD-32 issues one wave64 VALU instruction per 2 cycles at best",
-                }
+                t["other_kernels"] = {"k_splat_gather<float>": {"fetch_size_bytes_reported": g.get("FETCH_SIZE", 0.0) * 1024, "write_size_bytes": g.get("WRITE_SIZE", 0.0) * 1024,
+                                                                "hbm_bytes_per_launch": 2.0 * g.get("FETCH_SIZE", 0.0) * 1024 + g.get("WRITE_SIZE", 0.0) * 1024}}
         md.append("")
     open(os.path.join(DST, "r02_pmc_s10m_tank.md"), "w").write("\n".join(md) + "\n")
     json.dump(traffic, open(os.path.join(DST, "splat_traffic.json"), "w"), indent=1)
