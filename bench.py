@@ -374,7 +374,11 @@ def main():
         },
         "roofline": roof,
         "stages_ms": {k: round(v, 4) for k, v in last_stats.items() if k.startswith("ms_")},
-        "splat_blocks": {"active": int(last_stats.get("n_active_blocks", 0)), "large_tile": int(last_stats.get("n_large_tile_blocks", 0))},
+        "splat_blocks": {"active": int(last_stats.get("n_active_blocks", 0)), "large_tile": int(last_stats.get("n_large_tile_blocks", 0)),
+                         "certified_subblocks_frac": round(float(last_stats.get("n_certified_subblocks", 0)) / max(8.0 * float(last_stats.get("n_active_blocks", 1)), 1.0), 4),
+                         "completed_by_second_pass": int(last_stats.get("n_completed_blocks", 0)), "left_truncated": int(last_stats.get("n_truncated_blocks", 0)),
+                         "tile_entries": int(last_stats.get("n_block_candidates", 0)), "tile_arena_bytes_used": int(last_stats.get("bytes_tile_arena", 0)),
+                         "tile_arena_bytes_reserved": int(last_stats.get("bytes_tile_arena_reserved", 0)), "device_bytes_held": int(last_stats.get("bytes_device_peak", 0))},
     })
     line.update(extra)
 
