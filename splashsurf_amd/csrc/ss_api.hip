@@ -132,6 +132,16 @@ ss_status exclusive_scan_u32(ss_context* ctx, const T* in, T* out, size_t n) {
 struct WidenU32 {
     __host__ __device__ unsigned long long operator()(uint32_t v) const { return (unsigned long long)v; }
 };
+struct NonZeroAsU32 {
+    __host__ __device__ uint32_t operator()(uint32_t v) const { return v ? 1u : 0u; }
+};
+struct PopcountU32 {
+    __host__ __device__ unsigned long long operator()(uint32_t v) const {
+        unsigned long long c = 0;
+        for (; v; v &= v - 1) ++c;
+        return c;
+    }
+};
 struct NonZeroU32 {
     __host__ __device__ unsigned long long operator()(uint32_t v) const { return v ? 1ull : 0ull; }
 };
@@ -930,11 +940,16 @@ ss_status phase_finish(ss_context* ctx, ss_result* res) {
     uint32_t* rd_rank = rd_flag + ((size_t)n_active + 1);
     uint32_t* rd_list = rd_rank + ((size_t)n_active + 1);
     ss_launch_splat_accumulate(PK, ctx->splat_tiles.as<ss_real4<R>>(), ctx->splat_off.as<unsigned long long>(), ctx->splat_counts.as<uint32_t>(),
-                               res->active_xyz.as<uint32_t>(), n_active, res->G.as<R>(), res->blk_minmax.as<ss_real2<R>>(), tr_flag, full_ls, nullptr, nullptr, st);
+                               res->active_xyz.as<uint32_t>(), n_active, res->G.as<R>(), res->blk_minmax.as<ss_real2<R>>(), tr_flag, full_ls, nullptr, nullptr, nullptr, st);
     SS_HIP(ctx, hipEventRecord(ctx->ev[13], st));
     if (n_active && !full_ls) {
-        s = sum_u32_to_u64(ctx, tr_flag, n_active, ctx->counter.as<unsigned long long>() + 2);  // certified sub-blocks (decides the next call's strategy)
-        if (s != SS_OK) return s;
+        {   // certified sub-blocks = set bits of the per-block masks (decides the next call's strategy)
+            auto it = rocprim::make_transform_iterator(tr_flag, PopcountU32());
+            size_t bytes = 0;
+            SS_HIP(ctx, rocprim::reduce(nullptr, bytes, it, ctx->counter.as<unsigned long long>() + 2, 0ull, (size_t)n_active, rocprim::plus<unsigned long long>(), st));
+            SS_HIP(ctx, ctx->temp.reserve(bytes));
+            SS_HIP(ctx, rocprim::reduce(ctx->temp.p, bytes, it, ctx->counter.as<unsigned long long>() + 2, 0ull, (size_t)n_active, rocprim::plus<unsigned long long>(), st));
+        }
     }
 
     // ---- K4 prepare: MC blocks = blocks whose 2x2x2 level-set neighbourhood straddles the threshold ----
@@ -944,11 +959,16 @@ ss_status phase_finish(ss_context* ctx, ss_result* res) {
     if (n_active && !full_ls) {
         SS_HIP(ctx, hipMemsetAsync(rd_flag, 0, ((size_t)n_active + 1) * 4, st));
         ss_launch_mark_redo_blocks(P, ctx->mc_flag.as<uint32_t>(), res->block_slot.as<uint32_t>(), tr_flag, (uint32_t)nblocks, rd_flag, st);
-        s = exclusive_scan_u32<uint32_t>(ctx, rd_flag, rd_rank, (size_t)n_active + 1);
-        if (s != SS_OK) return s;
+        {   // rank of every block with a non-empty mask
+            auto it = rocprim::make_transform_iterator(rd_flag, NonZeroAsU32());
+            size_t bytes = 0;
+            SS_HIP(ctx, rocprim::exclusive_scan(nullptr, bytes, it, rd_rank, 0u, (size_t)n_active + 1, rocprim::plus<uint32_t>(), st));
+            SS_HIP(ctx, ctx->temp.reserve(bytes));
+            SS_HIP(ctx, rocprim::exclusive_scan(ctx->temp.p, bytes, it, rd_rank, 0u, (size_t)n_active + 1, rocprim::plus<uint32_t>(), st));
+        }
         ss_launch_compact_blocks(rd_flag, rd_rank, n_active, rd_list, lg_slot, st);
         ss_launch_splat_accumulate(PK, ctx->splat_tiles.as<ss_real4<R>>(), ctx->splat_off.as<unsigned long long>(), ctx->splat_counts.as<uint32_t>(),
-                                   res->active_xyz.as<uint32_t>(), n_active, res->G.as<R>(), res->blk_minmax.as<ss_real2<R>>(), tr_flag, true, rd_list, rd_rank + n_active, st);
+                                   res->active_xyz.as<uint32_t>(), n_active, res->G.as<R>(), res->blk_minmax.as<ss_real2<R>>(), tr_flag, true, rd_list, rd_rank + n_active, rd_flag, st);
         s = count_nonzero_u32(ctx, tr_flag, n_active, ctx->counter.as<unsigned long long>() + 1);  // blocks still truncated (statistics)
         if (s != SS_OK) return s;
     }

@@ -1245,7 +1245,8 @@ template <class R, int ARITH, bool EARLY>
 __device__ __forceinline__ void splat_accumulate_block(SplatAccShared<R>& sh, const SSDevT<R>& P, uint32_t logical, const ss_real4<R>* __restrict__ arena,
                                                        const unsigned long long* __restrict__ tile_off, const uint32_t* __restrict__ counts,
                                                        const uint32_t* __restrict__ active_xyz, R* __restrict__ G, ss_real2<R>* __restrict__ blk_minmax,
-                                                       uint32_t* __restrict__ trunc) {
+                                                       uint32_t* __restrict__ trunc, uint32_t wave_mask) {
+    // wave_mask: the sub-blocks to evaluate (second pass: the certified ones marching cubes reads); the others keep their values
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n_tile = (int)counts[logical];
     const ss_real4<R>* tile = arena + tile_off[logical];
@@ -1256,7 +1257,8 @@ __device__ __forceinline__ void splat_accumulate_block(SplatAccShared<R>& sh, co
     // this wave's sub-block and this lane's grid point
     const int g0[3] = {bx * SS_BLOCK + ((wave >> 2) & 1) * 4, by * SS_BLOCK + ((wave >> 1) & 1) * 4, bz * SS_BLOCK + (wave & 1) * 4};
     const int gl[3] = {g0[0] + ((lane >> 4) & 3), g0[1] + ((lane >> 2) & 3), g0[2] + (lane & 3)};
-    const bool wave_valid = g0[0] < P.np[0] && g0[1] < P.np[1] && g0[2] < P.np[2];
+    const bool wave_selected = ((wave_mask >> wave) & 1u) != 0u;
+    const bool wave_valid = wave_selected && g0[0] < P.np[0] && g0[1] < P.np[1] && g0[2] < P.np[2];
     const bool point_valid = gl[0] < P.np[0] && gl[1] < P.np[1] && gl[2] < P.np[2];
     // global point coordinates: uniform_grid.rs:418-425 on the GLOBAL grid (dense_subdomains.rs:817-826); the SIMD loop of the
     // reference forms z with one fma (:1069), x and y like the scalar loop (:1113-1114)
@@ -1309,13 +1311,19 @@ __device__ __forceinline__ void splat_accumulate_block(SplatAccShared<R>& sh, co
             if (n_chunks > 1) __syncthreads();  // pay is overwritten by the next chunk
         }
     }
-    if (EARLY && done && wave_valid && lane == 0) atomicAdd(&sh.trunc, 1u);  // number of certified sub-blocks of this block
+    if (EARLY && done && wave_valid && lane == 0) atomicOr(&sh.trunc, 1u << wave);  // bit mask of the certified sub-blocks of this block
     // store: block-local layout (x*8+y)*8+z, i-major / k-fastest like dense_subdomains.rs:839
     const int lx = ((wave >> 2) & 1) * 4 + ((lane >> 4) & 3);
     const int ly = ((wave >> 1) & 1) * 4 + ((lane >> 2) & 3);
     const int lz = (wave & 1) * 4 + (lane & 3);
-    const R val = point_valid ? acc : R(0.0);
-    G[(size_t)logical * SS_BLOCK_POINTS + (size_t)((lx * 8 + ly) * 8 + lz)] = val;
+    R* gp = G + (size_t)logical * SS_BLOCK_POINTS + (size_t)((lx * 8 + ly) * 8 + lz);
+    R val;
+    if (wave_selected) {
+        val = point_valid ? acc : R(0.0);
+        *gp = val;
+    } else {
+        val = *gp;  // second pass: a sub-block that is not re-evaluated keeps its value (it still enters the block's min / max)
+    }
     // block-wide min/max of the level-set values (points outside the grid count as 0 = "outside"), used to skip marching cubes
     // on blocks that cannot contain the iso-surface; a truncated wave reports values that are all above the threshold, like
     // its complete values would be
@@ -1347,7 +1355,7 @@ __device__ __forceinline__ void splat_accumulate_block(SplatAccShared<R>& sh, co
             mx = ss_max(mx, sh.red[8 + q]);
         }
         blk_minmax[logical] = ss_make2(mn, mx);
-        trunc[logical] = EARLY ? sh.trunc : 0u;
+        trunc[logical] = EARLY ? sh.trunc : (wave_mask == 0xFFu ? 0u : (trunc[logical] & ~wave_mask));
     }
 }
 
@@ -1362,28 +1370,31 @@ __global__ __launch_bounds__(512) void k_splat_accumulate(SSDevT<R> P, const ss_
     const uint32_t per_xcd = (n_active + 7u) / 8u;
     const uint32_t logical = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
     if ((blockIdx.x >> 3) >= per_xcd || logical >= n_active) return;
-    splat_accumulate_block<R, ARITH, EARLY>(sh, P, logical, arena, tile_off, counts, active_xyz, G, blk_minmax, trunc);
+    splat_accumulate_block<R, ARITH, EARLY>(sh, P, logical, arena, tile_off, counts, active_xyz, G, blk_minmax, trunc, 0xFFu);
 }
 
 // second pass: the truncated blocks marching cubes will read (list and its length on the device), in full
 template <class R, int ARITH>
 __global__ __launch_bounds__(512) void k_splat_accumulate_list(SSDevT<R> P, const ss_real4<R>* __restrict__ arena, const unsigned long long* __restrict__ tile_off,
                                                                const uint32_t* __restrict__ counts, const uint32_t* __restrict__ active_xyz,
-                                                               const uint32_t* __restrict__ list, const uint32_t* __restrict__ n_list_dev, R* __restrict__ G,
-                                                               ss_real2<R>* __restrict__ blk_minmax, uint32_t* __restrict__ trunc) {
+                                                               const uint32_t* __restrict__ list, const uint32_t* __restrict__ n_list_dev,
+                                                               const uint32_t* __restrict__ redo_mask, R* __restrict__ G, ss_real2<R>* __restrict__ blk_minmax,
+                                                               uint32_t* __restrict__ trunc) {
     __shared__ SplatAccShared<R> sh;
     const uint32_t n = *n_list_dev;
     for (uint32_t it = blockIdx.x; it < n; it += gridDim.x) {
-        splat_accumulate_block<R, ARITH, false>(sh, P, list[it], arena, tile_off, counts, active_xyz, G, blk_minmax, trunc);
+        const uint32_t logical = list[it];
+        splat_accumulate_block<R, ARITH, false>(sh, P, logical, arena, tile_off, counts, active_xyz, G, blk_minmax, trunc, redo_mask[logical]);
         __syncthreads();
     }
 }
 
-// A truncated block has to be completed iff marching cubes reads it: MC block m reads the level-set blocks m + {0,1}^3, and only
-// MC blocks whose eight blocks straddle the threshold are triangulated (k_mark_mc_blocks).
+// A certified sub-block has to be completed iff marching cubes reads it: only MC blocks whose eight level-set blocks m + {0,1}^3
+// straddle the threshold are triangulated (k_mark_mc_blocks), and of a neighbour block m + d they read the first layer of points
+// along every axis with d = 1 only, i.e. the sub-blocks with sub-block coordinate 0 on those axes.
 template <class R>
 __global__ __launch_bounds__(256) void k_mark_redo_blocks(SSDevT<R> P, const uint32_t* __restrict__ mc_flag, const uint32_t* __restrict__ block_slot,
-                                                          const uint32_t* __restrict__ trunc, uint32_t nblocks, uint32_t* __restrict__ redo_flag) {
+                                                          const uint32_t* __restrict__ trunc, uint32_t nblocks, uint32_t* __restrict__ redo_mask) {
     const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= nblocks || !mc_flag[b]) return;
     const int bz = (int)(b % (uint32_t)P.nb[2]);
@@ -1395,7 +1406,12 @@ __global__ __launch_bounds__(256) void k_mark_redo_blocks(SSDevT<R> P, const uin
                 const int x = bx + dx, y = by + dy, z = bz + dz;
                 if (x >= P.nb[0] || y >= P.nb[1] || z >= P.nb[2]) continue;
                 const uint32_t slot = block_slot[((size_t)x * P.nb[1] + y) * P.nb[2] + z];
-                if (slot != 0xFFFFFFFFu && trunc[slot]) redo_flag[slot] = 1u;  // plain flag stores (all writers store 1)
+                if (slot == 0xFFFFFFFFu) continue;
+                uint32_t read = 0;  // sub-blocks (wx, wy, wz) -> bit (wx << 2) | (wy << 1) | wz, as in splat_accumulate_block
+                for (int w = 0; w < 8; ++w)
+                    if ((!dx || !((w >> 2) & 1)) && (!dy || !((w >> 1) & 1)) && (!dz || !(w & 1))) read |= 1u << w;
+                const uint32_t need = read & trunc[slot];
+                if (need) atomicOr(&redo_mask[slot], need);
             }
 }
 
@@ -1427,13 +1443,13 @@ void ss_launch_splat_gather_large(const SSDevT<R>& P, const ss_real4<R>* posvol,
 template <class R>
 void ss_launch_splat_accumulate(const SSDevT<R>& P, const ss_real4<R>* arena, const unsigned long long* tile_off, const uint32_t* counts,
                                 const uint32_t* active_xyz, uint32_t n_active, R* G, ss_real2<R>* blk_minmax, uint32_t* trunc, bool full_levelset,
-                                const uint32_t* list, const uint32_t* n_list_dev, hipStream_t st) {
+                                const uint32_t* list, const uint32_t* n_list_dev, const uint32_t* redo_mask, hipStream_t st) {
     if (!n_active) return;
     const dim3 grid(((n_active + 7u) / 8u) * 8u), block(512), lgrid(2048);
 #define SS_ACC(A)                                                                                                                                   \
     do {                                                                                                                                            \
         if (list)                                                                                                                                   \
-            hipLaunchKernelGGL((k_splat_accumulate_list<R, A>), lgrid, block, 0, st, P, arena, tile_off, counts, active_xyz, list, n_list_dev, G, blk_minmax, trunc); \
+            hipLaunchKernelGGL((k_splat_accumulate_list<R, A>), lgrid, block, 0, st, P, arena, tile_off, counts, active_xyz, list, n_list_dev, redo_mask, G, blk_minmax, trunc); \
         else if (full_levelset)                                                                                                                     \
             hipLaunchKernelGGL((k_splat_accumulate<R, A, false>), grid, block, 0, st, P, arena, tile_off, counts, active_xyz, n_active, G, blk_minmax, trunc); \
         else                                                                                                                                        \
@@ -1754,9 +1770,9 @@ template void ss_launch_splat_gather_large<float>(const SSDevT<float>& P, const 
 template void ss_launch_splat_bounds<double>(const SSDevT<double>& P, const uint32_t* cell_start, const uint32_t* active_xyz, uint32_t n_active, uint32_t* bound, hipStream_t st);
 template void ss_launch_splat_gather<double>(const SSDevT<double>& P, const ss_real4<double>* posvol, const uint32_t* perm, const uint32_t* cell_start, const uint32_t* active_xyz, uint32_t n_active, const unsigned long long* tile_off, ss_real4<double>* arena, uint32_t* counts, uint32_t* large_flag, hipStream_t st);
 template void ss_launch_splat_gather_large<double>(const SSDevT<double>& P, const ss_real4<double>* posvol, const ss_real4<double>* posvol_by_index, const uint32_t* perm, const uint32_t* cell_start, const uint32_t* active_xyz, const uint32_t* large_list, const uint32_t* n_large_dev, const uint32_t* counts, const unsigned long long* tile_off, ss_real4<double>* arena, hipStream_t st);
-template void ss_launch_splat_accumulate<float>(const SSDevT<float>& P, const ss_real4<float>* arena, const unsigned long long* tile_off, const uint32_t* counts, const uint32_t* active_xyz, uint32_t n_active, float* G, ss_real2<float>* blk_minmax, uint32_t* trunc, bool full_levelset, const uint32_t* list, const uint32_t* n_list_dev, hipStream_t st);
+template void ss_launch_splat_accumulate<float>(const SSDevT<float>& P, const ss_real4<float>* arena, const unsigned long long* tile_off, const uint32_t* counts, const uint32_t* active_xyz, uint32_t n_active, float* G, ss_real2<float>* blk_minmax, uint32_t* trunc, bool full_levelset, const uint32_t* list, const uint32_t* n_list_dev, const uint32_t* redo_mask, hipStream_t st);
 template void ss_launch_mark_redo_blocks<float>(const SSDevT<float>& P, const uint32_t* mc_flag, const uint32_t* block_slot, const uint32_t* trunc, uint32_t nblocks, uint32_t* redo_flag, hipStream_t st);
-template void ss_launch_splat_accumulate<double>(const SSDevT<double>& P, const ss_real4<double>* arena, const unsigned long long* tile_off, const uint32_t* counts, const uint32_t* active_xyz, uint32_t n_active, double* G, ss_real2<double>* blk_minmax, uint32_t* trunc, bool full_levelset, const uint32_t* list, const uint32_t* n_list_dev, hipStream_t st);
+template void ss_launch_splat_accumulate<double>(const SSDevT<double>& P, const ss_real4<double>* arena, const unsigned long long* tile_off, const uint32_t* counts, const uint32_t* active_xyz, uint32_t n_active, double* G, ss_real2<double>* blk_minmax, uint32_t* trunc, bool full_levelset, const uint32_t* list, const uint32_t* n_list_dev, const uint32_t* redo_mask, hipStream_t st);
 template void ss_launch_mark_redo_blocks<double>(const SSDevT<double>& P, const uint32_t* mc_flag, const uint32_t* block_slot, const uint32_t* trunc, uint32_t nblocks, uint32_t* redo_flag, hipStream_t st);
 template void ss_launch_mc_count<float>(const SSDevT<float>& P, const float* G, const uint32_t* block_slot, const uint32_t* mc_xyz, uint32_t n_mc, unsigned long long* masks, uint32_t* vcount, uint32_t* tcount, hipStream_t st);
 template void ss_launch_mc_count<double>(const SSDevT<double>& P, const double* G, const uint32_t* block_slot, const uint32_t* mc_xyz, uint32_t n_mc, unsigned long long* masks, uint32_t* vcount, uint32_t* tcount, hipStream_t st);
