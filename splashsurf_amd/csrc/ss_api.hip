@@ -781,9 +781,19 @@ ss_status phase_begin(ss_context* ctx, const R* xyz, uint64_t n_in, const typena
             }
             s = ensure_fast_div<R>(ctx, P.h, st);
             if (s != SS_OK) return s;
+            // the copies whose density their subdomain computes (every particle has exactly one), compacted in cell order
+            SS_HIP(ctx, ctx->own_flag.reserve(((size_t)n_copies + 1) * 4 * 3 + 64));
+            uint32_t* own_flag = ctx->own_flag.as<uint32_t>();
+            uint32_t* own_rank = own_flag + ((size_t)n_copies + 1);
+            uint32_t* own_list = own_rank + ((size_t)n_copies + 1);
+            ss_launch_owned_copy_flags(P, n_copies, ctx->cpos.as<ss_real4<R>>(), ctx->ckeys_b.as<uint32_t>(), ctx->occ_sub.as<uint32_t>(), own_flag, st);
+            s = exclusive_scan_u32<uint32_t>(ctx, own_flag, own_rank, (size_t)n_copies + 1);
+            if (s != SS_OK) return s;
+            ss_launch_compact_blocks(own_flag, own_rank, n_copies, own_list, ctx->cvals_a.as<uint32_t>(), st);  // (cvals_a: scratch for the unused slot table)
+            const uint32_t n_owned_bound = n < n_copies ? n : n_copies;  // at most one owned copy per particle
             ss_launch_density_sub(P, n_copies, ctx->cpos.as<ss_real4<R>>(), ctx->cidx.as<uint32_t>(), ctx->ckeys_b.as<uint32_t>(),
                                   ctx->cell_start2.as<uint32_t>(), ctx->occ_sub.as<uint32_t>(), res->rho.as<R>(), want_nb ? 1 : 0,
-                                  ctx->nb_count.as<uint32_t>(), nullptr, nullptr, sizeof(R) == 4 && ctx->fastdiv_ok, st);
+                                  ctx->nb_count.as<uint32_t>(), nullptr, nullptr, sizeof(R) == 4 && ctx->fastdiv_ok, own_list, own_rank + n_copies, n_owned_bound, st);
             if (want_nb) {
                 // counts (u32, first n+1 entries) -> u64 -> exclusive scan = CSR row pointers
                 SS_HIP(ctx, ctx->nb_tmp.reserve(((size_t)n + 1) * 8));
@@ -798,7 +808,7 @@ ss_status phase_begin(ss_context* ctx, const R* xyz, uint64_t n_in, const typena
                 SS_HIP(ctx, res->nb_idx.reserve((size_t)total_nb * 4 + 16));
                 ss_launch_density_sub(P, n_copies, ctx->cpos.as<ss_real4<R>>(), ctx->cidx.as<uint32_t>(), ctx->ckeys_b.as<uint32_t>(),
                                       ctx->cell_start2.as<uint32_t>(), ctx->occ_sub.as<uint32_t>(), res->rho.as<R>(), 2, nullptr,
-                                      res->nb_ptr.as<unsigned long long>(), res->nb_idx.as<uint32_t>(), false, st);
+                                      res->nb_ptr.as<unsigned long long>(), res->nb_idx.as<uint32_t>(), false, own_list, own_rank + n_copies, n_owned_bound, st);
             }
             res->has_neighbors = want_nb;
         } else {
@@ -1403,7 +1413,7 @@ void ss_context_destroy(ss_context* c) {
     for (DevBuf* b : {&c->xyz_in, &c->xyz_filt, &c->flags32, &c->offsets, &c->keys_a, &c->keys_b, &c->vals_a, &c->cell_count,
                       &c->cell_start, &c->pos_sorted, &c->temp, &c->aabb_partial, &c->aabb_out, &c->block_flag, &c->block_rank, &c->mc_flag,
                       &c->mc_rank, &c->vcount, &c->tcount, &c->counter, &c->member_count, &c->copy_offset, &c->sub_flag, &c->sub_rank,
-                      &c->nb_count, &c->nb_tmp, &c->occ_sub, &c->ckeys_a, &c->ckeys_b, &c->cvals_a, &c->cidx, &c->cpos, &c->cell_count2, &c->cell_start2, &c->gboxes, &c->fastdiv_scratch, &c->splat_overflow, &c->splat_tiles, &c->splat_counts, &c->splat_off, &c->splat_bound, &c->splat_trunc})
+                      &c->nb_count, &c->nb_tmp, &c->occ_sub, &c->ckeys_a, &c->ckeys_b, &c->cvals_a, &c->cidx, &c->cpos, &c->cell_count2, &c->cell_start2, &c->gboxes, &c->fastdiv_scratch, &c->splat_overflow, &c->splat_tiles, &c->splat_counts, &c->splat_off, &c->splat_bound, &c->splat_trunc, &c->own_flag})
         b->release();
     for (DevBuf& b : c->post_pool) b.release();
     if (c->ev_ok)

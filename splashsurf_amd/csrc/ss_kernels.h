@@ -19,7 +19,9 @@ void ss_launch_occupied_list(const uint32_t* flag, const uint32_t* rank, uint32_
 template <class R>
 void ss_launch_emit_copies(const SSDevT<R>& P, const R* xyz, const uint32_t* copy_offset, const uint32_t* occ_rank, uint32_t* keys, uint32_t* vals, uint32_t* cell_count, hipStream_t st);
 template <class R>
-void ss_launch_density_sub(const SSDevT<R>& P, uint32_t n_copies, const ss_real4<R>* cpos, const uint32_t* cidx, const uint32_t* ckey, const uint32_t* cell_start, const uint32_t* occ_sub, R* rho, int mode, uint32_t* nb_count, const unsigned long long* nb_ptr, uint32_t* nb_idx, bool fast_div, hipStream_t st);
+void ss_launch_density_sub(const SSDevT<R>& P, uint32_t n_copies, const ss_real4<R>* cpos, const uint32_t* cidx, const uint32_t* ckey, const uint32_t* cell_start, const uint32_t* occ_sub, R* rho, int mode, uint32_t* nb_count, const unsigned long long* nb_ptr, uint32_t* nb_idx, bool fast_div, const uint32_t* owned_list, const uint32_t* n_owned_dev, uint32_t n_owned_bound, hipStream_t st);
+template <class R>
+void ss_launch_owned_copy_flags(const SSDevT<R>& P, uint32_t n_copies, const ss_real4<R>* cpos, const uint32_t* ckey, const uint32_t* occ_sub, uint32_t* owned, hipStream_t st);
 template <class R>
 void ss_launch_make_posvol(const SSDevT<R>& P, const ss_real4<R>* pos_sorted, const uint32_t* perm, const R* rho, ss_real4<R>* posvol, ss_real4<R>* posvol_by_index, hipStream_t st);
 template <class R>

@@ -382,6 +382,35 @@ template <class R> struct SSDensityQueue {
     static constexpr int cap = sizeof(R) == 4 ? 16 : 8;
     static constexpr int chunk = 4;  // candidates between two fill checks
 };
+// owned[p] = copy p lies inside the half-open AABB of its subdomain (is_inside, dense_subdomains.rs:567-576, aabb.rs:220-222):
+// the copy whose density this subdomain computes; the others are ghosts, their density comes from another subdomain
+template <class R>
+__global__ __launch_bounds__(256) void k_owned_copy_flags(SSDevT<R> P, uint32_t n_copies, const ss_real4<R>* __restrict__ cpos, const uint32_t* __restrict__ ckey,
+                                                          const uint32_t* __restrict__ occ_sub, uint32_t* __restrict__ owned) {
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p > n_copies) return;
+    uint32_t f = 0;
+    if (p < n_copies) {
+        const uint32_t ctot = (uint32_t)(P.sc[0] * P.sc[1] * P.sc[2]);
+        const uint32_t flat = occ_sub[ckey[p] / ctot];
+        const int s3[3] = {(int)(flat / ((uint32_t)P.ns[2] * (uint32_t)P.ns[1])), (int)((flat / (uint32_t)P.ns[2]) % (uint32_t)P.ns[1]), (int)(flat % (uint32_t)P.ns[2])};
+        const ss_real4<R> pi = cpos[p];
+        const R x3[3] = {pi.x, pi.y, pi.z};
+        f = 1;
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            const R lo = P.gmin[d] + (R)s3[d] * P.sub_size;
+            const R hi = P.gmin[d] + (R)(s3[d] + 1) * P.sub_size;
+            if (!(x3[d] >= lo && x3[d] < hi)) f = 0;
+        }
+    }
+    owned[p] = f;  // entry n_copies: 0, so that the exclusive scan ends with the count
+}
+template <class R>
+void ss_launch_owned_copy_flags(const SSDevT<R>& P, uint32_t n_copies, const ss_real4<R>* cpos, const uint32_t* ckey, const uint32_t* occ_sub, uint32_t* owned, hipStream_t st) {
+    hipLaunchKernelGGL(k_owned_copy_flags<R>, dim3((n_copies + 1u + 255u) / 256u), dim3(256), 0, st, P, n_copies, cpos, ckey, occ_sub, owned);
+}
+
 // MODE 0: densities.  MODE 1: densities + neighbour counts (global_neighborhood_list).
 // MODE 2: write the neighbour ids (global particle indices) at nb_ptr[i], in the reference's order
 // (dense_subdomains.rs:617-639: the per-subdomain lists remapped to global indices).
@@ -390,12 +419,16 @@ __global__ __launch_bounds__(256) void k_density_sub(SSDevT<R> P, uint32_t n_cop
                                                      const uint32_t* __restrict__ ckey, const uint32_t* __restrict__ cell_start,
                                                      const uint32_t* __restrict__ occ_sub, R* __restrict__ rho,
                                                      uint32_t* __restrict__ nb_count, const unsigned long long* __restrict__ nb_ptr,
-                                                     uint32_t* __restrict__ nb_idx) {
+                                                     uint32_t* __restrict__ nb_idx, const uint32_t* __restrict__ owned_list,
+                                                     const uint32_t* __restrict__ n_owned_dev) {
     constexpr int QC = SSDensityQueue<R>::cap, QD = SSDensityQueue<R>::chunk;
     __shared__ R s_q[(MODE == 2) ? 1 : QC][256];
     const int tid = threadIdx.x;
-    uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= n_copies) return;
+    // Threads walk the OWNED copies only (k_owned_copy_flags + scan + compaction, in cell order): about half of the copies are
+    // ghosts, and a wave of owners and idling ghosts costs as much as a wave of owners.
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= *n_owned_dev) return;
+    const uint32_t p = owned_list[t];
     const uint32_t ctot = (uint32_t)(P.sc[0] * P.sc[1] * P.sc[2]);
     const uint32_t key = ckey[p];
     const uint32_t occ = key / ctot, cell = key - occ * ctot;
@@ -404,17 +437,9 @@ __global__ __launch_bounds__(256) void k_density_sub(SSDevT<R> P, uint32_t n_cop
     const int sy = (int)((flat / (uint32_t)P.ns[2]) % (uint32_t)P.ns[1]);
     const int sx = (int)(flat / ((uint32_t)P.ns[2] * (uint32_t)P.ns[1]));
     const ss_real4<R> pi = cpos[p];
-    // is_inside: half-open AABB of the subdomain (dense_subdomains.rs:567-576, aabb.rs:220-222)
-    {
-        const int s3[3] = {sx, sy, sz};
-        const R x3[3] = {pi.x, pi.y, pi.z};
-#pragma unroll
-        for (int d = 0; d < 3; ++d) {
-            const R lo = P.gmin[d] + (R)s3[d] * P.sub_size;
-            const R hi = P.gmin[d] + (R)(s3[d] + 1) * P.sub_size;
-            if (!(x3[d] >= lo && x3[d] < hi)) return;  // ghost copy: density computed by another subdomain
-        }
-    }
+    (void)sx;
+    (void)sy;
+    (void)sz;
     const int cz = (int)(cell % (uint32_t)P.sc[2]);
     const int cy = (int)((cell / (uint32_t)P.sc[2]) % (uint32_t)P.sc[1]);
     const int cx = (int)(cell / ((uint32_t)P.sc[2] * (uint32_t)P.sc[1]));
@@ -529,24 +554,25 @@ void ss_launch_emit_copies(const SSDevT<R>& P, const R* xyz, const uint32_t* cop
 template <class R>
 void ss_launch_density_sub(const SSDevT<R>& P, uint32_t n_copies, const ss_real4<R>* cpos, const uint32_t* cidx, const uint32_t* ckey,
                            const uint32_t* cell_start, const uint32_t* occ_sub, R* rho, int mode, uint32_t* nb_count,
-                           const unsigned long long* nb_ptr, uint32_t* nb_idx, bool fast_div, hipStream_t st) {
+                           const unsigned long long* nb_ptr, uint32_t* nb_idx, bool fast_div, const uint32_t* owned_list, const uint32_t* n_owned_dev,
+                           uint32_t n_owned_bound, hipStream_t st) {
     if (!n_copies) return;
-    const dim3 g((n_copies + 255) / 256), b(256);
+    const dim3 g((n_owned_bound + 255) / 256), b(256);
     if constexpr (sizeof(R) == 4) {
         if (fast_div && mode != 2) {  // lean exact sqrt and verified reciprocal division inside W (see ss_kernel_w)
             if (mode == 0)
-                hipLaunchKernelGGL((k_density_sub<R, 0, true>), g, b, 0, st, P, n_copies, cpos, cidx, ckey, cell_start, occ_sub, rho, nb_count, nb_ptr, nb_idx);
+                hipLaunchKernelGGL((k_density_sub<R, 0, true>), g, b, 0, st, P, n_copies, cpos, cidx, ckey, cell_start, occ_sub, rho, nb_count, nb_ptr, nb_idx, owned_list, n_owned_dev);
             else
-                hipLaunchKernelGGL((k_density_sub<R, 1, true>), g, b, 0, st, P, n_copies, cpos, cidx, ckey, cell_start, occ_sub, rho, nb_count, nb_ptr, nb_idx);
+                hipLaunchKernelGGL((k_density_sub<R, 1, true>), g, b, 0, st, P, n_copies, cpos, cidx, ckey, cell_start, occ_sub, rho, nb_count, nb_ptr, nb_idx, owned_list, n_owned_dev);
             return;
         }
     }
     if (mode == 0)
-        hipLaunchKernelGGL((k_density_sub<R, 0, false>), g, b, 0, st, P, n_copies, cpos, cidx, ckey, cell_start, occ_sub, rho, nb_count, nb_ptr, nb_idx);
+        hipLaunchKernelGGL((k_density_sub<R, 0, false>), g, b, 0, st, P, n_copies, cpos, cidx, ckey, cell_start, occ_sub, rho, nb_count, nb_ptr, nb_idx, owned_list, n_owned_dev);
     else if (mode == 1)
-        hipLaunchKernelGGL((k_density_sub<R, 1, false>), g, b, 0, st, P, n_copies, cpos, cidx, ckey, cell_start, occ_sub, rho, nb_count, nb_ptr, nb_idx);
+        hipLaunchKernelGGL((k_density_sub<R, 1, false>), g, b, 0, st, P, n_copies, cpos, cidx, ckey, cell_start, occ_sub, rho, nb_count, nb_ptr, nb_idx, owned_list, n_owned_dev);
     else
-        hipLaunchKernelGGL((k_density_sub<R, 2, false>), g, b, 0, st, P, n_copies, cpos, cidx, ckey, cell_start, occ_sub, rho, nb_count, nb_ptr, nb_idx);
+        hipLaunchKernelGGL((k_density_sub<R, 2, false>), g, b, 0, st, P, n_copies, cpos, cidx, ckey, cell_start, occ_sub, rho, nb_count, nb_ptr, nb_idx, owned_list, n_owned_dev);
 }
 template <class R>
 void ss_launch_make_posvol(const SSDevT<R>& P, const ss_real4<R>* pos_sorted, const uint32_t* perm, const R* rho, ss_real4<R>* posvol,
@@ -1754,8 +1780,10 @@ template void ss_launch_classify_count<float>(const SSDevT<float>& P, const floa
 template void ss_launch_classify_count<double>(const SSDevT<double>& P, const double* xyz, uint32_t* member_count, uint32_t* sub_flag, hipStream_t st);
 template void ss_launch_emit_copies<float>(const SSDevT<float>& P, const float* xyz, const uint32_t* copy_offset, const uint32_t* occ_rank, uint32_t* keys, uint32_t* vals, uint32_t* cell_count, hipStream_t st);
 template void ss_launch_emit_copies<double>(const SSDevT<double>& P, const double* xyz, const uint32_t* copy_offset, const uint32_t* occ_rank, uint32_t* keys, uint32_t* vals, uint32_t* cell_count, hipStream_t st);
-template void ss_launch_density_sub<float>(const SSDevT<float>& P, uint32_t n_copies, const ss_real4<float>* cpos, const uint32_t* cidx, const uint32_t* ckey, const uint32_t* cell_start, const uint32_t* occ_sub, float* rho, int mode, uint32_t* nb_count, const unsigned long long* nb_ptr, uint32_t* nb_idx, bool fast_div, hipStream_t st);
-template void ss_launch_density_sub<double>(const SSDevT<double>& P, uint32_t n_copies, const ss_real4<double>* cpos, const uint32_t* cidx, const uint32_t* ckey, const uint32_t* cell_start, const uint32_t* occ_sub, double* rho, int mode, uint32_t* nb_count, const unsigned long long* nb_ptr, uint32_t* nb_idx, bool fast_div, hipStream_t st);
+template void ss_launch_owned_copy_flags<float>(const SSDevT<float>& P, uint32_t n_copies, const ss_real4<float>* cpos, const uint32_t* ckey, const uint32_t* occ_sub, uint32_t* owned, hipStream_t st);
+template void ss_launch_owned_copy_flags<double>(const SSDevT<double>& P, uint32_t n_copies, const ss_real4<double>* cpos, const uint32_t* ckey, const uint32_t* occ_sub, uint32_t* owned, hipStream_t st);
+template void ss_launch_density_sub<float>(const SSDevT<float>& P, uint32_t n_copies, const ss_real4<float>* cpos, const uint32_t* cidx, const uint32_t* ckey, const uint32_t* cell_start, const uint32_t* occ_sub, float* rho, int mode, uint32_t* nb_count, const unsigned long long* nb_ptr, uint32_t* nb_idx, bool fast_div, const uint32_t* owned_list, const uint32_t* n_owned_dev, uint32_t n_owned_bound, hipStream_t st);
+template void ss_launch_density_sub<double>(const SSDevT<double>& P, uint32_t n_copies, const ss_real4<double>* cpos, const uint32_t* cidx, const uint32_t* ckey, const uint32_t* cell_start, const uint32_t* occ_sub, double* rho, int mode, uint32_t* nb_count, const unsigned long long* nb_ptr, uint32_t* nb_idx, bool fast_div, const uint32_t* owned_list, const uint32_t* n_owned_dev, uint32_t n_owned_bound, hipStream_t st);
 template void ss_launch_block_coords<float>(const SSDevT<float>& P, const uint32_t* active_list, uint32_t n_active, uint32_t* xyz, hipStream_t st);
 template void ss_launch_block_coords<double>(const SSDevT<double>& P, const uint32_t* active_list, uint32_t n_active, uint32_t* xyz, hipStream_t st);
 template void ss_launch_make_posvol<float>(const SSDevT<float>& P, const ss_real4<float>* pos_sorted, const uint32_t* perm, const float* rho, ss_real4<float>* posvol, ss_real4<float>* posvol_by_index, hipStream_t st);
