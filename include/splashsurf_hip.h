@@ -178,8 +178,11 @@ int ss_last_error_detail(const ss_context *ctx);
  * accumulating (all terms are >= 0, so it is known to lie inside the fluid), and only those truncated blocks that marching
  * cubes reads -- blocks next to a sign change -- are completed by a second pass: mesh, densities and every level-set value
  * that influences them are unchanged, values deep inside the fluid are lower bounds.  Set it before ss_result_levelset_box
- * is used to inspect values away from the surface. */
-enum { SS_OPTION_FULL_LEVELSET = 1 };
+ * is used to inspect values away from the surface.
+ * SS_OPTION_SPLAT_TWO_PASS (default -1): -1 = the library decides per workload whether the certification scheme above pays off
+ * (jobs below 16 k active blocks and workloads whose previous call certified < 30 % of the sub-blocks evaluate everything), 0 = never,
+ * 1 = always (tests).  Output is identical in every setting. */
+enum { SS_OPTION_FULL_LEVELSET = 1, SS_OPTION_SPLAT_TWO_PASS = 2 };
 ss_status ss_context_set_option(ss_context *ctx, int option, int value);
 /* use an existing HIP stream (hipStream_t passed as void*); NULL = context's own stream */
 ss_status ss_context_set_stream(ss_context *ctx, void *hip_stream);

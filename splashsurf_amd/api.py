@@ -341,6 +341,13 @@ class Context:
         if st != 0:
             self._raise(st)
 
+    def set_two_pass(self, mode=-1):
+        """SS_OPTION_SPLAT_TWO_PASS: -1 automatic (default), 0 never, 1 always certify sub-blocks inside the fluid before evaluating them."""
+        self._lib.ss_context_set_option.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        st = self._lib.ss_context_set_option(self._h, 2, int(mode))
+        if st != 0:
+            self._raise(st)
+
     def set_stream(self, hip_stream_ptr):
         st = self._lib.ss_context_set_stream(self._h, C.c_void_p(hip_stream_ptr))
         if st != 0:

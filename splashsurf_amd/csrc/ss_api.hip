@@ -943,7 +943,7 @@ ss_status phase_finish(ss_context* ctx, ss_result* res) {
         probe = true;
         ctx->early_skipped = 0;
     }
-    const bool full_ls = ctx->full_levelset || n_active < 16384u || !(prm_threshold > R(0.0)) || !probe;
+    const bool full_ls = ctx->full_levelset || !(prm_threshold > R(0.0)) || ctx->two_pass == 0 || (ctx->two_pass < 0 && (n_active < 16384u || !probe));
     SS_HIP(ctx, ctx->splat_trunc.reserve(((size_t)n_active + 1) * 4 * 4 + 64));
     uint32_t* tr_flag = ctx->splat_trunc.as<uint32_t>();          // block carries truncated values
     uint32_t* rd_flag = tr_flag + ((size_t)n_active + 1);         // ... and marching cubes will read it
@@ -1429,6 +1429,11 @@ ss_status ss_context_set_option(ss_context* c, int option, int value) {
     if (!c) return SS_ERR_INVALID_ARGUMENT;
     if (option == SS_OPTION_FULL_LEVELSET) {
         c->full_levelset = value != 0;
+        return SS_OK;
+    }
+    if (option == SS_OPTION_SPLAT_TWO_PASS) {
+        if (value < -1 || value > 1) return fail(c, SS_ERR_INVALID_ARGUMENT, "SS_OPTION_SPLAT_TWO_PASS takes -1 (automatic), 0 or 1");
+        c->two_pass = value;
         return SS_OK;
     }
     return fail(c, SS_ERR_INVALID_ARGUMENT, "unknown context option");

@@ -84,6 +84,7 @@ struct ss_context {
     uint64_t early_key = 0;
     bool early_enabled = true;
     int early_skipped = 0;
+    int two_pass = -1;           // SS_OPTION_SPLAT_TWO_PASS: -1 automatic, 0 never, 1 always
     bool full_levelset = false;  // SS_OPTION_FULL_LEVELSET: no early exit in the splat (complete level-set values everywhere)
     // exhaustively verified "division by h via reciprocal + 2 FMA" (ss_kernels.hip ss_div_by_h)
     DevBuf fastdiv_scratch;

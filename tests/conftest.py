@@ -73,3 +73,15 @@ def full_levelset_ctx():
     ctx = Context(0)
     ctx.set_full_levelset(True)
     return ctx
+
+
+@pytest.fixture(scope="session")
+def two_pass_ctx():
+    """A context with SS_OPTION_SPLAT_TWO_PASS = 1: the splat certifies sub-blocks inside the fluid and completes only what
+    marching cubes reads, also on small jobs (the automatic setting reserves the scheme for >= 16 k active blocks)."""
+    import splashsurf_amd as S
+    from splashsurf_amd.api import Context
+    S.load_library()
+    ctx = Context(0)
+    ctx.set_two_pass(1)
+    return ctx

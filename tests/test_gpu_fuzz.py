@@ -51,7 +51,14 @@ for c in CASES:
 
 @pytest.mark.parametrize("case", CASES + SIMD_CASES, ids=lambda c: "%s-%s-c%.2g-n%d-%s%s%s" % (c["kind"], c["strategy"], c["c"], c["n_cubes"], "f64" if c["f64"] else "f32",
                                                                                                 "-aabb" if c["aabb"] else "", "-simd" if c["simd"] else ""))
-def test_random_configuration_bit_identical(gpu_ctx, oracle, case):
+def test_random_configuration_bit_identical(gpu_ctx, two_pass_ctx, oracle, case):
+    _run_case(gpu_ctx, oracle, case)
+    if case["strategy"] == "grid":  # the same with the two-pass splat forced on (certification of sub-blocks inside the fluid)
+        res = _run_case(two_pass_ctx, oracle, case)
+        assert res.stats["n_certified_subblocks"] >= 0
+
+
+def _run_case(gpu_ctx, oracle, case):
     import splashsurf_amd as S
     dt = np.float64 if case["f64"] else np.float32
     rng = np.random.default_rng(case["seed"])
@@ -81,3 +88,4 @@ def test_random_configuration_bit_identical(gpu_ctx, oracle, case):
         assert_gpu_equals_oracle(res, orc)
     ptr, idx = res.particle_neighbors_csr
     assert np.array_equal(ptr, orc.neighbor_ptr) and np.array_equal(idx, orc.neighbors)
+    return res
