@@ -174,11 +174,11 @@ void ss_context_destroy(ss_context *ctx);
 const char *ss_last_error(const ss_context *ctx);
 int ss_last_error_detail(const ss_context *ctx);
 /* Context options.  SS_OPTION_FULL_LEVELSET (default 0): 1 = evaluate the level set completely at every grid point of every
- * active block.  By default a 4x4x4 sub-block whose running values have all passed the iso-surface threshold stops
- * accumulating (all terms are >= 0, so it is known to lie inside the fluid), and only those truncated blocks that marching
- * cubes reads -- blocks next to a sign change -- are completed by a second pass: mesh, densities and every level-set value
- * that influences them are unchanged, values deep inside the fluid are lower bounds.  Set it before ss_result_levelset_box
- * is used to inspect values away from the surface.
+ * active block.  By default the splat first certifies 4x4x4 sub-blocks that lie inside the fluid with a lower bound of the level
+ * set (the sum over the nearby particles only; all terms are >= 0) and evaluates in full what is not certified plus the certified
+ * sub-blocks that marching cubes reads -- those next to a sign change: mesh, densities and every level-set value that influences
+ * them are unchanged, values deep inside the fluid are lower bounds.  Set it before ss_result_levelset_box is used to inspect
+ * values away from the surface.
  * SS_OPTION_SPLAT_TWO_PASS (default -1): -1 = the library decides per workload whether the certification scheme above pays off
  * (jobs below 16 k active blocks and workloads whose previous call certified < 30 % of the sub-blocks evaluate everything), 0 = never,
  * 1 = always (tests).  Output is identical in every setting. */
