@@ -944,13 +944,15 @@ ss_status phase_finish(ss_context* ctx, ss_result* res) {
         ctx->early_skipped = 0;
     }
     const bool full_ls = ctx->full_levelset || !(prm_threshold > R(0.0)) || ctx->two_pass == 0 || (ctx->two_pass < 0 && (n_active < 16384u || !probe));
-    SS_HIP(ctx, ctx->splat_trunc.reserve(((size_t)n_active + 1) * 4 * 4 + 64));
-    uint32_t* tr_flag = ctx->splat_trunc.as<uint32_t>();          // block carries truncated values
+    SS_HIP(ctx, ctx->splat_trunc.reserve(((size_t)n_active + 2) * (8 + 5 * 4) + 64));
+    unsigned long long* face_bits = ctx->splat_trunc.as<unsigned long long>();  // per block: faces of its sub-blocks with points outside the surface
+    uint32_t* tr_flag = (uint32_t*)(face_bits + ((size_t)n_active + 2));        // per block: mask of the certified sub-blocks
     uint32_t* rd_flag = tr_flag + ((size_t)n_active + 1);         // ... and marching cubes will read it
     uint32_t* rd_rank = rd_flag + ((size_t)n_active + 1);
     uint32_t* rd_list = rd_rank + ((size_t)n_active + 1);
+    uint32_t* big = rd_list + ((size_t)n_active + 1);            // blocks handed to the workgroup-per-block kernel (count, list)
     ss_launch_splat_accumulate(PK, ctx->splat_tiles.as<ss_real4<R>>(), ctx->splat_off.as<unsigned long long>(), ctx->splat_counts.as<uint32_t>(),
-                               res->active_xyz.as<uint32_t>(), n_active, res->G.as<R>(), res->blk_minmax.as<ss_real2<R>>(), tr_flag, full_ls, nullptr, nullptr, nullptr, st);
+                               res->active_xyz.as<uint32_t>(), n_active, res->G.as<R>(), res->blk_minmax.as<ss_real2<R>>(), tr_flag, full_ls, nullptr, nullptr, nullptr, face_bits, big, st);
     SS_HIP(ctx, hipEventRecord(ctx->ev[13], st));
     if (n_active && !full_ls) {
         {   // certified sub-blocks = set bits of the per-block masks (decides the next call's strategy)
@@ -967,8 +969,7 @@ ss_status phase_finish(ss_context* ctx, ss_result* res) {
     // second pass of the splat: truncated blocks that marching cubes is going to read are completed (list and count stay on the device)
     SS_HIP(ctx, hipEventRecord(ctx->ev[14], st));
     if (n_active && !full_ls) {
-        SS_HIP(ctx, hipMemsetAsync(rd_flag, 0, ((size_t)n_active + 1) * 4, st));
-        ss_launch_mark_redo_blocks(P, ctx->mc_flag.as<uint32_t>(), res->block_slot.as<uint32_t>(), tr_flag, (uint32_t)nblocks, rd_flag, st);
+        ss_launch_select_redo(P, res->active_xyz.as<uint32_t>(), n_active, res->block_slot.as<uint32_t>(), tr_flag, face_bits, rd_flag, st);
         {   // rank of every block with a non-empty mask
             auto it = rocprim::make_transform_iterator(rd_flag, NonZeroAsU32());
             size_t bytes = 0;
@@ -978,7 +979,7 @@ ss_status phase_finish(ss_context* ctx, ss_result* res) {
         }
         ss_launch_compact_blocks(rd_flag, rd_rank, n_active, rd_list, lg_slot, st);
         ss_launch_splat_accumulate(PK, ctx->splat_tiles.as<ss_real4<R>>(), ctx->splat_off.as<unsigned long long>(), ctx->splat_counts.as<uint32_t>(),
-                                   res->active_xyz.as<uint32_t>(), n_active, res->G.as<R>(), res->blk_minmax.as<ss_real2<R>>(), tr_flag, true, rd_list, rd_rank + n_active, rd_flag, st);
+                                   res->active_xyz.as<uint32_t>(), n_active, res->G.as<R>(), res->blk_minmax.as<ss_real2<R>>(), tr_flag, true, rd_list, rd_rank + n_active, rd_flag, face_bits, big, st);
         s = count_nonzero_u32(ctx, tr_flag, n_active, ctx->counter.as<unsigned long long>() + 1);  // blocks still truncated (statistics)
         if (s != SS_OK) return s;
     }

@@ -1258,6 +1258,13 @@ __device__ __forceinline__ float ss_wave_reduce_to_lane63(float v) {
     return v;
 }
 
+// Which of the six faces of a 4^3 sub-block (lane l <-> point ((l>>4)&3, (l>>2)&3, l&3)) hold a point that is NOT inside the
+// surface (marching cubes: inside <=> value > threshold, dense_subdomains.rs:1482).  bit f: 0 -x, 1 +x, 2 -y, 3 +y, 4 -z, 5 +z.
+__device__ __forceinline__ uint32_t splat_face_bits(unsigned long long outside) {
+    return ((outside & 0x000000000000FFFFull) ? 1u : 0u) | ((outside & 0xFFFF000000000000ull) ? 2u : 0u) | ((outside & 0x000F000F000F000Full) ? 4u : 0u) |
+           ((outside & 0xF000F000F000F000ull) ? 8u : 0u) | ((outside & 0x1111111111111111ull) ? 16u : 0u) | ((outside & 0x8888888888888888ull) ? 32u : 0u);
+}
+
 // step 3
 template <class R>
 struct SplatAccShared {
@@ -1265,13 +1272,14 @@ struct SplatAccShared {
     ss_real4<R> wl[8][SS_WAVE_LIST];
     R red[16];
     uint32_t trunc;
+    uint32_t face[8];
 };
 
 template <class R, int ARITH, bool EARLY>
 __device__ __forceinline__ void splat_accumulate_block(SplatAccShared<R>& sh, const SSDevT<R>& P, uint32_t logical, const ss_real4<R>* __restrict__ arena,
                                                        const unsigned long long* __restrict__ tile_off, const uint32_t* __restrict__ counts,
                                                        const uint32_t* __restrict__ active_xyz, R* __restrict__ G, ss_real2<R>* __restrict__ blk_minmax,
-                                                       uint32_t* __restrict__ trunc, uint32_t wave_mask) {
+                                                       uint32_t* __restrict__ trunc, unsigned long long* __restrict__ facebits, uint32_t wave_mask) {
     // wave_mask: the sub-blocks to evaluate (second pass: the certified ones marching cubes reads); the others keep their values
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n_tile = (int)counts[logical];
@@ -1350,6 +1358,10 @@ __device__ __forceinline__ void splat_accumulate_block(SplatAccShared<R>& sh, co
     } else {
         val = *gp;  // second pass: a sub-block that is not re-evaluated keeps its value (it still enters the block's min / max)
     }
+    if constexpr (EARLY) {
+        const unsigned long long outside = __ballot(point_valid && !(val > P.threshold));
+        if (lane == 0) sh.face[wave] = splat_face_bits(outside);
+    }
     // block-wide min/max of the level-set values (points outside the grid count as 0 = "outside"), used to skip marching cubes
     // on blocks that cannot contain the iso-surface; a truncated wave reports values that are all above the threshold, like
     // its complete values would be
@@ -1382,63 +1394,223 @@ __device__ __forceinline__ void splat_accumulate_block(SplatAccShared<R>& sh, co
         }
         blk_minmax[logical] = ss_make2(mn, mx);
         trunc[logical] = EARLY ? sh.trunc : (wave_mask == 0xFFu ? 0u : (trunc[logical] & ~wave_mask));
+        if constexpr (EARLY) {
+            unsigned long long fb = 0;
+            for (int q = 0; q < 8; ++q) fb |= (unsigned long long)sh.face[q] << (6 * q);
+            facebits[logical] = fb;
+        }
     }
 }
 
-// first pass: every active block, early exit for sub-blocks inside the fluid (unless the caller wants the complete level set)
+// ---- one WAVE per block -----------------------------------------------------------------------------------------------------
+// Blocks whose tile fits one wave's LDS chunk (all blocks of ordinary inputs: ~140 entries at the reference's default spacing)
+// are evaluated by a single wave that walks the eight 4^3 sub-blocks one after the other.  Against the workgroup-per-block
+// kernel above the work per (entry, point) pair is the same, but a CU keeps ~32 independent blocks in flight instead of 4
+// (the loads of the next block's tile hide behind other blocks' arithmetic), there is no workgroup barrier, the tile is
+// fetched once per block by one wave, block-uniform values live in SGPRs and the min / max reduction runs once per block.
+template <class R>
+struct SSWaveChunk {
+    static constexpr int value = sizeof(R) == 4 ? 192 : 128;  // whole 64-entry batches
+};
+
+template <class R>
+struct SplatAccWaveShared {
+    ss_real4<R> pay[SSWaveChunk<R>::value];
+    ss_real4<R> wl[SS_WAVE_LIST];
+};
+
 template <class R, int ARITH, bool EARLY>
-__global__ __launch_bounds__(512) void k_splat_accumulate(SSDevT<R> P, const ss_real4<R>* __restrict__ arena, const unsigned long long* __restrict__ tile_off,
-                                                          const uint32_t* __restrict__ counts, const uint32_t* __restrict__ active_xyz, uint32_t n_active,
-                                                          R* __restrict__ G, ss_real2<R>* __restrict__ blk_minmax, uint32_t* __restrict__ trunc) {
-    __shared__ SplatAccShared<R> sh;
-    // XCD-aware mapping: hardware places workgroup w on XCD w % 8; give each XCD a contiguous range of
-    // the (spatially ordered) active list so that neighbouring blocks share an L2.
-    const uint32_t per_xcd = (n_active + 7u) / 8u;
-    const uint32_t logical = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
-    if ((blockIdx.x >> 3) >= per_xcd || logical >= n_active) return;
-    splat_accumulate_block<R, ARITH, EARLY>(sh, P, logical, arena, tile_off, counts, active_xyz, G, blk_minmax, trunc, 0xFFu);
+__device__ __forceinline__ void splat_accumulate_block_wave(SplatAccWaveShared<R>& sh, const SSDevT<R>& P, uint32_t logical, int n_tile, const ss_real4<R>* __restrict__ tile,
+                                                            const uint32_t* __restrict__ active_xyz, R* __restrict__ G, ss_real2<R>* __restrict__ blk_minmax,
+                                                            uint32_t* __restrict__ trunc, unsigned long long* __restrict__ facebits, uint32_t wave_mask) {
+    constexpr int CH = SSWaveChunk<R>::value;
+    static_assert(CH % 64 == 0, "the tile is staged in whole batches of 64 entries");
+    constexpr int CLS = (sizeof(R) == 4) ? SS_ARITH_SIMD_HW : ARITH;  // see splat_accumulate_block
+    const int lane = threadIdx.x & 63;
+    ss_real4<R> stage[CH / 64];
+#pragma unroll
+    for (int k = 0; k < CH / 64; ++k) {
+        stage[k] = ss_make4(R(0.0), R(0.0), R(0.0), R(0.0));
+        if (lane + 64 * k < n_tile) stage[k] = tile[lane + 64 * k];
+    }
+    const int bx = __builtin_amdgcn_readfirstlane((int)active_xyz[3 * (size_t)logical]);
+    const int by = __builtin_amdgcn_readfirstlane((int)active_xyz[3 * (size_t)logical + 1]);
+    const int bz = __builtin_amdgcn_readfirstlane((int)active_xyz[3 * (size_t)logical + 2]);
+    const int ox = (lane >> 4) & 3, oy = (lane >> 2) & 3, oz = lane & 3;
+    R* gblock = G + (size_t)logical * SS_BLOCK_POINTS + (size_t)((ox * 8 + oy) * 8 + oz);
+    ss_wave_lds_sync();  // the previous block's reads of pay are done
+#pragma unroll
+    for (int k = 0; k < CH / 64; ++k)
+        if (lane + 64 * k < n_tile) sh.pay[lane + 64 * k] = stage[k];
+    ss_wave_lds_sync();
+    R mn = R(INFINITY), mx = -R(INFINITY);
+    uint32_t certified = 0;
+    unsigned long long faces = 0;
+#pragma unroll 1
+    for (int sb = 0; sb < 8; ++sb) {
+        const int sx = (sb >> 2) & 1, sy = (sb >> 1) & 1, sz = sb & 1;
+        const int g0[3] = {bx * SS_BLOCK + sx * 4, by * SS_BLOCK + sy * 4, bz * SS_BLOCK + sz * 4};
+        const int gl[3] = {g0[0] + ox, g0[1] + oy, g0[2] + oz};
+        const bool point_valid = gl[0] < P.np[0] && gl[1] < P.np[1] && gl[2] < P.np[2];
+        R* gp = gblock + (size_t)((sx * 4 * 8 + sy * 4) * 8 + sz * 4);  // block-local layout (x*8+y)*8+z, dense_subdomains.rs:839
+        R val;
+        if (!((wave_mask >> sb) & 1u)) {
+            val = *gp;  // second pass: a sub-block that is not re-evaluated keeps its value (it still enters the block's min / max)
+        } else {
+            R acc = R(0.0);  // levelset_grid.fill(0), dense_subdomains.rs:1390
+            if (g0[0] < P.np[0] && g0[1] < P.np[1] && g0[2] < P.np[2]) {
+                // global point coordinates: uniform_grid.rs:418-425 on the GLOBAL grid (dense_subdomains.rs:817-826); the SIMD loop
+                // of the reference forms z with one fma (:1069), x and y like the scalar loop (:1113-1114)
+                const R px = P.gmin[0] + (R)gl[0] * P.cs;
+                const R py = P.gmin[1] + (R)gl[1] * P.cs;
+                R pz;
+                if constexpr (ARITH >= SS_ARITH_SIMD)
+                    pz = __builtin_fmaf((R)gl[2], P.cs, P.gmin[2]);
+                else
+                    pz = P.gmin[2] + (R)gl[2] * P.cs;
+                R slo[3], shi[3];
+#pragma unroll
+                for (int d = 0; d < 3; ++d) {
+                    slo[d] = P.gmin[d] + (R)g0[d] * P.cs;
+                    shi[d] = P.gmin[d] + (R)min(g0[d] + 3, P.np[d] - 1) * P.cs;
+                }
+                bool done = false;
+                if constexpr (EARLY) {  // classification: lower bound from the entries close to the sub-block
+                    acc = splat_accumulate_wave<R, CLS>(P, sh.pay, sh.wl, n_tile, lane, px, py, pz, slo, shi, P.R2near, R(0.0));
+                    done = __ballot(acc > P.thr_inside || !point_valid) == ~0ull;
+                }
+                if (!done)
+                    acc = splat_accumulate_wave<R, ARITH>(P, sh.pay, sh.wl, n_tile, lane, px, py, pz, slo, shi, P.R2, R(0.0));
+                else
+                    certified |= 1u << sb;
+            }
+            val = point_valid ? acc : R(0.0);
+            *gp = val;
+        }
+        // points outside the grid count as 0 = "outside"; a certified sub-block reports values above the threshold, like its
+        // complete values would be
+        mn = ss_min(mn, val);
+        mx = ss_max(mx, val);
+        if constexpr (EARLY) faces |= (unsigned long long)splat_face_bits(__ballot(point_valid && !(val > P.threshold))) << (6 * sb);
+    }
+    int writer = 0;
+    if constexpr (sizeof(R) == 4) {
+        mn = ss_wave_reduce_to_lane63<false>(mn);
+        mx = ss_wave_reduce_to_lane63<true>(mx);
+        writer = 63;
+    } else {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            mn = ss_min(mn, __shfl_xor(mn, off));
+            mx = ss_max(mx, __shfl_xor(mx, off));
+        }
+    }
+    if (lane == writer) {
+        blk_minmax[logical] = ss_make2(mn, mx);
+        trunc[logical] = EARLY ? certified : (wave_mask == 0xFFu ? 0u : (trunc[logical] & ~wave_mask));
+        if constexpr (EARLY) facebits[logical] = faces;
+    }
 }
 
-// second pass: the truncated blocks marching cubes will read (list and its length on the device), in full
-template <class R, int ARITH>
+// list == nullptr: every active block; otherwise the blocks of the device-side list, the sub-blocks in redo_mask only.  Blocks
+// whose tile does not fit a wave's chunk are appended to big[1..] (count in big[0]) for k_splat_accumulate_list.
+template <class R, int ARITH, bool EARLY>
+__global__ __launch_bounds__(256) void k_splat_accumulate_w(SSDevT<R> P, const ss_real4<R>* __restrict__ arena, const unsigned long long* __restrict__ tile_off,
+                                                            const uint32_t* __restrict__ counts, const uint32_t* __restrict__ active_xyz, uint32_t n_active,
+                                                            const uint32_t* __restrict__ list, const uint32_t* __restrict__ n_list_dev,
+                                                            const uint32_t* __restrict__ redo_mask, R* __restrict__ G, ss_real2<R>* __restrict__ blk_minmax,
+                                                            uint32_t* __restrict__ trunc, unsigned long long* __restrict__ facebits, uint32_t* __restrict__ big) {
+    __shared__ SplatAccWaveShared<R> sh[4];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const uint32_t n = list ? *n_list_dev : n_active;
+    // XCD-aware mapping: hardware places workgroup w on XCD w % 8; every XCD gets a contiguous range of the (spatially ordered)
+    // list, so that neighbouring blocks share an L2
+    const uint32_t n_groups = (n + 3u) / 4u, per_xcd = (n_groups + 7u) / 8u, xcd = blockIdx.x & 7u, stride = gridDim.x >> 3;
+    for (uint32_t j = blockIdx.x >> 3; j < per_xcd; j += stride) {
+        const uint32_t it = (xcd * per_xcd + j) * 4u + (uint32_t)wave;
+        if (it >= n) continue;
+        const uint32_t logical = __builtin_amdgcn_readfirstlane(list ? list[it] : it);
+        const int n_tile = __builtin_amdgcn_readfirstlane((int)counts[logical]);
+        if (n_tile > SSWaveChunk<R>::value) {
+            if (lane == 0) big[1u + atomicAdd(&big[0], 1u)] = logical;
+            continue;
+        }
+        const unsigned long long off = tile_off[logical];
+        const unsigned long long off_u = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(off >> 32)) << 32) |
+                                         (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)off);
+        splat_accumulate_block_wave<R, ARITH, EARLY>(sh[wave], P, logical, n_tile, arena + off_u, active_xyz, G, blk_minmax, trunc, facebits,
+                                                     redo_mask ? __builtin_amdgcn_readfirstlane(redo_mask[logical]) : 0xFFu);
+    }
+}
+
+// the blocks with larger tiles (over-dense input), one workgroup per block; list and its length on the device
+template <class R, int ARITH, bool EARLY>
 __global__ __launch_bounds__(512) void k_splat_accumulate_list(SSDevT<R> P, const ss_real4<R>* __restrict__ arena, const unsigned long long* __restrict__ tile_off,
                                                                const uint32_t* __restrict__ counts, const uint32_t* __restrict__ active_xyz,
                                                                const uint32_t* __restrict__ list, const uint32_t* __restrict__ n_list_dev,
                                                                const uint32_t* __restrict__ redo_mask, R* __restrict__ G, ss_real2<R>* __restrict__ blk_minmax,
-                                                               uint32_t* __restrict__ trunc) {
+                                                               uint32_t* __restrict__ trunc, unsigned long long* __restrict__ facebits) {
     __shared__ SplatAccShared<R> sh;
     const uint32_t n = *n_list_dev;
     for (uint32_t it = blockIdx.x; it < n; it += gridDim.x) {
         const uint32_t logical = list[it];
-        splat_accumulate_block<R, ARITH, false>(sh, P, logical, arena, tile_off, counts, active_xyz, G, blk_minmax, trunc, redo_mask[logical]);
+        splat_accumulate_block<R, ARITH, EARLY>(sh, P, logical, arena, tile_off, counts, active_xyz, G, blk_minmax, trunc, facebits, redo_mask ? redo_mask[logical] : 0xFFu);
         __syncthreads();
     }
 }
 
-// A certified sub-block has to be completed iff marching cubes reads it: only MC blocks whose eight level-set blocks m + {0,1}^3
-// straddle the threshold are triangulated (k_mark_mc_blocks), and of a neighbour block m + d they read the first layer of points
-// along every axis with d = 1 only, i.e. the sub-blocks with sub-block coordinate 0 on those axes.
+// A certified sub-block carries lower bounds, all above the threshold.  Marching cubes classifies with them like with the
+// complete values; it needs the value itself only at the end points of edges that cross the surface (dense_subdomains.rs:1516-1517),
+// i.e. at points with a 6-neighbour outside.  Such a neighbour of a point of a certified sub-block lies in the face-adjacent
+// sub-block, on the touching face: the sub-block is completed iff one of its six neighbours reports an outside point there
+// (facebits, written by the first pass).  A neighbour in a block without particles in reach is all zero = outside.
 template <class R>
-__global__ __launch_bounds__(256) void k_mark_redo_blocks(SSDevT<R> P, const uint32_t* __restrict__ mc_flag, const uint32_t* __restrict__ block_slot,
-                                                          const uint32_t* __restrict__ trunc, uint32_t nblocks, uint32_t* __restrict__ redo_mask) {
-    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= nblocks || !mc_flag[b]) return;
-    const int bz = (int)(b % (uint32_t)P.nb[2]);
-    const int by = (int)((b / (uint32_t)P.nb[2]) % (uint32_t)P.nb[1]);
-    const int bx = (int)(b / ((uint32_t)P.nb[2] * (uint32_t)P.nb[1]));
-    for (int dx = 0; dx <= 1; ++dx)
-        for (int dy = 0; dy <= 1; ++dy)
-            for (int dz = 0; dz <= 1; ++dz) {
-                const int x = bx + dx, y = by + dy, z = bz + dz;
-                if (x >= P.nb[0] || y >= P.nb[1] || z >= P.nb[2]) continue;
-                const uint32_t slot = block_slot[((size_t)x * P.nb[1] + y) * P.nb[2] + z];
-                if (slot == 0xFFFFFFFFu) continue;
-                uint32_t read = 0;  // sub-blocks (wx, wy, wz) -> bit (wx << 2) | (wy << 1) | wz, as in splat_accumulate_block
-                for (int w = 0; w < 8; ++w)
-                    if ((!dx || !((w >> 2) & 1)) && (!dy || !((w >> 1) & 1)) && (!dz || !(w & 1))) read |= 1u << w;
-                const uint32_t need = read & trunc[slot];
-                if (need) atomicOr(&redo_mask[slot], need);
+__global__ __launch_bounds__(256) void k_select_redo(SSDevT<R> P, const uint32_t* __restrict__ active_xyz, uint32_t n_active, const uint32_t* __restrict__ block_slot,
+                                                     const uint32_t* __restrict__ trunc, const unsigned long long* __restrict__ facebits,
+                                                     uint32_t* __restrict__ redo_mask) {
+    const uint32_t a = blockIdx.x * blockDim.x + threadIdx.x;
+    if (a > n_active) return;
+    if (a == n_active) {
+        redo_mask[a] = 0u;  // the scan runs over n_active + 1 entries
+        return;
+    }
+    const uint32_t cert = trunc[a];
+    uint32_t redo = 0;
+    if (cert) {
+        const int b[3] = {(int)active_xyz[3 * (size_t)a], (int)active_xyz[3 * (size_t)a + 1], (int)active_xyz[3 * (size_t)a + 2]};
+        const unsigned long long own = facebits[a];
+        // face words of the six neighbour blocks: ~0 for a block without slot, 0 beyond the grid (no points there)
+        unsigned long long nbf[3][2];
+#pragma unroll
+        for (int d = 0; d < 3; ++d)
+#pragma unroll
+            for (int sgn = 0; sgn < 2; ++sgn) {
+                int c[3] = {b[0], b[1], b[2]};
+                c[d] += sgn ? 1 : -1;
+                unsigned long long w = 0;
+                if (c[d] >= 0 && c[d] < P.nb[d]) {
+                    const uint32_t slot = block_slot[((size_t)c[0] * P.nb[1] + c[1]) * P.nb[2] + c[2]];
+                    w = (slot == 0xFFFFFFFFu) ? ~0ull : facebits[slot];
+                }
+                nbf[d][sgn] = w;
             }
+        for (int sb = 0; sb < 8; ++sb) {
+            if (!((cert >> sb) & 1u)) continue;
+            bool need = false;
+#pragma unroll
+            for (int d = 0; d < 3; ++d) {
+                const int bit = 4 >> d;  // sub-block coordinate along d: sb = (sx << 2) | (sy << 1) | sz
+                const int sd = (sb & bit) ? 1 : 0;
+                const int other = sb ^ bit;  // the sub-block on the other side along d (same block or the neighbour block)
+                // towards -d: the neighbour's +d face (bit 2d+1); towards +d: its -d face (bit 2d)
+                const unsigned long long w_minus = sd ? own : nbf[d][0];
+                const unsigned long long w_plus = sd ? nbf[d][1] : own;
+                need = need || ((w_minus >> (6 * other + 2 * d + 1)) & 1ull) || ((w_plus >> (6 * other + 2 * d)) & 1ull);
+            }
+            if (need) redo |= 1u << sb;
+        }
+    }
+    redo_mask[a] = redo;
 }
 
 template <class R>
@@ -1465,21 +1637,29 @@ void ss_launch_splat_gather_large(const SSDevT<R>& P, const ss_real4<R>* posvol,
 }
 
 // list == nullptr: first pass over all n_active blocks (early exit unless full_levelset); otherwise the second pass over the
-// device-side list of truncated blocks marching cubes needs
+// device-side list of blocks with certified sub-blocks that marching cubes reads.  `big`: n_active + 1 words of scratch (the
+// blocks handed from the wave-per-block kernel to the workgroup-per-block kernel).
 template <class R>
 void ss_launch_splat_accumulate(const SSDevT<R>& P, const ss_real4<R>* arena, const unsigned long long* tile_off, const uint32_t* counts,
                                 const uint32_t* active_xyz, uint32_t n_active, R* G, ss_real2<R>* blk_minmax, uint32_t* trunc, bool full_levelset,
-                                const uint32_t* list, const uint32_t* n_list_dev, const uint32_t* redo_mask, hipStream_t st) {
+                                const uint32_t* list, const uint32_t* n_list_dev, const uint32_t* redo_mask, unsigned long long* facebits, uint32_t* big, hipStream_t st) {
     if (!n_active) return;
-    const dim3 grid(((n_active + 7u) / 8u) * 8u), block(512), lgrid(2048);
-#define SS_ACC(A)                                                                                                                                   \
-    do {                                                                                                                                            \
-        if (list)                                                                                                                                   \
-            hipLaunchKernelGGL((k_splat_accumulate_list<R, A>), lgrid, block, 0, st, P, arena, tile_off, counts, active_xyz, list, n_list_dev, redo_mask, G, blk_minmax, trunc); \
-        else if (full_levelset)                                                                                                                     \
-            hipLaunchKernelGGL((k_splat_accumulate<R, A, false>), grid, block, 0, st, P, arena, tile_off, counts, active_xyz, n_active, G, blk_minmax, trunc); \
-        else                                                                                                                                        \
-            hipLaunchKernelGGL((k_splat_accumulate<R, A, true>), grid, block, 0, st, P, arena, tile_off, counts, active_xyz, n_active, G, blk_minmax, trunc);  \
+    (void)hipMemsetAsync(big, 0, 4, st);
+    const uint32_t n_groups = (n_active + 3u) / 4u;
+    const dim3 grid(list ? 8192u : ((n_groups + 7u) / 8u) * 8u), lgrid(2048);
+#define SS_ACC_E(A, E)                                                                                                                                                  \
+    do {                                                                                                                                                                \
+        hipLaunchKernelGGL((k_splat_accumulate_w<R, A, E>), grid, dim3(256), 0, st, P, arena, tile_off, counts, active_xyz, n_active, list, n_list_dev, redo_mask, G,  \
+                           blk_minmax, trunc, facebits, big);                                                                                                                  \
+        hipLaunchKernelGGL((k_splat_accumulate_list<R, A, E>), lgrid, dim3(512), 0, st, P, arena, tile_off, counts, active_xyz, big + 1, big, redo_mask, G, blk_minmax, \
+                           trunc, facebits);                                                                                                                                     \
+    } while (0)
+#define SS_ACC(A)                        \
+    do {                                 \
+        if (list || full_levelset)       \
+            SS_ACC_E(A, false);          \
+        else                             \
+            SS_ACC_E(A, true);           \
     } while (0)
     if constexpr (sizeof(R) == 4) {
         switch (P.arith) {
@@ -1492,13 +1672,13 @@ void ss_launch_splat_accumulate(const SSDevT<R>& P, const ss_real4<R>* arena, co
     }
     SS_ACC(SS_ARITH_GENERIC);
 #undef SS_ACC
+#undef SS_ACC_E
 }
 
 template <class R>
-void ss_launch_mark_redo_blocks(const SSDevT<R>& P, const uint32_t* mc_flag, const uint32_t* block_slot, const uint32_t* trunc, uint32_t nblocks, uint32_t* redo_flag,
-                                hipStream_t st) {
-    if (!nblocks) return;
-    hipLaunchKernelGGL(k_mark_redo_blocks<R>, dim3((nblocks + 255) / 256), dim3(256), 0, st, P, mc_flag, block_slot, trunc, nblocks, redo_flag);
+void ss_launch_select_redo(const SSDevT<R>& P, const uint32_t* active_xyz, uint32_t n_active, const uint32_t* block_slot, const uint32_t* trunc,
+                           const unsigned long long* facebits, uint32_t* redo_mask, hipStream_t st) {
+    hipLaunchKernelGGL(k_select_redo<R>, dim3((n_active + 1u + 255u) / 256u), dim3(256), 0, st, P, active_xyz, n_active, block_slot, trunc, facebits, redo_mask);
 }
 
 // =====================================================================================================
@@ -1798,10 +1978,10 @@ template void ss_launch_splat_gather_large<float>(const SSDevT<float>& P, const 
 template void ss_launch_splat_bounds<double>(const SSDevT<double>& P, const uint32_t* cell_start, const uint32_t* active_xyz, uint32_t n_active, uint32_t* bound, hipStream_t st);
 template void ss_launch_splat_gather<double>(const SSDevT<double>& P, const ss_real4<double>* posvol, const uint32_t* perm, const uint32_t* cell_start, const uint32_t* active_xyz, uint32_t n_active, const unsigned long long* tile_off, ss_real4<double>* arena, uint32_t* counts, uint32_t* large_flag, hipStream_t st);
 template void ss_launch_splat_gather_large<double>(const SSDevT<double>& P, const ss_real4<double>* posvol, const ss_real4<double>* posvol_by_index, const uint32_t* perm, const uint32_t* cell_start, const uint32_t* active_xyz, const uint32_t* large_list, const uint32_t* n_large_dev, const uint32_t* counts, const unsigned long long* tile_off, ss_real4<double>* arena, hipStream_t st);
-template void ss_launch_splat_accumulate<float>(const SSDevT<float>& P, const ss_real4<float>* arena, const unsigned long long* tile_off, const uint32_t* counts, const uint32_t* active_xyz, uint32_t n_active, float* G, ss_real2<float>* blk_minmax, uint32_t* trunc, bool full_levelset, const uint32_t* list, const uint32_t* n_list_dev, const uint32_t* redo_mask, hipStream_t st);
-template void ss_launch_mark_redo_blocks<float>(const SSDevT<float>& P, const uint32_t* mc_flag, const uint32_t* block_slot, const uint32_t* trunc, uint32_t nblocks, uint32_t* redo_flag, hipStream_t st);
-template void ss_launch_splat_accumulate<double>(const SSDevT<double>& P, const ss_real4<double>* arena, const unsigned long long* tile_off, const uint32_t* counts, const uint32_t* active_xyz, uint32_t n_active, double* G, ss_real2<double>* blk_minmax, uint32_t* trunc, bool full_levelset, const uint32_t* list, const uint32_t* n_list_dev, const uint32_t* redo_mask, hipStream_t st);
-template void ss_launch_mark_redo_blocks<double>(const SSDevT<double>& P, const uint32_t* mc_flag, const uint32_t* block_slot, const uint32_t* trunc, uint32_t nblocks, uint32_t* redo_flag, hipStream_t st);
+template void ss_launch_splat_accumulate<float>(const SSDevT<float>& P, const ss_real4<float>* arena, const unsigned long long* tile_off, const uint32_t* counts, const uint32_t* active_xyz, uint32_t n_active, float* G, ss_real2<float>* blk_minmax, uint32_t* trunc, bool full_levelset, const uint32_t* list, const uint32_t* n_list_dev, const uint32_t* redo_mask, unsigned long long* facebits, uint32_t* big, hipStream_t st);
+template void ss_launch_select_redo<float>(const SSDevT<float>& P, const uint32_t* active_xyz, uint32_t n_active, const uint32_t* block_slot, const uint32_t* trunc, const unsigned long long* facebits, uint32_t* redo_mask, hipStream_t st);
+template void ss_launch_splat_accumulate<double>(const SSDevT<double>& P, const ss_real4<double>* arena, const unsigned long long* tile_off, const uint32_t* counts, const uint32_t* active_xyz, uint32_t n_active, double* G, ss_real2<double>* blk_minmax, uint32_t* trunc, bool full_levelset, const uint32_t* list, const uint32_t* n_list_dev, const uint32_t* redo_mask, unsigned long long* facebits, uint32_t* big, hipStream_t st);
+template void ss_launch_select_redo<double>(const SSDevT<double>& P, const uint32_t* active_xyz, uint32_t n_active, const uint32_t* block_slot, const uint32_t* trunc, const unsigned long long* facebits, uint32_t* redo_mask, hipStream_t st);
 template void ss_launch_mc_count<float>(const SSDevT<float>& P, const float* G, const uint32_t* block_slot, const uint32_t* mc_xyz, uint32_t n_mc, unsigned long long* masks, uint32_t* vcount, uint32_t* tcount, hipStream_t st);
 template void ss_launch_mc_count<double>(const SSDevT<double>& P, const double* G, const uint32_t* block_slot, const uint32_t* mc_xyz, uint32_t n_mc, unsigned long long* masks, uint32_t* vcount, uint32_t* tcount, hipStream_t st);
 template void ss_launch_mc_emit<float>(const SSDevT<float>& P, const float* G, const uint32_t* block_slot, const uint32_t* mc_xyz, const uint32_t* mc_slot, uint32_t n_mc, const unsigned long long* masks, const uint32_t* vbase, const uint32_t* tbase, float* vertices, unsigned long long* vkeys, uint32_t* triangles, hipStream_t st);
