@@ -214,7 +214,7 @@ ss_status make_device_params(ss_context* ctx, const typename TypesOf<R>::params*
     const R support_factor = simd ? R(1.0) : R(1.01);
     P.reach = ss_sqrt(support_factor) * h * R(1.0001);
     P.R2 = ((h * h) * support_factor) * R(1.0001);
-    P.R2near = (R(0.56) * h) * (R(0.56) * h);  // measured on S10M-tank (accumulate, ms): 0.50 h 12.9, 0.55 h 10.2, 0.60 h 10.4, 0.625 h 10.9, 0.70 h 12.0
+    P.R2near = (R(0.60) * h) * (R(0.60) * h);  // measured on S10M-tank (first pass, ms / certified sub-blocks): 0.56 h 6.86 / 81 %, 0.59 h 6.52 / 86 %, 0.60 h 6.60 / 86 %, 0.62 h 6.80 / 87 %, 0.70 h 7.87 / 88 %
     P.thr_inside = prm->iso_surface_threshold * R(1.0001);
     {   // CubicSplineKernelAvxF32::new (kernel.rs:327-337), in f32 like the reference
         const float hf = (float)h;
@@ -1005,7 +1005,7 @@ ss_status phase_finish(ss_context* ctx, ss_result* res) {
     SS_HIP(ctx, hipMemsetAsync(ctx->tcount.p, 0, ((size_t)n_mc + 1) * 4, st));
     SS_HIP(ctx, res->mc_xyz.reserve((size_t)n_mc * 12 + 16));
     ss_launch_block_coords(P, res->mc_list.as<uint32_t>(), n_mc, res->mc_xyz.as<uint32_t>(), st);
-    ss_launch_mc_count(P, res->G.as<R>(), res->block_slot.as<uint32_t>(), res->mc_xyz.as<uint32_t>(), n_mc, res->masks.as<unsigned long long>(),
+    ss_launch_mc_count(P, res->G.as<R>(), res->block_slot.as<uint32_t>(), full_ls ? nullptr : tr_flag, res->mc_xyz.as<uint32_t>(), n_mc, res->masks.as<unsigned long long>(),
                        ctx->vcount.as<uint32_t>(), ctx->tcount.as<uint32_t>(), st);
     SS_HIP(ctx, hipEventRecord(ctx->ev[7], st));
     // ---- "stitching": global numbering by prefix sums ----
@@ -1035,7 +1035,7 @@ ss_status phase_finish(ss_context* ctx, ss_result* res) {
     SS_HIP(ctx, res->tri32.reserve(nt * 12 + 16));
     SS_HIP(ctx, hipEventRecord(ctx->ev[8], st));
     // ---- K5: emission ----
-    ss_launch_mc_emit(P, res->G.as<R>(), res->block_slot.as<uint32_t>(), res->mc_xyz.as<uint32_t>(), res->mc_slot.as<uint32_t>(), n_mc,
+    ss_launch_mc_emit(P, res->G.as<R>(), res->block_slot.as<uint32_t>(), full_ls ? nullptr : tr_flag, res->mc_xyz.as<uint32_t>(), res->mc_slot.as<uint32_t>(), n_mc,
                       res->masks.as<unsigned long long>(), res->vbase.as<uint32_t>(), res->tbase.as<uint32_t>(), res->vertices.as<R>(),
                       res->vkeys.as<unsigned long long>(), res->tri32.as<uint32_t>(), st);
     SS_HIP(ctx, hipEventRecord(ctx->ev[9], st));

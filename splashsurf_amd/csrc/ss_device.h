@@ -25,7 +25,8 @@
 //                    point) pair: d^2 by two fma, mask d^2 < h^2, q = r * (1/h), v = max(1 - q, 0), fma polynomial, fma accumulate.
 //                    SIMD / SIMD_LEAN use a correctly rounded sqrt like _mm256_sqrt_ps (generic / lean variant), SIMD_HW the raw
 //                    v_sqrt_f32 (<= 1 ulp), requested with enable_simd = 2.
-enum : int { SS_ARITH_GENERIC = 0, SS_ARITH_FAST = 1, SS_ARITH_SIMD = 2, SS_ARITH_SIMD_LEAN = 3, SS_ARITH_SIMD_HW = 4 };
+enum : int { SS_ARITH_GENERIC = 0, SS_ARITH_FAST = 1, SS_ARITH_SIMD = 2, SS_ARITH_SIMD_LEAN = 3, SS_ARITH_SIMD_HW = 4,
+              SS_ARITH_BOUND = 5 /* classification pass only: SIMD_HW without the reach test (the clamp makes far terms 0) */ };
 
 // candidate particles (4-byte index keys) held in LDS per pass of the large-tile splat kernel
 template <class R> struct SSTileCap { static constexpr int value = 8192; };

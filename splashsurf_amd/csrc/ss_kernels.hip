@@ -859,14 +859,25 @@ __device__ __forceinline__ void splat_wave_scan(const SSDevT<R>& P, const ss_rea
 }
 
 // XCD-aware mapping of groups of four consecutive blocks to 256-thread workgroups (one wave per block): hardware places
-// workgroup w on XCD w % 8; every XCD gets a contiguous range of the spatially ordered active list, so neighbouring blocks
-// (which share most of their candidate rows) share an L2.
+// workgroup w on XCD w % 8.  Every XCD gets chunks of SS_XCD_CHUNK consecutive groups of the spatially ordered active list
+// (chunk c -> XCD c % 8): neighbouring blocks, which share most of their candidate rows, share an L2, and the cheap and the
+// expensive regions of the list (deep inside the fluid / at the surface) spread evenly over the XCDs.
+#define SS_XCD_CHUNK 64u
+__device__ __forceinline__ uint32_t ss_xcd_chunked_group(uint32_t w) {
+    const uint32_t x = w & 7u, s = w >> 3;
+    return ((s / SS_XCD_CHUNK) * 8u + x) * SS_XCD_CHUNK + (s % SS_XCD_CHUNK);
+}
+__device__ __forceinline__ uint32_t ss_xcd_chunked_grid_dev(uint32_t n_groups) {
+    const uint32_t span = 8u * SS_XCD_CHUNK;
+    return ((n_groups + span - 1u) / span) * span;
+}
+static inline uint32_t ss_xcd_chunked_grid(uint32_t n_groups) {
+    const uint32_t span = 8u * SS_XCD_CHUNK;
+    return ((n_groups + span - 1u) / span) * span;
+}
+
 __device__ __forceinline__ bool splat_wave_block(uint32_t n_active, uint32_t* logical) {
-    const uint32_t n_groups = (n_active + 3u) / 4u;
-    const uint32_t per_xcd = (n_groups + 7u) / 8u;
-    const uint32_t group = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
-    if ((blockIdx.x >> 3) >= per_xcd || group >= n_groups) return false;
-    *logical = group * 4u + (threadIdx.x >> 6);
+    *logical = ss_xcd_chunked_group(blockIdx.x) * 4u + (threadIdx.x >> 6);
     return *logical < n_active;
 }
 
@@ -1171,7 +1182,17 @@ __device__ __forceinline__ R ss_splat_pair(const SSDevT<R>& P, R rh, const ss_re
     if constexpr (ARITH >= SS_ARITH_SIMD) {
         static_assert(sizeof(R) == 4, "the reference's SIMD loop exists for f32 only (dense_subdomains.rs:1413-1415)");
         const float d2 = __builtin_fmaf(dz, dz, __builtin_fmaf(dx, dx, dy * dy));  // :1077-1080
-        if (d2 < P.h2) {                                                            // :1083
+        if constexpr (ARITH == SS_ARITH_BOUND) {
+            // lower-bound pass, in units of sigma (the caller scales the sum once): with v = max(1 - q, 0) the spline is
+            // min(2 v^3, 1 - 6 v (1 - v)^2), and v^2 lies between the two pieces' roles: v^2 >= 2 v^3 for v <= 1/2 and
+            // 1 - 6 v (1 - v)^2 - v^2 = -6 (v - 1)(v - 1/2)(v - 1/3) >= 0 on [1/2, 1].  So v^2 min(2 v, 1) <= W / sigma everywhere:
+            // five instructions after q, no second piece, no reach test (v = 0 beyond h), no EXEC bookkeeping.
+            const float q = __builtin_amdgcn_sqrtf(d2) * P.avx_inv_h;
+            float v, t;
+            asm("v_sub_f32_e64 %0, 1.0, %1 clamp" : "=v"(v) : "v"(q));
+            asm("v_add_f32_e64 %0, %1, %1 clamp" : "=v"(t) : "v"(v));
+            acc = __builtin_fmaf((v * v) * t, e.w, acc);
+        } else if (d2 < P.h2) {                                                     // :1083
             float r;
             if constexpr (ARITH == SS_ARITH_SIMD)
                 r = ss_sqrt(d2);
@@ -1196,15 +1217,22 @@ __device__ __forceinline__ R ss_splat_pair(const SSDevT<R>& P, R rh, const ss_re
 // shared by the four SIMDs of a CU and walking a 64-bit survivor mask cost 14 scalar instructions per entry.
 // `r2_filter` = squared reach of the sub-block filter: P.R2 for the exact sum (every entry that can contribute), P.R2near for
 // the classification pass of splat_accumulate_block (only the entries close to the sub-block).
+// `premask` (optional): per tile entry, bit s set <=> the entry passes the filter of sub-block s (splat_near_masks); then the
+// box test is not repeated here.
 template <class R, int ARITH>
 __device__ __forceinline__ R splat_accumulate_wave(const SSDevT<R>& P, const ss_real4<R>* pay, ss_real4<R>* wl, int n_tile, int lane, R px, R py, R pz,
-                                                   const R slo[3], const R shi[3], R r2_filter, R acc) {
+                                                   const R slo[3], const R shi[3], R r2_filter, R acc, const uint8_t* premask = nullptr, int premask_bit = 0) {
     const R rh = R(1.0) / P.h;
     for (int base = 0; base < n_tile; base += 64) {
         const int c = base + lane;
         bool pass = false;
         ss_real4<R> pv = ss_make4(R(0.0), R(0.0), R(0.0), R(0.0));
-        if (c < n_tile) {
+        if (premask) {
+            if (c < n_tile && ((premask[c] >> premask_bit) & 1u)) {
+                pass = true;
+                pv = pay[c];
+            }
+        } else if (c < n_tile) {
             pv = pay[c];
             const R ex = ss_max(ss_max(slo[0] - pv.x, pv.x - shi[0]) - P.coord_slack, R(0.0));
             const R ey = ss_max(ss_max(slo[1] - pv.y, pv.y - shi[1]) - P.coord_slack, R(0.0));
@@ -1216,18 +1244,21 @@ __device__ __forceinline__ R splat_accumulate_wave(const SSDevT<R>& P, const ss_
             const int cnt = __popcll(wmask);
             ss_wave_lds_sync();  // the previous batch's reads of wl are done
             if (pass) wl[__builtin_amdgcn_mbcnt_hi((uint32_t)(wmask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)wmask, 0u))] = pv;
+            // the walk below takes two entries per trip: an odd list ends with an entry out of everybody's reach and of volume 0
+            // (its term is skipped by the reach test, and +0 in the lower-bound pass)
+            if (lane == 0) wl[cnt] = ss_make4(R(1.0e18), R(1.0e18), R(1.0e18), R(0.0));
             ss_wave_lds_sync();
-            // Entries are fetched with a wave-uniform LDS read (broadcast: LDS pipe, no VALU issue slot, operands arrive in
-            // VGPRs) one iteration ahead of their use; two entries per trip, ping-ponging between two register sets (no
-            // loop-carried copies).  Reads past cnt stay inside wl and are not used.
+            // Entries are fetched with a wave-uniform LDS read (broadcast) one iteration ahead of their use, ping-ponging between
+            // two register sets (no loop-carried copies).  Reads past the end stay inside wl and are not used.  (Measured
+            // alternatives on S10M-tank, first pass 6.8 ms: survivors kept one per lane in VGPRs and broadcast with four
+            // v_readlane_b32 9.7 ms, every second entry that way 8.2 ms; entries fetched from the tile in global memory through
+            // the scalar cache, s_load_dwordx4 one entry ahead, 11.6 ms.)
             ss_real4<R> ea = wl[0];
-            for (int k = 0;; k += 2) {
+            for (int k = 0; k < cnt; k += 2) {
                 const ss_real4<R> eb = wl[k + 1];
                 acc = ss_splat_pair<R, ARITH>(P, rh, ea, px, py, pz, acc);
-                if (k + 1 >= cnt) break;
                 ea = wl[k + 2];
                 acc = ss_splat_pair<R, ARITH>(P, rh, eb, px, py, pz, acc);
-                if (k + 2 >= cnt) break;
             }
         }
     }
@@ -1292,6 +1323,7 @@ __device__ __forceinline__ void splat_accumulate_block(SplatAccShared<R>& sh, co
     const int g0[3] = {bx * SS_BLOCK + ((wave >> 2) & 1) * 4, by * SS_BLOCK + ((wave >> 1) & 1) * 4, bz * SS_BLOCK + (wave & 1) * 4};
     const int gl[3] = {g0[0] + ((lane >> 4) & 3), g0[1] + ((lane >> 2) & 3), g0[2] + (lane & 3)};
     const bool wave_selected = ((wave_mask >> wave) & 1u) != 0u;
+    const uint32_t certified_before = (!EARLY && wave_mask != 0xFFu) ? trunc[logical] : 0u;
     const bool wave_valid = wave_selected && g0[0] < P.np[0] && g0[1] < P.np[1] && g0[2] < P.np[2];
     const bool point_valid = gl[0] < P.np[0] && gl[1] < P.np[1] && gl[2] < P.np[2];
     // global point coordinates: uniform_grid.rs:418-425 on the GLOBAL grid (dense_subdomains.rs:817-826); the SIMD loop of the
@@ -1319,10 +1351,11 @@ __device__ __forceinline__ void splat_accumulate_block(SplatAccShared<R>& sh, co
     //   sub-block lies inside the fluid: marching cubes only needs that fact, unless the block is next to a sign change, in which
     //   case the second kernel pass (k_splat_accumulate_list) evaluates it in full.
     //  pass 1, the exact sum in the reference's order, for the waves pass 0 did not certify.
-    constexpr int CLS = (sizeof(R) == 4) ? SS_ARITH_SIMD_HW : ARITH;
+    constexpr int CLS = (sizeof(R) == 4) ? SS_ARITH_BOUND : ARITH;
     const int n_chunks = (n_tile + SS_WTILE - 1) / SS_WTILE;
     for (int pass = EARLY ? 0 : 1; pass < 2; ++pass) {
         if (pass == 1 && EARLY) {
+            if constexpr (CLS == SS_ARITH_BOUND) acc *= P.avx_sigma;  // the bound pass sums in units of sigma
             done = wave_valid ? (__ballot(acc > P.thr_inside || !point_valid) == ~0ull) : true;
             // (a single chunk stays in LDS: its waves go on independently, no workgroup barrier between the passes)
             if (n_chunks > 1 && !__syncthreads_or(done ? 0 : 1)) break;  // every sub-block of this block is certified: no second stream
@@ -1353,10 +1386,16 @@ __device__ __forceinline__ void splat_accumulate_block(SplatAccShared<R>& sh, co
     R* gp = G + (size_t)logical * SS_BLOCK_POINTS + (size_t)((lx * 8 + ly) * 8 + lz);
     R val;
     if (wave_selected) {
-        val = point_valid ? acc : R(0.0);
-        *gp = val;
+        if (EARLY && done && wave_valid) {
+            val = P.thr_inside;  // certified: nothing is stored, marching cubes takes the fact from the block's mask (mc_load_tile)
+        } else {
+            val = point_valid ? acc : R(0.0);
+            *gp = val;
+        }
     } else {
-        val = *gp;  // second pass: a sub-block that is not re-evaluated keeps its value (it still enters the block's min / max)
+        // second pass: a sub-block that is not re-evaluated keeps its value (it still enters the block's min / max); the values of
+        // a sub-block the first pass certified were never stored
+        val = ((certified_before >> wave) & 1u) ? P.thr_inside : *gp;
     }
     if constexpr (EARLY) {
         const unsigned long long outside = __ballot(point_valid && !(val > P.threshold));
@@ -1402,6 +1441,26 @@ __device__ __forceinline__ void splat_accumulate_block(SplatAccShared<R>& sh, co
     }
 }
 
+// Classification filter of all eight sub-blocks of a block at once, for one tile entry: bit s of the result <=> the entry's box
+// distance to sub-block s = (sx << 2) | (sy << 1) | sz is <= sqrt(r2).  The distance separates per axis, two intervals each:
+// 6 one-dimensional distances and 12 additions instead of 8 x (3 distances + 2 additions).
+template <class R>
+__device__ __forceinline__ uint32_t splat_near_masks(const SSDevT<R>& P, const ss_real4<R>& pv, const R lo[3][2], const R hi[3][2], R r2) {
+    R e2[3][2];
+    const R p[3] = {pv.x, pv.y, pv.z};
+#pragma unroll
+    for (int d = 0; d < 3; ++d)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const R e = ss_max(ss_max(lo[d][h] - p[d], p[d] - hi[d][h]) - P.coord_slack, R(0.0));
+            e2[d][h] = e * e;
+        }
+    uint32_t m = 0;
+#pragma unroll
+    for (int sb = 0; sb < 8; ++sb) m |= ((e2[0][(sb >> 2) & 1] + e2[1][(sb >> 1) & 1]) + e2[2][sb & 1] <= r2) ? (1u << sb) : 0u;
+    return m;
+}
+
 // ---- one WAVE per block -----------------------------------------------------------------------------------------------------
 // Blocks whose tile fits one wave's LDS chunk (all blocks of ordinary inputs: ~140 entries at the reference's default spacing)
 // are evaluated by a single wave that walks the eight 4^3 sub-blocks one after the other.  Against the workgroup-per-block
@@ -1417,6 +1476,7 @@ template <class R>
 struct SplatAccWaveShared {
     ss_real4<R> pay[SSWaveChunk<R>::value];
     ss_real4<R> wl[SS_WAVE_LIST];
+    uint8_t near[SSWaveChunk<R>::value];  // per tile entry: the sub-blocks whose classification pass visits it
 };
 
 template <class R, int ARITH, bool EARLY>
@@ -1425,7 +1485,7 @@ __device__ __forceinline__ void splat_accumulate_block_wave(SplatAccWaveShared<R
                                                             uint32_t* __restrict__ trunc, unsigned long long* __restrict__ facebits, uint32_t wave_mask) {
     constexpr int CH = SSWaveChunk<R>::value;
     static_assert(CH % 64 == 0, "the tile is staged in whole batches of 64 entries");
-    constexpr int CLS = (sizeof(R) == 4) ? SS_ARITH_SIMD_HW : ARITH;  // see splat_accumulate_block
+    constexpr int CLS = (sizeof(R) == 4) ? SS_ARITH_BOUND : ARITH;  // see splat_accumulate_block
     const int lane = threadIdx.x & 63;
     ss_real4<R> stage[CH / 64];
 #pragma unroll
@@ -1439,44 +1499,61 @@ __device__ __forceinline__ void splat_accumulate_block_wave(SplatAccWaveShared<R
     const int ox = (lane >> 4) & 3, oy = (lane >> 2) & 3, oz = lane & 3;
     R* gblock = G + (size_t)logical * SS_BLOCK_POINTS + (size_t)((ox * 8 + oy) * 8 + oz);
     ss_wave_lds_sync();  // the previous block's reads of pay are done
+    // per axis and half of the block (h = 0, 1): the sub-block's box [lo, hi] and this lane's point coordinate -- global point
+    // coordinates as in uniform_grid.rs:418-425 on the GLOBAL grid (dense_subdomains.rs:817-826); the SIMD loop of the reference
+    // forms z with one fma (:1069), x and y like the scalar loop (:1113-1114)
+    R lo[3][2], hi[3][2], pc[3][2];
+    bool sub_ok[3][2], pt_ok[3][2];
+    {
+        const int b3[3] = {bx, by, bz}, o3[3] = {ox, oy, oz};
+#pragma unroll
+        for (int d = 0; d < 3; ++d)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int g = b3[d] * SS_BLOCK + 4 * h;
+                lo[d][h] = P.gmin[d] + (R)g * P.cs;
+                hi[d][h] = P.gmin[d] + (R)min(g + 3, P.np[d] - 1) * P.cs;
+                if (d == 2 && ARITH >= SS_ARITH_SIMD)
+                    pc[d][h] = __builtin_fmaf((R)(g + o3[d]), P.cs, P.gmin[d]);
+                else
+                    pc[d][h] = P.gmin[d] + (R)(g + o3[d]) * P.cs;
+                sub_ok[d][h] = g < P.np[d];
+                pt_ok[d][h] = g + o3[d] < P.np[d];
+            }
+    }
+    if constexpr (EARLY) {
+#pragma unroll
+        for (int k = 0; k < CH / 64; ++k)
+            if (lane + 64 * k < n_tile) sh.near[lane + 64 * k] = (uint8_t)splat_near_masks<R>(P, stage[k], lo, hi, P.R2near);
+    }
 #pragma unroll
     for (int k = 0; k < CH / 64; ++k)
         if (lane + 64 * k < n_tile) sh.pay[lane + 64 * k] = stage[k];
     ss_wave_lds_sync();
+    // second pass: the sub-blocks the first pass certified (their values were never stored, see below)
+    const uint32_t certified_before = (!EARLY && wave_mask != 0xFFu) ? (uint32_t)__builtin_amdgcn_readfirstlane((int)trunc[logical]) : 0u;
     R mn = R(INFINITY), mx = -R(INFINITY);
     uint32_t certified = 0;
     unsigned long long faces = 0;
 #pragma unroll 1
     for (int sb = 0; sb < 8; ++sb) {
         const int sx = (sb >> 2) & 1, sy = (sb >> 1) & 1, sz = sb & 1;
-        const int g0[3] = {bx * SS_BLOCK + sx * 4, by * SS_BLOCK + sy * 4, bz * SS_BLOCK + sz * 4};
-        const int gl[3] = {g0[0] + ox, g0[1] + oy, g0[2] + oz};
-        const bool point_valid = gl[0] < P.np[0] && gl[1] < P.np[1] && gl[2] < P.np[2];
+        const bool point_valid = (sx ? pt_ok[0][1] : pt_ok[0][0]) && (sy ? pt_ok[1][1] : pt_ok[1][0]) && (sz ? pt_ok[2][1] : pt_ok[2][0]);
         R* gp = gblock + (size_t)((sx * 4 * 8 + sy * 4) * 8 + sz * 4);  // block-local layout (x*8+y)*8+z, dense_subdomains.rs:839
         R val;
         if (!((wave_mask >> sb) & 1u)) {
-            val = *gp;  // second pass: a sub-block that is not re-evaluated keeps its value (it still enters the block's min / max)
+            // second pass: a sub-block that is not re-evaluated keeps its value (it still enters the block's min / max)
+            val = ((certified_before >> sb) & 1u) ? P.thr_inside : *gp;
         } else {
             R acc = R(0.0);  // levelset_grid.fill(0), dense_subdomains.rs:1390
-            if (g0[0] < P.np[0] && g0[1] < P.np[1] && g0[2] < P.np[2]) {
-                // global point coordinates: uniform_grid.rs:418-425 on the GLOBAL grid (dense_subdomains.rs:817-826); the SIMD loop
-                // of the reference forms z with one fma (:1069), x and y like the scalar loop (:1113-1114)
-                const R px = P.gmin[0] + (R)gl[0] * P.cs;
-                const R py = P.gmin[1] + (R)gl[1] * P.cs;
-                R pz;
-                if constexpr (ARITH >= SS_ARITH_SIMD)
-                    pz = __builtin_fmaf((R)gl[2], P.cs, P.gmin[2]);
-                else
-                    pz = P.gmin[2] + (R)gl[2] * P.cs;
-                R slo[3], shi[3];
-#pragma unroll
-                for (int d = 0; d < 3; ++d) {
-                    slo[d] = P.gmin[d] + (R)g0[d] * P.cs;
-                    shi[d] = P.gmin[d] + (R)min(g0[d] + 3, P.np[d] - 1) * P.cs;
-                }
-                bool done = false;
+            bool done = false;
+            if ((sx ? sub_ok[0][1] : sub_ok[0][0]) && (sy ? sub_ok[1][1] : sub_ok[1][0]) && (sz ? sub_ok[2][1] : sub_ok[2][0])) {
+                const R px = sx ? pc[0][1] : pc[0][0], py = sy ? pc[1][1] : pc[1][0], pz = sz ? pc[2][1] : pc[2][0];
+                const R slo[3] = {sx ? lo[0][1] : lo[0][0], sy ? lo[1][1] : lo[1][0], sz ? lo[2][1] : lo[2][0]};
+                const R shi[3] = {sx ? hi[0][1] : hi[0][0], sy ? hi[1][1] : hi[1][0], sz ? hi[2][1] : hi[2][0]};
                 if constexpr (EARLY) {  // classification: lower bound from the entries close to the sub-block
-                    acc = splat_accumulate_wave<R, CLS>(P, sh.pay, sh.wl, n_tile, lane, px, py, pz, slo, shi, P.R2near, R(0.0));
+                    acc = splat_accumulate_wave<R, CLS>(P, sh.pay, sh.wl, n_tile, lane, px, py, pz, slo, shi, P.R2near, R(0.0), sh.near, sb);
+                    if constexpr (CLS == SS_ARITH_BOUND) acc *= P.avx_sigma;  // the bound pass sums in units of sigma
                     done = __ballot(acc > P.thr_inside || !point_valid) == ~0ull;
                 }
                 if (!done)
@@ -1484,11 +1561,15 @@ __device__ __forceinline__ void splat_accumulate_block_wave(SplatAccWaveShared<R
                 else
                     certified |= 1u << sb;
             }
-            val = point_valid ? acc : R(0.0);
-            *gp = val;
+            // A certified sub-block stores nothing: marching cubes takes "some value above the threshold" for its points from
+            // the block's mask (mc_load_tile), and the second pass writes the sub-blocks whose values are really read.
+            if (done) {
+                val = P.thr_inside;
+            } else {
+                val = point_valid ? acc : R(0.0);  // points outside the grid count as 0 = "outside"
+                *gp = val;
+            }
         }
-        // points outside the grid count as 0 = "outside"; a certified sub-block reports values above the threshold, like its
-        // complete values would be
         mn = ss_min(mn, val);
         mx = ss_max(mx, val);
         if constexpr (EARLY) faces |= (unsigned long long)splat_face_bits(__ballot(point_valid && !(val > P.threshold))) << (6 * sb);
@@ -1515,19 +1596,19 @@ __device__ __forceinline__ void splat_accumulate_block_wave(SplatAccWaveShared<R
 // list == nullptr: every active block; otherwise the blocks of the device-side list, the sub-blocks in redo_mask only.  Blocks
 // whose tile does not fit a wave's chunk are appended to big[1..] (count in big[0]) for k_splat_accumulate_list.
 template <class R, int ARITH, bool EARLY>
-__global__ __launch_bounds__(256) void k_splat_accumulate_w(SSDevT<R> P, const ss_real4<R>* __restrict__ arena, const unsigned long long* __restrict__ tile_off,
+__global__ __launch_bounds__(64) void k_splat_accumulate_w(SSDevT<R> P, const ss_real4<R>* __restrict__ arena, const unsigned long long* __restrict__ tile_off,
                                                             const uint32_t* __restrict__ counts, const uint32_t* __restrict__ active_xyz, uint32_t n_active,
                                                             const uint32_t* __restrict__ list, const uint32_t* __restrict__ n_list_dev,
                                                             const uint32_t* __restrict__ redo_mask, R* __restrict__ G, ss_real2<R>* __restrict__ blk_minmax,
                                                             uint32_t* __restrict__ trunc, unsigned long long* __restrict__ facebits, uint32_t* __restrict__ big) {
-    __shared__ SplatAccWaveShared<R> sh[4];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    // one-wave workgroups: the blocks of a larger workgroup differ widely in cost (certified inside / at the surface), and its
+    // wave slots and LDS are only released when the slowest one is done
+    __shared__ SplatAccWaveShared<R> sh;
+    const int lane = threadIdx.x;
     const uint32_t n = list ? *n_list_dev : n_active;
-    // XCD-aware mapping: hardware places workgroup w on XCD w % 8; every XCD gets a contiguous range of the (spatially ordered)
-    // list, so that neighbouring blocks share an L2
-    const uint32_t n_groups = (n + 3u) / 4u, per_xcd = (n_groups + 7u) / 8u, xcd = blockIdx.x & 7u, stride = gridDim.x >> 3;
-    for (uint32_t j = blockIdx.x >> 3; j < per_xcd; j += stride) {
-        const uint32_t it = (xcd * per_xcd + j) * 4u + (uint32_t)wave;
+    const uint32_t n_slots = ss_xcd_chunked_grid_dev(n);
+    for (uint32_t w = blockIdx.x; w < n_slots; w += gridDim.x) {
+        const uint32_t it = ss_xcd_chunked_group(w);
         if (it >= n) continue;
         const uint32_t logical = __builtin_amdgcn_readfirstlane(list ? list[it] : it);
         const int n_tile = __builtin_amdgcn_readfirstlane((int)counts[logical]);
@@ -1538,7 +1619,7 @@ __global__ __launch_bounds__(256) void k_splat_accumulate_w(SSDevT<R> P, const s
         const unsigned long long off = tile_off[logical];
         const unsigned long long off_u = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(off >> 32)) << 32) |
                                          (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)off);
-        splat_accumulate_block_wave<R, ARITH, EARLY>(sh[wave], P, logical, n_tile, arena + off_u, active_xyz, G, blk_minmax, trunc, facebits,
+        splat_accumulate_block_wave<R, ARITH, EARLY>(sh, P, logical, n_tile, arena + off_u, active_xyz, G, blk_minmax, trunc, facebits,
                                                      redo_mask ? __builtin_amdgcn_readfirstlane(redo_mask[logical]) : 0xFFu);
     }
 }
@@ -1623,7 +1704,7 @@ void ss_launch_splat_gather(const SSDevT<R>& P, const ss_real4<R>* posvol, const
                             const unsigned long long* tile_off, ss_real4<R>* arena, uint32_t* counts, uint32_t* large_flag, hipStream_t st) {
     if (!n_active) return;
     const uint32_t n_groups = (n_active + 3u) / 4u;
-    hipLaunchKernelGGL(k_splat_gather<R>, dim3(((n_groups + 7u) / 8u) * 8u), dim3(256), 0, st, P, posvol, perm, cell_start, active_xyz, n_active, tile_off, arena, counts,
+    hipLaunchKernelGGL(k_splat_gather<R>, dim3(ss_xcd_chunked_grid(n_groups)), dim3(256), 0, st, P, posvol, perm, cell_start, active_xyz, n_active, tile_off, arena, counts,
                        large_flag);
 }
 
@@ -1645,11 +1726,10 @@ void ss_launch_splat_accumulate(const SSDevT<R>& P, const ss_real4<R>* arena, co
                                 const uint32_t* list, const uint32_t* n_list_dev, const uint32_t* redo_mask, unsigned long long* facebits, uint32_t* big, hipStream_t st) {
     if (!n_active) return;
     (void)hipMemsetAsync(big, 0, 4, st);
-    const uint32_t n_groups = (n_active + 3u) / 4u;
-    const dim3 grid(list ? 8192u : ((n_groups + 7u) / 8u) * 8u), lgrid(2048);
+    const dim3 grid(list ? 32768u : ss_xcd_chunked_grid(n_active)), lgrid(2048);
 #define SS_ACC_E(A, E)                                                                                                                                                  \
     do {                                                                                                                                                                \
-        hipLaunchKernelGGL((k_splat_accumulate_w<R, A, E>), grid, dim3(256), 0, st, P, arena, tile_off, counts, active_xyz, n_active, list, n_list_dev, redo_mask, G,  \
+        hipLaunchKernelGGL((k_splat_accumulate_w<R, A, E>), grid, dim3(64), 0, st,  P, arena, tile_off, counts, active_xyz, n_active, list, n_list_dev, redo_mask, G,  \
                            blk_minmax, trunc, facebits, big);                                                                                                                  \
         hipLaunchKernelGGL((k_splat_accumulate_list<R, A, E>), lgrid, dim3(512), 0, st, P, arena, tile_off, counts, active_xyz, big + 1, big, redo_mask, G, blk_minmax, \
                            trunc, facebits);                                                                                                                                     \
@@ -1695,15 +1775,24 @@ struct McTile {
 };
 
 template <class R>
-__device__ inline void mc_load_tile(McTile<R>& t, const SSDevT<R>& P, const R* __restrict__ G, const uint32_t* __restrict__ block_slot, int bx,
-                                    int by, int bz, int tid) {
+__device__ inline void mc_load_tile(McTile<R>& t, const SSDevT<R>& P, const R* __restrict__ G, const uint32_t* __restrict__ block_slot,
+                                    const uint32_t* __restrict__ certified, int bx, int by, int bz, int tid) {
+    // certified (may be null): per level-set block, the mask of its 4^3 sub-blocks that the splat certified to lie inside the
+    // surface and never evaluated in full; their points read as "a value above the threshold" (they are no end point of an edge
+    // that crosses the surface, k_select_redo, so the value itself is never used)
     for (int e = tid; e < 729; e += 512) {
         const int x = e / 81, y = (e / 9) % 9, z = e % 9;
         const int nbx = bx + (x >> 3), nby = by + (y >> 3), nbz = bz + (z >> 3);
         R v = R(0.0);
         if (nbx < P.nb[0] && nby < P.nb[1] && nbz < P.nb[2]) {
             const uint32_t slot = block_slot[((size_t)nbx * P.nb[1] + nby) * P.nb[2] + nbz];
-            if (slot != 0xFFFFFFFFu) v = G[(size_t)slot * SS_BLOCK_POINTS + (size_t)((((x & 7) * 8) + (y & 7)) * 8 + (z & 7))];
+            if (slot != 0xFFFFFFFFu) {
+                const int sbit = (((x & 7) >> 2) << 2) | (((y & 7) >> 2) << 1) | ((z & 7) >> 2);
+                if (certified && ((certified[slot] >> sbit) & 1u))
+                    v = P.thr_inside;
+                else
+                    v = G[(size_t)slot * SS_BLOCK_POINTS + (size_t)((((x & 7) * 8) + (y & 7)) * 8 + (z & 7))];
+            }
         }
         t.g[e] = v;
     }
@@ -1748,7 +1837,7 @@ __device__ inline McLocal mc_classify(const McTile<R>& t, const SSDevT<R>& P, in
 }
 
 template <class R>
-__global__ __launch_bounds__(512) void k_mc_count(SSDevT<R> P, const R* __restrict__ G, const uint32_t* __restrict__ block_slot,
+__global__ __launch_bounds__(512) void k_mc_count(SSDevT<R> P, const R* __restrict__ G, const uint32_t* __restrict__ block_slot, const uint32_t* __restrict__ certified,
                                                   const uint32_t* __restrict__ mc_xyz, uint32_t n_mc, unsigned long long* __restrict__ masks,
                                                   uint32_t* __restrict__ vcount, uint32_t* __restrict__ tcount) {
     __shared__ McTile<R> tile;
@@ -1757,7 +1846,7 @@ __global__ __launch_bounds__(512) void k_mc_count(SSDevT<R> P, const R* __restri
     const uint32_t m = blockIdx.x;
     if (m >= n_mc) return;
     const int bx = (int)mc_xyz[3 * (size_t)m], by = (int)mc_xyz[3 * (size_t)m + 1], bz = (int)mc_xyz[3 * (size_t)m + 2];  // k_block_coords
-    mc_load_tile(tile, P, G, block_slot, bx, by, bz, tid);
+    mc_load_tile(tile, P, G, block_slot, certified, bx, by, bz, tid);
     __syncthreads();
     const McLocal L = mc_classify(tile, P, bx, by, bz, tid);
     uint32_t nv = 0;
@@ -1788,7 +1877,7 @@ __global__ __launch_bounds__(512) void k_mc_count(SSDevT<R> P, const R* __restri
 }
 
 template <class R>
-__global__ __launch_bounds__(512) void k_mc_emit(SSDevT<R> P, const R* __restrict__ G, const uint32_t* __restrict__ block_slot,
+__global__ __launch_bounds__(512) void k_mc_emit(SSDevT<R> P, const R* __restrict__ G, const uint32_t* __restrict__ block_slot, const uint32_t* __restrict__ certified,
                                                  const uint32_t* __restrict__ mc_xyz, const uint32_t* __restrict__ mc_slot, uint32_t n_mc,
                                                  const unsigned long long* __restrict__ masks, const uint32_t* __restrict__ vbase,
                                                  const uint32_t* __restrict__ tbase, R* __restrict__ vertices,
@@ -1803,7 +1892,7 @@ __global__ __launch_bounds__(512) void k_mc_emit(SSDevT<R> P, const R* __restric
     if (m >= n_mc) return;
     if (vbase[m + 1] == vbase[m] && tbase[m + 1] == tbase[m]) return;  // nothing to emit for this block
     const int bx = (int)mc_xyz[3 * (size_t)m], by = (int)mc_xyz[3 * (size_t)m + 1], bz = (int)mc_xyz[3 * (size_t)m + 2];  // k_block_coords
-    mc_load_tile(tile, P, G, block_slot, bx, by, bz, tid);
+    mc_load_tile(tile, P, G, block_slot, certified, bx, by, bz, tid);
     // crossing masks of this block and its 7 upper neighbours
     if (tid < 8 * 24) {
         const int nb = tid / 24, w = tid % 24;
@@ -1895,17 +1984,17 @@ __global__ __launch_bounds__(512) void k_mc_emit(SSDevT<R> P, const R* __restric
 }
 
 template <class R>
-void ss_launch_mc_count(const SSDevT<R>& P, const R* G, const uint32_t* block_slot, const uint32_t* mc_xyz, uint32_t n_mc,
+void ss_launch_mc_count(const SSDevT<R>& P, const R* G, const uint32_t* block_slot, const uint32_t* certified, const uint32_t* mc_xyz, uint32_t n_mc,
                         unsigned long long* masks, uint32_t* vcount, uint32_t* tcount, hipStream_t st) {
     if (!n_mc) return;
-    hipLaunchKernelGGL(k_mc_count<R>, dim3(n_mc), dim3(512), 0, st, P, G, block_slot, mc_xyz, n_mc, masks, vcount, tcount);
+    hipLaunchKernelGGL(k_mc_count<R>, dim3(n_mc), dim3(512), 0, st, P, G, block_slot, certified, mc_xyz, n_mc, masks, vcount, tcount);
 }
 template <class R>
-void ss_launch_mc_emit(const SSDevT<R>& P, const R* G, const uint32_t* block_slot, const uint32_t* mc_xyz, const uint32_t* mc_slot,
+void ss_launch_mc_emit(const SSDevT<R>& P, const R* G, const uint32_t* block_slot, const uint32_t* certified, const uint32_t* mc_xyz, const uint32_t* mc_slot,
                        uint32_t n_mc, const unsigned long long* masks, const uint32_t* vbase, const uint32_t* tbase, R* vertices,
                        unsigned long long* vkeys, uint32_t* triangles, hipStream_t st) {
     if (!n_mc) return;
-    hipLaunchKernelGGL(k_mc_emit<R>, dim3(n_mc), dim3(512), 0, st, P, G, block_slot, mc_xyz, mc_slot, n_mc, masks, vbase, tbase, vertices, vkeys,
+    hipLaunchKernelGGL(k_mc_emit<R>, dim3(n_mc), dim3(512), 0, st, P, G, block_slot, certified, mc_xyz, mc_slot, n_mc, masks, vbase, tbase, vertices, vkeys,
                        triangles);
 }
 
@@ -1982,9 +2071,9 @@ template void ss_launch_splat_accumulate<float>(const SSDevT<float>& P, const ss
 template void ss_launch_select_redo<float>(const SSDevT<float>& P, const uint32_t* active_xyz, uint32_t n_active, const uint32_t* block_slot, const uint32_t* trunc, const unsigned long long* facebits, uint32_t* redo_mask, hipStream_t st);
 template void ss_launch_splat_accumulate<double>(const SSDevT<double>& P, const ss_real4<double>* arena, const unsigned long long* tile_off, const uint32_t* counts, const uint32_t* active_xyz, uint32_t n_active, double* G, ss_real2<double>* blk_minmax, uint32_t* trunc, bool full_levelset, const uint32_t* list, const uint32_t* n_list_dev, const uint32_t* redo_mask, unsigned long long* facebits, uint32_t* big, hipStream_t st);
 template void ss_launch_select_redo<double>(const SSDevT<double>& P, const uint32_t* active_xyz, uint32_t n_active, const uint32_t* block_slot, const uint32_t* trunc, const unsigned long long* facebits, uint32_t* redo_mask, hipStream_t st);
-template void ss_launch_mc_count<float>(const SSDevT<float>& P, const float* G, const uint32_t* block_slot, const uint32_t* mc_xyz, uint32_t n_mc, unsigned long long* masks, uint32_t* vcount, uint32_t* tcount, hipStream_t st);
-template void ss_launch_mc_count<double>(const SSDevT<double>& P, const double* G, const uint32_t* block_slot, const uint32_t* mc_xyz, uint32_t n_mc, unsigned long long* masks, uint32_t* vcount, uint32_t* tcount, hipStream_t st);
-template void ss_launch_mc_emit<float>(const SSDevT<float>& P, const float* G, const uint32_t* block_slot, const uint32_t* mc_xyz, const uint32_t* mc_slot, uint32_t n_mc, const unsigned long long* masks, const uint32_t* vbase, const uint32_t* tbase, float* vertices, unsigned long long* vkeys, uint32_t* triangles, hipStream_t st);
-template void ss_launch_mc_emit<double>(const SSDevT<double>& P, const double* G, const uint32_t* block_slot, const uint32_t* mc_xyz, const uint32_t* mc_slot, uint32_t n_mc, const unsigned long long* masks, const uint32_t* vbase, const uint32_t* tbase, double* vertices, unsigned long long* vkeys, uint32_t* triangles, hipStream_t st);
+template void ss_launch_mc_count<float>(const SSDevT<float>& P, const float* G, const uint32_t* block_slot, const uint32_t* certified, const uint32_t* mc_xyz, uint32_t n_mc, unsigned long long* masks, uint32_t* vcount, uint32_t* tcount, hipStream_t st);
+template void ss_launch_mc_count<double>(const SSDevT<double>& P, const double* G, const uint32_t* block_slot, const uint32_t* certified, const uint32_t* mc_xyz, uint32_t n_mc, unsigned long long* masks, uint32_t* vcount, uint32_t* tcount, hipStream_t st);
+template void ss_launch_mc_emit<float>(const SSDevT<float>& P, const float* G, const uint32_t* block_slot, const uint32_t* certified, const uint32_t* mc_xyz, const uint32_t* mc_slot, uint32_t n_mc, const unsigned long long* masks, const uint32_t* vbase, const uint32_t* tbase, float* vertices, unsigned long long* vkeys, uint32_t* triangles, hipStream_t st);
+template void ss_launch_mc_emit<double>(const SSDevT<double>& P, const double* G, const uint32_t* block_slot, const uint32_t* certified, const uint32_t* mc_xyz, const uint32_t* mc_slot, uint32_t n_mc, const unsigned long long* masks, const uint32_t* vbase, const uint32_t* tbase, double* vertices, unsigned long long* vkeys, uint32_t* triangles, hipStream_t st);
 template void ss_launch_levelset_box<float>(const SSDevT<float>& P, const float* G, const uint32_t* block_slot, const int lo[3], const int ext[3], float* out, hipStream_t st);
 template void ss_launch_levelset_box<double>(const SSDevT<double>& P, const double* G, const uint32_t* block_slot, const int lo[3], const int ext[3], double* out, hipStream_t st);
