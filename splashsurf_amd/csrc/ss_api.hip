@@ -908,9 +908,10 @@ ss_status phase_finish(ss_context* ctx, ss_result* res) {
         SS_HIP(ctx, hipStreamSynchronize(st));
         n_reserved = h_total;
         SS_HIP(ctx, ctx->splat_tiles.reserve((size_t)n_reserved * sizeof(ss_real4<R>) + 64));
+        SS_HIP(ctx, ctx->splat_tile_idx.reserve((size_t)n_reserved * 4 + 64));
         SS_HIP(ctx, hipMemsetAsync(lg_flag + n_active, 0, 4, st));
         ss_launch_splat_gather(PK, res->posvol.as<ss_real4<R>>(), res->perm.as<uint32_t>(), ctx->cell_start.as<uint32_t>(), res->active_xyz.as<uint32_t>(), n_active,
-                               ctx->splat_off.as<unsigned long long>(), ctx->splat_tiles.as<ss_real4<R>>(), ctx->splat_counts.as<uint32_t>(), lg_flag, st);
+                               ctx->splat_off.as<unsigned long long>(), ctx->splat_tiles.as<ss_real4<R>>(), ctx->splat_tile_idx.as<uint32_t>(), ctx->splat_counts.as<uint32_t>(), lg_flag, st);
         // over-dense blocks: flags -> ordered list on the device; the workgroup-level gather reads its length there
         s = exclusive_scan_u32<uint32_t>(ctx, lg_flag, lg_rank, (size_t)n_active + 1);
         if (s != SS_OK) return s;
@@ -951,7 +952,7 @@ ss_status phase_finish(ss_context* ctx, ss_result* res) {
     uint32_t* rd_rank = rd_flag + ((size_t)n_active + 1);
     uint32_t* rd_list = rd_rank + ((size_t)n_active + 1);
     uint32_t* big = rd_list + ((size_t)n_active + 1);            // blocks handed to the workgroup-per-block kernel (count, list)
-    ss_launch_splat_accumulate(PK, ctx->splat_tiles.as<ss_real4<R>>(), ctx->splat_off.as<unsigned long long>(), ctx->splat_counts.as<uint32_t>(),
+    ss_launch_splat_accumulate(PK, ctx->splat_tiles.as<ss_real4<R>>(), ctx->splat_tile_idx.as<uint32_t>(), ctx->splat_off.as<unsigned long long>(), ctx->splat_counts.as<uint32_t>(),
                                res->active_xyz.as<uint32_t>(), n_active, res->G.as<R>(), res->blk_minmax.as<ss_real2<R>>(), tr_flag, full_ls, nullptr, nullptr, nullptr, face_bits, big, st);
     SS_HIP(ctx, hipEventRecord(ctx->ev[13], st));
     if (n_active && !full_ls) {
@@ -978,7 +979,7 @@ ss_status phase_finish(ss_context* ctx, ss_result* res) {
             SS_HIP(ctx, rocprim::exclusive_scan(ctx->temp.p, bytes, it, rd_rank, 0u, (size_t)n_active + 1, rocprim::plus<uint32_t>(), st));
         }
         ss_launch_compact_blocks(rd_flag, rd_rank, n_active, rd_list, lg_slot, st);
-        ss_launch_splat_accumulate(PK, ctx->splat_tiles.as<ss_real4<R>>(), ctx->splat_off.as<unsigned long long>(), ctx->splat_counts.as<uint32_t>(),
+        ss_launch_splat_accumulate(PK, ctx->splat_tiles.as<ss_real4<R>>(), ctx->splat_tile_idx.as<uint32_t>(), ctx->splat_off.as<unsigned long long>(), ctx->splat_counts.as<uint32_t>(),
                                    res->active_xyz.as<uint32_t>(), n_active, res->G.as<R>(), res->blk_minmax.as<ss_real2<R>>(), tr_flag, true, rd_list, rd_rank + n_active, rd_flag, face_bits, big, st);
         s = count_nonzero_u32(ctx, tr_flag, n_active, ctx->counter.as<unsigned long long>() + 1);  // blocks still truncated (statistics)
         if (s != SS_OK) return s;
@@ -1082,7 +1083,7 @@ ss_status phase_finish(ss_context* ctx, ss_result* res) {
     for (const DevBuf* b : {&ctx->xyz_in, &ctx->xyz_filt, &ctx->flags32, &ctx->offsets, &ctx->keys_a, &ctx->keys_b, &ctx->vals_a, &ctx->cell_count,
                             &ctx->cell_start, &ctx->pos_sorted, &ctx->temp, &ctx->block_flag, &ctx->block_rank, &ctx->mc_flag, &ctx->mc_rank,
                             &ctx->vcount, &ctx->tcount, &ctx->member_count, &ctx->copy_offset, &ctx->ckeys_a, &ctx->ckeys_b, &ctx->cvals_a, &ctx->cidx,
-                            &ctx->cpos, &ctx->cell_count2, &ctx->cell_start2, &res->rho, &res->posvol, &ctx->splat_tiles, &ctx->splat_counts, &ctx->splat_off, &ctx->splat_bound, &ctx->splat_overflow, &res->posvol_by_index, &res->perm, &res->inside8, &res->G, &res->block_slot,
+                            &ctx->cpos, &ctx->cell_count2, &ctx->cell_start2, &res->rho, &res->posvol, &ctx->splat_tile_idx, &ctx->splat_tiles, &ctx->splat_counts, &ctx->splat_off, &ctx->splat_bound, &ctx->splat_overflow, &res->posvol_by_index, &res->perm, &res->inside8, &res->G, &res->block_slot,
                             &res->active_list, &res->mc_list, &res->mc_slot, &res->masks, &res->vbase, &res->tbase, &res->vertices, &res->vkeys,
                             &res->tri32})
         held += b->cap;
@@ -1414,7 +1415,7 @@ void ss_context_destroy(ss_context* c) {
     for (DevBuf* b : {&c->xyz_in, &c->xyz_filt, &c->flags32, &c->offsets, &c->keys_a, &c->keys_b, &c->vals_a, &c->cell_count,
                       &c->cell_start, &c->pos_sorted, &c->temp, &c->aabb_partial, &c->aabb_out, &c->block_flag, &c->block_rank, &c->mc_flag,
                       &c->mc_rank, &c->vcount, &c->tcount, &c->counter, &c->member_count, &c->copy_offset, &c->sub_flag, &c->sub_rank,
-                      &c->nb_count, &c->nb_tmp, &c->occ_sub, &c->ckeys_a, &c->ckeys_b, &c->cvals_a, &c->cidx, &c->cpos, &c->cell_count2, &c->cell_start2, &c->gboxes, &c->fastdiv_scratch, &c->splat_overflow, &c->splat_tiles, &c->splat_counts, &c->splat_off, &c->splat_bound, &c->splat_trunc, &c->own_flag})
+                      &c->nb_count, &c->nb_tmp, &c->occ_sub, &c->ckeys_a, &c->ckeys_b, &c->cvals_a, &c->cidx, &c->cpos, &c->cell_count2, &c->cell_start2, &c->gboxes, &c->fastdiv_scratch, &c->splat_overflow, &c->splat_tile_idx, &c->splat_tiles, &c->splat_counts, &c->splat_off, &c->splat_bound, &c->splat_trunc, &c->own_flag})
         b->release();
     for (DevBuf& b : c->post_pool) b.release();
     if (c->ev_ok)

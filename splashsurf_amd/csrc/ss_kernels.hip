@@ -905,6 +905,12 @@ __global__ __launch_bounds__(256) void k_splat_bounds(SSDevT<R> P, const uint32_
     bound[logical] = u;  // entry n_active: 0, so that the exclusive scan ends with the arena size
 }
 
+// tile entries one wave of the wave-per-block accumulate kernel holds in LDS (k_splat_accumulate_w)
+template <class R>
+struct SSWaveChunk {
+    static constexpr int value = sizeof(R) == 4 ? 192 : 128;  // whole 64-entry batches
+};
+
 template <class R, int E>
 __device__ __forceinline__ void splat_rank_and_write(const uint32_t* s_idx, const uint32_t* s_src, uint32_t count, int lane, const ss_real4<R>* __restrict__ posvol,
                                                      ss_real4<R>* __restrict__ tile) {
@@ -932,8 +938,8 @@ __device__ __forceinline__ void splat_rank_and_write(const uint32_t* s_idx, cons
 template <class R>
 __global__ __launch_bounds__(256) void k_splat_gather(SSDevT<R> P, const ss_real4<R>* __restrict__ posvol, const uint32_t* __restrict__ perm,
                                                       const uint32_t* __restrict__ cell_start, const uint32_t* __restrict__ active_xyz, uint32_t n_active,
-                                                      const unsigned long long* __restrict__ tile_off, ss_real4<R>* __restrict__ arena, uint32_t* __restrict__ counts,
-                                                      uint32_t* __restrict__ large_flag) {
+                                                      const unsigned long long* __restrict__ tile_off, ss_real4<R>* __restrict__ arena, uint32_t* __restrict__ arena_idx,
+                                                      uint32_t* __restrict__ counts, uint32_t* __restrict__ large_flag) {
     __shared__ uint32_t s_idx[4][SS_WTILE];
     __shared__ uint32_t s_src[4][SS_WTILE];
     __shared__ uint32_t s_row_start[4][64];
@@ -963,11 +969,22 @@ __global__ __launch_bounds__(256) void k_splat_gather(SSDevT<R> P, const ss_real
     }
     if (count > (uint32_t)SS_WTILE) return;
     ss_wave_lds_sync();
+    ss_real4<R>* tile = arena + tile_off[logical];
+    if (count <= (uint32_t)SSWaveChunk<R>::value) {
+        // A tile the wave-per-block accumulate kernel takes: payload in scan order plus the particle indices.  Most blocks lie
+        // inside the fluid and are certified by the order-independent lower-bound pass; the accumulate kernel orders a tile
+        // itself (splat_sort_tile) when one of the block's sub-blocks needs the exact sum.
+        uint32_t* tidx = arena_idx + tile_off[logical];
+        for (uint32_t i = (uint32_t)lane; i < count; i += 64u) {
+            tile[i] = posvol[s_src[w][i]];
+            tidx[i] = s_idx[w][i];
+        }
+        return;
+    }
     // rank sort by original particle index (unique), payload written in that order.  (An in-register bitonic network -- 28 / 36 /
     // 45 dependent stages through ds_bpermute for 128 / 256 / 512 keys -- issues a third of the instructions but measured
     // slower, 4.1 instead of 3.3 ms on S10M-tank: the rank sort's LDS broadcast reads are independent and pipeline.)
     // Every lane ranks all of its (up to six) elements in ONE pass over the keys: one broadcast read serves them all.
-    ss_real4<R>* tile = arena + tile_off[logical];
     switch ((count + 63u) >> 6) {
         case 0: break;
         case 1: splat_rank_and_write<R, 1>(s_idx[w], s_src[w], count, lane, posvol, tile); break;
@@ -1467,20 +1484,49 @@ __device__ __forceinline__ uint32_t splat_near_masks(const SSDevT<R>& P, const s
 // kernel above the work per (entry, point) pair is the same, but a CU keeps ~32 independent blocks in flight instead of 4
 // (the loads of the next block's tile hide behind other blocks' arithmetic), there is no workgroup barrier, the tile is
 // fetched once per block by one wave, block-uniform values live in SGPRs and the min / max reduction runs once per block.
-template <class R>
-struct SSWaveChunk {
-    static constexpr int value = sizeof(R) == 4 ? 192 : 128;  // whole 64-entry batches
-};
 
 template <class R>
 struct SplatAccWaveShared {
     ss_real4<R> pay[SSWaveChunk<R>::value];
     ss_real4<R> wl[SS_WAVE_LIST];
     uint8_t near[SSWaveChunk<R>::value];  // per tile entry: the sub-blocks whose classification pass visits it
+    uint32_t idx[SSWaveChunk<R>::value];  // particle indices of the tile entries (splat_sort_tile)
 };
+
+// Orders the tile in LDS by original particle index (unique keys): rank sort, every lane ranks its entries in one pass over
+// the keys (one broadcast read serves them all), then the payload moves to its rank.  The exact sum needs this order
+// (dense_subdomains.rs:817-841 visits the particles in index order); the lower-bound pass does not.
+template <class R>
+__device__ __forceinline__ void splat_sort_tile(SplatAccWaveShared<R>& sh, const uint32_t* __restrict__ tile_idx, int n_tile, int lane) {
+    constexpr int E = SSWaveChunk<R>::value / 64;
+#pragma unroll
+    for (int e = 0; e < E; ++e)
+        if (lane + 64 * e < n_tile) sh.idx[lane + 64 * e] = tile_idx[lane + 64 * e];
+    ss_wave_lds_sync();
+    uint32_t my[E], rank[E];
+    ss_real4<R> pv[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const int i = lane + 64 * e;
+        my[e] = (i < n_tile) ? sh.idx[i] : 0u;
+        pv[e] = sh.pay[min(i, SSWaveChunk<R>::value - 1)];
+        rank[e] = 0u;
+    }
+    for (int k = 0; k < n_tile; ++k) {
+        const uint32_t v = sh.idx[k];
+#pragma unroll
+        for (int e = 0; e < E; ++e) rank[e] += (v < my[e]) ? 1u : 0u;
+    }
+    ss_wave_lds_sync();  // every lane holds its payload
+#pragma unroll
+    for (int e = 0; e < E; ++e)
+        if (lane + 64 * e < n_tile) sh.pay[rank[e]] = pv[e];
+    ss_wave_lds_sync();
+}
 
 template <class R, int ARITH, bool EARLY>
 __device__ __forceinline__ void splat_accumulate_block_wave(SplatAccWaveShared<R>& sh, const SSDevT<R>& P, uint32_t logical, int n_tile, const ss_real4<R>* __restrict__ tile,
+                                                            const uint32_t* __restrict__ tile_idx,
                                                             const uint32_t* __restrict__ active_xyz, R* __restrict__ G, ss_real2<R>* __restrict__ blk_minmax,
                                                             uint32_t* __restrict__ trunc, unsigned long long* __restrict__ facebits, uint32_t wave_mask) {
     constexpr int CH = SSWaveChunk<R>::value;
@@ -1533,8 +1579,9 @@ __device__ __forceinline__ void splat_accumulate_block_wave(SplatAccWaveShared<R
     // second pass: the sub-blocks the first pass certified (their values were never stored, see below)
     const uint32_t certified_before = (!EARLY && wave_mask != 0xFFu) ? (uint32_t)__builtin_amdgcn_readfirstlane((int)trunc[logical]) : 0u;
     R mn = R(INFINITY), mx = -R(INFINITY);
-    uint32_t certified = 0;
+    uint32_t certified = 0, need = 0;
     unsigned long long faces = 0;
+    // first the sub-blocks that need no exact sum: not selected (second pass), outside the grid, or certified by the lower bound
 #pragma unroll 1
     for (int sb = 0; sb < 8; ++sb) {
         const int sx = (sb >> 2) & 1, sy = (sb >> 1) & 1, sz = sb & 1;
@@ -1544,35 +1591,50 @@ __device__ __forceinline__ void splat_accumulate_block_wave(SplatAccWaveShared<R
         if (!((wave_mask >> sb) & 1u)) {
             // second pass: a sub-block that is not re-evaluated keeps its value (it still enters the block's min / max)
             val = ((certified_before >> sb) & 1u) ? P.thr_inside : *gp;
+        } else if (!((sx ? sub_ok[0][1] : sub_ok[0][0]) && (sy ? sub_ok[1][1] : sub_ok[1][0]) && (sz ? sub_ok[2][1] : sub_ok[2][0]))) {
+            val = R(0.0);  // points outside the grid count as 0 = "outside"
+            *gp = val;
         } else {
-            R acc = R(0.0);  // levelset_grid.fill(0), dense_subdomains.rs:1390
             bool done = false;
-            if ((sx ? sub_ok[0][1] : sub_ok[0][0]) && (sy ? sub_ok[1][1] : sub_ok[1][0]) && (sz ? sub_ok[2][1] : sub_ok[2][0])) {
+            if constexpr (EARLY) {  // classification: lower bound from the entries close to the sub-block, in any order
                 const R px = sx ? pc[0][1] : pc[0][0], py = sy ? pc[1][1] : pc[1][0], pz = sz ? pc[2][1] : pc[2][0];
                 const R slo[3] = {sx ? lo[0][1] : lo[0][0], sy ? lo[1][1] : lo[1][0], sz ? lo[2][1] : lo[2][0]};
                 const R shi[3] = {sx ? hi[0][1] : hi[0][0], sy ? hi[1][1] : hi[1][0], sz ? hi[2][1] : hi[2][0]};
-                if constexpr (EARLY) {  // classification: lower bound from the entries close to the sub-block
-                    acc = splat_accumulate_wave<R, CLS>(P, sh.pay, sh.wl, n_tile, lane, px, py, pz, slo, shi, P.R2near, R(0.0), sh.near, sb);
-                    if constexpr (CLS == SS_ARITH_BOUND) acc *= P.avx_sigma;  // the bound pass sums in units of sigma
-                    done = __ballot(acc > P.thr_inside || !point_valid) == ~0ull;
-                }
-                if (!done)
-                    acc = splat_accumulate_wave<R, ARITH>(P, sh.pay, sh.wl, n_tile, lane, px, py, pz, slo, shi, P.R2, R(0.0));
-                else
-                    certified |= 1u << sb;
+                R acc = splat_accumulate_wave<R, CLS>(P, sh.pay, sh.wl, n_tile, lane, px, py, pz, slo, shi, P.R2near, R(0.0), sh.near, sb);
+                if constexpr (CLS == SS_ARITH_BOUND) acc *= P.avx_sigma;  // the bound pass sums in units of sigma
+                done = __ballot(acc > P.thr_inside || !point_valid) == ~0ull;
+            }
+            if (!done) {
+                need |= 1u << sb;
+                continue;
             }
             // A certified sub-block stores nothing: marching cubes takes "some value above the threshold" for its points from
             // the block's mask (mc_load_tile), and the second pass writes the sub-blocks whose values are really read.
-            if (done) {
-                val = P.thr_inside;
-            } else {
-                val = point_valid ? acc : R(0.0);  // points outside the grid count as 0 = "outside"
-                *gp = val;
-            }
+            certified |= 1u << sb;
+            val = P.thr_inside;
         }
         mn = ss_min(mn, val);
         mx = ss_max(mx, val);
         if constexpr (EARLY) faces |= (unsigned long long)splat_face_bits(__ballot(point_valid && !(val > P.threshold))) << (6 * sb);
+    }
+    if (need) {
+        splat_sort_tile<R>(sh, tile_idx, n_tile, lane);
+#pragma unroll 1
+        for (int sb = 0; sb < 8; ++sb) {
+            if (!((need >> sb) & 1u)) continue;
+            const int sx = (sb >> 2) & 1, sy = (sb >> 1) & 1, sz = sb & 1;
+            const bool point_valid = (sx ? pt_ok[0][1] : pt_ok[0][0]) && (sy ? pt_ok[1][1] : pt_ok[1][0]) && (sz ? pt_ok[2][1] : pt_ok[2][0]);
+            const R px = sx ? pc[0][1] : pc[0][0], py = sy ? pc[1][1] : pc[1][0], pz = sz ? pc[2][1] : pc[2][0];
+            const R slo[3] = {sx ? lo[0][1] : lo[0][0], sy ? lo[1][1] : lo[1][0], sz ? lo[2][1] : lo[2][0]};
+            const R shi[3] = {sx ? hi[0][1] : hi[0][0], sy ? hi[1][1] : hi[1][0], sz ? hi[2][1] : hi[2][0]};
+            // levelset_grid.fill(0), dense_subdomains.rs:1390, then the sum in index order
+            const R acc = splat_accumulate_wave<R, ARITH>(P, sh.pay, sh.wl, n_tile, lane, px, py, pz, slo, shi, P.R2, R(0.0));
+            const R val = point_valid ? acc : R(0.0);
+            gblock[(size_t)((sx * 4 * 8 + sy * 4) * 8 + sz * 4)] = val;
+            mn = ss_min(mn, val);
+            mx = ss_max(mx, val);
+            if constexpr (EARLY) faces |= (unsigned long long)splat_face_bits(__ballot(point_valid && !(val > P.threshold))) << (6 * sb);
+        }
     }
     int writer = 0;
     if constexpr (sizeof(R) == 4) {
@@ -1596,7 +1658,8 @@ __device__ __forceinline__ void splat_accumulate_block_wave(SplatAccWaveShared<R
 // list == nullptr: every active block; otherwise the blocks of the device-side list, the sub-blocks in redo_mask only.  Blocks
 // whose tile does not fit a wave's chunk are appended to big[1..] (count in big[0]) for k_splat_accumulate_list.
 template <class R, int ARITH, bool EARLY>
-__global__ __launch_bounds__(64) void k_splat_accumulate_w(SSDevT<R> P, const ss_real4<R>* __restrict__ arena, const unsigned long long* __restrict__ tile_off,
+__global__ __launch_bounds__(64) void k_splat_accumulate_w(SSDevT<R> P, const ss_real4<R>* __restrict__ arena, const uint32_t* __restrict__ arena_idx,
+                                                            const unsigned long long* __restrict__ tile_off,
                                                             const uint32_t* __restrict__ counts, const uint32_t* __restrict__ active_xyz, uint32_t n_active,
                                                             const uint32_t* __restrict__ list, const uint32_t* __restrict__ n_list_dev,
                                                             const uint32_t* __restrict__ redo_mask, R* __restrict__ G, ss_real2<R>* __restrict__ blk_minmax,
@@ -1619,7 +1682,7 @@ __global__ __launch_bounds__(64) void k_splat_accumulate_w(SSDevT<R> P, const ss
         const unsigned long long off = tile_off[logical];
         const unsigned long long off_u = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(off >> 32)) << 32) |
                                          (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)off);
-        splat_accumulate_block_wave<R, ARITH, EARLY>(sh, P, logical, n_tile, arena + off_u, active_xyz, G, blk_minmax, trunc, facebits,
+        splat_accumulate_block_wave<R, ARITH, EARLY>(sh, P, logical, n_tile, arena + off_u, arena_idx + off_u, active_xyz, G, blk_minmax, trunc, facebits,
                                                      redo_mask ? __builtin_amdgcn_readfirstlane(redo_mask[logical]) : 0xFFu);
     }
 }
@@ -1701,10 +1764,10 @@ void ss_launch_splat_bounds(const SSDevT<R>& P, const uint32_t* cell_start, cons
 
 template <class R>
 void ss_launch_splat_gather(const SSDevT<R>& P, const ss_real4<R>* posvol, const uint32_t* perm, const uint32_t* cell_start, const uint32_t* active_xyz, uint32_t n_active,
-                            const unsigned long long* tile_off, ss_real4<R>* arena, uint32_t* counts, uint32_t* large_flag, hipStream_t st) {
+                            const unsigned long long* tile_off, ss_real4<R>* arena, uint32_t* arena_idx, uint32_t* counts, uint32_t* large_flag, hipStream_t st) {
     if (!n_active) return;
     const uint32_t n_groups = (n_active + 3u) / 4u;
-    hipLaunchKernelGGL(k_splat_gather<R>, dim3(ss_xcd_chunked_grid(n_groups)), dim3(256), 0, st, P, posvol, perm, cell_start, active_xyz, n_active, tile_off, arena, counts,
+    hipLaunchKernelGGL(k_splat_gather<R>, dim3(ss_xcd_chunked_grid(n_groups)), dim3(256), 0, st, P, posvol, perm, cell_start, active_xyz, n_active, tile_off, arena, arena_idx, counts,
                        large_flag);
 }
 
@@ -1721,7 +1784,7 @@ void ss_launch_splat_gather_large(const SSDevT<R>& P, const ss_real4<R>* posvol,
 // device-side list of blocks with certified sub-blocks that marching cubes reads.  `big`: n_active + 1 words of scratch (the
 // blocks handed from the wave-per-block kernel to the workgroup-per-block kernel).
 template <class R>
-void ss_launch_splat_accumulate(const SSDevT<R>& P, const ss_real4<R>* arena, const unsigned long long* tile_off, const uint32_t* counts,
+void ss_launch_splat_accumulate(const SSDevT<R>& P, const ss_real4<R>* arena, const uint32_t* arena_idx, const unsigned long long* tile_off, const uint32_t* counts,
                                 const uint32_t* active_xyz, uint32_t n_active, R* G, ss_real2<R>* blk_minmax, uint32_t* trunc, bool full_levelset,
                                 const uint32_t* list, const uint32_t* n_list_dev, const uint32_t* redo_mask, unsigned long long* facebits, uint32_t* big, hipStream_t st) {
     if (!n_active) return;
@@ -1729,7 +1792,7 @@ void ss_launch_splat_accumulate(const SSDevT<R>& P, const ss_real4<R>* arena, co
     const dim3 grid(list ? 32768u : ss_xcd_chunked_grid(n_active)), lgrid(2048);
 #define SS_ACC_E(A, E)                                                                                                                                                  \
     do {                                                                                                                                                                \
-        hipLaunchKernelGGL((k_splat_accumulate_w<R, A, E>), grid, dim3(64), 0, st,  P, arena, tile_off, counts, active_xyz, n_active, list, n_list_dev, redo_mask, G,  \
+        hipLaunchKernelGGL((k_splat_accumulate_w<R, A, E>), grid, dim3(64), 0, st, P, arena, arena_idx, tile_off, counts, active_xyz, n_active, list, n_list_dev, redo_mask, G,  \
                            blk_minmax, trunc, facebits, big);                                                                                                                  \
         hipLaunchKernelGGL((k_splat_accumulate_list<R, A, E>), lgrid, dim3(512), 0, st, P, arena, tile_off, counts, active_xyz, big + 1, big, redo_mask, G, blk_minmax, \
                            trunc, facebits);                                                                                                                                     \
@@ -2062,14 +2125,14 @@ template void ss_launch_mark_blocks<double>(const SSDevT<double>& P, const uint3
 template void ss_launch_mark_mc_blocks<float>(const SSDevT<float>& P, const uint32_t* block_slot, const ss_real2<float>* blk_minmax, uint32_t nblocks, uint32_t* mc_flag, hipStream_t st);
 template void ss_launch_mark_mc_blocks<double>(const SSDevT<double>& P, const uint32_t* block_slot, const ss_real2<double>* blk_minmax, uint32_t nblocks, uint32_t* mc_flag, hipStream_t st);
 template void ss_launch_splat_bounds<float>(const SSDevT<float>& P, const uint32_t* cell_start, const uint32_t* active_xyz, uint32_t n_active, uint32_t* bound, hipStream_t st);
-template void ss_launch_splat_gather<float>(const SSDevT<float>& P, const ss_real4<float>* posvol, const uint32_t* perm, const uint32_t* cell_start, const uint32_t* active_xyz, uint32_t n_active, const unsigned long long* tile_off, ss_real4<float>* arena, uint32_t* counts, uint32_t* large_flag, hipStream_t st);
+template void ss_launch_splat_gather<float>(const SSDevT<float>& P, const ss_real4<float>* posvol, const uint32_t* perm, const uint32_t* cell_start, const uint32_t* active_xyz, uint32_t n_active, const unsigned long long* tile_off, ss_real4<float>* arena, uint32_t* arena_idx, uint32_t* counts, uint32_t* large_flag, hipStream_t st);
 template void ss_launch_splat_gather_large<float>(const SSDevT<float>& P, const ss_real4<float>* posvol, const ss_real4<float>* posvol_by_index, const uint32_t* perm, const uint32_t* cell_start, const uint32_t* active_xyz, const uint32_t* large_list, const uint32_t* n_large_dev, const uint32_t* counts, const unsigned long long* tile_off, ss_real4<float>* arena, hipStream_t st);
 template void ss_launch_splat_bounds<double>(const SSDevT<double>& P, const uint32_t* cell_start, const uint32_t* active_xyz, uint32_t n_active, uint32_t* bound, hipStream_t st);
-template void ss_launch_splat_gather<double>(const SSDevT<double>& P, const ss_real4<double>* posvol, const uint32_t* perm, const uint32_t* cell_start, const uint32_t* active_xyz, uint32_t n_active, const unsigned long long* tile_off, ss_real4<double>* arena, uint32_t* counts, uint32_t* large_flag, hipStream_t st);
+template void ss_launch_splat_gather<double>(const SSDevT<double>& P, const ss_real4<double>* posvol, const uint32_t* perm, const uint32_t* cell_start, const uint32_t* active_xyz, uint32_t n_active, const unsigned long long* tile_off, ss_real4<double>* arena, uint32_t* arena_idx, uint32_t* counts, uint32_t* large_flag, hipStream_t st);
 template void ss_launch_splat_gather_large<double>(const SSDevT<double>& P, const ss_real4<double>* posvol, const ss_real4<double>* posvol_by_index, const uint32_t* perm, const uint32_t* cell_start, const uint32_t* active_xyz, const uint32_t* large_list, const uint32_t* n_large_dev, const uint32_t* counts, const unsigned long long* tile_off, ss_real4<double>* arena, hipStream_t st);
-template void ss_launch_splat_accumulate<float>(const SSDevT<float>& P, const ss_real4<float>* arena, const unsigned long long* tile_off, const uint32_t* counts, const uint32_t* active_xyz, uint32_t n_active, float* G, ss_real2<float>* blk_minmax, uint32_t* trunc, bool full_levelset, const uint32_t* list, const uint32_t* n_list_dev, const uint32_t* redo_mask, unsigned long long* facebits, uint32_t* big, hipStream_t st);
+template void ss_launch_splat_accumulate<float>(const SSDevT<float>& P, const ss_real4<float>* arena, const uint32_t* arena_idx, const unsigned long long* tile_off, const uint32_t* counts, const uint32_t* active_xyz, uint32_t n_active, float* G, ss_real2<float>* blk_minmax, uint32_t* trunc, bool full_levelset, const uint32_t* list, const uint32_t* n_list_dev, const uint32_t* redo_mask, unsigned long long* facebits, uint32_t* big, hipStream_t st);
 template void ss_launch_select_redo<float>(const SSDevT<float>& P, const uint32_t* active_xyz, uint32_t n_active, const uint32_t* block_slot, const uint32_t* trunc, const unsigned long long* facebits, uint32_t* redo_mask, hipStream_t st);
-template void ss_launch_splat_accumulate<double>(const SSDevT<double>& P, const ss_real4<double>* arena, const unsigned long long* tile_off, const uint32_t* counts, const uint32_t* active_xyz, uint32_t n_active, double* G, ss_real2<double>* blk_minmax, uint32_t* trunc, bool full_levelset, const uint32_t* list, const uint32_t* n_list_dev, const uint32_t* redo_mask, unsigned long long* facebits, uint32_t* big, hipStream_t st);
+template void ss_launch_splat_accumulate<double>(const SSDevT<double>& P, const ss_real4<double>* arena, const uint32_t* arena_idx, const unsigned long long* tile_off, const uint32_t* counts, const uint32_t* active_xyz, uint32_t n_active, double* G, ss_real2<double>* blk_minmax, uint32_t* trunc, bool full_levelset, const uint32_t* list, const uint32_t* n_list_dev, const uint32_t* redo_mask, unsigned long long* facebits, uint32_t* big, hipStream_t st);
 template void ss_launch_select_redo<double>(const SSDevT<double>& P, const uint32_t* active_xyz, uint32_t n_active, const uint32_t* block_slot, const uint32_t* trunc, const unsigned long long* facebits, uint32_t* redo_mask, hipStream_t st);
 template void ss_launch_mc_count<float>(const SSDevT<float>& P, const float* G, const uint32_t* block_slot, const uint32_t* certified, const uint32_t* mc_xyz, uint32_t n_mc, unsigned long long* masks, uint32_t* vcount, uint32_t* tcount, hipStream_t st);
 template void ss_launch_mc_count<double>(const SSDevT<double>& P, const double* G, const uint32_t* block_slot, const uint32_t* certified, const uint32_t* mc_xyz, uint32_t n_mc, unsigned long long* masks, uint32_t* vcount, uint32_t* tcount, hipStream_t st);
