@@ -10,6 +10,7 @@
 
 #include <algorithm>
 #include <climits>
+#include <iterator>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -126,6 +127,20 @@ ss_status exclusive_scan_u32(ss_context* ctx, const T* in, T* out, size_t n) {
     SS_HIP(ctx, rocprim::exclusive_scan(nullptr, bytes, in, out, (T)0, n, rocprim::plus<T>(), ctx->stream));
     SS_HIP(ctx, ctx->temp.reserve(bytes));
     SS_HIP(ctx, rocprim::exclusive_scan(ctx->temp.p, bytes, in, out, (T)0, n, rocprim::plus<T>(), ctx->stream));
+    return SS_OK;
+}
+
+// cell_start[c] (c = 0 .. ncells) from the sorted keys: run starts, then a reverse running minimum over the table
+ss_status cell_table_from_sorted(ss_context* ctx, const uint32_t* sorted_keys, uint32_t n, size_t ncells, uint32_t* first, uint32_t* cell_start) {
+    hipStream_t st = ctx->stream;
+    SS_HIP(ctx, hipMemsetAsync(first, 0xFF, (ncells + 1) * 4, st));
+    ss_launch_run_starts(sorted_keys, n, (uint32_t)ncells, first, st);
+    auto in = std::make_reverse_iterator(first + ncells + 1);
+    auto out = std::make_reverse_iterator(cell_start + ncells + 1);
+    size_t bytes = 0;
+    SS_HIP(ctx, rocprim::inclusive_scan(nullptr, bytes, in, out, ncells + 1, rocprim::minimum<uint32_t>(), st));
+    SS_HIP(ctx, ctx->temp.reserve(bytes));
+    SS_HIP(ctx, rocprim::inclusive_scan(ctx->temp.p, bytes, in, out, ncells + 1, rocprim::minimum<uint32_t>(), st));
     return SS_OK;
 }
 
@@ -701,16 +716,13 @@ ss_status phase_begin(ss_context* ctx, const R* xyz, uint64_t n_in, const typena
     SS_HIP(ctx, res->perm.reserve((size_t)n * 4 + 16));
     SS_HIP(ctx, ctx->cell_count.reserve((ncells + 1) * 4));
     SS_HIP(ctx, ctx->cell_start.reserve((ncells + 1) * 4));
-    SS_HIP(ctx, hipMemsetAsync(ctx->cell_count.p, 0, (ncells + 1) * 4, st));
+    SS_HIP(ctx, ctx->keys_b.reserve((size_t)n * 4 + 16));
     if (n > 0) {
         SS_HIP(ctx, ctx->keys_a.reserve((size_t)n * 4));
-        SS_HIP(ctx, ctx->keys_b.reserve((size_t)n * 4));
         SS_HIP(ctx, ctx->vals_a.reserve((size_t)n * 4));
         SS_HIP(ctx, ctx->pos_sorted.reserve((size_t)n * sizeof(ss_real4<R>)));
-        ss_launch_cell_keys(P, d_xyz, ctx->keys_a.as<uint32_t>(), ctx->vals_a.as<uint32_t>(), ctx->cell_count.as<uint32_t>(), st);
+        ss_launch_cell_keys(P, d_xyz, ctx->keys_a.as<uint32_t>(), ctx->vals_a.as<uint32_t>(), st);
     }
-    s = exclusive_scan_u32<uint32_t>(ctx, ctx->cell_count.as<uint32_t>(), ctx->cell_start.as<uint32_t>(), ncells + 1);
-    if (s != SS_OK) return s;
     if (n > 0) {
         unsigned bits = 1;
         while (bits < 32 && ((size_t)1 << bits) < ncells) ++bits;
@@ -722,6 +734,8 @@ ss_status phase_begin(ss_context* ctx, const R* xyz, uint64_t n_in, const typena
                                               res->perm.as<uint32_t>(), (size_t)n, 0u, bits, st));
         ss_launch_gather_sorted(n, d_xyz, res->perm.as<uint32_t>(), ctx->pos_sorted.as<ss_real4<R>>(), st);
     }
+    s = cell_table_from_sorted(ctx, ctx->keys_b.as<uint32_t>(), n, ncells, ctx->cell_count.as<uint32_t>(), ctx->cell_start.as<uint32_t>());
+    if (s != SS_OK) return s;
     SS_HIP(ctx, hipEventRecord(ctx->ev[3], st));
 
     // ---- K2: densities (per-subdomain particle copies, exactly the reference's organisation) ----
@@ -758,12 +772,9 @@ ss_status phase_begin(ss_context* ctx, const R* xyz, uint64_t n_in, const typena
             SS_HIP(ctx, ctx->cpos.reserve(((size_t)n_copies + 16) * sizeof(ss_real4<R>)));  // + padding: k_density_sub reads whole chunks
             SS_HIP(ctx, ctx->cell_count2.reserve((ncells2 + 1) * 4));
             SS_HIP(ctx, ctx->cell_start2.reserve((ncells2 + 1) * 4));
-            SS_HIP(ctx, hipMemsetAsync(ctx->cell_count2.p, 0, (ncells2 + 1) * 4, st));
             ss_launch_occupied_list(ctx->sub_flag.as<uint32_t>(), ctx->sub_rank.as<uint32_t>(), (uint32_t)nsub, ctx->occ_sub.as<uint32_t>(), st);
             ss_launch_emit_copies(P, d_xyz, ctx->copy_offset.as<uint32_t>(), ctx->sub_rank.as<uint32_t>(), ctx->ckeys_a.as<uint32_t>(),
-                                  ctx->cvals_a.as<uint32_t>(), ctx->cell_count2.as<uint32_t>(), st);
-            s = exclusive_scan_u32<uint32_t>(ctx, ctx->cell_count2.as<uint32_t>(), ctx->cell_start2.as<uint32_t>(), ncells2 + 1);
-            if (s != SS_OK) return s;
+                                  ctx->cvals_a.as<uint32_t>(), st);
             unsigned bits = 1;
             while (bits < 32 && ((size_t)1 << bits) < ncells2) ++bits;
             size_t bytes = 0;
@@ -773,6 +784,8 @@ ss_status phase_begin(ss_context* ctx, const R* xyz, uint64_t n_in, const typena
             SS_HIP(ctx, rocprim::radix_sort_pairs(ctx->temp.p, bytes, ctx->ckeys_a.as<uint32_t>(), ctx->ckeys_b.as<uint32_t>(), ctx->cvals_a.as<uint32_t>(),
                                                   ctx->cidx.as<uint32_t>(), (size_t)n_copies, 0u, bits, st));
             ss_launch_gather_sorted(n_copies, d_xyz, ctx->cidx.as<uint32_t>(), ctx->cpos.as<ss_real4<R>>(), st);
+            s = cell_table_from_sorted(ctx, ctx->ckeys_b.as<uint32_t>(), n_copies, ncells2, ctx->cell_count2.as<uint32_t>(), ctx->cell_start2.as<uint32_t>());
+            if (s != SS_OK) return s;
             const bool want_nb = prm->global_neighborhood_list != 0;
             if (want_nb) {
                 SS_HIP(ctx, ctx->nb_count.reserve(((size_t)n + 1) * 8));

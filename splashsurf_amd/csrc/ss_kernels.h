@@ -9,15 +9,16 @@ template <class R>
 void ss_launch_inside_flags(const R* d_xyz, uint32_t n, const R amin[3], const R amax[3], uint8_t* f8, uint32_t* f32, hipStream_t st);
 template <class R>
 void ss_launch_compact_xyz(const R* d_xyz, uint32_t n, const uint32_t* f32, const uint32_t* offs, R* out, hipStream_t st);
+void ss_launch_run_starts(const uint32_t* sorted_keys, uint32_t n, uint32_t ncells, uint32_t* first, hipStream_t st);
 template <class R>
-void ss_launch_cell_keys(const SSDevT<R>& P, const R* d_xyz, uint32_t* keys, uint32_t* vals, uint32_t* cell_count, hipStream_t st);
+void ss_launch_cell_keys(const SSDevT<R>& P, const R* d_xyz, uint32_t* keys, uint32_t* vals, hipStream_t st);
 template <class R>
 void ss_launch_gather_sorted(uint32_t n, const R* d_xyz, const uint32_t* perm, ss_real4<R>* pos_sorted, hipStream_t st);
 template <class R>
 void ss_launch_classify_count(const SSDevT<R>& P, const R* xyz, uint32_t* member_count, uint32_t* sub_flag, hipStream_t st);
 void ss_launch_occupied_list(const uint32_t* flag, const uint32_t* rank, uint32_t n, uint32_t* occ_sub, hipStream_t st);
 template <class R>
-void ss_launch_emit_copies(const SSDevT<R>& P, const R* xyz, const uint32_t* copy_offset, const uint32_t* occ_rank, uint32_t* keys, uint32_t* vals, uint32_t* cell_count, hipStream_t st);
+void ss_launch_emit_copies(const SSDevT<R>& P, const R* xyz, const uint32_t* copy_offset, const uint32_t* occ_rank, uint32_t* keys, uint32_t* vals, hipStream_t st);
 template <class R>
 void ss_launch_density_sub(const SSDevT<R>& P, uint32_t n_copies, const ss_real4<R>* cpos, const uint32_t* cidx, const uint32_t* ckey, const uint32_t* cell_start, const uint32_t* occ_sub, R* rho, int mode, uint32_t* nb_count, const unsigned long long* nb_ptr, uint32_t* nb_idx, bool fast_div, const uint32_t* owned_list, const uint32_t* n_owned_dev, uint32_t n_owned_bound, hipStream_t st);
 template <class R>

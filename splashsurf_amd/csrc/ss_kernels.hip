@@ -159,7 +159,7 @@ __device__ inline void ss_particle_cell(const SSDevT<R>& P, R x, R y, R z, int K
 
 template <class R>
 __global__ __launch_bounds__(256) void k_cell_keys(SSDevT<R> P, const R* __restrict__ xyz, uint32_t* __restrict__ keys,
-                                                   uint32_t* __restrict__ vals, uint32_t* __restrict__ cell_count) {
+                                                   uint32_t* __restrict__ vals) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= P.n) return;
     int K[3];
@@ -167,7 +167,23 @@ __global__ __launch_bounds__(256) void k_cell_keys(SSDevT<R> P, const R* __restr
     uint32_t key = ss_cell_key(P, K[0], K[1], K[2]);
     keys[i] = key;
     vals[i] = i;
-    atomicAdd(&cell_count[key], 1u);
+}
+
+// Cell table from the SORTED keys (no histogram atomics): first[c] = position of the first entry of cell c, written at the run
+// starts; first[] must be preset to 0xFFFFFFFF, entry ncells receives n.  A reverse running minimum then turns it into
+// cell_start (an empty cell starts where the next non-empty one does).
+__global__ __launch_bounds__(256) void k_run_starts(const uint32_t* __restrict__ sorted_keys, uint32_t n, uint32_t ncells, uint32_t* __restrict__ first) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i > n) return;
+    if (i == n) {
+        first[ncells] = n;
+        return;
+    }
+    const uint32_t k = sorted_keys[i];
+    if (i == 0 || sorted_keys[i - 1] != k) first[k] = i;
+}
+void ss_launch_run_starts(const uint32_t* sorted_keys, uint32_t n, uint32_t ncells, uint32_t* first, hipStream_t st) {
+    hipLaunchKernelGGL(k_run_starts, dim3((n + 1u + 255u) / 256u), dim3(256), 0, st, sorted_keys, n, ncells, first);
 }
 
 template <class R>
@@ -180,9 +196,9 @@ __global__ __launch_bounds__(256) void k_gather_sorted(uint32_t n, const R* __re
 }
 
 template <class R>
-void ss_launch_cell_keys(const SSDevT<R>& P, const R* d_xyz, uint32_t* keys, uint32_t* vals, uint32_t* cell_count, hipStream_t st) {
+void ss_launch_cell_keys(const SSDevT<R>& P, const R* d_xyz, uint32_t* keys, uint32_t* vals, hipStream_t st) {
     if (!P.n) return;
-    hipLaunchKernelGGL(k_cell_keys<R>, dim3((P.n + 255) / 256), dim3(256), 0, st, P, d_xyz, keys, vals, cell_count);
+    hipLaunchKernelGGL(k_cell_keys<R>, dim3((P.n + 255) / 256), dim3(256), 0, st, P, d_xyz, keys, vals);
 }
 template <class R>
 void ss_launch_gather_sorted(uint32_t n, const R* d_xyz, const uint32_t* perm, ss_real4<R>* pos_sorted, hipStream_t st) {
@@ -251,7 +267,8 @@ __device__ inline int ss_local_search_cell_axis(const SSDevT<R>& P, int s, R x, 
 }
 
 // member_count[i] = number of subdomains particle i belongs to; sub_flag[s] = 1 for every subdomain with
-// at least one (owned or ghost) particle.  Plain flag stores (all writers store 1): no atomics.
+// at least one (owned or ghost) particle.  Plain flag stores (all writers store 1): no atomics; a set flag is not written again
+// (20 M stores to a few thousand words serialise in the L2 channels that hold them, the reads are cached).
 template <class R>
 __global__ __launch_bounds__(256) void k_classify_count(SSDevT<R> P, const R* __restrict__ xyz, uint32_t* __restrict__ member_count,
                                                         uint32_t* __restrict__ sub_flag) {
@@ -261,7 +278,8 @@ __global__ __launch_bounds__(256) void k_classify_count(SSDevT<R> P, const R* __
     uint32_t m = 0;
     ss_for_each_member_subdomain(P, p, [&](int sx, int sy, int sz) {
         ++m;
-        sub_flag[((size_t)sx * P.ns[1] + sy) * P.ns[2] + sz] = 1u;
+        uint32_t* f = sub_flag + ((size_t)sx * P.ns[1] + sy) * P.ns[2] + sz;
+        if (!*f) *f = 1u;
     });
     member_count[i] = m;
 }
@@ -275,7 +293,7 @@ __global__ __launch_bounds__(256) void k_occupied_list(const uint32_t* __restric
 template <class R>
 __global__ __launch_bounds__(256) void k_emit_copies(SSDevT<R> P, const R* __restrict__ xyz, const uint32_t* __restrict__ copy_offset,
                                                      const uint32_t* __restrict__ occ_rank, uint32_t* __restrict__ keys,
-                                                     uint32_t* __restrict__ vals, uint32_t* __restrict__ cell_count) {
+                                                     uint32_t* __restrict__ vals) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= P.n) return;
     const R p[3] = {xyz[3 * (size_t)i], xyz[3 * (size_t)i + 1], xyz[3 * (size_t)i + 2]};
@@ -289,7 +307,6 @@ __global__ __launch_bounds__(256) void k_emit_copies(SSDevT<R> P, const R* __res
         const uint32_t key = occ * ctot + (uint32_t)((cx * P.sc[1] + cy) * P.sc[2] + cz);
         keys[o] = key;
         vals[o] = i;
-        atomicAdd(&cell_count[key], 1u);
         ++o;
     });
 }
@@ -547,9 +564,9 @@ void ss_launch_occupied_list(const uint32_t* flag, const uint32_t* rank, uint32_
 }
 template <class R>
 void ss_launch_emit_copies(const SSDevT<R>& P, const R* xyz, const uint32_t* copy_offset, const uint32_t* occ_rank, uint32_t* keys, uint32_t* vals,
-                           uint32_t* cell_count, hipStream_t st) {
+                           hipStream_t st) {
     if (!P.n) return;
-    hipLaunchKernelGGL(k_emit_copies<R>, dim3((P.n + 255) / 256), dim3(256), 0, st, P, xyz, copy_offset, occ_rank, keys, vals, cell_count);
+    hipLaunchKernelGGL(k_emit_copies<R>, dim3((P.n + 255) / 256), dim3(256), 0, st, P, xyz, copy_offset, occ_rank, keys, vals);
 }
 template <class R>
 void ss_launch_density_sub(const SSDevT<R>& P, uint32_t n_copies, const ss_real4<R>* cpos, const uint32_t* cidx, const uint32_t* ckey,
@@ -2104,14 +2121,14 @@ template void ss_launch_inside_flags<float>(const float* d_xyz, uint32_t n, cons
 template void ss_launch_inside_flags<double>(const double* d_xyz, uint32_t n, const double amin[3], const double amax[3], uint8_t* f8, uint32_t* f32, hipStream_t st);
 template void ss_launch_compact_xyz<float>(const float* d_xyz, uint32_t n, const uint32_t* f32, const uint32_t* offs, float* out, hipStream_t st);
 template void ss_launch_compact_xyz<double>(const double* d_xyz, uint32_t n, const uint32_t* f32, const uint32_t* offs, double* out, hipStream_t st);
-template void ss_launch_cell_keys<float>(const SSDevT<float>& P, const float* d_xyz, uint32_t* keys, uint32_t* vals, uint32_t* cell_count, hipStream_t st);
-template void ss_launch_cell_keys<double>(const SSDevT<double>& P, const double* d_xyz, uint32_t* keys, uint32_t* vals, uint32_t* cell_count, hipStream_t st);
+template void ss_launch_cell_keys<float>(const SSDevT<float>& P, const float* d_xyz, uint32_t* keys, uint32_t* vals, hipStream_t st);
+template void ss_launch_cell_keys<double>(const SSDevT<double>& P, const double* d_xyz, uint32_t* keys, uint32_t* vals, hipStream_t st);
 template void ss_launch_gather_sorted<float>(uint32_t n, const float* d_xyz, const uint32_t* perm, ss_real4<float>* pos_sorted, hipStream_t st);
 template void ss_launch_gather_sorted<double>(uint32_t n, const double* d_xyz, const uint32_t* perm, ss_real4<double>* pos_sorted, hipStream_t st);
 template void ss_launch_classify_count<float>(const SSDevT<float>& P, const float* xyz, uint32_t* member_count, uint32_t* sub_flag, hipStream_t st);
 template void ss_launch_classify_count<double>(const SSDevT<double>& P, const double* xyz, uint32_t* member_count, uint32_t* sub_flag, hipStream_t st);
-template void ss_launch_emit_copies<float>(const SSDevT<float>& P, const float* xyz, const uint32_t* copy_offset, const uint32_t* occ_rank, uint32_t* keys, uint32_t* vals, uint32_t* cell_count, hipStream_t st);
-template void ss_launch_emit_copies<double>(const SSDevT<double>& P, const double* xyz, const uint32_t* copy_offset, const uint32_t* occ_rank, uint32_t* keys, uint32_t* vals, uint32_t* cell_count, hipStream_t st);
+template void ss_launch_emit_copies<float>(const SSDevT<float>& P, const float* xyz, const uint32_t* copy_offset, const uint32_t* occ_rank, uint32_t* keys, uint32_t* vals, hipStream_t st);
+template void ss_launch_emit_copies<double>(const SSDevT<double>& P, const double* xyz, const uint32_t* copy_offset, const uint32_t* occ_rank, uint32_t* keys, uint32_t* vals, hipStream_t st);
 template void ss_launch_owned_copy_flags<float>(const SSDevT<float>& P, uint32_t n_copies, const ss_real4<float>* cpos, const uint32_t* ckey, const uint32_t* occ_sub, uint32_t* owned, hipStream_t st);
 template void ss_launch_owned_copy_flags<double>(const SSDevT<double>& P, uint32_t n_copies, const ss_real4<double>* cpos, const uint32_t* ckey, const uint32_t* occ_sub, uint32_t* owned, hipStream_t st);
 template void ss_launch_density_sub<float>(const SSDevT<float>& P, uint32_t n_copies, const ss_real4<float>* cpos, const uint32_t* cidx, const uint32_t* ckey, const uint32_t* cell_start, const uint32_t* occ_sub, float* rho, int mode, uint32_t* nb_count, const unsigned long long* nb_ptr, uint32_t* nb_idx, bool fast_div, const uint32_t* owned_list, const uint32_t* n_owned_dev, uint32_t n_owned_bound, hipStream_t st);
