@@ -94,6 +94,7 @@ struct ss_context {
     DevBuf gboxes;  // global strategy: stencil boxes per particle chunk
     DevBuf splat_overflow;  // flags / ranks / list of level-set blocks whose tile is ordered by the workgroup-level gather
     DevBuf splat_trunc;  // per active block: truncated flag, needed-by-MC flag, its scan and the list of blocks to complete
+    DevBuf mc_nb;  // per MC block: slots and certified masks of its eight level-set blocks
     DevBuf splat_tile_idx;  // particle index of every arena entry (tiles the wave-per-block kernel orders itself)
     DevBuf splat_tiles, splat_counts, splat_off, splat_bound;  // tile arena (index-ordered candidates of every block), per-block counts, 64-bit offsets, size bounds
     // post-processing: grow-only scratch slots handed out in call order (reset at the start of every ss_post_* call)

@@ -1854,25 +1854,41 @@ struct McTile {
     R g[9 * 9 * 9];
 };
 
+// The eight level-set blocks m + {0,1}^3 of every MC block, looked up once: mc_nb[16 m + n] = slot of neighbour n = (dx << 2) |
+// (dy << 1) | dz (0xFFFFFFFF: no such block), mc_nb[16 m + 8 + n] = mask of its 4^3 sub-blocks that the splat certified to lie
+// inside the surface and never evaluated in full.  The count and the emit kernel then reach the level-set values with two
+// dependent loads (record, value) instead of four (block coordinates, slot, mask, value) -- they are latency-bound.
 template <class R>
-__device__ inline void mc_load_tile(McTile<R>& t, const SSDevT<R>& P, const R* __restrict__ G, const uint32_t* __restrict__ block_slot,
-                                    const uint32_t* __restrict__ certified, int bx, int by, int bz, int tid) {
-    // certified (may be null): per level-set block, the mask of its 4^3 sub-blocks that the splat certified to lie inside the
-    // surface and never evaluated in full; their points read as "a value above the threshold" (they are no end point of an edge
-    // that crosses the surface, k_select_redo, so the value itself is never used)
+__global__ __launch_bounds__(256) void k_mc_neighbours(SSDevT<R> P, const uint32_t* __restrict__ mc_xyz, uint32_t n_mc, const uint32_t* __restrict__ block_slot,
+                                                       const uint32_t* __restrict__ certified, uint32_t* __restrict__ mc_nb) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t m = t >> 3, n = t & 7u;
+    if (m >= n_mc) return;
+    const int x = (int)mc_xyz[3 * (size_t)m] + (int)((n >> 2) & 1u), y = (int)mc_xyz[3 * (size_t)m + 1] + (int)((n >> 1) & 1u), z = (int)mc_xyz[3 * (size_t)m + 2] + (int)(n & 1u);
+    uint32_t slot = 0xFFFFFFFFu, cert = 0u;
+    if (x < P.nb[0] && y < P.nb[1] && z < P.nb[2]) {
+        slot = block_slot[((size_t)x * P.nb[1] + y) * P.nb[2] + z];
+        if (slot != 0xFFFFFFFFu && certified) cert = certified[slot];
+    }
+    mc_nb[16 * (size_t)m + n] = slot;
+    mc_nb[16 * (size_t)m + 8 + n] = cert;
+}
+
+// s_nb: the block's record of mc_nb in LDS.  Points of a certified sub-block read as "a value above the threshold" (they are no
+// end point of an edge that crosses the surface, k_select_redo, so the value itself is never used); absent blocks are all zero.
+template <class R>
+__device__ inline void mc_load_tile(McTile<R>& t, const SSDevT<R>& P, const R* __restrict__ G, const uint32_t* s_nb, int tid) {
     for (int e = tid; e < 729; e += 512) {
         const int x = e / 81, y = (e / 9) % 9, z = e % 9;
-        const int nbx = bx + (x >> 3), nby = by + (y >> 3), nbz = bz + (z >> 3);
+        const int n = ((x >> 3) << 2) | ((y >> 3) << 1) | (z >> 3);
+        const uint32_t slot = s_nb[n];
         R v = R(0.0);
-        if (nbx < P.nb[0] && nby < P.nb[1] && nbz < P.nb[2]) {
-            const uint32_t slot = block_slot[((size_t)nbx * P.nb[1] + nby) * P.nb[2] + nbz];
-            if (slot != 0xFFFFFFFFu) {
-                const int sbit = (((x & 7) >> 2) << 2) | (((y & 7) >> 2) << 1) | ((z & 7) >> 2);
-                if (certified && ((certified[slot] >> sbit) & 1u))
-                    v = P.thr_inside;
-                else
-                    v = G[(size_t)slot * SS_BLOCK_POINTS + (size_t)((((x & 7) * 8) + (y & 7)) * 8 + (z & 7))];
-            }
+        if (slot != 0xFFFFFFFFu) {
+            const int sbit = (((x & 7) >> 2) << 2) | (((y & 7) >> 2) << 1) | ((z & 7) >> 2);
+            if ((s_nb[8 + n] >> sbit) & 1u)
+                v = P.thr_inside;
+            else
+                v = G[(size_t)slot * SS_BLOCK_POINTS + (size_t)((((x & 7) * 8) + (y & 7)) * 8 + (z & 7))];
         }
         t.g[e] = v;
     }
@@ -1917,16 +1933,19 @@ __device__ inline McLocal mc_classify(const McTile<R>& t, const SSDevT<R>& P, in
 }
 
 template <class R>
-__global__ __launch_bounds__(512) void k_mc_count(SSDevT<R> P, const R* __restrict__ G, const uint32_t* __restrict__ block_slot, const uint32_t* __restrict__ certified,
+__global__ __launch_bounds__(512) void k_mc_count(SSDevT<R> P, const R* __restrict__ G, const uint32_t* __restrict__ mc_nb,
                                                   const uint32_t* __restrict__ mc_xyz, uint32_t n_mc, unsigned long long* __restrict__ masks,
                                                   uint32_t* __restrict__ vcount, uint32_t* __restrict__ tcount) {
     __shared__ McTile<R> tile;
+    __shared__ uint32_t s_nb[16];
     __shared__ uint32_t s_v[8], s_t[8];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t m = blockIdx.x;
     if (m >= n_mc) return;
     const int bx = (int)mc_xyz[3 * (size_t)m], by = (int)mc_xyz[3 * (size_t)m + 1], bz = (int)mc_xyz[3 * (size_t)m + 2];  // k_block_coords
-    mc_load_tile(tile, P, G, block_slot, certified, bx, by, bz, tid);
+    if (tid < 16) s_nb[tid] = mc_nb[16 * (size_t)m + tid];
+    __syncthreads();
+    mc_load_tile(tile, P, G, s_nb, tid);
     __syncthreads();
     const McLocal L = mc_classify(tile, P, bx, by, bz, tid);
     uint32_t nv = 0;
@@ -1957,12 +1976,13 @@ __global__ __launch_bounds__(512) void k_mc_count(SSDevT<R> P, const R* __restri
 }
 
 template <class R>
-__global__ __launch_bounds__(512) void k_mc_emit(SSDevT<R> P, const R* __restrict__ G, const uint32_t* __restrict__ block_slot, const uint32_t* __restrict__ certified,
+__global__ __launch_bounds__(512) void k_mc_emit(SSDevT<R> P, const R* __restrict__ G, const uint32_t* __restrict__ mc_nb,
                                                  const uint32_t* __restrict__ mc_xyz, const uint32_t* __restrict__ mc_slot, uint32_t n_mc,
                                                  const unsigned long long* __restrict__ masks, const uint32_t* __restrict__ vbase,
                                                  const uint32_t* __restrict__ tbase, R* __restrict__ vertices,
                                                  unsigned long long* __restrict__ vkeys, uint32_t* __restrict__ triangles) {
     __shared__ McTile<R> tile;
+    __shared__ uint32_t s_nb[16];
     __shared__ unsigned long long s_mask[8][24];  // [neighbour][axis*8+word]
     __shared__ uint32_t s_pref[8][24];            // vertices of that neighbour block before (axis, word)
     __shared__ uint32_t s_vbase[8];
@@ -1972,7 +1992,9 @@ __global__ __launch_bounds__(512) void k_mc_emit(SSDevT<R> P, const R* __restric
     if (m >= n_mc) return;
     if (vbase[m + 1] == vbase[m] && tbase[m + 1] == tbase[m]) return;  // nothing to emit for this block
     const int bx = (int)mc_xyz[3 * (size_t)m], by = (int)mc_xyz[3 * (size_t)m + 1], bz = (int)mc_xyz[3 * (size_t)m + 2];  // k_block_coords
-    mc_load_tile(tile, P, G, block_slot, certified, bx, by, bz, tid);
+    if (tid < 16) s_nb[tid] = mc_nb[16 * (size_t)m + tid];
+    __syncthreads();
+    mc_load_tile(tile, P, G, s_nb, tid);
     // crossing masks of this block and its 7 upper neighbours
     if (tid < 8 * 24) {
         const int nb = tid / 24, w = tid % 24;
@@ -2064,17 +2086,22 @@ __global__ __launch_bounds__(512) void k_mc_emit(SSDevT<R> P, const R* __restric
 }
 
 template <class R>
-void ss_launch_mc_count(const SSDevT<R>& P, const R* G, const uint32_t* block_slot, const uint32_t* certified, const uint32_t* mc_xyz, uint32_t n_mc,
-                        unsigned long long* masks, uint32_t* vcount, uint32_t* tcount, hipStream_t st) {
+void ss_launch_mc_neighbours(const SSDevT<R>& P, const uint32_t* mc_xyz, uint32_t n_mc, const uint32_t* block_slot, const uint32_t* certified, uint32_t* mc_nb, hipStream_t st) {
     if (!n_mc) return;
-    hipLaunchKernelGGL(k_mc_count<R>, dim3(n_mc), dim3(512), 0, st, P, G, block_slot, certified, mc_xyz, n_mc, masks, vcount, tcount);
+    hipLaunchKernelGGL(k_mc_neighbours<R>, dim3((n_mc * 8u + 255u) / 256u), dim3(256), 0, st, P, mc_xyz, n_mc, block_slot, certified, mc_nb);
 }
 template <class R>
-void ss_launch_mc_emit(const SSDevT<R>& P, const R* G, const uint32_t* block_slot, const uint32_t* certified, const uint32_t* mc_xyz, const uint32_t* mc_slot,
+void ss_launch_mc_count(const SSDevT<R>& P, const R* G, const uint32_t* mc_nb, const uint32_t* mc_xyz, uint32_t n_mc,
+                        unsigned long long* masks, uint32_t* vcount, uint32_t* tcount, hipStream_t st) {
+    if (!n_mc) return;
+    hipLaunchKernelGGL(k_mc_count<R>, dim3(n_mc), dim3(512), 0, st, P, G, mc_nb, mc_xyz, n_mc, masks, vcount, tcount);
+}
+template <class R>
+void ss_launch_mc_emit(const SSDevT<R>& P, const R* G, const uint32_t* mc_nb, const uint32_t* mc_xyz, const uint32_t* mc_slot,
                        uint32_t n_mc, const unsigned long long* masks, const uint32_t* vbase, const uint32_t* tbase, R* vertices,
                        unsigned long long* vkeys, uint32_t* triangles, hipStream_t st) {
     if (!n_mc) return;
-    hipLaunchKernelGGL(k_mc_emit<R>, dim3(n_mc), dim3(512), 0, st, P, G, block_slot, certified, mc_xyz, mc_slot, n_mc, masks, vbase, tbase, vertices, vkeys,
+    hipLaunchKernelGGL(k_mc_emit<R>, dim3(n_mc), dim3(512), 0, st, P, G, mc_nb, mc_xyz, mc_slot, n_mc, masks, vbase, tbase, vertices, vkeys,
                        triangles);
 }
 
@@ -2151,9 +2178,11 @@ template void ss_launch_splat_accumulate<float>(const SSDevT<float>& P, const ss
 template void ss_launch_select_redo<float>(const SSDevT<float>& P, const uint32_t* active_xyz, uint32_t n_active, const uint32_t* block_slot, const uint32_t* trunc, const unsigned long long* facebits, uint32_t* redo_mask, hipStream_t st);
 template void ss_launch_splat_accumulate<double>(const SSDevT<double>& P, const ss_real4<double>* arena, const uint32_t* arena_idx, const unsigned long long* tile_off, const uint32_t* counts, const uint32_t* active_xyz, uint32_t n_active, double* G, ss_real2<double>* blk_minmax, uint32_t* trunc, bool full_levelset, const uint32_t* list, const uint32_t* n_list_dev, const uint32_t* redo_mask, unsigned long long* facebits, uint32_t* big, hipStream_t st);
 template void ss_launch_select_redo<double>(const SSDevT<double>& P, const uint32_t* active_xyz, uint32_t n_active, const uint32_t* block_slot, const uint32_t* trunc, const unsigned long long* facebits, uint32_t* redo_mask, hipStream_t st);
-template void ss_launch_mc_count<float>(const SSDevT<float>& P, const float* G, const uint32_t* block_slot, const uint32_t* certified, const uint32_t* mc_xyz, uint32_t n_mc, unsigned long long* masks, uint32_t* vcount, uint32_t* tcount, hipStream_t st);
-template void ss_launch_mc_count<double>(const SSDevT<double>& P, const double* G, const uint32_t* block_slot, const uint32_t* certified, const uint32_t* mc_xyz, uint32_t n_mc, unsigned long long* masks, uint32_t* vcount, uint32_t* tcount, hipStream_t st);
-template void ss_launch_mc_emit<float>(const SSDevT<float>& P, const float* G, const uint32_t* block_slot, const uint32_t* certified, const uint32_t* mc_xyz, const uint32_t* mc_slot, uint32_t n_mc, const unsigned long long* masks, const uint32_t* vbase, const uint32_t* tbase, float* vertices, unsigned long long* vkeys, uint32_t* triangles, hipStream_t st);
-template void ss_launch_mc_emit<double>(const SSDevT<double>& P, const double* G, const uint32_t* block_slot, const uint32_t* certified, const uint32_t* mc_xyz, const uint32_t* mc_slot, uint32_t n_mc, const unsigned long long* masks, const uint32_t* vbase, const uint32_t* tbase, double* vertices, unsigned long long* vkeys, uint32_t* triangles, hipStream_t st);
+template void ss_launch_mc_neighbours<float>(const SSDevT<float>& P, const uint32_t* mc_xyz, uint32_t n_mc, const uint32_t* block_slot, const uint32_t* certified, uint32_t* mc_nb, hipStream_t st);
+template void ss_launch_mc_count<float>(const SSDevT<float>& P, const float* G, const uint32_t* mc_nb, const uint32_t* mc_xyz, uint32_t n_mc, unsigned long long* masks, uint32_t* vcount, uint32_t* tcount, hipStream_t st);
+template void ss_launch_mc_neighbours<double>(const SSDevT<double>& P, const uint32_t* mc_xyz, uint32_t n_mc, const uint32_t* block_slot, const uint32_t* certified, uint32_t* mc_nb, hipStream_t st);
+template void ss_launch_mc_count<double>(const SSDevT<double>& P, const double* G, const uint32_t* mc_nb, const uint32_t* mc_xyz, uint32_t n_mc, unsigned long long* masks, uint32_t* vcount, uint32_t* tcount, hipStream_t st);
+template void ss_launch_mc_emit<float>(const SSDevT<float>& P, const float* G, const uint32_t* mc_nb, const uint32_t* mc_xyz, const uint32_t* mc_slot, uint32_t n_mc, const unsigned long long* masks, const uint32_t* vbase, const uint32_t* tbase, float* vertices, unsigned long long* vkeys, uint32_t* triangles, hipStream_t st);
+template void ss_launch_mc_emit<double>(const SSDevT<double>& P, const double* G, const uint32_t* mc_nb, const uint32_t* mc_xyz, const uint32_t* mc_slot, uint32_t n_mc, const unsigned long long* masks, const uint32_t* vbase, const uint32_t* tbase, double* vertices, unsigned long long* vkeys, uint32_t* triangles, hipStream_t st);
 template void ss_launch_levelset_box<float>(const SSDevT<float>& P, const float* G, const uint32_t* block_slot, const int lo[3], const int ext[3], float* out, hipStream_t st);
 template void ss_launch_levelset_box<double>(const SSDevT<double>& P, const double* G, const uint32_t* block_slot, const int lo[3], const int ext[3], double* out, hipStream_t st);
