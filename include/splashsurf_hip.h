@@ -151,7 +151,7 @@ typedef struct ss_stats {
     uint64_t levelset_kernel_launches;
     uint64_t bytes_device_peak;       /* HBM held by the context after this call */
     double ms_levelset_gather;        /* part of ms_levelset: k_splat_count + offsets + k_splat_gather[_large] (index-ordered candidate tiles) */
-    double ms_levelset_accumulate;    /* part of ms_levelset: k_splat_accumulate (the arithmetic; the dominant kernel), both passes */
+    double ms_levelset_accumulate;    /* part of ms_levelset: k_splat_accumulate_w / _list (the arithmetic; the dominant kernel), both passes */
     uint64_t n_large_tile_blocks;     /* blocks whose candidate tile (> 384 entries) was ordered by the workgroup-level gather */
     uint64_t arith_mode;              /* arithmetic of the level-set accumulation that ran: 0 scalar (generic sqrt/divide), 1 scalar
                                        * (lean exact sqrt + verified reciprocal division), 2 / 3 SIMD with correctly rounded sqrt
@@ -161,7 +161,7 @@ typedef struct ss_stats {
     uint64_t n_certified_subblocks;   /* 4x4x4 sub-blocks the classification pass of the splat certified to lie inside the fluid */
     uint64_t n_truncated_blocks;      /* active blocks left with truncated (lower-bound) level-set values: inside the fluid, never read by MC */
     uint64_t n_completed_blocks;      /* truncated blocks next to the surface that the second splat pass evaluated in full */
-    double ms_levelset_accumulate_pass2; /* part of ms_levelset_accumulate: block selection + k_splat_accumulate_list (the second pass) */
+    double ms_levelset_accumulate_pass2; /* part of ms_levelset_accumulate: k_select_redo + the second launch of k_splat_accumulate_w */
 } ss_stats;
 
 typedef struct ss_context ss_context;
@@ -175,10 +175,11 @@ const char *ss_last_error(const ss_context *ctx);
 int ss_last_error_detail(const ss_context *ctx);
 /* Context options.  SS_OPTION_FULL_LEVELSET (default 0): 1 = evaluate the level set completely at every grid point of every
  * active block.  By default the splat first certifies 4x4x4 sub-blocks that lie inside the fluid with a lower bound of the level
- * set (the sum over the nearby particles only; all terms are >= 0) and evaluates in full what is not certified plus the certified
- * sub-blocks that marching cubes reads -- those next to a sign change: mesh, densities and every level-set value that influences
- * them are unchanged, values deep inside the fluid are lower bounds.  Set it before ss_result_levelset_box is used to inspect
- * values away from the surface.
+ * set (a sum over the nearby particles only; all terms are >= 0) and evaluates in full what is not certified plus the certified
+ * sub-blocks with a point next to a grid point outside the surface -- the end points of the edges marching cubes interpolates on:
+ * mesh, densities and every level-set value that influences them are unchanged; the values of the other certified sub-blocks are
+ * never computed or stored (ss_result_levelset_box reports an error while such blocks exist).  Set it before
+ * ss_result_levelset_box is used to inspect values away from the surface.
  * SS_OPTION_SPLAT_TWO_PASS (default -1): -1 = the library decides per workload whether the certification scheme above pays off
  * (jobs below 16 k active blocks and workloads whose previous call certified < 30 % of the sub-blocks evaluate everything), 0 = never,
  * 1 = always (tests).  Output is identical in every setting. */

@@ -54,11 +54,11 @@ def main():
                 v.get("SQ_WAVES", 0), v.get("SQ_INSTS_VALU", 0) / slots if slots else 0.0))
             if k.startswith("k_splat_accumulate"):
                 t = traffic["s10m_tank"].setdefault(mname, {
-                    "kernel": "k_splat_accumulate (both launches: first pass + k_splat_accumulate_list)", "hbm_bytes_per_launch": 0.0, "fetch_size_bytes_reported": 0.0,
+                    "kernel": "k_splat_accumulate_w (first and second pass) + k_splat_accumulate_list (tiles over 192 entries)", "hbm_bytes_per_launch": 0.0, "fetch_size_bytes_reported": 0.0,
                     "write_size_bytes": 0.0, "kernel_ms_rocprof_avg": 0.0, "valu_insts_per_launch": 0.0, "launches": {},
                     "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, --kernel-include-regex 'k_splat|k_density_sub') on S10M-tank, per step = sum over the "
-                            "two launches of the accumulate kernel; read side doubled per MI355X_MICROARCH.md (gfx950 FETCH_SIZE counts 128-B requests as 64 B); the "
-                            "accumulate kernel re-reads the index-ordered block tiles the gather kernel wrote (DESIGN.md section 5, profiles/r02_pmc_s10m_tank.md)",
+                            "launches of the accumulate kernel; read side doubled per MI355X_MICROARCH.md (gfx950 FETCH_SIZE counts 128-B requests as 64 B); the "
+                            "accumulate kernel re-reads the block tiles the gather kernel wrote (DESIGN.md section 5, profiles/r02_pmc_s10m_tank.md)",
                     "valu_note": "SQ_INSTS_VALU of both launches per step (profiles/r02_pmc_s10m_tank.md); a SIMD-32 issues one wave64 VALU instruction per 2 cycles at best"})
                 t["hbm_bytes_per_launch"] += hbm
                 t["fetch_size_bytes_reported"] += v.get("FETCH_SIZE", 0.0) * 1024
