@@ -15,6 +15,10 @@
 
 #define SS_BLOCK 8              // level-set block edge in grid points (8^3 = 512 points)
 #define SS_BLOCK_POINTS 512
+// Position of point (x, y, z), 0 <= x, y, z < 8, inside a level-set block: the eight 4x4x4 sub-blocks one after the other (sub-block
+// (sx, sy, sz) -> index (sx << 2) | (sy << 1) | sz), the 64 points of a sub-block in (x, y, z) order -- a wave stores its sub-block
+// as one 256-byte run.
+#define SS_BLOCK_OFFSET(x, y, z) ((((((x) >> 2) << 2) | (((y) >> 2) << 1) | ((z) >> 2)) << 6) | (((x) & 3) << 4) | (((y) & 3) << 2) | ((z) & 3))
 #define SS_MAX_ROWS 256         // (x,y) search-cell rows per batch while gathering a tile
 #define SS_WTILE 384            // tile entries one wave orders in LDS (k_splat_gather) = chunk of the accumulate kernel
 

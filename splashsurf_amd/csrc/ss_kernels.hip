@@ -1413,11 +1413,11 @@ __device__ __forceinline__ void splat_accumulate_block(SplatAccShared<R>& sh, co
         }
     }
     if (EARLY && done && wave_valid && lane == 0) atomicOr(&sh.trunc, 1u << wave);  // bit mask of the certified sub-blocks of this block
-    // store: block-local layout (x*8+y)*8+z, i-major / k-fastest like dense_subdomains.rs:839
+    // store: block-local layout SS_BLOCK_OFFSET (sub-block after sub-block); the value of dense_subdomains.rs:839
     const int lx = ((wave >> 2) & 1) * 4 + ((lane >> 4) & 3);
     const int ly = ((wave >> 1) & 1) * 4 + ((lane >> 2) & 3);
     const int lz = (wave & 1) * 4 + (lane & 3);
-    R* gp = G + (size_t)logical * SS_BLOCK_POINTS + (size_t)((lx * 8 + ly) * 8 + lz);
+    R* gp = G + (size_t)logical * SS_BLOCK_POINTS + (size_t)SS_BLOCK_OFFSET(lx, ly, lz);
     R val;
     if (wave_selected) {
         if (EARLY && done && wave_valid) {
@@ -1560,7 +1560,7 @@ __device__ __forceinline__ void splat_accumulate_block_wave(SplatAccWaveShared<R
     const int by = __builtin_amdgcn_readfirstlane((int)active_xyz[3 * (size_t)logical + 1]);
     const int bz = __builtin_amdgcn_readfirstlane((int)active_xyz[3 * (size_t)logical + 2]);
     const int ox = (lane >> 4) & 3, oy = (lane >> 2) & 3, oz = lane & 3;
-    R* gblock = G + (size_t)logical * SS_BLOCK_POINTS + (size_t)((ox * 8 + oy) * 8 + oz);
+    R* gblock = G + (size_t)logical * SS_BLOCK_POINTS + (size_t)SS_BLOCK_OFFSET(ox, oy, oz);  // + 64 sb: SS_BLOCK_OFFSET
     ss_wave_lds_sync();  // the previous block's reads of pay are done
     // per axis and half of the block (h = 0, 1): the sub-block's box [lo, hi] and this lane's point coordinate -- global point
     // coordinates as in uniform_grid.rs:418-425 on the GLOBAL grid (dense_subdomains.rs:817-826); the SIMD loop of the reference
@@ -1603,7 +1603,7 @@ __device__ __forceinline__ void splat_accumulate_block_wave(SplatAccWaveShared<R
     for (int sb = 0; sb < 8; ++sb) {
         const int sx = (sb >> 2) & 1, sy = (sb >> 1) & 1, sz = sb & 1;
         const bool point_valid = (sx ? pt_ok[0][1] : pt_ok[0][0]) && (sy ? pt_ok[1][1] : pt_ok[1][0]) && (sz ? pt_ok[2][1] : pt_ok[2][0]);
-        R* gp = gblock + (size_t)((sx * 4 * 8 + sy * 4) * 8 + sz * 4);  // block-local layout (x*8+y)*8+z, dense_subdomains.rs:839
+        R* gp = gblock + 64 * sb;
         R val;
         if (!((wave_mask >> sb) & 1u)) {
             // second pass: a sub-block that is not re-evaluated keeps its value (it still enters the block's min / max)
@@ -1647,7 +1647,7 @@ __device__ __forceinline__ void splat_accumulate_block_wave(SplatAccWaveShared<R
             // levelset_grid.fill(0), dense_subdomains.rs:1390, then the sum in index order
             const R acc = splat_accumulate_wave<R, ARITH>(P, sh.pay, sh.wl, n_tile, lane, px, py, pz, slo, shi, P.R2, R(0.0));
             const R val = point_valid ? acc : R(0.0);
-            gblock[(size_t)((sx * 4 * 8 + sy * 4) * 8 + sz * 4)] = val;
+            gblock[64 * sb] = val;
             mn = ss_min(mn, val);
             mx = ss_max(mx, val);
             if constexpr (EARLY) faces |= (unsigned long long)splat_face_bits(__ballot(point_valid && !(val > P.threshold))) << (6 * sb);
@@ -1888,7 +1888,7 @@ __device__ inline void mc_load_tile(McTile<R>& t, const SSDevT<R>& P, const R* _
             if ((s_nb[8 + n] >> sbit) & 1u)
                 v = P.thr_inside;
             else
-                v = G[(size_t)slot * SS_BLOCK_POINTS + (size_t)((((x & 7) * 8) + (y & 7)) * 8 + (z & 7))];
+                v = G[(size_t)slot * SS_BLOCK_POINTS + (size_t)SS_BLOCK_OFFSET(x & 7, y & 7, z & 7)];
         }
         t.g[e] = v;
     }
@@ -2128,7 +2128,7 @@ __global__ __launch_bounds__(256) void k_levelset_box(SSDevT<R> P, const R* __re
     R v = R(0.0);
     if (gx >= 0 && gy >= 0 && gz >= 0 && gx < P.np[0] && gy < P.np[1] && gz < P.np[2]) {
         uint32_t slot = block_slot[((size_t)(gx >> 3) * P.nb[1] + (gy >> 3)) * P.nb[2] + (gz >> 3)];
-        if (slot != 0xFFFFFFFFu) v = G[(size_t)slot * SS_BLOCK_POINTS + (size_t)((((gx & 7) * 8) + (gy & 7)) * 8 + (gz & 7))];
+        if (slot != 0xFFFFFFFFu) v = G[(size_t)slot * SS_BLOCK_POINTS + (size_t)SS_BLOCK_OFFSET(gx & 7, gy & 7, gz & 7)];
     }
     out[i] = v;
 }
