@@ -109,6 +109,8 @@ def _read_vtk(path, points_only=False):
     binary = ln.upper() == "BINARY"
     out = dict(points=None, cells=None, point_data={})
     n_points = 0
+    n_cells_total = 0  # tuples of the arrays of a CELL_DATA section
+    n_section = 0
     section = None
     while True:
         ln = r.line()
@@ -126,6 +128,7 @@ def _read_vtk(path, points_only=False):
                 return out
         elif key in ("CELLS", "POLYGONS", "VERTICES"):
             n_cells, size = int(tok[1]), int(tok[2])
+            n_cells_total += n_cells
             vals = r.values(size, "int", binary)
             if key != "VERTICES":
                 out["cells"] = (n_cells, vals)
@@ -133,8 +136,10 @@ def _read_vtk(path, points_only=False):
             r.values(int(tok[1]), "int", binary)
         elif key == "POINT_DATA":
             section = "point"
+            n_section = int(tok[1]) if len(tok) > 1 else n_points
         elif key == "CELL_DATA":
-            section = "cell"
+            section = "cell"  # arrays of a cell section hold one tuple per cell; they are read and discarded
+            n_section = int(tok[1]) if len(tok) > 1 else n_cells_total
         elif key == "SCALARS":
             name, ty = tok[1], tok[2]
             ncomp = int(tok[3]) if len(tok) > 3 else 1
@@ -142,11 +147,12 @@ def _read_vtk(path, points_only=False):
             nxt = r.line()
             if nxt is None or not nxt.upper().startswith("LOOKUP_TABLE"):
                 r.pos = save
-            vals = r.values(ncomp * n_points, ty, binary)
+            n_tuples = n_section if section else n_points
+            vals = r.values(ncomp * n_tuples, ty, binary)
             if section == "point":
                 out["point_data"][name] = vals.reshape(n_points, ncomp) if ncomp > 1 else vals
         elif key in ("VECTORS", "NORMALS"):
-            vals = r.values(3 * n_points, tok[2], binary)
+            vals = r.values(3 * (n_section if section else n_points), tok[2], binary)
             if section == "point":
                 out["point_data"][tok[1]] = vals.reshape(n_points, 3)
         elif key in ("METADATA", "INFORMATION", "FIELD", "OFFSETS", "CONNECTIVITY"):

@@ -164,3 +164,39 @@ def test_vtu_particle_files_of_the_reference():
     assert 520.0 < xa["density"].min() and xa["density"].max() < 1022.0  # RangeMin / RangeMax stated in the encoded file
     with pytest.raises(ValueError):
         IO.particle_attributes_from_file(os.path.join(d, "cube_8_particles.vtu"), ["temperature"])
+
+
+@pytest.mark.parametrize("binary", [False, True])
+def test_legacy_vtk_with_cell_attributes(tmp_path, binary):
+    """A legacy VTK mesh that carries CELL_DATA arrays (one tuple per cell, as ParaView writes them) between the geometry and the
+    point attributes: the cell arrays are skipped with the right length and the point attributes after them are still found."""
+    import struct
+    from splashsurf_amd import io as IO
+    pts = np.arange(12, dtype=np.float32).reshape(4, 3)
+    cells = [3, 0, 1, 2, 3, 1, 2, 3]
+    cell_scalar = [7.0, 9.0]
+    cell_vec = [1.0, 0.0, 0.0, 0.0, 1.0, 0.0]
+    point_scalar = [0.5, 1.5, 2.5, 3.5]
+    path = tmp_path / ("cells_%s.vtk" % ("bin" if binary else "ascii"))
+    with open(path, "wb") as f:
+        f.write(b"# vtk DataFile Version 4.2\ncell attributes\n" + (b"BINARY\n" if binary else b"ASCII\n") + b"DATASET UNSTRUCTURED_GRID\n")
+
+        def block(header, values, fmt):
+            f.write(header.encode() + b"\n")
+            if binary:
+                f.write(struct.pack(">%d%s" % (len(values), fmt), *values) + b"\n")
+            else:
+                f.write((" ".join(str(v) for v in values) + "\n").encode())
+        block("POINTS 4 float", [float(v) for v in pts.ravel()], "f")
+        block("CELLS 2 8", cells, "i")
+        block("CELL_TYPES 2", [5, 5], "i")
+        f.write(b"CELL_DATA 2\n")
+        block("SCALARS quality float 1\nLOOKUP_TABLE default", cell_scalar, "f")
+        block("VECTORS facing float", cell_vec, "f")
+        f.write(b"POINT_DATA 4\n")
+        block("SCALARS density float 1\nLOOKUP_TABLE default", point_scalar, "f")
+    d = IO._read_vtk(str(path))
+    assert np.array_equal(d["points"], pts)
+    assert d["cells"][0] == 2 and list(d["cells"][1]) == cells
+    assert list(d["point_data"]) == ["density"]
+    assert np.allclose(d["point_data"]["density"], point_scalar)
