@@ -272,6 +272,89 @@ class Context {  // replaces initialize_thread_pool (lib.rs:321-326) + the recon
     ss_result* res_ = nullptr;
 };
 
+// ---- multi-GPU: one ShardedReconstruction per process (or host thread) and GPU ------------------------------------------
+// The reference parallelises over subdomains inside one process (dense_subdomains.rs:1582-1598); across GPUs the library
+// cuts the subdomain grid into bricks and exchanges halo particles, halo densities and the ids of shared vertices itself
+// (ss_dist_*).  Every rank passes ITS share of the particles; the global particle order is the
+// concatenation by rank.  Collective: every rank calls step() with the same parameters.
+class ShardedReconstruction {
+  public:
+    using UniqueId = std::array<uint8_t, SS_COMM_ID_BYTES>;
+    // rank 0 creates the id and hands it to the other ranks out of band (MPI_Bcast, a file, a socket)
+    static UniqueId unique_id() {
+        UniqueId id{};
+        ss_status st = ss_comm_unique_id(id.data());
+        if (st != SS_OK) throw ReconstructionError(st, 0, "ss_comm_unique_id failed: RCCL could not be loaded");
+        return id;
+    }
+    ShardedReconstruction(int device_id, const UniqueId& id, int rank, int world) : ctx_(device_id) {
+        ss_status st = ss_result_create(ctx_.raw(), &res_);
+        if (st == SS_OK) st = ss_comm_create_rccl(ctx_.raw(), id.data(), rank, world, &comm_);
+        if (st != SS_OK) {
+            const ReconstructionError err(st, ss_last_error_detail(ctx_.raw()), ss_last_error(ctx_.raw()));
+            if (res_) ss_result_free(res_);
+            throw err;
+        }
+    }
+    ShardedReconstruction(const ShardedReconstruction&) = delete;
+    ShardedReconstruction& operator=(const ShardedReconstruction&) = delete;
+    ~ShardedReconstruction() {
+        if (comm_) ss_comm_destroy(comm_);
+        if (res_) ss_result_free(res_);
+    }
+
+    // Reconstruction of this rank's brick plus the global numbering of the mesh.  Returns the job's bookkeeping: brick, particle
+    // counts, this rank's vertex / triangle offsets in the global mesh, bytes sent.
+    template <class R>
+    ss_dist_info step(const std::vector<Vector3<R>>& local_particles, const ParametersT<R>& parameters) {
+        const typename Abi<R>::params p = parameters.to_c();
+        const R* xyz = local_particles.empty() ? nullptr : local_particles[0].data();
+        if constexpr (sizeof(R) == 4)
+            check(ss_dist_reconstruct_f32(comm_, xyz, local_particles.size(), &p, res_));
+        else
+            check(ss_dist_reconstruct_f64(comm_, xyz, local_particles.size(), &p, res_));
+        check(ss_dist_assemble(comm_, res_));
+        ss_dist_info info{};
+        check(ss_dist_get_info(comm_, &info));
+        return info;
+    }
+
+    // This rank's piece of the global mesh: the vertices it owns (global ids vertex_offset .. + n_vertices_owned) and its triangles
+    // with GLOBAL vertex ids; the mesh is the concatenation of the pieces over the ranks.
+    template <class R>
+    TriMesh3dT<R> mesh_piece() {
+        ss_dist_info info{};
+        check(ss_dist_get_info(comm_, &info));
+        TriMesh3dT<R> m;
+        m.vertices.resize(info.n_vertices_owned);
+        m.triangles.resize(info.n_triangles);
+        if (info.n_vertices_owned) check(ss_dist_copy_vertices(comm_, m.vertices[0].data()));
+        if (info.n_triangles) check(ss_dist_copy_triangles(comm_, m.triangles[0].data()));
+        return m;
+    }
+
+    // densities of the particles this rank holds (owned + ghosts) and their global ids (ascending)
+    template <class R>
+    void held_particles(std::vector<uint64_t>& global_ids, std::vector<R>& densities) {
+        ss_dist_info info{};
+        check(ss_dist_get_info(comm_, &info));
+        global_ids.resize(info.n_held);
+        if (info.n_held) check(ss_dist_copy_global_ids(comm_, global_ids.data()));
+        const R* rho = nullptr;
+        uint64_t n = 0;
+        check(Abi<R>::densities(res_, &rho, &n));
+        densities.assign(rho, rho + n);
+    }
+
+  private:
+    void check(ss_status st) {
+        if (st != SS_OK) throw ReconstructionError(st, ss_last_error_detail(ctx_.raw()), ss_last_error(ctx_.raw()));
+    }
+    Context ctx_;
+    ss_result* res_ = nullptr;
+    ss_comm* comm_ = nullptr;
+};
+
 // ---- splashsurf_lib::postprocessing (host stages) ----------------------------------------------------------------------
 namespace postprocessing {
 

@@ -97,6 +97,29 @@ int main() {
         UniformGridT<double> g = ctx.grid_for_reconstruction(particles, p);
         CHECK(g.cells_per_dim[0] == 5);
     }
+    // --- the sharded path over a one-rank RCCL communicator: same mesh as the single-context call ---
+    {
+        std::vector<Vector3f> particles;
+        for (int i = 0; i < 6; ++i)
+            for (int j = 0; j < 6; ++j)
+                for (int k = 0; k < 6; ++k) particles.push_back({0.05f * i, 0.05f * j, 0.05f * k});
+        Parameters p = Parameters::relative(0.025f, 2.0f, 0.75f);
+        p.spatial_decomposition.grid.auto_disable = false;
+        p.spatial_decomposition.grid.subdomain_num_cubes_per_dim = 16;
+        SurfaceReconstruction direct = ctx.reconstruct_surface(particles, p);
+        ShardedReconstruction sharded(0, ShardedReconstruction::unique_id(), 0, 1);
+        const ss_dist_info info = sharded.step<float>(particles, p);
+        CHECK(info.world == 1 && info.n_total == particles.size() && info.n_owned == particles.size());
+        CHECK(info.n_vertices_total == direct.mesh.vertices.size() && info.n_triangles_total == direct.mesh.triangles.size());
+        TriMesh3d piece = sharded.mesh_piece<float>();
+        CHECK(piece.vertices.size() == direct.mesh.vertices.size() && piece.triangles.size() == direct.mesh.triangles.size());
+        CHECK(closed_manifold(piece));
+        std::vector<uint64_t> ids;
+        std::vector<float> rho;
+        sharded.held_particles<float>(ids, rho);
+        CHECK(ids.size() == particles.size() && rho.size() == particles.size() && ids.front() == 0 && ids.back() == particles.size() - 1);
+        for (size_t i = 0; i < rho.size(); ++i) CHECK(rho[i] == (*direct.particle_densities)[i]);
+    }
     // --- empty input is Ok with an empty mesh (SURVEY 8b edge behaviour) ---
     {
         Parameters p = Parameters::relative(0.025f, 4.0f, 1.0f);

@@ -51,3 +51,12 @@ def test_no_cpu_fallback_without_gpu():
     from splashsurf_amd.api import Context, SplashsurfError
     with pytest.raises(SplashsurfError):
         Context(0)
+
+
+def test_cpp_header_compiles():
+    """include/splashsurf_hip.hpp (the C++ mirror of the reference's Rust API, incl. the multi-GPU wrapper) and its test
+    program are valid C++17 for a plain host compiler."""
+    import subprocess
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    for src in ("test_host.cpp", "test_cleanup_host.cpp"):
+        subprocess.check_call(["g++", "-std=c++17", "-fsyntax-only", "-Wall", "-I" + os.path.join(root, "include"), os.path.join(root, "tests", "cpp", src)])
