@@ -746,7 +746,7 @@ ss_status phase_begin(ss_context* ctx, const R* xyz, uint64_t n_in, const typena
         SS_HIP(ctx, ctx->copy_offset.reserve(((size_t)n + 1) * 4));
         SS_HIP(ctx, ctx->sub_flag.reserve((nsub + 1) * 4));
         SS_HIP(ctx, ctx->sub_rank.reserve((nsub + 1) * 4));
-        SS_HIP(ctx, hipMemsetAsync(ctx->member_count.p, 0, ((size_t)n + 1) * 4, st));
+        SS_HIP(ctx, hipMemsetAsync(ctx->member_count.as<uint32_t>() + n, 0, 4, st));  // k_classify_count writes the entries of all particles
         SS_HIP(ctx, hipMemsetAsync(ctx->sub_flag.p, 0, (nsub + 1) * 4, st));
         SS_HIP(ctx, hipMemsetAsync(res->rho.p, 0, (size_t)n * sizeof(R) + 16, st));  // vec![R::zero(); n], dense_subdomains.rs:504
         ss_launch_classify_count(P, d_xyz, ctx->member_count.as<uint32_t>(), ctx->sub_flag.as<uint32_t>(), st);
@@ -863,7 +863,7 @@ ss_status phase_finish(ss_context* ctx, ss_result* res) {
     SS_HIP(ctx, res->block_slot.reserve(nblocks * 4));
     SS_HIP(ctx, res->mc_slot.reserve(nblocks * 4));
     SS_HIP(ctx, hipMemsetAsync(ctx->block_flag.p, 0, (nblocks + 1) * 4, st));
-    SS_HIP(ctx, hipMemsetAsync(ctx->mc_flag.p, 0, (nblocks + 1) * 4, st));
+    SS_HIP(ctx, hipMemsetAsync(ctx->mc_flag.as<uint32_t>() + nblocks, 0, 4, st));  // k_mark_mc_blocks writes the flags of all blocks
     if (n > 0) ss_launch_mark_blocks(P, ctx->cell_start.as<uint32_t>(), (uint32_t)ncells, ctx->block_flag.as<uint32_t>(), st);
     s = exclusive_scan_u32<uint32_t>(ctx, ctx->block_flag.as<uint32_t>(), ctx->block_rank.as<uint32_t>(), nblocks + 1);
     if (s != SS_OK) return s;
