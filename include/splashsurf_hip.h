@@ -181,7 +181,7 @@ int ss_last_error_detail(const ss_context *ctx);
  * never computed or stored (ss_result_levelset_box reports an error while such blocks exist).  Set it before
  * ss_result_levelset_box is used to inspect values away from the surface.
  * SS_OPTION_SPLAT_TWO_PASS (default -1): -1 = the library decides per workload whether the certification scheme above pays off
- * (jobs below 16 k active blocks and workloads whose previous call certified < 30 % of the sub-blocks evaluate everything), 0 = never,
+ * (jobs below 1 k active blocks and workloads whose previous call certified < 30 % of the sub-blocks evaluate everything), 0 = never,
  * 1 = always (tests).  Output is identical in every setting. */
 enum { SS_OPTION_FULL_LEVELSET = 1, SS_OPTION_SPLAT_TWO_PASS = 2 };
 ss_status ss_context_set_option(ss_context *ctx, int option, int value);

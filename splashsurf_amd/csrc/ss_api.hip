@@ -937,7 +937,7 @@ ss_status phase_finish(ss_context* ctx, ss_result* res) {
     }
     SS_HIP(ctx, hipEventRecord(ctx->ev[12], st));
     // first pass: every active block; sub-blocks that a cheap lower bound certifies to lie inside the fluid are not evaluated in full
-    // (ss_kernels.hip, splat_accumulate_block).  Small jobs skip the two-pass scheme: its extra launches cost more than it saves there.
+    // (ss_kernels.hip, splat_accumulate_block).  Tiny jobs (< 1 k active blocks) skip the two-pass scheme: its extra launches cost more than it saves there.
     // ... and so do workloads where the previous call certified too few sub-blocks to pay for the classification pass (break-even:
     // 35 % of the sub-blocks); such a workload is probed again every 16th call.
     uint64_t early_key = (uint64_t)n * 0x9E3779B97F4A7C15ull;
@@ -957,7 +957,7 @@ ss_status phase_finish(ss_context* ctx, ss_result* res) {
         probe = true;
         ctx->early_skipped = 0;
     }
-    const bool full_ls = ctx->full_levelset || !(prm_threshold > R(0.0)) || ctx->two_pass == 0 || (ctx->two_pass < 0 && (n_active < 16384u || !probe));
+    const bool full_ls = ctx->full_levelset || !(prm_threshold > R(0.0)) || ctx->two_pass == 0 || (ctx->two_pass < 0 && (n_active < 1024u || !probe));
     SS_HIP(ctx, ctx->splat_trunc.reserve(((size_t)n_active + 2) * (8 + 5 * 4) + 64));
     unsigned long long* face_bits = ctx->splat_trunc.as<unsigned long long>();  // per block: faces of its sub-blocks with points outside the surface
     uint32_t* tr_flag = (uint32_t*)(face_bits + ((size_t)n_active + 2));        // per block: mask of the certified sub-blocks

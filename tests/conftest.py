@@ -78,7 +78,7 @@ def full_levelset_ctx():
 @pytest.fixture(scope="session")
 def two_pass_ctx():
     """A context with SS_OPTION_SPLAT_TWO_PASS = 1: the splat certifies sub-blocks inside the fluid and completes only what
-    marching cubes reads, also on small jobs (the automatic setting reserves the scheme for >= 16 k active blocks)."""
+    marching cubes reads, also on small jobs (the automatic setting reserves the scheme for >= 1 k active blocks and switches it off per workload)."""
     import splashsurf_amd as S
     from splashsurf_amd.api import Context
     S.load_library()
