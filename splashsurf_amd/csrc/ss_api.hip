@@ -931,7 +931,7 @@ ss_status phase_finish(ss_context* ctx, ss_result* res) {
         ss_launch_compact_blocks(lg_flag, lg_rank, n_active, lg_list, lg_slot, st);
         ss_launch_splat_gather_large(PK, res->posvol.as<ss_real4<R>>(), res->posvol_by_index.as<ss_real4<R>>(), res->perm.as<uint32_t>(), ctx->cell_start.as<uint32_t>(),
                                      res->active_xyz.as<uint32_t>(), lg_list, lg_rank + n_active, ctx->splat_counts.as<uint32_t>(), ctx->splat_off.as<unsigned long long>(),
-                                     ctx->splat_tiles.as<ss_real4<R>>(), st);
+                                     ctx->splat_tiles.as<ss_real4<R>>(), ctx->splat_tile_idx.as<uint32_t>(), st);
         s = sum_u32_to_u64(ctx, ctx->splat_counts.as<uint32_t>(), n_active, ctx->counter.as<unsigned long long>());  // tile entries in use (statistics)
         if (s != SS_OK) return s;
     }

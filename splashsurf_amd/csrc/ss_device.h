@@ -34,6 +34,9 @@ enum : int { SS_ARITH_GENERIC = 0, SS_ARITH_FAST = 1, SS_ARITH_SIMD = 2, SS_ARIT
 
 // candidate particles (4-byte index keys) held in LDS per pass of the large-tile splat kernel
 template <class R> struct SSTileCap { static constexpr int value = 8192; };
+// Tiles of SS_WTILE < n <= SS_SORT_TILE_MAX entries are written by k_splat_gather_large in scan order with their particle indices;
+// k_splat_accumulate_list orders them in LDS, and only for the blocks that need an exact sum.
+#define SS_SORT_TILE_MAX 4096
 
 template <class R> struct SSVec;
 template <> struct SSVec<float> { using v2 = float2; using v4 = float4; };

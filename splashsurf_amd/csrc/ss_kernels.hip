@@ -1088,7 +1088,8 @@ __device__ inline void splat_for_each_candidate(S& s, const SSDevT<R>& P, const 
 template <class R, int CAP>
 __device__ __forceinline__ void splat_gather_large_block(SplatShared<R, CAP>& s, const SSDevT<R>& P, const ss_real4<R>* __restrict__ posvol,
                                                          const ss_real4<R>* __restrict__ posvol_by_index, const uint32_t* __restrict__ perm,
-                                                         const uint32_t* __restrict__ cell_start, const uint32_t* __restrict__ bxyz, uint32_t expect, ss_real4<R>* __restrict__ tile) {
+                                                         const uint32_t* __restrict__ cell_start, const uint32_t* __restrict__ bxyz, uint32_t expect, ss_real4<R>* __restrict__ tile,
+                                                         uint32_t* __restrict__ tile_idx) {
     const int tid = threadIdx.x;
     const int b3[3] = {(int)bxyz[0], (int)bxyz[1], (int)bxyz[2]};
     R plo[3], phi[3];
@@ -1131,6 +1132,16 @@ __device__ __forceinline__ void splat_gather_large_block(SplatShared<R, CAP>& s,
         });
         const int n_tile = (int)min(s.count, (uint32_t)CAP);
         if (n_tile == 0) break;  // cannot happen (the count pass saw `expect` candidates); never spin
+        if (expect <= (uint32_t)SS_SORT_TILE_MAX) {
+            // left in scan order with the particle indices: the accumulate kernel orders the tile itself if the block needs an exact
+            // sum (most blocks inside a body of fluid are certified by the order-independent lower bound)
+            for (int e = tid; e < n_tile; e += 512) {
+                const uint32_t id = s.idx[e];
+                tile[e] = posvol_by_index[id];
+                tile_idx[e] = id;
+            }
+            break;
+        }
         if (n_tile <= 512) {
             if (tid < n_tile) {
                 const uint32_t my_idx = s.idx[tid];
@@ -1173,7 +1184,8 @@ __global__ __launch_bounds__(512) void k_splat_gather_large(SSDevT<R> P, const s
                                                             const uint32_t* __restrict__ perm, const uint32_t* __restrict__ cell_start,
                                                             const uint32_t* __restrict__ active_xyz, const uint32_t* __restrict__ large_list,
                                                             const uint32_t* __restrict__ n_large_dev, const uint32_t* __restrict__ counts,
-                                                            const unsigned long long* __restrict__ tile_off, ss_real4<R>* __restrict__ arena) {
+                                                            const unsigned long long* __restrict__ tile_off, ss_real4<R>* __restrict__ arena,
+                                                            uint32_t* __restrict__ arena_idx) {
     __shared__ SplatShared<R, CAP> s;
     // the list lives on the device (the host never waits for its length; an empty list costs one trivial launch); persistent
     // workgroups walk it, every XCD a contiguous range of the spatially ordered list
@@ -1183,7 +1195,8 @@ __global__ __launch_bounds__(512) void k_splat_gather_large(SSDevT<R> P, const s
         const uint32_t it = xcd * per_xcd + j;
         if (it < n_large) {
             const uint32_t logical = large_list[it];
-            splat_gather_large_block<R, CAP>(s, P, posvol, posvol_by_index, perm, cell_start, active_xyz + 3 * (size_t)logical, counts[logical], arena + tile_off[logical]);
+            splat_gather_large_block<R, CAP>(s, P, posvol, posvol_by_index, perm, cell_start, active_xyz + 3 * (size_t)logical, counts[logical], arena + tile_off[logical],
+                                             arena_idx + tile_off[logical]);
         }
         __syncthreads();
     }
@@ -1338,17 +1351,51 @@ struct SplatAccShared {
     R red[16];
     uint32_t trunc;
     uint32_t face[8];
+    uint32_t skey[SS_SORT_TILE_MAX];  // particle indices of an unordered tile (sort keys) ...
+    uint16_t spos[SS_SORT_TILE_MAX];  // ... and the positions of its entries, ordered by index after splat_order_tile
 };
+
+// Orders an unordered tile (SS_WTILE < n <= SS_SORT_TILE_MAX entries, written by k_splat_gather_large in scan order): bitonic
+// network over (particle index, position) pairs in LDS, one workgroup barrier per stage; afterwards sh.spos[k] is the position in
+// the tile of the entry with the k-th smallest index.  All 512 threads.
+template <class R>
+__device__ inline void splat_order_tile(SplatAccShared<R>& sh, const uint32_t* __restrict__ tile_idx, int n_tile, int tid) {
+    int m = 512;
+    while (m < n_tile) m <<= 1;
+    for (int e = tid; e < m; e += 512) {
+        sh.skey[e] = e < n_tile ? tile_idx[e] : 0xFFFFFFFFu;
+        sh.spos[e] = (uint16_t)e;
+    }
+    __syncthreads();
+    for (int k = 2; k <= m; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int t = tid; t < (m >> 1); t += 512) {
+                const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+                const int l = i | j;
+                const bool up = (i & k) == 0;
+                const uint32_t a = sh.skey[i], c = sh.skey[l];
+                if ((a > c) == up) {
+                    sh.skey[i] = c;
+                    sh.skey[l] = a;
+                    const uint16_t pa = sh.spos[i];
+                    sh.spos[i] = sh.spos[l];
+                    sh.spos[l] = pa;
+                }
+            }
+            __syncthreads();
+        }
+}
 
 template <class R, int ARITH, bool EARLY>
 __device__ __forceinline__ void splat_accumulate_block(SplatAccShared<R>& sh, const SSDevT<R>& P, uint32_t logical, const ss_real4<R>* __restrict__ arena,
-                                                       const unsigned long long* __restrict__ tile_off, const uint32_t* __restrict__ counts,
+                                                       const uint32_t* __restrict__ arena_idx, const unsigned long long* __restrict__ tile_off, const uint32_t* __restrict__ counts,
                                                        const uint32_t* __restrict__ active_xyz, R* __restrict__ G, ss_real2<R>* __restrict__ blk_minmax,
                                                        uint32_t* __restrict__ trunc, unsigned long long* __restrict__ facebits, uint32_t wave_mask) {
     // wave_mask: the sub-blocks to evaluate (second pass: the certified ones marching cubes reads); the others keep their values
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n_tile = (int)counts[logical];
     const ss_real4<R>* tile = arena + tile_off[logical];
+    const bool unordered = n_tile > SS_WTILE && n_tile <= SS_SORT_TILE_MAX;  // k_splat_gather_large left this tile in scan order
     ss_real4<R> nxt = ss_make4(R(0.0), R(0.0), R(0.0), R(0.0));
     if (tid < min(n_tile, SS_WTILE)) nxt = tile[tid];  // first chunk in flight while the coordinates are set up
     if (tid == 0) sh.trunc = 0u;
@@ -1394,14 +1441,18 @@ __device__ __forceinline__ void splat_accumulate_block(SplatAccShared<R>& sh, co
             // (a single chunk stays in LDS: its waves go on independently, no workgroup barrier between the passes)
             if (n_chunks > 1 && !__syncthreads_or(done ? 0 : 1)) break;  // every sub-block of this block is certified: no second stream
             if (!done) acc = R(0.0);
-            if (n_chunks > 1 && tid < SS_WTILE) nxt = tile[tid];  // over-dense block: the tile is streamed a second time
         }
+        const bool by_position = pass == 1 && unordered;  // the exact sum walks an unordered tile through its sorted positions
+        if (by_position) splat_order_tile<R>(sh, arena_idx + tile_off[logical], n_tile, tid);
+        if (pass == 1 && (by_position || (EARLY && n_chunks > 1)) && tid < min(n_tile, SS_WTILE))
+            nxt = by_position ? tile[sh.spos[tid]] : tile[tid];  // the tile is streamed (again)
         for (int c0 = 0; c0 < n_tile; c0 += SS_WTILE) {
             const int nc = min(SS_WTILE, n_tile - c0);
             if (n_chunks > 1 || pass == (EARLY ? 0 : 1)) {  // a single chunk stays in LDS between the passes
                 if (tid < nc) sh.pay[tid] = nxt;
                 __syncthreads();
-                if (c0 + SS_WTILE + tid < n_tile && tid < SS_WTILE) nxt = tile[c0 + SS_WTILE + tid];  // next chunk in flight during the arithmetic
+                if (c0 + SS_WTILE + tid < n_tile && tid < SS_WTILE)  // next chunk in flight during the arithmetic
+                    nxt = by_position ? tile[sh.spos[c0 + SS_WTILE + tid]] : tile[c0 + SS_WTILE + tid];
             }
             if (wave_valid && !done) {
                 if (pass == 0)
@@ -1706,7 +1757,8 @@ __global__ __launch_bounds__(64) void k_splat_accumulate_w(SSDevT<R> P, const ss
 
 // the blocks with larger tiles (over-dense input), one workgroup per block; list and its length on the device
 template <class R, int ARITH, bool EARLY>
-__global__ __launch_bounds__(512) void k_splat_accumulate_list(SSDevT<R> P, const ss_real4<R>* __restrict__ arena, const unsigned long long* __restrict__ tile_off,
+__global__ __launch_bounds__(512) void k_splat_accumulate_list(SSDevT<R> P, const ss_real4<R>* __restrict__ arena, const uint32_t* __restrict__ arena_idx,
+                                                               const unsigned long long* __restrict__ tile_off,
                                                                const uint32_t* __restrict__ counts, const uint32_t* __restrict__ active_xyz,
                                                                const uint32_t* __restrict__ list, const uint32_t* __restrict__ n_list_dev,
                                                                const uint32_t* __restrict__ redo_mask, R* __restrict__ G, ss_real2<R>* __restrict__ blk_minmax,
@@ -1715,7 +1767,7 @@ __global__ __launch_bounds__(512) void k_splat_accumulate_list(SSDevT<R> P, cons
     const uint32_t n = *n_list_dev;
     for (uint32_t it = blockIdx.x; it < n; it += gridDim.x) {
         const uint32_t logical = list[it];
-        splat_accumulate_block<R, ARITH, EARLY>(sh, P, logical, arena, tile_off, counts, active_xyz, G, blk_minmax, trunc, facebits, redo_mask ? redo_mask[logical] : 0xFFu);
+        splat_accumulate_block<R, ARITH, EARLY>(sh, P, logical, arena, arena_idx, tile_off, counts, active_xyz, G, blk_minmax, trunc, facebits, redo_mask ? redo_mask[logical] : 0xFFu);
         __syncthreads();
     }
 }
@@ -1792,9 +1844,9 @@ void ss_launch_splat_gather(const SSDevT<R>& P, const ss_real4<R>* posvol, const
 template <class R>
 void ss_launch_splat_gather_large(const SSDevT<R>& P, const ss_real4<R>* posvol, const ss_real4<R>* posvol_by_index, const uint32_t* perm, const uint32_t* cell_start,
                                   const uint32_t* active_xyz, const uint32_t* large_list, const uint32_t* n_large_dev, const uint32_t* counts,
-                                  const unsigned long long* tile_off, ss_real4<R>* arena, hipStream_t st) {
+                                  const unsigned long long* tile_off, ss_real4<R>* arena, uint32_t* arena_idx, hipStream_t st) {
     hipLaunchKernelGGL((k_splat_gather_large<R, SSTileCap<R>::value>), dim3(2048), dim3(512), 0, st, P, posvol, posvol_by_index, perm, cell_start, active_xyz, large_list,
-                       n_large_dev, counts, tile_off, arena);
+                       n_large_dev, counts, tile_off, arena, arena_idx);
 }
 
 // list == nullptr: first pass over all n_active blocks (early exit unless full_levelset); otherwise the second pass over the
@@ -1811,7 +1863,7 @@ void ss_launch_splat_accumulate(const SSDevT<R>& P, const ss_real4<R>* arena, co
     do {                                                                                                                                                                \
         hipLaunchKernelGGL((k_splat_accumulate_w<R, A, E>), grid, dim3(64), 0, st, P, arena, arena_idx, tile_off, counts, active_xyz, n_active, list, n_list_dev, redo_mask, G,  \
                            blk_minmax, trunc, facebits, big);                                                                                                                  \
-        hipLaunchKernelGGL((k_splat_accumulate_list<R, A, E>), lgrid, dim3(512), 0, st, P, arena, tile_off, counts, active_xyz, big + 1, big, redo_mask, G, blk_minmax, \
+        hipLaunchKernelGGL((k_splat_accumulate_list<R, A, E>), lgrid, dim3(512), 0, st, P, arena, arena_idx, tile_off, counts, active_xyz, big + 1, big, redo_mask, G, blk_minmax, \
                            trunc, facebits);                                                                                                                                     \
     } while (0)
 #define SS_ACC(A)                        \
@@ -2170,10 +2222,10 @@ template void ss_launch_mark_mc_blocks<float>(const SSDevT<float>& P, const uint
 template void ss_launch_mark_mc_blocks<double>(const SSDevT<double>& P, const uint32_t* block_slot, const ss_real2<double>* blk_minmax, uint32_t nblocks, uint32_t* mc_flag, hipStream_t st);
 template void ss_launch_splat_bounds<float>(const SSDevT<float>& P, const uint32_t* cell_start, const uint32_t* active_xyz, uint32_t n_active, uint32_t* bound, hipStream_t st);
 template void ss_launch_splat_gather<float>(const SSDevT<float>& P, const ss_real4<float>* posvol, const uint32_t* perm, const uint32_t* cell_start, const uint32_t* active_xyz, uint32_t n_active, const unsigned long long* tile_off, ss_real4<float>* arena, uint32_t* arena_idx, uint32_t* counts, uint32_t* large_flag, hipStream_t st);
-template void ss_launch_splat_gather_large<float>(const SSDevT<float>& P, const ss_real4<float>* posvol, const ss_real4<float>* posvol_by_index, const uint32_t* perm, const uint32_t* cell_start, const uint32_t* active_xyz, const uint32_t* large_list, const uint32_t* n_large_dev, const uint32_t* counts, const unsigned long long* tile_off, ss_real4<float>* arena, hipStream_t st);
+template void ss_launch_splat_gather_large<float>(const SSDevT<float>& P, const ss_real4<float>* posvol, const ss_real4<float>* posvol_by_index, const uint32_t* perm, const uint32_t* cell_start, const uint32_t* active_xyz, const uint32_t* large_list, const uint32_t* n_large_dev, const uint32_t* counts, const unsigned long long* tile_off, ss_real4<float>* arena, uint32_t* arena_idx, hipStream_t st);
 template void ss_launch_splat_bounds<double>(const SSDevT<double>& P, const uint32_t* cell_start, const uint32_t* active_xyz, uint32_t n_active, uint32_t* bound, hipStream_t st);
 template void ss_launch_splat_gather<double>(const SSDevT<double>& P, const ss_real4<double>* posvol, const uint32_t* perm, const uint32_t* cell_start, const uint32_t* active_xyz, uint32_t n_active, const unsigned long long* tile_off, ss_real4<double>* arena, uint32_t* arena_idx, uint32_t* counts, uint32_t* large_flag, hipStream_t st);
-template void ss_launch_splat_gather_large<double>(const SSDevT<double>& P, const ss_real4<double>* posvol, const ss_real4<double>* posvol_by_index, const uint32_t* perm, const uint32_t* cell_start, const uint32_t* active_xyz, const uint32_t* large_list, const uint32_t* n_large_dev, const uint32_t* counts, const unsigned long long* tile_off, ss_real4<double>* arena, hipStream_t st);
+template void ss_launch_splat_gather_large<double>(const SSDevT<double>& P, const ss_real4<double>* posvol, const ss_real4<double>* posvol_by_index, const uint32_t* perm, const uint32_t* cell_start, const uint32_t* active_xyz, const uint32_t* large_list, const uint32_t* n_large_dev, const uint32_t* counts, const unsigned long long* tile_off, ss_real4<double>* arena, uint32_t* arena_idx, hipStream_t st);
 template void ss_launch_splat_accumulate<float>(const SSDevT<float>& P, const ss_real4<float>* arena, const uint32_t* arena_idx, const unsigned long long* tile_off, const uint32_t* counts, const uint32_t* active_xyz, uint32_t n_active, float* G, ss_real2<float>* blk_minmax, uint32_t* trunc, bool full_levelset, const uint32_t* list, const uint32_t* n_list_dev, const uint32_t* redo_mask, unsigned long long* facebits, uint32_t* big, hipStream_t st);
 template void ss_launch_select_redo<float>(const SSDevT<float>& P, const uint32_t* active_xyz, uint32_t n_active, const uint32_t* block_slot, const uint32_t* trunc, const unsigned long long* facebits, uint32_t* redo_mask, hipStream_t st);
 template void ss_launch_splat_accumulate<double>(const SSDevT<double>& P, const ss_real4<double>* arena, const uint32_t* arena_idx, const unsigned long long* tile_off, const uint32_t* counts, const uint32_t* active_xyz, uint32_t n_active, double* G, ss_real2<double>* blk_minmax, uint32_t* trunc, bool full_levelset, const uint32_t* list, const uint32_t* n_list_dev, const uint32_t* redo_mask, unsigned long long* facebits, uint32_t* big, hipStream_t st);
