@@ -150,7 +150,7 @@ typedef struct ss_stats {
     uint64_t fast_div_verified;       /* 1 if the splat used the exhaustively verified reciprocal division for this h */
     uint64_t levelset_kernel_launches;
     uint64_t bytes_device_peak;       /* HBM held by the context after this call */
-    double ms_levelset_gather;        /* part of ms_levelset: k_splat_count + offsets + k_splat_gather[_large] (index-ordered candidate tiles) */
+    double ms_levelset_gather;        /* part of ms_levelset: k_splat_bounds + offsets + k_splat_gather[_large] (candidate tiles of the blocks) */
     double ms_levelset_accumulate;    /* part of ms_levelset: k_splat_accumulate_w / _list (the arithmetic; the dominant kernel), both passes */
     uint64_t n_large_tile_blocks;     /* blocks whose candidate tile (> 384 entries) was ordered by the workgroup-level gather */
     uint64_t arith_mode;              /* arithmetic of the level-set accumulation that ran: 0 scalar (generic sqrt/divide), 1 scalar

@@ -7,8 +7,9 @@
 //                                                                        -> k_cell_keys (+ rocPRIM sort), k_gather_sorted
 //   K2  dense_subdomains.rs:496-646 + neighborhood_search.rs:345-438 + density_map.rs:150-186
 //                                                                        -> k_classify_count, k_emit_copies, k_density_sub
-//   K3  dense_subdomains.rs:784-847 (density_grid_loop_scalar)            -> k_mark_blocks, k_splat_count, k_splat_gather[_large], k_splat_accumulate
-//   K4  dense_subdomains.rs:1470-1553 (triangulate_cell) classification   -> k_mc_count
+//   K3  dense_subdomains.rs:784-847 / :991-1133 (density_grid_loop_scalar / _avx)
+//                                                                        -> k_mark_blocks, k_splat_bounds, k_splat_gather[_large], k_splat_accumulate_w / _list, k_select_redo
+//   K4  dense_subdomains.rs:1470-1553 (triangulate_cell) classification   -> k_mark_mc_blocks, k_mc_neighbours, k_mc_count
 //   K5  same, vertex/triangle emission + dense_subdomains.rs:1603-1749    -> k_mc_emit
 //
 // Design: particles are sorted once by search cell (edge h, stable => ascending
@@ -705,18 +706,23 @@ void ss_launch_compact_blocks(const uint32_t* flag, const uint32_t* rank, uint32
 //      contiguous runs of the cell-sorted particle array; their total length (rows trimmed to the sphere's z extent) bounds the
 //      block's tile size from above at the price of two table look-ups per row.  An exclusive scan of the bounds gives every
 //      block its range in ONE tile arena (no fixed slots, no size limit per block; only the entries in use are touched).
-//   2. gather + order (ONE WAVE per block): the wave streams the rows, tests every particle against the box spanned by the
-//      block's points, compacts the survivors into LDS, sorts them by ORIGINAL particle index -- the
-//      reference's per-point summation order (sorted per-subdomain particle lists, dense_subdomains.rs:476-488) -- and the
-//      payload (x, y, z, V) written to the block's arena range in that order.  Up to SS_WTILE survivors: one wave per block
-//      (k_splat_gather: no workgroup barrier, rank sort by wave-wide compares).  More (over-dense input): one 512-thread
-//      workgroup per block (k_splat_gather_large: up to SSTileCap index keys in LDS per pass, bitonic network; even larger
-//      tiles in several passes over ascending index ranges found by bisection, so any input density stays exact).
-//   3. accumulate (k_splat_accumulate, 512 threads per block): wave w owns the 4x4x4 sub-block (w>>2, (w>>1)&1, w&1), lane l
-//      the point ((l>>4)&3, (l>>2)&3, l&3) of it.  The block's tile is streamed through LDS in chunks of SS_WTILE entries (the
-//      next chunk is in flight while the current one is used); per wave, phase A tests 64 tile entries at once against the
-//      wave's sub-block box (ballot), phase B walks the survivors in order and every lane evaluates G += V * W(|x - p|) for
-//      its point (dense_subdomains.rs:828-841 / :1077-1107, selected by the ARITH template parameter).
+//   2. gather (ONE WAVE per block, k_splat_gather): the wave streams the rows, tests every particle against the box spanned by
+//      the block's points, compacts the survivors into LDS and writes their payload (x, y, z, V) and particle indices to the
+//      block's arena range.  The reference sums per point in ascending ORIGINAL particle index (sorted per-subdomain particle
+//      lists, dense_subdomains.rs:476-488), but most blocks never need the order (step 3), so tiles of up to SSWaveChunk entries
+//      stay in scan order; tiles up to SS_WTILE entries are rank-sorted by the wave.  More (over-dense input): one 512-thread
+//      workgroup per block (k_splat_gather_large: scan order up to SS_SORT_TILE_MAX entries, beyond that up to SSTileCap index
+//      keys in LDS per pass, bitonic network, several passes over ascending index ranges found by bisection, so any input density
+//      stays exact).
+//   3. accumulate: ONE WAVE per block (k_splat_accumulate_w) walks the eight 4x4x4 sub-blocks of the block, lane l = point
+//      ((l>>4)&3, (l>>2)&3, l&3).  Per sub-block, phase A tests 64 tile entries at once against the sub-block's box (ballot) and
+//      phase B walks the survivors, every lane adding its point's term.  First a LOWER BOUND from the entries close to the
+//      sub-block (any order, cheap arithmetic): if it exceeds the threshold at all 64 points the sub-block is certified to lie
+//      inside the surface and neither evaluated nor stored.  Otherwise the wave orders the tile (splat_sort_tile) and evaluates
+//      G += V * W(|x - p|) in the reference's order and arithmetic (dense_subdomains.rs:828-841 / :1077-1107, the ARITH template
+//      parameter).  Certified sub-blocks with a point next to a grid point outside the surface are evaluated by a second launch
+//      (k_select_redo): those are the values marching cubes interpolates with.  Tiles over SSWaveChunk entries take
+//      k_splat_accumulate_list: a 512-thread workgroup per block, wave w = sub-block w, the tile streamed through LDS in chunks.
 // =====================================================================================================
 __global__ __launch_bounds__(256) void k_verify_fast_div(float h, float rh, uint32_t* __restrict__ bad) {
     // all significands of the binade [2^e, 2^(e+1)) that contains h
@@ -1425,8 +1431,8 @@ __device__ __forceinline__ void splat_accumulate_block(SplatAccShared<R>& sh, co
     R acc = R(0.0);  // levelset_grid.fill(0), dense_subdomains.rs:1390
     bool done = false;
     // The tile streams through LDS in chunks of SS_WTILE entries (one chunk for all but over-dense blocks), up to twice:
-    //  pass 0 (EARLY only), classification: the sum over the entries CLOSE to the sub-block only (box distance <= 0.56 h, about a
-    //   quarter of the tile, but >= 74 % of every point's kernel mass).  Every term is >= 0, so it bounds the level set from below
+    //  pass 0 (EARLY only), classification: the sum over the entries CLOSE to the sub-block only (box distance <= 0.60 h, about a
+    //   quarter of the tile, but most of every point's kernel mass).  Every term is >= 0, so it bounds the level set from below
     //   whatever the order and whatever the arithmetic -- f32 jobs use the cheapest variant (fma, v_sqrt_f32; within ~1e-6 relative
     //   of every other mode's terms, far inside the margin of thr_inside).  If it exceeds the threshold at all 64 points, the
     //   sub-block lies inside the fluid: marching cubes only needs that fact, unless the block is next to a sign change, in which
