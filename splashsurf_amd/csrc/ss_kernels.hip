@@ -1935,21 +1935,47 @@ __global__ __launch_bounds__(256) void k_mc_neighbours(SSDevT<R> P, const uint32
 // s_nb: the block's record of mc_nb in LDS.  Points of a certified sub-block read as "a value above the threshold" (they are no
 // end point of an edge that crosses the surface, k_select_redo, so the value itself is never used); absent blocks are all zero.
 template <class R>
+__device__ __forceinline__ R mc_fetch_point(const SSDevT<R>& P, const R* __restrict__ G, const uint32_t* s_nb, int x, int y, int z) {
+    const int n = ((x >> 3) << 2) | ((y >> 3) << 1) | (z >> 3);
+    const uint32_t slot = s_nb[n];
+    if (slot == 0xFFFFFFFFu) return R(0.0);
+    const int sbit = (((x & 7) >> 2) << 2) | (((y & 7) >> 2) << 1) | ((z & 7) >> 2);
+    if ((s_nb[8 + n] >> sbit) & 1u) return P.thr_inside;
+    return G[(size_t)slot * SS_BLOCK_POINTS + (size_t)SS_BLOCK_OFFSET(x & 7, y & 7, z & 7)];
+}
+// point (x, y, z) of the block that is stored at offset `off` (inverse of SS_BLOCK_OFFSET)
+__device__ __forceinline__ void mc_point_of_offset(int off, int* x, int* y, int* z) {
+    const int sb = off >> 6;
+    *x = ((sb >> 2) & 1) * 4 + ((off >> 4) & 3);
+    *y = ((sb >> 1) & 1) * 4 + ((off >> 2) & 3);
+    *z = (sb & 1) * 4 + (off & 3);
+}
+
+// 729 points for 512 threads.  Thread t reads the value at offset t of the block itself -- one contiguous 2-KiB read per workgroup
+// instead of 16-byte runs in (x, y, z) order -- and threads 0..216 one point of the halo (x = 8, then y = 8, then z = 8); both
+// loads are issued before either value is written to LDS.
+template <class R>
 __device__ inline void mc_load_tile(McTile<R>& t, const SSDevT<R>& P, const R* __restrict__ G, const uint32_t* s_nb, int tid) {
-    for (int e = tid; e < 729; e += 512) {
-        const int x = e / 81, y = (e / 9) % 9, z = e % 9;
-        const int n = ((x >> 3) << 2) | ((y >> 3) << 1) | (z >> 3);
-        const uint32_t slot = s_nb[n];
-        R v = R(0.0);
-        if (slot != 0xFFFFFFFFu) {
-            const int sbit = (((x & 7) >> 2) << 2) | (((y & 7) >> 2) << 1) | ((z & 7) >> 2);
-            if ((s_nb[8 + n] >> sbit) & 1u)
-                v = P.thr_inside;
-            else
-                v = G[(size_t)slot * SS_BLOCK_POINTS + (size_t)SS_BLOCK_OFFSET(x & 7, y & 7, z & 7)];
-        }
-        t.g[e] = v;
+    int x0, y0, z0;
+    mc_point_of_offset(tid, &x0, &y0, &z0);
+    const R v0 = mc_fetch_point(P, G, s_nb, x0, y0, z0);
+    int x1 = 8, y1 = 0, z1 = 0;
+    if (tid < 81) {  // plane x = 8
+        y1 = tid / 9;
+        z1 = tid % 9;
+    } else if (tid < 153) {  // plane y = 8, x < 8
+        x1 = (tid - 81) / 9;
+        y1 = 8;
+        z1 = (tid - 81) % 9;
+    } else {  // plane z = 8, x < 8, y < 8
+        x1 = ((tid - 153) >> 3) & 7;
+        y1 = (tid - 153) & 7;
+        z1 = 8;
     }
+    R v1 = R(0.0);
+    if (tid < 217) v1 = mc_fetch_point(P, G, s_nb, x1, y1, z1);
+    t.g[(x0 * 9 + y0) * 9 + z0] = v0;
+    if (tid < 217) t.g[(x1 * 9 + y1) * 9 + z1] = v1;
 }
 
 // per-thread classification shared by the count and emit kernels
@@ -1990,27 +2016,58 @@ __device__ inline McLocal mc_classify(const McTile<R>& t, const SSDevT<R>& P, in
     return L;
 }
 
+// the x-slabs 4 half .. 4 half + 4 of the 9^3 tile (what the points with x in 4 half .. 4 half + 3 and their cells read), 256 threads:
+// thread t reads offset 256 half + t of the block itself (the four sub-blocks with that x half are contiguous) and threads
+// 0..148 one of the other points: the slab x = 4 half + 4 (y, z < 8), then y = 8, then z = 8 (y < 8)
 template <class R>
-__global__ __launch_bounds__(512) void k_mc_count(SSDevT<R> P, const R* __restrict__ G, const uint32_t* __restrict__ mc_nb,
+__device__ inline void mc_load_half_tile(McTile<R>& t, const SSDevT<R>& P, const R* __restrict__ G, const uint32_t* s_nb, int half, int tid) {
+    int x0, y0, z0;
+    mc_point_of_offset(256 * half + tid, &x0, &y0, &z0);
+    const R v0 = mc_fetch_point(P, G, s_nb, x0, y0, z0);
+    int x1, y1, z1;
+    if (tid < 64) {
+        x1 = 4 * half + 4;
+        y1 = tid >> 3;
+        z1 = tid & 7;
+    } else if (tid < 109) {
+        x1 = 4 * half + (tid - 64) / 9;
+        y1 = 8;
+        z1 = (tid - 64) % 9;
+    } else {
+        x1 = 4 * half + (tid - 109) / 8;
+        y1 = (tid - 109) % 8;
+        z1 = 8;
+    }
+    R v1 = R(0.0);
+    if (tid < 149) v1 = mc_fetch_point(P, G, s_nb, x1, y1, z1);
+    t.g[(x0 * 9 + y0) * 9 + z0] = v0;
+    if (tid < 149) t.g[(x1 * 9 + y1) * 9 + z1] = v1;
+}
+
+// Two 256-thread workgroups per MC block, one per half of its x-slabs (wave = slab): the kernel is bound by the latency of its
+// dependent loads (record, values), and a CU holds eight such workgroups instead of four of 512 threads.
+template <class R>
+__global__ __launch_bounds__(256) void k_mc_count(SSDevT<R> P, const R* __restrict__ G, const uint32_t* __restrict__ mc_nb,
                                                   const uint32_t* __restrict__ mc_xyz, uint32_t n_mc, unsigned long long* __restrict__ masks,
                                                   uint32_t* __restrict__ vcount, uint32_t* __restrict__ tcount) {
     __shared__ McTile<R> tile;
     __shared__ uint32_t s_nb[16];
-    __shared__ uint32_t s_v[8], s_t[8];
+    __shared__ uint32_t s_v[4], s_t[4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const uint32_t m = blockIdx.x;
+    const uint32_t m = blockIdx.x >> 1;
+    const int half = (int)(blockIdx.x & 1u);
     if (m >= n_mc) return;
     const int bx = (int)mc_xyz[3 * (size_t)m], by = (int)mc_xyz[3 * (size_t)m + 1], bz = (int)mc_xyz[3 * (size_t)m + 2];  // k_block_coords
     if (tid < 16) s_nb[tid] = mc_nb[16 * (size_t)m + tid];
     __syncthreads();
-    mc_load_tile(tile, P, G, s_nb, tid);
+    mc_load_half_tile(tile, P, G, s_nb, half, tid);
     __syncthreads();
-    const McLocal L = mc_classify(tile, P, bx, by, bz, tid);
+    const McLocal L = mc_classify(tile, P, bx, by, bz, 256 * half + tid);
     uint32_t nv = 0;
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
         const unsigned long long mk = __ballot(L.cross[a]);
-        if (lane == 0) masks[(size_t)m * 24 + a * 8 + wave] = mk;
+        if (lane == 0) masks[(size_t)m * 24 + a * 8 + 4 * half + wave] = mk;
         nv += (uint32_t)__popcll(mk);
     }
     // triangles of this wave
@@ -2022,14 +2079,9 @@ __global__ __launch_bounds__(512) void k_mc_count(SSDevT<R> P, const R* __restri
         s_t[wave] = nt;
     }
     __syncthreads();
-    if (tid == 0) {
-        uint32_t v = 0, t = 0;
-        for (int w = 0; w < 8; ++w) {
-            v += s_v[w];
-            t += s_t[w];
-        }
-        vcount[m] = v;
-        tcount[m] = t;
+    if (tid == 0) {  // vcount / tcount are zeroed by the host; integer sums: the result does not depend on the order
+        atomicAdd(&vcount[m], s_v[0] + s_v[1] + s_v[2] + s_v[3]);
+        atomicAdd(&tcount[m], s_t[0] + s_t[1] + s_t[2] + s_t[3]);
     }
 }
 
@@ -2152,7 +2204,7 @@ template <class R>
 void ss_launch_mc_count(const SSDevT<R>& P, const R* G, const uint32_t* mc_nb, const uint32_t* mc_xyz, uint32_t n_mc,
                         unsigned long long* masks, uint32_t* vcount, uint32_t* tcount, hipStream_t st) {
     if (!n_mc) return;
-    hipLaunchKernelGGL(k_mc_count<R>, dim3(n_mc), dim3(512), 0, st, P, G, mc_nb, mc_xyz, n_mc, masks, vcount, tcount);
+    hipLaunchKernelGGL(k_mc_count<R>, dim3(2u * n_mc), dim3(256), 0, st, P, G, mc_nb, mc_xyz, n_mc, masks, vcount, tcount);
 }
 template <class R>
 void ss_launch_mc_emit(const SSDevT<R>& P, const R* G, const uint32_t* mc_nb, const uint32_t* mc_xyz, const uint32_t* mc_slot,
