@@ -1082,7 +1082,7 @@ __device__ inline void splat_for_each_candidate(S& s, const SSDevT<R>& P, const 
             }
             const uint32_t src = s.row_start[lo] + (q - s.row_prefix[lo]);
             const ss_real4<R> pv = posvol[src];
-            if (ss_within_reach_of_block<R>(P, pv, plo, phi)) f(perm[src]);
+            if (ss_within_reach_of_block<R>(P, pv, plo, phi)) f(perm[src], pv);
         }
         __syncthreads();
     }
@@ -1101,6 +1101,22 @@ __device__ __forceinline__ void splat_gather_large_block(SplatShared<R, CAP>& s,
     R plo[3], phi[3];
     int klo[3], khi[3];
     if (!splat_block_box<R>(P, b3, plo, phi, klo, khi)) return;
+    if (expect <= (uint32_t)SS_SORT_TILE_MAX) {
+        // Left in scan order with the particle indices: the accumulate kernel orders the tile itself if the block needs an exact sum
+        // (most blocks inside a body of fluid are certified by the order-independent lower bound).  The payload goes straight from
+        // the cell-sorted array the scan reads anyway to the tile -- no second, index-ordered fetch.
+        __syncthreads();
+        if (tid == 0) s.count = 0;
+        __syncthreads();
+        splat_for_each_candidate<R>(s, P, posvol, perm, cell_start, klo, khi, plo, phi, tid, [&](uint32_t idx, const ss_real4<R>& pv) {
+            const uint32_t pos = atomicAdd(&s.count, 1u);
+            if (pos < expect) {
+                tile[pos] = pv;
+                tile_idx[pos] = idx;
+            }
+        });
+        return;
+    }
     long long last = -1;  // particles with original index <= last are already written
     const long long idx_max = (long long)P.n - 1;
     uint32_t written = 0;
@@ -1116,7 +1132,7 @@ __device__ __forceinline__ void splat_gather_large_block(SplatShared<R, CAP>& s,
                 __syncthreads();
                 if (tid == 0) s.count = 0;
                 __syncthreads();
-                splat_for_each_candidate<R>(s, P, posvol, perm, cell_start, klo, khi, plo, phi, tid, [&](uint32_t idx) {
+                splat_for_each_candidate<R>(s, P, posvol, perm, cell_start, klo, khi, plo, phi, tid, [&](uint32_t idx, const ss_real4<R>&) {
                     if ((long long)idx > last && (long long)idx <= mid) atomicAdd(&s.count, 1u);
                 });
                 const uint32_t c = s.count;
@@ -1130,7 +1146,7 @@ __device__ __forceinline__ void splat_gather_large_block(SplatShared<R, CAP>& s,
         __syncthreads();
         if (tid == 0) s.count = 0;
         __syncthreads();
-        splat_for_each_candidate<R>(s, P, posvol, perm, cell_start, klo, khi, plo, phi, tid, [&](uint32_t idx) {
+        splat_for_each_candidate<R>(s, P, posvol, perm, cell_start, klo, khi, plo, phi, tid, [&](uint32_t idx, const ss_real4<R>&) {
             if ((long long)idx > last && (long long)idx <= T) {
                 const uint32_t pos = atomicAdd(&s.count, 1u);
                 if (pos < (uint32_t)CAP) s.idx[pos] = idx;
@@ -1138,16 +1154,6 @@ __device__ __forceinline__ void splat_gather_large_block(SplatShared<R, CAP>& s,
         });
         const int n_tile = (int)min(s.count, (uint32_t)CAP);
         if (n_tile == 0) break;  // cannot happen (the count pass saw `expect` candidates); never spin
-        if (expect <= (uint32_t)SS_SORT_TILE_MAX) {
-            // left in scan order with the particle indices: the accumulate kernel orders the tile itself if the block needs an exact
-            // sum (most blocks inside a body of fluid are certified by the order-independent lower bound)
-            for (int e = tid; e < n_tile; e += 512) {
-                const uint32_t id = s.idx[e];
-                tile[e] = posvol_by_index[id];
-                tile_idx[e] = id;
-            }
-            break;
-        }
         if (n_tile <= 512) {
             if (tid < n_tile) {
                 const uint32_t my_idx = s.idx[tid];
