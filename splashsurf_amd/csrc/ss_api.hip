@@ -1019,8 +1019,8 @@ ss_status phase_finish(ss_context* ctx, ss_result* res) {
     SS_HIP(ctx, hipMemsetAsync(ctx->tcount.p, 0, ((size_t)n_mc + 1) * 4, st));
     SS_HIP(ctx, res->mc_xyz.reserve((size_t)n_mc * 12 + 16));
     ss_launch_block_coords(P, res->mc_list.as<uint32_t>(), n_mc, res->mc_xyz.as<uint32_t>(), st);
-    SS_HIP(ctx, ctx->mc_nb.reserve((size_t)n_mc * 64 + 64));
-    ss_launch_mc_neighbours(P, res->mc_xyz.as<uint32_t>(), n_mc, res->block_slot.as<uint32_t>(), full_ls ? nullptr : tr_flag, ctx->mc_nb.as<uint32_t>(), st);
+    SS_HIP(ctx, ctx->mc_nb.reserve((size_t)n_mc * 96 + 64));
+    ss_launch_mc_neighbours(P, res->mc_xyz.as<uint32_t>(), n_mc, res->block_slot.as<uint32_t>(), res->mc_slot.as<uint32_t>(), full_ls ? nullptr : tr_flag, ctx->mc_nb.as<uint32_t>(), st);
     ss_launch_mc_count(P, res->G.as<R>(), ctx->mc_nb.as<uint32_t>(), res->mc_xyz.as<uint32_t>(), n_mc, res->masks.as<unsigned long long>(),
                        ctx->vcount.as<uint32_t>(), ctx->tcount.as<uint32_t>(), st);
     SS_HIP(ctx, hipEventRecord(ctx->ev[7], st));

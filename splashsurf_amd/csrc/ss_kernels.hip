@@ -1918,24 +1918,29 @@ struct McTile {
     R g[9 * 9 * 9];
 };
 
-// The eight level-set blocks m + {0,1}^3 of every MC block, looked up once: mc_nb[16 m + n] = slot of neighbour n = (dx << 2) |
-// (dy << 1) | dz (0xFFFFFFFF: no such block), mc_nb[16 m + 8 + n] = mask of its 4^3 sub-blocks that the splat certified to lie
-// inside the surface and never evaluated in full.  The count and the emit kernel then reach the level-set values with two
+// The eight blocks m + {0,1}^3 of every MC block, looked up once (SS_MC_REC words per MC block): mc_nb[n] = level-set slot of
+// neighbour n = (dx << 2) | (dy << 1) | dz (0xFFFFFFFF: no such block), mc_nb[8 + n] = mask of its 4^3 sub-blocks that the splat
+// certified to lie inside the surface and never evaluated in full, mc_nb[16 + n] = its slot in the MC list (crossing masks,
+// vertex base; 0xFFFFFFFF: not triangulated).  The count and the emit kernel then reach the level-set values with two
 // dependent loads (record, value) instead of four (block coordinates, slot, mask, value) -- they are latency-bound.
+#define SS_MC_REC 24
 template <class R>
 __global__ __launch_bounds__(256) void k_mc_neighbours(SSDevT<R> P, const uint32_t* __restrict__ mc_xyz, uint32_t n_mc, const uint32_t* __restrict__ block_slot,
-                                                       const uint32_t* __restrict__ certified, uint32_t* __restrict__ mc_nb) {
+                                                       const uint32_t* __restrict__ mc_slot, const uint32_t* __restrict__ certified, uint32_t* __restrict__ mc_nb) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t m = t >> 3, n = t & 7u;
     if (m >= n_mc) return;
     const int x = (int)mc_xyz[3 * (size_t)m] + (int)((n >> 2) & 1u), y = (int)mc_xyz[3 * (size_t)m + 1] + (int)((n >> 1) & 1u), z = (int)mc_xyz[3 * (size_t)m + 2] + (int)(n & 1u);
-    uint32_t slot = 0xFFFFFFFFu, cert = 0u;
+    uint32_t slot = 0xFFFFFFFFu, cert = 0u, mslot = 0xFFFFFFFFu;
     if (x < P.nb[0] && y < P.nb[1] && z < P.nb[2]) {
-        slot = block_slot[((size_t)x * P.nb[1] + y) * P.nb[2] + z];
+        const size_t b = ((size_t)x * P.nb[1] + y) * P.nb[2] + z;
+        slot = block_slot[b];
+        mslot = mc_slot[b];
         if (slot != 0xFFFFFFFFu && certified) cert = certified[slot];
     }
-    mc_nb[16 * (size_t)m + n] = slot;
-    mc_nb[16 * (size_t)m + 8 + n] = cert;
+    mc_nb[SS_MC_REC * (size_t)m + n] = slot;
+    mc_nb[SS_MC_REC * (size_t)m + 8 + n] = cert;
+    mc_nb[SS_MC_REC * (size_t)m + 16 + n] = mslot;
 }
 
 // s_nb: the block's record of mc_nb in LDS.  Points of a certified sub-block read as "a value above the threshold" (they are no
@@ -2057,14 +2062,14 @@ __global__ __launch_bounds__(256) void k_mc_count(SSDevT<R> P, const R* __restri
                                                   const uint32_t* __restrict__ mc_xyz, uint32_t n_mc, unsigned long long* __restrict__ masks,
                                                   uint32_t* __restrict__ vcount, uint32_t* __restrict__ tcount) {
     __shared__ McTile<R> tile;
-    __shared__ uint32_t s_nb[16];
+    __shared__ uint32_t s_nb[SS_MC_REC];
     __shared__ uint32_t s_v[4], s_t[4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t m = blockIdx.x >> 1;
     const int half = (int)(blockIdx.x & 1u);
     if (m >= n_mc) return;
     const int bx = (int)mc_xyz[3 * (size_t)m], by = (int)mc_xyz[3 * (size_t)m + 1], bz = (int)mc_xyz[3 * (size_t)m + 2];  // k_block_coords
-    if (tid < 16) s_nb[tid] = mc_nb[16 * (size_t)m + tid];
+    if (tid < SS_MC_REC) s_nb[tid] = mc_nb[SS_MC_REC * (size_t)m + tid];
     __syncthreads();
     mc_load_half_tile(tile, P, G, s_nb, half, tid);
     __syncthreads();
@@ -2098,7 +2103,7 @@ __global__ __launch_bounds__(512) void k_mc_emit(SSDevT<R> P, const R* __restric
                                                  const uint32_t* __restrict__ tbase, R* __restrict__ vertices,
                                                  unsigned long long* __restrict__ vkeys, uint32_t* __restrict__ triangles) {
     __shared__ McTile<R> tile;
-    __shared__ uint32_t s_nb[16];
+    __shared__ uint32_t s_nb[SS_MC_REC];
     __shared__ unsigned long long s_mask[8][24];  // [neighbour][axis*8+word]
     __shared__ uint32_t s_pref[8][24];            // vertices of that neighbour block before (axis, word)
     __shared__ uint32_t s_vbase[8];
@@ -2108,16 +2113,14 @@ __global__ __launch_bounds__(512) void k_mc_emit(SSDevT<R> P, const R* __restric
     if (m >= n_mc) return;
     if (vbase[m + 1] == vbase[m] && tbase[m + 1] == tbase[m]) return;  // nothing to emit for this block
     const int bx = (int)mc_xyz[3 * (size_t)m], by = (int)mc_xyz[3 * (size_t)m + 1], bz = (int)mc_xyz[3 * (size_t)m + 2];  // k_block_coords
-    if (tid < 16) s_nb[tid] = mc_nb[16 * (size_t)m + tid];
+    if (tid < SS_MC_REC) s_nb[tid] = mc_nb[SS_MC_REC * (size_t)m + tid];
     __syncthreads();
     mc_load_tile(tile, P, G, s_nb, tid);
     // crossing masks of this block and its 7 upper neighbours
     if (tid < 8 * 24) {
         const int nb = tid / 24, w = tid % 24;
-        const int x = bx + ((nb >> 2) & 1), y = by + ((nb >> 1) & 1), z = bz + (nb & 1);
         unsigned long long mk = 0;
-        uint32_t slot = 0xFFFFFFFFu;
-        if (x < P.nb[0] && y < P.nb[1] && z < P.nb[2]) slot = mc_slot[((size_t)x * P.nb[1] + y) * P.nb[2] + z];
+        const uint32_t slot = mc_nb[SS_MC_REC * (size_t)m + 16 + nb];  // (straight from the record: s_nb is being filled by other threads)
         if (slot != 0xFFFFFFFFu) mk = masks[(size_t)slot * 24 + w];
         s_mask[nb][w] = mk;
         if (w == 0) s_vbase[nb] = (slot != 0xFFFFFFFFu) ? vbase[slot] : 0u;
@@ -2202,9 +2205,9 @@ __global__ __launch_bounds__(512) void k_mc_emit(SSDevT<R> P, const R* __restric
 }
 
 template <class R>
-void ss_launch_mc_neighbours(const SSDevT<R>& P, const uint32_t* mc_xyz, uint32_t n_mc, const uint32_t* block_slot, const uint32_t* certified, uint32_t* mc_nb, hipStream_t st) {
+void ss_launch_mc_neighbours(const SSDevT<R>& P, const uint32_t* mc_xyz, uint32_t n_mc, const uint32_t* block_slot, const uint32_t* mc_slot, const uint32_t* certified, uint32_t* mc_nb, hipStream_t st) {
     if (!n_mc) return;
-    hipLaunchKernelGGL(k_mc_neighbours<R>, dim3((n_mc * 8u + 255u) / 256u), dim3(256), 0, st, P, mc_xyz, n_mc, block_slot, certified, mc_nb);
+    hipLaunchKernelGGL(k_mc_neighbours<R>, dim3((n_mc * 8u + 255u) / 256u), dim3(256), 0, st, P, mc_xyz, n_mc, block_slot, mc_slot, certified, mc_nb);
 }
 template <class R>
 void ss_launch_mc_count(const SSDevT<R>& P, const R* G, const uint32_t* mc_nb, const uint32_t* mc_xyz, uint32_t n_mc,
@@ -2294,9 +2297,9 @@ template void ss_launch_splat_accumulate<float>(const SSDevT<float>& P, const ss
 template void ss_launch_select_redo<float>(const SSDevT<float>& P, const uint32_t* active_xyz, uint32_t n_active, const uint32_t* block_slot, const uint32_t* trunc, const unsigned long long* facebits, uint32_t* redo_mask, hipStream_t st);
 template void ss_launch_splat_accumulate<double>(const SSDevT<double>& P, const ss_real4<double>* arena, const uint32_t* arena_idx, const unsigned long long* tile_off, const uint32_t* counts, const uint32_t* active_xyz, uint32_t n_active, double* G, ss_real2<double>* blk_minmax, uint32_t* trunc, bool full_levelset, const uint32_t* list, const uint32_t* n_list_dev, const uint32_t* redo_mask, unsigned long long* facebits, uint32_t* big, hipStream_t st);
 template void ss_launch_select_redo<double>(const SSDevT<double>& P, const uint32_t* active_xyz, uint32_t n_active, const uint32_t* block_slot, const uint32_t* trunc, const unsigned long long* facebits, uint32_t* redo_mask, hipStream_t st);
-template void ss_launch_mc_neighbours<float>(const SSDevT<float>& P, const uint32_t* mc_xyz, uint32_t n_mc, const uint32_t* block_slot, const uint32_t* certified, uint32_t* mc_nb, hipStream_t st);
+template void ss_launch_mc_neighbours<float>(const SSDevT<float>& P, const uint32_t* mc_xyz, uint32_t n_mc, const uint32_t* block_slot, const uint32_t* mc_slot, const uint32_t* certified, uint32_t* mc_nb, hipStream_t st);
 template void ss_launch_mc_count<float>(const SSDevT<float>& P, const float* G, const uint32_t* mc_nb, const uint32_t* mc_xyz, uint32_t n_mc, unsigned long long* masks, uint32_t* vcount, uint32_t* tcount, hipStream_t st);
-template void ss_launch_mc_neighbours<double>(const SSDevT<double>& P, const uint32_t* mc_xyz, uint32_t n_mc, const uint32_t* block_slot, const uint32_t* certified, uint32_t* mc_nb, hipStream_t st);
+template void ss_launch_mc_neighbours<double>(const SSDevT<double>& P, const uint32_t* mc_xyz, uint32_t n_mc, const uint32_t* block_slot, const uint32_t* mc_slot, const uint32_t* certified, uint32_t* mc_nb, hipStream_t st);
 template void ss_launch_mc_count<double>(const SSDevT<double>& P, const double* G, const uint32_t* mc_nb, const uint32_t* mc_xyz, uint32_t n_mc, unsigned long long* masks, uint32_t* vcount, uint32_t* tcount, hipStream_t st);
 template void ss_launch_mc_emit<float>(const SSDevT<float>& P, const float* G, const uint32_t* mc_nb, const uint32_t* mc_xyz, const uint32_t* mc_slot, uint32_t n_mc, const unsigned long long* masks, const uint32_t* vbase, const uint32_t* tbase, float* vertices, unsigned long long* vkeys, uint32_t* triangles, hipStream_t st);
 template void ss_launch_mc_emit<double>(const SSDevT<double>& P, const double* G, const uint32_t* mc_nb, const uint32_t* mc_xyz, const uint32_t* mc_slot, uint32_t n_mc, const unsigned long long* masks, const uint32_t* vbase, const uint32_t* tbase, double* vertices, unsigned long long* vkeys, uint32_t* triangles, hipStream_t st);
