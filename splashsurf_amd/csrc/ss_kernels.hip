@@ -1245,8 +1245,9 @@ __device__ __forceinline__ R ss_splat_pair(const SSDevT<R>& P, R rh, const ss_re
             // lower-bound pass, in units of sigma (the caller scales the sum once): with v = max(1 - q, 0) the spline is
             // min(2 v^3, 1 - 6 v (1 - v)^2), and v^2 lies between the two pieces' roles: v^2 >= 2 v^3 for v <= 1/2 and
             // 1 - 6 v (1 - v)^2 - v^2 = -6 (v - 1)(v - 1/2)(v - 1/3) >= 0 on [1/2, 1].  So v^2 min(2 v, 1) <= W / sigma everywhere:
-            // five instructions after q, no second piece, no reach test (v = 0 beyond h), no EXEC bookkeeping.
-            const float q = __builtin_amdgcn_sqrtf(d2) * P.avx_inv_h;
+            // five instructions after q, no second piece, no reach test (v = 0 beyond h), no EXEC bookkeeping.  Entry and point
+            // arrive in units of h relative to the sub-block's centre (splat_accumulate_wave), so q is the root itself.
+            const float q = __builtin_amdgcn_sqrtf(d2);
             float v, t;
             asm("v_sub_f32_e64 %0, 1.0, %1 clamp" : "=v"(v) : "v"(q));
             asm("v_add_f32_e64 %0, %1, %1 clamp" : "=v"(t) : "v"(v));
@@ -1282,6 +1283,17 @@ template <class R, int ARITH>
 __device__ __forceinline__ R splat_accumulate_wave(const SSDevT<R>& P, const ss_real4<R>* pay, ss_real4<R>* wl, int n_tile, int lane, R px, R py, R pz,
                                                    const R slo[3], const R shi[3], R r2_filter, R acc, const uint8_t* premask = nullptr, int premask_bit = 0) {
     const R rh = R(1.0) / P.h;
+    // lower-bound pass: positions in units of h relative to the sub-block's centre (differences of nearby numbers are exact, the
+    // scaling costs a relative 2^-24: nothing against the 1e-4 margin of thr_inside) -- saves the multiplication by 1/h per pair
+    R cx = R(0.0), cy = R(0.0), cz = R(0.0);
+    if constexpr (ARITH == SS_ARITH_BOUND) {
+        cx = R(0.5) * (slo[0] + shi[0]);
+        cy = R(0.5) * (slo[1] + shi[1]);
+        cz = R(0.5) * (slo[2] + shi[2]);
+        px = (px - cx) * P.avx_inv_h;
+        py = (py - cy) * P.avx_inv_h;
+        pz = (pz - cz) * P.avx_inv_h;
+    }
     for (int base = 0; base < n_tile; base += 64) {
         const int c = base + lane;
         bool pass = false;
@@ -1302,6 +1314,7 @@ __device__ __forceinline__ R splat_accumulate_wave(const SSDevT<R>& P, const ss_
         if (wmask) {
             const int cnt = __popcll(wmask);
             ss_wave_lds_sync();  // the previous batch's reads of wl are done
+            if constexpr (ARITH == SS_ARITH_BOUND) pv = ss_make4((pv.x - cx) * P.avx_inv_h, (pv.y - cy) * P.avx_inv_h, (pv.z - cz) * P.avx_inv_h, pv.w);
             if (pass) wl[__builtin_amdgcn_mbcnt_hi((uint32_t)(wmask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)wmask, 0u))] = pv;
             // the walk below takes two entries per trip: an odd list ends with an entry out of everybody's reach and of volume 0
             // (its term is skipped by the reach test, and +0 in the lower-bound pass)
