@@ -208,10 +208,14 @@ def test_grid_for_reconstruction(gpu_ctx, oracle):
     assert np.array_equal(g.aabb.min.view(np.uint32), o["aabb_min"].view(np.uint32))
 
 
-def test_dense_cloud_exceeding_tile_capacity(gpu_ctx, oracle):
+@pytest.mark.parametrize("forced_two_pass", [False, True])
+def test_dense_cloud_exceeding_tile_capacity(gpu_ctx, two_pass_ctx, oracle, forced_two_pass):
     """Over-dense input (many more candidates per level-set block than LDS slots): the multi-pass
-    ordered accumulation must still be bit-identical to the oracle."""
+    ordered accumulation must still be bit-identical to the oracle -- also with the certification scheme forced on (the
+    lower-bound pass then runs over tiles of > 8192 entries that the gather kernel ordered in several passes)."""
     from splashsurf_amd import workloads as W
+    if forced_two_pass:
+        gpu_ctx = two_pass_ctx
     pts = (W.uniform_cube_particles(100000, seed=99) * np.float32(0.25)).astype(np.float32)
     prm = dict(particle_radius=0.01, smoothing_length=2.0, cube_size=1.0, iso_surface_threshold=0.6)
     # a block in the middle of the cloud sees the particles of a (7 cells + 2 x 4 cells)^3 box: more than two passes of
@@ -224,6 +228,26 @@ def test_dense_cloud_exceeding_tile_capacity(gpu_ctx, oracle):
     st = res.stats  # stage timers of the three splat kernels (HIP events on the library's stream)
     assert st["ms_levelset_gather"] > 0.0 and st["ms_levelset_accumulate"] > 0.0
     assert st["ms_levelset"] >= st["ms_levelset_gather"] + st["ms_levelset_accumulate"]
+    assert_gpu_equals_oracle(res, orc)
+
+
+@pytest.mark.parametrize("forced_two_pass", [False, True])
+@pytest.mark.parametrize("simd", [False, True])
+def test_dense_cloud_with_unordered_tiles(gpu_ctx, two_pass_ctx, oracle, forced_two_pass, simd):
+    """Moderately over-dense input: tiles of a few hundred to a few thousand entries, which the large-tile gather leaves in scan
+    order and the workgroup-level accumulate kernel orders in LDS when a block needs an exact sum."""
+    from splashsurf_amd import workloads as W
+    pts = (W.uniform_cube_particles(20000, seed=7) * np.float32(0.3)).astype(np.float32)
+    prm = dict(particle_radius=0.01, smoothing_length=2.0, cube_size=1.0, iso_surface_threshold=0.6)
+    res = run_gpu(two_pass_ctx if forced_two_pass else gpu_ctx, pts, prm, simd=simd)
+    st = res.stats
+    per_block = st["n_block_candidates"] / max(st["n_active_blocks"], 1)
+    assert st["n_large_tile_blocks"] > 0 and 384 < per_block < 4096, (st["n_large_tile_blocks"], per_block)
+    if forced_two_pass:
+        assert st["n_certified_subblocks"] > 0
+    par = oracle.make_params_relative(prm["particle_radius"], prm["smoothing_length"], prm["cube_size"], iso_surface_threshold=prm["iso_surface_threshold"],
+                                      simd=2 if simd else 0)
+    orc = oracle.reconstruct_surface(pts, par)
     assert_gpu_equals_oracle(res, orc)
 
 
