@@ -116,18 +116,18 @@ def splat_roofline(st, n_occ, n_subp, nsc, k3_acc_ms, k3_large_ms):
     """roofline object of the dominant splat kernel from one rank's stats (16 B per subdomain particle incl.
     ghosts + 4 B per level-set value of every occupied subdomain)."""
     alg_bytes = 16.0 * n_subp + 4.0 * n_occ * nsc ** 3
-    name = "k_splat_accumulate_w" if k3_acc_ms >= k3_large_ms else "k_splat_large"
+    name = "k_splat_fused"
     k3 = max(k3_acc_ms, k3_large_ms) * 1e-3
     achieved = alg_bytes / k3 / 1e9 if k3 > 0 else 0.0
     return {
         "kernel": name, "bound": "hbm", "achieved": round(achieved, 2), "peak": 8000.0, "unit": "GB/s",
         "frac": round(achieved / 8000.0, 5), "traffic": None, "algorithmic_bytes": alg_bytes, "kernel_ms": round(k3 * 1e3, 4),
-        "launches_ms": {"k_splat_accumulate_w<.., true> (first pass, all active blocks; + k_splat_accumulate_list for tiles over 192 entries)":
+        "launches_ms": {"k_splat_fused<.., true> (first pass: gather + certify + evaluate, all active blocks; + k_splat_accumulate_list for blocks with over 192 candidates)":
                         round(k3_acc_ms - float(st.get("ms_levelset_accumulate_pass2", 0.0)), 4),
-                        "k_splat_accumulate_w<.., false> (second pass: certified sub-blocks with a face neighbour outside the surface; incl. their selection)":
+                        "k_splat_fused<.., false> (second pass: certified sub-blocks with a face neighbour outside the surface; incl. their selection)":
                         round(float(st.get("ms_levelset_accumulate_pass2", 0.0)), 4)},
         "note": "algorithmic bytes = 16 B x %d subdomain particles + 4 B x %d subdomains x %d^3 points; kernel_ms = HIP events around the launches of the "
-                "accumulate kernel on the library's stream (launches_ms; the last step's split); the kernel is FP32-VALU bound at this cube radius "
+                "splat kernel (gather + accumulate in one) on the library's stream (launches_ms; the last step's split); the kernel is FP32-VALU bound at this cube radius "
                 "(DESIGN.md section 5)" % (n_subp, n_occ, nsc),
     }
 

@@ -293,7 +293,7 @@ ss_status make_device_params(ss_context* ctx, const typename TypesOf<R>::params*
 
 ss_status ensure_events(ss_context* ctx) {
     if (ctx->ev_ok) return SS_OK;
-    for (int i = 0; i < 16; ++i) SS_HIP(ctx, hipEventCreate(&ctx->ev[i]));
+    for (int i = 0; i < 18; ++i) SS_HIP(ctx, hipEventCreate(&ctx->ev[i]));
     ctx->ev_ok = true;
     return SS_OK;
 }
@@ -902,42 +902,12 @@ ss_status phase_finish(ss_context* ctx, ss_result* res) {
     uint32_t* lg_list = lg_rank + ((size_t)n_active + 1);
     uint32_t* lg_slot = lg_list + ((size_t)n_active + 1);
     SS_HIP(ctx, ctx->splat_counts.reserve(((size_t)n_active + 1) * 4));
-    SS_HIP(ctx, ctx->splat_off.reserve(((size_t)n_active + 1) * 8));
     uint64_t n_reserved = 0;
-    SS_HIP(ctx, ctx->splat_bound.reserve(((size_t)n_active + 1) * 4));
     SS_HIP(ctx, ctx->counter.reserve(64));
     SS_HIP(ctx, hipMemsetAsync(ctx->counter.p, 0, 64, st));
-    if (n_active) {
-        ss_launch_splat_bounds(PK, ctx->cell_start.as<uint32_t>(), res->active_xyz.as<uint32_t>(), n_active, ctx->splat_bound.as<uint32_t>(), st);
-        {   // tile_off = exclusive scan of the bounds in 64 bits (the arena of S40M-tank holds > 2^32 bytes)
-            auto it = rocprim::make_transform_iterator(ctx->splat_bound.as<uint32_t>(), WidenU32());
-            size_t bytes = 0;
-            SS_HIP(ctx, rocprim::exclusive_scan(nullptr, bytes, it, ctx->splat_off.as<unsigned long long>(), 0ull, (size_t)n_active + 1, rocprim::plus<unsigned long long>(), st));
-            SS_HIP(ctx, ctx->temp.reserve(bytes));
-            SS_HIP(ctx, rocprim::exclusive_scan(ctx->temp.p, bytes, it, ctx->splat_off.as<unsigned long long>(), 0ull, (size_t)n_active + 1, rocprim::plus<unsigned long long>(), st));
-        }
-        unsigned long long h_total = 0;
-        SS_HIP(ctx, hipMemcpyAsync(&h_total, ctx->splat_off.as<unsigned long long>() + n_active, 8, hipMemcpyDeviceToHost, st));
-        SS_HIP(ctx, hipStreamSynchronize(st));
-        n_reserved = h_total;
-        SS_HIP(ctx, ctx->splat_tiles.reserve((size_t)n_reserved * sizeof(ss_real4<R>) + 64));
-        SS_HIP(ctx, ctx->splat_tile_idx.reserve((size_t)n_reserved * 4 + 64));
-        SS_HIP(ctx, hipMemsetAsync(lg_flag + n_active, 0, 4, st));
-        ss_launch_splat_gather(PK, res->posvol.as<ss_real4<R>>(), res->perm.as<uint32_t>(), ctx->cell_start.as<uint32_t>(), res->active_xyz.as<uint32_t>(), n_active,
-                               ctx->splat_off.as<unsigned long long>(), ctx->splat_tiles.as<ss_real4<R>>(), ctx->splat_tile_idx.as<uint32_t>(), ctx->splat_counts.as<uint32_t>(), lg_flag, st);
-        // over-dense blocks: flags -> ordered list on the device; the workgroup-level gather reads its length there
-        s = exclusive_scan_u32<uint32_t>(ctx, lg_flag, lg_rank, (size_t)n_active + 1);
-        if (s != SS_OK) return s;
-        ss_launch_compact_blocks(lg_flag, lg_rank, n_active, lg_list, lg_slot, st);
-        ss_launch_splat_gather_large(PK, res->posvol.as<ss_real4<R>>(), res->posvol_by_index.as<ss_real4<R>>(), res->perm.as<uint32_t>(), ctx->cell_start.as<uint32_t>(),
-                                     res->active_xyz.as<uint32_t>(), lg_list, lg_rank + n_active, ctx->splat_counts.as<uint32_t>(), ctx->splat_off.as<unsigned long long>(),
-                                     ctx->splat_tiles.as<ss_real4<R>>(), ctx->splat_tile_idx.as<uint32_t>(), st);
-        s = sum_u32_to_u64(ctx, ctx->splat_counts.as<uint32_t>(), n_active, ctx->counter.as<unsigned long long>());  // tile entries in use (statistics)
-        if (s != SS_OK) return s;
-    }
     SS_HIP(ctx, hipEventRecord(ctx->ev[12], st));
-    // first pass: every active block; sub-blocks that a cheap lower bound certifies to lie inside the fluid are not evaluated in full
-    // (ss_kernels.hip, splat_accumulate_block).  Tiny jobs (< 1 k active blocks) skip the two-pass scheme: its extra launches cost more than it saves there.
+    // Sub-blocks that a cheap lower bound certifies to lie inside the fluid are not evaluated in full (ss_kernels.hip,
+    // splat_accumulate_block_wave).  Tiny jobs (< 1 k active blocks) skip the scheme: its extra launches cost more than it saves there.
     // ... and so do workloads where the previous call certified too few sub-blocks to pay for the classification pass (break-even:
     // 35 % of the sub-blocks); such a workload is probed again every 16th call.
     uint64_t early_key = (uint64_t)n * 0x9E3779B97F4A7C15ull;
@@ -964,9 +934,53 @@ ss_status phase_finish(ss_context* ctx, ss_result* res) {
     uint32_t* rd_flag = tr_flag + ((size_t)n_active + 1);         // ... and marching cubes will read it
     uint32_t* rd_rank = rd_flag + ((size_t)n_active + 1);
     uint32_t* rd_list = rd_rank + ((size_t)n_active + 1);
-    uint32_t* big = rd_list + ((size_t)n_active + 1);            // blocks handed to the workgroup-per-block kernel (count, list)
-    ss_launch_splat_accumulate(PK, ctx->splat_tiles.as<ss_real4<R>>(), ctx->splat_tile_idx.as<uint32_t>(), ctx->splat_off.as<unsigned long long>(), ctx->splat_counts.as<uint32_t>(),
-                               res->active_xyz.as<uint32_t>(), n_active, res->G.as<R>(), res->blk_minmax.as<ss_real2<R>>(), tr_flag, full_ls, nullptr, nullptr, nullptr, face_bits, big, st);
+    uint32_t* big = rd_list + ((size_t)n_active + 1);            // blocks with more candidates than a wave holds (count, list): the arena path
+    uint32_t n_big = 0;
+    if (n_active) {
+        // first pass, gather and accumulate in one kernel: the tiles of ordinary blocks stay in LDS
+        ss_launch_splat_fused(PK, res->posvol.as<ss_real4<R>>(), res->perm.as<uint32_t>(), ctx->cell_start.as<uint32_t>(), res->active_xyz.as<uint32_t>(), n_active,
+                              res->G.as<R>(), res->blk_minmax.as<ss_real2<R>>(), tr_flag, full_ls, nullptr, nullptr, nullptr, face_bits, ctx->splat_counts.as<uint32_t>(), big, st);
+        SS_HIP(ctx, hipMemcpyAsync(&n_big, big, 4, hipMemcpyDeviceToHost, st));
+        SS_HIP(ctx, hipStreamSynchronize(st));
+    }
+    SS_HIP(ctx, hipEventRecord(ctx->ev[16], st));
+    if (n_big) {
+        // over-dense blocks: bounds -> offsets -> tile arena -> gather (-> ordered list of the very large ones) -> workgroup per block
+        SS_HIP(ctx, ctx->splat_off.reserve(((size_t)n_active + 1) * 8));
+        SS_HIP(ctx, ctx->splat_bound.reserve(((size_t)n_active + 1) * 4));
+        ss_launch_splat_bounds(PK, ctx->cell_start.as<uint32_t>(), res->active_xyz.as<uint32_t>(), n_active, ctx->splat_counts.as<uint32_t>(), ctx->splat_bound.as<uint32_t>(), st);
+        {   // tile_off = exclusive scan of the bounds in 64 bits (an arena can hold > 2^32 bytes)
+            auto it = rocprim::make_transform_iterator(ctx->splat_bound.as<uint32_t>(), WidenU32());
+            size_t bytes = 0;
+            SS_HIP(ctx, rocprim::exclusive_scan(nullptr, bytes, it, ctx->splat_off.as<unsigned long long>(), 0ull, (size_t)n_active + 1, rocprim::plus<unsigned long long>(), st));
+            SS_HIP(ctx, ctx->temp.reserve(bytes));
+            SS_HIP(ctx, rocprim::exclusive_scan(ctx->temp.p, bytes, it, ctx->splat_off.as<unsigned long long>(), 0ull, (size_t)n_active + 1, rocprim::plus<unsigned long long>(), st));
+        }
+        unsigned long long h_total = 0;
+        SS_HIP(ctx, hipMemcpyAsync(&h_total, ctx->splat_off.as<unsigned long long>() + n_active, 8, hipMemcpyDeviceToHost, st));
+        SS_HIP(ctx, hipStreamSynchronize(st));
+        n_reserved = h_total;
+        SS_HIP(ctx, ctx->splat_tiles.reserve((size_t)n_reserved * sizeof(ss_real4<R>) + 64));
+        SS_HIP(ctx, ctx->splat_tile_idx.reserve((size_t)n_reserved * 4 + 64));
+        SS_HIP(ctx, hipMemsetAsync(lg_flag + n_active, 0, 4, st));
+        ss_launch_splat_gather(PK, res->posvol.as<ss_real4<R>>(), res->perm.as<uint32_t>(), ctx->cell_start.as<uint32_t>(), res->active_xyz.as<uint32_t>(), n_active,
+                               ctx->splat_off.as<unsigned long long>(), ctx->splat_tiles.as<ss_real4<R>>(), ctx->splat_tile_idx.as<uint32_t>(), ctx->splat_counts.as<uint32_t>(), lg_flag, st);
+        // very large tiles: flags -> ordered list on the device; the workgroup-level gather reads its length there
+        s = exclusive_scan_u32<uint32_t>(ctx, lg_flag, lg_rank, (size_t)n_active + 1);
+        if (s != SS_OK) return s;
+        ss_launch_compact_blocks(lg_flag, lg_rank, n_active, lg_list, lg_slot, st);
+        ss_launch_splat_gather_large(PK, res->posvol.as<ss_real4<R>>(), res->posvol_by_index.as<ss_real4<R>>(), res->perm.as<uint32_t>(), ctx->cell_start.as<uint32_t>(),
+                                     res->active_xyz.as<uint32_t>(), lg_list, lg_rank + n_active, ctx->splat_counts.as<uint32_t>(), ctx->splat_off.as<unsigned long long>(),
+                                     ctx->splat_tiles.as<ss_real4<R>>(), ctx->splat_tile_idx.as<uint32_t>(), st);
+    }
+    SS_HIP(ctx, hipEventRecord(ctx->ev[17], st));
+    if (n_big)
+        ss_launch_splat_accumulate_big(PK, ctx->splat_tiles.as<ss_real4<R>>(), ctx->splat_tile_idx.as<uint32_t>(), ctx->splat_off.as<unsigned long long>(), ctx->splat_counts.as<uint32_t>(),
+                                       res->active_xyz.as<uint32_t>(), res->G.as<R>(), res->blk_minmax.as<ss_real2<R>>(), tr_flag, full_ls, false, nullptr, face_bits, big, st);
+    if (n_active) {
+        s = sum_u32_to_u64(ctx, ctx->splat_counts.as<uint32_t>(), n_active, ctx->counter.as<unsigned long long>());  // tile entries (statistics)
+        if (s != SS_OK) return s;
+    }
     SS_HIP(ctx, hipEventRecord(ctx->ev[13], st));
     if (n_active && !full_ls) {
         {   // certified sub-blocks = set bits of the per-block masks (decides the next call's strategy)
@@ -992,8 +1006,12 @@ ss_status phase_finish(ss_context* ctx, ss_result* res) {
             SS_HIP(ctx, rocprim::exclusive_scan(ctx->temp.p, bytes, it, rd_rank, 0u, (size_t)n_active + 1, rocprim::plus<uint32_t>(), st));
         }
         ss_launch_compact_blocks(rd_flag, rd_rank, n_active, rd_list, lg_slot, st);
-        ss_launch_splat_accumulate(PK, ctx->splat_tiles.as<ss_real4<R>>(), ctx->splat_tile_idx.as<uint32_t>(), ctx->splat_off.as<unsigned long long>(), ctx->splat_counts.as<uint32_t>(),
-                                   res->active_xyz.as<uint32_t>(), n_active, res->G.as<R>(), res->blk_minmax.as<ss_real2<R>>(), tr_flag, true, rd_list, rd_rank + n_active, rd_flag, face_bits, big, st);
+        ss_launch_splat_fused(PK, res->posvol.as<ss_real4<R>>(), res->perm.as<uint32_t>(), ctx->cell_start.as<uint32_t>(), res->active_xyz.as<uint32_t>(), n_active,
+                              res->G.as<R>(), res->blk_minmax.as<ss_real2<R>>(), tr_flag, true, rd_list, rd_rank + n_active, rd_flag, face_bits, ctx->splat_counts.as<uint32_t>(), big, st);
+        if (n_big)  // (the list kernel re-collected the large blocks among the selected ones in big[])
+            ss_launch_splat_accumulate_big(PK, ctx->splat_tiles.as<ss_real4<R>>(), ctx->splat_tile_idx.as<uint32_t>(), ctx->splat_off.as<unsigned long long>(),
+                                           ctx->splat_counts.as<uint32_t>(), res->active_xyz.as<uint32_t>(), res->G.as<R>(), res->blk_minmax.as<ss_real2<R>>(), tr_flag, true, true,
+                                           rd_flag, face_bits, big, st);
         s = count_nonzero_u32(ctx, tr_flag, n_active, ctx->counter.as<unsigned long long>() + 1);  // blocks still truncated (statistics)
         if (s != SS_OK) return s;
     }
@@ -1071,8 +1089,8 @@ ss_status phase_finish(ss_context* ctx, ss_result* res) {
     S.ms_density = ev_ms(ctx, 3, 4) + ev_ms(ctx, 10, 11);
     S.ms_levelset_prepare = ev_ms(ctx, 11, 5);
     S.ms_levelset = ev_ms(ctx, 5, 6);
-    S.ms_levelset_gather = ev_ms(ctx, 5, 12);
-    S.ms_levelset_accumulate = ev_ms(ctx, 12, 13) + ev_ms(ctx, 14, 15);  // both passes of k_splat_accumulate (the second incl. its block selection)
+    S.ms_levelset_gather = ev_ms(ctx, 16, 17);  // the arena path of blocks with more candidates than a wave holds (0 without such blocks)
+    S.ms_levelset_accumulate = ev_ms(ctx, 12, 13) - ev_ms(ctx, 16, 17) + ev_ms(ctx, 14, 15);  // both passes of the splat kernels (the second incl. its block selection)
     S.ms_marching_cubes = ev_ms(ctx, 6, 7) + ev_ms(ctx, 8, 9);
     S.ms_stitching = ev_ms(ctx, 7, 8);
     S.n_particles = n;
@@ -1434,7 +1452,7 @@ void ss_context_destroy(ss_context* c) {
         b->release();
     for (DevBuf& b : c->post_pool) b.release();
     if (c->ev_ok)
-        for (int i = 0; i < 16; ++i) (void)hipEventDestroy(c->ev[i]);
+        for (int i = 0; i < 18; ++i) (void)hipEventDestroy(c->ev[i]);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
 }

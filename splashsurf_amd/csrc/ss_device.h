@@ -34,6 +34,11 @@ enum : int { SS_ARITH_GENERIC = 0, SS_ARITH_FAST = 1, SS_ARITH_SIMD = 2, SS_ARIT
 
 // candidate particles (4-byte index keys) held in LDS per pass of the large-tile splat kernel
 template <class R> struct SSTileCap { static constexpr int value = 8192; };
+// tile entries one wave of the wave-per-block splat kernel holds in LDS (k_splat_fused); blocks with more candidates take the arena path
+template <class R>
+struct SSWaveChunk {
+    static constexpr int value = sizeof(R) == 4 ? 192 : 128;  // whole 64-entry batches
+};
 // Tiles of SS_WTILE < n <= SS_SORT_TILE_MAX entries are written by k_splat_gather_large in scan order with their particle indices;
 // k_splat_accumulate_list orders them in LDS, and only for the blocks that need an exact sum.
 #define SS_SORT_TILE_MAX 4096

@@ -78,7 +78,7 @@ struct ss_context {
     DevBuf nb_count, nb_tmp;
     DevBuf own_flag;  // per subdomain copy: owned flag, its scan, the list of owned copies
     DevBuf member_count, copy_offset, sub_flag, sub_rank, occ_sub, ckeys_a, ckeys_b, cvals_a, cidx, cpos, cell_count2, cell_start2;
-    hipEvent_t ev[16];  // 0..9 stage boundaries, 10/11 start of phase 2, 12..15 inside the splat
+    hipEvent_t ev[18];  // 0..9 stage boundaries, 10/11 start of phase 2, 12..15 inside the splat, 16/17 around the arena-path gather
     // the two-pass splat pays off when enough sub-blocks get certified 'inside' (bulk fluid); thin structures do not -- decided per
     // workload from the previous call's statistics, re-probed now and then
     uint64_t early_key = 0;

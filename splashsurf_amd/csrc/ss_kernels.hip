@@ -8,7 +8,7 @@
 //   K2  dense_subdomains.rs:496-646 + neighborhood_search.rs:345-438 + density_map.rs:150-186
 //                                                                        -> k_classify_count, k_emit_copies, k_density_sub
 //   K3  dense_subdomains.rs:784-847 / :991-1133 (density_grid_loop_scalar / _avx)
-//                                                                        -> k_mark_blocks, k_splat_bounds, k_splat_gather[_large], k_splat_accumulate_w / _list, k_select_redo
+//                                                                        -> k_mark_blocks, k_splat_fused, k_select_redo (+ k_splat_bounds, k_splat_gather[_large], k_splat_accumulate_list for over-dense blocks)
 //   K4  dense_subdomains.rs:1470-1553 (triangulate_cell) classification   -> k_mark_mc_blocks, k_mc_neighbours, k_mc_count
 //   K5  same, vertex/triangle emission + dense_subdomains.rs:1603-1749    -> k_mc_emit
 //
@@ -701,28 +701,26 @@ void ss_launch_compact_blocks(const uint32_t* flag, const uint32_t* rank, uint32
 // =====================================================================================================
 // K3: level-set splat in gather form.
 //
-// Work unit: one active block of 8x8x8 grid points.
-//   1. bounds  (k_splat_bounds, one thread per block): the (x, y) rows of search cells touching the dilated block box are
-//      contiguous runs of the cell-sorted particle array; their total length (rows trimmed to the sphere's z extent) bounds the
-//      block's tile size from above at the price of two table look-ups per row.  An exclusive scan of the bounds gives every
-//      block its range in ONE tile arena (no fixed slots, no size limit per block; only the entries in use are touched).
-//   2. gather (ONE WAVE per block, k_splat_gather): the wave streams the rows, tests every particle against the box spanned by
-//      the block's points, compacts the survivors into LDS and writes their payload (x, y, z, V) and particle indices to the
-//      block's arena range.  The reference sums per point in ascending ORIGINAL particle index (sorted per-subdomain particle
-//      lists, dense_subdomains.rs:476-488), but most blocks never need the order (step 3), so tiles of up to SSWaveChunk entries
-//      stay in scan order; tiles up to SS_WTILE entries are rank-sorted by the wave.  More (over-dense input): one 512-thread
-//      workgroup per block (k_splat_gather_large: scan order up to SS_SORT_TILE_MAX entries, beyond that up to SSTileCap index
-//      keys in LDS per pass, bitonic network, several passes over ascending index ranges found by bisection, so any input density
-//      stays exact).
-//   3. accumulate: ONE WAVE per block (k_splat_accumulate_w) walks the eight 4x4x4 sub-blocks of the block, lane l = point
-//      ((l>>4)&3, (l>>2)&3, l&3).  Per sub-block, phase A tests 64 tile entries at once against the sub-block's box (ballot) and
-//      phase B walks the survivors, every lane adding its point's term.  First a LOWER BOUND from the entries close to the
-//      sub-block (any order, cheap arithmetic): if it exceeds the threshold at all 64 points the sub-block is certified to lie
-//      inside the surface and neither evaluated nor stored.  Otherwise the wave orders the tile (splat_sort_tile) and evaluates
-//      G += V * W(|x - p|) in the reference's order and arithmetic (dense_subdomains.rs:828-841 / :1077-1107, the ARITH template
-//      parameter).  Certified sub-blocks with a point next to a grid point outside the surface are evaluated by a second launch
-//      (k_select_redo): those are the values marching cubes interpolates with.  Tiles over SSWaveChunk entries take
-//      k_splat_accumulate_list: a 512-thread workgroup per block, wave w = sub-block w, the tile streamed through LDS in chunks.
+// Work unit: one active block of 8x8x8 grid points; ONE WAVE per block (k_splat_fused), lane l = point ((l>>4)&3, (l>>2)&3, l&3)
+// of the current 4x4x4 sub-block.
+//   1. gather: the (x, y) rows of search cells touching the dilated block box are contiguous runs of the cell-sorted particle
+//      array (rows trimmed to the sphere's z extent); the wave streams them, tests every particle against the box spanned by the
+//      block's points and keeps the survivors -- payload (x, y, z, V) and particle index -- in LDS, in scan order.
+//   2. certify: for each of the eight sub-blocks a LOWER BOUND of the level set from the entries close to the sub-block (any
+//      order, cheap arithmetic; phase A tests 64 tile entries at once against the sub-block's box, phase B walks the survivors,
+//      every lane adding its point's term).  If it exceeds the threshold at all 64 points the sub-block lies inside the surface and
+//      is neither evaluated nor stored.
+//   3. evaluate: if sub-blocks remain, the wave orders the tile by ORIGINAL particle index (splat_sort_tile) -- the reference's
+//      per-point summation order (sorted per-subdomain particle lists, dense_subdomains.rs:476-488) -- and evaluates
+//      G += V * W(|x - p|) in the reference's arithmetic (dense_subdomains.rs:828-841 / :1077-1107, the ARITH template parameter).
+//   4. Certified sub-blocks with a point next to a grid point outside the surface are evaluated by a second launch over a list
+//      (k_select_redo): those are the values marching cubes interpolates with.
+// A block with more candidates than a wave holds (SSWaveChunk; over-dense input) takes the ARENA PATH instead: k_splat_bounds (an
+// upper bound of the tile size from the row lengths) -> exclusive scan = offsets in one tile arena -> k_splat_gather (one wave per
+// block, tiles up to SS_WTILE entries, rank-sorted) / k_splat_gather_large (512 threads per block: scan order up to
+// SS_SORT_TILE_MAX entries, beyond that index keys in LDS, bitonic network, several passes over ascending index ranges found by
+// bisection, so any input density stays exact) -> k_splat_accumulate_list (512 threads per block, wave w = sub-block w, the tile
+// streamed through LDS in chunks, the same certify / order / evaluate steps).
 // =====================================================================================================
 __global__ __launch_bounds__(256) void k_verify_fast_div(float h, float rh, uint32_t* __restrict__ bad) {
     // all significands of the binade [2^e, 2^(e+1)) that contains h
@@ -824,7 +822,7 @@ __device__ __forceinline__ bool splat_row_z_range(const SSDevT<R>& P, int kx, in
 }
 
 // ---- one wave visits every particle of the search-cell rows overlapping a block's dilated box -------------------------------
-// f(inside, src, id) is called in lock-step for 64 candidates at a time (inside = within reach of the block's points, src =
+// f(inside, src, id, pv) is called in lock-step for 64 candidates at a time (inside = within reach of the block's points, src =
 // position in the cell-sorted arrays, id = original particle index if NEED_ID).  Rows are handled 64 at a time (a block
 // overlaps more than 64 rows only when the cube size approaches the support radius).
 template <class R, bool NEED_ID, class F>
@@ -861,6 +859,7 @@ __device__ __forceinline__ void splat_wave_scan(const SSDevT<R>& P, const ss_rea
             const uint32_t q = q0 + (uint32_t)lane;
             bool inside = false;
             uint32_t src = 0, id = 0;
+            ss_real4<R> pv = ss_make4(R(0.0), R(0.0), R(0.0), R(0.0));
             if (q < total) {
                 int lo = 0, hi = nb - 1;  // last row r with row_prefix[r] <= q
                 while (lo < hi) {
@@ -871,11 +870,11 @@ __device__ __forceinline__ void splat_wave_scan(const SSDevT<R>& P, const ss_rea
                         hi = mid - 1;
                 }
                 src = s_row_start[lo] + (q - s_row_prefix[lo]);
-                const ss_real4<R> pv = posvol[src];
+                pv = posvol[src];
                 if (NEED_ID) id = perm[src];
                 inside = ss_within_reach_of_block<R>(P, pv, plo, phi);
             }
-            f(inside, src, id);
+            f(inside, src, id, pv);
         }
         ss_wave_lds_sync();  // the next batch overwrites the row tables
     }
@@ -909,11 +908,12 @@ __device__ __forceinline__ bool splat_wave_block(uint32_t n_active, uint32_t* lo
 // places every block's tile in the arena; only counts[b] <= bound[b] entries of a range are ever written or read.
 template <class R>
 __global__ __launch_bounds__(256) void k_splat_bounds(SSDevT<R> P, const uint32_t* __restrict__ cell_start, const uint32_t* __restrict__ active_xyz, uint32_t n_active,
-                                                      uint32_t* __restrict__ bound) {
+                                                      const uint32_t* __restrict__ counts, uint32_t* __restrict__ bound) {
     const uint32_t logical = blockIdx.x * blockDim.x + threadIdx.x;
     if (logical > n_active) return;
     uint32_t u = 0;
-    if (logical < n_active) {
+    // only the blocks k_splat_fused handed on get a tile in the arena (counts: their candidates)
+    if (logical < n_active && counts[logical] > (uint32_t)SSWaveChunk<R>::value) {
         const int b3[3] = {(int)active_xyz[3 * (size_t)logical], (int)active_xyz[3 * (size_t)logical + 1], (int)active_xyz[3 * (size_t)logical + 2]};
         R plo[3], phi[3];
         int klo[3], khi[3];
@@ -928,11 +928,6 @@ __global__ __launch_bounds__(256) void k_splat_bounds(SSDevT<R> P, const uint32_
     bound[logical] = u;  // entry n_active: 0, so that the exclusive scan ends with the arena size
 }
 
-// tile entries one wave of the wave-per-block accumulate kernel holds in LDS (k_splat_accumulate_w)
-template <class R>
-struct SSWaveChunk {
-    static constexpr int value = sizeof(R) == 4 ? 192 : 128;  // whole 64-entry batches
-};
 
 template <class R, int E>
 __device__ __forceinline__ void splat_rank_and_write(const uint32_t* s_idx, const uint32_t* s_src, uint32_t count, int lane, const ss_real4<R>* __restrict__ posvol,
@@ -970,13 +965,17 @@ __global__ __launch_bounds__(256) void k_splat_gather(SSDevT<R> P, const ss_real
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     uint32_t logical;
     if (!splat_wave_block(n_active, &logical)) return;
+    if (counts[logical] <= (uint32_t)SSWaveChunk<R>::value) {  // k_splat_fused evaluated this block without a tile in the arena
+        if (lane == 0) large_flag[logical] = 0u;
+        return;
+    }
     const int b3[3] = {(int)active_xyz[3 * (size_t)logical], (int)active_xyz[3 * (size_t)logical + 1], (int)active_xyz[3 * (size_t)logical + 2]};
     R plo[3], phi[3];
     int klo[3], khi[3];
     uint32_t count = 0;
     if (splat_block_box<R>(P, b3, plo, phi, klo, khi)) {
         const unsigned long long below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-        splat_wave_scan<R, true>(P, posvol, perm, cell_start, klo, khi, plo, phi, s_row_start[w], s_row_prefix[w], lane, [&](bool inside, uint32_t src, uint32_t id) {
+        splat_wave_scan<R, true>(P, posvol, perm, cell_start, klo, khi, plo, phi, s_row_start[w], s_row_prefix[w], lane, [&](bool inside, uint32_t src, uint32_t id, const ss_real4<R>&) {
             const unsigned long long m = __ballot(inside);
             const uint32_t pos = count + (uint32_t)__popcll(m & below);
             if (inside && pos < (uint32_t)SS_WTILE) {
@@ -1592,10 +1591,12 @@ struct SplatAccWaveShared {
 template <class R>
 __device__ __forceinline__ void splat_sort_tile(SplatAccWaveShared<R>& sh, const uint32_t* __restrict__ tile_idx, int n_tile, int lane) {
     constexpr int E = SSWaveChunk<R>::value / 64;
+    if (tile_idx) {  // (the fused kernel has the indices in LDS already)
 #pragma unroll
-    for (int e = 0; e < E; ++e)
-        if (lane + 64 * e < n_tile) sh.idx[lane + 64 * e] = tile_idx[lane + 64 * e];
-    ss_wave_lds_sync();
+        for (int e = 0; e < E; ++e)
+            if (lane + 64 * e < n_tile) sh.idx[lane + 64 * e] = tile_idx[lane + 64 * e];
+        ss_wave_lds_sync();
+    }
     uint32_t my[E], rank[E];
     ss_real4<R> pv[E];
 #pragma unroll
@@ -1617,7 +1618,8 @@ __device__ __forceinline__ void splat_sort_tile(SplatAccWaveShared<R>& sh, const
     ss_wave_lds_sync();
 }
 
-template <class R, int ARITH, bool EARLY>
+// STAGED: the tile (payload and particle indices) is in sh.pay / sh.idx already (k_splat_fused); otherwise it is fetched from the arena
+template <class R, int ARITH, bool EARLY, bool STAGED = false>
 __device__ __forceinline__ void splat_accumulate_block_wave(SplatAccWaveShared<R>& sh, const SSDevT<R>& P, uint32_t logical, int n_tile, const ss_real4<R>* __restrict__ tile,
                                                             const uint32_t* __restrict__ tile_idx,
                                                             const uint32_t* __restrict__ active_xyz, R* __restrict__ G, ss_real2<R>* __restrict__ blk_minmax,
@@ -1630,14 +1632,15 @@ __device__ __forceinline__ void splat_accumulate_block_wave(SplatAccWaveShared<R
 #pragma unroll
     for (int k = 0; k < CH / 64; ++k) {
         stage[k] = ss_make4(R(0.0), R(0.0), R(0.0), R(0.0));
-        if (lane + 64 * k < n_tile) stage[k] = tile[lane + 64 * k];
+        if constexpr (!STAGED)
+            if (lane + 64 * k < n_tile) stage[k] = tile[lane + 64 * k];
     }
     const int bx = __builtin_amdgcn_readfirstlane((int)active_xyz[3 * (size_t)logical]);
     const int by = __builtin_amdgcn_readfirstlane((int)active_xyz[3 * (size_t)logical + 1]);
     const int bz = __builtin_amdgcn_readfirstlane((int)active_xyz[3 * (size_t)logical + 2]);
     const int ox = (lane >> 4) & 3, oy = (lane >> 2) & 3, oz = lane & 3;
     R* gblock = G + (size_t)logical * SS_BLOCK_POINTS + (size_t)SS_BLOCK_OFFSET(ox, oy, oz);  // + 64 sb: SS_BLOCK_OFFSET
-    ss_wave_lds_sync();  // the previous block's reads of pay are done
+    if constexpr (!STAGED) ss_wave_lds_sync();  // the previous block's reads of pay are done
     // per axis and half of the block (h = 0, 1): the sub-block's box [lo, hi] and this lane's point coordinate -- global point
     // coordinates as in uniform_grid.rs:418-425 on the GLOBAL grid (dense_subdomains.rs:817-826); the SIMD loop of the reference
     // forms z with one fma (:1069), x and y like the scalar loop (:1113-1114)
@@ -1663,11 +1666,16 @@ __device__ __forceinline__ void splat_accumulate_block_wave(SplatAccWaveShared<R
     if constexpr (EARLY) {
 #pragma unroll
         for (int k = 0; k < CH / 64; ++k)
-            if (lane + 64 * k < n_tile) sh.near[lane + 64 * k] = (uint8_t)splat_near_masks<R>(P, stage[k], lo, hi, P.R2near);
+            if (lane + 64 * k < n_tile) {
+                if constexpr (STAGED) stage[k] = sh.pay[lane + 64 * k];
+                sh.near[lane + 64 * k] = (uint8_t)splat_near_masks<R>(P, stage[k], lo, hi, P.R2near);
+            }
     }
+    if constexpr (!STAGED) {
 #pragma unroll
-    for (int k = 0; k < CH / 64; ++k)
-        if (lane + 64 * k < n_tile) sh.pay[lane + 64 * k] = stage[k];
+        for (int k = 0; k < CH / 64; ++k)
+            if (lane + 64 * k < n_tile) sh.pay[lane + 64 * k] = stage[k];
+    }
     ss_wave_lds_sync();
     // second pass: the sub-blocks the first pass certified (their values were never stored, see below)
     const uint32_t certified_before = (!EARLY && wave_mask != 0xFFu) ? (uint32_t)__builtin_amdgcn_readfirstlane((int)trunc[logical]) : 0u;
@@ -1711,7 +1719,7 @@ __device__ __forceinline__ void splat_accumulate_block_wave(SplatAccWaveShared<R
         if constexpr (EARLY) faces |= (unsigned long long)splat_face_bits(__ballot(point_valid && !(val > P.threshold))) << (6 * sb);
     }
     if (need) {
-        splat_sort_tile<R>(sh, tile_idx, n_tile, lane);
+        splat_sort_tile<R>(sh, STAGED ? nullptr : tile_idx, n_tile, lane);
 #pragma unroll 1
         for (int sb = 0; sb < 8; ++sb) {
             if (!((need >> sb) & 1u)) continue;
@@ -1748,35 +1756,58 @@ __device__ __forceinline__ void splat_accumulate_block_wave(SplatAccWaveShared<R
     }
 }
 
-// list == nullptr: every active block; otherwise the blocks of the device-side list, the sub-blocks in redo_mask only.  Blocks
-// whose tile does not fit a wave's chunk are appended to big[1..] (count in big[0]) for k_splat_accumulate_list.
+// Gather and accumulate in one kernel, ONE WAVE per block: the wave scans the search-cell rows around the block like
+// k_splat_gather, keeps the candidates within reach in LDS (payload and particle index, scan order) and goes straight on to
+// the classification / ordering / exact sums of splat_accumulate_block_wave -- the tiles of ordinary blocks never pass through
+// HBM (S10M-tank: 3.4 GB written and 2.9 GB read back by the two-kernel version) and need no arena.  A block with more than
+// SSWaveChunk candidates only reports its count and is appended to big[1..] (count in big[0]): those take the arena path
+// (k_splat_bounds, k_splat_gather / _large, k_splat_accumulate_list).  list == nullptr: every active block; otherwise the blocks
+// of the device-side list, the sub-blocks in redo_mask only.
 template <class R, int ARITH, bool EARLY>
-__global__ __launch_bounds__(64) void k_splat_accumulate_w(SSDevT<R> P, const ss_real4<R>* __restrict__ arena, const uint32_t* __restrict__ arena_idx,
-                                                            const unsigned long long* __restrict__ tile_off,
-                                                            const uint32_t* __restrict__ counts, const uint32_t* __restrict__ active_xyz, uint32_t n_active,
-                                                            const uint32_t* __restrict__ list, const uint32_t* __restrict__ n_list_dev,
-                                                            const uint32_t* __restrict__ redo_mask, R* __restrict__ G, ss_real2<R>* __restrict__ blk_minmax,
-                                                            uint32_t* __restrict__ trunc, unsigned long long* __restrict__ facebits, uint32_t* __restrict__ big) {
-    // one-wave workgroups: the blocks of a larger workgroup differ widely in cost (certified inside / at the surface), and its
-    // wave slots and LDS are only released when the slowest one is done
+__global__ __launch_bounds__(64) void k_splat_fused(SSDevT<R> P, const ss_real4<R>* __restrict__ posvol, const uint32_t* __restrict__ perm,
+                                                    const uint32_t* __restrict__ cell_start, const uint32_t* __restrict__ active_xyz, uint32_t n_active,
+                                                    const uint32_t* __restrict__ list, const uint32_t* __restrict__ n_list_dev,
+                                                    const uint32_t* __restrict__ redo_mask, R* __restrict__ G, ss_real2<R>* __restrict__ blk_minmax,
+                                                    uint32_t* __restrict__ trunc, unsigned long long* __restrict__ facebits, uint32_t* __restrict__ counts,
+                                                    uint32_t* __restrict__ big) {
+    constexpr int CH = SSWaveChunk<R>::value;
     __shared__ SplatAccWaveShared<R> sh;
+    static_assert(sizeof(sh.wl) >= 128 * sizeof(uint32_t), "the row tables of the scan live in the list buffer");
+    uint32_t* s_row_start = reinterpret_cast<uint32_t*>(sh.wl);  // (wl is not in use during the scan)
+    uint32_t* s_row_prefix = s_row_start + 64;
     const int lane = threadIdx.x;
     const uint32_t n = list ? *n_list_dev : n_active;
     const uint32_t n_slots = ss_xcd_chunked_grid_dev(n);
+    const unsigned long long below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
     for (uint32_t w = blockIdx.x; w < n_slots; w += gridDim.x) {
         const uint32_t it = ss_xcd_chunked_group(w);
         if (it >= n) continue;
         const uint32_t logical = __builtin_amdgcn_readfirstlane(list ? list[it] : it);
-        const int n_tile = __builtin_amdgcn_readfirstlane((int)counts[logical]);
-        if (n_tile > SSWaveChunk<R>::value) {
+        const int b3[3] = {(int)active_xyz[3 * (size_t)logical], (int)active_xyz[3 * (size_t)logical + 1], (int)active_xyz[3 * (size_t)logical + 2]};
+        R plo[3], phi[3];
+        int klo[3], khi[3];
+        uint32_t count = 0;
+        ss_wave_lds_sync();  // the previous block's reads of the tile are done
+        if (splat_block_box<R>(P, b3, plo, phi, klo, khi)) {
+            splat_wave_scan<R, true>(P, posvol, perm, cell_start, klo, khi, plo, phi, s_row_start, s_row_prefix, lane,
+                                     [&](bool inside, uint32_t, uint32_t id, const ss_real4<R>& pv) {
+                                         const unsigned long long m = __ballot(inside);
+                                         const uint32_t pos = count + (uint32_t)__popcll(m & below);
+                                         if (inside && pos < (uint32_t)CH) {
+                                             sh.pay[pos] = pv;
+                                             sh.idx[pos] = id;
+                                         }
+                                         count += (uint32_t)__popcll(m);
+                                     });
+        }
+        if (!list && lane == 0) counts[logical] = count;  // tile entries (statistics; the arena path of the large blocks)
+        if (count > (uint32_t)CH) {
             if (lane == 0) big[1u + atomicAdd(&big[0], 1u)] = logical;
             continue;
         }
-        const unsigned long long off = tile_off[logical];
-        const unsigned long long off_u = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(off >> 32)) << 32) |
-                                         (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)off);
-        splat_accumulate_block_wave<R, ARITH, EARLY>(sh, P, logical, n_tile, arena + off_u, arena_idx + off_u, active_xyz, G, blk_minmax, trunc, facebits,
-                                                     redo_mask ? __builtin_amdgcn_readfirstlane(redo_mask[logical]) : 0xFFu);
+        ss_wave_lds_sync();
+        splat_accumulate_block_wave<R, ARITH, EARLY, true>(sh, P, logical, (int)count, nullptr, nullptr, active_xyz, G, blk_minmax, trunc, facebits,
+                                                           redo_mask ? __builtin_amdgcn_readfirstlane(redo_mask[logical]) : 0xFFu);
     }
 }
 
@@ -1852,8 +1883,8 @@ __global__ __launch_bounds__(256) void k_select_redo(SSDevT<R> P, const uint32_t
 }
 
 template <class R>
-void ss_launch_splat_bounds(const SSDevT<R>& P, const uint32_t* cell_start, const uint32_t* active_xyz, uint32_t n_active, uint32_t* bound, hipStream_t st) {
-    hipLaunchKernelGGL(k_splat_bounds<R>, dim3((n_active + 1u + 255u) / 256u), dim3(256), 0, st, P, cell_start, active_xyz, n_active, bound);
+void ss_launch_splat_bounds(const SSDevT<R>& P, const uint32_t* cell_start, const uint32_t* active_xyz, uint32_t n_active, const uint32_t* counts, uint32_t* bound, hipStream_t st) {
+    hipLaunchKernelGGL(k_splat_bounds<R>, dim3((n_active + 1u + 255u) / 256u), dim3(256), 0, st, P, cell_start, active_xyz, n_active, counts, bound);
 }
 
 template <class R>
@@ -1874,42 +1905,62 @@ void ss_launch_splat_gather_large(const SSDevT<R>& P, const ss_real4<R>* posvol,
                        n_large_dev, counts, tile_off, arena, arena_idx);
 }
 
-// list == nullptr: first pass over all n_active blocks (early exit unless full_levelset); otherwise the second pass over the
-// device-side list of blocks with certified sub-blocks that marching cubes reads.  `big`: n_active + 1 words of scratch (the
-// blocks handed from the wave-per-block kernel to the workgroup-per-block kernel).
+#define SS_SPLAT_DISPATCH(LAUNCH)                                  \
+    do {                                                           \
+        if constexpr (sizeof(R) == 4) {                            \
+            switch (P.arith) {                                     \
+                case SS_ARITH_FAST: LAUNCH(SS_ARITH_FAST); return; \
+                case SS_ARITH_SIMD: LAUNCH(SS_ARITH_SIMD); return; \
+                case SS_ARITH_SIMD_LEAN: LAUNCH(SS_ARITH_SIMD_LEAN); return; \
+                case SS_ARITH_SIMD_HW: LAUNCH(SS_ARITH_SIMD_HW); return;     \
+                default: break;                                    \
+            }                                                      \
+        }                                                          \
+        LAUNCH(SS_ARITH_GENERIC);                                  \
+    } while (0)
+
+// The splat of the ordinary blocks (k_splat_fused).  list == nullptr: first pass over all n_active blocks (lower-bound
+// certification unless full_levelset); otherwise the second pass over the device-side list of blocks with certified sub-blocks that
+// marching cubes reads.  `big`: n_active + 1 words -- the count and the list of the blocks with more than SSWaveChunk candidates,
+// which ss_launch_splat_accumulate_big finishes; counts: tile size per block (first pass).
 template <class R>
-void ss_launch_splat_accumulate(const SSDevT<R>& P, const ss_real4<R>* arena, const uint32_t* arena_idx, const unsigned long long* tile_off, const uint32_t* counts,
-                                const uint32_t* active_xyz, uint32_t n_active, R* G, ss_real2<R>* blk_minmax, uint32_t* trunc, bool full_levelset,
-                                const uint32_t* list, const uint32_t* n_list_dev, const uint32_t* redo_mask, unsigned long long* facebits, uint32_t* big, hipStream_t st) {
+void ss_launch_splat_fused(const SSDevT<R>& P, const ss_real4<R>* posvol, const uint32_t* perm, const uint32_t* cell_start, const uint32_t* active_xyz, uint32_t n_active,
+                           R* G, ss_real2<R>* blk_minmax, uint32_t* trunc, bool full_levelset, const uint32_t* list, const uint32_t* n_list_dev,
+                           const uint32_t* redo_mask, unsigned long long* facebits, uint32_t* counts, uint32_t* big, hipStream_t st) {
     if (!n_active) return;
     (void)hipMemsetAsync(big, 0, 4, st);
-    const dim3 grid(list ? 32768u : ss_xcd_chunked_grid(n_active)), lgrid(2048);
-#define SS_ACC_E(A, E)                                                                                                                                                  \
-    do {                                                                                                                                                                \
-        hipLaunchKernelGGL((k_splat_accumulate_w<R, A, E>), grid, dim3(64), 0, st, P, arena, arena_idx, tile_off, counts, active_xyz, n_active, list, n_list_dev, redo_mask, G,  \
-                           blk_minmax, trunc, facebits, big);                                                                                                                  \
-        hipLaunchKernelGGL((k_splat_accumulate_list<R, A, E>), lgrid, dim3(512), 0, st, P, arena, arena_idx, tile_off, counts, active_xyz, big + 1, big, redo_mask, G, blk_minmax, \
-                           trunc, facebits);                                                                                                                                     \
+    const dim3 grid(list ? 32768u : ss_xcd_chunked_grid(n_active));
+#define SS_FUSED(A)                                                                                                                                          \
+    do {                                                                                                                                                     \
+        if (list || full_levelset)                                                                                                                           \
+            hipLaunchKernelGGL((k_splat_fused<R, A, false>), grid, dim3(64), 0, st, P, posvol, perm, cell_start, active_xyz, n_active, list, n_list_dev,    \
+                               redo_mask, G, blk_minmax, trunc, facebits, counts, big);                                                                      \
+        else                                                                                                                                                 \
+            hipLaunchKernelGGL((k_splat_fused<R, A, true>), grid, dim3(64), 0, st, P, posvol, perm, cell_start, active_xyz, n_active, list, n_list_dev,     \
+                               redo_mask, G, blk_minmax, trunc, facebits, counts, big);                                                                      \
     } while (0)
-#define SS_ACC(A)                        \
-    do {                                 \
-        if (list || full_levelset)       \
-            SS_ACC_E(A, false);          \
-        else                             \
-            SS_ACC_E(A, true);           \
+    SS_SPLAT_DISPATCH(SS_FUSED);
+#undef SS_FUSED
+}
+
+// The blocks k_splat_fused handed on (big[0] of them, big[1..]): their tiles are in the arena (k_splat_gather / _large), one
+// workgroup per block.  second_pass: only the sub-blocks in redo_mask.
+template <class R>
+void ss_launch_splat_accumulate_big(const SSDevT<R>& P, const ss_real4<R>* arena, const uint32_t* arena_idx, const unsigned long long* tile_off, const uint32_t* counts,
+                                    const uint32_t* active_xyz, R* G, ss_real2<R>* blk_minmax, uint32_t* trunc, bool full_levelset, bool second_pass,
+                                    const uint32_t* redo_mask, unsigned long long* facebits, const uint32_t* big, hipStream_t st) {
+    const dim3 lgrid(2048);
+#define SS_BIG(A)                                                                                                                                              \
+    do {                                                                                                                                                       \
+        if (second_pass || full_levelset)                                                                                                                      \
+            hipLaunchKernelGGL((k_splat_accumulate_list<R, A, false>), lgrid, dim3(512), 0, st, P, arena, arena_idx, tile_off, counts, active_xyz, big + 1, big, \
+                               second_pass ? redo_mask : nullptr, G, blk_minmax, trunc, facebits);                                                            \
+        else                                                                                                                                                   \
+            hipLaunchKernelGGL((k_splat_accumulate_list<R, A, true>), lgrid, dim3(512), 0, st, P, arena, arena_idx, tile_off, counts, active_xyz, big + 1, big, \
+                               nullptr, G, blk_minmax, trunc, facebits);                                                                                      \
     } while (0)
-    if constexpr (sizeof(R) == 4) {
-        switch (P.arith) {
-            case SS_ARITH_FAST: SS_ACC(SS_ARITH_FAST); return;
-            case SS_ARITH_SIMD: SS_ACC(SS_ARITH_SIMD); return;
-            case SS_ARITH_SIMD_LEAN: SS_ACC(SS_ARITH_SIMD_LEAN); return;
-            case SS_ARITH_SIMD_HW: SS_ACC(SS_ARITH_SIMD_HW); return;
-            default: break;
-        }
-    }
-    SS_ACC(SS_ARITH_GENERIC);
-#undef SS_ACC
-#undef SS_ACC_E
+    SS_SPLAT_DISPATCH(SS_BIG);
+#undef SS_BIG
 }
 
 template <class R>
@@ -2300,15 +2351,17 @@ template void ss_launch_mark_blocks<float>(const SSDevT<float>& P, const uint32_
 template void ss_launch_mark_blocks<double>(const SSDevT<double>& P, const uint32_t* cell_start, uint32_t ncells, uint32_t* block_flag, hipStream_t st);
 template void ss_launch_mark_mc_blocks<float>(const SSDevT<float>& P, const uint32_t* block_slot, const ss_real2<float>* blk_minmax, uint32_t nblocks, uint32_t* mc_flag, hipStream_t st);
 template void ss_launch_mark_mc_blocks<double>(const SSDevT<double>& P, const uint32_t* block_slot, const ss_real2<double>* blk_minmax, uint32_t nblocks, uint32_t* mc_flag, hipStream_t st);
-template void ss_launch_splat_bounds<float>(const SSDevT<float>& P, const uint32_t* cell_start, const uint32_t* active_xyz, uint32_t n_active, uint32_t* bound, hipStream_t st);
+template void ss_launch_splat_bounds<float>(const SSDevT<float>& P, const uint32_t* cell_start, const uint32_t* active_xyz, uint32_t n_active, const uint32_t* counts, uint32_t* bound, hipStream_t st);
 template void ss_launch_splat_gather<float>(const SSDevT<float>& P, const ss_real4<float>* posvol, const uint32_t* perm, const uint32_t* cell_start, const uint32_t* active_xyz, uint32_t n_active, const unsigned long long* tile_off, ss_real4<float>* arena, uint32_t* arena_idx, uint32_t* counts, uint32_t* large_flag, hipStream_t st);
 template void ss_launch_splat_gather_large<float>(const SSDevT<float>& P, const ss_real4<float>* posvol, const ss_real4<float>* posvol_by_index, const uint32_t* perm, const uint32_t* cell_start, const uint32_t* active_xyz, const uint32_t* large_list, const uint32_t* n_large_dev, const uint32_t* counts, const unsigned long long* tile_off, ss_real4<float>* arena, uint32_t* arena_idx, hipStream_t st);
-template void ss_launch_splat_bounds<double>(const SSDevT<double>& P, const uint32_t* cell_start, const uint32_t* active_xyz, uint32_t n_active, uint32_t* bound, hipStream_t st);
+template void ss_launch_splat_bounds<double>(const SSDevT<double>& P, const uint32_t* cell_start, const uint32_t* active_xyz, uint32_t n_active, const uint32_t* counts, uint32_t* bound, hipStream_t st);
 template void ss_launch_splat_gather<double>(const SSDevT<double>& P, const ss_real4<double>* posvol, const uint32_t* perm, const uint32_t* cell_start, const uint32_t* active_xyz, uint32_t n_active, const unsigned long long* tile_off, ss_real4<double>* arena, uint32_t* arena_idx, uint32_t* counts, uint32_t* large_flag, hipStream_t st);
 template void ss_launch_splat_gather_large<double>(const SSDevT<double>& P, const ss_real4<double>* posvol, const ss_real4<double>* posvol_by_index, const uint32_t* perm, const uint32_t* cell_start, const uint32_t* active_xyz, const uint32_t* large_list, const uint32_t* n_large_dev, const uint32_t* counts, const unsigned long long* tile_off, ss_real4<double>* arena, uint32_t* arena_idx, hipStream_t st);
-template void ss_launch_splat_accumulate<float>(const SSDevT<float>& P, const ss_real4<float>* arena, const uint32_t* arena_idx, const unsigned long long* tile_off, const uint32_t* counts, const uint32_t* active_xyz, uint32_t n_active, float* G, ss_real2<float>* blk_minmax, uint32_t* trunc, bool full_levelset, const uint32_t* list, const uint32_t* n_list_dev, const uint32_t* redo_mask, unsigned long long* facebits, uint32_t* big, hipStream_t st);
+template void ss_launch_splat_fused<float>(const SSDevT<float>& P, const ss_real4<float>* posvol, const uint32_t* perm, const uint32_t* cell_start, const uint32_t* active_xyz, uint32_t n_active, float* G, ss_real2<float>* blk_minmax, uint32_t* trunc, bool full_levelset, const uint32_t* list, const uint32_t* n_list_dev, const uint32_t* redo_mask, unsigned long long* facebits, uint32_t* counts, uint32_t* big, hipStream_t st);
+template void ss_launch_splat_accumulate_big<float>(const SSDevT<float>& P, const ss_real4<float>* arena, const uint32_t* arena_idx, const unsigned long long* tile_off, const uint32_t* counts, const uint32_t* active_xyz, float* G, ss_real2<float>* blk_minmax, uint32_t* trunc, bool full_levelset, bool second_pass, const uint32_t* redo_mask, unsigned long long* facebits, const uint32_t* big, hipStream_t st);
 template void ss_launch_select_redo<float>(const SSDevT<float>& P, const uint32_t* active_xyz, uint32_t n_active, const uint32_t* block_slot, const uint32_t* trunc, const unsigned long long* facebits, uint32_t* redo_mask, hipStream_t st);
-template void ss_launch_splat_accumulate<double>(const SSDevT<double>& P, const ss_real4<double>* arena, const uint32_t* arena_idx, const unsigned long long* tile_off, const uint32_t* counts, const uint32_t* active_xyz, uint32_t n_active, double* G, ss_real2<double>* blk_minmax, uint32_t* trunc, bool full_levelset, const uint32_t* list, const uint32_t* n_list_dev, const uint32_t* redo_mask, unsigned long long* facebits, uint32_t* big, hipStream_t st);
+template void ss_launch_splat_fused<double>(const SSDevT<double>& P, const ss_real4<double>* posvol, const uint32_t* perm, const uint32_t* cell_start, const uint32_t* active_xyz, uint32_t n_active, double* G, ss_real2<double>* blk_minmax, uint32_t* trunc, bool full_levelset, const uint32_t* list, const uint32_t* n_list_dev, const uint32_t* redo_mask, unsigned long long* facebits, uint32_t* counts, uint32_t* big, hipStream_t st);
+template void ss_launch_splat_accumulate_big<double>(const SSDevT<double>& P, const ss_real4<double>* arena, const uint32_t* arena_idx, const unsigned long long* tile_off, const uint32_t* counts, const uint32_t* active_xyz, double* G, ss_real2<double>* blk_minmax, uint32_t* trunc, bool full_levelset, bool second_pass, const uint32_t* redo_mask, unsigned long long* facebits, const uint32_t* big, hipStream_t st);
 template void ss_launch_select_redo<double>(const SSDevT<double>& P, const uint32_t* active_xyz, uint32_t n_active, const uint32_t* block_slot, const uint32_t* trunc, const unsigned long long* facebits, uint32_t* redo_mask, hipStream_t st);
 template void ss_launch_mc_neighbours<float>(const SSDevT<float>& P, const uint32_t* mc_xyz, uint32_t n_mc, const uint32_t* block_slot, const uint32_t* mc_slot, const uint32_t* certified, uint32_t* mc_nb, hipStream_t st);
 template void ss_launch_mc_count<float>(const SSDevT<float>& P, const float* G, const uint32_t* mc_nb, const uint32_t* mc_xyz, uint32_t n_mc, unsigned long long* masks, uint32_t* vcount, uint32_t* tcount, hipStream_t st);

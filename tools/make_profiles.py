@@ -2,7 +2,7 @@
 """Turns the raw rocprofv3 output of tools/collect_profiles.sh (gpurun_out/r02prof/) into the tracked artefacts under profiles/:
   r02_s10m_tank_simd{0,1,2}_kernel_stats.csv   `rocprofv3 --kernel-trace --stats` of `bench.py --main-only --steps 10 --warmup 2 --simd M`
   r02_pmc_s10m_tank.md                          PMC counters per launch of the splat / density kernels (separate passes)
-  splat_traffic.json                            HBM bytes and VALU instructions per launch of k_splat_accumulate, read by bench.py
+  splat_traffic.json                            HBM bytes and VALU instructions per launch of the splat kernel (k_splat_fused), read by bench.py
 FETCH_SIZE / WRITE_SIZE are reported in KiB; per /opt/skills/guides/MI355X_MICROARCH.md (HBM section) gfx950's FETCH_SIZE tallies
 the 128-B requests of wide (16 B per lane) streaming reads at 64 B, so the read side is doubled; WRITE_SIZE is taken as reported."""
 import collections
@@ -52,13 +52,14 @@ def main():
             md.append("| %s | %.3f | %.6g | %.6g | %.4g | %.2f TB/s | %.4g | %.4g | %.4g | %.4g | %.3f |" % (
                 k, ms, v.get("FETCH_SIZE", 0), v.get("WRITE_SIZE", 0), hbm, rate, v.get("SQ_INSTS_VALU", 0), v.get("SQ_INSTS_SALU", 0), v.get("SQ_INSTS_LDS", 0),
                 v.get("SQ_WAVES", 0), v.get("SQ_INSTS_VALU", 0) / slots if slots else 0.0))
-            if k.startswith("k_splat_accumulate"):
+            if k.startswith("k_splat_accumulate") or k.startswith("k_splat_fused"):
                 t = traffic["s10m_tank"].setdefault(mname, {
-                    "kernel": "k_splat_accumulate_w (first and second pass) + k_splat_accumulate_list (tiles over 192 entries)", "hbm_bytes_per_launch": 0.0, "fetch_size_bytes_reported": 0.0,
+                    "kernel": "k_splat_fused (first and second pass) + k_splat_accumulate_list (blocks with over 192 candidates)", "hbm_bytes_per_launch": 0.0, "fetch_size_bytes_reported": 0.0,
                     "write_size_bytes": 0.0, "kernel_ms_rocprof_avg": 0.0, "valu_insts_per_launch": 0.0, "launches": {},
                     "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, --kernel-include-regex 'k_splat|k_density_sub') on S10M-tank, per step = sum over the "
-                            "launches of the accumulate kernel; read side doubled per MI355X_MICROARCH.md (gfx950 FETCH_SIZE counts 128-B requests as 64 B); the "
-                            "accumulate kernel re-reads the block tiles the gather kernel wrote (DESIGN.md section 5, profiles/r02_pmc_s10m_tank.md)",
+                            "launches of the splat kernel; read side doubled per MI355X_MICROARCH.md (gfx950 FETCH_SIZE counts 128-B requests as 64 B); the "
+                            "kernel gathers every block's candidates from the cell-sorted particle array (neighbouring blocks re-read the same rows, mostly "
+                            "from L2) and writes the level-set values of the evaluated sub-blocks (DESIGN.md section 5, profiles/r02_pmc_s10m_tank.md)",
                     "valu_note": "SQ_INSTS_VALU of both launches per step (profiles/r02_pmc_s10m_tank.md); a SIMD-32 issues one wave64 VALU instruction per 2 cycles at best"})
                 t["hbm_bytes_per_launch"] += hbm
                 t["fetch_size_bytes_reported"] += v.get("FETCH_SIZE", 0.0) * 1024
