@@ -822,7 +822,7 @@ __device__ __forceinline__ bool splat_row_z_range(const SSDevT<R>& P, int kx, in
 }
 
 // ---- one wave visits every particle of the search-cell rows overlapping a block's dilated box -------------------------------
-// f(inside, src, id, pv) is called in lock-step for 64 candidates at a time (inside = within reach of the block's points, src =
+// f(inside, src, id, pv) is called in lock-step for 64 candidates at a time and returns whether the scan goes on (inside = within reach of the block's points, src =
 // position in the cell-sorted arrays, id = original particle index if NEED_ID).  Rows are handled 64 at a time (a block
 // overlaps more than 64 rows only when the cube size approaches the support radius).
 template <class R, bool NEED_ID, class F>
@@ -874,7 +874,7 @@ __device__ __forceinline__ void splat_wave_scan(const SSDevT<R>& P, const ss_rea
                 if (NEED_ID) id = perm[src];
                 inside = ss_within_reach_of_block<R>(P, pv, plo, phi);
             }
-            f(inside, src, id, pv);
+            if (!f(inside, src, id, pv)) return;  // (wave-uniform)
         }
         ss_wave_lds_sync();  // the next batch overwrites the row tables
     }
@@ -983,6 +983,7 @@ __global__ __launch_bounds__(256) void k_splat_gather(SSDevT<R> P, const ss_real
                 s_src[w][pos] = src;
             }
             count += (uint32_t)__popcll(m);
+            return true;
         });
     }
     if (lane == 0) {
@@ -1798,9 +1799,10 @@ __global__ __launch_bounds__(64) void k_splat_fused(SSDevT<R> P, const ss_real4<
                                              sh.idx[pos] = id;
                                          }
                                          count += (uint32_t)__popcll(m);
+                                         return count <= (uint32_t)CH;  // a block with more candidates takes the arena path, which counts them itself
                                      });
         }
-        if (!list && lane == 0) counts[logical] = count;  // tile entries (statistics; the arena path of the large blocks)
+        if (!list && lane == 0) counts[logical] = count;  // tile entries (statistics; > CH: the arena path recounts)
         if (count > (uint32_t)CH) {
             if (lane == 0) big[1u + atomicAdd(&big[0], 1u)] = logical;
             continue;
