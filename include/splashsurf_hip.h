@@ -150,18 +150,18 @@ typedef struct ss_stats {
     uint64_t fast_div_verified;       /* 1 if the splat used the exhaustively verified reciprocal division for this h */
     uint64_t levelset_kernel_launches;
     uint64_t bytes_device_peak;       /* HBM held by the context after this call */
-    double ms_levelset_gather;        /* part of ms_levelset: k_splat_bounds + offsets + k_splat_gather[_large] (candidate tiles of the blocks) */
-    double ms_levelset_accumulate;    /* part of ms_levelset: k_splat_accumulate_w / _list (the arithmetic; the dominant kernel), both passes */
+    double ms_levelset_gather;        /* part of ms_levelset: the arena path of over-dense blocks (k_splat_bounds, offsets, k_splat_gather[_large]); 0 without such blocks */
+    double ms_levelset_accumulate;    /* part of ms_levelset: k_splat_fused (+ k_splat_accumulate_list for over-dense blocks), both passes: the dominant kernel */
     uint64_t n_large_tile_blocks;     /* blocks whose candidate tile (> 384 entries) was ordered by the workgroup-level gather */
     uint64_t arith_mode;              /* arithmetic of the level-set accumulation that ran: 0 scalar (generic sqrt/divide), 1 scalar
                                        * (lean exact sqrt + verified reciprocal division), 2 / 3 SIMD with correctly rounded sqrt
                                        * (generic / lean), 4 SIMD with v_sqrt_f32 */
-    uint64_t bytes_tile_arena;        /* bytes of index-ordered candidate tiles written by the gather and re-read by the accumulate kernel */
-    uint64_t bytes_tile_arena_reserved; /* size of the arena those tiles live in (ranges sized by a cheap per-block upper bound) */
+    uint64_t bytes_tile_arena;        /* bytes of the candidate tiles of all blocks (16 B x candidates within reach; in LDS, over-dense blocks in the arena) */
+    uint64_t bytes_tile_arena_reserved; /* size of the arena of the over-dense blocks' tiles (ranges sized by a cheap per-block upper bound; 0 without such blocks) */
     uint64_t n_certified_subblocks;   /* 4x4x4 sub-blocks the classification pass of the splat certified to lie inside the fluid */
     uint64_t n_truncated_blocks;      /* active blocks left with truncated (lower-bound) level-set values: inside the fluid, never read by MC */
     uint64_t n_completed_blocks;      /* truncated blocks next to the surface that the second splat pass evaluated in full */
-    double ms_levelset_accumulate_pass2; /* part of ms_levelset_accumulate: k_select_redo + the second launch of k_splat_accumulate_w */
+    double ms_levelset_accumulate_pass2; /* part of ms_levelset_accumulate: k_select_redo + the second launch of k_splat_fused */
 } ss_stats;
 
 typedef struct ss_context ss_context;
