@@ -1815,7 +1815,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(sizeof(R) ==
 
 // the blocks with larger tiles (over-dense input), one workgroup per block; list and its length on the device
 template <class R, int ARITH, bool EARLY>
-__global__ __launch_bounds__(512) void k_splat_accumulate_list(SSDevT<R> P, const ss_real4<R>* __restrict__ arena, const uint32_t* __restrict__ arena_idx,
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(sizeof(R) == 4 ? 8 : 4, 8))) void k_splat_accumulate_list(SSDevT<R> P, const ss_real4<R>* __restrict__ arena, const uint32_t* __restrict__ arena_idx,
                                                                const unsigned long long* __restrict__ tile_off,
                                                                const uint32_t* __restrict__ counts, const uint32_t* __restrict__ active_xyz,
                                                                const uint32_t* __restrict__ list, const uint32_t* __restrict__ n_list_dev,
