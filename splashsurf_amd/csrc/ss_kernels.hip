@@ -1765,7 +1765,7 @@ __device__ __forceinline__ void splat_accumulate_block_wave(SplatAccWaveShared<R
 // (k_splat_bounds, k_splat_gather / _large, k_splat_accumulate_list).  list == nullptr: every active block; otherwise the blocks
 // of the device-side list, the sub-blocks in redo_mask only.
 template <class R, int ARITH, bool EARLY>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(sizeof(R) == 4 ? 8 : 4, 8))) void k_splat_fused(SSDevT<R> P, const ss_real4<R>* __restrict__ posvol, const uint32_t* __restrict__ perm,
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(sizeof(R) == 4 ? 6 : 4, 8))) void k_splat_fused(SSDevT<R> P, const ss_real4<R>* __restrict__ posvol, const uint32_t* __restrict__ perm,
                                                     const uint32_t* __restrict__ cell_start, const uint32_t* __restrict__ active_xyz, uint32_t n_active,
                                                     const uint32_t* __restrict__ list, const uint32_t* __restrict__ n_list_dev,
                                                     const uint32_t* __restrict__ redo_mask, R* __restrict__ G, ss_real2<R>* __restrict__ blk_minmax,
