@@ -404,20 +404,6 @@ ss_status ss_post_sph_normals_f32(ss_context *ctx, const float *xyz, const float
                                   float *out);
 ss_status ss_post_sph_normals_f64(ss_context *ctx, const double *xyz, const double *rho, uint64_t n, double rest_mass, double h, const double *points, uint64_t n_points,
                                   double *out);
-/* postprocessing::marching_cubes_cleanup (splashsurf_lib/src/postprocessing.rs:99-242) -- a HOST stage: one sequential
- * sweep of half-edge collapses over the vertices in index order, as in the reference (halfedge_mesh.rs); all pointers are
- * host pointers.  Outputs never exceed the inputs: vertices_out holds n_vertices x 3 values, triangles_out n_triangles x 3,
- * connectivity_row_out n_vertices + 1 CSR row pointers, connectivity_idx_out up to connectivity_capacity entries
- * (6 x n_triangles always suffice) -- the vertex-vertex connectivity the reference returns, in its order.
- * counts_out[3] = {vertices, triangles, connectivity entries} written.  `grid` is the grid of the reconstruction. */
-ss_status ss_post_marching_cubes_cleanup_f32(ss_context *ctx, const float *vertices, uint64_t n_vertices, const uint32_t *triangles, uint64_t n_triangles,
-                                             const ss_grid_f32 *grid, int has_max_rel_snap_distance, float max_rel_snap_distance, uint64_t max_iter,
-                                             int keep_vertices, float *vertices_out, uint32_t *triangles_out, uint64_t *connectivity_row_out,
-                                             uint32_t *connectivity_idx_out, uint64_t connectivity_capacity, uint64_t *counts_out);
-ss_status ss_post_marching_cubes_cleanup_f64(ss_context *ctx, const double *vertices, uint64_t n_vertices, const uint32_t *triangles, uint64_t n_triangles,
-                                             const ss_grid_f64 *grid, int has_max_rel_snap_distance, double max_rel_snap_distance, uint64_t max_iter,
-                                             int keep_vertices, double *vertices_out, uint32_t *triangles_out, uint64_t *connectivity_row_out,
-                                             uint32_t *connectivity_idx_out, uint64_t connectivity_capacity, uint64_t *counts_out);
 /* HBM views of the neighbour lists of a reconstruction (NULL when absent): CSR rows (uint64) and uint32 indices */
 ss_status ss_result_device_particle_neighbors(const ss_result *res, const uint64_t **row_ptr, const uint32_t **neighbors, uint64_t *n_particles, uint64_t *n_entries);
 /* copies of the reconstruction's arrays into caller buffers (host or HBM; element type = the result's Real type):

@@ -355,50 +355,4 @@ class ShardedReconstruction {
     ss_comm* comm_ = nullptr;
 };
 
-// ---- splashsurf_lib::postprocessing (host stages) ----------------------------------------------------------------------
-namespace postprocessing {
-
-// marching_cubes_cleanup (postprocessing.rs:99-242): simplifies `mesh` in place and returns the vertex-vertex connectivity
-// of the result, as the reference does.  A sequential host stage (ss_post_marching_cubes_cleanup_*); needs no device.
-template <class R>
-std::vector<std::vector<size_t>> marching_cubes_cleanup(TriMesh3dT<R>& mesh, const UniformGridT<R>& grid, std::optional<R> max_rel_snap_distance,
-                                                        size_t max_iter, bool keep_vertices) {
-    typename Abi<R>::grid g{};
-    for (int d = 0; d < 3; ++d) {
-        g.aabb_min[d] = grid.aabb.min[d];
-        g.aabb_max[d] = grid.aabb.max[d];
-        g.n_points[d] = grid.points_per_dim[d];
-        g.n_cells[d] = grid.cells_per_dim[d];
-    }
-    g.cell_size = grid.cell_size;
-    const uint64_t nv = mesh.vertices.size(), nt = mesh.triangles.size();
-    std::vector<uint32_t> tri(3 * nt), tri_out(3 * nt), conn_idx(6 * nt + 1);
-    for (uint64_t f = 0; f < nt; ++f)
-        for (int c = 0; c < 3; ++c) {
-            if (mesh.triangles[f][c] >= (1ull << 32)) throw ReconstructionError(SS_ERR_UNSUPPORTED, 0, "vertex index does not fit 32 bits");
-            tri[3 * f + c] = (uint32_t)mesh.triangles[f][c];
-        }
-    std::vector<R> v_out(3 * nv + 1);
-    std::vector<uint64_t> conn_row(nv + 1);
-    uint64_t counts[3] = {0, 0, 0};
-    const R* v_in = nv ? mesh.vertices[0].data() : nullptr;
-    ss_status st;
-    if constexpr (sizeof(R) == 4)
-        st = ss_post_marching_cubes_cleanup_f32(nullptr, v_in, nv, tri.data(), nt, &g, max_rel_snap_distance ? 1 : 0, max_rel_snap_distance.value_or(R(0)), max_iter,
-                                                keep_vertices ? 1 : 0, v_out.data(), tri_out.data(), conn_row.data(), conn_idx.data(), conn_idx.size(), counts);
-    else
-        st = ss_post_marching_cubes_cleanup_f64(nullptr, v_in, nv, tri.data(), nt, &g, max_rel_snap_distance ? 1 : 0, max_rel_snap_distance.value_or(R(0)), max_iter,
-                                                keep_vertices ? 1 : 0, v_out.data(), tri_out.data(), conn_row.data(), conn_idx.data(), conn_idx.size(), counts);
-    if (st != SS_OK) throw ReconstructionError(st, 0, "marching_cubes_cleanup failed");
-    mesh.vertices.resize(counts[0]);
-    for (uint64_t i = 0; i < counts[0]; ++i) mesh.vertices[i] = {v_out[3 * i], v_out[3 * i + 1], v_out[3 * i + 2]};
-    mesh.triangles.resize(counts[1]);
-    for (uint64_t f = 0; f < counts[1]; ++f) mesh.triangles[f] = {tri_out[3 * f], tri_out[3 * f + 1], tri_out[3 * f + 2]};
-    std::vector<std::vector<size_t>> connectivity(counts[0]);
-    for (uint64_t i = 0; i < counts[0]; ++i) connectivity[i].assign(conn_idx.begin() + conn_row[i], conn_idx.begin() + conn_row[i + 1]);
-    return connectivity;
-}
-
-}  // namespace postprocessing
-
 }  // namespace splashsurf

@@ -4,10 +4,10 @@
 
 The `reconstruct` subcommand and the small `convert` subcommand (splashsurf/src/convert.rs) exist.  Flags are spelled as in the reference (`--normals=on`, `-r 0.025`, ...).
 Differences, all of them loud:
-  * `--decimate-barnacles` and `--generate-quads` are not provided; switching one of them on is an error.  The
-    `--check-mesh*` options run on the host; a finding fails the frame with the reference's message.  `--mesh-cleanup`
-    follows the reference's default (on as soon as `--mesh-smoothing-iters` is given and
-    not 0, reconstruct.rs:201-214) and runs as a host stage (see postprocessing.reconstruction_pipeline).
+  * `--decimate-barnacles`, `--generate-quads` and `--mesh-cleanup` (the reference's sequential mesh stages) are not provided;
+    switching one of them on is an error.  The binary switches the cleanup on by default as soon as `--mesh-smoothing-iters` is
+    given and not 0 (reconstruct.rs:201-214): such a command line needs an explicit `--mesh-cleanup=off` here.  The
+    `--check-mesh*` options run on the host; a finding fails the frame with the reference's message.
   * `--mt-files`, `--mt-particles`, `-n/--num-threads` and `--simd` are accepted and ignored: the work runs on the GPU.
 """
 import argparse
@@ -167,6 +167,8 @@ def pipeline_kwargs(args):
     mesh_cleanup = args.mesh_cleanup
     if mesh_cleanup is None:  # reconstruct.rs:201-214: "off" for 0 iterations, "on" as soon as the option is present
         mesh_cleanup = args.mesh_smoothing_iters not in (None, 0)
+    if mesh_cleanup:
+        unsupported.append("--mesh-cleanup (the binary's default once --mesh-smoothing-iters is given; pass --mesh-cleanup=off)")
     if args.decimate_barnacles:
         unsupported.append("--decimate-barnacles")
     if args.generate_quads:
@@ -186,7 +188,7 @@ def pipeline_kwargs(args):
         mesh_smoothing_weights=args.mesh_smoothing_weights, mesh_smoothing_weights_normalization=args.mesh_smoothing_weights_normalization,
         output_mesh_smoothing_weights=args.output_smoothing_weights, output_raw_normals=args.output_raw_normals, output_raw_mesh=args.output_raw_mesh,
         mesh_aabb_min=mmin, mesh_aabb_max=mmax, mesh_aabb_clamp_vertices=args.mesh_aabb_clamp_verts, keep_vertices=args.keep_verts,
-        mesh_cleanup=mesh_cleanup, mesh_cleanup_snap_dist=args.mesh_cleanup_snap_dist,
+        mesh_cleanup=False,
         # reconstruct.rs:660-666: --check-mesh switches the three checks on together
         check_mesh_closed=args.check_mesh or args.check_mesh_closed, check_mesh_manifold=args.check_mesh or args.check_mesh_manifold,
         check_mesh_orientation=args.check_mesh or args.check_mesh_orientation, check_mesh_debug=args.check_mesh_debug)

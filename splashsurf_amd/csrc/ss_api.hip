@@ -1388,6 +1388,11 @@ ss_status levelset_box_impl(ss_result* r, const int64_t lo[3], const int64_t ext
         tmp.release();
         return SS_OK;
     }
+    // certified sub-blocks were never evaluated in full or stored (SS_OPTION_FULL_LEVELSET, header): their slots hold no values
+    if (r->stats.n_truncated_blocks)
+        return fail(c, SS_ERR_INVALID_ARGUMENT,
+                    "ss_result_levelset_box: this result holds level-set blocks with certified (never evaluated) sub-blocks; set SS_OPTION_FULL_LEVELSET = 1 "
+                    "on the context before the reconstruction to read level-set values");
     if (r->n_active == 0) {
         SS_HIP(c, hipMemsetAsync(tmp.p, 0, tot * sizeof(R), c->stream));
     } else {

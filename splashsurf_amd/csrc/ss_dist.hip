@@ -77,7 +77,8 @@ RcclApi* rccl_api() {
             for (const char* n : names)
                 if ((api.handle = dlopen(n, RTLD_NOW | RTLD_GLOBAL))) break;
         if (!api.handle) {
-            api.error = std::string("RCCL not found: ") + (dlerror() ? dlerror() : "dlopen failed");
+            const char* why = dlerror();  // (a second call would return NULL: dlerror clears the state it reports)
+            api.error = std::string("RCCL not found: ") + (why ? why : "dlopen failed");
             return;
         }
         bool ok = true;

@@ -34,7 +34,6 @@ def _lib():
             getattr(L, "ss_post_smoothing_weights" + suf).argtypes = [vp, vp, u64, real, vp]
             getattr(L, "ss_post_sph_interpolate" + suf).argtypes = [vp, vp, vp, u64, real, real, vp, i32, vp, u64, i32, vp]
             getattr(L, "ss_post_sph_normals" + suf).argtypes = [vp, vp, vp, u64, real, real, vp, u64, vp]
-            getattr(L, "ss_post_marching_cubes_cleanup" + suf).argtypes = [vp, vp, u64, vp, u64, vp, C.c_int, real, u64, C.c_int, vp, vp, vp, vp, u64, vp]
         L.ss_result_device_particle_neighbors.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(u64), C.POINTER(u64)]
         L.ss_result_copy_vertices.argtypes = [vp, vp]
         L.ss_result_copy_triangles_u32.argtypes = [vp, vp]
@@ -155,47 +154,6 @@ def vertex_vertex_connectivity(n_vertices, triangles, context=None):
     n_entries = C.c_uint64()
     _check(ctx, L.ss_post_vertex_connectivity(ctx._h, nv, _ptr(t), nt, _ptr(row), _ptr(nb), cap, C.byref(n_entries)))
     return VertexVertexConnectivity(row, nb[:int(n_entries.value)])
-
-
-def marching_cubes_cleanup(vertices, triangles, grid, max_rel_snap_dist=None, max_iter=5, keep_vertices=False, context=None):
-    """`postprocessing::marching_cubes_cleanup` / `pysplashsurf.marching_cubes_cleanup` (postprocessing.rs:99-242): the
-    "mesh displacement" simplification of a marching cubes mesh.  A HOST stage (one sequential sweep of half-edge
-    collapses in vertex order, exactly as the reference runs it); numpy in, numpy out.
-    Returns (vertices, triangles (uint64), VertexVertexConnectivity) -- the connectivity in the reference's order.
-    Works without a device context (`context=None` keeps it that way; errors then carry no message text)."""
-    ctx = context
-    L = _lib()
-    v = np.ascontiguousarray(_to_numpy(vertices))
-    if v.dtype not in (np.float32, np.float64):
-        raise TypeError("vertices must be float32 or float64")
-    v = v.reshape(-1, 3)
-    t = np.ascontiguousarray(np.asarray(_to_numpy(triangles)).reshape(-1, 3).astype(np.uint32))
-    f64 = v.dtype == np.float64
-    g = api._Grid64() if f64 else api._Grid()
-    for d in range(3):
-        g.aabb_min[d] = grid.aabb.min[d]
-        g.aabb_max[d] = grid.aabb.max[d]
-        g.n_points[d] = int(grid.npoints_per_dim[d])
-        g.n_cells[d] = int(grid.ncells_per_dim[d])
-    g.cell_size = grid.cell_size
-    nv, nt = int(v.shape[0]), int(t.shape[0])
-    cap = max(6 * nt, 1)
-    out_v = np.empty((nv, 3), dtype=v.dtype)
-    out_t = np.empty((nt, 3), dtype=np.uint32)
-    row = np.empty(nv + 1, dtype=np.uint64)
-    idx = np.empty(cap, dtype=np.uint32)
-    counts = (C.c_uint64 * 3)()
-    real = C.c_double if f64 else C.c_float
-    fn = getattr(L, "ss_post_marching_cubes_cleanup" + ("_f64" if f64 else "_f32"))
-    st = fn(ctx._h if ctx is not None else None, _ptr(v), nv, _ptr(t), nt, C.byref(g), 0 if max_rel_snap_dist is None else 1,
-            real(0.0 if max_rel_snap_dist is None else float(max_rel_snap_dist)), int(max_iter), 1 if keep_vertices else 0,
-            _ptr(out_v), _ptr(out_t), _ptr(row), _ptr(idx), cap, counts)
-    if st != 0:
-        if ctx is not None:
-            ctx._raise(st)
-        raise api.SplashsurfError(st, "marching_cubes_cleanup failed")
-    n_v, n_t, n_c = int(counts[0]), int(counts[1]), int(counts[2])
-    return out_v[:n_v].copy(), out_t[:n_t].astype(np.uint64), VertexVertexConnectivity(row[:n_v + 1].copy(), idx[:n_c].copy())
 
 
 def check_mesh_consistency(vertices, triangles, check_closed=True, check_manifold=True, debug=False):
@@ -458,15 +416,15 @@ def reconstruction_pipeline(particles, *, attributes_to_interpolate=None, partic
     """pysplashsurf.reconstruction_pipeline (splashsurf/src/reconstruct.rs:1022-1345): reconstruction followed by the
     post-processing stages provided on the GPU -- smoothing weights, weighted Laplacian smoothing, normals (mesh or
     SPH), normal smoothing, attribute interpolation, clamping to a mesh AABB.  The mesh stays in HBM between the device
-    stages.  `mesh_cleanup` (marching_cubes_cleanup, 5 iterations as in reconstruct.rs:1066-1076) is a host stage: the raw
-    mesh goes to the host, is simplified there and returns to HBM together with the connectivity the cleanup produced.  Its
-    result depends on the vertex and triangle ORDER of the raw mesh; the reference's order follows the iteration order of a
-    concurrent hash map over the subdomains (dense_subdomains.rs:387-424), ours is the canonical order of this library, so
-    cleaned meshes agree with the reference's as surfaces but not vertex by vertex.  The `check_mesh_*` options run on the
-    final mesh on the host and raise MeshCheckError like the binary fails the frame.  Barnacle decimation and quad
-    conversion are not provided and raise.
+    stages.  The `check_mesh_*` options run on the final mesh on the host and raise MeshCheckError like the binary fails the
+    frame.  The sequential mesh stages of the reference -- `mesh_cleanup` (marching_cubes_cleanup, postprocessing.rs:99-242: one
+    sweep of half-edge collapses in vertex order, no data-parallel form with the same output), barnacle decimation and quad
+    conversion -- are outside the scope of this library and raise NotImplementedError when requested.
     Returns (MeshWithData, SurfaceReconstruction) with numpy arrays."""
     import torch
+    if mesh_cleanup:
+        raise NotImplementedError("post-processing option 'mesh_cleanup' is not provided by this build (a sequential host stage of the reference, "
+                                  "postprocessing.rs:99-242; outside the scope of this library)")
     for k, v in unsupported.items():
         if k not in _UNSUPPORTED:
             raise TypeError("unexpected keyword argument %r" % k)
@@ -513,13 +471,6 @@ def reconstruction_pipeline(particles, *, attributes_to_interpolate=None, partic
         interp = SphInterpolator(d_x, d_rho, rest_mass, h, context=ctx)
 
     connectivity = None
-    if mesh_cleanup:  # reconstruct.rs:1063-1085
-        cv, ct, conn = marching_cubes_cleanup(rec.mesh.vertices, rec.mesh.triangles, rec.grid, max_rel_snap_dist=mesh_cleanup_snap_dist, max_iter=5,
-                                              keep_vertices=keep_vertices, context=ctx)
-        nv, nt = int(cv.shape[0]), int(ct.shape[0])
-        d_v = torch.from_numpy(cv).to(dev)
-        d_t = torch.from_numpy(ct.astype(np.int32)).to(dev)
-        connectivity = VertexVertexConnectivity(torch.from_numpy(conn.row_ptr.astype(np.int64)).to(dev), torch.from_numpy(conn.neighbors.astype(np.int32)).to(dev))
     if connectivity is None and (normals_smoothing_iters is not None or mesh_smoothing_iters is not None):
         connectivity = vertex_vertex_connectivity(nv, d_t, ctx)
 

@@ -58,5 +58,5 @@ def test_cpp_header_compiles():
     program are valid C++17 for a plain host compiler."""
     import subprocess
     root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
-    for src in ("test_host.cpp", "test_cleanup_host.cpp"):
+    for src in ("test_host.cpp",):
         subprocess.check_call(["g++", "-std=c++17", "-fsyntax-only", "-Wall", "-I" + os.path.join(root, "include"), os.path.join(root, "tests", "cpp", src)])

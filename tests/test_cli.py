@@ -50,13 +50,15 @@ def test_unprovided_stages_fail_loudly():
     assert kw["check_mesh_closed"] and kw["check_mesh_manifold"] and kw["check_mesh_orientation"] and not kw["check_mesh_debug"]
     kw = cli.pipeline_kwargs(_parse(*base, "--check-mesh-closed=on"))
     assert kw["check_mesh_closed"] and not kw["check_mesh_manifold"] and not kw["check_mesh_orientation"]
-    # mesh cleanup: the binary's default is "on" as soon as --mesh-smoothing-iters is present and not 0 (reconstruct.rs:201-214)
+    # mesh cleanup (a sequential host stage of the reference, not provided): the binary's default is "on" as soon as
+    # --mesh-smoothing-iters is present and not 0 (reconstruct.rs:201-214), so such a command line must switch it off
     assert cli.pipeline_kwargs(_parse(*base))["mesh_cleanup"] is False
-    assert cli.pipeline_kwargs(_parse(*base, "--mesh-smoothing-iters=5"))["mesh_cleanup"] is True
     assert cli.pipeline_kwargs(_parse(*base, "--mesh-smoothing-iters=0"))["mesh_cleanup"] is False
     assert cli.pipeline_kwargs(_parse(*base, "--mesh-smoothing-iters=5", "--mesh-cleanup=off"))["mesh_cleanup"] is False
-    kw = cli.pipeline_kwargs(_parse(*base, "--mesh-cleanup=on", "--mesh-cleanup-snap-dist", "0.5", "--keep-verts=on"))
-    assert kw["mesh_cleanup"] is True and kw["mesh_cleanup_snap_dist"] == 0.5 and kw["keep_vertices"] is True
+    for extra in (["--mesh-smoothing-iters=5"], ["--mesh-cleanup=on"], ["--mesh-cleanup=on", "--mesh-cleanup-snap-dist", "0.5"]):
+        with pytest.raises(cli.CliError):
+            cli.pipeline_kwargs(_parse(*base, *extra))
+    assert cli.pipeline_kwargs(_parse(*base, "--keep-verts=on"))["keep_vertices"] is True
     with pytest.raises(cli.CliError):
         cli.pipeline_kwargs(_parse(*base, "--mesh-aabb-min", "1", "0", "0", "--mesh-aabb-max", "0", "1", "1"))
 
@@ -106,10 +108,9 @@ def test_cli_end_to_end_matches_the_library_call(tmp_path):
     assert raw.vertices.shape == (33026, 3) and raw.triangles.shape == (66220, 3)
     assert out.vertices.shape == raw.vertices.shape and "normals" in out.point_attributes
     assert not np.array_equal(out.vertices, raw.vertices)  # smoothed
-    # the binary's default recipe: smoothing switches the (host-side) mesh cleanup on
-    assert cli.main(["reconstruct", str(src), "-r=0.025", "-l=2.0", "-c=1.1", "-o", str(tmp_path / "clean.obj"), "--mesh-smoothing-iters=3", "--check-mesh=on"]) == 0
-    clean = io.mesh_from_file(str(tmp_path / "clean.obj"))
-    assert 0 < clean.vertices.shape[0] < raw.vertices.shape[0] and clean.triangles.max() < clean.vertices.shape[0]
+    # the binary's default recipe (smoothing switches the mesh cleanup on) is refused, not silently changed
+    assert cli.main(["reconstruct", str(src), "-r=0.025", "-l=2.0", "-c=1.1", "-o", str(tmp_path / "clean.obj"), "--mesh-smoothing-iters=3", "--check-mesh=on"]) == 1
+    assert not (tmp_path / "clean.obj").exists()
     # error path: exit code 1, nothing written
     assert cli.main(["reconstruct", str(src), "-r=0.025", "-l=2.0", "-c=1.1", "--decimate-barnacles=on"]) == 1
 

@@ -188,4 +188,9 @@ def test_early_exit_inside_the_fluid_changes_no_output(gpu_ctx, full_levelset_ct
     assert np.array_equal(a.mesh.triangles_u32, b.mesh.triangles_u32)
     with pytest.raises(RuntimeError):
         a.levelset_box([0, 0, 0], [8, 8, 8])
+    # ... and so does the C entry point itself (a C / C++ host does not go through the Python wrapper's check)
+    import ctypes as C
+    lo, ex, out = (C.c_int64 * 3)(0, 0, 0), (C.c_int64 * 3)(8, 8, 8), np.zeros(512, np.float32)
+    assert a._lib.ss_result_levelset_box(a._h, lo, ex, out.ctypes.data_as(C.c_void_p)) == 6  # SS_ERR_INVALID_ARGUMENT
+    assert b._lib.ss_result_levelset_box(b._h, lo, ex, out.ctypes.data_as(C.c_void_p)) == 0
     b.levelset_box([0, 0, 0], [8, 8, 8])

@@ -202,91 +202,17 @@ def test_clamp_with_aabb_matches_reference(oracle):
     assert v.shape == raw_v.shape and t.shape[0] == g["clamp1_t"].shape[0]
 
 
-# ---- marching_cubes_cleanup: a host stage of the product (splashsurf_lib/src/postprocessing.rs:99-242, halfedge_mesh.rs) ----
-CLEANUP = ["cleanup_bunny", "cleanup_bunny_snap_keep", "cleanup_f64_cube"]
-
-
-class _GoldenGrid:
-    def __init__(self, g):
-        class _A:
-            pass
-        self.aabb = _A()
-        self.aabb.min, self.aabb.max = g["grid_min"], g["grid_max"]
-        self.cell_size = g["cell_size"][()]
-        self.npoints_per_dim = [int(x) for x in g["n_points"]]
-        self.ncells_per_dim = [int(x) for x in g["n_cells"]]
-
-
-@pytest.mark.parametrize("name", CLEANUP)
-def test_mesh_cleanup_bit_identical_to_reference(oracle, name):
-    """The reference's own raw mesh in its own order (the result depends on it) -> the reference's cleaned mesh, bit for bit;
-    the connectivity the cleanup returns is pinned through three unweighted smoothing passes of the reference's pipeline."""
+def test_sequential_mesh_stages_are_refused():
+    """marching_cubes_cleanup (postprocessing.rs:99-242), barnacle decimation and quad conversion are sequential host stages of
+    the reference and outside this library: requesting one raises before any work is done."""
     from splashsurf_amd import postprocessing as PP
-    g = load_golden(name)
-    prm = json.loads(str(g["params"]))
-    V, T = g["vertices"], g["triangles"].astype(np.uint64)
-    U = np.uint32 if V.dtype == np.float32 else np.uint64
-    cv, ct, conn = PP.marching_cubes_cleanup(V, T, _GoldenGrid(g), max_rel_snap_dist=prm["max_rel_snap_dist"], max_iter=prm["max_iter"],
-                                             keep_vertices=prm["keep_vertices"], context=None)
-    assert cv.dtype == V.dtype and ct.dtype == np.uint64
-    assert cv.shape == g["clean_vertices"].shape and np.array_equal(cv.view(U), g["clean_vertices"].view(U))
-    assert np.array_equal(ct, g["clean_triangles"].astype(np.uint64))
-    assert cv.shape[0] < V.shape[0] or prm["keep_vertices"]
-    row, nb = conn.row_ptr, conn.neighbors
-    assert row.shape[0] == cv.shape[0] + 1 and int(row[-1]) == nb.shape[0]
-    smoothed = oracle.post_laplacian_smoothing(cv, row, nb, 3, 1.0, np.ones(cv.shape[0], cv.dtype))
-    assert np.array_equal(smoothed.view(U), g["clean_smoothed_3"].view(U))
-
-
-def test_mesh_cleanup_rejects_bad_input():
-    from splashsurf_amd import postprocessing as PP
-    from splashsurf_amd.api import SplashsurfError
-    g = load_golden("cleanup_f64_cube")
-    V, T = g["vertices"], g["triangles"].astype(np.uint64)
-    bad_t = T.copy()
-    bad_t[0, 0] = V.shape[0]
-    with pytest.raises(SplashsurfError):
-        PP.marching_cubes_cleanup(V, bad_t, _GoldenGrid(g), context=None)
-    far = V.copy()
-    far[0] += 100.0
-    with pytest.raises(SplashsurfError):
-        PP.marching_cubes_cleanup(far, T, _GoldenGrid(g), context=None)
-    ev, et, ec = PP.marching_cubes_cleanup(V[:0], T[:0], _GoldenGrid(g), context=None)
-    assert ev.shape == (0, 3) and et.shape == (0, 3) and ec.row_ptr.tolist() == [0]
-
-
-@pytest.mark.gpu
-def test_gpu_pipeline_with_mesh_cleanup(gpu_ctx, oracle):
-    """reconstruction_pipeline(mesh_cleanup=True): the raw GPU mesh goes through the host stage and back to HBM; the
-    result equals cleanup + oracle smoothing applied to that raw mesh by hand, and is a closed simplification of it."""
-    from splashsurf_amd import postprocessing as PP
-    pts = np.load(os.path.join(os.path.dirname(__file__), "data", "bunny_frame_14_7705_particles.npy")).astype(np.float32)
-    kw = dict(particle_radius=0.025, smoothing_length=2.0, cube_size=1.0, subdomain_grid=True, subdomain_grid_auto_disable=False)
-    mwd, rec = PP.reconstruction_pipeline(pts, mesh_cleanup=True, mesh_smoothing_iters=3, mesh_smoothing_weights=False, output_raw_mesh=True, context=gpu_ctx, **kw)
-    raw_v, raw_t = rec.mesh.vertices, rec.mesh.triangles
-    cv, ct, conn = PP.marching_cubes_cleanup(raw_v, raw_t, rec.grid, max_iter=5, context=gpu_ctx)
-    expect = oracle.post_laplacian_smoothing(cv, conn.row_ptr, conn.neighbors, 3, 1.0, np.ones(cv.shape[0], np.float32))
-    assert np.array_equal(np.asarray(mwd.mesh.triangles), ct)
-    assert np.array_equal(np.asarray(mwd.mesh.vertices).view(np.uint32), expect.view(np.uint32))
-    assert cv.shape[0] < 0.7 * raw_v.shape[0]
-    # every undirected edge of the cleaned mesh is shared by exactly two triangles (the raw mesh is closed, collapses keep it so)
-    e = np.sort(np.concatenate([ct[:, [0, 1]], ct[:, [1, 2]], ct[:, [2, 0]]]), axis=1)
-    _, counts = np.unique(e, axis=0, return_counts=True)
-    assert np.all(counts == 2)
-
-
-def test_cpp_cleanup_over_c_abi(tmp_path):
-    """The C++ mirror (include/splashsurf_hip.hpp, splashsurf::postprocessing::marching_cubes_cleanup) over the C ABI on a
-    small known case: a host stage, so this runs without a device."""
-    import subprocess
-    root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
-    exe = str(tmp_path / "test_cleanup_host")
-    libdir = os.path.join(root, "splashsurf_amd")
-    subprocess.check_call(["g++", "-std=c++17", "-O1", "-I" + os.path.join(root, "include"), os.path.join(root, "tests", "cpp", "test_cleanup_host.cpp"),
-                           "-L" + libdir, "-lsplashsurf_hip", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib", "-o", exe])
-    out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
-    assert out.returncode == 0, out.stdout + out.stderr
-    assert "cleanup host test ok" in out.stdout
+    pts = np.zeros((1, 3), np.float32)
+    kw = dict(particle_radius=0.025, smoothing_length=2.0, cube_size=1.0)
+    with pytest.raises(NotImplementedError):
+        PP.reconstruction_pipeline(pts, mesh_cleanup=True, **kw)
+    with pytest.raises(NotImplementedError):
+        PP.reconstruction_pipeline(pts, decimate_barnacles=True, **kw)
+    assert not hasattr(PP, "marching_cubes_cleanup")
 
 
 def _apply_mesh_check_mutation(T, ops):

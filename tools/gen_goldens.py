@@ -341,40 +341,22 @@ def gen_post_goldens(report):
                             sph_normals_vs_oracle=float(np.abs(sph_normals - O.post_sph_normals(pts, rho, mass, h, V)).max()), sw_bits_equal_fraction=sw_bits_equal)
 
 
-def gen_cleanup_goldens(report):
-    """postprocessing::marching_cubes_cleanup (a host stage of the product): the reference's own raw mesh -- in ITS vertex and
-    triangle order, on which the result depends -- and the mesh the reference makes of it.  The mesh is kept small
-    (int32 triangles, one data set per Real type)."""
-    cases = [("cleanup_bunny", "bunny_frame_14_7705_particles.npy", 0.025, 2.0, 1.0, np.float32, None, False),
-             ("cleanup_bunny_snap_keep", "bunny_frame_14_7705_particles.npy", 0.025, 2.0, 1.0, np.float32, 0.35, True),
-             ("cleanup_f64_cube", "cube_2366_particles.npy", 0.025, 2.0, 0.75, np.float64, None, False)]
-    for name, fn, r, l, c, dt, snap, keep in cases:
-        pts = np.ascontiguousarray(np.load(os.path.join(DATA, fn)).astype(np.float32), dtype=dt)
-        # the reference's pipeline: raw mesh (rec.mesh, in the order of THIS run), cleanup, three unweighted smoothing passes
-        # with the connectivity the cleanup returned -- which pins that connectivity's order, the wheel does not hand it out
-        mwd, res = pysplashsurf.reconstruction_pipeline(pts, particle_radius=r, smoothing_length=l, cube_size=c, simd=False, subdomain_grid=True,
-                                                        subdomain_grid_auto_disable=False, mesh_cleanup=True, mesh_cleanup_snap_dist=snap,
-                                                        keep_vertices=keep, mesh_smoothing_iters=3, mesh_smoothing_weights=False)
-        mesh = res.mesh
-        V = np.asarray(mesh.vertices).copy()
-        T = np.asarray(mesh.triangles).copy()
-        SV = np.asarray(mwd.mesh.vertices).copy()
-        m2 = mesh.copy()
-        pysplashsurf.marching_cubes_cleanup(m2, res.grid, max_rel_snap_dist=snap, max_iter=5, keep_vertices=keep)
-        CV = np.asarray(m2.vertices).copy()
-        CT = np.asarray(m2.triangles).copy()
-        assert np.array_equal(CT, np.asarray(mwd.mesh.triangles)) and CV.shape == SV.shape, name
-        np.savez_compressed(os.path.join(GOLD, name + ".npz"), vertices=V, triangles=T.astype(np.int32), clean_vertices=CV, clean_triangles=CT.astype(np.int32), clean_smoothed_3=SV,
-                            grid_min=np.asarray(res.grid.aabb.min, dtype=dt), grid_max=np.asarray(res.grid.aabb.max, dtype=dt), cell_size=dt(res.grid.cell_size),
-                            n_points=np.asarray(res.grid.npoints_per_dim, dtype=np.int64), n_cells=np.asarray(res.grid.ncells_per_dim, dtype=np.int64),
-                            params=np.array(json.dumps(dict(particle_radius=r, smoothing_length=l, cube_size=c, max_rel_snap_dist=snap, keep_vertices=keep, max_iter=5))),
-                            input=np.array(json.dumps(dict(kind="file", file=fn))))
-        report[name] = dict(n_vertices=int(V.shape[0]), n_triangles=int(T.shape[0]), n_clean_vertices=int(CV.shape[0]), n_clean_triangles=int(CT.shape[0]))
+def gen_raw_mesh_golden(report):
+    """The reference's own raw mesh of the bunny frame -- in ITS vertex and triangle order -- as the base mesh of the mesh-check
+    fixtures (tests/golden/mesh_check_messages.json).  Kept small (int32 triangles)."""
+    name, fn, r, l, c = "raw_mesh_bunny", "bunny_frame_14_7705_particles.npy", 0.025, 2.0, 1.0
+    pts = np.ascontiguousarray(np.load(os.path.join(DATA, fn)).astype(np.float32))
+    res = pysplashsurf.reconstruct_surface(pts, particle_radius=r, smoothing_length=l, cube_size=c, simd=False, subdomain_grid=True, subdomain_grid_auto_disable=False)
+    V = np.asarray(res.mesh.vertices).copy()
+    T = np.asarray(res.mesh.triangles).copy()
+    np.savez_compressed(os.path.join(GOLD, name + ".npz"), vertices=V, triangles=T.astype(np.int32),
+                        params=np.array(json.dumps(dict(particle_radius=r, smoothing_length=l, cube_size=c))), input=np.array(json.dumps(dict(kind="file", file=fn))))
+    report[name] = dict(n_vertices=int(V.shape[0]), n_triangles=int(T.shape[0]))
 
 
 
 MESH_CHECK_MUTATIONS = {
-    # name -> list of (op, args) replayed by tests/test_post.py on the raw mesh of tests/golden/cleanup_bunny.npz
+    # name -> list of (op, args) replayed by tests/test_post.py on the raw mesh of tests/golden/raw_mesh_bunny.npz
     "good": [],
     "duplicate_face": [("copy_face", 0, 1)],
     "bow_tie": [("merge_vertices", (0, 0), ("half", 0))],
@@ -397,8 +379,8 @@ def apply_mesh_check_mutation(T, ops):
 
 def gen_mesh_check_goldens(report):
     """marching_cubes::check_mesh_consistency: the reference's messages for edited copies of the raw mesh stored in
-    cleanup_bunny.npz (the wheel cannot build a mesh from arrays, but the arrays of one of its meshes are writeable)."""
-    g = np.load(os.path.join(GOLD, "cleanup_bunny.npz"))
+    raw_mesh_bunny.npz (the wheel cannot build a mesh from arrays, but the arrays of one of its meshes are writeable)."""
+    g = np.load(os.path.join(GOLD, "raw_mesh_bunny.npz"))
     V, T = g["vertices"], g["triangles"].astype(np.uint64)
     prm = json.loads(str(g["params"]))
     pts = np.load(os.path.join(DATA, json.loads(str(g["input"]))["file"])).astype(np.float32)
@@ -416,7 +398,7 @@ def gen_mesh_check_goldens(report):
             out[name]["closed=%d,manifold=%d" % (closed, manifold)] = pysplashsurf.check_mesh_consistency(m, rec.grid, check_closed=closed, check_manifold=manifold,
                                                                                                            debug=False)
     with open(os.path.join(GOLD, "mesh_check_messages.json"), "w") as f:
-        json.dump(dict(base="cleanup_bunny.npz", mutations={k: [list(o) for o in v] for k, v in MESH_CHECK_MUTATIONS.items()}, messages=out), f, indent=1)
+        json.dump(dict(base="raw_mesh_bunny.npz", mutations={k: [list(o) for o in v] for k, v in MESH_CHECK_MUTATIONS.items()}, messages=out), f, indent=1)
     report["mesh_check_messages"] = {k: v["closed=1,manifold=1"] for k, v in out.items()}
 
 
@@ -434,9 +416,9 @@ def main():
         for k, v in rep.items():
             print(k, v)
         return
-    if "--cleanup-only" in sys.argv:
+    if "--raw-mesh-only" in sys.argv:
         rep = {}
-        gen_cleanup_goldens(rep)
+        gen_raw_mesh_golden(rep)
         for k, v in rep.items():
             print(k, v)
         path = os.path.join(GOLD, "GENERATION_REPORT.json")
