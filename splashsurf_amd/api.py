@@ -123,7 +123,8 @@ _lib = None
 
 
 def library_path():
-    return os.path.join(_HERE, _LIB_NAME)
+    # SPLASHSURF_HIP_LIB: another build of the same library (kernel variants compared side by side by tools/ab_kernels.sh)
+    return os.environ.get("SPLASHSURF_HIP_LIB") or os.path.join(_HERE, _LIB_NAME)
 
 
 def _preload_hip_runtime():

@@ -229,7 +229,14 @@ ss_status make_device_params(ss_context* ctx, const typename TypesOf<R>::params*
     const R support_factor = simd ? R(1.0) : R(1.01);
     P.reach = ss_sqrt(support_factor) * h * R(1.0001);
     P.R2 = ((h * h) * support_factor) * R(1.0001);
-    P.R2near = (R(0.60) * h) * (R(0.60) * h);  // measured on S10M-tank (first pass, ms / certified sub-blocks): 0.56 h 6.86 / 81 %, 0.59 h 6.52 / 86 %, 0.60 h 6.60 / 86 %, 0.62 h 6.80 / 87 %, 0.70 h 7.87 / 88 %
+#ifndef SS_TUNE_RNEAR
+#define SS_TUNE_RNEAR 0.58
+#endif
+    // near radius of the classification pass, measured on S10M-tank with the polynomial bound u^3 (c0 + c1 u^2) (splat kernel ms /
+    // certified sub-blocks; gpurun_out/r3b): 0.50 h 9.87 / 74 %, 0.52 h 8.69 / 80 %, 0.55 h 7.73 / 85 %, 0.58 h 7.40 / 87 %, 0.60 h
+    // 7.50 / 87 % -- an uncertified sub-block costs five times its classification, so the optimum sits where the curve flattens.
+    // (Round 2's bound v^2 min(2 v, 1) with its v_sqrt_f32: 8.17 ms / 86 % at 0.60 h on the same box.)
+    P.R2near = (R(SS_TUNE_RNEAR) * h) * (R(SS_TUNE_RNEAR) * h);
     P.thr_inside = prm->iso_surface_threshold * R(1.0001);
     {   // CubicSplineKernelAvxF32::new (kernel.rs:327-337), in f32 like the reference
         const float hf = (float)h;

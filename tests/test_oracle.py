@@ -276,3 +276,28 @@ def test_oracle_avx_kernel_against_scalar_kernel(oracle):
             assert abs(a - b) <= max(5e-6, 1e-5 * abs(b)), (h, r, a, b)
             if r > h:
                 assert a == 0.0
+
+
+def test_splat_lower_bound_polynomial_bounds_the_spline():
+    """The splat's classification pass certifies 'inside' with u^3 (c0 + c1 u^2), u = max(1 - q^2, 0), as a lower bound of the cubic
+    spline W(q) / sigma (kernel.rs:71-81 in the v = 1 - q form: 1 - 6 q^2 + 6 q^3 below 1/2, 2 (1 - q)^3 above): the constants the
+    kernel is compiled with must satisfy g <= W on [0, 1] with a relative gap (1e-4 by construction) far above the grid's
+    Lipschitz error, and hold most of the kernel's mass."""
+    import os
+    import re
+    src = open(os.path.join(os.path.dirname(__file__), "..", "splashsurf_amd", "csrc", "ss_kernels.hip")).read()
+    c0 = float(np.float32(float(re.search(r"#define SS_BOUND_C0 ([0-9.eE+-]+)f", src).group(1))))
+    c1 = float(np.float32(float(re.search(r"#define SS_BOUND_C1 ([0-9.eE+-]+)f", src).group(1))))
+    q = np.linspace(0.0, 1.0, 200001)
+    u = 1.0 - q * q
+    w = np.where(q < 0.5, 1.0 - 6.0 * q * q + 6.0 * q ** 3, 2.0 * (1.0 - q) ** 3)
+    g = c0 * u ** 3 + c1 * u ** 5
+    assert np.all(g >= 0.0) and np.all(g <= w)
+    low = q <= 0.9
+    assert np.min((w - g)[low] / g[low]) > 5.0e-5
+    # the grid cannot hide a violation below 0.9: the smallest gap there is far above (Lipschitz constant of w - g) x (grid step)
+    assert np.min((w - g)[low]) > 10.0 * np.abs(np.gradient(w - g, q)).max() * (q[1] - q[0])
+    # above 0.9: u = (1 - q)(1 + q) <= 2 (1 - q) and u <= 0.19, so g <= 8 (1 - q)^3 (c0 + 0.0361 c1) < 2 (1 - q)^3 = W
+    assert 8.0 * (c0 + 0.0361 * c1) < 2.0
+    mass = np.trapezoid(g * q * q, q) / np.trapezoid(w * q * q, q)
+    assert mass > 0.95

@@ -1,0 +1,73 @@
+#!/usr/bin/env python3
+"""tools/ab_kernels.py -- one workload through the library named by SPLASHSURF_HIP_LIB (default: the in-tree build): stage timers,
+certification statistics and a digest of the output (densities, vertices, triangles), one JSON line.  tools/ab_kernels.sh runs it once per
+kernel variant on one GPU box so that variants are compared on the same machine and the digests prove the output did not change.
+
+    python tools/ab_kernels.py --workload s10m_tank --steps 6 [--simd 1] [--tag NAME] [--cube-size C] [--two-pass 1]
+"""
+import argparse
+import hashlib
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--workload", default="s10m_tank")
+    ap.add_argument("--steps", type=int, default=6)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--simd", type=int, default=1)
+    ap.add_argument("--tag", default=os.path.basename(os.environ.get("SPLASHSURF_HIP_LIB", "in-tree")))
+    ap.add_argument("--cube-size", type=float, default=None, help="override the workload's radius-relative cube size")
+    ap.add_argument("--two-pass", type=int, default=None)
+    ap.add_argument("--digest", action="store_true", help="hash densities / vertices / triangles of the last step (D2H of the whole mesh)")
+    a = ap.parse_args()
+    import torch
+    from splashsurf_amd import workloads as W
+    from splashsurf_amd.api import Context, Parameters
+    wl = dict(W.WORKLOADS[a.workload])
+    if a.cube_size is not None:
+        wl["cube_size"] = a.cube_size
+    r = wl["particle_radius"]
+    prm = Parameters(particle_radius=r, compact_support_radius=np.float32(2.0 * wl["smoothing_length"] * r), cube_size=np.float32(wl["cube_size"] * r),
+                     auto_disable=False, enable_simd=a.simd)
+    ctx = Context(0)
+    if a.two_pass is not None:
+        ctx.set_two_pass(a.two_pass)
+    pts = wl["gen"]()
+    d = torch.from_numpy(pts).to("cuda:0")
+    torch.cuda.synchronize()
+    out = None
+    for _ in range(a.warmup):
+        out = ctx.reconstruct(d, prm, out=out)
+    keys = ["ms_total", "ms_decomposition", "ms_density", "ms_levelset_prepare", "ms_levelset", "ms_levelset_gather", "ms_levelset_accumulate", "ms_levelset_accumulate_pass2",
+            "ms_marching_cubes", "ms_stitching"]
+    acc = {k: [] for k in keys}
+    for _ in range(a.steps):
+        out = ctx.reconstruct(d, prm, out=out)
+        s = out.stats
+        for k in keys:
+            acc[k].append(s.get(k, 0.0))
+    s = out.stats
+    line = {"tag": a.tag, "workload": a.workload, "simd": a.simd, "n": int(pts.shape[0])}
+    line.update({k: round(float(np.median(v)), 4) for k, v in acc.items()})
+    line["ms_total_min"] = round(float(np.min(acc["ms_total"])), 4)
+    na = max(int(s.get("n_active_blocks", 0)), 1)
+    line.update(n_active=int(s.get("n_active_blocks", 0)), certified_frac=round(float(s.get("n_certified_subblocks", 0)) / (8.0 * na), 4),
+                n_completed=int(s.get("n_completed_blocks", 0)), n_large=int(s.get("n_large_tile_blocks", 0)), n_vertices=int(s["n_vertices"]), n_triangles=int(s["n_triangles"]))
+    if a.digest:
+        h = hashlib.sha256()
+        h.update(np.ascontiguousarray(out.particle_densities).tobytes())
+        h.update(np.ascontiguousarray(out.mesh.vertices).tobytes())
+        h.update(np.ascontiguousarray(out.mesh.triangles_u32).tobytes())
+        line["digest"] = h.hexdigest()[:16]
+    print(json.dumps(line), flush=True)
+
+
+if __name__ == "__main__":
+    main()
