@@ -49,6 +49,11 @@ def parse():
                          "the command to profile, so that rocprofv3's per-kernel averages are those of this workload")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-sharded", action="store_true", help="run the multi-GPU (sharded) code path even with one rank")
+    ap.add_argument("--pseudo-ranks", type=int, default=0,
+                    help="N > 1: the multi-GPU code path (ss_dist_*: brick partition, the three exchanges, rank-owned assembly) with N ranks as host "
+                         "threads on ONE GPU over the library's in-process transport, the ranks taking turns on the device so that per-rank timers "
+                         "read what a rank takes on a GPU of its own.  Reports the per-rank critical path and a projected N-GPU step, NOT a measured "
+                         "multi-GPU throughput (`value` is what this one GPU did).")
     ap.add_argument("--exchange", choices=["auto", "native", "torch"], default="auto",
                     help="N > 1 transport of the halo exchange: the library's own RCCL path (ss_dist_*) or torch.distributed")
     ap.add_argument("--cpu-sample-scale", type=float, default=1.0, help="tank scale of the CPU-baseline sample (1.0 = the full 10 M workload)")
@@ -151,8 +156,176 @@ def timed_direct(ctx, prm, d_pts, steps, warmup, sync):
     return dt, out, k3m
 
 
+def local_share(args, wl, workload, W, rank, world, r, full=None):
+    """This rank's particles of the N > 1 workloads: (array, total count, description)."""
+    if args.scaling == "weak":
+        if workload not in ("s10m_tank", "tank_small", "s40m_tank"):
+            raise SystemExit("weak scaling uses the tank workloads")
+        scale = {"s10m_tank": 1.0, "s40m_tank": 1.0, "tank_small": 0.08}[workload]
+        pts = W.tank_slab_particles(rank, world, scale=scale, particle_radius=r)
+        return pts, pts.shape[0] * world, "tank(scale=%g) per rank, stacked along y" % scale
+    if full is None:
+        full = wl["gen"]()
+    n_total = full.shape[0]
+    cut = [int(round(n_total * k / world)) for k in range(world + 1)]
+    return np.ascontiguousarray(full[cut[rank]:cut[rank + 1]]), n_total, "%s, fixed size; rank r holds the r-th contiguous 1/%d of the cloud" % (workload, world)
+
+
+def rank_row(roof, last_stats, xbytes, steps):
+    """What every rank contributes to the per-rank table."""
+    return [roof["frac"], roof["kernel_ms"], roof["algorithmic_bytes"], float(last_stats["n_active_blocks"]), float(last_stats["n_vertices"]),
+            float(last_stats["n_triangles"]), float(xbytes) / max(steps, 1), float(last_stats["ms_total"])]
+
+
+def sharded_report(rows, bal, timings, steps, native, exchange_kind, rccl_world):
+    """per_rank / load_balance / exchange objects of the N > 1 record from the gathered rank rows."""
+    world = rows.shape[0]
+    per_rank = [{"rank": q, "k3_frac": round(float(rows[q, 0]), 5), "k3_ms": round(float(rows[q, 1]), 3), "k3_algorithmic_bytes": float(rows[q, 2]),
+                 "owned_particles": bal["owned"][q], "held_particles": bal["held"][q], "active_blocks": int(rows[q, 3]),
+                 "vertices": int(rows[q, 4]), "triangles": int(rows[q, 5]), "exchange_bytes_sent_per_step": int(rows[q, 6]),
+                 "device_ms": round(float(rows[q, 7]), 3), "brick": bal["bricks"][q]} for q in range(world)]
+    blocks = rows[:, 3]
+    xkeys = ("ms_position_exchange", "ms_density_exchange", "ms_assembly") if native else ("3_position_exchange", "5_density_exchange")
+    return {
+        "per_rank": per_rank,
+        "load_balance": {"imbalance_owned_particles": round(bal["imbalance_owned"], 4), "imbalance_held_particles": round(bal["imbalance_held"], 4),
+                         "imbalance_active_blocks": round(float(blocks.max() / max(blocks.mean(), 1.0)), 4),
+                         "note": "max / mean over ranks; bricks of the subdomain grid from recursive bisection of the owner histogram"},
+        "exchange": {"kind": exchange_kind, "bytes_sent_per_step_all_ranks": int(rows[:, 6].sum()),
+                     "ms_per_step": round(sum(timings.get(k_, 0.0) for k_ in xkeys) / max(steps, 1), 3),
+                     "rccl_world_size": rccl_world},
+        "sharded_step_ms": {k: round(v / max(steps, 1), 3) for k, v in timings.items()},
+    }
+
+
+def pseudo_rank_run(args):
+    """`--pseudo-ranks N`: the N > 1 code path on ONE GPU (see parse()).  Every rank is a host thread with its own context, stream and
+    communicator of an in-process group; brick partition, position / halo-density / shared-vertex exchanges and the rank-owned assembly
+    run exactly as over RCCL, only the byte transport differs (device-to-device copies).  The ranks take turns on the device, so the time a
+    rank holds it (`own_ms`) is what the rank would take on its own GPU; the record projects the N-GPU step from the slowest rank, the
+    bytes it sends over one xGMI link and the one-GPU run of the same workload measured in the same process."""
+    import threading
+    import torch
+    from splashsurf_amd import distributed as D
+    from splashsurf_amd import workloads as W
+    from splashsurf_amd.api import Context
+    world = args.pseudo_ranks
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(0)
+    workload = args.workload or "s40m_tank"
+    wl = W.WORKLOADS[workload]
+    r = wl["particle_radius"]
+    prm = make_params(wl, args.simd)
+    nsc = int(prm.subdomain_num_cubes_per_dim) + 1
+    full = wl["gen"]() if args.scaling == "strong" else None
+    ctxs = [Context(0) for _ in range(world)]
+    comms = D.NativeComm.local_group(ctxs, take_turns=True)
+    bar = threading.Barrier(world)
+    out = [None] * world
+    errors = []
+    t_wall = [0.0] * world
+
+    def worker(q):
+        try:
+            pts, n_total, desc = local_share(args, wl, workload, W, q, world, r, full)
+            native = D.NativeSharded(comms[q], prm)
+            d_local = torch.from_numpy(pts).to(dev)
+            torch.cuda.synchronize()
+            for _ in range(max(args.warmup, 1)):
+                native.step(d_local)
+                native.assemble()
+            timings, own, k3_ms, xbytes, last = {}, [], [], 0, None
+            bar.wait()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                last = native.step(d_local)
+                info = native.assemble()
+                for k_ in ("ms_partition", "ms_position_exchange", "ms_phase1", "ms_density_exchange", "ms_phase2", "ms_assembly"):
+                    timings[k_] = timings.get(k_, 0.0) + info[k_]
+                own.append(info["ms_own_turns"])
+                xbytes += info["bytes_sent_positions"] + info["bytes_sent_densities"] + info["bytes_sent_assembly"]
+                s_ = last.stats
+                t_acc = s_.get("ms_levelset_accumulate", 0.0)
+                k3_ms.append((t_acc, s_["ms_levelset"] - s_.get("ms_levelset_gather", 0.0) - t_acc))
+            bar.wait()
+            t_wall[q] = time.perf_counter() - t0
+            stats = last.stats
+            n_occ, n_subp = last.subdomain_stats()
+            k3_acc, k3_large = (float(v) for v in np.mean(np.asarray(k3_ms), axis=0))
+            roof = splat_roofline(stats, n_occ, n_subp, nsc, k3_acc, k3_large)
+            out[q] = dict(row=rank_row(roof, stats, xbytes, args.steps), roof=roof, stats=stats, timings=timings, own_ms=float(np.mean(own)),
+                          bal=native.partition(), n_total=n_total, desc=desc, xbytes=xbytes / max(args.steps, 1))
+            native.result._free()
+        except Exception as e:  # a failing rank must not leave the others waiting silently
+            errors.append((q, repr(e)))
+            try:
+                bar.abort()
+            except Exception:
+                pass
+
+    th = [threading.Thread(target=worker, args=(q,)) for q in range(world)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    for cm in comms:
+        cm.destroy()
+    if errors:
+        raise SystemExit("pseudo-rank run failed: %r" % (errors,))
+    n_total = out[0]["n_total"]
+    dt = max(t_wall)
+    rows = np.asarray([o["row"] for o in out], dtype=np.float64)
+    timings0 = out[0]["timings"]
+    extra = sharded_report(rows, out[0]["bal"], timings0, args.steps, True,
+                           "in-process transport of libsplashsurf_hip.so (ss_comm_create_local_group): device-to-device copies in place of ncclSend/ncclRecv", 1)
+    for q in range(world):
+        extra["per_rank"][q]["own_ms"] = round(out[q]["own_ms"], 3)
+        extra["per_rank"][q]["phase_ms"] = {k: round(v / args.steps, 3) for k, v in out[q]["timings"].items()}
+    # the same workload through the plain single-GPU call, same process, same box
+    single = None
+    if args.scaling == "strong" and not args.main_only:
+        d_full = torch.from_numpy(full).to(dev)
+        dt1, o1, _ = timed_direct(ctxs[0], prm, d_full, max(3, min(args.steps, 5)), 1, torch.cuda.synchronize)
+        single = {"ms_per_step": round(dt1 * 1e3, 3), "value": round(n_total / dt1 / 1e6, 3), "unit": "Mparticles/s", "device_ms": round(float(o1.stats["ms_total"]), 3)}
+        del d_full, o1
+    for cx in ctxs:
+        cx.close()
+    slowest = max(range(world), key=lambda q: out[q]["own_ms"])
+    link_gbs = 153.0  # one xGMI link, MI355X_MICROARCH.md; a brick's halo traffic goes to a handful of neighbours
+    xfer_ms = max(o["xbytes"] for o in out) / (link_gbs * 1e9) * 1e3
+    proj = {"ranks": world, "slowest_rank": slowest, "own_ms_slowest_rank": round(out[slowest]["own_ms"], 3),
+            "own_ms_mean": round(float(np.mean([o["own_ms"] for o in out])), 3),
+            "exchange_transfer_ms_at_one_xgmi_link": round(xfer_ms, 3),
+            "projected_step_ms": round(out[slowest]["own_ms"] + xfer_ms, 3),
+            "note": "own_ms = time a rank held the device per step (all of its kernels, packing and host work; the ranks took turns); projected N-GPU step = "
+                    "slowest rank + its exchange bytes over ONE 153 GB/s xGMI link, collective latencies (7 small host-synchronised steps) not included"}
+    if single:
+        proj["single_gpu_step_ms"] = single["ms_per_step"]
+        proj["projected_speedup"] = round(single["ms_per_step"] / proj["projected_step_ms"], 2)
+    tot_v = int(sum(o["stats"]["n_vertices"] for o in out))
+    tot_t = int(sum(o["stats"]["n_triangles"] for o in out))
+    st0 = out[slowest]["stats"]
+    line = {
+        "metric": "Mparticles/s end-to-end reconstruct", "value": round(n_total * args.steps / dt / 1e6, 3), "unit": "Mparticles/s", "n_gpus": 1,
+        "pseudo_ranks": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
+        "scaling": args.scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": workload, "n_particles": int(n_total), "particle_radius": r, "smoothing_length": wl["smoothing_length"], "cube_size": wl["cube_size"],
+                   "n_vertices_incl_shared": tot_v, "n_triangles": tot_t, "enable_simd": int(prm.enable_simd),
+                   "parallelism": "%d bricks of the subdomain grid, one per PSEUDO-rank (host threads taking turns on one GPU): `value` is this one GPU's throughput in "
+                                  "that mode, the multi-GPU estimate is `projection`" % world, "workload_desc": out[0]["desc"]},
+        "roofline": out[slowest]["roof"],
+        "stages_ms": {k: round(v, 4) for k, v in st0.items() if k.startswith("ms_")},
+        "projection": proj,
+        "single_gpu_same_workload": single,
+    }
+    line.update(extra)
+    print(json.dumps(line), flush=True)
+
+
 def main():
     args = parse()
+    if args.pseudo_ranks and args.pseudo_ranks > 1:
+        return pseudo_rank_run(args)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus > 1 and world == 1 and "RANK" not in os.environ:
         sys.exit(self_launch(args))
@@ -214,20 +387,7 @@ def main():
         extra = {}
     else:
         from splashsurf_amd import distributed as D
-        if args.scaling == "weak":
-            if workload not in ("s10m_tank", "tank_small", "s40m_tank"):
-                raise SystemExit("weak scaling uses the tank workloads")
-            scale = {"s10m_tank": 1.0, "s40m_tank": 1.0, "tank_small": 0.08}[workload]
-            pts = W.tank_slab_particles(rank, world, scale=scale, particle_radius=r)
-            n_total = pts.shape[0] * world
-            workload_desc = "tank(scale=%g) per rank, stacked along y" % scale
-        else:
-            full = wl["gen"]()
-            n_total = full.shape[0]
-            cut = [int(round(n_total * k / world)) for k in range(world + 1)]
-            pts = np.ascontiguousarray(full[cut[rank]:cut[rank + 1]])
-            del full
-            workload_desc = "%s, fixed size; rank r holds the r-th contiguous 1/%d of the cloud" % (workload, world)
+        pts, n_total, workload_desc = local_share(args, wl, workload, W, rank, world, r)
         # transport of the exchanges: the library's own RCCL path (ss_dist_*, csrc/ss_dist.hip) unless --exchange torch; with "auto"
         # a failing native set-up is reported LOUDLY (stderr + the "exchange" object of the JSON line) and the torch path runs
         native, native_error = None, None
@@ -257,7 +417,7 @@ def main():
                 res_ = native.step(d_local)
                 info_ = native.assemble()
                 if profile:
-                    for k_ in ("ms_partition", "ms_position_exchange", "ms_density_exchange", "ms_assembly"):
+                    for k_ in ("ms_partition", "ms_position_exchange", "ms_phase1", "ms_density_exchange", "ms_phase2", "ms_assembly"):
                         timings[k_] = timings.get(k_, 0.0) + info_[k_]
                 return res_, info_["bytes_sent_positions"] + info_["bytes_sent_densities"] + info_["bytes_sent_assembly"]
         else:
@@ -303,30 +463,14 @@ def main():
         roof = splat_roofline(last_stats, n_occ, n_subp, nsc, k3_acc, k3_large)
         bal = native.partition() if native is not None else sharded.last_balance
         # per-rank rows: K3 roofline fraction, owned / held particles, active blocks, mesh size, exchange bytes
-        mine = torch.tensor([roof["frac"], roof["kernel_ms"], roof["algorithmic_bytes"], float(last_stats["n_active_blocks"]), float(last_stats["n_vertices"]),
-                             float(last_stats["n_triangles"]), float(xbytes) / max(args.steps, 1), float(last_stats["ms_total"])], dtype=torch.float64, device=dev)
+        mine = torch.tensor(rank_row(roof, last_stats, xbytes, args.steps), dtype=torch.float64, device=dev)
         if world > 1:
             rows_l = [torch.zeros_like(mine) for _ in range(world)]
             dist.all_gather(rows_l, mine)
             rows = torch.stack(rows_l).cpu().numpy()
         else:
             rows = mine.unsqueeze(0).cpu().numpy()
-        per_rank = [{"rank": q, "k3_frac": round(float(rows[q, 0]), 5), "k3_ms": round(float(rows[q, 1]), 3), "k3_algorithmic_bytes": float(rows[q, 2]),
-                     "owned_particles": bal["owned"][q], "held_particles": bal["held"][q], "active_blocks": int(rows[q, 3]),
-                     "vertices": int(rows[q, 4]), "triangles": int(rows[q, 5]), "exchange_bytes_sent_per_step": int(rows[q, 6]),
-                     "device_ms": round(float(rows[q, 7]), 3), "brick": bal["bricks"][q]} for q in range(world)]
-        blocks = rows[:, 3]
-        xkeys = ("ms_position_exchange", "ms_density_exchange", "ms_assembly") if native is not None else ("3_position_exchange", "5_density_exchange")
-        extra = {
-            "per_rank": per_rank,
-            "load_balance": {"imbalance_owned_particles": round(bal["imbalance_owned"], 4), "imbalance_held_particles": round(bal["imbalance_held"], 4),
-                             "imbalance_active_blocks": round(float(blocks.max() / max(blocks.mean(), 1.0)), 4),
-                             "note": "max / mean over ranks; bricks of the subdomain grid from recursive bisection of the owner histogram"},
-            "exchange": {"kind": exchange_kind, "bytes_sent_per_step_all_ranks": int(rows[:, 6].sum()),
-                         "ms_per_step": round(sum(timings.get(k_, 0.0) for k_ in xkeys) / max(args.steps, 1), 3),
-                         "rccl_world_size": dist.get_world_size() if dist.is_initialized() else 1},
-            "sharded_step_ms": {k: round(v / max(args.steps, 1), 3) for k, v in timings.items()},
-        }
+        extra = sharded_report(rows, bal, timings, args.steps, native is not None, exchange_kind, dist.get_world_size() if dist.is_initialized() else 1)
         # triangles are disjoint between ranks; shared face vertices are counted by every holder
         tot = torch.tensor([float(last_stats["n_vertices"]), float(last_stats["n_triangles"])], dtype=torch.float64, device=dev)
         if world > 1:

@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define SS_ABI_VERSION 3
+#define SS_ABI_VERSION 4
 
 /* Return codes; 1..4 mirror ReconstructionError (lib.rs:289-314). */
 typedef enum ss_status {
@@ -162,6 +162,10 @@ typedef struct ss_stats {
     uint64_t n_truncated_blocks;      /* active blocks left with truncated (lower-bound) level-set values: inside the fluid, never read by MC */
     uint64_t n_completed_blocks;      /* truncated blocks next to the surface that the second splat pass evaluated in full */
     double ms_levelset_accumulate_pass2; /* part of ms_levelset_accumulate: k_select_redo + the second launch of k_splat_fused */
+    uint64_t n_mc_blocks;             /* blocks of 8^3 cells marching cubes visited (their 2x2x2 level-set blocks straddle the threshold) */
+    double ms_density_kernel;         /* part of ms_density: k_density_sub (the neighbourhood search + SPH sums themselves) */
+    double ms_mc_count;               /* part of ms_marching_cubes: k_mc_count (classification, crossing masks, counts) */
+    double ms_mc_emit;                /* part of ms_marching_cubes: k_mc_emit (vertices, keys, triangles) */
 } ss_stats;
 
 typedef struct ss_context ss_context;
@@ -312,6 +316,11 @@ ss_status ss_comm_adopt_rccl(ss_context *ctx, void *nccl_comm, int rank, int wor
 /* in-process group without RCCL: `world` communicators for `world` contexts on ONE device, each driven by its own host
  * thread (how the tests run the whole algorithm on a single-GPU box; RCCL refuses two ranks on one device) */
 ss_status ss_comm_create_local_group(ss_context *const *ctxs, int world, ss_comm **out /* world entries */);
+/* Measurement aid for in-process groups (call it on any member before the threads start): with on = 1 a rank holds the shared device
+ * exclusively while it computes between two exchange steps and drains its stream before handing it on, so that the per-rank stage
+ * timers (ss_result_stats, ss_dist_info) read what the rank takes on a GPU of its own instead of the time it spent queueing behind the
+ * other ranks' kernels.  Results are unaffected. */
+ss_status ss_comm_local_group_take_turns(ss_comm *comm, int on);
 void ss_comm_destroy(ss_comm *comm);
 
 typedef struct ss_dist_info {
@@ -321,7 +330,9 @@ typedef struct ss_dist_info {
     uint64_t n_held;                     /* particles this rank holds (owned + ghosts) */
     uint64_t n_owned;                    /* particles contained in this rank's brick */
     uint64_t bytes_sent_positions, bytes_sent_densities, bytes_sent_assembly; /* payload this rank sent to OTHER ranks */
-    double ms_partition, ms_position_exchange, ms_density_exchange, ms_assembly; /* host wall time incl. device waits */
+    double ms_partition, ms_position_exchange, ms_density_exchange, ms_assembly; /* host wall time incl. device waits and waits for peers */
+    double ms_phase1, ms_phase2;         /* host wall time of the two phases of the rank's own reconstruction (binning + densities; level set + marching cubes) */
+    double ms_own_turns;                 /* ss_comm_local_group_take_turns only: time this rank held the device (all of its own work of the step, exchanges excluded) */
     uint64_t n_vertices_owned, vertex_offset, n_vertices_total;  /* after ss_dist_assemble */
     uint64_t n_triangles, triangle_offset, n_triangles_total;
 } ss_dist_info;

@@ -300,7 +300,7 @@ ss_status make_device_params(ss_context* ctx, const typename TypesOf<R>::params*
 
 ss_status ensure_events(ss_context* ctx) {
     if (ctx->ev_ok) return SS_OK;
-    for (int i = 0; i < 18; ++i) SS_HIP(ctx, hipEventCreate(&ctx->ev[i]));
+    for (int i = 0; i < 22; ++i) SS_HIP(ctx, hipEventCreate(&ctx->ev[i]));
     ctx->ev_ok = true;
     return SS_OK;
 }
@@ -679,6 +679,7 @@ ss_status phase_begin(ss_context* ctx, const R* xyz, uint64_t n_in, const typena
     s = stage_particles(ctx, xyz, n_in, prm, res, &d_xyz, &n);
     if (s != SS_OK) return s;
     res->n_particles = n;
+    res->density_kernel_timed = false;
     SS_HIP(ctx, hipEventRecord(ctx->ev[1], st));
 
     // ---- grid set-up (lib.rs:409-417, reconstruction.rs:24-29) ----
@@ -811,9 +812,12 @@ ss_status phase_begin(ss_context* ctx, const R* xyz, uint64_t n_in, const typena
             if (s != SS_OK) return s;
             ss_launch_compact_blocks(own_flag, own_rank, n_copies, own_list, ctx->cvals_a.as<uint32_t>(), st);  // (cvals_a: scratch for the unused slot table)
             const uint32_t n_owned_bound = n < n_copies ? n : n_copies;  // at most one owned copy per particle
+            SS_HIP(ctx, hipEventRecord(ctx->ev[18], st));
             ss_launch_density_sub(P, n_copies, ctx->cpos.as<ss_real4<R>>(), ctx->cidx.as<uint32_t>(), ctx->ckeys_b.as<uint32_t>(),
                                   ctx->cell_start2.as<uint32_t>(), ctx->occ_sub.as<uint32_t>(), res->rho.as<R>(), want_nb ? 1 : 0,
                                   ctx->nb_count.as<uint32_t>(), nullptr, nullptr, sizeof(R) == 4 && ctx->fastdiv_ok, own_list, own_rank + n_copies, n_owned_bound, st);
+            SS_HIP(ctx, hipEventRecord(ctx->ev[19], st));
+            res->density_kernel_timed = true;
             if (want_nb) {
                 // counts (u32, first n+1 entries) -> u64 -> exclusive scan = CSR row pointers
                 SS_HIP(ctx, ctx->nb_tmp.reserve(((size_t)n + 1) * 8));
@@ -1046,8 +1050,10 @@ ss_status phase_finish(ss_context* ctx, ss_result* res) {
     ss_launch_block_coords(P, res->mc_list.as<uint32_t>(), n_mc, res->mc_xyz.as<uint32_t>(), st);
     SS_HIP(ctx, ctx->mc_nb.reserve((size_t)n_mc * 96 + 64));
     ss_launch_mc_neighbours(P, res->mc_xyz.as<uint32_t>(), n_mc, res->block_slot.as<uint32_t>(), res->mc_slot.as<uint32_t>(), full_ls ? nullptr : tr_flag, ctx->mc_nb.as<uint32_t>(), st);
+    SS_HIP(ctx, hipEventRecord(ctx->ev[20], st));
     ss_launch_mc_count(P, res->G.as<R>(), ctx->mc_nb.as<uint32_t>(), res->mc_xyz.as<uint32_t>(), n_mc, res->masks.as<unsigned long long>(),
                        ctx->vcount.as<uint32_t>(), ctx->tcount.as<uint32_t>(), st);
+    SS_HIP(ctx, hipEventRecord(ctx->ev[21], st));
     SS_HIP(ctx, hipEventRecord(ctx->ev[7], st));
     // ---- "stitching": global numbering by prefix sums ----
     s = exclusive_scan_u32<uint32_t>(ctx, ctx->vcount.as<uint32_t>(), res->vbase.as<uint32_t>(), (size_t)n_mc + 1);
@@ -1115,6 +1121,10 @@ ss_status phase_finish(ss_context* ctx, ss_result* res) {
         ctx->early_enabled = frac > (ctx->early_enabled ? 0.30 : 0.35);
     }
     S.ms_levelset_accumulate_pass2 = ev_ms(ctx, 14, 15);
+    S.n_mc_blocks = n_mc;
+    S.ms_density_kernel = res->density_kernel_timed ? ev_ms(ctx, 18, 19) : 0.0;
+    S.ms_mc_count = ev_ms(ctx, 20, 21);
+    S.ms_mc_emit = ev_ms(ctx, 8, 9);
     S.n_certified_subblocks = n_cert_waves;
     S.n_truncated_blocks = n_trunc_left;
     S.n_completed_blocks = n_redo;
@@ -1464,7 +1474,7 @@ void ss_context_destroy(ss_context* c) {
         b->release();
     for (DevBuf& b : c->post_pool) b.release();
     if (c->ev_ok)
-        for (int i = 0; i < 18; ++i) (void)hipEventDestroy(c->ev[i]);
+        for (int i = 0; i < 22; ++i) (void)hipEventDestroy(c->ev[i]);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
 }

@@ -119,6 +119,12 @@ struct LocalGroup {
     std::vector<const uint8_t*> send_ptr;            // exchange: device send buffers
     std::vector<std::vector<uint64_t>> send_off;     // exchange: byte offsets per destination (world + 1)
     std::vector<const uint32_t*> red_ptr;            // allreduce: device buffers
+    // ss_comm_local_group_take_turns: the ranks share ONE device, so their kernels delay each other and a rank's stage timers show
+    // the crowd, not the rank.  With take_turns a rank holds `turn` while it computes between two exchange steps (never while it
+    // waits for a peer) and drains its stream before it hands the device on: its timers then read what the rank takes on a GPU of
+    // its own, which is what bench.py --pseudo-ranks reports.
+    std::mutex turn;
+    bool take_turns = false;
     bool barrier(double timeout_s) {
         std::unique_lock<std::mutex> lk(m);
         if (failed) return false;
@@ -173,6 +179,29 @@ struct ss_comm {
 namespace {
 
 ss_status comm_fail(ss_comm* c, const std::string& msg) { return fail(c->ctx, SS_ERR_DEVICE, msg); }
+
+// see LocalGroup::turn.  Never hold one across a barrier or a collective.
+struct TurnGuard {
+    ss_comm* c;
+    bool held;
+    double t_start = 0.0;
+    explicit TurnGuard(ss_comm* comm) : c(comm), held(comm->kind == 0 && comm->world > 1 && comm->group && comm->group->take_turns) {
+        if (held) {
+            c->group->turn.lock();
+            t_start = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+        }
+    }
+    void release() {
+        if (!held) return;
+        (void)hipStreamSynchronize(c->ctx->stream);  // the device is handed on idle
+        c->info.ms_own_turns += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count() - t_start;
+        c->group->turn.unlock();
+        held = false;
+    }
+    ~TurnGuard() { release(); }
+    TurnGuard(const TurnGuard&) = delete;
+    TurnGuard& operator=(const TurnGuard&) = delete;
+};
 
 // wait for the context's stream, but never forever: a peer that died leaves RCCL kernels spinning
 ss_status wait_stream(ss_comm* c, const char* what) {
@@ -606,6 +635,7 @@ ss_status pack_and_exchange(ss_comm* c, uint64_t n, uint64_t id0, const unsigned
     SS_HIP(ctx, c->keys_a.reserve((size_t)world * (n + 1) * 4 + 64));  // the flags of every destination, consumed by the pack kernels once the counts are known
     std::vector<uint32_t> cnt((size_t)world, 0u);
     std::vector<char> active((size_t)world, 0);
+    TurnGuard turn(c);  // flags, scans and packing are this rank's own work; released before the ranks meet
     for (int q = 0; q < world; ++q) {
         if (!flags_for(q)) continue;
         active[q] = 1;
@@ -627,6 +657,7 @@ ss_status pack_and_exchange(ss_comm* c, uint64_t n, uint64_t id0, const unsigned
         hipLaunchKernelGGL(k_pack_rows, grid_for(n), dim3(256), 0, st, n, c->keys_a.as<uint32_t>() + (size_t)q * (n + 1), c->offs.as<uint32_t>() + (size_t)q * (n + 1), id0, ids,
                            payload, payload_words, reinterpret_cast<uint32_t*>(c->sendbuf.as<uint8_t>() + send_off[q]));
     }
+    turn.release();
     // matrix[r][q] = rows rank r sends to rank q
     std::vector<uint64_t> matrix((size_t)world * world, 0);
     ss_status s = comm_allgather_host(c, send_rows.data(), (size_t)world * 8, matrix.data());
@@ -672,6 +703,7 @@ ss_status dist_reconstruct(ss_comm* c, const R* xyz_in, uint64_t n_local, const 
     memset(&zero_head, 0, sizeof(zero_head));
     mine_head = zero_head;
     mine_head.n = n_local;
+    TurnGuard turn(c);
     if (n_local) {
         SS_HIP(ctx, ctx->aabb_partial.reserve(1024 * 6 * sizeof(R)));
         SS_HIP(ctx, ctx->aabb_out.reserve(6 * sizeof(R)));
@@ -684,6 +716,7 @@ ss_status dist_reconstruct(ss_comm* c, const R* xyz_in, uint64_t n_local, const 
             mine_head.hi[d] = (double)h6[3 + d];
         }
     }
+    turn.release();
     std::vector<Head> heads((size_t)world);
     ss_status s = comm_allgather_host(c, &mine_head, sizeof(Head), heads.data());
     if (s != SS_OK) return s;
@@ -723,10 +756,13 @@ ss_status dist_reconstruct(ss_comm* c, const R* xyz_in, uint64_t n_local, const 
 
     // ---- 2. bricks from the all-reduced owner histogram ----
     SS_HIP(ctx, c->hist.reserve(nsub * 4 + 64));
-    SS_HIP(ctx, hipMemsetAsync(c->hist.p, 0, nsub * 4, st));
-    if (n_local)
-        hipLaunchKernelGGL(k_owner_hist<R>, grid_for(n_local), dim3(256), 0, st, d_xyz, n_local, grid.aabb_min[0], grid.aabb_min[1], grid.aabb_min[2], subgrid.cell_size, ns[0],
-                           ns[1], ns[2], c->hist.as<uint32_t>());
+    {
+        TurnGuard hist_turn(c);
+        SS_HIP(ctx, hipMemsetAsync(c->hist.p, 0, nsub * 4, st));
+        if (n_local)
+            hipLaunchKernelGGL(k_owner_hist<R>, grid_for(n_local), dim3(256), 0, st, d_xyz, n_local, grid.aabb_min[0], grid.aabb_min[1], grid.aabb_min[2], subgrid.cell_size, ns[0],
+                               ns[1], ns[2], c->hist.as<uint32_t>());
+    }
     s = comm_allreduce_sum_u32(c, c->hist.as<uint32_t>(), nsub);
     if (s != SS_OK) return s;
     std::vector<uint32_t> h_hist(nsub);
@@ -780,6 +816,7 @@ ss_status dist_reconstruct(ss_comm* c, const R* xyz_in, uint64_t n_local, const 
     // ascending global-id order the engine needs (no sort).
     SS_HIP(ctx, c->gids.reserve(n_held * 8 + 64));
     SS_HIP(ctx, c->L.reserve(n_held * 3 * sizeof(R) + 64));
+    TurnGuard phase1_turn(c);  // unpacking and phase 1 are this rank's own work
     if (n_held)
         hipLaunchKernelGGL(k_unpack_rows, grid_for(n_held), dim3(256), 0, st, n_held, c->recvbuf.as<uint32_t>(), pos_words, c->gids.as<unsigned long long>(), c->L.as<uint32_t>());
     SS_HIP(ctx, hipStreamSynchronize(st));
@@ -794,8 +831,13 @@ ss_status dist_reconstruct(ss_comm* c, const R* xyz_in, uint64_t n_local, const 
         shard.sub_lo[d] = my_lo[d];
         shard.sub_hi[d] = my_hi[d];
     }
+    t0 = now_ms();
     s = T::begin(ctx, c->L.as<R>(), n_held, prm, &shard, res);
     if (s != SS_OK) return s;
+    // phase 1 returns with its last kernels in flight: drain the stream before the exchange's clock starts (round 2 billed them
+    // to the exchange: a one-rank run reported 10.7 ms of "exchange" for 0 bytes)
+    SS_HIP(ctx, hipStreamSynchronize(st));
+    c->info.ms_phase1 = now_ms() - t0;
     t0 = now_ms();
 
     // ---- 5. halo densities: owners -> ranks holding the particle as a ghost ----
@@ -814,6 +856,7 @@ ss_status dist_reconstruct(ss_comm* c, const R* xyz_in, uint64_t n_local, const 
             c->info.n_owned = h_owned;
         }
     }
+    phase1_turn.release();
     uint64_t n_rho_rows = 0;
     const int rho_words = (int)(sizeof(R) / 4);
     s = pack_and_exchange(c, n_held, 0, c->gids.as<unsigned long long>(), reinterpret_cast<const uint32_t*>(res->rho.as<R>()), rho_words,
@@ -826,6 +869,7 @@ ss_status dist_reconstruct(ss_comm* c, const R* xyz_in, uint64_t n_local, const 
                           },
                           &n_rho_rows, &c->info.bytes_sent_densities);
     if (s != SS_OK) return s;
+    TurnGuard phase2_turn(c);  // scattering the received densities and phase 2
     SS_HIP(ctx, c->err.reserve(64));
     SS_HIP(ctx, hipMemsetAsync(c->err.p, 0, 4, st));
     if (n_rho_rows)
@@ -839,8 +883,11 @@ ss_status dist_reconstruct(ss_comm* c, const R* xyz_in, uint64_t n_local, const 
     c->info.ms_density_exchange = now_ms() - t0;
 
     // ---- 6. phase 2: level set + marching cubes of the brick ----
+    t0 = now_ms();
     s = ss_shard_finish(ctx, res);
     if (s != SS_OK) return s;
+    c->info.ms_phase2 = now_ms() - t0;
+    phase2_turn.release();
 
     // load balance of the partition, identical on every rank
     uint64_t pair[2] = {c->info.n_owned, c->info.n_held};
@@ -885,6 +932,7 @@ ss_status dist_assemble(ss_comm* c, ss_result* res) {
     SS_HIP(ctx, c->mine_off.reserve((nv + 1) * 4 + 64));
     SS_HIP(ctx, c->vals_a.reserve((nv + 1) * 4 + 64));  // mine flags
     const unsigned long long* keys = res->vkeys.as<unsigned long long>();
+    TurnGuard turn(c);
     if (nv) hipLaunchKernelGGL(k_vertex_owner, grid_for(nv), dim3(256), 0, st, nv, keys, B, np1, np2, c->owner.as<uint32_t>(), c->holder.as<unsigned long long>());
     uint32_t* mine = c->vals_a.as<uint32_t>();
     hipLaunchKernelGGL(k_vertex_flags, grid_for(nv + 1), dim3(256), 0, st, nv, c->owner.as<uint32_t>(), c->holder.as<unsigned long long>(), (uint32_t)me, -1, mine);
@@ -893,6 +941,7 @@ ss_status dist_assemble(ss_comm* c, ss_result* res) {
     uint32_t n_owned = 0;
     SS_HIP(ctx, hipMemcpyAsync(&n_owned, c->mine_off.as<uint32_t>() + nv, 4, hipMemcpyDeviceToHost, st));
     SS_HIP(ctx, hipStreamSynchronize(st));
+    turn.release();
     uint64_t cnt[2] = {n_owned, nt};
     std::vector<uint64_t> all((size_t)world * 2);
     s = comm_allgather_host(c, cnt, sizeof(cnt), all.data());
@@ -906,7 +955,10 @@ ss_status dist_assemble(ss_comm* c, ss_result* res) {
         vtot += all[(size_t)q * 2];
         ttot += all[(size_t)q * 2 + 1];
     }
-    if (nv) hipLaunchKernelGGL(k_owned_gids, grid_for(nv), dim3(256), 0, st, nv, mine, c->mine_off.as<uint32_t>(), (unsigned long long)voff, c->gid_local.as<unsigned long long>());
+    {
+        TurnGuard gid_turn(c);
+        if (nv) hipLaunchKernelGGL(k_owned_gids, grid_for(nv), dim3(256), 0, st, nv, mine, c->mine_off.as<uint32_t>(), (unsigned long long)voff, c->gid_local.as<unsigned long long>());
+    }
     // owners -> the other ranks holding the edge: (key, global id)
     uint64_t n_rows = 0;
     s = pack_and_exchange(c, nv, 0, keys, reinterpret_cast<const uint32_t*>(c->gid_local.as<unsigned long long>()), 2,
@@ -920,6 +972,7 @@ ss_status dist_assemble(ss_comm* c, ss_result* res) {
                           },
                           &n_rows, &c->info.bytes_sent_assembly);
     if (s != SS_OK) return s;
+    TurnGuard join_turn(c);
     SS_HIP(ctx, c->err.reserve(64));
     SS_HIP(ctx, hipMemsetAsync(c->err.p, 0, 4, st));
     if (n_rows || nv) {
@@ -1064,6 +1117,13 @@ ss_status ss_comm_create_local_group(ss_context* const* ctxs, int world, ss_comm
         c->timeout_s = env_timeout();
         out[q] = c;
     }
+    return SS_OK;
+}
+
+ss_status ss_comm_local_group_take_turns(ss_comm* c, int on) {
+    if (!c || c->kind != 0 || !c->group) return SS_ERR_INVALID_ARGUMENT;
+    std::lock_guard<std::mutex> lk(c->group->m);
+    c->group->take_turns = on != 0;
     return SS_OK;
 }
 

@@ -78,7 +78,7 @@ struct ss_context {
     DevBuf nb_count, nb_tmp;
     DevBuf own_flag;  // per subdomain copy: owned flag, its scan, the list of owned copies
     DevBuf member_count, copy_offset, sub_flag, sub_rank, occ_sub, ckeys_a, ckeys_b, cvals_a, cidx, cpos, cell_count2, cell_start2;
-    hipEvent_t ev[18];  // 0..9 stage boundaries, 10/11 start of phase 2, 12..15 inside the splat, 16/17 around the arena-path gather
+    hipEvent_t ev[22];  // 0..9 stage boundaries, 10/11 start of phase 2, 12..15 inside the splat, 16/17 around the arena-path gather, 18/19 k_density_sub, 20/21 k_mc_count
     // the two-pass splat pays off when enough sub-blocks get certified 'inside' (bulk fluid); thin structures do not -- decided per
     // workload from the previous call's statistics, re-probed now and then
     uint64_t early_key = 0;
@@ -123,6 +123,7 @@ struct ss_result {
     bool global_strategy = false;  // reconstruct_surface_global ran: subdomain_grid is None, G is dense over grid.n_points
     int phase = 0;  // 0 nothing, 1 after phase_begin, 2 complete
     bool host_input = false;
+    bool density_kernel_timed = false;  // events 18/19 were recorded by this call (they are not when no particle has a copy)
     uint64_t n_occupied_subdomains = 0, n_subdomain_particles = 0;
     ss_stats stats;
     // device results

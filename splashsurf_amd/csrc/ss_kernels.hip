@@ -22,13 +22,26 @@
 #include "ss_kernels.h"
 
 // MC table in emitted (winding-flipped) order, see tools/gen_mc_table.py
-__constant__ int8_t c_mc_table[256][16] = {
+__constant__ __attribute__((aligned(16))) int8_t c_mc_table[256][16] = {
 #include "mc_table.inc"
 };
 // uniform_grid.rs:825-834
 __constant__ int8_t c_corner[8][3] = {{0, 0, 0}, {1, 0, 0}, {1, 1, 0}, {0, 1, 0}, {0, 0, 1}, {1, 0, 1}, {1, 1, 1}, {0, 1, 1}};
 // uniform_grid.rs:856-869: local edge -> (origin corner, axis)
 __constant__ int8_t c_edge[12][2] = {{0, 0}, {1, 1}, {3, 0}, {0, 1}, {4, 0}, {5, 1}, {7, 0}, {4, 1}, {0, 2}, {1, 2}, {2, 2}, {3, 2}};
+// the same two tables folded into one word: 5 bits per local edge e, (ox << 4) | (oy << 3) | (oz << 2) | axis of the edge's origin
+// corner -- decoded with a shift instead of five dependent byte loads per triangle corner
+constexpr unsigned long long ss_mc_edge_code(int e) {
+    constexpr int corner[8][3] = {{0, 0, 0}, {1, 0, 0}, {1, 1, 0}, {0, 1, 0}, {0, 0, 1}, {1, 0, 1}, {1, 1, 1}, {0, 1, 1}};
+    constexpr int edge[12][2] = {{0, 0}, {1, 1}, {3, 0}, {0, 1}, {4, 0}, {5, 1}, {7, 0}, {4, 1}, {0, 2}, {1, 2}, {2, 2}, {3, 2}};
+    return (unsigned long long)((corner[edge[e][0]][0] << 4) | (corner[edge[e][0]][1] << 3) | (corner[edge[e][0]][2] << 2) | edge[e][1]);
+}
+constexpr unsigned long long ss_mc_edge_codes() {
+    unsigned long long w = 0;
+    for (int e = 0; e < 12; ++e) w |= ss_mc_edge_code(e) << (5 * e);
+    return w;
+}
+#define SS_MC_EDGE_CODES ss_mc_edge_codes()
 
 // =====================================================================================================
 // K0: bounding box
@@ -2101,10 +2114,9 @@ __device__ inline McLocal mc_classify(const McTile<R>& t, const SSDevT<R>& P, in
             L.case_index |= (v > thr ? 1 : 0) << c;  // marching_cubes_lut.rs:322-329
         }
     }
-    int nt = 0;
-#pragma unroll
-    for (int i = 0; i < 5; ++i) nt += (c_mc_table[L.case_index][3 * i] >= 0) ? 1 : 0;
-    L.ntri = nt;
+    // triangles of the case: the row's entries 0, 3, 6, 9, 12 that are >= 0 (one 16-byte load, sign bits)
+    const uint4 row = *reinterpret_cast<const uint4*>(&c_mc_table[L.case_index][0]);
+    L.ntri = (int)(((~row.x >> 7) & 1u) + ((~row.x >> 31) & 1u) + ((~row.y >> 23) & 1u) + ((~row.z >> 15) & 1u) + ((~row.w >> 7) & 1u));
     return L;
 }
 
@@ -2189,10 +2201,13 @@ __global__ __launch_bounds__(512) void k_mc_emit(SSDevT<R> P, const R* __restric
     __shared__ uint32_t s_pref[8][24];            // vertices of that neighbour block before (axis, word)
     __shared__ uint32_t s_vbase[8];
     __shared__ uint32_t s_twave[8];
+    __shared__ uint32_t s_rec[8][5 * 64];  // per wave: (cell, triangle number, case) of its triangles, in cell order
+    __shared__ int8_t s_lut[256 * 16];     // the case table: the corner look-ups of a trip hit 64 different rows
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t m = blockIdx.x;
     if (m >= n_mc) return;
     if (vbase[m + 1] == vbase[m] && tbase[m + 1] == tbase[m]) return;  // nothing to emit for this block
+    reinterpret_cast<unsigned long long*>(s_lut)[tid] = reinterpret_cast<const unsigned long long*>(&c_mc_table[0][0])[tid];
     const int bx = (int)mc_xyz[3 * (size_t)m], by = (int)mc_xyz[3 * (size_t)m + 1], bz = (int)mc_xyz[3 * (size_t)m + 2];  // k_block_coords
     if (tid < SS_MC_REC) s_nb[tid] = mc_nb[SS_MC_REC * (size_t)m + tid];
     __syncthreads();
@@ -2254,7 +2269,11 @@ __global__ __launch_bounds__(512) void k_mc_emit(SSDevT<R> P, const R* __restric
                       (unsigned long long)O[2]) * 3ull + (unsigned long long)a;
     }
 
-    // ---- triangles of this thread's cell ----
+    // ---- triangles ----
+    // Only one cell in eight of a surface block has triangles: a loop "for my cell's triangles" keeps a few lanes busy for five
+    // trips and scatters 12-byte stores.  Instead every lane files a record (cell, case, triangle number) per triangle of its cell
+    // at the triangle's rank within the wave, and the wave then emits records 64 at a time: lane k builds the k-th triangle, so
+    // the stores of a trip form one contiguous run.
     uint32_t incl = (uint32_t)L.ntri;
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) {
@@ -2262,23 +2281,30 @@ __global__ __launch_bounds__(512) void k_mc_emit(SSDevT<R> P, const R* __restric
         if (lane >= off) incl += t;
     }
     if (lane == 63) s_twave[wave] = incl;
+    const uint32_t excl = incl - (uint32_t)L.ntri;
+    for (int i = 0; i < L.ntri; ++i) s_rec[wave][excl + (uint32_t)i] = (uint32_t)tid | ((uint32_t)i << 9) | ((uint32_t)L.case_index << 12);
     __syncthreads();
-    uint32_t toff = tbase[m] + incl - (uint32_t)L.ntri;
+    uint32_t toff = tbase[m];
     for (int w = 0; w < wave; ++w) toff += s_twave[w];
-    for (int i = 0; i < L.ntri; ++i) {
+    const uint32_t n_wave = s_twave[wave];
+    for (uint32_t k = (uint32_t)lane; k < n_wave; k += 64u) {
+        const uint32_t rec = s_rec[wave][k];
+        const int cell = (int)(rec & 511u), i = (int)((rec >> 9) & 7u), cs = (int)(rec >> 12);
+        const int cx = cell >> 6, cy = (cell >> 3) & 7, cz = cell & 7;
         uint32_t tri[3];
 #pragma unroll
         for (int v = 0; v < 3; ++v) {
-            const int e = c_mc_table[L.case_index][3 * i + v];
-            const int oc = c_edge[e][0], a = c_edge[e][1];
-            const int ox = lx + c_corner[oc][0], oy = ly + c_corner[oc][1], oz = lz + c_corner[oc][2];
+            const int e = s_lut[cs * 16 + 3 * i + v];
+            const uint32_t code = (uint32_t)(SS_MC_EDGE_CODES >> (5 * e)) & 31u;  // origin corner offsets and axis of local edge e
+            const int a = (int)(code & 3u);
+            const int ox = cx + (int)((code >> 4) & 1u), oy = cy + (int)((code >> 3) & 1u), oz = cz + (int)((code >> 2) & 1u);
             const int nb = ((ox >> 3) << 2) | ((oy >> 3) << 1) | (oz >> 3);
             const int p = (((ox & 7) * 8) + (oy & 7)) * 8 + (oz & 7);
             const int w = p >> 6, bit = p & 63;
             const unsigned long long bl = (bit == 0) ? 0ull : (~0ull >> (64 - bit));
             tri[v] = s_vbase[nb] + s_pref[nb][a * 8 + w] + (uint32_t)__popcll(s_mask[nb][a * 8 + w] & bl);
         }
-        const size_t o = 3 * (size_t)(toff + (uint32_t)i);
+        const size_t o = 3 * (size_t)(toff + k);
         triangles[o] = tri[0];
         triangles[o + 1] = tri[1];
         triangles[o + 2] = tri[2];

@@ -619,7 +619,7 @@ class _DistInfo(C.Structure):
     _fields_ = [("rank", C.c_int32), ("world", C.c_int32), ("brick_lo", C.c_int64 * 3), ("brick_hi", C.c_int64 * 3), ("n_total", C.c_uint64),
                 ("n_held", C.c_uint64), ("n_owned", C.c_uint64), ("bytes_sent_positions", C.c_uint64), ("bytes_sent_densities", C.c_uint64),
                 ("bytes_sent_assembly", C.c_uint64), ("ms_partition", C.c_double), ("ms_position_exchange", C.c_double), ("ms_density_exchange", C.c_double),
-                ("ms_assembly", C.c_double), ("n_vertices_owned", C.c_uint64), ("vertex_offset", C.c_uint64), ("n_vertices_total", C.c_uint64),
+                ("ms_assembly", C.c_double), ("ms_phase1", C.c_double), ("ms_phase2", C.c_double), ("ms_own_turns", C.c_double), ("n_vertices_owned", C.c_uint64), ("vertex_offset", C.c_uint64), ("n_vertices_total", C.c_uint64),
                 ("n_triangles", C.c_uint64), ("triangle_offset", C.c_uint64), ("n_triangles_total", C.c_uint64)]
 
 
@@ -634,6 +634,7 @@ def _dist_lib(ctx):
         L.ss_comm_create_local_group.argtypes = [C.POINTER(vp), i32, C.POINTER(vp)]
         L.ss_comm_destroy.argtypes = [vp]
         L.ss_comm_destroy.restype = None
+        L.ss_comm_local_group_take_turns.argtypes = [vp, i32]
         L.ss_dist_reconstruct_f32.argtypes = [vp, vp, u64, C.POINTER(api._Params), vp]
         L.ss_dist_reconstruct_f64.argtypes = [vp, vp, u64, C.POINTER(api._Params64), vp]
         L.ss_dist_assemble.argtypes = [vp, vp]
@@ -674,7 +675,9 @@ class NativeComm:
         return cls(ctx, h, rank, world, "rccl")
 
     @classmethod
-    def local_group(cls, ctxs):
+    def local_group(cls, ctxs, take_turns=False):
+        """`take_turns`: ss_comm_local_group_take_turns -- the ranks compute one at a time on the shared device, so that per-rank
+        timers read what a rank takes on its own GPU (bench.py --pseudo-ranks)."""
         L = _dist_lib(ctxs[0])
         n = len(ctxs)
         hs = (C.c_void_p * n)(*[c._h for c in ctxs])
@@ -682,6 +685,10 @@ class NativeComm:
         st = L.ss_comm_create_local_group(hs, n, out)
         if st != 0:
             raise RuntimeError("ss_comm_create_local_group failed: %d" % st)
+        if take_turns:
+            st = L.ss_comm_local_group_take_turns(C.c_void_p(out[0]), 1)
+            if st != 0:
+                raise RuntimeError("ss_comm_local_group_take_turns failed: %d" % st)
         return [cls(ctxs[q], C.c_void_p(out[q]), q, n, "local") for q in range(n)]
 
     def destroy(self):

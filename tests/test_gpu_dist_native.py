@@ -37,12 +37,12 @@ def _params(r, l, c, n_cubes, dt, simd):
                       enable_simd=simd)
 
 
-def _run_ranks(pts, prm, world, transport="local"):
+def _run_ranks(pts, prm, world, transport="local", take_turns=False):
     """Returns per-rank dicts (info, partition, gids, rho, mesh piece).  Rank r contributes the r-th contiguous slice of pts."""
     from splashsurf_amd import distributed as D
     from splashsurf_amd.api import Context
     ctxs = [Context(0) for _ in range(world)]
-    comms = D.NativeComm.local_group(ctxs) if transport == "local" else [D.NativeComm.rccl(ctxs[0], rank=0, world=1)]
+    comms = D.NativeComm.local_group(ctxs, take_turns=take_turns) if transport == "local" else [D.NativeComm.rccl(ctxs[0], rank=0, world=1)]
     cut = [int(round(pts.shape[0] * k / world)) for k in range(world + 1)]
     out, errors = [None] * world, []
 
@@ -124,6 +124,25 @@ def test_native_ranks_reproduce_single_context(gpu_ctx, case, world, dt, simd):
     _check_against_direct(pts, prm, ranks, gpu_ctx)
     if case == "tank_crop":  # 18 subdomains for 8 ranks: whole-subdomain bricks cannot balance better than this
         assert ranks[0]["partition"]["imbalance_owned"] <= 1.6, ranks[0]["partition"]
+
+
+def test_native_full_s40m_tank_four_ranks(gpu_ctx):
+    """BASELINE config 4 at FULL size through the native multi-GPU path: the 39.8 M-particle S40M-tank cut into four bricks (in-process
+    transport, the ranks taking turns on the device like bench.py --pseudo-ranks), exchanges and rank-owned assembly included; densities of
+    every held particle, vertices, edge keys and triangles of the merged mesh equal the single-context reconstruction bit for bit."""
+    from splashsurf_amd import workloads as W
+    wl = W.WORKLOADS["s40m_tank"]
+    pts = wl["gen"]()
+    assert pts.shape[0] > 39_000_000
+    prm = _params(wl["particle_radius"], wl["smoothing_length"], wl["cube_size"], 64, np.float32, 1)
+    ranks = _run_ranks(pts, prm, 4, take_turns=True)
+    _check_against_direct(pts, prm, ranks, gpu_ctx)
+    part = ranks[0]["partition"]
+    assert part["imbalance_owned"] <= 1.05, part
+    for r in ranks:  # the phases have their own clocks (round 2 billed phase 1 to the density exchange) and the turn timer ran
+        i = r["info"]
+        assert i["ms_phase1"] > 0.0 and i["ms_phase2"] > 0.0
+        assert 0.0 < i["ms_own_turns"] < i["ms_partition"] + i["ms_position_exchange"] + i["ms_phase1"] + i["ms_density_exchange"] + i["ms_phase2"] + i["ms_assembly"]
 
 
 def test_native_more_ranks_than_subdomains(gpu_ctx):

@@ -46,7 +46,7 @@ def main():
     for _ in range(a.warmup):
         out = ctx.reconstruct(d, prm, out=out)
     keys = ["ms_total", "ms_decomposition", "ms_density", "ms_levelset_prepare", "ms_levelset", "ms_levelset_gather", "ms_levelset_accumulate", "ms_levelset_accumulate_pass2",
-            "ms_marching_cubes", "ms_stitching"]
+            "ms_marching_cubes", "ms_stitching", "ms_density_kernel", "ms_mc_count", "ms_mc_emit"]
     acc = {k: [] for k in keys}
     for _ in range(a.steps):
         out = ctx.reconstruct(d, prm, out=out)
@@ -59,7 +59,7 @@ def main():
     line["ms_total_min"] = round(float(np.min(acc["ms_total"])), 4)
     na = max(int(s.get("n_active_blocks", 0)), 1)
     line.update(n_active=int(s.get("n_active_blocks", 0)), certified_frac=round(float(s.get("n_certified_subblocks", 0)) / (8.0 * na), 4),
-                n_completed=int(s.get("n_completed_blocks", 0)), n_large=int(s.get("n_large_tile_blocks", 0)), n_vertices=int(s["n_vertices"]), n_triangles=int(s["n_triangles"]))
+                n_completed=int(s.get("n_completed_blocks", 0)), n_mc=int(s.get("n_mc_blocks", 0)), n_large=int(s.get("n_large_tile_blocks", 0)), n_vertices=int(s["n_vertices"]), n_triangles=int(s["n_triangles"]))
     if a.digest:
         h = hashlib.sha256()
         h.update(np.ascontiguousarray(out.particle_densities).tobytes())
