@@ -117,6 +117,38 @@ def cpu_baseline(workload, scale):
     }
 
 
+def kernel_source_stamp():
+    """Digest of the kernel sources: profiles/splat_traffic.json carries the stamp of the build it was collected from."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in ("ss_kernels.hip", "ss_device.h", "ss_api.hip"):
+        h.update(open(os.path.join(ROOT, "splashsurf_amd", "csrc", f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+_PEAK_MEASURED = {}
+
+
+def measured_hbm_peak(ctx):
+    """(read, copy) GB/s of float4 streams over 2 GiB buffers on this device (ss_measure_hbm_bandwidth), measured once per process."""
+    if "v" not in _PEAK_MEASURED:
+        try:
+            _PEAK_MEASURED["v"] = ctx.measure_hbm_bandwidth(2 << 30, 5)
+        except Exception:
+            _PEAK_MEASURED["v"] = None
+    return _PEAK_MEASURED["v"]
+
+
+def add_measured_peak(roof, ctx):
+    pk = measured_hbm_peak(ctx)
+    if pk:
+        roof["peak_measured"] = {"read_gbs": round(pk[0], 1), "copy_gbs": round(pk[1], 1),
+                                 "note": "float4 read stream / float4 copy (read + write bytes) over 2 GiB buffers in this run (ss_measure_hbm_bandwidth); "
+                                         "`peak` is the data-sheet 8 TB/s"}
+        roof["frac_of_measured_peak"] = round(roof["achieved"] / max(pk[0], pk[1]), 5)
+    return roof
+
+
 def splat_roofline(st, n_occ, n_subp, nsc, k3_acc_ms, k3_large_ms):
     """roofline object of the dominant splat kernel from one rank's stats (16 B per subdomain particle incl.
     ghosts + 4 B per level-set value of every occupied subdomain)."""
@@ -530,6 +562,13 @@ def main():
 
     if not sharded_path and not args.main_only:
         single_gpu_extras(line, args, ctx, prm, wl, workload, pts, d_pts, out, dev, local_rank, sync)
+        add_measured_peak(line["roofline"], ctx)
+        # SURVEY.md 8(d)(i) defines the metric host-to-host; the task contract defines `value` with inputs resident in HBM.  Both lead the record:
+        h2h = line.get("e2e_host_u64") or {}
+        line["value_host_to_host"] = h2h.get("value")
+        line["ms_per_step_host_to_host"] = h2h.get("ms_per_step")
+        line["config"]["value_semantics"] = ("value: particles already in HBM, mesh left in HBM (task contract); value_host_to_host: pageable host input -> vertices + u64 "
+                                             "triangle indices in host memory through the C ABI's accessors (SURVEY.md 8(d)(i)), one frame at a time, PCIe not overlapped")
     if not sharded_path:
         attach_traffic(line, workload, dev)
     if rank == 0:
@@ -550,9 +589,18 @@ def attach_traffic(line, workload, dev):
         tr = json.load(open(os.path.join(ROOT, "profiles", "splat_traffic.json"))).get(workload)
         if isinstance(tr, dict) and "simd" in tr and "scalar" in tr:
             tr = tr[{0: "scalar", 1: "simd", 2: "simd_hw"}[int(line["config"].get("enable_simd", 0))]]
+        stamp = (json.load(open(os.path.join(ROOT, "profiles", "splat_traffic.json"))).get("_collected_from") or {}).get("kernel_source_stamp")
+        if tr and stamp != kernel_source_stamp():
+            line["roofline"]["traffic_note"] = ("profiles/splat_traffic.json was collected from other kernel sources (stamp %s, this build %s): not attached; "
+                                                "re-run tools/collect_profiles.sh + tools/make_profiles.py" % (stamp, kernel_source_stamp()))
+            tr = None
         if tr and tr.get("kernel", "").startswith(line["roofline"]["kernel"]):
             line["roofline"]["traffic"] = tr["hbm_bytes_per_launch"]
             line["roofline"]["traffic_note"] = tr["note"]
+            if line["roofline"]["kernel_ms"] > 0:
+                # the kernel's real HBM rate (PMC bytes of the profiled run over this run's kernel time), beside the algorithmic one
+                line["roofline"]["achieved_traffic"] = round(tr["hbm_bytes_per_launch"] / (line["roofline"]["kernel_ms"] * 1e-3) / 1e9, 2)
+                line["roofline"]["achieved_traffic_frac"] = round(line["roofline"]["achieved_traffic"] / 8000.0, 5)
             if tr.get("valu_insts_per_launch") and line["roofline"]["kernel_ms"] > 0:
                 # the kernel's real bound (informative): share of the VALU issue slots it uses, 1024 SIMDs, one wave64
                 # instruction per 2 cycles, at the device's maximum engine clock

@@ -191,6 +191,10 @@ enum { SS_OPTION_FULL_LEVELSET = 1, SS_OPTION_SPLAT_TWO_PASS = 2 };
 ss_status ss_context_set_option(ss_context *ctx, int option, int value);
 /* use an existing HIP stream (hipStream_t passed as void*); NULL = context's own stream */
 ss_status ss_context_set_stream(ss_context *ctx, void *hip_stream);
+/* Measurement aid: the HBM rate this device sustains for a float4 read stream and for a float4 copy (read + write bytes counted) over
+ * buffers of `bytes` each (use >= 1 GiB: beyond the 256 MiB Infinity Cache), best of `repetitions` -- the measured peak beside which
+ * bench.py quotes the splat kernel's roofline fraction; GB/s = 1e9 bytes per second. */
+ss_status ss_measure_hbm_bandwidth(ss_context *ctx, uint64_t bytes, int repetitions, double *read_gbs, double *copy_gbs);
 
 /* -- the boundary -- */
 ss_status ss_reconstruct_surface_f32(ss_context *ctx, const float *xyz, uint64_t n_particles,

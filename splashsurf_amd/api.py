@@ -353,6 +353,15 @@ class Context:
         if st != 0:
             self._raise(st)
 
+    def measure_hbm_bandwidth(self, nbytes=2 << 30, repetitions=5):
+        """ss_measure_hbm_bandwidth: (read GB/s, copy GB/s) this device sustains for float4 streams over `nbytes` per buffer."""
+        rd, cp = C.c_double(), C.c_double()
+        self._lib.ss_measure_hbm_bandwidth.argtypes = [C.c_void_p, C.c_uint64, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+        st = self._lib.ss_measure_hbm_bandwidth(self._h, int(nbytes), int(repetitions), C.byref(rd), C.byref(cp))
+        if st != 0:
+            self._raise(st)
+        return float(rd.value), float(cp.value)
+
     def set_stream(self, hip_stream_ptr):
         st = self._lib.ss_context_set_stream(self._h, C.c_void_p(hip_stream_ptr))
         if st != 0:

@@ -1496,6 +1496,36 @@ ss_status ss_context_set_option(ss_context* c, int option, int value) {
     return fail(c, SS_ERR_INVALID_ARGUMENT, "unknown context option");
 }
 
+ss_status ss_measure_hbm_bandwidth(ss_context* c, uint64_t bytes, int repetitions, double* read_gbs, double* copy_gbs) {
+    if (!c || !read_gbs || !copy_gbs || repetitions < 1 || bytes < (1ull << 20)) return SS_ERR_INVALID_ARGUMENT;
+    SS_HIP(c, hipSetDevice(c->device));
+    ss_status s = ensure_events(c);
+    if (s != SS_OK) return s;
+    hipStream_t st = c->stream;
+    const size_t n4 = (size_t)(bytes / 16);
+    DevBuf a, b;
+    SS_HIP(c, a.reserve(n4 * 16 + 64));
+    SS_HIP(c, b.reserve(n4 * 16 + 64));
+    SS_HIP(c, hipMemsetAsync(a.p, 0, n4 * 16, st));
+    SS_HIP(c, hipMemsetAsync(b.p, 0, n4 * 16, st));
+    double best[2] = {0.0, 0.0};
+    for (int mode = 0; mode < 2; ++mode)
+        for (int r = 0; r < repetitions + 1; ++r) {  // (the first launch is a warm-up)
+            SS_HIP(c, hipEventRecord(c->ev[0], st));
+            ss_launch_stream_probe(mode == 1, a.p, b.p, n4, b.as<float>(), st);
+            SS_HIP(c, hipEventRecord(c->ev[1], st));
+            SS_HIP(c, hipStreamSynchronize(st));
+            const double ms = ev_ms(c, 0, 1);
+            const double gbs = (double)(n4 * 16) * (mode == 1 ? 2.0 : 1.0) / (ms * 1.0e6);
+            if (r > 0 && gbs > best[mode]) best[mode] = gbs;
+        }
+    a.release();
+    b.release();
+    *read_gbs = best[0];
+    *copy_gbs = best[1];
+    return SS_OK;
+}
+
 ss_status ss_context_set_stream(ss_context* c, void* hip_stream) {
     if (!c) return SS_ERR_INVALID_ARGUMENT;
     c->stream = hip_stream ? reinterpret_cast<hipStream_t>(hip_stream) : c->own_stream;

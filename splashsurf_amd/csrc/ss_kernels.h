@@ -51,6 +51,7 @@ template <class R>
 void ss_launch_mc_count(const SSDevT<R>& P, const R* G, const uint32_t* mc_nb, const uint32_t* mc_xyz, uint32_t n_mc, unsigned long long* masks, uint32_t* vcount, uint32_t* tcount, hipStream_t st);
 template <class R>
 void ss_launch_mc_emit(const SSDevT<R>& P, const R* G, const uint32_t* mc_nb, const uint32_t* mc_xyz, const uint32_t* mc_slot, uint32_t n_mc, const unsigned long long* masks, const uint32_t* vbase, const uint32_t* tbase, R* vertices, unsigned long long* vkeys, uint32_t* triangles, hipStream_t st);
+void ss_launch_stream_probe(bool copy, const void* in, void* out, size_t n_float4, float* sink, hipStream_t st);
 void ss_launch_widen(const uint32_t* in, size_t n, unsigned long long* out, hipStream_t st);
 template <class R>
 void ss_launch_levelset_box(const SSDevT<R>& P, const R* G, const uint32_t* block_slot, const int lo[3], const int ext[3], R* out, hipStream_t st);

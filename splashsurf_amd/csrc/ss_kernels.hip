@@ -2332,6 +2332,30 @@ void ss_launch_mc_emit(const SSDevT<R>& P, const R* G, const uint32_t* mc_nb, co
 }
 
 // =====================================================================================================
+// HBM bandwidth probe (ss_measure_hbm_bandwidth): a float4 read stream or a float4 copy, grid-stride, the
+// achievable rate the splat's roofline fraction is also quoted against
+// =====================================================================================================
+template <bool COPY>
+__global__ __launch_bounds__(256) void k_stream_probe(const float4* __restrict__ in, float4* __restrict__ out, size_t n, float* __restrict__ sink) {
+    float acc = 0.0f;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const float4 v = in[i];
+        if (COPY)
+            out[i] = v;
+        else
+            acc += v.x + v.y + v.z + v.w;
+    }
+    if (!COPY && acc == 123.456f) *sink = acc;  // (keeps the loads alive; never true for the zeroed buffer)
+}
+void ss_launch_stream_probe(bool copy, const void* in, void* out, size_t n_float4, float* sink, hipStream_t st) {
+    const dim3 g(256 * 32), b(256);
+    if (copy)
+        hipLaunchKernelGGL(k_stream_probe<true>, g, b, 0, st, (const float4*)in, (float4*)out, n_float4, sink);
+    else
+        hipLaunchKernelGGL(k_stream_probe<false>, g, b, 0, st, (const float4*)in, (float4*)out, n_float4, sink);
+}
+
+// =====================================================================================================
 // helpers: widen triangle indices, level-set box extraction (tests), reference decomposition statistics
 // =====================================================================================================
 __global__ __launch_bounds__(256) void k_widen_u32_u64(const uint32_t* __restrict__ in, size_t n, unsigned long long* __restrict__ out) {

@@ -13,7 +13,8 @@ import shutil
 import sys
 
 ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
-SRC = os.path.join(ROOT, "gpurun_out", sys.argv[1] if len(sys.argv) > 1 else "r02prof")
+TAG = sys.argv[2] if len(sys.argv) > 2 else "r03"
+SRC = os.path.join(ROOT, "gpurun_out", sys.argv[1] if len(sys.argv) > 1 else TAG + "prof")
 DST = os.path.join(ROOT, "profiles")
 MODES = {0: "scalar", 1: "simd", 2: "simd_hw"}
 
@@ -25,14 +26,14 @@ def short(name):
 
 def main():
     traffic = {"s10m_tank": {}}
-    md = ["# rocprofv3 PMC counters, S10M-tank, 1x MI355X (round 2)",
+    md = ["# rocprofv3 PMC counters, S10M-tank, 1x MI355X (%s)" % TAG,
           "Command per pass: `rocprofv3 --pmc <COUNTERS> --kernel-include-regex 'k_splat|k_density_sub' --output-format csv -- python bench.py --main-only --steps 1 "
           "--warmup 1 --simd M` (tools/collect_profiles.sh; one pass per counter group, no --kernel-trace/--stats in a PMC pass).  Values are per launch "
           "(two launches per run agree to 4 digits).  FETCH_SIZE / WRITE_SIZE in KiB as reported; `hbm` = 2 x FETCH_SIZE + WRITE_SIZE in bytes "
           "(gfx950 tallies the 128-B requests of 16-B-per-lane streaming reads at 64 B, MI355X_MICROARCH.md).", ""]
     for m, mname in MODES.items():
         stats = os.path.join(SRC, "stats_simd%d" % m, "run_kernel_stats.csv")
-        shutil.copyfile(stats, os.path.join(DST, "r02_s10m_tank_simd%d_kernel_stats.csv" % m))
+        shutil.copyfile(stats, os.path.join(DST, TAG + "_s10m_tank_simd%d_kernel_stats.csv" % m))
         dur = {}
         for r in csv.DictReader(open(stats)):
             dur[short(r["Name"])] = (int(r["Calls"]), float(r["AverageNs"]) * 1e-6)
@@ -59,8 +60,8 @@ def main():
                     "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, --kernel-include-regex 'k_splat|k_density_sub') on S10M-tank, per step = sum over the "
                             "launches of the splat kernel; read side doubled per MI355X_MICROARCH.md (gfx950 FETCH_SIZE counts 128-B requests as 64 B); the "
                             "kernel gathers every block's candidates from the cell-sorted particle array (neighbouring blocks re-read the same rows, mostly "
-                            "from L2) and writes the level-set values of the evaluated sub-blocks (DESIGN.md section 5, profiles/r02_pmc_s10m_tank.md)",
-                    "valu_note": "SQ_INSTS_VALU of both launches per step (profiles/r02_pmc_s10m_tank.md); a SIMD-32 issues one wave64 VALU instruction per 2 cycles at best"})
+                            "from L2) and writes the level-set values of the evaluated sub-blocks (DESIGN.md section 5, profiles/" + TAG + "_pmc_s10m_tank.md)",
+                    "valu_note": "SQ_INSTS_VALU of both launches per step (profiles/" + TAG + "_pmc_s10m_tank.md); a SIMD-32 issues one wave64 VALU instruction per 2 cycles at best"})
                 t["hbm_bytes_per_launch"] += hbm
                 t["fetch_size_bytes_reported"] += v.get("FETCH_SIZE", 0.0) * 1024
                 t["write_size_bytes"] += v.get("WRITE_SIZE", 0.0) * 1024
@@ -71,7 +72,10 @@ def main():
                 t["other_kernels"] = {"k_splat_gather<float>": {"fetch_size_bytes_reported": g.get("FETCH_SIZE", 0.0) * 1024, "write_size_bytes": g.get("WRITE_SIZE", 0.0) * 1024,
                                                                 "hbm_bytes_per_launch": 2.0 * g.get("FETCH_SIZE", 0.0) * 1024 + g.get("WRITE_SIZE", 0.0) * 1024}}
         md.append("")
-    open(os.path.join(DST, "r02_pmc_s10m_tank.md"), "w").write("\n".join(md) + "\n")
+    open(os.path.join(DST, TAG + "_pmc_s10m_tank.md"), "w").write("\n".join(md) + "\n")
+    stamp_file = os.path.join(SRC, "kernel_source_stamp.txt")  # written by tools/collect_profiles.sh from the sources that were profiled
+    traffic["_collected_from"] = {"kernel_source_stamp": open(stamp_file).read().strip() if os.path.exists(stamp_file) else None, "round": TAG,
+                                  "note": "bench.py attaches these numbers only to a build with the same stamp (sha256 of ss_kernels.hip, ss_device.h, ss_api.hip)"}
     json.dump(traffic, open(os.path.join(DST, "splat_traffic.json"), "w"), indent=1)
     print("\n".join(md[-40:]))
 
