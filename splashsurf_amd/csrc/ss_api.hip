@@ -258,11 +258,7 @@ ss_status make_device_params(ss_context* ctx, const typename TypesOf<R>::params*
         if (!(k0 > -2.0e9 && k1 < 2.0e9)) return fail(ctx, SS_ERR_UNSUPPORTED, "search grid index out of i32 range");
         P.kmin[d] = (int)k0;
         P.kdim[d] = (int)(k1 - k0) + 1;
-        ncells *= (double)P.kdim[d];
-        nblocks *= (double)P.nb[d];
     }
-    if (ncells > 4.0e9 || nblocks > 4.0e9)
-        return fail(ctx, SS_ERR_UNSUPPORTED, "domain too large for the dense cell/block tables of this build (> 4e9 search cells or level-set blocks)");
     P.n = n;
     // shard region
     bool full = true;
@@ -294,6 +290,27 @@ ss_status make_device_params(ss_context* ctx, const typename TypesOf<R>::params*
         P.blk_lo[d] = P.pt_lo[d] / SS_BLOCK;
         P.blk_hi[d] = P.pt_hi[d] / SS_BLOCK;
     }
+    // The dense tables cover what this process touches: the blocks [blk_lo, blk_hi] plus the layer above that marching cubes looks into,
+    // and the search cells within reach of those blocks' points (the particles a shard holds lie within the ghost margin of its brick:
+    // inside that range; ss_particle_cell clamps).  For a single-process job that is the whole grid.
+    for (int d = 0; d < 3; ++d) {
+        const bool empty = P.blk_hi[d] < P.blk_lo[d];
+        P.bt_org[d] = empty ? 0 : P.blk_lo[d];
+        P.bt_dim[d] = empty ? 1 : std::min(P.blk_hi[d] + 1, P.nb[d] - 1) - P.blk_lo[d] + 1;
+        if (!full && !empty) {
+            const double pad = std::max(1.5 * (double)margin, (double)P.reach + (double)P.coord_slack) + 2.0e-3 * (double)h;
+            const double lo = (double)P.gmin[d] + (double)(P.blk_lo[d] * SS_BLOCK) * (double)P.cs - pad;
+            const double hi = (double)P.gmin[d] + (double)std::min((P.blk_hi[d] + 1) * SS_BLOCK, P.np[d] - 1) * (double)P.cs + pad;
+            const int k0 = std::max(P.kmin[d], (int)(floor(lo / (double)h) - 2.0));
+            const int k1 = std::min(P.kmin[d] + P.kdim[d] - 1, (int)(floor(hi / (double)h) + 2.0));
+            P.kmin[d] = k0;
+            P.kdim[d] = std::max(k1 - k0 + 1, 1);
+        }
+        ncells *= (double)P.kdim[d];
+        nblocks *= (double)P.bt_dim[d];
+    }
+    if (ncells > 4.0e9 || nblocks > 4.0e9)
+        return fail(ctx, SS_ERR_UNSUPPORTED, "domain too large for the dense cell/block tables of this build (> 4e9 search cells or level-set blocks)");
     *out = P;
     return SS_OK;
 }
@@ -861,7 +878,7 @@ ss_status phase_finish(ss_context* ctx, ss_result* res) {
     const uint32_t n = P.n;
     const bool host_input = res->host_input;
     const size_t ncells = (size_t)P.kdim[0] * P.kdim[1] * P.kdim[2];
-    const size_t nblocks = (size_t)P.nb[0] * P.nb[1] * P.nb[2];
+    const size_t nblocks = (size_t)P.bt_dim[0] * P.bt_dim[1] * P.bt_dim[2];  // (the table window: the whole grid unless this is a shard)
     SS_HIP(ctx, hipEventRecord(ctx->ev[10], st));
     ss_launch_make_posvol(P, ctx->pos_sorted.as<ss_real4<R>>(), res->perm.as<uint32_t>(), res->rho.as<R>(), res->posvol.as<ss_real4<R>>(), res->posvol_by_index.as<ss_real4<R>>(), st);
     SS_HIP(ctx, hipEventRecord(ctx->ev[11], st));

@@ -99,8 +99,11 @@ struct SSDevT {
     // dense array of search cells (edge h), absolute cell coordinate K in [kmin, kmin+kdim)
     int kmin[3];
     int kdim[3];
-    // level-set blocks
+    // level-set blocks: nb = blocks of the whole grid; the dense per-block tables (slots, flags, MC slots) cover the window
+    // [bt_org, bt_org + bt_dim) only -- the whole grid for a single-process job, the shard's blocks (+ one layer above, which
+    // marching cubes looks into) for a rank of a multi-GPU job: the tables and every pass over them scale with the brick, not the domain
     int nb[3];
+    int bt_org[3], bt_dim[3];
     // shard (multi-GPU): this process reconstructs the subdomains [sub_lo, sub_hi) only.  Full domain: [0, ns).
     int sub_lo[3], sub_hi[3];
     int pt_lo[3], pt_hi[3];      // grid points of the shard region, inclusive: [sub_lo*n, min(np-1, sub_hi*n)]
@@ -160,6 +163,23 @@ __host__ __device__ inline int ss_search_cell_axis(const SSDevT<R>& P, int s, R 
 template <class R>
 __host__ __device__ inline uint32_t ss_cell_key(const SSDevT<R>& P, int kx, int ky, int kz) {
     return (uint32_t)(((int64_t)(kx - P.kmin[0]) * P.kdim[1] + (ky - P.kmin[1])) * P.kdim[2] + (kz - P.kmin[2]));
+}
+
+// position of level-set block (bx, by, bz) in the dense per-block tables; blocks outside the window have no entry (and no values)
+template <class R>
+__host__ __device__ inline bool ss_block_in_table(const SSDevT<R>& P, int bx, int by, int bz) {
+    return bx >= P.bt_org[0] && by >= P.bt_org[1] && bz >= P.bt_org[2] && bx < P.bt_org[0] + P.bt_dim[0] && by < P.bt_org[1] + P.bt_dim[1] &&
+           bz < P.bt_org[2] + P.bt_dim[2];
+}
+template <class R>
+__host__ __device__ inline size_t ss_block_index(const SSDevT<R>& P, int bx, int by, int bz) {
+    return ((size_t)(bx - P.bt_org[0]) * (size_t)P.bt_dim[1] + (size_t)(by - P.bt_org[1])) * (size_t)P.bt_dim[2] + (size_t)(bz - P.bt_org[2]);
+}
+template <class R>
+__host__ __device__ inline void ss_block_of_index(const SSDevT<R>& P, uint32_t b, int* bx, int* by, int* bz) {
+    *bz = P.bt_org[2] + (int)(b % (uint32_t)P.bt_dim[2]);
+    *by = P.bt_org[1] + (int)((b / (uint32_t)P.bt_dim[2]) % (uint32_t)P.bt_dim[1]);
+    *bx = P.bt_org[0] + (int)(b / ((uint32_t)P.bt_dim[2] * (uint32_t)P.bt_dim[1]));
 }
 
 template <class R>

@@ -644,7 +644,7 @@ __global__ __launch_bounds__(256) void k_mark_blocks(SSDevT<R> P, const uint32_t
     }
     for (int bx = blo[0]; bx <= bhi[0]; ++bx)
         for (int by = blo[1]; by <= bhi[1]; ++by)
-            for (int bz = blo[2]; bz <= bhi[2]; ++bz) block_flag[((size_t)bx * P.nb[1] + by) * P.nb[2] + bz] = 1u;
+            for (int bz = blo[2]; bz <= bhi[2]; ++bz) block_flag[ss_block_index(P, bx, by, bz)] = 1u;  // (inside [blk_lo, blk_hi], hence inside the table)
 }
 
 // MC works on blocks of cells whose origin point lies in block b; it reads the points of blocks b+{0,1}^3.
@@ -655,9 +655,8 @@ __global__ __launch_bounds__(256) void k_mark_mc_blocks(SSDevT<R> P, const uint3
                                                         uint32_t nblocks, uint32_t* __restrict__ mc_flag) {
     uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= nblocks) return;
-    int bz = (int)(b % (uint32_t)P.nb[2]);
-    int by = (int)((b / (uint32_t)P.nb[2]) % (uint32_t)P.nb[1]);
-    int bx = (int)(b / ((uint32_t)P.nb[2] * (uint32_t)P.nb[1]));
+    int bx, by, bz;
+    ss_block_of_index(P, b, &bx, &by, &bz);
     if (bx < P.blk_lo[0] || by < P.blk_lo[1] || bz < P.blk_lo[2] || bx > P.blk_hi[0] || by > P.blk_hi[1] || bz > P.blk_hi[2]) {
         mc_flag[b] = 0u;
         return;
@@ -668,8 +667,8 @@ __global__ __launch_bounds__(256) void k_mark_mc_blocks(SSDevT<R> P, const uint3
             for (int dz = 0; dz <= 1; ++dz) {
                 int x = bx + dx, y = by + dy, z = bz + dz;
                 R mn = R(0.0), mx = R(0.0);
-                if (x < P.nb[0] && y < P.nb[1] && z < P.nb[2]) {
-                    const uint32_t slot = block_slot[((size_t)x * P.nb[1] + y) * P.nb[2] + z];
+                if (ss_block_in_table(P, x, y, z)) {
+                    const uint32_t slot = block_slot[ss_block_index(P, x, y, z)];
                     if (slot != 0xFFFFFFFFu) {
                         const ss_real2<R> mm = blk_minmax[slot];
                         mn = mm.x;
@@ -775,9 +774,11 @@ __global__ __launch_bounds__(256) void k_block_coords(SSDevT<R> P, const uint32_
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_active) return;
     const uint32_t b = active_list[i];
-    xyz[3 * (size_t)i + 0] = b / ((uint32_t)P.nb[2] * (uint32_t)P.nb[1]);
-    xyz[3 * (size_t)i + 1] = (b / (uint32_t)P.nb[2]) % (uint32_t)P.nb[1];
-    xyz[3 * (size_t)i + 2] = b % (uint32_t)P.nb[2];
+    int bx, by, bz;
+    ss_block_of_index(P, b, &bx, &by, &bz);
+    xyz[3 * (size_t)i + 0] = (uint32_t)bx;
+    xyz[3 * (size_t)i + 1] = (uint32_t)by;
+    xyz[3 * (size_t)i + 2] = (uint32_t)bz;
 }
 template <class R>
 void ss_launch_block_coords(const SSDevT<R>& P, const uint32_t* active_list, uint32_t n_active, uint32_t* xyz, hipStream_t st) {
@@ -1887,8 +1888,8 @@ __global__ __launch_bounds__(256) void k_select_redo(SSDevT<R> P, const uint32_t
                 int c[3] = {b[0], b[1], b[2]};
                 c[d] += sgn ? 1 : -1;
                 unsigned long long w = 0;
-                if (c[d] >= 0 && c[d] < P.nb[d]) {
-                    const uint32_t slot = block_slot[((size_t)c[0] * P.nb[1] + c[1]) * P.nb[2] + c[2]];
+                if (c[d] >= 0 && c[d] < P.nb[d]) {  // (a block of the grid outside the table is a block without particles in reach of this rank's points)
+                    const uint32_t slot = ss_block_in_table(P, c[0], c[1], c[2]) ? block_slot[ss_block_index(P, c[0], c[1], c[2])] : 0xFFFFFFFFu;
                     w = (slot == 0xFFFFFFFFu) ? ~0ull : facebits[slot];
                 }
                 nbf[d][sgn] = w;
@@ -2026,8 +2027,8 @@ __global__ __launch_bounds__(256) void k_mc_neighbours(SSDevT<R> P, const uint32
     if (m >= n_mc) return;
     const int x = (int)mc_xyz[3 * (size_t)m] + (int)((n >> 2) & 1u), y = (int)mc_xyz[3 * (size_t)m + 1] + (int)((n >> 1) & 1u), z = (int)mc_xyz[3 * (size_t)m + 2] + (int)(n & 1u);
     uint32_t slot = 0xFFFFFFFFu, cert = 0u, mslot = 0xFFFFFFFFu;
-    if (x < P.nb[0] && y < P.nb[1] && z < P.nb[2]) {
-        const size_t b = ((size_t)x * P.nb[1] + y) * P.nb[2] + z;
+    if (ss_block_in_table(P, x, y, z)) {
+        const size_t b = ss_block_index(P, x, y, z);
         slot = block_slot[b];
         mslot = mc_slot[b];
         if (slot != 0xFFFFFFFFu && certified) cert = certified[slot];
@@ -2377,7 +2378,7 @@ __global__ __launch_bounds__(256) void k_levelset_box(SSDevT<R> P, const R* __re
     int gx = lo0 + x, gy = lo1 + y, gz = lo2 + z;
     R v = R(0.0);
     if (gx >= 0 && gy >= 0 && gz >= 0 && gx < P.np[0] && gy < P.np[1] && gz < P.np[2]) {
-        uint32_t slot = block_slot[((size_t)(gx >> 3) * P.nb[1] + (gy >> 3)) * P.nb[2] + (gz >> 3)];
+        uint32_t slot = ss_block_in_table(P, gx >> 3, gy >> 3, gz >> 3) ? block_slot[ss_block_index(P, gx >> 3, gy >> 3, gz >> 3)] : 0xFFFFFFFFu;
         if (slot != 0xFFFFFFFFu) v = G[(size_t)slot * SS_BLOCK_POINTS + (size_t)SS_BLOCK_OFFSET(gx & 7, gy & 7, gz & 7)];
     }
     out[i] = v;
