@@ -166,7 +166,7 @@ struct ss_comm {
     DevBuf small_dev, small_dev2, red_tmp, peers_dev;
     HostBuf small_host;
     // state of the last ss_dist_reconstruct / ss_dist_assemble
-    DevBuf xyz_in, hist, flags, offs, sendbuf, recvbuf, gids, L, owned, sort_tmp, keys_a, keys_b, vals_a, vals_b, owner, holder, gid_local, mine_off, tri64, vown, kown, err;
+    DevBuf xyz_in, hist, flags, offs, boxes_dev, mask, sendbuf, recvbuf, gids, L, owned, sort_tmp, keys_a, keys_b, vals_a, vals_b, owner, holder, gid_local, mine_off, tri64, vown, kown, err;
     bool is_f64 = false;
     std::vector<int64_t> bricks;  // world x 6 (lo[3], hi[3])
     int ns[3] = {0, 0, 0};
@@ -221,7 +221,8 @@ ss_status wait_stream(ss_comm* c, const char* what) {
         }
         const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         if (dt > c->timeout_s) {
-            if (c->kind == 1 && c->nccl) (void)rccl_api()->CommAbort(c->nccl), c->nccl = nullptr;
+            // (a communicator the host handed in with ss_comm_adopt_rccl stays the host's: never aborted or destroyed here)
+            if (c->kind == 1 && c->nccl && c->own_nccl) (void)rccl_api()->CommAbort(c->nccl), c->nccl = nullptr;
             return comm_fail(c, std::string("timeout (") + std::to_string((int)c->timeout_s) + " s, SPLASH_COMM_TIMEOUT_S) waiting for " + what +
                                     ": a peer rank did not take part in the exchange");
         }
@@ -447,26 +448,55 @@ __global__ __launch_bounds__(256) void k_owner_hist(const R* __restrict__ xyz, u
     }
 }
 
-// flags[i] = particle i lies in the box (and is owned, if `owned` is given)
+// mask[i] = the destinations (bit q <=> rank q, among `active`) whose box holds particle i (and i is owned, if `owned` is given):
+// one pass over the particles for all destinations
+struct DistBoxes {  // world <= 64
+    DistBox box[64];
+};
 template <class R>
-__global__ __launch_bounds__(256) void k_box_flags(const R* __restrict__ xyz, uint64_t n, DistBox box, const uint32_t* __restrict__ owned, uint32_t* __restrict__ flags) {
+__global__ __launch_bounds__(256) void k_box_masks(const R* __restrict__ xyz, uint64_t n, const DistBoxes* __restrict__ boxes, unsigned long long active,
+                                                   const uint32_t* __restrict__ owned, unsigned long long* __restrict__ mask) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i > n) return;
-    uint32_t f = 0;
-    if (i < n && !box.empty) {
+    if (i >= n) return;
+    unsigned long long m = 0;
+    if (!owned || owned[i]) {
         const double x = (double)xyz[3 * i], y = (double)xyz[3 * i + 1], z = (double)xyz[3 * i + 2];
-        f = (x >= box.lo[0] && x <= box.hi[0] && y >= box.lo[1] && y <= box.hi[1] && z >= box.lo[2] && z <= box.hi[2]) ? 1u : 0u;
-        if (owned) f &= owned[i];
+        for (unsigned long long todo = active; todo; todo &= todo - 1) {
+            const int q = __ffsll((long long)todo) - 1;
+            const DistBox& b = boxes->box[q];
+            if (x >= b.lo[0] && x <= b.hi[0] && y >= b.lo[1] && y <= b.hi[1] && z >= b.lo[2] && z <= b.hi[2]) m |= 1ull << q;
+        }
     }
-    flags[i] = f;  // entry n: 0, so that the exclusive scan ends with the count
+    mask[i] = m;
 }
 
+// "element i goes to rank q" as functors over the element index (entry n of a scan reads 0, so that the scan ends with the count):
+// the per-destination scans and pack kernels read them straight from the masks -- no flag arrays, no copies
+struct MaskFlag {
+    const unsigned long long* mask;
+    uint64_t n;
+    int q;
+    __host__ __device__ uint32_t operator()(uint64_t i) const { return i < n ? (uint32_t)((mask[i] >> q) & 1ull) : 0u; }
+};
+struct VertexFlag {  // owner[v] == me && rank q also holds the vertex (q < 0: any)
+    const uint32_t* owner;
+    const unsigned long long* holder;
+    uint64_t n;
+    uint32_t me;
+    int q;
+    __host__ __device__ uint32_t operator()(uint64_t v) const {
+        if (v >= n) return 0u;
+        return (owner[v] == me && (q < 0 || ((holder[v] >> q) & 1ull))) ? 1u : 0u;
+    }
+};
+
 // rows[off[i]] = (id0 + i or ids[i], payload[i]) for flagged i; payload_words 32-bit words per element
-__global__ __launch_bounds__(256) void k_pack_rows(uint64_t n, const uint32_t* __restrict__ flags, const uint32_t* __restrict__ offs, uint64_t id0,
+template <class Flag>
+__global__ __launch_bounds__(256) void k_pack_rows(uint64_t n, Flag flag, const uint32_t* __restrict__ offs, uint64_t id0,
                                                    const unsigned long long* __restrict__ ids, const uint32_t* __restrict__ payload, int payload_words,
                                                    uint32_t* __restrict__ rows) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n || !flags[i]) return;
+    if (i >= n || !flag(i)) return;
     const unsigned long long id = ids ? ids[i] : (unsigned long long)(id0 + i);
     uint32_t* dst = rows + (size_t)offs[i] * (size_t)(2 + payload_words);
     dst[0] = (uint32_t)id;
@@ -547,14 +577,11 @@ __global__ __launch_bounds__(256) void k_vertex_owner(uint64_t nv, const unsigne
     holder[v] = mask;
 }
 
-// flags[v] = owner[v] == me (&& rank q also holds it, q >= 0); entry nv: 0
-__global__ __launch_bounds__(256) void k_vertex_flags(uint64_t nv, const uint32_t* __restrict__ owner, const unsigned long long* __restrict__ holder, uint32_t me, int q,
-                                                      uint32_t* __restrict__ flags) {
+// flags[v] = f(v) for v = 0 .. n (entry n: 0)
+template <class Flag>
+__global__ __launch_bounds__(256) void k_write_flags(uint64_t n, Flag f, uint32_t* __restrict__ flags) {
     const uint64_t v = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (v > nv) return;
-    uint32_t f = 0;
-    if (v < nv) f = (owner[v] == me && (q < 0 || ((holder[v] >> q) & 1ull))) ? 1u : 0u;
-    flags[v] = f;
+    if (v <= n) flags[v] = f(v);
 }
 
 __global__ __launch_bounds__(256) void k_owned_gids(uint64_t nv, const uint32_t* __restrict__ mine, const uint32_t* __restrict__ mine_off, unsigned long long voff,
@@ -621,29 +648,32 @@ template <> struct DistTypes<double> {
 double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 // Packs, for every destination rank, the flagged elements into consecutive rows of c->sendbuf, exchanges them and leaves the
-// received rows (ordered by source rank) in c->recvbuf.  flags_for(q) fills c->flags (n + 1 entries) for destination q;
-// destinations for which it returns false send nothing.
-template <class FlagsFor>
-ss_status pack_and_exchange(ss_comm* c, uint64_t n, uint64_t id0, const unsigned long long* ids, const uint32_t* payload, int payload_words, FlagsFor flags_for,
+// received rows (ordered by source rank) in c->recvbuf.  flag_for(q, &flag) says whether this rank may have anything for rank q and
+// hands out the functor "element i goes to q"; per destination there is one scan over the functor and one pack kernel.
+template <class Flag, class FlagFor>
+ss_status pack_and_exchange(ss_comm* c, uint64_t n, uint64_t id0, const unsigned long long* ids, const uint32_t* payload, int payload_words, FlagFor flag_for,
                             uint64_t* n_recv_rows, uint64_t* bytes_sent) {
     ss_context* ctx = c->ctx;
     hipStream_t st = ctx->stream;
     const int world = c->world, me = c->rank;
     const size_t row_bytes = (size_t)(2 + payload_words) * 4;
-    SS_HIP(ctx, c->flags.reserve((n + 1) * 4 + 64));
-    SS_HIP(ctx, c->offs.reserve((size_t)world * (n + 1) * 4 + 64));
-    SS_HIP(ctx, c->keys_a.reserve((size_t)world * (n + 1) * 4 + 64));  // the flags of every destination, consumed by the pack kernels once the counts are known
     std::vector<uint32_t> cnt((size_t)world, 0u);
-    std::vector<char> active((size_t)world, 0);
-    TurnGuard turn(c);  // flags, scans and packing are this rank's own work; released before the ranks meet
+    std::vector<int> slot_of((size_t)world, -1);
+    std::vector<Flag> flags((size_t)world);
+    int n_active = 0;
+    for (int q = 0; q < world; ++q)
+        if (flag_for(q, &flags[q])) slot_of[q] = n_active++;
+    TurnGuard turn(c);  // scans and packing are this rank's own work; released before the ranks meet
+    SS_HIP(ctx, c->offs.reserve((size_t)std::max(n_active, 1) * (n + 1) * 4 + 64));  // (one offset array per ACTIVE destination)
     for (int q = 0; q < world; ++q) {
-        if (!flags_for(q)) continue;
-        active[q] = 1;
-        uint32_t* offs_q = c->offs.as<uint32_t>() + (size_t)q * (n + 1);
-        ss_status s = scan_u32(c, c->flags.as<uint32_t>(), offs_q, n + 1);
-        if (s != SS_OK) return s;
+        if (slot_of[q] < 0) continue;
+        uint32_t* offs_q = c->offs.as<uint32_t>() + (size_t)slot_of[q] * (n + 1);
+        auto it = rocprim::make_transform_iterator(rocprim::make_counting_iterator<uint64_t>(0), flags[q]);
+        size_t bytes = 0;
+        SS_HIP(ctx, rocprim::exclusive_scan(nullptr, bytes, it, offs_q, 0u, (size_t)n + 1, rocprim::plus<uint32_t>(), st));
+        SS_HIP(ctx, c->sort_tmp.reserve(bytes + 64));
+        SS_HIP(ctx, rocprim::exclusive_scan(c->sort_tmp.p, bytes, it, offs_q, 0u, (size_t)n + 1, rocprim::plus<uint32_t>(), st));
         SS_HIP(ctx, hipMemcpyAsync(&cnt[q], offs_q + n, 4, hipMemcpyDeviceToHost, st));
-        SS_HIP(ctx, hipMemcpyAsync(c->keys_a.as<uint32_t>() + (size_t)q * (n + 1), c->flags.p, (n + 1) * 4, hipMemcpyDeviceToDevice, st));
     }
     SS_HIP(ctx, hipStreamSynchronize(st));
     std::vector<uint64_t> send_off((size_t)world + 1, 0), send_rows((size_t)world, 0);
@@ -653,9 +683,9 @@ ss_status pack_and_exchange(ss_comm* c, uint64_t n, uint64_t id0, const unsigned
     }
     SS_HIP(ctx, c->sendbuf.reserve(send_off[world] + 64));
     for (int q = 0; q < world; ++q) {
-        if (!active[q] || !cnt[q]) continue;
-        hipLaunchKernelGGL(k_pack_rows, grid_for(n), dim3(256), 0, st, n, c->keys_a.as<uint32_t>() + (size_t)q * (n + 1), c->offs.as<uint32_t>() + (size_t)q * (n + 1), id0, ids,
-                           payload, payload_words, reinterpret_cast<uint32_t*>(c->sendbuf.as<uint8_t>() + send_off[q]));
+        if (slot_of[q] < 0 || !cnt[q]) continue;
+        hipLaunchKernelGGL(k_pack_rows<Flag>, grid_for(n), dim3(256), 0, st, n, flags[q], c->offs.as<uint32_t>() + (size_t)slot_of[q] * (n + 1), id0, ids, payload, payload_words,
+                           reinterpret_cast<uint32_t*>(c->sendbuf.as<uint8_t>() + send_off[q]));
     }
     turn.release();
     // matrix[r][q] = rows rank r sends to rank q
@@ -801,15 +831,33 @@ ss_status dist_reconstruct(ss_comm* c, const R* xyz_in, uint64_t n_local, const 
     // ---- 3. positions to every rank that needs the particle (owner or ghost) ----
     uint64_t n_held = 0;
     const int pos_words = 3 * (int)(sizeof(R) / 4);
-    s = pack_and_exchange(c, n_local, id0, nullptr, reinterpret_cast<const uint32_t*>(d_xyz), pos_words,
-                          [&](int q) {
-                              if (boxes[q].empty || !n_local) return false;
-                              for (int d = 0; d < 3; ++d)  // nothing of this rank's input can lie in a box that misses its bounding box
-                                  if (mine_head.hi[d] < boxes[q].lo[d] || mine_head.lo[d] > boxes[q].hi[d]) return false;
-                              hipLaunchKernelGGL(k_box_flags<R>, grid_for(n_local + 1), dim3(256), 0, st, d_xyz, n_local, boxes[q], (const uint32_t*)nullptr, c->flags.as<uint32_t>());
-                              return true;
-                          },
-                          &n_held, &c->info.bytes_sent_positions);
+    // which boxes can hold anything of this rank's input, then ONE pass over the particles for all of them
+    DistBoxes h_boxes;
+    memset(&h_boxes, 0, sizeof(h_boxes));
+    for (int q = 0; q < world; ++q) h_boxes.box[q] = boxes[q];
+    SS_HIP(ctx, c->boxes_dev.reserve(sizeof(DistBoxes)));
+    SS_HIP(ctx, hipMemcpyAsync(c->boxes_dev.p, &h_boxes, sizeof(DistBoxes), hipMemcpyHostToDevice, st));
+    unsigned long long pos_active = 0;
+    for (int q = 0; q < world && n_local; ++q) {
+        if (boxes[q].empty) continue;
+        bool overlap = true;
+        for (int d = 0; d < 3; ++d)  // nothing of this rank's input can lie in a box that misses its bounding box
+            if (mine_head.hi[d] < boxes[q].lo[d] || mine_head.lo[d] > boxes[q].hi[d]) overlap = false;
+        if (overlap) pos_active |= 1ull << q;
+    }
+    SS_HIP(ctx, c->mask.reserve((n_local + 1) * 8 + 64));
+    if (pos_active) {
+        TurnGuard mask_turn(c);
+        hipLaunchKernelGGL(k_box_masks<R>, grid_for(n_local), dim3(256), 0, st, d_xyz, n_local, c->boxes_dev.as<DistBoxes>(), pos_active, (const uint32_t*)nullptr,
+                           c->mask.as<unsigned long long>());
+    }
+    s = pack_and_exchange<MaskFlag>(c, n_local, id0, nullptr, reinterpret_cast<const uint32_t*>(d_xyz), pos_words,
+                                    [&](int q, MaskFlag* f) {
+                                        if (!((pos_active >> q) & 1ull)) return false;
+                                        *f = MaskFlag{c->mask.as<unsigned long long>(), n_local, q};
+                                        return true;
+                                    },
+                                    &n_held, &c->info.bytes_sent_positions);
     if (s != SS_OK) return s;
     if (n_held >= (1ull << 31)) return fail(ctx, SS_ERR_UNSUPPORTED, "more than 2^31-1 particles held by one rank");
     // Rows arrive ascending from every source rank and the ranks' id ranges ascend, so the concatenation by source rank IS the
@@ -859,15 +907,27 @@ ss_status dist_reconstruct(ss_comm* c, const R* xyz_in, uint64_t n_local, const 
     phase1_turn.release();
     uint64_t n_rho_rows = 0;
     const int rho_words = (int)(sizeof(R) / 4);
-    s = pack_and_exchange(c, n_held, 0, c->gids.as<unsigned long long>(), reinterpret_cast<const uint32_t*>(res->rho.as<R>()), rho_words,
-                          [&](int q) {
-                              if (q == me || boxes[q].empty || boxes[me].empty || !n_held) return false;
-                              for (int d = 0; d < 3; ++d)  // held particles lie inside this rank's grown box: only overlapping boxes can want them
-                                  if (boxes[me].hi[d] < boxes[q].lo[d] || boxes[me].lo[d] > boxes[q].hi[d]) return false;
-                              hipLaunchKernelGGL(k_box_flags<R>, grid_for(n_held + 1), dim3(256), 0, st, c->L.as<R>(), n_held, boxes[q], c->owned.as<uint32_t>(), c->flags.as<uint32_t>());
-                              return true;
-                          },
-                          &n_rho_rows, &c->info.bytes_sent_densities);
+    unsigned long long rho_active = 0;
+    for (int q = 0; q < world && n_held; ++q) {
+        if (q == me || boxes[q].empty || boxes[me].empty) continue;
+        bool overlap = true;
+        for (int d = 0; d < 3; ++d)  // held particles lie inside this rank's grown box: only overlapping boxes can want them
+            if (boxes[me].hi[d] < boxes[q].lo[d] || boxes[me].lo[d] > boxes[q].hi[d]) overlap = false;
+        if (overlap) rho_active |= 1ull << q;
+    }
+    SS_HIP(ctx, c->mask.reserve((n_held + 1) * 8 + 64));
+    if (rho_active) {
+        TurnGuard mask_turn(c);
+        hipLaunchKernelGGL(k_box_masks<R>, grid_for(n_held), dim3(256), 0, st, c->L.as<R>(), n_held, c->boxes_dev.as<DistBoxes>(), rho_active, c->owned.as<uint32_t>(),
+                           c->mask.as<unsigned long long>());
+    }
+    s = pack_and_exchange<MaskFlag>(c, n_held, 0, c->gids.as<unsigned long long>(), reinterpret_cast<const uint32_t*>(res->rho.as<R>()), rho_words,
+                                    [&](int q, MaskFlag* f) {
+                                        if (!((rho_active >> q) & 1ull)) return false;
+                                        *f = MaskFlag{c->mask.as<unsigned long long>(), n_held, q};
+                                        return true;
+                                    },
+                                    &n_rho_rows, &c->info.bytes_sent_densities);
     if (s != SS_OK) return s;
     TurnGuard phase2_turn(c);  // scattering the received densities and phase 2
     SS_HIP(ctx, c->err.reserve(64));
@@ -935,7 +995,7 @@ ss_status dist_assemble(ss_comm* c, ss_result* res) {
     TurnGuard turn(c);
     if (nv) hipLaunchKernelGGL(k_vertex_owner, grid_for(nv), dim3(256), 0, st, nv, keys, B, np1, np2, c->owner.as<uint32_t>(), c->holder.as<unsigned long long>());
     uint32_t* mine = c->vals_a.as<uint32_t>();
-    hipLaunchKernelGGL(k_vertex_flags, grid_for(nv + 1), dim3(256), 0, st, nv, c->owner.as<uint32_t>(), c->holder.as<unsigned long long>(), (uint32_t)me, -1, mine);
+    hipLaunchKernelGGL(k_write_flags<VertexFlag>, grid_for(nv + 1), dim3(256), 0, st, nv, VertexFlag{c->owner.as<uint32_t>(), c->holder.as<unsigned long long>(), nv, (uint32_t)me, -1}, mine);
     ss_status s = scan_u32(c, mine, c->mine_off.as<uint32_t>(), nv + 1);
     if (s != SS_OK) return s;
     uint32_t n_owned = 0;
@@ -961,16 +1021,15 @@ ss_status dist_assemble(ss_comm* c, ss_result* res) {
     }
     // owners -> the other ranks holding the edge: (key, global id)
     uint64_t n_rows = 0;
-    s = pack_and_exchange(c, nv, 0, keys, reinterpret_cast<const uint32_t*>(c->gid_local.as<unsigned long long>()), 2,
-                          [&](int q) {
-                              if (q == me || B.empty[q] || B.empty[me] || !nv) return false;
-                              for (int d = 0; d < 3; ++d)  // closed point boxes that do not even touch share no edge
-                                  if (B.hi[me][d] < B.lo[q][d] || B.lo[me][d] > B.hi[q][d]) return false;
-                              hipLaunchKernelGGL(k_vertex_flags, grid_for(nv + 1), dim3(256), 0, st, nv, c->owner.as<uint32_t>(), c->holder.as<unsigned long long>(), (uint32_t)me, q,
-                                                 c->flags.as<uint32_t>());
-                              return true;
-                          },
-                          &n_rows, &c->info.bytes_sent_assembly);
+    s = pack_and_exchange<VertexFlag>(c, nv, 0, keys, reinterpret_cast<const uint32_t*>(c->gid_local.as<unsigned long long>()), 2,
+                                      [&](int q, VertexFlag* f) {
+                                          if (q == me || B.empty[q] || B.empty[me] || !nv) return false;
+                                          for (int d = 0; d < 3; ++d)  // closed point boxes that do not even touch share no edge
+                                              if (B.hi[me][d] < B.lo[q][d] || B.lo[me][d] > B.hi[q][d]) return false;
+                                          *f = VertexFlag{c->owner.as<uint32_t>(), c->holder.as<unsigned long long>(), nv, (uint32_t)me, q};
+                                          return true;
+                                      },
+                                      &n_rows, &c->info.bytes_sent_assembly);
     if (s != SS_OK) return s;
     TurnGuard join_turn(c);
     SS_HIP(ctx, c->err.reserve(64));
@@ -1025,7 +1084,7 @@ ss_status copy_to_caller(ss_comm* c, const void* src, void* dst, size_t bytes) {
 }
 
 void comm_release(ss_comm* c) {
-    for (DevBuf* b : {&c->small_dev, &c->small_dev2, &c->red_tmp, &c->peers_dev, &c->xyz_in, &c->hist, &c->flags, &c->offs, &c->sendbuf, &c->recvbuf, &c->gids, &c->L, &c->owned,
+    for (DevBuf* b : {&c->small_dev, &c->small_dev2, &c->red_tmp, &c->peers_dev, &c->xyz_in, &c->hist, &c->flags, &c->offs, &c->boxes_dev, &c->mask, &c->sendbuf, &c->recvbuf, &c->gids, &c->L, &c->owned,
                       &c->sort_tmp, &c->keys_a, &c->keys_b, &c->vals_a, &c->vals_b, &c->owner, &c->holder, &c->gid_local, &c->mine_off, &c->tri64, &c->vown, &c->kown, &c->err})
         b->release();
     c->small_host.release();
