@@ -186,8 +186,12 @@ int ss_last_error_detail(const ss_context *ctx);
  * ss_result_levelset_box is used to inspect values away from the surface.
  * SS_OPTION_SPLAT_TWO_PASS (default -1): -1 = the library decides per workload whether the certification scheme above pays off
  * (jobs below 1 k active blocks and workloads whose previous call certified < 30 % of the sub-blocks evaluate everything), 0 = never,
- * 1 = always (tests).  Output is identical in every setting. */
-enum { SS_OPTION_FULL_LEVELSET = 1, SS_OPTION_SPLAT_TWO_PASS = 2 };
+ * 1 = always (tests).  Output is identical in every setting; with -1 the time of a call depends on what the previous calls on this
+ * context certified (a workload is re-probed every 16th call).
+ * SS_OPTION_WIDEN_ON_DEVICE (default 0): ss_result_triangles hands out [usize; 3] = u64 indices; for meshes of a million indices and more
+ * they cross PCIe as u32 in chunks and host threads widen them into the pinned buffer while the next chunk is in flight; 1 = widen on
+ * the device and copy 8 bytes per index (what small meshes always do). */
+enum { SS_OPTION_FULL_LEVELSET = 1, SS_OPTION_SPLAT_TWO_PASS = 2, SS_OPTION_WIDEN_ON_DEVICE = 3 };
 ss_status ss_context_set_option(ss_context *ctx, int option, int value);
 /* use an existing HIP stream (hipStream_t passed as void*); NULL = context's own stream */
 ss_status ss_context_set_stream(ss_context *ctx, void *hip_stream);

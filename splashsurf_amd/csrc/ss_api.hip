@@ -16,6 +16,7 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include <rocprim/rocprim.hpp>
@@ -1505,6 +1506,10 @@ ss_status ss_context_set_option(ss_context* c, int option, int value) {
         c->full_levelset = value != 0;
         return SS_OK;
     }
+    if (option == SS_OPTION_WIDEN_ON_DEVICE) {
+        c->widen_on_device = value != 0;
+        return SS_OK;
+    }
     if (option == SS_OPTION_SPLAT_TWO_PASS) {
         if (value < -1 || value > 1) return fail(c, SS_ERR_INVALID_ARGUMENT, "SS_OPTION_SPLAT_TWO_PASS takes -1 (automatic), 0 or 1");
         c->two_pass = value;
@@ -1718,9 +1723,65 @@ ss_status ss_result_triangles(ss_result* r, const uint64_t** idx, uint64_t* m) {
     if (!r || !r->valid || !idx || !m) return SS_ERR_INVALID_ARGUMENT;
     ss_context* c = r->ctx;
     *m = r->n_triangles;
+    const size_t cnt = (size_t)r->n_triangles * 3;
+    if (!r->ht64 && cnt >= ((size_t)1 << 20) && !c->widen_on_device) {
+        // Large meshes: the indices cross PCIe as u32 (half the bytes of [usize; 3]) in chunks, and host threads widen each chunk into
+        // the pinned u64 buffer while the next one is on its way -- the link, not the widening, sets the time.
+        SS_HIP(c, hipSetDevice(c->device));
+        SS_HIP(c, r->h_tri32.reserve(cnt * 4 + 16));
+        SS_HIP(c, r->h_tri64.reserve(cnt * 8 + 16));
+        constexpr int n_chunks = 8;
+        hipEvent_t ev[n_chunks];
+        size_t off[n_chunks + 1];
+        for (int k = 0; k <= n_chunks; ++k) off[k] = std::min(cnt, (cnt * (size_t)k / n_chunks + 1023) / 1024 * 1024);  // chunk borders on multiples of 1024 elements
+        off[n_chunks] = cnt;
+        uint32_t* h32 = reinterpret_cast<uint32_t*>(r->h_tri32.p);
+        unsigned long long* h64 = reinterpret_cast<unsigned long long*>(r->h_tri64.p);
+        int n_ev = 0;
+        hipError_t err = hipSuccess;
+        for (int k = 0; k < n_chunks && err == hipSuccess; ++k) {
+            err = hipEventCreateWithFlags(&ev[k], hipEventDisableTiming);
+            if (err != hipSuccess) break;
+            ++n_ev;
+            if (off[k + 1] > off[k]) err = hipMemcpyAsync(h32 + off[k], r->tri32.as<uint32_t>() + off[k], (off[k + 1] - off[k]) * 4, hipMemcpyDeviceToHost, c->stream);
+            if (err == hipSuccess) err = hipEventRecord(ev[k], c->stream);
+        }
+        if (err == hipSuccess) {
+            const unsigned hw = std::thread::hardware_concurrency();
+            const int n_threads = (int)std::max(1u, std::min(16u, hw ? hw / 4u : 4u));
+            const int device = c->device;
+            std::vector<std::thread> pool;
+            std::vector<int> failed((size_t)n_threads, 0);
+            for (int t = 0; t < n_threads; ++t)
+                pool.emplace_back([=, &failed]() {
+                    if (hipSetDevice(device) != hipSuccess) {
+                        failed[(size_t)t] = 1;
+                        return;
+                    }
+                    for (int k = 0; k < n_chunks; ++k) {
+                        if (hipEventSynchronize(ev[k]) != hipSuccess) {
+                            failed[(size_t)t] = 1;
+                            return;
+                        }
+                        const size_t len = off[k + 1] - off[k];
+                        const size_t b = off[k] + len * (size_t)t / (size_t)n_threads, e = off[k] + len * (size_t)(t + 1) / (size_t)n_threads;
+                        const uint32_t* __restrict__ src = h32;
+                        unsigned long long* __restrict__ dst = h64;
+                        for (size_t i = b; i < e; ++i) dst[i] = src[i];
+                    }
+                });
+            for (auto& th : pool) th.join();
+            for (int f : failed)
+                if (f) err = hipErrorUnknown;
+        }
+        if (err == hipSuccess) err = hipStreamSynchronize(c->stream);
+        for (int k = 0; k < n_ev; ++k) (void)hipEventDestroy(ev[k]);
+        if (err != hipSuccess) return fail(c, SS_ERR_DEVICE, std::string("triangle download failed: ") + hipGetErrorString(err));
+        r->ht64 = true;
+        r->ht32 = true;  // (the u32 indices are on the host as well now)
+    }
     if (!r->ht64) {
-        // widen on the device (HBM bandwidth) rather than on the host
-        const size_t cnt = (size_t)r->n_triangles * 3;
+        // small meshes: widen on the device, one copy
         SS_HIP(c, hipSetDevice(c->device));
         SS_HIP(c, r->tri64.reserve(cnt * 8 + 16));
         ss_launch_widen(r->tri32.as<uint32_t>(), cnt, r->tri64.as<unsigned long long>(), c->stream);

@@ -77,6 +77,7 @@ struct ss_context {
     // per-subdomain particle copies for the density stage
     DevBuf nb_count, nb_tmp;
     DevBuf own_flag;  // per subdomain copy: owned flag, its scan, the list of owned copies
+    bool widen_on_device = false;  // SS_OPTION_WIDEN_ON_DEVICE: ss_result_triangles widens the u32 indices on the device and copies u64 (tests; the default for small meshes)
     DevBuf member_count, copy_offset, sub_flag, sub_rank, occ_sub, ckeys_a, ckeys_b, cvals_a, cidx, cpos, cell_count2, cell_start2;
     hipEvent_t ev[22];  // 0..9 stage boundaries, 10/11 start of phase 2, 12..15 inside the splat, 16/17 around the arena-path gather, 18/19 k_density_sub, 20/21 k_mc_count
     // the two-pass splat pays off when enough sub-blocks get certified 'inside' (bulk fluid); thin structures do not -- decided per

@@ -662,3 +662,25 @@ def test_gpu_neighborhood_search_standalone(gpu_ctx):
     from splashsurf_amd.api import SplashsurfError
     with pytest.raises(SplashsurfError):  # particle outside the domain: the reference panics
         S.neighborhood_search_spatial_hashing_parallel(pts, S.Aabb3d(g["grid_min"], g["grid_min"] + 0.1), h, context=gpu_ctx)
+
+
+def test_u64_triangles_cross_pcie_as_u32(gpu_ctx):
+    """ss_result_triangles hands out the reference's index type ([usize; 3]).  For large meshes the indices cross PCIe as u32 in
+    chunks and host threads widen them while the next chunk is in flight; SS_OPTION_WIDEN_ON_DEVICE = 1 widens on the device and
+    copies 8 bytes per index.  Both give the same array, equal to the widened u32 accessor."""
+    import ctypes as C
+    import splashsurf_amd as S
+    from splashsurf_amd import workloads as W
+    from splashsurf_amd.api import Context
+    pts = W.tank_particles(0.35)
+    kw = dict(particle_radius=0.005, smoothing_length=2.0, cube_size=0.5, subdomain_grid=True, subdomain_grid_auto_disable=False)
+    a = S.reconstruct_surface(pts, context=gpu_ctx, **kw)
+    assert a.counts()[1] * 3 >= (1 << 20)  # large enough for the chunked path
+    t64 = a.mesh.triangles
+    assert t64.dtype == np.uint64 and np.array_equal(t64, a.mesh.triangles_u32.astype(np.uint64))
+    ctx_dev = Context(0)
+    ctx_dev._lib.ss_context_set_option.argtypes = [C.c_void_p, C.c_int, C.c_int]
+    assert ctx_dev._lib.ss_context_set_option(ctx_dev._h, 3, 1) == 0  # SS_OPTION_WIDEN_ON_DEVICE
+    b = S.reconstruct_surface(pts, context=ctx_dev, **kw)
+    assert np.array_equal(b.mesh.triangles, t64)
+    ctx_dev.close()
