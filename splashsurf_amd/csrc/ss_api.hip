@@ -1153,7 +1153,7 @@ ss_status phase_finish(ss_context* ctx, ss_result* res) {
                             &ctx->vcount, &ctx->tcount, &ctx->member_count, &ctx->copy_offset, &ctx->ckeys_a, &ctx->ckeys_b, &ctx->cvals_a, &ctx->cidx,
                             &ctx->cpos, &ctx->cell_count2, &ctx->cell_start2, &res->rho, &res->posvol, &ctx->mc_nb, &ctx->splat_tile_idx, &ctx->splat_tiles, &ctx->splat_counts, &ctx->splat_off, &ctx->splat_bound, &ctx->splat_overflow, &res->posvol_by_index, &res->perm, &res->inside8, &res->G, &res->block_slot,
                             &res->active_list, &res->mc_list, &res->mc_slot, &res->masks, &res->vbase, &res->tbase, &res->vertices, &res->vkeys,
-                            &res->tri32})
+                            &res->tri32, &ctx->splat_trunc, &ctx->own_flag, &ctx->sub_flag, &ctx->sub_rank, &ctx->occ_sub, &res->blk_minmax, &res->active_xyz, &res->mc_xyz})
         held += b->cap;
     S.bytes_device_peak = held;
     res->valid = true;
