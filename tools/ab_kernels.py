@@ -25,9 +25,9 @@ def main():
     ap.add_argument("--tag", default=os.path.basename(os.environ.get("SPLASHSURF_HIP_LIB", "in-tree")))
     ap.add_argument("--cube-size", type=float, default=None, help="override the workload's radius-relative cube size")
     ap.add_argument("--two-pass", type=int, default=None)
+    ap.add_argument("--host", action="store_true", help="hand the library the host (numpy) array; nothing of torch is loaded (sanitizer runs)")
     ap.add_argument("--digest", action="store_true", help="hash densities / vertices / triangles of the last step (D2H of the whole mesh)")
     a = ap.parse_args()
-    import torch
     from splashsurf_amd import workloads as W
     from splashsurf_amd.api import Context, Parameters
     wl = dict(W.WORKLOADS[a.workload])
@@ -40,8 +40,12 @@ def main():
     if a.two_pass is not None:
         ctx.set_two_pass(a.two_pass)
     pts = wl["gen"]()
-    d = torch.from_numpy(pts).to("cuda:0")
-    torch.cuda.synchronize()
+    if a.host:
+        d = pts
+    else:
+        import torch
+        d = torch.from_numpy(pts).to("cuda:0")
+        torch.cuda.synchronize()
     out = None
     for _ in range(a.warmup):
         out = ctx.reconstruct(d, prm, out=out)
