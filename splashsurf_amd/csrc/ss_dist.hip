@@ -183,9 +183,10 @@ ss_status comm_fail(ss_comm* c, const std::string& msg) { return fail(c->ctx, SS
 // see LocalGroup::turn.  Never hold one across a barrier or a collective.
 struct TurnGuard {
     ss_comm* c;
+    const char* what;
     bool held;
     double t_start = 0.0;
-    explicit TurnGuard(ss_comm* comm) : c(comm), held(comm->kind == 0 && comm->world > 1 && comm->group && comm->group->take_turns) {
+    explicit TurnGuard(ss_comm* comm, const char* name) : c(comm), what(name), held(comm->kind == 0 && comm->world > 1 && comm->group && comm->group->take_turns) {
         if (held) {
             c->group->turn.lock();
             t_start = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
@@ -194,7 +195,10 @@ struct TurnGuard {
     void release() {
         if (!held) return;
         (void)hipStreamSynchronize(c->ctx->stream);  // the device is handed on idle
-        c->info.ms_own_turns += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count() - t_start;
+        const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count() - t_start;
+        c->info.ms_own_turns += ms;
+        static const bool trace = getenv("SPLASH_DIST_TRACE") != nullptr;  // per-section times of every rank on stderr
+        if (trace) fprintf(stderr, "[dist-trace] rank %d %s %.3f ms\n", c->rank, what, ms);
         c->group->turn.unlock();
         held = false;
     }
@@ -663,7 +667,7 @@ ss_status pack_and_exchange(ss_comm* c, uint64_t n, uint64_t id0, const unsigned
     int n_active = 0;
     for (int q = 0; q < world; ++q)
         if (flag_for(q, &flags[q])) slot_of[q] = n_active++;
-    TurnGuard turn(c);  // scans and packing are this rank's own work; released before the ranks meet
+    TurnGuard turn(c, "pack");  // scans and packing are this rank's own work; released before the ranks meet
     SS_HIP(ctx, c->offs.reserve((size_t)std::max(n_active, 1) * (n + 1) * 4 + 64));  // (one offset array per ACTIVE destination)
     for (int q = 0; q < world; ++q) {
         if (slot_of[q] < 0) continue;
@@ -733,7 +737,7 @@ ss_status dist_reconstruct(ss_comm* c, const R* xyz_in, uint64_t n_local, const 
     memset(&zero_head, 0, sizeof(zero_head));
     mine_head = zero_head;
     mine_head.n = n_local;
-    TurnGuard turn(c);
+    TurnGuard turn(c, "aabb");
     if (n_local) {
         SS_HIP(ctx, ctx->aabb_partial.reserve(1024 * 6 * sizeof(R)));
         SS_HIP(ctx, ctx->aabb_out.reserve(6 * sizeof(R)));
@@ -787,7 +791,7 @@ ss_status dist_reconstruct(ss_comm* c, const R* xyz_in, uint64_t n_local, const 
     // ---- 2. bricks from the all-reduced owner histogram ----
     SS_HIP(ctx, c->hist.reserve(nsub * 4 + 64));
     {
-        TurnGuard hist_turn(c);
+        TurnGuard hist_turn(c, "hist");
         SS_HIP(ctx, hipMemsetAsync(c->hist.p, 0, nsub * 4, st));
         if (n_local)
             hipLaunchKernelGGL(k_owner_hist<R>, grid_for(n_local), dim3(256), 0, st, d_xyz, n_local, grid.aabb_min[0], grid.aabb_min[1], grid.aabb_min[2], subgrid.cell_size, ns[0],
@@ -847,7 +851,7 @@ ss_status dist_reconstruct(ss_comm* c, const R* xyz_in, uint64_t n_local, const 
     }
     SS_HIP(ctx, c->mask.reserve((n_local + 1) * 8 + 64));
     if (pos_active) {
-        TurnGuard mask_turn(c);
+        TurnGuard mask_turn(c, "mask_pos");
         hipLaunchKernelGGL(k_box_masks<R>, grid_for(n_local), dim3(256), 0, st, d_xyz, n_local, c->boxes_dev.as<DistBoxes>(), pos_active, (const uint32_t*)nullptr,
                            c->mask.as<unsigned long long>());
     }
@@ -864,7 +868,7 @@ ss_status dist_reconstruct(ss_comm* c, const R* xyz_in, uint64_t n_local, const 
     // ascending global-id order the engine needs (no sort).
     SS_HIP(ctx, c->gids.reserve(n_held * 8 + 64));
     SS_HIP(ctx, c->L.reserve(n_held * 3 * sizeof(R) + 64));
-    TurnGuard phase1_turn(c);  // unpacking and phase 1 are this rank's own work
+    TurnGuard phase1_turn(c, "unpack_phase1");  // unpacking and phase 1 are this rank's own work
     if (n_held)
         hipLaunchKernelGGL(k_unpack_rows, grid_for(n_held), dim3(256), 0, st, n_held, c->recvbuf.as<uint32_t>(), pos_words, c->gids.as<unsigned long long>(), c->L.as<uint32_t>());
     SS_HIP(ctx, hipStreamSynchronize(st));
@@ -917,7 +921,7 @@ ss_status dist_reconstruct(ss_comm* c, const R* xyz_in, uint64_t n_local, const 
     }
     SS_HIP(ctx, c->mask.reserve((n_held + 1) * 8 + 64));
     if (rho_active) {
-        TurnGuard mask_turn(c);
+        TurnGuard mask_turn(c, "mask_rho");
         hipLaunchKernelGGL(k_box_masks<R>, grid_for(n_held), dim3(256), 0, st, c->L.as<R>(), n_held, c->boxes_dev.as<DistBoxes>(), rho_active, c->owned.as<uint32_t>(),
                            c->mask.as<unsigned long long>());
     }
@@ -929,7 +933,7 @@ ss_status dist_reconstruct(ss_comm* c, const R* xyz_in, uint64_t n_local, const 
                                     },
                                     &n_rho_rows, &c->info.bytes_sent_densities);
     if (s != SS_OK) return s;
-    TurnGuard phase2_turn(c);  // scattering the received densities and phase 2
+    TurnGuard phase2_turn(c, "scatter_phase2");  // scattering the received densities and phase 2
     SS_HIP(ctx, c->err.reserve(64));
     SS_HIP(ctx, hipMemsetAsync(c->err.p, 0, 4, st));
     if (n_rho_rows)
@@ -992,7 +996,7 @@ ss_status dist_assemble(ss_comm* c, ss_result* res) {
     SS_HIP(ctx, c->mine_off.reserve((nv + 1) * 4 + 64));
     SS_HIP(ctx, c->vals_a.reserve((nv + 1) * 4 + 64));  // mine flags
     const unsigned long long* keys = res->vkeys.as<unsigned long long>();
-    TurnGuard turn(c);
+    TurnGuard turn(c, "asm_mine");
     if (nv) hipLaunchKernelGGL(k_vertex_owner, grid_for(nv), dim3(256), 0, st, nv, keys, B, np1, np2, c->owner.as<uint32_t>(), c->holder.as<unsigned long long>());
     uint32_t* mine = c->vals_a.as<uint32_t>();
     hipLaunchKernelGGL(k_write_flags<VertexFlag>, grid_for(nv + 1), dim3(256), 0, st, nv, VertexFlag{c->owner.as<uint32_t>(), c->holder.as<unsigned long long>(), nv, (uint32_t)me, -1}, mine);
@@ -1016,7 +1020,7 @@ ss_status dist_assemble(ss_comm* c, ss_result* res) {
         ttot += all[(size_t)q * 2 + 1];
     }
     {
-        TurnGuard gid_turn(c);
+        TurnGuard gid_turn(c, "asm_gid");
         if (nv) hipLaunchKernelGGL(k_owned_gids, grid_for(nv), dim3(256), 0, st, nv, mine, c->mine_off.as<uint32_t>(), (unsigned long long)voff, c->gid_local.as<unsigned long long>());
     }
     // owners -> the other ranks holding the edge: (key, global id)
@@ -1031,7 +1035,7 @@ ss_status dist_assemble(ss_comm* c, ss_result* res) {
                                       },
                                       &n_rows, &c->info.bytes_sent_assembly);
     if (s != SS_OK) return s;
-    TurnGuard join_turn(c);
+    TurnGuard join_turn(c, "asm_join");
     SS_HIP(ctx, c->err.reserve(64));
     SS_HIP(ctx, hipMemsetAsync(c->err.p, 0, 4, st));
     if (n_rows || nv) {
