@@ -239,6 +239,11 @@ ss_status make_device_params(ss_context* ctx, const typename TypesOf<R>::params*
     // (Round 2's bound v^2 min(2 v, 1) with its v_sqrt_f32: 8.17 ms / 86 % at 0.60 h on the same box.)
     P.R2near = (R(SS_TUNE_RNEAR) * h) * (R(SS_TUNE_RNEAR) * h);
     P.thr_inside = prm->iso_surface_threshold * R(1.0001);
+    {   // splat_bound_record: list coordinates are f16, relative to the block's centre in units of h, at most emax in size
+        const double emax = 3.5 * (double)prm->cube_size / (double)h + (double)SS_TUNE_RNEAR + 1.0e-3;
+        const double eps = std::ldexp(1.0, (int)std::floor(std::log2(emax)) - 11);  // half an f16 ulp of emax's binade
+        P.bound_one = (R)std::max(0.0, 1.0 - (3.6 * eps + 3.0 * eps * eps + 2.0e-6));  // 2 sqrt(3) = 3.47
+    }
     {   // CubicSplineKernelAvxF32::new (kernel.rs:327-337), in f32 like the reference
         const float hf = (float)h;
         const float pi_f = 3.14159265358979323846f;

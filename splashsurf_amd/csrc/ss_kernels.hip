@@ -758,6 +758,34 @@ __device__ __forceinline__ void ss_wave_lds_sync() {
 #define SS_WAVE_LIST 66  // survivors of one 64-entry batch per wave (+ 2 slots the read-ahead may touch)
 // lower bound of the cubic spline in u = 1 - q^2 (ss_splat_pair, SS_ARITH_BOUND): u^3 (C0 + C1 u^2) <= W(q) / sigma
 #define SS_BOUND_C0 0.150818f
+#define SS_BOUND_POOL 264  // 8-byte list records of one block's lower-bound pass (SplatAccWaveShared::wl)
+// -DSS_PHASE_PROF (tools/build_variant.sh NAME -- -DSS_PHASE_PROF): wave-cycles per phase of k_splat_fused, summed over all waves
+// into g_phase_prof (256 rows of 16 counters against atomic contention), read with ss_debug_phase_prof (tools/phase_prof.py)
+#ifdef SS_PHASE_PROF
+__device__ unsigned long long g_phase_prof[256 * 16];
+#define SS_PROF_BEGIN() unsigned long long prof_t0 = __builtin_amdgcn_s_memtime()
+#define SS_PROF_MARK(i)                                                                                            \
+    do {                                                                                                           \
+        const unsigned long long prof_t1 = __builtin_amdgcn_s_memtime();                                           \
+        if ((threadIdx.x & 63) == 0) atomicAdd(&g_phase_prof[(blockIdx.x & 255u) * 16u + (i)], prof_t1 - prof_t0); \
+        prof_t0 = __builtin_amdgcn_s_memtime();                                                                    \
+    } while (0)
+extern "C" void ss_debug_phase_prof(unsigned long long* out16, int reset) {
+    static unsigned long long h[256 * 16];
+    (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_phase_prof), sizeof(h));
+    for (int i = 0; i < 16; ++i) {
+        out16[i] = 0;
+        for (int r = 0; r < 256; ++r) out16[i] += h[r * 16 + i];
+    }
+    if (reset) {
+        for (auto& v : h) v = 0;
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_phase_prof), h, sizeof(h));
+    }
+}
+#else
+#define SS_PROF_BEGIN() do { } while (0)
+#define SS_PROF_MARK(i) do { } while (0)
+#endif
 #define SS_BOUND_C1 0.785260f
 template <class R, int CAP>
 struct SplatShared {
@@ -892,6 +920,78 @@ __device__ __forceinline__ void splat_wave_scan(const SSDevT<R>& P, const ss_rea
                 inside = ss_within_reach_of_block<R>(P, pv, plo, phi);
             }
             if (!f(inside, src, id, pv)) return;  // (wave-uniform)
+        }
+        ss_wave_lds_sync();  // the next batch overwrites the row tables
+    }
+}
+
+// Inclusive prefix sum over the wave with DPP row shifts and row broadcasts (no LDS round trips; ss_wave_reduce_to_lane63 has
+// the same structure): Hillis-Steele inside the rows of 16, then lane 15 of rows 0 / 2 into rows 1 / 3, then lane 31 into rows 2, 3.
+__device__ __forceinline__ uint32_t ss_wave_inclusive_scan(uint32_t v) {
+    int x = (int)v;
+    x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xF, 0xF, true);  // row_shr:1, zeros shifted in
+    x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xF, 0xF, true);  // row_shr:2
+    x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xF, 0xF, true);  // row_shr:4
+    x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xF, 0xF, true);  // row_shr:8
+    x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xA, 0xF, false);  // row_bcast:15 into rows 1 and 3
+    x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xC, 0xF, false);  // row_bcast:31 into rows 2 and 3
+    return (uint32_t)x;
+}
+
+// splat_wave_scan for the fused kernel: the scan is a chain of latencies (row table -> row of a candidate -> its payload), and a
+// wave that waits holds one of the SIMD's six wave slots, so the candidates are taken SS_SCAN_GROUP batches of 64 at a time:
+// the row look-ups of all batches of a group run interleaved (branch-free bisection over the row prefix table in LDS), then
+// all their loads are in flight together, then the batches are filtered and handed to f in order.  f as in splat_wave_scan.
+#define SS_SCAN_GROUP 6
+template <class R, class F>
+__device__ __forceinline__ void splat_wave_scan_grouped(const SSDevT<R>& P, const ss_real4<R>* __restrict__ posvol, const uint32_t* __restrict__ perm,
+                                                        const uint32_t* __restrict__ cell_start, const int klo[3], const int khi[3], const R plo[3], const R phi[3],
+                                                        uint32_t* s_row_start, uint32_t* s_row_prefix, int lane, F f) {
+    const int ny = khi[1] - klo[1] + 1;
+    const int nrows = (khi[0] - klo[0] + 1) * ny;
+    for (int row_base = 0; row_base < nrows; row_base += 64) {
+        const int nb = min(64, nrows - row_base);
+        uint32_t len = 0;
+        if (lane < nb) {
+            const int r = row_base + lane;
+            const int kx = klo[0] + r / ny, ky = klo[1] + r % ny;
+            int zlo, zhi;
+            uint32_t rb = 0, re = 0;
+            if (splat_row_z_range<R>(P, kx, ky, klo, khi, plo, phi, &zlo, &zhi)) {
+                rb = cell_start[ss_cell_key(P, kx, ky, zlo)];
+                re = cell_start[ss_cell_key(P, kx, ky, zhi) + 1u];
+            }
+            s_row_start[lane] = rb;
+            len = re - rb;
+        }
+        const uint32_t incl = ss_wave_inclusive_scan(len);
+        s_row_prefix[lane] = (lane < nb) ? incl - len : 0xFFFFFFFFu;  // rows past the end are never chosen by the bisection
+        const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+        ss_wave_lds_sync();
+        for (uint32_t q0 = 0; q0 < total; q0 += 64u * SS_SCAN_GROUP) {
+            uint32_t src[SS_SCAN_GROUP];
+#pragma unroll
+            for (int j = 0; j < SS_SCAN_GROUP; ++j) {
+                const uint32_t q = min(q0 + 64u * (uint32_t)j + (uint32_t)lane, total - 1u);
+                int lo = 0;  // last row r with row_prefix[r] <= q
+#pragma unroll
+                for (int step = 32; step > 0; step >>= 1) lo += (s_row_prefix[lo + step] <= q) ? step : 0;
+                src[j] = s_row_start[lo] + (q - s_row_prefix[lo]);
+            }
+            ss_real4<R> pv[SS_SCAN_GROUP];
+            uint32_t id[SS_SCAN_GROUP];
+#pragma unroll
+            for (int j = 0; j < SS_SCAN_GROUP; ++j) {
+                pv[j] = posvol[src[j]];
+                id[j] = perm[src[j]];
+            }
+#pragma unroll
+            for (int j = 0; j < SS_SCAN_GROUP; ++j) {
+                const uint32_t qj = q0 + 64u * (uint32_t)j;
+                if (qj >= total) break;  // (wave-uniform)
+                const bool inside = (qj + (uint32_t)lane < total) && ss_within_reach_of_block<R>(P, pv[j], plo, phi);
+                if (!f(inside, src[j], id[j], pv[j])) return;  // (wave-uniform)
+            }
         }
         ss_wave_lds_sync();  // the next batch overwrites the row tables
     }
@@ -1597,6 +1697,79 @@ __device__ __forceinline__ uint32_t splat_near_masks(const SSDevT<R>& P, const s
     return m;
 }
 
+// The lower-bound pass over 8-BYTE list records (f32 kernels, one wave per block).  The records are packed: (x, y, z) relative to
+// the BLOCK's centre in units of h as three f16, V sigma as the fourth, two entries per 16-byte read, consumed by v_fma_mix_f32
+// (f16 operands converted on the fly: no unpacking instructions).  Still a LOWER bound: V sigma is rounded towards zero; a
+// coordinate rounded to nearest is off by at most eps = half an f16 ulp of the largest |coordinate| (P.bound_one,
+// make_device_params), which moves d^2 by at most 2 sqrt(3) |d| eps + 3 eps^2, and u' = max(bound_one - d'^2, 0) with
+// bound_one = 1 - 3.6 eps - ... is <= max(1 - d^2, 0) for every d.
+typedef _Float16 ss_half2v __attribute__((ext_vector_type(2)));
+#define SS_BOUND_DUMMY make_uint2(0x56405640u, 0x00005640u)  // (100, 100, 100), volume 0: u = 0
+__device__ __forceinline__ uint2 splat_bound_record(const SSDevT<float>& P, const ss_real4<float>& pv, float cx, float cy, float cz) {
+    const ss_half2v xy = {(_Float16)((pv.x - cx) * P.avx_inv_h), (_Float16)((pv.y - cy) * P.avx_inv_h)};
+    const uint32_t vv = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(0.0f, pv.w * P.avx_sigma));  // towards zero = down; high half
+    const ss_half2v zz = {(_Float16)((pv.z - cz) * P.avx_inv_h), (_Float16)0.0f};
+    return make_uint2(__builtin_bit_cast(uint32_t, xy), __builtin_bit_cast(uint32_t, zz) | vv);
+}
+
+// Walk of one list: n entries at `list` (8-byte aligned to 16), padded with dummies to a multiple of four, 16 readable bytes
+// behind the padding.  (npx, npy, npz) = minus the lane's point in the records' frame.  Returns the sum in units of 1 (V sigma g).
+__device__ __forceinline__ float splat_bound_walk(const SSDevT<float>& P, const uint2* list, int n, float npx, float npy, float npz) {
+    const float one = P.bound_one;
+    float acc = 0.0f;
+    auto pair = [&](uint32_t w0, uint32_t w1) {
+        float dx, dy, dz, u, r;
+        asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel_hi:[1,0,0]" : "=v"(dx) : "v"(w0), "v"(npx));
+        asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(dy) : "v"(w0), "v"(npy));
+        asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel_hi:[1,0,0]" : "=v"(dz) : "v"(w1), "v"(npz));
+        const float a = __builtin_fmaf(-dx, dx, __builtin_fmaf(-dy, dy, one));
+        asm("v_fma_f32 %0, -%1, %1, %2 clamp" : "=v"(u) : "v"(dz), "v"(a));
+        const float u2 = u * u;
+        const float t = (u2 * u) * __builtin_fmaf(u2, SS_BOUND_C1, SS_BOUND_C0);
+        asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[0,1,0]" : "=v"(r) : "v"(t), "v"(w1), "v"(acc));
+        acc = r;
+    };
+    // The walk is software-pipelined by hand: the compiler sinks a read-ahead written in C++ to the top of the next trip and
+    // waits for it at once (every trip then exposes one LDS latency), so the reads are issued in asm, one 16-byte read (two
+    // entries) ahead, with their own s_waitcnt -- LDS reads return in order, lgkmcnt(1) = "everything but the newest read".
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    const int trips = (n + 3) >> 2;
+    uint32_t addr = (uint32_t)(uintptr_t)list;  // LDS byte address of the list
+    u32x4 qa, qb;
+    asm volatile("ds_read_b128 %0, %1" : "=v"(qa) : "v"(addr) : "memory");
+    for (int k = 0; k < trips; ++k) {
+        asm volatile("ds_read_b128 %0, %1 offset:16" : "=v"(qb) : "v"(addr));
+        asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(qa));
+        pair(qa.x, qa.y);
+        pair(qa.z, qa.w);
+        asm volatile("ds_read_b128 %0, %1 offset:32" : "=v"(qa) : "v"(addr));
+        asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(qb));
+        pair(qb.x, qb.y);
+        pair(qb.z, qb.w);
+        addr += 32u;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(qa));  // the last read-ahead has landed before its registers are reused
+    return acc;
+}
+
+// One sub-block's list built on its own (blocks whose eight lists do not fit the pool together), then walked.
+__device__ __forceinline__ float splat_bound_single(const SSDevT<float>& P, const ss_real4<float>* pay, const uint8_t* near, uint2* pool, int n_tile, int lane,
+                                                    float cx, float cy, float cz, float npx, float npy, float npz, int sb, int* n_near) {
+    ss_wave_lds_sync();  // the previous sub-block's reads of the pool are done
+    int total = 0;
+    for (int base = 0; base < n_tile; base += 64) {
+        const int c = base + lane;
+        const bool pass = c < n_tile && ((near[c] >> sb) & 1u);
+        const unsigned long long m = __ballot(pass);
+        if (pass) pool[total + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] = splat_bound_record(P, pay[c], cx, cy, cz);
+        total += __popcll(m);
+    }
+    *n_near = total;
+    if (lane < 4) pool[total + lane] = SS_BOUND_DUMMY;
+    ss_wave_lds_sync();
+    return splat_bound_walk(P, pool, total, npx, npy, npz);
+}
+
 // ---- one WAVE per block -----------------------------------------------------------------------------------------------------
 // Blocks whose tile fits one wave's LDS chunk (all blocks of ordinary inputs: ~140 entries at the reference's default spacing)
 // are evaluated by a single wave that walks the eight 4^3 sub-blocks one after the other.  Against the workgroup-per-block
@@ -1607,7 +1780,9 @@ __device__ __forceinline__ uint32_t splat_near_masks(const SSDevT<R>& P, const s
 template <class R>
 struct SplatAccWaveShared {
     ss_real4<R> pay[SSWaveChunk<R>::value];
-    ss_real4<R> wl[SS_WAVE_LIST];
+    // list of one sub-block: one 64-entry batch of full records (exact sums), or -- f32 lower-bound pass -- the lists of near
+    // entries of ALL EIGHT sub-blocks as 8-byte records (SS_BOUND_POOL entries + 8 the read-ahead may touch)
+    ss_real4<R> wl[(sizeof(R) == 4) ? (SS_BOUND_POOL + 8) / 2 : SS_WAVE_LIST];
     uint8_t near[SSWaveChunk<R>::value];  // per tile entry: the sub-blocks whose classification pass visits it
     uint32_t idx[SSWaveChunk<R>::value];  // particle indices of the tile entries (splat_sort_tile)
 };
@@ -1655,6 +1830,7 @@ __device__ __forceinline__ void splat_accumulate_block_wave(SplatAccWaveShared<R
     static_assert(CH % 64 == 0, "the tile is staged in whole batches of 64 entries");
     constexpr int CLS = (sizeof(R) == 4) ? SS_ARITH_BOUND : ARITH;  // see splat_accumulate_block
     const int lane = threadIdx.x & 63;
+    SS_PROF_BEGIN();
     ss_real4<R> stage[CH / 64];
 #pragma unroll
     for (int k = 0; k < CH / 64; ++k) {
@@ -1690,13 +1866,60 @@ __device__ __forceinline__ void splat_accumulate_block_wave(SplatAccWaveShared<R
                 pt_ok[d][h] = g + o3[d] < P.np[d];
             }
     }
+    // f32 lower-bound pass: the lists of near entries of all eight sub-blocks are built in ONE pass over the tile (8-byte records
+    // relative to the block's centre, splat_bound_record) into a pool in LDS -- every entry is read once, the eight ballots per
+    // batch need no LDS round trip, and the walks of the sub-blocks follow each other without list building in between.
+    // lane sb of v_list: (offset << 16) | entries of sub-block sb's list.  Blocks whose lists do not fit the pool together
+    // (SS_BOUND_POOL entries, each list padded to whole trips of four) build them one by one (splat_bound_single).
+    [[maybe_unused]] uint32_t v_list = 0;
+    [[maybe_unused]] bool pooled = false;
+    [[maybe_unused]] R bcx = R(0.0), bcy = R(0.0), bcz = R(0.0);
     if constexpr (EARLY) {
+        uint32_t mask[CH / 64];
 #pragma unroll
-        for (int k = 0; k < CH / 64; ++k)
+        for (int k = 0; k < CH / 64; ++k) {
+            mask[k] = 0u;
             if (lane + 64 * k < n_tile) {
                 if constexpr (STAGED) stage[k] = sh.pay[lane + 64 * k];
-                sh.near[lane + 64 * k] = (uint8_t)splat_near_masks<R>(P, stage[k], lo, hi, P.R2near);
+                mask[k] = splat_near_masks<R>(P, stage[k], lo, hi, P.R2near);
+                sh.near[lane + 64 * k] = (uint8_t)mask[k];
             }
+        }
+        if constexpr (CLS == SS_ARITH_BOUND) {
+            bcx = lo[0][0] + R(3.5) * P.cs;
+            bcy = lo[1][0] + R(3.5) * P.cs;
+            bcz = lo[2][0] + R(3.5) * P.cs;
+            uint2 rec[CH / 64];
+#pragma unroll
+            for (int k = 0; k < CH / 64; ++k) rec[k] = splat_bound_record(P, stage[k], bcx, bcy, bcz);
+            int off[8], cnt[8], total = 0;
+#pragma unroll
+            for (int sb = 0; sb < 8; ++sb) {
+                int c = 0;
+#pragma unroll
+                for (int k = 0; k < CH / 64; ++k) c += __popcll(__ballot((mask[k] >> sb) & 1u));
+                off[sb] = total;
+                cnt[sb] = c;
+                if (lane == sb) v_list = ((uint32_t)total << 16) | (uint32_t)c;
+                total += (c + 3) & ~3;
+            }
+            pooled = total <= SS_BOUND_POOL;
+            if (pooled) {
+                uint2* pool = reinterpret_cast<uint2*>(sh.wl);
+#pragma unroll
+                for (int sb = 0; sb < 8; ++sb)
+                    if (lane < ((cnt[sb] + 3) & ~3) - cnt[sb]) pool[off[sb] + cnt[sb] + lane] = SS_BOUND_DUMMY;
+#pragma unroll
+                for (int k = 0; k < CH / 64; ++k)
+#pragma unroll
+                    for (int sb = 0; sb < 8; ++sb) {
+                        const bool bit = (mask[k] >> sb) & 1u;
+                        const unsigned long long m = __ballot(bit);
+                        if (bit) pool[off[sb] + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] = rec[k];
+                        off[sb] += __popcll(m);
+                    }
+            }
+        }
     }
     if constexpr (!STAGED) {
 #pragma unroll
@@ -1704,6 +1927,7 @@ __device__ __forceinline__ void splat_accumulate_block_wave(SplatAccWaveShared<R
             if (lane + 64 * k < n_tile) sh.pay[lane + 64 * k] = stage[k];
     }
     ss_wave_lds_sync();
+    SS_PROF_MARK(1);  // block set-up, near masks, lists of the lower-bound pass
     // second pass: the sub-blocks the first pass certified (their values were never stored, see below)
     const uint32_t certified_before = (!EARLY && wave_mask != 0xFFu) ? (uint32_t)__builtin_amdgcn_readfirstlane((int)trunc[logical]) : 0u;
     R mn = R(INFINITY), mx = -R(INFINITY);
@@ -1729,8 +1953,22 @@ __device__ __forceinline__ void splat_accumulate_block_wave(SplatAccWaveShared<R
                 const R slo[3] = {sx ? lo[0][1] : lo[0][0], sy ? lo[1][1] : lo[1][0], sz ? lo[2][1] : lo[2][0]};
                 const R shi[3] = {sx ? hi[0][1] : hi[0][0], sy ? hi[1][1] : hi[1][0], sz ? hi[2][1] : hi[2][0]};
                 int n_near = 0;
-                R acc = splat_accumulate_wave<R, CLS>(P, sh.pay, sh.wl, n_tile, lane, px, py, pz, slo, shi, P.R2near, R(0.0), sh.near, sb, &n_near);
-                if constexpr (CLS == SS_ARITH_BOUND) acc *= P.avx_sigma;  // the bound pass sums in units of sigma
+                R acc;
+                if constexpr (CLS == SS_ARITH_BOUND) {
+                    const float npx = (bcx - px) * P.avx_inv_h, npy = (bcy - py) * P.avx_inv_h, npz = (bcz - pz) * P.avx_inv_h;  // minus the point
+                    uint2* pool = reinterpret_cast<uint2*>(sh.wl);
+                    SS_PROF_MARK(5);  // (classification: everything but the walks)
+                    if (pooled) {
+                        const uint32_t ol = (uint32_t)__builtin_amdgcn_readlane((int)v_list, sb);
+                        n_near = (int)(ol & 0xFFFFu);
+                        acc = splat_bound_walk(P, pool + (ol >> 16), n_near, npx, npy, npz);
+                    } else {
+                        acc = splat_bound_single(P, sh.pay, sh.near, pool, n_tile, lane, bcx, bcy, bcz, npx, npy, npz, sb, &n_near);
+                    }
+                    SS_PROF_MARK(6);  // walks of the lists
+                } else {
+                    acc = splat_accumulate_wave<R, CLS>(P, sh.pay, sh.wl, n_tile, lane, px, py, pz, slo, shi, P.R2near, R(0.0), sh.near, sb, &n_near);
+                }
                 // the margin of thr_inside covers the rounding of the terms; a sum of n of them adds up to n 2^-24 relative
                 const R thr = P.thr_inside + ((R)n_near * R(1.2e-7)) * P.thr_inside;
                 done = __ballot(acc > thr || !point_valid) == ~0ull;
@@ -1748,8 +1986,10 @@ __device__ __forceinline__ void splat_accumulate_block_wave(SplatAccWaveShared<R
         mx = ss_max(mx, val);
         if constexpr (EARLY) faces |= (unsigned long long)splat_face_bits(__ballot(point_valid && !(val > P.threshold))) << (6 * sb);
     }
+    SS_PROF_MARK(2);  // classification of the eight sub-blocks
     if (need) {
         splat_sort_tile<R>(sh, STAGED ? nullptr : tile_idx, n_tile, lane);
+        SS_PROF_MARK(3);  // tile sort
 #pragma unroll 1
         for (int sb = 0; sb < 8; ++sb) {
             if (!((need >> sb) & 1u)) continue;
@@ -1767,6 +2007,7 @@ __device__ __forceinline__ void splat_accumulate_block_wave(SplatAccWaveShared<R
             if constexpr (EARLY) faces |= (unsigned long long)splat_face_bits(__ballot(point_valid && !(val > P.threshold))) << (6 * sb);
         }
     }
+    SS_PROF_MARK(4);  // exact sums
     int writer = 0;
     if constexpr (sizeof(R) == 4) {
         mn = ss_wave_reduce_to_lane63<false>(mn);
@@ -1817,9 +2058,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(sizeof(R) ==
         R plo[3], phi[3];
         int klo[3], khi[3];
         uint32_t count = 0;
+        SS_PROF_BEGIN();
         ss_wave_lds_sync();  // the previous block's reads of the tile are done
         if (splat_block_box<R>(P, b3, plo, phi, klo, khi)) {
-            splat_wave_scan<R, true>(P, posvol, perm, cell_start, klo, khi, plo, phi, s_row_start, s_row_prefix, lane,
+            splat_wave_scan_grouped<R>(P, posvol, perm, cell_start, klo, khi, plo, phi, s_row_start, s_row_prefix, lane,
                                      [&](bool inside, uint32_t, uint32_t id, const ss_real4<R>& pv) {
                                          const unsigned long long m = __ballot(inside);
                                          const uint32_t pos = count + (uint32_t)__popcll(m & below);
@@ -1837,8 +2079,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(sizeof(R) ==
             continue;
         }
         ss_wave_lds_sync();
+        SS_PROF_MARK(0);  // candidate scan
         splat_accumulate_block_wave<R, ARITH, EARLY, true>(sh, P, logical, (int)count, nullptr, nullptr, active_xyz, G, blk_minmax, trunc, facebits,
                                                            redo_mask ? __builtin_amdgcn_readfirstlane(redo_mask[logical]) : 0xFFu);
+        SS_PROF_MARK(7);  // whole sub-block walk incl. epilogue (phases 1-6 are inside)
     }
 }
 
