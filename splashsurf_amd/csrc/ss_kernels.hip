@@ -758,7 +758,7 @@ __device__ __forceinline__ void ss_wave_lds_sync() {
 #define SS_WAVE_LIST 66  // survivors of one 64-entry batch per wave (+ 2 slots the read-ahead may touch)
 // lower bound of the cubic spline in u = 1 - q^2 (ss_splat_pair, SS_ARITH_BOUND): u^3 (C0 + C1 u^2) <= W(q) / sigma
 #define SS_BOUND_C0 0.150818f
-#define SS_BOUND_POOL 264  // 8-byte list records of one block's lower-bound pass (SplatAccWaveShared::wl)
+#define SS_BOUND_POOL 212  // 8-byte list records of one block's lower-bound pass (SplatAccWaveShared::wl)
 // -DSS_PHASE_PROF (tools/build_variant.sh NAME -- -DSS_PHASE_PROF): wave-cycles per phase of k_splat_fused, summed over all waves
 // into g_phase_prof (256 rows of 16 counters against atomic contention), read with ss_debug_phase_prof (tools/phase_prof.py)
 #ifdef SS_PHASE_PROF
