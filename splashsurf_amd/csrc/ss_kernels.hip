@@ -2419,11 +2419,9 @@ __global__ __launch_bounds__(256) void k_mc_count(SSDevT<R> P, const R* __restri
         if (lane == 0) masks[(size_t)m * 24 + a * 8 + 4 * half + wave] = mk;
         nv += (uint32_t)__popcll(mk);
     }
-    // triangles of this wave
-    uint32_t nt = (uint32_t)L.ntri;
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) nt += __shfl_xor(nt, off);
-    if (lane == 0) {
+    // triangles of this wave (lane 63 of the DPP scan holds the sum)
+    const uint32_t nt = ss_wave_inclusive_scan((uint32_t)L.ntri);
+    if (lane == 63) {
         s_v[wave] = nv;
         s_t[wave] = nt;
     }
@@ -2451,27 +2449,36 @@ __global__ __launch_bounds__(512) void k_mc_emit(SSDevT<R> P, const R* __restric
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t m = blockIdx.x;
     if (m >= n_mc) return;
-    if (vbase[m + 1] == vbase[m] && tbase[m + 1] == tbase[m]) return;  // nothing to emit for this block
-    reinterpret_cast<unsigned long long*>(s_lut)[tid] = reinterpret_cast<const unsigned long long*>(&c_mc_table[0][0])[tid];
+    // everything the first round trip can fetch is requested before the "nothing to emit" test waits for its four words
+    const uint32_t vb0 = vbase[m], vb1 = vbase[m + 1], tb0 = tbase[m], tb1 = tbase[m + 1];
+    const unsigned long long lut_word = reinterpret_cast<const unsigned long long*>(&c_mc_table[0][0])[tid];
     const int bx = (int)mc_xyz[3 * (size_t)m], by = (int)mc_xyz[3 * (size_t)m + 1], bz = (int)mc_xyz[3 * (size_t)m + 2];  // k_block_coords
-    if (tid < SS_MC_REC) s_nb[tid] = mc_nb[SS_MC_REC * (size_t)m + tid];
+    uint32_t nb_word = 0;
+    if (tid < SS_MC_REC) nb_word = mc_nb[SS_MC_REC * (size_t)m + tid];
+    if (vb1 == vb0 && tb1 == tb0) return;  // nothing to emit for this block
+    reinterpret_cast<unsigned long long*>(s_lut)[tid] = lut_word;
+    if (tid < SS_MC_REC) s_nb[tid] = nb_word;
     __syncthreads();
     mc_load_tile(tile, P, G, s_nb, tid);
-    // crossing masks of this block and its 7 upper neighbours
-    if (tid < 8 * 24) {
-        const int nb = tid / 24, w = tid % 24;
+    // crossing masks of this block and its 7 upper neighbours, and for each (neighbour, word) the neighbour's vertices before that
+    // word: thread 32 nb + w holds word w of neighbour nb, and the prefix is a DPP scan over the wave's two neighbours (eight
+    // threads walking 24 words one after the other held the other 504 up for 24 LDS round trips)
+    if (tid < 8 * 32) {
+        const int nb = tid >> 5, w = tid & 31;
         unsigned long long mk = 0;
-        const uint32_t slot = mc_nb[SS_MC_REC * (size_t)m + 16 + nb];  // (straight from the record: s_nb is being filled by other threads)
-        if (slot != 0xFFFFFFFFu) mk = masks[(size_t)slot * 24 + w];
-        s_mask[nb][w] = mk;
-        if (w == 0) s_vbase[nb] = (slot != 0xFFFFFFFFu) ? vbase[slot] : 0u;
-    }
-    __syncthreads();
-    if (tid < 8) {
-        uint32_t run = 0;
-        for (int w = 0; w < 24; ++w) {
-            s_pref[tid][w] = run;
-            run += (uint32_t)__popcll(s_mask[tid][w]);
+        uint32_t slot = 0xFFFFFFFFu;
+        if (w < 24) {
+            slot = mc_nb[SS_MC_REC * (size_t)m + 16 + nb];  // (straight from the record: s_nb is being filled by other threads)
+            if (slot != 0xFFFFFFFFu) mk = masks[(size_t)slot * 24 + w];
+        }
+        const uint32_t c = (uint32_t)__popcll(mk);
+        uint32_t incl = ss_wave_inclusive_scan(c);
+        const uint32_t first_half = (uint32_t)__builtin_amdgcn_readlane((int)incl, 31);
+        if (lane >= 32) incl -= first_half;
+        if (w < 24) {
+            s_mask[nb][w] = mk;
+            s_pref[nb][w] = incl - c;
+            if (w == 0) s_vbase[nb] = (slot != 0xFFFFFFFFu) ? vbase[slot] : 0u;
         }
     }
     __syncthreads();
@@ -2519,17 +2526,12 @@ __global__ __launch_bounds__(512) void k_mc_emit(SSDevT<R> P, const R* __restric
     // trips and scatters 12-byte stores.  Instead every lane files a record (cell, case, triangle number) per triangle of its cell
     // at the triangle's rank within the wave, and the wave then emits records 64 at a time: lane k builds the k-th triangle, so
     // the stores of a trip form one contiguous run.
-    uint32_t incl = (uint32_t)L.ntri;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        uint32_t t = __shfl_up(incl, off);
-        if (lane >= off) incl += t;
-    }
+    const uint32_t incl = ss_wave_inclusive_scan((uint32_t)L.ntri);  // (DPP: no LDS round trips)
     if (lane == 63) s_twave[wave] = incl;
     const uint32_t excl = incl - (uint32_t)L.ntri;
     for (int i = 0; i < L.ntri; ++i) s_rec[wave][excl + (uint32_t)i] = (uint32_t)tid | ((uint32_t)i << 9) | ((uint32_t)L.case_index << 12);
     __syncthreads();
-    uint32_t toff = tbase[m];
+    uint32_t toff = tb0;
     for (int w = 0; w < wave; ++w) toff += s_twave[w];
     const uint32_t n_wave = s_twave[wave];
     for (uint32_t k = (uint32_t)lane; k < n_wave; k += 64u) {
