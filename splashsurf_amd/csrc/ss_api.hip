@@ -1067,8 +1067,8 @@ ss_status phase_finish(ss_context* ctx, ss_result* res) {
     SS_HIP(ctx, ctx->tcount.reserve(((size_t)n_mc + 1) * 4));
     SS_HIP(ctx, res->vbase.reserve(((size_t)n_mc + 1) * 4));
     SS_HIP(ctx, res->tbase.reserve(((size_t)n_mc + 1) * 4));
-    SS_HIP(ctx, hipMemsetAsync(ctx->vcount.p, 0, ((size_t)n_mc + 1) * 4, st));
-    SS_HIP(ctx, hipMemsetAsync(ctx->tcount.p, 0, ((size_t)n_mc + 1) * 4, st));
+    SS_HIP(ctx, hipMemsetAsync(ctx->vcount.as<uint32_t>() + n_mc, 0, 4, st));  // (k_mc_count stores the counts of all blocks; the scans end on a 0)
+    SS_HIP(ctx, hipMemsetAsync(ctx->tcount.as<uint32_t>() + n_mc, 0, 4, st));
     SS_HIP(ctx, res->mc_xyz.reserve((size_t)n_mc * 12 + 16));
     ss_launch_block_coords(P, res->mc_list.as<uint32_t>(), n_mc, res->mc_xyz.as<uint32_t>(), st);
     SS_HIP(ctx, ctx->mc_nb.reserve((size_t)n_mc * 96 + 64));

@@ -2393,8 +2393,38 @@ __device__ inline void mc_load_half_tile(McTile<R>& t, const SSDevT<R>& P, const
     if (tid < 149) t.g[(x1 * 9 + y1) * 9 + z1] = v1;
 }
 
-// Two 256-thread workgroups per MC block, one per half of its x-slabs (wave = slab): the kernel is bound by the latency of its
-// dependent loads (record, values), and a CU holds eight such workgroups instead of four of 512 threads.
+// all 729 points for 256 threads: thread t reads offsets t and 256 + t of the block itself (two contiguous 1-KiB reads per workgroup)
+// and threads 0..216 one point of the halo; the three loads are issued before any value is written to LDS
+template <class R>
+__device__ inline void mc_load_tile_256(McTile<R>& t, const SSDevT<R>& P, const R* __restrict__ G, const uint32_t* s_nb, int tid) {
+    int xa, ya, za, xb, yb, zb;
+    mc_point_of_offset(tid, &xa, &ya, &za);
+    mc_point_of_offset(256 + tid, &xb, &yb, &zb);
+    const R va = mc_fetch_point(P, G, s_nb, xa, ya, za);
+    const R vb = mc_fetch_point(P, G, s_nb, xb, yb, zb);
+    int x1 = 8, y1 = 0, z1 = 0;
+    if (tid < 81) {  // plane x = 8
+        y1 = tid / 9;
+        z1 = tid % 9;
+    } else if (tid < 153) {  // plane y = 8, x < 8
+        x1 = (tid - 81) / 9;
+        y1 = 8;
+        z1 = (tid - 81) % 9;
+    } else {  // plane z = 8, x < 8, y < 8
+        x1 = ((tid - 153) >> 3) & 7;
+        y1 = (tid - 153) & 7;
+        z1 = 8;
+    }
+    R v1 = R(0.0);
+    if (tid < 217) v1 = mc_fetch_point(P, G, s_nb, x1, y1, z1);
+    t.g[(xa * 9 + ya) * 9 + za] = va;
+    t.g[(xb * 9 + yb) * 9 + zb] = vb;
+    if (tid < 217) t.g[(x1 * 9 + y1) * 9 + z1] = v1;
+}
+
+// ONE 256-thread workgroup per MC block, two points per thread (wave w: the x-slabs w and 4 + w).  The kernel is bound by the
+// latency of its two dependent round trips (record, values): a workgroup of 512 threads per block halves the workgroups a CU holds,
+// two workgroups of 256 per block (round 2) pay both round trips and the record twice per block.  Counts are plain stores.
 template <class R>
 __global__ __launch_bounds__(256) void k_mc_count(SSDevT<R> P, const R* __restrict__ G, const uint32_t* __restrict__ mc_nb,
                                                   const uint32_t* __restrict__ mc_xyz, uint32_t n_mc, unsigned long long* __restrict__ masks,
@@ -2403,37 +2433,42 @@ __global__ __launch_bounds__(256) void k_mc_count(SSDevT<R> P, const R* __restri
     __shared__ uint32_t s_nb[SS_MC_REC];
     __shared__ uint32_t s_v[4], s_t[4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const uint32_t m = blockIdx.x >> 1;
-    const int half = (int)(blockIdx.x & 1u);
+    const uint32_t m = blockIdx.x;
     if (m >= n_mc) return;
     const int bx = (int)mc_xyz[3 * (size_t)m], by = (int)mc_xyz[3 * (size_t)m + 1], bz = (int)mc_xyz[3 * (size_t)m + 2];  // k_block_coords
     if (tid < SS_MC_REC) s_nb[tid] = mc_nb[SS_MC_REC * (size_t)m + tid];
     __syncthreads();
-    mc_load_half_tile(tile, P, G, s_nb, half, tid);
+    mc_load_tile_256(tile, P, G, s_nb, tid);
     __syncthreads();
-    const McLocal L = mc_classify(tile, P, bx, by, bz, 256 * half + tid);
-    uint32_t nv = 0;
+    uint32_t nv = 0, ntri = 0;
 #pragma unroll
-    for (int a = 0; a < 3; ++a) {
-        const unsigned long long mk = __ballot(L.cross[a]);
-        if (lane == 0) masks[(size_t)m * 24 + a * 8 + 4 * half + wave] = mk;
-        nv += (uint32_t)__popcll(mk);
+    for (int half = 0; half < 2; ++half) {
+        const McLocal L = mc_classify(tile, P, bx, by, bz, 256 * half + tid);
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const unsigned long long mk = __ballot(L.cross[a]);
+            if (lane == 0) masks[(size_t)m * 24 + a * 8 + 4 * half + wave] = mk;
+            nv += (uint32_t)__popcll(mk);
+        }
+        ntri += (uint32_t)L.ntri;
     }
     // triangles of this wave (lane 63 of the DPP scan holds the sum)
-    const uint32_t nt = ss_wave_inclusive_scan((uint32_t)L.ntri);
+    const uint32_t nt = ss_wave_inclusive_scan(ntri);
     if (lane == 63) {
         s_v[wave] = nv;
         s_t[wave] = nt;
     }
     __syncthreads();
-    if (tid == 0) {  // vcount / tcount are zeroed by the host; integer sums: the result does not depend on the order
-        atomicAdd(&vcount[m], s_v[0] + s_v[1] + s_v[2] + s_v[3]);
-        atomicAdd(&tcount[m], s_t[0] + s_t[1] + s_t[2] + s_t[3]);
+    if (tid == 0) {
+        vcount[m] = s_v[0] + s_v[1] + s_v[2] + s_v[3];
+        tcount[m] = s_t[0] + s_t[1] + s_t[2] + s_t[3];
     }
 }
 
+// ONE 256-thread workgroup per MC block, two points per thread like k_mc_count (wave w: the x-slabs w and 4 + w; eight such
+// workgroups per CU instead of four of 512 threads, the two round trips of a block -- record, then values and masks -- paid once).
 template <class R>
-__global__ __launch_bounds__(512) void k_mc_emit(SSDevT<R> P, const R* __restrict__ G, const uint32_t* __restrict__ mc_nb,
+__global__ __launch_bounds__(256) void k_mc_emit(SSDevT<R> P, const R* __restrict__ G, const uint32_t* __restrict__ mc_nb,
                                                  const uint32_t* __restrict__ mc_xyz, const uint32_t* __restrict__ mc_slot, uint32_t n_mc,
                                                  const unsigned long long* __restrict__ masks, const uint32_t* __restrict__ vbase,
                                                  const uint32_t* __restrict__ tbase, R* __restrict__ vertices,
@@ -2443,27 +2478,27 @@ __global__ __launch_bounds__(512) void k_mc_emit(SSDevT<R> P, const R* __restric
     __shared__ unsigned long long s_mask[8][24];  // [neighbour][axis*8+word]
     __shared__ uint32_t s_pref[8][24];            // vertices of that neighbour block before (axis, word)
     __shared__ uint32_t s_vbase[8];
-    __shared__ uint32_t s_twave[8];
-    __shared__ uint32_t s_rec[8][5 * 64];  // per wave: (cell, triangle number, case) of its triangles, in cell order
-    __shared__ int8_t s_lut[256 * 16];     // the case table: the corner look-ups of a trip hit 64 different rows
+    __shared__ uint32_t s_tslab[8];        // triangles of x-slab s
+    __shared__ uint32_t s_rec[8][5 * 64];  // per x-slab: (cell, triangle number, case) of its triangles, in cell order
+    __shared__ __attribute__((aligned(16))) int8_t s_lut[256 * 16];  // the case table: the corner look-ups of a trip hit 64 different rows
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t m = blockIdx.x;
     if (m >= n_mc) return;
     // everything the first round trip can fetch is requested before the "nothing to emit" test waits for its four words
     const uint32_t vb0 = vbase[m], vb1 = vbase[m + 1], tb0 = tbase[m], tb1 = tbase[m + 1];
-    const unsigned long long lut_word = reinterpret_cast<const unsigned long long*>(&c_mc_table[0][0])[tid];
+    const uint4 lut_word = reinterpret_cast<const uint4*>(&c_mc_table[0][0])[tid];
     const int bx = (int)mc_xyz[3 * (size_t)m], by = (int)mc_xyz[3 * (size_t)m + 1], bz = (int)mc_xyz[3 * (size_t)m + 2];  // k_block_coords
     uint32_t nb_word = 0;
     if (tid < SS_MC_REC) nb_word = mc_nb[SS_MC_REC * (size_t)m + tid];
     if (vb1 == vb0 && tb1 == tb0) return;  // nothing to emit for this block
-    reinterpret_cast<unsigned long long*>(s_lut)[tid] = lut_word;
+    reinterpret_cast<uint4*>(s_lut)[tid] = lut_word;
     if (tid < SS_MC_REC) s_nb[tid] = nb_word;
     __syncthreads();
-    mc_load_tile(tile, P, G, s_nb, tid);
+    mc_load_tile_256(tile, P, G, s_nb, tid);
     // crossing masks of this block and its 7 upper neighbours, and for each (neighbour, word) the neighbour's vertices before that
     // word: thread 32 nb + w holds word w of neighbour nb, and the prefix is a DPP scan over the wave's two neighbours (eight
-    // threads walking 24 words one after the other held the other 504 up for 24 LDS round trips)
-    if (tid < 8 * 32) {
+    // threads walking 24 words one after the other held the others up for 24 LDS round trips)
+    {
         const int nb = tid >> 5, w = tid & 31;
         unsigned long long mk = 0;
         uint32_t slot = 0xFFFFFFFFu;
@@ -2482,79 +2517,87 @@ __global__ __launch_bounds__(512) void k_mc_emit(SSDevT<R> P, const R* __restric
         }
     }
     __syncthreads();
-    const McLocal L = mc_classify(tile, P, bx, by, bz, tid);
-
-    // ---- vertices on the three edges owned by this thread's point (dense_subdomains.rs:1498-1539) ----
-    const int lx = tid >> 6, ly = (tid >> 3) & 7, lz = tid & 7;
     const int n = P.n_sub_cubes;
-    const int O[3] = {L.gx, L.gy, L.gz};
     const unsigned long long below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
 #pragma unroll
-    for (int a = 0; a < 3; ++a) {
-        if (!L.cross[a]) continue;
-        const uint32_t vid = s_vbase[0] + s_pref[0][a * 8 + wave] + (uint32_t)__popcll(s_mask[0][a * 8 + wave] & below);
-        const int tl[3] = {lx + (a == 0), ly + (a == 1), lz + (a == 2)};
-        const R ov = tile.g[(lx * 9 + ly) * 9 + lz];
-        const R tv = tile.g[(tl[0] * 9 + tl[1]) * 9 + tl[2]];
-        const R alpha = (P.threshold - ov) / (tv - ov);  // :1516-1517
-        R vc[3];
-#pragma unroll
-        for (int d = 0; d < 3; ++d) {
-            // coordinates in the marching-cubes grid of the lowest-index subdomain that generates this
-            // vertex ("first patch wins" with patches in ascending flat subdomain index, :1707-1716):
-            // the subdomain of the adjacent cell O - delta, delta_d = 1 on the orthogonal axes where possible
-            int sd;
-            if (d == a)
-                sd = O[d] / n;
-            else
-                sd = (O[d] >= 1) ? (O[d] - 1) / n : 0;
-            const int loc = O[d] - sd * n;
-            const R sub_min = P.gmin[d] + (R)sd * P.sub_size;  // uniform_grid.rs:454-467 on the subdomain grid
-            const R oc = sub_min + (R)loc * P.cs;               // uniform_grid.rs:418-425 on the subdomain MC grid
-            const R tc = sub_min + (R)(loc + (d == a ? 1 : 0)) * P.cs;
-            vc[d] = oc * (R(1.0) - alpha) + tc * alpha;  // :1518-1519
-        }
-        vertices[3 * (size_t)vid] = vc[0];
-        vertices[3 * (size_t)vid + 1] = vc[1];
-        vertices[3 * (size_t)vid + 2] = vc[2];
-        vkeys[vid] = (((unsigned long long)O[0] * (unsigned long long)P.np[1] + (unsigned long long)O[1]) * (unsigned long long)P.np[2] +
-                      (unsigned long long)O[2]) * 3ull + (unsigned long long)a;
-    }
+    for (int half = 0; half < 2; ++half) {
+        const int pt = 256 * half + tid, slab = 4 * half + wave;
+        const McLocal L = mc_classify(tile, P, bx, by, bz, pt);
 
-    // ---- triangles ----
-    // Only one cell in eight of a surface block has triangles: a loop "for my cell's triangles" keeps a few lanes busy for five
-    // trips and scatters 12-byte stores.  Instead every lane files a record (cell, case, triangle number) per triangle of its cell
-    // at the triangle's rank within the wave, and the wave then emits records 64 at a time: lane k builds the k-th triangle, so
-    // the stores of a trip form one contiguous run.
-    const uint32_t incl = ss_wave_inclusive_scan((uint32_t)L.ntri);  // (DPP: no LDS round trips)
-    if (lane == 63) s_twave[wave] = incl;
-    const uint32_t excl = incl - (uint32_t)L.ntri;
-    for (int i = 0; i < L.ntri; ++i) s_rec[wave][excl + (uint32_t)i] = (uint32_t)tid | ((uint32_t)i << 9) | ((uint32_t)L.case_index << 12);
-    __syncthreads();
-    uint32_t toff = tb0;
-    for (int w = 0; w < wave; ++w) toff += s_twave[w];
-    const uint32_t n_wave = s_twave[wave];
-    for (uint32_t k = (uint32_t)lane; k < n_wave; k += 64u) {
-        const uint32_t rec = s_rec[wave][k];
-        const int cell = (int)(rec & 511u), i = (int)((rec >> 9) & 7u), cs = (int)(rec >> 12);
-        const int cx = cell >> 6, cy = (cell >> 3) & 7, cz = cell & 7;
-        uint32_t tri[3];
+        // ---- vertices on the three edges owned by this thread's point (dense_subdomains.rs:1498-1539) ----
+        const int lx = pt >> 6, ly = (pt >> 3) & 7, lz = pt & 7;
+        const int O[3] = {L.gx, L.gy, L.gz};
 #pragma unroll
-        for (int v = 0; v < 3; ++v) {
-            const int e = s_lut[cs * 16 + 3 * i + v];
-            const uint32_t code = (uint32_t)(SS_MC_EDGE_CODES >> (5 * e)) & 31u;  // origin corner offsets and axis of local edge e
-            const int a = (int)(code & 3u);
-            const int ox = cx + (int)((code >> 4) & 1u), oy = cy + (int)((code >> 3) & 1u), oz = cz + (int)((code >> 2) & 1u);
-            const int nb = ((ox >> 3) << 2) | ((oy >> 3) << 1) | (oz >> 3);
-            const int p = (((ox & 7) * 8) + (oy & 7)) * 8 + (oz & 7);
-            const int w = p >> 6, bit = p & 63;
-            const unsigned long long bl = (bit == 0) ? 0ull : (~0ull >> (64 - bit));
-            tri[v] = s_vbase[nb] + s_pref[nb][a * 8 + w] + (uint32_t)__popcll(s_mask[nb][a * 8 + w] & bl);
+        for (int a = 0; a < 3; ++a) {
+            if (!L.cross[a]) continue;
+            const uint32_t vid = s_vbase[0] + s_pref[0][a * 8 + slab] + (uint32_t)__popcll(s_mask[0][a * 8 + slab] & below);
+            const int tl[3] = {lx + (a == 0), ly + (a == 1), lz + (a == 2)};
+            const R ov = tile.g[(lx * 9 + ly) * 9 + lz];
+            const R tv = tile.g[(tl[0] * 9 + tl[1]) * 9 + tl[2]];
+            const R alpha = (P.threshold - ov) / (tv - ov);  // :1516-1517
+            R vc[3];
+#pragma unroll
+            for (int d = 0; d < 3; ++d) {
+                // coordinates in the marching-cubes grid of the lowest-index subdomain that generates this
+                // vertex ("first patch wins" with patches in ascending flat subdomain index, :1707-1716):
+                // the subdomain of the adjacent cell O - delta, delta_d = 1 on the orthogonal axes where possible
+                int sd;
+                if (d == a)
+                    sd = O[d] / n;
+                else
+                    sd = (O[d] >= 1) ? (O[d] - 1) / n : 0;
+                const int loc = O[d] - sd * n;
+                const R sub_min = P.gmin[d] + (R)sd * P.sub_size;  // uniform_grid.rs:454-467 on the subdomain grid
+                const R oc = sub_min + (R)loc * P.cs;               // uniform_grid.rs:418-425 on the subdomain MC grid
+                const R tc = sub_min + (R)(loc + (d == a ? 1 : 0)) * P.cs;
+                vc[d] = oc * (R(1.0) - alpha) + tc * alpha;  // :1518-1519
+            }
+            vertices[3 * (size_t)vid] = vc[0];
+            vertices[3 * (size_t)vid + 1] = vc[1];
+            vertices[3 * (size_t)vid + 2] = vc[2];
+            vkeys[vid] = (((unsigned long long)O[0] * (unsigned long long)P.np[1] + (unsigned long long)O[1]) * (unsigned long long)P.np[2] +
+                          (unsigned long long)O[2]) * 3ull + (unsigned long long)a;
         }
-        const size_t o = 3 * (size_t)(toff + k);
-        triangles[o] = tri[0];
-        triangles[o + 1] = tri[1];
-        triangles[o + 2] = tri[2];
+
+        // ---- triangle records of this slab ----
+        // Only one cell in eight of a surface block has triangles: a loop "for my cell's triangles" keeps a few lanes busy for five
+        // trips and scatters 12-byte stores.  Instead every lane files a record (cell, case, triangle number) per triangle of its
+        // cell at the triangle's rank within the slab, and the wave then emits records 64 at a time: lane k builds the k-th
+        // triangle, so the stores of a trip form one contiguous run.
+        const uint32_t incl = ss_wave_inclusive_scan((uint32_t)L.ntri);  // (DPP: no LDS round trips)
+        if (lane == 63) s_tslab[slab] = incl;
+        const uint32_t excl = incl - (uint32_t)L.ntri;
+        for (int i = 0; i < L.ntri; ++i) s_rec[slab][excl + (uint32_t)i] = (uint32_t)pt | ((uint32_t)i << 9) | ((uint32_t)L.case_index << 12);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        const int slab = 4 * half + wave;
+        uint32_t toff = tb0;
+        for (int w = 0; w < slab; ++w) toff += s_tslab[w];
+        const uint32_t n_slab = s_tslab[slab];
+        for (uint32_t k = (uint32_t)lane; k < n_slab; k += 64u) {
+            const uint32_t rec = s_rec[slab][k];
+            const int cell = (int)(rec & 511u), i = (int)((rec >> 9) & 7u), cs = (int)(rec >> 12);
+            const int cx = cell >> 6, cy = (cell >> 3) & 7, cz = cell & 7;
+            uint32_t tri[3];
+#pragma unroll
+            for (int v = 0; v < 3; ++v) {
+                const int e = s_lut[cs * 16 + 3 * i + v];
+                const uint32_t code = (uint32_t)(SS_MC_EDGE_CODES >> (5 * e)) & 31u;  // origin corner offsets and axis of local edge e
+                const int a = (int)(code & 3u);
+                const int ox = cx + (int)((code >> 4) & 1u), oy = cy + (int)((code >> 3) & 1u), oz = cz + (int)((code >> 2) & 1u);
+                const int nb = ((ox >> 3) << 2) | ((oy >> 3) << 1) | (oz >> 3);
+                const int p = (((ox & 7) * 8) + (oy & 7)) * 8 + (oz & 7);
+                const int w = p >> 6, bit = p & 63;
+                const unsigned long long bl = (bit == 0) ? 0ull : (~0ull >> (64 - bit));
+                tri[v] = s_vbase[nb] + s_pref[nb][a * 8 + w] + (uint32_t)__popcll(s_mask[nb][a * 8 + w] & bl);
+            }
+            const size_t o = 3 * (size_t)(toff + k);
+            triangles[o] = tri[0];
+            triangles[o + 1] = tri[1];
+            triangles[o + 2] = tri[2];
+        }
     }
 }
 
@@ -2567,14 +2610,14 @@ template <class R>
 void ss_launch_mc_count(const SSDevT<R>& P, const R* G, const uint32_t* mc_nb, const uint32_t* mc_xyz, uint32_t n_mc,
                         unsigned long long* masks, uint32_t* vcount, uint32_t* tcount, hipStream_t st) {
     if (!n_mc) return;
-    hipLaunchKernelGGL(k_mc_count<R>, dim3(2u * n_mc), dim3(256), 0, st, P, G, mc_nb, mc_xyz, n_mc, masks, vcount, tcount);
+    hipLaunchKernelGGL(k_mc_count<R>, dim3(n_mc), dim3(256), 0, st, P, G, mc_nb, mc_xyz, n_mc, masks, vcount, tcount);
 }
 template <class R>
 void ss_launch_mc_emit(const SSDevT<R>& P, const R* G, const uint32_t* mc_nb, const uint32_t* mc_xyz, const uint32_t* mc_slot,
                        uint32_t n_mc, const unsigned long long* masks, const uint32_t* vbase, const uint32_t* tbase, R* vertices,
                        unsigned long long* vkeys, uint32_t* triangles, hipStream_t st) {
     if (!n_mc) return;
-    hipLaunchKernelGGL(k_mc_emit<R>, dim3(n_mc), dim3(512), 0, st, P, G, mc_nb, mc_xyz, mc_slot, n_mc, masks, vbase, tbase, vertices, vkeys,
+    hipLaunchKernelGGL(k_mc_emit<R>, dim3(n_mc), dim3(256), 0, st, P, G, mc_nb, mc_xyz, mc_slot, n_mc, masks, vbase, tbase, vertices, vkeys,
                        triangles);
 }
 
