@@ -1800,12 +1800,10 @@ __device__ __forceinline__ void splat_sort_tile(SplatAccWaveShared<R>& sh, const
         ss_wave_lds_sync();
     }
     uint32_t my[E], rank[E];
-    ss_real4<R> pv[E];
 #pragma unroll
     for (int e = 0; e < E; ++e) {
         const int i = lane + 64 * e;
         my[e] = (i < n_tile) ? sh.idx[i] : 0u;
-        pv[e] = sh.pay[min(i, SSWaveChunk<R>::value - 1)];
         rank[e] = 0u;
     }
     for (int k = 0; k < n_tile; ++k) {
@@ -1813,11 +1811,32 @@ __device__ __forceinline__ void splat_sort_tile(SplatAccWaveShared<R>& sh, const
 #pragma unroll
         for (int e = 0; e < E; ++e) rank[e] += (v < my[e]) ? 1u : 0u;
     }
-    ss_wave_lds_sync();  // every lane holds its payload
+    // The payload moves to its rank through the list buffer, the masks and the index array behind it (contiguous, and free from
+    // here on), one entry at a time: held in registers across the ranking loop or all at once, its twelve registers were spilled
+    // to scratch -- three memory round trips per block in the middle of an LDS-only phase.  Tiles too large for that buffer
+    // (over 170 entries in f32) take the register path.
+    constexpr int TMP_CAP = (int)((sizeof(SplatAccWaveShared<R>) - offsetof(SplatAccWaveShared<R>, wl)) / sizeof(ss_real4<R>));
+    if (n_tile <= TMP_CAP) {
+        ss_real4<R>* tmp = reinterpret_cast<ss_real4<R>*>(sh.wl);
+        ss_wave_lds_sync();  // every lane has its ranks: the index array may be overwritten
 #pragma unroll
-    for (int e = 0; e < E; ++e)
-        if (lane + 64 * e < n_tile) sh.pay[rank[e]] = pv[e];
-    ss_wave_lds_sync();
+        for (int e = 0; e < E; ++e)
+            if (lane + 64 * e < n_tile) tmp[rank[e]] = sh.pay[lane + 64 * e];
+        ss_wave_lds_sync();
+#pragma unroll
+        for (int e = 0; e < E; ++e)
+            if (lane + 64 * e < n_tile) sh.pay[lane + 64 * e] = tmp[lane + 64 * e];
+        ss_wave_lds_sync();
+    } else {
+        ss_real4<R> pv[E];
+#pragma unroll
+        for (int e = 0; e < E; ++e) pv[e] = sh.pay[min(lane + 64 * e, SSWaveChunk<R>::value - 1)];
+        ss_wave_lds_sync();  // every lane holds its payload
+#pragma unroll
+        for (int e = 0; e < E; ++e)
+            if (lane + 64 * e < n_tile) sh.pay[rank[e]] = pv[e];
+        ss_wave_lds_sync();
+    }
 }
 
 // STAGED: the tile (payload and particle indices) is in sh.pay / sh.idx already (k_splat_fused); otherwise it is fetched from the arena
