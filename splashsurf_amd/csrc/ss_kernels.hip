@@ -1399,10 +1399,11 @@ __device__ __forceinline__ R ss_splat_pair(const SSDevT<R>& P, R rh, const ss_re
 // the classification pass of splat_accumulate_block (only the entries close to the sub-block).
 // `premask` (optional): per tile entry, bit s set <=> the entry passes the filter of sub-block s (splat_near_masks); then the
 // box test is not repeated here.  `n_visited` (optional) is advanced by the number of entries that passed the filter.
+// `order` (optional): the tile is visited as pay[order[0]], pay[order[1]], ... instead of front to back.
 template <class R, int ARITH>
 __device__ __forceinline__ R splat_accumulate_wave(const SSDevT<R>& P, const ss_real4<R>* pay, ss_real4<R>* wl, int n_tile, int lane, R px, R py, R pz,
                                                    const R slo[3], const R shi[3], R r2_filter, R acc, const uint8_t* premask = nullptr, int premask_bit = 0,
-                                                   int* n_visited = nullptr) {
+                                                   int* n_visited = nullptr, const uint8_t* order = nullptr) {
     const R rh = R(1.0) / P.h;
     // lower-bound pass: positions in units of h relative to the sub-block's centre (differences of nearby numbers are exact, the
     // scaling costs a relative 2^-24: nothing against the 1e-4 margin of thr_inside) -- saves the multiplication by 1/h per pair
@@ -1425,7 +1426,7 @@ __device__ __forceinline__ R splat_accumulate_wave(const SSDevT<R>& P, const ss_
                 pv = pay[c];
             }
         } else if (c < n_tile) {
-            pv = pay[c];
+            pv = pay[order ? (int)order[c] : c];  // (order: the tile's entries in ascending particle index, splat_sort_tile)
             const R ex = ss_max(ss_max(slo[0] - pv.x, pv.x - shi[0]) - P.coord_slack, R(0.0));
             const R ey = ss_max(ss_max(slo[1] - pv.y, pv.y - shi[1]) - P.coord_slack, R(0.0));
             const R ez = ss_max(ss_max(slo[2] - pv.z, pv.z - shi[2]) - P.coord_slack, R(0.0));
@@ -1783,16 +1784,20 @@ struct SplatAccWaveShared {
     // list of one sub-block: one 64-entry batch of full records (exact sums), or -- f32 lower-bound pass -- the lists of near
     // entries of ALL EIGHT sub-blocks as 8-byte records (SS_BOUND_POOL entries + 8 the read-ahead may touch)
     ss_real4<R> wl[(sizeof(R) == 4) ? (SS_BOUND_POOL + 8) / 2 : SS_WAVE_LIST];
-    uint8_t near[SSWaveChunk<R>::value];  // per tile entry: the sub-blocks whose classification pass visits it
+    uint8_t near[SSWaveChunk<R>::value];  // per tile entry: the sub-blocks whose classification pass visits it; after splat_sort_tile: the order
     uint32_t idx[SSWaveChunk<R>::value];  // particle indices of the tile entries (splat_sort_tile)
 };
 
-// Orders the tile in LDS by original particle index (unique keys): rank sort, every lane ranks its entries in one pass over
-// the keys (one broadcast read serves them all), then the payload moves to its rank.  The exact sum needs this order
-// (dense_subdomains.rs:817-841 visits the particles in index order); the lower-bound pass does not.
+// Orders the tile by original particle index (unique keys) WITHOUT moving it: rank sort, every lane ranks its entries in one pass
+// over the keys (one broadcast read serves them all), then order[rank] = position goes into the mask array (free once the
+// classification is over), and the exact sums read the tile through it (splat_accumulate_wave).  The exact sum needs this order
+// (dense_subdomains.rs:817-841 visits the particles in index order); the lower-bound pass does not.  (Moving the payload to its
+// rank instead kept twelve registers alive across the ranking loop -- spilled to scratch -- or needed a second copy of the tile
+// in LDS, which costs a wave of occupancy.)
 template <class R>
 __device__ __forceinline__ void splat_sort_tile(SplatAccWaveShared<R>& sh, const uint32_t* __restrict__ tile_idx, int n_tile, int lane) {
     constexpr int E = SSWaveChunk<R>::value / 64;
+    static_assert(SSWaveChunk<R>::value <= 256, "positions are stored as bytes");
     if (tile_idx) {  // (the fused kernel has the indices in LDS already)
 #pragma unroll
         for (int e = 0; e < E; ++e)
@@ -1811,32 +1816,10 @@ __device__ __forceinline__ void splat_sort_tile(SplatAccWaveShared<R>& sh, const
 #pragma unroll
         for (int e = 0; e < E; ++e) rank[e] += (v < my[e]) ? 1u : 0u;
     }
-    // The payload moves to its rank through the list buffer, the masks and the index array behind it (contiguous, and free from
-    // here on), one entry at a time: held in registers across the ranking loop or all at once, its twelve registers were spilled
-    // to scratch -- three memory round trips per block in the middle of an LDS-only phase.  Tiles too large for that buffer
-    // (over 170 entries in f32) take the register path.
-    constexpr int TMP_CAP = (int)((sizeof(SplatAccWaveShared<R>) - offsetof(SplatAccWaveShared<R>, wl)) / sizeof(ss_real4<R>));
-    if (n_tile <= TMP_CAP) {
-        ss_real4<R>* tmp = reinterpret_cast<ss_real4<R>*>(sh.wl);
-        ss_wave_lds_sync();  // every lane has its ranks: the index array may be overwritten
 #pragma unroll
-        for (int e = 0; e < E; ++e)
-            if (lane + 64 * e < n_tile) tmp[rank[e]] = sh.pay[lane + 64 * e];
-        ss_wave_lds_sync();
-#pragma unroll
-        for (int e = 0; e < E; ++e)
-            if (lane + 64 * e < n_tile) sh.pay[lane + 64 * e] = tmp[lane + 64 * e];
-        ss_wave_lds_sync();
-    } else {
-        ss_real4<R> pv[E];
-#pragma unroll
-        for (int e = 0; e < E; ++e) pv[e] = sh.pay[min(lane + 64 * e, SSWaveChunk<R>::value - 1)];
-        ss_wave_lds_sync();  // every lane holds its payload
-#pragma unroll
-        for (int e = 0; e < E; ++e)
-            if (lane + 64 * e < n_tile) sh.pay[rank[e]] = pv[e];
-        ss_wave_lds_sync();
-    }
+    for (int e = 0; e < E; ++e)
+        if (lane + 64 * e < n_tile) sh.near[rank[e]] = (uint8_t)(lane + 64 * e);
+    ss_wave_lds_sync();
 }
 
 // STAGED: the tile (payload and particle indices) is in sh.pay / sh.idx already (k_splat_fused); otherwise it is fetched from the arena
@@ -2018,7 +2001,7 @@ __device__ __forceinline__ void splat_accumulate_block_wave(SplatAccWaveShared<R
             const R slo[3] = {sx ? lo[0][1] : lo[0][0], sy ? lo[1][1] : lo[1][0], sz ? lo[2][1] : lo[2][0]};
             const R shi[3] = {sx ? hi[0][1] : hi[0][0], sy ? hi[1][1] : hi[1][0], sz ? hi[2][1] : hi[2][0]};
             // levelset_grid.fill(0), dense_subdomains.rs:1390, then the sum in index order
-            const R acc = splat_accumulate_wave<R, ARITH>(P, sh.pay, sh.wl, n_tile, lane, px, py, pz, slo, shi, P.R2, R(0.0));
+            const R acc = splat_accumulate_wave<R, ARITH>(P, sh.pay, sh.wl, n_tile, lane, px, py, pz, slo, shi, P.R2, R(0.0), nullptr, 0, nullptr, sh.near);
             const R val = point_valid ? acc : R(0.0);
             gblock[64 * sb] = val;
             mn = ss_min(mn, val);
@@ -2069,9 +2052,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(sizeof(R) ==
     const uint32_t n = list ? *n_list_dev : n_active;
     const uint32_t n_slots = ss_xcd_chunked_grid_dev(n);
     const unsigned long long below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-    for (uint32_t w = blockIdx.x; w < n_slots; w += gridDim.x) {
+    auto one_slot = [&](uint32_t w) {
         const uint32_t it = ss_xcd_chunked_group(w);
-        if (it >= n) continue;
+        if (it >= n) return;
         const uint32_t logical = __builtin_amdgcn_readfirstlane(list ? list[it] : it);
         const int b3[3] = {(int)active_xyz[3 * (size_t)logical], (int)active_xyz[3 * (size_t)logical + 1], (int)active_xyz[3 * (size_t)logical + 2]};
         R plo[3], phi[3];
@@ -2095,13 +2078,20 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(sizeof(R) ==
         if (!list && lane == 0) counts[logical] = count;  // tile entries (statistics; > CH: the arena path recounts)
         if (count > (uint32_t)CH) {
             if (lane == 0) big[1u + atomicAdd(&big[0], 1u)] = logical;
-            continue;
+            return;
         }
         ss_wave_lds_sync();
         SS_PROF_MARK(0);  // candidate scan
         splat_accumulate_block_wave<R, ARITH, EARLY, true>(sh, P, logical, (int)count, nullptr, nullptr, active_xyz, G, blk_minmax, trunc, facebits,
                                                            redo_mask ? __builtin_amdgcn_readfirstlane(redo_mask[logical]) : 0xFFu);
         SS_PROF_MARK(7);  // whole sub-block walk incl. epilogue (phases 1-6 are inside)
+    };
+    // first pass: the grid has exactly one workgroup per slot -- written as a loop, the compiler hoists lane constants out of it
+    // and spills them to scratch (five stores per block: 1.8 GB per step on S10M-tank)
+    if constexpr (EARLY) {
+        if (blockIdx.x < n_slots) one_slot(blockIdx.x);
+    } else {
+        for (uint32_t w = blockIdx.x; w < n_slots; w += gridDim.x) one_slot(w);
     }
 }
 
