@@ -474,14 +474,7 @@ __global__ __launch_bounds__(256) void k_box_masks(const R* __restrict__ xyz, ui
     mask[i] = m;
 }
 
-// "element i goes to rank q" as functors over the element index (entry n of a scan reads 0, so that the scan ends with the count):
-// the per-destination scans and pack kernels read them straight from the masks -- no flag arrays, no copies
-struct MaskFlag {
-    const unsigned long long* mask;
-    uint64_t n;
-    int q;
-    __host__ __device__ uint32_t operator()(uint64_t i) const { return i < n ? (uint32_t)((mask[i] >> q) & 1ull) : 0u; }
-};
+// "vertex v is this rank's to number" as a functor over the vertex index (entry n of a scan reads 0, so that the scan ends with the count)
 struct VertexFlag {  // owner[v] == me && rank q also holds the vertex (q < 0: any)
     const uint32_t* owner;
     const unsigned long long* holder;
@@ -494,18 +487,72 @@ struct VertexFlag {  // owner[v] == me && rank q also holds the vertex (q < 0: a
     }
 };
 
-// rows[off[i]] = (id0 + i or ids[i], payload[i]) for flagged i; payload_words 32-bit words per element
-template <class Flag>
-__global__ __launch_bounds__(256) void k_pack_rows(uint64_t n, Flag flag, const uint32_t* __restrict__ offs, uint64_t id0,
-                                                   const unsigned long long* __restrict__ ids, const uint32_t* __restrict__ payload, int payload_words,
-                                                   uint32_t* __restrict__ rows) {
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n || !flag(i)) return;
+// "the ranks element i goes to" as a 64-bit mask: what the exchanges are packed from in ONE pass over the elements for all
+// destinations (a scan and a pack kernel per destination cost 0.25 ms per exchange and rank on S40M-tank at 8 ranks)
+struct MaskDests {
+    const unsigned long long* mask;
+    __device__ unsigned long long operator()(uint64_t i) const { return mask[i]; }
+};
+struct VertexDests {  // the other holders of a vertex this rank owns
+    const uint32_t* owner;
+    const unsigned long long* holder;
+    uint32_t me;
+    __device__ unsigned long long operator()(uint64_t v) const { return owner[v] == me ? holder[v] : 0ull; }
+};
+
+// counts[slot * n_wg + workgroup] = elements of this workgroup's 256 that go to the slot-th destination of `active`
+template <class Dests>
+__global__ __launch_bounds__(256) void k_dest_counts(uint64_t n, Dests dests, unsigned long long active, uint32_t n_wg, uint32_t* __restrict__ counts) {
+    __shared__ uint32_t s_cnt[64];
+    const int tid = threadIdx.x, lane = tid & 63;
+    if (tid < 64) s_cnt[tid] = 0u;
+    __syncthreads();
+    const uint64_t i = (uint64_t)blockIdx.x * 256u + (uint64_t)tid;
+    const unsigned long long m = (i < n) ? (dests(i) & active) : 0ull;
+    int slot = 0;
+    for (unsigned long long a = active; a; a &= a - 1ull, ++slot) {
+        const int q = __ffsll((long long)a) - 1;
+        const uint32_t cq = (uint32_t)__popcll(__ballot((m >> q) & 1ull));
+        if (lane == 0 && cq) atomicAdd(&s_cnt[slot], cq);
+    }
+    __syncthreads();
+    if (tid < slot) counts[(size_t)tid * n_wg + blockIdx.x] = s_cnt[tid];
+}
+
+// rows[offs[slot * n_wg + workgroup] + rank inside the workgroup] = (id0 + i or ids[i], payload[i]): the rows of a destination are
+// consecutive and in ascending element order, the destinations follow each other in the order of their ranks
+template <class Dests>
+__global__ __launch_bounds__(256) void k_pack_all(uint64_t n, Dests dests, unsigned long long active, uint32_t n_wg, const uint32_t* __restrict__ offs, uint64_t id0,
+                                                  const unsigned long long* __restrict__ ids, const uint32_t* __restrict__ payload, int payload_words,
+                                                  uint32_t* __restrict__ rows) {
+    __shared__ uint32_t s_wave[64][4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint64_t i = (uint64_t)blockIdx.x * 256u + (uint64_t)tid;
+    const unsigned long long m = (i < n) ? (dests(i) & active) : 0ull;
+    int slot = 0;
+    for (unsigned long long a = active; a; a &= a - 1ull, ++slot) {
+        const int q = __ffsll((long long)a) - 1;
+        const uint32_t cq = (uint32_t)__popcll(__ballot((m >> q) & 1ull));
+        if (lane == 0) s_wave[slot][wave] = cq;
+    }
+    __syncthreads();
+    if (!m) return;
+    const unsigned long long below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
     const unsigned long long id = ids ? ids[i] : (unsigned long long)(id0 + i);
-    uint32_t* dst = rows + (size_t)offs[i] * (size_t)(2 + payload_words);
-    dst[0] = (uint32_t)id;
-    dst[1] = (uint32_t)(id >> 32);
-    for (int w = 0; w < payload_words; ++w) dst[2 + w] = payload[(size_t)i * payload_words + w];
+    slot = 0;
+    for (unsigned long long a = active; a; a &= a - 1ull, ++slot) {
+        const int q = __ffsll((long long)a) - 1;
+        const bool bit = (m >> q) & 1ull;
+        // (the lanes that left above hold nothing for anybody: the ballot of the remaining ones is the ballot of all)
+        const unsigned long long bal = __ballot(bit);
+        if (!bit) continue;
+        uint32_t row = offs[(size_t)slot * n_wg + blockIdx.x] + (uint32_t)__popcll(bal & below);
+        for (int w = 0; w < wave; ++w) row += s_wave[slot][w];
+        uint32_t* dst = rows + (size_t)row * (size_t)(2 + payload_words);
+        dst[0] = (uint32_t)id;
+        dst[1] = (uint32_t)(id >> 32);
+        for (int w = 0; w < payload_words; ++w) dst[2 + w] = payload[(size_t)i * payload_words + w];
+    }
 }
 
 __global__ __launch_bounds__(256) void k_unpack_rows(uint64_t n, const uint32_t* __restrict__ rows, int payload_words, unsigned long long* __restrict__ ids,
@@ -651,46 +698,55 @@ template <> struct DistTypes<double> {
 
 double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
-// Packs, for every destination rank, the flagged elements into consecutive rows of c->sendbuf, exchanges them and leaves the
-// received rows (ordered by source rank) in c->recvbuf.  flag_for(q, &flag) says whether this rank may have anything for rank q and
-// hands out the functor "element i goes to q"; per destination there is one scan over the functor and one pack kernel.
-template <class Flag, class FlagFor>
-ss_status pack_and_exchange(ss_comm* c, uint64_t n, uint64_t id0, const unsigned long long* ids, const uint32_t* payload, int payload_words, FlagFor flag_for,
-                            uint64_t* n_recv_rows, uint64_t* bytes_sent) {
+// Packs, for every destination rank in `active`, the elements whose destination mask names it into consecutive rows of c->sendbuf
+// (destinations in rank order, rows in ascending element order), exchanges them and leaves the received rows (ordered by source
+// rank) in c->recvbuf.  One counting pass, one scan over (destination, workgroup) and one packing pass serve all destinations.
+template <class Dests>
+ss_status pack_and_exchange(ss_comm* c, uint64_t n, uint64_t id0, const unsigned long long* ids, const uint32_t* payload, int payload_words, Dests dests,
+                            unsigned long long active, uint64_t* n_recv_rows, uint64_t* bytes_sent) {
     ss_context* ctx = c->ctx;
     hipStream_t st = ctx->stream;
     const int world = c->world, me = c->rank;
     const size_t row_bytes = (size_t)(2 + payload_words) * 4;
+    if (!n) active = 0ull;
     std::vector<uint32_t> cnt((size_t)world, 0u);
-    std::vector<int> slot_of((size_t)world, -1);
-    std::vector<Flag> flags((size_t)world);
-    int n_active = 0;
-    for (int q = 0; q < world; ++q)
-        if (flag_for(q, &flags[q])) slot_of[q] = n_active++;
-    TurnGuard turn(c, "pack");  // scans and packing are this rank's own work; released before the ranks meet
-    SS_HIP(ctx, c->offs.reserve((size_t)std::max(n_active, 1) * (n + 1) * 4 + 64));  // (one offset array per ACTIVE destination)
-    for (int q = 0; q < world; ++q) {
-        if (slot_of[q] < 0) continue;
-        uint32_t* offs_q = c->offs.as<uint32_t>() + (size_t)slot_of[q] * (n + 1);
-        auto it = rocprim::make_transform_iterator(rocprim::make_counting_iterator<uint64_t>(0), flags[q]);
+    const int n_active = __builtin_popcountll(active);
+    const uint64_t n_wg64 = (n + 255) / 256;
+    if (n_wg64 * (uint64_t)std::max(n_active, 1) >= (1ull << 31)) return fail(ctx, SS_ERR_UNSUPPORTED, "exchange: too many (destination, workgroup) pairs for this build");
+    const uint32_t n_wg = (uint32_t)n_wg64;
+    const size_t n_pairs = (size_t)n_active * n_wg;
+    TurnGuard turn(c, "pack");  // counting, scan and packing are this rank's own work; released before the ranks meet
+    std::vector<uint32_t> bound((size_t)n_active + 1, 0u);
+    uint32_t* counts = nullptr;
+    uint32_t* offs = nullptr;
+    if (n_active) {
+        SS_HIP(ctx, c->offs.reserve((n_pairs + 1) * 8 + 64));
+        counts = c->offs.as<uint32_t>();
+        offs = counts + n_pairs + 1;
+        SS_HIP(ctx, hipMemsetAsync(counts + n_pairs, 0, 4, st));  // the scan ends with the total
+        hipLaunchKernelGGL(k_dest_counts<Dests>, dim3(n_wg), dim3(256), 0, st, n, dests, active, n_wg, counts);
         size_t bytes = 0;
-        SS_HIP(ctx, rocprim::exclusive_scan(nullptr, bytes, it, offs_q, 0u, (size_t)n + 1, rocprim::plus<uint32_t>(), st));
+        SS_HIP(ctx, rocprim::exclusive_scan(nullptr, bytes, counts, offs, 0u, n_pairs + 1, rocprim::plus<uint32_t>(), st));
         SS_HIP(ctx, c->sort_tmp.reserve(bytes + 64));
-        SS_HIP(ctx, rocprim::exclusive_scan(c->sort_tmp.p, bytes, it, offs_q, 0u, (size_t)n + 1, rocprim::plus<uint32_t>(), st));
-        SS_HIP(ctx, hipMemcpyAsync(&cnt[q], offs_q + n, 4, hipMemcpyDeviceToHost, st));
+        SS_HIP(ctx, rocprim::exclusive_scan(c->sort_tmp.p, bytes, counts, offs, 0u, n_pairs + 1, rocprim::plus<uint32_t>(), st));
+        for (int sl = 0; sl <= n_active; ++sl) SS_HIP(ctx, hipMemcpyAsync(&bound[(size_t)sl], offs + (size_t)sl * n_wg, 4, hipMemcpyDeviceToHost, st));
+        SS_HIP(ctx, hipStreamSynchronize(st));
     }
-    SS_HIP(ctx, hipStreamSynchronize(st));
     std::vector<uint64_t> send_off((size_t)world + 1, 0), send_rows((size_t)world, 0);
-    for (int q = 0; q < world; ++q) {
-        send_rows[q] = cnt[q];
-        send_off[q + 1] = send_off[q] + (uint64_t)cnt[q] * row_bytes;
+    {
+        int sl = 0;
+        for (int q = 0; q < world; ++q) {
+            if ((active >> q) & 1ull) {
+                cnt[q] = bound[(size_t)sl + 1] - bound[(size_t)sl];
+                ++sl;
+            }
+            send_rows[q] = cnt[q];
+            send_off[q + 1] = send_off[q] + (uint64_t)cnt[q] * row_bytes;
+        }
     }
     SS_HIP(ctx, c->sendbuf.reserve(send_off[world] + 64));
-    for (int q = 0; q < world; ++q) {
-        if (slot_of[q] < 0 || !cnt[q]) continue;
-        hipLaunchKernelGGL(k_pack_rows<Flag>, grid_for(n), dim3(256), 0, st, n, flags[q], c->offs.as<uint32_t>() + (size_t)slot_of[q] * (n + 1), id0, ids, payload, payload_words,
-                           reinterpret_cast<uint32_t*>(c->sendbuf.as<uint8_t>() + send_off[q]));
-    }
+    if (n_active && send_off[world])
+        hipLaunchKernelGGL(k_pack_all<Dests>, dim3(n_wg), dim3(256), 0, st, n, dests, active, n_wg, offs, id0, ids, payload, payload_words, c->sendbuf.as<uint32_t>());
     turn.release();
     // matrix[r][q] = rows rank r sends to rank q
     std::vector<uint64_t> matrix((size_t)world * world, 0);
@@ -855,13 +911,8 @@ ss_status dist_reconstruct(ss_comm* c, const R* xyz_in, uint64_t n_local, const 
         hipLaunchKernelGGL(k_box_masks<R>, grid_for(n_local), dim3(256), 0, st, d_xyz, n_local, c->boxes_dev.as<DistBoxes>(), pos_active, (const uint32_t*)nullptr,
                            c->mask.as<unsigned long long>());
     }
-    s = pack_and_exchange<MaskFlag>(c, n_local, id0, nullptr, reinterpret_cast<const uint32_t*>(d_xyz), pos_words,
-                                    [&](int q, MaskFlag* f) {
-                                        if (!((pos_active >> q) & 1ull)) return false;
-                                        *f = MaskFlag{c->mask.as<unsigned long long>(), n_local, q};
-                                        return true;
-                                    },
-                                    &n_held, &c->info.bytes_sent_positions);
+    s = pack_and_exchange(c, n_local, id0, nullptr, reinterpret_cast<const uint32_t*>(d_xyz), pos_words, MaskDests{c->mask.as<unsigned long long>()}, pos_active, &n_held,
+                          &c->info.bytes_sent_positions);
     if (s != SS_OK) return s;
     if (n_held >= (1ull << 31)) return fail(ctx, SS_ERR_UNSUPPORTED, "more than 2^31-1 particles held by one rank");
     // Rows arrive ascending from every source rank and the ranks' id ranges ascend, so the concatenation by source rank IS the
@@ -925,13 +976,8 @@ ss_status dist_reconstruct(ss_comm* c, const R* xyz_in, uint64_t n_local, const 
         hipLaunchKernelGGL(k_box_masks<R>, grid_for(n_held), dim3(256), 0, st, c->L.as<R>(), n_held, c->boxes_dev.as<DistBoxes>(), rho_active, c->owned.as<uint32_t>(),
                            c->mask.as<unsigned long long>());
     }
-    s = pack_and_exchange<MaskFlag>(c, n_held, 0, c->gids.as<unsigned long long>(), reinterpret_cast<const uint32_t*>(res->rho.as<R>()), rho_words,
-                                    [&](int q, MaskFlag* f) {
-                                        if (!((rho_active >> q) & 1ull)) return false;
-                                        *f = MaskFlag{c->mask.as<unsigned long long>(), n_held, q};
-                                        return true;
-                                    },
-                                    &n_rho_rows, &c->info.bytes_sent_densities);
+    s = pack_and_exchange(c, n_held, 0, c->gids.as<unsigned long long>(), reinterpret_cast<const uint32_t*>(res->rho.as<R>()), rho_words,
+                          MaskDests{c->mask.as<unsigned long long>()}, rho_active, &n_rho_rows, &c->info.bytes_sent_densities);
     if (s != SS_OK) return s;
     TurnGuard phase2_turn(c, "scatter_phase2");  // scattering the received densities and phase 2
     SS_HIP(ctx, c->err.reserve(64));
@@ -1025,15 +1071,16 @@ ss_status dist_assemble(ss_comm* c, ss_result* res) {
     }
     // owners -> the other ranks holding the edge: (key, global id)
     uint64_t n_rows = 0;
-    s = pack_and_exchange<VertexFlag>(c, nv, 0, keys, reinterpret_cast<const uint32_t*>(c->gid_local.as<unsigned long long>()), 2,
-                                      [&](int q, VertexFlag* f) {
-                                          if (q == me || B.empty[q] || B.empty[me] || !nv) return false;
-                                          for (int d = 0; d < 3; ++d)  // closed point boxes that do not even touch share no edge
-                                              if (B.hi[me][d] < B.lo[q][d] || B.lo[me][d] > B.hi[q][d]) return false;
-                                          *f = VertexFlag{c->owner.as<uint32_t>(), c->holder.as<unsigned long long>(), nv, (uint32_t)me, q};
-                                          return true;
-                                      },
-                                      &n_rows, &c->info.bytes_sent_assembly);
+    unsigned long long gid_active = 0ull;
+    for (int q = 0; q < world && nv; ++q) {
+        if (q == me || B.empty[q] || B.empty[me]) continue;
+        bool touch = true;
+        for (int d = 0; d < 3; ++d)  // closed point boxes that do not even touch share no edge
+            if (B.hi[me][d] < B.lo[q][d] || B.lo[me][d] > B.hi[q][d]) touch = false;
+        if (touch) gid_active |= 1ull << q;
+    }
+    s = pack_and_exchange(c, nv, 0, keys, reinterpret_cast<const uint32_t*>(c->gid_local.as<unsigned long long>()), 2,
+                          VertexDests{c->owner.as<uint32_t>(), c->holder.as<unsigned long long>(), (uint32_t)me}, gid_active, &n_rows, &c->info.bytes_sent_assembly);
     if (s != SS_OK) return s;
     TurnGuard join_turn(c, "asm_join");
     SS_HIP(ctx, c->err.reserve(64));
