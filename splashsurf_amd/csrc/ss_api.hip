@@ -231,12 +231,14 @@ ss_status make_device_params(ss_context* ctx, const typename TypesOf<R>::params*
     P.reach = ss_sqrt(support_factor) * h * R(1.0001);
     P.R2 = ((h * h) * support_factor) * R(1.0001);
 #ifndef SS_TUNE_RNEAR
-#define SS_TUNE_RNEAR 0.58
+#define SS_TUNE_RNEAR 0.60
 #endif
     // near radius of the classification pass, measured on S10M-tank with the polynomial bound u^3 (c0 + c1 u^2) (splat kernel ms /
-    // certified sub-blocks; gpurun_out/r3b): 0.50 h 9.87 / 74 %, 0.52 h 8.69 / 80 %, 0.55 h 7.73 / 85 %, 0.58 h 7.40 / 87 %, 0.60 h
-    // 7.50 / 87 % -- an uncertified sub-block costs five times its classification, so the optimum sits where the curve flattens.
-    // (Round 2's bound v^2 min(2 v, 1) with its v_sqrt_f32: 8.17 ms / 86 % at 0.60 h on the same box.)
+    // certified sub-blocks): 0.50 h 9.87 / 74 %, 0.52 h 8.69 / 80 %, 0.55 h 7.73 / 85 %, 0.58 h 7.40 / 87 %, 0.60 h 7.50 / 87 % with
+    // per-sub-block lists of f32 records; with the pooled f16 records (splat_bound_record): 0.56 h 6.35 / 85.6 %, 0.58 h 6.33 / 86.6 %,
+    // 0.60 h 6.26 / 87.2 %, 0.62 h 6.59 / 87.5 %, 0.65 h 7.23 / 87.6 % (the lists outgrow the pool) -- an uncertified sub-block costs
+    // five times its classification, so the optimum sits where the curve flattens.
+    // (Round 2's bound v^2 min(2 v, 1) with its v_sqrt_f32: 8.17 ms / 86 % at 0.60 h.)
     P.R2near = (R(SS_TUNE_RNEAR) * h) * (R(SS_TUNE_RNEAR) * h);
     P.thr_inside = prm->iso_surface_threshold * R(1.0001);
     {   // splat_bound_record: list coordinates are f16, relative to the block's centre in units of h, at most emax in size

@@ -311,7 +311,7 @@ def test_splat_lower_bound_survives_the_f16_list_records():
     support ratio the sweep uses, i.e. that the packed pass still bounds the spline from below."""
     rng = np.random.default_rng(5)
     for ratio in (1.0 / 30.0, 0.125, 0.2, 0.45, 1.0):  # cube size / compact support radius
-        emax = 3.5 * ratio + 0.58 + 1.0e-3
+        emax = 3.5 * ratio + 0.60 + 1.0e-3
         eps = 2.0 ** (np.floor(np.log2(emax)) - 11)
         bound_one = np.float32(max(0.0, 1.0 - (3.6 * eps + 3.0 * eps * eps + 2.0e-6)))
         n = 400000
