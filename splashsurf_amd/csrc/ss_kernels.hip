@@ -1876,6 +1876,7 @@ __device__ __forceinline__ void splat_accumulate_block_wave(SplatAccWaveShared<R
     [[maybe_unused]] uint32_t v_list = 0;
     [[maybe_unused]] bool pooled = false;
     [[maybe_unused]] R bcx = R(0.0), bcy = R(0.0), bcz = R(0.0);
+    [[maybe_unused]] float npc[3][2] = {{0.0f, 0.0f}, {0.0f, 0.0f}, {0.0f, 0.0f}};
     if constexpr (EARLY) {
         uint32_t mask[CH / 64];
 #pragma unroll
@@ -1891,6 +1892,11 @@ __device__ __forceinline__ void splat_accumulate_block_wave(SplatAccWaveShared<R
             bcx = lo[0][0] + R(3.5) * P.cs;
             bcy = lo[1][0] + R(3.5) * P.cs;
             bcz = lo[2][0] + R(3.5) * P.cs;
+            const R bc3[3] = {bcx, bcy, bcz};
+#pragma unroll
+            for (int d = 0; d < 3; ++d)
+#pragma unroll
+                for (int h = 0; h < 2; ++h) npc[d][h] = (float)((bc3[d] - pc[d][h]) * P.avx_inv_h);  // minus the lane's point in the records' frame
             uint2 rec[CH / 64];
 #pragma unroll
             for (int k = 0; k < CH / 64; ++k) rec[k] = splat_bound_record(P, stage[k], bcx, bcy, bcz);
@@ -1957,7 +1963,7 @@ __device__ __forceinline__ void splat_accumulate_block_wave(SplatAccWaveShared<R
                 int n_near = 0;
                 R acc;
                 if constexpr (CLS == SS_ARITH_BOUND) {
-                    const float npx = (bcx - px) * P.avx_inv_h, npy = (bcy - py) * P.avx_inv_h, npz = (bcz - pz) * P.avx_inv_h;  // minus the point
+                    const float npx = sx ? npc[0][1] : npc[0][0], npy = sy ? npc[1][1] : npc[1][0], npz = sz ? npc[2][1] : npc[2][0];  // minus the point
                     uint2* pool = reinterpret_cast<uint2*>(sh.wl);
                     SS_PROF_MARK(5);  // (classification: everything but the walks)
                     if (pooled) {
@@ -1983,6 +1989,11 @@ __device__ __forceinline__ void splat_accumulate_block_wave(SplatAccWaveShared<R
             // the block's mask (mc_load_tile), and the second pass writes the sub-blocks whose values are really read.
             certified |= 1u << sb;
             val = P.thr_inside;
+            if (P.thr_inside > P.threshold) {  // (always, but for thresholds <= 0) every point is inside: no face bits
+                mn = ss_min(mn, val);
+                mx = ss_max(mx, val);
+                continue;
+            }
         }
         mn = ss_min(mn, val);
         mx = ss_max(mx, val);
