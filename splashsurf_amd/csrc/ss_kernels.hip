@@ -2538,6 +2538,22 @@ __global__ __launch_bounds__(256) void k_mc_emit(SSDevT<R> P, const R* __restric
     }
     __syncthreads();
     const int n = P.n_sub_cubes;
+    // subdomain of the block's first point per axis, once per thread: the points of the block (and the point before the first
+    // one) are at most one subdomain border away from it when a subdomain has more than 8 cubes, so the per-vertex divisions
+    // below (five to nine a thread, ~25 instructions each: 40 % of this kernel's arithmetic) become a comparison
+    const int g0[3] = {bx * SS_BLOCK, by * SS_BLOCK, bz * SS_BLOCK};
+    int q0[3], r0[3];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        q0[d] = g0[d] / n;
+        r0[d] = g0[d] - q0[d] * n;
+    }
+    const bool near_border_rule = n > SS_BLOCK;  // (wave-uniform)
+    auto subdomain_of = [&](int d, int x) {  // x / n for a point index x in [g0[d] - 1, g0[d] + 8], x >= 0
+        if (!near_border_rule) return x / n;
+        const int t = r0[d] + (x - g0[d]);
+        return q0[d] + (t >= n ? 1 : 0) - (t < 0 ? 1 : 0);
+    };
     const unsigned long long below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
@@ -2547,6 +2563,10 @@ __global__ __launch_bounds__(256) void k_mc_emit(SSDevT<R> P, const R* __restric
         // ---- vertices on the three edges owned by this thread's point (dense_subdomains.rs:1498-1539) ----
         const int lx = pt >> 6, ly = (pt >> 3) & 7, lz = pt & 7;
         const int O[3] = {L.gx, L.gy, L.gz};
+        // global edge key = 3 x (flat index of the origin point) + axis: block-uniform base plus small multiples of the strides
+        const unsigned long long stride_y = 3ull * (unsigned long long)P.np[2], stride_x = stride_y * (unsigned long long)P.np[1];
+        const unsigned long long point_key = ((unsigned long long)g0[0] * (unsigned long long)P.np[1] + (unsigned long long)g0[1]) * stride_y + 3ull * (unsigned long long)g0[2] +
+                                             (unsigned long long)(uint32_t)lx * stride_x + (unsigned long long)(uint32_t)ly * stride_y + (unsigned long long)(3 * lz);
 #pragma unroll
         for (int a = 0; a < 3; ++a) {
             if (!L.cross[a]) continue;
@@ -2563,9 +2583,9 @@ __global__ __launch_bounds__(256) void k_mc_emit(SSDevT<R> P, const R* __restric
                 // the subdomain of the adjacent cell O - delta, delta_d = 1 on the orthogonal axes where possible
                 int sd;
                 if (d == a)
-                    sd = O[d] / n;
+                    sd = subdomain_of(d, O[d]);
                 else
-                    sd = (O[d] >= 1) ? (O[d] - 1) / n : 0;
+                    sd = (O[d] >= 1) ? subdomain_of(d, O[d] - 1) : 0;
                 const int loc = O[d] - sd * n;
                 const R sub_min = P.gmin[d] + (R)sd * P.sub_size;  // uniform_grid.rs:454-467 on the subdomain grid
                 const R oc = sub_min + (R)loc * P.cs;               // uniform_grid.rs:418-425 on the subdomain MC grid
@@ -2575,8 +2595,7 @@ __global__ __launch_bounds__(256) void k_mc_emit(SSDevT<R> P, const R* __restric
             vertices[3 * (size_t)vid] = vc[0];
             vertices[3 * (size_t)vid + 1] = vc[1];
             vertices[3 * (size_t)vid + 2] = vc[2];
-            vkeys[vid] = (((unsigned long long)O[0] * (unsigned long long)P.np[1] + (unsigned long long)O[1]) * (unsigned long long)P.np[2] +
-                          (unsigned long long)O[2]) * 3ull + (unsigned long long)a;
+            vkeys[vid] = point_key + (unsigned long long)a;
         }
 
         // ---- triangle records of this slab ----
