@@ -2356,8 +2356,10 @@ struct McLocal {
     int ntri;
 };
 
+// lut: the case table (c_mc_table) staged in LDS by the caller -- read from constant memory, the row of a cell's case is a third
+// dependent round trip at the end of a kernel that is bound by its first two
 template <class R>
-__device__ inline McLocal mc_classify(const McTile<R>& t, const SSDevT<R>& P, int bx, int by, int bz, int tid) {
+__device__ inline McLocal mc_classify(const McTile<R>& t, const SSDevT<R>& P, int bx, int by, int bz, int tid, const int8_t* lut) {
     McLocal L;
     const int lx = tid >> 6, ly = (tid >> 3) & 7, lz = tid & 7;
     L.gx = bx * SS_BLOCK + lx;
@@ -2380,7 +2382,7 @@ __device__ inline McLocal mc_classify(const McTile<R>& t, const SSDevT<R>& P, in
         }
     }
     // triangles of the case: the row's entries 0, 3, 6, 9, 12 that are >= 0 (one 16-byte load, sign bits)
-    const uint4 row = *reinterpret_cast<const uint4*>(&c_mc_table[L.case_index][0]);
+    const uint4 row = *reinterpret_cast<const uint4*>(lut + 16 * L.case_index);
     L.ntri = (int)(((~row.x >> 7) & 1u) + ((~row.x >> 31) & 1u) + ((~row.y >> 23) & 1u) + ((~row.z >> 15) & 1u) + ((~row.w >> 7) & 1u));
     return L;
 }
@@ -2452,10 +2454,12 @@ __global__ __launch_bounds__(256) void k_mc_count(SSDevT<R> P, const R* __restri
     __shared__ McTile<R> tile;
     __shared__ uint32_t s_nb[SS_MC_REC];
     __shared__ uint32_t s_v[4], s_t[4];
+    __shared__ __attribute__((aligned(16))) int8_t s_lut[256 * 16];  // the case table (mc_classify)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t m = blockIdx.x;
     if (m >= n_mc) return;
     const int bx = (int)mc_xyz[3 * (size_t)m], by = (int)mc_xyz[3 * (size_t)m + 1], bz = (int)mc_xyz[3 * (size_t)m + 2];  // k_block_coords
+    reinterpret_cast<uint4*>(s_lut)[tid] = reinterpret_cast<const uint4*>(&c_mc_table[0][0])[tid];
     if (tid < SS_MC_REC) s_nb[tid] = mc_nb[SS_MC_REC * (size_t)m + tid];
     __syncthreads();
     mc_load_tile_256(tile, P, G, s_nb, tid);
@@ -2463,7 +2467,7 @@ __global__ __launch_bounds__(256) void k_mc_count(SSDevT<R> P, const R* __restri
     uint32_t nv = 0, ntri = 0;
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
-        const McLocal L = mc_classify(tile, P, bx, by, bz, 256 * half + tid);
+        const McLocal L = mc_classify(tile, P, bx, by, bz, 256 * half + tid, s_lut);
 #pragma unroll
         for (int a = 0; a < 3; ++a) {
             const unsigned long long mk = __ballot(L.cross[a]);
@@ -2558,7 +2562,7 @@ __global__ __launch_bounds__(256) void k_mc_emit(SSDevT<R> P, const R* __restric
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
         const int pt = 256 * half + tid, slab = 4 * half + wave;
-        const McLocal L = mc_classify(tile, P, bx, by, bz, pt);
+        const McLocal L = mc_classify(tile, P, bx, by, bz, pt, s_lut);
 
         // ---- vertices on the three edges owned by this thread's point (dense_subdomains.rs:1498-1539) ----
         const int lx = pt >> 6, ly = (pt >> 3) & 7, lz = pt & 7;
