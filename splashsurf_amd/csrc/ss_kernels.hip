@@ -762,15 +762,19 @@ void ss_launch_compact_blocks(const uint32_t* flag, const uint32_t* rank, uint32
 // Work unit: one active block of 8x8x8 grid points; ONE WAVE per block (k_splat_fused), lane l = point ((l>>4)&3, (l>>2)&3, l&3)
 // of the current 4x4x4 sub-block.
 //   1. gather: the (x, y) rows of search cells touching the dilated block box are contiguous runs of the cell-sorted particle
-//      array (rows trimmed to the sphere's z extent); the wave streams them, tests every particle against the box spanned by the
-//      block's points and keeps the survivors -- payload (x, y, z, V) and particle index -- in LDS, in scan order.
+//      array (rows trimmed to the sphere's z extent); the wave streams them six batches of 64 candidates at a time (all loads of a
+//      group in flight together, splat_wave_scan_grouped), tests every particle against the box spanned by the block's points and
+//      keeps the survivors -- payload (x, y, z, V) and particle index -- in LDS, in scan order.
 //   2. certify: for each of the eight sub-blocks a LOWER BOUND of the level set from the entries close to the sub-block (any
-//      order, cheap arithmetic; phase A tests 64 tile entries at once against the sub-block's box, phase B walks the survivors,
-//      every lane adding its point's term).  If it exceeds the threshold at all 64 points the sub-block lies inside the surface and
-//      is neither evaluated nor stored.
-//   3. evaluate: if sub-blocks remain, the wave orders the tile by ORIGINAL particle index (splat_sort_tile) -- the reference's
-//      per-point summation order (sorted per-subdomain particle lists, dense_subdomains.rs:476-488) -- and evaluates
-//      G += V * W(|x - p|) in the reference's arithmetic (dense_subdomains.rs:828-841 / :1077-1107, the ARITH template parameter).
+//      order, cheap arithmetic).  f32: the near lists of all eight sub-blocks are built in one pass over the tile as 8-byte f16
+//      records in a pool in LDS (splat_bound_record), then walked one after the other (splat_bound_walk), every lane adding its
+//      point's term; f64: phase A tests 64 tile entries at once against the sub-block's box, phase B walks the survivors
+//      (splat_accumulate_wave).  If the bound exceeds the threshold at all 64 points the sub-block lies inside the surface and is
+//      neither evaluated nor stored.
+//   3. evaluate: if sub-blocks remain, the wave ranks the tile by ORIGINAL particle index (splat_sort_tile: an order array, the
+//      tile stays where it is) -- the reference's per-point summation order (sorted per-subdomain particle lists,
+//      dense_subdomains.rs:476-488) -- and evaluates G += V * W(|x - p|) in the reference's arithmetic
+//      (dense_subdomains.rs:828-841 / :1077-1107, the ARITH template parameter).
 //   4. Certified sub-blocks with a point next to a grid point outside the surface are evaluated by a second launch over a list
 //      (k_select_redo): those are the values marching cubes interpolates with.
 // A block with more candidates than a wave holds (SSWaveChunk; over-dense input) takes the ARENA PATH instead: k_splat_bounds (an
