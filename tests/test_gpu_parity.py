@@ -684,3 +684,17 @@ def test_u64_triangles_cross_pcie_as_u32(gpu_ctx):
     b = S.reconstruct_surface(pts, context=ctx_dev, **kw)
     assert np.array_equal(b.mesh.triangles, t64)
     ctx_dev.close()
+
+
+@pytest.mark.gpu
+def test_hbm_bandwidth_probe_reports_plausible_rates():
+    """ss_measure_hbm_bandwidth (the denominator of roofline.frac_of_measured_peak): a float4 read stream and a float4 copy over
+    buffers that do not fit any cache; both rates are positive, below the data-sheet peak, and a copy (read + write bytes) is not
+    slower than half the read stream."""
+    from splashsurf_amd.api import Context
+    ctx = Context(0)
+    read_gbs, copy_gbs = ctx.measure_hbm_bandwidth(nbytes=512 << 20, repetitions=3)
+    assert 500.0 < read_gbs < 8000.0, read_gbs
+    assert 500.0 < copy_gbs < 8000.0, copy_gbs
+    assert copy_gbs > 0.4 * read_gbs
+    ctx.close()
