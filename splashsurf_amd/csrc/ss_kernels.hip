@@ -2494,34 +2494,73 @@ __device__ inline void mc_load_tile_256(McTile<R>& t, const SSDevT<R>& P, const 
     if (tid < 217) t.g[(x1 * 9 + y1) * 9 + z1] = v1;
 }
 
-// ONE 256-thread workgroup per MC block, two points per thread (wave w: the x-slabs w and 4 + w).  The kernel is bound by the
-// latency of its two dependent round trips (record, values): a workgroup of 512 threads per block halves the workgroups a CU holds,
-// two workgroups of 256 per block (round 2) pay both round trips and the record twice per block.  Counts are plain stores.
+// all 729 points for 128 threads: thread t reads offsets t, 128 + t, 256 + t, 384 + t of the block itself (four contiguous 512-byte
+// reads per workgroup) and up to two points of the halo; all loads are issued before any value is written to LDS
 template <class R>
-__global__ __launch_bounds__(256) void k_mc_count(SSDevT<R> P, const R* __restrict__ G, const uint32_t* __restrict__ mc_nb,
+__device__ inline void mc_load_tile_128(McTile<R>& t, const SSDevT<R>& P, const R* __restrict__ G, const uint32_t* s_nb, int tid) {
+    R v[4];
+    int px[4], py[4], pz[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        mc_point_of_offset(128 * q + tid, &px[q], &py[q], &pz[q]);
+        v[q] = mc_fetch_point(P, G, s_nb, px[q], py[q], pz[q]);
+    }
+    R h[2] = {R(0.0), R(0.0)};
+    int hx[2], hy[2], hz[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int k = 128 * q + tid;
+        hx[q] = 8, hy[q] = 0, hz[q] = 0;
+        if (k < 81) {  // plane x = 8
+            hy[q] = k / 9;
+            hz[q] = k % 9;
+        } else if (k < 153) {  // plane y = 8, x < 8
+            hx[q] = (k - 81) / 9;
+            hy[q] = 8;
+            hz[q] = (k - 81) % 9;
+        } else {  // plane z = 8, x < 8, y < 8
+            hx[q] = ((k - 153) >> 3) & 7;
+            hy[q] = (k - 153) & 7;
+            hz[q] = 8;
+        }
+        if (k < 217) h[q] = mc_fetch_point(P, G, s_nb, hx[q], hy[q], hz[q]);
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) t.g[(px[q] * 9 + py[q]) * 9 + pz[q]] = v[q];
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+        if (128 * q + tid < 217) t.g[(hx[q] * 9 + hy[q]) * 9 + hz[q]] = h[q];
+}
+
+// ONE 128-thread workgroup per MC block, four points per thread (wave w: the x-slabs w, 2 + w, 4 + w, 6 + w).  The kernel is bound by the
+// latency of its two dependent round trips (record, values): a block's round trips are paid once (round 2: two workgroups of 256
+// per block paid them and the record twice), sixteen such workgroups fit a CU.  Counts are plain stores.
+template <class R>
+__global__ __launch_bounds__(128) void k_mc_count(SSDevT<R> P, const R* __restrict__ G, const uint32_t* __restrict__ mc_nb,
                                                   const uint32_t* __restrict__ mc_xyz, uint32_t n_mc, unsigned long long* __restrict__ masks,
                                                   uint32_t* __restrict__ vcount, uint32_t* __restrict__ tcount) {
     __shared__ McTile<R> tile;
     __shared__ uint32_t s_nb[SS_MC_REC];
-    __shared__ uint32_t s_v[4], s_t[4];
+    __shared__ uint32_t s_v[2], s_t[2];
     __shared__ __attribute__((aligned(16))) int8_t s_lut[256 * 16];  // the case table (mc_classify)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t m = blockIdx.x;
     if (m >= n_mc) return;
     const int bx = (int)mc_xyz[3 * (size_t)m], by = (int)mc_xyz[3 * (size_t)m + 1], bz = (int)mc_xyz[3 * (size_t)m + 2];  // k_block_coords
     reinterpret_cast<uint4*>(s_lut)[tid] = reinterpret_cast<const uint4*>(&c_mc_table[0][0])[tid];
+    reinterpret_cast<uint4*>(s_lut)[128 + tid] = reinterpret_cast<const uint4*>(&c_mc_table[0][0])[128 + tid];
     if (tid < SS_MC_REC) s_nb[tid] = mc_nb[SS_MC_REC * (size_t)m + tid];
     __syncthreads();
-    mc_load_tile_256(tile, P, G, s_nb, tid);
+    mc_load_tile_128(tile, P, G, s_nb, tid);
     __syncthreads();
     uint32_t nv = 0, ntri = 0;
 #pragma unroll
-    for (int half = 0; half < 2; ++half) {
-        const McLocal L = mc_classify(tile, P, bx, by, bz, 256 * half + tid, s_lut);
+    for (int q = 0; q < 4; ++q) {
+        const McLocal L = mc_classify(tile, P, bx, by, bz, 128 * q + tid, s_lut);
 #pragma unroll
         for (int a = 0; a < 3; ++a) {
             const unsigned long long mk = __ballot(L.cross[a]);
-            if (lane == 0) masks[(size_t)m * 24 + a * 8 + 4 * half + wave] = mk;
+            if (lane == 0) masks[(size_t)m * 24 + a * 8 + 2 * q + wave] = mk;
             nv += (uint32_t)__popcll(mk);
         }
         ntri += (uint32_t)L.ntri;
@@ -2534,8 +2573,8 @@ __global__ __launch_bounds__(256) void k_mc_count(SSDevT<R> P, const R* __restri
     }
     __syncthreads();
     if (tid == 0) {
-        vcount[m] = s_v[0] + s_v[1] + s_v[2] + s_v[3];
-        tcount[m] = s_t[0] + s_t[1] + s_t[2] + s_t[3];
+        vcount[m] = s_v[0] + s_v[1];
+        tcount[m] = s_t[0] + s_t[1];
     }
 }
 
@@ -2703,7 +2742,7 @@ template <class R>
 void ss_launch_mc_count(const SSDevT<R>& P, const R* G, const uint32_t* mc_nb, const uint32_t* mc_xyz, uint32_t n_mc,
                         unsigned long long* masks, uint32_t* vcount, uint32_t* tcount, hipStream_t st) {
     if (!n_mc) return;
-    hipLaunchKernelGGL(k_mc_count<R>, dim3(n_mc), dim3(256), 0, st, P, G, mc_nb, mc_xyz, n_mc, masks, vcount, tcount);
+    hipLaunchKernelGGL(k_mc_count<R>, dim3(n_mc), dim3(128), 0, st, P, G, mc_nb, mc_xyz, n_mc, masks, vcount, tcount);
 }
 template <class R>
 void ss_launch_mc_emit(const SSDevT<R>& P, const R* G, const uint32_t* mc_nb, const uint32_t* mc_xyz, const uint32_t* mc_slot,
