@@ -646,11 +646,11 @@ def single_gpu_extras(line, args, ctx, prm, wl, workload, pts, d_pts, out, dev, 
     host_pts = pts
     for key, u64, note in (("e2e_host_u64", True, "pageable host (numpy) input via ss_reconstruct_surface_inplace_f32; vertices through ss_result_vertices and "
                                                   "u64 triangle indices through ss_result_triangles ([usize;3] of the reference; widened on the device, 24 B per "
-                                                  "triangle over PCIe) into the library's pinned host buffers; best of 3"),
-                           ("pcie_inclusive", False, "as e2e_host_u64 but u32 triangle indices (ss_result_triangles_u32, 12 B per triangle); best of 3")):
+                                                  "triangle over PCIe) into the library's pinned host buffers; best of 6"),
+                           ("pcie_inclusive", False, "as e2e_host_u64 but u32 triangle indices (ss_result_triangles_u32, 12 B per triangle); best of 6")):
         try:
             t_io = []
-            for _ in range(3):
+            for _ in range(6):
                 t1 = time.perf_counter()
                 r_io = ctx.reconstruct(host_pts, prm, out=out)
                 _v, _t = r_io.mesh_views(u64=u64)
