@@ -161,14 +161,21 @@ def _aabb(lo, hi, what):
     return list(lo), list(hi)
 
 
-def pipeline_kwargs(args):
-    """reconstruct.rs:604-698 (ReconstructionRunnerArgs::try_from) in terms of `reconstruction_pipeline`'s keywords."""
+MESH_CLEANUP_WARNING = ("WARNING: mesh cleanup (marching_cubes_cleanup, the binary's default once --mesh-smoothing-iters is given) is NOT provided by "
+                        "this build and is SKIPPED: the smoothed mesh keeps the sliver triangles the reference would have collapsed first. "
+                        "Pass --mesh-cleanup=off to acknowledge, or run the reference's cleanup on the raw mesh (--output-raw-mesh=on).")
+
+
+def pipeline_kwargs(args, warn=None):
+    """reconstruct.rs:604-698 (ReconstructionRunnerArgs::try_from) in terms of `reconstruction_pipeline`'s keywords.
+    `warn`: callable for loud warnings about differences from the binary (default: stderr)."""
     unsupported = []
-    mesh_cleanup = args.mesh_cleanup
-    if mesh_cleanup is None:  # reconstruct.rs:201-214: "off" for 0 iterations, "on" as soon as the option is present
-        mesh_cleanup = args.mesh_smoothing_iters not in (None, 0)
-    if mesh_cleanup:
-        unsupported.append("--mesh-cleanup (the binary's default once --mesh-smoothing-iters is given; pass --mesh-cleanup=off)")
+    if args.mesh_cleanup:  # explicitly requested: refused
+        unsupported.append("--mesh-cleanup=on (not provided by this build; see INTEGRATION.md, \"Differences\")")
+    elif args.mesh_cleanup is None and args.mesh_smoothing_iters not in (None, 0):
+        # reconstruct.rs:201-214: the binary's default is "off" for 0 iterations and "on" as soon as smoothing is requested.  The reference
+        # README's recipe (--mesh-smoothing-iters=25 ...) relies on that default: it runs here WITHOUT the cleanup, with a loud warning.
+        (warn or (lambda m: print(m, file=sys.stderr)))(MESH_CLEANUP_WARNING)
     if args.decimate_barnacles:
         unsupported.append("--decimate-barnacles")
     if args.generate_quads:
@@ -210,7 +217,7 @@ def read_particles_with_attributes(path, names, dtype):
 def run_reconstruct(args, log=None):
     from . import io, postprocessing
     log = log or (lambda m: print(m, file=sys.stderr))
-    kwargs = pipeline_kwargs(args)
+    kwargs = pipeline_kwargs(args, warn=log)
     pairs = collect_paths(args)
     dtype = np.float64 if args.double_precision else np.float32
     written = []

@@ -40,6 +40,11 @@ def tank_slab_particles(rank, world, scale=1.0, particle_radius=0.005):
     return p
 
 
+def _data_file(name):
+    import os
+    return np.ascontiguousarray(np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "data", name)), dtype=np.float32)
+
+
 WORKLOADS = {
     # name: (generator kwargs, particle_radius, smoothing_length, cube_size) -- radius-relative l and c
     "s1m": dict(gen=lambda: uniform_cube_particles(1_000_000, 12345), particle_radius=0.01, smoothing_length=2.0, cube_size=1.0),
@@ -47,4 +52,7 @@ WORKLOADS = {
     "s10m_cube": dict(gen=lambda: uniform_cube_particles(10_000_000, 12346), particle_radius=0.005, smoothing_length=2.0, cube_size=0.5),
     "s40m_tank": dict(gen=lambda: tank_particles(4.0 ** (1.0 / 3.0)), particle_radius=0.005, smoothing_length=2.0, cube_size=0.5),
     "tank_small": dict(gen=lambda: tank_particles(0.08), particle_radius=0.005, smoothing_length=2.0, cube_size=0.5),
+    # the two data-file configurations of BASELINE.json (configs[0] and configs[4])
+    "config1": dict(gen=lambda: _data_file("double_dam_break_frame_26_4732_particles.npy"), particle_radius=0.025, smoothing_length=2.0, cube_size=1.1),
+    "config5": dict(gen=lambda: _data_file("hilbert_46843_particles.npy"), particle_radius=0.025, smoothing_length=2.0, cube_size=0.45),
 }

@@ -55,9 +55,15 @@ def test_unprovided_stages_fail_loudly():
     assert cli.pipeline_kwargs(_parse(*base))["mesh_cleanup"] is False
     assert cli.pipeline_kwargs(_parse(*base, "--mesh-smoothing-iters=0"))["mesh_cleanup"] is False
     assert cli.pipeline_kwargs(_parse(*base, "--mesh-smoothing-iters=5", "--mesh-cleanup=off"))["mesh_cleanup"] is False
-    for extra in (["--mesh-smoothing-iters=5"], ["--mesh-cleanup=on"], ["--mesh-cleanup=on", "--mesh-cleanup-snap-dist", "0.5"]):
-        with pytest.raises(cli.CliError):
+    for extra in (["--mesh-cleanup=on"], ["--mesh-cleanup=on", "--mesh-cleanup-snap-dist", "0.5"], ["--mesh-smoothing-iters=5", "--mesh-cleanup=on"]):
+        with pytest.raises(cli.CliError):  # explicitly requested: refused
             cli.pipeline_kwargs(_parse(*base, *extra))
+    said = []  # the binary's implicit default (the README's recipe): runs without the cleanup, loudly
+    assert cli.pipeline_kwargs(_parse(*base, "--mesh-smoothing-iters=5"), warn=said.append)["mesh_cleanup"] is False
+    assert len(said) == 1 and "SKIPPED" in said[0] and "mesh cleanup" in said[0]
+    said = []
+    cli.pipeline_kwargs(_parse(*base, "--mesh-smoothing-iters=5", "--mesh-cleanup=off"), warn=said.append)
+    assert said == []
     assert cli.pipeline_kwargs(_parse(*base, "--keep-verts=on"))["keep_vertices"] is True
     with pytest.raises(cli.CliError):
         cli.pipeline_kwargs(_parse(*base, "--mesh-aabb-min", "1", "0", "0", "--mesh-aabb-max", "0", "1", "1"))
@@ -92,7 +98,7 @@ def test_output_names_and_sequences(tmp_path):
 
 
 @pytest.mark.gpu
-def test_cli_end_to_end_matches_the_library_call(tmp_path):
+def test_cli_end_to_end_matches_the_library_call(tmp_path, capfd):
     import splashsurf_amd as S
     from splashsurf_amd import io
     p = np.load(os.path.join(HERE, "data", "double_dam_break_frame_26_4732_particles.npy")).astype(np.float32)
@@ -108,8 +114,11 @@ def test_cli_end_to_end_matches_the_library_call(tmp_path):
     assert raw.vertices.shape == (33026, 3) and raw.triangles.shape == (66220, 3)
     assert out.vertices.shape == raw.vertices.shape and "normals" in out.point_attributes
     assert not np.array_equal(out.vertices, raw.vertices)  # smoothed
-    # the binary's default recipe (smoothing switches the mesh cleanup on) is refused, not silently changed
-    assert cli.main(["reconstruct", str(src), "-r=0.025", "-l=2.0", "-c=1.1", "-o", str(tmp_path / "clean.obj"), "--mesh-smoothing-iters=3", "--check-mesh=on"]) == 1
+    # the binary's default recipe (smoothing switches the mesh cleanup on) runs WITHOUT the cleanup and says so on stderr;
+    # asking for the cleanup explicitly is refused
+    assert cli.main(["reconstruct", str(src), "-r=0.025", "-l=2.0", "-c=1.1", "-o", str(tmp_path / "recipe.obj"), "--mesh-smoothing-iters=3", "--check-mesh=on"]) == 0
+    assert "SKIPPED" in capfd.readouterr().err and (tmp_path / "recipe.obj").exists()
+    assert cli.main(["reconstruct", str(src), "-r=0.025", "-l=2.0", "-c=1.1", "-o", str(tmp_path / "clean.obj"), "--mesh-smoothing-iters=3", "--mesh-cleanup=on"]) == 1
     assert not (tmp_path / "clean.obj").exists()
     # error path: exit code 1, nothing written
     assert cli.main(["reconstruct", str(src), "-r=0.025", "-l=2.0", "-c=1.1", "--decimate-barnacles=on"]) == 1

@@ -388,25 +388,31 @@ def test_config4_s40m_tank(gpu_ctx):
         assert cmp["keys_equal"] and cmp["triangles_equal"] and cmp["vertices_bit_equal"], cmp
 
 
-def test_full_size_s10m_tank_bit_identical_to_oracle(gpu_ctx, oracle):
+@pytest.mark.parametrize("simd", [False, True], ids=["scalar", "simd"])
+def test_full_size_s10m_tank_bit_identical_to_oracle(gpu_ctx, oracle, simd):
     """BASELINE config 3 at FULL size (10 M particles, ~2.3 G grid cells): the whole result -- 10 M
     densities, 7.2 M vertices, 14.4 M triangles -- equals the CPU oracle bit for bit; plus the
     size-independent properties the reference's tests assert (closed manifold mesh) and run-to-run
-    determinism."""
+    determinism.  Both arithmetics: enable_simd = 0 against the oracle's scalar loop (dense_subdomains.rs:784-847)
+    and enable_simd = 1 -- the mode bench.py measures -- against the oracle's uniform AVX arithmetic (mode 2,
+    dense_subdomains.rs:991-1133)."""
     from splashsurf_amd import workloads as W
     wl = W.WORKLOADS["s10m_tank"]
     pts = wl["gen"]()
     prm = dict(particle_radius=wl["particle_radius"], smoothing_length=wl["smoothing_length"], cube_size=wl["cube_size"], iso_surface_threshold=0.6)
-    res = run_gpu(gpu_ctx, pts, prm)
+    res = run_gpu(gpu_ctx, pts, prm, simd=simd)
+    assert res.stats["arith_mode"] in ((2, 3) if simd else (0, 1))
     nv, nt = res.counts()
     assert nv > 5_000_000 and nt > 10_000_000
     h1 = hashlib.sha256(res.mesh.vertices.tobytes() + res.mesh.triangles_u32.tobytes() + res.particle_densities.tobytes()).hexdigest()
-    _, orc = run_oracle(oracle, pts, prm)
+    par = oracle.make_params_relative(prm["particle_radius"], prm["smoothing_length"], prm["cube_size"], iso_surface_threshold=0.6,
+                                      subdomain_num_cubes_per_dim=64, simd=2 if simd else 0)
+    orc = oracle.reconstruct_surface(pts, par)
     assert_gpu_equals_oracle(res, orc)
     assert MC.mesh_is_closed_manifold(res.mesh.triangles_u32)
     keys = res.vertex_keys
     assert np.unique(keys).size == keys.size
-    res2 = run_gpu(gpu_ctx, pts, prm)
+    res2 = run_gpu(gpu_ctx, pts, prm, simd=simd)
     h2 = hashlib.sha256(res2.mesh.vertices.tobytes() + res2.mesh.triangles_u32.tobytes() + res2.particle_densities.tobytes()).hexdigest()
     assert h1 == h2
 
