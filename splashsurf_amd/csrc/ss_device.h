@@ -97,9 +97,18 @@ struct SSDevT {
     R avx_inv_h, avx_sigma, avx_sigma2, avx_sigma6, avx_sigma12;
     int arith;    // SS_ARITH_* of the level-set accumulation chosen for this call
     R coord_slack;  // absolute slack covering rounding of coordinates in conservative tests
-    // dense array of search cells (edge h), absolute cell coordinate K in [kmin, kmin+kdim)
+    // Dense array of SPLAT CELLS, absolute cell coordinate K in [kmin, kmin+kdim): the cells the particles are sorted by for the level-set
+    // splat (k_cell_keys; the densities use per-subdomain copies in the reference's own search grids).  They are aligned with the lattice of
+    // level-set blocks: edge 8 cs / sk, cell 0 starts at sorg, and the box of block b's points dilated by the particle reach is covered on
+    // every axis by exactly the cells [sk b, sk b + sn1) -- the (x, y) rows of cells a block scans and their z extents are the same for
+    // every block (splat_row_cells), no per-block geometry.  sk is chosen so that a cell holds about one particle at SPH rest spacing.
     int kmin[3];
     int kdim[3];
+    double sorg[3];  // lower corner of splat cell 0 per axis
+    double sinv;     // 1 / cell edge
+    int sk;          // cells per block pitch (8 grid points)
+    int sn1;         // cells per axis that cover a block's dilated box
+    float so, se, srho;  // in units of cs relative to a block's first point: lower face of its first covering cell, cell edge, padded reach
     // level-set blocks: nb = blocks of the whole grid; the dense per-block tables (slots, flags, MC slots) cover the window
     // [bt_org, bt_org + bt_dim) only -- the whole grid for a single-process job, the shard's blocks (+ one layer above, which
     // marching cubes looks into) for a rank of a multi-GPU job: the tables and every pass over them scale with the brick, not the domain
@@ -159,6 +168,16 @@ __host__ __device__ inline int ss_search_cell_axis(const SSDevT<R>& P, int s, R 
     R aligned = kf * P.h;
     R c = ss_floor((x - aligned) / P.h);
     return (int)kf + (int)c;
+}
+
+// splat cell of a coordinate (per axis), clamped into the dense cell array.  (Clamping can only trigger for a rank of a multi-GPU job,
+// whose table covers its brick's blocks: a held particle beyond it is in reach of none of them, and every candidate of a block is
+// tested individually anyway.)
+template <class R>
+__host__ __device__ inline int ss_splat_cell_axis(const SSDevT<R>& P, R x, int d) {
+    const double c = floor(((double)x - P.sorg[d]) * P.sinv);
+    const double lo = (double)P.kmin[d], hi = (double)(P.kmin[d] + P.kdim[d] - 1);
+    return (int)(c < lo ? lo : (c > hi ? hi : c));
 }
 
 template <class R>

@@ -18,6 +18,8 @@
 // reference (sorted per-subdomain particle lists, dense_subdomains.rs:476-488) -- so level-set values
 // are bit-identical to the reference's scalar path, independent of subdomain or GPU boundaries, with
 // no R atomics anywhere.
+#include <algorithm>
+
 #include "ss_device.h"
 #include "ss_kernels.h"
 
@@ -155,20 +157,14 @@ void ss_launch_compact_xyz(const R* d_xyz, uint32_t n, const uint32_t* f32, cons
 }
 
 // =====================================================================================================
-// K1: search-cell keys.  A particle is filed under the cell it has in the search grid of the
-// subdomain that CONTAINS it (= the subdomain computing its density, dense_subdomains.rs:567-614).
+// K1: splat-cell keys.  The particles are sorted once by the cells of the splat grid (SSDevT: edge 8 cs / sk, aligned with the lattice
+// of level-set blocks, z fastest), so that the particles in reach of a block are a fixed set of contiguous runs (splat_row_cells).
 // =====================================================================================================
 template <class R>
 __device__ inline void ss_particle_cell(const SSDevT<R>& P, R x, R y, R z, int K[3]) {
-    R p[3] = {x, y, z};
-#pragma unroll
-    for (int d = 0; d < 3; ++d) {
-        int s = ss_container_subdomain_axis(P, p[d], d);
-        int k = ss_search_cell_axis(P, s, p[d], d);
-        // clamp into the dense cell array (cannot trigger for particles inside the grid; keeps indexing safe)
-        k = max(P.kmin[d], min(P.kmin[d] + P.kdim[d] - 1, k));
-        K[d] = k;
-    }
+    K[0] = ss_splat_cell_axis(P, x, 0);
+    K[1] = ss_splat_cell_axis(P, y, 1);
+    K[2] = ss_splat_cell_axis(P, z, 2);
 }
 
 template <class R>
@@ -659,9 +655,43 @@ void ss_launch_make_posvol(const SSDevT<R>& P, const ss_real4<R>* pos_sorted, co
 }
 
 // =====================================================================================================
-// K3 prepare: which 8^3-point level-set blocks can receive a contribution?  One thread per search cell;
-// a non-empty cell marks every block whose points lie within `reach` of the cell's box.
+// K3 prepare: which 8^3-point level-set blocks can receive a contribution?  One thread per splat cell; a non-empty cell marks every
+// block whose scan visits it: cell c lies in row (ix, iy) = (cx - sk bx, cy - sk by) of block (bx, by, .) iff 0 <= ix, iy < sn1, and
+// the scan of that row covers the cells sk bz + [zlo, zhi] (splat_row_cells: the row's z extent, the same for every block).
 // =====================================================================================================
+// Row r = ix * sn1 + iy of a block's sn1 x sn1 (x, y) rows of splat cells: the z-range [zlo, zhi] of cells (relative to the block's
+// first covering cell) that can hold a particle within reach of the block's points.  In units of cs relative to the block's first
+// point the points span [0, 7]^3 and the cells of row (ix, iy) the slab [so + ix se, so + (ix + 1) se] x [so + iy se, ...]: with
+// its distance d_xy to [0, 7]^2 only sqrt(rho^2 - d_xy^2) is left along z, which trims the corner rows (a quarter to a third of
+// the candidates).  srho is padded (make_device_params), everything here only has to be conservative.
+template <class R>
+__device__ __forceinline__ bool splat_row_cells_xy(const SSDevT<R>& P, int ix, int iy, int* zlo, int* zhi) {
+    const float lx = P.so + (float)ix * P.se, ly = P.so + (float)iy * P.se;
+    const float ex = fmaxf(fmaxf(lx - 7.0f, -(lx + P.se)), 0.0f);
+    const float ey = fmaxf(fmaxf(ly - 7.0f, -(ly + P.se)), 0.0f);
+    const float left = P.srho * P.srho - (ex * ex + ey * ey) * 0.99999f;
+    if (left < 0.0f) return false;
+    const float rz = __builtin_amdgcn_sqrtf(left) * 1.00001f + 1.0e-4f * P.se;
+    const float inv_e = (float)P.sk * 0.125f;
+    *zlo = max((int)floorf((-rz - P.so) * inv_e), 0);
+    *zhi = min((int)floorf((7.0f + rz - P.so) * inv_e), P.sn1 - 1);
+    return *zlo <= *zhi;
+}
+template <class R>
+__device__ __forceinline__ bool splat_row_cells(const SSDevT<R>& P, int r, uint32_t* lo_off, uint32_t* hi_off) {
+    // r / sn1 for 0 <= r < 2^14, sn1 < 2^14 (f32 division of small integers, corrected: no integer division)
+    int ix = (int)((float)r / (float)P.sn1);
+    ix -= (ix * P.sn1 > r) ? 1 : 0;
+    ix += ((ix + 1) * P.sn1 <= r) ? 1 : 0;
+    const int iy = r - ix * P.sn1;
+    int zlo, zhi;
+    if (!splat_row_cells_xy<R>(P, ix, iy, &zlo, &zhi)) return false;
+    const uint32_t row = (uint32_t)(ix * P.kdim[1] + iy) * (uint32_t)P.kdim[2];
+    *lo_off = row + (uint32_t)zlo;
+    *hi_off = row + (uint32_t)zhi + 1u;
+    return true;
+}
+
 template <class R>
 __global__ __launch_bounds__(256) void k_mark_blocks(SSDevT<R> P, const uint32_t* __restrict__ cell_start, uint32_t ncells,
                                                      uint32_t* __restrict__ block_flag) {
@@ -669,28 +699,28 @@ __global__ __launch_bounds__(256) void k_mark_blocks(SSDevT<R> P, const uint32_t
     if (c >= ncells) return;
     if (cell_start[c + 1] == cell_start[c]) return;
     int k[3];
-    k[2] = (int)(c % (uint32_t)P.kdim[2]);
-    k[1] = (int)((c / (uint32_t)P.kdim[2]) % (uint32_t)P.kdim[1]);
-    k[0] = (int)(c / ((uint32_t)P.kdim[2] * (uint32_t)P.kdim[1]));
+    k[2] = (int)(c % (uint32_t)P.kdim[2]) + P.kmin[2];
+    k[1] = (int)((c / (uint32_t)P.kdim[2]) % (uint32_t)P.kdim[1]) + P.kmin[1];
+    k[0] = (int)(c / ((uint32_t)P.kdim[2] * (uint32_t)P.kdim[1])) + P.kmin[0];
     int blo[3], bhi[3];
+#pragma unroll
     for (int d = 0; d < 3; ++d) {
-        // nominal cell box [K h, (K+1) h] widened by the particle reach, f32 slack and 1e-3 h for
-        // particles filed one cell off their nominal cell by rounding
-        const double K = (double)(k[d] + P.kmin[d]);
-        const double pad = (double)P.reach + (double)P.coord_slack + 1e-3 * (double)P.h;
-        const double lo = K * (double)P.h - pad, hi = (K + 1.0) * (double)P.h + pad;
-        long long i_lo = (long long)floor((lo - (double)P.gmin[d]) / (double)P.cs);      // conservative: one point early
-        long long i_hi = (long long)ceil((hi - (double)P.gmin[d]) / (double)P.cs);       // conservative: one point late
-        if (i_lo < 0) i_lo = 0;
-        if (i_hi > P.np[d] - 1) i_hi = P.np[d] - 1;
-        if (i_lo > i_hi) return;
-        blo[d] = max((int)(i_lo / SS_BLOCK), P.blk_lo[d]);
-        bhi[d] = min((int)(i_hi / SS_BLOCK), P.blk_hi[d]);
+        // blocks b with sk b <= k <= sk b + sn1 - 1 (k >= 0: the table starts at the first block's first cell)
+        const int lo = k[d] - P.sn1 + 1;
+        blo[d] = max(lo > 0 ? (lo + P.sk - 1) / P.sk : 0, P.blk_lo[d]);
+        bhi[d] = min(k[d] / P.sk, P.blk_hi[d]);
         if (blo[d] > bhi[d]) return;
     }
     for (int bx = blo[0]; bx <= bhi[0]; ++bx)
-        for (int by = blo[1]; by <= bhi[1]; ++by)
-            for (int bz = blo[2]; bz <= bhi[2]; ++bz) block_flag[ss_block_index(P, bx, by, bz)] = 1u;  // (inside [blk_lo, blk_hi], hence inside the table)
+        for (int by = blo[1]; by <= bhi[1]; ++by) {
+            int zlo, zhi;
+            if (!splat_row_cells_xy<R>(P, k[0] - P.sk * bx, k[1] - P.sk * by, &zlo, &zhi)) continue;
+            for (int bz = blo[2]; bz <= bhi[2]; ++bz) {
+                const int iz = k[2] - P.sk * bz;
+                uint32_t* f = block_flag + ss_block_index(P, bx, by, bz);  // (inside [blk_lo, blk_hi], hence inside the table)
+                if (iz >= zlo && iz <= zhi && !*f) *f = 1u;             // (a set flag is not written again: the stores of many cells to one word serialise)
+            }
+        }
 }
 
 // MC works on blocks of cells whose origin point lies in block b; it reads the points of blocks b+{0,1}^3.
@@ -875,45 +905,18 @@ __device__ __forceinline__ bool ss_within_reach_of_block(const SSDevT<R>& P, con
     return (ex * ex + ey * ey + ez * ez) <= P.R2;
 }
 
-// box of the block's points [plo, phi] and the search cells [klo, khi] overlapping it once dilated by the reach
+// box of the block's points [plo, phi]; key0 = table index of the first splat cell of the block's covering range: the block scans the
+// rows key0 + (ix * kdim[1] + iy) * kdim[2] + [zlo, zhi] of splat_row_cells (the same offsets for every block)
 template <class R>
-__device__ __forceinline__ bool splat_block_box(const SSDevT<R>& P, const int b3[3], R plo[3], R phi[3], int klo[3], int khi[3]) {
+__device__ __forceinline__ uint32_t splat_block_box(const SSDevT<R>& P, const int b3[3], R plo[3], R phi[3]) {
 #pragma unroll
     for (int d = 0; d < 3; ++d) {
         const int i0 = b3[d] * SS_BLOCK;
         const int i1 = min(i0 + SS_BLOCK - 1, P.np[d] - 1);
-        const R pad = P.reach + P.coord_slack;
         plo[d] = P.gmin[d] + (R)i0 * P.cs;
         phi[d] = P.gmin[d] + (R)i1 * P.cs;
-        // cells overlapping [plo - pad, phi + pad]; the pad of 1e-3 cells dwarfs the rounding of the product (< 1e-12 cells), so
-        // the range can only be a superset of the exact one -- every candidate is tested individually anyway
-        const double cellpad = 1e-3 * (double)P.h;
-        const int a = (int)floor(((double)(plo[d] - pad) - cellpad) * P.inv_h);
-        const int e = (int)floor(((double)(phi[d] + pad) + cellpad) * P.inv_h);
-        klo[d] = max(a, P.kmin[d]);
-        khi[d] = min(e, P.kmin[d] + P.kdim[d] - 1);
     }
-    return klo[0] <= khi[0] && klo[1] <= khi[1] && klo[2] <= khi[2];
-}
-
-// z-range of search cells of the (x, y) row (kx, ky) that can hold a particle within reach of the box [plo, phi]: the cells of
-// a row form the slab [kx h, (kx+1) h] x [ky h, (ky+1) h]; with its distance d_xy to the box's (x, y) rectangle only
-// sqrt(reach^2 - d_xy^2) is left along z, which trims the corner rows of the dilated box (a quarter to a third of the
-// candidates).  eps covers the rounding of the products and particles filed one cell off their nominal cell by rounding.
-template <class R>
-__device__ __forceinline__ bool splat_row_z_range(const SSDevT<R>& P, int kx, int ky, const int klo[3], const int khi[3], const R plo[3], const R phi[3],
-                                                  int* zlo, int* zhi) {
-    const R eps = P.coord_slack + R(2.0e-3) * P.h;
-    const R ex = ss_max(ss_max(plo[0] - (R)(kx + 1) * P.h, (R)kx * P.h - phi[0]) - eps, R(0.0));
-    const R ey = ss_max(ss_max(plo[1] - (R)(ky + 1) * P.h, (R)ky * P.h - phi[1]) - eps, R(0.0));
-    const R left = P.reach * P.reach - (ex * ex + ey * ey);
-    if (left < R(0.0)) return false;
-    const R rz = ss_sqrt(left) + eps;
-    const int a = (int)floor((double)(plo[2] - rz) * P.inv_h);
-    const int b = (int)floor((double)(phi[2] + rz) * P.inv_h);
-    *zlo = max(a, klo[2]);
-    *zhi = min(b, khi[2]);
-    return *zlo <= *zhi;
+    return ss_cell_key(P, P.sk * b3[0], P.sk * b3[1], P.sk * b3[2]);
 }
 
 // ---- one wave visits every particle of the search-cell rows overlapping a block's dilated box -------------------------------
@@ -922,21 +925,17 @@ __device__ __forceinline__ bool splat_row_z_range(const SSDevT<R>& P, int kx, in
 // overlaps more than 64 rows only when the cube size approaches the support radius).
 template <class R, bool NEED_ID, class F>
 __device__ __forceinline__ void splat_wave_scan(const SSDevT<R>& P, const ss_real4<R>* __restrict__ posvol, const uint32_t* __restrict__ perm,
-                                                const uint32_t* __restrict__ cell_start, const int klo[3], const int khi[3], const R plo[3], const R phi[3],
+                                                const uint32_t* __restrict__ cell_start, uint32_t key0, const R plo[3], const R phi[3],
                                                 uint32_t* s_row_start, uint32_t* s_row_prefix, int lane, F f) {
-    const int ny = khi[1] - klo[1] + 1;
-    const int nrows = (khi[0] - klo[0] + 1) * ny;
+    const int nrows = P.sn1 * P.sn1;
     for (int row_base = 0; row_base < nrows; row_base += 64) {
         const int nb = min(64, nrows - row_base);
         uint32_t len = 0;
         if (lane < nb) {
-            const int r = row_base + lane;
-            const int kx = klo[0] + r / ny, ky = klo[1] + r % ny;
-            int zlo, zhi;
-            uint32_t rb = 0, re = 0;
-            if (splat_row_z_range<R>(P, kx, ky, klo, khi, plo, phi, &zlo, &zhi)) {
-                rb = cell_start[ss_cell_key(P, kx, ky, zlo)];
-                re = cell_start[ss_cell_key(P, kx, ky, zhi) + 1u];
+            uint32_t lo_off, hi_off, rb = 0, re = 0;
+            if (splat_row_cells<R>(P, row_base + lane, &lo_off, &hi_off)) {
+                rb = cell_start[key0 + lo_off];
+                re = cell_start[key0 + hi_off];
             }
             s_row_start[lane] = rb;
             len = re - rb;
@@ -993,23 +992,22 @@ __device__ __forceinline__ uint32_t ss_wave_inclusive_scan(uint32_t v) {
 // the row look-ups of all batches of a group run interleaved (branch-free bisection over the row prefix table in LDS), then
 // all their loads are in flight together, then the batches are filtered and handed to f in order.  f as in splat_wave_scan.
 #define SS_SCAN_GROUP 6
+#ifndef SS_FUSED_BAIL
+#define SS_FUSED_BAIL 3
+#endif
 template <class R, class F>
 __device__ __forceinline__ void splat_wave_scan_grouped(const SSDevT<R>& P, const ss_real4<R>* __restrict__ posvol, const uint32_t* __restrict__ perm,
-                                                        const uint32_t* __restrict__ cell_start, const int klo[3], const int khi[3], const R plo[3], const R phi[3],
-                                                        uint32_t* s_row_start, uint32_t* s_row_prefix, int lane, F f) {
-    const int ny = khi[1] - klo[1] + 1;
-    const int nrows = (khi[0] - klo[0] + 1) * ny;
+                                                        const uint32_t* __restrict__ cell_start, uint32_t key0, const R plo[3], const R phi[3],
+                                                        uint32_t* s_row_start, uint32_t* s_row_prefix, int lane, uint32_t bail_total, uint32_t* bailed, F f) {
+    const int nrows = P.sn1 * P.sn1;
     for (int row_base = 0; row_base < nrows; row_base += 64) {
         const int nb = min(64, nrows - row_base);
         uint32_t len = 0;
         if (lane < nb) {
-            const int r = row_base + lane;
-            const int kx = klo[0] + r / ny, ky = klo[1] + r % ny;
-            int zlo, zhi;
-            uint32_t rb = 0, re = 0;
-            if (splat_row_z_range<R>(P, kx, ky, klo, khi, plo, phi, &zlo, &zhi)) {
-                rb = cell_start[ss_cell_key(P, kx, ky, zlo)];
-                re = cell_start[ss_cell_key(P, kx, ky, zhi) + 1u];
+            uint32_t lo_off, hi_off, rb = 0, re = 0;
+            if (splat_row_cells<R>(P, row_base + lane, &lo_off, &hi_off)) {
+                rb = cell_start[key0 + lo_off];
+                re = cell_start[key0 + hi_off];
             }
             s_row_start[lane] = rb;
             len = re - rb;
@@ -1017,6 +1015,10 @@ __device__ __forceinline__ void splat_wave_scan_grouped(const SSDevT<R>& P, cons
         const uint32_t incl = ss_wave_inclusive_scan(len);
         s_row_prefix[lane] = (lane < nb) ? incl - len : 0xFFFFFFFFu;  // rows past the end are never chosen by the bisection
         const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+        if (total > bail_total) {  // (wave-uniform) far more candidates in these rows than the caller can hold: it does not want them one by one
+            *bailed = total;
+            return;
+        }
         ss_wave_lds_sync();
         for (uint32_t q0 = 0; q0 < total; q0 += 64u * SS_SCAN_GROUP) {
             uint32_t src[SS_SCAN_GROUP];
@@ -1082,15 +1084,12 @@ __global__ __launch_bounds__(256) void k_splat_bounds(SSDevT<R> P, const uint32_
     // only the blocks k_splat_fused handed on get a tile in the arena (counts: their candidates)
     if (logical < n_active && counts[logical] > (uint32_t)SSWaveChunk<R>::value) {
         const int b3[3] = {(int)active_xyz[3 * (size_t)logical], (int)active_xyz[3 * (size_t)logical + 1], (int)active_xyz[3 * (size_t)logical + 2]};
-        R plo[3], phi[3];
-        int klo[3], khi[3];
-        if (splat_block_box<R>(P, b3, plo, phi, klo, khi))
-            for (int kx = klo[0]; kx <= khi[0]; ++kx)
-                for (int ky = klo[1]; ky <= khi[1]; ++ky) {
-                    int zlo, zhi;
-                    if (splat_row_z_range<R>(P, kx, ky, klo, khi, plo, phi, &zlo, &zhi))
-                        u += cell_start[ss_cell_key(P, kx, ky, zhi) + 1u] - cell_start[ss_cell_key(P, kx, ky, zlo)];
-                }
+        const uint32_t key0 = ss_cell_key(P, P.sk * b3[0], P.sk * b3[1], P.sk * b3[2]);
+        const int nrows = P.sn1 * P.sn1;
+        for (int r = 0; r < nrows; ++r) {
+            uint32_t lo_off, hi_off;
+            if (splat_row_cells<R>(P, r, &lo_off, &hi_off)) u += cell_start[key0 + hi_off] - cell_start[key0 + lo_off];
+        }
     }
     bound[logical] = u;  // entry n_active: 0, so that the exclusive scan ends with the arena size
 }
@@ -1138,11 +1137,11 @@ __global__ __launch_bounds__(256) void k_splat_gather(SSDevT<R> P, const ss_real
     }
     const int b3[3] = {(int)active_xyz[3 * (size_t)logical], (int)active_xyz[3 * (size_t)logical + 1], (int)active_xyz[3 * (size_t)logical + 2]};
     R plo[3], phi[3];
-    int klo[3], khi[3];
     uint32_t count = 0;
-    if (splat_block_box<R>(P, b3, plo, phi, klo, khi)) {
+    {
+        const uint32_t key0 = splat_block_box<R>(P, b3, plo, phi);
         const unsigned long long below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-        splat_wave_scan<R, true>(P, posvol, perm, cell_start, klo, khi, plo, phi, s_row_start[w], s_row_prefix[w], lane, [&](bool inside, uint32_t src, uint32_t id, const ss_real4<R>&) {
+        splat_wave_scan<R, true>(P, posvol, perm, cell_start, key0, plo, phi, s_row_start[w], s_row_prefix[w], lane, [&](bool inside, uint32_t src, uint32_t id, const ss_real4<R>&) {
             const unsigned long long m = __ballot(inside);
             const uint32_t pos = count + (uint32_t)__popcll(m & below);
             if (inside && pos < (uint32_t)SS_WTILE) {
@@ -1160,17 +1159,7 @@ __global__ __launch_bounds__(256) void k_splat_gather(SSDevT<R> P, const ss_real
     if (count > (uint32_t)SS_WTILE) return;
     ss_wave_lds_sync();
     ss_real4<R>* tile = arena + tile_off[logical];
-    if (count <= (uint32_t)SSWaveChunk<R>::value) {
-        // A tile the wave-per-block accumulate kernel takes: payload in scan order plus the particle indices.  Most blocks lie
-        // inside the fluid and are certified by the order-independent lower-bound pass; the accumulate kernel orders a tile
-        // itself (splat_sort_tile) when one of the block's sub-blocks needs the exact sum.
-        uint32_t* tidx = arena_idx + tile_off[logical];
-        for (uint32_t i = (uint32_t)lane; i < count; i += 64u) {
-            tile[i] = posvol[s_src[w][i]];
-            tidx[i] = s_idx[w][i];
-        }
-        return;
-    }
+    // (count can be below SSWaveChunk: k_splat_fused hands a block on by the size of its rows, without counting)
     // rank sort by original particle index (unique), payload written in that order.  (An in-register bitonic network -- 28 / 36 /
     // 45 dependent stages through ds_bpermute for 128 / 256 / 512 keys -- issues a third of the instructions but measured
     // slower, 4.1 instead of 3.3 ms on S10M-tank: the rank sort's LDS broadcast reads are independent and pipeline.)
@@ -1216,20 +1205,16 @@ __device__ inline void splat_row_prefix(S& s, int nbatch, uint32_t len, int tid)
 template <class R, class S, class F>
 __device__ inline void splat_for_each_candidate(S& s, const SSDevT<R>& P, const ss_real4<R>* __restrict__ posvol,
                                                 const uint32_t* __restrict__ perm, const uint32_t* __restrict__ cell_start,
-                                                const int klo[3], const int khi[3], const R plo[3], const R phi[3], int tid, F f) {
-    const int ny = khi[1] - klo[1] + 1;
-    const int nrows = (khi[0] - klo[0] + 1) * ny;
+                                                uint32_t key0, const R plo[3], const R phi[3], int tid, F f) {
+    const int nrows = P.sn1 * P.sn1;
     for (int row_base = 0; row_base < nrows; row_base += SS_MAX_ROWS) {
         const int nbatch = min(SS_MAX_ROWS, nrows - row_base);
         uint32_t len = 0;
         if (tid < nbatch) {
-            const int r = row_base + tid;
-            const int kx = klo[0] + r / ny, ky = klo[1] + r % ny;
-            int zlo, zhi;
-            uint32_t b = 0, e = 0;
-            if (splat_row_z_range<R>(P, kx, ky, klo, khi, plo, phi, &zlo, &zhi)) {
-                b = cell_start[ss_cell_key(P, kx, ky, zlo)];
-                e = cell_start[ss_cell_key(P, kx, ky, zhi) + 1u];
+            uint32_t lo_off, hi_off, b = 0, e = 0;
+            if (splat_row_cells<R>(P, row_base + tid, &lo_off, &hi_off)) {
+                b = cell_start[key0 + lo_off];
+                e = cell_start[key0 + hi_off];
             }
             s.row_start[tid] = b;
             len = e - b;
@@ -1266,8 +1251,7 @@ __device__ __forceinline__ void splat_gather_large_block(SplatShared<R, CAP>& s,
     const int tid = threadIdx.x;
     const int b3[3] = {(int)bxyz[0], (int)bxyz[1], (int)bxyz[2]};
     R plo[3], phi[3];
-    int klo[3], khi[3];
-    if (!splat_block_box<R>(P, b3, plo, phi, klo, khi)) return;
+    const uint32_t key0 = splat_block_box<R>(P, b3, plo, phi);
     if (expect <= (uint32_t)SS_SORT_TILE_MAX) {
         // Left in scan order with the particle indices: the accumulate kernel orders the tile itself if the block needs an exact sum
         // (most blocks inside a body of fluid are certified by the order-independent lower bound).  The payload goes straight from
@@ -1275,7 +1259,7 @@ __device__ __forceinline__ void splat_gather_large_block(SplatShared<R, CAP>& s,
         __syncthreads();
         if (tid == 0) s.count = 0;
         __syncthreads();
-        splat_for_each_candidate<R>(s, P, posvol, perm, cell_start, klo, khi, plo, phi, tid, [&](uint32_t idx, const ss_real4<R>& pv) {
+        splat_for_each_candidate<R>(s, P, posvol, perm, cell_start, key0, plo, phi, tid, [&](uint32_t idx, const ss_real4<R>& pv) {
             const uint32_t pos = atomicAdd(&s.count, 1u);
             if (pos < expect) {
                 tile[pos] = pv;
@@ -1299,7 +1283,7 @@ __device__ __forceinline__ void splat_gather_large_block(SplatShared<R, CAP>& s,
                 __syncthreads();
                 if (tid == 0) s.count = 0;
                 __syncthreads();
-                splat_for_each_candidate<R>(s, P, posvol, perm, cell_start, klo, khi, plo, phi, tid, [&](uint32_t idx, const ss_real4<R>&) {
+                splat_for_each_candidate<R>(s, P, posvol, perm, cell_start, key0, plo, phi, tid, [&](uint32_t idx, const ss_real4<R>&) {
                     if ((long long)idx > last && (long long)idx <= mid) atomicAdd(&s.count, 1u);
                 });
                 const uint32_t c = s.count;
@@ -1313,7 +1297,7 @@ __device__ __forceinline__ void splat_gather_large_block(SplatShared<R, CAP>& s,
         __syncthreads();
         if (tid == 0) s.count = 0;
         __syncthreads();
-        splat_for_each_candidate<R>(s, P, posvol, perm, cell_start, klo, khi, plo, phi, tid, [&](uint32_t idx, const ss_real4<R>&) {
+        splat_for_each_candidate<R>(s, P, posvol, perm, cell_start, key0, plo, phi, tid, [&](uint32_t idx, const ss_real4<R>&) {
             if ((long long)idx > last && (long long)idx <= T) {
                 const uint32_t pos = atomicAdd(&s.count, 1u);
                 if (pos < (uint32_t)CAP) s.idx[pos] = idx;
@@ -2119,12 +2103,16 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(sizeof(R) ==
         const uint32_t logical = __builtin_amdgcn_readfirstlane(list ? list[it] : it);
         const int b3[3] = {(int)active_xyz[3 * (size_t)logical], (int)active_xyz[3 * (size_t)logical + 1], (int)active_xyz[3 * (size_t)logical + 2]};
         R plo[3], phi[3];
-        int klo[3], khi[3];
         uint32_t count = 0;
         SS_PROF_BEGIN();
         ss_wave_lds_sync();  // the previous block's reads of the tile are done
-        if (splat_block_box<R>(P, b3, plo, phi, klo, khi)) {
-            splat_wave_scan_grouped<R>(P, posvol, perm, cell_start, klo, khi, plo, phi, s_row_start, s_row_prefix, lane,
+        {
+            const uint32_t key0 = splat_block_box<R>(P, b3, plo, phi);
+            // Over-dense input: a block whose rows hold more than SS_FUSED_BAIL x the tile capacity is handed to the arena path without
+            // scanning (about two thirds of the candidates of a row lie within reach; S10M-cube: the scans of the 89 % of the blocks
+            // that overflow anyway cost 1.6 ms).
+            uint32_t bailed = 0;
+            splat_wave_scan_grouped<R>(P, posvol, perm, cell_start, key0, plo, phi, s_row_start, s_row_prefix, lane, (uint32_t)(SS_FUSED_BAIL * CH), &bailed,
                                      [&](bool inside, uint32_t, uint32_t id, const ss_real4<R>& pv) {
                                          const unsigned long long m = __ballot(inside);
                                          const uint32_t pos = count + (uint32_t)__popcll(m & below);
@@ -2135,6 +2123,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(sizeof(R) ==
                                          count += (uint32_t)__popcll(m);
                                          return count <= (uint32_t)CH;  // a block with more candidates takes the arena path, which counts them itself
                                      });
+            if (bailed) count = bailed;  // (> CH; the arena path counts exactly)
         }
         if (!list && lane == 0) counts[logical] = count;  // tile entries (statistics; > CH: the arena path recounts)
         if (count > (uint32_t)CH) {
