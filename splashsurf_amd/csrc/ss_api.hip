@@ -993,13 +993,18 @@ ss_status phase_finish(ss_context* ctx, ss_result* res) {
         ctx->early_skipped = 0;
     }
     const bool full_ls = ctx->full_levelset || !(prm_threshold > R(0.0)) || ctx->two_pass == 0 || (ctx->two_pass < 0 && (n_active < 1024u || !probe));
-    SS_HIP(ctx, ctx->splat_trunc.reserve(((size_t)n_active + 2) * (8 + 5 * 4) + 64));
+    SS_HIP(ctx, ctx->splat_trunc.reserve(((size_t)n_active + 2) * (8 + 7 * 4) + 64));
     unsigned long long* face_bits = ctx->splat_trunc.as<unsigned long long>();  // per block: faces of its sub-blocks with points outside the surface
     uint32_t* tr_flag = (uint32_t*)(face_bits + ((size_t)n_active + 2));        // per block: mask of the certified sub-blocks
     uint32_t* rd_flag = tr_flag + ((size_t)n_active + 1);         // ... and marching cubes will read it
     uint32_t* rd_rank = rd_flag + ((size_t)n_active + 1);
     uint32_t* rd_list = rd_rank + ((size_t)n_active + 1);
     uint32_t* big = rd_list + ((size_t)n_active + 1);            // blocks with more candidates than a wave holds (count, list): the arena path
+    uint32_t* need_mask = big + ((size_t)n_active + 1);          // over-dense blocks: the sub-blocks k_splat_certify_big left to evaluate ...
+    uint32_t* exact_list = need_mask + ((size_t)n_active + 1);   // ... and the blocks that have such (count, list)
+    uint32_t* d_err = ctx->counter.as<uint32_t>() + 12;          // (ctx->counter: 64 bytes, zeroed above; words 0..7 hold statistics)
+    // over-dense blocks of an f32 job: certificates straight from the cells first, tiles only for the blocks somebody reads (ss_kernels.hip)
+    const bool certify_big = sizeof(R) == 4 && !full_ls;
     uint32_t n_big = 0;
     if (n_active) {
         // first pass, gather and accumulate in one kernel: the tiles of ordinary blocks stay in LDS
@@ -1010,6 +1015,14 @@ ss_status phase_finish(ss_context* ctx, ss_result* res) {
     }
     SS_HIP(ctx, hipEventRecord(ctx->ev[16], st));
     if (n_big) {
+        if constexpr (sizeof(R) == 4) {
+            if (certify_big) {
+                SS_HIP(ctx, hipMemsetAsync(exact_list, 0, 4, st));
+                ss_launch_splat_certify_big(PK, res->posvol.as<ss_real4<float>>(), ctx->cell_start.as<uint32_t>(), res->active_xyz.as<uint32_t>(), n_active,
+                                            res->block_slot.as<uint32_t>(), ctx->splat_counts.as<uint32_t>(), res->blk_minmax.as<ss_real2<float>>(), tr_flag, face_bits, need_mask,
+                                            exact_list, st);
+            }
+        }
         // over-dense blocks: bounds -> offsets -> tile arena -> gather (-> ordered list of the very large ones) -> workgroup per block
         SS_HIP(ctx, ctx->splat_off.reserve(((size_t)n_active + 1) * 8));
         SS_HIP(ctx, ctx->splat_bound.reserve(((size_t)n_active + 1) * 4));
@@ -1041,7 +1054,8 @@ ss_status phase_finish(ss_context* ctx, ss_result* res) {
     SS_HIP(ctx, hipEventRecord(ctx->ev[17], st));
     if (n_big)
         ss_launch_splat_accumulate_big(PK, ctx->splat_tiles.as<ss_real4<R>>(), ctx->splat_tile_idx.as<uint32_t>(), ctx->splat_off.as<unsigned long long>(), ctx->splat_counts.as<uint32_t>(),
-                                       res->active_xyz.as<uint32_t>(), res->G.as<R>(), res->blk_minmax.as<ss_real2<R>>(), tr_flag, full_ls, false, nullptr, face_bits, big, st);
+                                       res->active_xyz.as<uint32_t>(), res->G.as<R>(), res->blk_minmax.as<ss_real2<R>>(), tr_flag, full_ls, false, certify_big,
+                                       certify_big ? need_mask : nullptr, face_bits, certify_big ? exact_list : big, d_err, st);
     if (n_active) {
         s = sum_u32_to_u64(ctx, ctx->splat_counts.as<uint32_t>(), n_active, ctx->counter.as<unsigned long long>());  // tile entries (statistics)
         if (s != SS_OK) return s;
@@ -1075,8 +1089,8 @@ ss_status phase_finish(ss_context* ctx, ss_result* res) {
                               res->G.as<R>(), res->blk_minmax.as<ss_real2<R>>(), tr_flag, true, rd_list, rd_rank + n_active, rd_flag, face_bits, ctx->splat_counts.as<uint32_t>(), big, st);
         if (n_big)  // (the list kernel re-collected the large blocks among the selected ones in big[])
             ss_launch_splat_accumulate_big(PK, ctx->splat_tiles.as<ss_real4<R>>(), ctx->splat_tile_idx.as<uint32_t>(), ctx->splat_off.as<unsigned long long>(),
-                                           ctx->splat_counts.as<uint32_t>(), res->active_xyz.as<uint32_t>(), res->G.as<R>(), res->blk_minmax.as<ss_real2<R>>(), tr_flag, true, true,
-                                           rd_flag, face_bits, big, st);
+                                           ctx->splat_counts.as<uint32_t>(), res->active_xyz.as<uint32_t>(), res->G.as<R>(), res->blk_minmax.as<ss_real2<R>>(), tr_flag, true, true, false,
+                                           rd_flag, face_bits, big, d_err, st);
         s = count_nonzero_u32(ctx, tr_flag, n_active, ctx->counter.as<unsigned long long>() + 1);  // blocks still truncated (statistics)
         if (s != SS_OK) return s;
     }
@@ -1118,8 +1132,9 @@ ss_status phase_finish(ss_context* ctx, ss_result* res) {
     SS_HIP(ctx, hipMemcpyAsync(&totals[0], res->vbase.as<uint32_t>() + n_mc, 4, hipMemcpyDeviceToHost, st));
     SS_HIP(ctx, hipMemcpyAsync(&totals[1], res->tbase.as<uint32_t>() + n_mc, 4, hipMemcpyDeviceToHost, st));
     unsigned long long n_cand = 0;
-    uint32_t n_large = 0;
+    uint32_t n_large = 0, h_err = 0;
     SS_HIP(ctx, hipMemcpyAsync(&n_cand, ctx->counter.p, 8, hipMemcpyDeviceToHost, st));
+    if (n_big) SS_HIP(ctx, hipMemcpyAsync(&h_err, d_err, 4, hipMemcpyDeviceToHost, st));
     if (n_active) SS_HIP(ctx, hipMemcpyAsync(&n_large, lg_rank + n_active, 4, hipMemcpyDeviceToHost, st));
     unsigned long long n_trunc_left = 0, n_cert_waves = 0;
     uint32_t n_redo = 0;
@@ -1130,6 +1145,7 @@ ss_status phase_finish(ss_context* ctx, ss_result* res) {
     }
     SS_HIP(ctx, hipStreamSynchronize(st));
     const uint64_t nv = totals[0], nt = totals[1];
+    if (h_err) return fail(ctx, SS_ERR_UNKNOWN, "internal error: a level-set block without a tile was asked for values (k_big_tile_select)");
     if (nt * 3 >= (1ull << 32)) return fail(ctx, SS_ERR_UNSUPPORTED, "more than 2^32/3 triangles in one call are not supported by this build");
     SS_HIP(ctx, res->vertices.reserve(nv * 3 * sizeof(R) + 16));
     SS_HIP(ctx, res->vkeys.reserve(nv * 8 + 16));

@@ -1572,8 +1572,9 @@ template <class R, int ARITH, bool EARLY>
 __device__ __forceinline__ void splat_accumulate_block(SplatAccShared<R>& sh, const SSDevT<R>& P, uint32_t logical, const ss_real4<R>* __restrict__ arena,
                                                        const uint32_t* __restrict__ arena_idx, const unsigned long long* __restrict__ tile_off, const uint32_t* __restrict__ counts,
                                                        const uint32_t* __restrict__ active_xyz, R* __restrict__ G, ss_real2<R>* __restrict__ blk_minmax,
-                                                       uint32_t* __restrict__ trunc, unsigned long long* __restrict__ facebits, uint32_t wave_mask) {
+                                                       uint32_t* __restrict__ trunc, unsigned long long* __restrict__ facebits, uint32_t wave_mask, bool write_faces) {
     // wave_mask: the sub-blocks to evaluate (second pass: the certified ones marching cubes reads); the others keep their values
+    // write_faces (!EARLY only): the face bits of the block are written as in the EARLY pass (the exact pass that follows k_splat_certify_big)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n_tile = (int)counts[logical];
     const ss_real4<R>* tile = arena + tile_off[logical];
@@ -1668,7 +1669,7 @@ __device__ __forceinline__ void splat_accumulate_block(SplatAccShared<R>& sh, co
         // a sub-block the first pass certified were never stored
         val = ((certified_before >> wave) & 1u) ? P.thr_inside : *gp;
     }
-    if constexpr (EARLY) {
+    if (EARLY || write_faces) {
         const unsigned long long outside = __ballot(point_valid && !(val > P.threshold));
         if (lane == 0) sh.face[wave] = splat_face_bits(outside);
     }
@@ -1704,7 +1705,7 @@ __device__ __forceinline__ void splat_accumulate_block(SplatAccShared<R>& sh, co
         }
         blk_minmax[logical] = ss_make2(mn, mx);
         trunc[logical] = EARLY ? sh.trunc : (wave_mask == 0xFFu ? 0u : (trunc[logical] & ~wave_mask));
-        if constexpr (EARLY) {
+        if (EARLY || write_faces) {
             unsigned long long fb = 0;
             for (int q = 0; q < 8; ++q) fb |= (unsigned long long)sh.face[q] << (6 * q);
             facebits[logical] = fb;
@@ -2152,14 +2153,198 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(sizeof(R) =
                                                                const uint32_t* __restrict__ counts, const uint32_t* __restrict__ active_xyz,
                                                                const uint32_t* __restrict__ list, const uint32_t* __restrict__ n_list_dev,
                                                                const uint32_t* __restrict__ redo_mask, R* __restrict__ G, ss_real2<R>* __restrict__ blk_minmax,
-                                                               uint32_t* __restrict__ trunc, unsigned long long* __restrict__ facebits) {
+                                                               uint32_t* __restrict__ trunc, unsigned long long* __restrict__ facebits, bool write_faces, uint32_t* __restrict__ err) {
     __shared__ SplatAccShared<R> sh;
     const uint32_t n = *n_list_dev;
     for (uint32_t it = blockIdx.x; it < n; it += gridDim.x) {
         const uint32_t logical = list[it];
-        splat_accumulate_block<R, ARITH, EARLY>(sh, P, logical, arena, arena_idx, tile_off, counts, active_xyz, G, blk_minmax, trunc, facebits, redo_mask ? redo_mask[logical] : 0xFFu);
+        const uint32_t mask = redo_mask ? redo_mask[logical] : 0xFFu;
+        // a block whose tile was not gathered (k_big_tile_select decided nobody would read it) must not be asked for values
+        if (err && threadIdx.x == 0 && mask != 0u && tile_off[logical + 1] == tile_off[logical]) atomicOr(err, 4u);  // (a gathered tile has a non-empty reservation)
+        splat_accumulate_block<R, ARITH, EARLY>(sh, P, logical, arena, arena_idx, tile_off, counts, active_xyz, G, blk_minmax, trunc, facebits, mask, write_faces);
         __syncthreads();
     }
+}
+
+// ---- over-dense blocks: certification straight from the cells -----------------------------------------------------------------
+// A block with more candidates than a wave's tile holds (over-dense input: S10M-cube has ~2 200 particles in reach of a block) used
+// to get a tile in the arena first and the lower-bound pass then tested all of it against every sub-block.  Most such blocks lie
+// deep inside the fluid and need nothing but the certificate, so the certificate now comes first and without a tile: one workgroup
+// per block, wave w = sub-block w.  The wave streams the splat cells around ITS sub-block's near box (the box of its 4^3 points
+// dilated by the near radius of the classification, not by the particle reach: a quarter of the block's candidates), keeps the
+// particles whose box distance is within the near radius as 8-byte records (splat_bound_record) in a list in LDS and walks the
+// list with every lane adding its point's lower-bound term (splat_bound_walk); lists longer than SS_CERT_LIST are walked in pieces.
+// trunc[b] = the certified sub-blocks; a fully certified block is finished here (min / max, no face bits, nothing stored).
+// k_big_tile_select then decides which of these blocks need a tile at all: the ones with a sub-block left to evaluate, and the
+// fully certified ones that k_select_redo can ask to complete later -- it only does that for a block with a face neighbour that
+// holds (or is) an outside point, i.e. one that is absent or not fully certified itself.
+#define SS_CERT_LIST 192
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_splat_certify_big(SSDevT<float> P, const ss_real4<float>* __restrict__ posvol,
+                                                                                                     const uint32_t* __restrict__ cell_start, const uint32_t* __restrict__ active_xyz,
+                                                                                                     uint32_t n_active, const uint32_t* __restrict__ counts,
+                                                                                                     ss_real2<float>* __restrict__ blk_minmax, uint32_t* __restrict__ trunc,
+                                                                                                     unsigned long long* __restrict__ facebits, uint32_t* __restrict__ need_mask) {
+    __shared__ __attribute__((aligned(16))) uint2 s_list[8][SS_CERT_LIST + 64 + 8];
+    __shared__ uint32_t s_row_start[8][64];
+    __shared__ uint32_t s_row_prefix[8][64];
+    __shared__ uint32_t s_cert;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t logical = ss_xcd_chunked_group(blockIdx.x);
+    if (logical >= n_active) return;
+    if (counts[logical] <= (uint32_t)SSWaveChunk<float>::value) return;  // k_splat_fused finished this block
+    if (tid == 0) s_cert = 0u;
+    const int b3[3] = {(int)active_xyz[3 * (size_t)logical], (int)active_xyz[3 * (size_t)logical + 1], (int)active_xyz[3 * (size_t)logical + 2]};
+    const int s3[3] = {(wave >> 2) & 1, (wave >> 1) & 1, wave & 1};
+    const int o3[3] = {(lane >> 4) & 3, (lane >> 2) & 3, lane & 3};
+    float slo[3], shi[3], npc[3], bc[3];
+    bool valid = true, point_valid = true;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        const int g0 = b3[d] * SS_BLOCK + 4 * s3[d];
+        valid = valid && g0 < P.np[d];
+        point_valid = point_valid && (g0 + o3[d]) < P.np[d];
+        slo[d] = P.gmin[d] + (float)g0 * P.cs;
+        shi[d] = P.gmin[d] + (float)min(g0 + 3, P.np[d] - 1) * P.cs;
+        bc[d] = (P.gmin[d] + (float)(b3[d] * SS_BLOCK) * P.cs) + 3.5f * P.cs;  // the records' frame: the block's centre (splat_accumulate_block_wave)
+        const float pc = P.gmin[d] + (float)(g0 + o3[d]) * P.cs;
+        npc[d] = (bc[d] - pc) * P.avx_inv_h;
+    }
+    bool done = false;
+    if (valid) {  // (wave-uniform)
+        uint2* list = s_list[wave];
+        uint32_t* row_start = s_row_start[wave];
+        uint32_t* row_prefix = s_row_prefix[wave];
+        const float rn = __builtin_amdgcn_sqrtf(P.R2near) * 1.00001f + P.coord_slack;
+        // splat cells overlapping the near box per axis (table-relative)
+        int clo[3], chi[3];
+        const double cell = 1.0 / P.sinv, cpad = 1.0e-3 * cell;
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            const int a = (int)floor(((double)(slo[d] - rn) - cpad - P.sorg[d]) * P.sinv) - P.kmin[d];
+            const int e = (int)floor(((double)(shi[d] + rn) + cpad - P.sorg[d]) * P.sinv) - P.kmin[d];
+            clo[d] = max(a, 0);
+            chi[d] = min(e, P.kdim[d] - 1);
+        }
+        const int ny = chi[1] - clo[1] + 1;
+        const int nrows = (chi[0] - clo[0] + 1) * ny;
+        float acc = 0.0f;
+        int n_list = 0, n_near = 0;
+        auto flush = [&]() {
+            if (lane < 4) list[n_list + lane] = SS_BOUND_DUMMY;
+            ss_wave_lds_sync();
+            acc += splat_bound_walk(P, list, n_list, npc[0], npc[1], npc[2]);
+            ss_wave_lds_sync();
+            n_list = 0;
+        };
+        for (int row_base = 0; row_base < nrows; row_base += 64) {
+            const int nb = min(64, nrows - row_base);
+            uint32_t len = 0;
+            if (lane < nb) {
+                const int r = row_base + lane;
+                const int cx = clo[0] + r / ny, cy = clo[1] + r % ny;
+                // distance of the row's (x, y) cell to the sub-block's rectangle; what is left of the near radius along z
+                const double x0 = P.sorg[0] + (double)(cx + P.kmin[0]) * cell, y0 = P.sorg[1] + (double)(cy + P.kmin[1]) * cell;
+                const double ex = fmax(fmax((double)slo[0] - (x0 + cell), x0 - (double)shi[0]) - cpad, 0.0);
+                const double ey = fmax(fmax((double)slo[1] - (y0 + cell), y0 - (double)shi[1]) - cpad, 0.0);
+                const double left = (double)rn * (double)rn - (ex * ex + ey * ey);
+                uint32_t rb = 0, re = 0;
+                if (left >= 0.0) {
+                    const double rz = sqrt(left) + cpad;
+                    const int zl = max((int)floor(((double)slo[2] - rz - P.sorg[2]) * P.sinv) - P.kmin[2], clo[2]);
+                    const int zh = min((int)floor(((double)shi[2] + rz - P.sorg[2]) * P.sinv) - P.kmin[2], chi[2]);
+                    if (zl <= zh) {
+                        const uint32_t row = (uint32_t)(cx * P.kdim[1] + cy) * (uint32_t)P.kdim[2];
+                        rb = cell_start[row + (uint32_t)zl];
+                        re = cell_start[row + (uint32_t)zh + 1u];
+                    }
+                }
+                row_start[lane] = rb;
+                len = re - rb;
+            }
+            const uint32_t incl = ss_wave_inclusive_scan(len);
+            row_prefix[lane] = (lane < nb) ? incl - len : 0xFFFFFFFFu;
+            const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+            ss_wave_lds_sync();
+            constexpr int GRP = 4;
+            for (uint32_t q0 = 0; q0 < total; q0 += 64u * GRP) {
+                uint32_t src[GRP];
+#pragma unroll
+                for (int j = 0; j < GRP; ++j) {
+                    const uint32_t q = min(q0 + 64u * (uint32_t)j + (uint32_t)lane, total - 1u);
+                    int lo = 0;  // last row r with row_prefix[r] <= q
+#pragma unroll
+                    for (int step = 32; step > 0; step >>= 1) lo += (row_prefix[lo + step] <= q) ? step : 0;
+                    src[j] = row_start[lo] + (q - row_prefix[lo]);
+                }
+                ss_real4<float> pv[GRP];
+#pragma unroll
+                for (int j = 0; j < GRP; ++j) pv[j] = posvol[src[j]];
+#pragma unroll
+                for (int j = 0; j < GRP; ++j) {
+                    const uint32_t qj = q0 + 64u * (uint32_t)j;
+                    if (qj >= total) break;  // (wave-uniform)
+                    const float ex = fmaxf(fmaxf(slo[0] - pv[j].x, pv[j].x - shi[0]) - P.coord_slack, 0.0f);
+                    const float ey = fmaxf(fmaxf(slo[1] - pv[j].y, pv[j].y - shi[1]) - P.coord_slack, 0.0f);
+                    const float ez = fmaxf(fmaxf(slo[2] - pv[j].z, pv[j].z - shi[2]) - P.coord_slack, 0.0f);
+                    const bool pass = (qj + (uint32_t)lane < total) && ((ex * ex + ey * ey) + ez * ez <= P.R2near);
+                    const unsigned long long m = __ballot(pass);
+                    if (m) {
+                        if (pass) list[n_list + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] = splat_bound_record(P, pv[j], bc[0], bc[1], bc[2]);
+                        const int c = __popcll(m);
+                        n_list += c;
+                        n_near += c;
+                        if (n_list >= SS_CERT_LIST) flush();
+                    }
+                }
+            }
+            ss_wave_lds_sync();  // the next batch overwrites the row tables
+        }
+        if (n_list > 0) flush();
+        // the margin of thr_inside covers the rounding of the terms; a sum of n of them adds up to n 2^-24 relative
+        const float thr = P.thr_inside + ((float)n_near * 1.2e-7f) * P.thr_inside;
+        done = __ballot(acc > thr || !point_valid) == ~0ull;
+    }
+    __syncthreads();
+    if (done && lane == 0) atomicOr(&s_cert, 1u << wave);
+    __syncthreads();
+    if (tid == 0) {
+        const uint32_t cert = s_cert;
+        trunc[logical] = cert;
+        if (cert == 0xFFu) {
+            blk_minmax[logical] = ss_make2(P.thr_inside, P.thr_inside);
+            facebits[logical] = 0ull;
+            need_mask[logical] = 0u;
+        } else {
+            need_mask[logical] = ~cert & 0xFFu;  // (incl. sub-blocks beyond the grid: the exact pass stores their zeros)
+        }
+    }
+}
+
+// Which over-dense blocks need a tile in the arena (see k_splat_certify_big), and the list of those with sub-blocks left to evaluate.
+// counts[b] = 0 takes a block out of the arena path (k_splat_bounds, k_splat_gather).
+template <class R>
+__global__ __launch_bounds__(256) void k_big_tile_select(SSDevT<R> P, const uint32_t* __restrict__ active_xyz, uint32_t n_active, const uint32_t* __restrict__ block_slot,
+                                                         const uint32_t* __restrict__ trunc, const uint32_t* __restrict__ need_mask, uint32_t* __restrict__ counts,
+                                                         uint32_t* __restrict__ exact_list) {
+    const uint32_t a = blockIdx.x * blockDim.x + threadIdx.x;
+    if (a >= n_active) return;
+    if (counts[a] <= (uint32_t)SSWaveChunk<R>::value) return;
+    bool needs = trunc[a] != 0xFFu;
+    if (!needs) {
+        const int b[3] = {(int)active_xyz[3 * (size_t)a], (int)active_xyz[3 * (size_t)a + 1], (int)active_xyz[3 * (size_t)a + 2]};
+#pragma unroll
+        for (int d = 0; d < 3; ++d)
+#pragma unroll
+            for (int sgn = 0; sgn < 2; ++sgn) {
+                int c[3] = {b[0], b[1], b[2]};
+                c[d] += sgn ? 1 : -1;
+                if (c[d] < 0 || c[d] >= P.nb[d]) continue;  // beyond the grid: no points there (k_select_redo)
+                const uint32_t slot = ss_block_in_table(P, c[0], c[1], c[2]) ? block_slot[ss_block_index(P, c[0], c[1], c[2])] : 0xFFFFFFFFu;
+                needs = needs || slot == 0xFFFFFFFFu || trunc[slot] != 0xFFu;
+            }
+    }
+    if (!needs) counts[a] = 0u;
+    if (need_mask[a]) exact_list[1u + atomicAdd(&exact_list[0], 1u)] = a;
 }
 
 // A certified sub-block carries lower bounds, all above the threshold.  Marching cubes classifies with them like with the
@@ -2278,23 +2463,35 @@ void ss_launch_splat_fused(const SSDevT<R>& P, const ss_real4<R>* posvol, const 
 }
 
 // The blocks k_splat_fused handed on (big[0] of them, big[1..]): their tiles are in the arena (k_splat_gather / _large), one
-// workgroup per block.  second_pass: only the sub-blocks in redo_mask.
+// workgroup per block.  second_pass: only the sub-blocks in redo_mask.  exact_first: the first pass after k_splat_certify_big --
+// `big` is the list of blocks with sub-blocks left to evaluate, redo_mask those sub-blocks; exact sums only, face bits written.
 template <class R>
 void ss_launch_splat_accumulate_big(const SSDevT<R>& P, const ss_real4<R>* arena, const uint32_t* arena_idx, const unsigned long long* tile_off, const uint32_t* counts,
-                                    const uint32_t* active_xyz, R* G, ss_real2<R>* blk_minmax, uint32_t* trunc, bool full_levelset, bool second_pass,
-                                    const uint32_t* redo_mask, unsigned long long* facebits, const uint32_t* big, hipStream_t st) {
+                                    const uint32_t* active_xyz, R* G, ss_real2<R>* blk_minmax, uint32_t* trunc, bool full_levelset, bool second_pass, bool exact_first,
+                                    const uint32_t* redo_mask, unsigned long long* facebits, const uint32_t* big, uint32_t* err, hipStream_t st) {
     const dim3 lgrid(2048);
 #define SS_BIG(A)                                                                                                                                              \
     do {                                                                                                                                                       \
-        if (second_pass || full_levelset)                                                                                                                      \
+        if (second_pass || full_levelset || exact_first)                                                                                                       \
             hipLaunchKernelGGL((k_splat_accumulate_list<R, A, false>), lgrid, dim3(512), 0, st, P, arena, arena_idx, tile_off, counts, active_xyz, big + 1, big, \
-                               second_pass ? redo_mask : nullptr, G, blk_minmax, trunc, facebits);                                                            \
+                               (second_pass || exact_first) ? redo_mask : nullptr, G, blk_minmax, trunc, facebits, exact_first, err);                         \
         else                                                                                                                                                   \
             hipLaunchKernelGGL((k_splat_accumulate_list<R, A, true>), lgrid, dim3(512), 0, st, P, arena, arena_idx, tile_off, counts, active_xyz, big + 1, big, \
-                               nullptr, G, blk_minmax, trunc, facebits);                                                                                      \
+                               nullptr, G, blk_minmax, trunc, facebits, false, err);                                                                          \
     } while (0)
     SS_SPLAT_DISPATCH(SS_BIG);
 #undef SS_BIG
+}
+
+// Over-dense blocks of an f32 job with the two-pass scheme: certificates first (k_splat_certify_big), then the choice of the blocks that
+// get a tile (k_big_tile_select; exact_list[0] must be 0 on entry).
+void ss_launch_splat_certify_big(const SSDevT<float>& P, const ss_real4<float>* posvol, const uint32_t* cell_start, const uint32_t* active_xyz, uint32_t n_active,
+                                 const uint32_t* block_slot, uint32_t* counts, ss_real2<float>* blk_minmax, uint32_t* trunc, unsigned long long* facebits, uint32_t* need_mask,
+                                 uint32_t* exact_list, hipStream_t st) {
+    if (!n_active) return;
+    hipLaunchKernelGGL(k_splat_certify_big, dim3(ss_xcd_chunked_grid(n_active)), dim3(512), 0, st, P, posvol, cell_start, active_xyz, n_active, counts, blk_minmax, trunc, facebits,
+                       need_mask);
+    hipLaunchKernelGGL(k_big_tile_select<float>, dim3((n_active + 255u) / 256u), dim3(256), 0, st, P, active_xyz, n_active, block_slot, trunc, need_mask, counts, exact_list);
 }
 
 template <class R>
@@ -2836,10 +3033,10 @@ template void ss_launch_splat_bounds<double>(const SSDevT<double>& P, const uint
 template void ss_launch_splat_gather<double>(const SSDevT<double>& P, const ss_real4<double>* posvol, const uint32_t* perm, const uint32_t* cell_start, const uint32_t* active_xyz, uint32_t n_active, const unsigned long long* tile_off, ss_real4<double>* arena, uint32_t* arena_idx, uint32_t* counts, uint32_t* large_flag, hipStream_t st);
 template void ss_launch_splat_gather_large<double>(const SSDevT<double>& P, const ss_real4<double>* posvol, const ss_real4<double>* posvol_by_index, const uint32_t* perm, const uint32_t* cell_start, const uint32_t* active_xyz, const uint32_t* large_list, const uint32_t* n_large_dev, const uint32_t* counts, const unsigned long long* tile_off, ss_real4<double>* arena, uint32_t* arena_idx, hipStream_t st);
 template void ss_launch_splat_fused<float>(const SSDevT<float>& P, const ss_real4<float>* posvol, const uint32_t* perm, const uint32_t* cell_start, const uint32_t* active_xyz, uint32_t n_active, float* G, ss_real2<float>* blk_minmax, uint32_t* trunc, bool full_levelset, const uint32_t* list, const uint32_t* n_list_dev, const uint32_t* redo_mask, unsigned long long* facebits, uint32_t* counts, uint32_t* big, hipStream_t st);
-template void ss_launch_splat_accumulate_big<float>(const SSDevT<float>& P, const ss_real4<float>* arena, const uint32_t* arena_idx, const unsigned long long* tile_off, const uint32_t* counts, const uint32_t* active_xyz, float* G, ss_real2<float>* blk_minmax, uint32_t* trunc, bool full_levelset, bool second_pass, const uint32_t* redo_mask, unsigned long long* facebits, const uint32_t* big, hipStream_t st);
+template void ss_launch_splat_accumulate_big<float>(const SSDevT<float>& P, const ss_real4<float>* arena, const uint32_t* arena_idx, const unsigned long long* tile_off, const uint32_t* counts, const uint32_t* active_xyz, float* G, ss_real2<float>* blk_minmax, uint32_t* trunc, bool full_levelset, bool second_pass, bool exact_first, const uint32_t* redo_mask, unsigned long long* facebits, const uint32_t* big, uint32_t* err, hipStream_t st);
 template void ss_launch_select_redo<float>(const SSDevT<float>& P, const uint32_t* active_xyz, uint32_t n_active, const uint32_t* block_slot, const uint32_t* trunc, const unsigned long long* facebits, uint32_t* redo_mask, hipStream_t st);
 template void ss_launch_splat_fused<double>(const SSDevT<double>& P, const ss_real4<double>* posvol, const uint32_t* perm, const uint32_t* cell_start, const uint32_t* active_xyz, uint32_t n_active, double* G, ss_real2<double>* blk_minmax, uint32_t* trunc, bool full_levelset, const uint32_t* list, const uint32_t* n_list_dev, const uint32_t* redo_mask, unsigned long long* facebits, uint32_t* counts, uint32_t* big, hipStream_t st);
-template void ss_launch_splat_accumulate_big<double>(const SSDevT<double>& P, const ss_real4<double>* arena, const uint32_t* arena_idx, const unsigned long long* tile_off, const uint32_t* counts, const uint32_t* active_xyz, double* G, ss_real2<double>* blk_minmax, uint32_t* trunc, bool full_levelset, bool second_pass, const uint32_t* redo_mask, unsigned long long* facebits, const uint32_t* big, hipStream_t st);
+template void ss_launch_splat_accumulate_big<double>(const SSDevT<double>& P, const ss_real4<double>* arena, const uint32_t* arena_idx, const unsigned long long* tile_off, const uint32_t* counts, const uint32_t* active_xyz, double* G, ss_real2<double>* blk_minmax, uint32_t* trunc, bool full_levelset, bool second_pass, bool exact_first, const uint32_t* redo_mask, unsigned long long* facebits, const uint32_t* big, uint32_t* err, hipStream_t st);
 template void ss_launch_select_redo<double>(const SSDevT<double>& P, const uint32_t* active_xyz, uint32_t n_active, const uint32_t* block_slot, const uint32_t* trunc, const unsigned long long* facebits, uint32_t* redo_mask, hipStream_t st);
 template void ss_launch_mc_neighbours<float>(const SSDevT<float>& P, const uint32_t* mc_xyz, uint32_t n_mc, const uint32_t* block_slot, const uint32_t* mc_slot, const uint32_t* certified, uint32_t* mc_nb, hipStream_t st);
 template void ss_launch_mc_count<float>(const SSDevT<float>& P, const float* G, const uint32_t* mc_nb, const uint32_t* mc_xyz, uint32_t n_mc, unsigned long long* masks, uint32_t* vcount, uint32_t* tcount, hipStream_t st);
