@@ -1,0 +1,165 @@
+// ss_prims.h -- the two data-parallel primitives of the reconstruction path, hand-written for gfx950 (wave64): a single-pass chained
+// prefix sum whose input and output are functors (so that flag computation, compaction and the follow-up kernel fuse into the scan's
+// one dispatch) and a stable least-significant-digit radix sort of (u32 key, u32 value) pairs, one dispatch per 8-bit digit
+// ("onesweep": per-tile digit counts are chained by decoupled look-back inside the scatter kernel).  They replace rocPRIM's
+// exclusive_scan / inclusive_scan / reduce / radix_sort_pairs on the path -- fewer dispatches per call (a scan was
+// two dispatches plus a memset, a compaction a third, its count a copy kernel) and totals delivered straight into host-visible memory.
+//
+// Reference counterparts: the parallel prefix sums / sorts the reference takes from rayon and std (dense_subdomains.rs:476-488 sort_unstable of
+// the per-subdomain particle lists; neighborhood_search.rs:679-710 cell map; dense_subdomains.rs:1693-1733 stitching offsets).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+// A count the host waits for, written by a kernel into pinned host memory that is mapped into the device's address space: the host polls
+// `seq` instead of enqueueing a device-to-host copy (a dispatch of its own) and synchronising the stream.
+struct SSMailSlot {
+    unsigned long long* p = nullptr;  // device-visible address of {value, seq}
+    unsigned long long seq = 0;       // what the kernel stores into p[1] after p[0]
+};
+
+__device__ __forceinline__ void ss_mail_post(const SSMailSlot& m, unsigned long long value) {
+    if (!m.p) return;
+    __hip_atomic_store(m.p, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(m.p + 1, m.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// ---- chained scan ----------------------------------------------------------------------------------------------------------------
+// state: 2 + 2 * ceil(n / SS_SCAN_TILE) 32-bit words, zeroed before the launch (word 0: tile counter; from word 2: one 64-bit status per tile)
+#define SS_SCAN_TILE 2048
+inline size_t ss_scan_state_words(size_t n) { return 2 + 2 * ((n + SS_SCAN_TILE - 1) / SS_SCAN_TILE) + 2; }
+
+__device__ __forceinline__ uint32_t ss_prim_wave_incl_u32(uint32_t v) {
+    int x = (int)v;
+    x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xF, 0xF, true);   // row_shr:1
+    x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xF, 0xF, true);   // row_shr:2
+    x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xF, 0xF, true);   // row_shr:4
+    x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xF, 0xF, true);   // row_shr:8
+    x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xA, 0xF, false);  // row_bcast:15 into rows 1 and 3
+    x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xC, 0xF, false);  // row_bcast:31 into rows 2 and 3
+    return (uint32_t)x;
+}
+__device__ __forceinline__ unsigned long long ss_prim_wave_incl_u64(unsigned long long v) {
+    const int lane = (int)(threadIdx.x & 63u);
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const unsigned long long t = __shfl_up(v, off);
+        if (lane >= off) v += t;
+    }
+    return v;
+}
+template <class T>
+__device__ __forceinline__ T ss_prim_wave_incl(T v) {
+    if constexpr (sizeof(T) == 4)
+        return (T)ss_prim_wave_incl_u32((uint32_t)v);
+    else
+        return (T)ss_prim_wave_incl_u64((unsigned long long)v);
+}
+
+// out(i, x, exclusive prefix of x) for i in [0, n), x = in(i); the total goes to *total_dev (if not null) and to the mail slot.
+// One dispatch: tiles take their number from a counter in the order they start, publish their sum and look back over their
+// predecessors' sums 64 tiles at a time.  A status word carries flag and value together, so the look-back needs no ordering
+// against other memory: relaxed agent-scope atomics (an acquire / release at agent scope writes back and invalidates the L2 of
+// the XCD on every access -- measured 346 us instead of ~40 for 10 M elements).  In / Out are callable from the device; T is uint32_t or unsigned long long.
+template <class T, class In, class Out>
+__global__ __launch_bounds__(256) void k_chained_scan(In in, Out out, uint32_t n, uint32_t* __restrict__ state, T* __restrict__ total_dev, SSMailSlot mail) {
+    constexpr int ROWS = SS_SCAN_TILE / 256;
+    __shared__ T s_w[ROWS][4];
+    __shared__ T s_excl;
+    __shared__ uint32_t s_tile;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) s_tile = atomicAdd(state, 1u);
+    __syncthreads();
+    const uint32_t tile = s_tile;
+    const uint32_t base = tile * (uint32_t)SS_SCAN_TILE;
+    unsigned long long* status = reinterpret_cast<unsigned long long*>(state + 2);
+    T x[ROWS], incl[ROWS];
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r) {
+        const uint32_t i = base + (uint32_t)(r * 256 + tid);
+        x[r] = (i < n) ? in(i) : T(0);
+        incl[r] = ss_prim_wave_incl<T>(x[r]);
+        if (lane == 63) s_w[r][wave] = incl[r];
+    }
+    __syncthreads();
+    T tile_total = T(0);
+    T my_off[ROWS];
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r) {
+        T wsum = T(0);
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            if (w == wave) my_off[r] = tile_total + wsum;
+            wsum += s_w[r][w];
+        }
+        tile_total += wsum;
+    }
+    if (wave == 0) {
+        // publish the tile's sum, then look back: lane l reads the status of tile (p - l); flags 0 not there yet, 1 sum of that tile, 2 prefix up to and
+        // including that tile
+        const unsigned long long VALUE = (1ull << 62) - 1ull;
+        if (lane == 0 && tile > 0) __hip_atomic_store(&status[tile], (1ull << 62) | (unsigned long long)tile_total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        unsigned long long excl = 0;
+        long long p = (long long)tile - 1;
+        while (true) {
+            const long long idx = p - lane;
+            const unsigned long long s = (idx >= 0) ? __hip_atomic_load(&status[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : (2ull << 62);
+            const unsigned flag = (unsigned)(s >> 62);
+            const unsigned long long m_pref = __ballot(flag == 2u), m_zero = __ballot(flag == 0u);
+            if (m_pref) {
+                const int k = __ffsll((unsigned long long)m_pref) - 1;
+                const unsigned long long upto = (k == 63) ? ~0ull : ((1ull << (k + 1)) - 1ull);
+                if (m_zero & upto) {
+                    __builtin_amdgcn_s_sleep(1);
+                    continue;
+                }
+                unsigned long long v = (lane <= k) ? (s & VALUE) : 0ull;
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+                excl += v;
+                break;
+            }
+            if (m_zero) {
+                __builtin_amdgcn_s_sleep(1);
+                continue;
+            }
+            unsigned long long v = s & VALUE;
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+            excl += v;
+            p -= 64;
+        }
+        if (lane == 0) {
+            __hip_atomic_store(&status[tile], (2ull << 62) | (excl + (unsigned long long)tile_total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s_excl = (T)excl;
+            if (base + (uint32_t)SS_SCAN_TILE >= n) {  // the last tile knows the total
+                if (total_dev) *total_dev = (T)(excl + (unsigned long long)tile_total);
+                ss_mail_post(mail, excl + (unsigned long long)tile_total);
+            }
+        }
+    }
+    __syncthreads();
+    const T excl = s_excl;
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r) {
+        const uint32_t i = base + (uint32_t)(r * 256 + tid);
+        if (i < n) out(i, x[r], excl + my_off[r] + (incl[r] - x[r]));
+    }
+}
+
+// Launch; n == 0 posts a total of 0 (one thread).  The state words must be zero.
+template <class T, class In, class Out>
+void ss_chained_scan(In in, Out out, uint32_t n, uint32_t* state, T* total_dev, SSMailSlot mail, hipStream_t st) {
+    const uint32_t tiles = n == 0 ? 1u : (n + SS_SCAN_TILE - 1) / SS_SCAN_TILE;
+    hipLaunchKernelGGL((k_chained_scan<T, In, Out>), dim3(tiles), dim3(256), 0, st, in, out, n, state, total_dev, mail);
+}
+
+// ---- radix sort ------------------------------------------------------------------------------------------------------------------
+#define SS_RS_TILE 4096
+// work buffer (32-bit words), zeroed by ss_radix_sort_pairs itself with one memset
+size_t ss_radix_sort_work_words(uint32_t n, unsigned bits);
+// Stable sort of n (key, value) pairs by the low `bits` bits of the keys, 8 bits per pass, ping-pong between buffers 0 and 1.  iota: the
+// values are the positions 0 .. n-1 (vals[0] is not read in the first pass, but is written by an even pass).  Returns the index (0 / 1)
+// of the buffers that hold the result.  n < 2^30.
+int ss_radix_sort_pairs(uint32_t* keys[2], uint32_t* vals[2], uint32_t n, unsigned bits, bool iota, uint32_t* work, hipStream_t st);
