@@ -9,6 +9,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <chrono>
 #include <climits>
 #include <iterator>
 #include <cmath>
@@ -18,8 +19,6 @@
 #include <string>
 #include <thread>
 #include <vector>
-
-#include <rocprim/rocprim.hpp>
 
 #include "../../include/splashsurf_hip.h"
 #include "ss_device.h"
@@ -122,61 +121,98 @@ void initialize_subdomain_parameters(const typename TypesOf<R>::params* prm, con
 }
 
 
+// plain exclusive prefix sum of an array (the secondary paths: global strategy, particle AABB filter, neighbour lists); the hot path
+// uses the fused forms of ss_kernels.h
+template <class T>
+struct ArrayIn {
+    const T* p;
+    __device__ T operator()(uint32_t i) const { return p[i]; }
+};
+template <class T>
+struct ArrayExclOut {
+    T* p;
+    __device__ void operator()(uint32_t i, T, T excl) const { p[i] = excl; }
+};
 template <class T>
 ss_status exclusive_scan_u32(ss_context* ctx, const T* in, T* out, size_t n) {
-    size_t bytes = 0;
-    SS_HIP(ctx, rocprim::exclusive_scan(nullptr, bytes, in, out, (T)0, n, rocprim::plus<T>(), ctx->stream));
-    SS_HIP(ctx, ctx->temp.reserve(bytes));
-    SS_HIP(ctx, rocprim::exclusive_scan(ctx->temp.p, bytes, in, out, (T)0, n, rocprim::plus<T>(), ctx->stream));
+    if (n >= (1ull << 32) - 1) return fail(ctx, SS_ERR_UNSUPPORTED, "more than 2^32 - 2 entries in one prefix sum");
+    const size_t words = ss_scan_state_words(n);
+    SS_HIP(ctx, ctx->temp.reserve(words * 4));
+    SS_HIP(ctx, hipMemsetAsync(ctx->temp.p, 0, words * 4, ctx->stream));
+    ss_chained_scan<T, SSOpPlus>(ArrayIn<T>{in}, ArrayExclOut<T>{out}, (uint32_t)n, ctx->temp.as<uint32_t>(), (T*)nullptr, SSMailSlot{}, ctx->stream);
     return SS_OK;
 }
 
-// cell_start[c] (c = 0 .. ncells) from the sorted keys: run starts, then a reverse running minimum over the table
-ss_status cell_table_from_sorted(ss_context* ctx, const uint32_t* sorted_keys, uint32_t n, size_t ncells, uint32_t* first, uint32_t* cell_start) {
-    hipStream_t st = ctx->stream;
-    SS_HIP(ctx, hipMemsetAsync(first, 0xFF, (ncells + 1) * 4, st));
-    ss_launch_run_starts(sorted_keys, n, (uint32_t)ncells, first, st);
-    auto in = std::make_reverse_iterator(first + ncells + 1);
-    auto out = std::make_reverse_iterator(cell_start + ncells + 1);
-    size_t bytes = 0;
-    SS_HIP(ctx, rocprim::inclusive_scan(nullptr, bytes, in, out, ncells + 1, rocprim::minimum<uint32_t>(), st));
-    SS_HIP(ctx, ctx->temp.reserve(bytes));
-    SS_HIP(ctx, rocprim::inclusive_scan(ctx->temp.p, bytes, in, out, ncells + 1, rocprim::minimum<uint32_t>(), st));
+// ---- counts the host waits for (SSMailSlot, ss_prims.h) ----
+ss_status ensure_mail(ss_context* ctx) {
+    if (ctx->mail_host) return SS_OK;
+    void* h = nullptr;
+    SS_HIP(ctx, hipHostMalloc(&h, 16 * 2 * sizeof(unsigned long long), hipHostMallocMapped));
+    memset(h, 0, 16 * 2 * sizeof(unsigned long long));
+    void* d = nullptr;
+    SS_HIP(ctx, hipHostGetDevicePointer(&d, h, 0));
+    ctx->mail_host = reinterpret_cast<unsigned long long*>(h);
+    ctx->mail_dev = reinterpret_cast<unsigned long long*>(d);
     return SS_OK;
 }
-
-struct WidenU32 {
-    __host__ __device__ unsigned long long operator()(uint32_t v) const { return (unsigned long long)v; }
-};
-struct NonZeroAsU32 {
-    __host__ __device__ uint32_t operator()(uint32_t v) const { return v ? 1u : 0u; }
-};
-struct PopcountU32 {
-    __host__ __device__ unsigned long long operator()(uint32_t v) const {
-        unsigned long long c = 0;
-        for (; v; v &= v - 1) ++c;
-        return c;
+SSMailSlot mail_slot(ss_context* ctx, int k) { return SSMailSlot{ctx->mail_dev + 2 * k, ++ctx->mail_seq}; }
+// Waits until the kernel holding `m` has posted: the host polls the pinned word instead of synchronising the stream (the stream goes on with
+// whatever was enqueued behind that kernel).  A drained stream without the value, a stream error or 120 s end the wait with an error.
+ss_status mail_wait(ss_context* ctx, const SSMailSlot& m, unsigned long long* value) {
+    const int k = (int)((m.p - ctx->mail_dev) / 2);
+    volatile unsigned long long* h = ctx->mail_host + 2 * k;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (unsigned long it = 0;; ++it) {
+        if (__atomic_load_n(&h[1], __ATOMIC_ACQUIRE) == m.seq) {
+            *value = h[0];
+            return SS_OK;
+        }
+        if ((it & 0xFFFu) == 0xFFFu) {
+            const hipError_t q = hipStreamQuery(ctx->stream);
+            if (q == hipSuccess) {
+                if (__atomic_load_n(&h[1], __ATOMIC_ACQUIRE) == m.seq) {
+                    *value = h[0];
+                    return SS_OK;
+                }
+                return fail(ctx, SS_ERR_DEVICE, "a count the host waits for never arrived (stream drained)");
+            }
+            if (q != hipErrorNotReady) {
+                (void)hipGetLastError();
+                return fail(ctx, SS_ERR_DEVICE, std::string("HIP error while waiting for a count: ") + hipGetErrorString(q));
+            }
+            if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 120.0)
+                return fail(ctx, SS_ERR_DEVICE, "timed out waiting for a count from the device");
+        }
+#if defined(__x86_64__)
+        __builtin_ia32_pause();
+#endif
+    }
+}
+// n zeroed 32-bit words from the context's zero region (one memset per phase: reserve_zeros first, then take)
+struct ZeroTaker {
+    uint32_t* base = nullptr;
+    size_t used = 0, cap = 0;
+    uint32_t* take(size_t words) {
+        words = (words + 3) & ~(size_t)3;
+        uint32_t* p = base + used;
+        used += words;
+        return used <= cap ? p : nullptr;
     }
 };
-struct NonZeroU32 {
-    __host__ __device__ unsigned long long operator()(uint32_t v) const { return v ? 1ull : 0ull; }
-};
-// number of non-zero entries among n 32-bit values as a 64-bit value at *out (device)
-static ss_status count_nonzero_u32(ss_context* ctx, const uint32_t* in, size_t n, unsigned long long* out) {
-    auto it = rocprim::make_transform_iterator(in, NonZeroU32());
-    size_t bytes = 0;
-    SS_HIP(ctx, rocprim::reduce(nullptr, bytes, it, out, 0ull, n, rocprim::plus<unsigned long long>(), ctx->stream));
-    SS_HIP(ctx, ctx->temp.reserve(bytes));
-    SS_HIP(ctx, rocprim::reduce(ctx->temp.p, bytes, it, out, 0ull, n, rocprim::plus<unsigned long long>(), ctx->stream));
+ss_status reserve_zeros(ss_context* ctx, size_t words, ZeroTaker* z) {
+    words += 64;
+    SS_HIP(ctx, ctx->zeros.reserve(words * 4));
+    SS_HIP(ctx, hipMemsetAsync(ctx->zeros.p, 0, words * 4, ctx->stream));
+    z->base = ctx->zeros.as<uint32_t>();
+    z->used = 0;
+    z->cap = words;
     return SS_OK;
 }
-// sum of n 32-bit counts as a 64-bit value at *out (device)
-static ss_status sum_u32_to_u64(ss_context* ctx, const uint32_t* in, size_t n, unsigned long long* out) {
-    auto it = rocprim::make_transform_iterator(in, WidenU32());
-    size_t bytes = 0;
-    SS_HIP(ctx, rocprim::reduce(nullptr, bytes, it, out, 0ull, n, rocprim::plus<unsigned long long>(), ctx->stream));
-    SS_HIP(ctx, ctx->temp.reserve(bytes));
-    SS_HIP(ctx, rocprim::reduce(ctx->temp.p, bytes, it, out, 0ull, n, rocprim::plus<unsigned long long>(), ctx->stream));
+// stable sort of the (key, position) pairs by the low `bits` bits; returns the buffers that hold the result
+ss_status sort_pairs(ss_context* ctx, uint32_t* keys[2], uint32_t* vals[2], uint32_t n, unsigned bits, bool iota, int* result) {
+    if (n >= (1u << 30)) return fail(ctx, SS_ERR_UNSUPPORTED, "more than 2^30 - 1 entries to sort in one call are not supported by this build");
+    SS_HIP(ctx, ctx->sort_work.reserve(ss_radix_sort_work_words(n, bits) * 4));
+    *result = ss_radix_sort_pairs(keys, vals, n, bits, iota, ctx->sort_work.as<uint32_t>(), ctx->stream);
     return SS_OK;
 }
 
@@ -425,11 +461,15 @@ template <class R>
 ss_status compute_particle_aabb(ss_context* ctx, const R* d_xyz, uint32_t n, R pmin[3], R pmax[3]) {
     hipStream_t st = ctx->stream;
     SS_HIP(ctx, ctx->aabb_partial.reserve(1024 * 6 * sizeof(R)));
-    SS_HIP(ctx, ctx->aabb_out.reserve(6 * sizeof(R)));
-    ss_launch_aabb(d_xyz, n, ctx->aabb_partial.as<R>(), ctx->aabb_out.as<R>(), st);
-    R h6[6];
-    SS_HIP(ctx, hipMemcpyAsync(h6, ctx->aabb_out.p, 6 * sizeof(R), hipMemcpyDeviceToHost, st));
-    SS_HIP(ctx, hipStreamSynchronize(st));
+    ss_status s = ensure_mail(ctx);
+    if (s != SS_OK) return s;
+    // the six values land in pinned host memory (mail slots 12..15), announced through slot 11
+    const SSMailSlot m = mail_slot(ctx, 11);
+    ss_launch_aabb(d_xyz, n, ctx->aabb_partial.as<R>(), reinterpret_cast<R*>(ctx->mail_dev + 2 * 12), m, st);
+    unsigned long long unused = 0;
+    s = mail_wait(ctx, m, &unused);
+    if (s != SS_OK) return s;
+    const volatile R* h6 = reinterpret_cast<const volatile R*>(ctx->mail_host + 2 * 12);
     for (int d = 0; d < 3; ++d) {
         pmin[d] = h6[d];
         pmax[d] = h6[3 + d];
@@ -525,12 +565,17 @@ ss_status global_search_and_densities(ss_context* ctx, const SSGlobT<R>& Q, cons
         if (s != SS_OK) return s;
         unsigned bits = 1;
         while (bits < 32 && ((size_t)1 << bits) < nscell) ++bits;
-        size_t bytes = 0;
-        SS_HIP(ctx, rocprim::radix_sort_pairs(nullptr, bytes, ctx->keys_a.as<uint32_t>(), ctx->keys_b.as<uint32_t>(), ctx->vals_a.as<uint32_t>(),
-                                              res->perm.as<uint32_t>(), (size_t)n, 0u, bits, st));
-        SS_HIP(ctx, ctx->temp.reserve(bytes));
-        SS_HIP(ctx, rocprim::radix_sort_pairs(ctx->temp.p, bytes, ctx->keys_a.as<uint32_t>(), ctx->keys_b.as<uint32_t>(), ctx->vals_a.as<uint32_t>(),
-                                              res->perm.as<uint32_t>(), (size_t)n, 0u, bits, st));
+        {   // stable sort of (cell, particle) by cell; the buffers are assigned so that the sorted particle indices end in res->perm
+            const bool odd = (((bits + 7u) / 8u) & 1u) != 0u;
+            SS_HIP(ctx, ctx->vals_a.reserve((size_t)n * 4 + 16));
+            uint32_t* keys[2] = {ctx->keys_a.as<uint32_t>(), ctx->keys_b.as<uint32_t>()};
+            // (the values are the particle indices 0 .. n-1: the sort supplies them itself)
+            uint32_t* vals[2] = {odd ? ctx->vals_a.as<uint32_t>() : res->perm.as<uint32_t>(), odd ? res->perm.as<uint32_t>() : ctx->vals_a.as<uint32_t>()};
+            int r = 0;
+            s = sort_pairs(ctx, keys, vals, n, bits, true, &r);
+            if (s != SS_OK) return s;
+            if (vals[r] != res->perm.as<uint32_t>()) return fail(ctx, SS_ERR_UNKNOWN, "internal error: sort result in an unexpected buffer");
+        }
         uint32_t herr = 0;
         SS_HIP(ctx, hipMemcpyAsync(&herr, d_err, 4, hipMemcpyDeviceToHost, st));
         SS_HIP(ctx, hipStreamSynchronize(st));
@@ -772,82 +817,99 @@ ss_status phase_begin(ss_context* ctx, const R* xyz, uint64_t n_in, const typena
     const size_t ncells = (size_t)P.kdim[0] * P.kdim[1] * P.kdim[2];
 
     // ---- K1: bin + sort (decomposition) ----
+    s = ensure_mail(ctx);
+    if (s != SS_OK) return s;
     SS_HIP(ctx, res->rho.reserve((size_t)n * sizeof(R) + 16));
     SS_HIP(ctx, res->posvol.reserve((size_t)n * sizeof(ss_real4<R>) + 32));
     SS_HIP(ctx, res->posvol_by_index.reserve((size_t)n * sizeof(ss_real4<R>) + 32));
     SS_HIP(ctx, res->perm.reserve((size_t)n * 4 + 16));
     SS_HIP(ctx, ctx->cell_count.reserve((ncells + 1) * 4));
     SS_HIP(ctx, ctx->cell_start.reserve((ncells + 1) * 4));
+    SS_HIP(ctx, ctx->keys_a.reserve((size_t)n * 4 + 16));
     SS_HIP(ctx, ctx->keys_b.reserve((size_t)n * 4 + 16));
-    if (n > 0) {
-        SS_HIP(ctx, ctx->keys_a.reserve((size_t)n * 4));
-        SS_HIP(ctx, ctx->vals_a.reserve((size_t)n * 4));
-        SS_HIP(ctx, ctx->pos_sorted.reserve((size_t)n * sizeof(ss_real4<R>)));
-        ss_launch_cell_keys(P, d_xyz, ctx->keys_a.as<uint32_t>(), ctx->vals_a.as<uint32_t>(), st);
-    }
+    SS_HIP(ctx, ctx->vals_a.reserve((size_t)n * 4 + 16));
+    SS_HIP(ctx, ctx->pos_sorted.reserve((size_t)n * sizeof(ss_real4<R>) + 16));
+    const size_t nsub = (size_t)P.ns[0] * P.ns[1] * P.ns[2];
+    if (nsub >= (1ull << 32) - 2) return fail(ctx, SS_ERR_UNSUPPORTED, "more than 2^32 subdomains");
+    SS_HIP(ctx, ctx->copy_offset.reserve(((size_t)n + 1) * 4));
+    SS_HIP(ctx, ctx->sub_rank.reserve((nsub + 1) * 4));
+    SS_HIP(ctx, ctx->occ_sub.reserve((nsub + 1) * 4 + 16));  // (at most every subdomain is occupied)
+    // zeroed words of this phase up to the first count the host waits for: three scan states and the subdomain flags
+    ZeroTaker Z;
+    s = reserve_zeros(ctx, ss_scan_state_words(ncells + 1) + ss_scan_state_words(n) + ss_scan_state_words(nsub) + (nsub + 1) + 32, &Z);
+    if (s != SS_OK) return s;
+    uint32_t* st_cells = Z.take(ss_scan_state_words(ncells + 1));
+    uint32_t* st_member = Z.take(ss_scan_state_words(n));
+    uint32_t* st_sub = Z.take(ss_scan_state_words(nsub));
+    uint32_t* sub_flag = Z.take(nsub + 1);
+    SS_HIP(ctx, hipMemsetAsync(ctx->cell_count.p, 0, (ncells + 1) * 4, st));  // run starts of the cell table: 0 = empty cell
+    const uint32_t* sorted_keys = ctx->keys_a.as<uint32_t>();
     if (n > 0) {
         unsigned bits = 1;
         while (bits < 32 && ((size_t)1 << bits) < ncells) ++bits;
-        size_t bytes = 0;
-        SS_HIP(ctx, rocprim::radix_sort_pairs(nullptr, bytes, ctx->keys_a.as<uint32_t>(), ctx->keys_b.as<uint32_t>(), ctx->vals_a.as<uint32_t>(),
-                                              res->perm.as<uint32_t>(), (size_t)n, 0u, bits, st));
-        SS_HIP(ctx, ctx->temp.reserve(bytes));
-        SS_HIP(ctx, rocprim::radix_sort_pairs(ctx->temp.p, bytes, ctx->keys_a.as<uint32_t>(), ctx->keys_b.as<uint32_t>(), ctx->vals_a.as<uint32_t>(),
-                                              res->perm.as<uint32_t>(), (size_t)n, 0u, bits, st));
-        ss_launch_gather_sorted(n, d_xyz, res->perm.as<uint32_t>(), ctx->pos_sorted.as<ss_real4<R>>(), st);
+        // the buffers are assigned so that the sorted positions end in res->perm whatever the number of passes
+        const bool odd = (((bits + 7u) / 8u) & 1u) != 0u;
+        uint32_t* keys[2] = {ctx->keys_a.as<uint32_t>(), ctx->keys_b.as<uint32_t>()};
+        uint32_t* vals[2] = {odd ? ctx->vals_a.as<uint32_t>() : res->perm.as<uint32_t>(), odd ? res->perm.as<uint32_t>() : ctx->vals_a.as<uint32_t>()};
+        ss_launch_cell_keys(P, d_xyz, keys[0], (uint32_t*)nullptr, st);
+        int r = 0;
+        s = sort_pairs(ctx, keys, vals, n, bits, true, &r);
+        if (s != SS_OK) return s;
+        if (vals[r] != res->perm.as<uint32_t>()) return fail(ctx, SS_ERR_UNKNOWN, "internal error: sort result in an unexpected buffer");
+        sorted_keys = keys[r];
     }
-    s = cell_table_from_sorted(ctx, ctx->keys_b.as<uint32_t>(), n, ncells, ctx->cell_count.as<uint32_t>(), ctx->cell_start.as<uint32_t>());
-    if (s != SS_OK) return s;
+    ss_launch_sorted_gather_runs(n, d_xyz, res->perm.as<uint32_t>(), ctx->pos_sorted.as<ss_real4<R>>(), sorted_keys, (uint32_t)ncells, ctx->cell_count.as<uint32_t>(), st);
+    ss_launch_cell_table_scan(ctx->cell_count.as<uint32_t>(), (uint32_t)ncells, ctx->cell_start.as<uint32_t>(), st_cells, st);
     SS_HIP(ctx, hipEventRecord(ctx->ev[3], st));
 
     // ---- K2: densities (per-subdomain particle copies, exactly the reference's organisation) ----
     {
-        const size_t nsub = (size_t)P.ns[0] * P.ns[1] * P.ns[2];
         const double ctot_d = (double)P.sc[0] * P.sc[1] * P.sc[2];
-        SS_HIP(ctx, ctx->member_count.reserve(((size_t)n + 1) * 4));
-        SS_HIP(ctx, ctx->copy_offset.reserve(((size_t)n + 1) * 4));
-        SS_HIP(ctx, ctx->sub_flag.reserve((nsub + 1) * 4));
-        SS_HIP(ctx, ctx->sub_rank.reserve((nsub + 1) * 4));
-        SS_HIP(ctx, hipMemsetAsync(ctx->member_count.as<uint32_t>() + n, 0, 4, st));  // k_classify_count writes the entries of all particles
-        SS_HIP(ctx, hipMemsetAsync(ctx->sub_flag.p, 0, (nsub + 1) * 4, st));
         SS_HIP(ctx, hipMemsetAsync(res->rho.p, 0, (size_t)n * sizeof(R) + 16, st));  // vec![R::zero(); n], dense_subdomains.rs:504
-        ss_launch_classify_count(P, d_xyz, ctx->member_count.as<uint32_t>(), ctx->sub_flag.as<uint32_t>(), st);
-        s = exclusive_scan_u32<uint32_t>(ctx, ctx->member_count.as<uint32_t>(), ctx->copy_offset.as<uint32_t>(), (size_t)n + 1);
+        // member counts -> copy offsets (k_classify_count as the scan's input), occupied subdomains -> ranks and list
+        const SSMailSlot m_copies = mail_slot(ctx, 0), m_occ = mail_slot(ctx, 1);
+        ss_launch_classify_scan(P, d_xyz, ctx->copy_offset.as<uint32_t>(), sub_flag, st_member, m_copies, st);
+        ss_launch_flag_scan(sub_flag, (uint32_t)nsub, ctx->sub_rank.as<uint32_t>(), ctx->occ_sub.as<uint32_t>(), nullptr, st_sub, m_occ, st);
+        unsigned long long v_copies = 0, v_occ = 0;
+        s = mail_wait(ctx, m_copies, &v_copies);
         if (s != SS_OK) return s;
-        s = exclusive_scan_u32<uint32_t>(ctx, ctx->sub_flag.as<uint32_t>(), ctx->sub_rank.as<uint32_t>(), nsub + 1);
+        s = mail_wait(ctx, m_occ, &v_occ);
         if (s != SS_OK) return s;
-        uint32_t hc[2] = {0, 0};
-        SS_HIP(ctx, hipMemcpyAsync(&hc[0], ctx->copy_offset.as<uint32_t>() + n, 4, hipMemcpyDeviceToHost, st));
-        SS_HIP(ctx, hipMemcpyAsync(&hc[1], ctx->sub_rank.as<uint32_t>() + nsub, 4, hipMemcpyDeviceToHost, st));
-        SS_HIP(ctx, hipStreamSynchronize(st));
-        const uint32_t n_copies = hc[0], n_occ = hc[1];
+        if (v_copies >= (1ull << 30)) return fail(ctx, SS_ERR_UNSUPPORTED, "more than 2^30 - 1 (particle, subdomain) pairs in one call are not supported by this build");
+        const uint32_t n_copies = (uint32_t)v_copies, n_occ = (uint32_t)v_occ;
         res->n_occupied_subdomains = n_occ;
         res->n_subdomain_particles = n_copies;
         if ((double)n_occ * ctot_d > 4.0e9) return fail(ctx, SS_ERR_UNSUPPORTED, "too many (subdomain, search cell) pairs for this build");
         const size_t ncells2 = (size_t)n_occ * (size_t)ctot_d;
         if (n_copies > 0) {
-            SS_HIP(ctx, ctx->occ_sub.reserve((size_t)n_occ * 4 + 16));
-            SS_HIP(ctx, ctx->ckeys_a.reserve((size_t)n_copies * 4));
-            SS_HIP(ctx, ctx->ckeys_b.reserve((size_t)n_copies * 4));
-            SS_HIP(ctx, ctx->cvals_a.reserve((size_t)n_copies * 4));
-            SS_HIP(ctx, ctx->cidx.reserve((size_t)n_copies * 4));
+            SS_HIP(ctx, ctx->ckeys_a.reserve((size_t)n_copies * 4 + 16));
+            SS_HIP(ctx, ctx->ckeys_b.reserve((size_t)n_copies * 4 + 16));
+            SS_HIP(ctx, ctx->cvals_a.reserve((size_t)n_copies * 4 + 16));
+            SS_HIP(ctx, ctx->cidx.reserve((size_t)n_copies * 4 + 16));
             SS_HIP(ctx, ctx->cpos.reserve(((size_t)n_copies + 16) * sizeof(ss_real4<R>)));  // + padding: k_density_sub reads whole chunks
             SS_HIP(ctx, ctx->cell_count2.reserve((ncells2 + 1) * 4));
             SS_HIP(ctx, ctx->cell_start2.reserve((ncells2 + 1) * 4));
-            ss_launch_occupied_list(ctx->sub_flag.as<uint32_t>(), ctx->sub_rank.as<uint32_t>(), (uint32_t)nsub, ctx->occ_sub.as<uint32_t>(), st);
-            ss_launch_emit_copies(P, d_xyz, ctx->copy_offset.as<uint32_t>(), ctx->sub_rank.as<uint32_t>(), ctx->ckeys_a.as<uint32_t>(),
-                                  ctx->cvals_a.as<uint32_t>(), st);
+            SS_HIP(ctx, ctx->own_flag.reserve(((size_t)n_copies + 1) * 4 + 64));
+            ZeroTaker Z2;
+            s = reserve_zeros(ctx, ss_scan_state_words(ncells2 + 1) + ss_scan_state_words(n_copies) + 32, &Z2);
+            if (s != SS_OK) return s;
+            uint32_t* st_cells2 = Z2.take(ss_scan_state_words(ncells2 + 1));
+            uint32_t* st_owned = Z2.take(ss_scan_state_words(n_copies));
+            uint32_t* n_owned_dev = Z2.take(4);
+            SS_HIP(ctx, hipMemsetAsync(ctx->cell_count2.p, 0, (ncells2 + 1) * 4, st));
             unsigned bits = 1;
             while (bits < 32 && ((size_t)1 << bits) < ncells2) ++bits;
-            size_t bytes = 0;
-            SS_HIP(ctx, rocprim::radix_sort_pairs(nullptr, bytes, ctx->ckeys_a.as<uint32_t>(), ctx->ckeys_b.as<uint32_t>(), ctx->cvals_a.as<uint32_t>(),
-                                                  ctx->cidx.as<uint32_t>(), (size_t)n_copies, 0u, bits, st));
-            SS_HIP(ctx, ctx->temp.reserve(bytes));
-            SS_HIP(ctx, rocprim::radix_sort_pairs(ctx->temp.p, bytes, ctx->ckeys_a.as<uint32_t>(), ctx->ckeys_b.as<uint32_t>(), ctx->cvals_a.as<uint32_t>(),
-                                                  ctx->cidx.as<uint32_t>(), (size_t)n_copies, 0u, bits, st));
-            ss_launch_gather_sorted(n_copies, d_xyz, ctx->cidx.as<uint32_t>(), ctx->cpos.as<ss_real4<R>>(), st);
-            s = cell_table_from_sorted(ctx, ctx->ckeys_b.as<uint32_t>(), n_copies, ncells2, ctx->cell_count2.as<uint32_t>(), ctx->cell_start2.as<uint32_t>());
+            const bool odd = (((bits + 7u) / 8u) & 1u) != 0u;
+            uint32_t* keys[2] = {ctx->ckeys_a.as<uint32_t>(), ctx->ckeys_b.as<uint32_t>()};
+            uint32_t* vals[2] = {odd ? ctx->cvals_a.as<uint32_t>() : ctx->cidx.as<uint32_t>(), odd ? ctx->cidx.as<uint32_t>() : ctx->cvals_a.as<uint32_t>()};
+            ss_launch_emit_copies(P, d_xyz, ctx->copy_offset.as<uint32_t>(), ctx->sub_rank.as<uint32_t>(), keys[0], vals[0], st);
+            int r = 0;
+            s = sort_pairs(ctx, keys, vals, n_copies, bits, false, &r);
             if (s != SS_OK) return s;
+            if (vals[r] != ctx->cidx.as<uint32_t>()) return fail(ctx, SS_ERR_UNKNOWN, "internal error: sort result in an unexpected buffer");
+            const uint32_t* ckeys_sorted = keys[r];
+            ss_launch_sorted_gather_runs(n_copies, d_xyz, ctx->cidx.as<uint32_t>(), ctx->cpos.as<ss_real4<R>>(), ckeys_sorted, (uint32_t)ncells2, ctx->cell_count2.as<uint32_t>(), st);
+            ss_launch_cell_table_scan(ctx->cell_count2.as<uint32_t>(), (uint32_t)ncells2, ctx->cell_start2.as<uint32_t>(), st_cells2, st);
             const bool want_nb = prm->global_neighborhood_list != 0;
             if (want_nb) {
                 SS_HIP(ctx, ctx->nb_count.reserve(((size_t)n + 1) * 8));
@@ -857,19 +919,13 @@ ss_status phase_begin(ss_context* ctx, const R* xyz, uint64_t n_in, const typena
             s = ensure_fast_div<R>(ctx, P.h, st);
             if (s != SS_OK) return s;
             // the copies whose density their subdomain computes (every particle has exactly one), compacted in cell order
-            SS_HIP(ctx, ctx->own_flag.reserve(((size_t)n_copies + 1) * 4 * 3 + 64));
-            uint32_t* own_flag = ctx->own_flag.as<uint32_t>();
-            uint32_t* own_rank = own_flag + ((size_t)n_copies + 1);
-            uint32_t* own_list = own_rank + ((size_t)n_copies + 1);
-            ss_launch_owned_copy_flags(P, n_copies, ctx->cpos.as<ss_real4<R>>(), ctx->ckeys_b.as<uint32_t>(), ctx->occ_sub.as<uint32_t>(), own_flag, st);
-            s = exclusive_scan_u32<uint32_t>(ctx, own_flag, own_rank, (size_t)n_copies + 1);
-            if (s != SS_OK) return s;
-            ss_launch_compact_blocks(own_flag, own_rank, n_copies, own_list, ctx->cvals_a.as<uint32_t>(), st);  // (cvals_a: scratch for the unused slot table)
+            uint32_t* own_list = ctx->own_flag.as<uint32_t>();
+            ss_launch_owned_scan(P, n_copies, ctx->cpos.as<ss_real4<R>>(), ckeys_sorted, ctx->occ_sub.as<uint32_t>(), own_list, n_owned_dev, st_owned, st);
             const uint32_t n_owned_bound = n < n_copies ? n : n_copies;  // at most one owned copy per particle
             SS_HIP(ctx, hipEventRecord(ctx->ev[18], st));
-            ss_launch_density_sub(P, n_copies, ctx->cpos.as<ss_real4<R>>(), ctx->cidx.as<uint32_t>(), ctx->ckeys_b.as<uint32_t>(),
+            ss_launch_density_sub(P, n_copies, ctx->cpos.as<ss_real4<R>>(), ctx->cidx.as<uint32_t>(), ckeys_sorted,
                                   ctx->cell_start2.as<uint32_t>(), ctx->occ_sub.as<uint32_t>(), res->rho.as<R>(), want_nb ? 1 : 0,
-                                  ctx->nb_count.as<uint32_t>(), nullptr, nullptr, sizeof(R) == 4 && ctx->fastdiv_ok, own_list, own_rank + n_copies, n_owned_bound, st);
+                                  ctx->nb_count.as<uint32_t>(), nullptr, nullptr, sizeof(R) == 4 && ctx->fastdiv_ok, own_list, n_owned_dev, n_owned_bound, st);
             SS_HIP(ctx, hipEventRecord(ctx->ev[19], st));
             res->density_kernel_timed = true;
             if (want_nb) {
@@ -884,9 +940,9 @@ ss_status phase_begin(ss_context* ctx, const R* xyz, uint64_t n_in, const typena
                 if (total_nb >= (1ull << 32)) return fail(ctx, SS_ERR_UNSUPPORTED, "more than 2^32 neighbour entries");
                 res->n_neighbors = total_nb;
                 SS_HIP(ctx, res->nb_idx.reserve((size_t)total_nb * 4 + 16));
-                ss_launch_density_sub(P, n_copies, ctx->cpos.as<ss_real4<R>>(), ctx->cidx.as<uint32_t>(), ctx->ckeys_b.as<uint32_t>(),
+                ss_launch_density_sub(P, n_copies, ctx->cpos.as<ss_real4<R>>(), ctx->cidx.as<uint32_t>(), ckeys_sorted,
                                       ctx->cell_start2.as<uint32_t>(), ctx->occ_sub.as<uint32_t>(), res->rho.as<R>(), 2, nullptr,
-                                      res->nb_ptr.as<unsigned long long>(), res->nb_idx.as<uint32_t>(), false, own_list, own_rank + n_copies, n_owned_bound, st);
+                                      res->nb_ptr.as<unsigned long long>(), res->nb_idx.as<uint32_t>(), false, own_list, n_owned_dev, n_owned_bound, st);
             }
             res->has_neighbors = want_nb;
         } else {
@@ -916,43 +972,49 @@ ss_status phase_finish(ss_context* ctx, ss_result* res) {
     const bool host_input = res->host_input;
     const size_t ncells = (size_t)P.kdim[0] * P.kdim[1] * P.kdim[2];
     const size_t nblocks = (size_t)P.bt_dim[0] * P.bt_dim[1] * P.bt_dim[2];  // (the table window: the whole grid unless this is a shard)
+    s = ensure_mail(ctx);
+    if (s != SS_OK) return s;
     SS_HIP(ctx, hipEventRecord(ctx->ev[10], st));
     ss_launch_make_posvol(P, ctx->pos_sorted.as<ss_real4<R>>(), res->perm.as<uint32_t>(), res->rho.as<R>(), res->posvol.as<ss_real4<R>>(), res->posvol_by_index.as<ss_real4<R>>(), st);
     SS_HIP(ctx, hipEventRecord(ctx->ev[11], st));
 
     // ---- K3 prepare: active level-set blocks ----
+    if (nblocks >= (1ull << 32) - 2) return fail(ctx, SS_ERR_UNSUPPORTED, "more than 2^32 level-set blocks");
     SS_HIP(ctx, ctx->block_flag.reserve((nblocks + 1) * 4));
-    SS_HIP(ctx, ctx->block_rank.reserve((nblocks + 1) * 4));
-    SS_HIP(ctx, ctx->mc_flag.reserve((nblocks + 1) * 4));
-    SS_HIP(ctx, ctx->mc_rank.reserve((nblocks + 1) * 4));
-    SS_HIP(ctx, res->block_slot.reserve(nblocks * 4));
-    SS_HIP(ctx, res->mc_slot.reserve(nblocks * 4));
+    SS_HIP(ctx, res->block_slot.reserve(nblocks * 4 + 16));
+    SS_HIP(ctx, res->mc_slot.reserve(nblocks * 4 + 16));
+    SS_HIP(ctx, ctx->counter.reserve(64));
     SS_HIP(ctx, hipMemsetAsync(ctx->block_flag.p, 0, (nblocks + 1) * 4, st));
-    SS_HIP(ctx, hipMemsetAsync(ctx->mc_flag.as<uint32_t>() + nblocks, 0, 4, st));  // k_mark_mc_blocks writes the flags of all blocks
     if (n > 0) ss_launch_mark_blocks(P, ctx->cell_start.as<uint32_t>(), (uint32_t)ncells, ctx->block_flag.as<uint32_t>(), st);
-    s = exclusive_scan_u32<uint32_t>(ctx, ctx->block_flag.as<uint32_t>(), ctx->block_rank.as<uint32_t>(), nblocks + 1);
-    if (s != SS_OK) return s;
+    // flags -> slot table, block coordinates (list order = table order); the lists are filled up to their capacity: a call that has more active
+    // blocks than any before it repeats the scan with larger lists
     uint32_t n_active = 0;
-    SS_HIP(ctx, hipMemcpyAsync(&n_active, ctx->block_rank.as<uint32_t>() + nblocks, 4, hipMemcpyDeviceToHost, st));
-    SS_HIP(ctx, hipStreamSynchronize(st));
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        if (ctx->cap_active == 0) ctx->cap_active = (uint32_t)std::min<size_t>(nblocks, (size_t)1 << 16);
+        SS_HIP(ctx, res->active_xyz.reserve((size_t)ctx->cap_active * 12 + 16));
+        ZeroTaker Z;
+        s = reserve_zeros(ctx, ss_scan_state_words(nblocks) + 32, &Z);
+        if (s != SS_OK) return s;
+        const SSMailSlot m_active = mail_slot(ctx, 2);
+        ss_launch_active_blocks_scan(P, ctx->block_flag.as<uint32_t>(), (uint32_t)nblocks, ctx->cap_active, (uint32_t*)nullptr, res->block_slot.as<uint32_t>(),
+                                     res->active_xyz.as<uint32_t>(), Z.take(ss_scan_state_words(nblocks)), m_active, st);
+        unsigned long long v = 0;
+        s = mail_wait(ctx, m_active, &v);
+        if (s != SS_OK) return s;
+        n_active = (uint32_t)v;
+        if (n_active <= ctx->cap_active) break;
+        ctx->cap_active = (uint32_t)std::min<size_t>(nblocks, (size_t)n_active + n_active / 4 + 1024);
+    }
     res->n_active = n_active;
-    SS_HIP(ctx, res->active_list.reserve((size_t)n_active * 4 + 16));
     SS_HIP(ctx, res->G.reserve((size_t)n_active * SS_BLOCK_POINTS * sizeof(R) + 16));
     SS_HIP(ctx, res->blk_minmax.reserve((size_t)n_active * 2 * sizeof(R) + 16));
-    ss_launch_compact_blocks(ctx->block_flag.as<uint32_t>(), ctx->block_rank.as<uint32_t>(), (uint32_t)nblocks, res->active_list.as<uint32_t>(),
-                             res->block_slot.as<uint32_t>(), st);
-    SS_HIP(ctx, res->active_xyz.reserve((size_t)n_active * 12 + 16));
-    ss_launch_block_coords(P, res->active_list.as<uint32_t>(), n_active, res->active_xyz.as<uint32_t>(), st);
-    SS_HIP(ctx, ctx->counter.reserve(64));
-    SS_HIP(ctx, hipMemsetAsync(ctx->counter.p, 0, 64, st));
-    SS_HIP(ctx, hipEventRecord(ctx->ev[5], st));
 
-    // ---- K3: level-set splat (count -> arena offsets -> gather/order -> accumulate; ss_kernels.hip) ----
+    // ---- K3: level-set splat (ss_kernels.hip) ----
     {
         const bool checked_now = sizeof(R) == 4 && ctx->fastdiv_h != (float)P.h;
         ss_status fs = ensure_fast_div<R>(ctx, P.h, st);  // normally done before the densities already
         if (fs != SS_OK) return fs;
-        if (checked_now) SS_HIP(ctx, hipEventRecord(ctx->ev[5], st));  // keep the one-off check out of the splat timing
+        (void)checked_now;
     }
     const R prm_threshold = P.threshold;
     SSDevT<R> PK = P;
@@ -965,12 +1027,8 @@ ss_status phase_finish(ss_context* ctx, ss_result* res) {
     uint32_t* lg_flag = ctx->splat_overflow.as<uint32_t>();
     uint32_t* lg_rank = lg_flag + ((size_t)n_active + 1);
     uint32_t* lg_list = lg_rank + ((size_t)n_active + 1);
-    uint32_t* lg_slot = lg_list + ((size_t)n_active + 1);
     SS_HIP(ctx, ctx->splat_counts.reserve(((size_t)n_active + 1) * 4));
     uint64_t n_reserved = 0;
-    SS_HIP(ctx, ctx->counter.reserve(64));
-    SS_HIP(ctx, hipMemsetAsync(ctx->counter.p, 0, 64, st));
-    SS_HIP(ctx, hipEventRecord(ctx->ev[12], st));
     // Sub-blocks that a cheap lower bound certifies to lie inside the fluid are not evaluated in full (ss_kernels.hip,
     // splat_accumulate_block_wave).  Tiny jobs (< 1 k active blocks) skip the scheme: its extra launches cost more than it saves there.
     // ... and so do workloads where the previous call certified too few sub-blocks to pay for the classification pass (break-even:
@@ -997,58 +1055,66 @@ ss_status phase_finish(ss_context* ctx, ss_result* res) {
     unsigned long long* face_bits = ctx->splat_trunc.as<unsigned long long>();  // per block: faces of its sub-blocks with points outside the surface
     uint32_t* tr_flag = (uint32_t*)(face_bits + ((size_t)n_active + 2));        // per block: mask of the certified sub-blocks
     uint32_t* rd_flag = tr_flag + ((size_t)n_active + 1);         // ... and marching cubes will read it
-    uint32_t* rd_rank = rd_flag + ((size_t)n_active + 1);
-    uint32_t* rd_list = rd_rank + ((size_t)n_active + 1);
-    uint32_t* big = rd_list + ((size_t)n_active + 1);            // blocks with more candidates than a wave holds (count, list): the arena path
-    uint32_t* need_mask = big + ((size_t)n_active + 1);          // over-dense blocks: the sub-blocks k_splat_certify_big left to evaluate ...
-    uint32_t* exact_list = need_mask + ((size_t)n_active + 1);   // ... and the blocks that have such (count, list)
-    uint32_t* d_err = ctx->counter.as<uint32_t>() + 12;          // (ctx->counter: 64 bytes, zeroed above; words 0..7 hold statistics)
+    uint32_t* rd_unused = rd_flag + ((size_t)n_active + 1);
+    uint32_t* rd_list = rd_unused + ((size_t)n_active + 1);
+    uint32_t* need_mask = rd_list + ((size_t)n_active + 1);      // over-dense blocks: the sub-blocks k_splat_certify_big left to evaluate
     // over-dense blocks of an f32 job: certificates straight from the cells first, tiles only for the blocks somebody reads (ss_kernels.hip)
     const bool certify_big = sizeof(R) == 4 && !full_ls;
+    // zeroed words of the rest of this phase: the statistics counters, the states of the remaining scans, the length of the redo list
+    const size_t mc_cap_bound = std::min<size_t>(nblocks, (size_t)8 * (size_t)n_active);
+    ZeroTaker Z;
+    s = reserve_zeros(ctx, 16 + 3 * 64 * 2 + 3 * ss_scan_state_words((size_t)n_active + 1) + 2 * ss_scan_state_words(nblocks) + 2 * ss_scan_state_words(mc_cap_bound + 1) + 2 * ((size_t)n_active + 8) + 64, &Z);
+    if (s != SS_OK) return s;
+    uint32_t* big = Z.take((size_t)n_active + 2);         // blocks with more candidates than a wave holds (count, list): the arena path
+    uint32_t* exact_list = Z.take((size_t)n_active + 2);  // over-dense blocks with sub-blocks left to evaluate after k_splat_certify_big (count, list)
+    uint32_t* d_counters = Z.take(3 * 64 * 2);  // u64[3][64]: tile entries, blocks left truncated, certified sub-blocks (64 copies each, k_select_redo)
+    uint32_t* d_err = Z.take(4);                 // error flags
+    uint32_t* st_tiles = Z.take(ss_scan_state_words((size_t)n_active + 1));
+    uint32_t* st_large = Z.take(ss_scan_state_words((size_t)n_active + 1));
+    uint32_t* st_redo = Z.take(ss_scan_state_words((size_t)n_active + 1));
+    uint32_t* n_redo_dev = Z.take(4);
+    uint32_t* n_large_dev = Z.take(4);
     uint32_t n_big = 0;
+    SS_HIP(ctx, hipEventRecord(ctx->ev[5], st));
+    SS_HIP(ctx, hipEventRecord(ctx->ev[12], st));
     if (n_active) {
         // first pass, gather and accumulate in one kernel: the tiles of ordinary blocks stay in LDS
         ss_launch_splat_fused(PK, res->posvol.as<ss_real4<R>>(), res->perm.as<uint32_t>(), ctx->cell_start.as<uint32_t>(), res->active_xyz.as<uint32_t>(), n_active,
                               res->G.as<R>(), res->blk_minmax.as<ss_real2<R>>(), tr_flag, full_ls, nullptr, nullptr, nullptr, face_bits, ctx->splat_counts.as<uint32_t>(), big, st);
-        SS_HIP(ctx, hipMemcpyAsync(&n_big, big, 4, hipMemcpyDeviceToHost, st));
-        SS_HIP(ctx, hipStreamSynchronize(st));
+        const SSMailSlot m_big = mail_slot(ctx, 3);
+        ss_launch_publish_u32(big, m_big, st);
+        unsigned long long v = 0;
+        s = mail_wait(ctx, m_big, &v);
+        if (s != SS_OK) return s;
+        n_big = (uint32_t)v;
     }
     SS_HIP(ctx, hipEventRecord(ctx->ev[16], st));
     if (n_big) {
         if constexpr (sizeof(R) == 4) {
             if (certify_big) {
-                SS_HIP(ctx, hipMemsetAsync(exact_list, 0, 4, st));
                 ss_launch_splat_certify_big(PK, res->posvol.as<ss_real4<float>>(), ctx->cell_start.as<uint32_t>(), res->active_xyz.as<uint32_t>(), n_active,
                                             res->block_slot.as<uint32_t>(), ctx->splat_counts.as<uint32_t>(), res->blk_minmax.as<ss_real2<float>>(), tr_flag, face_bits, need_mask,
                                             exact_list, st);
             }
         }
         // over-dense blocks: bounds -> offsets -> tile arena -> gather (-> ordered list of the very large ones) -> workgroup per block
-        SS_HIP(ctx, ctx->splat_off.reserve(((size_t)n_active + 1) * 8));
+        SS_HIP(ctx, ctx->splat_off.reserve(((size_t)n_active + 2) * 8));
         SS_HIP(ctx, ctx->splat_bound.reserve(((size_t)n_active + 1) * 4));
         ss_launch_splat_bounds(PK, ctx->cell_start.as<uint32_t>(), res->active_xyz.as<uint32_t>(), n_active, ctx->splat_counts.as<uint32_t>(), ctx->splat_bound.as<uint32_t>(), st);
-        {   // tile_off = exclusive scan of the bounds in 64 bits (an arena can hold > 2^32 bytes)
-            auto it = rocprim::make_transform_iterator(ctx->splat_bound.as<uint32_t>(), WidenU32());
-            size_t bytes = 0;
-            SS_HIP(ctx, rocprim::exclusive_scan(nullptr, bytes, it, ctx->splat_off.as<unsigned long long>(), 0ull, (size_t)n_active + 1, rocprim::plus<unsigned long long>(), st));
-            SS_HIP(ctx, ctx->temp.reserve(bytes));
-            SS_HIP(ctx, rocprim::exclusive_scan(ctx->temp.p, bytes, it, ctx->splat_off.as<unsigned long long>(), 0ull, (size_t)n_active + 1, rocprim::plus<unsigned long long>(), st));
-        }
+        const SSMailSlot m_arena = mail_slot(ctx, 4);
+        ss_launch_tile_offsets_scan(ctx->splat_bound.as<uint32_t>(), n_active, ctx->splat_off.as<unsigned long long>(), st_tiles, m_arena, st);  // 64 bits: an arena can hold > 2^32 entries
         unsigned long long h_total = 0;
-        SS_HIP(ctx, hipMemcpyAsync(&h_total, ctx->splat_off.as<unsigned long long>() + n_active, 8, hipMemcpyDeviceToHost, st));
-        SS_HIP(ctx, hipStreamSynchronize(st));
+        s = mail_wait(ctx, m_arena, &h_total);
+        if (s != SS_OK) return s;
         n_reserved = h_total;
         SS_HIP(ctx, ctx->splat_tiles.reserve((size_t)n_reserved * sizeof(ss_real4<R>) + 64));
         SS_HIP(ctx, ctx->splat_tile_idx.reserve((size_t)n_reserved * 4 + 64));
-        SS_HIP(ctx, hipMemsetAsync(lg_flag + n_active, 0, 4, st));
         ss_launch_splat_gather(PK, res->posvol.as<ss_real4<R>>(), res->perm.as<uint32_t>(), ctx->cell_start.as<uint32_t>(), res->active_xyz.as<uint32_t>(), n_active,
                                ctx->splat_off.as<unsigned long long>(), ctx->splat_tiles.as<ss_real4<R>>(), ctx->splat_tile_idx.as<uint32_t>(), ctx->splat_counts.as<uint32_t>(), lg_flag, st);
         // very large tiles: flags -> ordered list on the device; the workgroup-level gather reads its length there
-        s = exclusive_scan_u32<uint32_t>(ctx, lg_flag, lg_rank, (size_t)n_active + 1);
-        if (s != SS_OK) return s;
-        ss_launch_compact_blocks(lg_flag, lg_rank, n_active, lg_list, lg_slot, st);
+        ss_launch_flag_scan(lg_flag, n_active, nullptr, lg_list, n_large_dev, st_large, SSMailSlot{}, st);
         ss_launch_splat_gather_large(PK, res->posvol.as<ss_real4<R>>(), res->posvol_by_index.as<ss_real4<R>>(), res->perm.as<uint32_t>(), ctx->cell_start.as<uint32_t>(),
-                                     res->active_xyz.as<uint32_t>(), lg_list, lg_rank + n_active, ctx->splat_counts.as<uint32_t>(), ctx->splat_off.as<unsigned long long>(),
+                                     res->active_xyz.as<uint32_t>(), lg_list, n_large_dev, ctx->splat_counts.as<uint32_t>(), ctx->splat_off.as<unsigned long long>(),
                                      ctx->splat_tiles.as<ss_real4<R>>(), ctx->splat_tile_idx.as<uint32_t>(), st);
     }
     SS_HIP(ctx, hipEventRecord(ctx->ev[17], st));
@@ -1056,66 +1122,50 @@ ss_status phase_finish(ss_context* ctx, ss_result* res) {
         ss_launch_splat_accumulate_big(PK, ctx->splat_tiles.as<ss_real4<R>>(), ctx->splat_tile_idx.as<uint32_t>(), ctx->splat_off.as<unsigned long long>(), ctx->splat_counts.as<uint32_t>(),
                                        res->active_xyz.as<uint32_t>(), res->G.as<R>(), res->blk_minmax.as<ss_real2<R>>(), tr_flag, full_ls, false, certify_big,
                                        certify_big ? need_mask : nullptr, face_bits, certify_big ? exact_list : big, d_err, st);
-    if (n_active) {
-        s = sum_u32_to_u64(ctx, ctx->splat_counts.as<uint32_t>(), n_active, ctx->counter.as<unsigned long long>());  // tile entries (statistics)
-        if (s != SS_OK) return s;
-    }
     SS_HIP(ctx, hipEventRecord(ctx->ev[13], st));
-    if (n_active && !full_ls) {
-        {   // certified sub-blocks = set bits of the per-block masks (decides the next call's strategy)
-            auto it = rocprim::make_transform_iterator(tr_flag, PopcountU32());
-            size_t bytes = 0;
-            SS_HIP(ctx, rocprim::reduce(nullptr, bytes, it, ctx->counter.as<unsigned long long>() + 2, 0ull, (size_t)n_active, rocprim::plus<unsigned long long>(), st));
-            SS_HIP(ctx, ctx->temp.reserve(bytes));
-            SS_HIP(ctx, rocprim::reduce(ctx->temp.p, bytes, it, ctx->counter.as<unsigned long long>() + 2, 0ull, (size_t)n_active, rocprim::plus<unsigned long long>(), st));
-        }
-    }
 
-    // ---- K4 prepare: MC blocks = blocks whose 2x2x2 level-set neighbourhood straddles the threshold ----
-    ss_launch_mark_mc_blocks(P, res->block_slot.as<uint32_t>(), res->blk_minmax.as<ss_real2<R>>(), (uint32_t)nblocks, ctx->mc_flag.as<uint32_t>(), st);
-    // second pass of the splat: truncated blocks that marching cubes is going to read are completed (list and count stay on the device)
+    // second pass of the splat: certified sub-blocks with a face neighbour outside the surface are completed (list and count stay on the device);
+    // the statistics of the first pass are taken by the same kernel
     SS_HIP(ctx, hipEventRecord(ctx->ev[14], st));
+    if (n_active)
+        ss_launch_select_redo(P, res->active_xyz.as<uint32_t>(), n_active, res->block_slot.as<uint32_t>(), full_ls ? nullptr : tr_flag, face_bits, rd_flag,
+                              ctx->splat_counts.as<uint32_t>(), reinterpret_cast<unsigned long long*>(d_counters), big, st);
     if (n_active && !full_ls) {
-        ss_launch_select_redo(P, res->active_xyz.as<uint32_t>(), n_active, res->block_slot.as<uint32_t>(), tr_flag, face_bits, rd_flag, st);
-        {   // rank of every block with a non-empty mask
-            auto it = rocprim::make_transform_iterator(rd_flag, NonZeroAsU32());
-            size_t bytes = 0;
-            SS_HIP(ctx, rocprim::exclusive_scan(nullptr, bytes, it, rd_rank, 0u, (size_t)n_active + 1, rocprim::plus<uint32_t>(), st));
-            SS_HIP(ctx, ctx->temp.reserve(bytes));
-            SS_HIP(ctx, rocprim::exclusive_scan(ctx->temp.p, bytes, it, rd_rank, 0u, (size_t)n_active + 1, rocprim::plus<uint32_t>(), st));
-        }
-        ss_launch_compact_blocks(rd_flag, rd_rank, n_active, rd_list, lg_slot, st);
+        ss_launch_flag_scan(rd_flag, n_active, nullptr, rd_list, n_redo_dev, st_redo, SSMailSlot{}, st);
         ss_launch_splat_fused(PK, res->posvol.as<ss_real4<R>>(), res->perm.as<uint32_t>(), ctx->cell_start.as<uint32_t>(), res->active_xyz.as<uint32_t>(), n_active,
-                              res->G.as<R>(), res->blk_minmax.as<ss_real2<R>>(), tr_flag, true, rd_list, rd_rank + n_active, rd_flag, face_bits, ctx->splat_counts.as<uint32_t>(), big, st);
+                              res->G.as<R>(), res->blk_minmax.as<ss_real2<R>>(), tr_flag, true, rd_list, n_redo_dev, rd_flag, face_bits, ctx->splat_counts.as<uint32_t>(), big, st);
         if (n_big)  // (the list kernel re-collected the large blocks among the selected ones in big[])
             ss_launch_splat_accumulate_big(PK, ctx->splat_tiles.as<ss_real4<R>>(), ctx->splat_tile_idx.as<uint32_t>(), ctx->splat_off.as<unsigned long long>(),
                                            ctx->splat_counts.as<uint32_t>(), res->active_xyz.as<uint32_t>(), res->G.as<R>(), res->blk_minmax.as<ss_real2<R>>(), tr_flag, true, true, false,
                                            rd_flag, face_bits, big, d_err, st);
-        s = count_nonzero_u32(ctx, tr_flag, n_active, ctx->counter.as<unsigned long long>() + 1);  // blocks still truncated (statistics)
-        if (s != SS_OK) return s;
     }
     SS_HIP(ctx, hipEventRecord(ctx->ev[15], st));
     SS_HIP(ctx, hipEventRecord(ctx->ev[6], st));
-    s = exclusive_scan_u32<uint32_t>(ctx, ctx->mc_flag.as<uint32_t>(), ctx->mc_rank.as<uint32_t>(), nblocks + 1);
-    if (s != SS_OK) return s;
+
+    // ---- K4 prepare: MC blocks = blocks whose 2x2x2 level-set neighbourhood straddles the threshold (the flag is the scan's input) ----
     uint32_t n_mc = 0;
-    SS_HIP(ctx, hipMemcpyAsync(&n_mc, ctx->mc_rank.as<uint32_t>() + nblocks, 4, hipMemcpyDeviceToHost, st));
-    SS_HIP(ctx, hipStreamSynchronize(st));
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        if (ctx->cap_mc == 0) ctx->cap_mc = (uint32_t)std::min<size_t>(mc_cap_bound, (size_t)1 << 16);
+        if ((size_t)ctx->cap_mc > mc_cap_bound) ctx->cap_mc = (uint32_t)mc_cap_bound;
+        SS_HIP(ctx, res->mc_xyz.reserve((size_t)ctx->cap_mc * 12 + 16));
+        const SSMailSlot m_mc = mail_slot(ctx, 5);
+        ss_launch_mc_blocks_scan(P, res->block_slot.as<uint32_t>(), res->blk_minmax.as<ss_real2<R>>(), (uint32_t)nblocks, ctx->cap_mc, (uint32_t*)nullptr, res->mc_slot.as<uint32_t>(),
+                                 res->mc_xyz.as<uint32_t>(), Z.take(ss_scan_state_words(nblocks)), m_mc, st);
+        unsigned long long v = 0;
+        s = mail_wait(ctx, m_mc, &v);
+        if (s != SS_OK) return s;
+        n_mc = (uint32_t)v;
+        if (n_mc <= ctx->cap_mc) break;
+        ctx->cap_mc = (uint32_t)std::min<size_t>(mc_cap_bound, (size_t)n_mc + n_mc / 4 + 1024);
+    }
     res->n_mc = n_mc;
-    SS_HIP(ctx, res->mc_list.reserve((size_t)n_mc * 4 + 16));
-    ss_launch_compact_blocks(ctx->mc_flag.as<uint32_t>(), ctx->mc_rank.as<uint32_t>(), (uint32_t)nblocks, res->mc_list.as<uint32_t>(),
-                             res->mc_slot.as<uint32_t>(), st);
 
     // ---- K4: MC classification + counts ----
     SS_HIP(ctx, res->masks.reserve((size_t)n_mc * 24 * 8 + 16));
     SS_HIP(ctx, ctx->vcount.reserve(((size_t)n_mc + 1) * 4));
     SS_HIP(ctx, ctx->tcount.reserve(((size_t)n_mc + 1) * 4));
-    SS_HIP(ctx, res->vbase.reserve(((size_t)n_mc + 1) * 4));
-    SS_HIP(ctx, res->tbase.reserve(((size_t)n_mc + 1) * 4));
-    SS_HIP(ctx, hipMemsetAsync(ctx->vcount.as<uint32_t>() + n_mc, 0, 4, st));  // (k_mc_count stores the counts of all blocks; the scans end on a 0)
-    SS_HIP(ctx, hipMemsetAsync(ctx->tcount.as<uint32_t>() + n_mc, 0, 4, st));
-    SS_HIP(ctx, res->mc_xyz.reserve((size_t)n_mc * 12 + 16));
-    ss_launch_block_coords(P, res->mc_list.as<uint32_t>(), n_mc, res->mc_xyz.as<uint32_t>(), st);
+    SS_HIP(ctx, res->vbase.reserve(((size_t)n_mc + 2) * 4));
+    SS_HIP(ctx, res->tbase.reserve(((size_t)n_mc + 2) * 4));
     SS_HIP(ctx, ctx->mc_nb.reserve((size_t)n_mc * 96 + 64));
     ss_launch_mc_neighbours(P, res->mc_xyz.as<uint32_t>(), n_mc, res->block_slot.as<uint32_t>(), res->mc_slot.as<uint32_t>(), full_ls ? nullptr : tr_flag, ctx->mc_nb.as<uint32_t>(), st);
     SS_HIP(ctx, hipEventRecord(ctx->ev[20], st));
@@ -1123,28 +1173,23 @@ ss_status phase_finish(ss_context* ctx, ss_result* res) {
                        ctx->vcount.as<uint32_t>(), ctx->tcount.as<uint32_t>(), st);
     SS_HIP(ctx, hipEventRecord(ctx->ev[21], st));
     SS_HIP(ctx, hipEventRecord(ctx->ev[7], st));
-    // ---- "stitching": global numbering by prefix sums ----
-    s = exclusive_scan_u32<uint32_t>(ctx, ctx->vcount.as<uint32_t>(), res->vbase.as<uint32_t>(), (size_t)n_mc + 1);
+    // ---- "stitching": global numbering by prefix sums (vertex and triangle counts in one scan) ----
+    const SSMailSlot m_tot = mail_slot(ctx, 6), m_stat0 = mail_slot(ctx, 7), m_stat1 = mail_slot(ctx, 8), m_stat2 = mail_slot(ctx, 9), m_stat3 = mail_slot(ctx, 10);
+    ss_launch_mc_offsets_scan(ctx->vcount.as<uint32_t>(), ctx->tcount.as<uint32_t>(), n_mc, res->vbase.as<uint32_t>(), res->tbase.as<uint32_t>(), Z.take(ss_scan_state_words((size_t)n_mc + 1)), m_tot, st);
+    ss_launch_publish_stats(reinterpret_cast<const unsigned long long*>(d_counters), n_redo_dev, n_large_dev, d_err, m_stat0, m_stat1, m_stat2, m_stat3, st);
+    unsigned long long v_tot = 0, n_cand = 0, n_trunc_left = 0, n_cert_waves = 0, v_misc = 0;
+    s = mail_wait(ctx, m_tot, &v_tot);
     if (s != SS_OK) return s;
-    s = exclusive_scan_u32<uint32_t>(ctx, ctx->tcount.as<uint32_t>(), res->tbase.as<uint32_t>(), (size_t)n_mc + 1);
+    s = mail_wait(ctx, m_stat0, &n_cand);
     if (s != SS_OK) return s;
-    uint32_t totals[2] = {0, 0};
-    SS_HIP(ctx, hipMemcpyAsync(&totals[0], res->vbase.as<uint32_t>() + n_mc, 4, hipMemcpyDeviceToHost, st));
-    SS_HIP(ctx, hipMemcpyAsync(&totals[1], res->tbase.as<uint32_t>() + n_mc, 4, hipMemcpyDeviceToHost, st));
-    unsigned long long n_cand = 0;
-    uint32_t n_large = 0, h_err = 0;
-    SS_HIP(ctx, hipMemcpyAsync(&n_cand, ctx->counter.p, 8, hipMemcpyDeviceToHost, st));
-    if (n_big) SS_HIP(ctx, hipMemcpyAsync(&h_err, d_err, 4, hipMemcpyDeviceToHost, st));
-    if (n_active) SS_HIP(ctx, hipMemcpyAsync(&n_large, lg_rank + n_active, 4, hipMemcpyDeviceToHost, st));
-    unsigned long long n_trunc_left = 0, n_cert_waves = 0;
-    uint32_t n_redo = 0;
-    if (n_active && !full_ls) {
-        SS_HIP(ctx, hipMemcpyAsync(&n_trunc_left, ctx->counter.as<unsigned long long>() + 1, 8, hipMemcpyDeviceToHost, st));
-        SS_HIP(ctx, hipMemcpyAsync(&n_redo, rd_rank + n_active, 4, hipMemcpyDeviceToHost, st));
-        SS_HIP(ctx, hipMemcpyAsync(&n_cert_waves, ctx->counter.as<unsigned long long>() + 2, 8, hipMemcpyDeviceToHost, st));
-    }
-    SS_HIP(ctx, hipStreamSynchronize(st));
-    const uint64_t nv = totals[0], nt = totals[1];
+    s = mail_wait(ctx, m_stat1, &n_trunc_left);
+    if (s != SS_OK) return s;
+    s = mail_wait(ctx, m_stat2, &n_cert_waves);
+    if (s != SS_OK) return s;
+    s = mail_wait(ctx, m_stat3, &v_misc);  // n_redo | n_large << 24 | err << 56 ... see k_publish_stats
+    if (s != SS_OK) return s;
+    const uint32_t n_redo = (uint32_t)(v_misc & 0xFFFFFFFull), n_large = (uint32_t)((v_misc >> 28) & 0xFFFFFFFull), h_err = (uint32_t)(v_misc >> 56);
+    const uint64_t nv = (uint32_t)v_tot, nt = (uint32_t)(v_tot >> 32);
     if (h_err) return fail(ctx, SS_ERR_UNKNOWN, "internal error: a level-set block without a tile was asked for values (k_big_tile_select)");
     if (nt * 3 >= (1ull << 32)) return fail(ctx, SS_ERR_UNSUPPORTED, "more than 2^32/3 triangles in one call are not supported by this build");
     SS_HIP(ctx, res->vertices.reserve(nv * 3 * sizeof(R) + 16));
@@ -1543,6 +1588,9 @@ void ss_context_destroy(ss_context* c) {
                       &c->nb_count, &c->nb_tmp, &c->occ_sub, &c->ckeys_a, &c->ckeys_b, &c->cvals_a, &c->cidx, &c->cpos, &c->cell_count2, &c->cell_start2, &c->gboxes, &c->fastdiv_scratch, &c->splat_overflow, &c->mc_nb, &c->splat_tile_idx, &c->splat_tiles, &c->splat_counts, &c->splat_off, &c->splat_bound, &c->splat_trunc, &c->own_flag})
         b->release();
     for (DevBuf& b : c->post_pool) b.release();
+    c->zeros.release();
+    c->sort_work.release();
+    if (c->mail_host) (void)hipHostFree(c->mail_host);
     if (c->ev_ok)
         for (int i = 0; i < 22; ++i) (void)hipEventDestroy(c->ev[i]);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);

@@ -797,7 +797,7 @@ ss_status dist_reconstruct(ss_comm* c, const R* xyz_in, uint64_t n_local, const 
     if (n_local) {
         SS_HIP(ctx, ctx->aabb_partial.reserve(1024 * 6 * sizeof(R)));
         SS_HIP(ctx, ctx->aabb_out.reserve(6 * sizeof(R)));
-        ss_launch_aabb<R>(d_xyz, (uint32_t)n_local, ctx->aabb_partial.as<R>(), ctx->aabb_out.as<R>(), st);
+        ss_launch_aabb<R>(d_xyz, (uint32_t)n_local, ctx->aabb_partial.as<R>(), ctx->aabb_out.as<R>(), SSMailSlot{}, st);
         R h6[6];
         SS_HIP(ctx, hipMemcpyAsync(h6, ctx->aabb_out.p, 6 * sizeof(R), hipMemcpyDeviceToHost, st));
         SS_HIP(ctx, hipStreamSynchronize(st));

@@ -9,6 +9,7 @@
 #include "../../include/splashsurf_hip.h"
 #include "ss_device.h"
 #include "ss_global.h"
+#include "ss_prims.h"
 
 struct DevBuf {
     void* p = nullptr;
@@ -98,6 +99,13 @@ struct ss_context {
     DevBuf mc_nb;  // per MC block: slots and certified masks of its eight level-set blocks
     DevBuf splat_tile_idx;  // particle index of every arena entry (tiles the wave-per-block kernel orders itself)
     DevBuf splat_tiles, splat_counts, splat_off, splat_bound;  // tile arena (index-ordered candidates of every block), per-block counts, 64-bit offsets, size bounds
+    // counts the host waits for arrive in pinned host memory mapped into the device (SSMailSlot, ss_prims.h): 16 slots of {value, seq}
+    unsigned long long* mail_host = nullptr;
+    unsigned long long* mail_dev = nullptr;
+    unsigned long long mail_seq = 0;
+    DevBuf zeros;     // zero-initialised words of one phase: scan states, counters (one memset per phase)
+    DevBuf sort_work; // work buffer of ss_radix_sort_pairs
+    uint32_t cap_active = 0, cap_mc = 0;  // capacities of the block lists (grow-only; a call that needs more repeats the scan that fills them)
     // post-processing: grow-only scratch slots handed out in call order (reset at the start of every ss_post_* call)
     DevBuf post_pool[24];
     int post_pool_next = 0;

@@ -2,9 +2,10 @@
 // Templated on the reference's Real type R (float / double); explicit instantiations live in ss_kernels.hip.
 #pragma once
 #include "ss_device.h"
+#include "ss_prims.h"
 
 template <class R>
-void ss_launch_aabb(const R* d_xyz, uint32_t n, R* d_partial, R* d_out6, hipStream_t st);
+void ss_launch_aabb(const R* d_xyz, uint32_t n, R* d_partial, R* d_out6, SSMailSlot mail, hipStream_t st);
 template <class R>
 void ss_launch_inside_flags(const R* d_xyz, uint32_t n, const R amin[3], const R amax[3], uint8_t* f8, uint32_t* f32, hipStream_t st);
 template <class R>
@@ -45,7 +46,8 @@ template <class R>
 void ss_launch_splat_accumulate_big(const SSDevT<R>& P, const ss_real4<R>* arena, const uint32_t* arena_idx, const unsigned long long* tile_off, const uint32_t* counts, const uint32_t* active_xyz, R* G, ss_real2<R>* blk_minmax, uint32_t* trunc, bool full_levelset, bool second_pass, bool exact_first, const uint32_t* redo_mask, unsigned long long* facebits, const uint32_t* big, uint32_t* err, hipStream_t st);
 void ss_launch_splat_certify_big(const SSDevT<float>& P, const ss_real4<float>* posvol, const uint32_t* cell_start, const uint32_t* active_xyz, uint32_t n_active, const uint32_t* block_slot, uint32_t* counts, ss_real2<float>* blk_minmax, uint32_t* trunc, unsigned long long* facebits, uint32_t* need_mask, uint32_t* exact_list, hipStream_t st);
 template <class R>
-void ss_launch_select_redo(const SSDevT<R>& P, const uint32_t* active_xyz, uint32_t n_active, const uint32_t* block_slot, const uint32_t* trunc, const unsigned long long* facebits, uint32_t* redo_mask, hipStream_t st);
+void ss_launch_select_redo(const SSDevT<R>& P, const uint32_t* active_xyz, uint32_t n_active, const uint32_t* block_slot, const uint32_t* trunc, const unsigned long long* facebits, uint32_t* redo_mask, const uint32_t* counts, unsigned long long* stats, uint32_t* big, hipStream_t st);
+void ss_launch_publish_stats(const unsigned long long* stats, const uint32_t* n_redo, const uint32_t* n_large, const uint32_t* err, SSMailSlot m0, SSMailSlot m1, SSMailSlot m2, SSMailSlot m3, hipStream_t st);
 template <class R>
 void ss_launch_mc_neighbours(const SSDevT<R>& P, const uint32_t* mc_xyz, uint32_t n_mc, const uint32_t* block_slot, const uint32_t* mc_slot, const uint32_t* certified, uint32_t* mc_nb, hipStream_t st);
 template <class R>
@@ -56,3 +58,20 @@ void ss_launch_stream_probe(bool copy, const void* in, void* out, size_t n_float
 void ss_launch_widen(const uint32_t* in, size_t n, unsigned long long* out, hipStream_t st);
 template <class R>
 void ss_launch_levelset_box(const SSDevT<R>& P, const R* G, const uint32_t* block_slot, const int lo[3], const int ext[3], R* out, hipStream_t st);
+
+// fused scans of the host flow (one dispatch each, ss_prims.h)
+template <class R>
+void ss_launch_sorted_gather_runs(uint32_t n, const R* xyz, const uint32_t* perm, ss_real4<R>* pos_sorted, const uint32_t* sorted_keys, uint32_t ncells, uint32_t* first, hipStream_t st);
+void ss_launch_cell_table_scan(const uint32_t* first, uint32_t ncells, uint32_t* cell_start, uint32_t* state, hipStream_t st);
+template <class R>
+void ss_launch_classify_scan(const SSDevT<R>& P, const R* xyz, uint32_t* copy_offset, uint32_t* sub_flag, uint32_t* state, SSMailSlot mail, hipStream_t st);
+void ss_launch_flag_scan(const uint32_t* flag, uint32_t n, uint32_t* rank, uint32_t* list, uint32_t* total_dev, uint32_t* state, SSMailSlot mail, hipStream_t st);
+template <class R>
+void ss_launch_owned_scan(const SSDevT<R>& P, uint32_t n_copies, const ss_real4<R>* cpos, const uint32_t* ckey, const uint32_t* occ_sub, uint32_t* own_list, uint32_t* n_owned_dev, uint32_t* state, hipStream_t st);
+template <class R>
+void ss_launch_active_blocks_scan(const SSDevT<R>& P, const uint32_t* block_flag, uint32_t nblocks, uint32_t cap, uint32_t* list, uint32_t* slot, uint32_t* xyz, uint32_t* state, SSMailSlot mail, hipStream_t st);
+template <class R>
+void ss_launch_mc_blocks_scan(const SSDevT<R>& P, const uint32_t* block_slot, const ss_real2<R>* blk_minmax, uint32_t nblocks, uint32_t cap, uint32_t* mc_list, uint32_t* mc_slot, uint32_t* mc_xyz, uint32_t* state, SSMailSlot mail, hipStream_t st);
+void ss_launch_mc_offsets_scan(const uint32_t* vcount, const uint32_t* tcount, uint32_t n_mc, uint32_t* vbase, uint32_t* tbase, uint32_t* state, SSMailSlot mail, hipStream_t st);
+void ss_launch_tile_offsets_scan(const uint32_t* bound, uint32_t n, unsigned long long* off, uint32_t* state, SSMailSlot mail, hipStream_t st);
+void ss_launch_publish_u32(const uint32_t* src, SSMailSlot mail, hipStream_t st);

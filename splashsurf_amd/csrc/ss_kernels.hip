@@ -22,6 +22,7 @@
 
 #include "ss_device.h"
 #include "ss_kernels.h"
+#include "ss_prims.h"
 
 // MC table in emitted (winding-flipped) order, see tools/gen_mc_table.py
 __constant__ __attribute__((aligned(16))) int8_t c_mc_table[256][16] = {
@@ -81,7 +82,7 @@ __global__ __launch_bounds__(256) void k_aabb_partial(const R* __restrict__ xyz,
 }
 
 template <class R>
-__global__ __launch_bounds__(256) void k_aabb_final(const R* __restrict__ partial, uint32_t nblocks, R* __restrict__ out6) {
+__global__ __launch_bounds__(256) void k_aabb_final(const R* __restrict__ partial, uint32_t nblocks, R* __restrict__ out6, SSMailSlot mail) {
     __shared__ R s_min[3][256];
     __shared__ R s_max[3][256];
     R mn[3] = {std::numeric_limits<R>::infinity(), std::numeric_limits<R>::infinity(), std::numeric_limits<R>::infinity()}, mx[3] = {-std::numeric_limits<R>::infinity(), -std::numeric_limits<R>::infinity(), -std::numeric_limits<R>::infinity()};
@@ -103,20 +104,22 @@ __global__ __launch_bounds__(256) void k_aabb_final(const R* __restrict__ partia
             }
         __syncthreads();
     }
-    if (threadIdx.x == 0)
+    if (threadIdx.x == 0) {
         for (int d = 0; d < 3; ++d) {
             out6[d] = s_min[d][0];
             out6[3 + d] = s_max[d][0];
         }
+        ss_mail_post(mail, 0ull);  // (out6 may be pinned host memory: the release of the post orders the six stores before it)
+    }
 }
 
 template <class R>
-void ss_launch_aabb(const R* d_xyz, uint32_t n, R* d_partial, R* d_out6, hipStream_t st) {
+void ss_launch_aabb(const R* d_xyz, uint32_t n, R* d_partial, R* d_out6, SSMailSlot mail, hipStream_t st) {
     uint32_t blocks = (n + 255) / 256;
     if (blocks > 1024) blocks = 1024;
     if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL(k_aabb_partial<R>, dim3(blocks), dim3(256), 0, st, d_xyz, n, d_partial);
-    hipLaunchKernelGGL(k_aabb_final<R>, dim3(1), dim3(256), 0, st, d_partial, blocks, d_out6);
+    hipLaunchKernelGGL(k_aabb_final<R>, dim3(1), dim3(256), 0, st, d_partial, blocks, d_out6, mail);
 }
 
 // =====================================================================================================
@@ -176,7 +179,7 @@ __global__ __launch_bounds__(256) void k_cell_keys(SSDevT<R> P, const R* __restr
     ss_particle_cell(P, xyz[3 * (size_t)i], xyz[3 * (size_t)i + 1], xyz[3 * (size_t)i + 2], K);
     uint32_t key = ss_cell_key(P, K[0], K[1], K[2]);
     keys[i] = key;
-    vals[i] = i;
+    if (vals) vals[i] = i;  // (null: the sort takes the positions as the values itself)
 }
 
 // Cell table from the SORTED keys (no histogram atomics): first[c] = position of the first entry of cell c, written at the run
@@ -2352,17 +2355,19 @@ __global__ __launch_bounds__(256) void k_big_tile_select(SSDevT<R> P, const uint
 // i.e. at points with a 6-neighbour outside.  Such a neighbour of a point of a certified sub-block lies in the face-adjacent
 // sub-block, on the touching face: the sub-block is completed iff one of its six neighbours reports an outside point there
 // (facebits, written by the first pass).  A neighbour in a block without particles in reach is all zero = outside.
+// The statistics of the first pass are taken on the way: stats[0][.] += tile entries, stats[2][.] += certified sub-blocks,
+// stats[1][.] += blocks that stay truncated after the second pass (certified sub-blocks nobody reads); 64 copies of every counter.
+// trunc == nullptr (no two-pass scheme): only the tile entries are summed.  big[0], the length of the list of over-dense blocks, is
+// reset for the second launch of the splat kernel.
 template <class R>
 __global__ __launch_bounds__(256) void k_select_redo(SSDevT<R> P, const uint32_t* __restrict__ active_xyz, uint32_t n_active, const uint32_t* __restrict__ block_slot,
                                                      const uint32_t* __restrict__ trunc, const unsigned long long* __restrict__ facebits,
-                                                     uint32_t* __restrict__ redo_mask) {
+                                                     uint32_t* __restrict__ redo_mask, const uint32_t* __restrict__ counts, unsigned long long* __restrict__ stats,
+                                                     uint32_t* __restrict__ big) {
     const uint32_t a = blockIdx.x * blockDim.x + threadIdx.x;
-    if (a > n_active) return;
-    if (a == n_active) {
-        redo_mask[a] = 0u;  // the scan runs over n_active + 1 entries
-        return;
-    }
-    const uint32_t cert = trunc[a];
+    if (a == 0 && big) big[0] = 0u;
+    const bool live = a < n_active;
+    const uint32_t cert = (live && trunc) ? trunc[a] : 0u;
     uint32_t redo = 0;
     if (cert) {
         const int b[3] = {(int)active_xyz[3 * (size_t)a], (int)active_xyz[3 * (size_t)a + 1], (int)active_xyz[3 * (size_t)a + 2]};
@@ -2398,7 +2403,45 @@ __global__ __launch_bounds__(256) void k_select_redo(SSDevT<R> P, const uint32_t
             if (need) redo |= 1u << sb;
         }
     }
-    redo_mask[a] = redo;
+    if (live && trunc) redo_mask[a] = redo;
+    // statistics
+    unsigned long long c0 = live ? (unsigned long long)counts[a] : 0ull, c1 = (cert & ~redo) ? 1ull : 0ull, c2 = (unsigned long long)__popc(cert);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        c0 += __shfl_xor(c0, off);
+        c1 += __shfl_xor(c1, off);
+        c2 += __shfl_xor(c2, off);
+    }
+    // one atomic per counter and WORKGROUP, spread over 64 copies of the counters (k_publish_stats adds them up): atomics on one address
+    // serialise in its L2 channel -- 65 k of them (one per wave) cost 0.7 ms on S10M-tank
+    __shared__ unsigned long long s_part[4][3];
+    if ((threadIdx.x & 63u) == 0u) {
+        s_part[threadIdx.x >> 6][0] = c0;
+        s_part[threadIdx.x >> 6][1] = c1;
+        s_part[threadIdx.x >> 6][2] = c2;
+    }
+    __syncthreads();
+    if (threadIdx.x < 3u) {
+        const unsigned long long v = s_part[0][threadIdx.x] + s_part[1][threadIdx.x] + s_part[2][threadIdx.x] + s_part[3][threadIdx.x];
+        if (v) atomicAdd(&stats[(size_t)threadIdx.x * 64u + (blockIdx.x & 63u)], v);
+    }
+}
+
+// the statistics counters and the lengths of the device-side lists, posted for the host in one dispatch
+__global__ void k_publish_stats(const unsigned long long* __restrict__ stats, const uint32_t* __restrict__ n_redo, const uint32_t* __restrict__ n_large, const uint32_t* __restrict__ err,
+                                SSMailSlot m0, SSMailSlot m1, SSMailSlot m2, SSMailSlot m3) {
+    unsigned long long t[3] = {0ull, 0ull, 0ull};
+    for (int k = 0; k < 3; ++k)
+        for (int j = 0; j < 64; ++j) t[k] += stats[k * 64 + j];
+    ss_mail_post(m0, t[0]);
+    ss_mail_post(m1, t[1]);
+    ss_mail_post(m2, t[2]);
+    const unsigned long long r = (unsigned long long)(n_redo[0] & 0xFFFFFFFu), l = (unsigned long long)(n_large[0] & 0xFFFFFFFu), e = (unsigned long long)(err[0] & 0xFFu);
+    ss_mail_post(m3, r | (l << 28) | (e << 56));
+}
+void ss_launch_publish_stats(const unsigned long long* stats, const uint32_t* n_redo, const uint32_t* n_large, const uint32_t* err, SSMailSlot m0, SSMailSlot m1, SSMailSlot m2, SSMailSlot m3,
+                             hipStream_t st) {
+    hipLaunchKernelGGL(k_publish_stats, dim3(1), dim3(1), 0, st, stats, n_redo, n_large, err, m0, m1, m2, m3);
 }
 
 template <class R>
@@ -2447,7 +2490,7 @@ void ss_launch_splat_fused(const SSDevT<R>& P, const ss_real4<R>* posvol, const 
                            R* G, ss_real2<R>* blk_minmax, uint32_t* trunc, bool full_levelset, const uint32_t* list, const uint32_t* n_list_dev,
                            const uint32_t* redo_mask, unsigned long long* facebits, uint32_t* counts, uint32_t* big, hipStream_t st) {
     if (!n_active) return;
-    (void)hipMemsetAsync(big, 0, 4, st);
+    // (big[0] must be 0: the host takes big[] from its zeroed words for the first launch, k_select_redo resets it for the second)
     const dim3 grid(list ? 32768u : ss_xcd_chunked_grid(n_active));
 #define SS_FUSED(A)                                                                                                                                          \
     do {                                                                                                                                                     \
@@ -2496,8 +2539,8 @@ void ss_launch_splat_certify_big(const SSDevT<float>& P, const ss_real4<float>* 
 
 template <class R>
 void ss_launch_select_redo(const SSDevT<R>& P, const uint32_t* active_xyz, uint32_t n_active, const uint32_t* block_slot, const uint32_t* trunc,
-                           const unsigned long long* facebits, uint32_t* redo_mask, hipStream_t st) {
-    hipLaunchKernelGGL(k_select_redo<R>, dim3((n_active + 1u + 255u) / 256u), dim3(256), 0, st, P, active_xyz, n_active, block_slot, trunc, facebits, redo_mask);
+                           const unsigned long long* facebits, uint32_t* redo_mask, const uint32_t* counts, unsigned long long* stats, uint32_t* big, hipStream_t st) {
+    hipLaunchKernelGGL(k_select_redo<R>, dim3((n_active + 255u) / 256u), dim3(256), 0, st, P, active_xyz, n_active, block_slot, trunc, facebits, redo_mask, counts, stats, big);
 }
 
 // =====================================================================================================
@@ -2999,9 +3042,249 @@ void ss_launch_levelset_box(const SSDevT<R>& P, const R* G, const uint32_t* bloc
                        ext[1], ext[2], out);
 }
 
+// =====================================================================================================
+// Fused scans of the host flow (ss_prims.h: one dispatch each; the functors below are the kernels that used to run before and
+// after a rocPRIM scan).  `state`: zeroed scan state (ss_scan_state_words); `mail`: where the total is posted for the host.
+// =====================================================================================================
+// sorted order -> payload, and the run starts of the cell table in the same pass: first[c] = ~(position of the first entry of cell c),
+// first[ncells] = ~n, 0 = no entry (the table is preset to 0); ss_launch_cell_table_scan turns it into cell_start
+template <class R>
+__global__ __launch_bounds__(256) void k_sorted_gather_runs(uint32_t n, const R* __restrict__ xyz, const uint32_t* __restrict__ perm, ss_real4<R>* __restrict__ pos_sorted,
+                                                            const uint32_t* __restrict__ sorted_keys, uint32_t ncells, uint32_t* __restrict__ first) {
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p > n) return;
+    if (p == n) {
+        first[ncells] = ~n;
+        return;
+    }
+    const size_t i = perm[p];
+    pos_sorted[p] = ss_make4(xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2], R(0.0));
+    const uint32_t k = sorted_keys[p];
+    if (p == 0 || sorted_keys[p - 1] != k) first[k] = ~p;
+}
+template <class R>
+void ss_launch_sorted_gather_runs(uint32_t n, const R* xyz, const uint32_t* perm, ss_real4<R>* pos_sorted, const uint32_t* sorted_keys, uint32_t ncells, uint32_t* first,
+                                  hipStream_t st) {
+    hipLaunchKernelGGL(k_sorted_gather_runs<R>, dim3((n + 1u + 255u) / 256u), dim3(256), 0, st, n, xyz, perm, pos_sorted, sorted_keys, ncells, first);
+}
+
+// cell_start[c] = first entry of cell c or of the next non-empty cell (n behind the last): a running maximum of the complemented
+// run starts from the END of the table (an empty cell is 0, the identity)
+struct SSCellTableIn {
+    const uint32_t* first;
+    uint32_t ncells;
+    __device__ uint32_t operator()(uint32_t j) const { return first[ncells - j]; }
+};
+struct SSCellTableOut {
+    uint32_t* cell_start;
+    uint32_t ncells;
+    __device__ void operator()(uint32_t j, uint32_t x, uint32_t excl) const { cell_start[ncells - j] = ~(x > excl ? x : excl); }
+};
+void ss_launch_cell_table_scan(const uint32_t* first, uint32_t ncells, uint32_t* cell_start, uint32_t* state, hipStream_t st) {
+    ss_chained_scan<uint32_t, SSOpMax>(SSCellTableIn{first, ncells}, SSCellTableOut{cell_start, ncells}, ncells + 1u, state, (uint32_t*)nullptr, SSMailSlot{}, st);
+}
+
+// membership count per particle (k_classify_count) as the scan's input: copy_offset[i] = copies of the particles before i; the flags of the
+// subdomains with particles are set on the way
+template <class R>
+struct SSClassifyIn {
+    SSDevT<R> P;
+    const R* xyz;
+    uint32_t* sub_flag;
+    __device__ uint32_t operator()(uint32_t i) const {
+        const R p[3] = {xyz[3 * (size_t)i], xyz[3 * (size_t)i + 1], xyz[3 * (size_t)i + 2]};
+        uint32_t m = 0;
+        const SSDevT<R>& Q = P;
+        uint32_t* flags = sub_flag;
+        ss_for_each_member_subdomain(Q, p, [&](int sx, int sy, int sz) {
+            ++m;
+            uint32_t* f = flags + ((size_t)sx * Q.ns[1] + sy) * Q.ns[2] + sz;
+            if (!*f) *f = 1u;
+        });
+        return m;
+    }
+};
+struct SSStoreExcl {
+    uint32_t* out;
+    __device__ void operator()(uint32_t i, uint32_t, uint32_t excl) const { out[i] = excl; }
+};
+template <class R>
+void ss_launch_classify_scan(const SSDevT<R>& P, const R* xyz, uint32_t* copy_offset, uint32_t* sub_flag, uint32_t* state, SSMailSlot mail, hipStream_t st) {
+    ss_chained_scan<uint32_t, SSOpPlus>(SSClassifyIn<R>{P, xyz, sub_flag}, SSStoreExcl{copy_offset}, P.n, state, (uint32_t*)nullptr, mail, st);
+}
+
+// flags -> ranks and the compacted list of the set entries (occupied subdomains; blocks to complete)
+struct SSFlagIn {
+    const uint32_t* flag;
+    __device__ uint32_t operator()(uint32_t i) const { return flag[i] ? 1u : 0u; }
+};
+struct SSRankListOut {
+    uint32_t* rank;  // may be null
+    uint32_t* list;
+    __device__ void operator()(uint32_t i, uint32_t f, uint32_t excl) const {
+        if (rank) rank[i] = excl;
+        if (f) list[excl] = i;
+    }
+};
+void ss_launch_flag_scan(const uint32_t* flag, uint32_t n, uint32_t* rank, uint32_t* list, uint32_t* total_dev, uint32_t* state, SSMailSlot mail, hipStream_t st) {
+    ss_chained_scan<uint32_t, SSOpPlus>(SSFlagIn{flag}, SSRankListOut{rank, list}, n, state, total_dev, mail, st);
+}
+
+// the copies whose density their subdomain computes (k_owned_copy_flags), compacted in cell order; the count stays on the device
+template <class R>
+struct SSOwnedIn {
+    SSDevT<R> P;
+    const ss_real4<R>* cpos;
+    const uint32_t* ckey;
+    const uint32_t* occ_sub;
+    __device__ uint32_t operator()(uint32_t p) const {
+        const uint32_t ctot = (uint32_t)(P.sc[0] * P.sc[1] * P.sc[2]);
+        const uint32_t flat = occ_sub[ckey[p] / ctot];
+        const int s3[3] = {(int)(flat / ((uint32_t)P.ns[2] * (uint32_t)P.ns[1])), (int)((flat / (uint32_t)P.ns[2]) % (uint32_t)P.ns[1]), (int)(flat % (uint32_t)P.ns[2])};
+        const ss_real4<R> pi = cpos[p];
+        const R x3[3] = {pi.x, pi.y, pi.z};
+        uint32_t f = 1;
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            const R lo = P.gmin[d] + (R)s3[d] * P.sub_size;
+            const R hi = P.gmin[d] + (R)(s3[d] + 1) * P.sub_size;
+            if (!(x3[d] >= lo && x3[d] < hi)) f = 0;
+        }
+        return f;
+    }
+};
+template <class R>
+void ss_launch_owned_scan(const SSDevT<R>& P, uint32_t n_copies, const ss_real4<R>* cpos, const uint32_t* ckey, const uint32_t* occ_sub, uint32_t* own_list, uint32_t* n_owned_dev,
+                          uint32_t* state, hipStream_t st) {
+    ss_chained_scan<uint32_t, SSOpPlus>(SSOwnedIn<R>{P, cpos, ckey, occ_sub}, SSRankListOut{nullptr, own_list}, n_copies, state, n_owned_dev, SSMailSlot{}, st);
+}
+
+// active level-set blocks: flags -> list, slot table and block coordinates in one pass (k_compact_blocks + k_block_coords); entries beyond
+// `cap` are not written (the host re-runs with larger buffers when the total exceeds it)
+template <class R>
+struct SSBlockListOut {
+    SSDevT<R> P;
+    uint32_t cap;
+    uint32_t* list;
+    uint32_t* slot;
+    uint32_t* xyz;
+    __device__ void operator()(uint32_t b, uint32_t f, uint32_t excl) const {
+        if (!f) {
+            slot[b] = 0xFFFFFFFFu;
+            return;
+        }
+        slot[b] = excl;
+        if (excl < cap) {
+            if (list) list[excl] = b;
+            int bx, by, bz;
+            ss_block_of_index(P, b, &bx, &by, &bz);
+            xyz[3 * (size_t)excl + 0] = (uint32_t)bx;
+            xyz[3 * (size_t)excl + 1] = (uint32_t)by;
+            xyz[3 * (size_t)excl + 2] = (uint32_t)bz;
+        }
+    }
+};
+template <class R>
+void ss_launch_active_blocks_scan(const SSDevT<R>& P, const uint32_t* block_flag, uint32_t nblocks, uint32_t cap, uint32_t* list, uint32_t* slot, uint32_t* xyz, uint32_t* state,
+                                  SSMailSlot mail, hipStream_t st) {
+    ss_chained_scan<uint32_t, SSOpPlus>(SSFlagIn{block_flag}, SSBlockListOut<R>{P, cap, list, slot, xyz}, nblocks, state, (uint32_t*)nullptr, mail, st);
+}
+
+// marching-cubes blocks: the flag of k_mark_mc_blocks computed as the scan's input, list / slot table / coordinates as its output
+template <class R>
+struct SSMcFlagIn {
+    SSDevT<R> P;
+    const uint32_t* block_slot;
+    const ss_real2<R>* blk_minmax;
+    __device__ uint32_t operator()(uint32_t b) const {
+        int bx, by, bz;
+        ss_block_of_index(P, b, &bx, &by, &bz);
+        if (bx < P.blk_lo[0] || by < P.blk_lo[1] || bz < P.blk_lo[2] || bx > P.blk_hi[0] || by > P.blk_hi[1] || bz > P.blk_hi[2]) return 0u;
+        bool any_in = false, any_out = false;
+        for (int dx = 0; dx <= 1; ++dx)
+            for (int dy = 0; dy <= 1; ++dy)
+                for (int dz = 0; dz <= 1; ++dz) {
+                    const int x = bx + dx, y = by + dy, z = bz + dz;
+                    R mn = R(0.0), mx = R(0.0);
+                    if (ss_block_in_table(P, x, y, z)) {
+                        const uint32_t slot = block_slot[ss_block_index(P, x, y, z)];
+                        if (slot != 0xFFFFFFFFu) {
+                            const ss_real2<R> mm = blk_minmax[slot];
+                            mn = mm.x;
+                            mx = mm.y;
+                        }
+                    }
+                    any_in = any_in || (mx > P.threshold);
+                    any_out = any_out || !(mn > P.threshold);
+                }
+        return (any_in && any_out) ? 1u : 0u;
+    }
+};
+template <class R>
+void ss_launch_mc_blocks_scan(const SSDevT<R>& P, const uint32_t* block_slot, const ss_real2<R>* blk_minmax, uint32_t nblocks, uint32_t cap, uint32_t* mc_list, uint32_t* mc_slot,
+                              uint32_t* mc_xyz, uint32_t* state, SSMailSlot mail, hipStream_t st) {
+    ss_chained_scan<uint32_t, SSOpPlus>(SSMcFlagIn<R>{P, block_slot, blk_minmax}, SSBlockListOut<R>{P, cap, mc_list, mc_slot, mc_xyz}, nblocks, state, (uint32_t*)nullptr, mail, st);
+}
+
+// vertex and triangle offsets of the marching-cubes blocks in one scan: the two counts packed into one 64-bit value (both totals < 2^32)
+struct SSMcCountsIn {
+    const uint32_t* vcount;
+    const uint32_t* tcount;
+    __device__ unsigned long long operator()(uint32_t i) const { return (unsigned long long)vcount[i] | ((unsigned long long)tcount[i] << 32); }
+};
+struct SSMcOffsetsOut {
+    uint32_t* vbase;
+    uint32_t* tbase;
+    uint32_t n;
+    __device__ void operator()(uint32_t i, unsigned long long x, unsigned long long excl) const {
+        vbase[i] = (uint32_t)excl;
+        tbase[i] = (uint32_t)(excl >> 32);
+        if (i + 1u == n) {  // entry n: the totals (the emit kernel reads base[m + 1] of the last block)
+            const unsigned long long t = excl + x;
+            vbase[n] = (uint32_t)t;
+            tbase[n] = (uint32_t)(t >> 32);
+        }
+    }
+};
+void ss_launch_mc_offsets_scan(const uint32_t* vcount, const uint32_t* tcount, uint32_t n_mc, uint32_t* vbase, uint32_t* tbase, uint32_t* state, SSMailSlot mail, hipStream_t st) {
+    ss_chained_scan<unsigned long long, SSOpPlus>(SSMcCountsIn{vcount, tcount}, SSMcOffsetsOut{vbase, tbase, n_mc}, n_mc, state, (unsigned long long*)nullptr, mail, st);
+}
+
+// 64-bit offsets of the tiles in the arena from the 32-bit bounds
+struct SSWidenIn {
+    const uint32_t* v;
+    __device__ unsigned long long operator()(uint32_t i) const { return (unsigned long long)v[i]; }
+};
+struct SSStoreExcl64 {
+    unsigned long long* out;
+    uint32_t n;
+    __device__ void operator()(uint32_t i, unsigned long long x, unsigned long long excl) const {
+        out[i] = excl;
+        if (i + 1u == n) out[n] = excl + x;
+    }
+};
+void ss_launch_tile_offsets_scan(const uint32_t* bound, uint32_t n, unsigned long long* off, uint32_t* state, SSMailSlot mail, hipStream_t st) {
+    ss_chained_scan<unsigned long long, SSOpPlus>(SSWidenIn{bound}, SSStoreExcl64{off, n}, n, state, (unsigned long long*)nullptr, mail, st);
+}
+
+// a count that lives on the device (the length of a list built with atomics), posted for the host
+__global__ void k_publish_u32(const uint32_t* __restrict__ src, SSMailSlot mail) { ss_mail_post(mail, (unsigned long long)src[0]); }
+void ss_launch_publish_u32(const uint32_t* src, SSMailSlot mail, hipStream_t st) { hipLaunchKernelGGL(k_publish_u32, dim3(1), dim3(1), 0, st, src, mail); }
+
+template void ss_launch_sorted_gather_runs<float>(uint32_t, const float*, const uint32_t*, ss_real4<float>*, const uint32_t*, uint32_t, uint32_t*, hipStream_t);
+template void ss_launch_sorted_gather_runs<double>(uint32_t, const double*, const uint32_t*, ss_real4<double>*, const uint32_t*, uint32_t, uint32_t*, hipStream_t);
+template void ss_launch_classify_scan<float>(const SSDevT<float>&, const float*, uint32_t*, uint32_t*, uint32_t*, SSMailSlot, hipStream_t);
+template void ss_launch_classify_scan<double>(const SSDevT<double>&, const double*, uint32_t*, uint32_t*, uint32_t*, SSMailSlot, hipStream_t);
+template void ss_launch_owned_scan<float>(const SSDevT<float>&, uint32_t, const ss_real4<float>*, const uint32_t*, const uint32_t*, uint32_t*, uint32_t*, uint32_t*, hipStream_t);
+template void ss_launch_owned_scan<double>(const SSDevT<double>&, uint32_t, const ss_real4<double>*, const uint32_t*, const uint32_t*, uint32_t*, uint32_t*, uint32_t*, hipStream_t);
+template void ss_launch_active_blocks_scan<float>(const SSDevT<float>&, const uint32_t*, uint32_t, uint32_t, uint32_t*, uint32_t*, uint32_t*, uint32_t*, SSMailSlot, hipStream_t);
+template void ss_launch_active_blocks_scan<double>(const SSDevT<double>&, const uint32_t*, uint32_t, uint32_t, uint32_t*, uint32_t*, uint32_t*, uint32_t*, SSMailSlot, hipStream_t);
+template void ss_launch_mc_blocks_scan<float>(const SSDevT<float>&, const uint32_t*, const ss_real2<float>*, uint32_t, uint32_t, uint32_t*, uint32_t*, uint32_t*, uint32_t*, SSMailSlot, hipStream_t);
+template void ss_launch_mc_blocks_scan<double>(const SSDevT<double>&, const uint32_t*, const ss_real2<double>*, uint32_t, uint32_t, uint32_t*, uint32_t*, uint32_t*, uint32_t*, SSMailSlot, hipStream_t);
+
 // ---- explicit instantiations of the launch wrappers (f32: reconstruct_surface::<i64,f32>, f64: ::<i64,f64>) ----
-template void ss_launch_aabb<float>(const float* d_xyz, uint32_t n, float* d_partial, float* d_out6, hipStream_t st);
-template void ss_launch_aabb<double>(const double* d_xyz, uint32_t n, double* d_partial, double* d_out6, hipStream_t st);
+template void ss_launch_aabb<float>(const float* d_xyz, uint32_t n, float* d_partial, float* d_out6, SSMailSlot mail, hipStream_t st);
+template void ss_launch_aabb<double>(const double* d_xyz, uint32_t n, double* d_partial, double* d_out6, SSMailSlot mail, hipStream_t st);
 template void ss_launch_inside_flags<float>(const float* d_xyz, uint32_t n, const float amin[3], const float amax[3], uint8_t* f8, uint32_t* f32, hipStream_t st);
 template void ss_launch_inside_flags<double>(const double* d_xyz, uint32_t n, const double amin[3], const double amax[3], uint8_t* f8, uint32_t* f32, hipStream_t st);
 template void ss_launch_compact_xyz<float>(const float* d_xyz, uint32_t n, const uint32_t* f32, const uint32_t* offs, float* out, hipStream_t st);
@@ -3034,10 +3317,10 @@ template void ss_launch_splat_gather<double>(const SSDevT<double>& P, const ss_r
 template void ss_launch_splat_gather_large<double>(const SSDevT<double>& P, const ss_real4<double>* posvol, const ss_real4<double>* posvol_by_index, const uint32_t* perm, const uint32_t* cell_start, const uint32_t* active_xyz, const uint32_t* large_list, const uint32_t* n_large_dev, const uint32_t* counts, const unsigned long long* tile_off, ss_real4<double>* arena, uint32_t* arena_idx, hipStream_t st);
 template void ss_launch_splat_fused<float>(const SSDevT<float>& P, const ss_real4<float>* posvol, const uint32_t* perm, const uint32_t* cell_start, const uint32_t* active_xyz, uint32_t n_active, float* G, ss_real2<float>* blk_minmax, uint32_t* trunc, bool full_levelset, const uint32_t* list, const uint32_t* n_list_dev, const uint32_t* redo_mask, unsigned long long* facebits, uint32_t* counts, uint32_t* big, hipStream_t st);
 template void ss_launch_splat_accumulate_big<float>(const SSDevT<float>& P, const ss_real4<float>* arena, const uint32_t* arena_idx, const unsigned long long* tile_off, const uint32_t* counts, const uint32_t* active_xyz, float* G, ss_real2<float>* blk_minmax, uint32_t* trunc, bool full_levelset, bool second_pass, bool exact_first, const uint32_t* redo_mask, unsigned long long* facebits, const uint32_t* big, uint32_t* err, hipStream_t st);
-template void ss_launch_select_redo<float>(const SSDevT<float>& P, const uint32_t* active_xyz, uint32_t n_active, const uint32_t* block_slot, const uint32_t* trunc, const unsigned long long* facebits, uint32_t* redo_mask, hipStream_t st);
+template void ss_launch_select_redo<float>(const SSDevT<float>& P, const uint32_t* active_xyz, uint32_t n_active, const uint32_t* block_slot, const uint32_t* trunc, const unsigned long long* facebits, uint32_t* redo_mask, const uint32_t* counts, unsigned long long* stats, uint32_t* big, hipStream_t st);
 template void ss_launch_splat_fused<double>(const SSDevT<double>& P, const ss_real4<double>* posvol, const uint32_t* perm, const uint32_t* cell_start, const uint32_t* active_xyz, uint32_t n_active, double* G, ss_real2<double>* blk_minmax, uint32_t* trunc, bool full_levelset, const uint32_t* list, const uint32_t* n_list_dev, const uint32_t* redo_mask, unsigned long long* facebits, uint32_t* counts, uint32_t* big, hipStream_t st);
 template void ss_launch_splat_accumulate_big<double>(const SSDevT<double>& P, const ss_real4<double>* arena, const uint32_t* arena_idx, const unsigned long long* tile_off, const uint32_t* counts, const uint32_t* active_xyz, double* G, ss_real2<double>* blk_minmax, uint32_t* trunc, bool full_levelset, bool second_pass, bool exact_first, const uint32_t* redo_mask, unsigned long long* facebits, const uint32_t* big, uint32_t* err, hipStream_t st);
-template void ss_launch_select_redo<double>(const SSDevT<double>& P, const uint32_t* active_xyz, uint32_t n_active, const uint32_t* block_slot, const uint32_t* trunc, const unsigned long long* facebits, uint32_t* redo_mask, hipStream_t st);
+template void ss_launch_select_redo<double>(const SSDevT<double>& P, const uint32_t* active_xyz, uint32_t n_active, const uint32_t* block_slot, const uint32_t* trunc, const unsigned long long* facebits, uint32_t* redo_mask, const uint32_t* counts, unsigned long long* stats, uint32_t* big, hipStream_t st);
 template void ss_launch_mc_neighbours<float>(const SSDevT<float>& P, const uint32_t* mc_xyz, uint32_t n_mc, const uint32_t* block_slot, const uint32_t* mc_slot, const uint32_t* certified, uint32_t* mc_nb, hipStream_t st);
 template void ss_launch_mc_count<float>(const SSDevT<float>& P, const float* G, const uint32_t* mc_nb, const uint32_t* mc_xyz, uint32_t n_mc, unsigned long long* masks, uint32_t* vcount, uint32_t* tcount, hipStream_t st);
 template void ss_launch_mc_neighbours<double>(const SSDevT<double>& P, const uint32_t* mc_xyz, uint32_t n_mc, const uint32_t* block_slot, const uint32_t* mc_slot, const uint32_t* certified, uint32_t* mc_nb, hipStream_t st);

@@ -410,7 +410,7 @@ ss_status build_sph_index(ss_context* ctx, const R* d_xyz, uint64_t n, R h, SphI
     if (n > 0) {
         SS_HIP(ctx, ctx->aabb_partial.reserve(1024 * 6 * sizeof(R)));
         SS_HIP(ctx, ctx->aabb_out.reserve(6 * sizeof(R)));
-        ss_launch_aabb<R>(d_xyz, (uint32_t)n, ctx->aabb_partial.as<R>(), ctx->aabb_out.as<R>(), ctx->stream);
+        ss_launch_aabb<R>(d_xyz, (uint32_t)n, ctx->aabb_partial.as<R>(), ctx->aabb_out.as<R>(), SSMailSlot{}, ctx->stream);
         R h6[6];
         SS_HIP(ctx, hipMemcpyAsync(h6, ctx->aabb_out.p, 6 * sizeof(R), hipMemcpyDeviceToHost, ctx->stream));
         SS_HIP(ctx, hipStreamSynchronize(ctx->stream));

@@ -12,6 +12,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 // A count the host waits for, written by a kernel into pinned host memory that is mapped into the device's address space: the host polls
 // `seq` instead of enqueueing a device-to-host copy (a dispatch of its own) and synchronising the stream.
 struct SSMailSlot {
@@ -49,20 +51,42 @@ __device__ __forceinline__ unsigned long long ss_prim_wave_incl_u64(unsigned lon
     }
     return v;
 }
-template <class T>
+struct SSOpPlus {
+    template <class T> __device__ static T apply(T a, T b) { return a + b; }
+    template <class T> __device__ static T identity() { return T(0); }
+};
+struct SSOpMax {
+    template <class T> __device__ static T apply(T a, T b) { return a > b ? a : b; }
+    template <class T> __device__ static T identity() { return T(0); }
+};
+template <class T, class Op>
 __device__ __forceinline__ T ss_prim_wave_incl(T v) {
-    if constexpr (sizeof(T) == 4)
+    if constexpr (sizeof(T) == 4 && std::is_same<Op, SSOpPlus>::value) {
         return (T)ss_prim_wave_incl_u32((uint32_t)v);
-    else
-        return (T)ss_prim_wave_incl_u64((unsigned long long)v);
+    } else {
+        const int lane = (int)(threadIdx.x & 63u);
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const T t = __shfl_up(v, off);
+            if (lane >= off) v = Op::template apply<T>(t, v);
+        }
+        return v;
+    }
+}
+template <class T, class Op>
+__device__ __forceinline__ T ss_prim_wave_reduce(T v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = Op::template apply<T>(v, (T)__shfl_xor(v, off));
+    return v;
 }
 
 // out(i, x, exclusive prefix of x) for i in [0, n), x = in(i); the total goes to *total_dev (if not null) and to the mail slot.
 // One dispatch: tiles take their number from a counter in the order they start, publish their sum and look back over their
 // predecessors' sums 64 tiles at a time.  A status word carries flag and value together, so the look-back needs no ordering
 // against other memory: relaxed agent-scope atomics (an acquire / release at agent scope writes back and invalidates the L2 of
-// the XCD on every access -- measured 346 us instead of ~40 for 10 M elements).  In / Out are callable from the device; T is uint32_t or unsigned long long.
-template <class T, class In, class Out>
+// the XCD on every access -- measured 346 us instead of ~40 for 10 M elements).  In / Out are callable from the device; T is
+// uint32_t or unsigned long long (values below 2^62); Op: SSOpPlus or SSOpMax.
+template <class T, class Op, class In, class Out>
 __global__ __launch_bounds__(256) void k_chained_scan(In in, Out out, uint32_t n, uint32_t* __restrict__ state, T* __restrict__ total_dev, SSMailSlot mail) {
     constexpr int ROWS = SS_SCAN_TILE / 256;
     __shared__ T s_w[ROWS][4];
@@ -78,29 +102,27 @@ __global__ __launch_bounds__(256) void k_chained_scan(In in, Out out, uint32_t n
 #pragma unroll
     for (int r = 0; r < ROWS; ++r) {
         const uint32_t i = base + (uint32_t)(r * 256 + tid);
-        x[r] = (i < n) ? in(i) : T(0);
-        incl[r] = ss_prim_wave_incl<T>(x[r]);
+        x[r] = (i < n) ? in(i) : Op::template identity<T>();
+        incl[r] = ss_prim_wave_incl<T, Op>(x[r]);
         if (lane == 63) s_w[r][wave] = incl[r];
     }
     __syncthreads();
-    T tile_total = T(0);
-    T my_off[ROWS];
+    T tile_total = Op::template identity<T>();
+    T my_off[ROWS];  // combined value of everything in the tile before this thread's wave in row r
 #pragma unroll
     for (int r = 0; r < ROWS; ++r) {
-        T wsum = T(0);
 #pragma unroll
         for (int w = 0; w < 4; ++w) {
-            if (w == wave) my_off[r] = tile_total + wsum;
-            wsum += s_w[r][w];
+            if (w == wave) my_off[r] = tile_total;
+            tile_total = Op::template apply<T>(tile_total, s_w[r][w]);
         }
-        tile_total += wsum;
     }
     if (wave == 0) {
         // publish the tile's sum, then look back: lane l reads the status of tile (p - l); flags 0 not there yet, 1 sum of that tile, 2 prefix up to and
         // including that tile
         const unsigned long long VALUE = (1ull << 62) - 1ull;
         if (lane == 0 && tile > 0) __hip_atomic_store(&status[tile], (1ull << 62) | (unsigned long long)tile_total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        unsigned long long excl = 0;
+        T excl = Op::template identity<T>();
         long long p = (long long)tile - 1;
         while (true) {
             const long long idx = p - lane;
@@ -114,28 +136,25 @@ __global__ __launch_bounds__(256) void k_chained_scan(In in, Out out, uint32_t n
                     __builtin_amdgcn_s_sleep(1);
                     continue;
                 }
-                unsigned long long v = (lane <= k) ? (s & VALUE) : 0ull;
-#pragma unroll
-                for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
-                excl += v;
+                const T v = ss_prim_wave_reduce<T, Op>((lane <= k) ? (T)(s & VALUE) : Op::template identity<T>());
+                excl = Op::template apply<T>(v, excl);
                 break;
             }
             if (m_zero) {
                 __builtin_amdgcn_s_sleep(1);
                 continue;
             }
-            unsigned long long v = s & VALUE;
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
-            excl += v;
+            const T v = ss_prim_wave_reduce<T, Op>((T)(s & VALUE));
+            excl = Op::template apply<T>(v, excl);
             p -= 64;
         }
         if (lane == 0) {
-            __hip_atomic_store(&status[tile], (2ull << 62) | (excl + (unsigned long long)tile_total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            s_excl = (T)excl;
+            const T incl_total = Op::template apply<T>(excl, tile_total);
+            __hip_atomic_store(&status[tile], (2ull << 62) | (unsigned long long)incl_total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s_excl = excl;
             if (base + (uint32_t)SS_SCAN_TILE >= n) {  // the last tile knows the total
-                if (total_dev) *total_dev = (T)(excl + (unsigned long long)tile_total);
-                ss_mail_post(mail, excl + (unsigned long long)tile_total);
+                if (total_dev) *total_dev = incl_total;
+                ss_mail_post(mail, (unsigned long long)incl_total);
             }
         }
     }
@@ -144,15 +163,20 @@ __global__ __launch_bounds__(256) void k_chained_scan(In in, Out out, uint32_t n
 #pragma unroll
     for (int r = 0; r < ROWS; ++r) {
         const uint32_t i = base + (uint32_t)(r * 256 + tid);
-        if (i < n) out(i, x[r], excl + my_off[r] + (incl[r] - x[r]));
+        if (i < n) {
+            // exclusive prefix inside the wave: the inclusive value of the lane before (identity for lane 0)
+            T before = (T)__shfl_up(incl[r], 1);
+            if (lane == 0) before = Op::template identity<T>();
+            out(i, x[r], Op::template apply<T>(Op::template apply<T>(excl, my_off[r]), before));
+        }
     }
 }
 
 // Launch; n == 0 posts a total of 0 (one thread).  The state words must be zero.
-template <class T, class In, class Out>
+template <class T, class Op = SSOpPlus, class In, class Out>
 void ss_chained_scan(In in, Out out, uint32_t n, uint32_t* state, T* total_dev, SSMailSlot mail, hipStream_t st) {
     const uint32_t tiles = n == 0 ? 1u : (n + SS_SCAN_TILE - 1) / SS_SCAN_TILE;
-    hipLaunchKernelGGL((k_chained_scan<T, In, Out>), dim3(tiles), dim3(256), 0, st, in, out, n, state, total_dev, mail);
+    hipLaunchKernelGGL((k_chained_scan<T, Op, In, Out>), dim3(tiles), dim3(256), 0, st, in, out, n, state, total_dev, mail);
 }
 
 // ---- radix sort ------------------------------------------------------------------------------------------------------------------

@@ -192,7 +192,7 @@ extern "C" int ss_debug_exclusive_scan_u32(const uint32_t* in, uint32_t* out, ui
     const size_t words = ss_scan_state_words(n);
     if (hipMalloc(&state, words * 4) != hipSuccess) return 1;
     (void)hipMemsetAsync(state, 0, words * 4, st);
-    ss_chained_scan<uint32_t>(SSDebugIdent{in}, SSDebugStore{out}, n, state, total_dev, SSMailSlot{}, st);
+    ss_chained_scan<uint32_t, SSOpPlus>(SSDebugIdent{in}, SSDebugStore{out}, n, state, total_dev, SSMailSlot{}, st);
     const hipError_t e = hipStreamSynchronize(st);
     (void)hipFree(state);
     return e == hipSuccess ? 0 : 2;
