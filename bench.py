@@ -109,12 +109,33 @@ def cpu_baseline(workload, scale):
     res = O.reconstruct_surface(pts, par)
     dt = time.perf_counter() - t0
     tm = getattr(res, "timings", {}) or {}
-    return {
+    base = {
         "value": round(pts.shape[0] / dt / 1e6, 4), "unit": "Mparticles/s", "cores": res.threads_used, "kind": "port",
         "sample": sample + "; %.2f s wall, %d vertices / %d triangles" % (dt, res.vertices.shape[0], res.triangles.shape[0]),
         "stages_s": {k: round(float(v), 3) for k, v in tm.items()},
         "threads_used": res.threads_used, "host_cpus": os.cpu_count(),
+        "loop": "scalar level-set loop (dense_subdomains.rs:784-847, enable_simd = false)",
     }
+    # second figure: the oracle's restatement of the reference's DEFAULT loop (enable_simd = true: the AVX2+FMA arithmetic lane by lane,
+    # dense_subdomains.rs:991-1133) on a bounded sample, so that the baseline next to the default-mode `value` is the default-mode loop
+    try:
+        sc2 = min(0.5, scale) if workload == "s10m_tank" else None
+        pts2 = W.tank_particles(sc2) if sc2 else pts
+        par2 = O.make_params_relative(wl["particle_radius"], wl["smoothing_length"], wl["cube_size"], simd=1)
+        t0 = time.perf_counter()
+        res2 = O.reconstruct_surface(pts2, par2)
+        dt2 = time.perf_counter() - t0
+        base["simd_loop"] = {"value": round(pts2.shape[0] / dt2 / 1e6, 4), "unit": "Mparticles/s", "cores": res2.threads_used, "kind": "port",
+                             "sample": "%d particles (tank scale %s), %.2f s wall; the AVX-shaped loop restated in scalar C (no intrinsics: the compiler may or may not "
+                                       "vectorise it), OpenMP over subdomains" % (pts2.shape[0], sc2 if sc2 else "as above", dt2)}
+    except Exception as e:
+        base["simd_loop"] = {"value": None, "note": "failed: %r" % (e,)}
+    base["reference_measured_elsewhere"] = {
+        "wheel_8_vcpu": "the reference's own wheel (AVX2+FMA, rayon) on the survey container's 8 vCPU Xeon @ 2.1 GHz: 0.57 Mparticles/s on a 1.25 M-particle crop of this "
+                        "workload, 0.166 on S1M (BASELINE.md section 2) -- cannot run on the GPU box (no reference there)",
+        "readme_m4_pro_14_cores": "5.80 Mparticles/s, 13.4 M particles (README.md:203): the only published figure",
+        "note": "reported baselines, not targets: the GPU / CPU ratio says nothing about kernel quality, the roofline fraction does"}
+    return base
 
 
 def kernel_source_stamp():
@@ -155,14 +176,22 @@ def splat_roofline(st, n_occ, n_subp, nsc, k3_acc_ms, k3_large_ms):
     alg_bytes = 16.0 * n_subp + 4.0 * n_occ * nsc ** 3
     name = "k_splat_fused"
     k3 = max(k3_acc_ms, k3_large_ms) * 1e-3
+    launches = {"k_splat_fused<.., true> (first pass: gather + certify + evaluate, all active blocks)":
+                round(k3_acc_ms - float(st.get("ms_levelset_accumulate_pass2", 0.0)), 4),
+                "k_splat_fused<.., false> (second pass: certified sub-blocks with a face neighbour outside the surface; incl. their selection)":
+                round(float(st.get("ms_levelset_accumulate_pass2", 0.0)), 4)}
+    gather_ms = float(st.get("ms_levelset_gather", 0.0))
+    if gather_ms > 0.05:
+        # over-dense input: the blocks with more candidates than a wave's tile holds go through k_splat_certify_big and the arena path
+        # (k_splat_bounds / _gather / _gather_large / _accumulate_list).  That is splat work too: the WHOLE level-set stage is priced.
+        name = "level-set stage: k_splat_fused + k_splat_certify_big + arena path (k_splat_gather*, k_splat_accumulate_list)"
+        k3 = float(st.get("ms_levelset", 0.0)) * 1e-3
+        launches["k_splat_certify_big + k_big_tile_select + k_splat_bounds + k_splat_gather + k_splat_gather_large (over-dense blocks)"] = round(gather_ms, 4)
     achieved = alg_bytes / k3 / 1e9 if k3 > 0 else 0.0
     return {
         "kernel": name, "bound": "hbm", "achieved": round(achieved, 2), "peak": 8000.0, "unit": "GB/s",
         "frac": round(achieved / 8000.0, 5), "traffic": None, "algorithmic_bytes": alg_bytes, "kernel_ms": round(k3 * 1e3, 4),
-        "launches_ms": {"k_splat_fused<.., true> (first pass: gather + certify + evaluate, all active blocks; + k_splat_accumulate_list for blocks with over 192 candidates)":
-                        round(k3_acc_ms - float(st.get("ms_levelset_accumulate_pass2", 0.0)), 4),
-                        "k_splat_fused<.., false> (second pass: certified sub-blocks with a face neighbour outside the surface; incl. their selection)":
-                        round(float(st.get("ms_levelset_accumulate_pass2", 0.0)), 4)},
+        "launches_ms": launches,
         "note": "algorithmic bytes = 16 B x %d subdomain particles + 4 B x %d subdomains x %d^3 points; kernel_ms = HIP events around the launches of the "
                 "splat kernel (gather + accumulate in one) on the library's stream (launches_ms; the last step's split); the kernel is FP32-VALU bound at this cube radius "
                 "(DESIGN.md section 5)" % (n_subp, n_occ, nsc),
@@ -414,7 +443,7 @@ def main():
         n_occ, n_subp = out.subdomain_stats()
         k3_acc, k3_large = (float(v) for v in np.mean(np.asarray(k3_ms), axis=0))
         roof = splat_roofline(last_stats, n_occ, n_subp, nsc, k3_acc, k3_large)
-        scaling = "weak"
+        scaling = "n/a (one GPU)"
         parallelism = "1 GPU"
         extra = {}
     else:
@@ -568,7 +597,8 @@ def main():
         line["value_host_to_host"] = h2h.get("value")
         line["ms_per_step_host_to_host"] = h2h.get("ms_per_step")
         line["config"]["value_semantics"] = ("value: particles already in HBM, mesh left in HBM (task contract); value_host_to_host: pageable host input -> vertices + u64 "
-                                             "triangle indices in host memory through the C ABI's accessors (SURVEY.md 8(d)(i)), one frame at a time, PCIe not overlapped")
+                                             "triangle indices in host memory through the C ABI's accessors (SURVEY.md 8(d)(i)), median of 10 frames, one frame at a time (upload -> kernels -> download is a chain: "
+                                             "nothing of one frame overlaps; pcie_pipelined = two frames in flight)")
     if not sharded_path:
         attach_traffic(line, workload, dev)
     if rank == 0:
@@ -644,18 +674,22 @@ def single_gpu_extras(line, args, ctx, prm, wl, workload, pts, d_pts, out, dev, 
     line["arithmetic_modes"] = modes
     # --- host-resident input -> host-resident output through the C ABI's host accessors ---
     host_pts = pts
-    for key, u64, note in (("e2e_host_u64", True, "pageable host (numpy) input via ss_reconstruct_surface_inplace_f32; vertices through ss_result_vertices and "
-                                                  "u64 triangle indices through ss_result_triangles ([usize;3] of the reference; widened on the device, 24 B per "
-                                                  "triangle over PCIe) into the library's pinned host buffers; best of 6"),
-                           ("pcie_inclusive", False, "as e2e_host_u64 but u32 triangle indices (ss_result_triangles_u32, 12 B per triangle); best of 6")):
+    for key, u64, note in (("e2e_host_u64", True, "pageable host (numpy) input via ss_reconstruct_surface_inplace_f32; vertices through ss_result_vertices and u64 triangle "
+                                                  "indices through ss_result_triangles ([usize;3] of the reference) into the library's pinned host buffers: the indices cross "
+                                                  "PCIe as u32 (12 B per triangle) in chunks and host threads widen every chunk to u64 while the next is in flight "
+                                                  "(SS_OPTION_WIDEN_ON_DEVICE would send 24 B per triangle instead); one frame at a time: upload, kernels and download do not overlap"),
+                           ("pcie_inclusive", False, "as e2e_host_u64 but u32 triangle indices (ss_result_triangles_u32, 12 B per triangle)")):
         try:
             t_io = []
-            for _ in range(6):
+            for _ in range(11):
                 t1 = time.perf_counter()
                 r_io = ctx.reconstruct(host_pts, prm, out=out)
                 _v, _t = r_io.mesh_views(u64=u64)
                 t_io.append(time.perf_counter() - t1)
-            line[key] = {"value": round(n_total / min(t_io) / 1e6, 3), "unit": "Mparticles/s", "ms_per_step": round(min(t_io) * 1e3, 3), "note": note}
+            t_io = sorted(t_io[1:])  # (the first frame sizes the pinned host buffers)
+            med = t_io[len(t_io) // 2]
+            line[key] = {"value": round(n_total / med / 1e6, 3), "unit": "Mparticles/s", "ms_per_step": round(med * 1e3, 3), "statistic": "median of 10 frames",
+                         "best": round(n_total / t_io[0] / 1e6, 3), "worst": round(n_total / t_io[-1] / 1e6, 3), "note": note}
         except Exception as e:
             line[key] = {"value": None, "note": "failed: %r" % (e,)}
     # same host-to-host call, two frames in flight: two contexts (one HIP stream each) driven by two host threads, so the

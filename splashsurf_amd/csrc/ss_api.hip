@@ -858,7 +858,8 @@ ss_status phase_begin(ss_context* ctx, const R* xyz, uint64_t n_in, const typena
         if (vals[r] != res->perm.as<uint32_t>()) return fail(ctx, SS_ERR_UNKNOWN, "internal error: sort result in an unexpected buffer");
         sorted_keys = keys[r];
     }
-    ss_launch_sorted_gather_runs(n, d_xyz, res->perm.as<uint32_t>(), ctx->pos_sorted.as<ss_real4<R>>(), sorted_keys, (uint32_t)ncells, ctx->cell_count.as<uint32_t>(), st);
+    ss_launch_sorted_gather_runs(P, n, d_xyz, res->perm.as<uint32_t>(), ctx->pos_sorted.as<ss_real4<R>>(), sorted_keys, (uint32_t)ncells, ctx->cell_count.as<uint32_t>(), (const uint32_t*)nullptr,
+                                 (uint8_t*)nullptr, st);
     ss_launch_cell_table_scan(ctx->cell_count.as<uint32_t>(), (uint32_t)ncells, ctx->cell_start.as<uint32_t>(), st_cells, st);
     SS_HIP(ctx, hipEventRecord(ctx->ev[3], st));
 
@@ -889,7 +890,7 @@ ss_status phase_begin(ss_context* ctx, const R* xyz, uint64_t n_in, const typena
             SS_HIP(ctx, ctx->cpos.reserve(((size_t)n_copies + 16) * sizeof(ss_real4<R>)));  // + padding: k_density_sub reads whole chunks
             SS_HIP(ctx, ctx->cell_count2.reserve((ncells2 + 1) * 4));
             SS_HIP(ctx, ctx->cell_start2.reserve((ncells2 + 1) * 4));
-            SS_HIP(ctx, ctx->own_flag.reserve(((size_t)n_copies + 1) * 4 + 64));
+            SS_HIP(ctx, ctx->own_flag.reserve(((size_t)n_copies + 16) * 5 + 128));  // the list of owned copies (u32), then their flags (u8)
             ZeroTaker Z2;
             s = reserve_zeros(ctx, ss_scan_state_words(ncells2 + 1) + ss_scan_state_words(n_copies) + 32, &Z2);
             if (s != SS_OK) return s;
@@ -908,7 +909,10 @@ ss_status phase_begin(ss_context* ctx, const R* xyz, uint64_t n_in, const typena
             if (s != SS_OK) return s;
             if (vals[r] != ctx->cidx.as<uint32_t>()) return fail(ctx, SS_ERR_UNKNOWN, "internal error: sort result in an unexpected buffer");
             const uint32_t* ckeys_sorted = keys[r];
-            ss_launch_sorted_gather_runs(n_copies, d_xyz, ctx->cidx.as<uint32_t>(), ctx->cpos.as<ss_real4<R>>(), ckeys_sorted, (uint32_t)ncells2, ctx->cell_count2.as<uint32_t>(), st);
+            uint32_t* own_list = ctx->own_flag.as<uint32_t>();
+            uint8_t* own_flags = reinterpret_cast<uint8_t*>(own_list + ((size_t)n_copies + 16));
+            ss_launch_sorted_gather_runs(P, n_copies, d_xyz, ctx->cidx.as<uint32_t>(), ctx->cpos.as<ss_real4<R>>(), ckeys_sorted, (uint32_t)ncells2, ctx->cell_count2.as<uint32_t>(),
+                                         ctx->occ_sub.as<uint32_t>(), own_flags, st);
             ss_launch_cell_table_scan(ctx->cell_count2.as<uint32_t>(), (uint32_t)ncells2, ctx->cell_start2.as<uint32_t>(), st_cells2, st);
             const bool want_nb = prm->global_neighborhood_list != 0;
             if (want_nb) {
@@ -919,8 +923,7 @@ ss_status phase_begin(ss_context* ctx, const R* xyz, uint64_t n_in, const typena
             s = ensure_fast_div<R>(ctx, P.h, st);
             if (s != SS_OK) return s;
             // the copies whose density their subdomain computes (every particle has exactly one), compacted in cell order
-            uint32_t* own_list = ctx->own_flag.as<uint32_t>();
-            ss_launch_owned_scan(P, n_copies, ctx->cpos.as<ss_real4<R>>(), ckeys_sorted, ctx->occ_sub.as<uint32_t>(), own_list, n_owned_dev, st_owned, st);
+            ss_launch_owned_scan(n_copies, own_flags, own_list, n_owned_dev, st_owned, st);
             const uint32_t n_owned_bound = n < n_copies ? n : n_copies;  // at most one owned copy per particle
             SS_HIP(ctx, hipEventRecord(ctx->ev[18], st));
             ss_launch_density_sub(P, n_copies, ctx->cpos.as<ss_real4<R>>(), ctx->cidx.as<uint32_t>(), ckeys_sorted,

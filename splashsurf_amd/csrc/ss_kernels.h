@@ -61,13 +61,12 @@ void ss_launch_levelset_box(const SSDevT<R>& P, const R* G, const uint32_t* bloc
 
 // fused scans of the host flow (one dispatch each, ss_prims.h)
 template <class R>
-void ss_launch_sorted_gather_runs(uint32_t n, const R* xyz, const uint32_t* perm, ss_real4<R>* pos_sorted, const uint32_t* sorted_keys, uint32_t ncells, uint32_t* first, hipStream_t st);
+void ss_launch_sorted_gather_runs(const SSDevT<R>& P, uint32_t n, const R* xyz, const uint32_t* perm, ss_real4<R>* pos_sorted, const uint32_t* sorted_keys, uint32_t ncells, uint32_t* first, const uint32_t* occ_sub, uint8_t* owned, hipStream_t st);
 void ss_launch_cell_table_scan(const uint32_t* first, uint32_t ncells, uint32_t* cell_start, uint32_t* state, hipStream_t st);
 template <class R>
 void ss_launch_classify_scan(const SSDevT<R>& P, const R* xyz, uint32_t* copy_offset, uint32_t* sub_flag, uint32_t* state, SSMailSlot mail, hipStream_t st);
 void ss_launch_flag_scan(const uint32_t* flag, uint32_t n, uint32_t* rank, uint32_t* list, uint32_t* total_dev, uint32_t* state, SSMailSlot mail, hipStream_t st);
-template <class R>
-void ss_launch_owned_scan(const SSDevT<R>& P, uint32_t n_copies, const ss_real4<R>* cpos, const uint32_t* ckey, const uint32_t* occ_sub, uint32_t* own_list, uint32_t* n_owned_dev, uint32_t* state, hipStream_t st);
+void ss_launch_owned_scan(uint32_t n_copies, const uint8_t* owned, uint32_t* own_list, uint32_t* n_owned_dev, uint32_t* state, hipStream_t st);
 template <class R>
 void ss_launch_active_blocks_scan(const SSDevT<R>& P, const uint32_t* block_flag, uint32_t nblocks, uint32_t cap, uint32_t* list, uint32_t* slot, uint32_t* xyz, uint32_t* state, SSMailSlot mail, hipStream_t st);
 template <class R>

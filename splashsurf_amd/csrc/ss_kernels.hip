@@ -994,7 +994,9 @@ __device__ __forceinline__ uint32_t ss_wave_inclusive_scan(uint32_t v) {
 // wave that waits holds one of the SIMD's six wave slots, so the candidates are taken SS_SCAN_GROUP batches of 64 at a time:
 // the row look-ups of all batches of a group run interleaved (branch-free bisection over the row prefix table in LDS), then
 // all their loads are in flight together, then the batches are filtered and handed to f in order.  f as in splat_wave_scan.
+#ifndef SS_SCAN_GROUP
 #define SS_SCAN_GROUP 6
+#endif
 #ifndef SS_FUSED_BAIL
 #define SS_FUSED_BAIL 3
 #endif
@@ -3048,9 +3050,10 @@ void ss_launch_levelset_box(const SSDevT<R>& P, const R* G, const uint32_t* bloc
 // =====================================================================================================
 // sorted order -> payload, and the run starts of the cell table in the same pass: first[c] = ~(position of the first entry of cell c),
 // first[ncells] = ~n, 0 = no entry (the table is preset to 0); ss_launch_cell_table_scan turns it into cell_start
-template <class R>
-__global__ __launch_bounds__(256) void k_sorted_gather_runs(uint32_t n, const R* __restrict__ xyz, const uint32_t* __restrict__ perm, ss_real4<R>* __restrict__ pos_sorted,
-                                                            const uint32_t* __restrict__ sorted_keys, uint32_t ncells, uint32_t* __restrict__ first) {
+template <class R, bool OWNED>
+__global__ __launch_bounds__(256) void k_sorted_gather_runs(SSDevT<R> P, uint32_t n, const R* __restrict__ xyz, const uint32_t* __restrict__ perm, ss_real4<R>* __restrict__ pos_sorted,
+                                                            const uint32_t* __restrict__ sorted_keys, uint32_t ncells, uint32_t* __restrict__ first,
+                                                            const uint32_t* __restrict__ occ_sub, uint8_t* __restrict__ owned) {
     const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p > n) return;
     if (p == n) {
@@ -3058,14 +3061,33 @@ __global__ __launch_bounds__(256) void k_sorted_gather_runs(uint32_t n, const R*
         return;
     }
     const size_t i = perm[p];
-    pos_sorted[p] = ss_make4(xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2], R(0.0));
+    const R x3[3] = {xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2]};
+    pos_sorted[p] = ss_make4(x3[0], x3[1], x3[2], R(0.0));
     const uint32_t k = sorted_keys[p];
     if (p == 0 || sorted_keys[p - 1] != k) first[k] = ~p;
+    if constexpr (OWNED) {
+        // subdomain copies: is this the copy whose density its subdomain computes, i.e. does it lie inside the subdomain's half-open AABB
+        // (is_inside, dense_subdomains.rs:567-576, aabb.rs:220-222)?  The others are ghosts, their density comes from another subdomain.
+        const uint32_t ctot = (uint32_t)(P.sc[0] * P.sc[1] * P.sc[2]);
+        const uint32_t flat = occ_sub[k / ctot];
+        const int s3[3] = {(int)(flat / ((uint32_t)P.ns[2] * (uint32_t)P.ns[1])), (int)((flat / (uint32_t)P.ns[2]) % (uint32_t)P.ns[1]), (int)(flat % (uint32_t)P.ns[2])};
+        uint8_t f = 1;
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            const R lo = P.gmin[d] + (R)s3[d] * P.sub_size;
+            const R hi = P.gmin[d] + (R)(s3[d] + 1) * P.sub_size;
+            if (!(x3[d] >= lo && x3[d] < hi)) f = 0;
+        }
+        owned[p] = f;
+    }
 }
 template <class R>
-void ss_launch_sorted_gather_runs(uint32_t n, const R* xyz, const uint32_t* perm, ss_real4<R>* pos_sorted, const uint32_t* sorted_keys, uint32_t ncells, uint32_t* first,
-                                  hipStream_t st) {
-    hipLaunchKernelGGL(k_sorted_gather_runs<R>, dim3((n + 1u + 255u) / 256u), dim3(256), 0, st, n, xyz, perm, pos_sorted, sorted_keys, ncells, first);
+void ss_launch_sorted_gather_runs(const SSDevT<R>& P, uint32_t n, const R* xyz, const uint32_t* perm, ss_real4<R>* pos_sorted, const uint32_t* sorted_keys, uint32_t ncells, uint32_t* first,
+                                  const uint32_t* occ_sub, uint8_t* owned, hipStream_t st) {
+    if (owned)
+        hipLaunchKernelGGL((k_sorted_gather_runs<R, true>), dim3((n + 1u + 255u) / 256u), dim3(256), 0, st, P, n, xyz, perm, pos_sorted, sorted_keys, ncells, first, occ_sub, owned);
+    else
+        hipLaunchKernelGGL((k_sorted_gather_runs<R, false>), dim3((n + 1u + 255u) / 256u), dim3(256), 0, st, P, n, xyz, perm, pos_sorted, sorted_keys, ncells, first, occ_sub, owned);
 }
 
 // cell_start[c] = first entry of cell c or of the next non-empty cell (n behind the last): a running maximum of the complemented
@@ -3130,33 +3152,13 @@ void ss_launch_flag_scan(const uint32_t* flag, uint32_t n, uint32_t* rank, uint3
     ss_chained_scan<uint32_t, SSOpPlus>(SSFlagIn{flag}, SSRankListOut{rank, list}, n, state, total_dev, mail, st);
 }
 
-// the copies whose density their subdomain computes (k_owned_copy_flags), compacted in cell order; the count stays on the device
-template <class R>
-struct SSOwnedIn {
-    SSDevT<R> P;
-    const ss_real4<R>* cpos;
-    const uint32_t* ckey;
-    const uint32_t* occ_sub;
-    __device__ uint32_t operator()(uint32_t p) const {
-        const uint32_t ctot = (uint32_t)(P.sc[0] * P.sc[1] * P.sc[2]);
-        const uint32_t flat = occ_sub[ckey[p] / ctot];
-        const int s3[3] = {(int)(flat / ((uint32_t)P.ns[2] * (uint32_t)P.ns[1])), (int)((flat / (uint32_t)P.ns[2]) % (uint32_t)P.ns[1]), (int)(flat % (uint32_t)P.ns[2])};
-        const ss_real4<R> pi = cpos[p];
-        const R x3[3] = {pi.x, pi.y, pi.z};
-        uint32_t f = 1;
-#pragma unroll
-        for (int d = 0; d < 3; ++d) {
-            const R lo = P.gmin[d] + (R)s3[d] * P.sub_size;
-            const R hi = P.gmin[d] + (R)(s3[d] + 1) * P.sub_size;
-            if (!(x3[d] >= lo && x3[d] < hi)) f = 0;
-        }
-        return f;
-    }
+// the copies whose density their subdomain computes (flags from k_sorted_gather_runs), compacted in cell order; the count stays on the device
+struct SSByteFlagIn {
+    const uint8_t* flag;
+    __device__ uint32_t operator()(uint32_t i) const { return (uint32_t)flag[i]; }
 };
-template <class R>
-void ss_launch_owned_scan(const SSDevT<R>& P, uint32_t n_copies, const ss_real4<R>* cpos, const uint32_t* ckey, const uint32_t* occ_sub, uint32_t* own_list, uint32_t* n_owned_dev,
-                          uint32_t* state, hipStream_t st) {
-    ss_chained_scan<uint32_t, SSOpPlus>(SSOwnedIn<R>{P, cpos, ckey, occ_sub}, SSRankListOut{nullptr, own_list}, n_copies, state, n_owned_dev, SSMailSlot{}, st);
+void ss_launch_owned_scan(uint32_t n_copies, const uint8_t* owned, uint32_t* own_list, uint32_t* n_owned_dev, uint32_t* state, hipStream_t st) {
+    ss_chained_scan<uint32_t, SSOpPlus>(SSByteFlagIn{owned}, SSRankListOut{nullptr, own_list}, n_copies, state, n_owned_dev, SSMailSlot{}, st);
 }
 
 // active level-set blocks: flags -> list, slot table and block coordinates in one pass (k_compact_blocks + k_block_coords); entries beyond
@@ -3271,12 +3273,10 @@ void ss_launch_tile_offsets_scan(const uint32_t* bound, uint32_t n, unsigned lon
 __global__ void k_publish_u32(const uint32_t* __restrict__ src, SSMailSlot mail) { ss_mail_post(mail, (unsigned long long)src[0]); }
 void ss_launch_publish_u32(const uint32_t* src, SSMailSlot mail, hipStream_t st) { hipLaunchKernelGGL(k_publish_u32, dim3(1), dim3(1), 0, st, src, mail); }
 
-template void ss_launch_sorted_gather_runs<float>(uint32_t, const float*, const uint32_t*, ss_real4<float>*, const uint32_t*, uint32_t, uint32_t*, hipStream_t);
-template void ss_launch_sorted_gather_runs<double>(uint32_t, const double*, const uint32_t*, ss_real4<double>*, const uint32_t*, uint32_t, uint32_t*, hipStream_t);
+template void ss_launch_sorted_gather_runs<float>(const SSDevT<float>&, uint32_t, const float*, const uint32_t*, ss_real4<float>*, const uint32_t*, uint32_t, uint32_t*, const uint32_t*, uint8_t*, hipStream_t);
+template void ss_launch_sorted_gather_runs<double>(const SSDevT<double>&, uint32_t, const double*, const uint32_t*, ss_real4<double>*, const uint32_t*, uint32_t, uint32_t*, const uint32_t*, uint8_t*, hipStream_t);
 template void ss_launch_classify_scan<float>(const SSDevT<float>&, const float*, uint32_t*, uint32_t*, uint32_t*, SSMailSlot, hipStream_t);
 template void ss_launch_classify_scan<double>(const SSDevT<double>&, const double*, uint32_t*, uint32_t*, uint32_t*, SSMailSlot, hipStream_t);
-template void ss_launch_owned_scan<float>(const SSDevT<float>&, uint32_t, const ss_real4<float>*, const uint32_t*, const uint32_t*, uint32_t*, uint32_t*, uint32_t*, hipStream_t);
-template void ss_launch_owned_scan<double>(const SSDevT<double>&, uint32_t, const ss_real4<double>*, const uint32_t*, const uint32_t*, uint32_t*, uint32_t*, uint32_t*, hipStream_t);
 template void ss_launch_active_blocks_scan<float>(const SSDevT<float>&, const uint32_t*, uint32_t, uint32_t, uint32_t*, uint32_t*, uint32_t*, uint32_t*, SSMailSlot, hipStream_t);
 template void ss_launch_active_blocks_scan<double>(const SSDevT<double>&, const uint32_t*, uint32_t, uint32_t, uint32_t*, uint32_t*, uint32_t*, uint32_t*, SSMailSlot, hipStream_t);
 template void ss_launch_mc_blocks_scan<float>(const SSDevT<float>&, const uint32_t*, const ss_real2<float>*, uint32_t, uint32_t, uint32_t*, uint32_t*, uint32_t*, uint32_t*, SSMailSlot, hipStream_t);

@@ -29,7 +29,7 @@ __device__ __forceinline__ void ss_mail_post(const SSMailSlot& m, unsigned long 
 
 // ---- chained scan ----------------------------------------------------------------------------------------------------------------
 // state: 2 + 2 * ceil(n / SS_SCAN_TILE) 32-bit words, zeroed before the launch (word 0: tile counter; from word 2: one 64-bit status per tile)
-#define SS_SCAN_TILE 2048
+#define SS_SCAN_TILE 4096
 inline size_t ss_scan_state_words(size_t n) { return 2 + 2 * ((n + SS_SCAN_TILE - 1) / SS_SCAN_TILE) + 2; }
 
 __device__ __forceinline__ uint32_t ss_prim_wave_incl_u32(uint32_t v) {
@@ -89,6 +89,7 @@ __device__ __forceinline__ T ss_prim_wave_reduce(T v) {
 template <class T, class Op, class In, class Out>
 __global__ __launch_bounds__(256) void k_chained_scan(In in, Out out, uint32_t n, uint32_t* __restrict__ state, T* __restrict__ total_dev, SSMailSlot mail) {
     constexpr int ROWS = SS_SCAN_TILE / 256;
+    static_assert(ROWS * 4 <= 64, "the pieces of a tile are summed by one wave");
     __shared__ T s_w[ROWS][4];
     __shared__ T s_excl;
     __shared__ uint32_t s_tile;
@@ -98,24 +99,19 @@ __global__ __launch_bounds__(256) void k_chained_scan(In in, Out out, uint32_t n
     const uint32_t tile = s_tile;
     const uint32_t base = tile * (uint32_t)SS_SCAN_TILE;
     unsigned long long* status = reinterpret_cast<unsigned long long*>(state + 2);
-    T x[ROWS], incl[ROWS];
+    // pass A: the inputs (kept in registers: In may be expensive or have side effects) and the sum of every (row, wave) piece
+    T x[ROWS];
 #pragma unroll
     for (int r = 0; r < ROWS; ++r) {
         const uint32_t i = base + (uint32_t)(r * 256 + tid);
         x[r] = (i < n) ? in(i) : Op::template identity<T>();
-        incl[r] = ss_prim_wave_incl<T, Op>(x[r]);
-        if (lane == 63) s_w[r][wave] = incl[r];
+        const T piece = ss_prim_wave_reduce<T, Op>(x[r]);
+        if (lane == 0) s_w[r][wave] = piece;
     }
     __syncthreads();
     T tile_total = Op::template identity<T>();
-    T my_off[ROWS];  // combined value of everything in the tile before this thread's wave in row r
-#pragma unroll
-    for (int r = 0; r < ROWS; ++r) {
-#pragma unroll
-        for (int w = 0; w < 4; ++w) {
-            if (w == wave) my_off[r] = tile_total;
-            tile_total = Op::template apply<T>(tile_total, s_w[r][w]);
-        }
+    if (wave == 0) {  // ROWS * 4 pieces, one per lane
+        tile_total = ss_prim_wave_reduce<T, Op>(lane < ROWS * 4 ? s_w[lane >> 2][lane & 3] : Op::template identity<T>());
     }
     if (wave == 0) {
         // publish the tile's sum, then look back: lane l reads the status of tile (p - l); flags 0 not there yet, 1 sum of that tile, 2 prefix up to and
@@ -159,16 +155,22 @@ __global__ __launch_bounds__(256) void k_chained_scan(In in, Out out, uint32_t n
         }
     }
     __syncthreads();
-    const T excl = s_excl;
+    // pass B: everything before this thread = the tiles before (s_excl), the rows before, the waves before in this row, the lanes before
+    T before_row = s_excl;
 #pragma unroll
     for (int r = 0; r < ROWS; ++r) {
         const uint32_t i = base + (uint32_t)(r * 256 + tid);
-        if (i < n) {
-            // exclusive prefix inside the wave: the inclusive value of the lane before (identity for lane 0)
-            T before = (T)__shfl_up(incl[r], 1);
-            if (lane == 0) before = Op::template identity<T>();
-            out(i, x[r], Op::template apply<T>(Op::template apply<T>(excl, my_off[r]), before));
+        T before_wave = before_row;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const T piece = s_w[r][w];
+            if (w < wave) before_wave = Op::template apply<T>(before_wave, piece);
+            before_row = Op::template apply<T>(before_row, piece);
         }
+        const T incl = ss_prim_wave_incl<T, Op>(x[r]);
+        T before_lane = (T)__shfl_up(incl, 1);
+        if (lane == 0) before_lane = Op::template identity<T>();
+        if (i < n) out(i, x[r], Op::template apply<T>(before_wave, before_lane));
     }
 }
 

@@ -11,18 +11,37 @@
 
 #define RS_ROUNDS 16  // SS_RS_TILE / 256
 
+// Digit histograms of all passes.  The keys of a wave often agree in their high digits (spatially coherent input): LDS atomics of all 64
+// lanes on one counter serialise, so every group of lanes with the same (lane & 7) has its own copy of the counters (8-way instead of
+// 64-way conflicts; matching equal digits with ballots first costs as much VALU time as it saves).
 __global__ __launch_bounds__(256) void k_rs_hist(const uint32_t* __restrict__ keys, uint32_t n, int npass, uint32_t* __restrict__ hist) {
-    __shared__ uint32_t h[4][256];
-    const int tid = threadIdx.x;
-    for (int p = 0; p < 4; ++p) h[p][tid] = 0u;
+    __shared__ uint32_t h[4][8][256];
+    const int tid = threadIdx.x, c = tid & 7;
+    for (int p = 0; p < 4; ++p)
+        for (int j = 0; j < 8; ++j) h[p][j][tid] = 0u;
     __syncthreads();
-    for (size_t i = (size_t)blockIdx.x * 256u + (size_t)tid; i < (size_t)n; i += (size_t)gridDim.x * 256u) {
+    const size_t stride = (size_t)gridDim.x * 256u;
+    size_t i = (size_t)blockIdx.x * 256u + (size_t)tid;
+    // four keys in flight per thread
+    for (; i + 3 * stride < (size_t)n; i += 4 * stride) {
+        const uint32_t k0 = keys[i], k1 = keys[i + stride], k2 = keys[i + 2 * stride], k3 = keys[i + 3 * stride];
+        for (int p = 0; p < npass; ++p) {
+            atomicAdd(&h[p][c][(k0 >> (8 * p)) & 255u], 1u);
+            atomicAdd(&h[p][c][(k1 >> (8 * p)) & 255u], 1u);
+            atomicAdd(&h[p][c][(k2 >> (8 * p)) & 255u], 1u);
+            atomicAdd(&h[p][c][(k3 >> (8 * p)) & 255u], 1u);
+        }
+    }
+    for (; i < (size_t)n; i += stride) {
         const uint32_t k = keys[i];
-        for (int p = 0; p < npass; ++p) atomicAdd(&h[p][(k >> (8 * p)) & 255u], 1u);
+        for (int p = 0; p < npass; ++p) atomicAdd(&h[p][c][(k >> (8 * p)) & 255u], 1u);
     }
     __syncthreads();
-    for (int p = 0; p < npass; ++p)
-        if (h[p][tid]) atomicAdd(&hist[p * 256 + tid], h[p][tid]);
+    for (int p = 0; p < npass; ++p) {
+        uint32_t t = 0;
+        for (int j = 0; j < 8; ++j) t += h[p][j][tid];
+        if (t) atomicAdd(&hist[p * 256 + tid], t);
+    }
 }
 
 // exclusive prefix over the 256 threads of the workgroup (s_tmp: 4 words)
