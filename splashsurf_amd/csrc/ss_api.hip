@@ -209,10 +209,15 @@ ss_status reserve_zeros(ss_context* ctx, size_t words, ZeroTaker* z) {
     return SS_OK;
 }
 // stable sort of the (key, position) pairs by the low `bits` bits; returns the buffers that hold the result
-ss_status sort_pairs(ss_context* ctx, uint32_t* keys[2], uint32_t* vals[2], uint32_t n, unsigned bits, bool iota, int* result) {
+// `zero_work`: zeroed words for the sort (ss_radix_sort_work_words) from the caller's zero region; null: the sort's own buffer, zeroed here
+ss_status sort_pairs(ss_context* ctx, uint32_t* keys[2], uint32_t* vals[2], uint32_t n, unsigned bits, bool iota, uint32_t* zero_work, int* result) {
     if (n >= (1u << 30)) return fail(ctx, SS_ERR_UNSUPPORTED, "more than 2^30 - 1 entries to sort in one call are not supported by this build");
+    if (zero_work) {
+        *result = ss_radix_sort_pairs(keys, vals, n, bits, iota, zero_work, true, ctx->stream);
+        return SS_OK;
+    }
     SS_HIP(ctx, ctx->sort_work.reserve(ss_radix_sort_work_words(n, bits) * 4));
-    *result = ss_radix_sort_pairs(keys, vals, n, bits, iota, ctx->sort_work.as<uint32_t>(), ctx->stream);
+    *result = ss_radix_sort_pairs(keys, vals, n, bits, iota, ctx->sort_work.as<uint32_t>(), false, ctx->stream);
     return SS_OK;
 }
 
@@ -572,7 +577,7 @@ ss_status global_search_and_densities(ss_context* ctx, const SSGlobT<R>& Q, cons
             // (the values are the particle indices 0 .. n-1: the sort supplies them itself)
             uint32_t* vals[2] = {odd ? ctx->vals_a.as<uint32_t>() : res->perm.as<uint32_t>(), odd ? res->perm.as<uint32_t>() : ctx->vals_a.as<uint32_t>()};
             int r = 0;
-            s = sort_pairs(ctx, keys, vals, n, bits, true, &r);
+            s = sort_pairs(ctx, keys, vals, n, bits, true, nullptr, &r);
             if (s != SS_OK) return s;
             if (vals[r] != res->perm.as<uint32_t>()) return fail(ctx, SS_ERR_UNKNOWN, "internal error: sort result in an unexpected buffer");
         }
@@ -823,7 +828,6 @@ ss_status phase_begin(ss_context* ctx, const R* xyz, uint64_t n_in, const typena
     SS_HIP(ctx, res->posvol.reserve((size_t)n * sizeof(ss_real4<R>) + 32));
     SS_HIP(ctx, res->posvol_by_index.reserve((size_t)n * sizeof(ss_real4<R>) + 32));
     SS_HIP(ctx, res->perm.reserve((size_t)n * 4 + 16));
-    SS_HIP(ctx, ctx->cell_count.reserve((ncells + 1) * 4));
     SS_HIP(ctx, ctx->cell_start.reserve((ncells + 1) * 4));
     SS_HIP(ctx, ctx->keys_a.reserve((size_t)n * 4 + 16));
     SS_HIP(ctx, ctx->keys_b.reserve((size_t)n * 4 + 16));
@@ -834,33 +838,36 @@ ss_status phase_begin(ss_context* ctx, const R* xyz, uint64_t n_in, const typena
     SS_HIP(ctx, ctx->copy_offset.reserve(((size_t)n + 1) * 4));
     SS_HIP(ctx, ctx->sub_rank.reserve((nsub + 1) * 4));
     SS_HIP(ctx, ctx->occ_sub.reserve((nsub + 1) * 4 + 16));  // (at most every subdomain is occupied)
-    // zeroed words of this phase up to the first count the host waits for: three scan states and the subdomain flags
+    // zeroed words of this phase up to the first count the host waits for, ONE memset: three scan states, the subdomain flags, the sort's
+    // work words and the run starts of the cell table (0 = empty cell)
+    unsigned bits = 1;
+    while (bits < 32 && ((size_t)1 << bits) < ncells) ++bits;
     ZeroTaker Z;
-    s = reserve_zeros(ctx, ss_scan_state_words(ncells + 1) + ss_scan_state_words(n) + ss_scan_state_words(nsub) + (nsub + 1) + 32, &Z);
+    s = reserve_zeros(ctx, ss_scan_state_words(ncells + 1) + ss_scan_state_words(n) + ss_scan_state_words(nsub) + (nsub + 1) + ss_radix_sort_work_words(n, bits) + (ncells + 1) + 64, &Z);
     if (s != SS_OK) return s;
     uint32_t* st_cells = Z.take(ss_scan_state_words(ncells + 1));
     uint32_t* st_member = Z.take(ss_scan_state_words(n));
     uint32_t* st_sub = Z.take(ss_scan_state_words(nsub));
     uint32_t* sub_flag = Z.take(nsub + 1);
-    SS_HIP(ctx, hipMemsetAsync(ctx->cell_count.p, 0, (ncells + 1) * 4, st));  // run starts of the cell table: 0 = empty cell
+    uint32_t* sort_work = Z.take(ss_radix_sort_work_words(n, bits));
+    uint32_t* cell_first = Z.take(ncells + 1);
+    if (!cell_first) return fail(ctx, SS_ERR_UNKNOWN, "internal error: zero region too small");
     const uint32_t* sorted_keys = ctx->keys_a.as<uint32_t>();
     if (n > 0) {
-        unsigned bits = 1;
-        while (bits < 32 && ((size_t)1 << bits) < ncells) ++bits;
         // the buffers are assigned so that the sorted positions end in res->perm whatever the number of passes
         const bool odd = (((bits + 7u) / 8u) & 1u) != 0u;
         uint32_t* keys[2] = {ctx->keys_a.as<uint32_t>(), ctx->keys_b.as<uint32_t>()};
         uint32_t* vals[2] = {odd ? ctx->vals_a.as<uint32_t>() : res->perm.as<uint32_t>(), odd ? res->perm.as<uint32_t>() : ctx->vals_a.as<uint32_t>()};
         ss_launch_cell_keys(P, d_xyz, keys[0], (uint32_t*)nullptr, st);
         int r = 0;
-        s = sort_pairs(ctx, keys, vals, n, bits, true, &r);
+        s = sort_pairs(ctx, keys, vals, n, bits, true, sort_work, &r);
         if (s != SS_OK) return s;
         if (vals[r] != res->perm.as<uint32_t>()) return fail(ctx, SS_ERR_UNKNOWN, "internal error: sort result in an unexpected buffer");
         sorted_keys = keys[r];
     }
-    ss_launch_sorted_gather_runs(P, n, d_xyz, res->perm.as<uint32_t>(), ctx->pos_sorted.as<ss_real4<R>>(), sorted_keys, (uint32_t)ncells, ctx->cell_count.as<uint32_t>(), (const uint32_t*)nullptr,
+    ss_launch_sorted_gather_runs(P, n, d_xyz, res->perm.as<uint32_t>(), ctx->pos_sorted.as<ss_real4<R>>(), sorted_keys, (uint32_t)ncells, cell_first, (const uint32_t*)nullptr,
                                  (uint8_t*)nullptr, st);
-    ss_launch_cell_table_scan(ctx->cell_count.as<uint32_t>(), (uint32_t)ncells, ctx->cell_start.as<uint32_t>(), st_cells, st);
+    ss_launch_cell_table_scan(cell_first, (uint32_t)ncells, ctx->cell_start.as<uint32_t>(), st_cells, st);
     SS_HIP(ctx, hipEventRecord(ctx->ev[3], st));
 
     // ---- K2: densities (per-subdomain particle copies, exactly the reference's organisation) ----
@@ -888,32 +895,33 @@ ss_status phase_begin(ss_context* ctx, const R* xyz, uint64_t n_in, const typena
             SS_HIP(ctx, ctx->cvals_a.reserve((size_t)n_copies * 4 + 16));
             SS_HIP(ctx, ctx->cidx.reserve((size_t)n_copies * 4 + 16));
             SS_HIP(ctx, ctx->cpos.reserve(((size_t)n_copies + 16) * sizeof(ss_real4<R>)));  // + padding: k_density_sub reads whole chunks
-            SS_HIP(ctx, ctx->cell_count2.reserve((ncells2 + 1) * 4));
             SS_HIP(ctx, ctx->cell_start2.reserve((ncells2 + 1) * 4));
             SS_HIP(ctx, ctx->own_flag.reserve(((size_t)n_copies + 16) * 5 + 128));  // the list of owned copies (u32), then their flags (u8)
-            ZeroTaker Z2;
-            s = reserve_zeros(ctx, ss_scan_state_words(ncells2 + 1) + ss_scan_state_words(n_copies) + 32, &Z2);
+            unsigned bits = 1;
+            while (bits < 32 && ((size_t)1 << bits) < ncells2) ++bits;
+            ZeroTaker Z2;  // (one memset again: scan states, the count of owned copies, the sort's work words, the run starts of the copies' cell table)
+            s = reserve_zeros(ctx, ss_scan_state_words(ncells2 + 1) + ss_scan_state_words(n_copies) + ss_radix_sort_work_words(n_copies, bits) + (ncells2 + 1) + 64, &Z2);
             if (s != SS_OK) return s;
             uint32_t* st_cells2 = Z2.take(ss_scan_state_words(ncells2 + 1));
             uint32_t* st_owned = Z2.take(ss_scan_state_words(n_copies));
             uint32_t* n_owned_dev = Z2.take(4);
-            SS_HIP(ctx, hipMemsetAsync(ctx->cell_count2.p, 0, (ncells2 + 1) * 4, st));
-            unsigned bits = 1;
-            while (bits < 32 && ((size_t)1 << bits) < ncells2) ++bits;
+            uint32_t* sort_work2 = Z2.take(ss_radix_sort_work_words(n_copies, bits));
+            uint32_t* cell_first2 = Z2.take(ncells2 + 1);
+            if (!cell_first2) return fail(ctx, SS_ERR_UNKNOWN, "internal error: zero region too small");
             const bool odd = (((bits + 7u) / 8u) & 1u) != 0u;
             uint32_t* keys[2] = {ctx->ckeys_a.as<uint32_t>(), ctx->ckeys_b.as<uint32_t>()};
             uint32_t* vals[2] = {odd ? ctx->cvals_a.as<uint32_t>() : ctx->cidx.as<uint32_t>(), odd ? ctx->cidx.as<uint32_t>() : ctx->cvals_a.as<uint32_t>()};
             ss_launch_emit_copies(P, d_xyz, ctx->copy_offset.as<uint32_t>(), ctx->sub_rank.as<uint32_t>(), keys[0], vals[0], st);
             int r = 0;
-            s = sort_pairs(ctx, keys, vals, n_copies, bits, false, &r);
+            s = sort_pairs(ctx, keys, vals, n_copies, bits, false, sort_work2, &r);
             if (s != SS_OK) return s;
             if (vals[r] != ctx->cidx.as<uint32_t>()) return fail(ctx, SS_ERR_UNKNOWN, "internal error: sort result in an unexpected buffer");
             const uint32_t* ckeys_sorted = keys[r];
             uint32_t* own_list = ctx->own_flag.as<uint32_t>();
             uint8_t* own_flags = reinterpret_cast<uint8_t*>(own_list + ((size_t)n_copies + 16));
-            ss_launch_sorted_gather_runs(P, n_copies, d_xyz, ctx->cidx.as<uint32_t>(), ctx->cpos.as<ss_real4<R>>(), ckeys_sorted, (uint32_t)ncells2, ctx->cell_count2.as<uint32_t>(),
+            ss_launch_sorted_gather_runs(P, n_copies, d_xyz, ctx->cidx.as<uint32_t>(), ctx->cpos.as<ss_real4<R>>(), ckeys_sorted, (uint32_t)ncells2, cell_first2,
                                          ctx->occ_sub.as<uint32_t>(), own_flags, st);
-            ss_launch_cell_table_scan(ctx->cell_count2.as<uint32_t>(), (uint32_t)ncells2, ctx->cell_start2.as<uint32_t>(), st_cells2, st);
+            ss_launch_cell_table_scan(cell_first2, (uint32_t)ncells2, ctx->cell_start2.as<uint32_t>(), st_cells2, st);
             const bool want_nb = prm->global_neighborhood_list != 0;
             if (want_nb) {
                 SS_HIP(ctx, ctx->nb_count.reserve(((size_t)n + 1) * 8));
@@ -983,24 +991,22 @@ ss_status phase_finish(ss_context* ctx, ss_result* res) {
 
     // ---- K3 prepare: active level-set blocks ----
     if (nblocks >= (1ull << 32) - 2) return fail(ctx, SS_ERR_UNSUPPORTED, "more than 2^32 level-set blocks");
-    SS_HIP(ctx, ctx->block_flag.reserve((nblocks + 1) * 4));
     SS_HIP(ctx, res->block_slot.reserve(nblocks * 4 + 16));
     SS_HIP(ctx, res->mc_slot.reserve(nblocks * 4 + 16));
-    SS_HIP(ctx, ctx->counter.reserve(64));
-    SS_HIP(ctx, hipMemsetAsync(ctx->block_flag.p, 0, (nblocks + 1) * 4, st));
-    if (n > 0) ss_launch_mark_blocks(P, ctx->cell_start.as<uint32_t>(), (uint32_t)ncells, ctx->block_flag.as<uint32_t>(), st);
+    ZeroTaker ZB;  // the block flags and the state of the scan over them (two states: the scan may be repeated), one memset
+    s = reserve_zeros(ctx, (nblocks + 1) + 2 * ss_scan_state_words(nblocks) + 64, &ZB);
+    if (s != SS_OK) return s;
+    uint32_t* block_flag = ZB.take(nblocks + 1);
+    if (n > 0) ss_launch_mark_blocks(P, ctx->cell_start.as<uint32_t>(), (uint32_t)ncells, block_flag, st);
     // flags -> slot table, block coordinates (list order = table order); the lists are filled up to their capacity: a call that has more active
     // blocks than any before it repeats the scan with larger lists
     uint32_t n_active = 0;
     for (int attempt = 0; attempt < 2; ++attempt) {
         if (ctx->cap_active == 0) ctx->cap_active = (uint32_t)std::min<size_t>(nblocks, (size_t)1 << 16);
         SS_HIP(ctx, res->active_xyz.reserve((size_t)ctx->cap_active * 12 + 16));
-        ZeroTaker Z;
-        s = reserve_zeros(ctx, ss_scan_state_words(nblocks) + 32, &Z);
-        if (s != SS_OK) return s;
         const SSMailSlot m_active = mail_slot(ctx, 2);
-        ss_launch_active_blocks_scan(P, ctx->block_flag.as<uint32_t>(), (uint32_t)nblocks, ctx->cap_active, (uint32_t*)nullptr, res->block_slot.as<uint32_t>(),
-                                     res->active_xyz.as<uint32_t>(), Z.take(ss_scan_state_words(nblocks)), m_active, st);
+        ss_launch_active_blocks_scan(P, block_flag, (uint32_t)nblocks, ctx->cap_active, (uint32_t*)nullptr, res->block_slot.as<uint32_t>(),
+                                     res->active_xyz.as<uint32_t>(), ZB.take(ss_scan_state_words(nblocks)), m_active, st);
         unsigned long long v = 0;
         s = mail_wait(ctx, m_active, &v);
         if (s != SS_OK) return s;
@@ -1078,8 +1084,7 @@ ss_status phase_finish(ss_context* ctx, ss_result* res) {
     uint32_t* n_redo_dev = Z.take(4);
     uint32_t* n_large_dev = Z.take(4);
     uint32_t n_big = 0;
-    SS_HIP(ctx, hipEventRecord(ctx->ev[5], st));
-    SS_HIP(ctx, hipEventRecord(ctx->ev[12], st));
+    SS_HIP(ctx, hipEventRecord(ctx->ev[5], st));  // (= event 12 of the timers below: one record per point of the stream)
     if (n_active) {
         // first pass, gather and accumulate in one kernel: the tiles of ordinary blocks stay in LDS
         ss_launch_splat_fused(PK, res->posvol.as<ss_real4<R>>(), res->perm.as<uint32_t>(), ctx->cell_start.as<uint32_t>(), res->active_xyz.as<uint32_t>(), n_active,
@@ -1125,11 +1130,10 @@ ss_status phase_finish(ss_context* ctx, ss_result* res) {
         ss_launch_splat_accumulate_big(PK, ctx->splat_tiles.as<ss_real4<R>>(), ctx->splat_tile_idx.as<uint32_t>(), ctx->splat_off.as<unsigned long long>(), ctx->splat_counts.as<uint32_t>(),
                                        res->active_xyz.as<uint32_t>(), res->G.as<R>(), res->blk_minmax.as<ss_real2<R>>(), tr_flag, full_ls, false, certify_big,
                                        certify_big ? need_mask : nullptr, face_bits, certify_big ? exact_list : big, d_err, st);
-    SS_HIP(ctx, hipEventRecord(ctx->ev[13], st));
+    SS_HIP(ctx, hipEventRecord(ctx->ev[13], st));  // (= event 14)
 
     // second pass of the splat: certified sub-blocks with a face neighbour outside the surface are completed (list and count stay on the device);
     // the statistics of the first pass are taken by the same kernel
-    SS_HIP(ctx, hipEventRecord(ctx->ev[14], st));
     if (n_active)
         ss_launch_select_redo(P, res->active_xyz.as<uint32_t>(), n_active, res->block_slot.as<uint32_t>(), full_ls ? nullptr : tr_flag, face_bits, rd_flag,
                               ctx->splat_counts.as<uint32_t>(), reinterpret_cast<unsigned long long*>(d_counters), big, st);
@@ -1142,8 +1146,7 @@ ss_status phase_finish(ss_context* ctx, ss_result* res) {
                                            ctx->splat_counts.as<uint32_t>(), res->active_xyz.as<uint32_t>(), res->G.as<R>(), res->blk_minmax.as<ss_real2<R>>(), tr_flag, true, true, false,
                                            rd_flag, face_bits, big, d_err, st);
     }
-    SS_HIP(ctx, hipEventRecord(ctx->ev[15], st));
-    SS_HIP(ctx, hipEventRecord(ctx->ev[6], st));
+    SS_HIP(ctx, hipEventRecord(ctx->ev[15], st));  // (= event 6)
 
     // ---- K4 prepare: MC blocks = blocks whose 2x2x2 level-set neighbourhood straddles the threshold (the flag is the scan's input) ----
     uint32_t n_mc = 0;
@@ -1174,8 +1177,7 @@ ss_status phase_finish(ss_context* ctx, ss_result* res) {
     SS_HIP(ctx, hipEventRecord(ctx->ev[20], st));
     ss_launch_mc_count(P, res->G.as<R>(), ctx->mc_nb.as<uint32_t>(), res->mc_xyz.as<uint32_t>(), n_mc, res->masks.as<unsigned long long>(),
                        ctx->vcount.as<uint32_t>(), ctx->tcount.as<uint32_t>(), st);
-    SS_HIP(ctx, hipEventRecord(ctx->ev[21], st));
-    SS_HIP(ctx, hipEventRecord(ctx->ev[7], st));
+    SS_HIP(ctx, hipEventRecord(ctx->ev[21], st));  // (= event 7)
     // ---- "stitching": global numbering by prefix sums (vertex and triangle counts in one scan) ----
     const SSMailSlot m_tot = mail_slot(ctx, 6), m_stat0 = mail_slot(ctx, 7), m_stat1 = mail_slot(ctx, 8), m_stat2 = mail_slot(ctx, 9), m_stat3 = mail_slot(ctx, 10);
     ss_launch_mc_offsets_scan(ctx->vcount.as<uint32_t>(), ctx->tcount.as<uint32_t>(), n_mc, res->vbase.as<uint32_t>(), res->tbase.as<uint32_t>(), Z.take(ss_scan_state_words((size_t)n_mc + 1)), m_tot, st);
@@ -1219,11 +1221,11 @@ ss_status phase_finish(ss_context* ctx, ss_result* res) {
     S.ms_decomposition = ev_ms(ctx, 2, 3);
     S.ms_density = ev_ms(ctx, 3, 4) + ev_ms(ctx, 10, 11);
     S.ms_levelset_prepare = ev_ms(ctx, 11, 5);
-    S.ms_levelset = ev_ms(ctx, 5, 6);
-    S.ms_levelset_gather = ev_ms(ctx, 16, 17);  // the arena path of blocks with more candidates than a wave holds (0 without such blocks)
-    S.ms_levelset_accumulate = ev_ms(ctx, 12, 13) - ev_ms(ctx, 16, 17) + ev_ms(ctx, 14, 15);  // both passes of the splat kernels (the second incl. its block selection)
-    S.ms_marching_cubes = ev_ms(ctx, 6, 7) + ev_ms(ctx, 8, 9);
-    S.ms_stitching = ev_ms(ctx, 7, 8);
+    S.ms_levelset = ev_ms(ctx, 5, 15);
+    S.ms_levelset_gather = ev_ms(ctx, 16, 17);  // the over-dense blocks' certificates and the arena path (0 without such blocks)
+    S.ms_levelset_accumulate = ev_ms(ctx, 5, 13) - ev_ms(ctx, 16, 17) + ev_ms(ctx, 13, 15);  // both passes of the splat kernels (the second incl. its block selection)
+    S.ms_marching_cubes = ev_ms(ctx, 15, 21) + ev_ms(ctx, 8, 9);
+    S.ms_stitching = ev_ms(ctx, 21, 8);
     S.n_particles = n;
     S.n_vertices = nv;
     S.n_triangles = nt;
@@ -1238,7 +1240,7 @@ ss_status phase_finish(ss_context* ctx, ss_result* res) {
         const double frac = (double)n_cert_waves / (8.0 * (double)n_active);
         ctx->early_enabled = frac > (ctx->early_enabled ? 0.30 : 0.35);
     }
-    S.ms_levelset_accumulate_pass2 = ev_ms(ctx, 14, 15);
+    S.ms_levelset_accumulate_pass2 = ev_ms(ctx, 13, 15);
     S.n_mc_blocks = n_mc;
     S.ms_density_kernel = res->density_kernel_timed ? ev_ms(ctx, 18, 19) : 0.0;
     S.ms_mc_count = ev_ms(ctx, 20, 21);

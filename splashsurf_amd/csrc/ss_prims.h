@@ -28,9 +28,13 @@ __device__ __forceinline__ void ss_mail_post(const SSMailSlot& m, unsigned long 
 }
 
 // ---- chained scan ----------------------------------------------------------------------------------------------------------------
-// state: 2 + 2 * ceil(n / SS_SCAN_TILE) 32-bit words, zeroed before the launch (word 0: tile counter; from word 2: one 64-bit status per tile)
+// state: 2 + 2 * (number of tiles) 32-bit words, zeroed before the launch (word 0: tile counter; from word 2: one 64-bit status per tile).
+// Tiles of 4096 elements (16 rows of 256) for large inputs, of 1024 (4 rows) for small ones, where the rows' fixed cost is the kernel's time.
 #define SS_SCAN_TILE 4096
-inline size_t ss_scan_state_words(size_t n) { return 2 + 2 * ((n + SS_SCAN_TILE - 1) / SS_SCAN_TILE) + 2; }
+#define SS_SCAN_TILE_SMALL 1024
+#define SS_SCAN_SMALL_N 65536
+inline size_t ss_scan_tile_of(size_t n) { return n <= SS_SCAN_SMALL_N ? SS_SCAN_TILE_SMALL : SS_SCAN_TILE; }
+inline size_t ss_scan_state_words(size_t n) { return 2 + 2 * ((n + ss_scan_tile_of(n) - 1) / ss_scan_tile_of(n)) + 2; }
 
 __device__ __forceinline__ uint32_t ss_prim_wave_incl_u32(uint32_t v) {
     int x = (int)v;
@@ -86,9 +90,9 @@ __device__ __forceinline__ T ss_prim_wave_reduce(T v) {
 // against other memory: relaxed agent-scope atomics (an acquire / release at agent scope writes back and invalidates the L2 of
 // the XCD on every access -- measured 346 us instead of ~40 for 10 M elements).  In / Out are callable from the device; T is
 // uint32_t or unsigned long long (values below 2^62); Op: SSOpPlus or SSOpMax.
-template <class T, class Op, class In, class Out>
+template <class T, class Op, int TILE, class In, class Out>
 __global__ __launch_bounds__(256) void k_chained_scan(In in, Out out, uint32_t n, uint32_t* __restrict__ state, T* __restrict__ total_dev, SSMailSlot mail) {
-    constexpr int ROWS = SS_SCAN_TILE / 256;
+    constexpr int ROWS = TILE / 256;
     static_assert(ROWS * 4 <= 64, "the pieces of a tile are summed by one wave");
     __shared__ T s_w[ROWS][4];
     __shared__ T s_excl;
@@ -97,7 +101,7 @@ __global__ __launch_bounds__(256) void k_chained_scan(In in, Out out, uint32_t n
     if (tid == 0) s_tile = atomicAdd(state, 1u);
     __syncthreads();
     const uint32_t tile = s_tile;
-    const uint32_t base = tile * (uint32_t)SS_SCAN_TILE;
+    const uint32_t base = tile * (uint32_t)TILE;
     unsigned long long* status = reinterpret_cast<unsigned long long*>(state + 2);
     // pass A: the inputs (kept in registers: In may be expensive or have side effects) and the sum of every (row, wave) piece
     T x[ROWS];
@@ -148,7 +152,7 @@ __global__ __launch_bounds__(256) void k_chained_scan(In in, Out out, uint32_t n
             const T incl_total = Op::template apply<T>(excl, tile_total);
             __hip_atomic_store(&status[tile], (2ull << 62) | (unsigned long long)incl_total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             s_excl = excl;
-            if (base + (uint32_t)SS_SCAN_TILE >= n) {  // the last tile knows the total
+            if (base + (uint32_t)TILE >= n) {  // the last tile knows the total
                 if (total_dev) *total_dev = incl_total;
                 ss_mail_post(mail, (unsigned long long)incl_total);
             }
@@ -177,15 +181,19 @@ __global__ __launch_bounds__(256) void k_chained_scan(In in, Out out, uint32_t n
 // Launch; n == 0 posts a total of 0 (one thread).  The state words must be zero.
 template <class T, class Op = SSOpPlus, class In, class Out>
 void ss_chained_scan(In in, Out out, uint32_t n, uint32_t* state, T* total_dev, SSMailSlot mail, hipStream_t st) {
-    const uint32_t tiles = n == 0 ? 1u : (n + SS_SCAN_TILE - 1) / SS_SCAN_TILE;
-    hipLaunchKernelGGL((k_chained_scan<T, Op, In, Out>), dim3(tiles), dim3(256), 0, st, in, out, n, state, total_dev, mail);
+    const uint32_t tile = (uint32_t)ss_scan_tile_of(n);
+    const uint32_t tiles = n == 0 ? 1u : (n + tile - 1) / tile;
+    if (tile == SS_SCAN_TILE)
+        hipLaunchKernelGGL((k_chained_scan<T, Op, SS_SCAN_TILE, In, Out>), dim3(tiles), dim3(256), 0, st, in, out, n, state, total_dev, mail);
+    else
+        hipLaunchKernelGGL((k_chained_scan<T, Op, SS_SCAN_TILE_SMALL, In, Out>), dim3(tiles), dim3(256), 0, st, in, out, n, state, total_dev, mail);
 }
 
 // ---- radix sort ------------------------------------------------------------------------------------------------------------------
 #define SS_RS_TILE 4096
-// work buffer (32-bit words), zeroed by ss_radix_sort_pairs itself with one memset
+// work buffer (32-bit words): zeroed by ss_radix_sort_pairs itself with one memset unless the caller says it is zero already
 size_t ss_radix_sort_work_words(uint32_t n, unsigned bits);
 // Stable sort of n (key, value) pairs by the low `bits` bits of the keys, 8 bits per pass, ping-pong between buffers 0 and 1.  iota: the
 // values are the positions 0 .. n-1 (vals[0] is not read in the first pass, but is written by an even pass).  Returns the index (0 / 1)
 // of the buffers that hold the result.  n < 2^30.
-int ss_radix_sort_pairs(uint32_t* keys[2], uint32_t* vals[2], uint32_t n, unsigned bits, bool iota, uint32_t* work, hipStream_t st);
+int ss_radix_sort_pairs(uint32_t* keys[2], uint32_t* vals[2], uint32_t n, unsigned bits, bool iota, uint32_t* work, bool work_is_zero, hipStream_t st);

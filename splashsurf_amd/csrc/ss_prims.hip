@@ -14,11 +14,12 @@
 // Digit histograms of all passes.  The keys of a wave often agree in their high digits (spatially coherent input): LDS atomics of all 64
 // lanes on one counter serialise, so every group of lanes with the same (lane & 7) has its own copy of the counters (8-way instead of
 // 64-way conflicts; matching equal digits with ballots first costs as much VALU time as it saves).
+template <int COPIES>
 __global__ __launch_bounds__(256) void k_rs_hist(const uint32_t* __restrict__ keys, uint32_t n, int npass, uint32_t* __restrict__ hist) {
-    __shared__ uint32_t h[4][8][256];
-    const int tid = threadIdx.x, c = tid & 7;
-    for (int p = 0; p < 4; ++p)
-        for (int j = 0; j < 8; ++j) h[p][j][tid] = 0u;
+    __shared__ uint32_t h[4][COPIES][256];
+    const int tid = threadIdx.x, c = tid & (COPIES - 1);
+    for (int p = 0; p < npass; ++p)
+        for (int j = 0; j < COPIES; ++j) h[p][j][tid] = 0u;
     __syncthreads();
     const size_t stride = (size_t)gridDim.x * 256u;
     size_t i = (size_t)blockIdx.x * 256u + (size_t)tid;
@@ -39,7 +40,7 @@ __global__ __launch_bounds__(256) void k_rs_hist(const uint32_t* __restrict__ ke
     __syncthreads();
     for (int p = 0; p < npass; ++p) {
         uint32_t t = 0;
-        for (int j = 0; j < 8; ++j) t += h[p][j][tid];
+        for (int j = 0; j < COPIES; ++j) t += h[p][j][tid];
         if (t) atomicAdd(&hist[p * 256 + tid], t);
     }
 }
@@ -175,17 +176,20 @@ size_t ss_radix_sort_work_words(uint32_t n, unsigned bits) {
     return np * 256 + 8 + np * tiles * 256 + 64;  // histograms, tile counters, status
 }
 
-int ss_radix_sort_pairs(uint32_t* keys[2], uint32_t* vals[2], uint32_t n, unsigned bits, bool iota, uint32_t* work, hipStream_t st) {
+int ss_radix_sort_pairs(uint32_t* keys[2], uint32_t* vals[2], uint32_t n, unsigned bits, bool iota, uint32_t* work, bool work_is_zero, hipStream_t st) {
     if (n == 0) return 0;
     const unsigned np = rs_passes(bits);
     const uint32_t tiles = (uint32_t)(((size_t)n + SS_RS_TILE - 1) / SS_RS_TILE);
-    (void)hipMemsetAsync(work, 0, ss_radix_sort_work_words(n, bits) * 4, st);
+    if (!work_is_zero) (void)hipMemsetAsync(work, 0, ss_radix_sort_work_words(n, bits) * 4, st);
     uint32_t* hist = work;
     uint32_t* counters = work + np * 256;
     uint32_t* status = counters + 8;
     uint32_t hgrid = (n + 256u * 32u - 1u) / (256u * 32u);
     if (hgrid > 2048u) hgrid = 2048u;
-    hipLaunchKernelGGL(k_rs_hist, dim3(hgrid), dim3(256), 0, st, keys[0], n, (int)np, hist);
+    if (n <= (1u << 16))  // (small inputs: one copy of the counters, nothing to zero and add up that is not needed)
+        hipLaunchKernelGGL(k_rs_hist<1>, dim3(hgrid), dim3(256), 0, st, keys[0], n, (int)np, hist);
+    else
+        hipLaunchKernelGGL(k_rs_hist<8>, dim3(hgrid), dim3(256), 0, st, keys[0], n, (int)np, hist);
     int cur = 0;
     for (unsigned p = 0; p < np; ++p) {
         const uint32_t* vin = (p == 0 && iota) ? nullptr : vals[cur];
@@ -224,7 +228,7 @@ extern "C" int ss_debug_radix_sort_pairs(uint32_t* keys0, uint32_t* keys1, uint3
     if (hipMalloc(&work, words * 4) != hipSuccess) return 1;
     uint32_t* keys[2] = {keys0, keys1};
     uint32_t* vals[2] = {vals0, vals1};
-    const int r = ss_radix_sort_pairs(keys, vals, n, bits, iota != 0, work, st);
+    const int r = ss_radix_sort_pairs(keys, vals, n, bits, iota != 0, work, false, st);
     const hipError_t e = hipStreamSynchronize(st);
     (void)hipFree(work);
     if (result_buffer) *result_buffer = r;

@@ -227,7 +227,7 @@ def test_dense_cloud_exceeding_tile_capacity(gpu_ctx, two_pass_ctx, oracle, forc
     assert res.stats["n_large_tile_blocks"] > 0 and res.stats["n_block_candidates"] > res.stats["n_active_blocks"] * 4096
     st = res.stats  # stage timers of the three splat kernels (HIP events on the library's stream)
     assert st["ms_levelset_gather"] > 0.0 and st["ms_levelset_accumulate"] > 0.0
-    assert st["ms_levelset"] >= st["ms_levelset_gather"] + st["ms_levelset_accumulate"]
+    assert st["ms_levelset"] >= st["ms_levelset_gather"] + st["ms_levelset_accumulate"] - 1e-3  # (the stage is the sum of its parts up to rounding)
     assert_gpu_equals_oracle(res, orc)
 
 

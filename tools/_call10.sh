@@ -1,0 +1,30 @@
+cd $GRAFT_REPO_ROOT
+O=gpurun_out/r04j; mkdir -p $O; rm -f $O/ab.jsonl
+(timeout 900 python -m pytest tests/test_gpu_prims.py tests/test_gpu_parity.py tests/test_gpu_simd.py -m gpu -x -q -k "not full_size and not config4" > $O/tests.log 2>&1; echo "rc=$?" >> $O/tests.log)
+grep -E "passed|failed|rc=" $O/tests.log | tail -3
+run() { SPLASHSURF_HIP_LIB=$2 timeout 300 python tools/ab_kernels.py --digest --tag $1 "${@:3}" >> $O/ab.jsonl 2>> $O/ab.err || echo "{\"tag\": \"$1\", \"failed\": true}" >> $O/ab.jsonl; }
+run new "" --workload s10m_tank --steps 8
+for w in config1 config5 s1m; do
+run new "" --workload $w --steps 30
+done
+python - <<'PY'
+import json
+for l in open('gpurun_out/r04j/ab.jsonl'):
+    d=json.loads(l)
+    if d.get('failed'): print(d); continue
+    print("%-5s %-10s total %7.3f (min %7.3f) dec %6.3f dens %6.3f (k %5.3f) lsprep %6.3f ls %7.3f (gather %6.3f acc %6.3f p2 %5.3f) mc %5.3f st %5.3f act %d cert %.3f big %d dig %s"%(d['tag'],d['workload'],d['ms_total'],d['ms_total_min'],d['ms_decomposition'],d['ms_density'],d['ms_density_kernel'],d['ms_levelset_prepare'],d['ms_levelset'],d['ms_levelset_gather'],d['ms_levelset_accumulate'],d['ms_levelset_accumulate_pass2'],d['ms_marching_cubes'],d['ms_stitching'],d['n_active'],d['certified_frac'],d['n_large'],d.get('digest')))
+PY
+NO_PMC=1 bash tools/profile_configs.sh r04mid config1 config5 > $O/prof.log 2>&1
+python3 - <<'PY'
+import csv
+rows=list(csv.DictReader(open('gpurun_out/r04midprof_cfg/config1/stats/run_kernel_trace.csv')))
+rows.sort(key=lambda r:int(r['Start_Timestamp']))
+idx=[i for i,r in enumerate(rows) if 'k_aabb_partial' in r['Kernel_Name']]
+a,b=idx[-2],idx[-1]
+t0=int(rows[a]['Start_Timestamp']); prev=t0
+for r in rows[a:b]:
+    s=int(r['Start_Timestamp']);e=int(r['End_Timestamp'])
+    n=r['Kernel_Name'].replace('void ','').split('(')[0][:70]
+    print("%8.1f us gap %6.1f dur %6.1f %s"%((s-t0)/1e3,(s-prev)/1e3,(e-s)/1e3,n)); prev=e
+print('count',b-a)
+PY
