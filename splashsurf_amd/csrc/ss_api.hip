@@ -832,7 +832,7 @@ ss_status phase_begin(ss_context* ctx, const R* xyz, uint64_t n_in, const typena
     SS_HIP(ctx, ctx->keys_a.reserve((size_t)n * 4 + 16));
     SS_HIP(ctx, ctx->keys_b.reserve((size_t)n * 4 + 16));
     SS_HIP(ctx, ctx->vals_a.reserve((size_t)n * 4 + 16));
-    SS_HIP(ctx, ctx->pos_sorted.reserve((size_t)n * sizeof(ss_real4<R>) + 16));
+    SS_HIP(ctx, ctx->pos_sorted.reserve((size_t)n * sizeof(ss_pos<R>) + 16));
     const size_t nsub = (size_t)P.ns[0] * P.ns[1] * P.ns[2];
     if (nsub >= (1ull << 32) - 2) return fail(ctx, SS_ERR_UNSUPPORTED, "more than 2^32 subdomains");
     SS_HIP(ctx, ctx->copy_offset.reserve(((size_t)n + 1) * 4));
@@ -865,7 +865,7 @@ ss_status phase_begin(ss_context* ctx, const R* xyz, uint64_t n_in, const typena
         if (vals[r] != res->perm.as<uint32_t>()) return fail(ctx, SS_ERR_UNKNOWN, "internal error: sort result in an unexpected buffer");
         sorted_keys = keys[r];
     }
-    ss_launch_sorted_gather_runs(P, n, d_xyz, res->perm.as<uint32_t>(), ctx->pos_sorted.as<ss_real4<R>>(), sorted_keys, (uint32_t)ncells, cell_first, (const uint32_t*)nullptr,
+    ss_launch_sorted_gather_runs(P, n, d_xyz, res->perm.as<uint32_t>(), ctx->pos_sorted.as<ss_pos<R>>(), sorted_keys, (uint32_t)ncells, cell_first, (const uint32_t*)nullptr,
                                  (uint8_t*)nullptr, st);
     ss_launch_cell_table_scan(cell_first, (uint32_t)ncells, ctx->cell_start.as<uint32_t>(), st_cells, st);
     SS_HIP(ctx, hipEventRecord(ctx->ev[3], st));
@@ -894,7 +894,7 @@ ss_status phase_begin(ss_context* ctx, const R* xyz, uint64_t n_in, const typena
             SS_HIP(ctx, ctx->ckeys_b.reserve((size_t)n_copies * 4 + 16));
             SS_HIP(ctx, ctx->cvals_a.reserve((size_t)n_copies * 4 + 16));
             SS_HIP(ctx, ctx->cidx.reserve((size_t)n_copies * 4 + 16));
-            SS_HIP(ctx, ctx->cpos.reserve(((size_t)n_copies + 16) * sizeof(ss_real4<R>)));  // + padding: k_density_sub reads whole chunks
+            SS_HIP(ctx, ctx->cpos.reserve(((size_t)n_copies + 16) * sizeof(ss_pos<R>)));  // + padding: k_density_sub reads whole chunks
             SS_HIP(ctx, ctx->cell_start2.reserve((ncells2 + 1) * 4));
             SS_HIP(ctx, ctx->own_flag.reserve(((size_t)n_copies + 16) * 5 + 128));  // the list of owned copies (u32), then their flags (u8)
             unsigned bits = 1;
@@ -919,7 +919,7 @@ ss_status phase_begin(ss_context* ctx, const R* xyz, uint64_t n_in, const typena
             const uint32_t* ckeys_sorted = keys[r];
             uint32_t* own_list = ctx->own_flag.as<uint32_t>();
             uint8_t* own_flags = reinterpret_cast<uint8_t*>(own_list + ((size_t)n_copies + 16));
-            ss_launch_sorted_gather_runs(P, n_copies, d_xyz, ctx->cidx.as<uint32_t>(), ctx->cpos.as<ss_real4<R>>(), ckeys_sorted, (uint32_t)ncells2, cell_first2,
+            ss_launch_sorted_gather_runs(P, n_copies, d_xyz, ctx->cidx.as<uint32_t>(), ctx->cpos.as<ss_pos<R>>(), ckeys_sorted, (uint32_t)ncells2, cell_first2,
                                          ctx->occ_sub.as<uint32_t>(), own_flags, st);
             ss_launch_cell_table_scan(cell_first2, (uint32_t)ncells2, ctx->cell_start2.as<uint32_t>(), st_cells2, st);
             const bool want_nb = prm->global_neighborhood_list != 0;
@@ -934,7 +934,7 @@ ss_status phase_begin(ss_context* ctx, const R* xyz, uint64_t n_in, const typena
             ss_launch_owned_scan(n_copies, own_flags, own_list, n_owned_dev, st_owned, st);
             const uint32_t n_owned_bound = n < n_copies ? n : n_copies;  // at most one owned copy per particle
             SS_HIP(ctx, hipEventRecord(ctx->ev[18], st));
-            ss_launch_density_sub(P, n_copies, ctx->cpos.as<ss_real4<R>>(), ctx->cidx.as<uint32_t>(), ckeys_sorted,
+            ss_launch_density_sub(P, n_copies, ctx->cpos.as<ss_pos<R>>(), ctx->cidx.as<uint32_t>(), ckeys_sorted,
                                   ctx->cell_start2.as<uint32_t>(), ctx->occ_sub.as<uint32_t>(), res->rho.as<R>(), want_nb ? 1 : 0,
                                   ctx->nb_count.as<uint32_t>(), nullptr, nullptr, sizeof(R) == 4 && ctx->fastdiv_ok, own_list, n_owned_dev, n_owned_bound, st);
             SS_HIP(ctx, hipEventRecord(ctx->ev[19], st));
@@ -951,7 +951,7 @@ ss_status phase_begin(ss_context* ctx, const R* xyz, uint64_t n_in, const typena
                 if (total_nb >= (1ull << 32)) return fail(ctx, SS_ERR_UNSUPPORTED, "more than 2^32 neighbour entries");
                 res->n_neighbors = total_nb;
                 SS_HIP(ctx, res->nb_idx.reserve((size_t)total_nb * 4 + 16));
-                ss_launch_density_sub(P, n_copies, ctx->cpos.as<ss_real4<R>>(), ctx->cidx.as<uint32_t>(), ckeys_sorted,
+                ss_launch_density_sub(P, n_copies, ctx->cpos.as<ss_pos<R>>(), ctx->cidx.as<uint32_t>(), ckeys_sorted,
                                       ctx->cell_start2.as<uint32_t>(), ctx->occ_sub.as<uint32_t>(), res->rho.as<R>(), 2, nullptr,
                                       res->nb_ptr.as<unsigned long long>(), res->nb_idx.as<uint32_t>(), false, own_list, n_owned_dev, n_owned_bound, st);
             }
@@ -986,7 +986,7 @@ ss_status phase_finish(ss_context* ctx, ss_result* res) {
     s = ensure_mail(ctx);
     if (s != SS_OK) return s;
     SS_HIP(ctx, hipEventRecord(ctx->ev[10], st));
-    ss_launch_make_posvol(P, ctx->pos_sorted.as<ss_real4<R>>(), res->perm.as<uint32_t>(), res->rho.as<R>(), res->posvol.as<ss_real4<R>>(), res->posvol_by_index.as<ss_real4<R>>(), st);
+    ss_launch_make_posvol(P, ctx->pos_sorted.as<ss_pos<R>>(), res->perm.as<uint32_t>(), res->rho.as<R>(), res->posvol.as<ss_real4<R>>(), res->posvol_by_index.as<ss_real4<R>>(), st);
     SS_HIP(ctx, hipEventRecord(ctx->ev[11], st));
 
     // ---- K3 prepare: active level-set blocks ----

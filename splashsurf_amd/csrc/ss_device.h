@@ -49,10 +49,27 @@ template <> struct SSVec<double> { using v2 = double2; using v4 = double4; };
 template <class R> using ss_real2 = typename SSVec<R>::v2;
 template <class R> using ss_real4 = typename SSVec<R>::v4;
 
+// positions in sorted order (the K1 cell order, the per-subdomain copies of the density stage): three values per particle, 12 / 24 bytes --
+// the density kernel is bound by the vector L1, and the fourth lane of a float4 was padding.  -DSS_POS4 restores the padded form (A/B).
+template <class R> struct ss_real3 { R x, y, z; };
+#ifdef SS_POS4
+template <class R> using ss_pos = typename SSVec<R>::v4;
+#else
+template <class R> using ss_pos = ss_real3<R>;
+#endif
 __host__ __device__ inline float4 ss_make4(float x, float y, float z, float w) { return make_float4(x, y, z, w); }
 __host__ __device__ inline double4 ss_make4(double x, double y, double z, double w) { return make_double4(x, y, z, w); }
 __host__ __device__ inline float2 ss_make2(float x, float y) { return make_float2(x, y); }
 __host__ __device__ inline double2 ss_make2(double x, double y) { return make_double2(x, y); }
+
+template <class R>
+__host__ __device__ inline ss_pos<R> ss_make_pos(R x, R y, R z) {
+#ifdef SS_POS4
+    return ss_make4(x, y, z, R(0.0));
+#else
+    return ss_pos<R>{x, y, z};
+#endif
+}
 
 __host__ __device__ inline float ss_floor(float x) { return floorf(x); }
 __host__ __device__ inline double ss_floor(double x) { return floor(x); }

@@ -14,18 +14,16 @@ void ss_launch_run_starts(const uint32_t* sorted_keys, uint32_t n, uint32_t ncel
 template <class R>
 void ss_launch_cell_keys(const SSDevT<R>& P, const R* d_xyz, uint32_t* keys, uint32_t* vals, hipStream_t st);
 template <class R>
-void ss_launch_gather_sorted(uint32_t n, const R* d_xyz, const uint32_t* perm, ss_real4<R>* pos_sorted, hipStream_t st);
+void ss_launch_gather_sorted(uint32_t n, const R* d_xyz, const uint32_t* perm, ss_pos<R>* pos_sorted, hipStream_t st);
 template <class R>
 void ss_launch_classify_count(const SSDevT<R>& P, const R* xyz, uint32_t* member_count, uint32_t* sub_flag, hipStream_t st);
 void ss_launch_occupied_list(const uint32_t* flag, const uint32_t* rank, uint32_t n, uint32_t* occ_sub, hipStream_t st);
 template <class R>
 void ss_launch_emit_copies(const SSDevT<R>& P, const R* xyz, const uint32_t* copy_offset, const uint32_t* occ_rank, uint32_t* keys, uint32_t* vals, hipStream_t st);
 template <class R>
-void ss_launch_density_sub(const SSDevT<R>& P, uint32_t n_copies, const ss_real4<R>* cpos, const uint32_t* cidx, const uint32_t* ckey, const uint32_t* cell_start, const uint32_t* occ_sub, R* rho, int mode, uint32_t* nb_count, const unsigned long long* nb_ptr, uint32_t* nb_idx, bool fast_div, const uint32_t* owned_list, const uint32_t* n_owned_dev, uint32_t n_owned_bound, hipStream_t st);
+void ss_launch_density_sub(const SSDevT<R>& P, uint32_t n_copies, const ss_pos<R>* cpos, const uint32_t* cidx, const uint32_t* ckey, const uint32_t* cell_start, const uint32_t* occ_sub, R* rho, int mode, uint32_t* nb_count, const unsigned long long* nb_ptr, uint32_t* nb_idx, bool fast_div, const uint32_t* owned_list, const uint32_t* n_owned_dev, uint32_t n_owned_bound, hipStream_t st);
 template <class R>
-void ss_launch_owned_copy_flags(const SSDevT<R>& P, uint32_t n_copies, const ss_real4<R>* cpos, const uint32_t* ckey, const uint32_t* occ_sub, uint32_t* owned, hipStream_t st);
-template <class R>
-void ss_launch_make_posvol(const SSDevT<R>& P, const ss_real4<R>* pos_sorted, const uint32_t* perm, const R* rho, ss_real4<R>* posvol, ss_real4<R>* posvol_by_index, hipStream_t st);
+void ss_launch_make_posvol(const SSDevT<R>& P, const ss_pos<R>* pos_sorted, const uint32_t* perm, const R* rho, ss_real4<R>* posvol, ss_real4<R>* posvol_by_index, hipStream_t st);
 template <class R>
 void ss_launch_mark_blocks(const SSDevT<R>& P, const uint32_t* cell_start, uint32_t ncells, uint32_t* block_flag, hipStream_t st);
 template <class R>
@@ -61,7 +59,7 @@ void ss_launch_levelset_box(const SSDevT<R>& P, const R* G, const uint32_t* bloc
 
 // fused scans of the host flow (one dispatch each, ss_prims.h)
 template <class R>
-void ss_launch_sorted_gather_runs(const SSDevT<R>& P, uint32_t n, const R* xyz, const uint32_t* perm, ss_real4<R>* pos_sorted, const uint32_t* sorted_keys, uint32_t ncells, uint32_t* first, const uint32_t* occ_sub, uint8_t* owned, hipStream_t st);
+void ss_launch_sorted_gather_runs(const SSDevT<R>& P, uint32_t n, const R* xyz, const uint32_t* perm, ss_pos<R>* pos_sorted, const uint32_t* sorted_keys, uint32_t ncells, uint32_t* first, const uint32_t* occ_sub, uint8_t* owned, hipStream_t st);
 void ss_launch_cell_table_scan(const uint32_t* first, uint32_t ncells, uint32_t* cell_start, uint32_t* state, hipStream_t st);
 template <class R>
 void ss_launch_classify_scan(const SSDevT<R>& P, const R* xyz, uint32_t* copy_offset, uint32_t* sub_flag, uint32_t* state, SSMailSlot mail, hipStream_t st);

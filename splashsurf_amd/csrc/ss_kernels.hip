@@ -201,11 +201,11 @@ void ss_launch_run_starts(const uint32_t* sorted_keys, uint32_t n, uint32_t ncel
 
 template <class R>
 __global__ __launch_bounds__(256) void k_gather_sorted(uint32_t n, const R* __restrict__ xyz, const uint32_t* __restrict__ perm,
-                                                       ss_real4<R>* __restrict__ pos_sorted) {
+                                                       ss_pos<R>* __restrict__ pos_sorted) {
     uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= n) return;
     size_t i = perm[p];
-    pos_sorted[p] = ss_make4(xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2], R(0.0));
+    pos_sorted[p] = ss_make_pos<R>(xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2]);
 }
 
 template <class R>
@@ -214,7 +214,7 @@ void ss_launch_cell_keys(const SSDevT<R>& P, const R* d_xyz, uint32_t* keys, uin
     hipLaunchKernelGGL(k_cell_keys<R>, dim3((P.n + 255) / 256), dim3(256), 0, st, P, d_xyz, keys, vals);
 }
 template <class R>
-void ss_launch_gather_sorted(uint32_t n, const R* d_xyz, const uint32_t* perm, ss_real4<R>* pos_sorted, hipStream_t st) {
+void ss_launch_gather_sorted(uint32_t n, const R* d_xyz, const uint32_t* perm, ss_pos<R>* pos_sorted, hipStream_t st) {
     if (!n) return;
     hipLaunchKernelGGL(k_gather_sorted<R>, dim3((n + 255) / 256), dim3(256), 0, st, n, d_xyz, perm, pos_sorted);
 }
@@ -458,40 +458,11 @@ template <class R> struct SSDensityQueue {
     static constexpr int cap = sizeof(R) == 4 ? 16 : 8;
     static constexpr int chunk = 4;  // candidates between two fill checks
 };
-// owned[p] = copy p lies inside the half-open AABB of its subdomain (is_inside, dense_subdomains.rs:567-576, aabb.rs:220-222):
-// the copy whose density this subdomain computes; the others are ghosts, their density comes from another subdomain
-template <class R>
-__global__ __launch_bounds__(256) void k_owned_copy_flags(SSDevT<R> P, uint32_t n_copies, const ss_real4<R>* __restrict__ cpos, const uint32_t* __restrict__ ckey,
-                                                          const uint32_t* __restrict__ occ_sub, uint32_t* __restrict__ owned) {
-    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p > n_copies) return;
-    uint32_t f = 0;
-    if (p < n_copies) {
-        const uint32_t ctot = (uint32_t)(P.sc[0] * P.sc[1] * P.sc[2]);
-        const uint32_t flat = occ_sub[ckey[p] / ctot];
-        const int s3[3] = {(int)(flat / ((uint32_t)P.ns[2] * (uint32_t)P.ns[1])), (int)((flat / (uint32_t)P.ns[2]) % (uint32_t)P.ns[1]), (int)(flat % (uint32_t)P.ns[2])};
-        const ss_real4<R> pi = cpos[p];
-        const R x3[3] = {pi.x, pi.y, pi.z};
-        f = 1;
-#pragma unroll
-        for (int d = 0; d < 3; ++d) {
-            const R lo = P.gmin[d] + (R)s3[d] * P.sub_size;
-            const R hi = P.gmin[d] + (R)(s3[d] + 1) * P.sub_size;
-            if (!(x3[d] >= lo && x3[d] < hi)) f = 0;
-        }
-    }
-    owned[p] = f;  // entry n_copies: 0, so that the exclusive scan ends with the count
-}
-template <class R>
-void ss_launch_owned_copy_flags(const SSDevT<R>& P, uint32_t n_copies, const ss_real4<R>* cpos, const uint32_t* ckey, const uint32_t* occ_sub, uint32_t* owned, hipStream_t st) {
-    hipLaunchKernelGGL(k_owned_copy_flags<R>, dim3((n_copies + 1u + 255u) / 256u), dim3(256), 0, st, P, n_copies, cpos, ckey, occ_sub, owned);
-}
-
 // MODE 0: densities.  MODE 1: densities + neighbour counts (global_neighborhood_list).
 // MODE 2: write the neighbour ids (global particle indices) at nb_ptr[i], in the reference's order
 // (dense_subdomains.rs:617-639: the per-subdomain lists remapped to global indices).
 template <class R, int MODE, bool FAST>
-__global__ __launch_bounds__(256) void k_density_sub(SSDevT<R> P, uint32_t n_copies, const ss_real4<R>* __restrict__ cpos, const uint32_t* __restrict__ cidx,
+__global__ __launch_bounds__(256) void k_density_sub(SSDevT<R> P, uint32_t n_copies, const ss_pos<R>* __restrict__ cpos, const uint32_t* __restrict__ cidx,
                                                      const uint32_t* __restrict__ ckey, const uint32_t* __restrict__ cell_start,
                                                      const uint32_t* __restrict__ occ_sub, R* __restrict__ rho,
                                                      uint32_t* __restrict__ nb_count, const unsigned long long* __restrict__ nb_ptr,
@@ -512,7 +483,7 @@ __global__ __launch_bounds__(256) void k_density_sub(SSDevT<R> P, uint32_t n_cop
     const int sz = (int)(flat % (uint32_t)P.ns[2]);
     const int sy = (int)((flat / (uint32_t)P.ns[2]) % (uint32_t)P.ns[1]);
     const int sx = (int)(flat / ((uint32_t)P.ns[2] * (uint32_t)P.ns[1]));
-    const ss_real4<R> pi = cpos[p];
+    const ss_pos<R> pi = cpos[p];
     (void)sx;
     (void)sy;
     (void)sz;
@@ -574,8 +545,8 @@ __global__ __launch_bounds__(256) void k_density_sub(SSDevT<R> P, uint32_t n_cop
                 if (__any(cnt > (uint32_t)(QC - QD))) flush();
             // QD candidates per trip, loads issued together from one base address; slots beyond the run are predicated
             // off (they read the next cells' copies -- cpos is padded by QD entries at its end)
-            const ss_real4<R>* cq = cpos + q;
-            ss_real4<R> pj[QD];
+            const ss_pos<R>* cq = cpos + q;
+            ss_pos<R> pj[QD];
 #pragma unroll
             for (int j = 0; j < QD; ++j) pj[j] = cq[j];
 #pragma unroll
@@ -601,11 +572,11 @@ __global__ __launch_bounds__(256) void k_density_sub(SSDevT<R> P, uint32_t n_cop
 
 // (x, y, z, V = m / rho) in global-cell order for the splat (v_i of dense_subdomains.rs:832)
 template <class R>
-__global__ __launch_bounds__(256) void k_make_posvol(SSDevT<R> P, const ss_real4<R>* __restrict__ pos_sorted, const uint32_t* __restrict__ perm,
+__global__ __launch_bounds__(256) void k_make_posvol(SSDevT<R> P, const ss_pos<R>* __restrict__ pos_sorted, const uint32_t* __restrict__ perm,
                                                      const R* __restrict__ rho, ss_real4<R>* __restrict__ posvol, ss_real4<R>* __restrict__ posvol_by_index) {
     uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= P.n) return;
-    const ss_real4<R> a = pos_sorted[p];
+    const ss_pos<R> a = pos_sorted[p];
     const uint32_t i = perm[p];
     const ss_real4<R> v = ss_make4(a.x, a.y, a.z, P.mass / rho[i]);
     posvol[p] = v;
@@ -628,7 +599,7 @@ void ss_launch_emit_copies(const SSDevT<R>& P, const R* xyz, const uint32_t* cop
     hipLaunchKernelGGL(k_emit_copies<R>, dim3((P.n + 255) / 256), dim3(256), 0, st, P, xyz, copy_offset, occ_rank, keys, vals);
 }
 template <class R>
-void ss_launch_density_sub(const SSDevT<R>& P, uint32_t n_copies, const ss_real4<R>* cpos, const uint32_t* cidx, const uint32_t* ckey,
+void ss_launch_density_sub(const SSDevT<R>& P, uint32_t n_copies, const ss_pos<R>* cpos, const uint32_t* cidx, const uint32_t* ckey,
                            const uint32_t* cell_start, const uint32_t* occ_sub, R* rho, int mode, uint32_t* nb_count,
                            const unsigned long long* nb_ptr, uint32_t* nb_idx, bool fast_div, const uint32_t* owned_list, const uint32_t* n_owned_dev,
                            uint32_t n_owned_bound, hipStream_t st) {
@@ -651,7 +622,7 @@ void ss_launch_density_sub(const SSDevT<R>& P, uint32_t n_copies, const ss_real4
         hipLaunchKernelGGL((k_density_sub<R, 2, false>), g, b, 0, st, P, n_copies, cpos, cidx, ckey, cell_start, occ_sub, rho, nb_count, nb_ptr, nb_idx, owned_list, n_owned_dev);
 }
 template <class R>
-void ss_launch_make_posvol(const SSDevT<R>& P, const ss_real4<R>* pos_sorted, const uint32_t* perm, const R* rho, ss_real4<R>* posvol,
+void ss_launch_make_posvol(const SSDevT<R>& P, const ss_pos<R>* pos_sorted, const uint32_t* perm, const R* rho, ss_real4<R>* posvol,
                            ss_real4<R>* posvol_by_index, hipStream_t st) {
     if (!P.n) return;
     hipLaunchKernelGGL(k_make_posvol<R>, dim3((P.n + 255) / 256), dim3(256), 0, st, P, pos_sorted, perm, rho, posvol, posvol_by_index);
@@ -3051,7 +3022,7 @@ void ss_launch_levelset_box(const SSDevT<R>& P, const R* G, const uint32_t* bloc
 // sorted order -> payload, and the run starts of the cell table in the same pass: first[c] = ~(position of the first entry of cell c),
 // first[ncells] = ~n, 0 = no entry (the table is preset to 0); ss_launch_cell_table_scan turns it into cell_start
 template <class R, bool OWNED>
-__global__ __launch_bounds__(256) void k_sorted_gather_runs(SSDevT<R> P, uint32_t n, const R* __restrict__ xyz, const uint32_t* __restrict__ perm, ss_real4<R>* __restrict__ pos_sorted,
+__global__ __launch_bounds__(256) void k_sorted_gather_runs(SSDevT<R> P, uint32_t n, const R* __restrict__ xyz, const uint32_t* __restrict__ perm, ss_pos<R>* __restrict__ pos_sorted,
                                                             const uint32_t* __restrict__ sorted_keys, uint32_t ncells, uint32_t* __restrict__ first,
                                                             const uint32_t* __restrict__ occ_sub, uint8_t* __restrict__ owned) {
     const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
@@ -3062,7 +3033,7 @@ __global__ __launch_bounds__(256) void k_sorted_gather_runs(SSDevT<R> P, uint32_
     }
     const size_t i = perm[p];
     const R x3[3] = {xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2]};
-    pos_sorted[p] = ss_make4(x3[0], x3[1], x3[2], R(0.0));
+    pos_sorted[p] = ss_make_pos<R>(x3[0], x3[1], x3[2]);
     const uint32_t k = sorted_keys[p];
     if (p == 0 || sorted_keys[p - 1] != k) first[k] = ~p;
     if constexpr (OWNED) {
@@ -3082,7 +3053,7 @@ __global__ __launch_bounds__(256) void k_sorted_gather_runs(SSDevT<R> P, uint32_
     }
 }
 template <class R>
-void ss_launch_sorted_gather_runs(const SSDevT<R>& P, uint32_t n, const R* xyz, const uint32_t* perm, ss_real4<R>* pos_sorted, const uint32_t* sorted_keys, uint32_t ncells, uint32_t* first,
+void ss_launch_sorted_gather_runs(const SSDevT<R>& P, uint32_t n, const R* xyz, const uint32_t* perm, ss_pos<R>* pos_sorted, const uint32_t* sorted_keys, uint32_t ncells, uint32_t* first,
                                   const uint32_t* occ_sub, uint8_t* owned, hipStream_t st) {
     if (owned)
         hipLaunchKernelGGL((k_sorted_gather_runs<R, true>), dim3((n + 1u + 255u) / 256u), dim3(256), 0, st, P, n, xyz, perm, pos_sorted, sorted_keys, ncells, first, occ_sub, owned);
@@ -3273,8 +3244,8 @@ void ss_launch_tile_offsets_scan(const uint32_t* bound, uint32_t n, unsigned lon
 __global__ void k_publish_u32(const uint32_t* __restrict__ src, SSMailSlot mail) { ss_mail_post(mail, (unsigned long long)src[0]); }
 void ss_launch_publish_u32(const uint32_t* src, SSMailSlot mail, hipStream_t st) { hipLaunchKernelGGL(k_publish_u32, dim3(1), dim3(1), 0, st, src, mail); }
 
-template void ss_launch_sorted_gather_runs<float>(const SSDevT<float>&, uint32_t, const float*, const uint32_t*, ss_real4<float>*, const uint32_t*, uint32_t, uint32_t*, const uint32_t*, uint8_t*, hipStream_t);
-template void ss_launch_sorted_gather_runs<double>(const SSDevT<double>&, uint32_t, const double*, const uint32_t*, ss_real4<double>*, const uint32_t*, uint32_t, uint32_t*, const uint32_t*, uint8_t*, hipStream_t);
+template void ss_launch_sorted_gather_runs<float>(const SSDevT<float>&, uint32_t, const float*, const uint32_t*, ss_pos<float>*, const uint32_t*, uint32_t, uint32_t*, const uint32_t*, uint8_t*, hipStream_t);
+template void ss_launch_sorted_gather_runs<double>(const SSDevT<double>&, uint32_t, const double*, const uint32_t*, ss_pos<double>*, const uint32_t*, uint32_t, uint32_t*, const uint32_t*, uint8_t*, hipStream_t);
 template void ss_launch_classify_scan<float>(const SSDevT<float>&, const float*, uint32_t*, uint32_t*, uint32_t*, SSMailSlot, hipStream_t);
 template void ss_launch_classify_scan<double>(const SSDevT<double>&, const double*, uint32_t*, uint32_t*, uint32_t*, SSMailSlot, hipStream_t);
 template void ss_launch_active_blocks_scan<float>(const SSDevT<float>&, const uint32_t*, uint32_t, uint32_t, uint32_t*, uint32_t*, uint32_t*, uint32_t*, SSMailSlot, hipStream_t);
@@ -3291,20 +3262,18 @@ template void ss_launch_compact_xyz<float>(const float* d_xyz, uint32_t n, const
 template void ss_launch_compact_xyz<double>(const double* d_xyz, uint32_t n, const uint32_t* f32, const uint32_t* offs, double* out, hipStream_t st);
 template void ss_launch_cell_keys<float>(const SSDevT<float>& P, const float* d_xyz, uint32_t* keys, uint32_t* vals, hipStream_t st);
 template void ss_launch_cell_keys<double>(const SSDevT<double>& P, const double* d_xyz, uint32_t* keys, uint32_t* vals, hipStream_t st);
-template void ss_launch_gather_sorted<float>(uint32_t n, const float* d_xyz, const uint32_t* perm, ss_real4<float>* pos_sorted, hipStream_t st);
-template void ss_launch_gather_sorted<double>(uint32_t n, const double* d_xyz, const uint32_t* perm, ss_real4<double>* pos_sorted, hipStream_t st);
+template void ss_launch_gather_sorted<float>(uint32_t n, const float* d_xyz, const uint32_t* perm, ss_pos<float>* pos_sorted, hipStream_t st);
+template void ss_launch_gather_sorted<double>(uint32_t n, const double* d_xyz, const uint32_t* perm, ss_pos<double>* pos_sorted, hipStream_t st);
 template void ss_launch_classify_count<float>(const SSDevT<float>& P, const float* xyz, uint32_t* member_count, uint32_t* sub_flag, hipStream_t st);
 template void ss_launch_classify_count<double>(const SSDevT<double>& P, const double* xyz, uint32_t* member_count, uint32_t* sub_flag, hipStream_t st);
 template void ss_launch_emit_copies<float>(const SSDevT<float>& P, const float* xyz, const uint32_t* copy_offset, const uint32_t* occ_rank, uint32_t* keys, uint32_t* vals, hipStream_t st);
 template void ss_launch_emit_copies<double>(const SSDevT<double>& P, const double* xyz, const uint32_t* copy_offset, const uint32_t* occ_rank, uint32_t* keys, uint32_t* vals, hipStream_t st);
-template void ss_launch_owned_copy_flags<float>(const SSDevT<float>& P, uint32_t n_copies, const ss_real4<float>* cpos, const uint32_t* ckey, const uint32_t* occ_sub, uint32_t* owned, hipStream_t st);
-template void ss_launch_owned_copy_flags<double>(const SSDevT<double>& P, uint32_t n_copies, const ss_real4<double>* cpos, const uint32_t* ckey, const uint32_t* occ_sub, uint32_t* owned, hipStream_t st);
-template void ss_launch_density_sub<float>(const SSDevT<float>& P, uint32_t n_copies, const ss_real4<float>* cpos, const uint32_t* cidx, const uint32_t* ckey, const uint32_t* cell_start, const uint32_t* occ_sub, float* rho, int mode, uint32_t* nb_count, const unsigned long long* nb_ptr, uint32_t* nb_idx, bool fast_div, const uint32_t* owned_list, const uint32_t* n_owned_dev, uint32_t n_owned_bound, hipStream_t st);
-template void ss_launch_density_sub<double>(const SSDevT<double>& P, uint32_t n_copies, const ss_real4<double>* cpos, const uint32_t* cidx, const uint32_t* ckey, const uint32_t* cell_start, const uint32_t* occ_sub, double* rho, int mode, uint32_t* nb_count, const unsigned long long* nb_ptr, uint32_t* nb_idx, bool fast_div, const uint32_t* owned_list, const uint32_t* n_owned_dev, uint32_t n_owned_bound, hipStream_t st);
+template void ss_launch_density_sub<float>(const SSDevT<float>& P, uint32_t n_copies, const ss_pos<float>* cpos, const uint32_t* cidx, const uint32_t* ckey, const uint32_t* cell_start, const uint32_t* occ_sub, float* rho, int mode, uint32_t* nb_count, const unsigned long long* nb_ptr, uint32_t* nb_idx, bool fast_div, const uint32_t* owned_list, const uint32_t* n_owned_dev, uint32_t n_owned_bound, hipStream_t st);
+template void ss_launch_density_sub<double>(const SSDevT<double>& P, uint32_t n_copies, const ss_pos<double>* cpos, const uint32_t* cidx, const uint32_t* ckey, const uint32_t* cell_start, const uint32_t* occ_sub, double* rho, int mode, uint32_t* nb_count, const unsigned long long* nb_ptr, uint32_t* nb_idx, bool fast_div, const uint32_t* owned_list, const uint32_t* n_owned_dev, uint32_t n_owned_bound, hipStream_t st);
 template void ss_launch_block_coords<float>(const SSDevT<float>& P, const uint32_t* active_list, uint32_t n_active, uint32_t* xyz, hipStream_t st);
 template void ss_launch_block_coords<double>(const SSDevT<double>& P, const uint32_t* active_list, uint32_t n_active, uint32_t* xyz, hipStream_t st);
-template void ss_launch_make_posvol<float>(const SSDevT<float>& P, const ss_real4<float>* pos_sorted, const uint32_t* perm, const float* rho, ss_real4<float>* posvol, ss_real4<float>* posvol_by_index, hipStream_t st);
-template void ss_launch_make_posvol<double>(const SSDevT<double>& P, const ss_real4<double>* pos_sorted, const uint32_t* perm, const double* rho, ss_real4<double>* posvol, ss_real4<double>* posvol_by_index, hipStream_t st);
+template void ss_launch_make_posvol<float>(const SSDevT<float>& P, const ss_pos<float>* pos_sorted, const uint32_t* perm, const float* rho, ss_real4<float>* posvol, ss_real4<float>* posvol_by_index, hipStream_t st);
+template void ss_launch_make_posvol<double>(const SSDevT<double>& P, const ss_pos<double>* pos_sorted, const uint32_t* perm, const double* rho, ss_real4<double>* posvol, ss_real4<double>* posvol_by_index, hipStream_t st);
 template void ss_launch_mark_blocks<float>(const SSDevT<float>& P, const uint32_t* cell_start, uint32_t ncells, uint32_t* block_flag, hipStream_t st);
 template void ss_launch_mark_blocks<double>(const SSDevT<double>& P, const uint32_t* cell_start, uint32_t ncells, uint32_t* block_flag, hipStream_t st);
 template void ss_launch_mark_mc_blocks<float>(const SSDevT<float>& P, const uint32_t* block_slot, const ss_real2<float>* blk_minmax, uint32_t nblocks, uint32_t* mc_flag, hipStream_t st);
