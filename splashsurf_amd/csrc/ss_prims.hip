@@ -9,7 +9,7 @@
 // index inside a cell = the reference's order, neighborhood_search.rs:692-707).
 #include "ss_prims.h"
 
-#define RS_ROUNDS 16  // SS_RS_TILE / 256
+#define RS_ROUNDS 16  // pairs per thread
 
 // Digit histograms of all passes.  The keys of a wave often agree in their high digits (spatially coherent input): LDS atomics of all 64
 // lanes on one counter serialise, so every group of lanes with the same (lane & 7) has its own copy of the counters (8-way instead of
@@ -45,7 +45,8 @@ __global__ __launch_bounds__(256) void k_rs_hist(const uint32_t* __restrict__ ke
     }
 }
 
-// exclusive prefix over the 256 threads of the workgroup (s_tmp: 4 words)
+// exclusive prefix over the NT threads of the workgroup (s_tmp: NT / 64 words)
+template <int NT>
 __device__ __forceinline__ uint32_t rs_block_excl(uint32_t v, uint32_t* s_tmp, int tid) {
     const int lane = tid & 63, wave = tid >> 6;
     const uint32_t incl = ss_prim_wave_incl_u32(v);
@@ -57,22 +58,26 @@ __device__ __forceinline__ uint32_t rs_block_excl(uint32_t v, uint32_t* s_tmp, i
     return base + incl - v;
 }
 
-__global__ __launch_bounds__(256) void k_rs_pass(const uint32_t* __restrict__ kin, const uint32_t* __restrict__ vin, uint32_t* __restrict__ kout, uint32_t* __restrict__ vout,
-                                                 uint32_t n, int shift, const uint32_t* __restrict__ hist, uint32_t* __restrict__ tile_counter, uint32_t* __restrict__ status) {
-    __shared__ uint32_t s_cnt[4][256];  // per wave: keys of digit d seen so far; afterwards: the wave's offset inside the tile's run of digit d
-    __shared__ uint32_t s_lbase[256];   // start of digit d's run in the staged tile
-    __shared__ uint32_t s_gbase[256];   // start of the tile's run of digit d in the output
-    __shared__ uint32_t s_keys[SS_RS_TILE];
-    __shared__ uint32_t s_vals[SS_RS_TILE];
-    __shared__ uint32_t s_tmp[4];
+// NT threads, a tile of 16 NT pairs; the tile is staged through LDS twice (keys, then values: one 4-byte array of the tile's size)
+template <int NT>
+__global__ __launch_bounds__(NT) void k_rs_pass(const uint32_t* __restrict__ kin, const uint32_t* __restrict__ vin, uint32_t* __restrict__ kout, uint32_t* __restrict__ vout,
+                                                uint32_t n, int shift, const uint32_t* __restrict__ hist, uint32_t* __restrict__ tile_counter, uint32_t* __restrict__ status) {
+    constexpr int NW = NT / 64, TILE = NT * RS_ROUNDS, PER_WAVE = TILE / NW;
+    __shared__ uint32_t s_cnt[NW][256];  // per wave: keys of digit d seen so far; afterwards: the wave's offset inside the tile's run of digit d
+    __shared__ uint32_t s_lbase[256];    // start of digit d's run in the staged tile
+    __shared__ uint32_t s_gbase[256];    // start of the tile's run of digit d in the output
+    __shared__ uint32_t s_stage[TILE];
+    __shared__ uint32_t s_tmp[NW];
     __shared__ uint32_t s_tile;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (tid == 0) s_tile = atomicAdd(tile_counter, 1u);
+    if (tid < 256) {
 #pragma unroll
-    for (int w = 0; w < 4; ++w) s_cnt[w][tid] = 0u;
+        for (int w = 0; w < NW; ++w) s_cnt[w][tid] = 0u;
+    }
     __syncthreads();
     const uint32_t tile = s_tile;
-    const size_t base = (size_t)tile * SS_RS_TILE + (size_t)wave * (SS_RS_TILE / 4);
+    const size_t base = (size_t)tile * TILE + (size_t)wave * PER_WAVE;
     uint32_t k[RS_ROUNDS], v[RS_ROUNDS];
     uint16_t rk[RS_ROUNDS];
 #pragma unroll
@@ -108,60 +113,77 @@ __global__ __launch_bounds__(256) void k_rs_pass(const uint32_t* __restrict__ ki
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
     __syncthreads();
-    // thread d: the tile's count of digit d, the waves' offsets inside that run
-    const uint32_t c0 = s_cnt[0][tid], c1 = s_cnt[1][tid], c2 = s_cnt[2][tid], c3 = s_cnt[3][tid];
-    const uint32_t total = c0 + c1 + c2 + c3;
-    s_cnt[0][tid] = 0u;
-    s_cnt[1][tid] = c0;
-    s_cnt[2][tid] = c0 + c1;
-    s_cnt[3][tid] = c0 + c1 + c2;
-    // look-back over the preceding tiles' counts of digit d: flags (bits 31:30) 0 not there yet, 1 count of that tile, 2 count of all tiles up to it
-    const uint32_t VALUE = (1u << 30) - 1u;
-    uint32_t prev = 0;
-    if (tile > 0) {
-        __hip_atomic_store(&status[(size_t)tile * 256u + (size_t)tid], (1u << 30) | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        long long p = (long long)tile - 1;
-        while (true) {
-            const uint32_t s = __hip_atomic_load(&status[(size_t)p * 256u + (size_t)tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const uint32_t flag = s >> 30;
-            if (flag == 0u) {
-                __builtin_amdgcn_s_sleep(1);
-                continue;
-            }
-            prev += s & VALUE;
-            if (flag == 2u) break;
-            --p;
+    uint32_t total = 0, prev = 0;
+    if (tid < 256) {
+        // thread d: the tile's count of digit d, the waves' offsets inside that run
+#pragma unroll
+        for (int w = 0; w < NW; ++w) {
+            const uint32_t c = s_cnt[w][tid];
+            s_cnt[w][tid] = total;
+            total += c;
         }
+        // look-back over the preceding tiles' counts of digit d: flags (bits 31:30) 0 not there yet, 1 count of that tile, 2 count of all tiles up to it
+        const uint32_t VALUE = (1u << 30) - 1u;
+        if (tile > 0) {
+            __hip_atomic_store(&status[(size_t)tile * 256u + (size_t)tid], (1u << 30) | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            long long p = (long long)tile - 1;
+            while (true) {
+                const uint32_t s = __hip_atomic_load(&status[(size_t)p * 256u + (size_t)tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const uint32_t flag = s >> 30;
+                if (flag == 0u) {
+                    __builtin_amdgcn_s_sleep(1);
+                    continue;
+                }
+                prev += s & VALUE;
+                if (flag == 2u) break;
+                --p;
+            }
+        }
+        __hip_atomic_store(&status[(size_t)tile * 256u + (size_t)tid], (2u << 30) | (prev + total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    __hip_atomic_store(&status[(size_t)tile * 256u + (size_t)tid], (2u << 30) | (prev + total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const uint32_t digit_base = rs_block_excl(hist[tid], s_tmp, tid);  // keys with a smaller digit, anywhere
-    s_gbase[tid] = digit_base + prev;
-    s_lbase[tid] = rs_block_excl(total, s_tmp, tid);
+    // (the block-wide prefix sums run over the first 256 threads' values; the other threads contribute zeros)
+    const uint32_t digit_base = rs_block_excl<NT>(tid < 256 ? hist[tid] : 0u, s_tmp, tid);  // keys with a smaller digit, anywhere
+    const uint32_t lbase = rs_block_excl<NT>(total, s_tmp, tid);
+    if (tid < 256) {
+        s_gbase[tid] = digit_base + prev;
+        s_lbase[tid] = lbase;
+    }
     __syncthreads();
-    // stage the tile in digit order
+    const size_t tile_begin = (size_t)tile * TILE;
+    const uint32_t tile_n = (uint32_t)(((size_t)n - tile_begin) < (size_t)TILE ? ((size_t)n - tile_begin) : (size_t)TILE);
+    // keys: stage in digit order, write every digit's run to its place (consecutive lanes, consecutive addresses); then the values the same way
+    uint32_t pos[RS_ROUNDS];
 #pragma unroll
     for (int r = 0; r < RS_ROUNDS; ++r) {
         const size_t i = base + (size_t)(r * 64 + lane);
-        if (i < (size_t)n) {
-            const uint32_t d = (k[r] >> shift) & 255u;
-            const uint32_t pos = s_lbase[d] + s_cnt[wave][d] + (uint32_t)rk[r];
-            s_keys[pos] = k[r];
-            s_vals[pos] = v[r];
+        const uint32_t d = (k[r] >> shift) & 255u;
+        pos[r] = s_lbase[d] + s_cnt[wave][d] + (uint32_t)rk[r];
+        if (i < (size_t)n) s_stage[pos[r]] = k[r];
+    }
+    __syncthreads();
+    size_t g[RS_ROUNDS];
+#pragma unroll
+    for (int j = 0; j < RS_ROUNDS; ++j) {
+        const uint32_t s = (uint32_t)(j * NT + tid);
+        g[j] = 0;
+        if (s < tile_n) {
+            const uint32_t key = s_stage[s];
+            const uint32_t d = (key >> shift) & 255u;
+            g[j] = (size_t)s_gbase[d] + (size_t)(s - s_lbase[d]);
+            kout[g[j]] = key;
         }
     }
     __syncthreads();
-    const size_t tile_begin = (size_t)tile * SS_RS_TILE;
-    const uint32_t tile_n = (uint32_t)(((size_t)n - tile_begin) < (size_t)SS_RS_TILE ? ((size_t)n - tile_begin) : (size_t)SS_RS_TILE);
+#pragma unroll
+    for (int r = 0; r < RS_ROUNDS; ++r) {
+        const size_t i = base + (size_t)(r * 64 + lane);
+        if (i < (size_t)n) s_stage[pos[r]] = v[r];
+    }
+    __syncthreads();
 #pragma unroll
     for (int j = 0; j < RS_ROUNDS; ++j) {
-        const uint32_t s = (uint32_t)(j * 256 + tid);
-        if (s < tile_n) {
-            const uint32_t key = s_keys[s];
-            const uint32_t d = (key >> shift) & 255u;
-            const size_t g = (size_t)s_gbase[d] + (size_t)(s - s_lbase[d]);
-            kout[g] = key;
-            vout[g] = s_vals[s];
-        }
+        const uint32_t s = (uint32_t)(j * NT + tid);
+        if (s < tile_n) vout[g[j]] = s_stage[s];
     }
 }
 
@@ -170,8 +192,12 @@ static inline unsigned rs_passes(unsigned bits) {
     return p < 1u ? 1u : (p > 4u ? 4u : p);
 }
 
+// tiles of 8192 pairs (512 threads) for large inputs: a digit's run in a tile is then 128 bytes on average (whole cache lines) and half as many
+// look-backs; 4096 (256 threads) below 2^20 pairs
+static inline uint32_t rs_tile(uint32_t n) { return n >= (1u << 20) ? 8192u : 4096u; }
+
 size_t ss_radix_sort_work_words(uint32_t n, unsigned bits) {
-    const size_t tiles = ((size_t)n + SS_RS_TILE - 1) / SS_RS_TILE;
+    const size_t tiles = ((size_t)n + 4096 - 1) / 4096;  // (sized for the small tile)
     const size_t np = rs_passes(bits);
     return np * 256 + 8 + np * tiles * 256 + 64;  // histograms, tile counters, status
 }
@@ -179,7 +205,8 @@ size_t ss_radix_sort_work_words(uint32_t n, unsigned bits) {
 int ss_radix_sort_pairs(uint32_t* keys[2], uint32_t* vals[2], uint32_t n, unsigned bits, bool iota, uint32_t* work, bool work_is_zero, hipStream_t st) {
     if (n == 0) return 0;
     const unsigned np = rs_passes(bits);
-    const uint32_t tiles = (uint32_t)(((size_t)n + SS_RS_TILE - 1) / SS_RS_TILE);
+    const uint32_t tile = rs_tile(n);
+    const uint32_t tiles = (uint32_t)(((size_t)n + tile - 1) / tile);
     if (!work_is_zero) (void)hipMemsetAsync(work, 0, ss_radix_sort_work_words(n, bits) * 4, st);
     uint32_t* hist = work;
     uint32_t* counters = work + np * 256;
@@ -193,8 +220,12 @@ int ss_radix_sort_pairs(uint32_t* keys[2], uint32_t* vals[2], uint32_t n, unsign
     int cur = 0;
     for (unsigned p = 0; p < np; ++p) {
         const uint32_t* vin = (p == 0 && iota) ? nullptr : vals[cur];
-        hipLaunchKernelGGL(k_rs_pass, dim3(tiles), dim3(256), 0, st, keys[cur], vin, keys[cur ^ 1], vals[cur ^ 1], n, (int)(8 * p), hist + p * 256, counters + p,
-                           status + (size_t)p * tiles * 256u);
+        if (tile == 8192u)
+            hipLaunchKernelGGL(k_rs_pass<512>, dim3(tiles), dim3(512), 0, st, keys[cur], vin, keys[cur ^ 1], vals[cur ^ 1], n, (int)(8 * p), hist + p * 256, counters + p,
+                               status + (size_t)p * tiles * 256u);
+        else
+            hipLaunchKernelGGL(k_rs_pass<256>, dim3(tiles), dim3(256), 0, st, keys[cur], vin, keys[cur ^ 1], vals[cur ^ 1], n, (int)(8 * p), hist + p * 256, counters + p,
+                               status + (size_t)p * tiles * 256u);
         cur ^= 1;
     }
     return cur;
