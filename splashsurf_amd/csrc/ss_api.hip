@@ -1848,15 +1848,26 @@ ss_status ss_result_triangles(ss_result* r, const uint64_t** idx, uint64_t* m) {
             err = hipEventCreateWithFlags(&ev[k], hipEventDisableTiming);
             if (err != hipSuccess) break;
             ++n_ev;
-            if (off[k + 1] > off[k]) err = hipMemcpyAsync(h32 + off[k], r->tri32.as<uint32_t>() + off[k], (off[k + 1] - off[k]) * 4, hipMemcpyDeviceToHost, c->stream);
+            if (off[k + 1] > off[k] && !r->ht32)  // (skipped when ss_result_triangles_u32 has brought the indices to the host already)
+                err = hipMemcpyAsync(h32 + off[k], r->tri32.as<uint32_t>() + off[k], (off[k + 1] - off[k]) * 4, hipMemcpyDeviceToHost, c->stream);
             if (err == hipSuccess) err = hipEventRecord(ev[k], c->stream);
         }
+        bool threads_ok = true;
         if (err == hipSuccess) {
+          try {  // (std::thread / std::vector may throw: nothing may leave an extern "C" function)
             const unsigned hw = std::thread::hardware_concurrency();
             const int n_threads = (int)std::max(1u, std::min(16u, hw ? hw / 4u : 4u));
             const int device = c->device;
             std::vector<std::thread> pool;
             std::vector<int> failed((size_t)n_threads, 0);
+            struct Joiner {  // joins whatever was started, also when a later emplace_back throws
+                std::vector<std::thread>& p;
+                ~Joiner() {
+                    for (auto& th : p)
+                        if (th.joinable()) th.join();
+                }
+            } joiner{pool};
+            pool.reserve((size_t)n_threads);
             for (int t = 0; t < n_threads; ++t)
                 pool.emplace_back([=, &failed]() {
                     if (hipSetDevice(device) != hipSuccess) {
@@ -1878,12 +1889,17 @@ ss_status ss_result_triangles(ss_result* r, const uint64_t** idx, uint64_t* m) {
             for (auto& th : pool) th.join();
             for (int f : failed)
                 if (f) err = hipErrorUnknown;
+          } catch (...) {
+            threads_ok = false;  // no threads to be had: the device widens instead (below)
+          }
         }
         if (err == hipSuccess) err = hipStreamSynchronize(c->stream);
         for (int k = 0; k < n_ev; ++k) (void)hipEventDestroy(ev[k]);
         if (err != hipSuccess) return fail(c, SS_ERR_DEVICE, std::string("triangle download failed: ") + hipGetErrorString(err));
-        r->ht64 = true;
-        r->ht32 = true;  // (the u32 indices are on the host as well now)
+        if (threads_ok) {
+            r->ht64 = true;
+            r->ht32 = true;  // (the u32 indices are on the host as well now)
+        }
     }
     if (!r->ht64) {
         // small meshes: widen on the device, one copy
