@@ -455,8 +455,14 @@ template <class R> struct SSDensityQueue {
     // 16 KiB of LDS per 256-thread workgroup either way.  Measured on S10M-cube / S1M / S10M-tank (density stage, ms):
     // cap 32: 21.1 / 1.66 / 3.97; 24: 18.1 / 1.49 / 3.73; 16: 17.4 / 1.53 / 3.69; 12: 17.6 / 1.49 / 3.69 -- a deeper queue is
     // fuller when it is flushed but leaves fewer waves per SIMD to cover the dependent chains of the W evaluation.
-    static constexpr int cap = sizeof(R) == 4 ? 16 : 8;
-    static constexpr int chunk = 4;  // candidates between two fill checks
+#ifndef SS_DENSITY_QCAP
+#define SS_DENSITY_QCAP 16
+#endif
+#ifndef SS_DENSITY_CHUNK
+#define SS_DENSITY_CHUNK 4
+#endif
+    static constexpr int cap = sizeof(R) == 4 ? SS_DENSITY_QCAP : 8;
+    static constexpr int chunk = SS_DENSITY_CHUNK;  // candidates between two fill checks
 };
 // MODE 0: densities.  MODE 1: densities + neighbour counts (global_neighborhood_list).
 // MODE 2: write the neighbour ids (global particle indices) at nb_ptr[i], in the reference's order
@@ -537,6 +543,37 @@ __global__ __launch_bounds__(256) void k_density_sub(SSDevT<R> P, uint32_t n_cop
         nn += cnt;
         cnt = 0;
     };
+    // Over-dense input: a search cell holds more particles than a wave has lanes, all 64 lanes sit in ONE cell and walk the same eleven
+    // runs.  The candidates are then fetched with wave-uniform addresses (scalar loads, one fetch for the wave instead of one per lane):
+    // the kernel is bound by the vector L1 otherwise (S10M-cube: 2 160 candidates per particle).
+    bool uniform = false;
+    if constexpr (MODE != 2) uniform = __ballot(key != (uint32_t)__builtin_amdgcn_readfirstlane((int)key)) == 0ull;
+    if constexpr (MODE != 2) {
+      if (uniform) {
+#pragma unroll
+        for (int run = 0; run < 11; ++run) {
+            const uint32_t e = (uint32_t)__builtin_amdgcn_readfirstlane((int)re[run]);
+            for (uint32_t q = (uint32_t)__builtin_amdgcn_readfirstlane((int)rb[run]); q < e; q += (uint32_t)QD) {
+                if (__any(cnt > (uint32_t)(QC - QD))) flush();
+                const ss_pos<R>* cq = cpos + q;  // (wave-uniform)
+                ss_pos<R> pj[QD];
+#pragma unroll
+                for (int j = 0; j < QD; ++j) pj[j] = cq[j];
+#pragma unroll
+                for (int j = 0; j < QD; ++j) {
+                    const uint32_t qq = q + (uint32_t)j;
+                    const R dx = pj[j].x - pi.x, dy = pj[j].y - pi.y, dz = pj[j].z - pi.z;
+                    const R d2 = dx * dx + dy * dy + dz * dz;
+                    bool hit = qq < e && d2 < P.h2;  // neighborhood_search.rs:431
+                    if (run == 10) hit = hit && qq != p;
+                    s_q[cnt][tid] = d2;
+                    cnt += hit ? 1u : 0u;
+                }
+            }
+        }
+      }
+    }
+    if (!uniform) {
 #pragma unroll
     for (int run = 0; run < 11; ++run) {
         const uint32_t e = re[run];
@@ -564,6 +601,7 @@ __global__ __launch_bounds__(256) void k_density_sub(SSDevT<R> P, uint32_t n_cop
                 }
             }
         }
+    }
     }
     if (MODE != 2) flush();
     if (MODE != 2) rho[cidx[p]] = acc * P.mass;  // density_map.rs:182, dense_subdomains.rs:596-614
@@ -812,7 +850,10 @@ __device__ __forceinline__ void ss_wave_lds_sync() {
 #define SS_WAVE_LIST 66  // survivors of one 64-entry batch per wave (+ 2 slots the read-ahead may touch)
 // lower bound of the cubic spline in u = 1 - q^2 (ss_splat_pair, SS_ARITH_BOUND): u^3 (C0 + C1 u^2) <= W(q) / sigma
 #define SS_BOUND_C0 0.150818f
-#define SS_BOUND_POOL 212  // 8-byte list records of one block's lower-bound pass (SplatAccWaveShared::wl)
+#ifndef SS_BOUND_POOL
+#define SS_BOUND_POOL 212
+#endif
+// ^ 8-byte list records of one block's lower-bound pass (SplatAccWaveShared::wl)
 // -DSS_PHASE_PROF (tools/build_variant.sh NAME -- -DSS_PHASE_PROF): wave-cycles per phase of k_splat_fused, summed over all waves
 // into g_phase_prof (256 rows of 16 counters against atomic contention), read with ss_debug_phase_prof (tools/phase_prof.py)
 #ifdef SS_PHASE_PROF
