@@ -1,7 +1,7 @@
 // ss_global.hip -- gfx950 kernels of the reference's GLOBAL (non-decomposed) strategy, SURVEY rows A14/A15.
 // Citations are relative to /root/reference/splashsurf_lib/src/.
 //
-//   neighborhood_search.rs:148-230 (sequential spatial hashing) + density_map.rs:113-186  -> k_g_cell_keys (+ rocPRIM sort), k_g_density
+//   neighborhood_search.rs:148-230 (sequential spatial hashing) + density_map.rs:113-186  -> k_g_cell_keys, ss_radix_sort_pairs (ss_prims.hip), k_g_density
 //   density_map.rs:364-412, 582-737 (SparseDensityMapGenerator, sequential)               -> k_g_chunk_boxes, k_g_levelset
 //   marching_cubes/narrow_band_extraction.rs:8-219 + triangulation.rs:23-95                -> k_g_edge_masks, k_g_cell_count,
 //                                                                                            k_g_emit_vertices, k_g_emit_triangles

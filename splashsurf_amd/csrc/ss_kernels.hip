@@ -4,20 +4,21 @@
 //   K0  aabb.rs:28-52 (par_from_points)                                   -> k_aabb_partial/k_aabb_final
 //   K0b lib.rs:369-406 (particle AABB filter)                             -> k_inside_flags/k_compact_xyz
 //   K1  dense_subdomains.rs:349-494 (decomposition) + neighborhood_search.rs:679-710 (cell map)
-//                                                                        -> k_cell_keys (+ rocPRIM sort), k_gather_sorted
+//                                                                        -> k_cell_keys, ss_radix_sort_pairs (ss_prims.hip), k_sorted_gather_runs
 //   K2  dense_subdomains.rs:496-646 + neighborhood_search.rs:345-438 + density_map.rs:150-186
-//                                                                        -> k_classify_count, k_emit_copies, k_density_sub
+//                                                                        -> classify scan (SSClassifyIn), k_emit_copies, sort, k_sorted_gather_runs, k_density_sub
 //   K3  dense_subdomains.rs:784-847 / :991-1133 (density_grid_loop_scalar / _avx)
-//                                                                        -> k_mark_blocks, k_splat_fused, k_select_redo (+ k_splat_bounds, k_splat_gather[_large], k_splat_accumulate_list for over-dense blocks)
-//   K4  dense_subdomains.rs:1470-1553 (triangulate_cell) classification   -> k_mark_mc_blocks, k_mc_neighbours, k_mc_count
-//   K5  same, vertex/triangle emission + dense_subdomains.rs:1603-1749    -> k_mc_emit
+//                                                                        -> k_mark_blocks, k_splat_fused, k_select_redo; over-dense blocks: k_splat_certify_big,
+//                                                                           k_big_tile_select, k_splat_bounds, k_splat_gather[_large], k_splat_accumulate_list
+//   K4  dense_subdomains.rs:1470-1553 (triangulate_cell) classification   -> marching-cubes flag scan (SSMcFlagIn), k_mc_neighbours, k_mc_count
+//   K5  same, vertex/triangle emission + dense_subdomains.rs:1603-1749    -> offsets scan (SSMcCountsIn), k_mc_emit
+// The scans and the sort are the library's own (ss_prims.h): their input / output functors, i.e. the kernels fused into them, are at the end of this file.
 //
-// Design: particles are sorted once by search cell (edge h, stable => ascending
-// original index inside a cell).  Every grid point / cell / edge is owned by exactly one thread which
-// GATHERS its contributions in ascending original particle index -- the summation order of the
-// reference (sorted per-subdomain particle lists, dense_subdomains.rs:476-488) -- so level-set values
-// are bit-identical to the reference's scalar path, independent of subdomain or GPU boundaries, with
-// no R atomics anywhere.
+// Design: the particles are sorted once by splat cell (aligned with the lattice of level-set blocks) for the level set and
+// copied per subdomain, in the reference's own search grids, for the densities.  Every grid point / cell / edge is owned by exactly one
+// thread which GATHERS its contributions in ascending original particle index -- the summation order of the reference (sorted
+// per-subdomain particle lists, dense_subdomains.rs:476-488) -- so level-set values are bit-identical to the reference's scalar path,
+// independent of subdomain or GPU boundaries, with no R atomics anywhere.
 #include <algorithm>
 
 #include "ss_device.h"
@@ -3058,7 +3059,7 @@ void ss_launch_levelset_box(const SSDevT<R>& P, const R* G, const uint32_t* bloc
 
 // =====================================================================================================
 // Fused scans of the host flow (ss_prims.h: one dispatch each; the functors below are the kernels that used to run before and
-// after a rocPRIM scan).  `state`: zeroed scan state (ss_scan_state_words); `mail`: where the total is posted for the host.
+// after a library scan in rounds 1-3).  `state`: zeroed scan state (ss_scan_state_words); `mail`: where the total is posted for the host.
 // =====================================================================================================
 // sorted order -> payload, and the run starts of the cell table in the same pass: first[c] = ~(position of the first entry of cell c),
 // first[ncells] = ~n, 0 = no entry (the table is preset to 0); ss_launch_cell_table_scan turns it into cell_start

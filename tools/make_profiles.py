@@ -13,7 +13,7 @@ import shutil
 import sys
 
 ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
-TAG = sys.argv[2] if len(sys.argv) > 2 else "r03"
+TAG = sys.argv[2] if len(sys.argv) > 2 else "r04"
 SRC = os.path.join(ROOT, "gpurun_out", sys.argv[1] if len(sys.argv) > 1 else TAG + "prof")
 DST = os.path.join(ROOT, "profiles")
 MODES = {0: "scalar", 1: "simd", 2: "simd_hw"}

@@ -25,7 +25,7 @@ for c in $CONFIGS; do
   if [ -z "$NO_PMC" ]; then
     for p in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_VALU"; do
       t=$(echo $p | cut -d' ' -f1)
-      timeout 600 rocprofv3 --pmc $p --kernel-include-regex 'k_splat|k_density_sub|k_mc_' --output-format csv -d $OUT/$c/pmc_$t -o run -- python tools/ab_kernels.py $ARGS --steps 1 --warmup 1 > $OUT/$c/pmc_$t.log 2>&1
+      timeout 600 rocprofv3 --pmc $p --kernel-include-regex 'k_splat|k_density_sub|k_mc_|k_rs_|k_chained_scan' --output-format csv -d $OUT/$c/pmc_$t -o run -- python tools/ab_kernels.py $ARGS --steps 1 --warmup 1 > $OUT/$c/pmc_$t.log 2>&1
     done
   fi
   tail -1 $OUT/$c/stats.log
