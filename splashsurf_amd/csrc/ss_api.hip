@@ -210,10 +210,10 @@ ss_status reserve_zeros(ss_context* ctx, size_t words, ZeroTaker* z) {
 }
 // stable sort of the (key, position) pairs by the low `bits` bits; returns the buffers that hold the result
 // `zero_work`: zeroed words for the sort (ss_radix_sort_work_words) from the caller's zero region; null: the sort's own buffer, zeroed here
-ss_status sort_pairs(ss_context* ctx, uint32_t* keys[2], uint32_t* vals[2], uint32_t n, unsigned bits, bool iota, uint32_t* zero_work, int* result) {
+ss_status sort_pairs(ss_context* ctx, uint32_t* keys[2], uint32_t* vals[2], uint32_t n, unsigned bits, bool iota, uint32_t* zero_work, int* result, hipStream_t st = nullptr) {
     if (n >= (1u << 30)) return fail(ctx, SS_ERR_UNSUPPORTED, "more than 2^30 - 1 entries to sort in one call are not supported by this build");
     if (zero_work) {
-        *result = ss_radix_sort_pairs(keys, vals, n, bits, iota, zero_work, true, ctx->stream);
+        *result = ss_radix_sort_pairs(keys, vals, n, bits, iota, zero_work, true, st ? st : ctx->stream);
         return SS_OK;
     }
     SS_HIP(ctx, ctx->sort_work.reserve(ss_radix_sort_work_words(n, bits) * 4));
@@ -395,7 +395,7 @@ ss_status make_device_params(ss_context* ctx, const typename TypesOf<R>::params*
 
 ss_status ensure_events(ss_context* ctx) {
     if (ctx->ev_ok) return SS_OK;
-    for (int i = 0; i < 22; ++i) SS_HIP(ctx, hipEventCreate(&ctx->ev[i]));
+    for (int i = 0; i < 26; ++i) SS_HIP(ctx, hipEventCreate(&ctx->ev[i]));
     ctx->ev_ok = true;
     return SS_OK;
 }
@@ -838,36 +838,62 @@ ss_status phase_begin(ss_context* ctx, const R* xyz, uint64_t n_in, const typena
     SS_HIP(ctx, ctx->copy_offset.reserve(((size_t)n + 1) * 4));
     SS_HIP(ctx, ctx->sub_rank.reserve((nsub + 1) * 4));
     SS_HIP(ctx, ctx->occ_sub.reserve((nsub + 1) * 4 + 16));  // (at most every subdomain is occupied)
-    // zeroed words of this phase up to the first count the host waits for, ONE memset: three scan states, the subdomain flags, the sort's
-    // work words and the run starts of the cell table (0 = empty cell)
+    // ---- K1: the splat-cell sort.  Independent of the densities; with SPLASH_K1_OVERLAP=1 the chain runs on a second stream beside the density kernel
+    // (forked right before it, joined at the end of the phase) -- measured, no gain worth its complexity (ss_host.h), off by default.
     unsigned bits = 1;
     while (bits < 32 && ((size_t)1 << bits) < ncells) ++bits;
+    auto launch_k1 = [&](hipStream_t s1) -> ss_status {
+        // zeroed words of the chain, one memset: a scan state, the sort's work words and the run starts of the cell table (0 = empty cell)
+        const size_t words = ss_scan_state_words(ncells + 1) + ss_radix_sort_work_words(n, bits) + (ncells + 1) + 64;
+        SS_HIP(ctx, ctx->zeros_k1.reserve(words * 4));
+        SS_HIP(ctx, hipMemsetAsync(ctx->zeros_k1.p, 0, words * 4, s1));
+        ZeroTaker Z1;
+        Z1.base = ctx->zeros_k1.as<uint32_t>();
+        Z1.cap = words;
+        uint32_t* st_cells = Z1.take(ss_scan_state_words(ncells + 1));
+        uint32_t* sort_work = Z1.take(ss_radix_sort_work_words(n, bits));
+        uint32_t* cell_first = Z1.take(ncells + 1);
+        if (!cell_first) return fail(ctx, SS_ERR_UNKNOWN, "internal error: zero region too small");
+        const uint32_t* sorted_keys = ctx->keys_a.as<uint32_t>();
+        if (n > 0) {
+            // the buffers are assigned so that the sorted positions end in res->perm whatever the number of passes
+            const bool odd = (((bits + 7u) / 8u) & 1u) != 0u;
+            uint32_t* keys[2] = {ctx->keys_a.as<uint32_t>(), ctx->keys_b.as<uint32_t>()};
+            uint32_t* vals[2] = {odd ? ctx->vals_a.as<uint32_t>() : res->perm.as<uint32_t>(), odd ? res->perm.as<uint32_t>() : ctx->vals_a.as<uint32_t>()};
+            ss_launch_cell_keys(P, d_xyz, keys[0], (uint32_t*)nullptr, s1);
+            int r = 0;
+            ss_status s2 = sort_pairs(ctx, keys, vals, n, bits, true, sort_work, &r, s1);
+            if (s2 != SS_OK) return s2;
+            if (vals[r] != res->perm.as<uint32_t>()) return fail(ctx, SS_ERR_UNKNOWN, "internal error: sort result in an unexpected buffer");
+            sorted_keys = keys[r];
+        }
+        ss_launch_sorted_gather_runs(P, n, d_xyz, res->perm.as<uint32_t>(), ctx->pos_sorted.as<ss_pos<R>>(), sorted_keys, (uint32_t)ncells, cell_first, (const uint32_t*)nullptr,
+                                     (uint8_t*)nullptr, s1);
+        ss_launch_cell_table_scan(cell_first, (uint32_t)ncells, ctx->cell_start.as<uint32_t>(), st_cells, s1);
+        return SS_OK;
+    };
+    bool k1_done = false;
+    if (ctx->overlap_k1 && !ctx->stream2) {
+        if (hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking) != hipSuccess) {
+            (void)hipGetLastError();
+            ctx->overlap_k1 = false;
+        }
+    }
+    if (!ctx->overlap_k1) {  // one stream: K1 first, as in rounds 1-3
+        SS_HIP(ctx, hipEventRecord(ctx->ev[22], st));
+        s = launch_k1(st);
+        if (s != SS_OK) return s;
+        SS_HIP(ctx, hipEventRecord(ctx->ev[23], st));
+        k1_done = true;
+    }
+    // zeroed words of the density preparation up to the first count the host waits for, ONE memset: two scan states and the subdomain flags
     ZeroTaker Z;
-    s = reserve_zeros(ctx, ss_scan_state_words(ncells + 1) + ss_scan_state_words(n) + ss_scan_state_words(nsub) + (nsub + 1) + ss_radix_sort_work_words(n, bits) + (ncells + 1) + 64, &Z);
+    s = reserve_zeros(ctx, ss_scan_state_words(n) + ss_scan_state_words(nsub) + (nsub + 1) + 64, &Z);
     if (s != SS_OK) return s;
-    uint32_t* st_cells = Z.take(ss_scan_state_words(ncells + 1));
     uint32_t* st_member = Z.take(ss_scan_state_words(n));
     uint32_t* st_sub = Z.take(ss_scan_state_words(nsub));
     uint32_t* sub_flag = Z.take(nsub + 1);
-    uint32_t* sort_work = Z.take(ss_radix_sort_work_words(n, bits));
-    uint32_t* cell_first = Z.take(ncells + 1);
-    if (!cell_first) return fail(ctx, SS_ERR_UNKNOWN, "internal error: zero region too small");
-    const uint32_t* sorted_keys = ctx->keys_a.as<uint32_t>();
-    if (n > 0) {
-        // the buffers are assigned so that the sorted positions end in res->perm whatever the number of passes
-        const bool odd = (((bits + 7u) / 8u) & 1u) != 0u;
-        uint32_t* keys[2] = {ctx->keys_a.as<uint32_t>(), ctx->keys_b.as<uint32_t>()};
-        uint32_t* vals[2] = {odd ? ctx->vals_a.as<uint32_t>() : res->perm.as<uint32_t>(), odd ? res->perm.as<uint32_t>() : ctx->vals_a.as<uint32_t>()};
-        ss_launch_cell_keys(P, d_xyz, keys[0], (uint32_t*)nullptr, st);
-        int r = 0;
-        s = sort_pairs(ctx, keys, vals, n, bits, true, sort_work, &r);
-        if (s != SS_OK) return s;
-        if (vals[r] != res->perm.as<uint32_t>()) return fail(ctx, SS_ERR_UNKNOWN, "internal error: sort result in an unexpected buffer");
-        sorted_keys = keys[r];
-    }
-    ss_launch_sorted_gather_runs(P, n, d_xyz, res->perm.as<uint32_t>(), ctx->pos_sorted.as<ss_pos<R>>(), sorted_keys, (uint32_t)ncells, cell_first, (const uint32_t*)nullptr,
-                                 (uint8_t*)nullptr, st);
-    ss_launch_cell_table_scan(cell_first, (uint32_t)ncells, ctx->cell_start.as<uint32_t>(), st_cells, st);
+    if (!sub_flag) return fail(ctx, SS_ERR_UNKNOWN, "internal error: zero region too small");
     SS_HIP(ctx, hipEventRecord(ctx->ev[3], st));
 
     // ---- K2: densities (per-subdomain particle copies, exactly the reference's organisation) ----
@@ -933,6 +959,16 @@ ss_status phase_begin(ss_context* ctx, const R* xyz, uint64_t n_in, const typena
             // the copies whose density their subdomain computes (every particle has exactly one), compacted in cell order
             ss_launch_owned_scan(n_copies, own_flags, own_list, n_owned_dev, st_owned, st);
             const uint32_t n_owned_bound = n < n_copies ? n : n_copies;  // at most one owned copy per particle
+            if (ctx->overlap_k1) {  // fork: the K1 chain on the second stream, beside the density kernel
+                SS_HIP(ctx, hipEventRecord(ctx->ev[24], st));
+                SS_HIP(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev[24], 0));
+                SS_HIP(ctx, hipEventRecord(ctx->ev[22], ctx->stream2));
+                s = launch_k1(ctx->stream2);
+                if (s != SS_OK) return s;
+                SS_HIP(ctx, hipEventRecord(ctx->ev[23], ctx->stream2));
+                SS_HIP(ctx, hipEventRecord(ctx->ev[25], ctx->stream2));
+                k1_done = true;
+            }
             SS_HIP(ctx, hipEventRecord(ctx->ev[18], st));
             ss_launch_density_sub(P, n_copies, ctx->cpos.as<ss_pos<R>>(), ctx->cidx.as<uint32_t>(), ckeys_sorted,
                                   ctx->cell_start2.as<uint32_t>(), ctx->occ_sub.as<uint32_t>(), res->rho.as<R>(), want_nb ? 1 : 0,
@@ -964,6 +1000,14 @@ ss_status phase_begin(ss_context* ctx, const R* xyz, uint64_t n_in, const typena
                 SS_HIP(ctx, hipMemsetAsync(res->nb_ptr.p, 0, ((size_t)n + 1) * 8, st));
             }
         }
+    }
+    if (k1_done) {
+        if (ctx->overlap_k1) SS_HIP(ctx, hipStreamWaitEvent(st, ctx->ev[25], 0));  // join
+    } else {  // (no particle has a copy: there was no density kernel to run beside)
+        SS_HIP(ctx, hipEventRecord(ctx->ev[22], st));
+        s = launch_k1(st);
+        if (s != SS_OK) return s;
+        SS_HIP(ctx, hipEventRecord(ctx->ev[23], st));
     }
     SS_HIP(ctx, hipEventRecord(ctx->ev[4], st));
     res->phase = 1;
@@ -1218,7 +1262,7 @@ ss_status phase_finish(ss_context* ctx, ss_result* res) {
     S.ms_total = ev_ms(ctx, 0, 4) + ev_ms(ctx, 10, 9);  // both phases (excludes what the host does between them)
     S.ms_upload = host_input ? ev_ms(ctx, 0, 1) : 0.0;
     S.ms_aabb_grid = ev_ms(ctx, 1, 2);
-    S.ms_decomposition = ev_ms(ctx, 2, 3);
+    S.ms_decomposition = ev_ms(ctx, 22, 23);  // the K1 chain (on the second stream it runs beside the density kernel: its time is then part of ms_density's interval as well)
     S.ms_density = ev_ms(ctx, 3, 4) + ev_ms(ctx, 10, 11);
     S.ms_levelset_prepare = ev_ms(ctx, 11, 5);
     S.ms_levelset = ev_ms(ctx, 5, 15);
@@ -1579,6 +1623,7 @@ ss_status ss_context_create(int device_id, ss_context** out) {
         return SS_ERR_DEVICE;
     }
     c->stream = c->own_stream;
+    if (const char* e = getenv("SPLASH_K1_OVERLAP")) c->overlap_k1 = e[0] == '1';
     *out = c;
     return SS_OK;
 }
@@ -1597,7 +1642,9 @@ void ss_context_destroy(ss_context* c) {
     c->sort_work.release();
     if (c->mail_host) (void)hipHostFree(c->mail_host);
     if (c->ev_ok)
-        for (int i = 0; i < 22; ++i) (void)hipEventDestroy(c->ev[i]);
+        for (int i = 0; i < 26; ++i) (void)hipEventDestroy(c->ev[i]);
+    if (c->stream2) (void)hipStreamDestroy(c->stream2);
+    c->zeros_k1.release();
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
 }

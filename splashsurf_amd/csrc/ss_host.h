@@ -80,7 +80,8 @@ struct ss_context {
     DevBuf own_flag;  // per subdomain copy: owned flag, its scan, the list of owned copies
     bool widen_on_device = false;  // SS_OPTION_WIDEN_ON_DEVICE: ss_result_triangles widens the u32 indices on the device and copies u64 (tests; the default for small meshes)
     DevBuf member_count, copy_offset, sub_flag, sub_rank, occ_sub, ckeys_a, ckeys_b, cvals_a, cidx, cpos, cell_count2, cell_start2;
-    hipEvent_t ev[22];  // 0..9 stage boundaries, 10/11 start of phase 2, 12..15 inside the splat, 16/17 around the arena-path gather, 18/19 k_density_sub, 20/21 k_mc_count
+    hipEvent_t ev[26];  // (22, 23: around the K1 chain on the second stream; 24 fork, 25 join)
+    // ^ 0..9 stage boundaries, 10/11 start of phase 2, 12..15 inside the splat, 16/17 around the arena-path gather, 18/19 k_density_sub, 20/21 k_mc_count
     // the two-pass splat pays off when enough sub-blocks get certified 'inside' (bulk fluid); thin structures do not -- decided per
     // workload from the previous call's statistics, re-probed now and then
     uint64_t early_key = 0;
@@ -103,6 +104,12 @@ struct ss_context {
     unsigned long long* mail_host = nullptr;
     unsigned long long* mail_dev = nullptr;
     unsigned long long mail_seq = 0;
+    // second stream (experiment, SPLASH_K1_OVERLAP=1): the splat-cell sort (K1, bandwidth-bound) beside the density kernel (bound by the vector L1 / VALU).
+    // Measured: S10M-tank 9.62 against 9.67 ms per step, S10M-cube 20.9 / 21.2 -- the K1 chain stretches from 0.41 to 1.33 ms, the density kernel from 0.96
+    // to 1.00 ms: the device is busy either way.  Off by default (one stream, K1 first).
+    hipStream_t stream2 = nullptr;
+    bool overlap_k1 = false;
+    DevBuf zeros_k1;  // the zeroed words of the K1 chain (its own memset, on the stream the chain runs on)
     DevBuf zeros;     // zero-initialised words of one phase: scan states, counters (one memset per phase)
     DevBuf sort_work; // work buffer of ss_radix_sort_pairs
     uint32_t cap_active = 0, cap_mc = 0;  // capacities of the block lists (grow-only; a call that needs more repeats the scan that fills them)
