@@ -1104,22 +1104,26 @@ ss_status phase_finish(ss_context* ctx, ss_result* res) {
         ctx->early_skipped = 0;
     }
     const bool full_ls = ctx->full_levelset || !(prm_threshold > R(0.0)) || ctx->two_pass == 0 || (ctx->two_pass < 0 && (n_active < 1024u || !probe));
-    SS_HIP(ctx, ctx->splat_trunc.reserve(((size_t)n_active + 2) * (8 + 7 * 4) + 64));
+    SS_HIP(ctx, ctx->splat_trunc.reserve(((size_t)n_active + 2) * (8 + 8 * 4) + 64));
     unsigned long long* face_bits = ctx->splat_trunc.as<unsigned long long>();  // per block: faces of its sub-blocks with points outside the surface
     uint32_t* tr_flag = (uint32_t*)(face_bits + ((size_t)n_active + 2));        // per block: mask of the certified sub-blocks
     uint32_t* rd_flag = tr_flag + ((size_t)n_active + 1);         // ... and marching cubes will read it
     uint32_t* rd_unused = rd_flag + ((size_t)n_active + 1);
     uint32_t* rd_list = rd_unused + ((size_t)n_active + 1);
-    uint32_t* need_mask = rd_list + ((size_t)n_active + 1);      // over-dense blocks: the sub-blocks k_splat_certify_big left to evaluate
+    uint32_t* big = rd_list + ((size_t)n_active + 1);            // blocks with more candidates than a wave holds (count, list): the arena path
+    uint32_t* exact_list = big + ((size_t)n_active + 2);         // over-dense blocks with sub-blocks left to evaluate after k_splat_certify_big (count, list)
     // over-dense blocks of an f32 job: certificates straight from the cells first, tiles only for the blocks somebody reads (ss_kernels.hip)
     const bool certify_big = sizeof(R) == 4 && !full_ls;
     // zeroed words of the rest of this phase: the statistics counters, the states of the remaining scans, the length of the redo list
     const size_t mc_cap_bound = std::min<size_t>(nblocks, (size_t)8 * (size_t)n_active);
     ZeroTaker Z;
-    s = reserve_zeros(ctx, 16 + 3 * 64 * 2 + 3 * ss_scan_state_words((size_t)n_active + 1) + 2 * ss_scan_state_words(nblocks) + 2 * ss_scan_state_words(mc_cap_bound + 1) + 2 * ((size_t)n_active + 8) + 64, &Z);
+    s = reserve_zeros(ctx, 16 + 3 * 64 * 2 + 6 * ss_scan_state_words((size_t)n_active + 1) + 2 * ss_scan_state_words(nblocks) + 2 * ss_scan_state_words(mc_cap_bound + 1) + 2 * ((size_t)n_active + 8) + 64, &Z);
     if (s != SS_OK) return s;
-    uint32_t* big = Z.take((size_t)n_active + 2);         // blocks with more candidates than a wave holds (count, list): the arena path
-    uint32_t* exact_list = Z.take((size_t)n_active + 2);  // over-dense blocks with sub-blocks left to evaluate after k_splat_certify_big (count, list)
+    uint32_t* big_flag = Z.take((size_t)n_active + 2);   // flags of the blocks with more candidates than a wave holds (set by k_splat_fused, compacted into big[])
+    uint32_t* need_mask = Z.take((size_t)n_active + 2);  // over-dense blocks: the sub-blocks k_splat_certify_big left to evaluate (0 for every other block)
+    uint32_t* st_big1 = Z.take(ss_scan_state_words((size_t)n_active + 1));
+    uint32_t* st_big2 = Z.take(ss_scan_state_words((size_t)n_active + 1));
+    uint32_t* st_exact = Z.take(ss_scan_state_words((size_t)n_active + 1));
     uint32_t* d_counters = Z.take(3 * 64 * 2);  // u64[3][64]: tile entries, blocks left truncated, certified sub-blocks (64 copies each, k_select_redo)
     uint32_t* d_err = Z.take(4);                 // error flags
     uint32_t* st_tiles = Z.take(ss_scan_state_words((size_t)n_active + 1));
@@ -1132,9 +1136,9 @@ ss_status phase_finish(ss_context* ctx, ss_result* res) {
     if (n_active) {
         // first pass, gather and accumulate in one kernel: the tiles of ordinary blocks stay in LDS
         ss_launch_splat_fused(PK, res->posvol.as<ss_real4<R>>(), res->perm.as<uint32_t>(), ctx->cell_start.as<uint32_t>(), res->active_xyz.as<uint32_t>(), n_active,
-                              res->G.as<R>(), res->blk_minmax.as<ss_real2<R>>(), tr_flag, full_ls, nullptr, nullptr, nullptr, face_bits, ctx->splat_counts.as<uint32_t>(), big, st);
+                              res->G.as<R>(), res->blk_minmax.as<ss_real2<R>>(), tr_flag, full_ls, nullptr, nullptr, nullptr, face_bits, ctx->splat_counts.as<uint32_t>(), big_flag, st);
         const SSMailSlot m_big = mail_slot(ctx, 3);
-        ss_launch_publish_u32(big, m_big, st);
+        ss_launch_flag_scan(big_flag, n_active, nullptr, big + 1, big, st_big1, m_big, st);  // flags -> (count, list in block order); the count goes to the host
         unsigned long long v = 0;
         s = mail_wait(ctx, m_big, &v);
         if (s != SS_OK) return s;
@@ -1145,8 +1149,8 @@ ss_status phase_finish(ss_context* ctx, ss_result* res) {
         if constexpr (sizeof(R) == 4) {
             if (certify_big) {
                 ss_launch_splat_certify_big(PK, res->posvol.as<ss_real4<float>>(), ctx->cell_start.as<uint32_t>(), res->active_xyz.as<uint32_t>(), n_active,
-                                            res->block_slot.as<uint32_t>(), ctx->splat_counts.as<uint32_t>(), res->blk_minmax.as<ss_real2<float>>(), tr_flag, face_bits, need_mask,
-                                            exact_list, st);
+                                            res->block_slot.as<uint32_t>(), ctx->splat_counts.as<uint32_t>(), res->blk_minmax.as<ss_real2<float>>(), tr_flag, face_bits, need_mask, st);
+                ss_launch_flag_scan(need_mask, n_active, nullptr, exact_list + 1, exact_list, st_exact, SSMailSlot{}, st);
             }
         }
         // over-dense blocks: bounds -> offsets -> tile arena -> gather (-> ordered list of the very large ones) -> workgroup per block
@@ -1180,15 +1184,17 @@ ss_status phase_finish(ss_context* ctx, ss_result* res) {
     // the statistics of the first pass are taken by the same kernel
     if (n_active)
         ss_launch_select_redo(P, res->active_xyz.as<uint32_t>(), n_active, res->block_slot.as<uint32_t>(), full_ls ? nullptr : tr_flag, face_bits, rd_flag,
-                              ctx->splat_counts.as<uint32_t>(), reinterpret_cast<unsigned long long*>(d_counters), big, st);
+                              ctx->splat_counts.as<uint32_t>(), reinterpret_cast<unsigned long long*>(d_counters), big_flag, st);
     if (n_active && !full_ls) {
         ss_launch_flag_scan(rd_flag, n_active, nullptr, rd_list, n_redo_dev, st_redo, SSMailSlot{}, st);
         ss_launch_splat_fused(PK, res->posvol.as<ss_real4<R>>(), res->perm.as<uint32_t>(), ctx->cell_start.as<uint32_t>(), res->active_xyz.as<uint32_t>(), n_active,
-                              res->G.as<R>(), res->blk_minmax.as<ss_real2<R>>(), tr_flag, true, rd_list, n_redo_dev, rd_flag, face_bits, ctx->splat_counts.as<uint32_t>(), big, st);
-        if (n_big)  // (the list kernel re-collected the large blocks among the selected ones in big[])
+                              res->G.as<R>(), res->blk_minmax.as<ss_real2<R>>(), tr_flag, true, rd_list, n_redo_dev, rd_flag, face_bits, ctx->splat_counts.as<uint32_t>(), big_flag, st);
+        if (n_big) {  // (the list kernel flagged the large blocks among the selected ones again)
+            ss_launch_flag_scan(big_flag, n_active, nullptr, big + 1, big, st_big2, SSMailSlot{}, st);
             ss_launch_splat_accumulate_big(PK, ctx->splat_tiles.as<ss_real4<R>>(), ctx->splat_tile_idx.as<uint32_t>(), ctx->splat_off.as<unsigned long long>(),
                                            ctx->splat_counts.as<uint32_t>(), res->active_xyz.as<uint32_t>(), res->G.as<R>(), res->blk_minmax.as<ss_real2<R>>(), tr_flag, true, true, false,
                                            rd_flag, face_bits, big, d_err, st);
+        }
     }
     SS_HIP(ctx, hipEventRecord(ctx->ev[15], st));  // (= event 6)
 

@@ -42,7 +42,7 @@ template <class R>
 void ss_launch_splat_fused(const SSDevT<R>& P, const ss_real4<R>* posvol, const uint32_t* perm, const uint32_t* cell_start, const uint32_t* active_xyz, uint32_t n_active, R* G, ss_real2<R>* blk_minmax, uint32_t* trunc, bool full_levelset, const uint32_t* list, const uint32_t* n_list_dev, const uint32_t* redo_mask, unsigned long long* facebits, uint32_t* counts, uint32_t* big, hipStream_t st);
 template <class R>
 void ss_launch_splat_accumulate_big(const SSDevT<R>& P, const ss_real4<R>* arena, const uint32_t* arena_idx, const unsigned long long* tile_off, const uint32_t* counts, const uint32_t* active_xyz, R* G, ss_real2<R>* blk_minmax, uint32_t* trunc, bool full_levelset, bool second_pass, bool exact_first, const uint32_t* redo_mask, unsigned long long* facebits, const uint32_t* big, uint32_t* err, hipStream_t st);
-void ss_launch_splat_certify_big(const SSDevT<float>& P, const ss_real4<float>* posvol, const uint32_t* cell_start, const uint32_t* active_xyz, uint32_t n_active, const uint32_t* block_slot, uint32_t* counts, ss_real2<float>* blk_minmax, uint32_t* trunc, unsigned long long* facebits, uint32_t* need_mask, uint32_t* exact_list, hipStream_t st);
+void ss_launch_splat_certify_big(const SSDevT<float>& P, const ss_real4<float>* posvol, const uint32_t* cell_start, const uint32_t* active_xyz, uint32_t n_active, const uint32_t* block_slot, uint32_t* counts, ss_real2<float>* blk_minmax, uint32_t* trunc, unsigned long long* facebits, uint32_t* need_mask, hipStream_t st);
 template <class R>
 void ss_launch_select_redo(const SSDevT<R>& P, const uint32_t* active_xyz, uint32_t n_active, const uint32_t* block_slot, const uint32_t* trunc, const unsigned long long* facebits, uint32_t* redo_mask, const uint32_t* counts, unsigned long long* stats, uint32_t* big, hipStream_t st);
 void ss_launch_publish_stats(const unsigned long long* stats, const uint32_t* n_redo, const uint32_t* n_large, const uint32_t* err, SSMailSlot m0, SSMailSlot m1, SSMailSlot m2, SSMailSlot m3, hipStream_t st);

@@ -2097,7 +2097,7 @@ __device__ __forceinline__ void splat_accumulate_block_wave(SplatAccWaveShared<R
 // k_splat_gather, keeps the candidates within reach in LDS (payload and particle index, scan order) and goes straight on to
 // the classification / ordering / exact sums of splat_accumulate_block_wave -- the tiles of ordinary blocks never pass through
 // HBM (S10M-tank: 3.4 GB written and 2.9 GB read back by the two-kernel version) and need no arena.  A block with more than
-// SSWaveChunk candidates only reports its count and is appended to big[1..] (count in big[0]): those take the arena path
+// SSWaveChunk candidates only reports its count and sets its flag in big[] (the host compacts the flags into a list with a scan): those take the arena path
 // (k_splat_bounds, k_splat_gather / _large, k_splat_accumulate_list).  list == nullptr: every active block; otherwise the blocks
 // of the device-side list, the sub-blocks in redo_mask only.
 template <class R, int ARITH, bool EARLY>
@@ -2146,7 +2146,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(sizeof(R) ==
         }
         if (!list && lane == 0) counts[logical] = count;  // tile entries (statistics; > CH: the arena path recounts)
         if (count > (uint32_t)CH) {
-            if (lane == 0) big[1u + atomicAdd(&big[0], 1u)] = logical;
+            if (lane == 0) big[logical] = 1u;  // (a flag per block: a list appended to with atomics on one counter serialises -- 132 k appends cost 1.3 ms on S10M-cube)
             return;
         }
         ss_wave_lds_sync();
@@ -2338,12 +2338,12 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     }
 }
 
-// Which over-dense blocks need a tile in the arena (see k_splat_certify_big), and the list of those with sub-blocks left to evaluate.
+// Which over-dense blocks need a tile in the arena (see k_splat_certify_big).  (The list of those with sub-blocks left to evaluate is the
+// compaction of need_mask != 0, a scan launched by the host.)
 // counts[b] = 0 takes a block out of the arena path (k_splat_bounds, k_splat_gather).
 template <class R>
 __global__ __launch_bounds__(256) void k_big_tile_select(SSDevT<R> P, const uint32_t* __restrict__ active_xyz, uint32_t n_active, const uint32_t* __restrict__ block_slot,
-                                                         const uint32_t* __restrict__ trunc, const uint32_t* __restrict__ need_mask, uint32_t* __restrict__ counts,
-                                                         uint32_t* __restrict__ exact_list) {
+                                                         const uint32_t* __restrict__ trunc, uint32_t* __restrict__ counts) {
     const uint32_t a = blockIdx.x * blockDim.x + threadIdx.x;
     if (a >= n_active) return;
     if (counts[a] <= (uint32_t)SSWaveChunk<R>::value) return;
@@ -2362,7 +2362,6 @@ __global__ __launch_bounds__(256) void k_big_tile_select(SSDevT<R> P, const uint
             }
     }
     if (!needs) counts[a] = 0u;
-    if (need_mask[a]) exact_list[1u + atomicAdd(&exact_list[0], 1u)] = a;
 }
 
 // A certified sub-block carries lower bounds, all above the threshold.  Marching cubes classifies with them like with the
@@ -2372,16 +2371,16 @@ __global__ __launch_bounds__(256) void k_big_tile_select(SSDevT<R> P, const uint
 // (facebits, written by the first pass).  A neighbour in a block without particles in reach is all zero = outside.
 // The statistics of the first pass are taken on the way: stats[0][.] += tile entries, stats[2][.] += certified sub-blocks,
 // stats[1][.] += blocks that stay truncated after the second pass (certified sub-blocks nobody reads); 64 copies of every counter.
-// trunc == nullptr (no two-pass scheme): only the tile entries are summed.  big[0], the length of the list of over-dense blocks, is
-// reset for the second launch of the splat kernel.
+// trunc == nullptr (no two-pass scheme): only the tile entries are summed.  big[], the flags of the over-dense blocks, are reset for
+// the second launch of the splat kernel.
 template <class R>
 __global__ __launch_bounds__(256) void k_select_redo(SSDevT<R> P, const uint32_t* __restrict__ active_xyz, uint32_t n_active, const uint32_t* __restrict__ block_slot,
                                                      const uint32_t* __restrict__ trunc, const unsigned long long* __restrict__ facebits,
                                                      uint32_t* __restrict__ redo_mask, const uint32_t* __restrict__ counts, unsigned long long* __restrict__ stats,
                                                      uint32_t* __restrict__ big) {
     const uint32_t a = blockIdx.x * blockDim.x + threadIdx.x;
-    if (a == 0 && big) big[0] = 0u;
     const bool live = a < n_active;
+    if (live && big) big[a] = 0u;
     const uint32_t cert = (live && trunc) ? trunc[a] : 0u;
     uint32_t redo = 0;
     if (cert) {
@@ -2498,14 +2497,14 @@ void ss_launch_splat_gather_large(const SSDevT<R>& P, const ss_real4<R>* posvol,
 
 // The splat of the ordinary blocks (k_splat_fused).  list == nullptr: first pass over all n_active blocks (lower-bound
 // certification unless full_levelset); otherwise the second pass over the device-side list of blocks with certified sub-blocks that
-// marching cubes reads.  `big`: n_active + 1 words -- the count and the list of the blocks with more than SSWaveChunk candidates,
-// which ss_launch_splat_accumulate_big finishes; counts: tile size per block (first pass).
+// marching cubes reads.  `big`: n_active flags, set for the blocks with more than SSWaveChunk candidates (compacted by the host into the
+// list ss_launch_splat_accumulate_big works on); counts: tile size per block (first pass).
 template <class R>
 void ss_launch_splat_fused(const SSDevT<R>& P, const ss_real4<R>* posvol, const uint32_t* perm, const uint32_t* cell_start, const uint32_t* active_xyz, uint32_t n_active,
                            R* G, ss_real2<R>* blk_minmax, uint32_t* trunc, bool full_levelset, const uint32_t* list, const uint32_t* n_list_dev,
                            const uint32_t* redo_mask, unsigned long long* facebits, uint32_t* counts, uint32_t* big, hipStream_t st) {
     if (!n_active) return;
-    // (big[0] must be 0: the host takes big[] from its zeroed words for the first launch, k_select_redo resets it for the second)
+    // (big[] must be 0: the host takes the flags from its zeroed words for the first launch, k_select_redo resets them for the second)
     const dim3 grid(list ? 32768u : ss_xcd_chunked_grid(n_active));
 #define SS_FUSED(A)                                                                                                                                          \
     do {                                                                                                                                                     \
@@ -2542,14 +2541,14 @@ void ss_launch_splat_accumulate_big(const SSDevT<R>& P, const ss_real4<R>* arena
 }
 
 // Over-dense blocks of an f32 job with the two-pass scheme: certificates first (k_splat_certify_big), then the choice of the blocks that
-// get a tile (k_big_tile_select; exact_list[0] must be 0 on entry).
+// get a tile (k_big_tile_select).  need_mask must be zero on entry (it is read for every active block afterwards).
 void ss_launch_splat_certify_big(const SSDevT<float>& P, const ss_real4<float>* posvol, const uint32_t* cell_start, const uint32_t* active_xyz, uint32_t n_active,
                                  const uint32_t* block_slot, uint32_t* counts, ss_real2<float>* blk_minmax, uint32_t* trunc, unsigned long long* facebits, uint32_t* need_mask,
-                                 uint32_t* exact_list, hipStream_t st) {
+                                 hipStream_t st) {
     if (!n_active) return;
     hipLaunchKernelGGL(k_splat_certify_big, dim3(ss_xcd_chunked_grid(n_active)), dim3(512), 0, st, P, posvol, cell_start, active_xyz, n_active, counts, blk_minmax, trunc, facebits,
                        need_mask);
-    hipLaunchKernelGGL(k_big_tile_select<float>, dim3((n_active + 255u) / 256u), dim3(256), 0, st, P, active_xyz, n_active, block_slot, trunc, need_mask, counts, exact_list);
+    hipLaunchKernelGGL(k_big_tile_select<float>, dim3((n_active + 255u) / 256u), dim3(256), 0, st, P, active_xyz, n_active, block_slot, trunc, counts);
 }
 
 template <class R>
