@@ -1167,6 +1167,7 @@ ss_status phase_finish(ss_context* ctx, ss_result* res) {
         SS_HIP(ctx, ctx->splat_tile_idx.reserve((size_t)n_reserved * 4 + 64));
         ss_launch_splat_gather(PK, res->posvol.as<ss_real4<R>>(), res->perm.as<uint32_t>(), ctx->cell_start.as<uint32_t>(), res->active_xyz.as<uint32_t>(), n_active,
                                ctx->splat_off.as<unsigned long long>(), ctx->splat_tiles.as<ss_real4<R>>(), ctx->splat_tile_idx.as<uint32_t>(), ctx->splat_counts.as<uint32_t>(), lg_flag, st);
+        ss_launch_posvol_by_index<R>(n, res->posvol.as<ss_real4<R>>(), res->perm.as<uint32_t>(), res->posvol_by_index.as<ss_real4<R>>(), st);  // (only calls with over-dense blocks need it)
         // very large tiles: flags -> ordered list on the device; the workgroup-level gather reads its length there
         ss_launch_flag_scan(lg_flag, n_active, nullptr, lg_list, n_large_dev, st_large, SSMailSlot{}, st);
         ss_launch_splat_gather_large(PK, res->posvol.as<ss_real4<R>>(), res->posvol_by_index.as<ss_real4<R>>(), res->perm.as<uint32_t>(), ctx->cell_start.as<uint32_t>(),

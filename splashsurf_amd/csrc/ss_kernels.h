@@ -72,3 +72,5 @@ void ss_launch_mc_blocks_scan(const SSDevT<R>& P, const uint32_t* block_slot, co
 void ss_launch_mc_offsets_scan(const uint32_t* vcount, const uint32_t* tcount, uint32_t n_mc, uint32_t* vbase, uint32_t* tbase, uint32_t* state, SSMailSlot mail, hipStream_t st);
 void ss_launch_tile_offsets_scan(const uint32_t* bound, uint32_t n, unsigned long long* off, uint32_t* state, SSMailSlot mail, hipStream_t st);
 void ss_launch_publish_u32(const uint32_t* src, SSMailSlot mail, hipStream_t st);
+template <class R>
+void ss_launch_posvol_by_index(uint32_t n, const ss_real4<R>* posvol, const uint32_t* perm, ss_real4<R>* posvol_by_index, hipStream_t st);

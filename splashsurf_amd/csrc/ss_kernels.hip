@@ -619,8 +619,22 @@ __global__ __launch_bounds__(256) void k_make_posvol(SSDevT<R> P, const ss_pos<R
     const uint32_t i = perm[p];
     const ss_real4<R> v = ss_make4(a.x, a.y, a.z, P.mass / rho[i]);
     posvol[p] = v;
-    posvol_by_index[i] = v;  // the large-tile path sorts particle indices only and fetches the payload through this copy
 }
+
+// the same payload in ORIGINAL particle order: the large-tile path (k_splat_gather_large) sorts particle indices only and fetches the payload
+// through this copy -- made only when a call has over-dense blocks (a scattered 16-byte store per particle otherwise wasted)
+template <class R>
+__global__ __launch_bounds__(256) void k_posvol_by_index(uint32_t n, const ss_real4<R>* __restrict__ posvol, const uint32_t* __restrict__ perm, ss_real4<R>* __restrict__ posvol_by_index) {
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p < n) posvol_by_index[perm[p]] = posvol[p];
+}
+template <class R>
+void ss_launch_posvol_by_index(uint32_t n, const ss_real4<R>* posvol, const uint32_t* perm, ss_real4<R>* posvol_by_index, hipStream_t st) {
+    if (!n) return;
+    hipLaunchKernelGGL(k_posvol_by_index<R>, dim3((n + 255) / 256), dim3(256), 0, st, n, posvol, perm, posvol_by_index);
+}
+template void ss_launch_posvol_by_index<float>(uint32_t, const ss_real4<float>*, const uint32_t*, ss_real4<float>*, hipStream_t);
+template void ss_launch_posvol_by_index<double>(uint32_t, const ss_real4<double>*, const uint32_t*, ss_real4<double>*, hipStream_t);
 
 template <class R>
 void ss_launch_classify_count(const SSDevT<R>& P, const R* xyz, uint32_t* member_count, uint32_t* sub_flag, hipStream_t st) {
@@ -2196,7 +2210,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(sizeof(R) =
 // k_big_tile_select then decides which of these blocks need a tile at all: the ones with a sub-block left to evaluate, and the
 // fully certified ones that k_select_redo can ask to complete later -- it only does that for a block with a face neighbour that
 // holds (or is) an outside point, i.e. one that is absent or not fully certified itself.
+#ifndef SS_CERT_LIST
 #define SS_CERT_LIST 192
+#endif
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_splat_certify_big(SSDevT<float> P, const ss_real4<float>* __restrict__ posvol,
                                                                                                      const uint32_t* __restrict__ cell_start, const uint32_t* __restrict__ active_xyz,
                                                                                                      uint32_t n_active, const uint32_t* __restrict__ counts,
