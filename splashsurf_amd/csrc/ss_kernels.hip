@@ -25,10 +25,33 @@
 #include "ss_kernels.h"
 #include "ss_prims.h"
 
-// MC table in emitted (winding-flipped) order, see tools/gen_mc_table.py
-__constant__ __attribute__((aligned(16))) int8_t c_mc_table[256][16] = {
-#include "mc_table.inc"
+// MC table in emitted (winding-flipped) order (mc_table.inc, see tools/gen_mc_table.py), packed at compile time: per case ONE 64-bit word
+// -- fifteen 4-bit edge ids (15 = none), the number of triangles in the top nibble -- and the triangle counts alone as nibbles (32 words).
+// The count kernel stages 128 bytes, the emit kernel 2 KiB per workgroup (the byte table is 4 KiB: staging it made up most of either
+// kernel's memory traffic, 0.74 GB per launch on S10M-tank).
+struct SSMcPacked {
+    unsigned long long row[256];
+    uint32_t ntri4[32];
 };
+constexpr SSMcPacked ss_make_mc_packed() {
+    constexpr int8_t t[256][16] = {
+#include "mc_table.inc"
+    };
+    SSMcPacked p{};
+    for (int c = 0; c < 256; ++c) {
+        unsigned long long row = 0;
+        unsigned ntri = 0;
+        for (int j = 0; j < 15; ++j) {
+            const int e = t[c][j];
+            row |= (unsigned long long)(e < 0 ? 15 : e) << (4 * j);
+            if (j % 3 == 0 && e >= 0) ++ntri;
+        }
+        p.row[c] = row | ((unsigned long long)ntri << 60);
+        p.ntri4[c >> 3] |= ntri << (4 * (c & 7));
+    }
+    return p;
+}
+__constant__ __attribute__((aligned(16))) SSMcPacked c_mc_packed = ss_make_mc_packed();
 // uniform_grid.rs:825-834
 __constant__ int8_t c_corner[8][3] = {{0, 0, 0}, {1, 0, 0}, {1, 1, 0}, {0, 1, 0}, {0, 0, 1}, {1, 0, 1}, {1, 1, 1}, {0, 1, 1}};
 // uniform_grid.rs:856-869: local edge -> (origin corner, axis)
@@ -2665,10 +2688,10 @@ struct McLocal {
     int ntri;
 };
 
-// lut: the case table (c_mc_table) staged in LDS by the caller -- read from constant memory, the row of a cell's case is a third
+// ntri_of_case: reads the caller's LDS copy of the packed case table (c_mc_packed) -- read from constant memory, the row of a cell's case is a third
 // dependent round trip at the end of a kernel that is bound by its first two
-template <class R>
-__device__ inline McLocal mc_classify(const McTile<R>& t, const SSDevT<R>& P, int bx, int by, int bz, int tid, const int8_t* lut) {
+template <class R, class NT>
+__device__ inline McLocal mc_classify(const McTile<R>& t, const SSDevT<R>& P, int bx, int by, int bz, int tid, NT ntri_of_case) {
     McLocal L;
     const int lx = tid >> 6, ly = (tid >> 3) & 7, lz = tid & 7;
     L.gx = bx * SS_BLOCK + lx;
@@ -2690,9 +2713,7 @@ __device__ inline McLocal mc_classify(const McTile<R>& t, const SSDevT<R>& P, in
             L.case_index |= (v > thr ? 1 : 0) << c;  // marching_cubes_lut.rs:322-329
         }
     }
-    // triangles of the case: the row's entries 0, 3, 6, 9, 12 that are >= 0 (one 16-byte load, sign bits)
-    const uint4 row = *reinterpret_cast<const uint4*>(lut + 16 * L.case_index);
-    L.ntri = (int)(((~row.x >> 7) & 1u) + ((~row.x >> 31) & 1u) + ((~row.y >> 23) & 1u) + ((~row.z >> 15) & 1u) + ((~row.w >> 7) & 1u));
+    L.ntri = ntri_of_case(L.case_index);  // triangles of the case, from the caller's copy of the packed table in LDS
     return L;
 }
 
@@ -2801,13 +2822,12 @@ __global__ __launch_bounds__(128) void k_mc_count(SSDevT<R> P, const R* __restri
     __shared__ McTile<R> tile;
     __shared__ uint32_t s_nb[SS_MC_REC];
     __shared__ uint32_t s_v[2], s_t[2];
-    __shared__ __attribute__((aligned(16))) int8_t s_lut[256 * 16];  // the case table (mc_classify)
+    __shared__ uint32_t s_ntri4[32];  // triangles per case, a nibble each (mc_classify)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t m = blockIdx.x;
     if (m >= n_mc) return;
     const int bx = (int)mc_xyz[3 * (size_t)m], by = (int)mc_xyz[3 * (size_t)m + 1], bz = (int)mc_xyz[3 * (size_t)m + 2];  // k_block_coords
-    reinterpret_cast<uint4*>(s_lut)[tid] = reinterpret_cast<const uint4*>(&c_mc_table[0][0])[tid];
-    reinterpret_cast<uint4*>(s_lut)[128 + tid] = reinterpret_cast<const uint4*>(&c_mc_table[0][0])[128 + tid];
+    if (tid >= 96) s_ntri4[tid - 96] = c_mc_packed.ntri4[tid - 96];
     if (tid < SS_MC_REC) s_nb[tid] = mc_nb[SS_MC_REC * (size_t)m + tid];
     __syncthreads();
     mc_load_tile_128(tile, P, G, s_nb, tid);
@@ -2815,7 +2835,7 @@ __global__ __launch_bounds__(128) void k_mc_count(SSDevT<R> P, const R* __restri
     uint32_t nv = 0, ntri = 0;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-        const McLocal L = mc_classify(tile, P, bx, by, bz, 128 * q + tid, s_lut);
+        const McLocal L = mc_classify(tile, P, bx, by, bz, 128 * q + tid, [&](int ci) { return (int)((s_ntri4[ci >> 3] >> (4 * (ci & 7))) & 7u); });
 #pragma unroll
         for (int a = 0; a < 3; ++a) {
             const unsigned long long mk = __ballot(L.cross[a]);
@@ -2852,18 +2872,18 @@ __global__ __launch_bounds__(256) void k_mc_emit(SSDevT<R> P, const R* __restric
     __shared__ uint32_t s_vbase[8];
     __shared__ uint32_t s_tslab[8];        // triangles of x-slab s
     __shared__ uint32_t s_rec[8][5 * 64];  // per x-slab: (cell, triangle number, case) of its triangles, in cell order
-    __shared__ __attribute__((aligned(16))) int8_t s_lut[256 * 16];  // the case table: the corner look-ups of a trip hit 64 different rows
+    __shared__ unsigned long long s_row[256];  // the packed case table: the look-ups of a trip hit 64 different rows
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t m = blockIdx.x;
     if (m >= n_mc) return;
     // everything the first round trip can fetch is requested before the "nothing to emit" test waits for its four words
     const uint32_t vb0 = vbase[m], vb1 = vbase[m + 1], tb0 = tbase[m], tb1 = tbase[m + 1];
-    const uint4 lut_word = reinterpret_cast<const uint4*>(&c_mc_table[0][0])[tid];
+    const unsigned long long lut_word = c_mc_packed.row[tid];
     const int bx = (int)mc_xyz[3 * (size_t)m], by = (int)mc_xyz[3 * (size_t)m + 1], bz = (int)mc_xyz[3 * (size_t)m + 2];  // k_block_coords
     uint32_t nb_word = 0;
     if (tid < SS_MC_REC) nb_word = mc_nb[SS_MC_REC * (size_t)m + tid];
     if (vb1 == vb0 && tb1 == tb0) return;  // nothing to emit for this block
-    reinterpret_cast<uint4*>(s_lut)[tid] = lut_word;
+    s_row[tid] = lut_word;
     if (tid < SS_MC_REC) s_nb[tid] = nb_word;
     __syncthreads();
     mc_load_tile_256(tile, P, G, s_nb, tid);
@@ -2910,7 +2930,7 @@ __global__ __launch_bounds__(256) void k_mc_emit(SSDevT<R> P, const R* __restric
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
         const int pt = 256 * half + tid, slab = 4 * half + wave;
-        const McLocal L = mc_classify(tile, P, bx, by, bz, pt, s_lut);
+        const McLocal L = mc_classify(tile, P, bx, by, bz, pt, [&](int ci) { return (int)(s_row[ci] >> 60); });
 
         // ---- vertices on the three edges owned by this thread's point (dense_subdomains.rs:1498-1539) ----
         const int lx = pt >> 6, ly = (pt >> 3) & 7, lz = pt & 7;
@@ -2972,9 +2992,10 @@ __global__ __launch_bounds__(256) void k_mc_emit(SSDevT<R> P, const R* __restric
             const int cell = (int)(rec & 511u), i = (int)((rec >> 9) & 7u), cs = (int)(rec >> 12);
             const int cx = cell >> 6, cy = (cell >> 3) & 7, cz = cell & 7;
             uint32_t tri[3];
+            const unsigned long long row = s_row[cs] >> (12 * i);  // the three edge ids of triangle i in the low nibbles
 #pragma unroll
             for (int v = 0; v < 3; ++v) {
-                const int e = s_lut[cs * 16 + 3 * i + v];
+                const int e = (int)((uint32_t)(row >> (4 * v)) & 15u);
                 const uint32_t code = (uint32_t)(SS_MC_EDGE_CODES >> (5 * e)) & 31u;  // origin corner offsets and axis of local edge e
                 const int a = (int)(code & 3u);
                 const int ox = cx + (int)((code >> 4) & 1u), oy = cy + (int)((code >> 3) & 1u), oz = cz + (int)((code >> 2) & 1u);
