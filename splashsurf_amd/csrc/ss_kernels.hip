@@ -52,12 +52,9 @@ constexpr SSMcPacked ss_make_mc_packed() {
     return p;
 }
 __constant__ __attribute__((aligned(16))) SSMcPacked c_mc_packed = ss_make_mc_packed();
-// uniform_grid.rs:825-834
-__constant__ int8_t c_corner[8][3] = {{0, 0, 0}, {1, 0, 0}, {1, 1, 0}, {0, 1, 0}, {0, 0, 1}, {1, 0, 1}, {1, 1, 1}, {0, 1, 1}};
-// uniform_grid.rs:856-869: local edge -> (origin corner, axis)
-__constant__ int8_t c_edge[12][2] = {{0, 0}, {1, 1}, {3, 0}, {0, 1}, {4, 0}, {5, 1}, {7, 0}, {4, 1}, {0, 2}, {1, 2}, {2, 2}, {3, 2}};
-// the same two tables folded into one word: 5 bits per local edge e, (ox << 4) | (oy << 3) | (oz << 2) | axis of the edge's origin
-// corner -- decoded with a shift instead of five dependent byte loads per triangle corner
+// The corners of a cell (uniform_grid.rs:825-834) and local edge -> (origin corner, axis) (uniform_grid.rs:856-869), folded into one
+// word: 5 bits per local edge e, (ox << 4) | (oy << 3) | (oz << 2) | axis of the edge's origin corner -- decoded with a shift instead
+// of five dependent byte loads per triangle corner
 constexpr unsigned long long ss_mc_edge_code(int e) {
     constexpr int corner[8][3] = {{0, 0, 0}, {1, 0, 0}, {1, 1, 0}, {0, 1, 0}, {0, 0, 1}, {1, 0, 1}, {1, 1, 1}, {0, 1, 1}};
     constexpr int edge[12][2] = {{0, 0}, {1, 1}, {3, 0}, {0, 1}, {4, 0}, {5, 1}, {7, 0}, {4, 1}, {0, 2}, {1, 2}, {2, 2}, {3, 2}};
@@ -2700,19 +2697,19 @@ __device__ inline McLocal mc_classify(const McTile<R>& t, const SSDevT<R>& P, in
     // points / edges / cells of the shard region only (full domain: pt_hi = np - 1)
     const bool point_exists = L.gx <= P.pt_hi[0] && L.gy <= P.pt_hi[1] && L.gz <= P.pt_hi[2];
     const R thr = P.threshold;
-    const bool in0 = t.g[(lx * 9 + ly) * 9 + lz] > thr;  // dense_subdomains.rs:1482 (strict >)
-    L.cross[0] = point_exists && (L.gx + 1 <= P.pt_hi[0]) && (in0 != (t.g[((lx + 1) * 9 + ly) * 9 + lz] > thr));
-    L.cross[1] = point_exists && (L.gy + 1 <= P.pt_hi[1]) && (in0 != (t.g[(lx * 9 + ly + 1) * 9 + lz] > thr));
-    L.cross[2] = point_exists && (L.gz + 1 <= P.pt_hi[2]) && (in0 != (t.g[(lx * 9 + ly) * 9 + lz + 1] > thr));
-    L.case_index = 0;
+    // the eight points of the cell, read once at constant offsets from the thread's own point (all 9^3 entries of the tile are
+    // filled, mc_load_tile*): v[dx][dy][dz]
+    const R* p = &t.g[(lx * 9 + ly) * 9 + lz];
+    const bool b000 = p[0] > thr, b001 = p[1] > thr, b010 = p[9] > thr, b011 = p[10] > thr;  // dense_subdomains.rs:1482 (strict >)
+    const bool b100 = p[81] > thr, b101 = p[82] > thr, b110 = p[90] > thr, b111 = p[91] > thr;
+    L.cross[0] = point_exists && (L.gx + 1 <= P.pt_hi[0]) && (b000 != b100);
+    L.cross[1] = point_exists && (L.gy + 1 <= P.pt_hi[1]) && (b000 != b010);
+    L.cross[2] = point_exists && (L.gz + 1 <= P.pt_hi[2]) && (b000 != b001);
     const bool cell_exists = L.gx < P.pt_hi[0] && L.gy < P.pt_hi[1] && L.gz < P.pt_hi[2];
-    if (cell_exists) {
-#pragma unroll
-        for (int c = 0; c < 8; ++c) {
-            const R v = t.g[((lx + c_corner[c][0]) * 9 + ly + c_corner[c][1]) * 9 + lz + c_corner[c][2]];
-            L.case_index |= (v > thr ? 1 : 0) << c;  // marching_cubes_lut.rs:322-329
-        }
-    }
+    // corner c of the cell is the point c_corner[c] (uniform_grid.rs:825-834), bit c of the case index says "above the threshold"
+    // (marching_cubes_lut.rs:322-329): corners 0..7 = 000, 100, 110, 010, 001, 101, 111, 011 in (dx, dy, dz)
+    const int bits = (b000 ? 1 : 0) | (b100 ? 2 : 0) | (b110 ? 4 : 0) | (b010 ? 8 : 0) | (b001 ? 16 : 0) | (b101 ? 32 : 0) | (b111 ? 64 : 0) | (b011 ? 128 : 0);
+    L.case_index = cell_exists ? bits : 0;  // 0 if the cell does not exist
     L.ntri = ntri_of_case(L.case_index);  // triangles of the case, from the caller's copy of the packed table in LDS
     return L;
 }
