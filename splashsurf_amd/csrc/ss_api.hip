@@ -1223,7 +1223,7 @@ ss_status phase_finish(ss_context* ctx, ss_result* res) {
     SS_HIP(ctx, ctx->tcount.reserve(((size_t)n_mc + 1) * 4));
     SS_HIP(ctx, res->vbase.reserve(((size_t)n_mc + 2) * 4));
     SS_HIP(ctx, res->tbase.reserve(((size_t)n_mc + 2) * 4));
-    SS_HIP(ctx, ctx->mc_nb.reserve((size_t)n_mc * 96 + 64));
+    SS_HIP(ctx, ctx->mc_nb.reserve((size_t)n_mc * SS_MC_REC * 4 + 64));
     ss_launch_mc_neighbours(P, res->mc_xyz.as<uint32_t>(), n_mc, res->block_slot.as<uint32_t>(), res->mc_slot.as<uint32_t>(), full_ls ? nullptr : tr_flag, ctx->mc_nb.as<uint32_t>(), st);
     SS_HIP(ctx, hipEventRecord(ctx->ev[20], st));
     ss_launch_mc_count(P, res->G.as<R>(), ctx->mc_nb.as<uint32_t>(), res->mc_xyz.as<uint32_t>(), n_mc, res->masks.as<unsigned long long>(),

@@ -46,6 +46,7 @@ void ss_launch_splat_certify_big(const SSDevT<float>& P, const ss_real4<float>* 
 template <class R>
 void ss_launch_select_redo(const SSDevT<R>& P, const uint32_t* active_xyz, uint32_t n_active, const uint32_t* block_slot, const uint32_t* trunc, const unsigned long long* facebits, uint32_t* redo_mask, const uint32_t* counts, unsigned long long* stats, uint32_t* big, hipStream_t st);
 void ss_launch_publish_stats(const unsigned long long* stats, const uint32_t* n_redo, const uint32_t* n_large, const uint32_t* err, SSMailSlot m0, SSMailSlot m1, SSMailSlot m2, SSMailSlot m3, hipStream_t st);
+#define SS_MC_REC 28  // words of a marching-cubes block's record in mc_nb (k_mc_neighbours)
 template <class R>
 void ss_launch_mc_neighbours(const SSDevT<R>& P, const uint32_t* mc_xyz, uint32_t n_mc, const uint32_t* block_slot, const uint32_t* mc_slot, const uint32_t* certified, uint32_t* mc_nb, hipStream_t st);
 template <class R>

@@ -2611,7 +2611,8 @@ struct McTile {
 // certified to lie inside the surface and never evaluated in full, mc_nb[16 + n] = its slot in the MC list (crossing masks,
 // vertex base; 0xFFFFFFFF: not triangulated).  The count and the emit kernel then reach the level-set values with two
 // dependent loads (record, value) instead of four (block coordinates, slot, mask, value) -- they are latency-bound.
-#define SS_MC_REC 24
+// mc_nb[24 + d] = subdomain of the block's first point along axis d (the emit kernel's per-vertex divisions start from it; the
+// division itself, wave-uniform but done by the vector unit, cost every wave of that kernel 75 instructions).  SS_MC_REC: ss_kernels.h.
 template <class R>
 __global__ __launch_bounds__(256) void k_mc_neighbours(SSDevT<R> P, const uint32_t* __restrict__ mc_xyz, uint32_t n_mc, const uint32_t* __restrict__ block_slot,
                                                        const uint32_t* __restrict__ mc_slot, const uint32_t* __restrict__ certified, uint32_t* __restrict__ mc_nb) {
@@ -2629,6 +2630,7 @@ __global__ __launch_bounds__(256) void k_mc_neighbours(SSDevT<R> P, const uint32
     mc_nb[SS_MC_REC * (size_t)m + n] = slot;
     mc_nb[SS_MC_REC * (size_t)m + 8 + n] = cert;
     mc_nb[SS_MC_REC * (size_t)m + 16 + n] = mslot;
+    if (n < 4u) mc_nb[SS_MC_REC * (size_t)m + 24 + n] = (n < 3u) ? (uint32_t)(((int)mc_xyz[3 * (size_t)m + n] * SS_BLOCK) / P.n_sub_cubes) : 0u;
 }
 
 // s_nb: the block's record of mc_nb in LDS.  Points of a certified sub-block read as "a value above the threshold" (they are no
@@ -2856,6 +2858,10 @@ __global__ __launch_bounds__(128) void k_mc_count(SSDevT<R> P, const R* __restri
 
 // ONE 256-thread workgroup per MC block, two points per thread like k_mc_count (wave w: the x-slabs w and 4 + w; eight such
 // workgroups per CU instead of four of 512 threads, the two round trips of a block -- record, then values and masks -- paid once).
+// Vertices and triangles are both emitted from RECORDS in LDS: a surface block has ~35 vertices and ~70 triangles on its 512 points, so
+// "every lane handles the crossings of its own point" ran the vertex arithmetic (a division, three coordinates) 24 times per block for
+// a few lanes each, with scattered 12-byte stores.  Instead every crossing files (point, axis) at its rank within the block -- the
+// rank is the vertex id minus the block's base -- and lane k then builds vertex k: one or two trips per block, contiguous stores.
 template <class R>
 __global__ __launch_bounds__(256) void k_mc_emit(SSDevT<R> P, const R* __restrict__ G, const uint32_t* __restrict__ mc_nb,
                                                  const uint32_t* __restrict__ mc_xyz, const uint32_t* __restrict__ mc_slot, uint32_t n_mc,
@@ -2870,6 +2876,8 @@ __global__ __launch_bounds__(256) void k_mc_emit(SSDevT<R> P, const R* __restric
     __shared__ uint32_t s_tslab[8];        // triangles of x-slab s
     __shared__ uint32_t s_rec[8][5 * 64];  // per x-slab: (cell, triangle number, case) of its triangles, in cell order
     __shared__ unsigned long long s_row[256];  // the packed case table: the look-ups of a trip hit 64 different rows
+    uint16_t* s_vrec = reinterpret_cast<uint16_t*>(&s_rec[0][0]);  // (point, axis) of the block's vertices by rank, 3 x 512 at most: in the triangle records' space, before those are filed
+    static_assert(sizeof(s_rec) >= 3 * 512 * sizeof(uint16_t), "vertex records share the triangle records' space");
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t m = blockIdx.x;
     if (m >= n_mc) return;
@@ -2892,7 +2900,7 @@ __global__ __launch_bounds__(256) void k_mc_emit(SSDevT<R> P, const R* __restric
         unsigned long long mk = 0;
         uint32_t slot = 0xFFFFFFFFu;
         if (w < 24) {
-            slot = mc_nb[SS_MC_REC * (size_t)m + 16 + nb];  // (straight from the record: s_nb is being filled by other threads)
+            slot = s_nb[16 + nb];
             if (slot != 0xFFFFFFFFu) mk = masks[(size_t)slot * 24 + w];
         }
         const uint32_t c = (uint32_t)__popcll(mk);
@@ -2906,43 +2914,50 @@ __global__ __launch_bounds__(256) void k_mc_emit(SSDevT<R> P, const R* __restric
         }
     }
     __syncthreads();
-    const int n = P.n_sub_cubes;
-    // subdomain of the block's first point per axis, once per thread: the points of the block (and the point before the first
-    // one) are at most one subdomain border away from it when a subdomain has more than 8 cubes, so the per-vertex divisions
-    // below (five to nine a thread, ~25 instructions each: 40 % of this kernel's arithmetic) become a comparison
-    const int g0[3] = {bx * SS_BLOCK, by * SS_BLOCK, bz * SS_BLOCK};
-    int q0[3], r0[3];
-#pragma unroll
-    for (int d = 0; d < 3; ++d) {
-        q0[d] = g0[d] / n;
-        r0[d] = g0[d] - q0[d] * n;
-    }
-    const bool near_border_rule = n > SS_BLOCK;  // (wave-uniform)
-    auto subdomain_of = [&](int d, int x) {  // x / n for a point index x in [g0[d] - 1, g0[d] + 8], x >= 0
-        if (!near_border_rule) return x / n;
-        const int t = r0[d] + (x - g0[d]);
-        return q0[d] + (t >= n ? 1 : 0) - (t < 0 ? 1 : 0);
-    };
     const unsigned long long below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    // ---- classification; the crossings of the three edges a point owns filed by rank (dense_subdomains.rs:1498-1539) ----
+    int case_of[2], ntri_of[2];
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
         const int pt = 256 * half + tid, slab = 4 * half + wave;
         const McLocal L = mc_classify(tile, P, bx, by, bz, pt, [&](int ci) { return (int)(s_row[ci] >> 60); });
-
-        // ---- vertices on the three edges owned by this thread's point (dense_subdomains.rs:1498-1539) ----
-        const int lx = pt >> 6, ly = (pt >> 3) & 7, lz = pt & 7;
-        const int O[3] = {L.gx, L.gy, L.gz};
+        case_of[half] = L.case_index;
+        ntri_of[half] = L.ntri;
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+            if (L.cross[a]) s_vrec[s_pref[0][a * 8 + slab] + (uint32_t)__popcll(s_mask[0][a * 8 + slab] & below)] = (uint16_t)(pt | (a << 9));
+    }
+    __syncthreads();
+    // ---- vertices: lane k builds the block's k-th vertex ----
+    {
+        const int n = P.n_sub_cubes;
+        // subdomain of the block's first point per axis (k_mc_neighbours): the points of the block (and the point before the first one)
+        // are at most one subdomain border away from it when a subdomain has more than 8 cubes, so the per-vertex divisions below
+        // (~25 instructions each) become a comparison
+        const int g0[3] = {bx * SS_BLOCK, by * SS_BLOCK, bz * SS_BLOCK};
+        int q0[3], r0[3];
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            q0[d] = (int)s_nb[24 + d];
+            r0[d] = g0[d] - q0[d] * n;
+        }
+        const bool near_border_rule = n > SS_BLOCK;  // (wave-uniform)
+        auto subdomain_of = [&](int d, int x) {  // x / n for a point index x in [g0[d] - 1, g0[d] + 8], x >= 0
+            if (!near_border_rule) return x / n;
+            const int t = r0[d] + (x - g0[d]);
+            return q0[d] + (t >= n ? 1 : 0) - (t < 0 ? 1 : 0);
+        };
         // global edge key = 3 x (flat index of the origin point) + axis: block-uniform base plus small multiples of the strides
         const unsigned long long stride_y = 3ull * (unsigned long long)P.np[2], stride_x = stride_y * (unsigned long long)P.np[1];
-        const unsigned long long point_key = ((unsigned long long)g0[0] * (unsigned long long)P.np[1] + (unsigned long long)g0[1]) * stride_y + 3ull * (unsigned long long)g0[2] +
-                                             (unsigned long long)(uint32_t)lx * stride_x + (unsigned long long)(uint32_t)ly * stride_y + (unsigned long long)(3 * lz);
-#pragma unroll
-        for (int a = 0; a < 3; ++a) {
-            if (!L.cross[a]) continue;
-            const uint32_t vid = s_vbase[0] + s_pref[0][a * 8 + slab] + (uint32_t)__popcll(s_mask[0][a * 8 + slab] & below);
-            const int tl[3] = {lx + (a == 0), ly + (a == 1), lz + (a == 2)};
-            const R ov = tile.g[(lx * 9 + ly) * 9 + lz];
-            const R tv = tile.g[(tl[0] * 9 + tl[1]) * 9 + tl[2]];
+        const unsigned long long block_key = ((unsigned long long)g0[0] * (unsigned long long)P.np[1] + (unsigned long long)g0[1]) * stride_y + 3ull * (unsigned long long)g0[2];
+        const uint32_t nv = vb1 - vb0;  // (= the crossings of the block's 24 mask words, k_mc_count)
+        for (uint32_t k = (uint32_t)tid; k < nv; k += 256u) {
+            const uint32_t rec = s_vrec[k];
+            const int pt = (int)(rec & 511u), a = (int)(rec >> 9);
+            const int l3[3] = {pt >> 6, (pt >> 3) & 7, pt & 7};
+            const int at = (l3[0] * 9 + l3[1]) * 9 + l3[2];
+            const R ov = tile.g[at];
+            const R tv = tile.g[at + (a == 0 ? 81 : (a == 1 ? 9 : 1))];
             const R alpha = (P.threshold - ov) / (tv - ov);  // :1516-1517
             R vc[3];
 #pragma unroll
@@ -2950,32 +2965,35 @@ __global__ __launch_bounds__(256) void k_mc_emit(SSDevT<R> P, const R* __restric
                 // coordinates in the marching-cubes grid of the lowest-index subdomain that generates this
                 // vertex ("first patch wins" with patches in ascending flat subdomain index, :1707-1716):
                 // the subdomain of the adjacent cell O - delta, delta_d = 1 on the orthogonal axes where possible
-                int sd;
-                if (d == a)
-                    sd = subdomain_of(d, O[d]);
-                else
-                    sd = (O[d] >= 1) ? subdomain_of(d, O[d] - 1) : 0;
-                const int loc = O[d] - sd * n;
+                const int O = g0[d] + l3[d];
+                const int xq = O - (d == a ? 0 : 1);
+                const int sd = (xq >= 0) ? subdomain_of(d, xq) : 0;
+                const int loc = O - sd * n;
                 const R sub_min = P.gmin[d] + (R)sd * P.sub_size;  // uniform_grid.rs:454-467 on the subdomain grid
                 const R oc = sub_min + (R)loc * P.cs;               // uniform_grid.rs:418-425 on the subdomain MC grid
                 const R tc = sub_min + (R)(loc + (d == a ? 1 : 0)) * P.cs;
                 vc[d] = oc * (R(1.0) - alpha) + tc * alpha;  // :1518-1519
             }
-            vertices[3 * (size_t)vid] = vc[0];
-            vertices[3 * (size_t)vid + 1] = vc[1];
-            vertices[3 * (size_t)vid + 2] = vc[2];
-            vkeys[vid] = point_key + (unsigned long long)a;
+            const size_t vid = (size_t)vb0 + k;
+            vertices[3 * vid] = vc[0];
+            vertices[3 * vid + 1] = vc[1];
+            vertices[3 * vid + 2] = vc[2];
+            vkeys[vid] = block_key + (unsigned long long)(uint32_t)l3[0] * stride_x + (unsigned long long)(uint32_t)l3[1] * stride_y + (unsigned long long)(3 * l3[2] + a);
         }
-
-        // ---- triangle records of this slab ----
-        // Only one cell in eight of a surface block has triangles: a loop "for my cell's triangles" keeps a few lanes busy for five
-        // trips and scatters 12-byte stores.  Instead every lane files a record (cell, case, triangle number) per triangle of its
-        // cell at the triangle's rank within the slab, and the wave then emits records 64 at a time: lane k builds the k-th
-        // triangle, so the stores of a trip form one contiguous run.
-        const uint32_t incl = ss_wave_inclusive_scan((uint32_t)L.ntri);  // (DPP: no LDS round trips)
+    }
+    __syncthreads();  // the vertex records are read: their space takes the triangle records
+    // ---- triangle records of the slabs ----
+    // Only one cell in eight of a surface block has triangles: a loop "for my cell's triangles" keeps a few lanes busy for five
+    // trips and scatters 12-byte stores.  Instead every lane files a record (cell, case, triangle number) per triangle of its
+    // cell at the triangle's rank within the slab, and the wave then emits records 64 at a time: lane k builds the k-th
+    // triangle, so the stores of a trip form one contiguous run.
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        const int pt = 256 * half + tid, slab = 4 * half + wave;
+        const uint32_t incl = ss_wave_inclusive_scan((uint32_t)ntri_of[half]);  // (DPP: no LDS round trips)
         if (lane == 63) s_tslab[slab] = incl;
-        const uint32_t excl = incl - (uint32_t)L.ntri;
-        for (int i = 0; i < L.ntri; ++i) s_rec[slab][excl + (uint32_t)i] = (uint32_t)pt | ((uint32_t)i << 9) | ((uint32_t)L.case_index << 12);
+        const uint32_t excl = incl - (uint32_t)ntri_of[half];
+        for (int i = 0; i < ntri_of[half]; ++i) s_rec[slab][excl + (uint32_t)i] = (uint32_t)pt | ((uint32_t)i << 9) | ((uint32_t)case_of[half] << 12);
     }
     __syncthreads();
 #pragma unroll
