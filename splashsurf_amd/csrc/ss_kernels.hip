@@ -311,8 +311,7 @@ __device__ inline void ss_for_each_member_subdomain(const SSDevT<R>& P, const R 
         if (sub[d] < 0 || sub[d] >= P.ns[d]) return;            // dense_subdomains.rs:1819-1822
         const R min_corner = P.gmin[d] + (R)sub[d] * P.sub_size;
         const R max_corner = P.gmin[d] + (R)(sub[d] + 1) * P.sub_size;
-        uint32_t m = 0;
-        for (int step = -r; step <= r; ++step) {
+        auto step_ok = [&](int step) {
             const R off = (R)((step < 0 ? -step : step) - 1);
             bool ok = true;
             if (step > 0)
@@ -321,8 +320,13 @@ __device__ inline void ss_for_each_member_subdomain(const SSDevT<R>& P, const R 
                 ok = (p[d] - (min_corner - off * dx)) < P.margin;
             const int nd = sub[d] + step;
             ok = ok && nd >= 0 && nd < P.ns[d];                      // :1895-1900
-            ok = ok && nd >= P.sub_lo[d] && nd < P.sub_hi[d];        // multi-GPU shard: only the subdomains this process reconstructs
-            m |= ok ? (1u << (step + r)) : 0u;
+            return ok && nd >= P.sub_lo[d] && nd < P.sub_hi[d];      // multi-GPU shard: only the subdomains this process reconstructs
+        };
+        uint32_t m = 0;
+        if (r == 1) {  // (wave-uniform) the margin is narrower than a subdomain: the three steps spelled out, their constants folded
+            m = (step_ok(-1) ? 1u : 0u) | (step_ok(0) ? 2u : 0u) | (step_ok(1) ? 4u : 0u);
+        } else {
+            for (int step = -r; step <= r; ++step) m |= step_ok(step) ? (1u << (step + r)) : 0u;
         }
         valid[d] = m;
     }
