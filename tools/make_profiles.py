@@ -27,7 +27,7 @@ def short(name):
 def main():
     traffic = {"s10m_tank": {}}
     md = ["# rocprofv3 PMC counters, S10M-tank, 1x MI355X (%s)" % TAG,
-          "Command per pass: `rocprofv3 --pmc <COUNTERS> --kernel-include-regex 'k_splat|k_density_sub' --output-format csv -- python bench.py --main-only --steps 1 "
+          "Command per pass: `rocprofv3 --pmc <COUNTERS> --kernel-include-regex 'k_splat|k_density_sub|k_mc_|k_rs_|k_chained_scan' --output-format csv -- python bench.py --main-only --steps 1 "
           "--warmup 1 --simd M` (tools/collect_profiles.sh; one pass per counter group, no --kernel-trace/--stats in a PMC pass).  Values are per launch "
           "(two launches per run agree to 4 digits).  FETCH_SIZE / WRITE_SIZE in KiB as reported; `hbm` = 2 x FETCH_SIZE + WRITE_SIZE in bytes "
           "(gfx950 tallies the 128-B requests of 16-B-per-lane streaming reads at 64 B, MI355X_MICROARCH.md).", ""]
@@ -57,7 +57,7 @@ def main():
                 t = traffic["s10m_tank"].setdefault(mname, {
                     "kernel": "k_splat_fused (first and second pass) + k_splat_accumulate_list (blocks with over 192 candidates)", "hbm_bytes_per_launch": 0.0, "fetch_size_bytes_reported": 0.0,
                     "write_size_bytes": 0.0, "kernel_ms_rocprof_avg": 0.0, "valu_insts_per_launch": 0.0, "launches": {},
-                    "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, --kernel-include-regex 'k_splat|k_density_sub') on S10M-tank, per step = sum over the "
+                    "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, --kernel-include-regex 'k_splat|k_density_sub|k_mc_|k_rs_|k_chained_scan') on S10M-tank, per step = sum over the "
                             "launches of the splat kernel; read side doubled per MI355X_MICROARCH.md (gfx950 FETCH_SIZE counts 128-B requests as 64 B); the "
                             "kernel gathers every block's candidates from the cell-sorted particle array (neighbouring blocks re-read the same rows, mostly "
                             "from L2) and writes the level-set values of the evaluated sub-blocks (DESIGN.md section 5, profiles/" + TAG + "_pmc_s10m_tank.md)",
