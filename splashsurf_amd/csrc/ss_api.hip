@@ -2,8 +2,8 @@
 //
 // Host-side restatement of the reference's grid set-up (lib.rs:476-516, density_map.rs:551-580,
 // uniform_grid.rs:175-232, dense_subdomains.rs:89-244) in IEEE f32 (this file is compiled with
-// -ffp-contract=off like the kernels).  Commodity primitives (radix sort, prefix sums) come from
-// rocPRIM; every domain kernel is hand-written in ss_kernels.hip.
+// -ffp-contract=off like the kernels).  The radix sort and the prefix sums are the library's own
+// (ss_prims.h), every domain kernel is hand-written in ss_kernels.hip.
 #include <hip/hip_runtime.h>
 
 #include <string.h>
@@ -900,7 +900,7 @@ ss_status phase_begin(ss_context* ctx, const R* xyz, uint64_t n_in, const typena
     {
         const double ctot_d = (double)P.sc[0] * P.sc[1] * P.sc[2];
         SS_HIP(ctx, hipMemsetAsync(res->rho.p, 0, (size_t)n * sizeof(R) + 16, st));  // vec![R::zero(); n], dense_subdomains.rs:504
-        // member counts -> copy offsets (k_classify_count as the scan's input), occupied subdomains -> ranks and list
+        // member counts -> copy offsets (the membership count as the scan's input), occupied subdomains -> ranks and list
         const SSMailSlot m_copies = mail_slot(ctx, 0), m_occ = mail_slot(ctx, 1);
         ss_launch_classify_scan(P, d_xyz, ctx->copy_offset.as<uint32_t>(), sub_flag, st_member, m_copies, st);
         ss_launch_flag_scan(sub_flag, (uint32_t)nsub, ctx->sub_rank.as<uint32_t>(), ctx->occ_sub.as<uint32_t>(), nullptr, st_sub, m_occ, st);

@@ -10,14 +10,8 @@ template <class R>
 void ss_launch_inside_flags(const R* d_xyz, uint32_t n, const R amin[3], const R amax[3], uint8_t* f8, uint32_t* f32, hipStream_t st);
 template <class R>
 void ss_launch_compact_xyz(const R* d_xyz, uint32_t n, const uint32_t* f32, const uint32_t* offs, R* out, hipStream_t st);
-void ss_launch_run_starts(const uint32_t* sorted_keys, uint32_t n, uint32_t ncells, uint32_t* first, hipStream_t st);
 template <class R>
 void ss_launch_cell_keys(const SSDevT<R>& P, const R* d_xyz, uint32_t* keys, uint32_t* vals, hipStream_t st);
-template <class R>
-void ss_launch_gather_sorted(uint32_t n, const R* d_xyz, const uint32_t* perm, ss_pos<R>* pos_sorted, hipStream_t st);
-template <class R>
-void ss_launch_classify_count(const SSDevT<R>& P, const R* xyz, uint32_t* member_count, uint32_t* sub_flag, hipStream_t st);
-void ss_launch_occupied_list(const uint32_t* flag, const uint32_t* rank, uint32_t n, uint32_t* occ_sub, hipStream_t st);
 template <class R>
 void ss_launch_emit_copies(const SSDevT<R>& P, const R* xyz, const uint32_t* copy_offset, const uint32_t* occ_rank, uint32_t* keys, uint32_t* vals, hipStream_t st);
 template <class R>
@@ -26,12 +20,7 @@ template <class R>
 void ss_launch_make_posvol(const SSDevT<R>& P, const ss_pos<R>* pos_sorted, const uint32_t* perm, const R* rho, ss_real4<R>* posvol, ss_real4<R>* posvol_by_index, hipStream_t st);
 template <class R>
 void ss_launch_mark_blocks(const SSDevT<R>& P, const uint32_t* cell_start, uint32_t ncells, uint32_t* block_flag, hipStream_t st);
-template <class R>
-void ss_launch_mark_mc_blocks(const SSDevT<R>& P, const uint32_t* block_slot, const ss_real2<R>* blk_minmax, uint32_t nblocks, uint32_t* mc_flag, hipStream_t st);
-void ss_launch_compact_blocks(const uint32_t* flag, const uint32_t* rank, uint32_t nblocks, uint32_t* list, uint32_t* slot, hipStream_t st);
 void ss_launch_verify_fast_div(float h, float rh, uint32_t* bad, hipStream_t st);
-template <class R>
-void ss_launch_block_coords(const SSDevT<R>& P, const uint32_t* active_list, uint32_t n_active, uint32_t* xyz, hipStream_t st);
 template <class R>
 void ss_launch_splat_bounds(const SSDevT<R>& P, const uint32_t* cell_start, const uint32_t* active_xyz, uint32_t n_active, const uint32_t* counts, uint32_t* bound, hipStream_t st);
 template <class R>
@@ -72,6 +61,5 @@ template <class R>
 void ss_launch_mc_blocks_scan(const SSDevT<R>& P, const uint32_t* block_slot, const ss_real2<R>* blk_minmax, uint32_t nblocks, uint32_t cap, uint32_t* mc_list, uint32_t* mc_slot, uint32_t* mc_xyz, uint32_t* state, SSMailSlot mail, hipStream_t st);
 void ss_launch_mc_offsets_scan(const uint32_t* vcount, const uint32_t* tcount, uint32_t n_mc, uint32_t* vbase, uint32_t* tbase, uint32_t* state, SSMailSlot mail, hipStream_t st);
 void ss_launch_tile_offsets_scan(const uint32_t* bound, uint32_t n, unsigned long long* off, uint32_t* state, SSMailSlot mail, hipStream_t st);
-void ss_launch_publish_u32(const uint32_t* src, SSMailSlot mail, hipStream_t st);
 template <class R>
 void ss_launch_posvol_by_index(uint32_t n, const ss_real4<R>* posvol, const uint32_t* perm, ss_real4<R>* posvol_by_index, hipStream_t st);

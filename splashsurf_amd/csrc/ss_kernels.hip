@@ -203,43 +203,11 @@ __global__ __launch_bounds__(256) void k_cell_keys(SSDevT<R> P, const R* __restr
     if (vals) vals[i] = i;  // (null: the sort takes the positions as the values itself)
 }
 
-// Cell table from the SORTED keys (no histogram atomics): first[c] = position of the first entry of cell c, written at the run
-// starts; first[] must be preset to 0xFFFFFFFF, entry ncells receives n.  A reverse running minimum then turns it into
-// cell_start (an empty cell starts where the next non-empty one does).
-__global__ __launch_bounds__(256) void k_run_starts(const uint32_t* __restrict__ sorted_keys, uint32_t n, uint32_t ncells, uint32_t* __restrict__ first) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i > n) return;
-    if (i == n) {
-        first[ncells] = n;
-        return;
-    }
-    const uint32_t k = sorted_keys[i];
-    if (i == 0 || sorted_keys[i - 1] != k) first[k] = i;
-}
-void ss_launch_run_starts(const uint32_t* sorted_keys, uint32_t n, uint32_t ncells, uint32_t* first, hipStream_t st) {
-    hipLaunchKernelGGL(k_run_starts, dim3((n + 1u + 255u) / 256u), dim3(256), 0, st, sorted_keys, n, ncells, first);
-}
-
-template <class R>
-__global__ __launch_bounds__(256) void k_gather_sorted(uint32_t n, const R* __restrict__ xyz, const uint32_t* __restrict__ perm,
-                                                       ss_pos<R>* __restrict__ pos_sorted) {
-    uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= n) return;
-    size_t i = perm[p];
-    pos_sorted[p] = ss_make_pos<R>(xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2]);
-}
-
 template <class R>
 void ss_launch_cell_keys(const SSDevT<R>& P, const R* d_xyz, uint32_t* keys, uint32_t* vals, hipStream_t st) {
     if (!P.n) return;
     hipLaunchKernelGGL(k_cell_keys<R>, dim3((P.n + 255) / 256), dim3(256), 0, st, P, d_xyz, keys, vals);
 }
-template <class R>
-void ss_launch_gather_sorted(uint32_t n, const R* d_xyz, const uint32_t* perm, ss_pos<R>* pos_sorted, hipStream_t st) {
-    if (!n) return;
-    hipLaunchKernelGGL(k_gather_sorted<R>, dim3((n + 255) / 256), dim3(256), 0, st, n, d_xyz, perm, pos_sorted);
-}
-
 // =====================================================================================================
 // K2: per-particle SPH density, organised exactly like the reference (dense_subdomains.rs:496-646):
 // every particle is COPIED into each subdomain it belongs to (owner + ghost margins, classification of
@@ -294,7 +262,7 @@ __device__ inline void ss_for_each_member_subdomain_generic(const SSDevT<R>& P, 
 // margin test holds -- is separable: per axis a mask of the valid steps (margin test :1844-1856, grid bounds :1895-1900, this
 // process's shard window), and the members are the product of the three sets, visited in the reference's order (i0, j0, k0
 // ascending).  A particle has 1.95 member subdomains on average: looping over the 27 (or (2r+1)^3) combinations and testing each
-// cost ~400 instructions per particle in k_classify_count and k_emit_copies.
+// cost ~400 instructions per particle in the membership count and in k_emit_copies.
 template <class R, class F>
 __device__ inline void ss_for_each_member_subdomain(const SSDevT<R>& P, const R p[3], F f) {
     int sub[3];
@@ -348,30 +316,6 @@ __device__ inline int ss_local_search_cell_axis(const SSDevT<R>& P, int s, R x, 
     const R aligned = ss_floor(mmin / P.h) * P.h;
     const int c = (int)ss_floor((x - aligned) / P.h);
     return max(0, min(P.sc[d] - 1, c));
-}
-
-// member_count[i] = number of subdomains particle i belongs to; sub_flag[s] = 1 for every subdomain with
-// at least one (owned or ghost) particle.  Plain flag stores (all writers store 1): no atomics; a set flag is not written again
-// (20 M stores to a few thousand words serialise in the L2 channels that hold them, the reads are cached).
-template <class R>
-__global__ __launch_bounds__(256) void k_classify_count(SSDevT<R> P, const R* __restrict__ xyz, uint32_t* __restrict__ member_count,
-                                                        uint32_t* __restrict__ sub_flag) {
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= P.n) return;
-    const R p[3] = {xyz[3 * (size_t)i], xyz[3 * (size_t)i + 1], xyz[3 * (size_t)i + 2]};
-    uint32_t m = 0;
-    ss_for_each_member_subdomain(P, p, [&](int sx, int sy, int sz) {
-        ++m;
-        uint32_t* f = sub_flag + ((size_t)sx * P.ns[1] + sy) * P.ns[2] + sz;
-        if (!*f) *f = 1u;
-    });
-    member_count[i] = m;
-}
-
-__global__ __launch_bounds__(256) void k_occupied_list(const uint32_t* __restrict__ flag, const uint32_t* __restrict__ rank, uint32_t n,
-                                                       uint32_t* __restrict__ occ_sub) {
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n && flag[i]) occ_sub[rank[i]] = i;
 }
 
 template <class R>
@@ -502,7 +446,7 @@ __global__ __launch_bounds__(256) void k_density_sub(SSDevT<R> P, uint32_t n_cop
     constexpr int QC = SSDensityQueue<R>::cap, QD = SSDensityQueue<R>::chunk;
     __shared__ R s_q[(MODE == 2) ? 1 : QC][256];
     const int tid = threadIdx.x;
-    // Threads walk the OWNED copies only (k_owned_copy_flags + scan + compaction, in cell order): about half of the copies are
+    // Threads walk the OWNED copies only (owned flags of k_sorted_gather_runs + scan + compaction, in cell order): about half of the copies are
     // ghosts, and a wave of owners and idling ghosts costs as much as a wave of owners.
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= *n_owned_dev) return;
@@ -661,15 +605,6 @@ template void ss_launch_posvol_by_index<float>(uint32_t, const ss_real4<float>*,
 template void ss_launch_posvol_by_index<double>(uint32_t, const ss_real4<double>*, const uint32_t*, ss_real4<double>*, hipStream_t);
 
 template <class R>
-void ss_launch_classify_count(const SSDevT<R>& P, const R* xyz, uint32_t* member_count, uint32_t* sub_flag, hipStream_t st) {
-    if (!P.n) return;
-    hipLaunchKernelGGL(k_classify_count<R>, dim3((P.n + 255) / 256), dim3(256), 0, st, P, xyz, member_count, sub_flag);
-}
-void ss_launch_occupied_list(const uint32_t* flag, const uint32_t* rank, uint32_t n, uint32_t* occ_sub, hipStream_t st) {
-    if (!n) return;
-    hipLaunchKernelGGL(k_occupied_list, dim3((n + 255) / 256), dim3(256), 0, st, flag, rank, n, occ_sub);
-}
-template <class R>
 void ss_launch_emit_copies(const SSDevT<R>& P, const R* xyz, const uint32_t* copy_offset, const uint32_t* occ_rank, uint32_t* keys, uint32_t* vals,
                            hipStream_t st) {
     if (!P.n) return;
@@ -774,69 +709,11 @@ __global__ __launch_bounds__(256) void k_mark_blocks(SSDevT<R> P, const uint32_t
         }
 }
 
-// MC works on blocks of cells whose origin point lies in block b; it reads the points of blocks b+{0,1}^3.
-// A block can only produce triangles if those eight level-set blocks together hold values on both
-// sides of the threshold (absent blocks are all zero); blk_minmax comes from the splat kernel.
-template <class R>
-__global__ __launch_bounds__(256) void k_mark_mc_blocks(SSDevT<R> P, const uint32_t* __restrict__ block_slot, const ss_real2<R>* __restrict__ blk_minmax,
-                                                        uint32_t nblocks, uint32_t* __restrict__ mc_flag) {
-    uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= nblocks) return;
-    int bx, by, bz;
-    ss_block_of_index(P, b, &bx, &by, &bz);
-    if (bx < P.blk_lo[0] || by < P.blk_lo[1] || bz < P.blk_lo[2] || bx > P.blk_hi[0] || by > P.blk_hi[1] || bz > P.blk_hi[2]) {
-        mc_flag[b] = 0u;
-        return;
-    }
-    bool any_in = false, any_out = false;
-    for (int dx = 0; dx <= 1; ++dx)
-        for (int dy = 0; dy <= 1; ++dy)
-            for (int dz = 0; dz <= 1; ++dz) {
-                int x = bx + dx, y = by + dy, z = bz + dz;
-                R mn = R(0.0), mx = R(0.0);
-                if (ss_block_in_table(P, x, y, z)) {
-                    const uint32_t slot = block_slot[ss_block_index(P, x, y, z)];
-                    if (slot != 0xFFFFFFFFu) {
-                        const ss_real2<R> mm = blk_minmax[slot];
-                        mn = mm.x;
-                        mx = mm.y;
-                    }
-                }
-                any_in = any_in || (mx > P.threshold);
-                any_out = any_out || !(mn > P.threshold);
-            }
-    mc_flag[b] = (any_in && any_out) ? 1u : 0u;
-}
-
-__global__ __launch_bounds__(256) void k_compact_blocks(const uint32_t* __restrict__ flag, const uint32_t* __restrict__ rank, uint32_t nblocks,
-                                                        uint32_t* __restrict__ list, uint32_t* __restrict__ slot) {
-    uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= nblocks) return;
-    if (flag[b]) {
-        uint32_t r = rank[b];
-        list[r] = b;
-        slot[b] = r;
-    } else {
-        slot[b] = 0xFFFFFFFFu;
-    }
-}
-
 template <class R>
 void ss_launch_mark_blocks(const SSDevT<R>& P, const uint32_t* cell_start, uint32_t ncells, uint32_t* block_flag, hipStream_t st) {
     if (!ncells) return;
     hipLaunchKernelGGL(k_mark_blocks<R>, dim3((ncells + 255) / 256), dim3(256), 0, st, P, cell_start, ncells, block_flag);
 }
-template <class R>
-void ss_launch_mark_mc_blocks(const SSDevT<R>& P, const uint32_t* block_slot, const ss_real2<R>* blk_minmax, uint32_t nblocks, uint32_t* mc_flag,
-                              hipStream_t st) {
-    if (!nblocks) return;
-    hipLaunchKernelGGL(k_mark_mc_blocks<R>, dim3((nblocks + 255) / 256), dim3(256), 0, st, P, block_slot, blk_minmax, nblocks, mc_flag);
-}
-void ss_launch_compact_blocks(const uint32_t* flag, const uint32_t* rank, uint32_t nblocks, uint32_t* list, uint32_t* slot, hipStream_t st) {
-    if (!nblocks) return;
-    hipLaunchKernelGGL(k_compact_blocks, dim3((nblocks + 255) / 256), dim3(256), 0, st, flag, rank, nblocks, list, slot);
-}
-
 // =====================================================================================================
 // K3: level-set splat in gather form.
 //
@@ -929,24 +806,6 @@ struct SplatShared {
     uint32_t wave_tot[8];
     uint32_t count;
 };
-
-// (bx, by, bz) of every active block, so that the splat kernels need no integer divisions per wave
-template <class R>
-__global__ __launch_bounds__(256) void k_block_coords(SSDevT<R> P, const uint32_t* __restrict__ active_list, uint32_t n_active, uint32_t* __restrict__ xyz) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_active) return;
-    const uint32_t b = active_list[i];
-    int bx, by, bz;
-    ss_block_of_index(P, b, &bx, &by, &bz);
-    xyz[3 * (size_t)i + 0] = (uint32_t)bx;
-    xyz[3 * (size_t)i + 1] = (uint32_t)by;
-    xyz[3 * (size_t)i + 2] = (uint32_t)bz;
-}
-template <class R>
-void ss_launch_block_coords(const SSDevT<R>& P, const uint32_t* active_list, uint32_t n_active, uint32_t* xyz, hipStream_t st) {
-    if (!n_active) return;
-    hipLaunchKernelGGL(k_block_coords<R>, dim3((n_active + 255) / 256), dim3(256), 0, st, P, active_list, n_active, xyz);
-}
 
 // Conservative block-level filter of the splat: does the particle lie within reach of the box spanned by the block's grid
 // points [plo, phi]?  Same expression as the per-wave test in splat_accumulate_wave on a box that contains every wave's
@@ -2829,7 +2688,7 @@ __global__ __launch_bounds__(128) void k_mc_count(SSDevT<R> P, const R* __restri
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t m = blockIdx.x;
     if (m >= n_mc) return;
-    const int bx = (int)mc_xyz[3 * (size_t)m], by = (int)mc_xyz[3 * (size_t)m + 1], bz = (int)mc_xyz[3 * (size_t)m + 2];  // k_block_coords
+    const int bx = (int)mc_xyz[3 * (size_t)m], by = (int)mc_xyz[3 * (size_t)m + 1], bz = (int)mc_xyz[3 * (size_t)m + 2];  // (block coordinates: SSBlockListOut)
     if (tid >= 96) s_ntri4[tid - 96] = c_mc_packed.ntri4[tid - 96];
     if (tid < SS_MC_REC) s_nb[tid] = mc_nb[SS_MC_REC * (size_t)m + tid];
     __syncthreads();
@@ -2888,7 +2747,7 @@ __global__ __launch_bounds__(256) void k_mc_emit(SSDevT<R> P, const R* __restric
     // everything the first round trip can fetch is requested before the "nothing to emit" test waits for its four words
     const uint32_t vb0 = vbase[m], vb1 = vbase[m + 1], tb0 = tbase[m], tb1 = tbase[m + 1];
     const unsigned long long lut_word = c_mc_packed.row[tid];
-    const int bx = (int)mc_xyz[3 * (size_t)m], by = (int)mc_xyz[3 * (size_t)m + 1], bz = (int)mc_xyz[3 * (size_t)m + 2];  // k_block_coords
+    const int bx = (int)mc_xyz[3 * (size_t)m], by = (int)mc_xyz[3 * (size_t)m + 1], bz = (int)mc_xyz[3 * (size_t)m + 2];  // (block coordinates: SSBlockListOut)
     uint32_t nb_word = 0;
     if (tid < SS_MC_REC) nb_word = mc_nb[SS_MC_REC * (size_t)m + tid];
     if (vb1 == vb0 && tb1 == tb0) return;  // nothing to emit for this block
@@ -3174,7 +3033,7 @@ void ss_launch_cell_table_scan(const uint32_t* first, uint32_t ncells, uint32_t*
     ss_chained_scan<uint32_t, SSOpMax>(SSCellTableIn{first, ncells}, SSCellTableOut{cell_start, ncells}, ncells + 1u, state, (uint32_t*)nullptr, SSMailSlot{}, st);
 }
 
-// membership count per particle (k_classify_count) as the scan's input: copy_offset[i] = copies of the particles before i; the flags of the
+// membership count per particle as the scan's input: copy_offset[i] = copies of the particles before i; the flags of the
 // subdomains with particles are set on the way
 template <class R>
 struct SSClassifyIn {
@@ -3229,7 +3088,7 @@ void ss_launch_owned_scan(uint32_t n_copies, const uint8_t* owned, uint32_t* own
     ss_chained_scan<uint32_t, SSOpPlus>(SSByteFlagIn{owned}, SSRankListOut{nullptr, own_list}, n_copies, state, n_owned_dev, SSMailSlot{}, st);
 }
 
-// active level-set blocks: flags -> list, slot table and block coordinates in one pass (k_compact_blocks + k_block_coords); entries beyond
+// active level-set blocks: flags -> list, slot table and block coordinates in one pass; entries beyond
 // `cap` are not written (the host re-runs with larger buffers when the total exceeds it)
 template <class R>
 struct SSBlockListOut {
@@ -3260,7 +3119,7 @@ void ss_launch_active_blocks_scan(const SSDevT<R>& P, const uint32_t* block_flag
     ss_chained_scan<uint32_t, SSOpPlus>(SSFlagIn{block_flag}, SSBlockListOut<R>{P, cap, list, slot, xyz}, nblocks, state, (uint32_t*)nullptr, mail, st);
 }
 
-// marching-cubes blocks: the flag of k_mark_mc_blocks computed as the scan's input, list / slot table / coordinates as its output
+// marching-cubes blocks: the flag (do the eight level-set blocks b + {0,1}^3 hold values on both sides of the threshold?) computed as the scan's input, list / slot table / coordinates as its output
 template <class R>
 struct SSMcFlagIn {
     SSDevT<R> P;
@@ -3338,8 +3197,6 @@ void ss_launch_tile_offsets_scan(const uint32_t* bound, uint32_t n, unsigned lon
 }
 
 // a count that lives on the device (the length of a list built with atomics), posted for the host
-__global__ void k_publish_u32(const uint32_t* __restrict__ src, SSMailSlot mail) { ss_mail_post(mail, (unsigned long long)src[0]); }
-void ss_launch_publish_u32(const uint32_t* src, SSMailSlot mail, hipStream_t st) { hipLaunchKernelGGL(k_publish_u32, dim3(1), dim3(1), 0, st, src, mail); }
 
 template void ss_launch_sorted_gather_runs<float>(const SSDevT<float>&, uint32_t, const float*, const uint32_t*, ss_pos<float>*, const uint32_t*, uint32_t, uint32_t*, const uint32_t*, uint8_t*, hipStream_t);
 template void ss_launch_sorted_gather_runs<double>(const SSDevT<double>&, uint32_t, const double*, const uint32_t*, ss_pos<double>*, const uint32_t*, uint32_t, uint32_t*, const uint32_t*, uint8_t*, hipStream_t);
@@ -3359,22 +3216,14 @@ template void ss_launch_compact_xyz<float>(const float* d_xyz, uint32_t n, const
 template void ss_launch_compact_xyz<double>(const double* d_xyz, uint32_t n, const uint32_t* f32, const uint32_t* offs, double* out, hipStream_t st);
 template void ss_launch_cell_keys<float>(const SSDevT<float>& P, const float* d_xyz, uint32_t* keys, uint32_t* vals, hipStream_t st);
 template void ss_launch_cell_keys<double>(const SSDevT<double>& P, const double* d_xyz, uint32_t* keys, uint32_t* vals, hipStream_t st);
-template void ss_launch_gather_sorted<float>(uint32_t n, const float* d_xyz, const uint32_t* perm, ss_pos<float>* pos_sorted, hipStream_t st);
-template void ss_launch_gather_sorted<double>(uint32_t n, const double* d_xyz, const uint32_t* perm, ss_pos<double>* pos_sorted, hipStream_t st);
-template void ss_launch_classify_count<float>(const SSDevT<float>& P, const float* xyz, uint32_t* member_count, uint32_t* sub_flag, hipStream_t st);
-template void ss_launch_classify_count<double>(const SSDevT<double>& P, const double* xyz, uint32_t* member_count, uint32_t* sub_flag, hipStream_t st);
 template void ss_launch_emit_copies<float>(const SSDevT<float>& P, const float* xyz, const uint32_t* copy_offset, const uint32_t* occ_rank, uint32_t* keys, uint32_t* vals, hipStream_t st);
 template void ss_launch_emit_copies<double>(const SSDevT<double>& P, const double* xyz, const uint32_t* copy_offset, const uint32_t* occ_rank, uint32_t* keys, uint32_t* vals, hipStream_t st);
 template void ss_launch_density_sub<float>(const SSDevT<float>& P, uint32_t n_copies, const ss_pos<float>* cpos, const uint32_t* cidx, const uint32_t* ckey, const uint32_t* cell_start, const uint32_t* occ_sub, float* rho, int mode, uint32_t* nb_count, const unsigned long long* nb_ptr, uint32_t* nb_idx, bool fast_div, const uint32_t* owned_list, const uint32_t* n_owned_dev, uint32_t n_owned_bound, hipStream_t st);
 template void ss_launch_density_sub<double>(const SSDevT<double>& P, uint32_t n_copies, const ss_pos<double>* cpos, const uint32_t* cidx, const uint32_t* ckey, const uint32_t* cell_start, const uint32_t* occ_sub, double* rho, int mode, uint32_t* nb_count, const unsigned long long* nb_ptr, uint32_t* nb_idx, bool fast_div, const uint32_t* owned_list, const uint32_t* n_owned_dev, uint32_t n_owned_bound, hipStream_t st);
-template void ss_launch_block_coords<float>(const SSDevT<float>& P, const uint32_t* active_list, uint32_t n_active, uint32_t* xyz, hipStream_t st);
-template void ss_launch_block_coords<double>(const SSDevT<double>& P, const uint32_t* active_list, uint32_t n_active, uint32_t* xyz, hipStream_t st);
 template void ss_launch_make_posvol<float>(const SSDevT<float>& P, const ss_pos<float>* pos_sorted, const uint32_t* perm, const float* rho, ss_real4<float>* posvol, ss_real4<float>* posvol_by_index, hipStream_t st);
 template void ss_launch_make_posvol<double>(const SSDevT<double>& P, const ss_pos<double>* pos_sorted, const uint32_t* perm, const double* rho, ss_real4<double>* posvol, ss_real4<double>* posvol_by_index, hipStream_t st);
 template void ss_launch_mark_blocks<float>(const SSDevT<float>& P, const uint32_t* cell_start, uint32_t ncells, uint32_t* block_flag, hipStream_t st);
 template void ss_launch_mark_blocks<double>(const SSDevT<double>& P, const uint32_t* cell_start, uint32_t ncells, uint32_t* block_flag, hipStream_t st);
-template void ss_launch_mark_mc_blocks<float>(const SSDevT<float>& P, const uint32_t* block_slot, const ss_real2<float>* blk_minmax, uint32_t nblocks, uint32_t* mc_flag, hipStream_t st);
-template void ss_launch_mark_mc_blocks<double>(const SSDevT<double>& P, const uint32_t* block_slot, const ss_real2<double>* blk_minmax, uint32_t nblocks, uint32_t* mc_flag, hipStream_t st);
 template void ss_launch_splat_bounds<float>(const SSDevT<float>& P, const uint32_t* cell_start, const uint32_t* active_xyz, uint32_t n_active, const uint32_t* counts, uint32_t* bound, hipStream_t st);
 template void ss_launch_splat_gather<float>(const SSDevT<float>& P, const ss_real4<float>* posvol, const uint32_t* perm, const uint32_t* cell_start, const uint32_t* active_xyz, uint32_t n_active, const unsigned long long* tile_off, ss_real4<float>* arena, uint32_t* arena_idx, uint32_t* counts, uint32_t* large_flag, hipStream_t st);
 template void ss_launch_splat_gather_large<float>(const SSDevT<float>& P, const ss_real4<float>* posvol, const ss_real4<float>* posvol_by_index, const uint32_t* perm, const uint32_t* cell_start, const uint32_t* active_xyz, const uint32_t* large_list, const uint32_t* n_large_dev, const uint32_t* counts, const unsigned long long* tile_off, ss_real4<float>* arena, uint32_t* arena_idx, hipStream_t st);
