@@ -142,7 +142,7 @@ def kernel_source_stamp():
     """Digest of the kernel sources: profiles/splat_traffic.json carries the stamp of the build it was collected from."""
     import hashlib
     h = hashlib.sha256()
-    for f in ("ss_kernels.hip", "ss_device.h", "ss_api.hip"):
+    for f in ("ss_kernels.hip", "ss_device.h", "ss_api.hip", "ss_prims.h", "ss_prims.hip"):
         h.update(open(os.path.join(ROOT, "splashsurf_amd", "csrc", f), "rb").read())
     return h.hexdigest()[:16]
 

@@ -29,11 +29,17 @@ __device__ __forceinline__ void ss_mail_post(const SSMailSlot& m, unsigned long 
 
 // ---- chained scan ----------------------------------------------------------------------------------------------------------------
 // state: 2 + 2 * (number of tiles) 32-bit words, zeroed before the launch (word 0: tile counter; from word 2: one 64-bit status per tile).
-// Tiles of 4096 elements (16 rows of 256) for large inputs, of 1024 (4 rows) for small ones, where the rows' fixed cost is the kernel's time.
+// Tiles of 4096 elements (16 rows of 256 threads), of 1024 (4 rows) for small inputs, where the rows' fixed cost is the kernel's time, and of
+// 8192 (16 rows of 512 threads) for large ones: a scan waits for its chain of tiles (one ticket atomic per tile on one address, the
+// look-back over tiles that start together; profiles/r04_pmc_wait_counters_prims.csv), so fewer tiles are a shorter scan.
 #define SS_SCAN_TILE 4096
 #define SS_SCAN_TILE_SMALL 1024
+#ifndef SS_SCAN_TILE_LARGE
+#define SS_SCAN_TILE_LARGE 8192
+#endif
 #define SS_SCAN_SMALL_N 65536
-inline size_t ss_scan_tile_of(size_t n) { return n <= SS_SCAN_SMALL_N ? SS_SCAN_TILE_SMALL : SS_SCAN_TILE; }
+#define SS_SCAN_LARGE_N (1u << 20)
+inline size_t ss_scan_tile_of(size_t n) { return n <= SS_SCAN_SMALL_N ? SS_SCAN_TILE_SMALL : (n >= SS_SCAN_LARGE_N ? SS_SCAN_TILE_LARGE : SS_SCAN_TILE); }
 inline size_t ss_scan_state_words(size_t n) { return 2 + 2 * ((n + ss_scan_tile_of(n) - 1) / ss_scan_tile_of(n)) + 2; }
 
 __device__ __forceinline__ uint32_t ss_prim_wave_incl_u32(uint32_t v) {
@@ -90,11 +96,11 @@ __device__ __forceinline__ T ss_prim_wave_reduce(T v) {
 // against other memory: relaxed agent-scope atomics (an acquire / release at agent scope writes back and invalidates the L2 of
 // the XCD on every access -- measured 346 us instead of ~40 for 10 M elements).  In / Out are callable from the device; T is
 // uint32_t or unsigned long long (values below 2^62); Op: SSOpPlus or SSOpMax.
-template <class T, class Op, int TILE, class In, class Out>
-__global__ __launch_bounds__(256) void k_chained_scan(In in, Out out, uint32_t n, uint32_t* __restrict__ state, T* __restrict__ total_dev, SSMailSlot mail) {
-    constexpr int ROWS = TILE / 256;
-    static_assert(ROWS * 4 <= 64, "the pieces of a tile are summed by one wave");
-    __shared__ T s_w[ROWS][4];
+template <class T, class Op, int TILE, int NT, class In, class Out>
+__global__ __launch_bounds__(NT) void k_chained_scan(In in, Out out, uint32_t n, uint32_t* __restrict__ state, T* __restrict__ total_dev, SSMailSlot mail) {
+    constexpr int ROWS = TILE / NT, NW = NT / 64;
+    static_assert(ROWS * NW <= 128 && TILE % NT == 0 && NT % 64 == 0, "the pieces of a tile are summed by one wave, at most two per lane");
+    __shared__ T s_w[ROWS * NW + 64];  // piece (r, w) at r * NW + w (+ 64: the second piece of a lane past the end reads the identity)
     __shared__ T s_excl;
     __shared__ uint32_t s_tile;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -107,15 +113,17 @@ __global__ __launch_bounds__(256) void k_chained_scan(In in, Out out, uint32_t n
     T x[ROWS];
 #pragma unroll
     for (int r = 0; r < ROWS; ++r) {
-        const uint32_t i = base + (uint32_t)(r * 256 + tid);
+        const uint32_t i = base + (uint32_t)(r * NT + tid);
         x[r] = (i < n) ? in(i) : Op::template identity<T>();
         const T piece = ss_prim_wave_reduce<T, Op>(x[r]);
-        if (lane == 0) s_w[r][wave] = piece;
+        if (lane == 0) s_w[r * NW + wave] = piece;
     }
     __syncthreads();
     T tile_total = Op::template identity<T>();
-    if (wave == 0) {  // ROWS * 4 pieces, one per lane
-        tile_total = ss_prim_wave_reduce<T, Op>(lane < ROWS * 4 ? s_w[lane >> 2][lane & 3] : Op::template identity<T>());
+    if (wave == 0) {  // ROWS * NW pieces, at most two per lane
+        T mine = lane < ROWS * NW ? s_w[lane] : Op::template identity<T>();
+        if constexpr (ROWS * NW > 64) mine = Op::template apply<T>(mine, lane + 64 < ROWS * NW ? s_w[lane + 64] : Op::template identity<T>());
+        tile_total = ss_prim_wave_reduce<T, Op>(mine);
     }
     if (wave == 0) {
         // publish the tile's sum, then look back: lane l reads the status of tile (p - l); flags 0 not there yet, 1 sum of that tile, 2 prefix up to and
@@ -163,11 +171,11 @@ __global__ __launch_bounds__(256) void k_chained_scan(In in, Out out, uint32_t n
     T before_row = s_excl;
 #pragma unroll
     for (int r = 0; r < ROWS; ++r) {
-        const uint32_t i = base + (uint32_t)(r * 256 + tid);
+        const uint32_t i = base + (uint32_t)(r * NT + tid);
         T before_wave = before_row;
 #pragma unroll
-        for (int w = 0; w < 4; ++w) {
-            const T piece = s_w[r][w];
+        for (int w = 0; w < NW; ++w) {
+            const T piece = s_w[r * NW + w];
             if (w < wave) before_wave = Op::template apply<T>(before_wave, piece);
             before_row = Op::template apply<T>(before_row, piece);
         }
@@ -183,10 +191,12 @@ template <class T, class Op = SSOpPlus, class In, class Out>
 void ss_chained_scan(In in, Out out, uint32_t n, uint32_t* state, T* total_dev, SSMailSlot mail, hipStream_t st) {
     const uint32_t tile = (uint32_t)ss_scan_tile_of(n);
     const uint32_t tiles = n == 0 ? 1u : (n + tile - 1) / tile;
-    if (tile == SS_SCAN_TILE)
-        hipLaunchKernelGGL((k_chained_scan<T, Op, SS_SCAN_TILE, In, Out>), dim3(tiles), dim3(256), 0, st, in, out, n, state, total_dev, mail);
+    if (tile == SS_SCAN_TILE_LARGE)
+        hipLaunchKernelGGL((k_chained_scan<T, Op, SS_SCAN_TILE_LARGE, 512, In, Out>), dim3(tiles), dim3(512), 0, st, in, out, n, state, total_dev, mail);
+    else if (tile == SS_SCAN_TILE)
+        hipLaunchKernelGGL((k_chained_scan<T, Op, SS_SCAN_TILE, 256, In, Out>), dim3(tiles), dim3(256), 0, st, in, out, n, state, total_dev, mail);
     else
-        hipLaunchKernelGGL((k_chained_scan<T, Op, SS_SCAN_TILE_SMALL, In, Out>), dim3(tiles), dim3(256), 0, st, in, out, n, state, total_dev, mail);
+        hipLaunchKernelGGL((k_chained_scan<T, Op, SS_SCAN_TILE_SMALL, 256, In, Out>), dim3(tiles), dim3(256), 0, st, in, out, n, state, total_dev, mail);
 }
 
 // ---- radix sort ------------------------------------------------------------------------------------------------------------------

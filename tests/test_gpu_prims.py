@@ -18,7 +18,7 @@ def _lib():
     return L
 
 
-@pytest.mark.parametrize("n", [0, 1, 63, 64, 2047, 2048, 2049, 4095, 4096, 4097, 8192, 100_000, 1_000_003, 20_000_001])
+@pytest.mark.parametrize("n", [0, 1, 63, 64, 2047, 2048, 2049, 4095, 4096, 4097, 8192, 100_000, 1_000_003, 1_048_575, 1_048_576, 1_056_767, 1_056_769, 20_000_001])
 def test_chained_scan_equals_cumsum(n):
     import torch
     L = _lib()

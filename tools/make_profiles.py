@@ -75,7 +75,7 @@ def main():
     open(os.path.join(DST, TAG + "_pmc_s10m_tank.md"), "w").write("\n".join(md) + "\n")
     stamp_file = os.path.join(SRC, "kernel_source_stamp.txt")  # written by tools/collect_profiles.sh from the sources that were profiled
     traffic["_collected_from"] = {"kernel_source_stamp": open(stamp_file).read().strip() if os.path.exists(stamp_file) else None, "round": TAG,
-                                  "note": "bench.py attaches these numbers only to a build with the same stamp (sha256 of ss_kernels.hip, ss_device.h, ss_api.hip)"}
+                                  "note": "bench.py attaches these numbers only to a build with the same stamp (sha256 of ss_kernels.hip, ss_device.h, ss_api.hip, ss_prims.h, ss_prims.hip)"}
     json.dump(traffic, open(os.path.join(DST, "splat_traffic.json"), "w"), indent=1)
     print("\n".join(md[-40:]))
 
