@@ -10,8 +10,9 @@ plus the splat kernel's achieved algorithmic HBM GB/s against the 8 TB/s peak ("
 the host cores ("cpu_baseline", a reported baseline only).
 
 N = 1 (default): BASELINE config 3, S10M-tank.  The JSON line also carries the host-to-host variants of the same call
-(`e2e_host_u64` = SURVEY 8d(i): pageable host input, vertices + u64 triangles back in host memory), both arithmetic modes
-(`enable_simd`), the other BASELINE configs (`other_configs`) and an HBM-bound splat configuration (`splat_hbm_bound`).
+(`e2e_host_u64` = SURVEY 8d(i): pageable host input, vertices + u64 triangles back in host memory), the three arithmetic modes
+(`arithmetic_modes`; the measured steps run `enable_simd = 0`, the mode whose mesh equals the reference wheel's own at this size:
+`config.reference_digest`), the other BASELINE configs (`other_configs`) and an HBM-bound splat configuration (`splat_hbm_bound`).
 
 N > 1: one process per GPU (torch.distributed, backend nccl = RCCL).  When launched WITHOUT a torch.distributed
 environment (`python bench.py --gpus N`), this script spawns its N ranks itself (torch.distributed.run, 127.0.0.1) and
@@ -42,8 +43,10 @@ def parse():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default=None, help="default: s10m_tank at 1 GPU, s40m_tank (fixed size, sharded) at N > 1")
     ap.add_argument("--scaling", choices=["strong", "weak"], default="strong", help="N > 1 only: fixed total size (default) or one tank per rank")
-    ap.add_argument("--simd", type=int, choices=[0, 1, 2], default=None,
-                    help="Parameters::enable_simd for the headline value (default: the library default, see DESIGN.md section 5)")
+    ap.add_argument("--simd", type=int, choices=[0, 1, 2], default=0,
+                    help="Parameters::enable_simd of the measured steps.  Default 0: the reference's scalar loop, the arithmetic whose S10M-tank mesh is pinned to the "
+                         "reference wheel's own output bit for bit in structure (tests/golden/config3_s10m_tank.npz); 1 = the library default (the reference's AVX "
+                         "arithmetic applied uniformly: 1.7 %% faster, one grid point of 2.3 G differs from the wheel's simd=True mesh at this size), 2 = 1 with v_sqrt_f32")
     ap.add_argument("--main-only", action="store_true",
                     help="only the timed steps of the named workload (no host-input variants, no other configs, no CPU baseline): "
                          "the command to profile, so that rocprofv3's per-kernel averages are those of this workload")
@@ -54,6 +57,12 @@ def parse():
                          "threads on ONE GPU over the library's in-process transport, the ranks taking turns on the device so that per-rank timers "
                          "read what a rank takes on a GPU of its own.  Reports the per-rank critical path and a projected N-GPU step, NOT a measured "
                          "multi-GPU throughput (`value` is what this one GPU did).")
+    ap.add_argument("--collective-latency-us", type=float, default=25.0,
+                    help="--pseudo-ranks: what one communication step between the ranks (a small all-gather, the histogram all-reduce, one grouped send/recv) is assumed "
+                         "to cost on a real node in addition to its bytes; multiplied by the number of such steps the library counted (ss_dist_info.n_collectives)")
+    ap.add_argument("--no-balance-feedback", action="store_true",
+                    help="--pseudo-ranks / native N > 1: bricks balanced by particle count in every step (default: from the second step on by the cost measured in the previous one, "
+                         "ss_comm_set_balance_feedback)")
     ap.add_argument("--exchange", choices=["auto", "native", "torch"], default="auto",
                     help="N > 1 transport of the halo exchange: the library's own RCCL path (ss_dist_*) or torch.distributed")
     ap.add_argument("--cpu-sample-scale", type=float, default=1.0, help="tank scale of the CPU-baseline sample (1.0 = the full 10 M workload)")
@@ -198,6 +207,32 @@ def splat_roofline(st, n_occ, n_subp, nsc, k3_acc_ms, k3_large_ms):
     }
 
 
+def reference_digest(out, workload, simd):
+    """Which digest of the REFERENCE WHEEL's own mesh (tests/golden/*.npz, tools/gen_goldens_fullsize.py) the measured steps' mesh matches: the canonical
+    (order-independent) vertex-id multiset and triangle set of the last step, hashed and compared outside the timed region."""
+    import hashlib
+    name = {("s10m_tank", 0): "config3_s10m_tank", ("s10m_tank", 1): "simd_config3_s10m_tank", ("s1m", 0): "config2_s1m", ("s1m", 1): "simd_config2_s1m"}.get((workload, int(simd)))
+    path = os.path.join(ROOT, "tests", "golden", (name or "") + ".npz")
+    if not name or not os.path.exists(path):
+        return {"golden": None, "note": "no reference-wheel digest for this workload / mode"}
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import mesh_compare as MC
+    g = np.load(path, allow_pickle=False)
+    sha = lambda a: hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()  # noqa: E731
+    ids, _vs, tc = MC.canonicalize_geometric(out.mesh.vertices, out.mesh.triangles_u32, g["grid_min"], g["cell_size"], g["n_points"])
+    rec = {"golden": "tests/golden/%s.npz" % name, "reference": "pysplashsurf 0.14.0.0 wheel, simd=%s, subdomain grid" % bool(simd),
+           "densities_bit_identical": sha(out.particle_densities) == str(g["density_sha256"]),
+           "vertex_ids_match": sha(ids.astype(np.int64)) == str(g["ids_sha256"]), "triangles_match": sha(tc.astype(np.int64)) == str(g["triangles_sha256"]),
+           "n_vertices": [int(ids.size), int(g["n_vertices"])], "n_triangles": [int(tc.shape[0]), int(g["n_triangles"])]}
+    if "lib_ids_sha256" in g.files and not (rec["vertex_ids_match"] and rec["triangles_match"]):
+        # the stored, counted difference of this arithmetic from the wheel's mesh (tests/test_gpu_fullsize.py asserts it exactly)
+        rec["matches_stored_difference"] = sha(ids.astype(np.int64)) == str(g["lib_ids_sha256"]) and sha(tc.astype(np.int64)) == str(g["lib_triangles_sha256"])
+        rec["stored_difference"] = {"ids_only_here": int(g["lib_ids_only_in_library"].size), "ids_only_in_reference": int(g["lib_ids_only_in_reference"].size),
+                                    "triangles_only_here": int(g["lib_triangles_only_in_library"].reshape(-1, 3).shape[0]),
+                                    "triangles_only_in_reference": int(g["lib_triangles_only_in_reference"].reshape(-1, 3).shape[0])}
+    return rec
+
+
 def timed_direct(ctx, prm, d_pts, steps, warmup, sync):
     """`steps` reconstructions of HBM-resident particles; returns (seconds per step, last result, mean (accumulate, large) kernel ms)."""
     out = None
@@ -289,13 +324,15 @@ def pseudo_rank_run(args):
     def worker(q):
         try:
             pts, n_total, desc = local_share(args, wl, workload, W, q, world, r, full)
+            if not args.no_balance_feedback:
+                comms[q].set_balance_feedback(True)
             native = D.NativeSharded(comms[q], prm)
             d_local = torch.from_numpy(pts).to(dev)
             torch.cuda.synchronize()
-            for _ in range(max(args.warmup, 1)):
+            for _ in range(max(args.warmup, 1 if args.no_balance_feedback else 4)):  # (the feedback needs a few frames to settle)
                 native.step(d_local)
                 native.assemble()
-            timings, own, k3_ms, xbytes, last = {}, [], [], 0, None
+            timings, own, k3_ms, xbytes, last, n_coll = {}, [], [], 0, None, 0
             bar.wait()
             t0 = time.perf_counter()
             for _ in range(args.steps):
@@ -304,6 +341,7 @@ def pseudo_rank_run(args):
                 for k_ in ("ms_partition", "ms_position_exchange", "ms_phase1", "ms_density_exchange", "ms_phase2", "ms_assembly"):
                     timings[k_] = timings.get(k_, 0.0) + info[k_]
                 own.append(info["ms_own_turns"])
+                n_coll = int(info["n_collectives"])
                 xbytes += info["bytes_sent_positions"] + info["bytes_sent_densities"] + info["bytes_sent_assembly"]
                 s_ = last.stats
                 t_acc = s_.get("ms_levelset_accumulate", 0.0)
@@ -315,6 +353,7 @@ def pseudo_rank_run(args):
             k3_acc, k3_large = (float(v) for v in np.mean(np.asarray(k3_ms), axis=0))
             roof = splat_roofline(stats, n_occ, n_subp, nsc, k3_acc, k3_large)
             out[q] = dict(row=rank_row(roof, stats, xbytes, args.steps), roof=roof, stats=stats, timings=timings, own_ms=float(np.mean(own)),
+                          own_ms_all=[float(x) for x in own], n_collectives=n_coll,
                           bal=native.partition(), n_total=n_total, desc=desc, xbytes=xbytes / max(args.steps, 1))
             native.result._free()
         except Exception as e:  # a failing rank must not leave the others waiting silently
@@ -351,15 +390,24 @@ def pseudo_rank_run(args):
         del d_full, o1
     for cx in ctxs:
         cx.close()
+    # the step's critical path: in every step the slowest rank (the bricks move between steps when the partition feedback is on)
+    own_steps = np.asarray([o["own_ms_all"] for o in out], dtype=np.float64)  # [rank, step]
+    crit_ms = float(own_steps.max(axis=0).mean())
     slowest = max(range(world), key=lambda q: out[q]["own_ms"])
     link_gbs = 153.0  # one xGMI link, MI355X_MICROARCH.md; a brick's halo traffic goes to a handful of neighbours
     xfer_ms = max(o["xbytes"] for o in out) / (link_gbs * 1e9) * 1e3
+    n_coll = max(o["n_collectives"] for o in out)
+    lat_ms = n_coll * args.collective_latency_us * 1e-3
     proj = {"ranks": world, "slowest_rank": slowest, "own_ms_slowest_rank": round(out[slowest]["own_ms"], 3),
-            "own_ms_mean": round(float(np.mean([o["own_ms"] for o in out])), 3),
+            "own_ms_mean": round(float(np.mean([o["own_ms"] for o in out])), 3), "own_ms_slowest_per_step_mean": round(crit_ms, 3),
             "exchange_transfer_ms_at_one_xgmi_link": round(xfer_ms, 3),
-            "projected_step_ms": round(out[slowest]["own_ms"] + xfer_ms, 3),
+            "collective_steps": n_coll, "collective_latency_us_assumed": args.collective_latency_us, "collective_latency_ms": round(lat_ms, 3),
+            "projected_step_ms": round(crit_ms + xfer_ms + lat_ms, 3),
+            "balance_feedback": not args.no_balance_feedback,
             "note": "own_ms = time a rank held the device per step (all of its kernels, packing and host work; the ranks took turns); projected N-GPU step = "
-                    "slowest rank + its exchange bytes over ONE 153 GB/s xGMI link, collective latencies (7 small host-synchronised steps) not included"}
+                    "mean over the steps of the slowest rank's own time + the largest rank's exchange bytes over ONE 153 GB/s xGMI link + the number of communication "
+                    "steps the library counted x an ASSUMED %.0f us each (no multi-GPU node was available: RCCL latencies are not measured); nothing of an exchange "
+                    "is overlapped with compute in this estimate" % args.collective_latency_us}
     if single:
         proj["single_gpu_step_ms"] = single["ms_per_step"]
         proj["projected_speedup"] = round(single["ms_per_step"] / proj["projected_step_ms"], 2)
@@ -446,6 +494,11 @@ def main():
         scaling = "n/a (one GPU)"
         parallelism = "1 GPU"
         extra = {}
+        if not args.main_only:
+            try:
+                extra["reference_digest"] = reference_digest(out, workload, prm.enable_simd)
+            except Exception as e:  # informative; never lose the measurement
+                extra["reference_digest"] = {"golden": None, "note": "failed: %r" % (e,)}
     else:
         from splashsurf_amd import distributed as D
         pts, n_total, workload_desc = local_share(args, wl, workload, W, rank, world, r)
@@ -455,6 +508,8 @@ def main():
         if args.exchange in ("auto", "native"):
             try:
                 comm = D.NativeComm.rccl(ctx, rank=rank, world=world) if dist.is_initialized() or world == 1 else None
+                if comm is not None and not args.no_balance_feedback:
+                    comm.set_balance_feedback(True)
                 native = D.NativeSharded(comm, prm)
                 native.step(torch.from_numpy(pts).to(dev))  # first call doubles as the self-test of the RCCL plumbing
                 native.assemble()
@@ -588,6 +643,8 @@ def main():
                          "tile_arena_bytes_reserved": int(last_stats.get("bytes_tile_arena_reserved", 0)), "device_bytes_held": int(last_stats.get("bytes_device_peak", 0))},
     })
     line.update(extra)
+    if "reference_digest" in line:
+        line["config"]["reference_digest"] = line.pop("reference_digest")
 
     if not sharded_path and not args.main_only:
         single_gpu_extras(line, args, ctx, prm, wl, workload, pts, d_pts, out, dev, local_rank, sync)

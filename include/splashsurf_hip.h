@@ -190,8 +190,11 @@ int ss_last_error_detail(const ss_context *ctx);
  * context certified (a workload is re-probed every 16th call).
  * SS_OPTION_WIDEN_ON_DEVICE (default 0): ss_result_triangles hands out [usize; 3] = u64 indices; for meshes of a million indices and more
  * they cross PCIe as u32 in chunks and host threads widen them into the pinned buffer while the next chunk is in flight; 1 = widen on
- * the device and copy 8 bytes per index (what small meshes always do). */
-enum { SS_OPTION_FULL_LEVELSET = 1, SS_OPTION_SPLAT_TWO_PASS = 2, SS_OPTION_WIDEN_ON_DEVICE = 3 };
+ * the device and copy 8 bytes per index (what small meshes always do).
+ * SS_OPTION_SPLIT_MC_OFFSETS (default 0): the vertex and triangle offsets of the marching-cubes blocks come out of ONE prefix sum over
+ * packed 31 + 31 bit counts while the worst case of the totals fits, and out of two 64-bit prefix sums for larger jobs (more than
+ * 838 860 surface blocks); 1 = always the two-sum form (tests).  Output is identical. */
+enum { SS_OPTION_FULL_LEVELSET = 1, SS_OPTION_SPLAT_TWO_PASS = 2, SS_OPTION_WIDEN_ON_DEVICE = 3, SS_OPTION_SPLIT_MC_OFFSETS = 4 };
 ss_status ss_context_set_option(ss_context *ctx, int option, int value);
 /* use an existing HIP stream (hipStream_t passed as void*); NULL = context's own stream */
 ss_status ss_context_set_stream(ss_context *ctx, void *hip_stream);
@@ -329,6 +332,11 @@ ss_status ss_comm_create_local_group(ss_context *const *ctxs, int world, ss_comm
  * timers (ss_result_stats, ss_dist_info) read what the rank takes on a GPU of its own instead of the time it spent queueing behind the
  * other ranks' kernels.  Results are unaffected. */
 ss_status ss_comm_local_group_take_turns(ss_comm *comm, int on);
+/* Partition feedback for time series (default off): with on = 1 every ss_dist_reconstruct after the first weighs the owner histogram of a subdomain with the
+ * cost per owned particle (ms_device / n_owned) measured in the previous call by the rank that owned it, so that the bricks balance measured cost instead of
+ * particle counts (surface-heavy bricks cost more per particle).  Collective: every rank of the communicator sets the same value.  The mesh does not depend
+ * on the partition. */
+ss_status ss_comm_set_balance_feedback(ss_comm *comm, int on);
 void ss_comm_destroy(ss_comm *comm);
 
 typedef struct ss_dist_info {
@@ -343,6 +351,9 @@ typedef struct ss_dist_info {
     double ms_own_turns;                 /* ss_comm_local_group_take_turns only: time this rank held the device (all of its own work of the step, exchanges excluded) */
     uint64_t n_vertices_owned, vertex_offset, n_vertices_total;  /* after ss_dist_assemble */
     uint64_t n_triangles, triangle_offset, n_triangles_total;
+    uint64_t n_collectives;              /* communication steps of the last ss_dist_reconstruct + ss_dist_assemble in which this rank met its peers (all-gathers, the all-reduce,
+                                            grouped send/recv): each costs a collective's latency on a real multi-GPU node, which the one-GPU projection of bench.py prices */
+    double ms_device;                    /* HIP-event time of this rank's two reconstruction phases (ss_result_stats ms_total): the cost the partition feedback balances */
 } ss_dist_info;
 
 /* xyz_local: this rank's n_local x 3 particles (host or HBM).  On return `inout` holds the brick's reconstruction: its mesh with

@@ -161,21 +161,23 @@ def _aabb(lo, hi, what):
     return list(lo), list(hi)
 
 
-MESH_CLEANUP_WARNING = ("WARNING: mesh cleanup (marching_cubes_cleanup, the binary's default once --mesh-smoothing-iters is given) is NOT provided by "
-                        "this build and is SKIPPED: the smoothed mesh keeps the sliver triangles the reference would have collapsed first. "
-                        "Pass --mesh-cleanup=off to acknowledge, or run the reference's cleanup on the raw mesh (--output-raw-mesh=on).")
+MESH_CLEANUP_REFUSAL = ("--mesh-smoothing-iters switches the reference binary's mesh cleanup ON by default (marching_cubes_cleanup, reconstruct.rs:201-214), "
+                        "and this build does not provide that stage: the command would produce a different mesh than the reference with a success exit "
+                        "code.  Pass --mesh-cleanup=off to run the smoothing on the raw marching-cubes mesh (the reference does the same with that flag), "
+                        "or run the reference's cleanup on the raw mesh (--output-raw-mesh=on)")
 
 
 def pipeline_kwargs(args, warn=None):
     """reconstruct.rs:604-698 (ReconstructionRunnerArgs::try_from) in terms of `reconstruction_pipeline`'s keywords.
-    `warn`: callable for loud warnings about differences from the binary (default: stderr)."""
+    `warn`: kept for callers of earlier versions (nothing is downgraded to a warning any more)."""
     unsupported = []
     if args.mesh_cleanup:  # explicitly requested: refused
         unsupported.append("--mesh-cleanup=on (not provided by this build; see INTEGRATION.md, \"Differences\")")
     elif args.mesh_cleanup is None and args.mesh_smoothing_iters not in (None, 0):
         # reconstruct.rs:201-214: the binary's default is "off" for 0 iterations and "on" as soon as smoothing is requested.  The reference
-        # README's recipe (--mesh-smoothing-iters=25 ...) relies on that default: it runs here WITHOUT the cleanup, with a loud warning.
-        (warn or (lambda m: print(m, file=sys.stderr)))(MESH_CLEANUP_WARNING)
+        # README's recipe (--mesh-smoothing-iters=25 ...) relies on that default: REFUSED here (exit status 1, nothing written) unless the
+        # caller opts out of the cleanup explicitly -- a silent skip would be a non-parity mesh behind a success status.
+        raise CliError(MESH_CLEANUP_REFUSAL)
     if args.decimate_barnacles:
         unsupported.append("--decimate-barnacles")
     if args.generate_quads:

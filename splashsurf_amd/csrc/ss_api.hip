@@ -135,7 +135,7 @@ struct ArrayExclOut {
 };
 template <class T>
 ss_status exclusive_scan_u32(ss_context* ctx, const T* in, T* out, size_t n) {
-    if (n >= (1ull << 32) - 1) return fail(ctx, SS_ERR_UNSUPPORTED, "more than 2^32 - 2 entries in one prefix sum");
+    if (n > SS_SCAN_MAX_N) return fail(ctx, SS_ERR_UNSUPPORTED, "more than 2^32 - 8193 entries in one prefix sum");
     const size_t words = ss_scan_state_words(n);
     SS_HIP(ctx, ctx->temp.reserve(words * 4));
     SS_HIP(ctx, hipMemsetAsync(ctx->temp.p, 0, words * 4, ctx->stream));
@@ -144,11 +144,12 @@ ss_status exclusive_scan_u32(ss_context* ctx, const T* in, T* out, size_t n) {
 }
 
 // ---- counts the host waits for (SSMailSlot, ss_prims.h) ----
+#define SS_MAIL_SLOTS 32  // 0-10 counts of the phases, 11 + 12..15 the particle AABB, 16 the triangle total of the split offsets scan
 ss_status ensure_mail(ss_context* ctx) {
     if (ctx->mail_host) return SS_OK;
     void* h = nullptr;
-    SS_HIP(ctx, hipHostMalloc(&h, 16 * 2 * sizeof(unsigned long long), hipHostMallocMapped));
-    memset(h, 0, 16 * 2 * sizeof(unsigned long long));
+    SS_HIP(ctx, hipHostMalloc(&h, SS_MAIL_SLOTS * 2 * sizeof(unsigned long long), hipHostMallocMapped));
+    memset(h, 0, SS_MAIL_SLOTS * 2 * sizeof(unsigned long long));
     void* d = nullptr;
     SS_HIP(ctx, hipHostGetDevicePointer(&d, h, 0));
     ctx->mail_host = reinterpret_cast<unsigned long long*>(h);
@@ -834,7 +835,7 @@ ss_status phase_begin(ss_context* ctx, const R* xyz, uint64_t n_in, const typena
     SS_HIP(ctx, ctx->vals_a.reserve((size_t)n * 4 + 16));
     SS_HIP(ctx, ctx->pos_sorted.reserve((size_t)n * sizeof(ss_pos<R>) + 16));
     const size_t nsub = (size_t)P.ns[0] * P.ns[1] * P.ns[2];
-    if (nsub >= (1ull << 32) - 2) return fail(ctx, SS_ERR_UNSUPPORTED, "more than 2^32 subdomains");
+    if (nsub >= SS_SCAN_MAX_N) return fail(ctx, SS_ERR_UNSUPPORTED, "more than 2^32 - 8193 subdomains");
     SS_HIP(ctx, ctx->copy_offset.reserve(((size_t)n + 1) * 4));
     SS_HIP(ctx, ctx->sub_rank.reserve((nsub + 1) * 4));
     SS_HIP(ctx, ctx->occ_sub.reserve((nsub + 1) * 4 + 16));  // (at most every subdomain is occupied)
@@ -1034,7 +1035,7 @@ ss_status phase_finish(ss_context* ctx, ss_result* res) {
     SS_HIP(ctx, hipEventRecord(ctx->ev[11], st));
 
     // ---- K3 prepare: active level-set blocks ----
-    if (nblocks >= (1ull << 32) - 2) return fail(ctx, SS_ERR_UNSUPPORTED, "more than 2^32 level-set blocks");
+    if (nblocks >= SS_SCAN_MAX_N) return fail(ctx, SS_ERR_UNSUPPORTED, "more than 2^32 - 8193 level-set blocks");
     SS_HIP(ctx, res->block_slot.reserve(nblocks * 4 + 16));
     SS_HIP(ctx, res->mc_slot.reserve(nblocks * 4 + 16));
     ZeroTaker ZB;  // the block flags and the state of the scan over them (two states: the scan may be repeated), one memset
@@ -1049,8 +1050,10 @@ ss_status phase_finish(ss_context* ctx, ss_result* res) {
         if (ctx->cap_active == 0) ctx->cap_active = (uint32_t)std::min<size_t>(nblocks, (size_t)1 << 16);
         SS_HIP(ctx, res->active_xyz.reserve((size_t)ctx->cap_active * 12 + 16));
         const SSMailSlot m_active = mail_slot(ctx, 2);
+        uint32_t* st_active = ZB.take(ss_scan_state_words(nblocks));
+        if (!block_flag || !st_active) return fail(ctx, SS_ERR_UNKNOWN, "internal error: zero region too small");
         ss_launch_active_blocks_scan(P, block_flag, (uint32_t)nblocks, ctx->cap_active, (uint32_t*)nullptr, res->block_slot.as<uint32_t>(),
-                                     res->active_xyz.as<uint32_t>(), ZB.take(ss_scan_state_words(nblocks)), m_active, st);
+                                     res->active_xyz.as<uint32_t>(), st_active, m_active, st);
         unsigned long long v = 0;
         s = mail_wait(ctx, m_active, &v);
         if (s != SS_OK) return s;
@@ -1058,6 +1061,7 @@ ss_status phase_finish(ss_context* ctx, ss_result* res) {
         if (n_active <= ctx->cap_active) break;
         ctx->cap_active = (uint32_t)std::min<size_t>(nblocks, (size_t)n_active + n_active / 4 + 1024);
     }
+    if (n_active > ctx->cap_active) return fail(ctx, SS_ERR_UNKNOWN, "internal error: the list of active blocks overflowed twice");
     res->n_active = n_active;
     SS_HIP(ctx, res->G.reserve((size_t)n_active * SS_BLOCK_POINTS * sizeof(R) + 16));
     SS_HIP(ctx, res->blk_minmax.reserve((size_t)n_active * 2 * sizeof(R) + 16));
@@ -1117,7 +1121,8 @@ ss_status phase_finish(ss_context* ctx, ss_result* res) {
     // zeroed words of the rest of this phase: the statistics counters, the states of the remaining scans, the length of the redo list
     const size_t mc_cap_bound = std::min<size_t>(nblocks, (size_t)8 * (size_t)n_active);
     ZeroTaker Z;
-    s = reserve_zeros(ctx, 16 + 3 * 64 * 2 + 6 * ss_scan_state_words((size_t)n_active + 1) + 2 * ss_scan_state_words(nblocks) + 2 * ss_scan_state_words(mc_cap_bound + 1) + 2 * ((size_t)n_active + 8) + 64, &Z);
+    // (the state of a scan whose length is not known yet is reserved with the monotone bound: ss_scan_state_words itself is not monotone)
+    s = reserve_zeros(ctx, 16 + 3 * 64 * 2 + 6 * ss_scan_state_words((size_t)n_active + 1) + 2 * ss_scan_state_words(nblocks) + 2 * ss_scan_state_words_bound(mc_cap_bound + 1) + 2 * ((size_t)n_active + 8) + 64, &Z);
     if (s != SS_OK) return s;
     uint32_t* big_flag = Z.take((size_t)n_active + 2);   // flags of the blocks with more candidates than a wave holds (set by k_splat_fused, compacted into big[])
     uint32_t* need_mask = Z.take((size_t)n_active + 2);  // over-dense blocks: the sub-blocks k_splat_certify_big left to evaluate (0 for every other block)
@@ -1131,6 +1136,7 @@ ss_status phase_finish(ss_context* ctx, ss_result* res) {
     uint32_t* st_redo = Z.take(ss_scan_state_words((size_t)n_active + 1));
     uint32_t* n_redo_dev = Z.take(4);
     uint32_t* n_large_dev = Z.take(4);
+    if (!n_large_dev) return fail(ctx, SS_ERR_UNKNOWN, "internal error: zero region too small");
     uint32_t n_big = 0;
     SS_HIP(ctx, hipEventRecord(ctx->ev[5], st));  // (= event 12 of the timers below: one record per point of the stream)
     if (n_active) {
@@ -1206,8 +1212,10 @@ ss_status phase_finish(ss_context* ctx, ss_result* res) {
         if ((size_t)ctx->cap_mc > mc_cap_bound) ctx->cap_mc = (uint32_t)mc_cap_bound;
         SS_HIP(ctx, res->mc_xyz.reserve((size_t)ctx->cap_mc * 12 + 16));
         const SSMailSlot m_mc = mail_slot(ctx, 5);
+        uint32_t* st_mc = Z.take(ss_scan_state_words(nblocks));
+        if (!st_mc) return fail(ctx, SS_ERR_UNKNOWN, "internal error: zero region too small");
         ss_launch_mc_blocks_scan(P, res->block_slot.as<uint32_t>(), res->blk_minmax.as<ss_real2<R>>(), (uint32_t)nblocks, ctx->cap_mc, (uint32_t*)nullptr, res->mc_slot.as<uint32_t>(),
-                                 res->mc_xyz.as<uint32_t>(), Z.take(ss_scan_state_words(nblocks)), m_mc, st);
+                                 res->mc_xyz.as<uint32_t>(), st_mc, m_mc, st);
         unsigned long long v = 0;
         s = mail_wait(ctx, m_mc, &v);
         if (s != SS_OK) return s;
@@ -1215,6 +1223,7 @@ ss_status phase_finish(ss_context* ctx, ss_result* res) {
         if (n_mc <= ctx->cap_mc) break;
         ctx->cap_mc = (uint32_t)std::min<size_t>(mc_cap_bound, (size_t)n_mc + n_mc / 4 + 1024);
     }
+    if (n_mc > ctx->cap_mc) return fail(ctx, SS_ERR_UNKNOWN, "internal error: the list of marching-cubes blocks overflowed twice");
     res->n_mc = n_mc;
 
     // ---- K4: MC classification + counts ----
@@ -1231,7 +1240,13 @@ ss_status phase_finish(ss_context* ctx, ss_result* res) {
     SS_HIP(ctx, hipEventRecord(ctx->ev[21], st));  // (= event 7)
     // ---- "stitching": global numbering by prefix sums (vertex and triangle counts in one scan) ----
     const SSMailSlot m_tot = mail_slot(ctx, 6), m_stat0 = mail_slot(ctx, 7), m_stat1 = mail_slot(ctx, 8), m_stat2 = mail_slot(ctx, 9), m_stat3 = mail_slot(ctx, 10);
-    ss_launch_mc_offsets_scan(ctx->vcount.as<uint32_t>(), ctx->tcount.as<uint32_t>(), n_mc, res->vbase.as<uint32_t>(), res->tbase.as<uint32_t>(), Z.take(ss_scan_state_words((size_t)n_mc + 1)), m_tot, st);
+    // one packed 31 + 31 bit scan while the worst case of the totals fits; two 64-bit scans for larger jobs (ss_kernels.hip, SSMcCountsIn)
+    const bool split_offsets = ctx->split_mc_offsets || (uint64_t)n_mc * SS_MC_MAX_TRI_PER_BLOCK >= (1ull << 31);
+    const SSMailSlot m_tot2 = split_offsets ? mail_slot(ctx, 16) : SSMailSlot{};
+    uint32_t* st_off = Z.take(ss_scan_state_words((size_t)n_mc + 1));
+    uint32_t* st_off2 = split_offsets ? Z.take(ss_scan_state_words((size_t)n_mc + 1)) : nullptr;
+    if (!st_off || (split_offsets && !st_off2)) return fail(ctx, SS_ERR_UNKNOWN, "internal error: zero region too small");
+    ss_launch_mc_offsets_scan(ctx->vcount.as<uint32_t>(), ctx->tcount.as<uint32_t>(), n_mc, res->vbase.as<uint32_t>(), res->tbase.as<uint32_t>(), st_off, st_off2, m_tot, m_tot2, st);
     ss_launch_publish_stats(reinterpret_cast<const unsigned long long*>(d_counters), n_redo_dev, n_large_dev, d_err, m_stat0, m_stat1, m_stat2, m_stat3, st);
     unsigned long long v_tot = 0, n_cand = 0, n_trunc_left = 0, n_cert_waves = 0, v_misc = 0;
     s = mail_wait(ctx, m_tot, &v_tot);
@@ -1245,7 +1260,15 @@ ss_status phase_finish(ss_context* ctx, ss_result* res) {
     s = mail_wait(ctx, m_stat3, &v_misc);  // n_redo | n_large << 24 | err << 56 ... see k_publish_stats
     if (s != SS_OK) return s;
     const uint32_t n_redo = (uint32_t)(v_misc & 0xFFFFFFFull), n_large = (uint32_t)((v_misc >> 28) & 0xFFFFFFFull), h_err = (uint32_t)(v_misc >> 56);
-    const uint64_t nv = (uint32_t)v_tot, nt = (uint32_t)(v_tot >> 32);
+    uint64_t nv = v_tot & 0x7FFFFFFFull, nt = v_tot >> 31;
+    if (split_offsets) {
+        unsigned long long v_tot2 = 0;
+        s = mail_wait(ctx, m_tot2, &v_tot2);
+        if (s != SS_OK) return s;
+        nv = v_tot;
+        nt = v_tot2;
+        if (nv >= (1ull << 32)) return fail(ctx, SS_ERR_UNSUPPORTED, "more than 2^32 - 1 vertices in one call are not supported by this build");
+    }
     if (h_err) return fail(ctx, SS_ERR_UNKNOWN, "internal error: a level-set block without a tile was asked for values (k_big_tile_select)");
     if (nt * 3 >= (1ull << 32)) return fail(ctx, SS_ERR_UNSUPPORTED, "more than 2^32/3 triangles in one call are not supported by this build");
     SS_HIP(ctx, res->vertices.reserve(nv * 3 * sizeof(R) + 16));
@@ -1302,11 +1325,11 @@ ss_status phase_finish(ss_context* ctx, ss_result* res) {
     S.levelset_kernel_launches = n_active ? 1 : 0;
     size_t held = 0;
     for (const DevBuf* b : {&ctx->xyz_in, &ctx->xyz_filt, &ctx->flags32, &ctx->offsets, &ctx->keys_a, &ctx->keys_b, &ctx->vals_a, &ctx->cell_count,
-                            &ctx->cell_start, &ctx->pos_sorted, &ctx->temp, &ctx->block_flag, &ctx->block_rank, &ctx->mc_flag, &ctx->mc_rank,
-                            &ctx->vcount, &ctx->tcount, &ctx->member_count, &ctx->copy_offset, &ctx->ckeys_a, &ctx->ckeys_b, &ctx->cvals_a, &ctx->cidx,
-                            &ctx->cpos, &ctx->cell_count2, &ctx->cell_start2, &res->rho, &res->posvol, &ctx->mc_nb, &ctx->splat_tile_idx, &ctx->splat_tiles, &ctx->splat_counts, &ctx->splat_off, &ctx->splat_bound, &ctx->splat_overflow, &res->posvol_by_index, &res->perm, &res->inside8, &res->G, &res->block_slot,
-                            &res->active_list, &res->mc_list, &res->mc_slot, &res->masks, &res->vbase, &res->tbase, &res->vertices, &res->vkeys,
-                            &res->tri32, &ctx->splat_trunc, &ctx->own_flag, &ctx->sub_flag, &ctx->sub_rank, &ctx->occ_sub, &res->blk_minmax, &res->active_xyz, &res->mc_xyz})
+                            &ctx->cell_start, &ctx->pos_sorted, &ctx->temp, &ctx->vcount, &ctx->tcount, &ctx->copy_offset, &ctx->ckeys_a, &ctx->ckeys_b, &ctx->cvals_a, &ctx->cidx,
+                            &ctx->cpos, &ctx->cell_start2, &res->rho, &res->posvol, &ctx->mc_nb, &ctx->splat_tile_idx, &ctx->splat_tiles, &ctx->splat_counts, &ctx->splat_off, &ctx->splat_bound, &ctx->splat_overflow, &res->posvol_by_index, &res->perm, &res->inside8, &res->G, &res->block_slot,
+                            &res->mc_slot, &res->masks, &res->vbase, &res->tbase, &res->vertices, &res->vkeys,
+                            &res->tri32, &ctx->splat_trunc, &ctx->own_flag, &ctx->sub_rank, &ctx->occ_sub, &res->blk_minmax, &res->active_xyz, &res->mc_xyz, &ctx->zeros, &ctx->zeros_k1, &ctx->sort_work,
+                            &ctx->aabb_partial, &ctx->fastdiv_scratch, &ctx->nb_count, &ctx->nb_tmp, &res->nb_ptr, &res->nb_idx})
         held += b->cap;
     S.bytes_device_peak = held;
     res->valid = true;
@@ -1480,7 +1503,7 @@ ss_status download(ss_result* r, const DevBuf& d, HostBuf& h, bool& flag, size_t
 }
 
 void result_release(ss_result* r) {
-    for (DevBuf* b : {&r->rho, &r->posvol, &r->posvol_by_index, &r->perm, &r->inside8, &r->G, &r->blk_minmax, &r->block_slot, &r->active_list, &r->active_xyz, &r->mc_xyz, &r->mc_list, &r->mc_slot, &r->masks,
+    for (DevBuf* b : {&r->rho, &r->posvol, &r->posvol_by_index, &r->perm, &r->inside8, &r->G, &r->blk_minmax, &r->block_slot, &r->active_xyz, &r->mc_xyz, &r->mc_slot, &r->masks,
                       &r->vbase, &r->tbase, &r->vertices, &r->vkeys, &r->tri32, &r->tri64})
         b->release();
     for (HostBuf* b : {&r->h_vertices, &r->h_tri64, &r->h_tri32, &r->h_rho, &r->h_vkeys, &r->h_inside, &r->h_nb_ptr, &r->h_nb_idx}) b->release();
@@ -1640,9 +1663,8 @@ void ss_context_destroy(ss_context* c) {
     (void)hipSetDevice(c->device);
     (void)hipDeviceSynchronize();
     for (DevBuf* b : {&c->xyz_in, &c->xyz_filt, &c->flags32, &c->offsets, &c->keys_a, &c->keys_b, &c->vals_a, &c->cell_count,
-                      &c->cell_start, &c->pos_sorted, &c->temp, &c->aabb_partial, &c->aabb_out, &c->block_flag, &c->block_rank, &c->mc_flag,
-                      &c->mc_rank, &c->vcount, &c->tcount, &c->counter, &c->member_count, &c->copy_offset, &c->sub_flag, &c->sub_rank,
-                      &c->nb_count, &c->nb_tmp, &c->occ_sub, &c->ckeys_a, &c->ckeys_b, &c->cvals_a, &c->cidx, &c->cpos, &c->cell_count2, &c->cell_start2, &c->gboxes, &c->fastdiv_scratch, &c->splat_overflow, &c->mc_nb, &c->splat_tile_idx, &c->splat_tiles, &c->splat_counts, &c->splat_off, &c->splat_bound, &c->splat_trunc, &c->own_flag})
+                      &c->cell_start, &c->pos_sorted, &c->temp, &c->aabb_partial, &c->aabb_out, &c->vcount, &c->tcount, &c->counter, &c->copy_offset, &c->sub_rank,
+                      &c->nb_count, &c->nb_tmp, &c->occ_sub, &c->ckeys_a, &c->ckeys_b, &c->cvals_a, &c->cidx, &c->cpos, &c->cell_start2, &c->gboxes, &c->fastdiv_scratch, &c->splat_overflow, &c->mc_nb, &c->splat_tile_idx, &c->splat_tiles, &c->splat_counts, &c->splat_off, &c->splat_bound, &c->splat_trunc, &c->own_flag})
         b->release();
     for (DevBuf& b : c->post_pool) b.release();
     c->zeros.release();
@@ -1667,6 +1689,10 @@ ss_status ss_context_set_option(ss_context* c, int option, int value) {
     }
     if (option == SS_OPTION_WIDEN_ON_DEVICE) {
         c->widen_on_device = value != 0;
+        return SS_OK;
+    }
+    if (option == SS_OPTION_SPLIT_MC_OFFSETS) {
+        c->split_mc_offsets = value != 0;
         return SS_OK;
     }
     if (option == SS_OPTION_SPLAT_TWO_PASS) {

@@ -37,11 +37,10 @@
 #include <string>
 #include <vector>
 
-#include <rocprim/rocprim.hpp>
-
 #include "../../include/splashsurf_hip.h"
 #include "ss_host.h"
 #include "ss_kernels.h"
+#include "ss_prims.h"
 
 namespace {
 
@@ -165,6 +164,18 @@ struct ss_comm {
     // scratch
     DevBuf small_dev, small_dev2, red_tmp, peers_dev;
     HostBuf small_host;
+    // counts the host waits for (SSMailSlot, ss_prims.h): pinned host memory mapped into the device, polled instead of a device-to-host copy
+    // and a stream synchronisation.  16 slots of {value, seq}, then COMM_MAIL_WORDS 64-bit words for small arrays (AABB, exchange bounds).
+    unsigned long long* mail_host = nullptr;
+    unsigned long long* mail_dev = nullptr;
+    unsigned long long mail_seq = 0;
+    DevBuf zeros;  // zeroed words of one step of the flow: scan states, counters (one memset per use)
+    // partition feedback (ss_comm_set_balance_feedback): the cost per owned particle every rank measured in the previous call weighs the
+    // owner histogram of the next one (a time series of frames is the real workload; the first call balances particle counts)
+    bool feedback = false;
+    std::vector<double> cost_per_particle;  // per rank, from the previous call (empty: none yet)
+    std::vector<int64_t> prev_bricks;
+    int prev_ns[3] = {0, 0, 0};
     // state of the last ss_dist_reconstruct / ss_dist_assemble
     DevBuf xyz_in, hist, flags, offs, boxes_dev, mask, sendbuf, recvbuf, gids, L, owned, sort_tmp, keys_a, keys_b, vals_a, vals_b, owner, holder, gid_local, mine_off, tri64, vown, kown, err;
     bool is_f64 = false;
@@ -232,6 +243,73 @@ ss_status wait_stream(ss_comm* c, const char* what) {
         }
         if (dt > 0.002) std::this_thread::sleep_for(std::chrono::microseconds(50));
     }
+    return SS_OK;
+}
+
+// ---- counts the host waits for ----
+#define COMM_MAIL_SLOTS 16
+#define COMM_MAIL_WORDS 96
+ss_status comm_ensure_mail(ss_comm* c) {
+    if (c->mail_host) return SS_OK;
+    ss_context* ctx = c->ctx;
+    void* h = nullptr;
+    const size_t bytes = (COMM_MAIL_SLOTS * 2 + COMM_MAIL_WORDS) * sizeof(unsigned long long);
+    SS_HIP(ctx, hipHostMalloc(&h, bytes, hipHostMallocMapped));
+    memset(h, 0, bytes);
+    void* d = nullptr;
+    SS_HIP(ctx, hipHostGetDevicePointer(&d, h, 0));
+    c->mail_host = reinterpret_cast<unsigned long long*>(h);
+    c->mail_dev = reinterpret_cast<unsigned long long*>(d);
+    return SS_OK;
+}
+SSMailSlot comm_slot(ss_comm* c, int k) { return SSMailSlot{c->mail_dev + 2 * k, ++c->mail_seq}; }
+unsigned long long* comm_words_dev(ss_comm* c) { return c->mail_dev + 2 * COMM_MAIL_SLOTS; }
+const volatile unsigned long long* comm_words_host(ss_comm* c) { return c->mail_host + 2 * COMM_MAIL_SLOTS; }
+// polls the pinned word (the stream goes on with whatever is enqueued behind the posting kernel); a drained stream without the value, a stream
+// or RCCL error or the communicator's timeout end the wait with an error
+ss_status comm_mail_wait(ss_comm* c, const SSMailSlot& m, unsigned long long* value, const char* what) {
+    ss_context* ctx = c->ctx;
+    const int k = (int)((m.p - c->mail_dev) / 2);
+    volatile unsigned long long* h = c->mail_host + 2 * k;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (unsigned long it = 0;; ++it) {
+        if (__atomic_load_n(&h[1], __ATOMIC_ACQUIRE) == m.seq) {
+            if (value) *value = h[0];
+            return SS_OK;
+        }
+        if ((it & 0xFFFu) == 0xFFFu) {
+            const hipError_t q = hipStreamQuery(ctx->stream);
+            if (q == hipSuccess) {
+                if (__atomic_load_n(&h[1], __ATOMIC_ACQUIRE) == m.seq) {
+                    if (value) *value = h[0];
+                    return SS_OK;
+                }
+                return comm_fail(c, std::string("a count the host waits for never arrived (stream drained): ") + what);
+            }
+            if (q != hipErrorNotReady) {
+                (void)hipGetLastError();
+                return comm_fail(c, std::string("HIP error while waiting for ") + what + ": " + hipGetErrorString(q));
+            }
+            if (c->kind == 1 && c->nccl) {
+                ncclResult_t ar = ncclSuccess;
+                if (rccl_api()->CommGetAsyncError(c->nccl, &ar) == ncclSuccess && ar != ncclSuccess && ar != ncclInProgress)
+                    return comm_fail(c, std::string("RCCL asynchronous error while waiting for ") + what + ": " + rccl_api()->GetErrorString(ar));
+            }
+            if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > c->timeout_s)
+                return comm_fail(c, std::string("timed out waiting for ") + what);
+        }
+#if defined(__x86_64__)
+        __builtin_ia32_pause();
+#endif
+    }
+}
+// n zeroed 32-bit words (one memset)
+ss_status comm_zeros(ss_comm* c, size_t words, uint32_t** out) {
+    ss_context* ctx = c->ctx;
+    words += 16;
+    SS_HIP(ctx, c->zeros.reserve(words * 4));
+    SS_HIP(ctx, hipMemsetAsync(c->zeros.p, 0, words * 4, ctx->stream));
+    *out = c->zeros.as<uint32_t>();
     return SS_OK;
 }
 
@@ -564,12 +642,6 @@ __global__ __launch_bounds__(256) void k_unpack_rows(uint64_t n, const uint32_t*
     for (int w = 0; w < payload_words; ++w) payload[(size_t)i * payload_words + w] = src[2 + w];
 }
 
-template <class R>
-__global__ __launch_bounds__(256) void k_owned_flags(const R* __restrict__ rho, uint64_t n, uint32_t* __restrict__ owned) {
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) owned[i] = rho[i] > R(0.0) ? 1u : 0u;
-}
-
 __device__ inline long long dist_lower_bound(const unsigned long long* __restrict__ a, long long n, unsigned long long key) {
     long long lo = 0, hi = n;
     while (lo < hi) {
@@ -628,13 +700,6 @@ __global__ __launch_bounds__(256) void k_vertex_owner(uint64_t nv, const unsigne
     holder[v] = mask;
 }
 
-// flags[v] = f(v) for v = 0 .. n (entry n: 0)
-template <class Flag>
-__global__ __launch_bounds__(256) void k_write_flags(uint64_t n, Flag f, uint32_t* __restrict__ flags) {
-    const uint64_t v = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (v <= n) flags[v] = f(v);
-}
-
 __global__ __launch_bounds__(256) void k_owned_gids(uint64_t nv, const uint32_t* __restrict__ mine, const uint32_t* __restrict__ mine_off, unsigned long long voff,
                                                     unsigned long long* __restrict__ gid_local) {
     const uint64_t v = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -675,13 +740,63 @@ __global__ __launch_bounds__(256) void k_compact_owned(uint64_t nv, const uint32
 
 inline dim3 grid_for(uint64_t n) { return dim3((unsigned)((n + 255) / 256)); }
 
-ss_status scan_u32(ss_comm* c, const uint32_t* in, uint32_t* out, size_t n) {
-    ss_context* ctx = c->ctx;
-    size_t bytes = 0;
-    SS_HIP(ctx, rocprim::exclusive_scan(nullptr, bytes, in, out, 0u, n, rocprim::plus<uint32_t>(), ctx->stream));
-    SS_HIP(ctx, c->sort_tmp.reserve(bytes + 64));
-    SS_HIP(ctx, rocprim::exclusive_scan(c->sort_tmp.p, bytes, in, out, 0u, n, rocprim::plus<uint32_t>(), ctx->stream));
-    return SS_OK;
+// n 32-bit words of the device, widened into the mapped host words, then the mail (one thread: the release of the post orders its stores)
+__global__ void k_post_words(const uint32_t* __restrict__ src, int n, unsigned long long* __restrict__ host_words, SSMailSlot m) {
+    for (int i = 0; i < n; ++i) __hip_atomic_store(host_words + i, (unsigned long long)src[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    ss_mail_post(m, (unsigned long long)n);
+}
+
+// (destination, workgroup) counts -> offsets; the first offset of every destination is its boundary in the send buffer
+struct PackCountsIn {
+    const uint32_t* counts;
+    __device__ uint32_t operator()(uint32_t i) const { return counts[i]; }
+};
+struct PackOffsOut {
+    uint32_t* offs;
+    uint32_t* bounds;
+    uint32_t n_wg;
+    __device__ void operator()(uint32_t i, uint32_t, uint32_t excl) const {
+        offs[i] = excl;
+        if (i % n_wg == 0u) bounds[i / n_wg] = excl;
+    }
+};
+// "this rank numbers vertex v": flag -> (flag array, rank among the flagged); the scan posts the count
+struct MineOut {
+    uint32_t* mine;
+    uint32_t* mine_off;
+    __device__ void operator()(uint32_t v, uint32_t x, uint32_t excl) const {
+        mine[v] = x;
+        mine_off[v] = excl;
+    }
+};
+struct VertexFlagIn {
+    VertexFlag f;
+    __device__ uint32_t operator()(uint32_t v) const { return f((uint64_t)v); }
+};
+// "this rank computed the density of held particle i" (rho > 0: exactly the particles its brick owns); the scan posts their number
+template <class R>
+struct OwnedIn {
+    const R* rho;
+    __device__ uint32_t operator()(uint32_t i) const { return rho[i] > R(0.0) ? 1u : 0u; }
+};
+struct OwnedOut {
+    uint32_t* owned;
+    __device__ void operator()(uint32_t i, uint32_t x, uint32_t) const { owned[i] = x; }
+};
+
+// ---- join of the received (edge key, global id) rows: stable LSD sort of the 64-bit keys with the library's own 32-bit pair sort, low word
+// first, then the high word's significant bits (ss_prims.h) ----
+__global__ __launch_bounds__(256) void k_row_word(uint64_t n, const uint32_t* __restrict__ rows, int row_words, int word, const uint32_t* __restrict__ perm, uint32_t* __restrict__ out) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = rows[(size_t)(perm ? perm[i] : (uint32_t)i) * (size_t)row_words + (size_t)word];
+}
+__global__ __launch_bounds__(256) void k_rows_by_perm(uint64_t n, const uint32_t* __restrict__ rows, const uint32_t* __restrict__ perm, unsigned long long* __restrict__ keys,
+                                                      unsigned long long* __restrict__ ids) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t* src = rows + (size_t)perm[i] * 4u;
+    keys[i] = (unsigned long long)src[0] | ((unsigned long long)src[1] << 32);
+    ids[i] = (unsigned long long)src[2] | ((unsigned long long)src[3] << 32);
 }
 
 template <class R> struct DistTypes;
@@ -700,9 +815,11 @@ double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::
 
 // Packs, for every destination rank in `active`, the elements whose destination mask names it into consecutive rows of c->sendbuf
 // (destinations in rank order, rows in ascending element order), exchanges them and leaves the received rows (ordered by source
-// rank) in c->recvbuf.  One counting pass, one scan over (destination, workgroup) and one packing pass serve all destinations.
+// rank) in c->recvbuf.  One counting pass, one scan over (destination, workgroup) and one packing pass serve all destinations; the
+// destinations' boundaries reach the host through a mail slot (no copy, no stream synchronisation).  `turn`: the caller's turn on a shared
+// device (it may have launched the kernel that produces the masks inside it); released here before the ranks meet.
 template <class Dests>
-ss_status pack_and_exchange(ss_comm* c, uint64_t n, uint64_t id0, const unsigned long long* ids, const uint32_t* payload, int payload_words, Dests dests,
+ss_status pack_and_exchange(ss_comm* c, TurnGuard& turn, uint64_t n, uint64_t id0, const unsigned long long* ids, const uint32_t* payload, int payload_words, Dests dests,
                             unsigned long long active, uint64_t* n_recv_rows, uint64_t* bytes_sent) {
     ss_context* ctx = c->ctx;
     hipStream_t st = ctx->stream;
@@ -715,29 +832,34 @@ ss_status pack_and_exchange(ss_comm* c, uint64_t n, uint64_t id0, const unsigned
     if (n_wg64 * (uint64_t)std::max(n_active, 1) >= (1ull << 31)) return fail(ctx, SS_ERR_UNSUPPORTED, "exchange: too many (destination, workgroup) pairs for this build");
     const uint32_t n_wg = (uint32_t)n_wg64;
     const size_t n_pairs = (size_t)n_active * n_wg;
-    TurnGuard turn(c, "pack");  // counting, scan and packing are this rank's own work; released before the ranks meet
-    std::vector<uint32_t> bound((size_t)n_active + 1, 0u);
-    uint32_t* counts = nullptr;
+    std::vector<uint64_t> bound((size_t)n_active + 1, 0u);
     uint32_t* offs = nullptr;
+    ss_status s = comm_ensure_mail(c);
+    if (s != SS_OK) return s;
     if (n_active) {
-        SS_HIP(ctx, c->offs.reserve((n_pairs + 1) * 8 + 64));
-        counts = c->offs.as<uint32_t>();
+        static_assert(COMM_MAIL_WORDS >= 66, "one boundary per destination plus the total");
+        SS_HIP(ctx, c->offs.reserve((2 * n_pairs + 2) * 4 + 64));
+        uint32_t* counts = c->offs.as<uint32_t>();
         offs = counts + n_pairs + 1;
-        SS_HIP(ctx, hipMemsetAsync(counts + n_pairs, 0, 4, st));  // the scan ends with the total
+        uint32_t* z = nullptr;  // zeroed: the scan's state, then the destinations' boundaries + the total
+        s = comm_zeros(c, ss_scan_state_words(n_pairs) + (size_t)n_active + 2, &z);
+        if (s != SS_OK) return s;
+        uint32_t* bounds_dev = z + ss_scan_state_words(n_pairs);
         hipLaunchKernelGGL(k_dest_counts<Dests>, dim3(n_wg), dim3(256), 0, st, n, dests, active, n_wg, counts);
-        size_t bytes = 0;
-        SS_HIP(ctx, rocprim::exclusive_scan(nullptr, bytes, counts, offs, 0u, n_pairs + 1, rocprim::plus<uint32_t>(), st));
-        SS_HIP(ctx, c->sort_tmp.reserve(bytes + 64));
-        SS_HIP(ctx, rocprim::exclusive_scan(c->sort_tmp.p, bytes, counts, offs, 0u, n_pairs + 1, rocprim::plus<uint32_t>(), st));
-        for (int sl = 0; sl <= n_active; ++sl) SS_HIP(ctx, hipMemcpyAsync(&bound[(size_t)sl], offs + (size_t)sl * n_wg, 4, hipMemcpyDeviceToHost, st));
-        SS_HIP(ctx, hipStreamSynchronize(st));
+        ss_chained_scan<uint32_t, SSOpPlus>(PackCountsIn{counts}, PackOffsOut{offs, bounds_dev, n_wg}, (uint32_t)n_pairs, z, bounds_dev + n_active, SSMailSlot{}, st);
+        const SSMailSlot m = comm_slot(c, 0);
+        hipLaunchKernelGGL(k_post_words, dim3(1), dim3(1), 0, st, bounds_dev, n_active + 1, comm_words_dev(c), m);
+        s = comm_mail_wait(c, m, nullptr, "the boundaries of an exchange");
+        if (s != SS_OK) return s;
+        const volatile unsigned long long* hw = comm_words_host(c);
+        for (int sl = 0; sl <= n_active; ++sl) bound[(size_t)sl] = hw[sl];
     }
     std::vector<uint64_t> send_off((size_t)world + 1, 0), send_rows((size_t)world, 0);
     {
         int sl = 0;
         for (int q = 0; q < world; ++q) {
             if ((active >> q) & 1ull) {
-                cnt[q] = bound[(size_t)sl + 1] - bound[(size_t)sl];
+                cnt[q] = (uint32_t)(bound[(size_t)sl + 1] - bound[(size_t)sl]);
                 ++sl;
             }
             send_rows[q] = cnt[q];
@@ -750,13 +872,15 @@ ss_status pack_and_exchange(ss_comm* c, uint64_t n, uint64_t id0, const unsigned
     turn.release();
     // matrix[r][q] = rows rank r sends to rank q
     std::vector<uint64_t> matrix((size_t)world * world, 0);
-    ss_status s = comm_allgather_host(c, send_rows.data(), (size_t)world * 8, matrix.data());
+    s = comm_allgather_host(c, send_rows.data(), (size_t)world * 8, matrix.data());
     if (s != SS_OK) return s;
+    ++c->info.n_collectives;
     std::vector<uint64_t> recv_off((size_t)world + 1, 0);
     for (int r = 0; r < world; ++r) recv_off[r + 1] = recv_off[r] + matrix[(size_t)r * world + me] * row_bytes;
     SS_HIP(ctx, c->recvbuf.reserve(recv_off[world] + 64));
     s = comm_exchange(c, c->sendbuf.as<uint8_t>(), send_off.data(), c->recvbuf.as<uint8_t>(), recv_off.data());
     if (s != SS_OK) return s;
+    ++c->info.n_collectives;
     *n_recv_rows = recv_off[world] / row_bytes;
     if (bytes_sent) *bytes_sent += send_off[world] - (send_off[me + 1] - send_off[me]);
     return SS_OK;
@@ -793,14 +917,17 @@ ss_status dist_reconstruct(ss_comm* c, const R* xyz_in, uint64_t n_local, const 
     memset(&zero_head, 0, sizeof(zero_head));
     mine_head = zero_head;
     mine_head.n = n_local;
+    ss_status s = comm_ensure_mail(c);
+    if (s != SS_OK) return s;
     TurnGuard turn(c, "aabb");
     if (n_local) {
+        // the six values land in the communicator's mapped host words, announced through a mail slot (no copy, no stream synchronisation)
         SS_HIP(ctx, ctx->aabb_partial.reserve(1024 * 6 * sizeof(R)));
-        SS_HIP(ctx, ctx->aabb_out.reserve(6 * sizeof(R)));
-        ss_launch_aabb<R>(d_xyz, (uint32_t)n_local, ctx->aabb_partial.as<R>(), ctx->aabb_out.as<R>(), SSMailSlot{}, st);
-        R h6[6];
-        SS_HIP(ctx, hipMemcpyAsync(h6, ctx->aabb_out.p, 6 * sizeof(R), hipMemcpyDeviceToHost, st));
-        SS_HIP(ctx, hipStreamSynchronize(st));
+        const SSMailSlot m = comm_slot(c, 1);
+        ss_launch_aabb<R>(d_xyz, (uint32_t)n_local, ctx->aabb_partial.as<R>(), reinterpret_cast<R*>(comm_words_dev(c) + 80), m, st);
+        s = comm_mail_wait(c, m, nullptr, "the bounding box of the local particles");
+        if (s != SS_OK) return s;
+        const volatile R* h6 = reinterpret_cast<const volatile R*>(comm_words_host(c) + 80);
         for (int d = 0; d < 3; ++d) {
             mine_head.lo[d] = (double)h6[d];
             mine_head.hi[d] = (double)h6[3 + d];
@@ -808,8 +935,9 @@ ss_status dist_reconstruct(ss_comm* c, const R* xyz_in, uint64_t n_local, const 
     }
     turn.release();
     std::vector<Head> heads((size_t)world);
-    ss_status s = comm_allgather_host(c, &mine_head, sizeof(Head), heads.data());
+    s = comm_allgather_host(c, &mine_head, sizeof(Head), heads.data());
     if (s != SS_OK) return s;
+    ++c->info.n_collectives;
     uint64_t id0 = 0, n_total = 0;
     R dmin[3] = {0, 0, 0}, dmax[3] = {0, 0, 0};
     bool any = false;
@@ -855,15 +983,36 @@ ss_status dist_reconstruct(ss_comm* c, const R* xyz_in, uint64_t n_local, const 
     }
     s = comm_allreduce_sum_u32(c, c->hist.as<uint32_t>(), nsub);
     if (s != SS_OK) return s;
+    ++c->info.n_collectives;
     std::vector<uint32_t> h_hist(nsub);
     SS_HIP(ctx, hipMemcpyAsync(h_hist.data(), c->hist.p, nsub * 4, hipMemcpyDeviceToHost, st));
     SS_HIP(ctx, hipStreamSynchronize(st));
     std::vector<double> hist_d(nsub);
     for (size_t i = 0; i < nsub; ++i) hist_d[i] = (double)h_hist[i];
+    // partition feedback: a subdomain's particles weigh what a particle cost the rank that owned the subdomain in the previous call (identical on every
+    // rank: the costs were all-gathered as integers); subdomains outside the previous bricks (the domain moved) keep weight 1
+    if (c->feedback && (int)c->cost_per_particle.size() == world && c->prev_bricks.size() == (size_t)world * 6 && c->prev_ns[0] == ns[0] && c->prev_ns[1] == ns[1] &&
+        c->prev_ns[2] == ns[2]) {
+        double mean = 0.0;
+        int cnt = 0;
+        for (int q = 0; q < world; ++q)
+            if (c->cost_per_particle[q] > 0.0) mean += c->cost_per_particle[q], ++cnt;
+        if (cnt) {
+            mean /= (double)cnt;
+            for (int q = 0; q < world; ++q) {
+                const double w = c->cost_per_particle[q] > 0.0 ? std::min(4.0, std::max(0.25, c->cost_per_particle[q] / mean)) : 1.0;
+                const int64_t* lo = &c->prev_bricks[(size_t)q * 6];
+                const int64_t* hi = lo + 3;
+                for (int64_t x = lo[0]; x < hi[0]; ++x)
+                    for (int64_t y = lo[1]; y < hi[1]; ++y)
+                        for (int64_t z = lo[2]; z < hi[2]; ++z) hist_d[((size_t)x * ns[1] + y) * ns[2] + z] *= w;
+            }
+        }
+    }
     c->bricks.assign((size_t)world * 6, 0);
     {
         const int lo0[3] = {0, 0, 0};
-        rcb_split(hist_d, ns, lo0, ns, 0, world, pref, 0.02, c->bricks);
+        rcb_split(hist_d, ns, lo0, ns, 0, world, pref, c->feedback ? 0.005 : 0.02, c->bricks);
     }
     const int64_t* my_lo = &c->bricks[(size_t)me * 6];
     const int64_t* my_hi = my_lo + 3;
@@ -906,23 +1055,23 @@ ss_status dist_reconstruct(ss_comm* c, const R* xyz_in, uint64_t n_local, const 
         if (overlap) pos_active |= 1ull << q;
     }
     SS_HIP(ctx, c->mask.reserve((n_local + 1) * 8 + 64));
-    if (pos_active) {
-        TurnGuard mask_turn(c, "mask_pos");
-        hipLaunchKernelGGL(k_box_masks<R>, grid_for(n_local), dim3(256), 0, st, d_xyz, n_local, c->boxes_dev.as<DistBoxes>(), pos_active, (const uint32_t*)nullptr,
-                           c->mask.as<unsigned long long>());
+    {
+        TurnGuard pack_turn(c, "pack_pos");  // destination masks, counting, scan and packing are this rank's own work; released before the ranks meet
+        if (pos_active)
+            hipLaunchKernelGGL(k_box_masks<R>, grid_for(n_local), dim3(256), 0, st, d_xyz, n_local, c->boxes_dev.as<DistBoxes>(), pos_active, (const uint32_t*)nullptr,
+                               c->mask.as<unsigned long long>());
+        s = pack_and_exchange(c, pack_turn, n_local, id0, nullptr, reinterpret_cast<const uint32_t*>(d_xyz), pos_words, MaskDests{c->mask.as<unsigned long long>()}, pos_active, &n_held,
+                              &c->info.bytes_sent_positions);
+        if (s != SS_OK) return s;
     }
-    s = pack_and_exchange(c, n_local, id0, nullptr, reinterpret_cast<const uint32_t*>(d_xyz), pos_words, MaskDests{c->mask.as<unsigned long long>()}, pos_active, &n_held,
-                          &c->info.bytes_sent_positions);
-    if (s != SS_OK) return s;
     if (n_held >= (1ull << 31)) return fail(ctx, SS_ERR_UNSUPPORTED, "more than 2^31-1 particles held by one rank");
     // Rows arrive ascending from every source rank and the ranks' id ranges ascend, so the concatenation by source rank IS the
     // ascending global-id order the engine needs (no sort).
     SS_HIP(ctx, c->gids.reserve(n_held * 8 + 64));
     SS_HIP(ctx, c->L.reserve(n_held * 3 * sizeof(R) + 64));
-    TurnGuard phase1_turn(c, "unpack_phase1");  // unpacking and phase 1 are this rank's own work
+    TurnGuard phase1_turn(c, "unpack_phase1");  // unpacking, phase 1, the owned flags, the density masks and their packing are this rank's own work
     if (n_held)
         hipLaunchKernelGGL(k_unpack_rows, grid_for(n_held), dim3(256), 0, st, n_held, c->recvbuf.as<uint32_t>(), pos_words, c->gids.as<unsigned long long>(), c->L.as<uint32_t>());
-    SS_HIP(ctx, hipStreamSynchronize(st));
     c->info.n_held = n_held;
     c->info.ms_position_exchange = now_ms() - t0;
 
@@ -937,29 +1086,18 @@ ss_status dist_reconstruct(ss_comm* c, const R* xyz_in, uint64_t n_local, const 
     t0 = now_ms();
     s = T::begin(ctx, c->L.as<R>(), n_held, prm, &shard, res);
     if (s != SS_OK) return s;
-    // phase 1 returns with its last kernels in flight: drain the stream before the exchange's clock starts (round 2 billed them
-    // to the exchange: a one-rank run reported 10.7 ms of "exchange" for 0 bytes)
-    SS_HIP(ctx, hipStreamSynchronize(st));
-    c->info.ms_phase1 = now_ms() - t0;
+    c->info.ms_phase1 = now_ms() - t0;  // (host time: the phase's last kernels are still in flight, the stream is not drained here)
     t0 = now_ms();
 
     // ---- 5. halo densities: owners -> ranks holding the particle as a ghost ----
     SS_HIP(ctx, c->owned.reserve((n_held + 1) * 4 + 64));
-    if (n_held) hipLaunchKernelGGL(k_owned_flags<R>, grid_for(n_held), dim3(256), 0, st, res->rho.as<R>(), n_held, c->owned.as<uint32_t>());
+    const SSMailSlot m_owned = comm_slot(c, 2);  // read at the end of the call: nothing of the flow depends on the count
     {
-        size_t bytes = 0;
-        SS_HIP(ctx, c->small_dev.reserve(64));
-        if (n_held) {
-            SS_HIP(ctx, rocprim::reduce(nullptr, bytes, c->owned.as<uint32_t>(), c->small_dev.as<uint32_t>(), 0u, (size_t)n_held, rocprim::plus<uint32_t>(), st));
-            SS_HIP(ctx, c->sort_tmp.reserve(bytes + 64));
-            SS_HIP(ctx, rocprim::reduce(c->sort_tmp.p, bytes, c->owned.as<uint32_t>(), c->small_dev.as<uint32_t>(), 0u, (size_t)n_held, rocprim::plus<uint32_t>(), st));
-            uint32_t h_owned = 0;
-            SS_HIP(ctx, hipMemcpyAsync(&h_owned, c->small_dev.p, 4, hipMemcpyDeviceToHost, st));
-            SS_HIP(ctx, hipStreamSynchronize(st));
-            c->info.n_owned = h_owned;
-        }
+        uint32_t* z = nullptr;
+        s = comm_zeros(c, ss_scan_state_words(n_held), &z);
+        if (s != SS_OK) return s;
+        ss_chained_scan<uint32_t, SSOpPlus>(OwnedIn<R>{res->rho.as<R>()}, OwnedOut{c->owned.as<uint32_t>()}, (uint32_t)n_held, z, (uint32_t*)nullptr, m_owned, st);
     }
-    phase1_turn.release();
     uint64_t n_rho_rows = 0;
     const int rho_words = (int)(sizeof(R) / 4);
     unsigned long long rho_active = 0;
@@ -971,12 +1109,10 @@ ss_status dist_reconstruct(ss_comm* c, const R* xyz_in, uint64_t n_local, const 
         if (overlap) rho_active |= 1ull << q;
     }
     SS_HIP(ctx, c->mask.reserve((n_held + 1) * 8 + 64));
-    if (rho_active) {
-        TurnGuard mask_turn(c, "mask_rho");
+    if (rho_active)
         hipLaunchKernelGGL(k_box_masks<R>, grid_for(n_held), dim3(256), 0, st, c->L.as<R>(), n_held, c->boxes_dev.as<DistBoxes>(), rho_active, c->owned.as<uint32_t>(),
                            c->mask.as<unsigned long long>());
-    }
-    s = pack_and_exchange(c, n_held, 0, c->gids.as<unsigned long long>(), reinterpret_cast<const uint32_t*>(res->rho.as<R>()), rho_words,
+    s = pack_and_exchange(c, phase1_turn, n_held, 0, c->gids.as<unsigned long long>(), reinterpret_cast<const uint32_t*>(res->rho.as<R>()), rho_words,
                           MaskDests{c->mask.as<unsigned long long>()}, rho_active, &n_rho_rows, &c->info.bytes_sent_densities);
     if (s != SS_OK) return s;
     TurnGuard phase2_turn(c, "scatter_phase2");  // scattering the received densities and phase 2
@@ -985,10 +1121,8 @@ ss_status dist_reconstruct(ss_comm* c, const R* xyz_in, uint64_t n_local, const 
     if (n_rho_rows)
         hipLaunchKernelGGL(k_scatter_density, grid_for(n_rho_rows), dim3(256), 0, st, n_rho_rows, c->recvbuf.as<uint32_t>(), rho_words, c->gids.as<unsigned long long>(), n_held,
                            res->rho.as<uint32_t>(), c->err.as<uint32_t>());
-    uint32_t h_err = 0;
-    SS_HIP(ctx, hipMemcpyAsync(&h_err, c->err.p, 4, hipMemcpyDeviceToHost, st));
-    SS_HIP(ctx, hipStreamSynchronize(st));
-    if (h_err) return fail(ctx, SS_ERR_UNKNOWN, "halo density exchange: a density arrived for a particle this rank does not hold");
+    const SSMailSlot m_err = comm_slot(c, 3);  // (checked after phase 2: the stream is not held up for it; a stray density is dropped by the kernel)
+    hipLaunchKernelGGL(k_post_words, dim3(1), dim3(1), 0, st, c->err.as<uint32_t>(), 1, comm_words_dev(c) + 72, m_err);
     res->hrho = false;
     c->info.ms_density_exchange = now_ms() - t0;
 
@@ -998,18 +1132,41 @@ ss_status dist_reconstruct(ss_comm* c, const R* xyz_in, uint64_t n_local, const 
     if (s != SS_OK) return s;
     c->info.ms_phase2 = now_ms() - t0;
     phase2_turn.release();
+    {
+        unsigned long long v = 0;
+        s = comm_mail_wait(c, m_err, nullptr, "the error flag of the density exchange");
+        if (s != SS_OK) return s;
+        if (comm_words_host(c)[72]) return fail(ctx, SS_ERR_UNKNOWN, "halo density exchange: a density arrived for a particle this rank does not hold");
+        if (n_held) {
+            s = comm_mail_wait(c, m_owned, &v, "the number of owned particles");
+            if (s != SS_OK) return s;
+        }
+        c->info.n_owned = v;
+    }
+    {
+        ss_stats st_;
+        if (ss_result_stats(res, &st_) == SS_OK) c->info.ms_device = st_.ms_total;
+    }
 
-    // load balance of the partition, identical on every rank
-    uint64_t pair[2] = {c->info.n_owned, c->info.n_held};
-    std::vector<uint64_t> pairs((size_t)world * 2);
-    s = comm_allgather_host(c, pair, sizeof(pair), pairs.data());
+    // load balance of the partition, identical on every rank; with it travels what the step cost this rank (microseconds of device time): the
+    // weights of the next call's partition (ss_comm_set_balance_feedback)
+    uint64_t triple[3] = {c->info.n_owned, c->info.n_held, (uint64_t)std::llround(std::max(0.0, c->info.ms_device) * 1000.0)};
+    std::vector<uint64_t> triples((size_t)world * 3);
+    s = comm_allgather_host(c, triple, sizeof(triple), triples.data());
     if (s != SS_OK) return s;
+    ++c->info.n_collectives;
     c->per_rank_owned.assign((size_t)world, 0);
     c->per_rank_held.assign((size_t)world, 0);
+    std::vector<double> cpp((size_t)world, 0.0);
     for (int q = 0; q < world; ++q) {
-        c->per_rank_owned[q] = pairs[(size_t)q * 2];
-        c->per_rank_held[q] = pairs[(size_t)q * 2 + 1];
+        c->per_rank_owned[q] = triples[(size_t)q * 3];
+        c->per_rank_held[q] = triples[(size_t)q * 3 + 1];
+        // relative to the previous weights: the measured cost per particle of a brick is the product of all corrections so far
+        cpp[q] = triples[(size_t)q * 3] ? (double)triples[(size_t)q * 3 + 2] / (double)triples[(size_t)q * 3] : 0.0;
     }
+    c->cost_per_particle = cpp;
+    c->prev_bricks = c->bricks;
+    for (int d = 0; d < 3; ++d) c->prev_ns[d] = ns[d];
     return SS_OK;
 }
 
@@ -1042,20 +1199,31 @@ ss_status dist_assemble(ss_comm* c, ss_result* res) {
     SS_HIP(ctx, c->mine_off.reserve((nv + 1) * 4 + 64));
     SS_HIP(ctx, c->vals_a.reserve((nv + 1) * 4 + 64));  // mine flags
     const unsigned long long* keys = res->vkeys.as<unsigned long long>();
+    if (nv >= SS_SCAN_MAX_N) return fail(ctx, SS_ERR_UNSUPPORTED, "too many vertices on one rank for the assembly");
+    ss_status s = comm_ensure_mail(c);
+    if (s != SS_OK) return s;
     TurnGuard turn(c, "asm_mine");
     if (nv) hipLaunchKernelGGL(k_vertex_owner, grid_for(nv), dim3(256), 0, st, nv, keys, B, np1, np2, c->owner.as<uint32_t>(), c->holder.as<unsigned long long>());
     uint32_t* mine = c->vals_a.as<uint32_t>();
-    hipLaunchKernelGGL(k_write_flags<VertexFlag>, grid_for(nv + 1), dim3(256), 0, st, nv, VertexFlag{c->owner.as<uint32_t>(), c->holder.as<unsigned long long>(), nv, (uint32_t)me, -1}, mine);
-    ss_status s = scan_u32(c, mine, c->mine_off.as<uint32_t>(), nv + 1);
+    // "mine" flags and their ranks in one dispatch (the flag is the scan's input); the number of owned vertices arrives by mail
+    const SSMailSlot m_mine = comm_slot(c, 4);
+    {
+        uint32_t* z = nullptr;
+        s = comm_zeros(c, ss_scan_state_words(nv), &z);
+        if (s != SS_OK) return s;
+        ss_chained_scan<uint32_t, SSOpPlus>(VertexFlagIn{VertexFlag{c->owner.as<uint32_t>(), c->holder.as<unsigned long long>(), nv, (uint32_t)me, -1}},
+                                            MineOut{mine, c->mine_off.as<uint32_t>()}, (uint32_t)nv, z, (uint32_t*)nullptr, m_mine, st);
+    }
+    unsigned long long v_owned = 0;
+    s = comm_mail_wait(c, m_mine, &v_owned, "the number of vertices this rank numbers");
     if (s != SS_OK) return s;
-    uint32_t n_owned = 0;
-    SS_HIP(ctx, hipMemcpyAsync(&n_owned, c->mine_off.as<uint32_t>() + nv, 4, hipMemcpyDeviceToHost, st));
-    SS_HIP(ctx, hipStreamSynchronize(st));
+    const uint32_t n_owned = (uint32_t)v_owned;
     turn.release();
     uint64_t cnt[2] = {n_owned, nt};
     std::vector<uint64_t> all((size_t)world * 2);
     s = comm_allgather_host(c, cnt, sizeof(cnt), all.data());
     if (s != SS_OK) return s;
+    ++c->info.n_collectives;
     uint64_t voff = 0, toff = 0, vtot = 0, ttot = 0;
     for (int q = 0; q < world; ++q) {
         if (q < me) {
@@ -1064,10 +1232,6 @@ ss_status dist_assemble(ss_comm* c, ss_result* res) {
         }
         vtot += all[(size_t)q * 2];
         ttot += all[(size_t)q * 2 + 1];
-    }
-    {
-        TurnGuard gid_turn(c, "asm_gid");
-        if (nv) hipLaunchKernelGGL(k_owned_gids, grid_for(nv), dim3(256), 0, st, nv, mine, c->mine_off.as<uint32_t>(), (unsigned long long)voff, c->gid_local.as<unsigned long long>());
     }
     // owners -> the other ranks holding the edge: (key, global id)
     uint64_t n_rows = 0;
@@ -1079,26 +1243,54 @@ ss_status dist_assemble(ss_comm* c, ss_result* res) {
             if (B.hi[me][d] < B.lo[q][d] || B.lo[me][d] > B.hi[q][d]) touch = false;
         if (touch) gid_active |= 1ull << q;
     }
-    s = pack_and_exchange(c, nv, 0, keys, reinterpret_cast<const uint32_t*>(c->gid_local.as<unsigned long long>()), 2,
-                          VertexDests{c->owner.as<uint32_t>(), c->holder.as<unsigned long long>(), (uint32_t)me}, gid_active, &n_rows, &c->info.bytes_sent_assembly);
-    if (s != SS_OK) return s;
+    {
+        TurnGuard gid_turn(c, "asm_gid_pack");
+        if (nv) hipLaunchKernelGGL(k_owned_gids, grid_for(nv), dim3(256), 0, st, nv, mine, c->mine_off.as<uint32_t>(), (unsigned long long)voff, c->gid_local.as<unsigned long long>());
+        s = pack_and_exchange(c, gid_turn, nv, 0, keys, reinterpret_cast<const uint32_t*>(c->gid_local.as<unsigned long long>()), 2,
+                              VertexDests{c->owner.as<uint32_t>(), c->holder.as<unsigned long long>(), (uint32_t)me}, gid_active, &n_rows, &c->info.bytes_sent_assembly);
+        if (s != SS_OK) return s;
+    }
+    if (n_rows >= (1ull << 30)) return fail(ctx, SS_ERR_UNSUPPORTED, "too many shared face vertices received by one rank");
     TurnGuard join_turn(c, "asm_join");
     SS_HIP(ctx, c->err.reserve(64));
     SS_HIP(ctx, hipMemsetAsync(c->err.p, 0, 4, st));
     if (n_rows || nv) {
-        // received rows: (key, id) -> sort by key, then every vertex owned elsewhere looks its key up
-        SS_HIP(ctx, c->keys_b.reserve((n_rows + 1) * 8 * 2 + 64));
-        SS_HIP(ctx, c->vals_b.reserve((n_rows + 1) * 8 * 2 + 64));
-        unsigned long long* rk = c->keys_b.as<unsigned long long>();
-        unsigned long long* rk_sorted = rk + (n_rows + 1);
-        unsigned long long* ri = c->vals_b.as<unsigned long long>();
-        unsigned long long* ri_sorted = ri + (n_rows + 1);
+        // received rows (key lo, key hi, id lo, id hi): stable LSD sort of the 64-bit keys -- the low word with the library's 32-bit pair sort, then the
+        // significant bits of the high word -- and every vertex owned elsewhere looks its key up
+        SS_HIP(ctx, c->keys_b.reserve((n_rows + 1) * 8 + 64));
+        SS_HIP(ctx, c->vals_b.reserve((n_rows + 1) * 8 + 64));
+        unsigned long long* rk_sorted = c->keys_b.as<unsigned long long>();
+        unsigned long long* ri_sorted = c->vals_b.as<unsigned long long>();
         if (n_rows) {
-            hipLaunchKernelGGL(k_unpack_rows, grid_for(n_rows), dim3(256), 0, st, n_rows, c->recvbuf.as<uint32_t>(), 2, rk, reinterpret_cast<uint32_t*>(ri));
-            size_t bytes = 0;
-            SS_HIP(ctx, rocprim::radix_sort_pairs(nullptr, bytes, rk, rk_sorted, ri, ri_sorted, (size_t)n_rows, 0u, 64u, st));
-            SS_HIP(ctx, c->sort_tmp.reserve(bytes + 64));
-            SS_HIP(ctx, rocprim::radix_sort_pairs(c->sort_tmp.p, bytes, rk, rk_sorted, ri, ri_sorted, (size_t)n_rows, 0u, 64u, st));
+            const uint32_t nr = (uint32_t)n_rows;
+            const uint32_t* rows = c->recvbuf.as<uint32_t>();
+            unsigned hi_bits = 0;
+            {   // keys are below 3 * (number of grid points)
+                const long double kmax = 3.0L * (long double)((unsigned long long)c->ns[0] * n + 1ull) * (long double)np1 * (long double)np2;
+                while (hi_bits < 32 && std::ldexp(1.0L, 32 + (int)hi_bits) < kmax) ++hi_bits;
+            }
+            const size_t work_words = ss_radix_sort_work_words(nr, 32) + ss_radix_sort_work_words(nr, hi_bits ? hi_bits : 1);
+            SS_HIP(ctx, c->sort_tmp.reserve(((size_t)nr + 16) * 4 * 4 + work_words * 4 + 64));
+            uint32_t* k0 = c->sort_tmp.as<uint32_t>();
+            uint32_t* k1 = k0 + ((size_t)nr + 16);
+            uint32_t* v0 = k1 + ((size_t)nr + 16);
+            uint32_t* v1 = v0 + ((size_t)nr + 16);
+            uint32_t* work = v1 + ((size_t)nr + 16);
+            SS_HIP(ctx, hipMemsetAsync(work, 0, work_words * 4, st));
+            hipLaunchKernelGGL(k_row_word, grid_for(nr), dim3(256), 0, st, (uint64_t)nr, rows, 4, 0, (const uint32_t*)nullptr, k0);
+            uint32_t* kk[2] = {k0, k1};
+            uint32_t* vv[2] = {v0, v1};
+            int r = ss_radix_sort_pairs(kk, vv, nr, 32, true, work, true, st);
+            const uint32_t* perm = vv[r];
+            if (hi_bits) {
+                // the high words in the order of the low words; the permutation so far travels as the values
+                uint32_t* kk2[2] = {kk[r ^ 1], kk[r]};  // (the sorted low words are not needed any more)
+                uint32_t* vv2[2] = {vv[r], vv[r ^ 1]};
+                hipLaunchKernelGGL(k_row_word, grid_for(nr), dim3(256), 0, st, (uint64_t)nr, rows, 4, 1, perm, kk2[0]);
+                const int r2 = ss_radix_sort_pairs(kk2, vv2, nr, hi_bits, false, work + ss_radix_sort_work_words(nr, 32), true, st);
+                perm = vv2[r2];
+            }
+            hipLaunchKernelGGL(k_rows_by_perm, grid_for(nr), dim3(256), 0, st, (uint64_t)nr, rows, perm, rk_sorted, ri_sorted);
         }
         if (nv)
             hipLaunchKernelGGL(k_resolve_shared, grid_for(nv), dim3(256), 0, st, nv, keys, mine, rk_sorted, ri_sorted, n_rows, c->gid_local.as<unsigned long long>(),
@@ -1109,10 +1301,11 @@ ss_status dist_assemble(ss_comm* c, ss_result* res) {
     SS_HIP(ctx, c->vown.reserve((size_t)n_owned * 3 * sizeof(R) + 64));
     SS_HIP(ctx, c->kown.reserve((size_t)n_owned * 8 + 64));
     if (nv) hipLaunchKernelGGL(k_compact_owned<R>, grid_for(nv), dim3(256), 0, st, nv, mine, c->mine_off.as<uint32_t>(), res->vertices.as<R>(), keys, c->vown.as<R>(), c->kown.as<unsigned long long>());
-    uint32_t h_err = 0;
-    SS_HIP(ctx, hipMemcpyAsync(&h_err, c->err.p, 4, hipMemcpyDeviceToHost, st));
-    SS_HIP(ctx, hipStreamSynchronize(st));
-    if (h_err) return fail(ctx, SS_ERR_UNKNOWN, "mesh assembly: a shared face vertex was not emitted by its owner rank (level sets differ between ranks)");
+    const SSMailSlot m_err = comm_slot(c, 5);  // the last kernel of the assembly: its mail is the end of the step
+    hipLaunchKernelGGL(k_post_words, dim3(1), dim3(1), 0, st, c->err.as<uint32_t>(), 1, comm_words_dev(c) + 73, m_err);
+    s = comm_mail_wait(c, m_err, nullptr, "the end of the mesh assembly");
+    if (s != SS_OK) return s;
+    if (comm_words_host(c)[73]) return fail(ctx, SS_ERR_UNKNOWN, "mesh assembly: a shared face vertex was not emitted by its owner rank (level sets differ between ranks)");
     c->info.n_vertices_owned = n_owned;
     c->info.vertex_offset = voff;
     c->info.n_vertices_total = vtot;
@@ -1136,9 +1329,11 @@ ss_status copy_to_caller(ss_comm* c, const void* src, void* dst, size_t bytes) {
 
 void comm_release(ss_comm* c) {
     for (DevBuf* b : {&c->small_dev, &c->small_dev2, &c->red_tmp, &c->peers_dev, &c->xyz_in, &c->hist, &c->flags, &c->offs, &c->boxes_dev, &c->mask, &c->sendbuf, &c->recvbuf, &c->gids, &c->L, &c->owned,
-                      &c->sort_tmp, &c->keys_a, &c->keys_b, &c->vals_a, &c->vals_b, &c->owner, &c->holder, &c->gid_local, &c->mine_off, &c->tri64, &c->vown, &c->kown, &c->err})
+                      &c->sort_tmp, &c->keys_a, &c->keys_b, &c->vals_a, &c->vals_b, &c->owner, &c->holder, &c->gid_local, &c->mine_off, &c->tri64, &c->vown, &c->kown, &c->err, &c->zeros})
         b->release();
     c->small_host.release();
+    if (c->mail_host) (void)hipHostFree(c->mail_host);
+    c->mail_host = c->mail_dev = nullptr;
 }
 
 double env_timeout() {
@@ -1234,6 +1429,13 @@ ss_status ss_comm_local_group_take_turns(ss_comm* c, int on) {
     if (!c || c->kind != 0 || !c->group) return SS_ERR_INVALID_ARGUMENT;
     std::lock_guard<std::mutex> lk(c->group->m);
     c->group->take_turns = on != 0;
+    return SS_OK;
+}
+
+ss_status ss_comm_set_balance_feedback(ss_comm* c, int on) {
+    if (!c) return SS_ERR_INVALID_ARGUMENT;
+    c->feedback = on != 0;
+    if (!c->feedback) c->cost_per_particle.clear();
     return SS_OK;
 }
 

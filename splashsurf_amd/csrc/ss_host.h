@@ -73,13 +73,13 @@ struct ss_context {
     std::string err;
     int err_detail = 0;
     // scratch (grow-only, reused across calls = the reference's workspace.rs)
-    DevBuf xyz_in, xyz_filt, flags32, offsets, keys_a, keys_b, vals_a, cell_count, cell_start, pos_sorted, temp, aabb_partial, aabb_out,
-        block_flag, block_rank, mc_flag, mc_rank, vcount, tcount, counter;
+    DevBuf xyz_in, xyz_filt, flags32, offsets, keys_a, keys_b, vals_a, cell_count, cell_start, pos_sorted, temp, aabb_partial, aabb_out, vcount, tcount, counter;
     // per-subdomain particle copies for the density stage
     DevBuf nb_count, nb_tmp;
     DevBuf own_flag;  // per subdomain copy: owned flag, its scan, the list of owned copies
+    bool split_mc_offsets = false;  // SS_OPTION_SPLIT_MC_OFFSETS: always two 64-bit scans for the vertex / triangle offsets (tests)
     bool widen_on_device = false;  // SS_OPTION_WIDEN_ON_DEVICE: ss_result_triangles widens the u32 indices on the device and copies u64 (tests; the default for small meshes)
-    DevBuf member_count, copy_offset, sub_flag, sub_rank, occ_sub, ckeys_a, ckeys_b, cvals_a, cidx, cpos, cell_count2, cell_start2;
+    DevBuf copy_offset, sub_rank, occ_sub, ckeys_a, ckeys_b, cvals_a, cidx, cpos, cell_start2;
     hipEvent_t ev[26];  // (22, 23: around the K1 chain on the second stream; 24 fork, 25 join)
     // ^ 0..9 stage boundaries, 10/11 start of phase 2, 12..15 inside the splat, 16/17 around the arena-path gather, 18/19 k_density_sub, 20/21 k_mc_count
     // the two-pass splat pays off when enough sub-blocks get certified 'inside' (bulk fluid); thin structures do not -- decided per
@@ -143,7 +143,7 @@ struct ss_result {
     uint64_t n_occupied_subdomains = 0, n_subdomain_particles = 0;
     ss_stats stats;
     // device results
-    DevBuf rho, posvol, posvol_by_index, perm, inside8, G, blk_minmax, block_slot, active_list, active_xyz, mc_list, mc_xyz, mc_slot, masks, vbase, tbase, vertices, vkeys, tri32, tri64;
+    DevBuf rho, posvol, posvol_by_index, perm, inside8, G, blk_minmax, block_slot, active_xyz, mc_xyz, mc_slot, masks, vbase, tbase, vertices, vkeys, tri32, tri64;
     // host mirrors
     HostBuf h_vertices, h_tri64, h_tri32, h_rho, h_vkeys, h_inside;
     bool hv = false, ht64 = false, ht32 = false, hrho = false, hkeys = false, hinside = false;

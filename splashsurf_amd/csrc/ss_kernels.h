@@ -59,7 +59,10 @@ template <class R>
 void ss_launch_active_blocks_scan(const SSDevT<R>& P, const uint32_t* block_flag, uint32_t nblocks, uint32_t cap, uint32_t* list, uint32_t* slot, uint32_t* xyz, uint32_t* state, SSMailSlot mail, hipStream_t st);
 template <class R>
 void ss_launch_mc_blocks_scan(const SSDevT<R>& P, const uint32_t* block_slot, const ss_real2<R>* blk_minmax, uint32_t nblocks, uint32_t cap, uint32_t* mc_list, uint32_t* mc_slot, uint32_t* mc_xyz, uint32_t* state, SSMailSlot mail, hipStream_t st);
-void ss_launch_mc_offsets_scan(const uint32_t* vcount, const uint32_t* tcount, uint32_t n_mc, uint32_t* vbase, uint32_t* tbase, uint32_t* state, SSMailSlot mail, hipStream_t st);
+// state2 == nullptr: one packed scan, mail = vertices | triangles << 31 (needs n_mc * SS_MC_MAX_TRI_PER_BLOCK < 2^31); otherwise two scans, mail = vertices, mail2 = triangles
+#define SS_MC_MAX_TRI_PER_BLOCK 2560u  // 8^3 cells of at most 5 triangles (and at most 3 * 8^3 = 1536 owned edge vertices)
+void ss_launch_mc_offsets_scan(const uint32_t* vcount, const uint32_t* tcount, uint32_t n_mc, uint32_t* vbase, uint32_t* tbase, uint32_t* state, uint32_t* state2, SSMailSlot mail,
+                               SSMailSlot mail2, hipStream_t st);
 void ss_launch_tile_offsets_scan(const uint32_t* bound, uint32_t n, unsigned long long* off, uint32_t* state, SSMailSlot mail, hipStream_t st);
 template <class R>
 void ss_launch_posvol_by_index(uint32_t n, const ss_real4<R>* posvol, const uint32_t* perm, ss_real4<R>* posvol_by_index, hipStream_t st);

@@ -3155,28 +3155,49 @@ void ss_launch_mc_blocks_scan(const SSDevT<R>& P, const uint32_t* block_slot, co
     ss_chained_scan<uint32_t, SSOpPlus>(SSMcFlagIn<R>{P, block_slot, blk_minmax}, SSBlockListOut<R>{P, cap, mc_list, mc_slot, mc_xyz}, nblocks, state, (uint32_t*)nullptr, mail, st);
 }
 
-// vertex and triangle offsets of the marching-cubes blocks in one scan: the two counts packed into one 64-bit value (both totals < 2^32)
+// vertex and triangle offsets of the marching-cubes blocks in ONE scan: the two counts packed into one 64-bit value, 31 bits each -- the scan's
+// status words keep bits 63:62 for their flags (ss_prims.h), so the running (vertex | triangle << 31) totals have to stay below 2^62.  The host
+// guarantees that from the number of blocks (SS_MC_MAX_TRI_PER_BLOCK); larger jobs take two 64-bit scans (`split`).
 struct SSMcCountsIn {
     const uint32_t* vcount;
     const uint32_t* tcount;
-    __device__ unsigned long long operator()(uint32_t i) const { return (unsigned long long)vcount[i] | ((unsigned long long)tcount[i] << 32); }
+    __device__ unsigned long long operator()(uint32_t i) const { return (unsigned long long)vcount[i] | ((unsigned long long)tcount[i] << 31); }
 };
 struct SSMcOffsetsOut {
     uint32_t* vbase;
     uint32_t* tbase;
     uint32_t n;
     __device__ void operator()(uint32_t i, unsigned long long x, unsigned long long excl) const {
-        vbase[i] = (uint32_t)excl;
-        tbase[i] = (uint32_t)(excl >> 32);
+        vbase[i] = (uint32_t)(excl & 0x7FFFFFFFull);
+        tbase[i] = (uint32_t)(excl >> 31);
         if (i + 1u == n) {  // entry n: the totals (the emit kernel reads base[m + 1] of the last block)
             const unsigned long long t = excl + x;
-            vbase[n] = (uint32_t)t;
-            tbase[n] = (uint32_t)(t >> 32);
+            vbase[n] = (uint32_t)(t & 0x7FFFFFFFull);
+            tbase[n] = (uint32_t)(t >> 31);
         }
     }
 };
-void ss_launch_mc_offsets_scan(const uint32_t* vcount, const uint32_t* tcount, uint32_t n_mc, uint32_t* vbase, uint32_t* tbase, uint32_t* state, SSMailSlot mail, hipStream_t st) {
-    ss_chained_scan<unsigned long long, SSOpPlus>(SSMcCountsIn{vcount, tcount}, SSMcOffsetsOut{vbase, tbase, n_mc}, n_mc, state, (unsigned long long*)nullptr, mail, st);
+struct SSStoreExcl32 {  // (totals of the split form stay below 2^32: the host checks the posted 64-bit totals before anybody reads the bases)
+    uint32_t* out;
+    uint32_t n;
+    __device__ void operator()(uint32_t i, unsigned long long x, unsigned long long excl) const {
+        out[i] = (uint32_t)excl;
+        if (i + 1u == n) out[n] = (uint32_t)(excl + x);
+    }
+};
+struct SSWidenIn;
+void ss_launch_mc_offsets_scan(const uint32_t* vcount, const uint32_t* tcount, uint32_t n_mc, uint32_t* vbase, uint32_t* tbase, uint32_t* state, uint32_t* state2, SSMailSlot mail,
+                               SSMailSlot mail2, hipStream_t st) {
+    if (!state2) {  // packed: mail = vertices | triangles << 31
+        ss_chained_scan<unsigned long long, SSOpPlus>(SSMcCountsIn{vcount, tcount}, SSMcOffsetsOut{vbase, tbase, n_mc}, n_mc, state, (unsigned long long*)nullptr, mail, st);
+        return;
+    }
+    struct Widen {
+        const uint32_t* v;
+        __device__ unsigned long long operator()(uint32_t i) const { return (unsigned long long)v[i]; }
+    };
+    ss_chained_scan<unsigned long long, SSOpPlus>(Widen{vcount}, SSStoreExcl32{vbase, n_mc}, n_mc, state, (unsigned long long*)nullptr, mail, st);    // mail = vertices
+    ss_chained_scan<unsigned long long, SSOpPlus>(Widen{tcount}, SSStoreExcl32{tbase, n_mc}, n_mc, state2, (unsigned long long*)nullptr, mail2, st);  // mail2 = triangles
 }
 
 // 64-bit offsets of the tiles in the arena from the 32-bit bounds

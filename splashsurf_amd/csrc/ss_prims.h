@@ -41,6 +41,16 @@ __device__ __forceinline__ void ss_mail_post(const SSMailSlot& m, unsigned long 
 #define SS_SCAN_LARGE_N (1u << 20)
 inline size_t ss_scan_tile_of(size_t n) { return n <= SS_SCAN_SMALL_N ? SS_SCAN_TILE_SMALL : (n >= SS_SCAN_LARGE_N ? SS_SCAN_TILE_LARGE : SS_SCAN_TILE); }
 inline size_t ss_scan_state_words(size_t n) { return 2 + 2 * ((n + ss_scan_tile_of(n) - 1) / ss_scan_tile_of(n)) + 2; }
+// ss_scan_state_words is not monotone in n (the tile size changes at SS_SCAN_SMALL_N and SS_SCAN_LARGE_N: 132 words at n = 65536, 38 at 65537).
+// A caller that reserves the state before it knows the count uses this bound: max of ss_scan_state_words(m) over all m <= n.
+inline size_t ss_scan_state_words_bound(size_t n) {
+    size_t w = ss_scan_state_words(n);
+    if (n > SS_SCAN_SMALL_N) w = w > ss_scan_state_words(SS_SCAN_SMALL_N) ? w : ss_scan_state_words(SS_SCAN_SMALL_N);
+    if (n >= SS_SCAN_LARGE_N) w = w > ss_scan_state_words(SS_SCAN_LARGE_N - 1) ? w : ss_scan_state_words(SS_SCAN_LARGE_N - 1);
+    return w;
+}
+// The kernel indexes elements with 32 bits: the last tile's `base + r * NT + tid` must not wrap.
+#define SS_SCAN_MAX_N (0xFFFFFFFFull - (unsigned long long)SS_SCAN_TILE_LARGE)
 
 __device__ __forceinline__ uint32_t ss_prim_wave_incl_u32(uint32_t v) {
     int x = (int)v;
@@ -160,7 +170,7 @@ __global__ __launch_bounds__(NT) void k_chained_scan(In in, Out out, uint32_t n,
             const T incl_total = Op::template apply<T>(excl, tile_total);
             __hip_atomic_store(&status[tile], (2ull << 62) | (unsigned long long)incl_total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             s_excl = excl;
-            if (base + (uint32_t)TILE >= n) {  // the last tile knows the total
+            if ((unsigned long long)base + (unsigned long long)TILE >= (unsigned long long)n) {  // the last tile knows the total (64 bits: base + TILE may pass 2^32)
                 if (total_dev) *total_dev = incl_total;
                 ss_mail_post(mail, (unsigned long long)incl_total);
             }

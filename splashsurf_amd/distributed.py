@@ -620,7 +620,7 @@ class _DistInfo(C.Structure):
                 ("n_held", C.c_uint64), ("n_owned", C.c_uint64), ("bytes_sent_positions", C.c_uint64), ("bytes_sent_densities", C.c_uint64),
                 ("bytes_sent_assembly", C.c_uint64), ("ms_partition", C.c_double), ("ms_position_exchange", C.c_double), ("ms_density_exchange", C.c_double),
                 ("ms_assembly", C.c_double), ("ms_phase1", C.c_double), ("ms_phase2", C.c_double), ("ms_own_turns", C.c_double), ("n_vertices_owned", C.c_uint64), ("vertex_offset", C.c_uint64), ("n_vertices_total", C.c_uint64),
-                ("n_triangles", C.c_uint64), ("triangle_offset", C.c_uint64), ("n_triangles_total", C.c_uint64)]
+                ("n_triangles", C.c_uint64), ("triangle_offset", C.c_uint64), ("n_triangles_total", C.c_uint64), ("n_collectives", C.c_uint64), ("ms_device", C.c_double)]
 
 
 def _dist_lib(ctx):
@@ -635,6 +635,7 @@ def _dist_lib(ctx):
         L.ss_comm_destroy.argtypes = [vp]
         L.ss_comm_destroy.restype = None
         L.ss_comm_local_group_take_turns.argtypes = [vp, i32]
+        L.ss_comm_set_balance_feedback.argtypes = [vp, i32]
         L.ss_dist_reconstruct_f32.argtypes = [vp, vp, u64, C.POINTER(api._Params), vp]
         L.ss_dist_reconstruct_f64.argtypes = [vp, vp, u64, C.POINTER(api._Params64), vp]
         L.ss_dist_assemble.argtypes = [vp, vp]
@@ -690,6 +691,12 @@ class NativeComm:
             if st != 0:
                 raise RuntimeError("ss_comm_local_group_take_turns failed: %d" % st)
         return [cls(ctxs[q], C.c_void_p(out[q]), q, n, "local") for q in range(n)]
+
+    def set_balance_feedback(self, on=True):
+        """ss_comm_set_balance_feedback: from the second step on the bricks balance the cost measured in the previous step (time series)."""
+        st = self.ctx._lib.ss_comm_set_balance_feedback(self._h, 1 if on else 0)
+        if st != 0:
+            raise RuntimeError("ss_comm_set_balance_feedback failed: %d" % st)
 
     def destroy(self):
         if self._h:

@@ -27,7 +27,7 @@ from test_gpu_parity import assert_gpu_equals_oracle
 pytestmark = pytest.mark.gpu
 
 SIMD_FULL = ["simd_kat1", "simd_cube_2366_n16", "simd_config1_double_dam_break"]
-SIMD_DIGEST = ["simd_config1_n16", "simd_bunny_7705", "simd_config5_hilbert", "simd_tank_small"]
+SIMD_DIGEST = ["simd_config1_n16", "simd_bunny_7705", "simd_config5_hilbert", "simd_tank_small", "simd_config2_s1m"]
 
 
 def _run_gpu(ctx, pts, prm, simd):
