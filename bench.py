@@ -60,9 +60,10 @@ def parse():
     ap.add_argument("--collective-latency-us", type=float, default=25.0,
                     help="--pseudo-ranks: what one communication step between the ranks (a small all-gather, the histogram all-reduce, one grouped send/recv) is assumed "
                          "to cost on a real node in addition to its bytes; multiplied by the number of such steps the library counted (ss_dist_info.n_collectives)")
-    ap.add_argument("--no-balance-feedback", action="store_true",
-                    help="--pseudo-ranks / native N > 1: bricks balanced by particle count in every step (default: from the second step on by the cost measured in the previous one, "
-                         "ss_comm_set_balance_feedback)")
+    ap.add_argument("--balance-feedback", action="store_true",
+                    help="--pseudo-ranks / native N > 1: from the second step on the bricks balance the cost measured in the previous step (ss_comm_set_balance_feedback) instead of "
+                         "particle counts.  Off by default: bricks are whole subdomains, and on S40M-tank at 8 ranks no plane can move without making another rank the slowest "
+                         "(measured, profiles/r05_s40m_tank_pseudo_ranks_8*.json)")
     ap.add_argument("--exchange", choices=["auto", "native", "torch"], default="auto",
                     help="N > 1 transport of the halo exchange: the library's own RCCL path (ss_dist_*) or torch.distributed")
     ap.add_argument("--cpu-sample-scale", type=float, default=1.0, help="tank scale of the CPU-baseline sample (1.0 = the full 10 M workload)")
@@ -324,12 +325,12 @@ def pseudo_rank_run(args):
     def worker(q):
         try:
             pts, n_total, desc = local_share(args, wl, workload, W, q, world, r, full)
-            if not args.no_balance_feedback:
+            if args.balance_feedback:
                 comms[q].set_balance_feedback(True)
             native = D.NativeSharded(comms[q], prm)
             d_local = torch.from_numpy(pts).to(dev)
             torch.cuda.synchronize()
-            for _ in range(max(args.warmup, 1 if args.no_balance_feedback else 4)):  # (the feedback needs a few frames to settle)
+            for _ in range(max(args.warmup, 4 if args.balance_feedback else 1)):  # (the feedback needs a few frames to settle)
                 native.step(d_local)
                 native.assemble()
             timings, own, k3_ms, xbytes, last, n_coll = {}, [], [], 0, None, 0
@@ -403,7 +404,7 @@ def pseudo_rank_run(args):
             "exchange_transfer_ms_at_one_xgmi_link": round(xfer_ms, 3),
             "collective_steps": n_coll, "collective_latency_us_assumed": args.collective_latency_us, "collective_latency_ms": round(lat_ms, 3),
             "projected_step_ms": round(crit_ms + xfer_ms + lat_ms, 3),
-            "balance_feedback": not args.no_balance_feedback,
+            "balance_feedback": bool(args.balance_feedback),
             "note": "own_ms = time a rank held the device per step (all of its kernels, packing and host work; the ranks took turns); projected N-GPU step = "
                     "mean over the steps of the slowest rank's own time + the largest rank's exchange bytes over ONE 153 GB/s xGMI link + the number of communication "
                     "steps the library counted x an ASSUMED %.0f us each (no multi-GPU node was available: RCCL latencies are not measured); nothing of an exchange "
@@ -508,7 +509,7 @@ def main():
         if args.exchange in ("auto", "native"):
             try:
                 comm = D.NativeComm.rccl(ctx, rank=rank, world=world) if dist.is_initialized() or world == 1 else None
-                if comm is not None and not args.no_balance_feedback:
+                if comm is not None and args.balance_feedback:
                     comm.set_balance_feedback(True)
                 native = D.NativeSharded(comm, prm)
                 native.step(torch.from_numpy(pts).to(dev))  # first call doubles as the self-test of the RCCL plumbing

@@ -579,6 +579,19 @@ class SurfaceReconstruction:
         self._check(fn(self._h, lo_a, ex_a, out.ctypes.data_as(C.c_void_p)))
         return out
 
+    def certified_subblocks(self):
+        """ss_result_debug_certified (test aid): (masks[n_active] uint32, block_xyz[n_active, 3] uint32) -- the 4^3 sub-blocks the lower bound
+        certified inside the fluid and the splat never evaluated."""
+        n = C.c_uint64()
+        fn = self._lib.ss_result_debug_certified
+        fn.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]
+        self._check(fn(self._h, None, None, 0, C.byref(n)))
+        masks = np.zeros(int(n.value), dtype=np.uint32)
+        xyz = np.zeros((int(n.value), 3), dtype=np.uint32)
+        if n.value:
+            self._check(fn(self._h, masks.ctypes.data_as(C.c_void_p), xyz.ctypes.data_as(C.c_void_p), n.value, C.byref(n)))
+        return masks, xyz
+
     def subdomain_stats(self):
         a, b = C.c_uint64(), C.c_uint64()
         self._check(self._lib.ss_result_subdomain_stats(self._h, C.byref(a), C.byref(b)))

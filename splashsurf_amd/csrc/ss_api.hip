@@ -776,6 +776,7 @@ ss_status phase_begin(ss_context* ctx, const R* xyz, uint64_t n_in, const typena
     res->n_input = n_in;
     res->n_vertices = res->n_triangles = 0;
     res->n_active = res->n_mc = 0;
+    res->dbg_certified = nullptr;
 
     const bool host_input = n_in > 0 && xyz && !is_device_pointer(xyz);
     SS_HIP(ctx, hipEventRecord(ctx->ev[0], st));
@@ -1288,6 +1289,7 @@ ss_status phase_finish(ss_context* ctx, ss_result* res) {
 
     res->n_vertices = nv;
     res->n_triangles = nt;
+    res->dbg_certified = full_ls ? nullptr : tr_flag;
     ss_stats& S = res->stats;
     S.ms_total = ev_ms(ctx, 0, 4) + ev_ms(ctx, 10, 9);  // both phases (excludes what the host does between them)
     S.ms_upload = host_input ? ev_ms(ctx, 0, 1) : 0.0;
@@ -2125,6 +2127,23 @@ ss_status ss_result_levelset_box(ss_result* r, const int64_t lo[3], const int64_
 ss_status ss_result_levelset_box_f64(ss_result* r, const int64_t lo[3], const int64_t extent[3], double* out) {
     if (!r || !r->valid || !r->is_f64 || !lo || !extent || !out) return SS_ERR_INVALID_ARGUMENT;
     return levelset_box_impl<double>(r, lo, extent, out);
+}
+
+ss_status ss_result_debug_certified(ss_result* r, uint32_t* masks, uint32_t* block_xyz, uint64_t capacity, uint64_t* n_active) {
+    if (!r || !r->valid || !n_active || r->global_strategy) return SS_ERR_INVALID_ARGUMENT;
+    ss_context* ctx = r->ctx;
+    *n_active = r->n_active;
+    const uint64_t n = std::min<uint64_t>(capacity, r->n_active);
+    if (!n) return SS_OK;
+    if (!masks || !block_xyz) return SS_ERR_INVALID_ARGUMENT;
+    SS_HIP(ctx, hipSetDevice(ctx->device));
+    SS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (r->dbg_certified)
+        SS_HIP(ctx, hipMemcpy(masks, r->dbg_certified, n * 4, hipMemcpyDeviceToHost));
+    else
+        memset(masks, 0, n * 4);  // (every block was evaluated completely)
+    SS_HIP(ctx, hipMemcpy(block_xyz, r->active_xyz.p, n * 12, hipMemcpyDeviceToHost));
+    return SS_OK;
 }
 
 ss_status ss_result_subdomain_stats(ss_result* r, uint64_t* n_occupied, uint64_t* n_sub_particles) {

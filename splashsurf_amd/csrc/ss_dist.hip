@@ -991,6 +991,7 @@ ss_status dist_reconstruct(ss_comm* c, const R* xyz_in, uint64_t n_local, const 
     for (size_t i = 0; i < nsub; ++i) hist_d[i] = (double)h_hist[i];
     // partition feedback: a subdomain's particles weigh what a particle cost the rank that owned the subdomain in the previous call (identical on every
     // rank: the costs were all-gathered as integers); subdomains outside the previous bricks (the domain moved) keep weight 1
+    bool weighted = false;
     if (c->feedback && (int)c->cost_per_particle.size() == world && c->prev_bricks.size() == (size_t)world * 6 && c->prev_ns[0] == ns[0] && c->prev_ns[1] == ns[1] &&
         c->prev_ns[2] == ns[2]) {
         double mean = 0.0;
@@ -998,6 +999,7 @@ ss_status dist_reconstruct(ss_comm* c, const R* xyz_in, uint64_t n_local, const 
         for (int q = 0; q < world; ++q)
             if (c->cost_per_particle[q] > 0.0) mean += c->cost_per_particle[q], ++cnt;
         if (cnt) {
+            weighted = true;
             mean /= (double)cnt;
             for (int q = 0; q < world; ++q) {
                 const double w = c->cost_per_particle[q] > 0.0 ? std::min(4.0, std::max(0.25, c->cost_per_particle[q] / mean)) : 1.0;
@@ -1012,7 +1014,23 @@ ss_status dist_reconstruct(ss_comm* c, const R* xyz_in, uint64_t n_local, const 
     c->bricks.assign((size_t)world * 6, 0);
     {
         const int lo0[3] = {0, 0, 0};
-        rcb_split(hist_d, ns, lo0, ns, 0, world, pref, c->feedback ? 0.005 : 0.02, c->bricks);
+        rcb_split(hist_d, ns, lo0, ns, 0, world, pref, 0.02, c->bricks);
+    }
+    if (weighted) {
+        // hysteresis: bricks are whole subdomains, so a cut plane that flips between two frames moves several per cent of a rank's work and
+        // regrows every buffer of both ranks -- the previous bricks stay unless the weighted histogram predicts a clearly better maximum
+        auto worst = [&](const std::vector<int64_t>& b) {
+            double mx = 0.0;
+            for (int q = 0; q < world; ++q) {
+                double t = 0.0;
+                for (int64_t x = b[(size_t)q * 6]; x < b[(size_t)q * 6 + 3]; ++x)
+                    for (int64_t y = b[(size_t)q * 6 + 1]; y < b[(size_t)q * 6 + 4]; ++y)
+                        for (int64_t z = b[(size_t)q * 6 + 2]; z < b[(size_t)q * 6 + 5]; ++z) t += hist_d[((size_t)x * ns[1] + y) * ns[2] + z];
+                mx = std::max(mx, t);
+            }
+            return mx;
+        };
+        if (!(worst(c->bricks) < 0.97 * worst(c->prev_bricks))) c->bricks = c->prev_bricks;
     }
     const int64_t* my_lo = &c->bricks[(size_t)me * 6];
     const int64_t* my_hi = my_lo + 3;

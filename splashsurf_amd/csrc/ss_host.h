@@ -131,6 +131,7 @@ struct ss_result {
     bool has_inside = false;
     uint64_t n_input = 0, n_particles = 0, n_vertices = 0, n_triangles = 0;
     uint32_t n_active = 0, n_mc = 0;
+    const uint32_t* dbg_certified = nullptr;  // per active block: the certified, never evaluated sub-blocks (context scratch of the last call; ss_result_debug_certified)
     bool has_neighbors = false;
     uint64_t n_neighbors = 0;
     DevBuf nb_ptr, nb_idx, nb_idx64;

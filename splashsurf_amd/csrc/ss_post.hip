@@ -19,8 +19,6 @@
 #include <limits>
 #include <string>
 
-#include <rocprim/rocprim.hpp>
-
 #include "ss_host.h"
 #include "ss_kernels.h"
 
@@ -76,22 +74,47 @@ struct TmpBuf {
     }
 };
 
+// the library's own primitives (ss_prims.h): a single-dispatch chained scan and the 8-bit LSD pair sort
+template <class T>
+struct PostArrayIn {
+    const T* p;
+    __device__ T operator()(uint32_t i) const { return p[i]; }
+};
+template <class T>
+struct PostExclOut {
+    T* p;
+    __device__ void operator()(uint32_t i, T, T excl) const { p[i] = excl; }
+};
 template <class T>
 ss_status scan_exclusive(ss_context* ctx, const T* in, T* out, size_t n) {
-    size_t bytes = 0;
-    SS_HIP(ctx, rocprim::exclusive_scan(nullptr, bytes, in, out, (T)0, n, rocprim::plus<T>(), ctx->stream));
-    SS_HIP(ctx, ctx->temp.reserve(bytes));
-    SS_HIP(ctx, rocprim::exclusive_scan(ctx->temp.p, bytes, in, out, (T)0, n, rocprim::plus<T>(), ctx->stream));
+    if (n > SS_SCAN_MAX_N) return fail(ctx, SS_ERR_UNSUPPORTED, "more than 2^32 - 8193 entries in one prefix sum");
+    const size_t words = ss_scan_state_words(n);
+    SS_HIP(ctx, ctx->temp.reserve(words * 4));
+    SS_HIP(ctx, hipMemsetAsync(ctx->temp.p, 0, words * 4, ctx->stream));
+    ss_chained_scan<T, SSOpPlus>(PostArrayIn<T>{in}, PostExclOut<T>{out}, (uint32_t)n, ctx->temp.as<uint32_t>(), (T*)nullptr, SSMailSlot{}, ctx->stream);
     return SS_OK;
 }
 
+// stable sort of (key, value) pairs by key <= max_key into keys_out / vals_out; the inputs are left untouched (they may be the caller's arrays): the sort's
+// ping-pong buffers are the outputs and two scratch arrays, arranged so that the last pass writes the outputs
 ss_status sort_pairs_u32(ss_context* ctx, const uint32_t* keys_in, uint32_t* keys_out, const uint32_t* vals_in, uint32_t* vals_out, size_t n, uint64_t max_key) {
+    if (n == 0) return SS_OK;
+    if (n >= ((size_t)1 << 30)) return fail(ctx, SS_ERR_UNSUPPORTED, "more than 2^30 - 1 entries to sort in one post-processing call are not supported by this build");
     unsigned bits = 1;
     while (bits < 32 && ((uint64_t)1 << bits) <= max_key) ++bits;
-    size_t bytes = 0;
-    SS_HIP(ctx, rocprim::radix_sort_pairs(nullptr, bytes, keys_in, keys_out, vals_in, vals_out, n, 0u, bits, ctx->stream));
-    SS_HIP(ctx, ctx->temp.reserve(bytes));
-    SS_HIP(ctx, rocprim::radix_sort_pairs(ctx->temp.p, bytes, keys_in, keys_out, vals_in, vals_out, n, 0u, bits, ctx->stream));
+    const bool odd = (((bits + 7u) / 8u) & 1u) != 0u;
+    const size_t work_words = ss_radix_sort_work_words((uint32_t)n, bits);
+    SS_HIP(ctx, ctx->temp.reserve((2 * (n + 16) + work_words) * 4 + 64));
+    uint32_t* sk = ctx->temp.as<uint32_t>();
+    uint32_t* sv = sk + (n + 16);
+    uint32_t* work = sv + (n + 16);
+    // an odd number of passes ends in buffer 1, an even number in buffer 0: the outputs sit where the result lands, the input copies go into buffer 0
+    uint32_t* keys[2] = {odd ? sk : keys_out, odd ? keys_out : sk};
+    uint32_t* vals[2] = {odd ? sv : vals_out, odd ? vals_out : sv};
+    SS_HIP(ctx, hipMemcpyAsync(keys[0], keys_in, n * 4, hipMemcpyDeviceToDevice, ctx->stream));
+    SS_HIP(ctx, hipMemcpyAsync(vals[0], vals_in, n * 4, hipMemcpyDeviceToDevice, ctx->stream));
+    const int r = ss_radix_sort_pairs(keys, vals, (uint32_t)n, bits, false, work, false, ctx->stream);
+    if (keys[r] != keys_out || vals[r] != vals_out) return fail(ctx, SS_ERR_UNKNOWN, "internal error: sort result in an unexpected buffer");
     return SS_OK;
 }
 

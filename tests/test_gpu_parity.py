@@ -692,6 +692,25 @@ def test_u64_triangles_cross_pcie_as_u32(gpu_ctx):
     ctx_dev.close()
 
 
+def test_split_mc_offsets_gives_the_same_mesh(gpu_ctx):
+    """SS_OPTION_SPLIT_MC_OFFSETS: the vertex / triangle offsets of the marching-cubes blocks from two 64-bit prefix sums (the form jobs with more
+    than 838 860 surface blocks take) instead of one packed 31 + 31 bit sum: same mesh, bit for bit."""
+    import ctypes as C
+    import splashsurf_amd as S
+    from splashsurf_amd.api import Context
+    g = load_golden("config5_hilbert")
+    pts, prm = golden_input(g), golden_params(g)
+    a = run_gpu(gpu_ctx, pts, prm)
+    ctx2 = Context(0)
+    ctx2._lib.ss_context_set_option.argtypes = [C.c_void_p, C.c_int, C.c_int]
+    assert ctx2._lib.ss_context_set_option(ctx2._h, 4, 1) == 0  # SS_OPTION_SPLIT_MC_OFFSETS
+    b = run_gpu(ctx2, pts, prm)
+    assert a.counts() == b.counts() and a.counts()[0] > 100000
+    assert np.array_equal(a.mesh.vertices.view(np.uint32), b.mesh.vertices.view(np.uint32))
+    assert np.array_equal(a.mesh.triangles_u32, b.mesh.triangles_u32) and np.array_equal(a.vertex_keys, b.vertex_keys)
+    ctx2.close()
+
+
 @pytest.mark.gpu
 def test_hbm_bandwidth_probe_reports_plausible_rates():
     """ss_measure_hbm_bandwidth (the denominator of roofline.frac_of_measured_peak): a float4 read stream and a float4 copy over
