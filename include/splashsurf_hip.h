@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define SS_ABI_VERSION 4
+#define SS_ABI_VERSION 5
 
 /* Return codes; 1..4 mirror ReconstructionError (lib.rs:289-314). */
 typedef enum ss_status {
@@ -166,6 +166,8 @@ typedef struct ss_stats {
     double ms_density_kernel;         /* part of ms_density: k_density_sub (the neighbourhood search + SPH sums themselves) */
     double ms_mc_count;               /* part of ms_marching_cubes: k_mc_count (classification, crossing masks, counts) */
     double ms_mc_emit;                /* part of ms_marching_cubes: k_mc_emit (vertices, keys, triangles) */
+    uint64_t n_host_waits;            /* points of the call at which the host waited for the device before it could enqueue more work: counts polled from
+                                       * mail slots (waits on slots that are posted together count once), device-to-host copies of a count, the final drain */
 } ss_stats;
 
 typedef struct ss_context ss_context;

@@ -120,6 +120,7 @@ class _Stats(C.Structure):
         ("ms_density_kernel", C.c_double),
         ("ms_mc_count", C.c_double),
         ("ms_mc_emit", C.c_double),
+        ("n_host_waits", C.c_uint64),
     ]
 
 
@@ -206,7 +207,7 @@ def load_library():
     L.ss_result_grid_f64.argtypes = [vp, P(_Grid64)]
     L.ss_result_subdomain_grid_f64.argtypes = [vp, P(_Grid64), P(i32)]
     L.ss_result_levelset_box_f64.argtypes = [vp, P(C.c_int64), P(C.c_int64), vp]
-    if L.ss_abi_version() != 4:
+    if L.ss_abi_version() != 5:
         raise ImportError("libsplashsurf_hip.so ABI version mismatch")
     _lib = L
     return L

@@ -159,7 +159,9 @@ ss_status ensure_mail(ss_context* ctx) {
 SSMailSlot mail_slot(ss_context* ctx, int k) { return SSMailSlot{ctx->mail_dev + 2 * k, ++ctx->mail_seq}; }
 // Waits until the kernel holding `m` has posted: the host polls the pinned word instead of synchronising the stream (the stream goes on with
 // whatever was enqueued behind that kernel).  A drained stream without the value, a stream error or 120 s end the wait with an error.
-ss_status mail_wait(ss_context* ctx, const SSMailSlot& m, unsigned long long* value) {
+// `grouped`: the slot is posted together with the one waited for just before (one blocking point, counted once)
+ss_status mail_wait(ss_context* ctx, const SSMailSlot& m, unsigned long long* value, bool grouped = false) {
+    if (!grouped) ++ctx->host_waits;
     const int k = (int)((m.p - ctx->mail_dev) / 2);
     volatile unsigned long long* h = ctx->mail_host + 2 * k;
     const auto t0 = std::chrono::steady_clock::now();
@@ -451,6 +453,7 @@ ss_status stage_particles(ss_context* ctx, const R* xyz, uint64_t n_in, const ty
     uint32_t cnt = 0;
     SS_HIP(ctx, hipMemcpyAsync(&cnt, ctx->offsets.as<uint32_t>() + n_in, 4, hipMemcpyDeviceToHost, st));
     SS_HIP(ctx, hipStreamSynchronize(st));
+    ++ctx->host_waits;
     SS_HIP(ctx, ctx->xyz_filt.reserve((size_t)cnt * 3 * sizeof(R) + 16));
     ss_launch_compact_xyz(d_xyz, (uint32_t)n_in, ctx->flags32.as<uint32_t>(), ctx->offsets.as<uint32_t>(), ctx->xyz_filt.as<R>(), st);
     *d_used = ctx->xyz_filt.as<R>();
@@ -752,6 +755,7 @@ static ss_status ensure_fast_div(ss_context* ctx, R h, hipStream_t st) {
             ss_launch_verify_fast_div(h, R(1.0) / h, ctx->fastdiv_scratch.as<uint32_t>(), st);
             SS_HIP(ctx, hipMemcpyAsync(&bad, ctx->fastdiv_scratch.p, 4, hipMemcpyDeviceToHost, st));
             SS_HIP(ctx, hipStreamSynchronize(st));
+            ++ctx->host_waits;  // (once per distinct h and context)
             ctx->fastdiv_ok = (bad == 0);
         }
         ctx->fastdiv_h = h;
@@ -777,6 +781,7 @@ ss_status phase_begin(ss_context* ctx, const R* xyz, uint64_t n_in, const typena
     res->n_vertices = res->n_triangles = 0;
     res->n_active = res->n_mc = 0;
     res->dbg_certified = nullptr;
+    ctx->host_waits = 0;
 
     const bool host_input = n_in > 0 && xyz && !is_device_pointer(xyz);
     SS_HIP(ctx, hipEventRecord(ctx->ev[0], st));
@@ -909,7 +914,7 @@ ss_status phase_begin(ss_context* ctx, const R* xyz, uint64_t n_in, const typena
         unsigned long long v_copies = 0, v_occ = 0;
         s = mail_wait(ctx, m_copies, &v_copies);
         if (s != SS_OK) return s;
-        s = mail_wait(ctx, m_occ, &v_occ);
+        s = mail_wait(ctx, m_occ, &v_occ, true);
         if (s != SS_OK) return s;
         if (v_copies >= (1ull << 30)) return fail(ctx, SS_ERR_UNSUPPORTED, "more than 2^30 - 1 (particle, subdomain) pairs in one call are not supported by this build");
         const uint32_t n_copies = (uint32_t)v_copies, n_occ = (uint32_t)v_occ;
@@ -986,6 +991,7 @@ ss_status phase_begin(ss_context* ctx, const R* xyz, uint64_t n_in, const typena
                 unsigned long long total_nb = 0;
                 SS_HIP(ctx, hipMemcpyAsync(&total_nb, res->nb_ptr.as<unsigned long long>() + n, 8, hipMemcpyDeviceToHost, st));
                 SS_HIP(ctx, hipStreamSynchronize(st));
+                ++ctx->host_waits;
                 if (total_nb >= (1ull << 32)) return fail(ctx, SS_ERR_UNSUPPORTED, "more than 2^32 neighbour entries");
                 res->n_neighbors = total_nb;
                 SS_HIP(ctx, res->nb_idx.reserve((size_t)total_nb * 4 + 16));
@@ -1252,19 +1258,19 @@ ss_status phase_finish(ss_context* ctx, ss_result* res) {
     unsigned long long v_tot = 0, n_cand = 0, n_trunc_left = 0, n_cert_waves = 0, v_misc = 0;
     s = mail_wait(ctx, m_tot, &v_tot);
     if (s != SS_OK) return s;
-    s = mail_wait(ctx, m_stat0, &n_cand);
+    s = mail_wait(ctx, m_stat0, &n_cand, true);
     if (s != SS_OK) return s;
-    s = mail_wait(ctx, m_stat1, &n_trunc_left);
+    s = mail_wait(ctx, m_stat1, &n_trunc_left, true);
     if (s != SS_OK) return s;
-    s = mail_wait(ctx, m_stat2, &n_cert_waves);
+    s = mail_wait(ctx, m_stat2, &n_cert_waves, true);
     if (s != SS_OK) return s;
-    s = mail_wait(ctx, m_stat3, &v_misc);  // n_redo | n_large << 24 | err << 56 ... see k_publish_stats
+    s = mail_wait(ctx, m_stat3, &v_misc, true);  // n_redo | n_large << 24 | err << 56 ... see k_publish_stats
     if (s != SS_OK) return s;
     const uint32_t n_redo = (uint32_t)(v_misc & 0xFFFFFFFull), n_large = (uint32_t)((v_misc >> 28) & 0xFFFFFFFull), h_err = (uint32_t)(v_misc >> 56);
     uint64_t nv = v_tot & 0x7FFFFFFFull, nt = v_tot >> 31;
     if (split_offsets) {
         unsigned long long v_tot2 = 0;
-        s = mail_wait(ctx, m_tot2, &v_tot2);
+        s = mail_wait(ctx, m_tot2, &v_tot2, true);
         if (s != SS_OK) return s;
         nv = v_tot;
         nt = v_tot2;
@@ -1282,6 +1288,7 @@ ss_status phase_finish(ss_context* ctx, ss_result* res) {
                       res->vkeys.as<unsigned long long>(), res->tri32.as<uint32_t>(), st);
     SS_HIP(ctx, hipEventRecord(ctx->ev[9], st));
     SS_HIP(ctx, hipStreamSynchronize(st));
+    ++ctx->host_waits;  // the final drain
     {
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return fail(ctx, SS_ERR_DEVICE, std::string("kernel launch failed: ") + hipGetErrorString(e));
@@ -1321,6 +1328,7 @@ ss_status phase_finish(ss_context* ctx, ss_result* res) {
     S.ms_density_kernel = res->density_kernel_timed ? ev_ms(ctx, 18, 19) : 0.0;
     S.ms_mc_count = ev_ms(ctx, 20, 21);
     S.ms_mc_emit = ev_ms(ctx, 8, 9);
+    S.n_host_waits = ctx->host_waits;
     S.n_certified_subblocks = n_cert_waves;
     S.n_truncated_blocks = n_trunc_left;
     S.n_completed_blocks = n_redo;

@@ -104,6 +104,7 @@ struct ss_context {
     unsigned long long* mail_host = nullptr;
     unsigned long long* mail_dev = nullptr;
     unsigned long long mail_seq = 0;
+    uint64_t host_waits = 0;  // blocking points of the current call (ss_stats::n_host_waits)
     // second stream (experiment, SPLASH_K1_OVERLAP=1): the splat-cell sort (K1, bandwidth-bound) beside the density kernel (bound by the vector L1 / VALU).
     // Measured: S10M-tank 9.62 against 9.67 ms per step, S10M-cube 20.9 / 21.2 -- the K1 chain stretches from 0.41 to 1.33 ms, the density kernel from 0.96
     // to 1.00 ms: the device is busy either way.  Off by default (one stream, K1 first).

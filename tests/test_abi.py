@@ -19,7 +19,7 @@ def test_library_exports_all_declared_symbols():
     for s in syms:
         assert hasattr(L, s), s
     L.ss_abi_version.restype = ctypes.c_int
-    assert L.ss_abi_version() == 4  # SS_ABI_VERSION in include/splashsurf_hip.h
+    assert L.ss_abi_version() == 5  # SS_ABI_VERSION in include/splashsurf_hip.h
 
 
 def test_struct_layouts_match_header():
@@ -28,7 +28,7 @@ def test_struct_layouts_match_header():
     assert ctypes.sizeof(api._Grid) == 28 + 4 + 48  # 7 floats + pad + 6 int64
     # + gather/accumulate timings, large-tile block count (ABI 2), arithmetic mode and arena bytes used / reserved (ABI 3), MC block count and the
     # density / MC kernel timers (ABI 4)
-    assert ctypes.sizeof(api._Stats) == 9 * 8 + 8 * 8 + 3 * 8 + 7 * 8 + 4 * 8
+    assert ctypes.sizeof(api._Stats) == 9 * 8 + 8 * 8 + 3 * 8 + 7 * 8 + 4 * 8 + 8
 
 
 def test_python_signature_mirrors_reference():

@@ -21,7 +21,7 @@ def main():
     ap.add_argument("--workload", default="s10m_tank")
     ap.add_argument("--steps", type=int, default=6)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--simd", type=int, default=1)
+    ap.add_argument("--simd", type=int, default=0, help="Parameters::enable_simd (default 0: the mode bench.py measures)")
     ap.add_argument("--tag", default=os.path.basename(os.environ.get("SPLASHSURF_HIP_LIB", "in-tree")))
     ap.add_argument("--cube-size", type=float, default=None, help="override the workload's radius-relative cube size")
     ap.add_argument("--two-pass", type=int, default=None)
