@@ -37,7 +37,7 @@ def _params(r, l, c, n_cubes, dt, simd):
                       enable_simd=simd)
 
 
-def _run_ranks(pts, prm, world, transport="local", take_turns=False):
+def _run_ranks(pts, prm, world, transport="local", take_turns=False, feedback=False, steps=2):
     """Returns per-rank dicts (info, partition, gids, rho, mesh piece).  Rank r contributes the r-th contiguous slice of pts."""
     from splashsurf_amd import distributed as D
     from splashsurf_amd.api import Context
@@ -48,8 +48,10 @@ def _run_ranks(pts, prm, world, transport="local", take_turns=False):
 
     def worker(q):
         try:
+            if feedback:
+                comms[q].set_balance_feedback(True)
             sh = D.NativeSharded(comms[q], prm)
-            for _ in range(2):  # the second step reuses every buffer
+            for _ in range(steps):  # the second step reuses every buffer
                 res = sh.step(np.ascontiguousarray(pts[cut[q]:cut[q + 1]]))
                 info = sh.assemble()
             out[q] = dict(info=info, partition=sh.partition(), gids=sh.global_ids(), rho=res.particle_densities.copy(), piece=sh.mesh_piece(),
@@ -143,6 +145,20 @@ def test_native_full_s40m_tank_four_ranks(gpu_ctx):
         i = r["info"]
         assert i["ms_phase1"] > 0.0 and i["ms_phase2"] > 0.0
         assert 0.0 < i["ms_own_turns"] < i["ms_partition"] + i["ms_position_exchange"] + i["ms_phase1"] + i["ms_density_exchange"] + i["ms_phase2"] + i["ms_assembly"]
+
+
+def test_native_partition_feedback_keeps_the_mesh(gpu_ctx):
+    """ss_comm_set_balance_feedback: from the second step on the bricks are balanced by the cost every rank measured in the previous step (with
+    hysteresis).  Whatever partition comes out, it is the same on every rank, tiles the subdomain grid, and the merged mesh and densities equal the
+    single-context reconstruction bit for bit; the step counts its ten communication steps."""
+    pts, r, l, c, n_cubes = _case("tank_crop")
+    pts = np.ascontiguousarray(pts, dtype=np.float32)
+    prm = _params(r, l, c, 16, np.float32, 0)  # 16-cell subdomains: enough of them for the weights to move a plane
+    ranks = _run_ranks(pts, prm, 4, take_turns=True, feedback=True, steps=5)
+    _check_against_direct(pts, prm, ranks, gpu_ctx)
+    for r_ in ranks:
+        assert r_["info"]["n_collectives"] == 10
+        assert r_["info"]["ms_device"] > 0.0
 
 
 def test_native_more_ranks_than_subdomains(gpu_ctx):

@@ -692,6 +692,19 @@ def test_u64_triangles_cross_pcie_as_u32(gpu_ctx):
     ctx_dev.close()
 
 
+def test_host_waits_are_counted(gpu_ctx):
+    """ss_stats.n_host_waits: the blocking points of a call (counts polled from mail slots, the final drain).  A plain subdomain-grid call on
+    device-resident particles has seven (bounding box; copies + occupied subdomains; active blocks; over-dense blocks; MC blocks; totals;
+    drain), one more per over-dense arena, list regrowth or first use of a new h."""
+    import torch
+    g = load_golden("config5_hilbert")
+    pts, prm = golden_input(g), golden_params(g)
+    d = torch.from_numpy(np.ascontiguousarray(pts)).to("cuda:0")
+    run_gpu(gpu_ctx, d, prm)  # (sizes the lists, verifies the division for this h)
+    res = run_gpu(gpu_ctx, d, prm)
+    assert 7 <= res.stats["n_host_waits"] <= 8, res.stats["n_host_waits"]
+
+
 def test_split_mc_offsets_gives_the_same_mesh(gpu_ctx):
     """SS_OPTION_SPLIT_MC_OFFSETS: the vertex / triangle offsets of the marching-cubes blocks from two 64-bit prefix sums (the form jobs with more
     than 838 860 surface blocks take) instead of one packed 31 + 31 bit sum: same mesh, bit for bit."""
