@@ -143,6 +143,9 @@ def cpu_baseline(workload, scale):
     base["reference_measured_elsewhere"] = {
         "wheel_8_vcpu": "the reference's own wheel (AVX2+FMA, rayon) on the survey container's 8 vCPU Xeon @ 2.1 GHz: 0.57 Mparticles/s on a 1.25 M-particle crop of this "
                         "workload, 0.166 on S1M (BASELINE.md section 2) -- cannot run on the GPU box (no reference there)",
+        "wheel_8_vcpu_this_workload": "the FULL S10M-tank through the reference's wheel on the build container's 8 CPUs (tools/gen_goldens_fullsize.py, "
+                                      "tests/golden/FULLSIZE_REPORT.json): 28.7 s with simd=False = 0.35 Mparticles/s, 9.5 s with simd=True = 1.06 Mparticles/s; this port "
+                                      "takes 28.5 s there (scalar): per core it is the reference's speed, it scales worse over many cores (serial binning / stitching)",
         "readme_m4_pro_14_cores": "5.80 Mparticles/s, 13.4 M particles (README.md:203): the only published figure",
         "note": "reported baselines, not targets: the GPU / CPU ratio says nothing about kernel quality, the roofline fraction does"}
     return base
