@@ -10,11 +10,6 @@
 #include "ss_prims.h"
 
 #define RS_ROUNDS 16  // pairs per thread
-// -DSS_RS_ABLATE=n (tools/build_variant.sh): timing experiments that switch ONE part of k_rs_pass off (the output is then wrong): 1 no look-back,
-// 2 no ranking rounds, 3 no value staging / writes, 4 no global writes at all, 5 no key / value loads
-#ifndef SS_RS_ABLATE
-#define SS_RS_ABLATE 0
-#endif
 
 // Digit histograms of all passes.  The keys of a wave often agree in their high digits (spatially coherent input): LDS atomics of all 64
 // lanes on one counter serialise, so every group of lanes with the same (lane & 7) has its own copy of the counters (8-way instead of
@@ -88,13 +83,8 @@ __global__ __launch_bounds__(NT) void k_rs_pass(const uint32_t* __restrict__ kin
 #pragma unroll
     for (int r = 0; r < RS_ROUNDS; ++r) {
         const size_t i = base + (size_t)(r * 64 + lane);
-#if SS_RS_ABLATE == 5
-        k[r] = (uint32_t)i * 2654435761u;
-        v[r] = (uint32_t)i;
-#else
         k[r] = (i < (size_t)n) ? kin[i] : 0xFFFFFFFFu;
         v[r] = (i < (size_t)n) ? (vin ? vin[i] : (uint32_t)i) : 0u;
-#endif
     }
     const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
 #pragma unroll
@@ -102,11 +92,6 @@ __global__ __launch_bounds__(NT) void k_rs_pass(const uint32_t* __restrict__ kin
         const size_t i = base + (size_t)(r * 64 + lane);
         const bool valid = i < (size_t)n;
         const uint32_t d = (k[r] >> shift) & 255u;
-#if SS_RS_ABLATE == 2
-        rk[r] = (uint16_t)lane;
-        if (valid && lane == 0) s_cnt[wave][d] += 64u;
-        continue;
-#endif
         unsigned long long peers = __ballot(valid);
 #pragma unroll
         for (int b = 0; b < 8; ++b) {
@@ -139,7 +124,7 @@ __global__ __launch_bounds__(NT) void k_rs_pass(const uint32_t* __restrict__ kin
         }
         // look-back over the preceding tiles' counts of digit d: flags (bits 31:30) 0 not there yet, 1 count of that tile, 2 count of all tiles up to it
         const uint32_t VALUE = (1u << 30) - 1u;
-        if (tile > 0 && SS_RS_ABLATE != 1) {
+        if (tile > 0) {
             __hip_atomic_store(&status[(size_t)tile * 256u + (size_t)tid], (1u << 30) | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             long long p = (long long)tile - 1;
             while (true) {
@@ -154,9 +139,6 @@ __global__ __launch_bounds__(NT) void k_rs_pass(const uint32_t* __restrict__ kin
                 --p;
             }
         }
-#if SS_RS_ABLATE == 1
-        prev = tile * total;  // (about right for uniformly distributed digits: the writes keep their pattern)
-#endif
         __hip_atomic_store(&status[(size_t)tile * 256u + (size_t)tid], (2u << 30) | (prev + total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     // (the block-wide prefix sums run over the first 256 threads' values; the other threads contribute zeros)
@@ -188,19 +170,10 @@ __global__ __launch_bounds__(NT) void k_rs_pass(const uint32_t* __restrict__ kin
             const uint32_t key = s_stage[s];
             const uint32_t d = (key >> shift) & 255u;
             g[j] = (size_t)s_gbase[d] + (size_t)(s - s_lbase[d]);
-#if SS_RS_ABLATE == 1 || SS_RS_ABLATE == 2
-            if (g[j] >= (size_t)n) g[j] = (size_t)n - 1;  // (the ablated offsets may point anywhere)
-#endif
-#if SS_RS_ABLATE != 4
             kout[g[j]] = key;
-#endif
         }
     }
     __syncthreads();
-#if SS_RS_ABLATE == 3
-    if (tile_n == 0xFFFFFFFFu) vout[0] = v[0] + pos[0];
-    return;
-#endif
 #pragma unroll
     for (int r = 0; r < RS_ROUNDS; ++r) {
         const size_t i = base + (size_t)(r * 64 + lane);
@@ -210,11 +183,7 @@ __global__ __launch_bounds__(NT) void k_rs_pass(const uint32_t* __restrict__ kin
 #pragma unroll
     for (int j = 0; j < RS_ROUNDS; ++j) {
         const uint32_t s = (uint32_t)(j * NT + tid);
-#if SS_RS_ABLATE == 4
-        if (s < tile_n && s_stage[s] == 0xFFFFFFFEu) vout[g[j]] = s_stage[s];
-#else
         if (s < tile_n) vout[g[j]] = s_stage[s];
-#endif
     }
 }
 
