@@ -52,8 +52,12 @@ def main():
     keys = ["ms_total", "ms_decomposition", "ms_density", "ms_levelset_prepare", "ms_levelset", "ms_levelset_gather", "ms_levelset_accumulate", "ms_levelset_accumulate_pass2",
             "ms_marching_cubes", "ms_stitching", "ms_density_kernel", "ms_mc_count", "ms_mc_emit"]
     acc = {k: [] for k in keys}
+    import time
+    wall = []
     for _ in range(a.steps):
-        out = ctx.reconstruct(d, prm, out=out)
+        t0 = time.perf_counter()
+        out = ctx.reconstruct(d, prm, out=out)  # (returns with the stream drained)
+        wall.append((time.perf_counter() - t0) * 1e3)
         s = out.stats
         for k in keys:
             acc[k].append(s.get(k, 0.0))
@@ -61,6 +65,8 @@ def main():
     line = {"tag": a.tag, "workload": a.workload, "simd": a.simd, "n": int(pts.shape[0])}
     line.update({k: round(float(np.median(v)), 4) for k, v in acc.items()})
     line["ms_total_min"] = round(float(np.min(acc["ms_total"])), 4)
+    line["ms_wall"] = round(float(np.median(wall)), 4)
+    line["n_host_waits"] = int(s.get("n_host_waits", 0))
     na = max(int(s.get("n_active_blocks", 0)), 1)
     line.update(n_active=int(s.get("n_active_blocks", 0)), certified_frac=round(float(s.get("n_certified_subblocks", 0)) / (8.0 * na), 4),
                 n_completed=int(s.get("n_completed_blocks", 0)), n_mc=int(s.get("n_mc_blocks", 0)), n_large=int(s.get("n_large_tile_blocks", 0)), n_vertices=int(s["n_vertices"]), n_triangles=int(s["n_triangles"]))
