@@ -8,9 +8,11 @@ lib.rs:330-337, dense_subdomains.rs:784-847 scalar, :991-1133 + :1413-1415 SIMD)
     (sha256 over the canonical forms), sampled vertices within 1e-5 relative (north_star);
   * enable_simd = 1 (uniform AVX arithmetic, include/splashsurf_hip.h): the mesh equals the digest of that arithmetic, and its relation to
     the wheel's `simd=True` mesh is the STORED, COUNTED difference -- removing the stored library-only ids / triangles and adding the stored
-    reference-only ones reproduces the wheel's digests.  At 7.18 M vertices that difference is 1 vertex and 13 / 11 triangles around two
-    grid points whose level-set value lies within 1e-6 relative of the threshold (the reference's own two modes differ from each other in
-    312 ids and 2 700 triangles on this input; FULLSIZE_REPORT.json).
+    reference-only ones reproduces the wheel's digests.  At 7.18 M vertices that difference is 1 vertex and 13 / 11 triangles at two grid
+    points: (197, 810, 640), whose value equals the threshold to the last bit and which lies on a subdomain face -- the reference's two
+    adjacent subdomains compute it with different lanes and disagree about its side --, and (1610, 92, 1598), a vertex 8e-4 of a cell from
+    the grid point that the geometric canonicalisation files under "grid point" for one mesh and "edge" for the other (the reference's own
+    two modes differ from each other in 312 ids and 2 700 triangles on this input; FULLSIZE_REPORT.json).
 """
 import hashlib
 
