@@ -303,6 +303,10 @@ class ShardedReconstruction {
         if (res_) ss_result_free(res_);
     }
 
+    // Time series: balance the bricks by the cost every rank measured in the previous frame instead of particle counts (with hysteresis; every
+    // rank of the job sets the same value; the mesh does not depend on the partition).
+    void set_balance_feedback(bool on) { check(ss_comm_set_balance_feedback(comm_, on ? 1 : 0)); }
+
     // Reconstruction of this rank's brick plus the global numbering of the mesh.  Returns the job's bookkeeping: brick, particle
     // counts, this rank's vertex / triangle offsets in the global mesh, bytes sent.
     template <class R>
