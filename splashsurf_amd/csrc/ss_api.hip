@@ -295,6 +295,13 @@ ss_status make_device_params(ss_context* ctx, const typename TypesOf<R>::params*
         const double eps = std::ldexp(1.0, (int)std::floor(std::log2(emax)) - 11);  // half an f16 ulp of emax's binade
         P.bound_one = (R)std::max(0.0, 1.0 - (3.6 * eps + 3.0 * eps * eps + 2.0e-6));  // 2 sqrt(3) = 3.47
     }
+    {   // splat_cert_record (ss_kernels.hip): slack of the f16 operands of the certificate's tiles.  xm: largest |coordinate| of a block's points
+        // relative to the block's centre, in units of h.
+        const double xm = 3.5 * (double)prm->cube_size / (double)h * (1.0 + 1.0e-5) + 1.0e-6;
+        const double r = std::ldexp(1.0, -10) * (1.0 + std::ldexp(1.0, -10));
+        P.cert_e1 = (R)(r * 2.0 * xm * (1.0 + 1.0e-6));
+        P.cert_e0 = (R)((r * 3.0 * xm * xm + 3.0e-5) * (1.0 + 1.0e-6));
+    }
     {   // CubicSplineKernelAvxF32::new (kernel.rs:327-337), in f32 like the reference
         const float hf = (float)h;
         const float pi_f = 3.14159265358979323846f;
@@ -304,6 +311,7 @@ ss_status make_device_params(ss_context* ctx, const typename TypesOf<R>::params*
         P.avx_sigma2 = (R)(2.0f * sig);
         P.avx_sigma6 = (R)(6.0f * sig);
         P.avx_sigma12 = (R)(12.0f * sig);
+        P.cert_vscale = (R)((double)0.76293 * (double)sig * (1.0 - 2.0e-5));  // C4 sigma: the bound C4 u^4 <= W / sigma (SS_CERT_C4), rounded down
     }
     double ncells = 1.0, nblocks = 1.0;
     {   // splat cells (ss_device.h): edge e = 8 / sk grid cells, aligned with the block lattice.  In units of cs relative to a block's first

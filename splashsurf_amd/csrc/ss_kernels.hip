@@ -910,7 +910,7 @@ __device__ __forceinline__ uint32_t ss_wave_inclusive_scan(uint32_t v) {
 #ifndef SS_FUSED_BAIL
 #define SS_FUSED_BAIL 3
 #endif
-template <class R, class F>
+template <class R, bool NEED_ID, class F>
 __device__ __forceinline__ void splat_wave_scan_grouped(const SSDevT<R>& P, const ss_real4<R>* __restrict__ posvol, const uint32_t* __restrict__ perm,
                                                         const uint32_t* __restrict__ cell_start, uint32_t key0, const R plo[3], const R phi[3],
                                                         uint32_t* s_row_start, uint32_t* s_row_prefix, int lane, uint32_t bail_total, uint32_t* bailed, F f) {
@@ -950,7 +950,7 @@ __device__ __forceinline__ void splat_wave_scan_grouped(const SSDevT<R>& P, cons
 #pragma unroll
             for (int j = 0; j < SS_SCAN_GROUP; ++j) {
                 pv[j] = posvol[src[j]];
-                id[j] = perm[src[j]];
+                id[j] = NEED_ID ? perm[src[j]] : 0u;
             }
 #pragma unroll
             for (int j = 0; j < SS_SCAN_GROUP; ++j) {
@@ -1703,22 +1703,71 @@ __device__ __forceinline__ float splat_bound_walk(const SSDevT<float>& P, const 
     return acc;
 }
 
-// One sub-block's list built on its own (blocks whose eight lists do not fit the pool together), then walked.
-__device__ __forceinline__ float splat_bound_single(const SSDevT<float>& P, const ss_real4<float>* pay, const uint8_t* near, uint2* pool, int n_tile, int lane,
-                                                    float cx, float cy, float cz, float npx, float npy, float npz, int sb, int* n_near) {
-    ss_wave_lds_sync();  // the previous sub-block's reads of the pool are done
-    int total = 0;
-    for (int base = 0; base < n_tile; base += 64) {
-        const int c = base + lane;
-        const bool pass = c < n_tile && ((near[c] >> sb) & 1u);
-        const unsigned long long m = __ballot(pass);
-        if (pass) pool[total + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] = splat_bound_record(P, pay[c], cx, cy, cz);
-        total += __popcll(m);
-    }
-    *n_near = total;
-    if (lane < 4) pool[total + lane] = SS_BOUND_DUMMY;
-    ss_wave_lds_sync();
-    return splat_bound_walk(P, pool, total, npx, npy, npz);
+// ---- the certificate on the MATRIX PIPE (f32, one wave per block; round 6) -----------------------------------------------------
+// The bound  W(q) / sigma >= C4 u^4,  u = max(1 - q^2, 0):  for q >= 1/2 the ratio 2 (1 - q)^3 / (1 - q^2)^4 = 2 / ((1 - q) (1 + q)^4) has its
+// minimum 0.762939... at q = 3/5, the inner piece stays above it (tests/test_oracle.py checks the inequality); it carries 90.2 % of the
+// kernel's mass (the polynomial u^3 (c0 + c1 u^2) of splat_bound_walk: 95.9 %).  It is HOMOGENEOUS in u, so a particle's weight folds
+// into the argument,  V sigma C4 u^4 = (s u)^4  with  s = (C4 sigma V)^(1/4),  and
+//     s u = s (1 - |p|^2) + 2 s p . x - s |x|^2        (p: entry, x: grid point; relative to the block's centre, in units of h)
+// is BILINEAR in a vector of the entry and a vector of the point: ONE v_mfma_f32_32x32x8_f16 evaluates it for 32 entries x 32 points,
+//     slot           0          1          2        3     |    4        5       6      7
+//     entry  (A)  (s a)_hi   (s a)_lo    2 s px    -s     |  2 s py   2 s pz    -s     -s          a = 1 - |p|^2 - eps
+//     point  (B)     1          1          x       x^2    |    y        z      y^2    z^2
+// (lanes 0-31 hold slots 0-3 of row / column `lane`, lanes 32-63 slots 4-7 of row / column `lane - 32`; D: column = lane & 31, row =
+// (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5); layout and rates: tools/ubench/mfma_cert.hip), and THREE VALU instructions per (entry, point)
+// pair are left -- max with 0 (an integer max on the bit pattern: no canonicalisation), a square, an fmac of the square with itself --
+// against the eleven of splat_bound_walk: 150 cycles per 1024 pairs per SIMD instead of ~480 (mfma_cert.hip; the matrix pipe's 32
+// cycles do not overlap the VALU's on this chip, they add).
+// STILL A LOWER BOUND: the products of f16 operands are exact and summed in f32; against the f32 values an operand rounded to nearest is off by
+// 2^-11 relative, so  |P~ x~ - 2 s p x| <= 2 s |p| |x| 2^-10 (1 + 2^-11)  per axis and  |s~ (x^2)~ - s x^2| <= s x^2 2^-10 (1 + 2^-11);
+// (s a)_hi + (s a)_lo = s a up to 2^-22.  With xm >= |x| per axis (the block's points: 3.5 cs / h)
+//     eps = 2^-10 (1 + 2^-10) (2 xm (|px| + |py| + |pz|) + 3 xm^2) + 3e-5        (P.cert_e1 (|px| + |py| + |pz|) + P.cert_e0)
+// taken off a makes the computed value <= s u for every point of the block; the 3e-5 cover the f32 roundings of the operands'
+// own computation, the accumulation inside the instruction (eight products of magnitude < 10) and f16 subnormals.  s itself is a
+// factor of the whole term: its rounding (v_sqrt_f32 twice, <= 3 ulp) is inside P.cert_vscale = C4 sigma (1 - 2e-5).
+typedef _Float16 ss_half4v __attribute__((ext_vector_type(4)));
+typedef float ss_float16v __attribute__((ext_vector_type(16)));
+#define SS_CERT_C4 0.76293f
+#ifndef SS_CERT_POOL
+#define SS_CERT_POOL 768  // bytes of index lists of one block (each list padded to whole tiles of 32 rows); blocks beyond build their lists one by one
+#endif
+__device__ __forceinline__ uint32_t ss_pack_f16(float lo, float hi) {
+    const ss_half2v v = {(_Float16)lo, (_Float16)hi};  // (round to nearest even)
+    return __builtin_bit_cast(uint32_t, v);
+}
+// the 16-byte record of a tile entry: slots 0-3 in (x, y), slots 4-7 in (z, w)
+__device__ __forceinline__ uint4 splat_cert_record(const SSDevT<float>& P, const ss_real4<float>& pv, float cx, float cy, float cz) {
+    const float px = (pv.x - cx) * P.avx_inv_h, py = (pv.y - cy) * P.avx_inv_h, pz = (pv.z - cz) * P.avx_inv_h;
+    const float s = __builtin_amdgcn_sqrtf(__builtin_amdgcn_sqrtf(pv.w * P.cert_vscale));
+    const float eps = __builtin_fmaf(P.cert_e1, (__builtin_fabsf(px) + __builtin_fabsf(py)) + __builtin_fabsf(pz), P.cert_e0);
+    const float a = ((1.0f - eps) - px * px) - (py * py + pz * pz);
+    const float sa = s * a;
+    const _Float16 sa_hi = (_Float16)sa;
+    const float sa_lo = sa - (float)sa_hi;
+    const float s2 = s + s;
+    const ss_half2v w0 = {sa_hi, (_Float16)sa_lo};
+    return make_uint4(__builtin_bit_cast(uint32_t, w0), ss_pack_f16(s2 * px, -s), ss_pack_f16(s2 * py, s2 * pz), ss_pack_f16(-s, -s));
+}
+#define SS_CERT_DUMMY make_uint4(0x0000E3D0u, 0u, 0u, 0u)  // (s a)_hi = -1000: below zero at every point
+// max(d, 0)^4 of four outputs added to acc.  The integer max is exact on the bit patterns (negative floats are negative integers).
+__device__ __forceinline__ float splat_cert_term4(float d0, float d1, float d2, float d3, float acc) {
+    auto t = [](float d, float a) {
+        const float m = __int_as_float(max(__float_as_int(d), 0));
+        const float m2 = m * m;
+        return __builtin_fmaf(m2, m2, a);
+    };
+    return t(d3, t(d2, t(d1, t(d0, acc))));
+}
+// one 32 x 32 tile: rows = entries a (A operand, this lane's half of its row's record), columns = points b; returns acc + this lane's part of
+// sum_rows max(s u, 0)^4 for its column (rows (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)); `rows` > 0 live rows, the others hold the dummy
+__device__ __forceinline__ float splat_cert_tile(uint2 a, uint32_t b0, uint32_t b1, int rows, float acc) {
+    const ss_float16v z = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    const ss_float16v d = __builtin_amdgcn_mfma_f32_32x32x8f16(__builtin_bit_cast(ss_half4v, a), __builtin_bit_cast(ss_half4v, make_uint2(b0, b1)), z, 0, 0, 0);
+    acc = splat_cert_term4(d[0], d[1], d[2], d[3], acc);
+    if (rows > 8) acc = splat_cert_term4(d[4], d[5], d[6], d[7], acc);      // (wave-uniform: whole groups of eight rows beyond the list are skipped)
+    if (rows > 16) acc = splat_cert_term4(d[8], d[9], d[10], d[11], acc);
+    if (rows > 24) acc = splat_cert_term4(d[12], d[13], d[14], d[15], acc);
+    return acc;
 }
 
 // ---- one WAVE per block -----------------------------------------------------------------------------------------------------
@@ -1730,13 +1779,16 @@ __device__ __forceinline__ float splat_bound_single(const SSDevT<float>& P, cons
 
 template <class R>
 struct SplatAccWaveShared {
-    ss_real4<R> pay[SSWaveChunk<R>::value];
-    // list of one sub-block: one 64-entry batch of full records (exact sums), or -- f32 lower-bound pass -- the lists of near
-    // entries of ALL EIGHT sub-blocks as 8-byte records (SS_BOUND_POOL entries + 8 the read-ahead may touch)
-    ss_real4<R> wl[(sizeof(R) == 4) ? (SS_BOUND_POOL + 8) / 2 : SS_WAVE_LIST];
-    uint8_t near[SSWaveChunk<R>::value];  // per tile entry: the sub-blocks whose classification pass visits it; after splat_sort_tile: the order
-    uint32_t idx[SSWaveChunk<R>::value];  // particle indices of the tile entries (splat_sort_tile)
+    // the tile in scan order: payload (x, y, z, V); f32 first pass: overwritten entry by entry with the certificate's 16-byte records
+    // (splat_cert_record; [CH] = the dummy record the lists are padded with) and fetched again by the blocks that go on to exact sums
+    ss_real4<R> pay[SSWaveChunk<R>::value + 1];
+    // one 64-entry batch of full records (exact sums); before that the row tables of the scan and -- f32 certificate -- the index lists
+    // of the near entries of all eight sub-blocks (SS_CERT_POOL bytes)
+    ss_real4<R> wl[SS_WAVE_LIST];
+    uint8_t near[SSWaveChunk<R>::value];  // f64: per tile entry the sub-blocks whose classification pass visits it; after splat_sort_tile: the order
+    uint32_t idx[SSWaveChunk<R>::value];  // positions of the tile entries in the cell-sorted arrays; for the exact sums: their particle indices (splat_sort_tile)
 };
+static_assert(sizeof(SplatAccWaveShared<float>::wl) >= SS_CERT_POOL, "the index lists of the certificate live in the list buffer");
 
 // Orders the tile by original particle index (unique keys) WITHOUT moving it: rank sort, every lane ranks its entries in one pass
 // over the keys (one broadcast read serves them all), then order[rank] = position goes into the mask array (free once the
@@ -1772,30 +1824,22 @@ __device__ __forceinline__ void splat_sort_tile(SplatAccWaveShared<R>& sh, const
     ss_wave_lds_sync();
 }
 
-// STAGED: the tile (payload and particle indices) is in sh.pay / sh.idx already (k_splat_fused); otherwise it is fetched from the arena
-template <class R, int ARITH, bool EARLY, bool STAGED = false>
-__device__ __forceinline__ void splat_accumulate_block_wave(SplatAccWaveShared<R>& sh, const SSDevT<R>& P, uint32_t logical, int n_tile, const ss_real4<R>* __restrict__ tile,
-                                                            const uint32_t* __restrict__ tile_idx,
+// The tile is in LDS: sh.pay[0, n_tile) payload in scan order, sh.idx its positions in the cell-sorted arrays (k_splat_fused).
+template <class R, int ARITH, bool EARLY>
+__device__ __forceinline__ void splat_accumulate_block_wave(SplatAccWaveShared<R>& sh, const SSDevT<R>& P, uint32_t logical, int n_tile, const ss_real4<R>* __restrict__ posvol,
+                                                            const uint32_t* __restrict__ perm,
                                                             const uint32_t* __restrict__ active_xyz, R* __restrict__ G, ss_real2<R>* __restrict__ blk_minmax,
                                                             uint32_t* __restrict__ trunc, unsigned long long* __restrict__ facebits, uint32_t wave_mask) {
     constexpr int CH = SSWaveChunk<R>::value;
     static_assert(CH % 64 == 0, "the tile is staged in whole batches of 64 entries");
-    constexpr int CLS = (sizeof(R) == 4) ? SS_ARITH_BOUND : ARITH;  // see splat_accumulate_block
+    constexpr bool CERT = EARLY && sizeof(R) == 4;  // f32: the certificate on the matrix pipe; f64: the reference's own arithmetic on the near entries
     const int lane = threadIdx.x & 63;
     SS_PROF_BEGIN();
-    ss_real4<R> stage[CH / 64];
-#pragma unroll
-    for (int k = 0; k < CH / 64; ++k) {
-        stage[k] = ss_make4(R(0.0), R(0.0), R(0.0), R(0.0));
-        if constexpr (!STAGED)
-            if (lane + 64 * k < n_tile) stage[k] = tile[lane + 64 * k];
-    }
     const int bx = __builtin_amdgcn_readfirstlane((int)active_xyz[3 * (size_t)logical]);
     const int by = __builtin_amdgcn_readfirstlane((int)active_xyz[3 * (size_t)logical + 1]);
     const int bz = __builtin_amdgcn_readfirstlane((int)active_xyz[3 * (size_t)logical + 2]);
     const int ox = (lane >> 4) & 3, oy = (lane >> 2) & 3, oz = lane & 3;
     R* gblock = G + (size_t)logical * SS_BLOCK_POINTS + (size_t)SS_BLOCK_OFFSET(ox, oy, oz);  // + 64 sb: SS_BLOCK_OFFSET
-    if constexpr (!STAGED) ss_wave_lds_sync();  // the previous block's reads of pay are done
     // per axis and half of the block (h = 0, 1): the sub-block's box [lo, hi] and this lane's point coordinate -- global point
     // coordinates as in uniform_grid.rs:418-425 on the GLOBAL grid (dense_subdomains.rs:817-826); the SIMD loop of the reference
     // forms z with one fma (:1069), x and y like the scalar loop (:1113-1114)
@@ -1818,114 +1862,153 @@ __device__ __forceinline__ void splat_accumulate_block_wave(SplatAccWaveShared<R
                 pt_ok[d][h] = g + o3[d] < P.np[d];
             }
     }
-    // f32 lower-bound pass: the lists of near entries of all eight sub-blocks are built in ONE pass over the tile (8-byte records
-    // relative to the block's centre, splat_bound_record) into a pool in LDS -- every entry is read once, the eight ballots per
-    // batch need no LDS round trip, and the walks of the sub-blocks follow each other without list building in between.
-    // lane sb of v_list: (offset << 16) | entries of sub-block sb's list.  Blocks whose lists do not fit the pool together
-    // (SS_BOUND_POOL entries, each list padded to whole trips of four) build them one by one (splat_bound_single).
-    [[maybe_unused]] uint32_t v_list = 0;
+    // ---- f32 first pass: records, near masks, index lists (see splat_cert_record) ----
+    // Every entry's payload is replaced IN PLACE by its 16-byte record (coordinates relative to the block's centre); the near entries of
+    // all eight sub-blocks are listed in ONE pass over the tile as byte indices into the tile -- every entry is read once, the eight
+    // ballots per batch need no LDS round trip.  off[sb] / cnt[sb]: list of sub-block sb in the pool, padded with the dummy's index to
+    // whole tiles of 32 rows.  Blocks whose lists do not fit the pool together build them one by one.
+    [[maybe_unused]] uint32_t mask[CH / 64];
+    [[maybe_unused]] int off[8], cnt[8];
     [[maybe_unused]] bool pooled = false;
-    [[maybe_unused]] R bcx = R(0.0), bcy = R(0.0), bcz = R(0.0);
-    [[maybe_unused]] float npc[3][2] = {{0.0f, 0.0f}, {0.0f, 0.0f}, {0.0f, 0.0f}};
+    [[maybe_unused]] uint32_t rb0[4], rb1[4];
     if constexpr (EARLY) {
-        uint32_t mask[CH / 64];
 #pragma unroll
-        for (int k = 0; k < CH / 64; ++k) {
-            mask[k] = 0u;
-            if (lane + 64 * k < n_tile) {
-                if constexpr (STAGED) stage[k] = sh.pay[lane + 64 * k];
-                mask[k] = splat_near_masks<R>(P, stage[k], lo, hi, P.R2near);
-                sh.near[lane + 64 * k] = (uint8_t)mask[k];
-            }
-        }
-        if constexpr (CLS == SS_ARITH_BOUND) {
-            bcx = lo[0][0] + R(3.5) * P.cs;
-            bcy = lo[1][0] + R(3.5) * P.cs;
-            bcz = lo[2][0] + R(3.5) * P.cs;
-            const R bc3[3] = {bcx, bcy, bcz};
-#pragma unroll
-            for (int d = 0; d < 3; ++d)
-#pragma unroll
-                for (int h = 0; h < 2; ++h) npc[d][h] = (float)((bc3[d] - pc[d][h]) * P.avx_inv_h);  // minus the lane's point in the records' frame
-            uint2 rec[CH / 64];
-#pragma unroll
-            for (int k = 0; k < CH / 64; ++k) rec[k] = splat_bound_record(P, stage[k], bcx, bcy, bcz);
-            int off[8], cnt[8], total = 0;
-#pragma unroll
-            for (int sb = 0; sb < 8; ++sb) {
-                int c = 0;
-#pragma unroll
-                for (int k = 0; k < CH / 64; ++k) c += __popcll(__ballot((mask[k] >> sb) & 1u));
-                off[sb] = total;
-                cnt[sb] = c;
-                if (lane == sb) v_list = ((uint32_t)total << 16) | (uint32_t)c;
-                total += (c + 3) & ~3;
-            }
-            pooled = total <= SS_BOUND_POOL;
-            if (pooled) {
-                uint2* pool = reinterpret_cast<uint2*>(sh.wl);
-#pragma unroll
-                for (int sb = 0; sb < 8; ++sb)
-                    if (lane < ((cnt[sb] + 3) & ~3) - cnt[sb]) pool[off[sb] + cnt[sb] + lane] = SS_BOUND_DUMMY;
-#pragma unroll
-                for (int k = 0; k < CH / 64; ++k)
-#pragma unroll
-                    for (int sb = 0; sb < 8; ++sb) {
-                        const bool bit = (mask[k] >> sb) & 1u;
-                        const unsigned long long m = __ballot(bit);
-                        if (bit) pool[off[sb] + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] = rec[k];
-                        off[sb] += __popcll(m);
-                    }
-            }
-        }
+        for (int k = 0; k < CH / 64; ++k) mask[k] = 0u;
     }
-    if constexpr (!STAGED) {
+    if constexpr (CERT) {
+        const float bcx = lo[0][0] + 3.5f * P.cs, bcy = lo[1][0] + 3.5f * P.cs, bcz = lo[2][0] + 3.5f * P.cs;
+        uint4* recs = reinterpret_cast<uint4*>(sh.pay);
 #pragma unroll
         for (int k = 0; k < CH / 64; ++k)
-            if (lane + 64 * k < n_tile) sh.pay[lane + 64 * k] = stage[k];
+            if (lane + 64 * k < n_tile) {
+                const ss_real4<R> pv = sh.pay[lane + 64 * k];
+                mask[k] = splat_near_masks<R>(P, pv, lo, hi, P.R2near);
+                recs[lane + 64 * k] = splat_cert_record(P, pv, bcx, bcy, bcz);
+            }
+        if (lane == 0) recs[CH] = SS_CERT_DUMMY;
+        // the B operands: lanes 0-31 hold the x content of their column for its four x positions q = 2 sx + g (g: tile = points
+        // [32 g, 32 g + 32) of the sub-block), lanes 32-63 the (y, z) content of their column for q = 2 sy + sz
+        const bool lo_half = lane < 32;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int gx = bx * SS_BLOCK + 4 * (q >> 1) + 2 * (q & 1) + ((lane >> 4) & 1);
+            const int gy = by * SS_BLOCK + 4 * (q >> 1) + oy, gz = bz * SS_BLOCK + 4 * (q & 1) + oz;
+            const float x = ((P.gmin[0] + (float)gx * P.cs) - bcx) * P.avx_inv_h;
+            const float y = ((P.gmin[1] + (float)gy * P.cs) - bcy) * P.avx_inv_h;
+            const float zc = (ARITH >= SS_ARITH_SIMD) ? __builtin_fmaf((float)gz, P.cs, P.gmin[2]) : P.gmin[2] + (float)gz * P.cs;
+            const float z = (zc - bcz) * P.avx_inv_h;
+            rb0[q] = ss_pack_f16(lo_half ? 1.0f : y, lo_half ? 1.0f : z);
+            rb1[q] = ss_pack_f16(lo_half ? x : y * y, lo_half ? x * x : z * z);
+        }
+        int total = 0;
+#pragma unroll
+        for (int sb = 0; sb < 8; ++sb) {
+            int c = 0;
+#pragma unroll
+            for (int k = 0; k < CH / 64; ++k) c += __popcll(__ballot((mask[k] >> sb) & 1u));
+            off[sb] = total;
+            cnt[sb] = c;
+            total += (c + 31) & ~31;
+        }
+        pooled = total <= SS_CERT_POOL;
+        if (pooled) {
+            uint8_t* pool = reinterpret_cast<uint8_t*>(sh.wl);
+            uint32_t* pool32 = reinterpret_cast<uint32_t*>(sh.wl);
+#pragma unroll
+            for (int w = 0; w < SS_CERT_POOL / 256; ++w) pool32[lane + 64 * w] = 0x01010101u * (uint32_t)CH;  // padding: the dummy's index
+            int at[8];
+#pragma unroll
+            for (int sb = 0; sb < 8; ++sb) at[sb] = off[sb];
+#pragma unroll
+            for (int k = 0; k < CH / 64; ++k)
+#pragma unroll
+                for (int sb = 0; sb < 8; ++sb) {
+                    const bool bit = (mask[k] >> sb) & 1u;
+                    const unsigned long long m = __ballot(bit);
+                    if (bit) pool[at[sb] + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] = (uint8_t)(lane + 64 * k);
+                    at[sb] += __popcll(m);
+                }
+        }
+        ss_wave_lds_sync();
+    } else if constexpr (EARLY) {
+#pragma unroll
+        for (int k = 0; k < CH / 64; ++k)
+            if (lane + 64 * k < n_tile) {
+                mask[k] = splat_near_masks<R>(P, sh.pay[lane + 64 * k], lo, hi, P.R2near);
+                sh.near[lane + 64 * k] = (uint8_t)mask[k];
+            }
+        ss_wave_lds_sync();
     }
-    ss_wave_lds_sync();
-    SS_PROF_MARK(1);  // block set-up, near masks, lists of the lower-bound pass
+    SS_PROF_MARK(1);  // block set-up, near masks, records and lists of the certificate
     // second pass: the sub-blocks the first pass certified (their values were never stored, see below)
     const uint32_t certified_before = (!EARLY && wave_mask != 0xFFu) ? (uint32_t)__builtin_amdgcn_readfirstlane((int)trunc[logical]) : 0u;
     R mn = R(INFINITY), mx = -R(INFINITY);
     uint32_t certified = 0, need = 0;
     unsigned long long faces = 0;
     // first the sub-blocks that need no exact sum: not selected (second pass), outside the grid, or certified by the lower bound
-#pragma unroll 1
+#pragma unroll
     for (int sb = 0; sb < 8; ++sb) {
         const int sx = (sb >> 2) & 1, sy = (sb >> 1) & 1, sz = sb & 1;
-        const bool point_valid = (sx ? pt_ok[0][1] : pt_ok[0][0]) && (sy ? pt_ok[1][1] : pt_ok[1][0]) && (sz ? pt_ok[2][1] : pt_ok[2][0]);
+        const bool point_valid = pt_ok[0][sx] && pt_ok[1][sy] && pt_ok[2][sz];
         R* gp = gblock + 64 * sb;
         R val;
         if (!((wave_mask >> sb) & 1u)) {
             // second pass: a sub-block that is not re-evaluated keeps its value (it still enters the block's min / max)
             val = ((certified_before >> sb) & 1u) ? P.thr_inside : *gp;
-        } else if (!((sx ? sub_ok[0][1] : sub_ok[0][0]) && (sy ? sub_ok[1][1] : sub_ok[1][0]) && (sz ? sub_ok[2][1] : sub_ok[2][0]))) {
+        } else if (!(sub_ok[0][sx] && sub_ok[1][sy] && sub_ok[2][sz])) {
             val = R(0.0);  // points outside the grid count as 0 = "outside"
             *gp = val;
         } else {
             bool done = false;
             if constexpr (EARLY) {  // classification: lower bound from the entries close to the sub-block, in any order
-                const R px = sx ? pc[0][1] : pc[0][0], py = sy ? pc[1][1] : pc[1][0], pz = sz ? pc[2][1] : pc[2][0];
-                const R slo[3] = {sx ? lo[0][1] : lo[0][0], sy ? lo[1][1] : lo[1][0], sz ? lo[2][1] : lo[2][0]};
-                const R shi[3] = {sx ? hi[0][1] : hi[0][0], sy ? hi[1][1] : hi[1][0], sz ? hi[2][1] : hi[2][0]};
                 int n_near = 0;
                 R acc;
-                if constexpr (CLS == SS_ARITH_BOUND) {
-                    const float npx = sx ? npc[0][1] : npc[0][0], npy = sy ? npc[1][1] : npc[1][0], npz = sz ? npc[2][1] : npc[2][0];  // minus the point
-                    uint2* pool = reinterpret_cast<uint2*>(sh.wl);
-                    SS_PROF_MARK(5);  // (classification: everything but the walks)
-                    if (pooled) {
-                        const uint32_t ol = (uint32_t)__builtin_amdgcn_readlane((int)v_list, sb);
-                        n_near = (int)(ol & 0xFFFFu);
-                        acc = splat_bound_walk(P, pool + (ol >> 16), n_near, npx, npy, npz);
-                    } else {
-                        acc = splat_bound_single(P, sh.pay, sh.near, pool, n_tile, lane, bcx, bcy, bcz, npx, npy, npz, sb, &n_near);
+                if constexpr (CERT) {
+                    SS_PROF_MARK(5);  // (classification: everything but the tiles)
+                    const uint8_t* pool = reinterpret_cast<const uint8_t*>(sh.wl);
+                    const char* recs = reinterpret_cast<const char*>(sh.pay);
+                    int first = off[sb];
+                    n_near = cnt[sb];
+                    if (!pooled) {  // this sub-block's list alone, at the start of the pool (CH + 32 <= SS_CERT_POOL bytes)
+                        ss_wave_lds_sync();  // the previous sub-block's reads of the pool are done
+                        uint8_t* wpool = reinterpret_cast<uint8_t*>(sh.wl);
+                        int at = 0;
+#pragma unroll
+                        for (int k = 0; k < CH / 64; ++k) {
+                            const bool bit = (mask[k] >> sb) & 1u;
+                            const unsigned long long m = __ballot(bit);
+                            if (bit) wpool[at + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] = (uint8_t)(lane + 64 * k);
+                            at += __popcll(m);
+                        }
+                        if (lane < 32) wpool[at + lane] = (uint8_t)CH;
+                        ss_wave_lds_sync();
+                        first = 0;
                     }
-                    SS_PROF_MARK(6);  // walks of the lists
+                    // tiles g = 0, 1 of this sub-block: columns = its points [32 g, 32 g + 32); lanes 0-31 take the x content of position
+                    // 2 sx + g, lanes 32-63 the (y, z) content of 2 sy + sz (rb0 is the same constant in all lanes 0-31)
+                    const int j = 2 * sy + sz;
+                    const bool lo_half = lane < 32;
+                    const uint32_t b1g0 = (2 * sx == j) ? rb1[j] : (lo_half ? rb1[2 * sx] : rb1[j]);
+                    const uint32_t b1g1 = (2 * sx + 1 == j) ? rb1[j] : (lo_half ? rb1[2 * sx + 1] : rb1[j]);
+                    float a0 = 0.0f, a1 = 0.0f;
+                    for (int base = 0; base < n_near; base += 32) {  // (one trip unless the list has more than 32 entries)
+                        const uint32_t e = pool[first + base + (lane & 31)];
+                        const uint2 arow = *reinterpret_cast<const uint2*>(recs + e * 16u + (uint32_t)(lane >> 5) * 8u);
+                        const int rows = n_near - base;
+                        a0 = splat_cert_tile(arow, rb0[j], b1g0, rows, a0);
+                        a1 = splat_cert_tile(arow, rb0[j], b1g1, rows, a1);
+                    }
+                    // lane l < 32 holds in a0 its part of point l, lane l + 32 the other rows' part of point l (a1: point 32 + l): one
+                    // exchange of the halves puts both parts of a lane's OWN point (lane = point of the sub-block) into that lane
+                    typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+                    const u32x2 sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(a0), __float_as_uint(a1), false, false);
+                    acc = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+                    SS_PROF_MARK(6);  // tiles of the certificate
                 } else {
-                    acc = splat_accumulate_wave<R, CLS>(P, sh.pay, sh.wl, n_tile, lane, px, py, pz, slo, shi, P.R2near, R(0.0), sh.near, sb, &n_near);
+                    const R px = pc[0][sx], py = pc[1][sy], pz = pc[2][sz];
+                    const R slo[3] = {lo[0][sx], lo[1][sy], lo[2][sz]};
+                    const R shi[3] = {hi[0][sx], hi[1][sy], hi[2][sz]};
+                    acc = splat_accumulate_wave<R, ARITH>(P, sh.pay, sh.wl, n_tile, lane, px, py, pz, slo, shi, P.R2near, R(0.0), sh.near, sb, &n_near);
                 }
                 // the margin of thr_inside covers the rounding of the terms; a sum of n of them adds up to n 2^-24 relative
                 const R thr = P.thr_inside + ((R)n_near * R(1.2e-7)) * P.thr_inside;
@@ -1951,7 +2034,18 @@ __device__ __forceinline__ void splat_accumulate_block_wave(SplatAccWaveShared<R
     }
     SS_PROF_MARK(2);  // classification of the eight sub-blocks
     if (need) {
-        splat_sort_tile<R>(sh, STAGED ? nullptr : tile_idx, n_tile, lane);
+        // the exact sums want the payload (the certificate overwrote it) and the particle indices: both by the entries' positions in the
+        // cell-sorted arrays, rows this block has just read
+        ss_wave_lds_sync();
+#pragma unroll
+        for (int k = 0; k < CH / 64; ++k)
+            if (lane + 64 * k < n_tile) {
+                const uint32_t src = sh.idx[lane + 64 * k];
+                if constexpr (CERT) sh.pay[lane + 64 * k] = posvol[src];
+                sh.idx[lane + 64 * k] = perm[src];
+            }
+        ss_wave_lds_sync();
+        splat_sort_tile<R>(sh, nullptr, n_tile, lane);
         SS_PROF_MARK(3);  // tile sort
 #pragma unroll 1
         for (int sb = 0; sb < 8; ++sb) {
@@ -1978,9 +2072,9 @@ __device__ __forceinline__ void splat_accumulate_block_wave(SplatAccWaveShared<R
         writer = 63;
     } else {
 #pragma unroll
-        for (int off = 32; off > 0; off >>= 1) {
-            mn = ss_min(mn, __shfl_xor(mn, off));
-            mx = ss_max(mx, __shfl_xor(mx, off));
+        for (int off2 = 32; off2 > 0; off2 >>= 1) {
+            mn = ss_min(mn, __shfl_xor(mn, off2));
+            mx = ss_max(mx, __shfl_xor(mx, off2));
         }
     }
     if (lane == writer) {
@@ -2028,13 +2122,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(sizeof(R) ==
             // scanning (about two thirds of the candidates of a row lie within reach; S10M-cube: the scans of the 89 % of the blocks
             // that overflow anyway cost 1.6 ms).
             uint32_t bailed = 0;
-            splat_wave_scan_grouped<R>(P, posvol, perm, cell_start, key0, plo, phi, s_row_start, s_row_prefix, lane, (uint32_t)(SS_FUSED_BAIL * CH), &bailed,
-                                     [&](bool inside, uint32_t, uint32_t id, const ss_real4<R>& pv) {
+            splat_wave_scan_grouped<R, false>(P, posvol, perm, cell_start, key0, plo, phi, s_row_start, s_row_prefix, lane, (uint32_t)(SS_FUSED_BAIL * CH), &bailed,
+                                     [&](bool inside, uint32_t src, uint32_t, const ss_real4<R>& pv) {
                                          const unsigned long long m = __ballot(inside);
                                          const uint32_t pos = count + (uint32_t)__popcll(m & below);
                                          if (inside && pos < (uint32_t)CH) {
                                              sh.pay[pos] = pv;
-                                             sh.idx[pos] = id;
+                                             sh.idx[pos] = src;  // (the particle index is looked up by the blocks that order their tile)
                                          }
                                          count += (uint32_t)__popcll(m);
                                          return count <= (uint32_t)CH;  // a block with more candidates takes the arena path, which counts them itself
@@ -2048,7 +2142,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(sizeof(R) ==
         }
         ss_wave_lds_sync();
         SS_PROF_MARK(0);  // candidate scan
-        splat_accumulate_block_wave<R, ARITH, EARLY, true>(sh, P, logical, (int)count, nullptr, nullptr, active_xyz, G, blk_minmax, trunc, facebits,
+        splat_accumulate_block_wave<R, ARITH, EARLY>(sh, P, logical, (int)count, posvol, perm, active_xyz, G, blk_minmax, trunc, facebits,
                                                            redo_mask ? __builtin_amdgcn_readfirstlane(redo_mask[logical]) : 0xFFu);
         SS_PROF_MARK(7);  // whole sub-block walk incl. epilogue (phases 1-6 are inside)
     };
