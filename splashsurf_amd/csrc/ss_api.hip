@@ -275,7 +275,7 @@ ss_status make_device_params(ss_context* ctx, const typename TypesOf<R>::params*
     P.reach = ss_sqrt(support_factor) * h * R(1.0001);
     P.R2 = ((h * h) * support_factor) * R(1.0001);
 #ifndef SS_TUNE_RNEAR
-#define SS_TUNE_RNEAR 0.60
+#define SS_TUNE_RNEAR 0.64
 #endif
     // near radius of the classification pass, measured on S10M-tank with the polynomial bound u^3 (c0 + c1 u^2) (splat kernel ms /
     // certified sub-blocks): 0.50 h 9.87 / 74 %, 0.52 h 8.69 / 80 %, 0.55 h 7.73 / 85 %, 0.58 h 7.40 / 87 %, 0.60 h 7.50 / 87 % with
@@ -283,6 +283,9 @@ ss_status make_device_params(ss_context* ctx, const typename TypesOf<R>::params*
     // 0.60 h 6.26 / 87.2 %, 0.62 h 6.59 / 87.5 %, 0.65 h 7.23 / 87.6 % (the lists outgrow the pool) -- an uncertified sub-block costs
     // five times its classification, so the optimum sits where the curve flattens.
     // (Round 2's bound v^2 min(2 v, 1) with its v_sqrt_f32: 8.17 ms / 86 % at 0.60 h.)
+    // Round 6, the certificate on the matrix pipe with the bound C4 u^4 (90 % of the kernel's mass instead of 96 %; an entry of a list costs a
+    // third of what it did, whole tiles of 32 rows cost the same up to the next eight rows): 0.60 h 4.64-4.68 ms / 86.9 %, 0.62 h 4.32-4.38 / 87.8 %,
+    // 0.64 h 4.27-4.28 / 88.1 %, 0.66 h 4.30-4.31 / 88.2 %, 0.68 h 4.32-4.34 / 88.3 % (profiles/r06_ab_mfma_certificate.jsonl).
     P.R2near = (R(SS_TUNE_RNEAR) * h) * (R(SS_TUNE_RNEAR) * h);
     P.thr_inside = prm->iso_surface_threshold * R(1.0001);
     R amax = R(0.0);

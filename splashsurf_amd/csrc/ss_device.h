@@ -107,7 +107,7 @@ struct SSDevT {
     R margin;     // ghost particle margin     (dense_subdomains.rs:120-121)
     R reach;      // conservative reach of a particle: sqrt(support^2)*(1+1e-4), support^2 = 1.01 h^2 (scalar) or h^2 (SIMD arithmetic)
     R R2;         // support^2 * (1+1e-4): squared reach of the conservative block / wave filters of the splat
-    R R2near;     // (0.60 h)^2: sub-block filter of the splat's classification pass (make_device_params)
+    R R2near;     // (0.64 h)^2: sub-block filter of the splat's classification pass (make_device_params)
     R thr_inside; // threshold * (1 + 1e-4): a lower bound above it certifies 'inside' whatever the summation order
     R bound_one;  // 1 - slack covering the f16 coordinates of the packed lower-bound pass (splat_bound_packed, make_device_params)
     // certificate on the matrix pipe (splat_cert_record): C4 sigma (1 - 2e-5), and the slack eps = cert_e1 (|px| + |py| + |pz|) + cert_e0 taken off 1 - |p|^2

@@ -1728,8 +1728,14 @@ __device__ __forceinline__ float splat_bound_walk(const SSDevT<float>& P, const 
 typedef _Float16 ss_half4v __attribute__((ext_vector_type(4)));
 typedef float ss_float16v __attribute__((ext_vector_type(16)));
 #define SS_CERT_C4 0.76293f
+#ifndef SS_CERT_DUAL
+#define SS_CERT_DUAL 0
+#endif
+#ifndef SS_ABLATE
+#define SS_ABLATE 0  // 1 / 2 / 3: k_splat_fused stops after the scan / after the records and lists / before the exact sums (instruction counts per phase)
+#endif
 #ifndef SS_CERT_POOL
-#define SS_CERT_POOL 768  // bytes of index lists of one block (each list padded to whole tiles of 32 rows); blocks beyond build their lists one by one
+#define SS_CERT_POOL 512  // bytes of index lists of one block: 64 per sub-block (two tiles of 32 rows)
 #endif
 __device__ __forceinline__ uint32_t ss_pack_f16(float lo, float hi) {
     const ss_half2v v = {(_Float16)lo, (_Float16)hi};  // (round to nearest even)
@@ -1760,9 +1766,11 @@ __device__ __forceinline__ float splat_cert_term4(float d0, float d1, float d2, 
 }
 // one 32 x 32 tile: rows = entries a (A operand, this lane's half of its row's record), columns = points b; returns acc + this lane's part of
 // sum_rows max(s u, 0)^4 for its column (rows (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)); `rows` > 0 live rows, the others hold the dummy
-__device__ __forceinline__ float splat_cert_tile(uint2 a, uint32_t b0, uint32_t b1, int rows, float acc) {
+__device__ __forceinline__ ss_float16v splat_cert_mfma(uint2 a, uint32_t b0, uint32_t b1) {
     const ss_float16v z = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    const ss_float16v d = __builtin_amdgcn_mfma_f32_32x32x8f16(__builtin_bit_cast(ss_half4v, a), __builtin_bit_cast(ss_half4v, make_uint2(b0, b1)), z, 0, 0, 0);
+    return __builtin_amdgcn_mfma_f32_32x32x8f16(__builtin_bit_cast(ss_half4v, a), __builtin_bit_cast(ss_half4v, make_uint2(b0, b1)), z, 0, 0, 0);
+}
+__device__ __forceinline__ float splat_cert_reduce(const ss_float16v& d, int rows, float acc) {
     acc = splat_cert_term4(d[0], d[1], d[2], d[3], acc);
     if (rows > 8) acc = splat_cert_term4(d[4], d[5], d[6], d[7], acc);      // (wave-uniform: whole groups of eight rows beyond the list are skipped)
     if (rows > 16) acc = splat_cert_term4(d[8], d[9], d[10], d[11], acc);
@@ -1862,30 +1870,49 @@ __device__ __forceinline__ void splat_accumulate_block_wave(SplatAccWaveShared<R
                 pt_ok[d][h] = g + o3[d] < P.np[d];
             }
     }
-    // ---- f32 first pass: records, near masks, index lists (see splat_cert_record) ----
+    // ---- f32 first pass: records and index lists of the certificate (see splat_cert_record) ----
     // Every entry's payload is replaced IN PLACE by its 16-byte record (coordinates relative to the block's centre); the near entries of
-    // all eight sub-blocks are listed in ONE pass over the tile as byte indices into the tile -- every entry is read once, the eight
-    // ballots per batch need no LDS round trip.  off[sb] / cnt[sb]: list of sub-block sb in the pool, padded with the dummy's index to
-    // whole tiles of 32 rows.  Blocks whose lists do not fit the pool together build them one by one.
-    [[maybe_unused]] uint32_t mask[CH / 64];
-    [[maybe_unused]] int off[8], cnt[8];
-    [[maybe_unused]] bool pooled = false;
+    // all eight sub-blocks are listed in ONE pass over the tile as byte indices into the tile: list sb = bytes [64 sb, 64 sb + 64) of the
+    // pool, padded with the dummy's index.  The near test of a sub-block (box distance <= R_near, separable: six one-dimensional
+    // distances per entry) goes straight into its ballot -- no mask word per entry -- and the ballot's prefix count places the entry.
+    // cnt[sb]: entries near sub-block sb; a list longer than its 64 slots (two tiles) is not walked: that sub-block goes to the exact sums.
+    [[maybe_unused]] int cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     [[maybe_unused]] uint32_t rb0[4], rb1[4];
-    if constexpr (EARLY) {
-#pragma unroll
-        for (int k = 0; k < CH / 64; ++k) mask[k] = 0u;
-    }
     if constexpr (CERT) {
         const float bcx = lo[0][0] + 3.5f * P.cs, bcy = lo[1][0] + 3.5f * P.cs, bcz = lo[2][0] + 3.5f * P.cs;
         uint4* recs = reinterpret_cast<uint4*>(sh.pay);
+        uint8_t* pool = reinterpret_cast<uint8_t*>(sh.wl);
+        {
+            uint32_t* pool32 = reinterpret_cast<uint32_t*>(sh.wl);
+            pool32[lane] = 0x01010101u * (uint32_t)CH;  // padding: the dummy's index
+            pool32[lane + 64] = 0x01010101u * (uint32_t)CH;
+            if (lane == 0) recs[CH] = SS_CERT_DUMMY;
+        }
 #pragma unroll
-        for (int k = 0; k < CH / 64; ++k)
-            if (lane + 64 * k < n_tile) {
-                const ss_real4<R> pv = sh.pay[lane + 64 * k];
-                mask[k] = splat_near_masks<R>(P, pv, lo, hi, P.R2near);
-                recs[lane + 64 * k] = splat_cert_record(P, pv, bcx, bcy, bcz);
+        for (int k = 0; k < CH / 64; ++k) {
+            if (64 * k >= n_tile) break;  // (wave-uniform)
+            const int c = lane + 64 * k;
+            const bool valid = c < n_tile;
+            const ss_real4<R> pv = sh.pay[valid ? c : 0];
+            float e2[3][2];
+            const float p3[3] = {pv.x, pv.y, pv.z};
+#pragma unroll
+            for (int d = 0; d < 3; ++d)
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const float e = ss_max(ss_max(lo[d][h] - p3[d], p3[d] - hi[d][h]) - P.coord_slack, 0.0f);
+                    e2[d][h] = e * e;
+                }
+            if (valid) recs[c] = splat_cert_record(P, pv, bcx, bcy, bcz);
+#pragma unroll
+            for (int sb = 0; sb < 8; ++sb) {
+                const bool bit = valid && ((e2[0][(sb >> 2) & 1] + e2[1][(sb >> 1) & 1]) + e2[2][sb & 1] <= P.R2near);
+                const unsigned long long m = __ballot(bit);
+                const int pos = cnt[sb] + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                if (bit && pos < 64) pool[64 * sb + pos] = (uint8_t)c;
+                cnt[sb] += __popcll(m);
             }
-        if (lane == 0) recs[CH] = SS_CERT_DUMMY;
+        }
         // the B operands: lanes 0-31 hold the x content of their column for its four x positions q = 2 sx + g (g: tile = points
         // [32 g, 32 g + 32) of the sub-block), lanes 32-63 the (y, z) content of their column for q = 2 sy + sz
         const bool lo_half = lane < 32;
@@ -1900,55 +1927,37 @@ __device__ __forceinline__ void splat_accumulate_block_wave(SplatAccWaveShared<R
             rb0[q] = ss_pack_f16(lo_half ? 1.0f : y, lo_half ? 1.0f : z);
             rb1[q] = ss_pack_f16(lo_half ? x : y * y, lo_half ? x * x : z * z);
         }
-        int total = 0;
-#pragma unroll
-        for (int sb = 0; sb < 8; ++sb) {
-            int c = 0;
-#pragma unroll
-            for (int k = 0; k < CH / 64; ++k) c += __popcll(__ballot((mask[k] >> sb) & 1u));
-            off[sb] = total;
-            cnt[sb] = c;
-            total += (c + 31) & ~31;
-        }
-        pooled = total <= SS_CERT_POOL;
-        if (pooled) {
-            uint8_t* pool = reinterpret_cast<uint8_t*>(sh.wl);
-            uint32_t* pool32 = reinterpret_cast<uint32_t*>(sh.wl);
-#pragma unroll
-            for (int w = 0; w < SS_CERT_POOL / 256; ++w) pool32[lane + 64 * w] = 0x01010101u * (uint32_t)CH;  // padding: the dummy's index
-            int at[8];
-#pragma unroll
-            for (int sb = 0; sb < 8; ++sb) at[sb] = off[sb];
-#pragma unroll
-            for (int k = 0; k < CH / 64; ++k)
-#pragma unroll
-                for (int sb = 0; sb < 8; ++sb) {
-                    const bool bit = (mask[k] >> sb) & 1u;
-                    const unsigned long long m = __ballot(bit);
-                    if (bit) pool[at[sb] + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] = (uint8_t)(lane + 64 * k);
-                    at[sb] += __popcll(m);
-                }
-        }
         ss_wave_lds_sync();
     } else if constexpr (EARLY) {
 #pragma unroll
         for (int k = 0; k < CH / 64; ++k)
-            if (lane + 64 * k < n_tile) {
-                mask[k] = splat_near_masks<R>(P, sh.pay[lane + 64 * k], lo, hi, P.R2near);
-                sh.near[lane + 64 * k] = (uint8_t)mask[k];
-            }
+            if (lane + 64 * k < n_tile) sh.near[lane + 64 * k] = (uint8_t)splat_near_masks<R>(P, sh.pay[lane + 64 * k], lo, hi, P.R2near);
         ss_wave_lds_sync();
     }
     SS_PROF_MARK(1);  // block set-up, near masks, records and lists of the certificate
+#if SS_ABLATE == 2
+    if (n_tile < 100000) return;
+#endif
     // second pass: the sub-blocks the first pass certified (their values were never stored, see below)
     const uint32_t certified_before = (!EARLY && wave_mask != 0xFFu) ? (uint32_t)__builtin_amdgcn_readfirstlane((int)trunc[logical]) : 0u;
     R mn = R(INFINITY), mx = -R(INFINITY);
     uint32_t certified = 0, need = 0;
     unsigned long long faces = 0;
     // first the sub-blocks that need no exact sum: not selected (second pass), outside the grid, or certified by the lower bound
+    // (certificate: the A operand -- this lane's half of its row's record -- of a sub-block's first tile is fetched one sub-block ahead:
+    // index, then record, are two dependent LDS round trips that would otherwise head every sub-block's chain)
+    [[maybe_unused]] auto cert_row = [&](int sb_, int base) -> uint2 {
+        const uint32_t e = reinterpret_cast<const uint8_t*>(sh.wl)[64 * sb_ + base + (lane & 31)];
+        return *reinterpret_cast<const uint2*>(reinterpret_cast<const char*>(sh.pay) + e * 16u + (uint32_t)(lane >> 5) * 8u);
+    };
+    [[maybe_unused]] uint2 arow_ahead = make_uint2(0u, 0u);
+    if constexpr (CERT) arow_ahead = cert_row(0, 0);
 #pragma unroll
     for (int sb = 0; sb < 8; ++sb) {
         const int sx = (sb >> 2) & 1, sy = (sb >> 1) & 1, sz = sb & 1;
+        [[maybe_unused]] const uint2 arow_first = arow_ahead;
+        if constexpr (CERT)
+            if (sb < 7) arow_ahead = cert_row(sb + 1, 0);
         const bool point_valid = pt_ok[0][sx] && pt_ok[1][sy] && pt_ok[2][sz];
         R* gp = gblock + 64 * sb;
         R val;
@@ -1965,25 +1974,7 @@ __device__ __forceinline__ void splat_accumulate_block_wave(SplatAccWaveShared<R
                 R acc;
                 if constexpr (CERT) {
                     SS_PROF_MARK(5);  // (classification: everything but the tiles)
-                    const uint8_t* pool = reinterpret_cast<const uint8_t*>(sh.wl);
-                    const char* recs = reinterpret_cast<const char*>(sh.pay);
-                    int first = off[sb];
                     n_near = cnt[sb];
-                    if (!pooled) {  // this sub-block's list alone, at the start of the pool (CH + 32 <= SS_CERT_POOL bytes)
-                        ss_wave_lds_sync();  // the previous sub-block's reads of the pool are done
-                        uint8_t* wpool = reinterpret_cast<uint8_t*>(sh.wl);
-                        int at = 0;
-#pragma unroll
-                        for (int k = 0; k < CH / 64; ++k) {
-                            const bool bit = (mask[k] >> sb) & 1u;
-                            const unsigned long long m = __ballot(bit);
-                            if (bit) wpool[at + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] = (uint8_t)(lane + 64 * k);
-                            at += __popcll(m);
-                        }
-                        if (lane < 32) wpool[at + lane] = (uint8_t)CH;
-                        ss_wave_lds_sync();
-                        first = 0;
-                    }
                     // tiles g = 0, 1 of this sub-block: columns = its points [32 g, 32 g + 32); lanes 0-31 take the x content of position
                     // 2 sx + g, lanes 32-63 the (y, z) content of 2 sy + sz (rb0 is the same constant in all lanes 0-31)
                     const int j = 2 * sy + sz;
@@ -1991,12 +1982,18 @@ __device__ __forceinline__ void splat_accumulate_block_wave(SplatAccWaveShared<R
                     const uint32_t b1g0 = (2 * sx == j) ? rb1[j] : (lo_half ? rb1[2 * sx] : rb1[j]);
                     const uint32_t b1g1 = (2 * sx + 1 == j) ? rb1[j] : (lo_half ? rb1[2 * sx + 1] : rb1[j]);
                     float a0 = 0.0f, a1 = 0.0f;
-                    for (int base = 0; base < n_near; base += 32) {  // (one trip unless the list has more than 32 entries)
-                        const uint32_t e = pool[first + base + (lane & 31)];
-                        const uint2 arow = *reinterpret_cast<const uint2*>(recs + e * 16u + (uint32_t)(lane >> 5) * 8u);
-                        const int rows = n_near - base;
-                        a0 = splat_cert_tile(arow, rb0[j], b1g0, rows, a0);
-                        a1 = splat_cert_tile(arow, rb0[j], b1g1, rows, a1);
+                    const int n_walk = n_near <= 64 ? n_near : 0;  // (a list that outgrew its slots certifies nothing)
+                    for (int base = 0; base < n_walk; base += 32) {  // (one trip unless the list has more than 32 entries)
+                        const uint2 arow = base == 0 ? arow_first : cert_row(sb, base);
+                        const int rows = n_walk - base;
+#if SS_CERT_DUAL  // both tiles on the matrix pipe before either is consumed (16 registers more)
+                        const ss_float16v d0 = splat_cert_mfma(arow, rb0[j], b1g0), d1 = splat_cert_mfma(arow, rb0[j], b1g1);
+                        a0 = splat_cert_reduce(d0, rows, a0);
+                        a1 = splat_cert_reduce(d1, rows, a1);
+#else
+                        a0 = splat_cert_reduce(splat_cert_mfma(arow, rb0[j], b1g0), rows, a0);
+                        a1 = splat_cert_reduce(splat_cert_mfma(arow, rb0[j], b1g1), rows, a1);
+#endif
                     }
                     // lane l < 32 holds in a0 its part of point l, lane l + 32 the other rows' part of point l (a1: point 32 + l): one
                     // exchange of the halves puts both parts of a lane's OWN point (lane = point of the sub-block) into that lane
@@ -2033,6 +2030,9 @@ __device__ __forceinline__ void splat_accumulate_block_wave(SplatAccWaveShared<R
         if constexpr (EARLY) faces |= (unsigned long long)splat_face_bits(__ballot(point_valid && !(val > P.threshold))) << (6 * sb);
     }
     SS_PROF_MARK(2);  // classification of the eight sub-blocks
+#if SS_ABLATE == 3
+    need = 0;
+#endif
     if (need) {
         // the exact sums want the payload (the certificate overwrote it) and the particle indices: both by the entries' positions in the
         // cell-sorted arrays, rows this block has just read
@@ -2091,8 +2091,11 @@ __device__ __forceinline__ void splat_accumulate_block_wave(SplatAccWaveShared<R
 // SSWaveChunk candidates only reports its count and sets its flag in big[] (the host compacts the flags into a list with a scan): those take the arena path
 // (k_splat_bounds, k_splat_gather / _large, k_splat_accumulate_list).  list == nullptr: every active block; otherwise the blocks
 // of the device-side list, the sub-blocks in redo_mask only.
+#ifndef SS_FUSED_MINWAVES
+#define SS_FUSED_MINWAVES 6
+#endif
 template <class R, int ARITH, bool EARLY>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(sizeof(R) == 4 ? 6 : 4, 8))) void k_splat_fused(SSDevT<R> P, const ss_real4<R>* __restrict__ posvol, const uint32_t* __restrict__ perm,
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(sizeof(R) == 4 ? SS_FUSED_MINWAVES : 4, 8))) void k_splat_fused(SSDevT<R> P, const ss_real4<R>* __restrict__ posvol, const uint32_t* __restrict__ perm,
                                                     const uint32_t* __restrict__ cell_start, const uint32_t* __restrict__ active_xyz, uint32_t n_active,
                                                     const uint32_t* __restrict__ list, const uint32_t* __restrict__ n_list_dev,
                                                     const uint32_t* __restrict__ redo_mask, R* __restrict__ G, ss_real2<R>* __restrict__ blk_minmax,
@@ -2142,6 +2145,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(sizeof(R) ==
         }
         ss_wave_lds_sync();
         SS_PROF_MARK(0);  // candidate scan
+#if SS_ABLATE == 1  // (timing / instruction-count knob: the output is wrong)
+        if (count < 100000u) return;
+#endif
         splat_accumulate_block_wave<R, ARITH, EARLY>(sh, P, logical, (int)count, posvol, perm, active_xyz, G, blk_minmax, trunc, facebits,
                                                            redo_mask ? __builtin_amdgcn_readfirstlane(redo_mask[logical]) : 0xFFu);
         SS_PROF_MARK(7);  // whole sub-block walk incl. epilogue (phases 1-6 are inside)

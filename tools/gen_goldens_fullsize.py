@@ -7,7 +7,8 @@ Build container only: imports the reference's pre-built wheel (tools/oracle_env.
 the scalar loop for sparse subdomains, dense_subdomains.rs:991-1133, :1413-1415; lib.rs:330-337) on
 
   * S10M-tank  (BASELINE config 3, bench.py's default workload: 10 M particles, ~7.2 M vertices), and
-  * S1M        (BASELINE config 2, simd=True; the scalar digest is tests/golden/config2_s1m.npz).
+  * S1M        (BASELINE config 2, simd=True; the scalar digest is tests/golden/config2_s1m.npz),
+  * S40M-tank  (BASELINE config 4, 39.8 M particles, simd=False) and S10M-cube (SURVEY 8d's literal reading 3' of config 3, both flags).
 
 Stored per case (data only): counts, sha256 of the sorted geometric vertex ids / the canonical triangle list over those
 ids / the densities, and 65 536 sampled (id, vertex) pairs.  The oracle (mode 0 against simd=False; modes 1 and 2 against
@@ -118,7 +119,12 @@ def main():
         # workload, simd flags to generate, oracle modes to compare per flag
         ("s1m", dict(kind="workload", name="uniform_cube", n=1_000_000, seed=12345), {True: (1, 2)}),
         ("s10m_tank", dict(kind="workload", name="tank", scale=1.0), {False: (0,), True: (1, 2)}),
+        # round 6: the two largest workloads -- config 4 (39.8 M particles, scalar mode = what the sharded bench
+        # measures) and the literal reading 3' of config 3 (10 x over-dense unit cube: the only large input of the over-dense kernels)
+        ("s40m_tank", dict(kind="workload", name="tank", scale=4.0 ** (1.0 / 3.0)), {False: (0,)}),
+        ("s10m_cube", dict(kind="workload", name="uniform_cube", n=10_000_000, seed=12346), {False: (0,), True: (1, 2)}),
     ]
+    golden_name = {"s1m": "config2_s1m", "s10m_tank": "config3_s10m_tank", "s40m_tank": "config4_s40m_tank", "s10m_cube": "config3p_s10m_cube"}
     rpath = os.path.join(GOLD, "FULLSIZE_REPORT.json")
     report = json.load(open(rpath)) if os.path.exists(rpath) else {}
     for wname, desc, flags in cases:
@@ -135,7 +141,7 @@ def main():
             ref = ref_run(pts, r, l, c, t, simd)
             rc = canon(ref, ref)
             canon_by_flag[simd] = rc
-            gname = ("simd_" if simd else "") + ("config2_s1m" if wname == "s1m" else "config3_s10m_tank")
+            gname = ("simd_" if simd else "") + golden_name[wname]
             rec = dict(reference_seconds=round(ref["seconds"], 2), n_vertices=int(rc[0].size), n_triangles=int(rc[2].shape[0]))
             if rho_sha is None:
                 rho_sha = sha(ref["densities"])
