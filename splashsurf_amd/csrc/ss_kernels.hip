@@ -811,11 +811,15 @@ struct SplatShared {
 // points [plo, phi]?  Same expression as the per-wave test in splat_accumulate_wave on a box that contains every wave's
 // sub-block, and all operations involved are monotone under rounding, so whatever a wave accepts passes here as well.
 template <class R>
-__device__ __forceinline__ bool ss_within_reach_of_block(const SSDevT<R>& P, const ss_real4<R>& pv, const R plo[3], const R phi[3]) {
+__device__ __forceinline__ R ss_block_box_dist2(const SSDevT<R>& P, const ss_real4<R>& pv, const R plo[3], const R phi[3]) {
     const R ex = ss_max(ss_max(plo[0] - pv.x, pv.x - phi[0]) - P.coord_slack, R(0.0));
     const R ey = ss_max(ss_max(plo[1] - pv.y, pv.y - phi[1]) - P.coord_slack, R(0.0));
     const R ez = ss_max(ss_max(plo[2] - pv.z, pv.z - phi[2]) - P.coord_slack, R(0.0));
-    return (ex * ex + ey * ey + ez * ez) <= P.R2;
+    return ex * ex + ey * ey + ez * ez;
+}
+template <class R>
+__device__ __forceinline__ bool ss_within_reach_of_block(const SSDevT<R>& P, const ss_real4<R>& pv, const R plo[3], const R phi[3]) {
+    return ss_block_box_dist2<R>(P, pv, plo, phi) <= P.R2;
 }
 
 // box of the block's points [plo, phi]; key0 = table index of the first splat cell of the block's covering range: the block scans the
@@ -903,7 +907,8 @@ __device__ __forceinline__ uint32_t ss_wave_inclusive_scan(uint32_t v) {
 // splat_wave_scan for the fused kernel: the scan is a chain of latencies (row table -> row of a candidate -> its payload), and a
 // wave that waits holds one of the SIMD's six wave slots, so the candidates are taken SS_SCAN_GROUP batches of 64 at a time:
 // the row look-ups of all batches of a group run interleaved (branch-free bisection over the row prefix table in LDS), then
-// all their loads are in flight together, then the batches are filtered and handed to f in order.  f as in splat_wave_scan.
+// all their loads are in flight together, then the batches are handed to f in order: f(d2, src, id, pv) with d2 = the candidate's
+// squared box distance to the block's points (<= P.R2: within reach; infinite for the lanes past the end), otherwise as in splat_wave_scan.
 #ifndef SS_SCAN_GROUP
 #define SS_SCAN_GROUP 6
 #endif
@@ -956,8 +961,9 @@ __device__ __forceinline__ void splat_wave_scan_grouped(const SSDevT<R>& P, cons
             for (int j = 0; j < SS_SCAN_GROUP; ++j) {
                 const uint32_t qj = q0 + 64u * (uint32_t)j;
                 if (qj >= total) break;  // (wave-uniform)
-                const bool inside = (qj + (uint32_t)lane < total) && ss_within_reach_of_block<R>(P, pv[j], plo, phi);
-                if (!f(inside, src[j], id[j], pv[j])) return;  // (wave-uniform)
+                // squared box distance of the candidate to the block's points (infinite beyond the rows' end): f decides what is within reach
+                const R d2 = (qj + (uint32_t)lane < total) ? ss_block_box_dist2<R>(P, pv[j], plo, phi) : R(INFINITY);
+                if (!f(d2, src[j], id[j], pv[j])) return;  // (wave-uniform)
             }
         }
         ss_wave_lds_sync();  // the next batch overwrites the row tables
@@ -1832,9 +1838,10 @@ __device__ __forceinline__ void splat_sort_tile(SplatAccWaveShared<R>& sh, const
     ss_wave_lds_sync();
 }
 
-// The tile is in LDS: sh.pay[0, n_tile) payload in scan order, sh.idx its positions in the cell-sorted arrays (k_splat_fused).
+// The tile is in LDS: sh.pay[0, n_tile) payload in scan order, sh.idx its positions in the cell-sorted arrays; f32 first pass: sh.near[0, n_near_block)
+// the positions in the tile of the entries within the near radius of the block's box (k_splat_fused).
 template <class R, int ARITH, bool EARLY>
-__device__ __forceinline__ void splat_accumulate_block_wave(SplatAccWaveShared<R>& sh, const SSDevT<R>& P, uint32_t logical, int n_tile, const ss_real4<R>* __restrict__ posvol,
+__device__ __forceinline__ void splat_accumulate_block_wave(SplatAccWaveShared<R>& sh, const SSDevT<R>& P, uint32_t logical, int n_tile, int n_near_block, const ss_real4<R>* __restrict__ posvol,
                                                             const uint32_t* __restrict__ perm,
                                                             const uint32_t* __restrict__ active_xyz, R* __restrict__ G, ss_real2<R>* __restrict__ blk_minmax,
                                                             uint32_t* __restrict__ trunc, unsigned long long* __restrict__ facebits, uint32_t wave_mask) {
@@ -1871,8 +1878,8 @@ __device__ __forceinline__ void splat_accumulate_block_wave(SplatAccWaveShared<R
             }
     }
     // ---- f32 first pass: records and index lists of the certificate (see splat_cert_record) ----
-    // Every entry's payload is replaced IN PLACE by its 16-byte record (coordinates relative to the block's centre); the near entries of
-    // all eight sub-blocks are listed in ONE pass over the tile as byte indices into the tile: list sb = bytes [64 sb, 64 sb + 64) of the
+    // The payload of every entry within the near radius of the BLOCK's box is replaced IN PLACE by its 16-byte record (coordinates relative
+    // to the block's centre); the near entries of all eight sub-blocks are listed in ONE pass over those entries as byte indices into the tile: list sb = bytes [64 sb, 64 sb + 64) of the
     // pool, padded with the dummy's index.  The near test of a sub-block (box distance <= R_near, separable: six one-dimensional
     // distances per entry) goes straight into its ballot -- no mask word per entry -- and the ballot's prefix count places the entry.
     // cnt[sb]: entries near sub-block sb; a list longer than its 64 slots (two tiles) is not walked: that sub-block goes to the exact sums.
@@ -1890,10 +1897,10 @@ __device__ __forceinline__ void splat_accumulate_block_wave(SplatAccWaveShared<R
         }
 #pragma unroll
         for (int k = 0; k < CH / 64; ++k) {
-            if (64 * k >= n_tile) break;  // (wave-uniform)
-            const int c = lane + 64 * k;
-            const bool valid = c < n_tile;
-            const ss_real4<R> pv = sh.pay[valid ? c : 0];
+            if (64 * k >= n_near_block) break;  // (wave-uniform; S10M-tank: 63 of a tile's 142 entries, one trip)
+            const bool valid = lane + 64 * k < n_near_block;
+            const int c = valid ? (int)sh.near[lane + 64 * k] : 0;
+            const ss_real4<R> pv = sh.pay[c];
             float e2[3][2];
             const float p3[3] = {pv.x, pv.y, pv.z};
 #pragma unroll
@@ -2116,7 +2123,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(sizeof(R) ==
         const uint32_t logical = __builtin_amdgcn_readfirstlane(list ? list[it] : it);
         const int b3[3] = {(int)active_xyz[3 * (size_t)logical], (int)active_xyz[3 * (size_t)logical + 1], (int)active_xyz[3 * (size_t)logical + 2]};
         R plo[3], phi[3];
-        uint32_t count = 0;
+        uint32_t count = 0, n_near_block = 0;
         SS_PROF_BEGIN();
         ss_wave_lds_sync();  // the previous block's reads of the tile are done
         {
@@ -2126,7 +2133,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(sizeof(R) ==
             // that overflow anyway cost 1.6 ms).
             uint32_t bailed = 0;
             splat_wave_scan_grouped<R, false>(P, posvol, perm, cell_start, key0, plo, phi, s_row_start, s_row_prefix, lane, (uint32_t)(SS_FUSED_BAIL * CH), &bailed,
-                                     [&](bool inside, uint32_t src, uint32_t, const ss_real4<R>& pv) {
+                                     [&](R d2, uint32_t src, uint32_t, const ss_real4<R>& pv) {
+                                         const bool inside = d2 <= P.R2;
                                          const unsigned long long m = __ballot(inside);
                                          const uint32_t pos = count + (uint32_t)__popcll(m & below);
                                          if (inside && pos < (uint32_t)CH) {
@@ -2134,6 +2142,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(sizeof(R) ==
                                              sh.idx[pos] = src;  // (the particle index is looked up by the blocks that order their tile)
                                          }
                                          count += (uint32_t)__popcll(m);
+                                         if constexpr (EARLY && sizeof(R) == 4) {
+                                             // the certificate works on the entries within the NEAR radius of the block's box only (every sub-block's near
+                                             // entries are among them: its box lies inside the block's): their positions in the tile, in sh.near
+                                             const bool nb = d2 <= P.R2near;
+                                             const unsigned long long mn = __ballot(nb);
+                                             if (nb && pos < (uint32_t)CH) sh.near[n_near_block + (uint32_t)__popcll(mn & below)] = (uint8_t)pos;
+                                             n_near_block += (uint32_t)__popcll(mn);
+                                         }
                                          return count <= (uint32_t)CH;  // a block with more candidates takes the arena path, which counts them itself
                                      });
             if (bailed) count = bailed;  // (> CH; the arena path counts exactly)
@@ -2148,7 +2164,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(sizeof(R) ==
 #if SS_ABLATE == 1  // (timing / instruction-count knob: the output is wrong)
         if (count < 100000u) return;
 #endif
-        splat_accumulate_block_wave<R, ARITH, EARLY>(sh, P, logical, (int)count, posvol, perm, active_xyz, G, blk_minmax, trunc, facebits,
+        splat_accumulate_block_wave<R, ARITH, EARLY>(sh, P, logical, (int)count, (int)n_near_block, posvol, perm, active_xyz, G, blk_minmax, trunc, facebits,
                                                            redo_mask ? __builtin_amdgcn_readfirstlane(redo_mask[logical]) : 0xFFu);
         SS_PROF_MARK(7);  // whole sub-block walk incl. epilogue (phases 1-6 are inside)
     };
