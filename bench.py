@@ -462,6 +462,10 @@ def main():
     r = wl["particle_radius"]
     prm = make_params(wl, args.simd)
     ctx = Context(local_rank)
+    # SS_OPTION_SPLAT_TWO_PASS pinned for the timed steps (include/splashsurf_hip.h: the automatic mode decides from what the context's earlier calls
+    # certified, so a timed mode could depend on call history); the secondary configurations run in the automatic mode and say so
+    two_pass_main = 1 if workload in ("s10m_tank", "s40m_tank", "s10m_cube", "s1m") else -1
+    ctx.set_two_pass(two_pass_main)
     nsc = int(prm.subdomain_num_cubes_per_dim) + 1
 
     def barrier():
@@ -634,7 +638,7 @@ def main():
         "config": {
             "workload": workload, "n_particles": int(n_total), "particle_radius": r, "smoothing_length": wl["smoothing_length"],
             "cube_size": wl["cube_size"], "n_vertices": int(last_stats["n_vertices"]), "n_triangles": int(last_stats["n_triangles"]),
-            "enable_simd": int(prm.enable_simd), "arith_mode": int(last_stats.get("arith_mode", -1)),
+            "enable_simd": int(prm.enable_simd), "arith_mode": int(last_stats.get("arith_mode", -1)), "splat_two_pass": two_pass_main,
             "input": "HBM-resident (x,y,z) f32 (the task contract's definition of `value`; host-to-host figures: e2e_host_u64, pcie_inclusive)",
             "output": "mesh in HBM (vertices f32, triangles u32, global edge keys)", "parallelism": parallelism,
         },
@@ -661,7 +665,7 @@ def main():
                                              "triangle indices in host memory through the C ABI's accessors (SURVEY.md 8(d)(i)), median of 10 frames, one frame at a time (upload -> kernels -> download is a chain: "
                                              "nothing of one frame overlaps; pcie_pipelined = two frames in flight)")
     if not sharded_path:
-        attach_traffic(line, workload, dev)
+        attach_traffic(line, workload, dev, live=(rank == 0 and not args.main_only))
     if rank == 0:
         if not sharded_path and not args.no_cpu_baseline and not args.main_only:
             try:
@@ -685,7 +689,7 @@ def attach_traffic(line, workload, dev):
             line["roofline"]["traffic_note"] = ("profiles/splat_traffic.json was collected from other kernel sources (stamp %s, this build %s): not attached; "
                                                 "re-run tools/collect_profiles.sh + tools/make_profiles.py" % (stamp, kernel_source_stamp()))
             tr = None
-        if tr and tr.get("kernel", "").startswith(line["roofline"]["kernel"]):
+        if tr and (line["roofline"]["traffic_source"] == "live" or tr.get("kernel", "").startswith(line["roofline"]["kernel"])):
             line["roofline"]["traffic"] = tr["hbm_bytes_per_launch"]
             line["roofline"]["traffic_note"] = tr["note"]
             if line["roofline"]["kernel_ms"] > 0:
@@ -712,6 +716,7 @@ def single_gpu_extras(line, args, ctx, prm, wl, workload, pts, d_pts, out, dev, 
     from splashsurf_amd.api import Context
     n_total = pts.shape[0]
     nsc = int(prm.subdomain_num_cubes_per_dim) + 1
+    line["enable_simd"] = int(prm.enable_simd)  # (top level, next to `value`: the headline is the scalar arithmetic, the library's default is 1 -- arithmetic_modes has both)
     # --- the other arithmetic modes of the same workload (Parameters::enable_simd: 0 scalar bit-exact, 1 the reference's
     #     default SIMD arithmetic, 2 the same with v_sqrt_f32), each with its own roofline ---
     modes = {}
@@ -733,6 +738,7 @@ def single_gpu_extras(line, args, ctx, prm, wl, workload, pts, d_pts, out, dev, 
         except Exception as e:
             modes[names[m]] = {"enable_simd": m, "value": None, "note": "failed: %r" % (e,)}
     line["arithmetic_modes"] = modes
+    line["value_enable_simd_1"] = (modes.get("simd") or {}).get("value")  # the library-default arithmetic, next to the headline
     # --- host-resident input -> host-resident output through the C ABI's host accessors ---
     host_pts = pts
     for key, u64, note in (("e2e_host_u64", True, "pageable host (numpy) input via ss_reconstruct_surface_inplace_f32; vertices through ss_result_vertices and u64 triangle "
@@ -782,7 +788,8 @@ def single_gpu_extras(line, args, ctx, prm, wl, workload, pts, d_pts, out, dev, 
         ctxs[1].close()
     except Exception as e:
         line["pcie_pipelined"] = {"value": None, "note": "failed: %r" % (e,)}
-    # --- the other BASELINE.json configs, HBM-resident like `value`, driver-timed in the same run ---
+    # --- the other BASELINE.json configs, HBM-resident like `value`, driver-timed in the same run (SS_OPTION_SPLAT_TWO_PASS automatic: tiny jobs skip the scheme) ---
+    ctx.set_two_pass(-1)
     others = {}
     data = os.path.join(ROOT, "tests", "data")
     cases = [
@@ -814,6 +821,7 @@ def single_gpu_extras(line, args, ctx, prm, wl, workload, pts, d_pts, out, dev, 
             others[name] = {"value": None, "note": "failed: %r" % (e,)}
     line["other_configs"] = others
     # --- an HBM-bound splat configuration: the same particles on a coarse grid (cube radius R = ceil(h / cs) = 2) ---
+    ctx.set_two_pass(1)
     try:
         p_ = make_params(dict(wl, cube_size=2.0), args.simd)
         dt_, o_, k3_ = timed_direct(ctx, p_, d_pts, max(3, args.steps // 2), 2, sync)

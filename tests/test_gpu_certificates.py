@@ -1,8 +1,9 @@
 """Soundness of the splat's certificates (-m gpu).
 
-By default the level-set splat certifies 4^3 sub-blocks "inside the fluid" with a cheap LOWER bound of the level set (near particles only, a
-polynomial below the cubic spline, f16 list records and -- since round 5 -- packed f16 arithmetic; ss_kernels.hip, splat_bound_walk16) and never
-evaluates them unless marching cubes reads their values.  The mesh tests show that the output does not change; this file checks the property
+By default the level-set splat certifies 4^3 sub-blocks "inside the fluid" with a cheap LOWER bound of the level set (near particles only; since
+round 6 the bound C4 u^4 below the cubic spline, evaluated for 32 entries x 32 points per v_mfma_f32_32x32x8_f16 on f16 operand records with a
+slack that covers their rounding: ss_kernels.hip, splat_cert_record / splat_cert_tile; over-dense blocks: the polynomial bound of
+splat_bound_walk on f16 list records) and never evaluates them unless marching cubes reads their values.  The mesh tests show that the output does not change; this file checks the property
 itself: for every sub-block that stayed certified, all 64 values of the COMPLETELY evaluated level set (SS_OPTION_FULL_LEVELSET on a second
 context, bit-identical to the oracle: test_levelset_bit_identical_per_subdomain) lie above the iso-surface threshold -- on bulk fluid, on a scene
 far from the origin (coordinate slack), on a coarse and on a fine grid (f16 ranges), and in both arithmetics.

@@ -303,6 +303,63 @@ def test_splat_lower_bound_polynomial_bounds_the_spline():
     assert mass > 0.95
 
 
+def test_splat_certificate_quartic_bounds_the_spline():
+    """Round 6: the certificate on the matrix pipe uses C4 u^4 <= W(q) / sigma, u = max(1 - q^2, 0) (splat_cert_record).  For q >= 1/2 the ratio
+    2 (1 - q)^3 / (1 - q^2)^4 = 2 / ((1 - q)(1 + q)^4) has its minimum 2 / (0.4 * 1.6^4) = 0.762939... at q = 3/5; the constants the kernel and the
+    host are compiled with must lie below it, the inner piece must stay above, and the bound holds 90 % of the kernel's mass."""
+    import os
+    import re
+    root = os.path.join(os.path.dirname(__file__), "..", "splashsurf_amd", "csrc")
+    c4 = float(np.float32(float(re.search(r"#define SS_CERT_C4 ([0-9.eE+-]+)f", open(os.path.join(root, "ss_kernels.hip")).read()).group(1))))
+    c4_host = float(re.search(r"P\.cert_vscale = \(R\)\(\(double\)([0-9.]+) \* \(double\)sig", open(os.path.join(root, "ss_api.hip")).read()).group(1))
+    assert c4_host == pytest.approx(c4, abs=1e-7) and c4 < 2.0 / (0.4 * 1.6 ** 4)
+    q = np.linspace(0.0, 1.0, 400001)
+    u = 1.0 - q * q
+    w = np.where(q < 0.5, 1.0 - 6.0 * q * q + 6.0 * q ** 3, 2.0 * (1.0 - q) ** 3)
+    g = c4 * u ** 4
+    assert np.all(g <= w)
+    low = q <= 0.99
+    assert np.min((w - g)[low] / g[low]) > 1.0e-6  # (tight at q = 0.6 by construction: the gap there is 0.762939 / 0.76293 - 1 = 1.2e-5)
+    assert abs(np.gradient(w - g, q)[np.argmin(np.abs(q - 0.6))]) < 1e-3  # the gap's minimum at q = 0.6 is a tangent minimum, not a crossing the grid could straddle
+    mass = np.trapezoid(g * q * q, q) / np.trapezoid(w * q * q, q)
+    assert 0.90 < mass < 0.905
+
+
+def test_splat_certificate_f16_operands_stay_below_the_bilinear_form():
+    """splat_cert_record / the B operands of splat_accumulate_block_wave: every operand of the 32 x 32 x 8 tile is an f16, the products are exact and summed
+    in f32.  With the slack eps = cert_e1 (|px| + |py| + |pz|) + cert_e0 taken off a = 1 - |p|^2 (make_device_params) the tile's value must not exceed
+    s (1 - |x - p|^2) for any entry / point pair -- checked here by restating the record in numpy f32 / f16 and the exact value in f64, for the cube-size /
+    support ratios of the sweep (coordinates relative to the block's centre in units of h)."""
+    rng = np.random.default_rng(11)
+    f16, f32 = np.float16, np.float32
+    worst = -1.0
+    for ratio in (1.0 / 30.0, 0.125, 0.2, 0.45, 1.0, 0.11, 2.0):
+        xm = 3.5 * ratio * (1.0 + 1.0e-5) + 1.0e-6
+        r = 2.0 ** -10 * (1.0 + 2.0 ** -10)
+        e1, e0 = f32(r * 2.0 * xm * (1.0 + 1.0e-6)), f32((r * 3.0 * xm * xm + 3.0e-5) * (1.0 + 1.0e-6))
+        n = 4000
+        p = ((rng.random((n, 3)) * 2.0 - 1.0) * (3.5 * ratio + 0.66)).astype(f32)          # entries within the near radius of the block's box
+        x = ((rng.integers(0, 8, size=(n, 3)).astype(np.float64) - 3.5) * ratio).astype(f32)  # the block's points
+        x = (x.astype(np.float64) * (1.0 + (rng.random((n, 3)) - 0.5) * 1e-6)).astype(f32)    # (f32 noise of far-from-origin scenes)
+        s = (0.55 + 0.3 * rng.random(n)).astype(f32)
+        eps = (e1 * ((np.abs(p[:, 0]) + np.abs(p[:, 1])) + np.abs(p[:, 2])) + e0).astype(f32)
+        a = (((f32(1.0) - eps) - p[:, 0] * p[:, 0]) - (p[:, 1] * p[:, 1] + p[:, 2] * p[:, 2])).astype(f32)
+        sa = (s * a).astype(f32)
+        sa_hi = sa.astype(f16)
+        sa_lo = (sa - sa_hi.astype(f32)).astype(f32).astype(f16)
+        s2 = (s + s).astype(f32)
+        P3 = (s2[:, None] * p).astype(f32).astype(f16)
+        ms = (-s).astype(f16)
+        xh = x.astype(f16)
+        xxh = (x * x).astype(f32).astype(f16)
+        d = (sa_hi.astype(np.float64) + sa_lo.astype(np.float64) + (P3.astype(np.float64) * xh.astype(np.float64)).sum(1) + (ms.astype(np.float64)[:, None] * xxh.astype(np.float64)).sum(1))
+        truth = s.astype(np.float64) * (1.0 - ((x.astype(np.float64) - p.astype(np.float64)) ** 2).sum(1))
+        # the f32 accumulation inside the instruction: eight products of magnitude < 10 -> below 1e-5, which cert_e0 holds (3e-5 s >= 1.6e-5)
+        worst = max(worst, float(np.max(d + 1.0e-5 - truth)))
+        assert np.all(d + 1.0e-5 <= truth), (ratio, float(np.max(d - truth)))
+    assert worst < 0.0
+
+
 def test_splat_lower_bound_survives_the_f16_list_records():
     """The list records of the lower-bound pass hold (x, y, z) as f16 relative to the block's centre in units of h and V sigma as
     f16 rounded towards zero (splat_bound_record); the kernel evaluates u' = max(bound_one - |e16 - p|^2, 0) with bound_one =

@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
-"""tools/lab/soak.py -- run-to-run determinism at benchmark scale: N frames of S10M-tank on one context, every frame's densities / vertices /
+"""tools/soak.py -- run-to-run determinism at benchmark scale: N frames of S10M-tank on one context, every frame's densities / vertices /
 triangles hashed; all digests must agree (a race or an order-dependent sum would show as a differing frame)."""
 import hashlib, json, os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import torch
 from splashsurf_amd import workloads as W

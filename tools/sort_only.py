@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
-"""tools/lab/sort_only.py -- the library's pair sort on 10 M random 24-bit keys, a few times (profiled with rocprofv3 --kernel-trace --stats per variant)."""
+"""tools/sort_only.py -- the library's pair sort on 10 M random 24-bit keys, a few times (profiled with rocprofv3 --kernel-trace --stats per variant)."""
 import ctypes as C, os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import splashsurf_amd as S
 L = S.load_library()
