@@ -291,13 +291,6 @@ ss_status make_device_params(ss_context* ctx, const typename TypesOf<R>::params*
     R amax = R(0.0);
     for (int d = 0; d < 3; ++d) amax = ss_max(amax, ss_max(std::fabs(g.aabb_min[d]), std::fabs(g.aabb_max[d])));
     P.coord_slack = R(16.0) * std::numeric_limits<R>::epsilon() * amax + 1e-30f;
-    {   // splat_bound_record: list coordinates are f16, relative to the block's centre in units of h, at most emax in size.  The near
-        // filter admits entries up to R_near + coord_slack from the sub-block's box, and coord_slack (16 ulp of the largest coordinate)
-        // is not small against h for scenes far from the origin: it is part of emax.
-        const double emax = 3.5 * (double)prm->cube_size / (double)h + (double)SS_TUNE_RNEAR + (double)P.coord_slack / (double)h + 1.0e-3;
-        const double eps = std::ldexp(1.0, (int)std::floor(std::log2(emax)) - 11);  // half an f16 ulp of emax's binade
-        P.bound_one = (R)std::max(0.0, 1.0 - (3.6 * eps + 3.0 * eps * eps + 2.0e-6));  // 2 sqrt(3) = 3.47
-    }
     {   // splat_cert_record (ss_kernels.hip): slack of the f16 operands of the certificate's tiles.  xm: largest |coordinate| of a block's points
         // relative to the block's centre, in units of h.
         const double xm = 3.5 * (double)prm->cube_size / (double)h * (1.0 + 1.0e-5) + 1.0e-6;

@@ -109,7 +109,6 @@ struct SSDevT {
     R R2;         // support^2 * (1+1e-4): squared reach of the conservative block / wave filters of the splat
     R R2near;     // (0.64 h)^2: sub-block filter of the splat's classification pass (make_device_params)
     R thr_inside; // threshold * (1 + 1e-4): a lower bound above it certifies 'inside' whatever the summation order
-    R bound_one;  // 1 - slack covering the f16 coordinates of the packed lower-bound pass (splat_bound_packed, make_device_params)
     // certificate on the matrix pipe (splat_cert_record): C4 sigma (1 - 2e-5), and the slack eps = cert_e1 (|px| + |py| + |pz|) + cert_e0 taken off 1 - |p|^2
     R cert_vscale, cert_e1, cert_e0;
     // Parameters::enable_simd: constants of CubicSplineKernelAvxF32 (kernel.rs:327-337), formed in f32 like the reference does

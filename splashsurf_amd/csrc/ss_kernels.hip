@@ -724,11 +724,12 @@ void ss_launch_mark_blocks(const SSDevT<R>& P, const uint32_t* cell_start, uint3
 //      group in flight together, splat_wave_scan_grouped), tests every particle against the box spanned by the block's points and
 //      keeps the survivors -- payload (x, y, z, V) and particle index -- in LDS, in scan order.
 //   2. certify: for each of the eight sub-blocks a LOWER BOUND of the level set from the entries close to the sub-block (any
-//      order, cheap arithmetic).  f32: the near lists of all eight sub-blocks are built in one pass over the tile as 8-byte f16
-//      records in a pool in LDS (splat_bound_record), then walked one after the other (splat_bound_walk), every lane adding its
-//      point's term; f64: phase A tests 64 tile entries at once against the sub-block's box, phase B walks the survivors
-//      (splat_accumulate_wave).  If the bound exceeds the threshold at all 64 points the sub-block lies inside the surface and is
-//      neither evaluated nor stored.
+//      order, cheap arithmetic).  f32: the entries within the near radius of the block's box get a 16-byte record of f16 operands
+//      in place of their payload, the near entries of all eight sub-blocks are listed as byte indices in one pass, and every list goes
+//      through the MATRIX PIPE 32 entries x 32 points at a time (splat_cert_record / splat_cert_mfma: s u is bilinear in an entry's and a
+//      point's vector, the bound C4 u^4 leaves three VALU instructions per pair); f64: phase A tests 64 tile entries at once against the
+//      sub-block's box, phase B walks the survivors (splat_accumulate_wave).  If the bound exceeds the threshold at all 64 points the
+//      sub-block lies inside the surface and is neither evaluated nor stored.
 //   3. evaluate: if sub-blocks remain, the wave ranks the tile by ORIGINAL particle index (splat_sort_tile: an order array, the
 //      tile stays where it is) -- the reference's per-point summation order (sorted per-subdomain particle lists,
 //      dense_subdomains.rs:476-488) -- and evaluates G += V * W(|x - p|) in the reference's arithmetic
@@ -766,10 +767,6 @@ __device__ __forceinline__ void ss_wave_lds_sync() {
 #define SS_WAVE_LIST 66  // survivors of one 64-entry batch per wave (+ 2 slots the read-ahead may touch)
 // lower bound of the cubic spline in u = 1 - q^2 (ss_splat_pair, SS_ARITH_BOUND): u^3 (C0 + C1 u^2) <= W(q) / sigma
 #define SS_BOUND_C0 0.150818f
-#ifndef SS_BOUND_POOL
-#define SS_BOUND_POOL 212
-#endif
-// ^ 8-byte list records of one block's lower-bound pass (SplatAccWaveShared::wl)
 // -DSS_PHASE_PROF (tools/build_variant.sh NAME -- -DSS_PHASE_PROF): wave-cycles per phase of k_splat_fused, summed over all waves
 // into g_phase_prof (256 rows of 16 counters against atomic contention), read with ss_debug_phase_prof (tools/phase_prof.py)
 #ifdef SS_PHASE_PROF
@@ -1654,65 +1651,12 @@ __device__ __forceinline__ uint32_t splat_near_masks(const SSDevT<R>& P, const s
     return m;
 }
 
-// The lower-bound pass over 8-BYTE list records (f32 kernels, one wave per block).  The records are packed: (x, y, z) relative to
-// the BLOCK's centre in units of h as three f16, V sigma as the fourth, two entries per 16-byte read, consumed by v_fma_mix_f32
-// (f16 operands converted on the fly: no unpacking instructions).  Still a LOWER bound: V sigma is rounded towards zero; a
-// coordinate rounded to nearest is off by at most eps = half an f16 ulp of the largest |coordinate| (P.bound_one,
-// make_device_params), which moves d^2 by at most 2 sqrt(3) |d| eps + 3 eps^2, and u' = max(bound_one - d'^2, 0) with
-// bound_one = 1 - 3.6 eps - ... is <= max(1 - d^2, 0) for every d.
 typedef _Float16 ss_half2v __attribute__((ext_vector_type(2)));
-#define SS_BOUND_DUMMY make_uint2(0x56405640u, 0x00005640u)  // (100, 100, 100), volume 0: u = 0
-__device__ __forceinline__ uint2 splat_bound_record(const SSDevT<float>& P, const ss_real4<float>& pv, float cx, float cy, float cz) {
-    const ss_half2v xy = {(_Float16)((pv.x - cx) * P.avx_inv_h), (_Float16)((pv.y - cy) * P.avx_inv_h)};
-    const uint32_t vv = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(0.0f, pv.w * P.avx_sigma));  // towards zero = down; high half
-    const ss_half2v zz = {(_Float16)((pv.z - cz) * P.avx_inv_h), (_Float16)0.0f};
-    return make_uint2(__builtin_bit_cast(uint32_t, xy), __builtin_bit_cast(uint32_t, zz) | vv);
-}
-
-// Walk of one list: n entries at `list` (8-byte aligned to 16), padded with dummies to a multiple of four, 16 readable bytes
-// behind the padding.  (npx, npy, npz) = minus the lane's point in the records' frame.  Returns the sum in units of 1 (V sigma g).
-__device__ __forceinline__ float splat_bound_walk(const SSDevT<float>& P, const uint2* list, int n, float npx, float npy, float npz) {
-    const float one = P.bound_one;
-    float acc = 0.0f;
-    auto pair = [&](uint32_t w0, uint32_t w1) {
-        float dx, dy, dz, u, r;
-        asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel_hi:[1,0,0]" : "=v"(dx) : "v"(w0), "v"(npx));
-        asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(dy) : "v"(w0), "v"(npy));
-        asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel_hi:[1,0,0]" : "=v"(dz) : "v"(w1), "v"(npz));
-        const float a = __builtin_fmaf(-dx, dx, __builtin_fmaf(-dy, dy, one));
-        asm("v_fma_f32 %0, -%1, %1, %2 clamp" : "=v"(u) : "v"(dz), "v"(a));
-        const float u2 = u * u;
-        const float t = (u2 * u) * __builtin_fmaf(u2, SS_BOUND_C1, SS_BOUND_C0);
-        asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[0,1,0]" : "=v"(r) : "v"(t), "v"(w1), "v"(acc));
-        acc = r;
-    };
-    // The walk is software-pipelined by hand: the compiler sinks a read-ahead written in C++ to the top of the next trip and
-    // waits for it at once (every trip then exposes one LDS latency), so the reads are issued in asm, one 16-byte read (two
-    // entries) ahead, with their own s_waitcnt -- LDS reads return in order, lgkmcnt(1) = "everything but the newest read".
-    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-    const int trips = (n + 3) >> 2;
-    uint32_t addr = (uint32_t)(uintptr_t)list;  // LDS byte address of the list
-    u32x4 qa, qb;
-    asm volatile("ds_read_b128 %0, %1" : "=v"(qa) : "v"(addr) : "memory");
-    for (int k = 0; k < trips; ++k) {
-        asm volatile("ds_read_b128 %0, %1 offset:16" : "=v"(qb) : "v"(addr));
-        asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(qa));
-        pair(qa.x, qa.y);
-        pair(qa.z, qa.w);
-        asm volatile("ds_read_b128 %0, %1 offset:32" : "=v"(qa) : "v"(addr));
-        asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(qb));
-        pair(qb.x, qb.y);
-        pair(qb.z, qb.w);
-        addr += 32u;
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(qa));  // the last read-ahead has landed before its registers are reused
-    return acc;
-}
 
 // ---- the certificate on the MATRIX PIPE (f32, one wave per block; round 6) -----------------------------------------------------
 // The bound  W(q) / sigma >= C4 u^4,  u = max(1 - q^2, 0):  for q >= 1/2 the ratio 2 (1 - q)^3 / (1 - q^2)^4 = 2 / ((1 - q) (1 + q)^4) has its
 // minimum 0.762939... at q = 3/5, the inner piece stays above it (tests/test_oracle.py checks the inequality); it carries 90.2 % of the
-// kernel's mass (the polynomial u^3 (c0 + c1 u^2) of splat_bound_walk: 95.9 %).  It is HOMOGENEOUS in u, so a particle's weight folds
+// kernel's mass (the polynomial u^3 (c0 + c1 u^2) of rounds 3-5 and of the arena kernel's classification, ss_splat_pair: 95.9 %).  It is HOMOGENEOUS in u, so a particle's weight folds
 // into the argument,  V sigma C4 u^4 = (s u)^4  with  s = (C4 sigma V)^(1/4),  and
 //     s u = s (1 - |p|^2) + 2 s p . x - s |x|^2        (p: entry, x: grid point; relative to the block's centre, in units of h)
 // is BILINEAR in a vector of the entry and a vector of the point: ONE v_mfma_f32_32x32x8_f16 evaluates it for 32 entries x 32 points,
@@ -1722,7 +1666,7 @@ __device__ __forceinline__ float splat_bound_walk(const SSDevT<float>& P, const 
 // (lanes 0-31 hold slots 0-3 of row / column `lane`, lanes 32-63 slots 4-7 of row / column `lane - 32`; D: column = lane & 31, row =
 // (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5); layout and rates: tools/ubench/mfma_cert.hip), and THREE VALU instructions per (entry, point)
 // pair are left -- max with 0 (an integer max on the bit pattern: no canonicalisation), a square, an fmac of the square with itself --
-// against the eleven of splat_bound_walk: 150 cycles per 1024 pairs per SIMD instead of ~480 (mfma_cert.hip; the matrix pipe's 32
+// against the eleven of the list walk of rounds 3-5 (f16 records, v_fma_mix_f32): 150 cycles per 1024 pairs per SIMD instead of ~480 (mfma_cert.hip; the matrix pipe's 32
 // cycles do not overlap the VALU's on this chip, they add).
 // STILL A LOWER BOUND: the products of f16 operands are exact and summed in f32; against the f32 values an operand rounded to nearest is off by
 // 2^-11 relative, so  |P~ x~ - 2 s p x| <= 2 s |p| |x| 2^-10 (1 + 2^-11)  per axis and  |s~ (x^2)~ - s x^2| <= s x^2 2^-10 (1 + 2^-11);
@@ -2203,8 +2147,12 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(sizeof(R) =
 // deep inside the fluid and need nothing but the certificate, so the certificate now comes first and without a tile: one workgroup
 // per block, wave w = sub-block w.  The wave streams the splat cells around ITS sub-block's near box (the box of its 4^3 points
 // dilated by the near radius of the classification, not by the particle reach: a quarter of the block's candidates), keeps the
-// particles whose box distance is within the near radius as 8-byte records (splat_bound_record) in a list in LDS and walks the
-// list with every lane adding its point's lower-bound term (splat_bound_walk); lists longer than SS_CERT_LIST are walked in pieces.
+// particles whose box distance is within the near radius as 16-byte records (splat_cert_record) in a list in LDS and puts the list through
+// the matrix pipe 32 entries at a time (splat_cert_mfma: the certificate of k_splat_fused); lists longer than SS_CERT_LIST go in pieces, and
+// after every piece the wave tests whether all its points are above the threshold already and stops streaming if so.  (Over-dense does
+// not mean "certified early": the level set is normalised by the particles' own densities, V = m / rho, so its value inside an over-dense
+// fluid is 1 as well and the bound needs the same share of the kernel's mass -- a smaller near radius tried first for dense blocks made
+// S10M-cube's certification 5.65 instead of 4.38 ms: it fails and the full radius follows.)
 // trunc[b] = the certified sub-blocks; a fully certified block is finished here (min / max, no face bits, nothing stored).
 // k_big_tile_select then decides which of these blocks need a tile at all: the ones with a sub-block left to evaluate, and the
 // fully certified ones that k_select_redo can ask to complete later -- it only does that for a block with a face neighbour that
@@ -2217,7 +2165,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
                                                                                                      uint32_t n_active, const uint32_t* __restrict__ counts,
                                                                                                      ss_real2<float>* __restrict__ blk_minmax, uint32_t* __restrict__ trunc,
                                                                                                      unsigned long long* __restrict__ facebits, uint32_t* __restrict__ need_mask) {
-    __shared__ __attribute__((aligned(16))) uint2 s_list[8][SS_CERT_LIST + 64 + 8];
+    __shared__ __attribute__((aligned(16))) uint4 s_list[8][SS_CERT_LIST + 64 + 31];  // certificate records (splat_cert_record); + 31: padding to whole tiles (four workgroups per CU: <= 40 960 bytes)
     __shared__ uint32_t s_row_start[8][64];
     __shared__ uint32_t s_row_prefix[8][64];
     __shared__ uint32_t s_cert;
@@ -2229,7 +2177,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     const int b3[3] = {(int)active_xyz[3 * (size_t)logical], (int)active_xyz[3 * (size_t)logical + 1], (int)active_xyz[3 * (size_t)logical + 2]};
     const int s3[3] = {(wave >> 2) & 1, (wave >> 1) & 1, wave & 1};
     const int o3[3] = {(lane >> 4) & 3, (lane >> 2) & 3, lane & 3};
-    float slo[3], shi[3], npc[3], bc[3];
+    float slo[3], shi[3], bc[3];
     bool valid = true, point_valid = true;
 #pragma unroll
     for (int d = 0; d < 3; ++d) {
@@ -2239,15 +2187,29 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
         slo[d] = P.gmin[d] + (float)g0 * P.cs;
         shi[d] = P.gmin[d] + (float)min(g0 + 3, P.np[d] - 1) * P.cs;
         bc[d] = (P.gmin[d] + (float)(b3[d] * SS_BLOCK) * P.cs) + 3.5f * P.cs;  // the records' frame: the block's centre (splat_accumulate_block_wave)
-        const float pc = P.gmin[d] + (float)(g0 + o3[d]) * P.cs;
-        npc[d] = (bc[d] - pc) * P.avx_inv_h;
+    }
+    // B operands of this wave's two tiles (columns = points [32 g, 32 g + 32) of its sub-block; splat_cert_record): lanes 0-31 hold the x content
+    // of their column, lanes 32-63 the (y, z) content.  (The certificate bounds the level set from below whatever arithmetic evaluates it: the
+    // points' coordinates are those of the scalar loop, the SIMD loop's z -- one fma -- differs by an ulp, far inside the slack.)
+    uint32_t cb0, cb1[2];
+    {
+        const bool lo_half = lane < 32;
+        const float y = ((P.gmin[1] + (float)(b3[1] * SS_BLOCK + 4 * s3[1] + o3[1]) * P.cs) - bc[1]) * P.avx_inv_h;
+        const float z = ((P.gmin[2] + (float)(b3[2] * SS_BLOCK + 4 * s3[2] + o3[2]) * P.cs) - bc[2]) * P.avx_inv_h;
+        cb0 = ss_pack_f16(lo_half ? 1.0f : y, lo_half ? 1.0f : z);
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            const float x = ((P.gmin[0] + (float)(b3[0] * SS_BLOCK + 4 * s3[0] + 2 * g + ((lane >> 4) & 1)) * P.cs) - bc[0]) * P.avx_inv_h;
+            cb1[g] = ss_pack_f16(lo_half ? x : y * y, lo_half ? x * x : z * z);
+        }
     }
     bool done = false;
     if (valid) {  // (wave-uniform)
-        uint2* list = s_list[wave];
+        uint4* list = s_list[wave];
         uint32_t* row_start = s_row_start[wave];
         uint32_t* row_prefix = s_row_prefix[wave];
-        const float rn = __builtin_amdgcn_sqrtf(P.R2near) * 1.00001f + P.coord_slack;
+        const float r2near = P.R2near;
+        const float rn = __builtin_amdgcn_sqrtf(r2near) * 1.00001f + P.coord_slack;
         // splat cells overlapping the near box per axis (table-relative)
         int clo[3], chi[3];
         const double cell = 1.0 / P.sinv, cpad = 1.0e-3 * cell;
@@ -2260,14 +2222,27 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
         }
         const int ny = chi[1] - clo[1] + 1;
         const int nrows = (chi[0] - clo[0] + 1) * ny;
-        float acc = 0.0f;
+        float acc0 = 0.0f, acc1 = 0.0f;  // this lane's parts of the two tiles' columns (splat_cert_reduce)
         int n_list = 0, n_near = 0;
-        auto flush = [&]() {
-            if (lane < 4) list[n_list + lane] = SS_BOUND_DUMMY;
+        // The list so far through the matrix pipe, 32 entries (rows) at a time, both tiles; then the test whether every point of the sub-block is
+        // above the threshold ALREADY -- an over-dense fluid is certified by a fraction of its near entries (S10M-cube: ten times the rest density).
+        auto flush = [&]() -> bool {
+            if (lane < 32) list[n_list + lane] = SS_CERT_DUMMY;
             ss_wave_lds_sync();
-            acc += splat_bound_walk(P, list, n_list, npc[0], npc[1], npc[2]);
+            for (int base = 0; base < n_list; base += 32) {
+                const uint2 arow = *reinterpret_cast<const uint2*>(reinterpret_cast<const char*>(list + base + (lane & 31)) + (lane >> 5) * 8);
+                const int rows = n_list - base;
+                acc0 = splat_cert_reduce(splat_cert_mfma(arow, cb0, cb1[0]), rows, acc0);
+                acc1 = splat_cert_reduce(splat_cert_mfma(arow, cb0, cb1[1]), rows, acc1);
+            }
             ss_wave_lds_sync();
             n_list = 0;
+            typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+            const u32x2 sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc0), __float_as_uint(acc1), false, false);
+            const float tot = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+            // the margin of thr_inside covers the rounding of the terms; a sum of n of them adds up to n 2^-24 relative
+            const float thr = P.thr_inside + ((float)n_near * 1.2e-7f) * P.thr_inside;
+            return __ballot(tot > thr || !point_valid) == ~0ull;
         };
         for (int row_base = 0; row_base < nrows; row_base += 64) {
             const int nb = min(64, nrows - row_base);
@@ -2319,23 +2294,24 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
                     const float ex = fmaxf(fmaxf(slo[0] - pv[j].x, pv[j].x - shi[0]) - P.coord_slack, 0.0f);
                     const float ey = fmaxf(fmaxf(slo[1] - pv[j].y, pv[j].y - shi[1]) - P.coord_slack, 0.0f);
                     const float ez = fmaxf(fmaxf(slo[2] - pv[j].z, pv[j].z - shi[2]) - P.coord_slack, 0.0f);
-                    const bool pass = (qj + (uint32_t)lane < total) && ((ex * ex + ey * ey) + ez * ez <= P.R2near);
+                    const bool pass = (qj + (uint32_t)lane < total) && ((ex * ex + ey * ey) + ez * ez <= r2near);
                     const unsigned long long m = __ballot(pass);
                     if (m) {
-                        if (pass) list[n_list + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] = splat_bound_record(P, pv[j], bc[0], bc[1], bc[2]);
+                        if (pass) list[n_list + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] = splat_cert_record(P, pv[j], bc[0], bc[1], bc[2]);
                         const int c = __popcll(m);
                         n_list += c;
                         n_near += c;
-                        if (n_list >= SS_CERT_LIST) flush();
+                        if (n_list >= SS_CERT_LIST) done = flush();
                     }
+                    if (done) break;  // (wave-uniform)
                 }
+                if (done) break;
             }
+            if (done) break;
             ss_wave_lds_sync();  // the next batch overwrites the row tables
         }
-        if (n_list > 0) flush();
-        // the margin of thr_inside covers the rounding of the terms; a sum of n of them adds up to n 2^-24 relative
-        const float thr = P.thr_inside + ((float)n_near * 1.2e-7f) * P.thr_inside;
-        done = __ballot(acc > thr || !point_valid) == ~0ull;
+        if (!done && n_list > 0) done = flush();
+        if (!done && n_near == 0) done = __ballot(!point_valid) == ~0ull;  // (no entry at all: only a sub-block without valid points is "inside")
     }
     __syncthreads();
     if (done && lane == 0) atomicOr(&s_cert, 1u << wave);

@@ -360,39 +360,3 @@ def test_splat_certificate_f16_operands_stay_below_the_bilinear_form():
     assert worst < 0.0
 
 
-def test_splat_lower_bound_survives_the_f16_list_records():
-    """The list records of the lower-bound pass hold (x, y, z) as f16 relative to the block's centre in units of h and V sigma as
-    f16 rounded towards zero (splat_bound_record); the kernel evaluates u' = max(bound_one - |e16 - p|^2, 0) with bound_one =
-    1 - (3.6 eps + 3 eps^2 + 2e-6), eps = half an f16 ulp of the largest coordinate emax = 3.5 cs/h + R_near + coord_slack/h + 1e-3
-    (make_device_params).  Check on random
-    pairs, with the kernel's f32 operation order, that u' <= max(1 - |e - p|^2, 0) in exact arithmetic for every cube-size /
-    support ratio the sweep uses, i.e. that the packed pass still bounds the spline from below."""
-    rng = np.random.default_rng(5)
-    # (cube size / compact support radius, coord_slack / h): coord_slack = 16 ulp of the largest coordinate is what the near filter
-    # admits beyond the near radius -- negligible next to the origin, 1e-3 h at |x| = 500 h, 0.1 h at |x| = 5e4 h.  (0.11, 0.02) puts
-    # emax just across a power of two, where the f16 ulp doubles.
-    for ratio, slack in ((1.0 / 30.0, 0.0), (0.125, 0.0), (0.2, 0.0), (0.45, 0.0), (1.0, 0.0), (0.11, 0.0), (0.11, 0.02), (1.0 / 30.0, 0.1), (0.45, 1.2e-3),
-                         (0.115, 0.1)):
-        emax = 3.5 * ratio + 0.60 + slack + 1.0e-3
-        eps = 2.0 ** (np.floor(np.log2(emax)) - 11)
-        bound_one = np.float32(max(0.0, 1.0 - (3.6 * eps + 3.0 * eps * eps + 2.0e-6)))
-        n = 400000
-        e = rng.uniform(-emax, emax, size=(n, 3))
-        p = rng.uniform(-3.5 * ratio, 3.5 * ratio, size=(n, 3))
-        e32, p32 = e.astype(np.float32), p.astype(np.float32)
-        e16 = e32.astype(np.float16)
-        assert np.max(np.abs(e16.astype(np.float64) - e32.astype(np.float64))) <= eps
-        # kernel order: d = e16 + (-p) (one rounding, v_fma_mix_f32), a = fma(-dy, dy, one); a = fma(-dx, dx, a); u = clamp(fma(-dz, dz, a))
-        d = (e16.astype(np.float32) - p32).astype(np.float32)
-        a = np.float32(bound_one) - (d[:, 1].astype(np.float64) ** 2)
-        a = a.astype(np.float32).astype(np.float64) - d[:, 0].astype(np.float64) ** 2
-        a = a.astype(np.float32).astype(np.float64) - d[:, 2].astype(np.float64) ** 2
-        u_kernel = np.clip(a.astype(np.float32).astype(np.float64), 0.0, 1.0)
-        d_true = e32.astype(np.float64) - p32.astype(np.float64)
-        u_true = np.maximum(1.0 - np.sum(d_true * d_true, axis=1), 0.0)
-        assert np.all(u_kernel <= u_true), (ratio, slack, float(np.max(u_kernel - u_true)))
-    # volumes: towards zero never rounds up
-    v = rng.uniform(1.0e-6, 2.0, size=100000).astype(np.float32)
-    v16 = v.astype(np.float16)
-    v16 = np.where(v16.astype(np.float32) > v, np.nextafter(v16, np.float16(0.0)), v16)
-    assert np.all(v16.astype(np.float32) <= v)
