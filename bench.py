@@ -215,7 +215,8 @@ def reference_digest(out, workload, simd):
     """Which digest of the REFERENCE WHEEL's own mesh (tests/golden/*.npz, tools/gen_goldens_fullsize.py) the measured steps' mesh matches: the canonical
     (order-independent) vertex-id multiset and triangle set of the last step, hashed and compared outside the timed region."""
     import hashlib
-    name = {("s10m_tank", 0): "config3_s10m_tank", ("s10m_tank", 1): "simd_config3_s10m_tank", ("s1m", 0): "config2_s1m", ("s1m", 1): "simd_config2_s1m"}.get((workload, int(simd)))
+    name = {("s10m_tank", 0): "config3_s10m_tank", ("s10m_tank", 1): "simd_config3_s10m_tank", ("s1m", 0): "config2_s1m", ("s1m", 1): "simd_config2_s1m",
+            ("s40m_tank", 0): "config4_s40m_tank", ("s10m_cube", 0): "config3p_s10m_cube", ("s10m_cube", 1): "simd_config3p_s10m_cube"}.get((workload, int(simd)))
     path = os.path.join(ROOT, "tests", "golden", (name or "") + ".npz")
     if not name or not os.path.exists(path):
         return {"golden": None, "note": "no reference-wheel digest for this workload / mode"}

@@ -131,14 +131,19 @@ def test_native_ranks_reproduce_single_context(gpu_ctx, case, world, dt, simd):
 def test_native_full_s40m_tank_four_ranks(gpu_ctx):
     """BASELINE config 4 at FULL size through the native multi-GPU path: the 39.8 M-particle S40M-tank cut into four bricks (in-process
     transport, the ranks taking turns on the device like bench.py --pseudo-ranks), exchanges and rank-owned assembly included; densities of
-    every held particle, vertices, edge keys and triangles of the merged mesh equal the single-context reconstruction bit for bit."""
+    every held particle, vertices, edge keys and triangles of the merged mesh equal the single-context reconstruction bit for bit, and that
+    reconstruction equals the reference wheel's own mesh of this input (vertex-id multiset, triangle set, all 39.8 M densities)."""
     from splashsurf_amd import workloads as W
     wl = W.WORKLOADS["s40m_tank"]
     pts = wl["gen"]()
     assert pts.shape[0] > 39_000_000
-    prm = _params(wl["particle_radius"], wl["smoothing_length"], wl["cube_size"], 64, np.float32, 1)
+    prm = _params(wl["particle_radius"], wl["smoothing_length"], wl["cube_size"], 64, np.float32, 0)  # the scalar arithmetic: the mode pinned to the wheel
     ranks = _run_ranks(pts, prm, 4, take_turns=True)
-    _check_against_direct(pts, prm, ranks, gpu_ctx)
+    direct = _check_against_direct(pts, prm, ranks, gpu_ctx)
+    # ... and that single-context mesh IS the reference wheel's (tests/golden/config4_s40m_tank.npz): merged == direct == wheel
+    from conftest import load_golden
+    from test_gpu_fullsize import assert_equals_the_wheels_digest
+    assert_equals_the_wheels_digest(direct, load_golden("config4_s40m_tank"), False, "config4_s40m_tank (merged mesh of four ranks == this)")
     part = ranks[0]["partition"]
     assert part["imbalance_owned"] <= 1.05, part
     for r in ranks:  # the phases have their own clocks (round 2 billed phase 1 to the density exchange) and the turn timer ran

@@ -13,6 +13,11 @@ lib.rs:330-337, dense_subdomains.rs:784-847 scalar, :991-1133 + :1413-1415 SIMD)
     adjacent subdomains compute it with different lanes and disagree about its side --, and (1610, 92, 1598), a vertex 8e-4 of a cell from
     the grid point that the geometric canonicalisation files under "grid point" for one mesh and "edge" for the other (the reference's own
     two modes differ from each other in 312 ids and 2 700 triangles on this input; FULLSIZE_REPORT.json).
+
+Round 6 adds the two largest workloads in the same way: config4_s40m_tank.npz (BASELINE config 4, 39.8 M particles, 18.05 M vertices, simd=False: the
+scalar mode's mesh EQUALS the wheel's) and [simd_]config3p_s10m_cube.npz (SURVEY 8d's literal reading 3' of config 3: 10 M particles ten times over-dense,
+1.10 M vertices -- the only large input of k_splat_certify_big and the arena kernels; scalar: equal; uniform AVX arithmetic: a stored difference of 1 id and
+6 / 6 triangles, where the wheel's own two modes differ in 7 ids and 40 triangles).
 """
 import hashlib
 
@@ -62,12 +67,9 @@ def _check_samples(g, ids, vs):
     return int((~present).sum())
 
 
-@pytest.mark.parametrize("name", ["config3_s10m_tank", "simd_config3_s10m_tank"])
-def test_full_size_s10m_tank_against_the_reference_wheel(gpu_ctx, name, capsys):
-    g = load_golden(name)
-    prm = golden_params(g)
-    simd = bool(prm["simd"])
-    res = run_gpu(gpu_ctx, golden_input(g), prm, simd=simd)
+def assert_equals_the_wheels_digest(res, g, simd, name="", capsys=None):
+    """The mesh and densities of `res` against a full-size golden of the reference wheel (see the module's docstring); also used by
+    tests/test_gpu_dist_native.py for the merged mesh of the sharded path."""
     assert res.stats["arith_mode"] in ((2, 3) if simd else (0, 1))
     assert list(res.grid.ncells_per_dim) == list(g["n_cells"])
     assert _sha(res.particle_densities) == str(g["density_sha256"]), "densities not bit-identical to the reference"
@@ -90,7 +92,19 @@ def test_full_size_s10m_tank_against_the_reference_wheel(gpu_ctx, name, capsys):
     missing = _check_samples(g, ids, vs)
     assert missing <= rem_i.size + add_i.size
     assert MC.mesh_is_closed_manifold(res.mesh.triangles_u32)
-    with capsys.disabled():
+    import contextlib
+    with (capsys.disabled() if capsys is not None else contextlib.nullcontext()):
         print("\n[%s] enable_simd=%d: %d vertices / %d triangles; against the wheel's simd=%s mesh (%d / %d): ids only here %d, only in the wheel %d; "
               "triangles only here %d, only in the wheel %d" % (name, int(simd), ids.size, tc.shape[0], simd, int(g["n_vertices"]), int(g["n_triangles"]),
                                                                 rem_i.size, add_i.size, rem_t.shape[0], add_t.shape[0]))
+
+
+# config3 (S10M-tank, bench.py's workload), config 4 (S40M-tank, 39.8 M particles / 18.05 M vertices: the workload of the multi-GPU bench, scalar
+# mode) and SURVEY 8d's literal reading 3' of config 3 (S10M-cube, ten times over-dense: the only large input of k_splat_certify_big and the arena path)
+@pytest.mark.parametrize("name", ["config3_s10m_tank", "simd_config3_s10m_tank", "config3p_s10m_cube", "simd_config3p_s10m_cube", "config4_s40m_tank"])
+def test_full_size_against_the_reference_wheel(gpu_ctx, name, capsys):
+    g = load_golden(name)
+    prm = golden_params(g)
+    simd = bool(prm["simd"])
+    res = run_gpu(gpu_ctx, golden_input(g), prm, simd=simd)
+    assert_equals_the_wheels_digest(res, g, simd, name, capsys)
