@@ -337,7 +337,7 @@ def pseudo_rank_run(args):
             for _ in range(max(args.warmup, 4 if args.balance_feedback else 1)):  # (the feedback needs a few frames to settle)
                 native.step(d_local)
                 native.assemble()
-            timings, own, k3_ms, xbytes, last, n_coll = {}, [], [], 0, None, 0
+            timings, own, k3_ms, xbytes, last, n_coll, linkbytes = {}, [], [], 0, None, 0, 0
             bar.wait()
             t0 = time.perf_counter()
             for _ in range(args.steps):
@@ -348,6 +348,7 @@ def pseudo_rank_run(args):
                 own.append(info["ms_own_turns"])
                 n_coll = int(info["n_collectives"])
                 xbytes += info["bytes_sent_positions"] + info["bytes_sent_densities"] + info["bytes_sent_assembly"]
+                linkbytes += info.get("bytes_link_max", 0)
                 s_ = last.stats
                 t_acc = s_.get("ms_levelset_accumulate", 0.0)
                 k3_ms.append((t_acc, s_["ms_levelset"] - s_.get("ms_levelset_gather", 0.0) - t_acc))
@@ -359,7 +360,7 @@ def pseudo_rank_run(args):
             roof = splat_roofline(stats, n_occ, n_subp, nsc, k3_acc, k3_large)
             out[q] = dict(row=rank_row(roof, stats, xbytes, args.steps), roof=roof, stats=stats, timings=timings, own_ms=float(np.mean(own)),
                           own_ms_all=[float(x) for x in own], n_collectives=n_coll,
-                          bal=native.partition(), n_total=n_total, desc=desc, xbytes=xbytes / max(args.steps, 1))
+                          bal=native.partition(), n_total=n_total, desc=desc, xbytes=xbytes / max(args.steps, 1), linkbytes=linkbytes / max(args.steps, 1))
             native.result._free()
         except Exception as e:  # a failing rank must not leave the others waiting silently
             errors.append((q, repr(e)))
@@ -401,21 +402,28 @@ def pseudo_rank_run(args):
     slowest = max(range(world), key=lambda q: out[q]["own_ms"])
     link_gbs = 153.0  # one xGMI link, MI355X_MICROARCH.md; a brick's halo traffic goes to a handful of neighbours
     xfer_ms = max(o["xbytes"] for o in out) / (link_gbs * 1e9) * 1e3
+    # ... and the same exchanges with every pair of GPUs on its OWN link (the node's xGMI is point to point, 7 links per GPU): an exchange takes as long as its busiest
+    # link, ss_dist_info.bytes_link_max sums that over the step's three exchanges
+    xfer_links_ms = max(o["linkbytes"] for o in out) / (link_gbs * 1e9) * 1e3
     n_coll = max(o["n_collectives"] for o in out)
     lat_ms = n_coll * args.collective_latency_us * 1e-3
     proj = {"ranks": world, "slowest_rank": slowest, "own_ms_slowest_rank": round(out[slowest]["own_ms"], 3),
             "own_ms_mean": round(float(np.mean([o["own_ms"] for o in out])), 3), "own_ms_slowest_per_step_mean": round(crit_ms, 3),
-            "exchange_transfer_ms_at_one_xgmi_link": round(xfer_ms, 3),
+            "exchange_transfer_ms_at_one_xgmi_link": round(xfer_ms, 3), "exchange_transfer_ms_busiest_link": round(xfer_links_ms, 3),
+            "projected_step_ms_point_to_point_links": round(crit_ms + xfer_links_ms + lat_ms, 3),
             "collective_steps": n_coll, "collective_latency_us_assumed": args.collective_latency_us, "collective_latency_ms": round(lat_ms, 3),
             "projected_step_ms": round(crit_ms + xfer_ms + lat_ms, 3),
             "balance_feedback": bool(args.balance_feedback),
             "note": "own_ms = time a rank held the device per step (all of its kernels, packing and host work; the ranks took turns); projected N-GPU step = "
                     "mean over the steps of the slowest rank's own time + the largest rank's exchange bytes over ONE 153 GB/s xGMI link + the number of communication "
                     "steps the library counted x an ASSUMED %.0f us each (no multi-GPU node was available: RCCL latencies are not measured); nothing of an exchange "
-                    "is overlapped with compute in this estimate" % args.collective_latency_us}
+                    "is overlapped with compute in this estimate.  `projected_step_ms` prices ALL of a rank's exchange bytes on one link (the pessimistic reading kept from "
+                    "rounds 3-5); `..._point_to_point_links` prices every exchange by its busiest pair of GPUs, each pair on its own 153 GB/s link -- how a fully connected "
+                    "xGMI node moves a sparse all-to-all" % args.collective_latency_us}
     if single:
         proj["single_gpu_step_ms"] = single["ms_per_step"]
         proj["projected_speedup"] = round(single["ms_per_step"] / proj["projected_step_ms"], 2)
+        proj["projected_speedup_point_to_point_links"] = round(single["ms_per_step"] / proj["projected_step_ms_point_to_point_links"], 2)
     tot_v = int(sum(o["stats"]["n_vertices"] for o in out))
     tot_t = int(sum(o["stats"]["n_triangles"] for o in out))
     st0 = out[slowest]["stats"]

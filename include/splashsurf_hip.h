@@ -362,6 +362,8 @@ typedef struct ss_dist_info {
     uint64_t n_collectives;              /* communication steps of the last ss_dist_reconstruct + ss_dist_assemble in which this rank met its peers (all-gathers, the all-reduce,
                                             grouped send/recv): each costs a collective's latency on a real multi-GPU node, which the one-GPU projection of bench.py prices */
     double ms_device;                    /* HIP-event time of this rank's two reconstruction phases (ss_result_stats ms_total): the cost the partition feedback balances */
+    uint64_t bytes_link_max;             /* sum over the step's three exchanges of the largest payload this rank exchanged with ONE peer in one direction (max over peers of
+                                            max(sent, received)): on a fully connected xGMI node every pair of GPUs has its own link, so this, not the total, sets an exchange's transfer time */
 } ss_dist_info;
 
 /* xyz_local: this rank's n_local x 3 particles (host or HBM).  On return `inout` holds the brick's reconstruction: its mesh with

@@ -883,6 +883,12 @@ ss_status pack_and_exchange(ss_comm* c, TurnGuard& turn, uint64_t n, uint64_t id
     ++c->info.n_collectives;
     *n_recv_rows = recv_off[world] / row_bytes;
     if (bytes_sent) *bytes_sent += send_off[world] - (send_off[me + 1] - send_off[me]);
+    {   // the busiest of this rank's point-to-point links in this exchange (ss_dist_info::bytes_link_max)
+        uint64_t busiest = 0;
+        for (int q = 0; q < world; ++q)
+            if (q != me) busiest = std::max(busiest, std::max(send_off[q + 1] - send_off[q], recv_off[q + 1] - recv_off[q]));
+        c->info.bytes_link_max += busiest;
+    }
     return SS_OK;
 }
 

@@ -620,7 +620,7 @@ class _DistInfo(C.Structure):
                 ("n_held", C.c_uint64), ("n_owned", C.c_uint64), ("bytes_sent_positions", C.c_uint64), ("bytes_sent_densities", C.c_uint64),
                 ("bytes_sent_assembly", C.c_uint64), ("ms_partition", C.c_double), ("ms_position_exchange", C.c_double), ("ms_density_exchange", C.c_double),
                 ("ms_assembly", C.c_double), ("ms_phase1", C.c_double), ("ms_phase2", C.c_double), ("ms_own_turns", C.c_double), ("n_vertices_owned", C.c_uint64), ("vertex_offset", C.c_uint64), ("n_vertices_total", C.c_uint64),
-                ("n_triangles", C.c_uint64), ("triangle_offset", C.c_uint64), ("n_triangles_total", C.c_uint64), ("n_collectives", C.c_uint64), ("ms_device", C.c_double)]
+                ("n_triangles", C.c_uint64), ("triangle_offset", C.c_uint64), ("n_triangles_total", C.c_uint64), ("n_collectives", C.c_uint64), ("ms_device", C.c_double), ("bytes_link_max", C.c_uint64)]
 
 
 def _dist_lib(ctx):
