@@ -1152,7 +1152,16 @@ ss_status phase_finish(ss_context* ctx, ss_result* res) {
     SS_HIP(ctx, hipEventRecord(ctx->ev[5], st));  // (= event 12 of the timers below: one record per point of the stream)
     if (n_active) {
         // first pass, gather and accumulate in one kernel: the tiles of ordinary blocks stay in LDS
-        ss_launch_splat_fused(PK, res->posvol.as<ss_real4<R>>(), res->perm.as<uint32_t>(), ctx->cell_start.as<uint32_t>(), res->active_xyz.as<uint32_t>(), n_active,
+        {   // the rows of splat cells a block scans (the same for every block): made once per parameter set
+            const ss_context::RowTabKey key = {PK.sn1, PK.sk, PK.kdim[1], PK.kdim[2], (int)sizeof(R), PK.so, PK.se, PK.srho};
+            const size_t need = (size_t)PK.sn1 * (size_t)PK.sn1 * 8 + 64;
+            if (memcmp(&ctx->rowtab_key, &key, sizeof(key)) != 0 || ctx->splat_rowtab.cap < need) {
+                SS_HIP(ctx, ctx->splat_rowtab.reserve(need));
+                ss_launch_splat_row_table(PK, ctx->splat_rowtab.as<uint2>(), st);
+                ctx->rowtab_key = key;
+            }
+        }
+        ss_launch_splat_fused(PK, res->posvol.as<ss_real4<R>>(), res->perm.as<uint32_t>(), ctx->cell_start.as<uint32_t>(), ctx->splat_rowtab.as<uint2>(), res->active_xyz.as<uint32_t>(), n_active,
                               res->G.as<R>(), res->blk_minmax.as<ss_real2<R>>(), tr_flag, full_ls, nullptr, nullptr, nullptr, face_bits, ctx->splat_counts.as<uint32_t>(), big_flag, st);
         const SSMailSlot m_big = mail_slot(ctx, 3);
         ss_launch_flag_scan(big_flag, n_active, nullptr, big + 1, big, st_big1, m_big, st);  // flags -> (count, list in block order); the count goes to the host
@@ -1205,7 +1214,7 @@ ss_status phase_finish(ss_context* ctx, ss_result* res) {
                               ctx->splat_counts.as<uint32_t>(), reinterpret_cast<unsigned long long*>(d_counters), big_flag, st);
     if (n_active && !full_ls) {
         ss_launch_flag_scan(rd_flag, n_active, nullptr, rd_list, n_redo_dev, st_redo, SSMailSlot{}, st);
-        ss_launch_splat_fused(PK, res->posvol.as<ss_real4<R>>(), res->perm.as<uint32_t>(), ctx->cell_start.as<uint32_t>(), res->active_xyz.as<uint32_t>(), n_active,
+        ss_launch_splat_fused(PK, res->posvol.as<ss_real4<R>>(), res->perm.as<uint32_t>(), ctx->cell_start.as<uint32_t>(), ctx->splat_rowtab.as<uint2>(), res->active_xyz.as<uint32_t>(), n_active,
                               res->G.as<R>(), res->blk_minmax.as<ss_real2<R>>(), tr_flag, true, rd_list, n_redo_dev, rd_flag, face_bits, ctx->splat_counts.as<uint32_t>(), big_flag, st);
         if (n_big) {  // (the list kernel flagged the large blocks among the selected ones again)
             ss_launch_flag_scan(big_flag, n_active, nullptr, big + 1, big, st_big2, SSMailSlot{}, st);

@@ -98,6 +98,8 @@ struct ss_context {
     DevBuf splat_overflow;  // flags / ranks / list of level-set blocks whose tile is ordered by the workgroup-level gather
     DevBuf splat_trunc;  // per active block: truncated flag, needed-by-MC flag, its scan and the list of blocks to complete
     DevBuf mc_nb;  // per MC block: slots and certified masks of its eight level-set blocks
+    DevBuf splat_rowtab;    // per (x, y) row of splat cells a block scans: first / one-past-last cell offset (the same for every block: k_splat_row_table); rowtab_key: everything splat_row_cells reads, for the table in the buffer
+    struct RowTabKey { int sn1, sk, kdim1, kdim2, real_bytes; float so, se, srho; } rowtab_key = {0, 0, 0, 0, 0, 0.0f, 0.0f, 0.0f};
     DevBuf splat_tile_idx;  // particle index of every arena entry (tiles the wave-per-block kernel orders itself)
     DevBuf splat_tiles, splat_counts, splat_off, splat_bound;  // tile arena (index-ordered candidates of every block), per-block counts, 64-bit offsets, size bounds
     // counts the host waits for arrive in pinned host memory mapped into the device (SSMailSlot, ss_prims.h): 16 slots of {value, seq}

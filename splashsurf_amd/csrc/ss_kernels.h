@@ -28,7 +28,9 @@ void ss_launch_splat_gather(const SSDevT<R>& P, const ss_real4<R>* posvol, const
 template <class R>
 void ss_launch_splat_gather_large(const SSDevT<R>& P, const ss_real4<R>* posvol, const ss_real4<R>* posvol_by_index, const uint32_t* perm, const uint32_t* cell_start, const uint32_t* active_xyz, const uint32_t* large_list, const uint32_t* n_large_dev, const uint32_t* counts, const unsigned long long* tile_off, ss_real4<R>* arena, uint32_t* arena_idx, hipStream_t st);
 template <class R>
-void ss_launch_splat_fused(const SSDevT<R>& P, const ss_real4<R>* posvol, const uint32_t* perm, const uint32_t* cell_start, const uint32_t* active_xyz, uint32_t n_active, R* G, ss_real2<R>* blk_minmax, uint32_t* trunc, bool full_levelset, const uint32_t* list, const uint32_t* n_list_dev, const uint32_t* redo_mask, unsigned long long* facebits, uint32_t* counts, uint32_t* big, hipStream_t st);
+void ss_launch_splat_row_table(const SSDevT<R>& P, uint2* tab, hipStream_t st);
+template <class R>
+void ss_launch_splat_fused(const SSDevT<R>& P, const ss_real4<R>* posvol, const uint32_t* perm, const uint32_t* cell_start, const uint2* row_tab, const uint32_t* active_xyz, uint32_t n_active, R* G, ss_real2<R>* blk_minmax, uint32_t* trunc, bool full_levelset, const uint32_t* list, const uint32_t* n_list_dev, const uint32_t* redo_mask, unsigned long long* facebits, uint32_t* counts, uint32_t* big, hipStream_t st);
 template <class R>
 void ss_launch_splat_accumulate_big(const SSDevT<R>& P, const ss_real4<R>* arena, const uint32_t* arena_idx, const unsigned long long* tile_off, const uint32_t* counts, const uint32_t* active_xyz, R* G, ss_real2<R>* blk_minmax, uint32_t* trunc, bool full_levelset, bool second_pass, bool exact_first, const uint32_t* redo_mask, unsigned long long* facebits, const uint32_t* big, uint32_t* err, hipStream_t st);
 void ss_launch_splat_certify_big(const SSDevT<float>& P, const ss_real4<float>* posvol, const uint32_t* cell_start, const uint32_t* active_xyz, uint32_t n_active, const uint32_t* block_slot, uint32_t* counts, ss_real2<float>* blk_minmax, uint32_t* trunc, unsigned long long* facebits, uint32_t* need_mask, hipStream_t st);

@@ -678,6 +678,23 @@ __device__ __forceinline__ bool splat_row_cells(const SSDevT<R>& P, int r, uint3
     return true;
 }
 
+// The rows are the same for every block: made once per parameter set, read by k_splat_fused (one 8-byte load per row instead of the
+// arithmetic above per block).  (0, 0): the row holds no cell within reach.
+template <class R>
+__global__ __launch_bounds__(256) void k_splat_row_table(SSDevT<R> P, uint2* __restrict__ tab) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= P.sn1 * P.sn1) return;
+    uint32_t lo_off, hi_off;
+    tab[r] = splat_row_cells<R>(P, r, &lo_off, &hi_off) ? make_uint2(lo_off, hi_off) : make_uint2(0u, 0u);
+}
+template <class R>
+void ss_launch_splat_row_table(const SSDevT<R>& P, uint2* tab, hipStream_t st) {
+    const int n = P.sn1 * P.sn1;
+    hipLaunchKernelGGL(k_splat_row_table<R>, dim3((n + 255) / 256), dim3(256), 0, st, P, tab);
+}
+template void ss_launch_splat_row_table<float>(const SSDevT<float>&, uint2*, hipStream_t);
+template void ss_launch_splat_row_table<double>(const SSDevT<double>&, uint2*, hipStream_t);
+
 template <class R>
 __global__ __launch_bounds__(256) void k_mark_blocks(SSDevT<R> P, const uint32_t* __restrict__ cell_start, uint32_t ncells,
                                                      uint32_t* __restrict__ block_flag) {
@@ -914,17 +931,18 @@ __device__ __forceinline__ uint32_t ss_wave_inclusive_scan(uint32_t v) {
 #endif
 template <class R, bool NEED_ID, class F>
 __device__ __forceinline__ void splat_wave_scan_grouped(const SSDevT<R>& P, const ss_real4<R>* __restrict__ posvol, const uint32_t* __restrict__ perm,
-                                                        const uint32_t* __restrict__ cell_start, uint32_t key0, const R plo[3], const R phi[3],
+                                                        const uint32_t* __restrict__ cell_start, const uint2* __restrict__ row_tab, uint32_t key0, const R plo[3], const R phi[3],
                                                         uint32_t* s_row_start, uint32_t* s_row_prefix, int lane, uint32_t bail_total, uint32_t* bailed, F f) {
     const int nrows = P.sn1 * P.sn1;
     for (int row_base = 0; row_base < nrows; row_base += 64) {
         const int nb = min(64, nrows - row_base);
         uint32_t len = 0;
         if (lane < nb) {
-            uint32_t lo_off, hi_off, rb = 0, re = 0;
-            if (splat_row_cells<R>(P, row_base + lane, &lo_off, &hi_off)) {
-                rb = cell_start[key0 + lo_off];
-                re = cell_start[key0 + hi_off];
+            uint32_t rb = 0, re = 0;
+            const uint2 t = row_tab[row_base + lane];  // (k_splat_row_table)
+            if (t.y > t.x) {
+                rb = cell_start[key0 + t.x];
+                re = cell_start[key0 + t.y];
             }
             s_row_start[lane] = rb;
             len = re - rb;
@@ -2047,7 +2065,7 @@ __device__ __forceinline__ void splat_accumulate_block_wave(SplatAccWaveShared<R
 #endif
 template <class R, int ARITH, bool EARLY>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(sizeof(R) == 4 ? SS_FUSED_MINWAVES : 4, 8))) void k_splat_fused(SSDevT<R> P, const ss_real4<R>* __restrict__ posvol, const uint32_t* __restrict__ perm,
-                                                    const uint32_t* __restrict__ cell_start, const uint32_t* __restrict__ active_xyz, uint32_t n_active,
+                                                    const uint32_t* __restrict__ cell_start, const uint2* __restrict__ row_tab, const uint32_t* __restrict__ active_xyz, uint32_t n_active,
                                                     const uint32_t* __restrict__ list, const uint32_t* __restrict__ n_list_dev,
                                                     const uint32_t* __restrict__ redo_mask, R* __restrict__ G, ss_real2<R>* __restrict__ blk_minmax,
                                                     uint32_t* __restrict__ trunc, unsigned long long* __restrict__ facebits, uint32_t* __restrict__ counts,
@@ -2076,7 +2094,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(sizeof(R) ==
             // scanning (about two thirds of the candidates of a row lie within reach; S10M-cube: the scans of the 89 % of the blocks
             // that overflow anyway cost 1.6 ms).
             uint32_t bailed = 0;
-            splat_wave_scan_grouped<R, false>(P, posvol, perm, cell_start, key0, plo, phi, s_row_start, s_row_prefix, lane, (uint32_t)(SS_FUSED_BAIL * CH), &bailed,
+            splat_wave_scan_grouped<R, false>(P, posvol, perm, cell_start, row_tab, key0, plo, phi, s_row_start, s_row_prefix, lane, (uint32_t)(SS_FUSED_BAIL * CH), &bailed,
                                      [&](R d2, uint32_t src, uint32_t, const ss_real4<R>& pv) {
                                          const bool inside = d2 <= P.R2;
                                          const unsigned long long m = __ballot(inside);
@@ -2109,7 +2127,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(sizeof(R) ==
         if (count < 100000u) return;
 #endif
         splat_accumulate_block_wave<R, ARITH, EARLY>(sh, P, logical, (int)count, (int)n_near_block, posvol, perm, active_xyz, G, blk_minmax, trunc, facebits,
-                                                           redo_mask ? __builtin_amdgcn_readfirstlane(redo_mask[logical]) : 0xFFu);
+                                                           // (the first pass evaluates every sub-block: a compile-time mask removes the second pass's branches from its code)
+                                                           EARLY ? 0xFFu : (redo_mask ? (uint32_t)__builtin_amdgcn_readfirstlane(redo_mask[logical]) : 0xFFu));
         SS_PROF_MARK(7);  // whole sub-block walk incl. epilogue (phases 1-6 are inside)
     };
     // first pass: the grid has exactly one workgroup per slot -- written as a loop, the compiler hoists lane constants out of it
@@ -2491,7 +2510,7 @@ void ss_launch_splat_gather_large(const SSDevT<R>& P, const ss_real4<R>* posvol,
 // marching cubes reads.  `big`: n_active flags, set for the blocks with more than SSWaveChunk candidates (compacted by the host into the
 // list ss_launch_splat_accumulate_big works on); counts: tile size per block (first pass).
 template <class R>
-void ss_launch_splat_fused(const SSDevT<R>& P, const ss_real4<R>* posvol, const uint32_t* perm, const uint32_t* cell_start, const uint32_t* active_xyz, uint32_t n_active,
+void ss_launch_splat_fused(const SSDevT<R>& P, const ss_real4<R>* posvol, const uint32_t* perm, const uint32_t* cell_start, const uint2* row_tab, const uint32_t* active_xyz, uint32_t n_active,
                            R* G, ss_real2<R>* blk_minmax, uint32_t* trunc, bool full_levelset, const uint32_t* list, const uint32_t* n_list_dev,
                            const uint32_t* redo_mask, unsigned long long* facebits, uint32_t* counts, uint32_t* big, hipStream_t st) {
     if (!n_active) return;
@@ -2500,10 +2519,10 @@ void ss_launch_splat_fused(const SSDevT<R>& P, const ss_real4<R>* posvol, const 
 #define SS_FUSED(A)                                                                                                                                          \
     do {                                                                                                                                                     \
         if (list || full_levelset)                                                                                                                           \
-            hipLaunchKernelGGL((k_splat_fused<R, A, false>), grid, dim3(64), 0, st, P, posvol, perm, cell_start, active_xyz, n_active, list, n_list_dev,    \
+            hipLaunchKernelGGL((k_splat_fused<R, A, false>), grid, dim3(64), 0, st, P, posvol, perm, cell_start, row_tab, active_xyz, n_active, list, n_list_dev,    \
                                redo_mask, G, blk_minmax, trunc, facebits, counts, big);                                                                      \
         else                                                                                                                                                 \
-            hipLaunchKernelGGL((k_splat_fused<R, A, true>), grid, dim3(64), 0, st, P, posvol, perm, cell_start, active_xyz, n_active, list, n_list_dev,     \
+            hipLaunchKernelGGL((k_splat_fused<R, A, true>), grid, dim3(64), 0, st, P, posvol, perm, cell_start, row_tab, active_xyz, n_active, list, n_list_dev,     \
                                redo_mask, G, blk_minmax, trunc, facebits, counts, big);                                                                      \
     } while (0)
     SS_SPLAT_DISPATCH(SS_FUSED);
@@ -3343,10 +3362,10 @@ template void ss_launch_splat_gather_large<float>(const SSDevT<float>& P, const 
 template void ss_launch_splat_bounds<double>(const SSDevT<double>& P, const uint32_t* cell_start, const uint32_t* active_xyz, uint32_t n_active, const uint32_t* counts, uint32_t* bound, hipStream_t st);
 template void ss_launch_splat_gather<double>(const SSDevT<double>& P, const ss_real4<double>* posvol, const uint32_t* perm, const uint32_t* cell_start, const uint32_t* active_xyz, uint32_t n_active, const unsigned long long* tile_off, ss_real4<double>* arena, uint32_t* arena_idx, uint32_t* counts, uint32_t* large_flag, hipStream_t st);
 template void ss_launch_splat_gather_large<double>(const SSDevT<double>& P, const ss_real4<double>* posvol, const ss_real4<double>* posvol_by_index, const uint32_t* perm, const uint32_t* cell_start, const uint32_t* active_xyz, const uint32_t* large_list, const uint32_t* n_large_dev, const uint32_t* counts, const unsigned long long* tile_off, ss_real4<double>* arena, uint32_t* arena_idx, hipStream_t st);
-template void ss_launch_splat_fused<float>(const SSDevT<float>& P, const ss_real4<float>* posvol, const uint32_t* perm, const uint32_t* cell_start, const uint32_t* active_xyz, uint32_t n_active, float* G, ss_real2<float>* blk_minmax, uint32_t* trunc, bool full_levelset, const uint32_t* list, const uint32_t* n_list_dev, const uint32_t* redo_mask, unsigned long long* facebits, uint32_t* counts, uint32_t* big, hipStream_t st);
+template void ss_launch_splat_fused<float>(const SSDevT<float>& P, const ss_real4<float>* posvol, const uint32_t* perm, const uint32_t* cell_start, const uint2* row_tab, const uint32_t* active_xyz, uint32_t n_active, float* G, ss_real2<float>* blk_minmax, uint32_t* trunc, bool full_levelset, const uint32_t* list, const uint32_t* n_list_dev, const uint32_t* redo_mask, unsigned long long* facebits, uint32_t* counts, uint32_t* big, hipStream_t st);
 template void ss_launch_splat_accumulate_big<float>(const SSDevT<float>& P, const ss_real4<float>* arena, const uint32_t* arena_idx, const unsigned long long* tile_off, const uint32_t* counts, const uint32_t* active_xyz, float* G, ss_real2<float>* blk_minmax, uint32_t* trunc, bool full_levelset, bool second_pass, bool exact_first, const uint32_t* redo_mask, unsigned long long* facebits, const uint32_t* big, uint32_t* err, hipStream_t st);
 template void ss_launch_select_redo<float>(const SSDevT<float>& P, const uint32_t* active_xyz, uint32_t n_active, const uint32_t* block_slot, const uint32_t* trunc, const unsigned long long* facebits, uint32_t* redo_mask, const uint32_t* counts, unsigned long long* stats, uint32_t* big, hipStream_t st);
-template void ss_launch_splat_fused<double>(const SSDevT<double>& P, const ss_real4<double>* posvol, const uint32_t* perm, const uint32_t* cell_start, const uint32_t* active_xyz, uint32_t n_active, double* G, ss_real2<double>* blk_minmax, uint32_t* trunc, bool full_levelset, const uint32_t* list, const uint32_t* n_list_dev, const uint32_t* redo_mask, unsigned long long* facebits, uint32_t* counts, uint32_t* big, hipStream_t st);
+template void ss_launch_splat_fused<double>(const SSDevT<double>& P, const ss_real4<double>* posvol, const uint32_t* perm, const uint32_t* cell_start, const uint2* row_tab, const uint32_t* active_xyz, uint32_t n_active, double* G, ss_real2<double>* blk_minmax, uint32_t* trunc, bool full_levelset, const uint32_t* list, const uint32_t* n_list_dev, const uint32_t* redo_mask, unsigned long long* facebits, uint32_t* counts, uint32_t* big, hipStream_t st);
 template void ss_launch_splat_accumulate_big<double>(const SSDevT<double>& P, const ss_real4<double>* arena, const uint32_t* arena_idx, const unsigned long long* tile_off, const uint32_t* counts, const uint32_t* active_xyz, double* G, ss_real2<double>* blk_minmax, uint32_t* trunc, bool full_levelset, bool second_pass, bool exact_first, const uint32_t* redo_mask, unsigned long long* facebits, const uint32_t* big, uint32_t* err, hipStream_t st);
 template void ss_launch_select_redo<double>(const SSDevT<double>& P, const uint32_t* active_xyz, uint32_t n_active, const uint32_t* block_slot, const uint32_t* trunc, const unsigned long long* facebits, uint32_t* redo_mask, const uint32_t* counts, unsigned long long* stats, uint32_t* big, hipStream_t st);
 template void ss_launch_mc_neighbours<float>(const SSDevT<float>& P, const uint32_t* mc_xyz, uint32_t n_mc, const uint32_t* block_slot, const uint32_t* mc_slot, const uint32_t* certified, uint32_t* mc_nb, hipStream_t st);
