@@ -767,6 +767,70 @@ def attach_traffic(line, workload, dev, live=True):
         pass
 
 
+def post_pipeline(ctx, prm, d_pts, n_total, sync):
+    """reconstruct -> connectivity -> weighted-form Laplacian smoothing x 25 (uniform weights) -> vertex normals, device-resident and through host arrays."""
+    import ctypes as C
+    import torch
+    from splashsurf_amd import postprocessing as PP
+    L = PP._lib()
+    iters = 25
+
+    def device_frame():
+        rec = ctx.reconstruct(d_pts, prm)
+        nv, nt = rec.counts()
+        d_v = torch.empty((nv, 3), dtype=torch.float32, device=d_pts.device)
+        d_t = torch.empty((nt, 3), dtype=torch.int32, device=d_pts.device)
+        L.ss_result_copy_vertices(rec._h, C.c_void_p(d_v.data_ptr()))
+        L.ss_result_copy_triangles_u32(rec._h, C.c_void_p(d_t.data_ptr()))
+        conn = PP.vertex_vertex_connectivity(nv, d_t, ctx)
+        mesh = PP.TriMesh3d(d_v, d_t, ctx)
+        sync()
+        t0 = time.perf_counter()
+        PP.laplacian_smoothing_parallel(mesh, conn, iterations=iters, beta=1.0, weights=None)
+        sync()
+        t_smooth = time.perf_counter() - t0
+        nrm = PP.vertex_normals(d_v, d_t, ctx)
+        sync()
+        n_edges = int(conn.neighbors.shape[0]) if hasattr(conn.neighbors, "shape") else 0
+        rec._free()
+        return nv, nt, n_edges, t_smooth, nrm
+
+    def host_frame():
+        rec = ctx.reconstruct(d_pts, prm)
+        v, t = rec.mesh_views(u64=False)
+        v = np.array(v, dtype=np.float32, order="C")
+        t = np.ascontiguousarray(t)
+        conn = PP.vertex_vertex_connectivity(v.shape[0], t, ctx)
+        mesh = PP.TriMesh3d(v, t, ctx)
+        PP.laplacian_smoothing_parallel(mesh, conn, iterations=iters, beta=1.0, weights=None)
+        nrm = PP.vertex_normals(mesh.vertices, t, ctx)
+        rec._free()
+        return nrm
+
+    device_frame()
+    sync()
+    t0 = time.perf_counter()
+    nv, nt, n_edges, t_smooth, _ = device_frame()
+    sync()
+    t_dev = time.perf_counter() - t0
+    host_frame()
+    sync()
+    t0 = time.perf_counter()
+    host_frame()
+    sync()
+    t_host = time.perf_counter() - t0
+    # one smoothing iteration: reads every vertex (12 B), its CSR row bounds (8 B) and neighbour ids (4 B each) + their positions (counted once per vertex: 12 B, the
+    # gather's re-reads hit L2), writes the vertex (12 B)
+    it_bytes = nv * (12.0 + 8.0 + 12.0 + 12.0) + 4.0 * n_edges
+    it_s = t_smooth / iters
+    return {"recipe": "reconstruct -> vertex connectivity -> Laplacian smoothing x %d (beta 1, uniform weights) -> vertex normals" % iters,
+            "device_resident_ms": round(t_dev * 1e3, 3), "through_host_arrays_ms": round(t_host * 1e3, 3), "value": round(n_total / t_dev / 1e6, 3), "unit": "Mparticles/s",
+            "n_vertices": int(nv), "n_triangles": int(nt), "connectivity_entries": int(n_edges), "smoothing_ms_per_iteration": round(it_s * 1e3, 4),
+            "smoothing_roofline": {"bound": "hbm", "achieved": round(it_bytes / it_s / 1e9, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(it_bytes / it_s / 1e9 / 8000.0, 4),
+                                   "algorithmic_bytes_per_iteration": it_bytes},
+            "note": "SURVEY 8f N3 (csrc/ss_post.hip): the mesh never leaves HBM in the first figure; the second downloads it and lets every stage upload / download its arrays"}
+
+
 def single_gpu_extras(line, args, ctx, prm, wl, workload, pts, d_pts, out, dev, local_rank, sync):
     """Secondary figures of the N = 1 record (never `value`)."""
     import torch
@@ -846,6 +910,13 @@ def single_gpu_extras(line, args, ctx, prm, wl, workload, pts, d_pts, out, dev, 
         ctxs[1].close()
     except Exception as e:
         line["pcie_pipelined"] = {"value": None, "note": "failed: %r" % (e,)}
+    # --- the CLI's smoothing recipe right behind the reconstruction (reconstruct -> vertex connectivity -> 25 iterations of Laplacian smoothing -> vertex
+    #     normals; README.md:165-167, postprocessing.rs:17-97) with the mesh KEPT IN HBM, against the same stages fed through host arrays (mesh downloaded, every
+    #     stage uploading its inputs and downloading its outputs: what a caller without device pointers pays) ---
+    try:
+        line["post_pipeline"] = post_pipeline(ctx, prm, d_pts, n_total, sync)
+    except Exception as e:
+        line["post_pipeline"] = {"value": None, "note": "failed: %r" % (e,)}
     # --- the other BASELINE.json configs, HBM-resident like `value`, driver-timed in the same run (SS_OPTION_SPLAT_TWO_PASS automatic: tiny jobs skip the scheme) ---
     ctx.set_two_pass(-1)
     others = {}
