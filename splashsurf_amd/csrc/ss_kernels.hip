@@ -961,8 +961,12 @@ __device__ __forceinline__ void splat_wave_scan_grouped(const SSDevT<R>& P, cons
             for (int j = 0; j < SS_SCAN_GROUP; ++j) {
                 const uint32_t q = min(q0 + 64u * (uint32_t)j + (uint32_t)lane, total - 1u);
                 int lo = 0;  // last row r with row_prefix[r] <= q
+                if (nb > 16) {  // (wave-uniform; a block of the usual grids has 3 x 3 rows: the two widest steps would find nothing)
+                    lo += (s_row_prefix[32] <= q) ? 32 : 0;
+                    lo += (s_row_prefix[lo + 16] <= q) ? 16 : 0;
+                }
 #pragma unroll
-                for (int step = 32; step > 0; step >>= 1) lo += (s_row_prefix[lo + step] <= q) ? step : 0;
+                for (int step = 8; step > 0; step >>= 1) lo += (s_row_prefix[lo + step] <= q) ? step : 0;
                 src[j] = s_row_start[lo] + (q - s_row_prefix[lo]);
             }
             ss_real4<R> pv[SS_SCAN_GROUP];
@@ -2078,7 +2082,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(sizeof(R) ==
     const int lane = threadIdx.x;
     const uint32_t n = list ? *n_list_dev : n_active;
     const uint32_t n_slots = ss_xcd_chunked_grid_dev(n);
-    const unsigned long long below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
     auto one_slot = [&](uint32_t w) {
         const uint32_t it = ss_xcd_chunked_group(w);
         if (it >= n) return;
@@ -2098,7 +2101,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(sizeof(R) ==
                                      [&](R d2, uint32_t src, uint32_t, const ss_real4<R>& pv) {
                                          const bool inside = d2 <= P.R2;
                                          const unsigned long long m = __ballot(inside);
-                                         const uint32_t pos = count + (uint32_t)__popcll(m & below);
+                                         const uint32_t pos = count + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
                                          if (inside && pos < (uint32_t)CH) {
                                              sh.pay[pos] = pv;
                                              sh.idx[pos] = src;  // (the particle index is looked up by the blocks that order their tile)
@@ -2109,7 +2112,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(sizeof(R) ==
                                              // entries are among them: its box lies inside the block's): their positions in the tile, in sh.near
                                              const bool nb = d2 <= P.R2near;
                                              const unsigned long long mn = __ballot(nb);
-                                             if (nb && pos < (uint32_t)CH) sh.near[n_near_block + (uint32_t)__popcll(mn & below)] = (uint8_t)pos;
+                                             if (nb && pos < (uint32_t)CH) sh.near[n_near_block + __builtin_amdgcn_mbcnt_hi((uint32_t)(mn >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mn, 0u))] = (uint8_t)pos;
                                              n_near_block += (uint32_t)__popcll(mn);
                                          }
                                          return count <= (uint32_t)CH;  // a block with more candidates takes the arena path, which counts them itself
