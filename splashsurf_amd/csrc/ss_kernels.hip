@@ -1687,9 +1687,9 @@ typedef _Float16 ss_half2v __attribute__((ext_vector_type(2)));
 //     point  (B)     1          1          x       x^2    |    y        z      y^2    z^2
 // (lanes 0-31 hold slots 0-3 of row / column `lane`, lanes 32-63 slots 4-7 of row / column `lane - 32`; D: column = lane & 31, row =
 // (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5); layout and rates: tools/ubench/mfma_cert.hip), and THREE VALU instructions per (entry, point)
-// pair are left -- max with 0 (an integer max on the bit pattern: no canonicalisation), a square, an fmac of the square with itself --
-// against the eleven of the list walk of rounds 3-5 (f16 records, v_fma_mix_f32): 150 cycles per 1024 pairs per SIMD instead of ~480 (mfma_cert.hip; the matrix pipe's 32
-// cycles do not overlap the VALU's on this chip, they add).
+// pair are left -- in fact two (splat_cert_term4: d |d| clamped to [0, 1] = max(d, 0)^2 in one instruction, then an fmac of the square with itself) --
+// against the eleven of the list walk of rounds 3-5 (f16 records, v_fma_mix_f32): ~120 cycles per 1024 pairs per SIMD instead of ~480 (mfma_cert.hip; the matrix
+// pipe's 32 cycles do not overlap the VALU's on this chip, they add).
 // STILL A LOWER BOUND: the products of f16 operands are exact and summed in f32; against the f32 values an operand rounded to nearest is off by
 // 2^-11 relative, so  |P~ x~ - 2 s p x| <= 2 s |p| |x| 2^-10 (1 + 2^-11)  per axis and  |s~ (x^2)~ - s x^2| <= s x^2 2^-10 (1 + 2^-11);
 // (s a)_hi + (s a)_lo = s a up to 2^-22.  With xm >= |x| per axis (the block's points: 3.5 cs / h)
@@ -1727,11 +1727,13 @@ __device__ __forceinline__ uint4 splat_cert_record(const SSDevT<float>& P, const
     return make_uint4(__builtin_bit_cast(uint32_t, w0), ss_pack_f16(s2 * px, -s), ss_pack_f16(s2 * py, s2 * pz), ss_pack_f16(-s, -s));
 }
 #define SS_CERT_DUMMY make_uint4(0x0000E3D0u, 0u, 0u, 0u)  // (s a)_hi = -1000: below zero at every point
-// max(d, 0)^4 of four outputs added to acc.  The integer max is exact on the bit patterns (negative floats are negative integers).
+// max(d, 0)^4 of four outputs added to acc, TWO instructions each: d |d| with the result clamped to [0, 1] is max(d, 0)^2 -- a negative d gives
+// -d^2 -> 0, and d = s u <= s < 1 (s^4 = C4 sigma V <= C4: V W(0) <= 1 for every particle) never meets the upper bound --, written as
+// fmed3(d |d|, 0, 1), which hipcc folds into v_mul_f32_e64 v, d, |d| clamp; then the fmac of the square with itself.  (Plain C++ on purpose: the
+// wait states between the MFMA and the first reader of its results are inserted for the compiler's own instructions only.)
 __device__ __forceinline__ float splat_cert_term4(float d0, float d1, float d2, float d3, float acc) {
     auto t = [](float d, float a) {
-        const float m = __int_as_float(max(__float_as_int(d), 0));
-        const float m2 = m * m;
+        const float m2 = __builtin_amdgcn_fmed3f(d * __builtin_fabsf(d), 0.0f, 1.0f);
         return __builtin_fmaf(m2, m2, a);
     };
     return t(d3, t(d2, t(d1, t(d0, acc))));
