@@ -831,6 +831,15 @@ __device__ __forceinline__ R ss_block_box_dist2(const SSDevT<R>& P, const ss_rea
     const R ez = ss_max(ss_max(plo[2] - pv.z, pv.z - phi[2]) - P.coord_slack, R(0.0));
     return ex * ex + ey * ey + ez * ez;
 }
+// The same distance from a box that has the slack folded into its corners (lo - slack, hi + slack; f32): max3(lo' - p, p - hi', 0) per axis, three
+// instructions instead of five.  The two forms differ by a rounding of the corner -- an ulp of a coordinate, against a slack of 16 ulp of the LARGEST
+// coordinate and reach / near radii padded by 1e-4 relative: every filter built on either stays a superset of what the exact arithmetic lets contribute.
+__device__ __forceinline__ float ss_box_dist2_folded(const ss_real4<float>& pv, const float lo[3], const float hi[3]) {
+    const float ex = __builtin_fmaxf(__builtin_fmaxf(lo[0] - pv.x, pv.x - hi[0]), 0.0f);  // (v_max3_f32)
+    const float ey = __builtin_fmaxf(__builtin_fmaxf(lo[1] - pv.y, pv.y - hi[1]), 0.0f);
+    const float ez = __builtin_fmaxf(__builtin_fmaxf(lo[2] - pv.z, pv.z - hi[2]), 0.0f);
+    return ex * ex + ey * ey + ez * ez;
+}
 template <class R>
 __device__ __forceinline__ bool ss_within_reach_of_block(const SSDevT<R>& P, const ss_real4<R>& pv, const R plo[3], const R phi[3]) {
     return ss_block_box_dist2<R>(P, pv, plo, phi) <= P.R2;
@@ -934,6 +943,14 @@ __device__ __forceinline__ void splat_wave_scan_grouped(const SSDevT<R>& P, cons
                                                         const uint32_t* __restrict__ cell_start, const uint2* __restrict__ row_tab, uint32_t key0, const R plo[3], const R phi[3],
                                                         uint32_t* s_row_start, uint32_t* s_row_prefix, int lane, uint32_t bail_total, uint32_t* bailed, F f) {
     const int nrows = P.sn1 * P.sn1;
+    [[maybe_unused]] float flo[3] = {0.0f, 0.0f, 0.0f}, fhi[3] = {0.0f, 0.0f, 0.0f};  // f32: the block's box with the coordinate slack folded in (ss_box_dist2_folded)
+    if constexpr (sizeof(R) == 4) {
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            flo[d] = plo[d] - P.coord_slack;
+            fhi[d] = phi[d] + P.coord_slack;
+        }
+    }
     for (int row_base = 0; row_base < nrows; row_base += 64) {
         const int nb = min(64, nrows - row_base);
         uint32_t len = 0;
@@ -981,7 +998,11 @@ __device__ __forceinline__ void splat_wave_scan_grouped(const SSDevT<R>& P, cons
                 const uint32_t qj = q0 + 64u * (uint32_t)j;
                 if (qj >= total) break;  // (wave-uniform)
                 // squared box distance of the candidate to the block's points (infinite beyond the rows' end): f decides what is within reach
-                const R d2 = (qj + (uint32_t)lane < total) ? ss_block_box_dist2<R>(P, pv[j], plo, phi) : R(INFINITY);
+                R d2;
+                if constexpr (sizeof(R) == 4)
+                    d2 = (qj + (uint32_t)lane < total) ? ss_box_dist2_folded(pv[j], flo, fhi) : INFINITY;
+                else
+                    d2 = (qj + (uint32_t)lane < total) ? ss_block_box_dist2<R>(P, pv[j], plo, phi) : R(INFINITY);
                 if (!f(d2, src[j], id[j], pv[j])) return;  // (wave-uniform)
             }
         }
@@ -1855,6 +1876,14 @@ __device__ __forceinline__ void splat_accumulate_block_wave(SplatAccWaveShared<R
     [[maybe_unused]] uint32_t rb0[4], rb1[4];
     if constexpr (CERT) {
         const float bcx = lo[0][0] + 3.5f * P.cs, bcy = lo[1][0] + 3.5f * P.cs, bcz = lo[2][0] + 3.5f * P.cs;
+        float flo[3][2], fhi[3][2];
+#pragma unroll
+        for (int d = 0; d < 3; ++d)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                flo[d][h] = lo[d][h] - P.coord_slack;
+                fhi[d][h] = hi[d][h] + P.coord_slack;
+            }
         uint4* recs = reinterpret_cast<uint4*>(sh.pay);
         uint8_t* pool = reinterpret_cast<uint8_t*>(sh.wl);
         {
@@ -1875,7 +1904,7 @@ __device__ __forceinline__ void splat_accumulate_block_wave(SplatAccWaveShared<R
             for (int d = 0; d < 3; ++d)
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
-                    const float e = ss_max(ss_max(lo[d][h] - p3[d], p3[d] - hi[d][h]) - P.coord_slack, 0.0f);
+                    const float e = __builtin_fmaxf(__builtin_fmaxf(flo[d][h] - p3[d], p3[d] - fhi[d][h]), 0.0f);  // (the slack folded into the corners: v_max3_f32)
                     e2[d][h] = e * e;
                 }
             if (valid) recs[c] = splat_cert_record(P, pv, bcx, bcy, bcz);
@@ -1982,8 +2011,9 @@ __device__ __forceinline__ void splat_accumulate_block_wave(SplatAccWaveShared<R
                     const R shi[3] = {hi[0][sx], hi[1][sy], hi[2][sz]};
                     acc = splat_accumulate_wave<R, ARITH>(P, sh.pay, sh.wl, n_tile, lane, px, py, pz, slo, shi, P.R2near, R(0.0), sh.near, sb, &n_near);
                 }
-                // the margin of thr_inside covers the rounding of the terms; a sum of n of them adds up to n 2^-24 relative
-                const R thr = P.thr_inside + ((R)n_near * R(1.2e-7)) * P.thr_inside;
+                // the margin of thr_inside covers the rounding of the terms; a sum of n of them adds up to n 2^-24 relative (the certificate's
+                // lists hold at most 64 entries: one constant serves them all)
+                const R thr = CERT ? P.thr_inside + (R(64.0) * R(1.2e-7)) * P.thr_inside : P.thr_inside + ((R)n_near * R(1.2e-7)) * P.thr_inside;
                 done = __ballot(acc > thr || !point_valid) == ~0ull;
             }
             if (!done) {
@@ -1994,15 +2024,15 @@ __device__ __forceinline__ void splat_accumulate_block_wave(SplatAccWaveShared<R
             // the block's mask (mc_load_tile), and the second pass writes the sub-blocks whose values are really read.
             certified |= 1u << sb;
             val = P.thr_inside;
-            if (P.thr_inside > P.threshold) {  // (always, but for thresholds <= 0) every point is inside: no face bits
-                mn = ss_min(mn, val);
-                mx = ss_max(mx, val);
-                continue;
-            }
+            if (P.thr_inside > P.threshold) continue;  // (always, but for thresholds <= 0) every point is inside: no face bits; min / max: after the loop
         }
         mn = ss_min(mn, val);
         mx = ss_max(mx, val);
         if constexpr (EARLY) faces |= (unsigned long long)splat_face_bits(__ballot(point_valid && !(val > P.threshold))) << (6 * sb);
+    }
+    if (certified && P.thr_inside > P.threshold) {  // the certified sub-blocks' stand-in value enters the block's min / max once
+        mn = ss_min(mn, P.thr_inside);
+        mx = ss_max(mx, P.thr_inside);
     }
     SS_PROF_MARK(2);  // classification of the eight sub-blocks
 #if SS_ABLATE == 3
