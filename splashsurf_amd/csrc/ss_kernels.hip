@@ -933,7 +933,7 @@ __device__ __forceinline__ uint32_t ss_wave_inclusive_scan(uint32_t v) {
 // all their loads are in flight together, then the batches are handed to f in order: f(d2, src, id, pv) with d2 = the candidate's
 // squared box distance to the block's points (<= P.R2: within reach; infinite for the lanes past the end), otherwise as in splat_wave_scan.
 #ifndef SS_SCAN_GROUP
-#define SS_SCAN_GROUP 6
+#define SS_SCAN_GROUP 4  // (round 6: 4 / 5 / 6 batches in flight give 3.11-3.21 / 3.15-3.19 / 3.23-3.27 ms on S10M-tank: a block's ~216 candidates are one group of four)
 #endif
 #ifndef SS_FUSED_BAIL
 #define SS_FUSED_BAIL 3
@@ -2050,7 +2050,13 @@ __device__ __forceinline__ void splat_accumulate_block_wave(SplatAccWaveShared<R
                 sh.idx[lane + 64 * k] = perm[src];
             }
         ss_wave_lds_sync();
+#if SS_ABLATE != 4  // (4: the exact sums without the tile sort -- wrong order, same work otherwise)
         splat_sort_tile<R>(sh, nullptr, n_tile, lane);
+#else
+#pragma unroll
+        for (int k = 0; k < CH / 64; ++k) sh.near[lane + 64 * k] = (uint8_t)(lane + 64 * k);
+        ss_wave_lds_sync();
+#endif
         SS_PROF_MARK(3);  // tile sort
 #pragma unroll 1
         for (int sb = 0; sb < 8; ++sb) {
