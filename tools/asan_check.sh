@@ -12,7 +12,7 @@ RT=$(ls /opt/rocm/lib/llvm/lib/clang/*/lib/linux/libclang_rt.asan-x86_64.so | he
 for simd in 0 1; do
   timeout 120 python tools/ab_kernels.py --workload $WL --steps 1 --warmup 1 --simd $simd --digest --host --tag release >> "$OUT/asan_check.jsonl" 2>> "$OUT/asan_check.err"
   for run in 1 2; do
-    LD_PRELOAD=$RT HSA_XNACK=1 ASAN_OPTIONS=detect_leaks=0:halt_on_error=1:protect_shadow_gap=0 \
+    LD_PRELOAD=$RT ASAN_OPTIONS=detect_leaks=0:halt_on_error=1:protect_shadow_gap=0 \
       SPLASHSURF_HIP_LIB=$ROOT/splashsurf_amd/variants/libsplashsurf_hip_asan.so \
       timeout 300 python tools/ab_kernels.py --workload $WL --steps 1 --warmup 1 --simd $simd --digest --host --tag asan_run$run >> "$OUT/asan_check.jsonl" 2>> "$OUT/asan_check.err"
     echo "simd=$simd run=$run exit=$?" >> "$OUT/asan_check.err"
