@@ -355,7 +355,9 @@ typedef struct ss_dist_info {
     uint64_t n_owned;                    /* particles contained in this rank's brick */
     uint64_t bytes_sent_positions, bytes_sent_densities, bytes_sent_assembly; /* payload this rank sent to OTHER ranks */
     double ms_partition, ms_position_exchange, ms_density_exchange, ms_assembly; /* host wall time incl. device waits and waits for peers */
-    double ms_phase1, ms_phase2;         /* host wall time of the two phases of the rank's own reconstruction (binning + densities; level set + marching cubes) */
+    double ms_phase1, ms_phase2;         /* host time of the two phases of the rank's own reconstruction (binning + densities; level set + marching cubes).  ms_phase1 is the
+                                            time to ENQUEUE phase 1 plus its in-phase count waits: its kernels are not drained at the end of the phase, so their tail is part of
+                                            ms_density_exchange (the first wait that follows); ms_device has the phases' device time from HIP events */
     double ms_own_turns;                 /* ss_comm_local_group_take_turns only: time this rank held the device (all of its own work of the step, exchanges excluded) */
     uint64_t n_vertices_owned, vertex_offset, n_vertices_total;  /* after ss_dist_assemble */
     uint64_t n_triangles, triangle_offset, n_triangles_total;
