@@ -62,3 +62,25 @@ def test_cpp_header_compiles():
     root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
     for src in ("test_host.cpp",):
         subprocess.check_call(["g++", "-std=c++17", "-fsyntax-only", "-Wall", "-I" + os.path.join(root, "include"), os.path.join(root, "tests", "cpp", src)])
+
+
+def test_dist_info_layout_matches_the_c_header(tmp_path):
+    """ss_dist_info as the C compiler lays it out (gcc on include/splashsurf_hip.h) == the ctypes mirror the Python host reads it through
+    (splashsurf_amd/distributed.py): size and the offset of every field (round 6 appended bytes_link_max)."""
+    import shutil
+    import subprocess
+    from splashsurf_amd import distributed as D
+    gcc = shutil.which("gcc")
+    if gcc is None:
+        pytest.skip("no C compiler")
+    fields = [n for n, _ in D._DistInfo._fields_]
+    root = os.path.join(os.path.dirname(__file__), "..")
+    src = tmp_path / "layout.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "splashsurf_hip.h"\nint main(void) {\n  printf("%zu\\n", sizeof(ss_dist_info));\n' +
+                   "".join('  printf("%%zu\\n", offsetof(ss_dist_info, %s));\n' % f for f in fields) + "  return 0;\n}\n")
+    exe = tmp_path / "layout"
+    subprocess.check_call([gcc, "-std=c99", "-I", os.path.join(root, "include"), str(src), "-o", str(exe)])
+    out = [int(x) for x in subprocess.check_output([str(exe)]).split()]
+    assert out[0] == ctypes.sizeof(D._DistInfo)
+    for name, off in zip(fields, out[1:]):
+        assert getattr(D._DistInfo, name).offset == off, name
