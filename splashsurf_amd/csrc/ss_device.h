@@ -32,6 +32,17 @@
 enum : int { SS_ARITH_GENERIC = 0, SS_ARITH_FAST = 1, SS_ARITH_SIMD = 2, SS_ARITH_SIMD_LEAN = 3, SS_ARITH_SIMD_HW = 4,
               SS_ARITH_BOUND = 5 /* classification pass only: SIMD_HW without the reach test (the clamp makes far terms 0) */ };
 
+// out = c - x with the result clamped to [0, 1] by the subtraction's output modifier (ONE VALU instruction, c an inline constant), and a
+// comment in the instruction stream that keeps hipcc from if-converting a wave-uniform branch.  SS_HIP_EMU is defined by tests/emu only: the
+// host build that runs these kernels on the CPU for the no-GPU tests (never by the product's build) spells the instruction out in C.
+#ifdef SS_HIP_EMU
+#define SS_SUB_CLAMP(out, c, x) (out) = emu_clamp01((float)(c) - (float)(x))
+#define SS_ASM_NOTE(text)
+#else
+#define SS_SUB_CLAMP(out, c, x) asm("v_sub_f32_e64 %0, " #c ", %1 clamp" : "=v"(out) : "v"(x))
+#define SS_ASM_NOTE(text) asm volatile("; " text ::)
+#endif
+
 // candidate particles (4-byte index keys) held in LDS per pass of the large-tile splat kernel
 template <class R> struct SSTileCap { static constexpr int value = 8192; };
 // tile entries one wave of the wave-per-block splat kernel holds in LDS (k_splat_fused); blocks with more candidates take the arena path

@@ -401,7 +401,7 @@ __device__ __forceinline__ R ss_kernel_w(R d2, R h, R rh, R sigma) {
         // clamp to [0, 1] is the subtraction's output modifier (no extra instruction); its upper bound only touches lanes
         // with q < 1, whose value is replaced by the inner piece below.
         R x;
-        asm("v_sub_f32_e64 %0, 2.0, %1 clamp" : "=v"(x) : "v"(q));
+        SS_SUB_CLAMP(x, 2.0, q);
         R f = (R(1.0) / (R(4.0) * pi)) * x * x * x;
         const bool inner = q < R(1.0);
         if (__ballot(inner)) {
@@ -1332,13 +1332,13 @@ __device__ __forceinline__ float ss_kernel_w_avx(const SSDevT<float>& P, float r
     const float q = r * P.avx_inv_h;
     // v = max(1 - q, 0): the clamp to [0, 1] is the subtraction's output modifier; q >= 0, so the upper bound never acts
     float v;
-    asm("v_sub_f32_e64 %0, 1.0, %1 clamp" : "=v"(v) : "v"(q));
+    SS_SUB_CLAMP(v, 1.0, q);
     const float v2 = v * v;
     const float v3 = v2 * v;
     float w = v3 * P.avx_sigma2;  // outer piece
     const bool inner = q <= 0.5f;
     if (__ballot(inner)) {  // wave-uniform: most entries a wave visits are farther than h/2 from all of its points
-        asm volatile("; inner spline piece" ::);  // keeps the compiler from if-converting this block into five always-executed VALU ops
+        SS_ASM_NOTE("inner spline piece");  // keeps the compiler from if-converting this block into five always-executed VALU ops
         float ri = __builtin_fmaf(-v, P.avx_sigma6, P.avx_sigma);
         ri = __builtin_fmaf(v2, P.avx_sigma12, ri);
         ri = __builtin_fmaf(-v3, P.avx_sigma6, ri);
@@ -1363,7 +1363,7 @@ __device__ __forceinline__ R ss_splat_pair(const SSDevT<R>& P, R rh, const ss_re
             // full-rate instructions after d2 instead of five and v_sqrt_f32, a quarter-rate instruction: no reach test (u = 0
             // beyond h), no second piece, no EXEC bookkeeping.
             float u;
-            asm("v_sub_f32_e64 %0, 1.0, %1 clamp" : "=v"(u) : "v"(d2));
+            SS_SUB_CLAMP(u, 1.0, d2);
             const float u2 = u * u;
             const float poly = __builtin_fmaf(u2, SS_BOUND_C1, SS_BOUND_C0);
             acc = __builtin_fmaf((u2 * u) * poly, e.w, acc);
