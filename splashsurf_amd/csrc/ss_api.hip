@@ -297,6 +297,9 @@ ss_status make_device_params(ss_context* ctx, const typename TypesOf<R>::params*
         const double r = std::ldexp(1.0, -10) * (1.0 + std::ldexp(1.0, -10));
         P.cert_e1 = (R)(r * 2.0 * xm * (1.0 + 1.0e-6));
         P.cert_e0 = (R)((r * 3.0 * xm * xm + 3.0e-5) * (1.0 + 1.0e-6));
+        const double xs = 1.5 * (double)prm->cube_size / (double)h * (1.0 + 1.0e-5) + 1.0e-6;  // relative to a sub-block's centre
+        P.cert_e1s = (R)(r * 2.0 * xs * (1.0 + 1.0e-6));
+        P.cert_e0s = (R)((r * 3.0 * xs * xs + 3.0e-5) * (1.0 + 1.0e-6));
     }
     {   // CubicSplineKernelAvxF32::new (kernel.rs:327-337), in f32 like the reference
         const float hf = (float)h;

@@ -122,6 +122,7 @@ struct SSDevT {
     R thr_inside; // threshold * (1 + 1e-4): a lower bound above it certifies 'inside' whatever the summation order
     // certificate on the matrix pipe (splat_cert_record): C4 sigma (1 - 2e-5), and the slack eps = cert_e1 (|px| + |py| + |pz|) + cert_e0 taken off 1 - |p|^2
     R cert_vscale, cert_e1, cert_e0;
+    R cert_e1s, cert_e0s;  // the same slack for records relative to a SUB-BLOCK's centre (largest point coordinate 1.5 cs / h; k_splat_certify_big)
     // Parameters::enable_simd: constants of CubicSplineKernelAvxF32 (kernel.rs:327-337), formed in f32 like the reference does
     R avx_inv_h, avx_sigma, avx_sigma2, avx_sigma6, avx_sigma12;
     int arith;    // SS_ARITH_* of the level-set accumulation chosen for this call

@@ -22,7 +22,11 @@ struct DevBuf {
             cap = 0;
             if (e != hipSuccess) return e;
         }
+#ifdef SS_HIP_EMU  // tests/emu (the kernels on the CPU): exact sizes, so that its AddressSanitizer build sees a kernel that runs past what was asked for
+        size_t want = bytes;
+#else
         size_t want = bytes + bytes / 8 + 256;
+#endif
         hipError_t e = hipMalloc(&p, want);
         if (e != hipSuccess) {
             p = nullptr;

@@ -1735,10 +1735,11 @@ __device__ __forceinline__ uint32_t ss_pack_f16(float lo, float hi) {
     return __builtin_bit_cast(uint32_t, v);
 }
 // the 16-byte record of a tile entry: slots 0-3 in (x, y), slots 4-7 in (z, w)
-__device__ __forceinline__ uint4 splat_cert_record(const SSDevT<float>& P, const ss_real4<float>& pv, float cx, float cy, float cz) {
+// (e1, e0: the slack constants of the frame the coordinates are relative to -- P.cert_e1 / _e0 for a block's centre, P.cert_e1s / _e0s for a sub-block's)
+__device__ __forceinline__ uint4 splat_cert_record(const SSDevT<float>& P, const ss_real4<float>& pv, float cx, float cy, float cz, float e1, float e0) {
     const float px = (pv.x - cx) * P.avx_inv_h, py = (pv.y - cy) * P.avx_inv_h, pz = (pv.z - cz) * P.avx_inv_h;
     const float s = __builtin_amdgcn_sqrtf(__builtin_amdgcn_sqrtf(pv.w * P.cert_vscale));
-    const float eps = __builtin_fmaf(P.cert_e1, (__builtin_fabsf(px) + __builtin_fabsf(py)) + __builtin_fabsf(pz), P.cert_e0);
+    const float eps = __builtin_fmaf(e1, (__builtin_fabsf(px) + __builtin_fabsf(py)) + __builtin_fabsf(pz), e0);
     const float a = ((1.0f - eps) - px * px) - (py * py + pz * pz);
     const float sa = s * a;
     const _Float16 sa_hi = (_Float16)sa;
@@ -1871,7 +1872,9 @@ __device__ __forceinline__ void splat_accumulate_block_wave(SplatAccWaveShared<R
     // to the block's centre); the near entries of all eight sub-blocks are listed in ONE pass over those entries as byte indices into the tile: list sb = bytes [64 sb, 64 sb + 64) of the
     // pool, padded with the dummy's index.  The near test of a sub-block (box distance <= R_near, separable: six one-dimensional
     // distances per entry) goes straight into its ballot -- no mask word per entry -- and the ballot's prefix count places the entry.
-    // cnt[sb]: entries near sub-block sb; a list longer than its 64 slots (two tiles) is not walked: that sub-block goes to the exact sums.
+    // cnt[sb]: entries near sub-block sb.  A sub-block with more near entries than its 64 slots (two tiles; fine grids list ~25, a grid of cube size h / 2
+    // over a hundred) walks the BLOCK's near list instead (sh.near, padded to whole tiles below): every entry bounds the level set from below, near or not --
+    // the near lists only keep the tiles few --, so the longer walk certifies at least what the sub-block's own list would.
     [[maybe_unused]] int cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     [[maybe_unused]] uint32_t rb0[4], rb1[4];
     if constexpr (CERT) {
@@ -1907,7 +1910,7 @@ __device__ __forceinline__ void splat_accumulate_block_wave(SplatAccWaveShared<R
                     const float e = __builtin_fmaxf(__builtin_fmaxf(flo[d][h] - p3[d], p3[d] - fhi[d][h]), 0.0f);  // (the slack folded into the corners: v_max3_f32)
                     e2[d][h] = e * e;
                 }
-            if (valid) recs[c] = splat_cert_record(P, pv, bcx, bcy, bcz);
+            if (valid) recs[c] = splat_cert_record(P, pv, bcx, bcy, bcz, P.cert_e1, P.cert_e0);
 #pragma unroll
             for (int sb = 0; sb < 8; ++sb) {
                 const bool bit = valid && ((e2[0][(sb >> 2) & 1] + e2[1][(sb >> 1) & 1]) + e2[2][sb & 1] <= P.R2near);
@@ -1916,6 +1919,11 @@ __device__ __forceinline__ void splat_accumulate_block_wave(SplatAccWaveShared<R
                 if (bit && pos < 64) pool[64 * sb + pos] = (uint8_t)c;
                 cnt[sb] += __popcll(m);
             }
+        }
+        if (((cnt[0] > 64) | (cnt[1] > 64) | (cnt[2] > 64) | (cnt[3] > 64)) | ((cnt[4] > 64) | (cnt[5] > 64) | (cnt[6] > 64) | (cnt[7] > 64))) {  // (wave-uniform)
+            // some sub-block walks the block's near list: pad it to whole tiles of 32 rows with the dummy's index (positions below CH: the array's own)
+            const int i = n_near_block + (lane & 31);
+            if (lane < 32 && i < ((n_near_block + 31) & ~31)) sh.near[i] = (uint8_t)CH;
         }
         // the B operands: lanes 0-31 hold the x content of their column for its four x positions q = 2 sx + g (g: tile = points
         // [32 g, 32 g + 32) of the sub-block), lanes 32-63 the (y, z) content of their column for q = 2 sy + sz
@@ -1950,18 +1958,20 @@ __device__ __forceinline__ void splat_accumulate_block_wave(SplatAccWaveShared<R
     // first the sub-blocks that need no exact sum: not selected (second pass), outside the grid, or certified by the lower bound
     // (certificate: the A operand -- this lane's half of its row's record -- of a sub-block's first tile is fetched one sub-block ahead:
     // index, then record, are two dependent LDS round trips that would otherwise head every sub-block's chain)
-    [[maybe_unused]] auto cert_row = [&](int sb_, int base) -> uint2 {
-        const uint32_t e = reinterpret_cast<const uint8_t*>(sh.wl)[64 * sb_ + base + (lane & 31)];
+    // (list_of(sb): where sub-block sb's list starts -- its 64 slots of the pool, or the block's near list if it outgrew them; wave-uniform)
+    [[maybe_unused]] auto list_of = [&](int sb_) -> const uint8_t* { return cnt[sb_] > 64 ? sh.near : reinterpret_cast<const uint8_t*>(sh.wl) + 64 * sb_; };
+    [[maybe_unused]] auto cert_row = [&](const uint8_t* lst, int base) -> uint2 {
+        const uint32_t e = lst[base + (lane & 31)];
         return *reinterpret_cast<const uint2*>(reinterpret_cast<const char*>(sh.pay) + e * 16u + (uint32_t)(lane >> 5) * 8u);
     };
     [[maybe_unused]] uint2 arow_ahead = make_uint2(0u, 0u);
-    if constexpr (CERT) arow_ahead = cert_row(0, 0);
+    if constexpr (CERT) arow_ahead = cert_row(list_of(0), 0);
 #pragma unroll
     for (int sb = 0; sb < 8; ++sb) {
         const int sx = (sb >> 2) & 1, sy = (sb >> 1) & 1, sz = sb & 1;
         [[maybe_unused]] const uint2 arow_first = arow_ahead;
         if constexpr (CERT)
-            if (sb < 7) arow_ahead = cert_row(sb + 1, 0);
+            if (sb < 7) arow_ahead = cert_row(list_of(sb + 1), 0);
         const bool point_valid = pt_ok[0][sx] && pt_ok[1][sy] && pt_ok[2][sz];
         R* gp = gblock + 64 * sb;
         R val;
@@ -1986,9 +1996,10 @@ __device__ __forceinline__ void splat_accumulate_block_wave(SplatAccWaveShared<R
                     const uint32_t b1g0 = (2 * sx == j) ? rb1[j] : (lo_half ? rb1[2 * sx] : rb1[j]);
                     const uint32_t b1g1 = (2 * sx + 1 == j) ? rb1[j] : (lo_half ? rb1[2 * sx + 1] : rb1[j]);
                     float a0 = 0.0f, a1 = 0.0f;
-                    const int n_walk = n_near <= 64 ? n_near : 0;  // (a list that outgrew its slots certifies nothing)
+                    const int n_walk = n_near <= 64 ? n_near : n_near_block;  // (a list that outgrew its slots: the block's near list)
+                    const uint8_t* lst = list_of(sb);
                     for (int base = 0; base < n_walk; base += 32) {  // (one trip unless the list has more than 32 entries)
-                        const uint2 arow = base == 0 ? arow_first : cert_row(sb, base);
+                        const uint2 arow = base == 0 ? arow_first : cert_row(lst, base);
                         const int rows = n_walk - base;
 #if SS_CERT_DUAL  // both tiles on the matrix pipe before either is consumed (16 registers more)
                         const ss_float16v d0 = splat_cert_mfma(arow, rb0[j], b1g0), d1 = splat_cert_mfma(arow, rb0[j], b1g1);
@@ -2012,8 +2023,8 @@ __device__ __forceinline__ void splat_accumulate_block_wave(SplatAccWaveShared<R
                     acc = splat_accumulate_wave<R, ARITH>(P, sh.pay, sh.wl, n_tile, lane, px, py, pz, slo, shi, P.R2near, R(0.0), sh.near, sb, &n_near);
                 }
                 // the margin of thr_inside covers the rounding of the terms; a sum of n of them adds up to n 2^-24 relative (the certificate's
-                // lists hold at most 64 entries: one constant serves them all)
-                const R thr = CERT ? P.thr_inside + (R(64.0) * R(1.2e-7)) * P.thr_inside : P.thr_inside + ((R)n_near * R(1.2e-7)) * P.thr_inside;
+                // lists hold at most 64 entries, the block's near list a tile's CH: two constants serve them all)
+                const R thr = CERT ? P.thr_inside + (R(n_near <= 64 ? 64 : CH) * R(1.2e-7)) * P.thr_inside : P.thr_inside + ((R)n_near * R(1.2e-7)) * P.thr_inside;
                 done = __ballot(acc > thr || !point_valid) == ~0ull;
             }
             if (!done) {
@@ -2246,7 +2257,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
         point_valid = point_valid && (g0 + o3[d]) < P.np[d];
         slo[d] = P.gmin[d] + (float)g0 * P.cs;
         shi[d] = P.gmin[d] + (float)min(g0 + 3, P.np[d] - 1) * P.cs;
-        bc[d] = (P.gmin[d] + (float)(b3[d] * SS_BLOCK) * P.cs) + 3.5f * P.cs;  // the records' frame: the block's centre (splat_accumulate_block_wave)
+        // the records' frame: the centre of THIS WAVE's sub-block (a wave builds its own records: the smaller coordinates cost nothing here and keep the
+        // slack of the f16 operands small on coarse grids, where the block's half width is several h -- tools/cert_study.py)
+        bc[d] = slo[d] + 1.5f * P.cs;
     }
     // B operands of this wave's two tiles (columns = points [32 g, 32 g + 32) of its sub-block; splat_cert_record): lanes 0-31 hold the x content
     // of their column, lanes 32-63 the (y, z) content.  (The certificate bounds the level set from below whatever arithmetic evaluates it: the
@@ -2357,7 +2370,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
                     const bool pass = (qj + (uint32_t)lane < total) && ((ex * ex + ey * ey) + ez * ez <= r2near);
                     const unsigned long long m = __ballot(pass);
                     if (m) {
-                        if (pass) list[n_list + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] = splat_cert_record(P, pv[j], bc[0], bc[1], bc[2]);
+                        if (pass) list[n_list + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] = splat_cert_record(P, pv[j], bc[0], bc[1], bc[2], P.cert_e1s, P.cert_e0s);
                         const int c = __popcll(m);
                         n_list += c;
                         n_near += c;

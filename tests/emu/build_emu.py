@@ -1,7 +1,10 @@
 """Builds tests/emu/_build/libsplashsurf_emu.so: the library's own sources (splashsurf_amd/csrc/*.hip, unmodified) compiled as C++ for
 the host against tests/emu/include/hip/hip_runtime.h -- the CPU execution model of the kernels.  TEST INFRASTRUCTURE: only tests load it.
 
-    python tests/emu/build_emu.py [--force] [-DNAME=VALUE ...] [--out PATH]
+    python tests/emu/build_emu.py [--force] [--asan] [-DNAME=VALUE ...] [--out PATH]
+
+--asan: the same with -fsanitize=address (libsplashsurf_emu_asan.so): AddressSanitizer over the KERNELS' loads and stores -- the GPU pool offers no device
+sanitizer --; run with LD_PRELOAD=$(clang++ -print-file-name=libclang_rt.asan-x86_64.so) ASAN_OPTIONS=detect_leaks=0 (tests/emu/run_asan.sh).
 """
 import os
 import subprocess
@@ -56,7 +59,7 @@ def build(force=False, defines=(), out=OUT):
         objs = list(pool.map(compile_one, units))
     if force or stale(out, objs):
         cmd = [cxx(), "-shared", "-fPIC", "-Wl,-Bsymbolic"] + objs  # (-Bsymbolic: the hip* calls bind to the emulator even when a real libamdhip64 is loaded in the process)
-        cmd += ["-ldl", "-lpthread", "-o", out]
+        cmd += [d for d in defines if d.startswith("-fsanitize")] + ["-ldl", "-lpthread", "-o", out]
         print("[emu-build]", " ".join(cmd), flush=True)
         subprocess.check_call(cmd)
     return out
@@ -69,4 +72,9 @@ if __name__ == "__main__":
         i = args.index("--out")
         out = os.path.abspath(args[i + 1])
         del args[i:i + 2]
-    print(build(force="--force" in args, defines=[a for a in args if a.startswith("-D")], out=out))
+    extra = [a for a in args if a.startswith("-D")]
+    if "--asan" in args:
+        extra += ["-fsanitize=address", "-fno-omit-frame-pointer", "-O1"]
+        if out == OUT:
+            out = OUT.replace("_emu.so", "_emu_asan.so")
+    print(build(force="--force" in args, defines=extra, out=out))

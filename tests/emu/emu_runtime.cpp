@@ -13,6 +13,14 @@
 #include <thread>
 #include <vector>
 
+#if defined(__has_feature)
+#if __has_feature(address_sanitizer)
+#define EMU_ASAN 1
+#include <sanitizer/asan_interface.h>
+#include <sanitizer/common_interface_defs.h>
+#endif
+#endif
+
 namespace emu {
 
 thread_local Lane* cur = nullptr;
@@ -52,6 +60,8 @@ struct Worker {
     Lane lanes[MAX_THREADS];
     Block blk;
     void* sched_sp = nullptr;
+    const void* sched_stack_bottom = nullptr;  // (AddressSanitizer build: the OS thread's stack, learnt at the first switch into a fiber)
+    size_t sched_stack_size = 0;
     void (*thunk)(void*) = nullptr;
     void* ctx = nullptr;
     std::vector<char> dyn;
@@ -62,18 +72,43 @@ struct Worker {
 static thread_local Worker* tl_worker = nullptr;
 static thread_local Worker* tl_running = nullptr;  // the worker whose fibers run on this OS thread
 
+// AddressSanitizer build (build_emu.py --asan): the sanitizer is told about every change of stack, so that its stack checks follow the fibers
 static void to_scheduler() {
     Worker* w = tl_running;
     Lane* me = cur;
+#ifdef EMU_ASAN
+    void* fake = nullptr;
+    __sanitizer_start_switch_fiber(me->state == ST_DONE ? nullptr : &fake, w->sched_stack_bottom, w->sched_stack_size);
+#endif
     emu_ctx_switch(&me->sp, w->sched_sp);
+#ifdef EMU_ASAN
+    __sanitizer_finish_switch_fiber(fake, nullptr, nullptr);
+#endif
 }
 
 static void fiber_main() {
     Worker* w = tl_running;
+#ifdef EMU_ASAN
+    __sanitizer_finish_switch_fiber(nullptr, &w->sched_stack_bottom, &w->sched_stack_size);
+#endif
     w->thunk(w->ctx);
     cur->state = ST_DONE;
     to_scheduler();
     abort();  // a finished fiber is never resumed
+}
+
+// scheduler side of a switch into lane L
+static inline void resume_lane(Worker* w, Lane* L) {
+    cur = L;
+#ifdef EMU_ASAN
+    void* fake = nullptr;
+    const char* bottom = w->stacks + STACK_BYTES * (size_t)L->flat;
+    __sanitizer_start_switch_fiber(&fake, bottom, STACK_BYTES);
+#endif
+    emu_ctx_switch(&w->sched_sp, L->sp);
+#ifdef EMU_ASAN
+    __sanitizer_finish_switch_fiber(fake, nullptr, nullptr);
+#endif
 }
 
 void wave_sync(int op, int site) {
@@ -135,6 +170,9 @@ static void run_block(Worker* w, uint3 bid, dim3 grid, dim3 block, size_t shmem)
         sp[6] = (void*)&fiber_main;
         sp[7] = nullptr;
         L.sp = sp;  // after the six pops and the ret: rsp = top - 8, i.e. 8 modulo 16 as at any function entry
+#ifdef EMU_ASAN
+        __asan_unpoison_memory_region(w->stacks + STACK_BYTES * (size_t)t, STACK_BYTES);  // (the frames the previous fiber on this stack never returned from)
+#endif
     }
     tl_running = w;
     int live = nt;
@@ -147,8 +185,7 @@ static void run_block(Worker* w, uint3 bid, dim3 grid, dim3 block, size_t shmem)
             while (true) {
                 for (int l = 0; l < nl; ++l) {
                     if (wl[l].state != ST_READY) continue;
-                    cur = &wl[l];
-                    emu_ctx_switch(&w->sched_sp, wl[l].sp);
+                    resume_lane(w, &wl[l]);
                 }
                 // nobody of this wave can run: complete a wave-level operation if one is pending
                 int site = 0x7fffffff;

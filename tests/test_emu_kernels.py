@@ -1,0 +1,122 @@
+"""The library's HIP kernels, run WITHOUT a GPU: the `-m gpu` parity tests themselves in a child process whose SPLASHSURF_HIP_LIB names
+tests/emu/_build/libsplashsurf_emu.so -- splashsurf_amd/csrc/*.hip compiled for the host against tests/emu's CPU execution model of the HIP
+kernel language (wave64 fibers, ballots, DPP, MFMA, permlane swap, chained look-back; tests/emu/include/hip/hip_runtime.h).  Same sources,
+same C ABI, same tests, same oracle and wheel goldens: what this tier adds to the CPU suite is the kernels' LOGIC (indexing, wave-level
+protocols, summation order, certificates), which so far only ran on the GPU box.  What it cannot show: anything about time, occupancy or
+the memory system, and the two approximate device instructions (v_sqrt_f32 in the certificates' records and in enable_simd = 2).
+
+Test infrastructure only: the emulated library is never loaded by the product (api.py needs SPLASHSURF_HIP_LIB set explicitly, as here).
+"""
+import os
+import re
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+
+# -m gpu tests that cannot run on the emulated library: they hand the library torch DEVICE tensors, create an RCCL communicator or link
+# the C++ host against the HIP build
+NEED_A_DEVICE = [
+    "tests/test_cli.py::test_cli_end_to_end_matches_the_library_call",
+    "tests/test_distributed.py::test_gpu_ranks_on_one_device_reproduce_single_process",
+    "tests/test_gpu_dist_native.py::test_native_one_rank_rccl",
+    "tests/test_gpu_parity.py::test_device_pointer_input_and_determinism",
+    "tests/test_gpu_parity.py::test_sharded_engine_reproduces_full_reconstruction",
+    "tests/test_gpu_parity.py::test_splat_on_reference_grid_loop_fixture",
+    "tests/test_gpu_parity.py::test_cpp_host_over_c_abi",
+    "tests/test_gpu_parity.py::test_gpu_dense_marching_cubes[hbm]",
+    "tests/test_gpu_parity.py::test_host_waits_are_counted",
+    "tests/test_gpu_parity.py::test_hbm_bandwidth_probe_reports_plausible_rates",
+    "tests/test_gpu_simd.py::test_simd_on_reference_grid_loop_fixture",
+    "tests/test_post.py::test_gpu_post_stages_bit_identical_to_oracle[post_cube_2366-hbm]",
+    "tests/test_post.py::test_gpu_post_stages_bit_identical_to_oracle[post_f64_cube_2366-hbm]",
+    "tests/test_post.py::test_gpu_pipeline_matches_oracle_and_reference",
+]
+# ... and the ones that take more than ~4 s emulated (8 host threads); SPLASHSURF_EMU_ALL=1 runs them too (about 20 minutes, 1 M particles
+# included; the 10 M / 40 M full-size tests stay out)
+SLOW_EMULATED = [
+    "tests/test_gpu_parity.py::test_full_size_s10m_tank_bit_identical_to_oracle",
+    "tests/test_gpu_parity.py::test_config4_s40m_tank",
+    "tests/test_gpu_dist_native.py::test_native_full_s40m_tank_four_ranks",
+]
+SLOW_EMULATED_OPTIONAL = [
+    "tests/test_gpu_parity.py::test_gpu_global_strategy_bit_identical_to_oracle_and_reference[global_free_particles_125]",
+    "tests/test_gpu_parity.py::test_u64_triangles_cross_pcie_as_u32",
+    "tests/test_gpu_simd.py::test_simd_bit_identical_to_uniform_oracle[simd_config2_s1m]",
+    "tests/test_gpu_simd.py::test_simd_bit_identical_to_uniform_oracle[simd_config5_hilbert]",
+    "tests/test_gpu_fuzz.py::test_random_configuration_bit_identical[clusters-global-c0.33-n7-f64]",
+    "tests/test_gpu_fuzz.py::test_random_configuration_bit_identical[clusters-grid-c0.2-n64-f32]",
+    "tests/test_gpu_fuzz.py::test_random_configuration_bit_identical[clusters-global-c0.33-n9-f32]",
+    "tests/test_gpu_parity.py::test_gpu_matches_reference_digest[config2_s1m]",
+    "tests/test_gpu_parity.py::test_gpu_matches_reference_digest[config5_hilbert]",
+    "tests/test_gpu_parity.py::test_gpu_bit_identical_to_oracle_large[config5_hilbert]",
+    "tests/test_gpu_parity.py::test_dense_cloud_exceeding_tile_capacity[True]",
+    "tests/test_gpu_parity.py::test_split_mc_offsets_gives_the_same_mesh",
+    "tests/test_gpu_simd.py::test_early_exit_inside_the_fluid_changes_no_output[1]",
+    "tests/test_gpu_simd.py::test_early_exit_inside_the_fluid_changes_no_output[2]",
+    "tests/test_gpu_simd.py::test_simd_matches_reference_simd_digest[simd_config2_s1m]",
+    "tests/test_gpu_simd.py::test_simd_matches_reference_simd_digest[simd_config5_hilbert]",
+    "tests/test_gpu_simd.py::test_simd_hw_sqrt_within_the_references_own_tolerance[simd_config5_hilbert]",
+    "tests/test_gpu_dist_native.py::test_native_partition_feedback_keeps_the_mesh",
+    "tests/test_gpu_dist_native.py::test_native_ranks_reproduce_single_context[tank_crop-8-float32-1]",
+    "tests/test_gpu_dist_native.py::test_native_ranks_reproduce_single_context[hilbert_n32-8-float32-1]",
+    "tests/test_gpu_dist_native.py::test_native_ranks_reproduce_single_context[hilbert_n32-4-float32-0]",
+    "tests/test_gpu_certificates.py::test_certified_subblocks_lie_inside_the_fluid[tank_bulk_scalar]",
+    "tests/test_gpu_certificates.py::test_certified_subblocks_lie_inside_the_fluid[tank_bulk_simd]",
+    "tests/test_gpu_certificates.py::test_certified_subblocks_lie_inside_the_fluid[tank_fine_grid]",
+    "tests/test_gpu_certificates.py::test_certified_subblocks_lie_inside_the_fluid[tank_large_units]",
+    "tests/test_reference_suite.py::test_full_rs[free_particles_02]",
+    "tests/test_reference_suite.py::test_full_rs[free_particles_01]",
+    "tests/test_reference_suite.py::test_subdomains_rs_single_particle[0.025-tris2-verts2-subdomains2]",
+]
+FILES = ["tests/test_gpu_parity.py", "tests/test_gpu_simd.py", "tests/test_gpu_fuzz.py", "tests/test_gpu_certificates.py", "tests/test_gpu_dist_native.py",
+         "tests/test_reference_suite.py", "tests/test_post.py", "tests/test_distributed.py", "tests/test_cli.py"]
+
+
+def emulated_library():
+    sys.path.insert(0, os.path.join(ROOT, "tests", "emu"))
+    import build_emu
+    return build_emu.build()
+
+
+def run_gpu_tests_emulated(extra_args, deselect, timeout_s):
+    lib = emulated_library()
+    env = dict(os.environ, SPLASHSURF_HIP_LIB=lib)
+    cmd = [sys.executable, "-m", "pytest", "-m", "gpu", "-q", "-p", "no:cacheprovider", "--timeout", "600"] + FILES + list(extra_args)
+    for d in deselect:
+        cmd += ["--deselect", d]
+    p = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=timeout_s)
+    tail = "\n".join(p.stdout.splitlines()[-40:])
+    m = re.search(r"(\d+) passed", p.stdout)
+    return p.returncode, (int(m.group(1)) if m else 0), tail
+
+
+def test_the_gpu_parity_tests_pass_on_the_cpu_execution_model_of_the_kernels():
+    everything = os.environ.get("SPLASHSURF_EMU_ALL") == "1"
+    deselect = NEED_A_DEVICE + SLOW_EMULATED + ([] if everything else SLOW_EMULATED_OPTIONAL)
+    rc, passed, tail = run_gpu_tests_emulated([], deselect, 7200 if everything else 1500)
+    assert rc == 0, tail
+    assert passed >= 140, tail  # 50 parity / golden cases, 52 fuzz cases, the SIMD modes, certificates, in-process ranks, the reference's own test cases
+
+
+def test_the_emulated_library_is_not_what_the_product_loads():
+    """api.library_path() names the HIP build unless SPLASHSURF_HIP_LIB says otherwise; nothing under splashsurf_amd/, bench.py or
+    __graft_entry__.py mentions the emulator."""
+    import splashsurf_amd.api as A
+    if "SPLASHSURF_HIP_LIB" not in os.environ:
+        assert A.library_path().endswith(os.path.join("splashsurf_amd", "libsplashsurf_hip.so"))
+    hits = []
+    for base, _, names in os.walk(os.path.join(ROOT, "splashsurf_amd")):
+        if "csrc" + os.sep + "build" in base or "__pycache__" in base or "variants" in base:
+            continue
+        for n in names:
+            if n.endswith((".py", ".hip", ".h", ".hpp")):
+                text = open(os.path.join(base, n), errors="replace").read()
+                if "libsplashsurf_emu" in text or "tests/emu/_build" in text:
+                    hits.append(os.path.join(base, n))
+    for n in ("bench.py", "__graft_entry__.py"):
+        if "libsplashsurf_emu" in open(os.path.join(ROOT, n)).read():
+            hits.append(n)
+    assert not hits, hits
