@@ -263,7 +263,8 @@ ss_status ss_result_vertex_keys(ss_result *res, const uint64_t **keys, uint64_t 
  * reconstruction held by `res` (points outside evaluated blocks read 0); out is host memory,
  * extent[0]*extent[1]*extent[2] floats, k fastest (dense_subdomains.rs:839 flattening). */
 ss_status ss_result_levelset_box(ss_result *res, const int64_t lo[3], const int64_t extent[3], float *out);
-/* Test aid: the certificates of the last subdomain-grid reconstruction held by `res` (valid until the next call on its context).  n_active: number of
+/* Test aid: the certificates of the last subdomain-grid reconstruction held by `res` (valid until the next call on its context: SS_ERR_INVALID_ARGUMENT
+ * after that, the masks live in the context's scratch).  n_active: number of
  * active 8^3 level-set blocks; masks[b] bit s set <=> the 4^3 sub-block s = (sx << 2 | sy << 1 | sz) of block b was certified "inside the fluid" by the
  * lower bound and NEVER evaluated (SS_OPTION_FULL_LEVELSET above); block_xyz[3 b ..]: the block's coordinates in units of blocks.  `capacity`: blocks the
  * two arrays hold (masks: capacity, block_xyz: 3 * capacity; host memory); n_active is always reported.  tests/test_gpu_certificates.py checks every such

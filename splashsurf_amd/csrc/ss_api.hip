@@ -788,6 +788,7 @@ ss_status phase_begin(ss_context* ctx, const R* xyz, uint64_t n_in, const typena
     res->n_vertices = res->n_triangles = 0;
     res->n_active = res->n_mc = 0;
     res->dbg_certified = nullptr;
+    ++ctx->call_serial;  // (whatever an earlier result still points to in this context's scratch is stale from here on: ss_result_debug_certified)
     ctx->host_waits = 0;
 
     const bool host_input = n_in > 0 && xyz && !is_device_pointer(xyz);
@@ -1313,6 +1314,7 @@ ss_status phase_finish(ss_context* ctx, ss_result* res) {
     res->n_vertices = nv;
     res->n_triangles = nt;
     res->dbg_certified = full_ls ? nullptr : tr_flag;
+    res->dbg_serial = ctx->call_serial;
     ss_stats& S = res->stats;
     S.ms_total = ev_ms(ctx, 0, 4) + ev_ms(ctx, 10, 9);  // both phases (excludes what the host does between them)
     S.ms_upload = host_input ? ev_ms(ctx, 0, 1) : 0.0;
@@ -2168,6 +2170,9 @@ ss_status ss_result_debug_certified(ss_result* r, uint32_t* masks, uint32_t* blo
     const uint64_t n = std::min<uint64_t>(capacity, r->n_active);
     if (!n) return SS_OK;
     if (!masks || !block_xyz) return SS_ERR_INVALID_ARGUMENT;
+    // the masks live in the context's scratch: another reconstruction on the context (with any result object) has overwritten or freed them
+    if (r->dbg_certified && r->dbg_serial != ctx->call_serial)
+        return fail(ctx, SS_ERR_INVALID_ARGUMENT, "ss_result_debug_certified: the certificates of this result are gone (another call ran on its context since)");
     SS_HIP(ctx, hipSetDevice(ctx->device));
     SS_HIP(ctx, hipStreamSynchronize(ctx->stream));
     if (r->dbg_certified)

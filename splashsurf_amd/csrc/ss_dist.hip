@@ -176,6 +176,7 @@ struct ss_comm {
     std::vector<double> cost_per_particle;  // per rank, from the previous call (empty: none yet)
     std::vector<int64_t> prev_bricks;
     int prev_ns[3] = {0, 0, 0};
+    double prev_origin[3] = {0.0, 0.0, 0.0};  // grid origin of the call the previous bricks belong to
     // state of the last ss_dist_reconstruct / ss_dist_assemble
     DevBuf xyz_in, hist, flags, offs, boxes_dev, mask, sendbuf, recvbuf, gids, L, owned, sort_tmp, keys_a, keys_b, vals_a, vals_b, owner, holder, gid_local, mine_off, tri64, vown, kown, err;
     bool is_f64 = false;
@@ -919,10 +920,22 @@ ss_status dist_reconstruct(ss_comm* c, const R* xyz_in, uint64_t n_local, const 
         SS_HIP(ctx, hipMemcpyAsync(c->xyz_in.p, xyz_in, n_local * 3 * sizeof(R), hipMemcpyHostToDevice, st));
         d_xyz = c->xyz_in.as<R>();
     }
-    struct Head { uint64_t n; double lo[3], hi[3]; } mine_head, zero_head;
+    struct Head { uint64_t n; double lo[3], hi[3]; uint64_t fb; } mine_head, zero_head;
     memset(&zero_head, 0, sizeof(zero_head));
     mine_head = zero_head;
     mine_head.n = n_local;
+    // every rank must hold the SAME partition-feedback state (flag, previous bricks, measured costs): ranks that disagree would cut different bricks
+    // and exchange with the wrong peers.  A digest of the state travels with the head and is compared below.
+    {
+        uint64_t hsh = c->feedback ? 0x9E3779B97F4A7C15ull : 1ull;
+        auto mix = [&](uint64_t v) { hsh = (hsh ^ v) * 0x100000001B3ull; hsh ^= hsh >> 29; };
+        if (c->feedback) {
+            for (double v : c->cost_per_particle) { uint64_t b; memcpy(&b, &v, 8); mix(b); }
+            for (int64_t v : c->prev_bricks) mix((uint64_t)v);
+            for (int d = 0; d < 3; ++d) { mix((uint64_t)c->prev_ns[d]); uint64_t b; memcpy(&b, &c->prev_origin[d], 8); mix(b); }
+        }
+        mine_head.fb = hsh;
+    }
     ss_status s = comm_ensure_mail(c);
     if (s != SS_OK) return s;
     TurnGuard turn(c, "aabb");
@@ -948,6 +961,9 @@ ss_status dist_reconstruct(ss_comm* c, const R* xyz_in, uint64_t n_local, const 
     R dmin[3] = {0, 0, 0}, dmax[3] = {0, 0, 0};
     bool any = false;
     double pref[3] = {0.0, 0.0, 0.0};
+    for (int q = 0; q < world; ++q)
+        if (heads[q].fb != mine_head.fb)
+            return fail(ctx, SS_ERR_INVALID_ARGUMENT, "the ranks disagree on the partition-feedback state (ss_comm_set_balance_feedback must be called on every rank, at the same step)", q);
     for (int q = 0; q < world; ++q) {
         if (q < me) id0 += heads[q].n;
         n_total += heads[q].n;
@@ -998,7 +1014,9 @@ ss_status dist_reconstruct(ss_comm* c, const R* xyz_in, uint64_t n_local, const 
     // partition feedback: a subdomain's particles weigh what a particle cost the rank that owned the subdomain in the previous call (identical on every
     // rank: the costs were all-gathered as integers); subdomains outside the previous bricks (the domain moved) keep weight 1
     bool weighted = false;
-    if (c->feedback && (int)c->cost_per_particle.size() == world && c->prev_bricks.size() == (size_t)world * 6 && c->prev_ns[0] == ns[0] && c->prev_ns[1] == ns[1] &&
+    // (a domain whose origin moved: the previous bricks name other regions of space -- their weights are dropped)
+    const bool same_origin = c->prev_origin[0] == (double)grid.aabb_min[0] && c->prev_origin[1] == (double)grid.aabb_min[1] && c->prev_origin[2] == (double)grid.aabb_min[2];
+    if (c->feedback && same_origin && (int)c->cost_per_particle.size() == world && c->prev_bricks.size() == (size_t)world * 6 && c->prev_ns[0] == ns[0] && c->prev_ns[1] == ns[1] &&
         c->prev_ns[2] == ns[2]) {
         double mean = 0.0;
         int cnt = 0;
@@ -1191,6 +1209,7 @@ ss_status dist_reconstruct(ss_comm* c, const R* xyz_in, uint64_t n_local, const 
     c->cost_per_particle = cpp;
     c->prev_bricks = c->bricks;
     for (int d = 0; d < 3; ++d) c->prev_ns[d] = ns[d];
+    for (int d = 0; d < 3; ++d) c->prev_origin[d] = (double)grid.aabb_min[d];
     return SS_OK;
 }
 

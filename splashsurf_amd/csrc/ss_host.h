@@ -111,6 +111,7 @@ struct ss_context {
     unsigned long long* mail_dev = nullptr;
     unsigned long long mail_seq = 0;
     uint64_t host_waits = 0;  // blocking points of the current call (ss_stats::n_host_waits)
+    uint64_t call_serial = 0;  // reconstructions started on this context (stamps what a result keeps in the context's scratch)
     // second stream (experiment, SPLASH_K1_OVERLAP=1): the splat-cell sort (K1, bandwidth-bound) beside the density kernel (bound by the vector L1 / VALU).
     // Measured: S10M-tank 9.62 against 9.67 ms per step, S10M-cube 20.9 / 21.2 -- the K1 chain stretches from 0.41 to 1.33 ms, the density kernel from 0.96
     // to 1.00 ms: the device is busy either way.  Off by default (one stream, K1 first).
@@ -139,6 +140,7 @@ struct ss_result {
     uint64_t n_input = 0, n_particles = 0, n_vertices = 0, n_triangles = 0;
     uint32_t n_active = 0, n_mc = 0;
     const uint32_t* dbg_certified = nullptr;  // per active block: the certified, never evaluated sub-blocks (context scratch of the last call; ss_result_debug_certified)
+    uint64_t dbg_serial = 0;                  // ctx->call_serial of the call that set dbg_certified
     bool has_neighbors = false;
     uint64_t n_neighbors = 0;
     DevBuf nb_ptr, nb_idx, nb_idx64;

@@ -318,7 +318,10 @@ static Pool* pool() {
 
 static std::atomic<unsigned long long> g_launches{0};
 
-void run_grid(dim3 grid, dim3 block, size_t shmem, void (*thunk)(void*), void* ctx) {
+static const bool g_trace = getenv("HIP_EMU_TRACE") != nullptr;  // one line per launch / memset / copy on stderr (what a call dispatches, in order)
+
+void run_grid(const char* name, dim3 grid, dim3 block, size_t shmem, void (*thunk)(void*), void* ctx) {
+    if (g_trace) fprintf(stderr, "[hip-emu] launch %s grid %u x %u x %u block %u\n", name, grid.x, grid.y, grid.z, block.x * block.y * block.z);
     if (cur) {
         fprintf(stderr, "[hip-emu] kernel launch from device code\n");
         abort();
@@ -393,10 +396,12 @@ hipError_t hipMemcpy(void* dst, const void* src, size_t n, hipMemcpyKind) {
     return hipSuccess;
 }
 hipError_t hipMemcpyAsync(void* dst, const void* src, size_t n, hipMemcpyKind, hipStream_t) {
+    if (emu::g_trace) fprintf(stderr, "[hip-emu] memcpyAsync %zu bytes\n", n);
     if (n) memmove(dst, src, n);
     return hipSuccess;
 }
 hipError_t hipMemsetAsync(void* dst, int value, size_t n, hipStream_t) {
+    if (emu::g_trace) fprintf(stderr, "[hip-emu] memsetAsync %zu bytes\n", n);
     if (n) memset(dst, value, n);
     return hipSuccess;
 }

@@ -139,13 +139,13 @@ struct Block {
 extern thread_local Lane* cur;
 void wave_sync(int op, int site);  // the lane has filled cur->x[cur->parity]; returns when its group is released
 int block_sync(int pred);          // returns the OR of the predicates of all threads of the workgroup
-void run_grid(dim3 grid, dim3 block, size_t shmem, void (*thunk)(void*), void* ctx);
+void run_grid(const char* name, dim3 grid, dim3 block, size_t shmem, void (*thunk)(void*), void* ctx);
 
 template <class... P, class... A>
-static inline void launch(void (*kern)(P...), dim3 grid, dim3 block, size_t shmem, A&&... a) {
+static inline void launch(const char* name, void (*kern)(P...), dim3 grid, dim3 block, size_t shmem, A&&... a) {
     std::tuple<std::decay_t<P>...> params(static_cast<std::decay_t<P>>(std::forward<A>(a))...);
     struct Ctx { void (*kern)(P...); std::tuple<std::decay_t<P>...>* params; } ctx{kern, &params};
-    run_grid(grid, block, shmem, [](void* c) { Ctx* x = (Ctx*)c; std::apply(x->kern, *x->params); }, &ctx);
+    run_grid(name, grid, block, shmem, [](void* c) { Ctx* x = (Ctx*)c; std::apply(x->kern, *x->params); }, &ctx);
 }
 // the value lane `src` showed in the operation this lane was released from; ok = false: src was not part of it
 template <class T>
@@ -174,7 +174,7 @@ static inline void show(const T& v) {
 #define blockDim (emu::cur->blk->bdim)
 #define gridDim (emu::cur->blk->gdim)
 #define warpSize 64
-#define hipLaunchKernelGGL(kern, grid, block, shmem, stream, ...) emu::launch((kern), dim3(grid), dim3(block), (size_t)(shmem), ##__VA_ARGS__)
+#define hipLaunchKernelGGL(kern, grid, block, shmem, stream, ...) emu::launch(#kern, (kern), dim3(grid), dim3(block), (size_t)(shmem), ##__VA_ARGS__)
 
 // ---- integer / bit helpers --------------------------------------------------------------------------------------------------------
 static inline int __popc(unsigned x) { return __builtin_popcount(x); }

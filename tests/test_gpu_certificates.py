@@ -2,8 +2,8 @@
 
 By default the level-set splat certifies 4^3 sub-blocks "inside the fluid" with a cheap LOWER bound of the level set (near particles only; since
 round 6 the bound C4 u^4 below the cubic spline, evaluated for 32 entries x 32 points per v_mfma_f32_32x32x8_f16 on f16 operand records with a
-slack that covers their rounding: ss_kernels.hip, splat_cert_record / splat_cert_tile; over-dense blocks: the polynomial bound of
-splat_bound_walk on f16 list records) and never evaluates them unless marching cubes reads their values.  The mesh tests show that the output does not change; this file checks the property
+slack that covers their rounding: ss_kernels.hip, splat_cert_record / splat_cert_mfma in k_splat_fused; over-dense blocks: the same tiles on
+records relative to the sub-block's centre, k_splat_certify_big) and never evaluates them unless marching cubes reads their values.  The mesh tests show that the output does not change; this file checks the property
 itself: for every sub-block that stayed certified, all 64 values of the COMPLETELY evaluated level set (SS_OPTION_FULL_LEVELSET on a second
 context, bit-identical to the oracle: test_levelset_bit_identical_per_subdomain) lie above the iso-surface threshold -- on bulk fluid, on a scene
 far from the origin (coordinate slack), on a coarse and on a fine grid (f16 ranges), and in both arithmetics.
@@ -58,3 +58,21 @@ def test_certified_subblocks_lie_inside_the_fluid(two_pass_ctx, full_levelset_ct
                     checked += int(ok.sum())
     assert checked >= 60 * n_cert
     assert worst > float(thr), "a certified sub-block holds a level-set value of %.7g <= threshold %.7g" % (worst, float(thr))
+
+
+def test_certificates_of_an_overwritten_call_are_refused(two_pass_ctx):
+    """The masks live in the context's scratch: once another reconstruction has run on the context, asking an earlier result for them is an
+    error, not garbage."""
+    import splashsurf_amd as S
+    from splashsurf_amd import workloads as W
+    pts = W.tank_particles(0.1)
+    kw = dict(particle_radius=0.005, smoothing_length=2.0, cube_size=0.5, iso_surface_threshold=0.6, subdomain_grid=True, subdomain_grid_auto_disable=False, simd=False)
+    first = S.reconstruct_surface(pts, context=two_pass_ctx, **kw)
+    masks, _ = first.certified_subblocks()
+    assert masks.any()
+    second = S.reconstruct_surface(pts[: pts.shape[0] // 2], context=two_pass_ctx, **kw)
+    from splashsurf_amd.api import SplashsurfError
+    with pytest.raises(SplashsurfError):
+        first.certified_subblocks()
+    masks2, _ = second.certified_subblocks()
+    assert masks2.size == second.stats["n_active_blocks"]

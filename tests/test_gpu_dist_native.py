@@ -202,3 +202,38 @@ def test_native_missing_peer_times_out_loudly(monkeypatch):
         cm.destroy()
     for cx in ctxs:
         cx.close()
+
+
+def test_native_ranks_that_disagree_on_the_feedback_setting_fail_loudly(monkeypatch):
+    """ss_comm_set_balance_feedback on ONE of two ranks only: the ranks would cut different bricks from the second step on.  The digest of the
+    feedback state that travels with every step's first all-gather makes both fail with an error instead."""
+    from splashsurf_amd import distributed as D
+    from splashsurf_amd.api import Context, SplashsurfError
+    monkeypatch.setenv("SPLASH_COMM_TIMEOUT_S", "20")
+    pts, r, l, c, n_cubes = _case("dam_break_n16")
+    pts = pts.astype(np.float32)
+    prm = _params(r, l, c, n_cubes, np.float32, 0)
+    ctxs = [Context(0), Context(0)]
+    comms = D.NativeComm.local_group(ctxs)
+    comms[1].set_balance_feedback(True)
+    cut = [0, pts.shape[0] // 2, pts.shape[0]]
+    raised = [None, None]
+
+    def worker(q):
+        sh = D.NativeSharded(comms[q], prm)
+        try:
+            sh.step(np.ascontiguousarray(pts[cut[q]:cut[q + 1]]))
+        except SplashsurfError as e:
+            raised[q] = str(e)
+        sh.result._free()
+
+    th = [threading.Thread(target=worker, args=(q,)) for q in range(2)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    for c_ in comms:
+        c_.destroy()
+    for c_ in ctxs:
+        c_.close()
+    assert raised[0] and raised[1] and "feedback" in raised[0] and "feedback" in raised[1], raised
