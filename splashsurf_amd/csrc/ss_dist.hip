@@ -68,10 +68,19 @@ RcclApi* rccl_api() {
     static RcclApi api;
     static std::once_flag once;
     std::call_once(once, [] {
+        // SPLASH_RCCL_LIB: the RCCL build to bind, by path (a site's own build; the stand-in of the no-GPU tests, tests/emu/fake_rccl.cpp).  Otherwise
         // prefer a copy that is already in the process (PyTorch-ROCm bundles its own librccl.so): one RCCL per process
         const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
-        for (const char* n : names)
-            if ((api.handle = dlopen(n, RTLD_NOW | RTLD_NOLOAD | RTLD_GLOBAL))) break;
+        if (const char* named = getenv("SPLASH_RCCL_LIB")) {
+            if (!(api.handle = dlopen(named, RTLD_NOW | RTLD_LOCAL))) {
+                const char* why = dlerror();
+                api.error = std::string("SPLASH_RCCL_LIB: ") + (why ? why : "dlopen failed");
+                return;
+            }
+        }
+        if (!api.handle)
+            for (const char* n : names)
+                if ((api.handle = dlopen(n, RTLD_NOW | RTLD_NOLOAD | RTLD_GLOBAL))) break;
         if (!api.handle)
             for (const char* n : names)
                 if ((api.handle = dlopen(n, RTLD_NOW | RTLD_GLOBAL))) break;

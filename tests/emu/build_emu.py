@@ -65,8 +65,24 @@ def build(force=False, defines=(), out=OUT):
     return out
 
 
+def build_fake_rccl(force=False):
+    """tests/emu/_build/libfake_rccl.so: the stand-in RCCL of the multi-process tests (fake_rccl.cpp), bound through SPLASH_RCCL_LIB."""
+    src = os.path.join(HERE, "fake_rccl.cpp")
+    out = os.path.join(HERE, "_build", "libfake_rccl.so")
+    os.makedirs(os.path.dirname(out), exist_ok=True)
+    if force or stale(out, [src]):
+        # (-Bsymbolic: its own nccl* calls stay inside it even when a real librccl is loaded in the process)
+        cmd = [cxx(), "-std=c++17", "-O1", "-g1", "-fPIC", "-shared", "-Wl,-Bsymbolic", "-Wall", src, "-o", out]
+        print("[emu-build]", " ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+    return out
+
+
 if __name__ == "__main__":
     args = sys.argv[1:]
+    if "--fake-rccl" in args:
+        print(build_fake_rccl(force="--force" in args))
+        sys.exit(0)
     out = OUT
     if "--out" in args:
         i = args.index("--out")

@@ -58,7 +58,13 @@ def main():
     import torch
     import torch.distributed as dist
     rank, world, local = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"]), int(os.environ.get("LOCAL_RANK", "0"))
-    torch.cuda.set_device(local)
+    # no-GPU container (tests/test_emu_kernels.py): the emulated library (SPLASHSURF_HIP_LIB) with the stand-in RCCL (SPLASH_RCCL_LIB), every
+    # rank on the emulator's one "device", host arrays as input -- the RCCL branch of ss_dist.hip between real processes
+    emulated = os.environ.get("SPLASH_EMULATED_RANKS") == "1"
+    if emulated:
+        local = 0
+    else:
+        torch.cuda.set_device(local)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from splashsurf_amd import distributed as D
     from splashsurf_amd.api import Context
@@ -71,12 +77,15 @@ def main():
     assert comm.kind == "rccl" and comm.world == world
     cut = [int(round(pts.shape[0] * k / world)) for k in range(world + 1)]
     sh = D.NativeSharded(comm, prm)
-    mine = torch.from_numpy(np.ascontiguousarray(pts[cut[rank]:cut[rank + 1]])).to("cuda:%d" % local)  # HBM-resident share, as in bench.py --gpus N
+    mine = np.ascontiguousarray(pts[cut[rank]:cut[rank + 1]])
+    if not emulated:
+        mine = torch.from_numpy(mine).to("cuda:%d" % local)  # HBM-resident share, as in bench.py --gpus N
     for _ in range(2):  # the second step reuses every buffer and every RCCL connection
         res = sh.step(mine)
         info = sh.assemble()
     out = dict(info=info, partition=sh.partition(), gids=sh.global_ids(), rho=res.particle_densities.copy(), piece=sh.mesh_piece(),
-               local_counts=res.counts(), stats=dict(res.stats), device=local, device_name=torch.cuda.get_device_name(local))
+               local_counts=res.counts(), stats=dict(res.stats), device=rank if emulated else local,
+               device_name="hip-emu" if emulated else torch.cuda.get_device_name(local))
     with open(os.path.join(outdir, "rank%d.pkl" % rank), "wb") as f:
         pickle.dump(out, f, protocol=4)
     dist.barrier()

@@ -101,6 +101,23 @@ def test_the_gpu_parity_tests_pass_on_the_cpu_execution_model_of_the_kernels():
     assert passed >= 140, tail  # 50 parity / golden cases, 52 fuzz cases, the SIMD modes, certificates, in-process ranks, the reference's own test cases
 
 
+def test_the_rccl_branch_between_rank_processes_with_a_stand_in_rccl():
+    """tests/test_gpu_dist_rccl.py for world 2 and 4 on the smallest case: one PROCESS per rank (torch.distributed.run), each with the emulated
+    library, ss_comm_create_rccl bound to tests/emu/fake_rccl.cpp through SPLASH_RCCL_LIB -- the branch of ss_dist.hip a one-GPU box never
+    takes (count matrices, offsets, grouped ncclSend / ncclRecv per peer, the small collectives), checked against the single-context mesh bit for
+    bit.  The stand-in verifies that every receive finds its message with the announced size and type; what real RCCL does on real links stays
+    unmeasured.  (All twelve cases -- three clouds, world 1 / 2 / 4 / 8 -- pass this way; the 1.2 M-particle ones take minutes each.)"""
+    sys.path.insert(0, os.path.join(ROOT, "tests", "emu"))
+    import build_emu
+    lib, fake = build_emu.build(), build_emu.build_fake_rccl()
+    env = dict(os.environ, SPLASHSURF_HIP_LIB=lib, SPLASH_RCCL_LIB=fake, SPLASH_EMULATED_RANKS="1", HIP_EMU_THREADS="2")
+    cmd = [sys.executable, "-m", "pytest", "-m", "gpu", "-q", "-p", "no:cacheprovider", "--timeout", "600", "tests/test_gpu_dist_rccl.py", "-k",
+           "test_rccl_ranks and dam_break and (f64-0-2 or f64-0-4)"]
+    p = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=1200)
+    tail = "\n".join(p.stdout.splitlines()[-40:])
+    assert p.returncode == 0 and re.search(r"\b2 passed", p.stdout), tail
+
+
 def test_the_emulated_library_is_not_what_the_product_loads():
     """api.library_path() names the HIP build unless SPLASHSURF_HIP_LIB says otherwise; nothing under splashsurf_amd/, bench.py or
     __graft_entry__.py mentions the emulator."""

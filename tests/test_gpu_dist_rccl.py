@@ -31,6 +31,8 @@ WORKER = os.path.join(ROOT, "tests", "rccl_rank_worker.py")
 
 
 def _device_count():
+    if os.environ.get("SPLASH_EMULATED_RANKS") == "1":  # tests/test_emu_kernels.py: emulated library + stand-in RCCL, any number of rank processes
+        return 8
     import torch
     return torch.cuda.device_count()
 
