@@ -128,6 +128,9 @@ int block_sync(int pred) {
 }
 
 static bool g_warn_divergent = getenv("HIP_EMU_WARN_DIVERGENT") != nullptr;
+// HIP_EMU_SHUFFLE=seed: workgroups in a scrambled order, the waves of a workgroup and the lanes between two synchronisation points in REVERSE order.  All of
+// these are schedules the device may produce (tiles take their number from a ticket, not from blockIdx): an output that changes with the seed is a race.
+static const unsigned long long g_shuffle = getenv("HIP_EMU_SHUFFLE") ? strtoull(getenv("HIP_EMU_SHUFFLE"), nullptr, 10) + 1ull : 0ull;
 
 static void run_block(Worker* w, uint3 bid, dim3 grid, dim3 block, size_t shmem) {
     const int nt = (int)(block.x * block.y * block.z);
@@ -179,11 +182,13 @@ static void run_block(Worker* w, uint3 bid, dim3 grid, dim3 block, size_t shmem)
     while (live > 0) {
         int at_barrier = 0;
         live = 0;
-        for (int wv = 0; wv < nwaves; ++wv) {
+        for (int wv0 = 0; wv0 < nwaves; ++wv0) {
+            const int wv = g_shuffle ? nwaves - 1 - wv0 : wv0;
             Lane* wl = &w->lanes[wv * 64];
             const int nl = std::min(64, nt - wv * 64);
             while (true) {
-                for (int l = 0; l < nl; ++l) {
+                for (int l0 = 0; l0 < nl; ++l0) {
+                    const int l = g_shuffle ? nl - 1 - l0 : l0;
                     if (wl[l].state != ST_READY) continue;
                     resume_lane(w, &wl[l]);
                 }
@@ -266,8 +271,19 @@ struct Pool {
     static void work(Job* j) {
         if (!tl_worker) tl_worker = new Worker();
         while (true) {
-            const unsigned long long b = j->next.fetch_add(1, std::memory_order_relaxed);
+            unsigned long long b = j->next.fetch_add(1, std::memory_order_relaxed);
             if (b >= j->total) break;
+            if (g_shuffle && j->total > 1) {  // a bijection of [0, total): multiplication by a stride coprime to it, plus an offset
+                static const unsigned long long primes[] = {7919ull, 104729ull, 1299709ull, 15485863ull, 179424673ull};
+                unsigned long long stride = 1;
+                for (unsigned long long pr : primes)
+                    if (j->total % pr != 0) {
+                        stride = pr % j->total;
+                        break;
+                    }
+                if (stride == 0) stride = 1;
+                b = (unsigned long long)(((unsigned __int128)b * stride + g_shuffle * 2654435761ull) % j->total);
+            }
             uint3 bid;
             bid.x = (unsigned)(b % j->grid.x);
             bid.y = (unsigned)((b / j->grid.x) % j->grid.y);
@@ -347,6 +363,14 @@ namespace {
 std::mutex g_mem_mu;
 std::map<uintptr_t, size_t> g_dev_allocs;  // base -> size of what hipMalloc handed out ("device memory" for hipPointerGetAttributes)
 const bool g_poison = getenv("HIP_EMU_NO_POISON") == nullptr;
+// fault injection (tools/emu_fault_injection.py): the n-th hipMalloc / hipHostMalloc from now on fails with hipErrorOutOfMemory (0: none)
+std::atomic<long long> g_fail_malloc_in{0}, g_fail_host_malloc_in{0};
+std::atomic<unsigned long long> g_mallocs{0}, g_host_mallocs{0};
+bool injected(std::atomic<long long>& countdown) {
+    long long v = countdown.load();
+    while (v > 0 && !countdown.compare_exchange_weak(v, v - 1)) {}
+    return v == 1;
+}
 double now_ms() {
     timespec ts;
     clock_gettime(CLOCK_MONOTONIC, &ts);
@@ -357,6 +381,8 @@ double now_ms() {
 extern "C" {
 hipError_t hipMalloc(void** p, size_t bytes) {
     if (!p) return hipErrorInvalidValue;
+    g_mallocs.fetch_add(1);
+    if (injected(g_fail_malloc_in)) return hipErrorOutOfMemory;
     void* q = nullptr;
     const size_t sz = bytes ? bytes : 1;
     if (posix_memalign(&q, 256, sz) != 0) return hipErrorOutOfMemory;
@@ -378,6 +404,8 @@ hipError_t hipFree(void* p) {
     return hipSuccess;
 }
 hipError_t hipHostMalloc(void** p, size_t bytes, unsigned) {
+    g_host_mallocs.fetch_add(1);
+    if (injected(g_fail_host_malloc_in)) return hipErrorOutOfMemory;
     void* q = nullptr;
     if (posix_memalign(&q, 256, bytes ? bytes : 1) != 0) return hipErrorOutOfMemory;
     *p = q;
@@ -471,4 +499,6 @@ hipError_t hipPointerGetAttributes(hipPointerAttribute_t* attr, const void* p) {
 }
 // how many kernel launches the emulator has executed (tests)
 unsigned long long hip_emu_launch_count(void) { return emu::g_launches.load(); }
+unsigned long long hip_emu_malloc_count(int host) { return host ? g_host_mallocs.load() : g_mallocs.load(); }
+void hip_emu_fail_malloc_in(int host, long long n) { (host ? g_fail_host_malloc_in : g_fail_malloc_in).store(n); }
 }

@@ -118,6 +118,21 @@ def test_the_rccl_branch_between_rank_processes_with_a_stand_in_rccl():
     assert p.returncode == 0 and re.search(r"\b2 passed", p.stdout), tail
 
 
+def test_outputs_do_not_depend_on_the_schedule():
+    """Race check: the same five reconstructions (tools/emu_schedule_digest.py: fine and coarse grid, both arithmetics, certification forced, an
+    over-dense cube) under the default schedule and under HIP_EMU_SHUFFLE -- workgroups in a scrambled order, the waves of a workgroup and the
+    lanes between two synchronisation points in reverse order, all schedules the device may produce -- must give one digest."""
+    lib = emulated_library()
+    digests = []
+    for extra in ({}, {"HIP_EMU_SHUFFLE": "1"}, {"HIP_EMU_SHUFFLE": "2", "HIP_EMU_THREADS": "3"}):
+        env = dict(os.environ, SPLASHSURF_HIP_LIB=lib, **extra)
+        p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "emu_schedule_digest.py")], cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                           text=True, timeout=600)
+        assert p.returncode == 0, p.stdout[-2000:]
+        digests.append(p.stdout.split()[-2])
+    assert len(set(digests)) == 1 and len(digests[0]) == 24, digests
+
+
 def test_the_emulated_library_is_not_what_the_product_loads():
     """api.library_path() names the HIP build unless SPLASHSURF_HIP_LIB says otherwise; nothing under splashsurf_amd/, bench.py or
     __graft_entry__.py mentions the emulator."""
