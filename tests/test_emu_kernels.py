@@ -42,6 +42,12 @@ SLOW_EMULATED = [
     "tests/test_gpu_dist_native.py::test_native_full_s40m_tank_four_ranks",
 ]
 SLOW_EMULATED_OPTIONAL = [
+    "tests/test_gpu_prims.py::test_radix_sort_is_a_stable_sort[20000001-24-1]",
+    "tests/test_gpu_prims.py::test_radix_sort_is_a_stable_sort[3000001-25-1]",
+    "tests/test_gpu_prims.py::test_radix_sort_is_a_stable_sort[3000001-32-0]",
+    "tests/test_gpu_prims.py::test_radix_sort_is_a_stable_sort[1000003-24-0]",
+    "tests/test_gpu_prims.py::test_radix_sort_is_a_stable_sort[1000003-23-1]",
+    "tests/test_gpu_prims.py::test_chained_scan_equals_cumsum[20000001]",
     "tests/test_gpu_parity.py::test_gpu_global_strategy_bit_identical_to_oracle_and_reference[global_free_particles_125]",
     "tests/test_gpu_parity.py::test_u64_triangles_cross_pcie_as_u32",
     "tests/test_gpu_simd.py::test_simd_bit_identical_to_uniform_oracle[simd_config2_s1m]",
@@ -71,7 +77,7 @@ SLOW_EMULATED_OPTIONAL = [
     "tests/test_reference_suite.py::test_full_rs[free_particles_01]",
     "tests/test_reference_suite.py::test_subdomains_rs_single_particle[0.025-tris2-verts2-subdomains2]",
 ]
-FILES = ["tests/test_gpu_parity.py", "tests/test_gpu_simd.py", "tests/test_gpu_fuzz.py", "tests/test_gpu_certificates.py", "tests/test_gpu_dist_native.py",
+FILES = ["tests/test_gpu_prims.py", "tests/test_gpu_parity.py", "tests/test_gpu_simd.py", "tests/test_gpu_fuzz.py", "tests/test_gpu_certificates.py", "tests/test_gpu_dist_native.py",
          "tests/test_reference_suite.py", "tests/test_post.py", "tests/test_distributed.py", "tests/test_cli.py"]
 
 
@@ -98,7 +104,7 @@ def test_the_gpu_parity_tests_pass_on_the_cpu_execution_model_of_the_kernels():
     deselect = NEED_A_DEVICE + SLOW_EMULATED + ([] if everything else SLOW_EMULATED_OPTIONAL)
     rc, passed, tail = run_gpu_tests_emulated([], deselect, 7200 if everything else 1500)
     assert rc == 0, tail
-    assert passed >= 140, tail  # 50 parity / golden cases, 52 fuzz cases, the SIMD modes, certificates, in-process ranks, the reference's own test cases
+    assert passed >= 160, tail  # the scan / sort primitives, 50 parity / golden cases, 52 fuzz cases, the SIMD modes, certificates, in-process ranks, the reference's own test cases
 
 
 def test_the_rccl_branch_between_rank_processes_with_a_stand_in_rccl():

@@ -10,6 +10,18 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
+def _dev():
+    """The GPU -- or host memory when the library under test is the CPU execution model of tests/emu (SPLASHSURF_HIP_LIB; its "device" memory is the host's)."""
+    import torch
+    return "cuda" if torch.cuda.is_available() else "cpu"
+
+
+def _sync():
+    import torch
+    if torch.cuda.is_available():
+        _sync()
+
+
 def _lib():
     import splashsurf_amd as S
     L = S.load_library()
@@ -22,11 +34,11 @@ def _lib():
 def test_chained_scan_equals_cumsum(n):
     import torch
     L = _lib()
-    g = torch.Generator(device="cuda").manual_seed(n + 1)
-    x = torch.randint(0, 50, (max(n, 1),), device="cuda", dtype=torch.int32, generator=g)[:n]
-    out = torch.empty(max(n, 1), device="cuda", dtype=torch.int32)
-    tot = torch.zeros(2, device="cuda", dtype=torch.int32)
-    torch.cuda.synchronize()
+    g = torch.Generator(device=_dev()).manual_seed(n + 1)
+    x = torch.randint(0, 50, (max(n, 1),), device=_dev(), dtype=torch.int32, generator=g)[:n]
+    out = torch.empty(max(n, 1), device=_dev(), dtype=torch.int32)
+    tot = torch.zeros(2, device=_dev(), dtype=torch.int32)
+    _sync()
     assert L.ss_debug_exclusive_scan_u32(x.data_ptr(), out.data_ptr(), n, tot.data_ptr(), None) == 0
     ref = torch.cumsum(x.to(torch.int64), 0)
     if n:
@@ -41,25 +53,25 @@ def test_chained_scan_equals_cumsum(n):
 def test_radix_sort_is_a_stable_sort(n, bits, iota):
     import torch
     L = _lib()
-    g = torch.Generator(device="cuda").manual_seed(7 * n + bits)
+    g = torch.Generator(device=_dev()).manual_seed(7 * n + bits)
     hi = (1 << bits) if bits < 31 else (1 << 31) - 1
     m = max(n, 1)
-    k0 = torch.randint(0, hi, (m,), device="cuda", dtype=torch.int64, generator=g)
+    k0 = torch.randint(0, hi, (m,), device=_dev(), dtype=torch.int64, generator=g)
     if bits == 32:
-        k0 = k0 * 2 + torch.randint(0, 2, (m,), device="cuda", dtype=torch.int64, generator=g)
+        k0 = k0 * 2 + torch.randint(0, 2, (m,), device=_dev(), dtype=torch.int64, generator=g)
     if n > 1000:
         k0[: n // 3] = k0[0]  # a long run of equal keys: stability
     keys = [k0.to(torch.uint32) if hasattr(torch, "uint32") else None, None]
     ka = (k0 & 0xFFFFFFFF).to(torch.int64)
-    buf_k0 = torch.empty(m, device="cuda", dtype=torch.int32)
+    buf_k0 = torch.empty(m, device=_dev(), dtype=torch.int32)
     buf_k0.copy_(torch.where(ka >= 2 ** 31, ka - 2 ** 32, ka).to(torch.int32))
     buf_k1 = torch.empty_like(buf_k0)
-    v0 = torch.randint(0, 2 ** 31 - 1, (m,), device="cuda", dtype=torch.int32, generator=g)
-    vals = torch.arange(m, device="cuda", dtype=torch.int32) if iota else v0.clone()
+    v0 = torch.randint(0, 2 ** 31 - 1, (m,), device=_dev(), dtype=torch.int32, generator=g)
+    vals = torch.arange(m, device=_dev(), dtype=torch.int32) if iota else v0.clone()
     buf_v0 = torch.full_like(v0, -1) if iota else v0.clone()
     buf_v1 = torch.empty_like(v0)
     res = C.c_int(-1)
-    torch.cuda.synchronize()
+    _sync()
     assert L.ss_debug_radix_sort_pairs(buf_k0.data_ptr(), buf_k1.data_ptr(), buf_v0.data_ptr(), buf_v1.data_ptr(), n, bits, iota, C.byref(res), None) == 0
     if n == 0:
         return
