@@ -17,6 +17,19 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: test needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def device_name():
+    """"cuda:0" on a GPU box; "cpu" when the library under test is the CPU execution model of tests/emu (SPLASHSURF_HIP_LIB), whose "device" memory is the host's:
+    tests that hand the library torch tensors then hand it host tensors -- the arithmetic under test is the same, the HBM-resident input path is not exercised."""
+    import torch
+    return "cuda:0" if torch.cuda.is_available() else "cpu"
+
+
+def device_sync():
+    import torch
+    if torch.cuda.is_available():
+        torch.cuda.synchronize()
+
+
 def load_points(name):
     return np.load(os.path.join(DATA, name))
 

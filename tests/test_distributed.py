@@ -225,8 +225,11 @@ def _gpu_worker(rank, world, port, case, out_path):
         from splashsurf_amd import distributed as D
         from splashsurf_amd.api import Context, Parameters
         pts, r, l, c, n_cubes = _case(case)
-        torch.cuda.set_device(0)
-        dev = torch.device("cuda", 0)
+        if torch.cuda.is_available():
+            torch.cuda.set_device(0)
+            dev = torch.device("cuda", 0)
+        else:  # the library under test is the CPU execution model of tests/emu (SPLASHSURF_HIP_LIB): its device memory is the host's
+            dev = torch.device("cpu")
         prm = Parameters(particle_radius=r, compact_support_radius=np.float32(2.0 * l * r), cube_size=np.float32(c * r),
                          subdomain_num_cubes_per_dim=n_cubes, auto_disable=False, enable_simd=False)
         cut = [0] + [int(round(pts.shape[0] * (k + 1) / world)) for k in range(world)]

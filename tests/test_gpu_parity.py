@@ -13,7 +13,7 @@ import numpy as np
 import pytest
 
 import mesh_compare as MC
-from conftest import golden_input, golden_params, load_golden
+from conftest import golden_input, golden_params, load_golden, device_name, device_sync
 
 pytestmark = pytest.mark.gpu
 
@@ -160,8 +160,8 @@ def test_device_pointer_input_and_determinism(gpu_ctx):
     import splashsurf_amd as S
     pts = golden_input(load_golden("cube_2366"))
     a = S.reconstruct_surface(pts, particle_radius=0.025, smoothing_length=2.0, cube_size=0.5, subdomain_grid_auto_disable=False, context=gpu_ctx)
-    t = torch.from_numpy(pts).to("cuda:0")
-    torch.cuda.synchronize()
+    t = torch.from_numpy(pts).to(device_name())
+    device_sync()
     b = S.reconstruct_surface(t, particle_radius=0.025, smoothing_length=2.0, cube_size=0.5, subdomain_grid_auto_disable=False, context=gpu_ctx)
     c = S.reconstruct_surface(pts, particle_radius=0.025, smoothing_length=2.0, cube_size=0.5, subdomain_grid_auto_disable=False, context=gpu_ctx)
     for x in (b, c):
@@ -267,13 +267,13 @@ def test_sharded_engine_reproduces_full_reconstruction(oracle, case):
     prm = Parameters(particle_radius=r, compact_support_radius=dt(2.0 * l * r), cube_size=dt(c * r),
                      subdomain_num_cubes_per_dim=n_cubes, auto_disable=False, enable_simd=False)
     engines = [D.HipEngine(Context(0), prm, dtype=dt) for _ in range(k)]
-    P_all = torch.from_numpy(pts).to("cuda:0")
+    P_all = torch.from_numpy(pts).to(device_name())
     dmin, dmax = pts.min(axis=0), pts.max(axis=0)
     gmin, sub_size, ns, margin, _ = engines[0].grid_for_domain(dmin, dmax)
     axis = int(np.argmax(ns))
     slabs = D.partition_slabs(P_all[:, axis], float(gmin[axis]), sub_size, ns[axis], k)
     assert sum(1 for lo, hi in slabs if hi > lo) >= 2
-    rho_global = torch.zeros(pts.shape[0], dtype=torch.float32 if dt == np.float32 else torch.float64, device="cuda:0")
+    rho_global = torch.zeros(pts.shape[0], dtype=torch.float32 if dt == np.float32 else torch.float64, device=device_name())
     sel = []
     for q, (lo, hi) in enumerate(slabs):
         sub_lo, sub_hi = [0, 0, 0], list(ns)
@@ -281,7 +281,7 @@ def test_sharded_engine_reproduces_full_reconstruction(oracle, case):
         shard = D.ShardDesc(dmin, dmax, sub_lo, sub_hi)
         pad = margin * 1.001 + 1e-6
         c_lo, c_hi = float(gmin[axis]) + lo * sub_size - pad, float(gmin[axis]) + hi * sub_size + pad
-        ids = torch.nonzero((P_all[:, axis] >= c_lo) & (P_all[:, axis] <= c_hi), as_tuple=False).squeeze(1) if hi > lo else torch.zeros(0, dtype=torch.int64, device="cuda:0")
+        ids = torch.nonzero((P_all[:, axis] >= c_lo) & (P_all[:, axis] <= c_hi), as_tuple=False).squeeze(1) if hi > lo else torch.zeros(0, dtype=torch.int64, device=device_name())
         L = P_all.index_select(0, ids).contiguous()
         rho_local = engines[q].begin(L, shard)
         rho_global.index_add_(0, ids, rho_local)  # stands in for the all-reduce: one non-zero contribution per particle
@@ -316,17 +316,17 @@ def _pseudo_rank_bricks(pts, prm, k, dt=np.float32):
     from splashsurf_amd import distributed as D
     from splashsurf_amd.api import Context
     engines = [D.HipEngine(Context(0), prm, dtype=dt) for _ in range(k)]
-    P_all = torch.from_numpy(pts).to("cuda:0")
+    P_all = torch.from_numpy(pts).to(device_name())
     dmin, dmax = pts.min(axis=0), pts.max(axis=0)
     gmin, sub_size, ns, margin, _ = engines[0].grid_for_domain(dmin, dmax)
     sub = [torch.floor((P_all[:, d] - float(gmin[d])) / sub_size).to(torch.int64).clamp_(0, ns[d] - 1) for d in range(3)]
     hist3 = torch.bincount((sub[0] * ns[1] + sub[1]) * ns[2] + sub[2], minlength=ns[0] * ns[1] * ns[2]).cpu().numpy().reshape(ns)
     bricks = D.bricks_from_histogram(hist3, k)
-    rho_global = torch.zeros(pts.shape[0], dtype=torch.float32 if dt == np.float32 else torch.float64, device="cuda:0")
+    rho_global = torch.zeros(pts.shape[0], dtype=torch.float32 if dt == np.float32 else torch.float64, device=device_name())
     sel = []
     pad = margin * 1.001 + 1e-6
     for q, (lo, hi) in enumerate(bricks):
-        m = torch.ones(P_all.shape[0], dtype=torch.bool, device="cuda:0")
+        m = torch.ones(P_all.shape[0], dtype=torch.bool, device=device_name())
         for d in range(3):
             m &= (P_all[:, d] >= float(gmin[d]) + lo[d] * sub_size - pad) & (P_all[:, d] <= float(gmin[d]) + hi[d] * sub_size + pad)
         if any(hi[d] <= lo[d] for d in range(3)):
@@ -465,8 +465,8 @@ def test_splat_on_reference_grid_loop_fixture(oracle):
     ctx.set_full_levelset(True)
     eng = D.HipEngine(ctx, Parameters(particle_radius=r, compact_support_radius=np.float32(h), cube_size=np.float32(cs), auto_disable=False, enable_simd=False))
     shard = D.ShardDesc(dmin, dmax, sub, [s + 1 for s in sub])
-    eng.begin(torch.from_numpy(pts).to("cuda:0"), shard)
-    res = eng.finish(torch.from_numpy(rho).to("cuda:0"))
+    eng.begin(torch.from_numpy(pts).to(device_name()), shard)
+    res = eng.finish(torch.from_numpy(rho).to(device_name()))
     got = res.levelset_box([s * 64 for s in sub], [65, 65, 65])
     assert int((ref != 0).sum()) > 100000
     nbad = int((got.view(np.uint32) != ref.view(np.uint32)).sum())
@@ -634,7 +634,7 @@ def test_gpu_dense_marching_cubes(gpu_ctx, oracle, where):
     for dt, tag in ((np.float32, "f32"), (np.float64, "f64")):
         U = np.uint32 if dt == np.float32 else np.uint64
         vals = np.ascontiguousarray(g["values"].astype(dt))
-        arg = torch.from_numpy(vals).cuda() if where == "hbm" else vals
+        arg = torch.from_numpy(vals).to(device_name()) if where == "hbm" else vals
         mesh, grid = S.marching_cubes(arg, iso_surface_threshold=float(g["threshold"]), cube_size=float(g["cube_size"]), translation=list(g["translation"]),
                                       return_grid=True, context=gpu_ctx)
         orc = oracle.marching_cubes(vals, float(g["threshold"]), float(g["cube_size"]), g["translation"])
@@ -699,7 +699,7 @@ def test_host_waits_are_counted(gpu_ctx):
     import torch
     g = load_golden("config5_hilbert")
     pts, prm = golden_input(g), golden_params(g)
-    d = torch.from_numpy(np.ascontiguousarray(pts)).to("cuda:0")
+    d = torch.from_numpy(np.ascontiguousarray(pts)).to(device_name())
     run_gpu(gpu_ctx, d, prm)  # (sizes the lists, verifies the division for this h)
     res = run_gpu(gpu_ctx, d, prm)
     assert 7 <= res.stats["n_host_waits"] <= 8, res.stats["n_host_waits"]

@@ -21,7 +21,7 @@ import numpy as np
 import pytest
 
 import mesh_compare as MC
-from conftest import golden_input, golden_params, load_golden
+from conftest import golden_input, golden_params, load_golden, device_name, device_sync
 from test_gpu_parity import assert_gpu_equals_oracle
 
 pytestmark = pytest.mark.gpu
@@ -155,9 +155,9 @@ def test_simd_on_reference_grid_loop_fixture(oracle):
         ctx.set_full_levelset(True)
         eng = D.HipEngine(ctx, Parameters(particle_radius=r, compact_support_radius=np.float32(h), cube_size=np.float32(cs), auto_disable=False, enable_simd=simd))
         shard = D.ShardDesc(dmin, dmax, sub, [s + 1 for s in sub])
-        t = torch.from_numpy(pts).to("cuda:0")
+        t = torch.from_numpy(pts).to(device_name())
         eng.begin(t, shard)
-        res = eng.finish(torch.from_numpy(rho).to("cuda:0"))
+        res = eng.finish(torch.from_numpy(rho).to(device_name()))
         out[simd] = res.levelset_box([s * 64 for s in sub], [65] * 3).copy()
         eng.result._free()
         eng.ctx.close()

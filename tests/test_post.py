@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 
 import mesh_compare as MC
-from conftest import golden_input, load_golden
+from conftest import golden_input, load_golden, device_name, device_sync
 
 POST = ["post_cube_2366", "post_f64_cube_2366"]
 
@@ -87,7 +87,7 @@ def _to(x, device):
     import torch
     if device == "hbm":
         t = torch.from_numpy(np.ascontiguousarray(x))
-        return t.cuda()
+        return t.to(device_name())
     return np.ascontiguousarray(x)
 
 
