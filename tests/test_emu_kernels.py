@@ -22,13 +22,6 @@ NEED_A_DEVICE = [
     "tests/test_cli.py::test_cli_end_to_end_matches_the_library_call",
     "tests/test_gpu_parity.py::test_cpp_host_over_c_abi",
     "tests/test_post.py::test_gpu_pipeline_matches_oracle_and_reference",
-]",
-    "tests/test_gpu_parity.py::test_host_waits_are_counted",
-    "tests/test_gpu_parity.py::test_hbm_bandwidth_probe_reports_plausible_rates",
-    "tests/test_gpu_simd.py::test_simd_on_reference_grid_loop_fixture",
-    "tests/test_post.py::test_gpu_post_stages_bit_identical_to_oracle[post_cube_2366-hbm]",
-    "tests/test_post.py::test_gpu_post_stages_bit_identical_to_oracle[post_f64_cube_2366-hbm]",
-    "tests/test_post.py::test_gpu_pipeline_matches_oracle_and_reference",
 ]
 # ... and the ones that take more than ~4 s emulated (8 host threads); SPLASHSURF_EMU_ALL=1 runs them too (about 20 minutes, 1 M particles
 # included; the 10 M / 40 M full-size tests stay out)
