@@ -704,6 +704,23 @@ class NativeComm:
             self._h = None
 
 
+def brick_owner_of(points, subdomain_grid, bricks):
+    """Rank whose brick contains each particle's subdomain -- the owner rule of ss_dist.hip's histogram (floor of the coordinate in units of the subdomain
+    edge, clamped into the grid).  Host-side helper for time series that keep their particles resident where they are owned: a rank that hands
+    `ss_dist_reconstruct_*` the particles of its OWN brick exchanges halos only (the partition of the previous frame is `NativeSharded.partition()`,
+    the subdomain grid `result.subdomain_grid`).  A particle this rule puts on the "wrong" side of a brick face because of rounding costs bytes, never
+    correctness: the library decides ownership itself."""
+    p = np.asarray(points)
+    g = np.asarray(subdomain_grid.aabb.min, dtype=p.dtype)
+    s = np.floor((p - g) / p.dtype.type(subdomain_grid.cell_size)).astype(np.int64)
+    s = np.clip(s, 0, np.asarray(subdomain_grid.ncells_per_dim, dtype=np.int64) - 1)
+    owner = np.full(p.shape[0], -1, dtype=np.int64)
+    for q, (lo, hi) in enumerate(bricks):
+        m = np.all(s >= np.asarray(lo), axis=1) & np.all(s < np.asarray(hi), axis=1)
+        owner[m] = q
+    return owner
+
+
 class NativeSharded:
     """Per-rank driver of ss_dist_reconstruct_* / ss_dist_assemble.  `particles`: this rank's share, (n,3) numpy array or
     torch tensor (host or this rank's GPU) of float32 / float64."""
