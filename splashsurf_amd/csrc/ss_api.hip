@@ -476,15 +476,18 @@ ss_status stage_particles(ss_context* ctx, const R* xyz, uint64_t n_in, const ty
 template <class R>
 ss_status compute_particle_aabb(ss_context* ctx, const R* d_xyz, uint32_t n, R pmin[3], R pmax[3]) {
     hipStream_t st = ctx->stream;
-    SS_HIP(ctx, ctx->aabb_partial.reserve(1024 * 6 * sizeof(R)));
+    SS_HIP(ctx, ctx->aabb_partial.reserve(SS_AABB_PARTIAL_WORDS * sizeof(R)));
     ss_status s = ensure_mail(ctx);
     if (s != SS_OK) return s;
     // the six values land in pinned host memory (mail slots 12..15), announced through slot 11
     const SSMailSlot m = mail_slot(ctx, 11);
     ss_launch_aabb(d_xyz, n, ctx->aabb_partial.as<R>(), reinterpret_cast<R*>(ctx->mail_dev + 2 * 12), m, st);
-    unsigned long long unused = 0;
-    s = mail_wait(ctx, m, &unused);
+    unsigned long long not_finite = 0;
+    s = mail_wait(ctx, m, &not_finite);
     if (s != SS_OK) return s;
+    // (the reference's AABB skips a NaN like ours and then files the particle under cell 0 -- `NaN as i64` -- with undefined consequences; here a
+    // non-finite coordinate has no cell at all, so the input is refused; with an explicit particle AABB such particles are filtered out like any other outside it)
+    if (not_finite) return fail(ctx, SS_ERR_INVALID_ARGUMENT, "particle coordinates must be finite (the input holds a NaN or an infinity)");
     const volatile R* h6 = reinterpret_cast<const volatile R*>(ctx->mail_host + 2 * 12);
     for (int d = 0; d < 3; ++d) {
         pmin[d] = h6[d];

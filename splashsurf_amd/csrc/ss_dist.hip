@@ -929,7 +929,7 @@ ss_status dist_reconstruct(ss_comm* c, const R* xyz_in, uint64_t n_local, const 
         SS_HIP(ctx, hipMemcpyAsync(c->xyz_in.p, xyz_in, n_local * 3 * sizeof(R), hipMemcpyHostToDevice, st));
         d_xyz = c->xyz_in.as<R>();
     }
-    struct Head { uint64_t n; double lo[3], hi[3]; uint64_t fb; } mine_head, zero_head;
+    struct Head { uint64_t n; double lo[3], hi[3]; uint64_t fb, not_finite; } mine_head, zero_head;
     memset(&zero_head, 0, sizeof(zero_head));
     mine_head = zero_head;
     mine_head.n = n_local;
@@ -950,11 +950,13 @@ ss_status dist_reconstruct(ss_comm* c, const R* xyz_in, uint64_t n_local, const 
     TurnGuard turn(c, "aabb");
     if (n_local) {
         // the six values land in the communicator's mapped host words, announced through a mail slot (no copy, no stream synchronisation)
-        SS_HIP(ctx, ctx->aabb_partial.reserve(1024 * 6 * sizeof(R)));
+        SS_HIP(ctx, ctx->aabb_partial.reserve(SS_AABB_PARTIAL_WORDS * sizeof(R)));
         const SSMailSlot m = comm_slot(c, 1);
         ss_launch_aabb<R>(d_xyz, (uint32_t)n_local, ctx->aabb_partial.as<R>(), reinterpret_cast<R*>(comm_words_dev(c) + 80), m, st);
-        s = comm_mail_wait(c, m, nullptr, "the bounding box of the local particles");
+        unsigned long long not_finite = 0;
+        s = comm_mail_wait(c, m, &not_finite, "the bounding box of the local particles");
         if (s != SS_OK) return s;
+        mine_head.not_finite = not_finite;  // (travels with the head: every rank must refuse the step together)
         const volatile R* h6 = reinterpret_cast<const volatile R*>(comm_words_host(c) + 80);
         for (int d = 0; d < 3; ++d) {
             mine_head.lo[d] = (double)h6[d];
@@ -970,6 +972,9 @@ ss_status dist_reconstruct(ss_comm* c, const R* xyz_in, uint64_t n_local, const 
     R dmin[3] = {0, 0, 0}, dmax[3] = {0, 0, 0};
     bool any = false;
     double pref[3] = {0.0, 0.0, 0.0};
+    for (int q = 0; q < world; ++q)
+        if (heads[q].not_finite)
+            return fail(ctx, SS_ERR_INVALID_ARGUMENT, "particle coordinates must be finite (a rank's input holds a NaN or an infinity)", q);
     for (int q = 0; q < world; ++q)
         if (heads[q].fb != mine_head.fb)
             return fail(ctx, SS_ERR_INVALID_ARGUMENT, "the ranks disagree on the partition-feedback state (ss_comm_set_balance_feedback must be called on every rank, at the same step)", q);

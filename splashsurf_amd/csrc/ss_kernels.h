@@ -6,6 +6,9 @@
 
 template <class R>
 void ss_launch_aabb(const R* d_xyz, uint32_t n, R* d_partial, R* d_out6, SSMailSlot mail, hipStream_t st);
+// d_partial holds SS_AABB_PARTIAL_WORDS values of R (<= 1024 blocks, SS_AABB_PARTIAL_STRIDE each); the mail's VALUE is 1 if a coordinate is not finite
+#define SS_AABB_PARTIAL_STRIDE 7
+#define SS_AABB_PARTIAL_WORDS (1024 * SS_AABB_PARTIAL_STRIDE)
 template <class R>
 void ss_launch_inside_flags(const R* d_xyz, uint32_t n, const R amin[3], const R amax[3], uint8_t* f8, uint32_t* f32, hipStream_t st);
 template <class R>

@@ -70,23 +70,27 @@ constexpr unsigned long long ss_mc_edge_codes() {
 // =====================================================================================================
 // K0: bounding box
 // =====================================================================================================
+// (partial: SS_AABB_PARTIAL_STRIDE values per block -- min[3], max[3], and 1 if the block saw a coordinate that is not finite: ss_min / ss_max skip a NaN like
+// the reference's f32::min / max do (aabb.rs:28-52), so the box alone would not tell, and a NaN coordinate has no cell -- the host refuses such input)
 template <class R>
 __global__ __launch_bounds__(256) void k_aabb_partial(const R* __restrict__ xyz, uint32_t n, R* __restrict__ partial) {
     __shared__ R s_min[3][256];
     __shared__ R s_max[3][256];
+    bool bad = false;
     R mn[3] = {std::numeric_limits<R>::infinity(), std::numeric_limits<R>::infinity(), std::numeric_limits<R>::infinity()}, mx[3] = {-std::numeric_limits<R>::infinity(), -std::numeric_limits<R>::infinity(), -std::numeric_limits<R>::infinity()};
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         for (int d = 0; d < 3; ++d) {
             R v = xyz[3 * (size_t)i + d];
             mn[d] = ss_min(mn[d], v);
             mx[d] = ss_max(mx[d], v);
+            bad = bad || !(v - v == R(0.0));  // NaN or infinity
         }
     }
     for (int d = 0; d < 3; ++d) {
         s_min[d][threadIdx.x] = mn[d];
         s_max[d][threadIdx.x] = mx[d];
     }
-    __syncthreads();
+    const int any_bad = __syncthreads_or(bad ? 1 : 0);
     for (int s = 128; s > 0; s >>= 1) {
         if ((int)threadIdx.x < s)
             for (int d = 0; d < 3; ++d) {
@@ -95,11 +99,13 @@ __global__ __launch_bounds__(256) void k_aabb_partial(const R* __restrict__ xyz,
             }
         __syncthreads();
     }
-    if (threadIdx.x == 0)
+    if (threadIdx.x == 0) {
         for (int d = 0; d < 3; ++d) {
-            partial[blockIdx.x * 6 + d] = s_min[d][0];
-            partial[blockIdx.x * 6 + 3 + d] = s_max[d][0];
+            partial[blockIdx.x * SS_AABB_PARTIAL_STRIDE + d] = s_min[d][0];
+            partial[blockIdx.x * SS_AABB_PARTIAL_STRIDE + 3 + d] = s_max[d][0];
         }
+        partial[blockIdx.x * SS_AABB_PARTIAL_STRIDE + 6] = any_bad ? R(1.0) : R(0.0);
+    }
 }
 
 template <class R>
@@ -107,16 +113,19 @@ __global__ __launch_bounds__(256) void k_aabb_final(const R* __restrict__ partia
     __shared__ R s_min[3][256];
     __shared__ R s_max[3][256];
     R mn[3] = {std::numeric_limits<R>::infinity(), std::numeric_limits<R>::infinity(), std::numeric_limits<R>::infinity()}, mx[3] = {-std::numeric_limits<R>::infinity(), -std::numeric_limits<R>::infinity(), -std::numeric_limits<R>::infinity()};
-    for (uint32_t i = threadIdx.x; i < nblocks; i += blockDim.x)
+    bool bad = false;
+    for (uint32_t i = threadIdx.x; i < nblocks; i += blockDim.x) {
         for (int d = 0; d < 3; ++d) {
-            mn[d] = ss_min(mn[d], partial[i * 6 + d]);
-            mx[d] = ss_max(mx[d], partial[i * 6 + 3 + d]);
+            mn[d] = ss_min(mn[d], partial[i * SS_AABB_PARTIAL_STRIDE + d]);
+            mx[d] = ss_max(mx[d], partial[i * SS_AABB_PARTIAL_STRIDE + 3 + d]);
         }
+        bad = bad || partial[i * SS_AABB_PARTIAL_STRIDE + 6] != R(0.0);
+    }
     for (int d = 0; d < 3; ++d) {
         s_min[d][threadIdx.x] = mn[d];
         s_max[d][threadIdx.x] = mx[d];
     }
-    __syncthreads();
+    const int any_bad = __syncthreads_or(bad ? 1 : 0);
     for (int s = 128; s > 0; s >>= 1) {
         if ((int)threadIdx.x < s)
             for (int d = 0; d < 3; ++d) {
@@ -130,7 +139,7 @@ __global__ __launch_bounds__(256) void k_aabb_final(const R* __restrict__ partia
             out6[d] = s_min[d][0];
             out6[3 + d] = s_max[d][0];
         }
-        ss_mail_post(mail, 0ull);  // (out6 may be pinned host memory: the release of the post orders the six stores before it)
+        ss_mail_post(mail, any_bad ? 1ull : 0ull);  // value: some coordinate is NaN / infinite.  (out6 may be pinned host memory: the release of the post orders the six stores before it)
     }
 }
 

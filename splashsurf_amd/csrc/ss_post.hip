@@ -431,7 +431,7 @@ ss_status build_sph_index(ss_context* ctx, const R* d_xyz, uint64_t n, R h, SphI
     if (n >= (1ull << 31)) return fail(ctx, SS_ERR_UNSUPPORTED, "too many particles");
     R mn[3] = {0, 0, 0}, mx[3] = {0, 0, 0};
     if (n > 0) {
-        SS_HIP(ctx, ctx->aabb_partial.reserve(1024 * 6 * sizeof(R)));
+        SS_HIP(ctx, ctx->aabb_partial.reserve(SS_AABB_PARTIAL_WORDS * sizeof(R)));
         SS_HIP(ctx, ctx->aabb_out.reserve(6 * sizeof(R)));
         ss_launch_aabb<R>(d_xyz, (uint32_t)n, ctx->aabb_partial.as<R>(), ctx->aabb_out.as<R>(), SSMailSlot{}, ctx->stream);
         R h6[6];

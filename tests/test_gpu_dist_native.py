@@ -301,3 +301,38 @@ def test_native_brick_resident_time_series_ships_halos_only(gpu_ctx):
     assert before > 0 and after * 5 <= before * 4, (before, after)
     # (the bisection breaks ties by how far the ranks' inputs extend along each axis, so the partition of the re-dealt frames may differ from the one the
     # deal was made for: some particles then still travel -- bytes, never correctness)
+
+
+def test_native_non_finite_input_on_one_rank_fails_on_every_rank(monkeypatch):
+    """One rank's share holds a NaN: the flag travels with the step's first all-gather and EVERY rank refuses the step (nobody waits for a peer that gave up)."""
+    from splashsurf_amd import distributed as D
+    from splashsurf_amd.api import Context, SplashsurfError
+    monkeypatch.setenv("SPLASH_COMM_TIMEOUT_S", "20")
+    pts, r, l, c, n_cubes = _case("dam_break_n16")
+    pts = pts.astype(np.float32)
+    prm = _params(r, l, c, n_cubes, np.float32, 0)
+    ctxs = [Context(0), Context(0)]
+    comms = D.NativeComm.local_group(ctxs)
+    cut = [0, pts.shape[0] // 2, pts.shape[0]]
+    shares = [np.ascontiguousarray(pts[cut[q]:cut[q + 1]]) for q in range(2)]
+    shares[1][5, 2] = np.nan
+    raised = [None, None]
+
+    def worker(q):
+        sh = D.NativeSharded(comms[q], prm)
+        try:
+            sh.step(shares[q])
+        except SplashsurfError as e:
+            raised[q] = str(e)
+        sh.result._free()
+
+    th = [threading.Thread(target=worker, args=(q,)) for q in range(2)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    for c_ in comms:
+        c_.destroy()
+    for c_ in ctxs:
+        c_.close()
+    assert raised[0] and raised[1] and "finite" in raised[0] and "finite" in raised[1], raised

@@ -736,3 +736,30 @@ def test_hbm_bandwidth_probe_reports_plausible_rates():
     assert 500.0 < copy_gbs < 8000.0, copy_gbs
     assert copy_gbs > 0.4 * read_gbs
     ctx.close()
+
+
+@pytest.mark.parametrize("bad", [np.nan, np.inf, -np.inf])
+@pytest.mark.parametrize("dt,grid", [(np.float32, True), (np.float32, False), (np.float64, True)])
+def test_non_finite_coordinates_are_refused(gpu_ctx, bad, dt, grid):
+    """A NaN or infinite coordinate has no cell: the call fails with SS_ERR_INVALID_ARGUMENT instead of indexing out of its tables (found with the
+    AddressSanitizer build of tests/emu: a wild store in k_sorted_gather_runs).  The reference's f32::min / max skip the NaN in the AABB and its
+    `NaN as i64` files the particle under cell 0; nothing useful follows from that either.  With an explicit particle AABB the particle is outside
+    it and filtered out like any other (lib.rs:369-406): the result equals the one without the particle."""
+    import splashsurf_amd as S
+    from splashsurf_amd import workloads as W
+    from splashsurf_amd.api import SplashsurfError
+    good = W.tank_particles(0.06).astype(dt)
+    pts = good.copy()
+    pts[17, 1] = bad
+    kw = dict(particle_radius=0.005, smoothing_length=2.0, cube_size=0.5 if grid else 1.0, subdomain_grid=grid, subdomain_grid_auto_disable=False, simd=False, context=gpu_ctx)
+    with pytest.raises(SplashsurfError) as e:
+        S.reconstruct_surface(pts, **kw)
+    assert "finite" in str(e.value)
+    ok = S.reconstruct_surface(good, **kw)  # the context is fine afterwards
+    assert ok.mesh.vertices.shape[0] > 0
+    if grid and dt == np.float32:
+        lo, hi = good.min(axis=0) - 1.0, good.max(axis=0) + 1.0
+        box = dict(aabb_min=[float(x) for x in lo], aabb_max=[float(x) for x in hi])
+        a = S.reconstruct_surface(pts, **kw, **box)
+        b = S.reconstruct_surface(np.delete(good, 17, axis=0), **kw, **box)
+        assert np.array_equal(a.mesh.vertices.view(np.uint32), b.mesh.vertices.view(np.uint32)) and np.array_equal(a.mesh.triangles_u32, b.mesh.triangles_u32)
