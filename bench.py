@@ -881,35 +881,30 @@ def single_gpu_extras(line, args, ctx, prm, wl, workload, pts, d_pts, out, dev, 
                          "best": round(n_total / t_io[0] / 1e6, 3), "worst": round(n_total / t_io[-1] / 1e6, 3), "note": note}
         except Exception as e:
             line[key] = {"value": None, "note": "failed: %r" % (e,)}
-    # same host-to-host call, two frames in flight: two contexts (one HIP stream each) driven by two host threads, so the
-    # H2D / D2H copies of one frame overlap the kernels of the other (a time series of frames is the real workload)
-    try:
-        import threading
-        ctxs = [ctx, Context(local_rank)]
-        outs = [out, None]
-        frames = 3
-
-        def worker(i):
-            for _ in range(frames):
-                outs[i] = ctxs[i].reconstruct(host_pts, prm, out=outs[i])
-                outs[i].mesh_views()
-
-        for i in range(2):  # warm-up of the second context's buffers
-            outs[i] = ctxs[i].reconstruct(host_pts, prm, out=outs[i])
-        sync()
-        t1 = time.perf_counter()
-        th = [threading.Thread(target=worker, args=(i,)) for i in range(2)]
-        for t in th:
-            t.start()
-        for t in th:
-            t.join()
-        dt2 = time.perf_counter() - t1
-        line["pcie_pipelined"] = {"value": round(n_total * 2 * frames / dt2 / 1e6, 3), "unit": "Mparticles/s", "ms_per_frame": round(dt2 / (2 * frames) * 1e3, 3),
-                                  "note": "host input and host output (u32 indices), two frames in flight (2 contexts / streams / host threads)"}
-        outs[1] = None
-        ctxs[1].close()
-    except Exception as e:
-        line["pcie_pipelined"] = {"value": None, "note": "failed: %r" % (e,)}
+    # same host-to-host frames, two in flight: the library's frame pipeline (ss_pipeline_*, csrc/ss_pipeline.hip: two contexts, one HIP stream and one
+    # host thread each, behind one handle), so the H2D / D2H copies and the index widening of one frame overlap the kernels of the next (a time
+    # series of frames is the real workload; lib.rs:340-346)
+    from splashsurf_amd.api import FramePipeline
+    for key, fetch, u64, what in (("pcie_pipelined", FramePipeline.FETCH_VERTICES | FramePipeline.FETCH_TRIANGLES_U32, False, "u32 indices"),
+                                  ("pcie_pipelined_u64", FramePipeline.FETCH_VERTICES | FramePipeline.FETCH_TRIANGLES_U64, True, "u64 indices ([usize; 3])")):
+        try:
+            frames = 8
+            with FramePipeline(local_rank, 2) as pipe:
+                pipe.set_two_pass(int(line["config"].get("splat_two_pass", -1)))  # (the mode the headline was timed in)
+                for r_ in pipe.map([host_pts] * 2, prm, fetch):  # warm-up: both slots size their device and pinned buffers
+                    r_.mesh_views(u64=u64)
+                sync()
+                t1 = time.perf_counter()
+                nv_seen = 0
+                for r_ in pipe.map([host_pts] * frames, prm, fetch):
+                    v_, t_ = r_.mesh_views(u64=u64)  # (already in host memory: the slot's thread fetched them)
+                    nv_seen += v_.shape[0]
+                dt2 = time.perf_counter() - t1
+            line[key] = {"value": round(n_total * frames / dt2 / 1e6, 3), "unit": "Mparticles/s", "ms_per_frame": round(dt2 / frames * 1e3, 3), "frames": frames,
+                         "n_vertices_per_frame": nv_seen // frames,
+                         "note": "host input and host output (%s), two frames in flight through ss_pipeline_* (depth 2: two contexts / streams / host threads inside the library)" % what}
+        except Exception as e:
+            line[key] = {"value": None, "note": "failed: %r" % (e,)}
     # --- the CLI's smoothing recipe right behind the reconstruction (reconstruct -> vertex connectivity -> 25 iterations of Laplacian smoothing -> vertex
     #     normals; README.md:165-167, postprocessing.rs:17-97) with the mesh KEPT IN HBM, against the same stages fed through host arrays (mesh downloaded, every
     #     stage uploading its inputs and downloading its outputs: what a caller without device pointers pays) ---

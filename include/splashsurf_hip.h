@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define SS_ABI_VERSION 5
+#define SS_ABI_VERSION 6
 
 /* Return codes; 1..4 mirror ReconstructionError (lib.rs:289-314). */
 typedef enum ss_status {
@@ -274,6 +274,41 @@ ss_status ss_result_debug_certified(ss_result *res, uint32_t *masks, uint32_t *b
  * subdomains S and sum of per-subdomain particle counts incl. ghosts, dense_subdomains.rs:349-494);
  * only needed to price the splat kernel in the reference's algorithmic bytes. */
 ss_status ss_result_subdomain_stats(ss_result *res, uint64_t *n_occupied_subdomains, uint64_t *n_subdomain_particles);
+
+/* -- frame pipeline: a time series of frames through `depth` contexts of ONE device (csrc/ss_pipeline.hip) --
+ * The reference's time-series use is a loop of reconstruct_surface_inplace over the frames with one workspace (lib.rs:340-346, 466-470).  A
+ * host-to-host frame of this library is a chain (upload -> kernels -> mesh download -> index widening) in which nothing of one frame overlaps;
+ * the pipeline overlaps CONSECUTIVE frames instead: every slot owns a context (stream, workspace), a result and a host thread, frame t runs
+ * on slot t % depth, and while frame t's mesh crosses PCIe frame t + 1 uploads and computes.  Output of a frame is what
+ * ss_reconstruct_surface_inplace_f32 on a context of its own returns (tests/test_gpu_pipeline.py: bit-identical).  The canonical loop:
+ *     submit(f0); submit(f1); for (k = 0; k < n; ++k) { next(&res); consume(res); if (k + 2 < n) submit(f[k+2]); }
+ *   ss_pipeline_submit_*   queues a frame and returns at once.  xyz (host or device memory, N x 3) must stay valid and unchanged until the frame
+ *                          was handed back by ss_pipeline_next; the parameters are copied.  `fetch`: SS_FETCH_* bits of the host mirrors the
+ *                          slot's thread fills before the frame counts as complete (the matching ss_result_* accessors then return without
+ *                          copying).  SS_ERR_INVALID_ARGUMENT while `depth` frames are in flight.
+ *   ss_pipeline_next       blocks until the OLDEST frame in flight is complete and hands it back: its status (message: ss_pipeline_last_error),
+ *                          its ticket and -- on success -- its result.  The result belongs to the pipeline and is valid until the submit that
+ *                          reuses its slot (the `depth`-th submit after the frame's own); never pass it to ss_result_free.
+ *   ss_pipeline_ready      1 if ss_pipeline_next would return without blocking.
+ *   ss_pipeline_set_option ss_context_set_option on every slot's context; only while no frame is in flight.
+ *   ss_pipeline_context    the context of a slot (e.g. for ss_last_error after a failing accessor of that slot's result); NULL if out of range.
+ *   ss_pipeline_frame_times  host wall time of the last frame of a slot: the reconstruct call and the fetches behind it.
+ * One thread drives a pipeline (submit / next / destroy are not re-entrant); the frames themselves run on the slots' threads. */
+typedef struct ss_pipeline ss_pipeline;
+#define SS_PIPELINE_MAX_DEPTH 8
+enum { SS_FETCH_VERTICES = 1, SS_FETCH_TRIANGLES_U64 = 2, SS_FETCH_TRIANGLES_U32 = 4, SS_FETCH_DENSITIES = 8 };
+ss_status ss_pipeline_create(int device_id, int depth, ss_pipeline **out);
+void ss_pipeline_destroy(ss_pipeline *p); /* waits for the frames in flight */
+const char *ss_pipeline_last_error(const ss_pipeline *p);
+int ss_pipeline_depth(const ss_pipeline *p);
+int ss_pipeline_in_flight(const ss_pipeline *p);
+ss_context *ss_pipeline_context(ss_pipeline *p, int slot);
+ss_status ss_pipeline_set_option(ss_pipeline *p, int option, int value);
+ss_status ss_pipeline_submit_f32(ss_pipeline *p, const float *xyz, uint64_t n_particles, const ss_params_f32 *params, uint32_t fetch, uint64_t *ticket);
+ss_status ss_pipeline_submit_f64(ss_pipeline *p, const double *xyz, uint64_t n_particles, const ss_params_f64 *params, uint32_t fetch, uint64_t *ticket);
+ss_status ss_pipeline_next(ss_pipeline *p, ss_result **result, uint64_t *ticket);
+int ss_pipeline_ready(ss_pipeline *p);
+ss_status ss_pipeline_frame_times(ss_pipeline *p, int slot, double *ms_reconstruct, double *ms_fetch);
 
 /* -- multi-GPU extension (no counterpart in the single-process reference) --
  * One process per GPU reconstructs a box of subdomains of ONE global grid.  The host (e.g.

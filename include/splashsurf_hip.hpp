@@ -168,6 +168,52 @@ struct SurfaceReconstructionT {  // lib.rs:247-262
 };
 using SurfaceReconstruction = SurfaceReconstructionT<float>;
 
+// fills a SurfaceReconstruction (lib.rs:247-262) from the accessors of a completed result; `check_` turns a status into an exception
+template <class R, class Check>
+void unpack_result(ss_result* res, Check check_, SurfaceReconstructionT<R>& output_surface) {
+    typename Abi<R>::grid g{};
+    check_(Abi<R>::result_grid(res, &g));
+    output_surface.grid = UniformGridT<R>::from_c(g);
+    int32_t present = 0;
+    check_(Abi<R>::result_subdomain_grid(res, &g, &present));
+    if (present)
+        output_surface.subdomain_grid = UniformGridT<R>::from_c(g);
+    else
+        output_surface.subdomain_grid.reset();
+    const R* v = nullptr;
+    uint64_t nv = 0;
+    check_(Abi<R>::vertices(res, &v, &nv));
+    output_surface.mesh.vertices.resize(nv);
+    for (uint64_t i = 0; i < nv; ++i) output_surface.mesh.vertices[i] = {v[3 * i], v[3 * i + 1], v[3 * i + 2]};
+    const uint64_t* t = nullptr;
+    uint64_t nt = 0;
+    check_(ss_result_triangles(res, &t, &nt));
+    output_surface.mesh.triangles.resize(nt);
+    for (uint64_t i = 0; i < nt; ++i) output_surface.mesh.triangles[i] = {t[3 * i], t[3 * i + 1], t[3 * i + 2]};
+    const R* rho = nullptr;
+    uint64_t n = 0;
+    check_(Abi<R>::densities(res, &rho, &n));
+    output_surface.particle_densities = std::vector<R>(rho, rho + n);
+    const uint8_t* inside = nullptr;
+    uint64_t ni = 0;
+    check_(ss_result_particle_inside_aabb(res, &inside, &ni));
+    if (inside)
+        output_surface.particle_inside_aabb = std::vector<bool>(inside, inside + ni);
+    else
+        output_surface.particle_inside_aabb.reset();
+    const uint64_t *row = nullptr, *nb = nullptr;
+    uint64_t np = 0;
+    check_(ss_result_particle_neighbors(res, &row, &nb, &np));
+    if (row) {
+        std::vector<std::vector<uint64_t>> lists(np);
+        for (uint64_t i = 0; i < np; ++i) lists[i].assign(nb + row[i], nb + row[i + 1]);
+        output_surface.particle_neighbors = std::move(lists);
+    } else {
+        output_surface.particle_neighbors.reset();
+    }
+    check_(ss_result_stats(res, &output_surface.stats));
+}
+
 class Context {  // replaces initialize_thread_pool (lib.rs:321-326) + the reconstruction workspace
   public:
     explicit Context(int device_id = 0) {
@@ -201,47 +247,7 @@ class Context {  // replaces initialize_thread_pool (lib.rs:321-326) + the recon
         const typename Abi<R>::params p = parameters.to_c();
         const R* xyz = particle_positions.empty() ? nullptr : particle_positions[0].data();
         check(Abi<R>::reconstruct_inplace(ctx_, xyz, particle_positions.size(), &p, res_));
-        typename Abi<R>::grid g{};
-        check(Abi<R>::result_grid(res_, &g));
-        output_surface.grid = UniformGridT<R>::from_c(g);
-        int32_t present = 0;
-        check(Abi<R>::result_subdomain_grid(res_, &g, &present));
-        if (present)
-            output_surface.subdomain_grid = UniformGridT<R>::from_c(g);
-        else
-            output_surface.subdomain_grid.reset();
-        const R* v = nullptr;
-        uint64_t nv = 0;
-        check(Abi<R>::vertices(res_, &v, &nv));
-        output_surface.mesh.vertices.resize(nv);
-        for (uint64_t i = 0; i < nv; ++i) output_surface.mesh.vertices[i] = {v[3 * i], v[3 * i + 1], v[3 * i + 2]};
-        const uint64_t* t = nullptr;
-        uint64_t nt = 0;
-        check(ss_result_triangles(res_, &t, &nt));
-        output_surface.mesh.triangles.resize(nt);
-        for (uint64_t i = 0; i < nt; ++i) output_surface.mesh.triangles[i] = {t[3 * i], t[3 * i + 1], t[3 * i + 2]};
-        const R* rho = nullptr;
-        uint64_t n = 0;
-        check(Abi<R>::densities(res_, &rho, &n));
-        output_surface.particle_densities = std::vector<R>(rho, rho + n);
-        const uint8_t* inside = nullptr;
-        uint64_t ni = 0;
-        check(ss_result_particle_inside_aabb(res_, &inside, &ni));
-        if (inside)
-            output_surface.particle_inside_aabb = std::vector<bool>(inside, inside + ni);
-        else
-            output_surface.particle_inside_aabb.reset();
-        const uint64_t *row = nullptr, *nb = nullptr;
-        uint64_t np = 0;
-        check(ss_result_particle_neighbors(res_, &row, &nb, &np));
-        if (row) {
-            std::vector<std::vector<uint64_t>> lists(np);
-            for (uint64_t i = 0; i < np; ++i) lists[i].assign(nb + row[i], nb + row[i + 1]);
-            output_surface.particle_neighbors = std::move(lists);
-        } else {
-            output_surface.particle_neighbors.reset();
-        }
-        check(ss_result_stats(res_, &output_surface.stats));
+        unpack_result<R>(res_, [this](ss_status st) { check(st); }, output_surface);
     }
 
     // grid_for_reconstruction (lib.rs:476-516)
@@ -270,6 +276,62 @@ class Context {  // replaces initialize_thread_pool (lib.rs:321-326) + the recon
     }
     ss_context* ctx_ = nullptr;
     ss_result* res_ = nullptr;
+};
+
+// ---- time series: the reference's frame loop with `depth` frames in flight -----------------------------------------------
+// `for frame in series { reconstruct_surface_inplace(&particles, &parameters, &mut output) }` (lib.rs:340-346: one workspace reused by every
+// frame) as submit / next over ss_pipeline_*: every slot of the pipeline owns a context, a result and a host thread, so the upload and
+// kernels of one frame run beside the mesh download of the frame before it.  Frames come back in submission order, each exactly what
+// Context::reconstruct_surface_inplace gives.  The particle vector handed to submit() must stay alive and unchanged until next() returned
+// that frame.
+class FrameSeries {
+  public:
+    explicit FrameSeries(int device_id = 0, int depth = 2) {
+        const ss_status st = ss_pipeline_create(device_id, depth, &pipe_);
+        if (st != SS_OK) throw ReconstructionError(st, 0, "ss_pipeline_create failed: no usable HIP device, or depth outside 1..8");
+    }
+    FrameSeries(const FrameSeries&) = delete;
+    FrameSeries& operator=(const FrameSeries&) = delete;
+    ~FrameSeries() {
+        if (pipe_) ss_pipeline_destroy(pipe_);
+    }
+
+    int depth() const { return ss_pipeline_depth(pipe_); }
+    int in_flight() const { return ss_pipeline_in_flight(pipe_); }
+
+    // queues a frame (returns at once) and gives its ticket; throws while depth() frames are in flight
+    template <class R>
+    uint64_t submit(const std::vector<Vector3<R>>& particle_positions, const ParametersT<R>& parameters) {
+        const typename Abi<R>::params p = parameters.to_c();
+        const R* xyz = particle_positions.empty() ? nullptr : particle_positions[0].data();
+        uint64_t ticket = 0;
+        const uint32_t fetch = SS_FETCH_VERTICES | SS_FETCH_TRIANGLES_U64 | SS_FETCH_DENSITIES;
+        if constexpr (sizeof(R) == 4)
+            check(ss_pipeline_submit_f32(pipe_, xyz, particle_positions.size(), &p, fetch, &ticket));
+        else
+            check(ss_pipeline_submit_f64(pipe_, xyz, particle_positions.size(), &p, fetch, &ticket));
+        return ticket;
+    }
+
+    // blocks for the oldest frame in flight and fills `output_surface` with it (the Real type must be the one the frame was submitted with);
+    // a failed frame throws its ReconstructionError here, the series goes on with the next frame
+    template <class R>
+    uint64_t next(SurfaceReconstructionT<R>& output_surface) {
+        ss_result* res = nullptr;
+        uint64_t ticket = 0;
+        check(ss_pipeline_next(pipe_, &res, &ticket));
+        ss_context* ctx = ss_pipeline_context(pipe_, (int)(ticket % (uint64_t)depth()));
+        unpack_result<R>(res, [ctx](ss_status st) {
+            if (st != SS_OK) throw ReconstructionError(st, ss_last_error_detail(ctx), ss_last_error(ctx));
+        }, output_surface);
+        return ticket;
+    }
+
+  private:
+    void check(ss_status st) {
+        if (st != SS_OK) throw ReconstructionError(st, 0, ss_pipeline_last_error(pipe_));
+    }
+    ss_pipeline* pipe_ = nullptr;
 };
 
 // ---- multi-GPU: one ShardedReconstruction per process (or host thread) and GPU ------------------------------------------

@@ -10,6 +10,7 @@ The library is loaded lazily, so importing the package (e.g. for `workloads`) wo
 from .api import (  # noqa: F401
     Parameters,
     SurfaceReconstruction,
+    FramePipeline,
     reconstruct_surface,
     reconstruct_surface_abs,
     grid_for_reconstruction,

@@ -207,7 +207,7 @@ def load_library():
     L.ss_result_grid_f64.argtypes = [vp, P(_Grid64)]
     L.ss_result_subdomain_grid_f64.argtypes = [vp, P(_Grid64), P(i32)]
     L.ss_result_levelset_box_f64.argtypes = [vp, P(C.c_int64), P(C.c_int64), vp]
-    if L.ss_abi_version() != 5:
+    if L.ss_abi_version() != 6:
         raise ImportError("libsplashsurf_hip.so ABI version mismatch")
     _lib = L
     return L
@@ -607,6 +607,160 @@ class SurfaceReconstruction:
             self._check(fn(self._h, C.byref(ptr), C.byref(n)))
             out[name] = (ptr.value, int(n.value))
         return out
+
+
+class _SlotContext:
+    """The context of a pipeline slot as the accessors of `SurfaceReconstruction` see it (error messages); owned by the pipeline."""
+
+    def __init__(self, lib, handle, device_id):
+        self._lib = lib
+        self._h = handle
+        self.device_id = device_id
+        self._results = weakref.WeakSet()
+
+    _raise = Context._raise
+    _as_ptr = Context._as_ptr
+
+
+class _SlotResult(SurfaceReconstruction):
+    """A result that belongs to a pipeline slot: never freed from Python."""
+
+    def _free(self):
+        self._h = None
+
+
+class FramePipeline:
+    """`ss_pipeline_*` (include/splashsurf_hip.h, csrc/ss_pipeline.hip): a time series of frames through `depth` contexts of one device -- the
+    reference's loop of `reconstruct_surface_inplace` over the frames (lib.rs:340-346) with consecutive frames overlapping (upload and kernels of
+    frame k + 1 beside the mesh download of frame k).  Frames come back in submission order::
+
+        with FramePipeline(depth=2) as pipe:
+            for mesh in pipe.map(frames, parameters):   # frames: iterable of (N, 3) float32 / float64 arrays
+                use(mesh.mesh_views())                   # valid until `depth` further frames were submitted
+
+    `fetch`: the host mirrors a slot's thread fills before its frame counts as complete."""
+
+    FETCH_VERTICES, FETCH_TRIANGLES_U64, FETCH_TRIANGLES_U32, FETCH_DENSITIES = 1, 2, 4, 8
+
+    def __init__(self, device_id=0, depth=2):
+        self._lib = L = load_library()
+        vp, u64 = C.c_void_p, C.c_uint64
+        L.ss_pipeline_create.argtypes = [C.c_int, C.c_int, C.POINTER(vp)]
+        L.ss_pipeline_destroy.argtypes = [vp]
+        L.ss_pipeline_destroy.restype = None
+        L.ss_pipeline_last_error.argtypes = [vp]
+        L.ss_pipeline_last_error.restype = C.c_char_p
+        L.ss_pipeline_depth.argtypes = [vp]
+        L.ss_pipeline_in_flight.argtypes = [vp]
+        L.ss_pipeline_context.argtypes = [vp, C.c_int]
+        L.ss_pipeline_context.restype = vp
+        L.ss_pipeline_set_option.argtypes = [vp, C.c_int, C.c_int]
+        L.ss_pipeline_submit_f32.argtypes = [vp, vp, u64, C.POINTER(_Params), C.c_uint32, C.POINTER(u64)]
+        L.ss_pipeline_submit_f64.argtypes = [vp, vp, u64, C.POINTER(_Params64), C.c_uint32, C.POINTER(u64)]
+        L.ss_pipeline_next.argtypes = [vp, C.POINTER(vp), C.POINTER(u64)]
+        L.ss_pipeline_ready.argtypes = [vp]
+        L.ss_pipeline_frame_times.argtypes = [vp, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+        h = vp()
+        st = L.ss_pipeline_create(int(device_id), int(depth), C.byref(h))
+        if st != 0:
+            raise SplashsurfError(st, "ss_pipeline_create failed (device %d, depth %d)" % (device_id, depth))
+        self._h = h
+        self.device_id = device_id
+        self.depth = int(depth)
+        self._slot_ctx = [_SlotContext(L, vp(L.ss_pipeline_context(h, i)), device_id) for i in range(self.depth)]
+        self._slot_res = {}   # result handle -> _SlotResult
+        self._keep = {}       # ticket -> the particle array of a frame in flight (the library reads it until the frame is handed back)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.ss_pipeline_destroy(self._h)
+            self._h = None
+            for r in self._slot_res.values():
+                r._h = None
+            for c in self._slot_ctx:
+                c._h = None
+            self._keep.clear()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def _raise(self, st):
+        msg = self._lib.ss_pipeline_last_error(self._h)
+        msg = msg.decode() if msg else ""
+        if st == 1:
+            raise GridConstructionError(st, msg)
+        raise SplashsurfError(st, msg)
+
+    def set_option(self, option, value):
+        st = self._lib.ss_pipeline_set_option(self._h, int(option), int(value))
+        if st != 0:
+            self._raise(st)
+
+    def set_two_pass(self, mode=-1):
+        self.set_option(2, mode)
+
+    @property
+    def in_flight(self):
+        return int(self._lib.ss_pipeline_in_flight(self._h))
+
+    def ready(self):
+        return bool(self._lib.ss_pipeline_ready(self._h))
+
+    def submit(self, particles, parameters, fetch=FETCH_VERTICES | FETCH_TRIANGLES_U32):
+        """Queues a frame; returns its ticket.  The array is kept alive (and must stay unchanged) until the frame was handed back."""
+        ptr, n, keep, f64 = self._slot_ctx[0]._as_ptr(particles)
+        p = parameters._c(f64)
+        t = C.c_uint64()
+        fn = self._lib.ss_pipeline_submit_f64 if f64 else self._lib.ss_pipeline_submit_f32
+        st = fn(self._h, ptr, n, C.byref(p), int(fetch), C.byref(t))
+        if st != 0:
+            self._raise(st)
+        self._keep[int(t.value)] = keep
+        return int(t.value)
+
+    def next(self):
+        """Blocks for the oldest frame in flight: (ticket, SurfaceReconstruction).  The result is valid until its slot is reused (the `depth`-th
+        submit after the frame's own); a failed frame raises like `Context.reconstruct` does."""
+        h, t = C.c_void_p(), C.c_uint64()
+        st = self._lib.ss_pipeline_next(self._h, C.byref(h), C.byref(t))
+        self._keep.pop(int(t.value), None)
+        if st != 0:
+            self._raise(st)
+        r = self._slot_res.get(h.value)
+        if r is None:
+            r = self._slot_res[h.value] = _SlotResult(self._slot_ctx[int(t.value) % self.depth], h)
+        r._invalidate()
+        return int(t.value), r
+
+    def frame_times(self, slot):
+        a, b = C.c_double(), C.c_double()
+        st = self._lib.ss_pipeline_frame_times(self._h, int(slot), C.byref(a), C.byref(b))
+        if st != 0:
+            self._raise(st)
+        return float(a.value), float(b.value)
+
+    def map(self, frames, parameters, fetch=FETCH_VERTICES | FETCH_TRIANGLES_U32):
+        """Generator over the results of `frames` (an iterable of particle arrays), in order, `depth` frames in flight."""
+        it = iter(frames)
+        done = False
+        while True:
+            while not done and self.in_flight < self.depth:
+                try:
+                    self.submit(next(it), parameters, fetch)
+                except StopIteration:
+                    done = True
+            if self.in_flight == 0:
+                return
+            yield self.next()[1]
 
 
 _default_ctx = {}

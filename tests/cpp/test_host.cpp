@@ -120,6 +120,49 @@ int main() {
         CHECK(ids.size() == particles.size() && rho.size() == particles.size() && ids.front() == 0 && ids.back() == particles.size() - 1);
         for (size_t i = 0; i < rho.size(); ++i) CHECK(rho[i] == (*direct.particle_densities)[i]);
     }
+    // --- a time series through FrameSeries (ss_pipeline_*): the frame loop of lib.rs:340-346 with two frames in flight; every frame equals
+    //     the one-context call, frames come back in order, a failing frame throws at next() and the series goes on ---
+    {
+        std::vector<std::vector<Vector3f>> frames(5);
+        for (int f = 0; f < 5; ++f)
+            for (int i = 0; i < 5 + f; ++i)
+                for (int j = 0; j < 6; ++j)
+                    for (int k = 0; k < 6; ++k) frames[f].push_back({0.05f * i + 0.004f * f, 0.05f * j, 0.05f * k - 0.002f * f});
+        Parameters p = Parameters::relative(0.025f, 2.0f, 0.75f);
+        p.spatial_decomposition.grid.auto_disable = false;
+        p.spatial_decomposition.grid.subdomain_num_cubes_per_dim = 16;
+        Parameters bad = p;
+        bad.cube_size = 0.0f;
+        FrameSeries series(0, 2);
+        CHECK(series.depth() == 2 && series.in_flight() == 0);
+        CHECK(series.submit(frames[0], p) == 0);
+        CHECK(series.submit(frames[1], p) == 1);
+        try {  // full
+            series.submit(frames[2], p);
+            CHECK(false);
+        } catch (const ReconstructionError& e) {
+            CHECK(e.variant == ReconstructionError::Variant::InvalidArgument);
+        }
+        SurfaceReconstruction out;
+        for (int f = 0; f < 5; ++f) {
+            if (f == 3) {  // (frame 3 was submitted with a cube size of 0: the reference panics, the series reports and continues)
+                try {
+                    series.next(out);
+                    CHECK(false);
+                } catch (const ReconstructionError& e) {
+                    CHECK(e.variant == ReconstructionError::Variant::Unknown);
+                }
+            } else {
+                CHECK(series.next(out) == (uint64_t)f);
+                SurfaceReconstruction direct = ctx.reconstruct_surface(frames[f], p);
+                CHECK(out.mesh.vertices == direct.mesh.vertices && out.mesh.triangles == direct.mesh.triangles);
+                CHECK(out.particle_densities && *out.particle_densities == *direct.particle_densities);
+                CHECK(closed_manifold(out.mesh));
+            }
+            if (f + 2 < 5) series.submit(frames[f + 2], f + 2 == 3 ? bad : p);
+        }
+        CHECK(series.in_flight() == 0);
+    }
     // --- empty input is Ok with an empty mesh (SURVEY 8b edge behaviour) ---
     {
         Parameters p = Parameters::relative(0.025f, 4.0f, 1.0f);

@@ -15,7 +15,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 CSRC = os.path.join(ROOT, "splashsurf_amd", "csrc")
 OUT = os.path.join(HERE, "_build", "libsplashsurf_emu.so")
-SOURCES = ["ss_api.hip", "ss_kernels.hip", "ss_global.hip", "ss_post.hip", "ss_dist.hip", "ss_prims.hip"]
+SOURCES = ["ss_api.hip", "ss_kernels.hip", "ss_global.hip", "ss_post.hip", "ss_dist.hip", "ss_prims.hip", "ss_pipeline.hip"]
 CXX_CANDIDATES = ["/opt/rocm/lib/llvm/bin/clang++", "clang++"]
 # the device build's floating-point contract (no contraction; fma only where the source says fma) on the host's IEEE arithmetic
 FLAGS = ["-x", "c++", "-std=c++17", "-O2", "-g1", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-mfma", "-mf16c", "-mavx2", "-fno-slp-vectorize",

@@ -19,7 +19,7 @@ def test_library_exports_all_declared_symbols():
     for s in syms:
         assert hasattr(L, s), s
     L.ss_abi_version.restype = ctypes.c_int
-    assert L.ss_abi_version() == 5  # SS_ABI_VERSION in include/splashsurf_hip.h
+    assert L.ss_abi_version() == 6  # SS_ABI_VERSION in include/splashsurf_hip.h
 
 
 def test_struct_layouts_match_header():

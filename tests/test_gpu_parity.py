@@ -475,14 +475,16 @@ def test_splat_on_reference_grid_loop_fixture(oracle):
 
 def test_cpp_host_over_c_abi(tmp_path):
     """A C++ host (include/splashsurf_hip.hpp, mirroring the reference's Rust API) drives the C ABI without
-    Python: the reference's known-answer test (test_simple.rs:71-126), in-place reuse, neighbour lists and
-    the error variants."""
+    Python: the reference's known-answer test (test_simple.rs:71-126), in-place reuse, neighbour lists, the
+    error variants, the one-rank sharded path and a time series through FrameSeries (ss_pipeline_*)."""
     import subprocess
     root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
     exe = str(tmp_path / "test_host")
-    libdir = os.path.join(root, "splashsurf_amd")
+    # (the library under test: the HIP build, or the CPU execution model of tests/emu when SPLASHSURF_HIP_LIB names it -- tests/test_emu_kernels.py)
+    lib = os.environ.get("SPLASHSURF_HIP_LIB") or os.path.join(root, "splashsurf_amd", "libsplashsurf_hip.so")
+    libdir, libname = os.path.dirname(os.path.abspath(lib)), os.path.basename(lib)[3:-3]
     subprocess.check_call(["g++", "-std=c++17", "-O1", "-I" + os.path.join(root, "include"), os.path.join(root, "tests", "cpp", "test_host.cpp"),
-                           "-L" + libdir, "-lsplashsurf_hip", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib", "-o", exe])
+                           "-L" + libdir, "-l" + libname, "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib", "-o", exe])
     out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "all checks passed" in out.stdout

@@ -15,13 +15,13 @@ ARCH=gfx950; GPUSAN=-fno-gpu-sanitize
 if [ "$DEVICE" == "1" ]; then ARCH=gfx950:xnack+; GPUSAN=; fi
 FLAGS="--offload-arch=$ARCH -fsanitize=address $GPUSAN -shared-libsan -g -O1 -std=c++17 -ffp-contract=off -fno-slp-vectorize -fPIC -Wall -Wno-unused-function -Wno-pass-failed"
 pids=()
-for f in ss_api ss_kernels ss_global ss_post ss_dist ss_prims; do
+for f in ss_api ss_kernels ss_global ss_post ss_dist ss_prims ss_pipeline; do
   hipcc $FLAGS -c $f.hip -o "$OBJ/$f.o" &
   pids+=($!)
 done
 for p in "${pids[@]}"; do wait $p; done
 mkdir -p "$ROOT/splashsurf_amd/variants"
-hipcc --offload-arch=$ARCH -fsanitize=address $GPUSAN -shared-libsan -shared -fPIC "$OBJ"/ss_api.o "$OBJ"/ss_kernels.o "$OBJ"/ss_global.o "$OBJ"/ss_post.o "$OBJ"/ss_dist.o "$OBJ"/ss_prims.o \
+hipcc --offload-arch=$ARCH -fsanitize=address $GPUSAN -shared-libsan -shared -fPIC "$OBJ"/ss_api.o "$OBJ"/ss_kernels.o "$OBJ"/ss_global.o "$OBJ"/ss_post.o "$OBJ"/ss_dist.o "$OBJ"/ss_prims.o "$OBJ"/ss_pipeline.o \
   -ldl -lpthread -o "$ROOT/splashsurf_amd/variants/libsplashsurf_hip_asan.so"
 rm -rf "$OBJ"
 echo "built splashsurf_amd/variants/libsplashsurf_hip_asan.so"

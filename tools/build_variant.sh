@@ -17,13 +17,13 @@ fi
 cd "$W/splashsurf_amd/csrc"
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fno-slp-vectorize -fPIC -Wall -Wno-unused-function"
 pids=()
-for f in ss_api ss_kernels ss_global ss_post ss_dist ss_prims; do
+for f in ss_api ss_kernels ss_global ss_post ss_dist ss_prims ss_pipeline; do
   [ -e $f.hip ] || continue
   hipcc $FLAGS "$@" -c $f.hip -o $f.o &
   pids+=($!)
 done
 for p in "${pids[@]}"; do wait $p; done
 mkdir -p "$ROOT/splashsurf_amd/variants"
-hipcc --offload-arch=gfx950 -shared -fPIC $(ls ss_api.o ss_kernels.o ss_global.o ss_post.o ss_dist.o ss_prims.o 2>/dev/null) -ldl -lpthread -o "$ROOT/splashsurf_amd/variants/libsplashsurf_hip_$NAME.so"
+hipcc --offload-arch=gfx950 -shared -fPIC $(ls ss_api.o ss_kernels.o ss_global.o ss_post.o ss_dist.o ss_prims.o ss_pipeline.o 2>/dev/null) -ldl -lpthread -o "$ROOT/splashsurf_amd/variants/libsplashsurf_hip_$NAME.so"
 rm -rf "$W"
 echo "built splashsurf_amd/variants/libsplashsurf_hip_$NAME.so"
