@@ -137,8 +137,8 @@ template <class T>
 ss_status exclusive_scan_u32(ss_context* ctx, const T* in, T* out, size_t n) {
     if (n > SS_SCAN_MAX_N) return fail(ctx, SS_ERR_UNSUPPORTED, "more than 2^32 - 8193 entries in one prefix sum");
     const size_t words = ss_scan_state_words(n);
-    SS_HIP(ctx, ctx->temp.reserve(words * 4));
-    SS_HIP(ctx, hipMemsetAsync(ctx->temp.p, 0, words * 4, ctx->stream));
+    SS_HIP(ctx, ctx->temp.reserve(ss_round16(words * 4)));
+    SS_HIP(ctx, hipMemsetAsync(ctx->temp.p, 0, ss_round16(words * 4), ctx->stream));
     ss_chained_scan<T, SSOpPlus>(ArrayIn<T>{in}, ArrayExclOut<T>{out}, (uint32_t)n, ctx->temp.as<uint32_t>(), (T*)nullptr, SSMailSlot{}, ctx->stream);
     return SS_OK;
 }
@@ -203,7 +203,7 @@ struct ZeroTaker {
     }
 };
 ss_status reserve_zeros(ss_context* ctx, size_t words, ZeroTaker* z) {
-    words += 64;
+    words = (words + 64 + 3) & ~(size_t)3;  // (whole 16-byte units: ss_round16)
     SS_HIP(ctx, ctx->zeros.reserve(words * 4));
     SS_HIP(ctx, hipMemsetAsync(ctx->zeros.p, 0, words * 4, ctx->stream));
     z->base = ctx->zeros.as<uint32_t>();
@@ -451,9 +451,9 @@ ss_status stage_particles(ss_context* ctx, const R* xyz, uint64_t n_in, const ty
     DevBuf local_inside;
     DevBuf* inside = res ? &res->inside8 : &local_inside;
     SS_HIP(ctx, inside->reserve(n_in));
-    SS_HIP(ctx, ctx->flags32.reserve((n_in + 1) * 4));
+    SS_HIP(ctx, ctx->flags32.reserve(ss_round16((n_in + 1) * 4)));
     SS_HIP(ctx, ctx->offsets.reserve((n_in + 1) * 4));
-    SS_HIP(ctx, hipMemsetAsync(ctx->flags32.p, 0, (n_in + 1) * 4, st));
+    SS_HIP(ctx, hipMemsetAsync(ctx->flags32.p, 0, ss_round16((n_in + 1) * 4), st));
     ss_launch_inside_flags(d_xyz, (uint32_t)n_in, prm->aabb_min, prm->aabb_max, inside->as<uint8_t>(), ctx->flags32.as<uint32_t>(), st);
     ss_status s = exclusive_scan_u32<uint32_t>(ctx, ctx->flags32.as<uint32_t>(), ctx->offsets.as<uint32_t>(), n_in + 1);
     if (s != SS_OK) return s;
@@ -569,9 +569,9 @@ ss_status global_search_and_densities(ss_context* ctx, const SSGlobT<R>& Q, cons
     uint32_t* d_err = ctx->counter.as<uint32_t>();
     SS_HIP(ctx, res->rho.reserve((size_t)n * sizeof(R) + 16));
     SS_HIP(ctx, res->perm.reserve((size_t)n * 4 + 16));
-    SS_HIP(ctx, ctx->cell_count.reserve((nscell + 1) * 4));
+    SS_HIP(ctx, ctx->cell_count.reserve(ss_round16((nscell + 1) * 4)));
     SS_HIP(ctx, ctx->cell_start.reserve((nscell + 1) * 4));
-    SS_HIP(ctx, hipMemsetAsync(ctx->cell_count.p, 0, (nscell + 1) * 4, st));
+    SS_HIP(ctx, hipMemsetAsync(ctx->cell_count.p, 0, ss_round16((nscell + 1) * 4), st));
     SS_HIP(ctx, res->nb_ptr.reserve(((size_t)n + 1) * 8));
     res->has_neighbors = true;  // the global strategy always returns the neighbour lists (reconstruction.rs:107-108)
     res->n_neighbors = 0;
@@ -600,9 +600,9 @@ ss_status global_search_and_densities(ss_context* ctx, const SSGlobT<R>& Q, cons
         SS_HIP(ctx, hipStreamSynchronize(st));
         if (herr & 1u) return fail(ctx, SS_ERR_UNKNOWN, "particle outside the neighborhood-search grid (reference: panic in get_cell().unwrap())");
         SS_HIP(ctx, hipEventRecord(ctx->ev[3], st));
-        SS_HIP(ctx, ctx->nb_count.reserve(((size_t)n + 1) * 8));
+        SS_HIP(ctx, ctx->nb_count.reserve(ss_round16(((size_t)n + 1) * 8)));
         SS_HIP(ctx, ctx->nb_tmp.reserve(((size_t)n + 1) * 8));
-        SS_HIP(ctx, hipMemsetAsync(ctx->nb_count.p, 0, ((size_t)n + 1) * 8, st));
+        SS_HIP(ctx, hipMemsetAsync(ctx->nb_count.p, 0, ss_round16(((size_t)n + 1) * 8), st));
         ssg_launch_density<R>(Q, d_xyz, ctx->cell_start.as<uint32_t>(), res->perm.as<uint32_t>(), res->rho.as<R>(), 0, ctx->nb_count.as<uint32_t>(), nullptr,
                               nullptr, st);
         ss_launch_widen(ctx->nb_count.as<uint32_t>(), (size_t)n + 1, ctx->nb_tmp.as<unsigned long long>(), st);
@@ -842,7 +842,7 @@ ss_status phase_begin(ss_context* ctx, const R* xyz, uint64_t n_in, const typena
     // ---- K1: bin + sort (decomposition) ----
     s = ensure_mail(ctx);
     if (s != SS_OK) return s;
-    SS_HIP(ctx, res->rho.reserve((size_t)n * sizeof(R) + 16));
+    SS_HIP(ctx, res->rho.reserve(ss_round16((size_t)n * sizeof(R) + 16)));
     SS_HIP(ctx, res->posvol.reserve((size_t)n * sizeof(ss_real4<R>) + 32));
     SS_HIP(ctx, res->posvol_by_index.reserve((size_t)n * sizeof(ss_real4<R>) + 32));
     SS_HIP(ctx, res->perm.reserve((size_t)n * 4 + 16));
@@ -862,7 +862,7 @@ ss_status phase_begin(ss_context* ctx, const R* xyz, uint64_t n_in, const typena
     while (bits < 32 && ((size_t)1 << bits) < ncells) ++bits;
     auto launch_k1 = [&](hipStream_t s1) -> ss_status {
         // zeroed words of the chain, one memset: a scan state, the sort's work words and the run starts of the cell table (0 = empty cell)
-        const size_t words = ss_scan_state_words(ncells + 1) + ss_radix_sort_work_words(n, bits) + (ncells + 1) + 64;
+        const size_t words = (ss_scan_state_words(ncells + 1) + ss_radix_sort_work_words(n, bits) + (ncells + 1) + 64 + 3) & ~(size_t)3;  // (whole 16-byte units: ss_round16)
         SS_HIP(ctx, ctx->zeros_k1.reserve(words * 4));
         SS_HIP(ctx, hipMemsetAsync(ctx->zeros_k1.p, 0, words * 4, s1));
         ZeroTaker Z1;
@@ -917,7 +917,7 @@ ss_status phase_begin(ss_context* ctx, const R* xyz, uint64_t n_in, const typena
     // ---- K2: densities (per-subdomain particle copies, exactly the reference's organisation) ----
     {
         const double ctot_d = (double)P.sc[0] * P.sc[1] * P.sc[2];
-        SS_HIP(ctx, hipMemsetAsync(res->rho.p, 0, (size_t)n * sizeof(R) + 16, st));  // vec![R::zero(); n], dense_subdomains.rs:504
+        SS_HIP(ctx, hipMemsetAsync(res->rho.p, 0, ss_round16((size_t)n * sizeof(R) + 16), st));  // vec![R::zero(); n], dense_subdomains.rs:504
         // member counts -> copy offsets (the membership count as the scan's input), occupied subdomains -> ranks and list
         const SSMailSlot m_copies = mail_slot(ctx, 0), m_occ = mail_slot(ctx, 1);
         ss_launch_classify_scan(P, d_xyz, ctx->copy_offset.as<uint32_t>(), sub_flag, st_member, m_copies, st);
@@ -968,9 +968,9 @@ ss_status phase_begin(ss_context* ctx, const R* xyz, uint64_t n_in, const typena
             ss_launch_cell_table_scan(cell_first2, (uint32_t)ncells2, ctx->cell_start2.as<uint32_t>(), st_cells2, st);
             const bool want_nb = prm->global_neighborhood_list != 0;
             if (want_nb) {
-                SS_HIP(ctx, ctx->nb_count.reserve(((size_t)n + 1) * 8));
-                SS_HIP(ctx, res->nb_ptr.reserve(((size_t)n + 1) * 8));
-                SS_HIP(ctx, hipMemsetAsync(ctx->nb_count.p, 0, ((size_t)n + 1) * 8, st));
+                SS_HIP(ctx, ctx->nb_count.reserve(ss_round16(((size_t)n + 1) * 8)));
+                SS_HIP(ctx, res->nb_ptr.reserve(ss_round16(((size_t)n + 1) * 8)));
+                SS_HIP(ctx, hipMemsetAsync(ctx->nb_count.p, 0, ss_round16(((size_t)n + 1) * 8), st));
             }
             s = ensure_fast_div<R>(ctx, P.h, st);
             if (s != SS_OK) return s;
@@ -1015,8 +1015,8 @@ ss_status phase_begin(ss_context* ctx, const R* xyz, uint64_t n_in, const typena
             res->has_neighbors = prm->global_neighborhood_list != 0;
             res->n_neighbors = 0;
             if (res->has_neighbors) {
-                SS_HIP(ctx, res->nb_ptr.reserve(((size_t)n + 1) * 8));
-                SS_HIP(ctx, hipMemsetAsync(res->nb_ptr.p, 0, ((size_t)n + 1) * 8, st));
+                SS_HIP(ctx, res->nb_ptr.reserve(ss_round16(((size_t)n + 1) * 8)));
+                SS_HIP(ctx, hipMemsetAsync(res->nb_ptr.p, 0, ss_round16(((size_t)n + 1) * 8), st));
             }
         }
     }

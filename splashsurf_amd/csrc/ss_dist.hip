@@ -316,7 +316,7 @@ ss_status comm_mail_wait(ss_comm* c, const SSMailSlot& m, unsigned long long* va
 // n zeroed 32-bit words (one memset)
 ss_status comm_zeros(ss_comm* c, size_t words, uint32_t** out) {
     ss_context* ctx = c->ctx;
-    words += 16;
+    words = (words + 16 + 3) & ~(size_t)3;  // (whole 16-byte units: ss_round16, ss_host.h)
     SS_HIP(ctx, c->zeros.reserve(words * 4));
     SS_HIP(ctx, hipMemsetAsync(c->zeros.p, 0, words * 4, ctx->stream));
     *out = c->zeros.as<uint32_t>();
@@ -1012,7 +1012,7 @@ ss_status dist_reconstruct(ss_comm* c, const R* xyz_in, uint64_t n_local, const 
     SS_HIP(ctx, c->hist.reserve(nsub * 4 + 64));
     {
         TurnGuard hist_turn(c, "hist");
-        SS_HIP(ctx, hipMemsetAsync(c->hist.p, 0, nsub * 4, st));
+        SS_HIP(ctx, hipMemsetAsync(c->hist.p, 0, ss_round16(nsub * 4), st));  // (reserved with 64 bytes to spare)
         if (n_local)
             hipLaunchKernelGGL(k_owner_hist<R>, grid_for(n_local), dim3(256), 0, st, d_xyz, n_local, grid.aabb_min[0], grid.aabb_min[1], grid.aabb_min[2], subgrid.cell_size, ns[0],
                                ns[1], ns[2], c->hist.as<uint32_t>());
@@ -1326,7 +1326,7 @@ ss_status dist_assemble(ss_comm* c, ss_result* res) {
                 const long double kmax = 3.0L * (long double)((unsigned long long)c->ns[0] * n + 1ull) * (long double)np1 * (long double)np2;
                 while (hi_bits < 32 && std::ldexp(1.0L, 32 + (int)hi_bits) < kmax) ++hi_bits;
             }
-            const size_t work_words = ss_radix_sort_work_words(nr, 32) + ss_radix_sort_work_words(nr, hi_bits ? hi_bits : 1);
+            const size_t work_words = (ss_radix_sort_work_words(nr, 32) + ss_radix_sort_work_words(nr, hi_bits ? hi_bits : 1) + 3) & ~(size_t)3;  // (whole 16-byte units: ss_round16)
             SS_HIP(ctx, c->sort_tmp.reserve(((size_t)nr + 16) * 4 * 4 + work_words * 4 + 64));
             uint32_t* k0 = c->sort_tmp.as<uint32_t>();
             uint32_t* k1 = k0 + ((size_t)nr + 16);

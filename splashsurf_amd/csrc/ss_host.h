@@ -178,6 +178,10 @@ inline ss_status fail(ss_context* ctx, ss_status st, const std::string& msg, int
 }
 
 
+// hipMemsetAsync of a size that is not a multiple of 16 bytes costs TWO fill launches on ROCm (the aligned body and a tail: config 1 spent 10 fill
+// launches on its 6 memsets, profiles/r06_cfg_pmc.md); every zero region of the host flow is therefore reserved and cleared in whole 16-byte units
+inline size_t ss_round16(size_t bytes) { return (bytes + 15) & ~(size_t)15; }
+
 inline bool is_device_pointer(const void* p) {
     hipPointerAttribute_t attr;
     hipError_t e = hipPointerGetAttributes(&attr, p);

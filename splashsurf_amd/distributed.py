@@ -661,14 +661,15 @@ class NativeComm:
         rank = dist.get_rank() if rank is None else rank
         world = dist.get_world_size() if world is None else world
         uid = (C.c_uint8 * 128)()
-        if rank == 0:
-            st = L.ss_comm_unique_id(uid)
-            if st != 0:
-                raise RuntimeError("ss_comm_unique_id failed (RCCL not loadable?)")
-        if world > 1:
-            box = [bytes(uid)]
+        failed = rank == 0 and L.ss_comm_unique_id(uid) != 0
+        if world > 1:  # (rank 0 takes part in the broadcast even when it has no id: the other ranks must not wait for one that never comes)
+            box = [None if failed else bytes(uid)]
             dist.broadcast_object_list(box, src=0)
-            uid = (C.c_uint8 * 128).from_buffer_copy(box[0])
+            failed = box[0] is None
+            if not failed:
+                uid = (C.c_uint8 * 128).from_buffer_copy(box[0])
+        if failed:
+            raise RuntimeError("ss_comm_unique_id failed on rank 0 (RCCL not loadable?)")
         h = C.c_void_p()
         st = L.ss_comm_create_rccl(ctx._h, uid, int(rank), int(world), C.byref(h))
         if st != 0:

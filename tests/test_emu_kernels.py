@@ -129,6 +129,30 @@ def test_outputs_do_not_depend_on_the_schedule():
     assert len(set(digests)) == 1 and len(digests[0]) == 24, digests
 
 
+def test_launch_trace_of_a_small_job():
+    """What one steady-state call on BASELINE config 1 dispatches (tools/emu_launch_trace.py over HIP_EMU_TRACE): a small job's time is its list of
+    dispatches and host waits, and the list is the same on the GPU (same host flow).  Budgets = the values of the build the round-6 numbers were taken
+    from; every memset clears whole 16-byte units (ss_round16: an unaligned size costs ROCm a second fill launch -- 10 fill launches for 6 memsets in
+    profiles/r06_cfg_pmc.md)."""
+    lib = emulated_library()
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import emu_launch_trace
+    old = os.environ.get("SPLASHSURF_HIP_LIB")
+    os.environ["SPLASHSURF_HIP_LIB"] = lib
+    try:
+        t = emu_launch_trace.trace("config1")
+    finally:
+        if old is None:
+            del os.environ["SPLASHSURF_HIP_LIB"]
+        else:
+            os.environ["SPLASHSURF_HIP_LIB"] = old
+    assert (t["n_vertices"], t["n_triangles"]) == (33026, 66220)
+    assert t["launches"] <= 37, t["kernels"]
+    assert len(t["memsets"]) <= 6 and all(m % 16 == 0 for m in t["memsets"]), t["memsets"]
+    assert t["copies"] == [4732 * 12]  # the upload; no other copy (counts reach the host through mail slots)
+    assert t["n_host_waits"] <= 8
+
+
 def test_the_emulated_library_is_not_what_the_product_loads():
     """api.library_path() names the HIP build unless SPLASHSURF_HIP_LIB says otherwise; nothing under splashsurf_amd/, bench.py or
     __graft_entry__.py mentions the emulator."""
