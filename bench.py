@@ -64,6 +64,10 @@ def parse():
                     help="--pseudo-ranks / native N > 1: from the second step on the bricks balance the cost measured in the previous step (ss_comm_set_balance_feedback) instead of "
                          "particle counts.  Off by default: bricks are whole subdomains, and on S40M-tank at 8 ranks no plane can move without making another rank the slowest "
                          "(measured, profiles/r05_s40m_tank_pseudo_ranks_8*.json)")
+    ap.add_argument("--resident", action="store_true",
+                    help="--pseudo-ranks / native N > 1, strong scaling: after a first frame every rank holds the particles of its OWN brick (the cloud re-dealt by "
+                         "splashsurf_amd.distributed.brick_owner_of on that frame's partition) -- a simulation's time series that keeps its particles where they are owned: "
+                         "the position exchange then ships ghost layers only.  Default: rank r holds the r-th contiguous 1/N of the cloud (an unsorted slice, the worst case)")
     ap.add_argument("--exchange", choices=["auto", "native", "torch"], default="auto",
                     help="N > 1 transport of the halo exchange: the library's own RCCL path (ss_dist_*) or torch.distributed")
     ap.add_argument("--cpu-sample-scale", type=float, default=1.0, help="tank scale of the CPU-baseline sample (1.0 = the full 10 M workload)")
@@ -272,6 +276,12 @@ def local_share(args, wl, workload, W, rank, world, r, full=None):
     return np.ascontiguousarray(full[cut[rank]:cut[rank + 1]]), n_total, "%s, fixed size; rank r holds the r-th contiguous 1/%d of the cloud" % (workload, world)
 
 
+def resident_share(D, full, native, res, rank):
+    """--resident: this rank's particles once the cloud is dealt by owner brick (partition and subdomain grid of the frame just computed)."""
+    owner = D.brick_owner_of(full, res.subdomain_grid, native.partition()["bricks"])
+    return np.ascontiguousarray(full[owner == rank])
+
+
 def rank_row(roof, last_stats, xbytes, steps):
     """What every rank contributes to the per-rank table."""
     return [roof["frac"], roof["kernel_ms"], roof["algorithmic_bytes"], float(last_stats["n_active_blocks"]), float(last_stats["n_vertices"]),
@@ -334,6 +344,14 @@ def pseudo_rank_run(args):
             native = D.NativeSharded(comms[q], prm)
             d_local = torch.from_numpy(pts).to(dev)
             torch.cuda.synchronize()
+            if args.resident and args.scaling == "strong":
+                res0 = native.step(d_local)
+                native.assemble()
+                pts = resident_share(D, full, native, res0, q)
+                desc = "%s, fixed size; rank r holds the particles of ITS brick (dealt by the first frame's partition)" % workload
+                bar.wait()  # (every rank read the first frame's partition before anyone computes the next)
+                d_local = torch.from_numpy(pts).to(dev)
+                torch.cuda.synchronize()
             for _ in range(max(args.warmup, 4 if args.balance_feedback else 1)):  # (the feedback needs a few frames to settle)
                 native.step(d_local)
                 native.assemble()
@@ -434,7 +452,7 @@ def pseudo_rank_run(args):
         "config": {"workload": workload, "n_particles": int(n_total), "particle_radius": r, "smoothing_length": wl["smoothing_length"], "cube_size": wl["cube_size"],
                    "n_vertices_incl_shared": tot_v, "n_triangles": tot_t, "enable_simd": int(prm.enable_simd),
                    "parallelism": "%d bricks of the subdomain grid, one per PSEUDO-rank (host threads taking turns on one GPU): `value` is this one GPU's throughput in "
-                                  "that mode, the multi-GPU estimate is `projection`" % world, "workload_desc": out[0]["desc"]},
+                                  "that mode, the multi-GPU estimate is `projection`" % world, "workload_desc": out[0]["desc"], "resident": bool(args.resident)},
         "roofline": out[slowest]["roof"],
         "stages_ms": {k: round(v, 4) for k, v in st0.items() if k.startswith("ms_")},
         "projection": proj,
@@ -541,6 +559,14 @@ def main():
                 dist.all_reduce(ok, op=dist.ReduceOp.MIN)
                 if int(ok.item()) == 0:
                     native = None
+        if args.resident and native is not None and args.scaling == "strong":
+            full_ = wl["gen"]()  # (every rank generates the cloud and keeps its brick's particles: set-up, outside the timed region)
+            res0 = native.step(torch.from_numpy(pts).to(dev))
+            native.assemble()
+            pts = resident_share(D, full_, native, res0, rank)
+            del full_
+            workload_desc = "%s, fixed size; rank r holds the particles of ITS brick (dealt by the first frame's partition)" % workload
+            barrier()
         d_local = torch.from_numpy(pts).to(dev)
         timings = {}
         if native is not None:
@@ -613,6 +639,7 @@ def main():
         scaling = args.scaling
         parallelism = "%d bricks of the subdomain grid (recursive bisection by particle count), one per GPU" % world
         extra["workload_desc"] = workload_desc
+        extra["resident"] = bool(args.resident and native is not None and args.scaling == "strong")
         if world > 1 and args.scaling == "strong" and not args.main_only:
             # the same fixed-size workload on ONE GPU (rank 0's), measured in the same job: the strong-scaling reference
             single = None

@@ -467,9 +467,11 @@ hipError_t hipEventElapsedTime(float* ms, hipEvent_t a, hipEvent_t b) {
     *ms = (float)(b->t_ms - a->t_ms);
     return hipSuccess;
 }
-hipError_t hipSetDevice(int dev) { return dev == 0 ? hipSuccess : hipErrorInvalidValue; }
+// HIP_EMU_DEVICES=n: the process sees n "devices" (all of them this emulator: one process per rank selects its LOCAL_RANK, bench.py --gpus N dry runs)
+static const int g_devices = getenv("HIP_EMU_DEVICES") ? (atoi(getenv("HIP_EMU_DEVICES")) > 0 ? atoi(getenv("HIP_EMU_DEVICES")) : 1) : 1;
+hipError_t hipSetDevice(int dev) { return dev >= 0 && dev < g_devices ? hipSuccess : hipErrorInvalidValue; }
 hipError_t hipGetDeviceCount(int* n) {
-    *n = 1;
+    *n = g_devices;
     return hipSuccess;
 }
 hipError_t hipGetLastError(void) { return hipSuccess; }

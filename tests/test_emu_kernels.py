@@ -153,6 +153,99 @@ def test_launch_trace_of_a_small_job():
     assert t["n_host_waits"] <= 8
 
 
+def _bench_dry_run(args, timeout_s=1200):
+    import json
+    lib = emulated_library()
+    env = dict(os.environ, SPLASHSURF_HIP_LIB=lib)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "emu", "bench_dry_run.py")] + list(args), cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                       text=True, timeout=timeout_s)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{\"metric\"")]
+    assert len(lines) == 1, p.stdout[-2000:]  # ONE JSON line
+    return json.loads(lines[0])
+
+
+def test_bench_py_default_record_dry_run():
+    """bench.py's own code, unchanged, on the CPU execution model (tests/emu/bench_dry_run.py: torch's CUDA entry points pointed at the host, workloads of a few
+    thousand particles): the default N = 1 record is complete -- contract keys, roofline, every extra (arithmetic modes, host-to-host frames, the frame
+    pipeline, the post-processing recipe, the other configurations, the coarse-grid splat) -- and no extra reports a failure.  The driver's bench run is the
+    one artifact nobody can re-run when the GPU pool is closed; this keeps a typo in it from costing the round's measurement."""
+    d = _bench_dry_run(["--steps", "2", "--warmup", "1", "--no-cpu-baseline"])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline"):
+        assert k in d, k
+    assert d["metric"] == "Mparticles/s end-to-end reconstruct" and d["n_gpus"] == 1 and d["steps"] == 2 and d["dtype"] == "f32" and d["dry_run"] is True
+    assert d["config"]["workload"] == "s10m_tank" and d["config"]["splat_two_pass"] == 1 and d["enable_simd"] == 0
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel_ms"):
+        assert k in d["roofline"], k
+    failed = []
+
+    def walk(x, path):
+        if isinstance(x, dict):
+            if ("value" in x and x["value"] is None and path != "") or str(x.get("note", "")).startswith("failed"):
+                failed.append((path, str(x)[:300]))
+            for k, v in x.items():
+                walk(v, path + "/" + k)
+
+    for k in ("arithmetic_modes", "e2e_host_u64", "pcie_inclusive", "pcie_pipelined", "pcie_pipelined_u64", "post_pipeline", "other_configs", "splat_hbm_bound"):
+        assert k in d, k
+        walk(d[k], k)
+    assert not failed, failed
+    assert set(d["other_configs"]) == {"s1m", "s10m_cube", "s40m_tank_1gpu", "config1_dam_break", "config5_hilbert"}
+    assert d["pcie_pipelined"]["n_vertices_per_frame"] == d["config"]["n_vertices"] == d["pcie_pipelined_u64"]["n_vertices_per_frame"]
+    assert d["other_configs"]["config1_dam_break"]["n_vertices"] == 33026  # (the real input file: the wheel golden's mesh size)
+
+
+def test_bench_py_pseudo_rank_record_dry_run():
+    """... and the sharded code path of bench.py (--pseudo-ranks: ss_dist_* over an in-process group), with the contiguous slices and with brick-resident
+    particles (--resident): same mesh either way, a complete projection object."""
+    a = _bench_dry_run(["--pseudo-ranks", "2", "--steps", "1", "--warmup", "1", "--main-only"])
+    b = _bench_dry_run(["--pseudo-ranks", "2", "--steps", "1", "--warmup", "1", "--main-only", "--resident"])
+    assert a["config"]["resident"] is False and b["config"]["resident"] is True
+    for d in (a, b):
+        assert d["pseudo_ranks"] == 2 and len(d["per_rank"]) == 2 and d["scaling"] == "strong"
+        for k in ("own_ms_slowest_rank", "projected_step_ms", "projected_step_ms_point_to_point_links", "collective_steps"):
+            assert k in d["projection"], k
+        assert sum(r["owned_particles"] for r in d["per_rank"]) == d["config"]["n_particles"]
+    assert (a["config"]["n_vertices_incl_shared"], a["config"]["n_triangles"]) == (b["config"]["n_vertices_incl_shared"], b["config"]["n_triangles"])
+    assert b["exchange"]["bytes_sent_per_step_all_ranks"] <= a["exchange"]["bytes_sent_per_step_all_ranks"]
+
+
+def _bench_ranks_dry_run(world, extra, port):
+    """The driver's own command line for N > 1 (python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py
+    --gpus N ...), with tests/emu/bench_dry_run.py in bench.py's place: one PROCESS per rank, each with the emulated library (HIP_EMU_DEVICES = N: every rank
+    selects its LOCAL_RANK), RCCL = the stand-in of tests/emu/fake_rccl.cpp, torch.distributed over gloo."""
+    import json
+    sys.path.insert(0, os.path.join(ROOT, "tests", "emu"))
+    import build_emu
+    env = dict(os.environ, SPLASHSURF_HIP_LIB=build_emu.build(), SPLASH_RCCL_LIB=build_emu.build_fake_rccl(), HIP_EMU_THREADS="2", HIP_EMU_DEVICES=str(world))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(ROOT, "tests", "emu", "bench_dry_run.py"), "--gpus", str(world), "--steps", "1", "--warmup", "1"] + list(extra)
+    p = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=1200)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{\"metric\"")]
+    assert len(lines) == 1, p.stdout[-2000:]  # rank 0 prints ONE JSON line
+    return json.loads(lines[0])
+
+
+def test_bench_py_multi_gpu_command_line_dry_run():
+    """bench.py --gpus N as the driver launches it, N = 2 and 4, never run on more than one real GPU: rank processes, the library's RCCL exchange path
+    (stand-in RCCL), the strong-scaling reference on rank 0, the per-rank table; with brick-resident particles (--resident) and over the torch.distributed
+    fallback (--exchange torch) as well.  All variants give the same mesh."""
+    base = _bench_ranks_dry_run(2, [], 29621)
+    assert base["n_gpus"] == 2 and base["scaling"] == "strong" and base["config"]["workload"] == "s40m_tank" and len(base["per_rank"]) == 2
+    assert base["exchange"]["kind"].startswith("native") and base["exchange"]["rccl_world_size"] == 2
+    assert base["single_gpu_same_workload"]["value"] and base["single_gpu_same_workload"]["speedup_of_this_run"] > 0
+    mesh = (base["config"]["n_vertices"], base["config"]["n_triangles"])
+    res = _bench_ranks_dry_run(2, ["--main-only", "--resident"], 29622)
+    assert res["resident"] is True and (res["config"]["n_vertices"], res["config"]["n_triangles"]) == mesh
+    tor = _bench_ranks_dry_run(2, ["--main-only", "--exchange", "torch"], 29623)
+    assert tor["exchange"]["kind"].startswith("torch.distributed") and (tor["config"]["n_vertices"], tor["config"]["n_triangles"]) == mesh
+    four = _bench_ranks_dry_run(4, ["--main-only"], 29624)
+    assert four["n_gpus"] == 4 and len(four["per_rank"]) == 4 and four["exchange"]["rccl_world_size"] == 4
+    assert four["config"]["n_triangles"] == mesh[1]  # (triangles are disjoint between ranks; shared face vertices are counted by every holder)
+    assert sum(r["owned_particles"] for r in four["per_rank"]) == four["config"]["n_particles"]
+
+
 def test_the_emulated_library_is_not_what_the_product_loads():
     """api.library_path() names the HIP build unless SPLASHSURF_HIP_LIB says otherwise; nothing under splashsurf_amd/, bench.py or
     __graft_entry__.py mentions the emulator."""
