@@ -70,5 +70,9 @@ def _capture(*a, **k):
 import builtins  # noqa: E402
 
 builtins.print = _capture
-sys.argv = [os.path.join(ROOT, "bench.py")] + sys.argv[1:]
-runpy.run_path(os.path.join(ROOT, "bench.py"), run_name="__main__")
+script = os.path.join(ROOT, "bench.py")
+if len(sys.argv) > 2 and sys.argv[1] == "--script":  # (the measurement tools of tools/ take the same treatment: tools/final_collect.sh's steps can be rehearsed)
+    script = os.path.abspath(sys.argv[2])
+    del sys.argv[1:3]
+sys.argv = [script] + sys.argv[1:]
+runpy.run_path(script, run_name="__main__")

@@ -153,6 +153,13 @@ def test_launch_trace_of_a_small_job():
     assert t["n_host_waits"] <= 8
 
 
+def test_graft_entry_smoke_on_the_cpu_execution_model():
+    """__graft_entry__.smoke() -- the driver's first call on the GPU box -- with the emulated library in the HIP build's place: config 1 bit-identical to the oracle."""
+    env = dict(os.environ, SPLASHSURF_HIP_LIB=emulated_library())
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "__graft_entry__.py"), "smoke"], cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+    assert p.returncode == 0 and "[smoke] ok: 33026 vertices / 66220 triangles" in p.stdout, p.stdout[-2000:]
+
+
 def _bench_dry_run(args, timeout_s=1200):
     import json
     lib = emulated_library()
