@@ -96,7 +96,12 @@ struct Slot {
             if (state != QUEUED) return;  // quit, nothing queued
             state = RUNNING;
             lk.unlock();
-            run_frame();
+            try {
+                run_frame();
+            } catch (...) {  // (out of host memory inside the call: the frame fails, the thread lives)
+                status = SS_ERR_UNKNOWN;
+                err = "exception in the frame's host code (out of host memory?)";
+            }
             lk.lock();
             state = DONE;
             cv.notify_all();
@@ -177,12 +182,25 @@ ss_status ss_pipeline_create(int device_id, int depth, ss_pipeline** out) {
         p->slots.push_back(std::move(sl));
     }
     if (s == SS_OK) {
-        for (auto& sl : p->slots) {
-            Slot* raw = sl.get();
-            raw->th = std::thread([raw] { raw->loop(); });
+        try {
+            for (auto& sl : p->slots) {
+                Slot* raw = sl.get();
+                raw->th = std::thread([raw] { raw->loop(); });
+            }
+        } catch (...) {  // (no thread to be had: nothing may leave a C entry point but a status)
+            s = SS_ERR_UNKNOWN;
         }
-    } else {
+    }
+    if (s != SS_OK) {
         for (auto& sl : p->slots) {
+            if (sl->th.joinable()) {
+                {
+                    std::lock_guard<std::mutex> lk(sl->mu);
+                    sl->quit = true;
+                }
+                sl->cv.notify_all();
+                sl->th.join();
+            }
             if (sl->res) ss_result_free(sl->res);
             if (sl->ctx) ss_context_destroy(sl->ctx);
         }

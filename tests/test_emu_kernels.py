@@ -49,6 +49,9 @@ SLOW_EMULATED_OPTIONAL = [
     "tests/test_gpu_parity.py::test_gpu_bit_identical_to_oracle_large[config5_hilbert]",
     "tests/test_gpu_parity.py::test_dense_cloud_exceeding_tile_capacity[True]",
     "tests/test_gpu_parity.py::test_split_mc_offsets_gives_the_same_mesh",
+    "tests/test_gpu_simd.py::test_early_exit_inside_the_fluid_changes_no_output[0]",
+    "tests/test_gpu_dist_native.py::test_native_brick_resident_time_series_ships_halos_only",
+    "tests/test_gpu_parity.py::test_host_waits_are_counted",
     "tests/test_gpu_simd.py::test_early_exit_inside_the_fluid_changes_no_output[1]",
     "tests/test_gpu_simd.py::test_early_exit_inside_the_fluid_changes_no_output[2]",
     "tests/test_gpu_simd.py::test_simd_matches_reference_simd_digest[simd_config2_s1m]",
@@ -80,7 +83,8 @@ def run_gpu_tests_emulated(extra_args, deselect, timeout_s):
     lib = emulated_library()
     import build_emu
     env = dict(os.environ, SPLASHSURF_HIP_LIB=lib, SPLASH_RCCL_LIB=build_emu.build_fake_rccl())  # (the one-rank RCCL test binds the stand-in)
-    cmd = [sys.executable, "-m", "pytest", "-m", "gpu", "-q", "-p", "no:cacheprovider", "--timeout", "600"] + FILES + list(extra_args)
+    env.setdefault("HIP_EMU_THREADS", "2")  # four pytest workers with two emulator threads each: most cases are small and bound by launch latency, not by cores
+    cmd = [sys.executable, "-m", "pytest", "-m", "gpu", "-q", "-p", "no:cacheprovider", "--timeout", "600", "-n", "4"] + FILES + list(extra_args)
     for d in deselect:
         cmd += ["--deselect", d]
     p = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=timeout_s)
@@ -94,7 +98,7 @@ def test_the_gpu_parity_tests_pass_on_the_cpu_execution_model_of_the_kernels():
     deselect = NEED_A_DEVICE + SLOW_EMULATED + ([] if everything else SLOW_EMULATED_OPTIONAL)
     rc, passed, tail = run_gpu_tests_emulated([], deselect, 7200 if everything else 1500)
     assert rc == 0, tail
-    assert passed >= 183, tail  # the scan / sort primitives, 50 parity / golden cases, 52 fuzz cases, the SIMD modes, certificates, in-process ranks, the reference's own test cases
+    assert passed >= 200, tail  # the scan / sort primitives, 50 parity / golden cases, 52 fuzz cases, the SIMD modes, certificates, in-process ranks, the reference's own test cases
 
 
 def test_the_rccl_branch_between_rank_processes_with_a_stand_in_rccl():
