@@ -8,7 +8,8 @@ Differences, all of them loud:
     switching one of them on is an error.  The binary switches the cleanup on by default as soon as `--mesh-smoothing-iters` is
     given and not 0 (reconstruct.rs:201-214): such a command line needs an explicit `--mesh-cleanup=off` here.  The
     `--check-mesh*` options run on the host; a finding fails the frame with the reference's message.
-  * `--mt-files`, `--mt-particles`, `-n/--num-threads` and `--simd` are accepted and ignored: the work runs on the GPU.
+  * `--mt-files`, `--mt-particles`, `-n/--num-threads` and `--simd` are accepted and ignored: the work runs on the GPU (a sequence always overlaps
+    the next frame's file read and the previous frame's file write with the current frame's reconstruction).
 """
 import argparse
 import os
@@ -223,16 +224,39 @@ def run_reconstruct(args, log=None):
     pairs = collect_paths(args)
     dtype = np.float64 if args.double_precision else np.float32
     written = []
-    for src, dst in pairs:
-        particles, attrs = read_particles_with_attributes(src, args.interpolate_attributes, dtype)
-        log('Reconstructing "%s" (%d particles) -> "%s"' % (src, particles.shape[0], dst))
-        mesh, rec = postprocessing.reconstruction_pipeline(particles, attributes_to_interpolate=attrs, **kwargs)
-        if args.output_raw_mesh:  # reconstruct.rs:1622-1654: raw_<output file name> next to the output file
-            raw = os.path.join(os.path.dirname(dst), "raw_" + os.path.basename(dst))
-            io.mesh_to_file(io.MeshWithData(rec.mesh.vertices, rec.mesh.triangles), raw)
-            written.append(raw)
-        io.mesh_to_file(io.MeshWithData(mesh.mesh.vertices, mesh.mesh.triangles, mesh.point_attributes), dst)
-        written.append(dst)
+    # A sequence is a chain per frame -- read the file, reconstruct on the GPU, write the mesh -- of which only the middle runs on the device: the next
+    # frame's file is read and the previous frame's mesh written on two host threads while the current frame reconstructs (the reference overlaps frames with
+    # --mt-files, reconstruct.rs:380-470; here the flag is accepted and the overlap is always on).  Files are written in order, one at a time; a failing read or
+    # write surfaces at the frame it belongs to.
+    from concurrent.futures import ThreadPoolExecutor
+    reader, writer = ThreadPoolExecutor(max_workers=1), ThreadPoolExecutor(max_workers=1)
+    try:
+        pending_write = None
+        ahead = reader.submit(read_particles_with_attributes, pairs[0][0], args.interpolate_attributes, dtype) if pairs else None
+        for k, (src, dst) in enumerate(pairs):
+            particles, attrs = ahead.result()
+            ahead = reader.submit(read_particles_with_attributes, pairs[k + 1][0], args.interpolate_attributes, dtype) if k + 1 < len(pairs) else None
+            log('Reconstructing "%s" (%d particles) -> "%s"' % (src, particles.shape[0], dst))
+            mesh, rec = postprocessing.reconstruction_pipeline(particles, attributes_to_interpolate=attrs, **kwargs)
+            jobs = []
+            if args.output_raw_mesh:  # reconstruct.rs:1622-1654: raw_<output file name> next to the output file
+                raw = os.path.join(os.path.dirname(dst), "raw_" + os.path.basename(dst))
+                jobs.append((io.MeshWithData(rec.mesh.vertices, rec.mesh.triangles), raw))  # (owning copies: the next frame reuses nothing of them)
+            jobs.append((io.MeshWithData(mesh.mesh.vertices, mesh.mesh.triangles, mesh.point_attributes), dst))
+            if pending_write is not None:
+                pending_write.result()  # (the previous frame's files are complete -- or its error is raised -- before this frame's are queued)
+
+            def write_all(jobs=jobs):
+                for data, path in jobs:
+                    io.mesh_to_file(data, path)
+
+            pending_write = writer.submit(write_all)
+            written.extend(path for _, path in jobs)
+        if pending_write is not None:
+            pending_write.result()
+    finally:
+        reader.shutdown(wait=True)
+        writer.shutdown(wait=True)
     return written
 
 

@@ -125,6 +125,84 @@ def test_cli_end_to_end_matches_the_library_call(tmp_path, capfd):
     assert cli.main(["reconstruct", str(src), "-r=0.025", "-l=2.0", "-c=1.1", "--decimate-barnacles=on"]) == 1
 
 
+@pytest.mark.gpu
+def test_cli_sequence_equals_frame_by_frame_calls(tmp_path):
+    """A three-frame sequence through the overlapped frame loop writes, per frame, the file a single-file call writes."""
+    from splashsurf_amd import io
+    p = np.load(os.path.join(HERE, "data", "double_dam_break_frame_26_4732_particles.npy")).astype(np.float32)
+    for k in (1, 2, 3):
+        io.particles_to_file((p[: len(p) - 500 * k] + np.float32(0.01 * k)).astype(np.float32), str(tmp_path / ("dam_%d.xyz" % k)))
+    common = ["-r=0.025", "-l=2.0", "-c=1.1", "--normals=on"]
+    assert cli.main(["reconstruct", str(tmp_path / "dam_{}.xyz")] + common + ["--output-dir", str(tmp_path / "seq")]) == 0
+    for k in (1, 2, 3):
+        assert cli.main(["reconstruct", str(tmp_path / ("dam_%d.xyz" % k))] + common + ["-o", str(tmp_path / ("one_%d.vtk" % k))]) == 0
+        a = io.mesh_from_file(str(tmp_path / "seq" / ("dam_surface_%d.vtk" % k)))
+        b = io.mesh_from_file(str(tmp_path / ("one_%d.vtk" % k)))
+        assert np.array_equal(a.vertices, b.vertices) and np.array_equal(a.triangles, b.triangles)
+        assert np.array_equal(a.point_attributes["normals"], b.point_attributes["normals"])
+    assert len({io.mesh_from_file(str(tmp_path / "seq" / ("dam_surface_%d.vtk" % k))).vertices.shape for k in (1, 2, 3)}) == 3
+
+
+def test_sequence_frames_overlap_file_io_in_order(tmp_path, monkeypatch):
+    """The frame loop of a sequence (reconstruct.rs:380-470) reads the next file and writes the previous mesh on host threads while the current frame is
+    reconstructed: outputs are written in frame order, each from its own frame's data, and an error of a read or a write fails the command at that frame.
+    (The device stage is replaced by a stub here; tests -m gpu run the real one.)"""
+    import threading
+    import time
+    import types
+    from splashsurf_amd import io, postprocessing
+    for k in (3, 4, 5, 6):
+        io.particles_to_file(np.full((k, 3), float(k), np.float32), str(tmp_path / ("f_%d.xyz" % k)))
+    events, lock = [], threading.Lock()
+
+    def note(kind, what):
+        with lock:
+            events.append((kind, what))
+
+    real_read = cli.read_particles_with_attributes
+
+    def slow_read(path, names, dtype):
+        note("read", os.path.basename(path))
+        time.sleep(0.05)
+        return real_read(path, names, dtype)
+
+    def stub_pipeline(particles, attributes_to_interpolate=None, **kw):
+        note("reconstruct", int(particles.shape[0]))
+        time.sleep(0.1)
+        n = int(particles.shape[0])
+        m = types.SimpleNamespace(mesh=types.SimpleNamespace(vertices=np.full((n, 3), n, np.float32), triangles=np.zeros((1, 3), np.uint64)), point_attributes={})
+        return m, m
+
+    def slow_write(data, path):
+        note("write", (os.path.basename(path), int(data.vertices.shape[0])))
+        time.sleep(0.05)
+        if "surface_5" in path and os.environ.get("FAIL_WRITE_5"):
+            raise OSError("disk full")
+        open(path, "w").write("%d" % data.vertices.shape[0])
+
+    monkeypatch.setattr(cli, "read_particles_with_attributes", slow_read)
+    monkeypatch.setattr(postprocessing, "reconstruction_pipeline", stub_pipeline)
+    monkeypatch.setattr(io, "mesh_to_file", slow_write)
+    args = _parse(str(tmp_path / "f_{}.xyz"), "-r=0.025", "-l=2.0", "-c=1.0", "--output-dir", str(tmp_path / "out"))
+    os.makedirs(tmp_path / "out")
+    written = cli.run_reconstruct(args, log=lambda m: None)
+    assert [os.path.basename(w) for w in written] == ["f_surface_%d.vtk" % k for k in (3, 4, 5, 6)]
+    for k in (3, 4, 5, 6):
+        assert open(tmp_path / "out" / ("f_surface_%d.vtk" % k)).read() == str(k)  # every file from its own frame
+    assert [e[1] for e in events if e[0] == "reconstruct"] == [3, 4, 5, 6]
+    assert [e[1][0] for e in events if e[0] == "write"] == ["f_surface_%d.vtk" % k for k in (3, 4, 5, 6)]
+    # overlap: frame k + 1 was read before frame k's reconstruction ended, i.e. before frame k was written
+    order = [e for e in events if e[0] in ("read", "write")]
+    assert order.index(("read", "f_4.xyz")) < order.index(("write", ("f_surface_3.vtk", 3)))
+    # a failing write fails the command (at the next frame's hand-over at the latest); earlier frames are complete
+    monkeypatch.setenv("FAIL_WRITE_5", "1")
+    for k in (3, 4, 5, 6):
+        os.remove(tmp_path / "out" / ("f_surface_%d.vtk" % k))
+    with pytest.raises(OSError):
+        cli.run_reconstruct(args, log=lambda m: None)
+    assert (tmp_path / "out" / "f_surface_4.vtk").exists() and not (tmp_path / "out" / "f_surface_5.vtk").exists()
+
+
 def test_convert_subcommand(tmp_path):
     """splashsurf/src/convert.rs: particle and mesh files between formats, domain filter, overwrite guard -- host only."""
     from splashsurf_amd import io
