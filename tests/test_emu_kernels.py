@@ -20,6 +20,7 @@ ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
 # test_cpp_host_over_c_abi links against whatever SPLASHSURF_HIP_LIB names.)  (Tests that hand the library torch tensors hand it HOST tensors here: conftest.device_name().)
 NEED_A_DEVICE = [
     "tests/test_cli.py::test_cli_end_to_end_matches_the_library_call",
+    "tests/test_cli.py::test_cli_sequence_equals_frame_by_frame_calls",
     "tests/test_post.py::test_gpu_pipeline_matches_oracle_and_reference",
 ]
 # ... and the ones that take more than ~4 s emulated (8 host threads); SPLASHSURF_EMU_ALL=1 runs them too (about 20 minutes, 1 M particles
