@@ -13,6 +13,21 @@ DATA = os.path.join(ROOT, "tests", "data")
 GOLD = os.path.join(ROOT, "tests", "golden")
 
 
+if os.environ.get("SPLASHSURF_EMU_HOST_DEVICE") == "1":
+    # tests/test_emu_kernels.py only: the library under test is the CPU execution model of tests/emu, whose "device" memory is the host's, so host code that
+    # asks torch for a "cuda" device (postprocessing.reconstruction_pipeline, the CLI) gets the host.  Never set on a GPU box.
+    import torch
+
+    _torch_device = torch.device
+
+    class _HostDevice:
+        def __call__(self, *a, **k):
+            return _torch_device("cpu")
+
+    torch.device = _HostDevice()
+    torch.cuda.synchronize = lambda *a, **k: None
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: test needs a real MI355X (run with -m gpu on the GPU box)")
 

@@ -16,13 +16,8 @@ import pytest
 
 ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
 
-# -m gpu tests that cannot run on the emulated library: host code of theirs asks torch for a CUDA device.  (The C++ host of
-# test_cpp_host_over_c_abi links against whatever SPLASHSURF_HIP_LIB names.)  (Tests that hand the library torch tensors hand it HOST tensors here: conftest.device_name().)
-NEED_A_DEVICE = [
-    "tests/test_cli.py::test_cli_end_to_end_matches_the_library_call",
-    "tests/test_cli.py::test_cli_sequence_equals_frame_by_frame_calls",
-    "tests/test_post.py::test_gpu_pipeline_matches_oracle_and_reference",
-]
+# -m gpu tests that cannot run on the emulated library.  (The C++ host of test_cpp_host_over_c_abi links against whatever SPLASHSURF_HIP_LIB names.)  (Tests that hand the library torch tensors hand it HOST tensors here: conftest.device_name().)
+NEED_A_DEVICE = []  # (none left: SPLASHSURF_EMU_HOST_DEVICE makes tests/conftest.py hand out the host where host code asks torch for a "cuda" device)
 # ... and the ones that take more than ~4 s emulated (8 host threads); SPLASHSURF_EMU_ALL=1 runs them too (about 20 minutes, 1 M particles
 # included; the 10 M / 40 M full-size tests stay out)
 SLOW_EMULATED = [
@@ -84,6 +79,7 @@ def run_gpu_tests_emulated(extra_args, deselect, timeout_s):
     lib = emulated_library()
     import build_emu
     env = dict(os.environ, SPLASHSURF_HIP_LIB=lib, SPLASH_RCCL_LIB=build_emu.build_fake_rccl())  # (the one-rank RCCL test binds the stand-in)
+    env["SPLASHSURF_EMU_HOST_DEVICE"] = "1"
     env.setdefault("HIP_EMU_THREADS", "2")  # four pytest workers with two emulator threads each: most cases are small and bound by launch latency, not by cores
     cmd = [sys.executable, "-m", "pytest", "-m", "gpu", "-q", "-p", "no:cacheprovider", "--timeout", "600", "-n", "4"] + FILES + list(extra_args)
     for d in deselect:
@@ -99,7 +95,7 @@ def test_the_gpu_parity_tests_pass_on_the_cpu_execution_model_of_the_kernels():
     deselect = NEED_A_DEVICE + SLOW_EMULATED + ([] if everything else SLOW_EMULATED_OPTIONAL)
     rc, passed, tail = run_gpu_tests_emulated([], deselect, 7200 if everything else 1500)
     assert rc == 0, tail
-    assert passed >= 200, tail  # the scan / sort primitives, 50 parity / golden cases, 52 fuzz cases, the SIMD modes, certificates, in-process ranks, the reference's own test cases
+    assert passed >= 205, tail  # the scan / sort primitives, 50 parity / golden cases, 52 fuzz cases, the SIMD modes, certificates, in-process ranks, the reference's own test cases
 
 
 def test_the_rccl_branch_between_rank_processes_with_a_stand_in_rccl():
