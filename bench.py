@@ -912,26 +912,37 @@ def single_gpu_extras(line, args, ctx, prm, wl, workload, pts, d_pts, out, dev, 
     # host thread each, behind one handle), so the H2D / D2H copies and the index widening of one frame overlap the kernels of the next (a time
     # series of frames is the real workload; lib.rs:340-346)
     from splashsurf_amd.api import FramePipeline
+    def pipelined(depth, fetch, u64, frames):
+        with FramePipeline(local_rank, depth) as pipe:
+            pipe.set_two_pass(int(line["config"].get("splat_two_pass", -1)))  # (the mode the headline was timed in)
+            for r_ in pipe.map([host_pts] * depth, prm, fetch):  # warm-up: every slot sizes its device and pinned buffers
+                r_.mesh_views(u64=u64)
+            sync()
+            t1 = time.perf_counter()
+            nv_seen = 0
+            for r_ in pipe.map([host_pts] * frames, prm, fetch):
+                v_, t_ = r_.mesh_views(u64=u64)  # (already in host memory: the slot's thread fetched them)
+                nv_seen += v_.shape[0]
+            return (time.perf_counter() - t1) / frames, nv_seen // frames
+
     for key, fetch, u64, what in (("pcie_pipelined", FramePipeline.FETCH_VERTICES | FramePipeline.FETCH_TRIANGLES_U32, False, "u32 indices"),
                                   ("pcie_pipelined_u64", FramePipeline.FETCH_VERTICES | FramePipeline.FETCH_TRIANGLES_U64, True, "u64 indices ([usize; 3])")):
         try:
             frames = 8
-            with FramePipeline(local_rank, 2) as pipe:
-                pipe.set_two_pass(int(line["config"].get("splat_two_pass", -1)))  # (the mode the headline was timed in)
-                for r_ in pipe.map([host_pts] * 2, prm, fetch):  # warm-up: both slots size their device and pinned buffers
-                    r_.mesh_views(u64=u64)
-                sync()
-                t1 = time.perf_counter()
-                nv_seen = 0
-                for r_ in pipe.map([host_pts] * frames, prm, fetch):
-                    v_, t_ = r_.mesh_views(u64=u64)  # (already in host memory: the slot's thread fetched them)
-                    nv_seen += v_.shape[0]
-                dt2 = time.perf_counter() - t1
-            line[key] = {"value": round(n_total * frames / dt2 / 1e6, 3), "unit": "Mparticles/s", "ms_per_frame": round(dt2 / frames * 1e3, 3), "frames": frames,
-                         "n_vertices_per_frame": nv_seen // frames,
+            dt2, nv2 = pipelined(2, fetch, u64, frames)
+            line[key] = {"value": round(n_total / dt2 / 1e6, 3), "unit": "Mparticles/s", "ms_per_frame": round(dt2 * 1e3, 3), "frames": frames, "depth": 2,
+                         "n_vertices_per_frame": nv2,
                          "note": "host input and host output (%s), two frames in flight through ss_pipeline_* (depth 2: two contexts / streams / host threads inside the library)" % what}
+            if not u64:  # more frames in flight: where the overlap saturates (a frame's chain is upload 2.1 -> kernels 6.6 -> download 5.4 ms; the device alone bounds a frame at 6.6)
+                line[key]["by_depth"] = {}
+                for depth in (3, 4):
+                    dtd, _ = pipelined(depth, fetch, u64, 3 * depth)
+                    line[key]["by_depth"][str(depth)] = {"value": round(n_total / dtd / 1e6, 3), "ms_per_frame": round(dtd * 1e3, 3)}
         except Exception as e:
-            line[key] = {"value": None, "note": "failed: %r" % (e,)}
+            if key in line:  # (the depth-2 figure stands; the sweep behind it failed)
+                line[key]["by_depth"] = {"value": None, "note": "failed: %r" % (e,)}
+            else:
+                line[key] = {"value": None, "note": "failed: %r" % (e,)}
     # --- the CLI's smoothing recipe right behind the reconstruction (reconstruct -> vertex connectivity -> 25 iterations of Laplacian smoothing -> vertex
     #     normals; README.md:165-167, postprocessing.rs:17-97) with the mesh KEPT IN HBM, against the same stages fed through host arrays (mesh downloaded, every
     #     stage uploading its inputs and downloading its outputs: what a caller without device pointers pays) ---
