@@ -64,10 +64,12 @@ def parse():
                     help="--pseudo-ranks / native N > 1: from the second step on the bricks balance the cost measured in the previous step (ss_comm_set_balance_feedback) instead of "
                          "particle counts.  Off by default: bricks are whole subdomains, and on S40M-tank at 8 ranks no plane can move without making another rank the slowest "
                          "(measured, profiles/r05_s40m_tank_pseudo_ranks_8*.json)")
-    ap.add_argument("--resident", action="store_true",
-                    help="--pseudo-ranks / native N > 1, strong scaling: after a first frame every rank holds the particles of its OWN brick (the cloud re-dealt by "
-                         "splashsurf_amd.distributed.brick_owner_of on that frame's partition) -- a simulation's time series that keeps its particles where they are owned: "
-                         "the position exchange then ships ghost layers only.  Default: rank r holds the r-th contiguous 1/N of the cloud (an unsorted slice, the worst case)")
+    ap.add_argument("--slices", action="store_true",
+                    help="--pseudo-ranks / native N > 1, strong scaling: rank r holds the r-th contiguous 1/N of the cloud for every step -- an unsorted slice, so ALL of a "
+                         "rank's particles cross a link every step (the distribution rounds 3-6 were profiled with).  Default: after a first frame every rank holds the "
+                         "particles of its OWN brick (the cloud re-dealt by splashsurf_amd.distributed.brick_owner_of on that frame's partition) -- a simulation that keeps "
+                         "its particles where they are owned: the position exchange then ships ghost layers only, north_star's 'halo particle exchange'")
+    ap.add_argument("--resident", action="store_true", help="(the default since the end of round 6; kept for command lines that name it)")
     ap.add_argument("--exchange", choices=["auto", "native", "torch"], default="auto",
                     help="N > 1 transport of the halo exchange: the library's own RCCL path (ss_dist_*) or torch.distributed")
     ap.add_argument("--cpu-sample-scale", type=float, default=1.0, help="tank scale of the CPU-baseline sample (1.0 = the full 10 M workload)")
@@ -344,7 +346,7 @@ def pseudo_rank_run(args):
             native = D.NativeSharded(comms[q], prm)
             d_local = torch.from_numpy(pts).to(dev)
             torch.cuda.synchronize()
-            if args.resident and args.scaling == "strong":
+            if not args.slices and args.scaling == "strong":
                 res0 = native.step(d_local)
                 native.assemble()
                 pts = resident_share(D, full, native, res0, q)
@@ -452,7 +454,7 @@ def pseudo_rank_run(args):
         "config": {"workload": workload, "n_particles": int(n_total), "particle_radius": r, "smoothing_length": wl["smoothing_length"], "cube_size": wl["cube_size"],
                    "n_vertices_incl_shared": tot_v, "n_triangles": tot_t, "enable_simd": int(prm.enable_simd),
                    "parallelism": "%d bricks of the subdomain grid, one per PSEUDO-rank (host threads taking turns on one GPU): `value` is this one GPU's throughput in "
-                                  "that mode, the multi-GPU estimate is `projection`" % world, "workload_desc": out[0]["desc"], "resident": bool(args.resident)},
+                                  "that mode, the multi-GPU estimate is `projection`" % world, "workload_desc": out[0]["desc"], "resident": bool(not args.slices and args.scaling == "strong")},
         "roofline": out[slowest]["roof"],
         "stages_ms": {k: round(v, 4) for k, v in st0.items() if k.startswith("ms_")},
         "projection": proj,
@@ -559,13 +561,24 @@ def main():
                 dist.all_reduce(ok, op=dist.ReduceOp.MIN)
                 if int(ok.item()) == 0:
                     native = None
-        if args.resident and native is not None and args.scaling == "strong":
-            full_ = wl["gen"]()  # (every rank generates the cloud and keeps its brick's particles: set-up, outside the timed region)
-            res0 = native.step(torch.from_numpy(pts).to(dev))
-            native.assemble()
-            pts = resident_share(D, full_, native, res0, rank)
-            del full_
-            workload_desc = "%s, fixed size; rank r holds the particles of ITS brick (dealt by the first frame's partition)" % workload
+        resident = False
+        if not args.slices and native is not None and args.scaling == "strong":
+            mine_, err_ = None, None
+            try:
+                full_ = wl["gen"]()  # (every rank generates the cloud and keeps its brick's particles: set-up, outside the timed region)
+                res0 = native.step(torch.from_numpy(pts).to(dev))
+                native.assemble()
+                mine_ = resident_share(D, full_, native, res0, rank)
+                del full_
+            except Exception as e:  # never lose the measurement to the set-up: the slices are a valid (more expensive) distribution
+                err_ = repr(e)
+                print("[bench] rank %d: dealing the cloud by owner brick failed (%s) -- every rank keeps its contiguous slice" % (rank, err_), file=sys.stderr, flush=True)
+            ok = torch.tensor([0 if mine_ is None else 1], dtype=torch.int32, device=dev)
+            if world > 1:  # every rank must hold the same kind of share
+                dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if int(ok.item()) == 1:
+                pts, resident = mine_, True
+                workload_desc = "%s, fixed size; rank r holds the particles of ITS brick (dealt by the first frame's partition)" % workload
             barrier()
         d_local = torch.from_numpy(pts).to(dev)
         timings = {}
@@ -639,7 +652,7 @@ def main():
         scaling = args.scaling
         parallelism = "%d bricks of the subdomain grid (recursive bisection by particle count), one per GPU" % world
         extra["workload_desc"] = workload_desc
-        extra["resident"] = bool(args.resident and native is not None and args.scaling == "strong")
+        extra["resident"] = resident
         if world > 1 and args.scaling == "strong" and not args.main_only:
             # the same fixed-size workload on ONE GPU (rank 0's), measured in the same job: the strong-scaling reference
             single = None

@@ -205,9 +205,9 @@ def test_bench_py_default_record_dry_run():
 
 def test_bench_py_pseudo_rank_record_dry_run():
     """... and the sharded code path of bench.py (--pseudo-ranks: ss_dist_* over an in-process group), with the contiguous slices and with brick-resident
-    particles (--resident): same mesh either way, a complete projection object."""
-    a = _bench_dry_run(["--pseudo-ranks", "2", "--steps", "1", "--warmup", "1", "--main-only"])
-    b = _bench_dry_run(["--pseudo-ranks", "2", "--steps", "1", "--warmup", "1", "--main-only", "--resident"])
+    particles (the default; --slices for the former): same mesh either way, a complete projection object."""
+    a = _bench_dry_run(["--pseudo-ranks", "2", "--steps", "1", "--warmup", "1", "--main-only", "--slices"])
+    b = _bench_dry_run(["--pseudo-ranks", "2", "--steps", "1", "--warmup", "1", "--main-only"])
     assert a["config"]["resident"] is False and b["config"]["resident"] is True
     for d in (a, b):
         assert d["pseudo_ranks"] == 2 and len(d["per_rank"]) == 2 and d["scaling"] == "strong"
@@ -237,15 +237,16 @@ def _bench_ranks_dry_run(world, extra, port):
 
 def test_bench_py_multi_gpu_command_line_dry_run():
     """bench.py --gpus N as the driver launches it, N = 2 and 4, never run on more than one real GPU: rank processes, the library's RCCL exchange path
-    (stand-in RCCL), the strong-scaling reference on rank 0, the per-rank table; with brick-resident particles (--resident) and over the torch.distributed
-    fallback (--exchange torch) as well.  All variants give the same mesh."""
+    (stand-in RCCL), the strong-scaling reference on rank 0, the per-rank table; with brick-resident particles (the default), with contiguous slices
+    (--slices) and over the torch.distributed fallback (--exchange torch) as well.  All variants give the same mesh."""
     base = _bench_ranks_dry_run(2, [], 29621)
     assert base["n_gpus"] == 2 and base["scaling"] == "strong" and base["config"]["workload"] == "s40m_tank" and len(base["per_rank"]) == 2
     assert base["exchange"]["kind"].startswith("native") and base["exchange"]["rccl_world_size"] == 2
     assert base["single_gpu_same_workload"]["value"] and base["single_gpu_same_workload"]["speedup_of_this_run"] > 0
     mesh = (base["config"]["n_vertices"], base["config"]["n_triangles"])
-    res = _bench_ranks_dry_run(2, ["--main-only", "--resident"], 29622)
-    assert res["resident"] is True and (res["config"]["n_vertices"], res["config"]["n_triangles"]) == mesh
+    assert base["resident"] is True  # (the default: every rank holds its brick's particles)
+    res = _bench_ranks_dry_run(2, ["--main-only", "--slices"], 29622)
+    assert res["resident"] is False and (res["config"]["n_vertices"], res["config"]["n_triangles"]) == mesh
     tor = _bench_ranks_dry_run(2, ["--main-only", "--exchange", "torch"], 29623)
     assert tor["exchange"]["kind"].startswith("torch.distributed") and (tor["config"]["n_vertices"], tor["config"]["n_triangles"]) == mesh
     four = _bench_ranks_dry_run(4, ["--main-only"], 29624)

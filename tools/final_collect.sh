@@ -12,6 +12,6 @@ python tools/make_profiles.py ${TAG}prof $TAG > $O/make_profiles.log 2>&1
 timeout 900 python bench.py > $O/bench_line.json 2> $O/bench.err; echo "bench rc=$?"
 bash tools/profile_configs.sh $TAG s10m_cube s1m r2 config1 config5 > $O/cfg.log 2>&1
 for n in 8 4 2; do timeout 600 python bench.py --pseudo-ranks $n > $O/pseudo$n.json 2> $O/pseudo$n.err; done
-timeout 600 python bench.py --pseudo-ranks 8 --resident > $O/pseudo8_resident.json 2> $O/pseudo8_resident.err   # brick-resident particles: the position exchange ships ghost layers only
+timeout 600 python bench.py --pseudo-ranks 8 --slices > $O/pseudo8_slices.json 2> $O/pseudo8_slices.err   # rank r holds the r-th contiguous eighth (the distribution of the round 3-6 profiles; the default is brick-resident particles)
 python tools/e2e_frames.py > $O/e2e_frames.log 2>&1
 ls $O
