@@ -142,6 +142,7 @@ def test_launch_trace_of_a_small_job():
     os.environ["SPLASHSURF_HIP_LIB"] = lib
     try:
         t = emu_launch_trace.trace("config1")
+        t5 = emu_launch_trace.trace("config5")
     finally:
         if old is None:
             del os.environ["SPLASHSURF_HIP_LIB"]
@@ -152,6 +153,9 @@ def test_launch_trace_of_a_small_job():
     assert len(t["memsets"]) <= 6 and all(m % 16 == 0 for m in t["memsets"]), t["memsets"]
     assert t["copies"] == [4732 * 12]  # the upload; no other copy (counts reach the host through mail slots)
     assert t["n_host_waits"] <= 8
+    # BASELINE config 5 (no over-dense blocks: the arena path is not launched)
+    assert (t5["n_vertices"], t5["n_triangles"]) == (533960, 1067920)
+    assert t5["launches"] <= 31 and len(t5["memsets"]) <= 6 and all(m % 16 == 0 for m in t5["memsets"]) and t5["n_host_waits"] <= 7, t5
 
 
 def test_graft_entry_smoke_on_the_cpu_execution_model():

@@ -17,7 +17,7 @@ import sys, numpy as np
 sys.path.insert(0, %(root)r)
 from splashsurf_amd.api import Parameters, Context
 pts = np.load(%(data)r)
-prm = Parameters.new_relative(0.025, 4.0, %(cube)r, enable_simd=False)
+prm = Parameters(particle_radius=0.025, compact_support_radius=2.0 * 2.0 * 0.025, cube_size=%(cube)r * 0.025, enable_simd=False)  # (f64 products, like pysplashsurf: reconstruction.rs:171-193)
 ctx = Context(0)
 out = ctx.reconstruct(pts, prm)
 out = ctx.reconstruct(pts, prm, out=out)           # (buffers sized, row table made, division verified)
