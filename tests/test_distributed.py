@@ -260,3 +260,19 @@ def test_gpu_ranks_on_one_device_reproduce_single_process(tmp_path, oracle, case
     assert np.array_equal(got["rho"].view(np.uint32), ref.particle_densities.view(np.uint32))
     cmp = MC.compare_keyed(got["vertices"], got["keys"], got["triangles"], ref.vertices, ref.vertex_keys, ref.triangles)
     assert cmp["keys_equal"] and cmp["triangles_equal"] and cmp["vertices_bit_equal"], cmp
+
+
+def test_brick_owner_of_follows_the_owner_histogram_rule():
+    """distributed.brick_owner_of (the dealing rule of bench.py's brick-resident shares and of a time series that keeps its particles where they are owned):
+    floor of the coordinate in units of the subdomain edge, clamped into the grid, looked up in the bricks -- every particle gets exactly one owner."""
+    import types
+    from splashsurf_amd import distributed as D
+    grid = types.SimpleNamespace(aabb=types.SimpleNamespace(min=np.array([-1.0, 0.0, 0.0], np.float32)), cell_size=np.float32(0.5), ncells_per_dim=np.array([4, 2, 1]))
+    bricks = [[[0, 0, 0], [1, 2, 1]], [[1, 0, 0], [4, 1, 1]], [[1, 1, 0], [4, 2, 1]]]
+    pts = np.array([[-0.9, 0.1, 0.2], [-0.5, 0.1, 0.2], [-0.51, 0.9, 0.4], [0.99, 0.49, 0.0], [0.2, 0.5, 0.1],
+                    [-7.0, -3.0, -1.0], [9.0, 9.0, 9.0], [9.0, 0.2, 0.3]], np.float32)  # (the last three lie outside the grid: clamped)
+    assert D.brick_owner_of(pts, grid, bricks).tolist() == [0, 1, 0, 1, 2, 0, 2, 1]
+    rng = np.random.default_rng(3)
+    cloud = rng.uniform(-1.5, 1.5, size=(5000, 3)).astype(np.float32)
+    owner = D.brick_owner_of(cloud, grid, bricks)
+    assert owner.min() >= 0 and owner.max() <= 2 and np.bincount(owner, minlength=3).sum() == 5000
